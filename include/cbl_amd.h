@@ -1,0 +1,118 @@
+/*
+ * cbl_amd.h — C ABI of libcbl_amd.so: the MI355X (gfx950) point-neighbourhood hot path of
+ * LiyaoTang/contrastBoundary (pointops + CBL pair mining + TF-side neighbour/subsampling ops).
+ *
+ * Conventions (same as the reference boundary):
+ *   - every pointer is a DEVICE pointer to contiguous row-major float32 / int32 data unless a
+ *     parameter is documented as "host";
+ *   - the caller owns and allocates every output and scratch buffer, and pre-zeroes the ones the
+ *     reference pre-zeroes (documented per function); the callee borrows pointers for the duration
+ *     of the asynchronous launch and never allocates or frees;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is enqueued on it
+ *     and the call returns without synchronising;
+ *   - stacked clouds: `offset[b]` int32 cumulative END offsets (pytorch side) or `lengths[b]` int32
+ *     per-cloud lengths (TF side);
+ *   - return value: 0 on success, CBL_ERR_* (<0) for rejected arguments, or a positive hipError_t.
+ *
+ * Each entry point cites the reference interface it replaces as path:line under /root/reference.
+ * The reference launchers take no stream and return void; the extra leading `b` on the segmented
+ * ops is the number of clouds (the reference recovers it by scanning `offset` linearly on device,
+ * knnquery_cuda_kernel.cu:51-62).
+ */
+#ifndef CBL_AMD_H
+#define CBL_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CBL_OK               0
+#define CBL_ERR_BAD_ARG     (-1)   /* null pointer / negative size / K out of range */
+#define CBL_ERR_WORKSPACE   (-2)   /* caller-provided workspace too small */
+#define CBL_ERR_UNSUPPORTED (-3)
+
+#define CBL_KNN_MAX_NSAMPLE 1024   /* knnquery_cuda_kernel.cu:89-90: float best_dist[1024] */
+
+/* library / build identification (host only) */
+const char* cbl_version(void);            /* e.g. "cbl_amd 0.1 gfx950" */
+int         cbl_device_arch_ok(void);     /* 1 if the current HIP device is gfx950, 0 otherwise, <0 no device */
+
+/* ------------------------------------------------------------------------------------------------
+ * pytorch/lib/pointops — the 10 exported entry points (pointops_api.cpp:12-23)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* K1  knnquery_cuda_launcher  pytorch/lib/pointops/src/knnquery/knnquery_cuda_kernel.h:13
+ *     kernel: knnquery_cuda_kernel.cu:65-111.
+ * Segmented exact KNN: for query q in cloud c, scan supports [start_c, end_c) in index order with a
+ * size-nsample max-heap (strict '<' replacement), then heap-sort ascending. Bit-identical idx/dist2
+ * including tie order and the (1e10, start) sentinels when n_c < nsample.
+ * Dispatches to the uniform-grid kernel (certified, with exact replay of tied queries) when
+ * `workspace` is large enough (cbl_knnquery_workspace_bytes) and to the brute-force kernel otherwise
+ * (workspace may be NULL / 0).
+ *   xyz (n,3) new_xyz (m,3) offset (b) new_offset (b) -> idx (m,nsample) i32, dist2 (m,nsample) f32 */
+int cbl_knnquery(int b, int n, int m, int nsample,
+                 const float* xyz, const float* new_xyz,
+                 const int* offset, const int* new_offset,
+                 int* idx, float* dist2,
+                 void* workspace, size_t workspace_bytes, void* stream);
+size_t cbl_knnquery_workspace_bytes(int b, int n, int m, int nsample);
+
+/* brute-force variant only (always bit-exact, O(m*n)); `algo` for tests/bench: see cbl_knnquery */
+int cbl_knnquery_exact(int b, int n, int m, int nsample,
+                       const float* xyz, const float* new_xyz,
+                       const int* offset, const int* new_offset,
+                       int* idx, float* dist2, void* stream);
+
+/* K2  furthestsampling_cuda_launcher  sampling/sampling_cuda_kernel.h:12 ; kernel .cu:14-129.
+ * `n_max` = longest cloud (selects the reference block size B = 2^floor(log2 n_max) <= 1024 whose
+ * tree reduction defines the tie rule).  tmp (n) must be pre-filled with 1e10 (pointops.py:22).
+ *   xyz (n,3) offset (b) new_offset (b) tmp (n) -> idx (new_offset[b-1]) i32 */
+int cbl_furthestsampling(int b, int n_max, const float* xyz, const int* offset, const int* new_offset,
+                         float* tmp, int* idx, void* stream);
+
+/* K3/K4  grouping_{forward,backward}_cuda_launcher  grouping/grouping_cuda_kernel.h:13-14.
+ *   forward : input (n,c), idx (m,nsample) -> output (m,nsample,c)        (output fully overwritten)
+ *   backward: grad_output (m,nsample,c), idx -> grad_input (n,c) +=       (caller pre-zeroes) */
+int cbl_grouping_forward(int m, int nsample, int c, const float* input, const int* idx, float* output, void* stream);
+int cbl_grouping_backward(int m, int nsample, int c, const float* grad_output, const int* idx, float* grad_input, void* stream);
+
+/* K5/K6  interpolation_{forward,backward}_cuda_launcher  interpolation/interpolation_cuda_kernel.h:13-14.
+ *   forward : input (m,c), idx (n,k), weight (n,k) -> output (n,c) +=     (caller pre-zeroes)
+ *   backward: grad_output (n,c), idx, weight -> grad_input (m,c) +=       (caller pre-zeroes) */
+int cbl_interpolation_forward(int n, int c, int k, const float* input, const int* idx, const float* weight, float* output, void* stream);
+int cbl_interpolation_backward(int n, int c, int k, const float* grad_output, const int* idx, const float* weight, float* grad_input, void* stream);
+
+/* K7/K8  subtraction_{forward,backward}_cuda_launcher  subtraction/subtraction_cuda_kernel.h:13-14.
+ *   forward : input1 (n,c), input2 (n,c), idx (n,nsample) -> output (n,nsample,c) = in1[n]-in2[idx]
+ *   backward: grad_output (n,nsample,c) -> grad_input1 (n,c) +=, grad_input2 (n,c) +=  (pre-zeroed) */
+int cbl_subtraction_forward(int n, int nsample, int c, const float* input1, const float* input2, const int* idx, float* output, void* stream);
+int cbl_subtraction_backward(int n, int nsample, int c, const int* idx, const float* grad_output, float* grad_input1, float* grad_input2, void* stream);
+
+/* K9/K10 aggregation_{forward,backward}_cuda_launcher  aggregation/aggregation_cuda_kernel.h:13-14.
+ *   forward : input (n,c), position (n,nsample,c), weight (n,nsample,w_c), idx (n,nsample)
+ *             -> output (n,c) += sum_k (input[idx]+position)*weight[..., c % w_c]   (pre-zeroed)
+ *   backward: -> grad_input (n,c) += (pre-zeroed), grad_position (n,nsample,c) = (overwritten),
+ *             grad_weight (n,nsample,w_c) += (pre-zeroed) */
+int cbl_aggregation_forward(int n, int nsample, int c, int w_c, const float* input, const float* position, const float* weight, const int* idx, float* output, void* stream);
+int cbl_aggregation_backward(int n, int nsample, int c, int w_c, const float* input, const float* position, const float* weight, const int* idx, const float* grad_output, float* grad_input, float* grad_position, float* grad_weight, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused composites of the reference's python-level ops (same values, one launch)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* F1  queryandgroup  pytorch/lib/pointops/functions/pointops.py:79-100 (idx given).
+ *   xyz (n,3) new_xyz (m,3) feat (n,c) idx (m,nsample) -> out (m,nsample,3+c) if use_xyz else (m,nsample,c)
+ *   out[m,k,0:3] = xyz[idx]-new_xyz[m]; out[m,k,3:] = feat[idx] */
+int cbl_queryandgroup(int m, int nsample, int c, int use_xyz, const float* xyz, const float* new_xyz, const float* feat, const int* idx, float* out, void* stream);
+
+/* F4  interpolation weights  pointops.py:171-174: w = (1/(dist+1e-8)) / sum_k(1/(dist+1e-8)), dist = sqrt(dist2)
+ *   dist2 (n,k) -> weight (n,k), dist (n,k) (dist may be NULL) */
+int cbl_interpolation_weights(int n, int k, const float* dist2, float* weight, float* dist, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CBL_AMD_H */
