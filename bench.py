@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""bench.py — points/sec through the KNN + group + local-aggregation + CBL block on S3DIS-shaped synthetic scenes.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--points 40960] [--channels 64] [--k 16]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one pass of the hot path (contrastboundary_amd/hotpath.py) over one scene whose inputs are already
+resident in HBM.  Scenes are independent, so N ranks run N scene replicas with no data-path collective (weak
+scaling); the timed region is bracketed by barrier + synchronize and the MAX over ranks is used.
+Rank 0 prints ONE JSON line with the driver's fields plus `roofline` (dominant kernel, HIP-event timed inside the
+timed region) and `cpu_baseline` (the CPU oracle = a port of the reference's algorithm, one thread, one scene).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 matrix = f32 vector peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--points", type=int, default=40960)
+    ap.add_argument("--channels", type=int, default=64)
+    ap.add_argument("--k", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(n, c, k, seed):
+    """the oracle (port of the reference algorithm), 1 thread, ONE full scene of the same workload"""
+    from tests import oracle_lib as O
+    from contrastboundary_amd import synthetic as S
+    xyz, labels = S.s_room(n, seed)
+    feat = np.random.default_rng(seed + 1000).normal(size=(n, c)).astype(np.float32)
+    off = np.array([n], np.int32)
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    t0 = time.perf_counter()
+    parts = {}
+    idx, _ = O.knnquery(k, xyz, xyz, off, off)
+    parts["knnquery"] = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    g = O.grouping_forward(np.concatenate([xyz, feat], 1), idx)
+    g[..., :3] -= xyz[:, None, :]
+    parts["queryandgroup"] = time.perf_counter() - t1
+    try:
+        from tests import oracle_hotpath
+        parts.update(oracle_hotpath.run_rest(xyz, feat, labels, off, idx, k))
+    except ImportError:
+        pass
+    total = sum(parts.values())
+    return {"value": n / total, "unit": "points/s", "cores": 1, "kind": "port",
+            "sample": "1 scene of %d points (same workload), single thread; stage seconds: %s" % (
+                n, {a: round(b, 3) for a, b in parts.items()})}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")            # "nccl" is RCCL on ROCm; used for barriers/max only
+
+    from contrastboundary_amd import hotpath
+    n, c, k = args.points, args.channels, args.k
+    scene = hotpath.Scene.synthetic(n, c, seed=rank, b=1)    # every rank its own scene (weak scaling)
+    stages = hotpath.stages(scene, k)
+    state = {}
+
+    def step(events=None):
+        for i, (_, fn, _, _) in enumerate(stages):
+            if events is not None:
+                events[i][0].record()
+            fn(state)
+            if events is not None:
+                events[i][1].record()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in stages] for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        step(ev[s])
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-stage average device time from the HIP events recorded inside the timed region (same stream as the launches)
+    stage_ms = [float(np.mean([ev[s][i][0].elapsed_time(ev[s][i][1]) for s in range(args.steps)])) for i in range(len(stages))]
+    dom = int(np.argmax(stage_ms))
+    name, _, abytes, aflops = stages[dom]
+    ach_gbs = abytes / (stage_ms[dom] * 1e-3) / 1e9
+    roofline = {"kernel": name, "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
+                "stage_ms": {stages[i][0]: round(stage_ms[i], 4) for i in range(len(stages))},
+                "stage_algorithmic_GBps": {stages[i][0]: round(stages[i][2] / (stage_ms[i] * 1e-3) / 1e9, 1) for i in range(len(stages))}}
+
+    if rank == 0:
+        out = {
+            "metric": "points/sec through KNN+group+KPConv+CBL block, S3DIS N=40960 K=16",
+            "value": n * args.steps * world / elapsed, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "S3DIS-shaped synthetic scene (S-room), N=%d, K=%d, C=%d, 1 scene per GPU per step; stages: %s"
+                       % (n, k, c, " -> ".join(s[0] for s in stages)), "parallelism": "scene-per-GPU replicas x%d (no data-path collective)" % world},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, c, k, seed=0)
+        print(json.dumps(out))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

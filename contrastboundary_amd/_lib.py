@@ -1,0 +1,58 @@
+"""ctypes binding of libcbl_amd.so (include/cbl_amd.h).  There is NO fallback: if the HIP library is
+missing and cannot be built, or a call returns an error code, this raises."""
+import ctypes
+import os
+import re
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_PKG, "lib", "libcbl_amd.so")
+_HEADER = os.path.join(os.path.dirname(_PKG), "include", "cbl_amd.h")
+_lib = None
+
+
+class CblError(RuntimeError):
+    pass
+
+
+def declared_symbols():
+    """every function name include/cbl_amd.h declares"""
+    txt = open(_HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(cbl_\w+)\s*\(", txt)))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        from . import build as _build
+        if _build.is_stale():
+            _build.build()          # raises if hipcc is absent or a source does not compile
+        if not os.path.exists(_SO):
+            raise CblError("libcbl_amd.so is missing: run `python -m contrastboundary_amd.build`")
+        _lib = ctypes.CDLL(_SO)
+        _lib.cbl_version.restype = ctypes.c_char_p
+        for name in declared_symbols():
+            fn = getattr(_lib, name, None)
+            if fn is None:
+                raise CblError(f"libcbl_amd.so does not export {name} (declared in include/cbl_amd.h)")
+            if name.endswith("_bytes"):
+                fn.restype = ctypes.c_size_t
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        raise CblError(f"{what} failed with code {code} "
+                       f"({'bad argument' if code == -1 else 'workspace too small' if code == -2 else 'unsupported' if code == -3 else 'hipError_t'})")
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or None) as c_void_p"""
+    if t is None:
+        return ctypes.c_void_p(0)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_of(t):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)

@@ -1,0 +1,79 @@
+"""Build libcbl_amd.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+    python -m contrastboundary_amd.build [--force] [--verbose]
+
+Objects are cached under contrastboundary_amd/lib/obj and rebuilt when the source or a header is newer.
+The .so is git-ignored but travels to the GPU box with the repo snapshot.
+"""
+import concurrent.futures
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIBDIR = os.path.join(PKG, "lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
+SO = os.path.join(LIBDIR, "libcbl_amd.so")
+INCLUDE = os.path.join(os.path.dirname(PKG), "include")
+
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+# -ffp-contract=off: every float expression keeps the CPU oracle's rounding (no silent FMA), see DESIGN.md
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
+         "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-I" + INCLUDE, "-I" + CSRC]
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
+    return hs
+
+
+def _compile(src, obj, verbose):
+    cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+    if verbose and r.stderr.strip():
+        print(r.stderr)
+
+
+def is_stale():
+    if not os.path.exists(SO):
+        return True
+    t = os.path.getmtime(SO)
+    return any(os.path.getmtime(p) > t for p in sources() + headers())
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJDIR, exist_ok=True)
+    hdr_time = max([os.path.getmtime(h) for h in headers()] + [os.path.getmtime(__file__)])
+    jobs, objs = [], []
+    for src in sources():
+        obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            jobs.append((src, obj))
+    if jobs:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            for f in [ex.submit(_compile, s, o, verbose) for s, o in jobs]:
+                f.result()
+    if jobs or not os.path.exists(SO):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))

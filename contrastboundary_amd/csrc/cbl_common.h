@@ -1,0 +1,50 @@
+// Shared device/host helpers for libcbl_amd.so (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/cbl_amd.h"
+
+#define CBL_EXPORT extern "C" __attribute__((visibility("default")))
+#define CBL_WAVE 64
+
+static inline int cbl_status()
+{
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? CBL_OK : (int)e;
+}
+
+static inline hipStream_t cbl_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline unsigned cbl_div_up(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
+
+// grid size for a grid-stride elementwise kernel: enough blocks to fill 256 CUs x 8, never 0
+static inline unsigned cbl_grid_for(long long work_items, int block, int max_blocks = 256 * 16)
+{
+    long long g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > max_blocks) g = max_blocks;
+    return (unsigned)g;
+}
+
+// cloud of a stacked row: first c with row < ends[c]  (knnquery_cuda_kernel.cu:51-62 does this by
+// linear scan; binary search gives the same answer for non-decreasing ends, empty clouds included)
+__device__ __forceinline__ int cbl_cloud_of(int row, const int* __restrict__ ends, int b)
+{
+    int lo = 0, hi = b - 1;          // answer in [0, b-1]; rows >= ends[b-1] clamp to b-1
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (row < ends[mid]) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+// squared distance with the reference's association and no FMA contraction
+// (knnquery_cuda_kernel.cu:99; the library is built with -ffp-contract=off)
+__device__ __forceinline__ float cbl_dist2(float ax, float ay, float az, float bx, float by, float bz)
+{
+    const float dx = ax - bx, dy = ay - by, dz = az - bz;
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+__device__ __forceinline__ bool cbl_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline bool cbl_host_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -1,0 +1,353 @@
+// K3..K10 + F1/F4: neighbour-index gather / scatter family (all HBM-bound).
+// Replaces /root/reference/pytorch/lib/pointops/src/{grouping,interpolation,subtraction,aggregation}/*_cuda_kernel.cu
+// and the torch-op chain of queryandgroup (pointops.py:79-100).
+//
+// MI355X mapping: the reference runs one thread per output SCALAR and re-derives (row, k, channel) by
+// division, re-loading idx once per scalar.  Here a lane owns 4 consecutive channels (16 B, one
+// global_load_dwordx4 / global_store_dwordx4), so a wave moves whole 64..256 B feature rows with
+// fully coalesced 1 KiB stores, idx is loaded once per 4 channels, and the grid is a fixed
+// 256 CU x 16 grid-stride launch.  Rows whose channel count is not a multiple of 4 (xyz: c = 3, the
+// 3+c concat) take the scalar path with the same values.  Accumulating ops (+=) read the caller's
+// pre-zeroed output, like the reference, and sum neighbours in index order without FMA contraction
+// so forward results are bit-identical to the CPU oracle; scatter-add backward passes use hardware
+// fp32 atomics (order-dependent rounding only, as in the reference).
+#include "cbl_common.h"
+
+namespace {
+
+constexpr int GB = 256;  // threads per block
+
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
+
+// ---------------------------------------------------------------- K3 grouping forward
+// out[r, :] = in[idx[r], :]   r over m*nsample rows                 grouping_cuda_kernel.cu:5-14
+__global__ __launch_bounds__(GB) void grouping_fwd_v4(long long rows, int c4, const float4* __restrict__ in,
+                                                      const int* __restrict__ idx, float4* __restrict__ out)
+{
+    const long long total = rows * c4;
+    for (long long e = (long long)blockIdx.x * GB + threadIdx.x; e < total; e += (long long)gridDim.x * GB) {
+        const long long r = e / c4; const int ch = (int)(e - r * c4);
+        out[e] = in[(long long)idx[r] * c4 + ch];
+    }
+}
+__global__ __launch_bounds__(GB) void grouping_fwd_s(long long rows, int c, const float* __restrict__ in,
+                                                     const int* __restrict__ idx, float* __restrict__ out)
+{
+    const long long total = rows * c;
+    for (long long e = (long long)blockIdx.x * GB + threadIdx.x; e < total; e += (long long)gridDim.x * GB) {
+        const long long r = e / c; const int ch = (int)(e - r * c);
+        out[e] = in[(long long)idx[r] * c + ch];
+    }
+}
+
+// ---------------------------------------------------------------- K4 grouping backward
+// grad_in[idx[r], :] += grad_out[r, :]                              grouping_cuda_kernel.cu:16-25
+__global__ __launch_bounds__(GB) void grouping_bwd(long long rows, int c, const float* __restrict__ go,
+                                                   const int* __restrict__ idx, float* __restrict__ gi)
+{
+    const long long total = rows * c;
+    for (long long e = (long long)blockIdx.x * GB + threadIdx.x; e < total; e += (long long)gridDim.x * GB) {
+        const long long r = e / c; const int ch = (int)(e - r * c);
+        atomic_add_f32(gi + (long long)idx[r] * c + ch, go[e]);
+    }
+}
+
+// ---------------------------------------------------------------- K5 interpolation forward
+// out[p, ch] += sum_i in[idx[p,i], ch] * w[p,i]   (i ascending)     interpolation_cuda_kernel.cu:5-18
+template <int V>
+__global__ __launch_bounds__(GB) void interp_fwd(int n, int cv, int k, const float* __restrict__ in,
+                                                 const int* __restrict__ idx, const float* __restrict__ w, float* __restrict__ out)
+{
+    const long long total = (long long)n * cv;
+    for (long long e = (long long)blockIdx.x * GB + threadIdx.x; e < total; e += (long long)gridDim.x * GB) {
+        const long long p = e / cv; const int ch = (int)(e - p * cv);
+        if (V == 4) {
+            float4 acc = reinterpret_cast<float4*>(out)[e];
+            for (int i = 0; i < k; i++) {
+                const float wi = w[p * k + i];
+                const float4 v = reinterpret_cast<const float4*>(in)[(long long)idx[p * k + i] * cv + ch];
+                acc.x += v.x * wi; acc.y += v.y * wi; acc.z += v.z * wi; acc.w += v.w * wi;
+            }
+            reinterpret_cast<float4*>(out)[e] = acc;
+        } else {
+            float acc = out[e];
+            for (int i = 0; i < k; i++) acc += in[(long long)idx[p * k + i] * cv + ch] * w[p * k + i];
+            out[e] = acc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- K6 interpolation backward
+// grad_in[idx[p,i], ch] += grad_out[p, ch] * w[p,i]                 interpolation_cuda_kernel.cu:20-33
+__global__ __launch_bounds__(GB) void interp_bwd(int n, int c, int k, const float* __restrict__ go,
+                                                 const int* __restrict__ idx, const float* __restrict__ w, float* __restrict__ gi)
+{
+    const long long total = (long long)n * c;
+    for (long long e = (long long)blockIdx.x * GB + threadIdx.x; e < total; e += (long long)gridDim.x * GB) {
+        const long long p = e / c; const int ch = (int)(e - p * c);
+        const float g = go[e];
+        for (int i = 0; i < k; i++) atomic_add_f32(gi + (long long)idx[p * k + i] * c + ch, g * w[p * k + i]);
+    }
+}
+
+// ---------------------------------------------------------------- K7 subtraction forward
+// out[p,s,:] = in1[p,:] - in2[idx[p,s],:]                           subtraction_cuda_kernel.cu:5-16
+template <int V>
+__global__ __launch_bounds__(GB) void sub_fwd(long long rows, int ns, int cv, const float* __restrict__ a,
+                                              const float* __restrict__ b2, const int* __restrict__ idx, float* __restrict__ out)
+{
+    const long long total = rows * cv;
+    for (long long e = (long long)blockIdx.x * GB + threadIdx.x; e < total; e += (long long)gridDim.x * GB) {
+        const long long r = e / cv; const int ch = (int)(e - r * cv);
+        const long long p = r / ns;
+        if (V == 4) {
+            const float4 x = reinterpret_cast<const float4*>(a)[p * cv + ch];
+            const float4 y = reinterpret_cast<const float4*>(b2)[(long long)idx[r] * cv + ch];
+            reinterpret_cast<float4*>(out)[e] = make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w);
+        } else {
+            out[e] = a[p * cv + ch] - b2[(long long)idx[r] * cv + ch];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- K8 subtraction backward
+// g1[p,:] += go[p,s,:] ; g2[idx[p,s],:] += -go[p,s,:]               subtraction_cuda_kernel.cu:18-30
+// g1 is a per-row sum over s: done in registers by the lane that owns (p, ch) — no atomics, fixed order.
+__global__ __launch_bounds__(GB) void sub_bwd(int n, int ns, int c, const int* __restrict__ idx,
+                                              const float* __restrict__ go, float* __restrict__ g1, float* __restrict__ g2)
+{
+    const long long total = (long long)n * c;
+    for (long long e = (long long)blockIdx.x * GB + threadIdx.x; e < total; e += (long long)gridDim.x * GB) {
+        const long long p = e / c; const int ch = (int)(e - p * c);
+        float acc = g1[e];
+        for (int s = 0; s < ns; s++) {
+            const long long r = p * ns + s;
+            const float g = go[r * c + ch];
+            acc += g;
+            atomic_add_f32(g2 + (long long)idx[r] * c + ch, -g);
+        }
+        g1[e] = acc;
+    }
+}
+
+// ---------------------------------------------------------------- K9 aggregation forward
+// out[p,ch] += sum_s (in[idx[p,s],ch] + pos[p,s,ch]) * w[p,s,ch % w_c]    aggregation_cuda_kernel.cu:5-20
+template <int V>
+__global__ __launch_bounds__(GB) void agg_fwd(int n, int ns, int cv, int wcv, const float* __restrict__ in,
+                                              const float* __restrict__ pos, const float* __restrict__ w,
+                                              const int* __restrict__ idx, float* __restrict__ out)
+{
+    const long long total = (long long)n * cv;
+    for (long long e = (long long)blockIdx.x * GB + threadIdx.x; e < total; e += (long long)gridDim.x * GB) {
+        const long long p = e / cv; const int ch = (int)(e - p * cv);
+        const int wch = ch % wcv;
+        if (V == 4) {
+            float4 acc = reinterpret_cast<float4*>(out)[e];
+            for (int s = 0; s < ns; s++) {
+                const long long r = p * ns + s;
+                const float4 x = reinterpret_cast<const float4*>(in)[(long long)idx[r] * cv + ch];
+                const float4 q = reinterpret_cast<const float4*>(pos)[r * cv + ch];
+                const float4 ww = reinterpret_cast<const float4*>(w)[r * wcv + wch];
+                acc.x += (x.x + q.x) * ww.x; acc.y += (x.y + q.y) * ww.y;
+                acc.z += (x.z + q.z) * ww.z; acc.w += (x.w + q.w) * ww.w;
+            }
+            reinterpret_cast<float4*>(out)[e] = acc;
+        } else {
+            float acc = out[e];
+            for (int s = 0; s < ns; s++) {
+                const long long r = p * ns + s;
+                acc += (in[(long long)idx[r] * cv + ch] + pos[r * cv + ch]) * w[r * wcv + wch];
+            }
+            out[e] = acc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- K10 aggregation backward
+// gi[idx[p,s],ch] += g*w ; gpos[p,s,ch] = g*w ; gw[p,s,ch%w_c] += g*(in+pos)   aggregation_cuda_kernel.cu:22-39
+__global__ __launch_bounds__(GB) void agg_bwd(int n, int ns, int c, int wc, const float* __restrict__ in,
+                                              const float* __restrict__ pos, const float* __restrict__ w,
+                                              const int* __restrict__ idx, const float* __restrict__ go,
+                                              float* __restrict__ gi, float* __restrict__ gpos, float* __restrict__ gw)
+{
+    const long long total = (long long)n * c;
+    for (long long e = (long long)blockIdx.x * GB + threadIdx.x; e < total; e += (long long)gridDim.x * GB) {
+        const long long p = e / c; const int ch = (int)(e - p * c);
+        const int wch = ch % wc;
+        const float g = go[e];
+        for (int s = 0; s < ns; s++) {
+            const long long r = p * ns + s;
+            const long long src = (long long)idx[r] * c + ch;
+            const float wv = w[r * wc + wch];
+            const float gwv = g * wv;
+            atomic_add_f32(gi + src, gwv);
+            gpos[r * c + ch] = gwv;
+            atomic_add_f32(gw + r * wc + wch, g * (in[src] + pos[r * c + ch]));
+        }
+    }
+}
+
+// ---------------------------------------------------------------- F1 queryandgroup (idx given)
+// out[r, 0:3] = xyz[idx[r]] - new_xyz[r / ns] ; out[r, 3:3+c] = feat[idx[r]]     pointops.py:90-98
+__global__ __launch_bounds__(GB) void query_group(long long rows, int ns, int c, int use_xyz,
+                                                  const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+                                                  const float* __restrict__ feat, const int* __restrict__ idx, float* __restrict__ out)
+{
+    const int oc = c + (use_xyz ? 3 : 0);
+    const long long total = rows * oc;
+    for (long long e = (long long)blockIdx.x * GB + threadIdx.x; e < total; e += (long long)gridDim.x * GB) {
+        const long long r = e / oc; int ch = (int)(e - r * oc);
+        const long long src = idx[r];
+        float v;
+        if (use_xyz) {
+            if (ch < 3) v = xyz[src * 3 + ch] - new_xyz[(r / ns) * 3 + ch];
+            else        v = feat[src * c + (ch - 3)];
+        } else v = feat[src * c + ch];
+        out[e] = v;
+    }
+}
+
+// ---------------------------------------------------------------- F4 interpolation weights
+// dist = sqrt(dist2); r = 1/(dist + 1e-8); w = r / sum_i r                       pointops.py:170-173
+__global__ __launch_bounds__(GB) void interp_weights(int n, int k, const float* __restrict__ dist2,
+                                                     float* __restrict__ weight, float* __restrict__ dist)
+{
+    for (long long p = (long long)blockIdx.x * GB + threadIdx.x; p < n; p += (long long)gridDim.x * GB) {
+        float norm = 0.f;
+        for (int i = 0; i < k; i++) {
+            const float d = sqrtf(dist2[p * k + i]);          // correctly rounded (hipcc default)
+            if (dist) dist[p * k + i] = d;
+            const float r = 1.0f / (d + 1e-8f);
+            weight[p * k + i] = r;
+            norm += r;                                                // torch.sum over k, ascending
+        }
+        for (int i = 0; i < k; i++) weight[p * k + i] = weight[p * k + i] / norm;
+    }
+}
+
+inline bool vec4_ok(int c, const void* a, const void* b, const void* d = nullptr, const void* e = nullptr)
+{
+    return (c % 4 == 0) && cbl_host_aligned16(a) && cbl_host_aligned16(b) && cbl_host_aligned16(d) && cbl_host_aligned16(e);
+}
+
+}  // namespace
+
+#define CBL_CHECK_DIMS(...)   do { const long long _d[] = {__VA_ARGS__}; for (long long v : _d) if (v < 0) return CBL_ERR_BAD_ARG; } while (0)
+#define CBL_CHECK_PTRS(...)   do { const void* _p[] = {__VA_ARGS__}; for (const void* v : _p) if (!v) return CBL_ERR_BAD_ARG; } while (0)
+
+CBL_EXPORT int cbl_grouping_forward(int m, int nsample, int c, const float* input, const int* idx, float* output, void* stream)
+{
+    CBL_CHECK_DIMS(m, nsample, c);
+    const long long rows = (long long)m * nsample;
+    if (rows * c == 0) return CBL_OK;
+    CBL_CHECK_PTRS(input, idx, output);
+    hipStream_t st = cbl_stream(stream);
+    if (vec4_ok(c, input, output))
+        hipLaunchKernelGGL(grouping_fwd_v4, dim3(cbl_grid_for(rows * (c / 4), GB)), dim3(GB), 0, st, rows, c / 4,
+                           reinterpret_cast<const float4*>(input), idx, reinterpret_cast<float4*>(output));
+    else
+        hipLaunchKernelGGL(grouping_fwd_s, dim3(cbl_grid_for(rows * c, GB)), dim3(GB), 0, st, rows, c, input, idx, output);
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_grouping_backward(int m, int nsample, int c, const float* grad_output, const int* idx, float* grad_input, void* stream)
+{
+    CBL_CHECK_DIMS(m, nsample, c);
+    const long long rows = (long long)m * nsample;
+    if (rows * c == 0) return CBL_OK;
+    CBL_CHECK_PTRS(grad_output, idx, grad_input);
+    hipLaunchKernelGGL(grouping_bwd, dim3(cbl_grid_for(rows * c, GB)), dim3(GB), 0, cbl_stream(stream), rows, c, grad_output, idx, grad_input);
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_interpolation_forward(int n, int c, int k, const float* input, const int* idx, const float* weight, float* output, void* stream)
+{
+    CBL_CHECK_DIMS(n, c, k);
+    if ((long long)n * c == 0) return CBL_OK;
+    CBL_CHECK_PTRS(input, idx, weight, output);
+    hipStream_t st = cbl_stream(stream);
+    if (vec4_ok(c, input, output))
+        hipLaunchKernelGGL(interp_fwd<4>, dim3(cbl_grid_for((long long)n * (c / 4), GB)), dim3(GB), 0, st, n, c / 4, k, input, idx, weight, output);
+    else
+        hipLaunchKernelGGL(interp_fwd<1>, dim3(cbl_grid_for((long long)n * c, GB)), dim3(GB), 0, st, n, c, k, input, idx, weight, output);
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_interpolation_backward(int n, int c, int k, const float* grad_output, const int* idx, const float* weight, float* grad_input, void* stream)
+{
+    CBL_CHECK_DIMS(n, c, k);
+    if ((long long)n * c == 0) return CBL_OK;
+    CBL_CHECK_PTRS(grad_output, idx, weight, grad_input);
+    hipLaunchKernelGGL(interp_bwd, dim3(cbl_grid_for((long long)n * c, GB)), dim3(GB), 0, cbl_stream(stream), n, c, k, grad_output, idx, weight, grad_input);
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_subtraction_forward(int n, int nsample, int c, const float* input1, const float* input2, const int* idx, float* output, void* stream)
+{
+    CBL_CHECK_DIMS(n, nsample, c);
+    const long long rows = (long long)n * nsample;
+    if (rows * c == 0) return CBL_OK;
+    CBL_CHECK_PTRS(input1, input2, idx, output);
+    hipStream_t st = cbl_stream(stream);
+    if (vec4_ok(c, input1, input2, output))
+        hipLaunchKernelGGL(sub_fwd<4>, dim3(cbl_grid_for(rows * (c / 4), GB)), dim3(GB), 0, st, rows, nsample, c / 4, input1, input2, idx, output);
+    else
+        hipLaunchKernelGGL(sub_fwd<1>, dim3(cbl_grid_for(rows * c, GB)), dim3(GB), 0, st, rows, nsample, c, input1, input2, idx, output);
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_subtraction_backward(int n, int nsample, int c, const int* idx, const float* grad_output, float* grad_input1, float* grad_input2, void* stream)
+{
+    CBL_CHECK_DIMS(n, nsample, c);
+    if ((long long)n * nsample * c == 0) return CBL_OK;
+    CBL_CHECK_PTRS(idx, grad_output, grad_input1, grad_input2);
+    hipLaunchKernelGGL(sub_bwd, dim3(cbl_grid_for((long long)n * c, GB)), dim3(GB), 0, cbl_stream(stream), n, nsample, c, idx, grad_output, grad_input1, grad_input2);
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_aggregation_forward(int n, int nsample, int c, int w_c, const float* input, const float* position, const float* weight, const int* idx, float* output, void* stream)
+{
+    CBL_CHECK_DIMS(n, nsample, c, w_c);
+    if ((long long)n * c == 0) return CBL_OK;
+    if (w_c == 0) return CBL_ERR_BAD_ARG;
+    CBL_CHECK_PTRS(input, position, weight, idx, output);
+    hipStream_t st = cbl_stream(stream);
+    if (vec4_ok(c, input, position, weight, output) && w_c % 4 == 0)
+        hipLaunchKernelGGL(agg_fwd<4>, dim3(cbl_grid_for((long long)n * (c / 4), GB)), dim3(GB), 0, st, n, nsample, c / 4, w_c / 4, input, position, weight, idx, output);
+    else
+        hipLaunchKernelGGL(agg_fwd<1>, dim3(cbl_grid_for((long long)n * c, GB)), dim3(GB), 0, st, n, nsample, c, w_c, input, position, weight, idx, output);
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_aggregation_backward(int n, int nsample, int c, int w_c, const float* input, const float* position, const float* weight, const int* idx,
+                                        const float* grad_output, float* grad_input, float* grad_position, float* grad_weight, void* stream)
+{
+    CBL_CHECK_DIMS(n, nsample, c, w_c);
+    if ((long long)n * c == 0) return CBL_OK;
+    if (w_c == 0) return CBL_ERR_BAD_ARG;
+    CBL_CHECK_PTRS(input, position, weight, idx, grad_output, grad_input, grad_position, grad_weight);
+    hipLaunchKernelGGL(agg_bwd, dim3(cbl_grid_for((long long)n * c, GB)), dim3(GB), 0, cbl_stream(stream), n, nsample, c, w_c, input, position, weight, idx, grad_output, grad_input, grad_position, grad_weight);
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_queryandgroup(int m, int nsample, int c, int use_xyz, const float* xyz, const float* new_xyz, const float* feat, const int* idx, float* out, void* stream)
+{
+    CBL_CHECK_DIMS(m, nsample, c);
+    const long long rows = (long long)m * nsample;
+    const int oc = c + (use_xyz ? 3 : 0);
+    if (rows * oc == 0) return CBL_OK;
+    CBL_CHECK_PTRS(idx, out);
+    if (use_xyz) CBL_CHECK_PTRS(xyz, new_xyz);
+    if (c > 0) CBL_CHECK_PTRS(feat);
+    hipLaunchKernelGGL(query_group, dim3(cbl_grid_for(rows * oc, GB)), dim3(GB), 0, cbl_stream(stream), rows, nsample, c, use_xyz, xyz, new_xyz, feat, idx, out);
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_interpolation_weights(int n, int k, const float* dist2, float* weight, float* dist, void* stream)
+{
+    CBL_CHECK_DIMS(n, k);
+    if ((long long)n * k == 0) return CBL_OK;
+    CBL_CHECK_PTRS(dist2, weight);
+    hipLaunchKernelGGL(interp_weights, dim3(cbl_grid_for(n, GB)), dim3(GB), 0, cbl_stream(stream), n, k, dist2, weight, dist);
+    return cbl_status();
+}

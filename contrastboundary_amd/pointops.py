@@ -1,0 +1,306 @@
+"""Host-side mirror of the reference's pointops Python API, over libcbl_amd.so (hand-written HIP, gfx950).
+
+Same names, argument order and value semantics as /root/reference/pytorch/lib/pointops/functions/pointops.py:
+    furthestsampling :27   knnquery :45   grouping :76   queryandgroup :79   subtraction :130
+    aggregation :161       interpolation :164             interpolation2 :214
+Tensors are stacked clouds `(sum n_i, .)` with int32 cumulative end `offset (b,)`.  torch is used for device
+memory, streams and autograd plumbing only; every op body is a C-ABI call (include/cbl_amd.h).
+Unlike the reference (no checks at all), dtype / device / contiguity are validated and a
+failing launch raises instead of surfacing later as an asynchronous error.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+
+_c_int = ctypes.c_int
+
+
+def _req(t, dtype, name, dim=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise _lib.CblError(f"{name}: must live on the GPU (got {t.device}); there is no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    if dim is not None and t.dim() != dim:
+        raise ValueError(f"{name}: expected {dim} dims, got shape {tuple(t.shape)}")
+    return t
+
+
+def _as_int(v):
+    """nsample / k may arrive as a 0-dim tensor (heads.py:190, basic_operators.py:22)"""
+    return int(v.item()) if isinstance(v, torch.Tensor) else int(v)
+
+
+# ------------------------------------------------------------------------------------------------ K2
+class FurthestSampling(Function):
+    @staticmethod
+    def forward(ctx, xyz, offset, new_offset):
+        """xyz (n,3) f32, offset (b) i32, new_offset (b) i32 -> idx (m) i32          pointops.py:12-25"""
+        _req(xyz, torch.float32, "xyz", 2); _req(offset, torch.int32, "offset", 1); _req(new_offset, torch.int32, "new_offset", 1)
+        n, b = xyz.shape[0], offset.shape[0]
+        off_h = offset.cpu()                       # the reference also syncs here (n_max, new_offset[b-1].item())
+        lens = torch.diff(off_h, prepend=off_h.new_zeros(1))
+        n_max = int(lens.max().item()) if b > 0 else 0
+        m = int(new_offset[b - 1].item()) if b > 0 else 0
+        idx = torch.zeros(m, dtype=torch.int32, device=xyz.device)
+        tmp = torch.full((n,), 1e10, dtype=torch.float32, device=xyz.device)
+        rc = _lib.lib().cbl_furthestsampling(_c_int(b), _c_int(n_max), _lib.ptr(xyz), _lib.ptr(offset), _lib.ptr(new_offset),
+                                             _lib.ptr(tmp), _lib.ptr(idx), _lib.stream_of(xyz))
+        _lib.check(rc, "cbl_furthestsampling")
+        return idx
+
+
+furthestsampling = FurthestSampling.apply
+
+# ------------------------------------------------------------------------------------------------ K1
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    """per-(device, stream) scratch for the grid KNN; grown on demand, reused across calls"""
+    if nbytes == 0:
+        return None
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def knnquery_raw(nsample, xyz, new_xyz, offset, new_offset, algo="auto"):
+    """-> idx (m,nsample) i32, dist2 (m,nsample) f32 (squared).  algo: 'auto' | 'exact' | 'grid'"""
+    nsample = _as_int(nsample)
+    if new_xyz is None:
+        new_xyz = xyz
+    _req(xyz, torch.float32, "xyz", 2); _req(new_xyz, torch.float32, "new_xyz", 2)
+    _req(offset, torch.int32, "offset", 1); _req(new_offset, torch.int32, "new_offset", 1)
+    if not 1 <= nsample <= 1024:
+        raise ValueError(f"nsample={nsample} outside [1, 1024] (knnquery_cuda_kernel.cu:89)")
+    n, m, b = xyz.shape[0], new_xyz.shape[0], offset.shape[0]
+    idx = torch.zeros((m, nsample), dtype=torch.int32, device=xyz.device)
+    dist2 = torch.zeros((m, nsample), dtype=torch.float32, device=xyz.device)
+    L = _lib.lib()
+    st = _lib.stream_of(xyz)
+    args = (_c_int(b), _c_int(n), _c_int(m), _c_int(nsample), _lib.ptr(xyz), _lib.ptr(new_xyz), _lib.ptr(offset),
+            _lib.ptr(new_offset), _lib.ptr(idx), _lib.ptr(dist2))
+    if algo == "exact":
+        _lib.check(L.cbl_knnquery_exact(*args, st), "cbl_knnquery_exact")
+    else:
+        need = L.cbl_knnquery_workspace_bytes(_c_int(b), _c_int(n), _c_int(m), _c_int(nsample))
+        if algo == "grid" and need == 0:
+            raise _lib.CblError("grid KNN not available for this problem shape")
+        ws = _workspace(need, xyz.device)
+        _lib.check(L.cbl_knnquery(*args, _lib.ptr(ws), ctypes.c_size_t(ws.numel() if ws is not None else 0), st), "cbl_knnquery")
+    return idx, dist2
+
+
+class KNNQuery(Function):
+    @staticmethod
+    def forward(ctx, nsample, xyz, new_xyz, offset, new_offset):
+        """-> idx (m,nsample) i32, dist (m,nsample) f32 = sqrt(dist2)                   pointops.py:32-43"""
+        idx, dist2 = knnquery_raw(nsample, xyz, new_xyz, offset, new_offset)
+        ctx.mark_non_differentiable(idx)
+        return idx, torch.sqrt(dist2)
+
+    @staticmethod
+    def backward(ctx, *grads):      # indices are not differentiable; the reference defines no backward
+        return None, None, None, None, None
+
+
+knnquery = KNNQuery.apply
+
+
+# ------------------------------------------------------------------------------------------------ K3/K4
+class Grouping(Function):
+    @staticmethod
+    def forward(ctx, input, idx):
+        """input (n,c), idx (m,nsample) -> (m,nsample,c)                               pointops.py:50-61"""
+        _req(input, torch.float32, "input", 2); _req(idx, torch.int32, "idx", 2)
+        m, nsample, n, c = idx.shape[0], idx.shape[1], input.shape[0], input.shape[1]
+        output = torch.empty((m, nsample, c), dtype=torch.float32, device=input.device)
+        _lib.check(_lib.lib().cbl_grouping_forward(_c_int(m), _c_int(nsample), _c_int(c), _lib.ptr(input), _lib.ptr(idx),
+                                                   _lib.ptr(output), _lib.stream_of(input)), "cbl_grouping_forward")
+        ctx.n = n
+        ctx.save_for_backward(idx)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        idx, = ctx.saved_tensors
+        grad_output = grad_output.contiguous()          # the reference forgets this
+        m, nsample, c = grad_output.shape
+        grad_input = torch.zeros((ctx.n, c), dtype=torch.float32, device=grad_output.device)
+        _lib.check(_lib.lib().cbl_grouping_backward(_c_int(m), _c_int(nsample), _c_int(c), _lib.ptr(grad_output), _lib.ptr(idx),
+                                                    _lib.ptr(grad_input), _lib.stream_of(grad_output)), "cbl_grouping_backward")
+        return grad_input, None
+
+
+grouping = Grouping.apply
+
+
+# ------------------------------------------------------------------------------------------------ F1
+class _QueryAndGroup(Function):
+    """fused gather(xyz)-centre + gather(feat) + concat of pointops.py:90-98; backward = scatter-add"""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, feat, idx, use_xyz):
+        m, nsample = idx.shape
+        c = feat.shape[1]
+        oc = c + (3 if use_xyz else 0)
+        out = torch.empty((m, nsample, oc), dtype=torch.float32, device=feat.device)
+        _lib.check(_lib.lib().cbl_queryandgroup(_c_int(m), _c_int(nsample), _c_int(c), _c_int(1 if use_xyz else 0), _lib.ptr(xyz),
+                                                _lib.ptr(new_xyz), _lib.ptr(feat), _lib.ptr(idx), _lib.ptr(out), _lib.stream_of(feat)),
+                   "cbl_queryandgroup")
+        ctx.save_for_backward(idx)
+        ctx.dims = (xyz.shape[0], feat.shape[0], c, use_xyz)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, = ctx.saved_tensors
+        n_xyz, n_feat, c, use_xyz = ctx.dims
+        m, nsample = idx.shape
+        L = _lib.lib()
+        g_xyz = g_new = g_feat = None
+        gf = grad_out[..., 3:].contiguous() if use_xyz else grad_out.contiguous()
+        if ctx.needs_input_grad[2]:
+            g_feat = torch.zeros((n_feat, c), dtype=torch.float32, device=grad_out.device)
+            _lib.check(L.cbl_grouping_backward(_c_int(m), _c_int(nsample), _c_int(c), _lib.ptr(gf), _lib.ptr(idx), _lib.ptr(g_feat),
+                                               _lib.stream_of(gf)), "cbl_grouping_backward")
+        if use_xyz and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            gx = grad_out[..., :3].contiguous()
+            if ctx.needs_input_grad[0]:
+                g_xyz = torch.zeros((n_xyz, 3), dtype=torch.float32, device=grad_out.device)
+                _lib.check(L.cbl_grouping_backward(_c_int(m), _c_int(nsample), _c_int(3), _lib.ptr(gx), _lib.ptr(idx), _lib.ptr(g_xyz),
+                                                   _lib.stream_of(gx)), "cbl_grouping_backward")
+            if ctx.needs_input_grad[1]:
+                g_new = -gx.sum(1)
+        return g_xyz, g_new, g_feat, None, None
+
+
+def queryandgroup(nsample, xyz, new_xyz, feat, idx, offset, new_offset, use_xyz=True):
+    """-> (m,nsample,3+c) if use_xyz else (m,nsample,c)                               pointops.py:79-100"""
+    if new_xyz is None:
+        new_xyz = xyz
+    _req(xyz, torch.float32, "xyz", 2); _req(new_xyz, torch.float32, "new_xyz", 2); _req(feat, torch.float32, "feat", 2)
+    if idx is None:
+        idx, _ = knnquery(nsample, xyz, new_xyz, offset, new_offset)
+    _req(idx, torch.int32, "idx", 2)
+    return _QueryAndGroup.apply(xyz, new_xyz, feat, idx, bool(use_xyz))
+
+
+# ------------------------------------------------------------------------------------------------ K7/K8
+class Subtraction(Function):
+    @staticmethod
+    def forward(ctx, input1, input2, idx):
+        """input1 (n,c), input2 (n,c), idx (n,nsample) -> (n,nsample,c)               pointops.py:103-115"""
+        _req(input1, torch.float32, "input1", 2); _req(input2, torch.float32, "input2", 2); _req(idx, torch.int32, "idx", 2)
+        n, c = input1.shape
+        nsample = idx.shape[-1]
+        output = torch.empty((n, nsample, c), dtype=torch.float32, device=input1.device)
+        _lib.check(_lib.lib().cbl_subtraction_forward(_c_int(n), _c_int(nsample), _c_int(c), _lib.ptr(input1), _lib.ptr(input2),
+                                                      _lib.ptr(idx), _lib.ptr(output), _lib.stream_of(input1)), "cbl_subtraction_forward")
+        ctx.save_for_backward(idx)
+        ctx.n2 = input2.shape[0]
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        idx, = ctx.saved_tensors
+        grad_output = grad_output.contiguous()
+        n, nsample, c = grad_output.shape
+        g1 = torch.zeros((n, c), dtype=torch.float32, device=grad_output.device)
+        g2 = torch.zeros((ctx.n2, c), dtype=torch.float32, device=grad_output.device)
+        _lib.check(_lib.lib().cbl_subtraction_backward(_c_int(n), _c_int(nsample), _c_int(c), _lib.ptr(idx), _lib.ptr(grad_output),
+                                                       _lib.ptr(g1), _lib.ptr(g2), _lib.stream_of(grad_output)), "cbl_subtraction_backward")
+        return g1, g2, None
+
+
+subtraction = Subtraction.apply
+
+
+# ------------------------------------------------------------------------------------------------ K9/K10
+class Aggregation(Function):
+    @staticmethod
+    def forward(ctx, input, position, weight, idx):
+        """input (n,c), position (n,nsample,c), weight (n,nsample,c'), idx (n,nsample) -> (n,c)   pointops.py:133-144"""
+        _req(input, torch.float32, "input", 2); _req(position, torch.float32, "position", 3)
+        _req(weight, torch.float32, "weight", 3); _req(idx, torch.int32, "idx", 2)
+        n, nsample, c = position.shape
+        w_c = weight.shape[-1]
+        output = torch.zeros((n, c), dtype=torch.float32, device=input.device)
+        _lib.check(_lib.lib().cbl_aggregation_forward(_c_int(n), _c_int(nsample), _c_int(c), _c_int(w_c), _lib.ptr(input), _lib.ptr(position),
+                                                      _lib.ptr(weight), _lib.ptr(idx), _lib.ptr(output), _lib.stream_of(input)),
+                   "cbl_aggregation_forward")
+        ctx.save_for_backward(input, position, weight, idx)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input, position, weight, idx = ctx.saved_tensors
+        grad_output = grad_output.contiguous()
+        n, nsample, c = position.shape
+        w_c = weight.shape[-1]
+        dev = grad_output.device
+        gi = torch.zeros((input.shape[0], c), dtype=torch.float32, device=dev)
+        gp = torch.zeros((n, nsample, c), dtype=torch.float32, device=dev)
+        gw = torch.zeros((n, nsample, w_c), dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().cbl_aggregation_backward(_c_int(n), _c_int(nsample), _c_int(c), _c_int(w_c), _lib.ptr(input), _lib.ptr(position),
+                                                       _lib.ptr(weight), _lib.ptr(idx), _lib.ptr(grad_output), _lib.ptr(gi), _lib.ptr(gp),
+                                                       _lib.ptr(gw), _lib.stream_of(grad_output)), "cbl_aggregation_backward")
+        return gi, gp, gw, None
+
+
+aggregation = Aggregation.apply
+
+
+# ------------------------------------------------------------------------------------------------ F4 / K5 / K6
+def _interp_idx_weight(xyz, new_xyz, offset, new_offset, k):
+    idx, dist2 = knnquery_raw(k, xyz, new_xyz, offset, new_offset)
+    n = new_xyz.shape[0]
+    weight = torch.empty((n, k), dtype=torch.float32, device=xyz.device)
+    _lib.check(_lib.lib().cbl_interpolation_weights(_c_int(n), _c_int(k), _lib.ptr(dist2), _lib.ptr(weight), ctypes.c_void_p(0),
+                                                    _lib.stream_of(xyz)), "cbl_interpolation_weights")
+    return idx, weight
+
+
+class Interpolation(Function):
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, input, offset, new_offset, k=3):
+        """xyz (m,3) coarse, new_xyz (n,3) fine, input (m,c) -> (n,c)                  pointops.py:181-199"""
+        k = _as_int(k)
+        _req(input, torch.float32, "input", 2)
+        idx, weight = _interp_idx_weight(xyz, new_xyz, offset, new_offset, k)
+        n, c, m = new_xyz.shape[0], input.shape[1], input.shape[0]
+        output = torch.zeros((n, c), dtype=torch.float32, device=input.device)
+        _lib.check(_lib.lib().cbl_interpolation_forward(_c_int(n), _c_int(c), _c_int(k), _lib.ptr(input), _lib.ptr(idx), _lib.ptr(weight),
+                                                        _lib.ptr(output), _lib.stream_of(input)), "cbl_interpolation_forward")
+        ctx.m, ctx.k = m, k
+        ctx.save_for_backward(idx, weight)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        idx, weight = ctx.saved_tensors
+        grad_output = grad_output.contiguous()
+        n, c = grad_output.shape
+        grad_input = torch.zeros((ctx.m, c), dtype=torch.float32, device=grad_output.device)
+        _lib.check(_lib.lib().cbl_interpolation_backward(_c_int(n), _c_int(c), _c_int(ctx.k), _lib.ptr(grad_output), _lib.ptr(idx),
+                                                         _lib.ptr(weight), _lib.ptr(grad_input), _lib.stream_of(grad_output)),
+                   "cbl_interpolation_backward")
+        return None, None, grad_input, None, None, None
+
+
+interpolation2 = Interpolation.apply
+
+
+def interpolation(xyz, new_xyz, feat, offset, new_offset, k=3):
+    """pure-torch composite in the reference (pointops.py:164-178); same values, one gather kernel here"""
+    return Interpolation.apply(xyz, new_xyz, feat, offset, new_offset, k)

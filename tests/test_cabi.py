@@ -1,0 +1,50 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/cbl_amd.h declares.
+No compute call is made (no GPU here)."""
+import ctypes
+import os
+
+import pytest
+
+from contrastboundary_amd import _lib, build
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    so = build.build()
+    assert os.path.exists(so)
+    L = ctypes.CDLL(so)
+    syms = _lib.declared_symbols()
+    assert len(syms) >= 16
+    missing = [s for s in syms if not hasattr(L, s)]
+    assert missing == []
+    assert b"gfx950" in _lib.lib().cbl_version()
+
+
+def test_code_object_is_gfx950_only():
+    # the fat binary inside the .so must carry exactly one device target: gfx950 (no multi-arch / fallback paths)
+    data = open(build.SO, "rb").read()
+    assert b"amdgcn-amd-amdhsa--gfx950" in data
+    for other in (b"gfx942", b"gfx90a", b"gfx1100", b"sm_80"):
+        assert other not in data
+
+
+def test_bad_arguments_are_rejected_without_a_gpu():
+    L = _lib.lib()
+    null = ctypes.c_void_p(0)
+    # argument validation happens before any HIP call, so it can be exercised on the CPU box
+    assert L.cbl_knnquery_exact(1, 10, 10, 0, null, null, null, null, null, null, null) == -1          # nsample = 0
+    assert L.cbl_knnquery_exact(1, 10, 10, 2000, null, null, null, null, null, null, null) == -1       # nsample > 1024
+    assert L.cbl_knnquery_exact(1, 10, 10, 4, null, null, null, null, null, null, null) == -1          # null pointers
+    assert L.cbl_grouping_forward(-1, 4, 4, null, null, null, null) == -1
+    assert L.cbl_grouping_forward(0, 4, 4, null, null, null, null) == 0                                 # empty = no-op
+    assert L.cbl_aggregation_forward(4, 4, 4, 0, null, null, null, null, null, null) == -1             # w_c = 0
+
+
+def test_host_mirror_refuses_cpu_tensors():
+    import torch
+    from contrastboundary_amd import pointops
+    x = torch.zeros(8, 3)
+    o = torch.tensor([8], dtype=torch.int32)
+    with pytest.raises(_lib.CblError):
+        pointops.knnquery(2, x, x, o, o)
+    with pytest.raises(_lib.CblError):
+        pointops.grouping(torch.zeros(8, 4), torch.zeros(8, 2, dtype=torch.int32))

@@ -1,0 +1,237 @@
+"""GPU parity: HIP kernels (through the C ABI, via contrastboundary_amd.pointops) vs the CPU oracle and the
+golden vectors from the reference kernel bodies.  idx / integer outputs bit-exact; forward float outputs
+bit-exact (same rounding, no FMA); atomically-accumulated gradients within 1e-4 (north_star tolerance)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+ATOL = 1e-4   # BASELINE.json north_star: "float outputs within 1e-4"
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def names(npz, prefix):
+    return sorted({k.split("/")[1] for k in npz.files if k.startswith(prefix + "/")})
+
+
+KNN = np.load(os.path.join(G, "pointops_knn.npz"))
+FPS = np.load(os.path.join(G, "pointops_fps.npz"))
+K310 = np.load(os.path.join(G, "pointops_k3_k10.npz"))
+
+
+@pytest.fixture(scope="module")
+def P():
+    from contrastboundary_amd import pointops
+    return pointops
+
+
+def test_library_is_native_gfx950():
+    from contrastboundary_amd import _lib
+    assert _lib.lib().cbl_device_arch_ok() == 1
+
+
+@pytest.mark.parametrize("algo", ["exact", "auto"])
+@pytest.mark.parametrize("name", names(KNN, "knn"))
+def test_knn_golden(P, name, algo):
+    g = lambda f: KNN[f"knn/{name}/{f}"]
+    idx, d2 = P.knnquery_raw(int(g("k")), dev(g("xyz")), dev(g("new_xyz")), dev(g("offset")), dev(g("new_offset")), algo=algo)
+    np.testing.assert_array_equal(idx.cpu().numpy(), g("idx"))
+    np.testing.assert_array_equal(d2.cpu().numpy().view(np.uint32), g("dist2").view(np.uint32))
+
+
+@pytest.mark.parametrize("algo", ["exact", "auto"])
+@pytest.mark.parametrize("n,m,b,k,seed", [(5000, 5000, 1, 16, 0), (6000, 1500, 3, 16, 1), (3000, 3000, 4, 36, 2),
+                                          (2000, 700, 2, 3, 3), (2000, 2000, 1, 1, 4), (4096, 64, 2, 256, 5),
+                                          (1500, 200, 1, 400, 6)])
+def test_knn_vs_oracle_random(P, n, m, b, k, seed, algo):
+    rng = np.random.default_rng(seed)
+    xyz = rng.uniform(0, 2, (n, 3)).astype(np.float32)
+    cuts = np.sort(rng.choice(np.arange(1, n), b - 1, replace=False)) if b > 1 else np.array([], int)
+    offset = np.concatenate([cuts, [n]]).astype(np.int32)
+    if m == n:
+        q, noff = xyz, offset
+    else:   # queries: a random subset per cloud, jittered
+        lens = np.diff(np.concatenate([[0], offset]))
+        take = np.maximum(1, (lens * m // n)).astype(int)
+        sel = np.concatenate([np.sort(rng.choice(l, t, replace=False)) + s for l, t, s in zip(lens, take, np.concatenate([[0], offset[:-1]]))])
+        q = (xyz[sel] + rng.normal(0, 0.01, (len(sel), 3))).astype(np.float32)
+        noff = np.cumsum(take).astype(np.int32)
+    idx, d2 = P.knnquery_raw(k, dev(xyz), dev(q), dev(offset), dev(noff), algo=algo)
+    ridx, rd2 = O.knnquery(k, xyz, q, offset, noff)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+    np.testing.assert_array_equal(d2.cpu().numpy().view(np.uint32), rd2.view(np.uint32))
+
+
+def test_knn_python_api_matches_reference_signature(P):
+    # knnquery(nsample, xyz, new_xyz=None, offset, new_offset) -> (idx int32, dist = sqrt(dist2)); nsample may be a 0-dim tensor
+    rng = np.random.default_rng(0)
+    xyz = dev(rng.uniform(size=(300, 3)).astype(np.float32))
+    o = dev(np.int32([300]))
+    idx, dist = P.knnquery(torch.tensor(5), xyz, None, o, o)
+    assert idx.dtype == torch.int32 and idx.shape == (300, 5) and dist.shape == (300, 5)
+    ridx, rd2 = O.knnquery(5, xyz.cpu().numpy(), xyz.cpu().numpy(), [300], [300])
+    np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+    np.testing.assert_array_equal(dist.cpu().numpy(), np.sqrt(rd2))
+    with pytest.raises(Exception):
+        P.knnquery(5, xyz.cpu(), None, o, o)          # CPU tensors are rejected loudly, no fallback
+
+
+@pytest.mark.parametrize("name", names(FPS, "fps"))
+def test_fps_golden(P, name):
+    g = lambda f: FPS[f"fps/{name}/{f}"]
+    idx = P.furthestsampling(dev(g("xyz")), dev(g("offset")), dev(g("new_offset")))
+    np.testing.assert_array_equal(idx.cpu().numpy(), g("idx"))
+
+
+@pytest.mark.parametrize("n,b,seed", [(900, 1, 0), (3000, 2, 1), (9000, 1, 2), (14000, 1, 3), (30000, 2, 4), (45000, 1, 5)])
+def test_fps_vs_oracle(P, n, b, seed):
+    # covers every register-resident variant (1,4,10,16,40 rows) and the streaming kernel (n_max > 40960)
+    rng = np.random.default_rng(seed)
+    xyz = rng.uniform(0, 3, (n, 3)).astype(np.float32)
+    cuts = np.sort(rng.choice(np.arange(100, n - 100), b - 1, replace=False)) if b > 1 else np.array([], int)
+    offset = np.concatenate([cuts, [n]]).astype(np.int32)
+    lens = np.diff(np.concatenate([[0], offset]))
+    noff = np.cumsum(np.minimum(lens // 4, 400)).astype(np.int32)       # <= 400 samples per cloud keeps the oracle fast
+    idx = P.furthestsampling(dev(xyz), dev(offset), dev(noff))
+    ridx, _ = O.furthestsampling(xyz, offset, noff)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+
+
+def test_fps_lattice_ties_all_block_sizes(P):
+    # lattices make every distance tie; n_max selects the reference block size 2^floor(log2 n_max)
+    for side in (3, 5, 7, 11):
+        g = np.arange(side, dtype=np.float32)
+        xyz = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+        n = xyz.shape[0]
+        idx = P.furthestsampling(dev(xyz), dev(np.int32([n])), dev(np.int32([n // 3])))
+        ridx, _ = O.furthestsampling(xyz, [n], [n // 3])
+        np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+
+
+def test_k3_k10_golden(P):
+    g = lambda f: K310[f]
+    inp = dev(g("grouping/input")).requires_grad_(True)
+    out = P.grouping(inp, dev(g("grouping/idx")))
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), g("grouping/output"))
+    out.backward(dev(g("grouping/grad_output")))
+    np.testing.assert_allclose(inp.grad.cpu().numpy(), g("grouping/grad_input"), rtol=0, atol=ATOL)
+
+    a = dev(g("subtraction/input1")).requires_grad_(True); b = dev(g("subtraction/input2")).requires_grad_(True)
+    out = P.subtraction(a, b, dev(g("subtraction/idx")))
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), g("subtraction/output"))
+    out.backward(dev(g("subtraction/grad_output")))
+    np.testing.assert_array_equal(a.grad.cpu().numpy(), g("subtraction/grad_input1"))     # in-register sum, fixed order
+    np.testing.assert_allclose(b.grad.cpu().numpy(), g("subtraction/grad_input2"), rtol=0, atol=ATOL)
+
+    x = dev(g("aggregation/input")).requires_grad_(True); pos = dev(g("aggregation/position")).requires_grad_(True)
+    w = dev(g("aggregation/weight")).requires_grad_(True)
+    out = P.aggregation(x, pos, w, dev(g("aggregation/idx")))
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), g("aggregation/output"))
+    out.backward(dev(g("aggregation/grad_output")))
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g("aggregation/grad_input"), rtol=0, atol=ATOL)
+    np.testing.assert_array_equal(pos.grad.cpu().numpy(), g("aggregation/grad_position"))
+    np.testing.assert_allclose(w.grad.cpu().numpy(), g("aggregation/grad_weight"), rtol=0, atol=ATOL)
+
+
+def _call_interp(P, inp, idx, w, go):
+    """K5/K6 through the raw C ABI (the python-level Interpolation recomputes idx/weight itself)"""
+    import ctypes
+    from contrastboundary_amd import _lib
+    n, k = idx.shape; c = inp.shape[1]
+    out = torch.zeros((n, c), device="cuda")
+    L = _lib.lib()
+    _lib.check(L.cbl_interpolation_forward(n, c, k, _lib.ptr(inp), _lib.ptr(idx), _lib.ptr(w), _lib.ptr(out), _lib.stream_of(inp)), "fwd")
+    gi = torch.zeros_like(inp)
+    _lib.check(L.cbl_interpolation_backward(n, c, k, _lib.ptr(go), _lib.ptr(idx), _lib.ptr(w), _lib.ptr(gi), _lib.stream_of(inp)), "bwd")
+    return out, gi
+
+
+def test_interpolation_kernels_golden(P):
+    g = lambda f: K310[f"interpolation/{f}"]
+    out, gi = _call_interp(P, dev(g("input")), dev(g("idx")), dev(g("weight")), dev(g("grad_output")))
+    np.testing.assert_array_equal(out.cpu().numpy(), g("output"))
+    np.testing.assert_allclose(gi.cpu().numpy(), g("grad_input"), rtol=0, atol=ATOL)
+
+
+@pytest.mark.parametrize("c", [3, 13, 32, 64])
+def test_gather_family_vs_oracle(P, c):
+    rng = np.random.default_rng(c)
+    n, m, ns = 1000, 777, 16
+    wc = 4 if c % 4 == 0 else 1
+    inp = rng.normal(size=(n, c)).astype(np.float32); idx = rng.integers(0, n, (m, ns)).astype(np.int32)
+    np.testing.assert_array_equal(P.grouping(dev(inp), dev(idx)).cpu().numpy(), O.grouping_forward(inp, idx))
+    go = rng.normal(size=(m, ns, c)).astype(np.float32)
+    t = dev(inp).requires_grad_(True); P.grouping(t, dev(idx)).backward(dev(go))
+    np.testing.assert_allclose(t.grad.cpu().numpy(), O.grouping_backward(go, idx, n), rtol=0, atol=ATOL)
+    # subtraction / aggregation use idx (n, ns)
+    idx2 = rng.integers(0, n, (n, ns)).astype(np.int32); b2 = rng.normal(size=(n, c)).astype(np.float32)
+    np.testing.assert_array_equal(P.subtraction(dev(inp), dev(b2), dev(idx2)).cpu().numpy(), O.subtraction_forward(inp, b2, idx2))
+    pos = rng.normal(size=(n, ns, c)).astype(np.float32); w = rng.normal(size=(n, ns, wc)).astype(np.float32)
+    np.testing.assert_array_equal(P.aggregation(dev(inp), dev(pos), dev(w), dev(idx2)).cpu().numpy(), O.aggregation_forward(inp, pos, w, idx2))
+    # K5/K6
+    k = 3; iidx = rng.integers(0, n, (m, k)).astype(np.int32); iw = rng.uniform(size=(m, k)).astype(np.float32)
+    igo = rng.normal(size=(m, c)).astype(np.float32)
+    out, gi = _call_interp(P, dev(inp), dev(iidx), dev(iw), dev(igo))
+    np.testing.assert_array_equal(out.cpu().numpy(), O.interpolation_forward(inp, iidx, iw))
+    np.testing.assert_allclose(gi.cpu().numpy(), O.interpolation_backward(igo, iidx, iw, n), rtol=0, atol=ATOL)
+
+
+def test_queryandgroup_and_interpolation_composites(P):
+    rng = np.random.default_rng(7)
+    n, m, c, k = 2000, 500, 32, 16
+    xyz = rng.uniform(size=(n, 3)).astype(np.float32); feat = rng.normal(size=(n, c)).astype(np.float32)
+    off = np.int32([1200, 2000]); sel = np.concatenate([np.arange(0, 1200, 4), np.arange(1200, 2000, 4)]); q = xyz[sel]; noff = np.int32([300, 500])
+    out = P.queryandgroup(k, dev(xyz), dev(q), dev(feat), None, dev(off), dev(noff), use_xyz=True)
+    ridx, _ = O.knnquery(k, xyz, q, off, noff)
+    ref = np.concatenate([xyz[ridx] - q[:, None, :], feat[ridx]], -1)          # pointops.py:90-98
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    out2 = P.queryandgroup(k, dev(xyz), dev(q), dev(feat), dev(ridx), dev(off), dev(noff), use_xyz=False)
+    np.testing.assert_array_equal(out2.cpu().numpy(), feat[ridx])
+    # interpolation: coarse (q, fq) -> fine xyz, k=3 and k=1                    pointops.py:164-178
+    fq = rng.normal(size=(m, c)).astype(np.float32)
+    for kk in (3, 1):
+        got = P.interpolation(dev(q), dev(xyz), dev(fq), dev(noff), dev(off), k=kk).cpu().numpy()
+        iidx, id2 = O.knnquery(kk, q, xyz, noff, off)
+        dist = np.sqrt(id2); rec = (np.float32(1.0) / (dist + np.float32(1e-8))).astype(np.float32)
+        norm = np.zeros((n, 1), np.float32)
+        for i in range(kk):
+            norm[:, 0] += rec[:, i]
+        w = (rec / norm).astype(np.float32)
+        np.testing.assert_array_equal(got, O.interpolation_forward(fq, iidx, w))
+
+
+def test_full_size_properties(P):
+    """BASELINE C2 size (N=40960, K=16, C=64): size-independent properties instead of the O(N^2) oracle."""
+    rng = np.random.default_rng(0)
+    n, k, c = 40960, 16, 64
+    xyz = dev(rng.uniform(0, 2.05, (n, 3)).astype(np.float32)); o = dev(np.int32([n]))
+    idx, d2 = P.knnquery_raw(k, xyz, xyz, o, o)
+    assert (d2[:, 1:] >= d2[:, :-1]).all()                       # ascending
+    assert (idx[:, 0] == torch.arange(n, device="cuda")).all() and (d2[:, 0] == 0).all()   # self is nearest
+    assert int(idx.min()) >= 0 and int(idx.max()) < n
+    # recomputing d2 from idx reproduces the stored distances bit for bit
+    nb = xyz[idx.long()]; dd = xyz[:, None, :] - nb
+    re = (dd[..., 0] * dd[..., 0] + dd[..., 1] * dd[..., 1]) + dd[..., 2] * dd[..., 2]
+    assert torch.equal(re, d2)
+    # exact and auto paths agree on the whole scene
+    idx_e, d2_e = P.knnquery_raw(k, xyz, xyz, o, o, algo="exact")
+    assert torch.equal(idx, idx_e) and torch.equal(d2, d2_e)
+    # a random 256-query sample against the oracle
+    sel = np.sort(rng.choice(n, 256, replace=False))
+    ridx, _ = O.knnquery(k, xyz.cpu().numpy(), xyz.cpu().numpy()[sel], [n], [256])
+    np.testing.assert_array_equal(idx.cpu().numpy()[sel], ridx)
+    # grouping: gather == torch indexing; backward of ones == neighbour in-degree (linearity / checksum)
+    feat = dev(rng.normal(size=(n, c)).astype(np.float32)).requires_grad_(True)
+    grouped = P.grouping(feat, idx)
+    assert torch.equal(grouped, feat[idx.long()])
+    grouped.backward(torch.ones_like(grouped))
+    deg = torch.bincount(idx.view(-1).long(), minlength=n).float()
+    assert torch.equal(feat.grad, deg[:, None].expand(-1, c))
