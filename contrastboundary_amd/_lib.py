@@ -24,6 +24,10 @@ def declared_symbols():
 def lib():
     global _lib
     if _lib is None:
+        # torch first: its wheel bundles its own libamdhip64 (soname libamdhip64.so.7).  Loaded first, it is
+        # the ONE HIP runtime of the process and libcbl_amd.so binds to it by soname; loaded second, the
+        # process would hold two runtimes and torch's streams/pointers would be foreign to ours.
+        import torch  # noqa: F401
         from . import build as _build
         if _build.is_stale():
             _build.build()          # raises if hipcc is absent or a source does not compile

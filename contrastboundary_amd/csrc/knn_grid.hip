@@ -1,9 +1,220 @@
-// K1 (fast): uniform-grid KNN with tie certification — placeholder until the grid kernel lands:
-// reports "no workspace needed" so cbl_knnquery always takes the exact kernel.
+// K1 (fast): uniform-grid KNN with tie certification and exact replay.
+// Same results as knnquery_cuda_kernel (/root/reference/pytorch/lib/pointops/src/knnquery/knnquery_cuda_kernel.cu:65-111),
+// bit for bit, in O(m * candidates) instead of O(m * n):
+//   1. per cloud: bounding box -> cell size -> dense grid (cbl_grid_choose, grid_core.h)
+//   2. counting sort of the supports by cell (histogram with L2 atomics, one-workgroup scan, scatter)
+//      into float4 {x,y,z,bits(idx)} so a neighbourhood row of cells is ONE contiguous, coalescable range
+//   3. one lane per query, queries taken in cell-sorted order when the query set is the support set
+//      (lanes of a wave then walk the same cells -> L1/L2 hits); top-K kept in registers (static indices)
+//   4. a query is final only if its result provably does not depend on the reference's heap layout:
+//      K distinct distances and no outside candidate tied with the K-th (CblTopK::certify) — everything else
+//      (ties, clouds with <= K supports) is appended to a worklist and recomputed by the exact kernel
+//      (knn_exact.hip) in the reference's visiting order.  No host synchronisation anywhere.
 #include "cbl_common.h"
+#include "grid_core.h"
 
-size_t cbl_knn_grid_workspace_bytes(int, int, int, int) { return 0; }
-int cbl_knn_grid_launch(int, int, int, int, const float*, const float*, const int*, const int*, int*, float*, void*, size_t, hipStream_t)
+int cbl_knn_exact_worklist(int b, int m, int K, const float* xyz, const float* new_xyz, const int* offset,
+                           const int* new_offset, int* idx, float* dist2,
+                           const int* worklist, const int* worklist_count, int max_work, hipStream_t st);
+
+namespace {
+
+constexpr int GRID_MAX_K = 64;          // larger nsample -> exact kernel (register list would spill)
+constexpr int CELLS_PER_POINT = 2;      // cell capacity per cloud = 2*n_c + 64
+constexpr int CELLS_PER_CLOUD = 64;
+
+struct Workspace {
+    CblGrid* grids;      // [b]
+    int* counters;       // [0] = worklist length
+    int* cell_count;     // [ncap + 1]  histogram, then running fill cursor
+    int* cell_start;     // [ncap + 1]  exclusive scan
+    int* pt_cell;        // [n]
+    float4* sorted;      // [n]
+    int* worklist;       // [m]
+    size_t bytes;
+    int ncap;
+};
+
+inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+Workspace carve(void* base, int b, int n, int m)
 {
-    return CBL_ERR_UNSUPPORTED;
+    Workspace w;
+    w.ncap = CELLS_PER_POINT * n + CELLS_PER_CLOUD * b;
+    char* p = reinterpret_cast<char*>(base);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* r = p ? p + off : nullptr; off += align_up(bytes); return r; };
+    w.grids = reinterpret_cast<CblGrid*>(take(sizeof(CblGrid) * (size_t)b));
+    w.counters = reinterpret_cast<int*>(take(sizeof(int) * 64));
+    w.cell_count = reinterpret_cast<int*>(take(sizeof(int) * ((size_t)w.ncap + 1)));
+    w.cell_start = reinterpret_cast<int*>(take(sizeof(int) * ((size_t)w.ncap + 1)));
+    w.pt_cell = reinterpret_cast<int*>(take(sizeof(int) * (size_t)n));
+    w.sorted = reinterpret_cast<float4*>(take(sizeof(float4) * (size_t)n));
+    w.worklist = reinterpret_cast<int*>(take(sizeof(int) * (size_t)m));
+    w.bytes = off;
+    return w;
+}
+
+// ---- 1. per-cloud bounding box + grid parameters: one 1024-lane workgroup per cloud ------------------
+__global__ __launch_bounds__(1024) void grid_setup_kernel(int b, float pts_per_cell, const float* __restrict__ xyz,
+                                                          const int* __restrict__ offset, CblGrid* __restrict__ grids)
+{
+    __shared__ float red[6][16];
+    const int c = blockIdx.x;
+    const int start = c ? offset[c - 1] : 0, end = offset[c];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = start + threadIdx.x; i < end; i += blockDim.x) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) { const float v = xyz[3 * i + a]; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+        for (int s = 32; s >= 1; s >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], s)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], s)); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+        for (int a = 0; a < 3; a++) { red[a][wave] = lo[a]; red[3 + a][wave] = hi[a]; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int a = 0; a < 3; a++)
+            for (int w = 1; w < 16; w++) { red[a][0] = fminf(red[a][0], red[a][w]); red[3 + a][0] = fmaxf(red[3 + a][0], red[3 + a][w]); }
+        float l[3] = {red[0][0], red[1][0], red[2][0]}, h[3] = {red[3][0], red[4][0], red[5][0]};
+        if (end <= start) { l[0] = l[1] = l[2] = 0.f; h[0] = h[1] = h[2] = 0.f; }
+        CblGrid g;
+        cbl_grid_choose(g, l, h, end - start, pts_per_cell, CELLS_PER_POINT * (end - start) + CELLS_PER_CLOUD);
+        g.cell_base = CELLS_PER_POINT * start + CELLS_PER_CLOUD * c;
+        g.start = start; g.end = end; g.pad0 = g.pad1 = 0;
+        grids[c] = g;
+    }
+}
+
+// ---- 2a. histogram -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grid_count_kernel(int b, int n, const float* __restrict__ xyz, const int* __restrict__ offset,
+                                                         const CblGrid* __restrict__ grids, int* __restrict__ pt_cell, int* __restrict__ cell_count)
+{
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int c = cbl_cloud_of(i, offset, b);
+        const CblGrid g = grids[c];
+        const int cell = cbl_cell_of(g, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+        pt_cell[i] = cell;
+        atomicAdd(cell_count + cell, 1);
+    }
+}
+
+// ---- 2b. exclusive scan of the histogram, one workgroup; leaves the running cursor in cell_count ---------
+__global__ __launch_bounds__(1024) void grid_scan_kernel(int ncap, int* __restrict__ cell_count, int* __restrict__ cell_start)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    // tiles of 1024 consecutive entries: coalesced, wave scan + cross-wave carry
+    for (int base = 0; base <= ncap; base += 1024) {
+        const int i = base + tid;
+        const int v = (i <= ncap) ? cell_count[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) { const int o = __shfl_up(incl, s); if (lane >= s) incl += o; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; w++) woff += wsum[w];
+        const int carry = carry_s;
+        const int excl = carry + woff + incl - v;
+        if (i <= ncap) { cell_start[i] = excl; cell_count[i] = excl; }
+        __syncthreads();
+        if (tid == 1023) carry_s = excl + v;
+        __syncthreads();
+    }
+}
+
+// ---- 2c. scatter into cell order ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grid_scatter_kernel(int n, const float* __restrict__ xyz, const int* __restrict__ pt_cell,
+                                                           int* __restrict__ cell_cursor, float4* __restrict__ sorted)
+{
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int pos = atomicAdd(cell_cursor + pt_cell[i], 1);
+        sorted[pos] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], __int_as_float(i));
+    }
+}
+
+// ---- 3. queries -------------------------------------------------------------------------------------------
+template <int K, bool SELF>
+__global__ __launch_bounds__(256) void knn_grid_kernel(int b, int m, int k_out, const float* __restrict__ new_xyz,
+                                                       const int* __restrict__ offset, const int* __restrict__ new_offset,
+                                                       const CblGrid* __restrict__ grids, const int* __restrict__ cell_start,
+                                                       const float4* __restrict__ sorted, int* __restrict__ idx, float* __restrict__ dist2,
+                                                       int* __restrict__ worklist, int* __restrict__ counters)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= m) return;
+    int q; float qx, qy, qz;
+    if (SELF) {                     // queries == supports: walk them in cell order
+        const float4 s = sorted[t];
+        q = __float_as_int(s.w); qx = s.x; qy = s.y; qz = s.z;
+    } else {
+        q = t; qx = new_xyz[3 * q]; qy = new_xyz[3 * q + 1]; qz = new_xyz[3 * q + 2];
+    }
+    const int c = cbl_cloud_of(q, SELF ? offset : new_offset, b);
+    const CblGrid g = grids[c];
+    bool ok = cbl_knn_grid_query<K>(g, cell_start, sorted, qx, qy, qz, k_out, idx + (size_t)q * k_out, dist2 + (size_t)q * k_out);
+    ok = ok && (g.end - g.start > K);          // tiny clouds carry (1e10, start) sentinels: exact kernel
+    if (!ok) worklist[atomicAdd(counters, 1)] = q;
+}
+
+template <int K>
+void launch_query(bool self, int b, int m, int k_out, const float* new_xyz, const int* offset, const int* new_offset, const Workspace& w,
+                  int* idx, float* dist2, hipStream_t st)
+{
+    const dim3 grid(cbl_div_up(m, 256)), block(256);
+    if (self) hipLaunchKernelGGL((knn_grid_kernel<K, true>), grid, block, 0, st, b, m, k_out, new_xyz, offset, new_offset, w.grids, w.cell_start, w.sorted, idx, dist2, w.worklist, w.counters);
+    else      hipLaunchKernelGGL((knn_grid_kernel<K, false>), grid, block, 0, st, b, m, k_out, new_xyz, offset, new_offset, w.grids, w.cell_start, w.sorted, idx, dist2, w.worklist, w.counters);
+}
+
+}  // namespace
+
+// build the per-cloud grids + cell-sorted supports into the workspace (shared with the radius search)
+int cbl_grid_build(int b, int n, float pts_per_cell, const float* xyz, const int* offset, void* ws, hipStream_t st)
+{
+    Workspace w = carve(ws, b, n, 0);
+    hipError_t e = hipMemsetAsync(w.counters, 0, (char*)(w.cell_count + w.ncap + 1) - (char*)w.counters, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(grid_setup_kernel, dim3(b), dim3(1024), 0, st, b, pts_per_cell, xyz, offset, w.grids);
+    hipLaunchKernelGGL(grid_count_kernel, dim3(cbl_grid_for(n, 256)), dim3(256), 0, st, b, n, xyz, offset, w.grids, w.pt_cell, w.cell_count);
+    hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(1024), 0, st, w.ncap, w.cell_count, w.cell_start);
+    hipLaunchKernelGGL(grid_scatter_kernel, dim3(cbl_grid_for(n, 256)), dim3(256), 0, st, n, xyz, w.pt_cell, w.cell_count, w.sorted);
+    return cbl_status();
+}
+
+size_t cbl_knn_grid_workspace_bytes(int b, int n, int m, int nsample)
+{
+    // the grid pays off once the brute-force scan is long; tiny problems and huge K stay on the exact kernel
+    if (nsample > GRID_MAX_K || n < 2048 || b <= 0) return 0;
+    if ((long long)CELLS_PER_POINT * n + (long long)CELLS_PER_CLOUD * b > 0x3fffffffLL) return 0;
+    return carve(nullptr, b, n, m).bytes;
+}
+
+int cbl_knn_grid_launch(int b, int n, int m, int nsample, const float* xyz, const float* new_xyz, const int* offset,
+                        const int* new_offset, int* idx, float* dist2, void* ws, size_t ws_bytes, hipStream_t st)
+{
+    Workspace w = carve(ws, b, n, m);
+    if (ws_bytes < w.bytes) return CBL_ERR_WORKSPACE;
+    const int KT = nsample <= 1 ? 1 : nsample <= 4 ? 4 : nsample <= 8 ? 8 : nsample <= 16 ? 16 : nsample <= 24 ? 24 : nsample <= 36 ? 36 : 64;
+    int rc = cbl_grid_build(b, n, 0.42f * (float)KT, xyz, offset, ws, st);
+    if (rc) return rc;
+    const bool self = (new_xyz == xyz) && (m == n);
+    switch (KT) {
+        case 1:  launch_query<1>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, st); break;
+        case 4:  launch_query<4>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, st); break;
+        case 8:  launch_query<8>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, st); break;
+        case 16: launch_query<16>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, st); break;
+        case 24: launch_query<24>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, st); break;
+        case 36: launch_query<36>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, st); break;
+        default: launch_query<64>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, st); break;
+    }
+    rc = cbl_status();
+    if (rc) return rc;
+    // exact replay of everything that was not certified (device-side count, no host sync)
+    return cbl_knn_exact_worklist(b, m, nsample, xyz, new_xyz, self ? offset : offset, self ? offset : new_offset, idx, dist2,
+                                  w.worklist, w.counters, m, st);
 }
