@@ -1,34 +1,49 @@
 // K1 (exact): segmented brute-force KNN with the reference's heap semantics, bit for bit.
 // Replaces knnquery_cuda_kernel  /root/reference/pytorch/lib/pointops/src/knnquery/knnquery_cuda_kernel.cu:65-111.
 //
-// MI355X mapping (not the reference's): one LANE per query, one WAVE per workgroup so that even
-// m = 40960 queries give 640 independent workgroups across the 256 CUs.  The support index `i` is
-// wave-uniform: its coordinates come through the scalar cache into SGPRs (no per-lane reloads of
-// xyz as in the reference) and the only per-lane state in the hot loop is the query point, the
-// [start,end) range of its cloud and the heap root.  The K-entry max-heap lives in LDS, k-major
-// (slot*64 + lane) so that lanes touching the same slot never bank-conflict; for nsample too large
-// for LDS the heap lives in the caller's idx/dist2 rows themselves.
-//
-// The visiting order is the reference's (ascending support index), every comparison keeps its
-// strictness (d2 < root; right child only if strictly larger; stop only if parent strictly larger),
-// so ties resolve identically — see oracle/pointops_oracle.c for the CPU statement of the same.
+// MI355X mapping (not the reference's one-thread-per-query): one WAVE per query.  The 64 lanes sweep
+// the query's cloud 64 supports at a time (coalesced loads, one distance per lane); a ballot picks the
+// lanes whose d2 beats the heap root and they are fed to the heap in ascending lane order — i.e. in the
+// reference's visiting order — re-checking against the root, which may have dropped in between.  The
+// K-entry max-heap is held ACROSS the lanes of the wave (slot j in lane j, K <= 64) and walked with
+// v_readlane / compare-select under wave-uniform control flow: no LDS round trips, no divergence, a few
+// cycles per heap access.  For 64 < K <= 1024 the heap sits in LDS (same code shape, broadcast reads).
+// Every comparison keeps the reference's strictness (d2 < root; right child only if strictly larger;
+// stop only if parent strictly larger), so ties resolve identically — oracle/pointops_oracle.c is the
+// CPU statement of the same.  The same kernel replays the queries the grid kernel could not certify
+// (worklist mode): m waves spread over the chip instead of one lane scanning a whole cloud.
 #include "cbl_common.h"
+#include <type_traits>
 
 namespace {
 
-constexpr int KNN_BLOCK = 64;
+constexpr int WAVES_PER_BLOCK = 4;
 
-// Heap storage accessors.  LDS: element j of this lane at base[j * 64]; global: base[j].
-template <bool IN_LDS> struct HeapRef {
+__device__ __forceinline__ float rl_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ __forceinline__ int   rl_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+
+// Heap held across lanes: slot j = (hd, hi) of lane j.
+struct LaneHeap {
+    float hd; int hi;
+    __device__ __forceinline__ void init(int, float d, int i) { hd = d; hi = i; }
+    __device__ __forceinline__ float D(int j) const { return rl_f(hd, j); }
+    __device__ __forceinline__ int I(int j) const { return rl_i(hi, j); }
+    // "writelane" as compare + select: two plain VALU ops, no lane-select hazards to pad
+    __device__ __forceinline__ void set(int j, float d, int i) { const bool me = (int)(threadIdx.x & 63) == j; hd = me ? d : hd; hi = me ? i : hi; }
+};
+// Heap in LDS (one per wave); every lane executes the same accesses (broadcast reads, identical writes).
+struct LdsHeap {
     float* d; int* i;
-    __device__ __forceinline__ float& D(int j) const { return IN_LDS ? d[j * KNN_BLOCK] : d[j]; }
-    __device__ __forceinline__ int&   I(int j) const { return IN_LDS ? i[j * KNN_BLOCK] : i[j]; }
+    __device__ __forceinline__ void init(int K, float dv, int iv) { for (int j = threadIdx.x & 63; j < K; j += 64) { d[j] = dv; i[j] = iv; } }
+    __device__ __forceinline__ float D(int j) const { return d[j]; }
+    __device__ __forceinline__ int I(int j) const { return i[j]; }
+    __device__ __forceinline__ void set(int j, float dv, int iv) { d[j] = dv; i[j] = iv; }
 };
 
-// Put (d, id) at the root of a max-heap of `len` entries and sift it down ("hole" form of
-// reheap(), knnquery_cuda_kernel.cu:21-36: identical final layout, fewer stores).
-template <bool IN_LDS>
-__device__ __forceinline__ void heap_replace_root(const HeapRef<IN_LDS>& h, int len, float d, int id)
+// Put (d, id) at the root of a max-heap of `len` entries and sift it down ("hole" form of reheap(),
+// knnquery_cuda_kernel.cu:21-36: identical final layout, fewer stores).  All operands wave-uniform.
+template <class Heap>
+__device__ __forceinline__ void heap_replace_root(Heap& h, int len, float d, int id)
 {
     int parent = 0;
     for (;;) {
@@ -37,17 +52,17 @@ __device__ __forceinline__ void heap_replace_root(const HeapRef<IN_LDS>& h, int 
         float kd = h.D(kid);
         if (kid + 1 < len) {
             const float rd = h.D(kid + 1);
-            if (rd > kd) { kd = rd; kid += 1; }          // right child only when strictly larger
+            if (rd > kd) { kd = rd; kid += 1; }          // right child only when strictly larger (:27)
         }
-        if (d > kd) break;                                // stop only when strictly larger
-        h.D(parent) = kd; h.I(parent) = h.I(kid);
+        if (d > kd) break;                                // stop only when strictly larger (:29)
+        h.set(parent, kd, h.I(kid));
         parent = kid;
     }
-    h.D(parent) = d; h.I(parent) = id;
+    h.set(parent, d, id);
 }
 
-template <bool IN_LDS>
-__global__ __launch_bounds__(KNN_BLOCK) void knn_exact_kernel(
+template <bool IN_LANES>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void knn_exact_wave_kernel(
     int b, int m, int K,
     const float* __restrict__ xyz, const float* __restrict__ new_xyz,
     const int* __restrict__ offset, const int* __restrict__ new_offset,
@@ -55,111 +70,93 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_exact_kernel(
     const int* __restrict__ worklist, const int* __restrict__ worklist_count)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int w = blockIdx.x * WAVES_PER_BLOCK + wave;              // wave-uniform work item
 
-    // optional indirection: only the queries listed in worklist[0 .. *worklist_count) (tied queries
-    // handed over by the grid kernel); otherwise queries are blockIdx.x*64 + lane.
-    int q, n_active;
+    // optional indirection: only the queries listed in worklist[0 .. *worklist_count)
+    int q;
     if (worklist) {
-        n_active = *worklist_count;
-        const int w = blockIdx.x * KNN_BLOCK + lane;
-        if (blockIdx.x * KNN_BLOCK >= n_active) return;
-        q = (w < n_active) ? worklist[w] : -1;
+        const int n_active = *worklist_count;
+        if (w >= n_active) return;
+        q = worklist[w];
     } else {
-        n_active = m;
-        q = blockIdx.x * KNN_BLOCK + lane;
-        if (q >= m) q = -1;
+        if (w >= m) return;
+        q = w;
     }
-    const bool live = q >= 0;
+    q = __builtin_amdgcn_readfirstlane(q);
 
-    int start = 0, end = 0;
-    float qx = 0.f, qy = 0.f, qz = 0.f;
-    if (live) {
-        const int c = cbl_cloud_of(q, new_offset, b);
-        start = (c == 0) ? 0 : offset[c - 1];
-        end = offset[c];
-        qx = new_xyz[3 * q + 0]; qy = new_xyz[3 * q + 1]; qz = new_xyz[3 * q + 2];
-    }
-    // wave-uniform union of the lanes' support ranges
-    int lo = live ? start : 0x7fffffff, hi = live ? end : 0;
-    for (int s = 32; s >= 1; s >>= 1) {
-        lo = min(lo, __shfl_xor(lo, s));
-        hi = max(hi, __shfl_xor(hi, s));
-    }
-    lo = __builtin_amdgcn_readfirstlane(lo);
-    hi = __builtin_amdgcn_readfirstlane(hi);
+    const int c = cbl_cloud_of(q, new_offset, b);
+    const int start = (c == 0) ? 0 : offset[c - 1];                  // :75-79
+    const int end = offset[c];                                       // :80
+    const float qx = new_xyz[3 * q + 0], qy = new_xyz[3 * q + 1], qz = new_xyz[3 * q + 2];
 
-    HeapRef<IN_LDS> h;
-    if (IN_LDS) {
-        h.d = reinterpret_cast<float*>(smem) + lane;
-        h.i = reinterpret_cast<int*>(smem) + K * KNN_BLOCK + lane;
-    } else {
-        h.d = dist2 + (size_t)(live ? q : 0) * K;
-        h.i = idx + (size_t)(live ? q : 0) * K;
+    typename std::conditional<IN_LANES, LaneHeap, LdsHeap>::type h;
+    if constexpr (!IN_LANES) {
+        h.d = reinterpret_cast<float*>(smem) + (size_t)wave * 2 * K;
+        h.i = reinterpret_cast<int*>(h.d + K);
     }
-    if (IN_LDS || live)
-        for (int j = 0; j < K; j++) { h.D(j) = 1e10f; h.I(j) = start; }     // :91-94
-
+    h.init(K, 1e10f, start);                                         // :91-94
     float root = 1e10f;
-    const unsigned span = (unsigned)(end - start);
-    auto consider = [&](int i, float sx, float sy, float sz) {
-        const float d2 = cbl_dist2(qx, qy, qz, sx, sy, sz);                  // (new - x)^2 ..., :99
-        const bool mine = (unsigned)(i - start) < span;
-        if (mine && d2 < root) {                                             // strict, :100
-            heap_replace_root(h, K, d2, i);
-            root = h.D(0);
-        }
-    };
-    // wave-uniform addresses -> scalar loads; 8 supports are fetched ahead of their use so the
-    // scalar-cache latency overlaps the (rare, divergent) heap updates
+
+    // U chunks of 64 supports are loaded ahead of their use: a lone wave (replay mode) would otherwise pay
+    // one full memory latency per 64 supports.  Chunks are still consumed strictly in index order.
     constexpr int U = 8;
-    int i = lo;
-    for (; i + U <= hi; i += U) {
-        float s[3 * U];
+    for (int base = start; base < end; base += 64 * U) {
+        float d2[U];
 #pragma unroll
-        for (int t = 0; t < 3 * U; t++) s[t] = xyz[3 * i + t];
+        for (int u = 0; u < U; u++) {
+            // clamped, UNCONDITIONAL loads: under an exec-masked branch hipcc waits for each chunk's load
+            // before issuing the next one; like this all U are in flight together
+            const int i = base + 64 * u + lane;
+            const int ic = min(i, end - 1);
+            const float d = cbl_dist2(qx, qy, qz, xyz[3 * ic + 0], xyz[3 * ic + 1], xyz[3 * ic + 2]);   // (new - x)^2 ..., :99
+            d2[u] = (i < end) ? d : INFINITY;
+        }
 #pragma unroll
-        for (int t = 0; t < U; t++) consider(i + t, s[3 * t], s[3 * t + 1], s[3 * t + 2]);
+        for (int u = 0; u < U; u++) {
+            unsigned long long mask = __ballot(d2[u] < root);        // strict, :100
+            while (mask) {                                           // ascending lane = ascending support index
+                const int l = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const float dl = rl_f(d2[u], l);
+                if (dl < root) {                                     // root may have dropped since the ballot
+                    heap_replace_root(h, K, dl, base + 64 * u + l);
+                    root = h.D(0);
+                }
+            }
+        }
     }
-    for (; i < hi; i++) consider(i, xyz[3 * i + 0], xyz[3 * i + 1], xyz[3 * i + 2]);
-    if (!live) return;
 
     // heap_sort(), :39-48
     for (int last = K - 1; last > 0; last--) {
         const float d = h.D(last); const int id = h.I(last);
-        h.D(last) = h.D(0); h.I(last) = h.I(0);
+        h.set(last, h.D(0), h.I(0));
         heap_replace_root(h, last, d, id);
     }
-    if (IN_LDS) {
-        int* orow = idx + (size_t)q * K; float* drow = dist2 + (size_t)q * K;
-        for (int j = 0; j < K; j++) { orow[j] = h.I(j); drow[j] = h.D(j); }
+    int* orow = idx + (size_t)q * K; float* drow = dist2 + (size_t)q * K;
+    if constexpr (IN_LANES) {
+        if (lane < K) { orow[lane] = h.hi; drow[lane] = h.hd; }
+    } else {
+        for (int j = lane; j < K; j += 64) { orow[j] = h.i[j]; drow[j] = h.d[j]; }
     }
 }
 
 }  // namespace
 
-// LDS heap while nsample*64*8 B fits in the CU's 160 KiB, else heap in the output rows.
 static int launch_knn_exact(int b, int m, int K, const float* xyz, const float* new_xyz, const int* offset,
                             const int* new_offset, int* idx, float* dist2,
                             const int* worklist, const int* worklist_count, int max_work, hipStream_t st)
 {
     const int nq = worklist ? max_work : m;
     if (nq <= 0) return CBL_OK;
-    const unsigned grid = cbl_div_up(nq, KNN_BLOCK);
-    const size_t lds = (size_t)K * KNN_BLOCK * 8;
-    if (lds <= 160 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_exact_kernel<true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(knn_exact_kernel<true>, dim3(grid), dim3(KNN_BLOCK), lds, st,
+    const dim3 grid(cbl_div_up(nq, WAVES_PER_BLOCK)), block(64 * WAVES_PER_BLOCK);
+    if (K <= 64)
+        hipLaunchKernelGGL(knn_exact_wave_kernel<true>, grid, block, 0, st,
                            b, m, K, xyz, new_xyz, offset, new_offset, idx, dist2, worklist, worklist_count);
-    } else {
-        hipLaunchKernelGGL(knn_exact_kernel<false>, dim3(grid), dim3(KNN_BLOCK), 0, st,
+    else
+        hipLaunchKernelGGL(knn_exact_wave_kernel<false>, grid, block, (size_t)WAVES_PER_BLOCK * K * 8, st,
                            b, m, K, xyz, new_xyz, offset, new_offset, idx, dist2, worklist, worklist_count);
-    }
     return cbl_status();
 }
 

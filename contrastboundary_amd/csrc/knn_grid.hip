@@ -4,8 +4,12 @@
 //   1. per cloud: bounding box -> cell size -> dense grid (cbl_grid_choose, grid_core.h)
 //   2. counting sort of the supports by cell (histogram with L2 atomics, one-workgroup scan, scatter)
 //      into float4 {x,y,z,bits(idx)} so a neighbourhood row of cells is ONE contiguous, coalescable range
-//   3. one lane per query, queries taken in cell-sorted order when the query set is the support set
-//      (lanes of a wave then walk the same cells -> L1/L2 hits); top-K kept in registers (static indices)
+//   3. one 16-lane GROUP per query (64-lane for 16 < K <= 64), queries taken in cell-sorted order when the
+//      query set is the support set (the 4 groups of a wave then walk the same cells -> L1/L2 hits).  The
+//      group's lanes fetch 16 consecutive candidates of a cell row with one coalesced 256 B load, and the
+//      ascending top-K list is DISTRIBUTED over the lanes (element j in lane j): inserting a candidate is
+//      one compare + one DPP row-shift, independent of K.  (A lane-per-query version of the same search,
+//      cbl_knn_grid_query in grid_core.h, is what tests/host_emul runs on the CPU.)
 //   4. a query is final only if its result provably does not depend on the reference's heap layout:
 //      K distinct distances and no outside candidate tied with the K-th (CblTopK::certify) — everything else
 //      (ties, clouds with <= K supports) is appended to a worklist and recomputed by the exact kernel
@@ -26,8 +30,10 @@ constexpr int CELLS_PER_CLOUD = 64;
 struct Workspace {
     CblGrid* grids;      // [b]
     int* counters;       // [0] = worklist length
+    unsigned* bbox;      // [6*b] order-preserving keys of the per-cloud min / max
     int* cell_count;     // [ncap + 1]  histogram, then running fill cursor
     int* cell_start;     // [ncap + 1]  exclusive scan
+    int* tile_sum;       // [ceil((ncap + 1) / 4096)]
     int* pt_cell;        // [n]
     float4* sorted;      // [n]
     int* worklist;       // [m]
@@ -46,8 +52,10 @@ Workspace carve(void* base, int b, int n, int m)
     auto take = [&](size_t bytes) { char* r = p ? p + off : nullptr; off += align_up(bytes); return r; };
     w.grids = reinterpret_cast<CblGrid*>(take(sizeof(CblGrid) * (size_t)b));
     w.counters = reinterpret_cast<int*>(take(sizeof(int) * 64));
+    w.bbox = reinterpret_cast<unsigned*>(take(sizeof(unsigned) * 6 * (size_t)b));
     w.cell_count = reinterpret_cast<int*>(take(sizeof(int) * ((size_t)w.ncap + 1)));
     w.cell_start = reinterpret_cast<int*>(take(sizeof(int) * ((size_t)w.ncap + 1)));
+    w.tile_sum = reinterpret_cast<int*>(take(sizeof(int) * ((size_t)w.ncap / 4096 + 2)));
     w.pt_cell = reinterpret_cast<int*>(take(sizeof(int) * (size_t)n));
     w.sorted = reinterpret_cast<float4*>(take(sizeof(float4) * (size_t)n));
     w.worklist = reinterpret_cast<int*>(take(sizeof(int) * (size_t)m));
@@ -55,36 +63,55 @@ Workspace carve(void* base, int b, int n, int m)
     return w;
 }
 
-// ---- 1. per-cloud bounding box + grid parameters: one 1024-lane workgroup per cloud ------------------
-__global__ __launch_bounds__(1024) void grid_setup_kernel(int b, float pts_per_cell, const float* __restrict__ xyz,
-                                                          const int* __restrict__ offset, CblGrid* __restrict__ grids)
+// ---- 1. per-cloud bounding box (many workgroups, L2 atomics on order-preserving keys) + grid parameters ----
+__device__ __forceinline__ unsigned f2key(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float key2f(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+// bbox[c*6 + a] = min key, bbox[c*6 + 3 + a] = max key; pre-set to 0xffffffff / 0 by the memset below
+__global__ __launch_bounds__(256) void grid_bbox_kernel(int b, int n, const float* __restrict__ xyz, const int* __restrict__ offset,
+                                                        unsigned* __restrict__ bbox)
 {
-    __shared__ float red[6][16];
-    const int c = blockIdx.x;
+    // every workgroup takes a contiguous slice of rows.  A slice normally lies inside one cloud; where it
+    // straddles a boundary the wave works cloud by cloud: the lowest lane with rows left names the cloud,
+    // lanes whose next row is in another cloud sit the round out (so the cross-lane reduction never mixes clouds)
+    const int per = (n + gridDim.x - 1) / gridDim.x;
+    const int r0 = blockIdx.x * per, r1 = min(n, r0 + per);
+    const int lane = threadIdx.x & 63;
+    int i = r0 + threadIdx.x;
+    while (__any(i < r1)) {
+        const bool act = i < r1;
+        const int myc = act ? cbl_cloud_of(i, offset, b) : -1;
+        const int lead = __builtin_ctzll(__ballot(act));
+        const int c0 = __shfl(myc, lead);
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        if (act && myc == c0) {
+            const int cend = min(r1, offset[c0]);
+            for (; i < cend; i += 256) {
+#pragma unroll
+                for (int a = 0; a < 3; a++) { const float v = xyz[3 * i + a]; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); }
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            for (int s = 32; s >= 1; s >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], s)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], s)); }
+            if (lane == 0) { atomicMin(bbox + c0 * 6 + a, f2key(lo[a])); atomicMax(bbox + c0 * 6 + 3 + a, f2key(hi[a])); }
+        }
+    }
+}
+
+__global__ void grid_setup_kernel(int b, float pts_per_cell, const int* __restrict__ offset, const unsigned* __restrict__ bbox, CblGrid* __restrict__ grids)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= b) return;
     const int start = c ? offset[c - 1] : 0, end = offset[c];
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = start + threadIdx.x; i < end; i += blockDim.x) {
-#pragma unroll
-        for (int a = 0; a < 3; a++) { const float v = xyz[3 * i + a]; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); }
-    }
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-        for (int s = 32; s >= 1; s >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], s)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], s)); }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0)
-        for (int a = 0; a < 3; a++) { red[a][wave] = lo[a]; red[3 + a][wave] = hi[a]; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int a = 0; a < 3; a++)
-            for (int w = 1; w < 16; w++) { red[a][0] = fminf(red[a][0], red[a][w]); red[3 + a][0] = fmaxf(red[3 + a][0], red[3 + a][w]); }
-        float l[3] = {red[0][0], red[1][0], red[2][0]}, h[3] = {red[3][0], red[4][0], red[5][0]};
-        if (end <= start) { l[0] = l[1] = l[2] = 0.f; h[0] = h[1] = h[2] = 0.f; }
-        CblGrid g;
-        cbl_grid_choose(g, l, h, end - start, pts_per_cell, CELLS_PER_POINT * (end - start) + CELLS_PER_CLOUD);
-        g.cell_base = CELLS_PER_POINT * start + CELLS_PER_CLOUD * c;
-        g.start = start; g.end = end; g.pad0 = g.pad1 = 0;
-        grids[c] = g;
-    }
+    float l[3] = {0.f, 0.f, 0.f}, h[3] = {0.f, 0.f, 0.f};
+    if (end > start)
+        for (int a = 0; a < 3; a++) { l[a] = key2f(bbox[c * 6 + a]); h[a] = key2f(bbox[c * 6 + 3 + a]); }
+    CblGrid g;
+    cbl_grid_choose(g, l, h, end - start, pts_per_cell, CELLS_PER_POINT * (end - start) + CELLS_PER_CLOUD);
+    g.cell_base = CELLS_PER_POINT * start + CELLS_PER_CLOUD * c;
+    g.start = start; g.end = end; g.pad0 = g.pad1 = 0;
+    grids[c] = g;
 }
 
 // ---- 2a. histogram -------------------------------------------------------------------------------------
@@ -100,32 +127,60 @@ __global__ __launch_bounds__(256) void grid_count_kernel(int b, int n, const flo
     }
 }
 
-// ---- 2b. exclusive scan of the histogram, one workgroup; leaves the running cursor in cell_count ---------
-__global__ __launch_bounds__(1024) void grid_scan_kernel(int ncap, int* __restrict__ cell_count, int* __restrict__ cell_start)
+// ---- 2b. exclusive scan of the histogram: tile-local scans (one workgroup per 4096 entries, 16 per lane as
+// four independent 16 B loads) + a second launch that adds each tile's prefix.  Leaves the running fill cursor
+// in cell_count.  (A single-workgroup scan is latency-bound: ~1 us per dependent L2 round trip.)
+constexpr int SCAN_TILE = 4096;
+
+__global__ __launch_bounds__(256) void grid_scan_tiles_kernel(int total, const int* __restrict__ cell_count, int* __restrict__ cell_start,
+                                                              int* __restrict__ tile_sum)
 {
-    __shared__ int wsum[16];
-    __shared__ int carry_s;
+    __shared__ int wsum[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    // tiles of 1024 consecutive entries: coalesced, wave scan + cross-wave carry
-    for (int base = 0; base <= ncap; base += 1024) {
-        const int i = base + tid;
-        const int v = (i <= ncap) ? cell_count[i] : 0;
-        int incl = v;
+    const int base = blockIdx.x * SCAN_TILE + tid * 16;
+    int v[16];
 #pragma unroll
-        for (int s = 1; s < 64; s <<= 1) { const int o = __shfl_up(incl, s); if (lane >= s) incl += o; }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        int woff = 0;
-        for (int w = 0; w < wave; w++) woff += wsum[w];
-        const int carry = carry_s;
-        const int excl = carry + woff + incl - v;
-        if (i <= ncap) { cell_start[i] = excl; cell_count[i] = excl; }
-        __syncthreads();
-        if (tid == 1023) carry_s = excl + v;
-        __syncthreads();
+    for (int j = 0; j < 16; j += 4) {
+        if (base + j + 3 < total) {
+            const int4 x = *reinterpret_cast<const int4*>(cell_count + base + j);
+            v[j] = x.x; v[j + 1] = x.y; v[j + 2] = x.z; v[j + 3] = x.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[j + k] = (base + j + k < total) ? cell_count[base + j + k] : 0;
+        }
     }
+    int sum = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { const int x = v[j]; v[j] = sum; sum += x; }     // thread-local exclusive
+    int incl = sum;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) { const int o = __shfl_up(incl, s); if (lane >= s) incl += o; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int off = incl - sum;
+    for (int w = 0; w < wave; w++) off += wsum[w];
+    if (tid == 255) tile_sum[blockIdx.x] = off + sum;
+#pragma unroll
+    for (int j = 0; j < 16; j++) if (base + j < total) cell_start[base + j] = off + v[j];
+}
+
+__global__ __launch_bounds__(256) void grid_scan_fix_kernel(int total, int ntiles, const int* __restrict__ tile_sum,
+                                                            int* __restrict__ cell_start, int* __restrict__ cell_count)
+{
+    __shared__ int wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int pre = 0;                                          // sum of the totals of all earlier tiles
+    for (int t = tid; t < (int)blockIdx.x; t += 256) pre += tile_sum[t];
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) pre += __shfl_xor(pre, s);
+    if (lane == 0) wsum[wave] = pre;
+    __syncthreads();
+    pre = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    const int base = blockIdx.x * SCAN_TILE + tid * 16;
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+        if (base + j < total) { const int x = cell_start[base + j] + pre; cell_start[base + j] = x; cell_count[base + j] = x; }
+    (void)ntiles;
 }
 
 // ---- 2c. scatter into cell order ------------------------------------------------------------------------
@@ -138,50 +193,145 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(int n, const float* _
     }
 }
 
-// ---- 3. queries -------------------------------------------------------------------------------------------
-template <int K, bool SELF>
-__global__ __launch_bounds__(256) void knn_grid_kernel(int b, int m, int k_out, const float* __restrict__ new_xyz,
-                                                       const int* __restrict__ offset, const int* __restrict__ new_offset,
-                                                       const CblGrid* __restrict__ grids, const int* __restrict__ cell_start,
-                                                       const float4* __restrict__ sorted, int* __restrict__ idx, float* __restrict__ dist2,
-                                                       int* __restrict__ worklist, int* __restrict__ counters)
+// ---- 3. queries: one G-lane group per query ------------------------------------------------------------------
+template <int G> __device__ __forceinline__ float dpp_shr1_f(float v);
+template <int G> __device__ __forceinline__ int dpp_shr1_i(int v);
+// row_shr:1 (0x111) shifts inside each 16-lane row, wave_shr:1 (0x138) across the whole wave; lane 0 of the
+// row / wave keeps `old` (= its own value, masked out by the caller)
+template <> __device__ __forceinline__ int dpp_shr1_i<16>(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false); }
+template <> __device__ __forceinline__ int dpp_shr1_i<64>(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
+template <> __device__ __forceinline__ float dpp_shr1_f<16>(float v) { return __int_as_float(dpp_shr1_i<16>(__float_as_int(v))); }
+template <> __device__ __forceinline__ float dpp_shr1_f<64>(float v) { return __int_as_float(dpp_shr1_i<64>(__float_as_int(v))); }
+
+template <int G, bool SELF>
+__global__ __launch_bounds__(256) void knn_grid_group_kernel(int b, int m, int K, const float* __restrict__ new_xyz,
+                                                             const int* __restrict__ offset, const int* __restrict__ new_offset,
+                                                             const CblGrid* __restrict__ grids, const int* __restrict__ cell_start,
+                                                             const float4* __restrict__ sorted, int* __restrict__ idx, float* __restrict__ dist2,
+                                                             int* __restrict__ worklist, int* __restrict__ counters)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= m) return;
+    constexpr int QPW = 64 / G;                                     // queries per wave
+    using mask_t = unsigned long long;
+    const int lane = threadIdx.x & 63;
+    const int gl = lane & (G - 1);                                  // lane within the group
+    const int grp = lane / G;                                       // group within the wave
+    const int wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int t = wave_global * QPW + grp;                          // group-uniform query slot
+    const bool live = t < m;
+    const int tt = live ? t : m - 1;                                // dead groups shadow the last query, write nothing
+
     int q; float qx, qy, qz;
-    if (SELF) {                     // queries == supports: walk them in cell order
-        const float4 s = sorted[t];
-        q = __float_as_int(s.w); qx = s.x; qy = s.y; qz = s.z;
-    } else {
-        q = t; qx = new_xyz[3 * q]; qy = new_xyz[3 * q + 1]; qz = new_xyz[3 * q + 2];
-    }
+    if (SELF) { const float4 s = sorted[tt]; q = __float_as_int(s.w); qx = s.x; qy = s.y; qz = s.z; }   // cell order
+    else      { q = tt; qx = new_xyz[3 * q]; qy = new_xyz[3 * q + 1]; qz = new_xyz[3 * q + 2]; }
     const int c = cbl_cloud_of(q, SELF ? offset : new_offset, b);
     const CblGrid g = grids[c];
-    bool ok = cbl_knn_grid_query<K>(g, cell_start, sorted, qx, qy, qz, k_out, idx + (size_t)q * k_out, dist2 + (size_t)q * k_out);
-    ok = ok && (g.end - g.start > K);          // tiny clouds carry (1e10, start) sentinels: exact kernel
-    if (!ok) worklist[atomicAdd(counters, 1)] = q;
+    const float uqx = cbl_u(qx, g.ox, g.inv_cs), uqy = cbl_u(qy, g.oy, g.inv_cs), uqz = cbl_u(qz, g.oz, g.inv_cs);
+    const int cx = cbl_cell_coord(uqx, g.nx), cy = cbl_cell_coord(uqy, g.ny), cz = cbl_cell_coord(uqz, g.nz);
+
+    float ed = INFINITY; int ei = -1;                               // element `gl` of the group's ascending top list
+    float rejmin = INFINITY;                                        // min d2 over candidates not in the list (per lane, reduced at the end)
+    bool done = !live;
+
+    for (int r = 1;; r++) {
+        // r == 1: the 3x3x3 block around the query's cell (shells 0 and 1) as 9 full rows;
+        // r >= 2: shell r — face rows take the whole x-range, interior rows only the two end cells
+        for (int dz = -r; dz <= r; dz++) {
+            for (int dy = -r; dy <= r; dy++) {
+                const bool full = (r == 1) || dz == -r || dz == r || dy == -r || dy == r;
+                const int nseg = full ? 1 : 2;
+                for (int sg = 0; sg < nseg; sg++) {
+                    int x0, x1;
+                    if (full) { x0 = max(cx - r, 0); x1 = min(cx + r, g.nx - 1); }
+                    else      { x0 = x1 = sg ? cx + r : cx - r; }
+                    const int y = cy + dy, z = cz + dz;
+                    int s = 0, e = 0;
+                    if (!done && y >= 0 && y < g.ny && z >= 0 && z < g.nz && x0 >= 0 && x1 <= g.nx - 1) {
+                        const int row = g.cell_base + g.nx * (y + g.ny * z);
+                        s = cell_start[row + x0]; e = cell_start[row + x1 + 1];
+                    }
+                    // ---- the group consumes its range G candidates at a time (wave-level loop: any group busy)
+                    for (int p = s; __any(p < e); p += G) {
+                        const int pi = p + gl;
+                        float d2 = INFINITY; int ci = -1;
+                        if (pi < e) {
+                            const float4 v = sorted[pi];
+                            d2 = cbl_dist2(qx, qy, qz, v.x, v.y, v.z);       // (new - x)^2 ..., knnquery_cuda_kernel.cu:99
+                            ci = __float_as_int(v.w);
+                        }
+                        const float worst = __shfl(ed, K - 1, G);
+                        const bool pass = d2 < worst;
+                        rejmin = fminf(rejmin, pass ? INFINITY : d2);
+                        mask_t gm = (__ballot(pass) >> (grp * G)) & (G == 64 ? ~0ull : ((1ull << G) - 1ull));
+                        while (__any(gm != 0)) {                              // each group inserts its next passing candidate
+                            const bool has = gm != 0;
+                            const int l = has ? __builtin_ctzll(gm) : 0;
+                            gm &= gm - 1;
+                            float dc = __shfl(d2, l, G); const int ic = __shfl(ci, l, G);
+                            if (!has) dc = INFINITY;
+                            const float pd = dpp_shr1_f<G>(ed); const int pidx = dpp_shr1_i<G>(ei);   // left neighbour's element
+                            const bool gt = ed > dc;                          // strictly larger elements move right
+                            const bool left_gt = (gl > 0) && (pd > dc);
+                            if (gl == K - 1) rejmin = fminf(rejmin, gt ? ed : dc);   // evicted element, or a candidate that lost its race
+                            if (gt) { if (left_gt) { ed = pd; ei = pidx; } else { ed = dc; ei = ic; } }
+                        }
+                    }
+                }
+            }
+        }
+        // nothing outside the visited cube may enter the list or tie with its last entry (grid_core.h)
+        const float bound2 = cbl_outside_bound2(g, uqx, uqy, uqz, cx, cy, cz, r);
+        const float worst = __shfl(ed, K - 1, G);
+        if (!done) done = (bound2 == INFINITY) || (worst < bound2);
+        if (__all(done)) break;
+    }
+
+    // certify: list full, K distinct distances, no outside candidate tied with the K-th  (CblTopK::certify)
+    const float worst = __shfl(ed, K - 1, G);
+    float rm = rejmin;
+#pragma unroll
+    for (int s = G / 2; s >= 1; s >>= 1) rm = fminf(rm, __shfl_xor(rm, s, G));
+    const float pd = dpp_shr1_f<G>(ed);
+    const bool dup = (gl > 0) && (gl < K) && (ed == pd);
+    const mask_t dm = (__ballot(dup) >> (grp * G)) & (G == 64 ? ~0ull : ((1ull << G) - 1ull));
+    const bool ok = (worst < INFINITY) && (rm != worst) && (dm == 0);
+    if (live) {
+        if (gl < K) { idx[(size_t)q * K + gl] = ei; dist2[(size_t)q * K + gl] = ed; }
+        if (!ok && gl == 0) worklist[atomicAdd(counters, 1)] = q;
+    }
 }
 
-template <int K>
-void launch_query(bool self, int b, int m, int k_out, const float* new_xyz, const int* offset, const int* new_offset, const Workspace& w,
+template <int G>
+void launch_query(bool self, int b, int m, int K, const float* new_xyz, const int* offset, const int* new_offset, const Workspace& w,
                   int* idx, float* dist2, hipStream_t st)
 {
-    const dim3 grid(cbl_div_up(m, 256)), block(256);
-    if (self) hipLaunchKernelGGL((knn_grid_kernel<K, true>), grid, block, 0, st, b, m, k_out, new_xyz, offset, new_offset, w.grids, w.cell_start, w.sorted, idx, dist2, w.worklist, w.counters);
-    else      hipLaunchKernelGGL((knn_grid_kernel<K, false>), grid, block, 0, st, b, m, k_out, new_xyz, offset, new_offset, w.grids, w.cell_start, w.sorted, idx, dist2, w.worklist, w.counters);
+    const long long waves = ((long long)m + (64 / G) - 1) / (64 / G);
+    const dim3 grid(cbl_div_up(waves, 4)), block(256);
+    if (self) hipLaunchKernelGGL((knn_grid_group_kernel<G, true>), grid, block, 0, st, b, m, K, new_xyz, offset, new_offset, w.grids, w.cell_start, w.sorted, idx, dist2, w.worklist, w.counters);
+    else      hipLaunchKernelGGL((knn_grid_group_kernel<G, false>), grid, block, 0, st, b, m, K, new_xyz, offset, new_offset, w.grids, w.cell_start, w.sorted, idx, dist2, w.worklist, w.counters);
 }
 
 }  // namespace
 
 // build the per-cloud grids + cell-sorted supports into the workspace (shared with the radius search)
+__global__ void grid_init_kernel(int b, int* __restrict__ counters, unsigned* __restrict__ bbox)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 64) counters[i] = 0;
+    if (i < 6 * b) bbox[i] = ((i % 6) < 3) ? 0xffffffffu : 0u;
+}
+
 int cbl_grid_build(int b, int n, float pts_per_cell, const float* xyz, const int* offset, void* ws, hipStream_t st)
 {
     Workspace w = carve(ws, b, n, 0);
-    hipError_t e = hipMemsetAsync(w.counters, 0, (char*)(w.cell_count + w.ncap + 1) - (char*)w.counters, st);
+    hipError_t e = hipMemsetAsync(w.cell_count, 0, sizeof(int) * ((size_t)w.ncap + 1), st);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(grid_setup_kernel, dim3(b), dim3(1024), 0, st, b, pts_per_cell, xyz, offset, w.grids);
+    hipLaunchKernelGGL(grid_init_kernel, dim3(cbl_div_up(max(64, 6 * b), 256)), dim3(256), 0, st, b, w.counters, w.bbox);
+    hipLaunchKernelGGL(grid_bbox_kernel, dim3(cbl_grid_for(n, 1024, 512)), dim3(256), 0, st, b, n, xyz, offset, w.bbox);
+    hipLaunchKernelGGL(grid_setup_kernel, dim3(cbl_div_up(b, 64)), dim3(64), 0, st, b, pts_per_cell, offset, w.bbox, w.grids);
     hipLaunchKernelGGL(grid_count_kernel, dim3(cbl_grid_for(n, 256)), dim3(256), 0, st, b, n, xyz, offset, w.grids, w.pt_cell, w.cell_count);
-    hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(1024), 0, st, w.ncap, w.cell_count, w.cell_start);
+    const int total = w.ncap + 1, ntiles = (total + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL(grid_scan_tiles_kernel, dim3(ntiles), dim3(256), 0, st, total, w.cell_count, w.cell_start, w.tile_sum);
+    hipLaunchKernelGGL(grid_scan_fix_kernel, dim3(ntiles), dim3(256), 0, st, total, ntiles, w.tile_sum, w.cell_start, w.cell_count);
     hipLaunchKernelGGL(grid_scatter_kernel, dim3(cbl_grid_for(n, 256)), dim3(256), 0, st, n, xyz, w.pt_cell, w.cell_count, w.sorted);
     return cbl_status();
 }
@@ -199,19 +349,13 @@ int cbl_knn_grid_launch(int b, int n, int m, int nsample, const float* xyz, cons
 {
     Workspace w = carve(ws, b, n, m);
     if (ws_bytes < w.bytes) return CBL_ERR_WORKSPACE;
-    const int KT = nsample <= 1 ? 1 : nsample <= 4 ? 4 : nsample <= 8 ? 8 : nsample <= 16 ? 16 : nsample <= 24 ? 24 : nsample <= 36 ? 36 : 64;
-    int rc = cbl_grid_build(b, n, 0.42f * (float)KT, xyz, offset, ws, st);
+    const int G = nsample <= 16 ? 16 : 64;
+    // ~0.42*K points per cell if the cloud filled its bbox: the K-th neighbour is then usually inside the 27-cell block
+    int rc = cbl_grid_build(b, n, 0.42f * (float)(nsample < 4 ? 4 : nsample), xyz, offset, ws, st);
     if (rc) return rc;
     const bool self = (new_xyz == xyz) && (m == n);
-    switch (KT) {
-        case 1:  launch_query<1>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, st); break;
-        case 4:  launch_query<4>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, st); break;
-        case 8:  launch_query<8>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, st); break;
-        case 16: launch_query<16>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, st); break;
-        case 24: launch_query<24>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, st); break;
-        case 36: launch_query<36>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, st); break;
-        default: launch_query<64>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, st); break;
-    }
+    if (G == 16) launch_query<16>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, st);
+    else         launch_query<64>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, st);
     rc = cbl_status();
     if (rc) return rc;
     // exact replay of everything that was not certified (device-side count, no host sync)

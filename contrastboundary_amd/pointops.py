@@ -84,8 +84,9 @@ def knnquery_raw(nsample, xyz, new_xyz, offset, new_offset, algo="auto"):
     if not 1 <= nsample <= 1024:
         raise ValueError(f"nsample={nsample} outside [1, 1024] (knnquery_cuda_kernel.cu:89)")
     n, m, b = xyz.shape[0], new_xyz.shape[0], offset.shape[0]
-    idx = torch.zeros((m, nsample), dtype=torch.int32, device=xyz.device)
-    dist2 = torch.zeros((m, nsample), dtype=torch.float32, device=xyz.device)
+    # every element is written by the kernels, so no zero fill (the reference zero-fills, pointops.py:40-41)
+    idx = torch.empty((m, nsample), dtype=torch.int32, device=xyz.device)
+    dist2 = torch.empty((m, nsample), dtype=torch.float32, device=xyz.device)
     L = _lib.lib()
     st = _lib.stream_of(xyz)
     args = (_c_int(b), _c_int(n), _c_int(m), _c_int(nsample), _lib.ptr(xyz), _lib.ptr(new_xyz), _lib.ptr(offset),
