@@ -1,0 +1,272 @@
+// F5 / a7 / a9: Contrastive Boundary Learning head — sub-scene labels, positive/negative pair mining,
+// soft-nearest-neighbour loss (forward + analytic backward), boundary masks.
+// Replaces the torch-op chains of
+//   get_subscene_label / get_subscene_features   /root/reference/pytorch/model/basic_operators.py:9-50
+//   ContrastHead.point_contrast                  /root/reference/pytorch/model/heads.py:185-246
+//       (posmask_cnt :145-149, dist_l2 :116-119, contrast_softnn :151-165)
+//   get_boundary_mask                            /root/reference/pytorch/model/basic_operators.py:69-97
+//
+// MI355X mapping: the reference materialises neighbor_label (m,K-1,ncls), neighbor_feature (m,K-1,d), boolean
+// masks, compacts rows with a host sync (torch.any, heads.py:222) and runs ~15 elementwise kernels.  Here one
+// G-lane group owns one point (G = 16/32/64 >= K-1): lane j gathers neighbour j's whole feature row with 16 B
+// loads (rows are 128 B at d=32: whole cache lines), reduces |f_i - f_j|^2 in registers, and the max / sums of the
+// soft-NN loss are cross-lane reductions inside the group.  Nothing but the per-point loss (4 B) is written; rows
+// without both a positive and a negative neighbour are masked, not compacted, so there is no host sync.
+// Backward recomputes the same quantities and scatters with fp32 L2 atomics, one coalesced 4*d-byte row per
+// (point, neighbour) — the same access pattern autograd's index_select backward has in the reference.
+#include "cbl_common.h"
+
+namespace {
+
+template <int G> __device__ __forceinline__ float group_max(float v)
+{
+#pragma unroll
+    for (int s = G / 2; s >= 1; s >>= 1) v = fmaxf(v, __shfl_xor(v, s, G));
+    return v;
+}
+template <int G> __device__ __forceinline__ float group_sum(float v)
+{
+#pragma unroll
+    for (int s = G / 2; s >= 1; s >>= 1) v += __shfl_xor(v, s, G);
+    return v;
+}
+template <int G> __device__ __forceinline__ int group_sum_i(int v)
+{
+#pragma unroll
+    for (int s = G / 2; s >= 1; s >>= 1) v += __shfl_xor(v, s, G);
+    return v;
+}
+
+// ---- a7: soft label = mean one-hot of the kr nearest stage-0 points ------------------------------------
+// one wave per query; lanes sweep the kr neighbours, class counts by ballot + popcount
+__global__ __launch_bounds__(256) void subscene_label_kernel(int m, int kr, int ncls, const long long* __restrict__ target,
+                                                             const int* __restrict__ nidx, float* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int q = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (q >= m) return;
+    int mycount = 0;                                    // lane c accumulates the count of class c (ncls <= 64)
+    for (int base = 0; base < kr; base += 64) {
+        const int j = base + lane;
+        const int lab = (j < kr) ? (int)target[nidx[(size_t)q * kr + j]] : -1;
+        for (int c = 0; c < ncls; c++) {
+            const int cnt = __popcll(__ballot(lab == c));
+            if (lane == c) mycount += cnt;
+        }
+    }
+    if (lane < ncls) out[(size_t)q * ncls + lane] = (float)mycount / (float)kr;       // x.float().mean(-2), :41
+}
+
+// ---- argmax over classes, first maximal index (torch.argmax) -------------------------------------------
+__global__ __launch_bounds__(256) void label_argmax_kernel(int m, int ncls, const float* __restrict__ labels, int* __restrict__ amax)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const float* row = labels + (size_t)i * ncls;
+    float best = row[0]; int bi = 0;
+    for (int c = 1; c < ncls; c++) { const float v = row[c]; if (v > best) { best = v; bi = c; } }
+    amax[i] = bi;
+}
+
+// per-group state shared by forward and backward
+template <int G, int DV>
+struct ContrastRow {
+    bool nb;          // this lane holds a real neighbour (j < ns)
+    bool pos;         // neighbour has the centre's label
+    bool valid;       // the point has both positive and negative neighbours (group-uniform)
+    float dist, e, P, A;
+    float diff[DV * 4];
+    int nbr;
+};
+
+template <int G, int DV>
+__device__ __forceinline__ void contrast_row(ContrastRow<G, DV>& r, int i, int gl, int nsample, int d, const float* __restrict__ feat,
+                                             const int* __restrict__ amax, const int* __restrict__ nidx, float inv_temperature)
+{
+    const int ns = nsample - 1;                                     // self column dropped, heads.py:195-196
+    r.nb = gl < ns;
+    r.nbr = nidx[(size_t)i * nsample + 1 + (r.nb ? gl : 0)];
+    r.pos = r.nb && (amax[r.nbr] == amax[i]);                       // posmask_cnt :145-149
+    const int cnt = group_sum_i<G>(r.pos ? 1 : 0);
+    r.valid = cnt > 0 && cnt < ns;                                  // :212-213
+    const float4* fi = reinterpret_cast<const float4*>(feat + (size_t)i * d);
+    const float4* fj = reinterpret_cast<const float4*>(feat + (size_t)r.nbr * d);
+    float acc = 0.f;
+#pragma unroll
+    for (int v = 0; v < DV; v++) {
+        const float4 a = fi[v], b = fj[v];
+        r.diff[4 * v + 0] = a.x - b.x; r.diff[4 * v + 1] = a.y - b.y; r.diff[4 * v + 2] = a.z - b.z; r.diff[4 * v + 3] = a.w - b.w;
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc += r.diff[4 * v + k] * r.diff[4 * v + k];
+    }
+    r.dist = sqrtf(acc + 1e-12f);                                   // dist_l2 :116-119
+    float neg = r.nb ? -r.dist : -INFINITY;
+    const float mx = group_max<G>(neg);                             // :153
+    neg = (neg - mx) * inv_temperature;                             // :154-155
+    r.e = r.nb ? expf(neg) : 0.f;
+    r.P = group_sum<G>(r.pos ? r.e : 0.f);
+    r.A = group_sum<G>(r.e);
+}
+
+template <int G, int DV>
+__global__ __launch_bounds__(256) void contrast_fwd_kernel(int m, int nsample, const float* __restrict__ feat, const int* __restrict__ amax,
+                                                           const int* __restrict__ nidx, float inv_temperature,
+                                                           float* __restrict__ per_point, int* __restrict__ point_mask)
+{
+    const int t = (blockIdx.x * 256 + threadIdx.x) / G;
+    const int gl = threadIdx.x & (G - 1);
+    const int i = t < m ? t : m - 1;
+    ContrastRow<G, DV> r;
+    contrast_row<G, DV>(r, i, gl, nsample, DV * 4, feat, amax, nidx, inv_temperature);
+    if (t < m && gl == 0) {
+        per_point[t] = r.valid ? -logf(r.P / r.A + 1e-12f) : 0.f;  // contrast_softnn :161-163
+        point_mask[t] = r.valid ? 1 : 0;
+    }
+}
+
+// deterministic reduction: stats[0] = sum of per-point losses, stats[1] = #valid points, loss = w * mean
+__global__ __launch_bounds__(1024) void contrast_finalize_kernel(int m, float weight, const float* __restrict__ per_point,
+                                                                 const int* __restrict__ point_mask, float* __restrict__ stats, float* __restrict__ loss)
+{
+    __shared__ float ssum[16]; __shared__ float scnt[16];
+    float s = 0.f, c = 0.f;
+    for (int i = threadIdx.x; i < m; i += 1024) { s += per_point[i]; c += (float)point_mask[i]; }
+    for (int k = 32; k >= 1; k >>= 1) { s += __shfl_xor(s, k); c += __shfl_xor(c, k); }
+    if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = s; scnt[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float S = 0.f, C = 0.f;
+        for (int w = 0; w < 16; w++) { S += ssum[w]; C += scnt[w]; }
+        stats[0] = S; stats[1] = C;
+        loss[0] = C > 0.f ? (S / C) * weight : 0.f;                 // torch.mean(loss) * float(w), :241-243; 0 if no boundary point (:233)
+    }
+}
+
+template <int G, int DV>
+__global__ __launch_bounds__(256) void contrast_bwd_kernel(int m, int nsample, const float* __restrict__ feat, const int* __restrict__ amax,
+                                                           const int* __restrict__ nidx, float inv_temperature, float weight,
+                                                           const float* __restrict__ stats, const float* __restrict__ grad_loss,
+                                                           float* __restrict__ grad_feat)
+{
+    const int t = (blockIdx.x * 256 + threadIdx.x) / G;
+    const int gl = threadIdx.x & (G - 1);
+    const int i = t < m ? t : m - 1;
+    const float count = stats[1];
+    if (!(count > 0.f)) return;                                     // uniform: loss was the constant 0
+    ContrastRow<G, DV> r;
+    contrast_row<G, DV>(r, i, gl, nsample, DV * 4, feat, amax, nidx, inv_temperature);
+    if (t >= m || !r.valid) return;                                 // group-uniform
+    // d loss/d dist_j = g*w/count * e_j (pos_j*A - P) / (T A^2 (P/A + eps));   d dist_j/d f_i = diff/dist = -d dist_j/d f_j
+    const float scale = grad_loss[0] * weight / count;
+    const float ratio = r.P / r.A;
+    float coef = r.nb ? scale * r.e * ((r.pos ? r.A : 0.f) - r.P) * inv_temperature / (r.A * r.A * (ratio + 1e-12f)) / r.dist : 0.f;
+    float* gj = grad_feat + (size_t)r.nbr * (DV * 4);
+    float* gi = grad_feat + (size_t)i * (DV * 4);
+#pragma unroll
+    for (int k = 0; k < DV * 4; k++) {
+        const float c = coef * r.diff[k];
+        if (r.nb) unsafeAtomicAdd(gj + k, -c);
+        const float s = group_sum<G>(c);                            // the centre's own gradient: one add per channel
+        if (gl == (k & (G - 1))) unsafeAtomicAdd(gi + k, s);
+    }
+}
+
+// ---- a9: boundary / plain masks from neighbour labels ---------------------------------------------------
+__global__ __launch_bounds__(256) void boundary_mask_kernel(int n, int k, const long long* __restrict__ labels, const int* __restrict__ nidx,
+                                                            unsigned char* __restrict__ bound, unsigned char* __restrict__ plain, int* __restrict__ cnt)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long me = labels[i];
+    int neq = 0; bool all_eq = true;
+    for (int j = 0; j < k; j++) {
+        const long long nl = labels[nidx[(size_t)i * k + j]];
+        const bool valid = nl >= 0;                                 // valid_neighbor, :77
+        neq += (valid && nl != me) ? 1 : 0;                         // :80-81
+        all_eq = all_eq && (nl == me || !valid);                    // :92-93
+    }
+    if (bound) bound[i] = neq > 0;
+    if (plain) plain[i] = all_eq;
+    if (cnt) cnt[i] = neq;
+}
+
+template <int G>
+int launch_contrast(bool fwd, int m, int nsample, int d, const float* feat, const int* amax, const int* nidx, float inv_t, float weight,
+                    float* per_point, int* point_mask, const float* stats, const float* grad_loss, float* grad_feat, hipStream_t st)
+{
+    const dim3 grid(cbl_div_up((long long)m * G, 256)), block(256);
+#define CBL_CONTRAST_DV(DV)                                                                                                                  \
+    if (fwd) hipLaunchKernelGGL((contrast_fwd_kernel<G, DV>), grid, block, 0, st, m, nsample, feat, amax, nidx, inv_t, per_point, point_mask); \
+    else     hipLaunchKernelGGL((contrast_bwd_kernel<G, DV>), grid, block, 0, st, m, nsample, feat, amax, nidx, inv_t, weight, stats, grad_loss, grad_feat)
+    switch (d) {
+        case 4:  CBL_CONTRAST_DV(1); break;
+        case 8:  CBL_CONTRAST_DV(2); break;
+        case 16: CBL_CONTRAST_DV(4); break;
+        case 32: CBL_CONTRAST_DV(8); break;
+        case 64: CBL_CONTRAST_DV(16); break;
+        default: return CBL_ERR_UNSUPPORTED;
+    }
+#undef CBL_CONTRAST_DV
+    return cbl_status();
+}
+
+int dispatch_contrast(bool fwd, int m, int nsample, int d, const float* feat, const int* amax, const int* nidx, float temperature, float weight,
+                      float* per_point, int* point_mask, const float* stats, const float* grad_loss, float* grad_feat, hipStream_t st)
+{
+    const int ns = nsample - 1;
+    const float inv_t = 1.0f / temperature;
+    if (ns <= 16) return launch_contrast<16>(fwd, m, nsample, d, feat, amax, nidx, inv_t, weight, per_point, point_mask, stats, grad_loss, grad_feat, st);
+    if (ns <= 32) return launch_contrast<32>(fwd, m, nsample, d, feat, amax, nidx, inv_t, weight, per_point, point_mask, stats, grad_loss, grad_feat, st);
+    return launch_contrast<64>(fwd, m, nsample, d, feat, amax, nidx, inv_t, weight, per_point, point_mask, stats, grad_loss, grad_feat, st);
+}
+
+}  // namespace
+
+CBL_EXPORT int cbl_subscene_label(int m, int kr, int num_classes, const long long* target, const int* neighbor_idx, float* out, void* stream)
+{
+    if (m < 0 || kr <= 0 || num_classes <= 0 || num_classes > 64) return CBL_ERR_BAD_ARG;
+    if (m == 0) return CBL_OK;
+    if (!target || !neighbor_idx || !out) return CBL_ERR_BAD_ARG;
+    hipLaunchKernelGGL(subscene_label_kernel, dim3(cbl_div_up((long long)m * 64, 256)), dim3(256), 0, cbl_stream(stream), m, kr, num_classes, target, neighbor_idx, out);
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_label_argmax(int m, int num_classes, const float* labels, int* amax, void* stream)
+{
+    if (m < 0 || num_classes <= 0) return CBL_ERR_BAD_ARG;
+    if (m == 0) return CBL_OK;
+    if (!labels || !amax) return CBL_ERR_BAD_ARG;
+    hipLaunchKernelGGL(label_argmax_kernel, dim3(cbl_div_up(m, 256)), dim3(256), 0, cbl_stream(stream), m, num_classes, labels, amax);
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_point_contrast_forward(int m, int nsample, int d, const float* features, const int* amax, const int* neighbor_idx,
+                                          float temperature, float weight, float* per_point, int* point_mask, float* stats, float* loss, void* stream)
+{
+    if (m <= 0 || nsample < 2 || nsample > 65 || d <= 0 || !(temperature > 0.f)) return CBL_ERR_BAD_ARG;
+    if (!features || !amax || !neighbor_idx || !per_point || !point_mask || !stats || !loss) return CBL_ERR_BAD_ARG;
+    if (!cbl_host_aligned16(features)) return CBL_ERR_BAD_ARG;
+    hipStream_t st = cbl_stream(stream);
+    const int rc = dispatch_contrast(true, m, nsample, d, features, amax, neighbor_idx, temperature, weight, per_point, point_mask, nullptr, nullptr, nullptr, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(contrast_finalize_kernel, dim3(1), dim3(1024), 0, st, m, weight, per_point, point_mask, stats, loss);
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_point_contrast_backward(int m, int nsample, int d, const float* features, const int* amax, const int* neighbor_idx,
+                                           float temperature, float weight, const float* stats, const float* grad_loss, float* grad_features, void* stream)
+{
+    if (m <= 0 || nsample < 2 || nsample > 65 || d <= 0 || !(temperature > 0.f)) return CBL_ERR_BAD_ARG;
+    if (!features || !amax || !neighbor_idx || !stats || !grad_loss || !grad_features) return CBL_ERR_BAD_ARG;
+    if (!cbl_host_aligned16(features)) return CBL_ERR_BAD_ARG;
+    return dispatch_contrast(false, m, nsample, d, features, amax, neighbor_idx, temperature, weight, nullptr, nullptr, stats, grad_loss, grad_features, cbl_stream(stream));
+}
+
+CBL_EXPORT int cbl_boundary_mask(int n, int k, const long long* labels, const int* neighbor_idx, unsigned char* bound, unsigned char* plain, int* cnt, void* stream)
+{
+    if (n < 0 || k <= 0) return CBL_ERR_BAD_ARG;
+    if (n == 0) return CBL_OK;
+    if (!labels || !neighbor_idx) return CBL_ERR_BAD_ARG;
+    hipLaunchKernelGGL(boundary_mask_kernel, dim3(cbl_div_up(n, 256)), dim3(256), 0, cbl_stream(stream), n, k, labels, neighbor_idx, bound, plain, cnt);
+    return cbl_status();
+}

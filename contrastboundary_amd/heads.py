@@ -1,0 +1,113 @@
+"""Host mirror of the reference's CBL criterion, /root/reference/pytorch/model/heads.py:63-253 (ContrastHead).
+
+Same constructor arguments (head_cfg, config), same forward(output, target, stage_list) -> list of scalar losses (one per
+stage of head_cfg.stage), same numbers.  The whole of point_contrast (:185-246) after the two knnquery calls is ONE fused HIP
+kernel forward and one backward (csrc/cbl.hip) instead of ~15 torch ops, 4 materialised (m,K-1,.) tensors and a host sync.
+Supported head options = the shipped config (config/s3dis/origin_multi-...-contrast-Ua-softnn-latent-label-l2-w.1.yaml:60-68):
+pos='cnt', dist='l2', contrast='softnn', sample='label', no projection MLP; anything else raises NotImplementedError.
+"""
+import ctypes
+import re
+
+import torch
+from torch.autograd import Function
+
+from . import _lib, pointops
+from .basic_operators import get_subscene_label
+
+_c_int = ctypes.c_int
+_c_float = ctypes.c_float
+
+
+def parse_stage(stage, num_layers):
+    """model/utils.py:27-35: 'Ua' -> [('up',0),...,('up',4)], 'D012_U34' -> ..."""
+    stage = stage.replace("a", "".join(f"{i}" for i in range(num_layers)))
+    parts = [i.strip("_") for i in re.split(r"(\d+)", stage) if i and i.strip("_")]
+    assert len(parts) % 2 == 0, f"invalid stage compound: {parts} from {stage}"
+    names = {"D": "down", "down": "down", "U": "up", "up": "up"}
+    out = []
+    for n, digits in zip(parts[0::2], parts[1::2]):
+        out += [(names[n], int(d)) for d in digits]
+    return out
+
+
+class _PointContrast(Function):
+    @staticmethod
+    def forward(ctx, features, amax, neighbor_idx, temperature, weight):
+        m, d = features.shape
+        nsample = neighbor_idx.shape[1]
+        dev = features.device
+        per_point = torch.empty(m, dtype=torch.float32, device=dev)
+        mask = torch.empty(m, dtype=torch.int32, device=dev)
+        stats = torch.empty(2, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().cbl_point_contrast_forward(_c_int(m), _c_int(nsample), _c_int(d), _lib.ptr(features), _lib.ptr(amax),
+                                                         _lib.ptr(neighbor_idx), _c_float(temperature), _c_float(weight), _lib.ptr(per_point),
+                                                         _lib.ptr(mask), _lib.ptr(stats), _lib.ptr(loss), _lib.stream_of(features)),
+                   "cbl_point_contrast_forward")
+        ctx.save_for_backward(features, amax, neighbor_idx, stats)
+        ctx.cfg = (temperature, weight)
+        ctx.mark_non_differentiable(mask)
+        return loss.view(()), mask
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_mask):
+        features, amax, neighbor_idx, stats = ctx.saved_tensors
+        temperature, weight = ctx.cfg
+        m, d = features.shape
+        g = torch.zeros_like(features)
+        gl = grad_loss.reshape(1).to(torch.float32).contiguous()
+        _lib.check(_lib.lib().cbl_point_contrast_backward(_c_int(m), _c_int(neighbor_idx.shape[1]), _c_int(d), _lib.ptr(features), _lib.ptr(amax),
+                                                          _lib.ptr(neighbor_idx), _c_float(temperature), _c_float(weight), _lib.ptr(stats),
+                                                          _lib.ptr(gl), _lib.ptr(g), _lib.stream_of(features)), "cbl_point_contrast_backward")
+        return g, None, None, None, None
+
+
+def point_contrast(features, labels, neighbor_idx, temperature=1.0, weight=0.1, return_mask=False):
+    """features (m,d) f32, labels (m,ncls) f32 soft/one-hot OR (m,) int class ids, neighbor_idx (m,nsample) i32 incl. the self column
+    -> scalar loss (device tensor, differentiable w.r.t. features)"""
+    m = features.shape[0]
+    if labels.dim() == 2:
+        amax = torch.empty(m, dtype=torch.int32, device=features.device)
+        labels = labels.contiguous()
+        _lib.check(_lib.lib().cbl_label_argmax(_c_int(m), _c_int(labels.shape[1]), _lib.ptr(labels), _lib.ptr(amax), _lib.stream_of(features)),
+                   "cbl_label_argmax")
+    else:
+        amax = labels.to(torch.int32).contiguous()
+    loss, mask = _PointContrast.apply(features.contiguous(), amax, neighbor_idx.contiguous(), float(temperature), float(weight))
+    return (loss, mask) if return_mask else loss
+
+
+class ContrastHead(torch.nn.Module):
+    """heads.py:63-253.  Used as a criterion: forward(output, target, stage_list) -> [loss per stage]."""
+
+    def __init__(self, head_cfg, config):
+        super().__init__()
+        self.nsample = [int(v) for v in config.nsample]
+        self.nstride = [int(v) for v in config.nstride]
+        self.num_classes = int(config.num_classes)
+        self.head_cfg, self.config = head_cfg, config
+        self.stages = parse_stage(head_cfg.stage, config.num_layers)
+        self.ftype = head_cfg.ftype if head_cfg.ftype not in ("out", "fout") else "f_out"
+        for key, allowed in (("dist", ("l2",)), ("pos", ("cnt",)), ("contrast", ("softnn",))):
+            if getattr(head_cfg, key) not in allowed:
+                raise NotImplementedError(f"ContrastHead {key}={getattr(head_cfg, key)!r}: the fused HIP path covers {allowed} "
+                                          "(the reference's shipped config)")
+        assert head_cfg.sample in ["cnt", "glb", "sub", "subspatial", "pts", "label", "vote"], f"not support sample = {head_cfg.sample}"
+        if "project" in head_cfg and head_cfg.project:
+            raise NotImplementedError("projection MLP before the contrast is not part of the fused path")
+        self.temperature = float(head_cfg.temperature) if "temperature" in head_cfg and head_cfg.temperature is not None else 1.0
+        self.weight = float(head_cfg.weight[1:])                         # 'w.1' -> 0.1, heads.py:241-243
+
+    def point_contrast(self, n, i, stage_list, target):
+        stage = stage_list[n][i]
+        p, features, o = stage["p_out"], stage[self.ftype], stage["offset"]
+        if i == 0:
+            labels = target                                               # one-hot's argmax is the label itself
+        else:
+            labels = get_subscene_label(n, i, stage_list, target, self.nstride, self.num_classes)   # :189
+        neighbor_idx, _ = pointops.knnquery_raw(self.nsample[i], p, p, o, o)                       # :192
+        return point_contrast(features, labels, neighbor_idx, self.temperature, self.weight)
+
+    def forward(self, output, target, stage_list):
+        return [self.point_contrast(n, i, stage_list, target) for n, i in self.stages]              # :248-253

@@ -112,6 +112,37 @@ int cbl_queryandgroup(int m, int nsample, int c, int use_xyz, const float* xyz, 
  *   dist2 (n,k) -> weight (n,k), dist (n,k) (dist may be NULL) */
 int cbl_interpolation_weights(int n, int k, const float* dist2, float* weight, float* dist, void* stream);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * Contrastive Boundary Learning head (pytorch side)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* a7  get_subscene_label / get_subscene_features  pytorch/model/basic_operators.py:9-50 (idx given)
+ *   target (N) int64 class ids, neighbor_idx (m,kr) rows into target (from cbl_knnquery with nsample = kr,
+ *   supports = stage-0 points) -> out (m,num_classes) = mean one-hot label of the kr neighbours.  num_classes <= 64 */
+int cbl_subscene_label(int m, int kr, int num_classes, const long long* target, const int* neighbor_idx, float* out, void* stream);
+
+/* torch.argmax(labels, -1) (first maximal index), as used by posmask_cnt  pytorch/model/heads.py:145-149
+ *   labels (m,num_classes) -> amax (m) int32 */
+int cbl_label_argmax(int m, int num_classes, const float* labels, int* amax, void* stream);
+
+/* F5  ContrastHead.point_contrast  pytorch/model/heads.py:185-246 with pos='cnt', dist='l2', contrast='softnn'
+ *   features (m,d) f32 (d in {4,8,16,32,64}, 16-byte aligned), amax (m) i32 = argmax of the (sub-scene) label,
+ *   neighbor_idx (m,nsample) i32 from cbl_knnquery on the stage's own points (column 0 = self, dropped; nsample <= 65)
+ *   -> per_point (m) f32 loss of each point (0 where masked), point_mask (m) i32 (1 = has both positive and negative
+ *      neighbours), stats (2) f32 = {sum of per-point losses, #masked-in points}, loss (1) f32 = weight * mean
+ *      (0 when no point qualifies, heads.py:233).  No host synchronisation. */
+int cbl_point_contrast_forward(int m, int nsample, int d, const float* features, const int* amax, const int* neighbor_idx,
+                               float temperature, float weight, float* per_point, int* point_mask, float* stats, float* loss, void* stream);
+/* backward of the above w.r.t. features: grad_features (m,d) += grad_loss[0] * d loss / d features  (caller pre-zeroes) */
+int cbl_point_contrast_backward(int m, int nsample, int d, const float* features, const int* amax, const int* neighbor_idx,
+                                float temperature, float weight, const float* stats, const float* grad_loss, float* grad_features, void* stream);
+
+/* a9  get_boundary_mask  pytorch/model/basic_operators.py:69-97 (labels (n) int64, negative = invalid neighbour label)
+ *   neighbor_idx (n,k) -> bound (n) u8 [any valid neighbour label differs], plain (n) u8 [all valid neighbour labels equal],
+ *   cnt (n) i32 [number of differing valid neighbours]; any output may be NULL */
+int cbl_boundary_mask(int n, int k, const long long* labels, const int* neighbor_idx, unsigned char* bound, unsigned char* plain, int* cnt, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/cbl_pytorch.npz by IMPORTING the reference's own Python (Route C).
+
+RUNS ONLY IN THE BUILD CONTAINER (needs /root/reference).  The reference's CBL head
+(pytorch/model/heads.py:63-253 ContrastHead, pytorch/model/basic_operators.py:9-50 sub-scene labels) is pure
+torch on top of `pointops.knnquery`; its only native dependency is the CUDA module `pointops_cuda`, imported at
+module load (pointops.py:7).  Here an empty module of that name is injected so the import succeeds, and
+`pointops.knnquery` is pointed at the CPU oracle (oracle/pointops_oracle.c, itself pinned bit-exact to the
+reference's KNN kernel body by pointops_knn.npz).  Everything else — one-hot labels, gathers, masks, dist_l2,
+contrast_softnn, mean, weight — is the reference's code executing unmodified on CPU tensors.
+
+Stored: a 5-stage synthetic `stage_list` (2 clouds, 4096 -> 1024 -> 256 -> 64 -> 16 points, 32-d latent; the last stage has fewer points per cloud than nsample), the
+targets, the per-stage sub-scene soft labels, the 5 CBL losses and d(sum of losses)/d(latent) per stage.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/pytorch"
+
+
+def main():
+    assert os.path.isdir(REF), "needs /root/reference (build container only)"
+    sys.modules["pointops_cuda"] = types.ModuleType("pointops_cuda")
+    sys.path.insert(0, REF)
+    from lib.pointops.functions import pointops as ref_pointops          # noqa: E402
+    from model import heads as ref_heads                                  # noqa: E402
+    from model import basic_operators as ref_ops                          # noqa: E402
+    from util.config import CfgNode                                       # noqa: E402
+    from tests import oracle_lib as O
+    from contrastboundary_amd import synthetic as S
+
+    def knnquery_cpu(nsample, xyz, new_xyz, offset, new_offset):
+        nsample = int(nsample)
+        if new_xyz is None:
+            new_xyz = xyz
+        idx, d2 = O.knnquery(nsample, xyz.numpy(), new_xyz.numpy(), offset.numpy(), new_offset.numpy())
+        return torch.from_numpy(idx), torch.sqrt(torch.from_numpy(d2))     # KNNQuery.forward, pointops.py:42-43
+
+    ref_pointops.knnquery = knnquery_cpu
+
+    # ---- config exactly as the shipped yaml (config/s3dis/origin_multi-...-contrast-Ua-softnn-latent-label-l2-w.1.yaml:56-68)
+    cfg = CfgNode({"nsample": [36, 24, 24, 24, 24], "nstride": [4, 4, 4, 4], "num_classes": 13, "num_layers": 5, "voxel_size": 0.04,
+                   "base_fdim": 32,
+                   "contrast": {"stage": "Ua", "contrast": "softnn", "ftype": "latent", "sample": "label", "pos": "cnt", "dist": "l2",
+                                "temperature": 1, "weight": "w.1"}})
+    out = {}
+    for case, (n0, temperature, seed) in {"default": (4096, 1, 0), "temp0p5": (2048, 0.5, 1)}.items():
+        cfg.contrast.temperature = temperature
+        torch.manual_seed(seed)
+        rng = np.random.default_rng(seed)
+        xyz, labels = S.s_room(n0, seed=seed)
+        off = S.offsets(n0, 2, seed=seed)
+        # pyramid by FPS with the oracle (same stage sizes rule as TransitionDown, blocks.py:63-69: n_i // stride per cloud)
+        stage_list = {"inputs": None, "down": [], "up": []}
+        p, o = xyz, off
+        for i in range(5):
+            if i > 0:
+                lens = np.diff(np.concatenate([[0], o]))
+                n_o = np.cumsum(lens // 4).astype(np.int32)
+                fidx, _ = O.furthestsampling(p, o, n_o)
+                p, o = p[fidx], n_o
+            latent = torch.randn(p.shape[0], 32, dtype=torch.float32, requires_grad=True)
+            # neighbouring points get similar features so that positive/negative distances differ in scale
+            st = {"p_out": torch.from_numpy(np.ascontiguousarray(p)), "f_out": None, "offset": torch.from_numpy(np.ascontiguousarray(o)),
+                  "latent": latent}
+            stage_list["up"].append(st)
+            stage_list["down"].append(st)
+        target = torch.from_numpy(labels)
+        head = ref_heads.ContrastHead(cfg.contrast, cfg)
+        losses = head(None, target, stage_list)
+        total = torch.stack([l for l in losses]).sum()
+        total.backward()
+        for i in range(5):
+            st = stage_list["up"][i]
+            soft = ref_ops.get_subscene_label("up", i, stage_list, target, torch.tensor(cfg.nstride), cfg.num_classes)
+            out[f"{case}/stage{i}/p"] = st["p_out"].numpy()
+            out[f"{case}/stage{i}/offset"] = st["offset"].numpy()
+            out[f"{case}/stage{i}/latent"] = st["latent"].detach().numpy()
+            out[f"{case}/stage{i}/soft_label"] = soft.numpy()
+            out[f"{case}/stage{i}/loss"] = np.float32(losses[i].item())
+            out[f"{case}/stage{i}/grad_latent"] = st["latent"].grad.numpy() if st["latent"].grad is not None else np.zeros((p.shape[0], 32), np.float32)
+        out[f"{case}/target"] = labels
+        out[f"{case}/temperature"] = np.float32(temperature)
+        print(case, "losses", [float(l) for l in losses])
+    out["nsample"] = np.int32([36, 24, 24, 24, 24])
+    out["nstride"] = np.int32([4, 4, 4, 4])
+    out["weight"] = np.float32(0.1)
+    np.savez_compressed(os.path.join(HERE, "cbl_pytorch.npz"), **out)
+
+    # ---- get_boundary_mask (basic_operators.py:69-97) on a small case
+    rng = np.random.default_rng(5)
+    lab = torch.from_numpy(rng.integers(0, 4, 200))
+    nidx = torch.from_numpy(rng.integers(0, 200, (200, 6)).astype(np.int32))
+    nl = lab[nidx.view(-1).long()].view(200, 6)
+    nl[::7, 2] = -1                                     # invalid neighbours
+    bound, plain = ref_ops.get_boundary_mask(lab, neighbor_label=nl, get_plain=True)
+    cnt = ref_ops.get_boundary_mask(lab, neighbor_label=nl, get_cnt=True)
+    np.savez_compressed(os.path.join(HERE, "boundary_mask.npz"), labels=lab.numpy(), neighbor_label=nl.numpy(),
+                        bound=bound.numpy(), plain=plain.numpy(), cnt=cnt.numpy())
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,119 @@
+"""GPU parity: fused CBL head (csrc/cbl.hip through the C ABI) vs goldens from the reference's own heads.py and vs the oracle."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cbl_oracle as C
+from tests import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+CBL = np.load(os.path.join(G, "cbl_pytorch.npz"))
+TOL = 1e-4        # north_star: float outputs within 1e-4
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+class Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+def make_stage_list(case):
+    up = []
+    for i in range(5):
+        up.append({"p_out": dev(CBL[f"{case}/stage{i}/p"]), "offset": dev(CBL[f"{case}/stage{i}/offset"]),
+                   "latent": dev(CBL[f"{case}/stage{i}/latent"]).requires_grad_(True), "f_out": None})
+    return {"inputs": None, "up": up, "down": up}
+
+
+@pytest.mark.parametrize("case", ["default", "temp0p5"])
+def test_contrast_head_matches_reference(case):
+    from contrastboundary_amd.heads import ContrastHead
+    cfg = Cfg(nsample=[36, 24, 24, 24, 24], nstride=[4, 4, 4, 4], num_classes=13, num_layers=5, voxel_size=0.04,
+              contrast=Cfg(stage="Ua", contrast="softnn", ftype="latent", sample="label", pos="cnt", dist="l2",
+                           temperature=float(CBL[f"{case}/temperature"]), weight="w.1"))
+    head = ContrastHead(cfg.contrast, cfg)
+    sl = make_stage_list(case)
+    losses = head(None, dev(CBL[f"{case}/target"]), sl)
+    assert len(losses) == 5
+    torch.stack(losses).sum().backward()
+    for i in range(5):
+        np.testing.assert_allclose(losses[i].item(), CBL[f"{case}/stage{i}/loss"], rtol=TOL, atol=1e-6)
+        np.testing.assert_allclose(sl["up"][i]["latent"].grad.cpu().numpy(), CBL[f"{case}/stage{i}/grad_latent"], rtol=1e-3, atol=TOL * 1e-2)
+
+
+@pytest.mark.parametrize("case", ["default", "temp0p5"])
+def test_subscene_labels_match_reference(case):
+    from contrastboundary_amd.basic_operators import get_subscene_label
+    sl = make_stage_list(case)
+    target = dev(CBL[f"{case}/target"])
+    for i in range(5):
+        soft = get_subscene_label("up", i, sl, target, [4, 4, 4, 4], 13)
+        np.testing.assert_array_equal(soft.cpu().numpy(), CBL[f"{case}/stage{i}/soft_label"])       # counts / kr: exact
+
+
+@pytest.mark.parametrize("nsample,d", [(8, 16), (17, 32), (33, 32), (40, 64), (65, 8)])
+def test_point_contrast_vs_oracle(nsample, d):
+    """every group width (16/32/64 lanes) and feature width, random blocky labels"""
+    from contrastboundary_amd import heads, pointops
+    rng = np.random.default_rng(nsample)
+    n = 3000
+    xyz = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    lab = (np.floor(xyz[:, 0] * 4) + 4 * np.floor(xyz[:, 1] * 3)).astype(np.int64) % 13
+    feat = (rng.normal(size=(n, d)) * 0.5).astype(np.float32)
+    off = np.int32([1200, 3000])
+    idx, _ = O.knnquery(nsample, xyz, xyz, off, off)
+    f = dev(feat).requires_grad_(True)
+    loss, mask = heads.point_contrast(f, dev(lab), dev(idx), temperature=0.7, weight=0.1, return_mask=True)
+    loss.backward()
+    rloss, rgrad, rmask = C.point_contrast(feat, np.eye(13, dtype=np.float32)[lab], idx, temperature=0.7, weight=0.1)
+    np.testing.assert_array_equal(mask.cpu().numpy().astype(bool), rmask)
+    np.testing.assert_allclose(loss.item(), rloss, rtol=TOL)
+    np.testing.assert_allclose(f.grad.cpu().numpy(), rgrad, rtol=1e-3, atol=1e-7)
+
+
+def test_no_boundary_point_gives_zero_loss_and_zero_grad():
+    from contrastboundary_amd import heads
+    rng = np.random.default_rng(0)
+    n = 500
+    xyz = rng.uniform(size=(n, 3)).astype(np.float32)
+    idx, _ = O.knnquery(8, xyz, xyz, [n], [n])
+    f = dev(rng.normal(size=(n, 32)).astype(np.float32)).requires_grad_(True)
+    loss = heads.point_contrast(f, dev(np.zeros(n, np.int64)), dev(idx))      # a single class: no negatives anywhere (heads.py:233)
+    loss.backward()
+    assert loss.item() == 0.0 and float(f.grad.abs().max()) == 0.0
+
+
+def test_boundary_mask():
+    from contrastboundary_amd.basic_operators import get_boundary_mask
+    g = np.load(os.path.join(G, "boundary_mask.npz"))
+    b, p = get_boundary_mask(dev(g["labels"]), neighbor_label=dev(g["neighbor_label"]), get_plain=True)
+    np.testing.assert_array_equal(b.cpu().numpy(), g["bound"]); np.testing.assert_array_equal(p.cpu().numpy(), g["plain"])
+    # native path from indices, labels with invalid (-1) entries
+    rng = np.random.default_rng(1)
+    lab = rng.integers(-1, 5, 4000).astype(np.int64); nidx = rng.integers(0, 4000, (4000, 16)).astype(np.int32)
+    b, p = get_boundary_mask(dev(lab), neighbor_idx=dev(nidx), get_plain=True)
+    c = get_boundary_mask(dev(lab), neighbor_idx=dev(nidx), get_cnt=True)
+    rb, rp = C.boundary_mask(lab, lab[nidx], get_plain=True)
+    np.testing.assert_array_equal(b.cpu().numpy(), rb); np.testing.assert_array_equal(p.cpu().numpy(), rp)
+    np.testing.assert_array_equal(c.cpu().numpy(), C.boundary_mask(lab, lab[nidx], get_cnt=True))
+
+
+def test_cbl_full_size_properties():
+    """N=40960, nsample=36 (stage 0 of the shipped config): loss invariant to a global feature translation, scales with weight,
+    gradient sums to zero over all points (every pair contributes +c to one point and -c to another)."""
+    from contrastboundary_amd import heads, hotpath, pointops
+    sc = hotpath.Scene.synthetic(40960, 32, seed=0)
+    idx, _ = pointops.knnquery_raw(36, sc.xyz, sc.xyz, sc.offset, sc.offset)
+    f = sc.feat.clone().requires_grad_(True)
+    l1 = heads.point_contrast(f, sc.labels, idx, 1.0, 0.1)
+    l1.backward()
+    l2 = heads.point_contrast(sc.feat + 3.0, sc.labels, idx, 1.0, 0.1)
+    l3 = heads.point_contrast(sc.feat, sc.labels, idx, 1.0, 0.3)
+    assert abs(l1.item() - l2.item()) < 1e-4 and abs(3 * l1.item() - l3.item()) < 1e-4 and l1.item() > 0
+    assert float(f.grad.sum(0).abs().max()) < 1e-4

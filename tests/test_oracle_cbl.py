@@ -1,0 +1,47 @@
+"""CPU: oracle/cbl_oracle.py against goldens produced by running the reference's own heads.py / basic_operators.py
+(tests/golden/gen_cbl_goldens.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import cbl_oracle as C
+from tests import oracle_lib as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+CBL = np.load(os.path.join(G, "cbl_pytorch.npz"))
+NSAMPLE = CBL["nsample"]; NSTRIDE = CBL["nstride"]
+
+
+def stage(case, i, f):
+    return CBL[f"{case}/stage{i}/{f}"]
+
+
+@pytest.mark.parametrize("case", ["default", "temp0p5"])
+def test_subscene_labels(case):
+    target = CBL[f"{case}/target"]
+    p0, o0 = stage(case, 0, "p"), stage(case, 0, "offset")
+    np.testing.assert_array_equal(C.one_hot_label(target, 13), stage(case, 0, "soft_label"))
+    for i in range(1, 5):
+        kr = int(np.prod(NSTRIDE[:i]))                                     # basic_operators.py:22
+        idx, _ = O.knnquery(kr, p0, stage(case, i, "p"), o0, stage(case, i, "offset"))
+        np.testing.assert_array_equal(C.subscene_label(target, idx, 13), stage(case, i, "soft_label"))
+
+
+@pytest.mark.parametrize("case", ["default", "temp0p5"])
+def test_point_contrast_loss_and_grad(case):
+    T = float(CBL[f"{case}/temperature"])
+    for i in range(5):
+        p, o = stage(case, i, "p"), stage(case, i, "offset")
+        idx, _ = O.knnquery(int(NSAMPLE[i]), p, p, o, o)
+        loss, grad, mask = C.point_contrast(stage(case, i, "latent"), stage(case, i, "soft_label"), idx, temperature=T, weight=0.1)
+        np.testing.assert_allclose(loss, stage(case, i, "loss"), rtol=1e-5)
+        np.testing.assert_allclose(grad, stage(case, i, "grad_latent"), rtol=1e-4, atol=1e-7)
+        assert mask.any()
+
+
+def test_boundary_mask():
+    g = np.load(os.path.join(G, "boundary_mask.npz"))
+    b, p = C.boundary_mask(g["labels"], g["neighbor_label"], get_plain=True)
+    np.testing.assert_array_equal(b, g["bound"]); np.testing.assert_array_equal(p, g["plain"])
+    np.testing.assert_array_equal(C.boundary_mask(g["labels"], g["neighbor_label"], get_cnt=True), g["cnt"])
