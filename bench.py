@@ -39,26 +39,22 @@ def parse():
 
 
 def cpu_baseline(n, c, k, seed):
-    """the oracle (port of the reference algorithm), 1 thread, ONE full scene of the same workload"""
+    """the oracles (ports of the reference algorithms: brute-force KNN in C, the rest numpy), 1 thread, ONE full scene"""
     from tests import oracle_lib as O
-    from contrastboundary_amd import synthetic as S
-    xyz, labels = S.s_room(n, seed)
-    feat = np.random.default_rng(seed + 1000).normal(size=(n, c)).astype(np.float32)
-    off = np.array([n], np.int32)
+    from tests import oracle_hotpath
+    from contrastboundary_amd import hotpath
+    sc = hotpath.Scene.synthetic_numpy(n, c, seed)
+    xyz, feat, off = sc["xyz"], sc["feat"], sc["offset"]
     os.environ.setdefault("OMP_NUM_THREADS", "1")
-    t0 = time.perf_counter()
     parts = {}
+    t0 = time.perf_counter()
     idx, _ = O.knnquery(k, xyz, xyz, off, off)
-    parts["knnquery"] = time.perf_counter() - t0
+    parts["knnquery_k%d" % k] = time.perf_counter() - t0
     t1 = time.perf_counter()
     g = O.grouping_forward(np.concatenate([xyz, feat], 1), idx)
     g[..., :3] -= xyz[:, None, :]
     parts["queryandgroup"] = time.perf_counter() - t1
-    try:
-        from tests import oracle_hotpath
-        parts.update(oracle_hotpath.run_rest(xyz, feat, labels, off, idx, k))
-    except ImportError:
-        pass
+    parts.update(oracle_hotpath.run_rest(sc, idx, k))
     total = sum(parts.values())
     return {"value": n / total, "unit": "points/s", "cores": 1, "kind": "port",
             "sample": "1 scene of %d points (same workload), single thread; stage seconds: %s" % (

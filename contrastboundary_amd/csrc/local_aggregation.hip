@@ -1,0 +1,343 @@
+// a14 / a15: TF-side local aggregation over radius neighbourhoods with a shadow (padding) index.
+// Replaces the TF1 op chains of
+//   PseudoGrid (KPConv, depthwise)   /root/reference/tensorflow/models/local_aggregation_operators.py:620-746 (math :681-728)
+//   AdaptiveWeight                   ...:316-500 (shipped config: dp -> 1 FC -> weights, mean reduction with the :466-470 quirk)
+//   ind_max_pool / ind_closest_pool  /root/reference/tensorflow/models/basic_operators.py:155-192
+// Index convention of the TF side: neighbors_indices (n, K) int32, value == n0 (number of supports) means "no neighbour"
+// and selects a shadow row (zeros for features, 1e6 / 0 for points, column-min for max pooling).
+//
+// MI355X mapping.  KPConv forward is the one GEMM-shaped piece of the hot path: per query point the influence matrix
+// w (KP x K) times the gathered neighbour features (K x C).  One wave per point feeds it to the matrix cores as
+// v_mfma_f32_16x16x4_f32 tiles (M = 16 kernel points, N = 16 channels, k = 4 neighbours): the A operand (influence
+// weights) is COMPUTED in registers by the lane that owns (kernel point, neighbour) and never exists in memory, the B
+// operand is the gathered feature row (64 B contiguous per neighbour), the accumulator tile is contracted with the
+// depthwise kernel weights in the epilogue.  Exact f32 (fma chain), no reduced precision.  Nothing of shape (n,K,.) or
+// (n,KP,.) is materialised, unlike the reference's gather / tile / matmul chain.  Backward passes and AdaptiveWeight are
+// lane-per-channel VALU kernels (their contraction depth is 3..16), gradients of the shared parameters are reduced
+// in registers over a persistent wave's points, then across the workgroup in LDS, then one L2 atomic per element.
+#include "cbl_common.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// ---------------------------------------------------------------------------------------------- KPConv forward (MFMA)
+// influence: 0 constant, 1 linear.  closest: only the nearest kernel point of each neighbour keeps its weight (:705-708).
+template <int CHUNKS>     // 16-channel chunks handled per pass (registers: 4 floats each)
+__global__ __launch_bounds__(256) void kpconv_fwd_kernel(int n, int n0, int K, int C, int KP, const float* __restrict__ q,
+                                                         const float* __restrict__ s, const int* __restrict__ idx, const float* __restrict__ f,
+                                                         const float* __restrict__ kpts, const float* __restrict__ kw, float extent,
+                                                         int influence, int closest, float* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int kp_id = lane & 15;          // A row / kernel point          (A[i = lane&15][k = lane>>4])
+    const int kq = lane >> 4;             // neighbour within a chunk of 4 (B[k = lane>>4][j = lane&15])
+    const int wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (gridDim.x * 256) >> 6;
+    const bool kp_ok = kp_id < KP;
+    const float kx = kp_ok ? kpts[3 * kp_id] : 0.f, ky = kp_ok ? kpts[3 * kp_id + 1] : 0.f, kz = kp_ok ? kpts[3 * kp_id + 2] : 0.f;
+
+    for (int p = wave0; p < n; p += nwaves) {
+        const float qx = q[3 * p], qy = q[3 * p + 1], qz = q[3 * p + 2];
+        for (int c0 = 0; c0 < C; c0 += 16 * CHUNKS) {
+            f32x4 acc[CHUNKS];
+#pragma unroll
+            for (int ch = 0; ch < CHUNKS; ch++) acc[ch] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int kc = 0; kc < K; kc += 4) {
+                const int nb = kc + kq;
+                const int id = (nb < K) ? idx[(size_t)p * K + nb] : n0;
+                const bool real = id >= 0 && id < n0;
+                // neighbour relative to the query; the shadow point sits at (1e6,1e6,1e6)  (:681-684)
+                const float rx = (real ? s[3 * id] : 1e6f) - qx, ry = (real ? s[3 * id + 1] : 1e6f) - qy, rz = (real ? s[3 * id + 2] : 1e6f) - qz;
+                const float dx = rx - kx, dy = ry - ky, dz = rz - kz;
+                const float sq = (dx * dx + dy * dy) + dz * dz;                                  // :688
+                float w = influence ? fmaxf(1.0f - sqrtf(sq) / extent, 0.0f) : 1.0f;            // :697 / :693
+                if (closest) {                                                                   // argmin over kernel points, first minimum
+                    float bs = kp_ok ? sq : INFINITY; int bi = kp_id;
+#pragma unroll
+                    for (int sft = 8; sft >= 1; sft >>= 1) {
+                        const float os = __shfl_xor(bs, sft, 16); const int oi = __shfl_xor(bi, sft, 16);
+                        if (os < bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
+                    }
+                    if (bi != kp_id) w = 0.f;
+                }
+                const float a = (kp_ok && nb < K) ? w : 0.f;
+#pragma unroll
+                for (int ch = 0; ch < CHUNKS; ch++) {
+                    const int c = c0 + 16 * ch + kp_id;                                          // B column = lane & 15
+                    const float bval = (real && c < C) ? f[(size_t)id * C + c] : 0.f;           // shadow feature row = 0 (:713)
+                    acc[ch] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bval, acc[ch], 0, 0, 0);  // wf = w @ f_nbr (:716)
+                }
+            }
+            // epilogue: out[c] = sum_kp kernel_weights[kp,c] * wf[kp,c]  (:723-727).  D: col = lane&15, row = (lane>>4)*4 + r
+#pragma unroll
+            for (int ch = 0; ch < CHUNKS; ch++) {
+                const int c = c0 + 16 * ch + kp_id;
+                float part = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = kq * 4 + r;
+                    const float kwv = (row < KP && c < C) ? kw[(size_t)row * C + c] : 0.f;
+                    part += kwv * acc[ch][r];
+                }
+                part += __shfl_xor(part, 16);
+                part += __shfl_xor(part, 32);
+                if (lane < 16 && c < C) out[(size_t)p * C + c] = part;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- KPConv backward (VALU)
+// grad_features[nbr_k, c] += go[c] * sum_kp w[kp,k] * kw[kp,c]      grad_kw[kp,c] += go[c] * sum_k w[kp,k] * f[nbr_k, c]
+// one wave per point; lanes first build w (KP x K) in LDS, then lane = channel.
+constexpr int KPB_MAXKP = 16, KPB_MAXK = 64;
+__global__ __launch_bounds__(256) void kpconv_bwd_kernel(int n, int n0, int K, int C, int KP, const float* __restrict__ q,
+                                                         const float* __restrict__ s, const int* __restrict__ idx, const float* __restrict__ f,
+                                                         const float* __restrict__ kpts, const float* __restrict__ kw, float extent,
+                                                         int influence, int closest, const float* __restrict__ go,
+                                                         float* __restrict__ gf, float* __restrict__ gkw)
+{
+    __shared__ float w_s[4][KPB_MAXKP * KPB_MAXK];
+    __shared__ int id_s[4][KPB_MAXK];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (gridDim.x * 256) >> 6;
+    float* W = w_s[wv]; int* ID = id_s[wv];
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const int c = c0 + lane;
+        const bool cok = c < C;
+        float kwr[KPB_MAXKP], gacc[KPB_MAXKP];
+#pragma unroll
+        for (int kp = 0; kp < KPB_MAXKP; kp++) { kwr[kp] = (cok && kp < KP) ? kw[(size_t)kp * C + c] : 0.f; gacc[kp] = 0.f; }
+        for (int p = wave0; p < n; p += nwaves) {
+            const float qx = q[3 * p], qy = q[3 * p + 1], qz = q[3 * p + 2];
+            // phase 1: neighbour ids and the influence matrix
+            for (int k = lane; k < K; k += 64) ID[k] = idx[(size_t)p * K + k];
+            for (int e = lane; e < KP * K; e += 64) {
+                const int kp = e / K, k = e - kp * K;
+                const int id = idx[(size_t)p * K + k];
+                const bool real = id >= 0 && id < n0;
+                const float rx = (real ? s[3 * id] : 1e6f) - qx, ry = (real ? s[3 * id + 1] : 1e6f) - qy, rz = (real ? s[3 * id + 2] : 1e6f) - qz;
+                const float dx = rx - kpts[3 * kp], dy = ry - kpts[3 * kp + 1], dz = rz - kpts[3 * kp + 2];
+                const float sq = (dx * dx + dy * dy) + dz * dz;
+                float w = influence ? fmaxf(1.0f - sqrtf(sq) / extent, 0.0f) : 1.0f;
+                if (closest) {
+                    for (int o = 0; o < KP; o++) {
+                        const float ex = rx - kpts[3 * o], ey = ry - kpts[3 * o + 1], ez = rz - kpts[3 * o + 2];
+                        const float osq = (ex * ex + ey * ey) + ez * ez;
+                        if (osq < sq || (osq == sq && o < kp)) { w = 0.f; break; }
+                    }
+                }
+                W[kp * K + k] = w;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): this wave's LDS writes have landed
+            __builtin_amdgcn_wave_barrier();               // and the compiler keeps the reads below after them
+            const float g = cok ? go[(size_t)p * C + c] : 0.f;
+            float wf[KPB_MAXKP];
+#pragma unroll
+            for (int kp = 0; kp < KPB_MAXKP; kp++) wf[kp] = 0.f;
+            for (int k = 0; k < K; k++) {
+                const int id = ID[k];
+                const bool real = id >= 0 && id < n0;
+                const float fk = (real && cok) ? f[(size_t)id * C + c] : 0.f;
+                float coef = 0.f;
+#pragma unroll
+                for (int kp = 0; kp < KPB_MAXKP; kp++) {
+                    const float w = (kp < KP) ? W[kp * K + k] : 0.f;
+                    wf[kp] += w * fk;
+                    coef += w * kwr[kp];
+                }
+                if (real && cok && gf) unsafeAtomicAdd(gf + (size_t)id * C + c, g * coef);
+            }
+#pragma unroll
+            for (int kp = 0; kp < KPB_MAXKP; kp++) gacc[kp] += g * wf[kp];
+        }
+        if (gkw && cok)
+            for (int kp = 0; kp < KP; kp++) unsafeAtomicAdd(gkw + (size_t)kp * C + c, gacc[kp]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- AdaptiveWeight
+// agg[p,c] = (1/nn[p]) * sum_k (rel[p,k,:] . fcw[:,c] + fcb[c]) * f[nbr_k, c],  rel = (s[nbr] - q[p]) / radius, shadow point = 0
+// nn[p] = #{k : idx[p,k] < max(idx)} + 1e-5  ("mean" reduction, :466-470);  reduction_mean = 0 -> plain sum
+__global__ __launch_bounds__(256) void index_max_kernel(long long total, const int* __restrict__ idx, int* __restrict__ out)
+{
+    int m = -2147483647 - 1;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) m = max(m, idx[e]);
+    for (int s = 32; s >= 1; s >>= 1) m = max(m, __shfl_xor(m, s));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void adaptive_weight_kernel(int n, int n0, int K, int C, const float* __restrict__ q, const float* __restrict__ s,
+                                                              const int* __restrict__ idx, const float* __restrict__ f, float radius,
+                                                              const float* __restrict__ fcw, const float* __restrict__ fcb,
+                                                              const int* __restrict__ padding_num, int reduction_mean,
+                                                              float* __restrict__ out,                       // forward
+                                                              const float* __restrict__ go, float* __restrict__ gf,
+                                                              float* __restrict__ gfcw, float* __restrict__ gfcb)   // backward
+{
+    const int lane = threadIdx.x & 63;
+    const int wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (gridDim.x * 256) >> 6;
+    const int pad = reduction_mean ? *padding_num : 0;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const int c = c0 + lane;
+        const bool cok = c < C;
+        const float w0 = cok ? fcw[c] : 0.f, w1 = cok ? fcw[C + c] : 0.f, w2 = cok ? fcw[2 * C + c] : 0.f, bb = cok ? fcb[c] : 0.f;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, ab = 0.f;                      // parameter gradients of this channel
+        for (int p = wave0; p < n; p += nwaves) {
+            const float qx = q[3 * p], qy = q[3 * p + 1], qz = q[3 * p + 2];
+            float nn = 1.f;
+            if (reduction_mean) {
+                int cnt = 0;
+                for (int k = lane; k < K; k += 64) cnt += idx[(size_t)p * K + k] < pad ? 1 : 0;
+                for (int sft = 32; sft >= 1; sft >>= 1) cnt += __shfl_xor(cnt, sft);
+                nn = (float)cnt + 1e-5f;
+            }
+            const float g = (BWD && cok) ? go[(size_t)p * C + c] / nn : 0.f;
+            float acc = 0.f;
+            for (int k = 0; k < K; k++) {
+                const int id = idx[(size_t)p * K + k];                      // wave-uniform
+                const bool real = id >= 0 && id < n0;
+                const float rx = ((real ? s[3 * id] : 0.f) - qx) / radius, ry = ((real ? s[3 * id + 1] : 0.f) - qy) / radius,
+                            rz = ((real ? s[3 * id + 2] : 0.f) - qz) / radius;                  // :369-373
+                const float w = ((rx * w0 + ry * w1) + rz * w2) + bb;                            // fc_1 with bias (:426-430)
+                const float fk = (real && cok) ? f[(size_t)id * C + c] : 0.f;
+                if (!BWD) acc += w * fk;                                                         // :457-464
+                else {
+                    if (real && cok && gf) unsafeAtomicAdd(gf + (size_t)id * C + c, g * w);
+                    const float gw = g * fk;
+                    a0 += gw * rx; a1 += gw * ry; a2 += gw * rz; ab += gw;
+                }
+            }
+            if (!BWD && cok) out[(size_t)p * C + c] = acc / nn;
+        }
+        if (BWD && cok) {
+            if (gfcw) { unsafeAtomicAdd(gfcw + c, a0); unsafeAtomicAdd(gfcw + C + c, a1); unsafeAtomicAdd(gfcw + 2 * C + c, a2); }
+            if (gfcb) unsafeAtomicAdd(gfcb + c, ab);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- index pooling
+__global__ __launch_bounds__(256) void column_min_kernel(int n, int d, const float* __restrict__ x, unsigned* __restrict__ keymin)
+{
+    // grid.y strides rows, threads cover columns; order-preserving integer keys so that atomicMin works on floats
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < d; c += gridDim.x * 256) {
+        float m = INFINITY;
+        for (int r = blockIdx.y; r < n; r += gridDim.y) m = fminf(m, x[(size_t)r * d + c]);
+        const unsigned u = __float_as_uint(m);
+        atomicMin(keymin + c, (u & 0x80000000u) ? ~u : (u | 0x80000000u));
+    }
+}
+__global__ __launch_bounds__(256) void ind_max_pool_kernel(int n1, int n2, int k, int d, const float* __restrict__ x, const int* __restrict__ inds,
+                                                           const unsigned* __restrict__ keymin, float* __restrict__ out)
+{
+    const long long total = (long long)n2 * d;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long r = e / d; const int c = (int)(e - r * d);
+        const unsigned key = keymin[c];
+        const float shadow = __uint_as_float((key & 0x80000000u) ? (key & 0x7fffffffu) : ~key);
+        float m = -INFINITY;
+        for (int j = 0; j < k; j++) {
+            const int id = inds[r * k + j];
+            m = fmaxf(m, (id >= 0 && id < n1) ? x[(size_t)id * d + c] : shadow);
+        }
+        out[e] = m;
+    }
+}
+__global__ __launch_bounds__(256) void ind_closest_pool_kernel(int n1, int n2, int k, int d, const float* __restrict__ x, const int* __restrict__ inds,
+                                                               float* __restrict__ out)
+{
+    const long long total = (long long)n2 * d;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long r = e / d; const int c = (int)(e - r * d);
+        const int id = inds[r * k];
+        out[e] = (id >= 0 && id < n1) ? x[(size_t)id * d + c] : 0.f;
+    }
+}
+__global__ void fill_u32_kernel(int n, unsigned v, unsigned* __restrict__ p) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
+
+inline unsigned persistent_grid(int n) { const long long waves = n; long long blocks = (waves + 3) / 4; if (blocks > 256 * 8) blocks = 256 * 8; if (blocks < 1) blocks = 1; return (unsigned)blocks; }
+
+}  // namespace
+
+CBL_EXPORT int cbl_kpconv_forward(int n, int n0, int K, int C, int KP, const float* query_points, const float* support_points, const int* neighbors_indices,
+                                  const float* features, const float* kernel_points, const float* kernel_weights, float extent, int influence, int closest,
+                                  float* out, void* stream)
+{
+    if (n < 0 || n0 < 0 || K <= 0 || C <= 0 || KP <= 0 || KP > 16 || !(extent > 0.f) || influence < 0 || influence > 1) return CBL_ERR_BAD_ARG;
+    if (n == 0) return CBL_OK;
+    if (!query_points || !support_points || !neighbors_indices || !features || !kernel_points || !kernel_weights || !out) return CBL_ERR_BAD_ARG;
+    hipStream_t st = cbl_stream(stream);
+    const dim3 grid(persistent_grid(n)), block(256);
+    if (C > 32) hipLaunchKernelGGL(kpconv_fwd_kernel<4>, grid, block, 0, st, n, n0, K, C, KP, query_points, support_points, neighbors_indices, features, kernel_points, kernel_weights, extent, influence, closest, out);
+    else if (C > 16) hipLaunchKernelGGL(kpconv_fwd_kernel<2>, grid, block, 0, st, n, n0, K, C, KP, query_points, support_points, neighbors_indices, features, kernel_points, kernel_weights, extent, influence, closest, out);
+    else hipLaunchKernelGGL(kpconv_fwd_kernel<1>, grid, block, 0, st, n, n0, K, C, KP, query_points, support_points, neighbors_indices, features, kernel_points, kernel_weights, extent, influence, closest, out);
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_kpconv_backward(int n, int n0, int K, int C, int KP, const float* query_points, const float* support_points, const int* neighbors_indices,
+                                   const float* features, const float* kernel_points, const float* kernel_weights, float extent, int influence, int closest,
+                                   const float* grad_out, float* grad_features, float* grad_kernel_weights, void* stream)
+{
+    if (n < 0 || n0 < 0 || K <= 0 || K > KPB_MAXK || C <= 0 || KP <= 0 || KP > KPB_MAXKP || !(extent > 0.f) || influence < 0 || influence > 1) return CBL_ERR_BAD_ARG;
+    if (n == 0) return CBL_OK;
+    if (!query_points || !support_points || !neighbors_indices || !features || !kernel_points || !kernel_weights || !grad_out) return CBL_ERR_BAD_ARG;
+    hipLaunchKernelGGL(kpconv_bwd_kernel, dim3(persistent_grid(n)), dim3(256), 0, cbl_stream(stream), n, n0, K, C, KP, query_points, support_points, neighbors_indices,
+                       features, kernel_points, kernel_weights, extent, influence, closest, grad_out, grad_features, grad_kernel_weights);
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_index_max(long long total, const int* idx, int* out_max, void* stream)
+{
+    if (total <= 0 || !idx || !out_max) return CBL_ERR_BAD_ARG;
+    hipStream_t st = cbl_stream(stream);
+    hipLaunchKernelGGL(fill_u32_kernel, dim3(1), dim3(64), 0, st, 1, 0x80000000u, reinterpret_cast<unsigned*>(out_max));   // INT_MIN
+    hipLaunchKernelGGL(index_max_kernel, dim3(cbl_grid_for(total, 256, 1024)), dim3(256), 0, st, total, idx, out_max);
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_adaptive_weight_forward(int n, int n0, int K, int C, const float* query_points, const float* support_points, const int* neighbors_indices,
+                                           const float* features, float radius, const float* fc_weight, const float* fc_bias, const int* padding_num,
+                                           int reduction_mean, float* out, void* stream)
+{
+    if (n < 0 || n0 < 0 || K <= 0 || C <= 0 || !(radius > 0.f)) return CBL_ERR_BAD_ARG;
+    if (n == 0) return CBL_OK;
+    if (!query_points || !support_points || !neighbors_indices || !features || !fc_weight || !fc_bias || !out || (reduction_mean && !padding_num)) return CBL_ERR_BAD_ARG;
+    hipLaunchKernelGGL(adaptive_weight_kernel<false>, dim3(persistent_grid(n)), dim3(256), 0, cbl_stream(stream), n, n0, K, C, query_points, support_points,
+                       neighbors_indices, features, radius, fc_weight, fc_bias, padding_num, reduction_mean, out, nullptr, nullptr, nullptr, nullptr);
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_adaptive_weight_backward(int n, int n0, int K, int C, const float* query_points, const float* support_points, const int* neighbors_indices,
+                                            const float* features, float radius, const float* fc_weight, const float* fc_bias, const int* padding_num,
+                                            int reduction_mean, const float* grad_out, float* grad_features, float* grad_fc_weight, float* grad_fc_bias, void* stream)
+{
+    if (n < 0 || n0 < 0 || K <= 0 || C <= 0 || !(radius > 0.f)) return CBL_ERR_BAD_ARG;
+    if (n == 0) return CBL_OK;
+    if (!query_points || !support_points || !neighbors_indices || !features || !fc_weight || !fc_bias || !grad_out || (reduction_mean && !padding_num)) return CBL_ERR_BAD_ARG;
+    hipLaunchKernelGGL(adaptive_weight_kernel<true>, dim3(persistent_grid(n)), dim3(256), 0, cbl_stream(stream), n, n0, K, C, query_points, support_points,
+                       neighbors_indices, features, radius, fc_weight, fc_bias, padding_num, reduction_mean, nullptr, grad_out, grad_features, grad_fc_weight, grad_fc_bias);
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_ind_max_pool(int n1, int n2, int k, int d, const float* x, const int* inds, unsigned* scratch_d, float* out, void* stream)
+{
+    if (n1 <= 0 || n2 < 0 || k <= 0 || d <= 0) return CBL_ERR_BAD_ARG;
+    if (n2 == 0) return CBL_OK;
+    if (!x || !inds || !scratch_d || !out) return CBL_ERR_BAD_ARG;
+    hipStream_t st = cbl_stream(stream);
+    hipLaunchKernelGGL(fill_u32_kernel, dim3(cbl_div_up(d, 256)), dim3(256), 0, st, d, 0xffffffffu, scratch_d);
+    hipLaunchKernelGGL(column_min_kernel, dim3(cbl_div_up(d, 256), (unsigned)min(n1, 512)), dim3(256), 0, st, n1, d, x, scratch_d);
+    hipLaunchKernelGGL(ind_max_pool_kernel, dim3(cbl_grid_for((long long)n2 * d, 256)), dim3(256), 0, st, n1, n2, k, d, x, inds, scratch_d, out);
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_ind_closest_pool(int n1, int n2, int k, int d, const float* x, const int* inds, float* out, void* stream)
+{
+    if (n1 < 0 || n2 < 0 || k <= 0 || d <= 0) return CBL_ERR_BAD_ARG;
+    if (n2 == 0) return CBL_OK;
+    if (!x || !inds || !out) return CBL_ERR_BAD_ARG;
+    hipLaunchKernelGGL(ind_closest_pool_kernel, dim3(cbl_grid_for((long long)n2 * d, 256)), dim3(256), 0, cbl_stream(stream), n1, n2, k, d, x, inds, out);
+    return cbl_status();
+}

@@ -6,7 +6,11 @@ Each stage is one or a few C-ABI launches on the current stream; `stages()` list
 """
 import torch
 
-from . import pointops
+from . import heads, local_aggregation, pointops
+
+KP = 15                 # kernel points of the KPConv stage (KPConv's default 15; rigid kernel generator absent from the reference)
+CBL_NSAMPLE = 36        # nsample[0] of the shipped CBL config (config/s3dis/origin_multi-...yaml:57)
+CBL_DIM = 32            # latent width the CBL head works on (base_fdim)
 
 
 class Scene:
@@ -17,15 +21,26 @@ class Scene:
         self.n, self.c = feat.shape
 
     @staticmethod
-    def synthetic(n, c, seed=0, b=1, device="cuda"):
+    def synthetic_numpy(n, c, seed=0, b=1):
+        """host arrays: xyz, feat, labels, offset, kernel_points (KP,3), kernel_weights (KP,c), latent (n,CBL_DIM)"""
         import numpy as np
         from . import synthetic as S
         xyz, labels = S.s_room(n, seed)
         rng = np.random.default_rng(seed + 1000)
         feat = rng.normal(size=(n, c)).astype(np.float32)
         off = S.offsets(n, b, seed)
-        t = lambda a: torch.from_numpy(a).to(device)
-        return Scene(t(xyz), t(feat), t(labels), t(off))
+        kpts = (rng.normal(size=(KP, 3)) * 0.06).astype(np.float32); kpts[0] = 0
+        kw = (rng.normal(size=(KP, c)) / np.sqrt(KP)).astype(np.float32)
+        latent = rng.normal(size=(n, CBL_DIM)).astype(np.float32)
+        return dict(xyz=xyz, feat=feat, labels=labels, offset=off, kernel_points=kpts, kernel_weights=kw, latent=latent)
+
+    @staticmethod
+    def synthetic(n, c, seed=0, b=1, device="cuda"):
+        a = Scene.synthetic_numpy(n, c, seed, b)
+        t = lambda v: torch.from_numpy(v).to(device)
+        sc = Scene(t(a["xyz"]), t(a["feat"]), t(a["labels"]), t(a["offset"]))
+        sc.kernel_points, sc.kernel_weights, sc.latent = t(a["kernel_points"]), t(a["kernel_weights"]), t(a["latent"])
+        return sc
 
 
 def stages(scene, k=16):
@@ -42,6 +57,25 @@ def stages(scene, k=16):
         s["grouped"] = pointops.queryandgroup(k, scene.xyz, scene.xyz, scene.feat, s["idx"], scene.offset, scene.offset, use_xyz=True)
     # a3 fused queryandgroup: 4mK + 12n + 12m + 4nC + 4mK(3+C)
     st.append(("queryandgroup", group, 4 * n * k + 12 * n + 12 * n + 4 * n * c + 4 * n * k * (3 + c), 3.0 * n * k))
+
+    extent = 0.12      # KP_extent 1.0 * radius 0.1*... / density (local_aggregation_operators.py:664); ~ the K=16 neighbourhood radius here
+
+    def kpconv(s):
+        s["kpconv"] = local_aggregation.kpconv(scene.xyz, scene.xyz, s["idx"], scene.feat, scene.kernel_points, scene.kernel_weights, extent)
+    # a15 (idx given): 12n + 12n0 + 4n0C + 4nK + 4nC bytes; flops 2nK*KP*(C + 6) + 2n*KP*C  
+    st.append(("kpconv_fwd", kpconv, 12 * n + 12 * n + 4 * n * c + 4 * n * k + 4 * n * c, 2.0 * n * k * KP * (c + 6) + 2.0 * n * KP * c))
+
+    def cbl(s):
+        # the CBL head of stage 0 (heads.py:185-246): its own KNN (nsample = 36), pair mining + soft-NN loss, backward to the latent
+        latent = scene.latent.detach().requires_grad_(True)
+        nidx, _ = pointops.knnquery_raw(CBL_NSAMPLE, scene.xyz, scene.xyz, scene.offset, scene.offset)
+        loss = heads.point_contrast(latent, scene.labels, nidx, 1.0, 0.1)
+        loss.backward()
+        s["cbl_loss"], s["cbl_grad"] = loss.detach(), latent.grad
+    d = CBL_DIM
+    # a8 mining (idx given) 4n(K-1) + 4nd + 4n fwd, the same again + 4nd written bwd; + the K=36 KNN's compulsory 24n + 8n*36
+    st.append(("cbl_head_fwd_bwd", cbl, 2 * (4 * n * (CBL_NSAMPLE - 1) + 4 * n * d + 4 * n) + 4 * n * d + 24 * n + 8 * n * CBL_NSAMPLE,
+               2.0 * n * (CBL_NSAMPLE - 1) * (3 * d + 20)))
     return st
 
 

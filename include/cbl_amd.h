@@ -143,6 +143,43 @@ int cbl_point_contrast_backward(int m, int nsample, int d, const float* features
  *   cnt (n) i32 [number of differing valid neighbours]; any output may be NULL */
 int cbl_boundary_mask(int n, int k, const long long* labels, const int* neighbor_idx, unsigned char* bound, unsigned char* plain, int* cnt, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * TF-side local aggregation over radius neighbourhoods (index == n0 selects the shadow / padding row)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* a15  PseudoGrid = KPConv, depthwise  tensorflow/models/local_aggregation_operators.py:620-746 (math :681-728)
+ *   query_points (n,3), support_points (n0,3), neighbors_indices (n,K) i32 (pad = n0), features (n0,C),
+ *   kernel_points (KP,3) [KP <= 16; their generator create_kernel_points is absent from the reference: an input here],
+ *   kernel_weights (KP,C), extent = KP_extent*radius/density_parameter (:664), influence 0 'constant' | 1 'linear' (:691-699),
+ *   closest 0 'sum' | 1 'closest' (:705-708)  ->  out (n,C) = sum_kp kernel_weights[kp] * (w[kp,:] @ features[nbrs])  (before bn/act)
+ *   The (KP x K)·(K x C) contraction runs on the matrix cores (v_mfma_f32_16x16x4_f32, exact f32). */
+int cbl_kpconv_forward(int n, int n0, int K, int C, int KP, const float* query_points, const float* support_points, const int* neighbors_indices,
+                       const float* features, const float* kernel_points, const float* kernel_weights, float extent, int influence, int closest,
+                       float* out, void* stream);
+/* gradients w.r.t. features (n0,C) += and kernel_weights (KP,C) += (caller pre-zeroes; either may be NULL); K <= 64 */
+int cbl_kpconv_backward(int n, int n0, int K, int C, int KP, const float* query_points, const float* support_points, const int* neighbors_indices,
+                        const float* features, const float* kernel_points, const float* kernel_weights, float extent, int influence, int closest,
+                        const float* grad_out, float* grad_features, float* grad_kernel_weights, void* stream);
+
+/* a14  AdaptiveWeight  tensorflow/models/local_aggregation_operators.py:316-500 with the shipped options
+ *   (config/s3dis/adapt.yaml:19-26: local_input_feature 'dp', fc_num 1, shared_channels 1, no softmax):
+ *   w[p,k,:] = ((support[nbr]-query[p])/radius) @ fc_weight (3,C) + fc_bias (C);  out[p,:] = sum_k w[p,k,:]*features[nbr]  (/ nn[p] if reduction_mean)
+ *   nn[p] = #{k: idx[p,k] < *padding_num} + 1e-5 with *padding_num = max over ALL of neighbors_indices (:466-470) — cbl_index_max computes it. */
+int cbl_index_max(long long total, const int* idx, int* out_max, void* stream);
+int cbl_adaptive_weight_forward(int n, int n0, int K, int C, const float* query_points, const float* support_points, const int* neighbors_indices,
+                                const float* features, float radius, const float* fc_weight, const float* fc_bias, const int* padding_num,
+                                int reduction_mean, float* out, void* stream);
+/* gradients: features (n0,C) +=, fc_weight (3,C) +=, fc_bias (C) +=  (caller pre-zeroes; any may be NULL) */
+int cbl_adaptive_weight_backward(int n, int n0, int K, int C, const float* query_points, const float* support_points, const int* neighbors_indices,
+                                 const float* features, float radius, const float* fc_weight, const float* fc_bias, const int* padding_num,
+                                 int reduction_mean, const float* grad_out, float* grad_features, float* grad_fc_weight, float* grad_fc_bias, void* stream);
+
+/* ind_max_pool / ind_closest_pool  tensorflow/models/basic_operators.py:155-172 / :175-192
+ *   x (n1,d), inds (n2,k) i32 (pad = n1) -> out (n2,d): max over the row's entries (shadow row = column-wise min of x; scratch_d (d) u32)
+ *   / the entry of the FIRST column (shadow row = 0) */
+int cbl_ind_max_pool(int n1, int n2, int k, int d, const float* x, const int* inds, unsigned* scratch_d, float* out, void* stream);
+int cbl_ind_closest_pool(int n1, int n2, int k, int d, const float* x, const int* inds, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,102 @@
+"""GPU parity: KPConv (MFMA) / AdaptiveWeight / index pooling vs the numpy restatement of the TF graph code
+(oracle/local_aggregation_oracle.py; parity unpinned by execution — TF absent).  Tolerance 1e-4 (north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import local_aggregation_oracle as LA
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def make(n0, n, K, C, seed, pad_frac=0.2):
+    rng = np.random.default_rng(seed)
+    s = rng.uniform(0, 1, (n0, 3)).astype(np.float32)
+    q = s[rng.choice(n0, n, replace=False)] + rng.normal(0, 0.01, (n, 3)).astype(np.float32)
+    idx = rng.integers(0, n0, (n, K)).astype(np.int32)
+    # neighbours close to the query so that the linear influence is non-trivial + trailing shadow (== n0) padding like the radius search
+    d = ((s[None, :, :] - q[:, None, :]) ** 2).sum(-1)
+    idx = np.argsort(d, 1)[:, :K].astype(np.int32)
+    npad = rng.integers(0, int(K * pad_frac) + 1, n)
+    for i in range(n):
+        if npad[i]:
+            idx[i, K - npad[i]:] = n0
+    f = rng.normal(size=(n0, C)).astype(np.float32)
+    return q.astype(np.float32), s, idx, f, rng
+
+
+@pytest.mark.parametrize("K,C,KP,influence,mode", [(16, 64, 15, "linear", "sum"), (26, 72, 15, "linear", "sum"), (9, 16, 7, "linear", "closest"),
+                                                   (31, 144, 15, "constant", "sum"), (5, 20, 16, "linear", "sum")])
+def test_kpconv(K, C, KP, influence, mode):
+    from contrastboundary_amd import local_aggregation as L
+    q, s, idx, f, rng = make(700, 300, K, C, seed=K)
+    kpts = (rng.normal(size=(KP, 3)) * 0.06).astype(np.float32); kpts[0] = 0
+    kw = rng.normal(size=(KP, C)).astype(np.float32)
+    extent = 0.09
+    ft = dev(f).requires_grad_(True); kwt = dev(kw).requires_grad_(True)
+    out = L.kpconv(dev(q), dev(s), dev(idx), ft, dev(kpts), kwt, extent, influence, mode)
+    ref = LA.kpconv(q, s, idx, f, kpts, kw, extent, influence, mode)
+    scale = np.abs(ref).max()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * scale)
+    go = rng.normal(size=ref.shape).astype(np.float32)
+    out.backward(dev(go))
+    gf, gkw = LA.kpconv_grads(q, s, idx, f, kpts, kw, extent, go, influence, mode)
+    np.testing.assert_allclose(ft.grad.cpu().numpy(), gf, rtol=1e-3, atol=1e-4 * np.abs(gf).max())
+    np.testing.assert_allclose(kwt.grad.cpu().numpy(), gkw, rtol=1e-3, atol=1e-4 * np.abs(gkw).max())
+
+
+@pytest.mark.parametrize("K,C,reduction", [(26, 72, "mean"), (16, 64, "mean"), (41, 100, "sum")])
+def test_adaptive_weight(K, C, reduction):
+    from contrastboundary_amd import local_aggregation as L
+    q, s, idx, f, rng = make(900, 400, K, C, seed=C)
+    W = (rng.normal(size=(3, C)) * 0.5).astype(np.float32); b = rng.normal(size=(C,)).astype(np.float32)
+    radius = 0.1
+    ft = dev(f).requires_grad_(True); Wt = dev(W).requires_grad_(True); bt = dev(b).requires_grad_(True)
+    out = L.adaptive_weight(dev(q), dev(s), dev(idx), ft, radius, Wt, bt, reduction)
+    ref = LA.adaptive_weight(q, s, idx, f, radius, W, b, reduction)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+    go = rng.normal(size=ref.shape).astype(np.float32)
+    out.backward(dev(go))
+    gf, gW, gb = LA.adaptive_weight_grads(q, s, idx, f, radius, W, b, go, reduction)
+    np.testing.assert_allclose(ft.grad.cpu().numpy(), gf, rtol=1e-3, atol=1e-4 * np.abs(gf).max())
+    np.testing.assert_allclose(Wt.grad.cpu().numpy(), gW, rtol=1e-3, atol=1e-4 * np.abs(gW).max())
+    np.testing.assert_allclose(bt.grad.cpu().numpy(), gb, rtol=1e-3, atol=1e-4 * np.abs(gb).max())
+
+
+def test_adaptive_weight_mean_quirk_without_padding():
+    # no row is padded -> padding_num = max(idx) is a REAL index and rows containing it count one neighbour less (:466-470)
+    from contrastboundary_amd import local_aggregation as L
+    q, s, idx, f, rng = make(300, 100, 8, 16, seed=1, pad_frac=0.0)
+    W = rng.normal(size=(3, 16)).astype(np.float32); b = rng.normal(size=(16,)).astype(np.float32)
+    out = L.adaptive_weight(dev(q), dev(s), dev(idx), dev(f), 0.2, dev(W), dev(b), "mean")
+    np.testing.assert_allclose(out.cpu().numpy(), LA.adaptive_weight(q, s, idx, f, 0.2, W, b, "mean"), rtol=1e-4, atol=1e-5)
+
+
+def test_index_pooling():
+    from contrastboundary_amd import local_aggregation as L
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(500, 37)).astype(np.float32)
+    inds = rng.integers(0, 501, (200, 9)).astype(np.int32)          # 500 == shadow
+    inds[0, :] = 500
+    np.testing.assert_array_equal(L.ind_max_pool(dev(x), dev(inds)).cpu().numpy(), LA.ind_max_pool(x, inds))
+    np.testing.assert_array_equal(L.ind_closest_pool(dev(x), dev(inds)).cpu().numpy(), LA.ind_closest_pool(x, inds))
+
+
+def test_kpconv_full_size_linearity():
+    """C2 size: KPConv is linear in the features and in the kernel weights"""
+    from contrastboundary_amd import hotpath, local_aggregation as L, pointops
+    sc = hotpath.Scene.synthetic(40960, 64, seed=0)
+    idx, _ = pointops.knnquery_raw(16, sc.xyz, sc.xyz, sc.offset, sc.offset)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    kpts = torch.randn(15, 3, device="cuda", generator=g) * 0.06
+    kw = torch.randn(15, 64, device="cuda", generator=g)
+    f2 = torch.randn(40960, 64, device="cuda", generator=g)
+    a = L.kpconv(sc.xyz, sc.xyz, idx, sc.feat, kpts, kw, 0.12)
+    b = L.kpconv(sc.xyz, sc.xyz, idx, f2, kpts, kw, 0.12)
+    ab = L.kpconv(sc.xyz, sc.xyz, idx, sc.feat + 2 * f2, kpts, kw, 0.12)
+    assert torch.allclose(ab, a + 2 * b, rtol=1e-4, atol=1e-3)
+    assert torch.isfinite(a).all() and float(a.abs().max()) > 0
