@@ -57,7 +57,8 @@ def get_boundary_mask(labels, neighbor_label=None, neighbor_idx=None, valid_mask
         b8 = torch.empty(n, dtype=torch.uint8, device=labels.device)
         p8 = torch.empty(n, dtype=torch.uint8, device=labels.device)
         cnt = torch.empty(n, dtype=torch.int32, device=labels.device)
-        _lib.check(_lib.lib().cbl_boundary_mask(_c_int(n), _c_int(k), _lib.ptr(labels.contiguous()), _lib.ptr(neighbor_idx.contiguous()),
+        labels_c, nidx_c = labels.contiguous(), neighbor_idx.contiguous()      # named: both must outlive the call (see tf_ops.py)
+        _lib.check(_lib.lib().cbl_boundary_mask(_c_int(n), _c_int(k), _lib.ptr(labels_c), _lib.ptr(nidx_c),
                                                 _lib.ptr(b8), _lib.ptr(p8), _lib.ptr(cnt), _lib.stream_of(labels)), "cbl_boundary_mask")
         bound = cnt.long() if get_cnt else b8.bool()
         plain = p8.bool()

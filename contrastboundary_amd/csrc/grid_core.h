@@ -62,6 +62,26 @@ CBL_HD void cbl_grid_choose(CblGrid& g, const float lo[3], const float hi[3], in
     g.nx = nx; g.ny = ny; g.nz = nz;
 }
 
+// Grid for a RADIUS search: cell edge = 1.001 * radius (enlarged only if the cell budget `cap` is exceeded), so every support
+// within `radius` of a query lies in the 27-cell block around the query's cell: a true axis offset < radius is < 0.999 cells,
+// and the two u values carry < 2.5e-4 cells of rounding (|u| <= ~1030), so the floor()ed cell coordinates differ by at most 1.
+CBL_HD void cbl_grid_choose_radius(CblGrid& g, const float lo[3], const float hi[3], float radius, int cap)
+{
+    const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+    float emax = fmaxf(ex, fmaxf(ey, ez));
+    if (!(emax > 0.f)) emax = 1.f;
+    float cs = fmaxf(radius * 1.001f, emax * (1.0f / 1024.0f));
+    int nx, ny, nz;
+    for (int it = 0; it < 200; it++) {
+        nx = (int)floorf(ex / cs) + 1; ny = (int)floorf(ey / cs) + 1; nz = (int)floorf(ez / cs) + 1;
+        if ((long long)nx * ny * nz <= (long long)cap) break;
+        cs *= 1.1f;
+    }
+    g.ox = lo[0]; g.oy = lo[1]; g.oz = lo[2];
+    g.inv_cs = 1.0f / cs;
+    g.nx = nx; g.ny = ny; g.nz = nz;
+}
+
 CBL_HD int cbl_cell_of(const CblGrid& g, float x, float y, float z)
 {
     const int cx = cbl_cell_coord(cbl_u(x, g.ox, g.inv_cs), g.nx);

@@ -108,7 +108,9 @@ __global__ void grid_setup_kernel(int b, float pts_per_cell, const int* __restri
     if (end > start)
         for (int a = 0; a < 3; a++) { l[a] = key2f(bbox[c * 6 + a]); h[a] = key2f(bbox[c * 6 + 3 + a]); }
     CblGrid g;
-    cbl_grid_choose(g, l, h, end - start, pts_per_cell, CELLS_PER_POINT * (end - start) + CELLS_PER_CLOUD);
+    const int cap = CELLS_PER_POINT * (end - start) + CELLS_PER_CLOUD;
+    if (pts_per_cell < 0.f) cbl_grid_choose_radius(g, l, h, -pts_per_cell, cap);      // radius search: cell edge ~ radius
+    else cbl_grid_choose(g, l, h, end - start, pts_per_cell, cap);
     g.cell_base = CELLS_PER_POINT * start + CELLS_PER_CLOUD * c;
     g.start = start; g.end = end; g.pad0 = g.pad1 = 0;
     grids[c] = g;
@@ -200,8 +202,10 @@ template <int G> __device__ __forceinline__ int dpp_shr1_i(int v);
 // row / wave keeps `old` (= its own value, masked out by the caller)
 template <> __device__ __forceinline__ int dpp_shr1_i<16>(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false); }
 template <> __device__ __forceinline__ int dpp_shr1_i<64>(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
+template <> __device__ __forceinline__ int dpp_shr1_i<32>(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }   // lane 32 receives lane 31: masked by gl > 0
 template <> __device__ __forceinline__ float dpp_shr1_f<16>(float v) { return __int_as_float(dpp_shr1_i<16>(__float_as_int(v))); }
 template <> __device__ __forceinline__ float dpp_shr1_f<64>(float v) { return __int_as_float(dpp_shr1_i<64>(__float_as_int(v))); }
+template <> __device__ __forceinline__ float dpp_shr1_f<32>(float v) { return __int_as_float(dpp_shr1_i<32>(__float_as_int(v))); }
 
 template <int G, bool SELF>
 __global__ __launch_bounds__(256) void knn_grid_group_kernel(int b, int m, int K, const float* __restrict__ new_xyz,
@@ -310,9 +314,87 @@ void launch_query(bool self, int b, int m, int K, const float* new_xyz, const in
     else      hipLaunchKernelGGL((knn_grid_group_kernel<G, false>), grid, block, 0, st, b, m, K, new_xyz, offset, new_offset, w.grids, w.cell_start, w.sorted, idx, dist2, w.worklist, w.counters);
 }
 
+
+// ---- N2: sorted radius neighbours, cropped to `limit` and padded with Ns -------------------------------------------
+// Replaces batch_nanoflann_neighbors (tensorflow/ops/tf_custom_ops/tf_neighbors/neighbors/neighbors.cpp:213-336) plus the
+// callers' crop to neighborhood_limits (tensorflow/datasets/base.py:756-765).  Same group-per-query structure as the KNN
+// kernel: the group keeps the `limit` nearest candidates with d2 < r^2 (strict, nanoflann.hpp:249-253) in ascending
+// (d2, index) order; one pass over the 27-cell block suffices because the grid's cell edge is >= radius
+// (cbl_grid_choose_radius).  counts[q] = true number of supports inside the ball (the reference's row length before padding).
+template <int G>
+__global__ __launch_bounds__(256) void radius_group_kernel(int b, int nq, int ns_total, int limit, float r2, const float* __restrict__ queries,
+                                                           const int* __restrict__ q_offset, const CblGrid* __restrict__ grids,
+                                                           const int* __restrict__ cell_start, const float4* __restrict__ sorted,
+                                                           int* __restrict__ out, int* __restrict__ counts, int* __restrict__ max_count)
+{
+    constexpr int QPW = 64 / G;
+    using mask_t = unsigned long long;
+    const int lane = threadIdx.x & 63, gl = lane & (G - 1), grp = lane / G;
+    const int wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int t = wave_global * QPW + grp;
+    const bool live = t < nq;
+    const int q = live ? t : nq - 1;
+    const float qx = queries[3 * q], qy = queries[3 * q + 1], qz = queries[3 * q + 2];
+    const int c = cbl_cloud_of(q, q_offset, b);
+    const CblGrid g = grids[c];
+    const int cx = cbl_cell_coord(cbl_u(qx, g.ox, g.inv_cs), g.nx), cy = cbl_cell_coord(cbl_u(qy, g.oy, g.inv_cs), g.ny),
+              cz = cbl_cell_coord(cbl_u(qz, g.oz, g.inv_cs), g.nz);
+    float ed = INFINITY; int ei = 0x7fffffff;
+    int inside = 0;
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+    for (int dz = -1; dz <= 1; dz++) {
+        for (int dy = -1; dy <= 1; dy++) {
+            const int y = cy + dy, z = cz + dz;
+            int s = 0, e = 0;
+            if (live && g.end > g.start && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
+                const int row = g.cell_base + g.nx * (y + g.ny * z);
+                s = cell_start[row + x0]; e = cell_start[row + x1 + 1];
+            }
+            for (int p = s; __any(p < e); p += G) {
+                const int pi = p + gl;
+                float d2 = INFINITY; int ci = 0x7fffffff;
+                if (pi < e) {
+                    const float4 v = sorted[pi];
+                    d2 = cbl_dist2(qx, qy, qz, v.x, v.y, v.z);       // (query - support)^2 summed over x,y,z like L2_Simple_Adaptor
+                    ci = __float_as_int(v.w);
+                }
+                const bool in_ball = d2 < r2;
+                inside += in_ball ? 1 : 0;
+                const float wd = __shfl(ed, limit - 1, G); const int wi = __shfl(ei, limit - 1, G);
+                const bool pass = in_ball && (d2 < wd || (d2 == wd && ci < wi));
+                mask_t gm = (__ballot(pass) >> (grp * G)) & (G == 64 ? ~0ull : ((1ull << G) - 1ull));
+                while (__any(gm != 0)) {
+                    const bool has = gm != 0;
+                    const int l = has ? __builtin_ctzll(gm) : 0;
+                    gm &= gm - 1;
+                    float dc = __shfl(d2, l, G); const int ic = __shfl(ci, l, G);
+                    if (!has) dc = INFINITY;
+                    const float pd = dpp_shr1_f<G>(ed); const int pidx = dpp_shr1_i<G>(ei);
+                    const bool gt = has && (ed > dc || (ed == dc && ei > ic));           // canonical (d2, index) order
+                    const bool left_gt = (gl > 0) && (pd > dc || (pd == dc && pidx > ic));
+                    if (gt) { if (left_gt) { ed = pd; ei = pidx; } else { ed = dc; ei = ic; } }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int s = G / 2; s >= 1; s >>= 1) inside += __shfl_xor(inside, s, G);
+    if (live) {
+        if (gl < limit) out[(size_t)q * limit + gl] = (ed < INFINITY) ? ei : ns_total;     // pad with supports.size(), neighbors.cpp:328
+        if (gl == 0) { if (counts) counts[q] = inside; atomicMax(max_count, inside); }
+    }
+}
+
 }  // namespace
 
 // build the per-cloud grids + cell-sorted supports into the workspace (shared with the radius search)
+// per-cloud bounding boxes as order-preserving keys (bbox pre-set to 0xffffffff / 0 by the caller); shared with tfops.hip
+int cbl_bbox_keys_launch(int b, int n, const float* xyz, const int* offset, unsigned* bbox, hipStream_t st)
+{
+    hipLaunchKernelGGL(grid_bbox_kernel, dim3(cbl_grid_for(n, 1024, 512)), dim3(256), 0, st, b, n, xyz, offset, bbox);
+    return cbl_status();
+}
+
 __global__ void grid_init_kernel(int b, int* __restrict__ counters, unsigned* __restrict__ bbox)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -349,16 +431,39 @@ int cbl_knn_grid_launch(int b, int n, int m, int nsample, const float* xyz, cons
 {
     Workspace w = carve(ws, b, n, m);
     if (ws_bytes < w.bytes) return CBL_ERR_WORKSPACE;
-    const int G = nsample <= 16 ? 16 : 64;
+    const int G = nsample <= 16 ? 16 : nsample <= 32 ? 32 : 64;
     // ~0.42*K points per cell if the cloud filled its bbox: the K-th neighbour is then usually inside the 27-cell block
     int rc = cbl_grid_build(b, n, 0.42f * (float)(nsample < 4 ? 4 : nsample), xyz, offset, ws, st);
     if (rc) return rc;
     const bool self = (new_xyz == xyz) && (m == n);
-    if (G == 16) launch_query<16>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, st);
-    else         launch_query<64>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, st);
+    if (G == 16)      launch_query<16>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, st);
+    else if (G == 32) launch_query<32>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, st);
+    else              launch_query<64>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, st);
     rc = cbl_status();
     if (rc) return rc;
     // exact replay of everything that was not certified (device-side count, no host sync)
     return cbl_knn_exact_worklist(b, m, nsample, xyz, new_xyz, self ? offset : offset, self ? offset : new_offset, idx, dist2,
                                   w.worklist, w.counters, m, st);
+}
+
+// N2 entry: queries (nq,3) with cumulative q_offset (b), supports (ns,3) with cumulative s_offset (b).
+size_t cbl_radius_workspace_bytes_impl(int b, int ns) { return (b > 0 && ns >= 0) ? carve(nullptr, b, ns, 0).bytes : 0; }
+
+int cbl_radius_launch(int b, int nq, int ns, const float* queries, const float* supports, const int* q_offset, const int* s_offset,
+                      float radius, int limit, int* out, int* counts, int* max_count, void* ws, size_t ws_bytes, hipStream_t st)
+{
+    Workspace w = carve(ws, b, ns, 0);
+    if (ws_bytes < w.bytes) return CBL_ERR_WORKSPACE;
+    int rc = cbl_grid_build(b, ns, -radius, supports, s_offset, ws, st);
+    if (rc) return rc;
+    hipError_t e = hipMemsetAsync(max_count, 0, sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
+    const int G = limit <= 16 ? 16 : limit <= 32 ? 32 : 64;
+    const long long waves = ((long long)nq + (64 / G) - 1) / (64 / G);
+    const dim3 grid(cbl_div_up(waves, 4)), block(256);
+    const float r2 = radius * radius;                               // neighbors.cpp:230
+    if (G == 16)      hipLaunchKernelGGL(radius_group_kernel<16>, grid, block, 0, st, b, nq, ns, limit, r2, queries, q_offset, w.grids, w.cell_start, w.sorted, out, counts, max_count);
+    else if (G == 32) hipLaunchKernelGGL(radius_group_kernel<32>, grid, block, 0, st, b, nq, ns, limit, r2, queries, q_offset, w.grids, w.cell_start, w.sorted, out, counts, max_count);
+    else              hipLaunchKernelGGL(radius_group_kernel<64>, grid, block, 0, st, b, nq, ns, limit, r2, queries, q_offset, w.grids, w.cell_start, w.sorted, out, counts, max_count);
+    return cbl_status();
 }

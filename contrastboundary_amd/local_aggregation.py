@@ -42,10 +42,11 @@ class _KPConv(Function):
         extent, influence, closest = ctx.cfg
         n, K = idx.shape
         n0, C = f.shape
+        grad_out = grad_out.contiguous()
         gf = torch.zeros_like(f) if ctx.needs_input_grad[3] else None
         gkw = torch.zeros_like(kw) if ctx.needs_input_grad[5] else None
         _lib.check(_lib.lib().cbl_kpconv_backward(_i(n), _i(n0), _i(K), _i(C), _i(kp.shape[0]), _lib.ptr(q), _lib.ptr(s), _lib.ptr(idx), _lib.ptr(f),
-                                                  _lib.ptr(kp), _lib.ptr(kw), _f(extent), _i(influence), _i(closest), _lib.ptr(grad_out.contiguous()),
+                                                  _lib.ptr(kp), _lib.ptr(kw), _f(extent), _i(influence), _i(closest), _lib.ptr(grad_out),
                                                   _lib.ptr(gf), _lib.ptr(gkw), _lib.stream_of(f)), "cbl_kpconv_backward")
         return None, None, None, gf, None, gkw, None, None, None
 
@@ -88,11 +89,12 @@ class _AdaptiveWeight(Function):
         radius, reduction_mean = ctx.cfg
         n, K = idx.shape
         n0, C = f.shape
+        grad_out = grad_out.contiguous()
         gf = torch.zeros_like(f) if ctx.needs_input_grad[3] else None
         gw = torch.zeros_like(w) if ctx.needs_input_grad[4] else None
         gb = torch.zeros_like(b) if ctx.needs_input_grad[5] else None
         _lib.check(_lib.lib().cbl_adaptive_weight_backward(_i(n), _i(n0), _i(K), _i(C), _lib.ptr(q), _lib.ptr(s), _lib.ptr(idx), _lib.ptr(f), _f(radius),
-                                                           _lib.ptr(w), _lib.ptr(b), _lib.ptr(pad), _i(reduction_mean), _lib.ptr(grad_out.contiguous()),
+                                                           _lib.ptr(w), _lib.ptr(b), _lib.ptr(pad), _i(reduction_mean), _lib.ptr(grad_out),
                                                            _lib.ptr(gf), _lib.ptr(gw), _lib.ptr(gb), _lib.stream_of(f)), "cbl_adaptive_weight_backward")
         return None, None, None, gf, gw, gb, None, None
 

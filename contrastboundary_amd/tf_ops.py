@@ -1,0 +1,155 @@
+"""Host mirror of the reference's TF-side op dispatch, /root/reference/tensorflow/ops/tf_ops.py:
+    TF_OPS.get_tf_func(key) :26-73 with keys  grid_preprocess | grid | knn | radius
+    tf_batch_subsampling :158-163, tf_batch_neighbors :165-168, tf_knn_search :111-129, grid_subsampling :82-103
+and of the pyramid builder that calls them, /root/reference/tensorflow/datasets/base.py:767-842
+(tf_segmentation_inputs_radius).  TensorFlow is not part of this path (absent here and on the GPU box): tensors are torch
+CUDA tensors, stacked clouds are described by int32 per-cloud LENGTHS exactly as on the TF side.
+Differences, stated once: grid-subsampled points come out in ascending-voxel-key order per cloud (the reference: libstdc++
+hash order); radius neighbours of exactly equal distance are ordered by index (the reference: std::sort, unspecified)."""
+import ctypes
+
+import torch
+
+from . import _lib, pointops
+
+_i = ctypes.c_int
+_f = ctypes.c_float
+_ws = {}
+
+
+def _workspace(kind, nbytes, device):
+    key = (kind, device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+        _ws[key] = ws
+    return ws
+
+
+def _chk(t, dtype, name, dim):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype and t.is_contiguous() and t.dim() == dim):
+        raise TypeError(f"{name}: expected a contiguous {dim}-d CUDA tensor of {dtype}")
+    return t
+
+
+def _offsets(lengths):
+    return torch.cumsum(lengths, 0, dtype=torch.int32)
+
+
+def tf_batch_subsampling(points, batches_len, sampleDl, features=None, labels=None):
+    """BatchGridSubsampling: (points (N,3), batches_len (B,) i32, sampleDl) -> (sub_points (M,3), sub_batches_len (B,))  tf_ops.py:158-163.
+    With features (N,d) / labels (N,l) i32 also returns their per-voxel mean / majority (grid_subsampling.compute flavour)."""
+    _chk(points, torch.float32, "points", 2); _chk(batches_len, torch.int32, "batches_len", 1)
+    n, b = points.shape[0], batches_len.shape[0]
+    L = _lib.lib()
+    dev = points.device
+    fdim = features.shape[1] if features is not None else 0
+    ldim = labels.shape[1] if labels is not None else 0
+    if features is not None: _chk(features, torch.float32, "features", 2)
+    if labels is not None: _chk(labels, torch.int32, "labels", 2)
+    out_p = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    out_f = torch.empty((n, fdim), dtype=torch.float32, device=dev) if fdim else None
+    out_l = torch.empty((n, ldim), dtype=torch.int32, device=dev) if ldim else None
+    out_len = torch.empty(b, dtype=torch.int32, device=dev)
+    total = torch.empty(1, dtype=torch.int32, device=dev)
+    need = L.cbl_grid_subsampling_workspace_bytes(_i(b), _i(n))
+    ws = _workspace("sub", need, dev)
+    offset = _offsets(batches_len)            # keep alive across the call: its raw pointer is what travels through the C ABI
+    _lib.check(L.cbl_grid_subsampling(_i(b), _i(n), _lib.ptr(points), _lib.ptr(offset), _f(sampleDl), _i(fdim), _lib.ptr(features),
+                                      _i(ldim), _lib.ptr(labels), _lib.ptr(out_p), _lib.ptr(out_f), _lib.ptr(out_l), _lib.ptr(out_len), _lib.ptr(total),
+                                      _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(points)), "cbl_grid_subsampling")
+    m = int(total.item())                     # data-dependent output size: one sync, like the TF op's dynamic shape
+    res = [out_p[:m], out_len]
+    if fdim: res.append(out_f[:m])
+    if ldim: res.append(out_l[:m])
+    return tuple(res)
+
+
+def grid_subsampling(points, features=None, labels=None, sampleDl=0.1, verbose=0):
+    """cpp_subsampling.compute(points, features=, classes=, sampleDl=) on one cloud  (tf_ops.py:82-103)"""
+    lens = torch.tensor([points.shape[0]], dtype=torch.int32, device=points.device)
+    if labels is not None and labels.dim() == 1:
+        labels = labels.view(-1, 1)
+    out = tf_batch_subsampling(points, lens, sampleDl, features, labels.to(torch.int32).contiguous() if labels is not None else None)
+    res = [out[0]] + list(out[2:])
+    return res[0] if len(res) == 1 else tuple(res)
+
+
+def tf_batch_neighbors(queries, supports, q_batches, s_batches, radius, limit=None, exact_shape=True):
+    """BatchOrderedNeighbors: -> neighbors (Nq, width) i32 sorted by distance, padded with Ns  (tf_ops.py:165-168).
+    limit=None: width = the largest neighbourhood, like the TF op (needs one host sync and, above 64, is unsupported);
+    limit=L: the callers' crop big_neighborhood_filter (datasets/base.py:756-765) fused in; exact_shape also trims the width to
+    min(L, largest neighbourhood) as the reference's slicing would."""
+    _chk(queries, torch.float32, "queries", 2); _chk(supports, torch.float32, "supports", 2)
+    _chk(q_batches, torch.int32, "q_batches", 1); _chk(s_batches, torch.int32, "s_batches", 1)
+    nq, ns, b = queries.shape[0], supports.shape[0], q_batches.shape[0]
+    L = _lib.lib()
+    dev = queries.device
+    lim = 64 if limit is None else int(limit)
+    out = torch.empty((nq, lim), dtype=torch.int32, device=dev)
+    counts = torch.empty(nq, dtype=torch.int32, device=dev)
+    mc = torch.empty(1, dtype=torch.int32, device=dev)
+    ws = _workspace("radius", L.cbl_radius_neighbors_workspace_bytes(_i(b), _i(ns)), dev)
+    q_off, s_off = _offsets(q_batches), _offsets(s_batches)   # both alive until the launch is enqueued (two temporaries would share one block)
+    _lib.check(L.cbl_radius_neighbors(_i(b), _i(nq), _i(ns), _lib.ptr(queries), _lib.ptr(supports), _lib.ptr(q_off), _lib.ptr(s_off),
+                                      _f(radius), _i(lim), _lib.ptr(out), _lib.ptr(counts), _lib.ptr(mc), _lib.ptr(ws), ctypes.c_size_t(ws.numel()),
+                                      _lib.stream_of(queries)), "cbl_radius_neighbors")
+    if limit is None or exact_shape:
+        width = int(mc.item())
+        if limit is None and width > 64:
+            raise _lib.CblError(f"largest neighbourhood has {width} points; pass limit= (the reference crops to neighborhood_limits anyway)")
+        out = out[:, :min(width, lim)].contiguous()
+    return out
+
+
+def tf_knn_search(points, queries, k):
+    """knn_batch(points [B,N,3], queries [B,M,3], K, omp=True) -> [B,M,K] int64 local indices  (tf_ops.py:111-129)"""
+    _chk(points, torch.float32, "points", 3); _chk(queries, torch.float32, "queries", 3)
+    B, N, _ = points.shape
+    M = queries.shape[1]
+    dev = points.device
+    off = torch.arange(1, B + 1, dtype=torch.int32, device=dev) * N
+    qoff = torch.arange(1, B + 1, dtype=torch.int32, device=dev) * M
+    idx, _ = pointops.knnquery_raw(int(k), points.view(-1, 3), queries.view(-1, 3), off, qoff)
+    out = torch.empty((B, M, int(k)), dtype=torch.int64, device=dev)
+    _lib.check(_lib.lib().cbl_knn_indices_to_local(_i(B), _i(M), _i(int(k)), _i(N), _lib.ptr(idx), _lib.ptr(out), _lib.stream_of(points)), "cbl_knn_indices_to_local")
+    return out
+
+
+class TF_OPS(object):
+    """same lookup surface as the reference's TF_OPS.get_tf_func (tf_ops.py:26-73)"""
+
+    @staticmethod
+    def get_tf_func(key, verbose=False):
+        table = {"grid_preprocess": grid_subsampling, "grid": tf_batch_subsampling, "knn": tf_knn_search, "radius": tf_batch_neighbors}
+        if key not in table:
+            raise NotImplementedError(f"not supported module init for key = {key}")   # 'farthest*' point at ops/sampling, absent from the reference
+        return table[key]
+
+
+get_tf_func = TF_OPS.get_tf_func
+
+
+def segmentation_inputs_radius(stacked_points, stacks_lengths, first_subsampling_dl, density_parameter, num_layers, neighborhood_limits):
+    """The pyramid builder tf_segmentation_inputs_radius (datasets/base.py:767-842), geometry part: per layer the radius
+    neighbours, the grid-subsampled next layer, the pooling and upsampling indices, all cropped to neighborhood_limits.
+    13 radius searches + 4 grid subsamplings, on the GPU instead of single-threaded C++ inside tf.data workers."""
+    dl = float(first_subsampling_dl)
+    r = dl * float(density_parameter) / 2.0                                  # :784-786
+    pts, lens = stacked_points, stacks_lengths
+    out = {"points": [], "neighbors": [], "pools": [], "upsamples": [torch.zeros((0, 1), dtype=torch.int32, device=pts.device)], "batches_len": []}
+    for dt in range(num_layers - 1):                                         # :795-812
+        lim = int(neighborhood_limits[dt])
+        neighbors = tf_batch_neighbors(pts, pts, lens, lens, r, lim)
+        pool_pts, pool_lens = tf_batch_subsampling(pts, lens, 2 * dl)
+        pools = tf_batch_neighbors(pool_pts, pts, pool_lens, lens, r, lim)
+        ups = tf_batch_neighbors(pts, pool_pts, lens, pool_lens, 2 * r, lim)
+        out["points"].append(pts); out["neighbors"].append(neighbors); out["pools"].append(pools); out["upsamples"].append(ups)
+        out["batches_len"].append(lens)
+        pts, lens = pool_pts.contiguous(), pool_lens
+        r *= 2; dl *= 2
+    out["points"].append(pts)                                                # :815-820
+    out["neighbors"].append(tf_batch_neighbors(pts, pts, lens, lens, r, int(neighborhood_limits[num_layers - 1])))
+    out["pools"].append(torch.zeros((0, 1), dtype=torch.int32, device=pts.device))
+    out["batches_len"].append(lens)
+    return out

@@ -180,6 +180,40 @@ int cbl_adaptive_weight_backward(int n, int n0, int K, int C, const float* query
 int cbl_ind_max_pool(int n1, int n2, int k, int d, const float* x, const int* inds, unsigned* scratch_d, float* out, void* stream);
 int cbl_ind_closest_pool(int n1, int n2, int k, int d, const float* x, const int* inds, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * TF-side CPU ops of the reference (stacked clouds; here described by cumulative END offsets like the
+ * pytorch side — the TF ops take per-cloud lengths, the host mirror converts)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* N1 / N3  batch_grid_subsampling  tensorflow/ops/tf_custom_ops/tf_subsampling/grid_subsampling/grid_subsampling.cpp:114-161
+ *          (TF op BatchGridSubsampling, tf_batch_subsampling.cpp:8-20), and with features / labels the dataset
+ *          preprocessing flavour cpp_wrappers/cpp_subsampling/grid_subsampling/grid_subsampling.cpp:5-106
+ *          (grid_subsampling.compute(points, features=, classes=, sampleDl=), wrapper.cpp:70-76).
+ *   points (n,3), offset (b) [b <= 65535], dl; optional features (n,fdim) f32 -> per-voxel mean, labels (n,ldim) i32 -> per-voxel
+ *   majority (ties: smallest label; the reference's tie winner is hash-map order)
+ *   -> out_points (>= n rows capacity; first *out_total valid, voxels in ascending key order cloud by cloud), out_features,
+ *      out_labels, out_lengths (b) voxels per cloud, out_total (1).  Barycentres are bit-identical to the reference
+ *      (same accumulation order); only the ORDER of the voxels differs (the reference emits unordered_map iteration order). */
+size_t cbl_grid_subsampling_workspace_bytes(int b, int n);
+int cbl_grid_subsampling(int b, int n, const float* points, const int* offset, float dl,
+                         int fdim, const float* features, int ldim, const int* labels,
+                         float* out_points, float* out_features, int* out_labels, int* out_lengths, int* out_total,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* N2  batch_nanoflann_neighbors  tensorflow/ops/tf_custom_ops/tf_neighbors/neighbors/neighbors.cpp:213-336 (TF op
+ *     BatchOrderedNeighbors, tf_batch_neighbors.cpp:8-30) fused with the callers' crop to neighborhood_limits
+ *     (tensorflow/datasets/base.py:756-765).
+ *   queries (nq,3) / q_offset (b), supports (ns,3) / s_offset (b), radius, limit (<= 64)
+ *   -> out (nq,limit) i32: the supports with d2 < radius^2 (strict), ascending by (d2, index), global row ids, padded with ns;
+ *      counts (nq, may be NULL) true number inside the ball; max_count (1) = the reference's output width before the crop. */
+size_t cbl_radius_neighbors_workspace_bytes(int b, int ns);
+int cbl_radius_neighbors(int b, int nq, int ns, const float* queries, const float* supports, const int* q_offset, const int* s_offset,
+                         float radius, int limit, int* out, int* counts, int* max_count, void* workspace, size_t workspace_bytes, void* stream);
+
+/* N4  cpp_knn_batch_omp  tensorflow/ops/nearest_neighbors/knn_.cxx:104-135: dense batch (B,N,3) x (B,M,3) -> (B,M,K) int64 LOCAL indices.
+ *     = cbl_knnquery on the flattened batch (offset = N, 2N, ...) followed by this conversion of the global int32 rows. */
+int cbl_knn_indices_to_local(int B, int M, int K, int N, const int* idx, long long* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

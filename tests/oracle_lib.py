@@ -129,3 +129,52 @@ def aggregation_backward(inp, pos, w, idx, go):
     gw = np.zeros((n, ns, wc), np.float32)
     lib().oracle_aggregation_backward(n, ns, c, wc, P(inp), P(pos), P(w), P(idx), P(go), P(gi), P(gp), P(gw))
     return gi, gp, gw
+
+
+# ---- TF-side ops -------------------------------------------------------------------------------
+def grid_subsampling(points, lengths, dl):
+    points, lengths = f32(points), i32(lengths)
+    n, b = points.shape[0], len(lengths)
+    out = np.zeros((n, 3), np.float32)
+    ol = np.zeros(b, np.int32)
+    m = lib().oracle_batch_grid_subsampling(n, P(points), b, P(lengths), ctypes.c_float(dl), P(out), P(ol))
+    return out[:m].copy(), ol
+
+
+def grid_subsampling_full(points, features, labels, dl):
+    points, features, labels = f32(points), f32(features), i32(labels)
+    n, fdim, ldim = points.shape[0], features.shape[1], labels.shape[1]
+    op = np.zeros((n, 3), np.float32); of = np.zeros((n, fdim), np.float32); ol = np.zeros((n, ldim), np.int32); tie = np.zeros((n, ldim), np.int32)
+    m = lib().oracle_grid_subsampling_full(n, P(points), fdim, P(features), ldim, P(labels), ctypes.c_float(dl), P(op), P(of), P(ol), P(tie))
+    return op[:m].copy(), of[:m].copy(), ol[:m].copy(), tie[:m].copy()
+
+
+def radius_neighbors(queries, supports, q_len, s_len, radius, limit):
+    queries, supports, q_len, s_len = f32(queries), f32(supports), i32(q_len), i32(s_len)
+    nq, ns = queries.shape[0], supports.shape[0]
+    out = np.zeros((nq, limit), np.int32); counts = np.zeros(nq, np.int32)
+    mc = lib().oracle_radius_neighbors(nq, P(queries), ns, P(supports), len(q_len), P(q_len), P(s_len), ctypes.c_float(radius), limit, P(out), P(counts))
+    return out, counts, mc
+
+
+def knn_batch(points, queries, k):
+    points, queries = f32(points), f32(queries)
+    B, N, _ = points.shape
+    M = queries.shape[1]
+    out = np.zeros((B, M, k), np.int64)
+    lib().oracle_knn_batch(B, N, M, k, P(points), P(queries), P(out))
+    return out
+
+
+# ---- oracle/_ref: the reference's own TF-side C++ cores (built in the build container, prebuilt .so travels) ------
+_REF = {}
+
+
+def ref(name):
+    """ctypes handle of oracle/_ref/lib<name>.so or None if it is not available"""
+    if name not in _REF:
+        so = os.path.join(ORACLE_DIR, "_ref", f"lib{name}.so")
+        if not os.path.exists(so) and os.path.isdir("/root/reference"):
+            subprocess.call(["make", "-s", "-C", ORACLE_DIR, "ref"])
+        _REF[name] = ctypes.CDLL(so) if os.path.exists(so) else None
+    return _REF[name]

@@ -1,0 +1,125 @@
+"""CPU: oracle/tfops_oracle.c against oracle/_ref — the reference's own TF-side C++ (nanoflann radius search / kd-tree KNN /
+grid subsampling) compiled from /root/reference by oracle/Makefile.  Skipped only if oracle/_ref could not be built
+(then the TF-side oracle would be 'parity unpinned')."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from tests import oracle_lib as O
+from contrastboundary_amd import synthetic as S
+
+tf = O.ref("ref_tfops")
+wrap = O.ref("ref_wrap")
+knn = O.ref("ref_knn")
+need = pytest.mark.skipif(tf is None or wrap is None or knn is None, reason="oracle/_ref not built (needs /root/reference at build time)")
+
+
+def ref_radius(which, q, s, ql, sl, r):
+    q, s, ql, sl = O.f32(q), O.f32(s), O.i32(ql), O.i32(sl)
+    nq, ns = len(q), len(s)
+    mc = tf.ref_batch_neighbors(which, nq, O.P(q), ns, O.P(s), len(ql), O.P(ql), O.P(sl), ctypes.c_float(r), None, ctypes.c_longlong(0))
+    out = np.zeros((nq, max(mc, 1)), np.int32)
+    tf.ref_batch_neighbors(which, nq, O.P(q), ns, O.P(s), len(ql), O.P(ql), O.P(sl), ctypes.c_float(r), O.P(out), ctypes.c_longlong(out.size))
+    return out[:, :mc], mc
+
+
+def rows_equal_mod_ties(got, ref, q, s, ns):
+    """same neighbours per row; order may differ only inside groups of exactly equal distance"""
+    sp = np.concatenate([s, np.full((1, 3), np.inf, np.float32)])
+    d = lambda idx: ((q[:, None, :] - sp[idx]) ** 2).astype(np.float32)
+    dg = (d(got)[..., 0] + d(got)[..., 1]) + d(got)[..., 2]
+    dr = (d(ref)[..., 0] + d(ref)[..., 1]) + d(ref)[..., 2]
+    np.testing.assert_array_equal(np.nan_to_num(dg, posinf=1e30), np.nan_to_num(dr, posinf=1e30))
+    np.testing.assert_array_equal(np.sort(got, 1), np.sort(ref, 1))
+
+
+@need
+@pytest.mark.parametrize("seed,r", [(0, 0.1), (1, 0.2), (2, 0.05)])
+def test_radius_neighbors_match_nanoflann(seed, r):
+    xyz, _ = S.s_room(6000, seed=seed)
+    lens = np.int32([2500, 3500])
+    sub = np.concatenate([xyz[:2500:3], xyz[2500::3]]); sl = np.int32([len(xyz[:2500:3]), len(xyz[2500::3])])
+    for (q, ql, s, slen) in [(xyz, lens, xyz, lens), (sub, sl, xyz, lens), (xyz, lens, sub, sl)]:
+        refn, mc = ref_radius(0, q, s, ql, slen, r)
+        refo, mc2 = ref_radius(1, q, s, ql, slen, r)          # the brute-force variant of the same file must agree too
+        assert mc == mc2
+        got, counts, omc = O.radius_neighbors(q, s, ql, slen, r, limit=max(mc, 1))
+        assert omc == mc
+        rows_equal_mod_ties(got[:, :mc], refn, q, s, len(s))
+        rows_equal_mod_ties(got[:, :mc], refo, q, s, len(s))
+        # the callers' crop (datasets/base.py:762) == asking the oracle for `limit` columns directly
+        lim = max(1, mc // 2)
+        got2, _, _ = O.radius_neighbors(q, s, ql, slen, r, limit=lim)
+        np.testing.assert_array_equal(got2, got[:, :lim])
+
+
+@need
+def test_radius_neighbors_empty_cloud_and_no_neighbours():
+    rng = np.random.default_rng(0)
+    s = rng.uniform(size=(300, 3)).astype(np.float32)
+    q = np.concatenate([s[:50], rng.uniform(5, 6, (10, 3)).astype(np.float32)])     # 10 queries with no neighbour at all
+    refn, mc = ref_radius(0, q, s, [60], [300], 0.15)
+    got, counts, omc = O.radius_neighbors(q, s, [60], [300], 0.15, limit=mc)
+    assert omc == mc and (counts[50:] == 0).all() and (got[50:] == 300).all()
+    rows_equal_mod_ties(got, refn, q, s, 300)
+
+
+@need
+@pytest.mark.parametrize("dl", [0.04, 0.08, 0.3])
+def test_grid_subsampling_matches_reference(dl):
+    xyz, _ = S.s_room(8000, seed=3)
+    lens = np.int32([3000, 1, 4999])
+    xyz[3000] = xyz[10]                                                   # 1-point cloud
+    out = np.zeros((8000, 3), np.float32); ol = np.zeros(3, np.int32)
+    m = tf.ref_batch_grid_subsampling(8000, O.P(O.f32(xyz)), 3, O.P(lens), ctypes.c_float(dl), O.P(out), O.P(ol), 8000)
+    got, gl = O.grid_subsampling(xyz, lens, dl)
+    np.testing.assert_array_equal(gl, ol)
+    assert len(got) == m
+    # reference order = unordered_map iteration order; canonical here = ascending voxel key: compare per cloud as sorted sets, BIT-exact
+    a = 0
+    for c in range(3):
+        r = out[a:a + ol[c]]; g = got[a:a + ol[c]]
+        key = lambda p: np.lexsort((p[:, 2], p[:, 1], p[:, 0]))
+        np.testing.assert_array_equal(g[key(g)].view(np.uint32), r[key(r)].view(np.uint32))
+        a += ol[c]
+
+
+@need
+def test_grid_subsampling_with_features_and_labels_matches_reference():
+    xyz, lab = S.s_room(5000, seed=4)
+    rng = np.random.default_rng(4)
+    feat = rng.uniform(size=(5000, 4)).astype(np.float32)
+    labels = np.stack([lab, rng.integers(0, 3, 5000)], 1).astype(np.int32)
+    dl = 0.12
+    rp = np.zeros((5000, 3), np.float32); rf = np.zeros((5000, 4), np.float32); rl = np.zeros((5000, 2), np.int32)
+    m = wrap.ref_grid_subsampling_full(5000, O.P(O.f32(xyz)), 4, O.P(feat), 2, O.P(labels), ctypes.c_float(dl), O.P(rp), O.P(rf), O.P(rl), 5000)
+    gp, gf, gl, tie = O.grid_subsampling_full(xyz, feat, labels, dl)
+    assert len(gp) == m
+    ko, kr = np.lexsort((gp[:, 2], gp[:, 1], gp[:, 0])), np.lexsort((rp[:m, 2], rp[:m, 1], rp[:m, 0]))
+    np.testing.assert_array_equal(gp[ko].view(np.uint32), rp[:m][kr].view(np.uint32))
+    np.testing.assert_array_equal(gf[ko].view(np.uint32), rf[:m][kr].view(np.uint32))
+    untied = tie[ko] == 0                                                  # tied votes: the reference picks by hash-map order
+    np.testing.assert_array_equal(gl[ko][untied], rl[:m][kr][untied])
+    assert untied.mean() > 0.5
+
+
+@need
+@pytest.mark.parametrize("omp", [0, 1])
+def test_knn_batch_matches_kdtree(omp):
+    rng = np.random.default_rng(7)
+    pts = rng.uniform(size=(3, 900, 3)).astype(np.float32)
+    qs = rng.uniform(size=(3, 200, 3)).astype(np.float32)
+    K = 7
+    out = np.zeros((3, 200, K), np.int64)
+    knn.ref_knn_batch(O.P(pts), ctypes.c_long(3), ctypes.c_long(900), O.P(qs), ctypes.c_long(200), ctypes.c_long(K), O.P(out), omp)
+    np.testing.assert_array_equal(O.knn_batch(pts, qs, K), out)            # random floats: tie-free
+
+
+def test_oracle_knn_batch_equals_pointops_knn_on_tie_free_data():
+    # the two KNN flavours of the reference (kd-tree, TF side; heap scan, pytorch side) agree when no distances tie
+    rng = np.random.default_rng(1)
+    pts = rng.uniform(size=(2, 500, 3)).astype(np.float32)
+    a = O.knn_batch(pts, pts, 5)
+    idx, _ = O.knnquery(5, pts.reshape(-1, 3), pts.reshape(-1, 3), [500, 1000], [500, 1000])
+    np.testing.assert_array_equal(a.reshape(-1, 5) + np.repeat([0, 500], 500)[:, None], idx)
