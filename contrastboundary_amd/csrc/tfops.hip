@@ -137,6 +137,53 @@ __global__ __launch_bounds__(256) void knn_to_local_kernel(long long total, int 
     }
 }
 
+
+// ---- a13: dataloader voxelisation, /root/reference/pytorch/util/voxelize.py:4-16 (fnv_hash_vec), :38-56 (voxelize) --------
+// key = FNV hash of floor(coord / voxel_size) taken as uint64 per axis (the reference multiplies by the prime THEN xors), argsort by
+// key, run lengths per voxel.  The reference's np.argsort is quicksort (order inside a voxel unspecified); here the sort is stable,
+// i.e. ascending original index inside a voxel.
+template <typename T>
+__global__ __launch_bounds__(256) void voxel_keys_kernel(int n, const T* __restrict__ coord, T voxel, unsigned long long* __restrict__ keys, int* __restrict__ vals)
+{
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        unsigned long long h = 14695981039346656037ull;                                  // :12
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const T d = floor(coord[3 * (size_t)i + a] / voxel);                         // np.floor(coord / voxel_size), :39
+            h *= 1099511628211ull;                                                       // :14
+            h ^= (unsigned long long)(long long)d;                                       // astype(np.uint64) of a non-negative float, :11,:15
+        }
+        keys[i] = h; vals[i] = i;
+    }
+}
+
+// per voxel head: start position and count (count[v], start[v]); total voxels
+__global__ __launch_bounds__(256) void voxel_runs_kernel(int n, const unsigned long long* __restrict__ keys, const int* __restrict__ flags,
+                                                         const int* __restrict__ vox_id, int* __restrict__ start, int* __restrict__ count, int* __restrict__ total)
+{
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        if (!flags[i]) continue;
+        const int v = vox_id[i] - 1;
+        int e = i + 1;
+        while (e < n && !flags[e]) e++;
+        start[v] = i; count[v] = e - i;
+        if (e == n) total[0] = v + 1;
+    }
+}
+
+// order-preserving key of the squared distance to a centre point (data_util.py:62-64: argsort(sum(square(coord - coord_init), 1)))
+template <typename T>
+__global__ __launch_bounds__(256) void crop_keys_kernel(int n, const T* __restrict__ coord, int center, unsigned long long* __restrict__ keys, int* __restrict__ vals)
+{
+    const T cx = coord[3 * (size_t)center], cy = coord[3 * (size_t)center + 1], cz = coord[3 * (size_t)center + 2];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const T dx = coord[3 * (size_t)i] - cx, dy = coord[3 * (size_t)i + 1] - cy, dz = coord[3 * (size_t)i + 2] - cz;
+        const double d = (double)((dx * dx + dy * dy) + dz * dz);                        // np.sum over 3 elements: sequential
+        keys[i] = (unsigned long long)__double_as_longlong(d);                           // d >= 0: bit pattern is monotone
+        vals[i] = i;
+    }
+}
+
 }  // namespace
 
 CBL_EXPORT size_t cbl_grid_subsampling_workspace_bytes(int b, int n) { return (b > 0 && n >= 0) ? carve_sub(nullptr, b, n).bytes : 0; }
@@ -190,4 +237,50 @@ CBL_EXPORT int cbl_knn_indices_to_local(int B, int M, int K, int N, const int* i
     if (!idx || !out) return CBL_ERR_BAD_ARG;
     hipLaunchKernelGGL(knn_to_local_kernel, dim3(cbl_grid_for(total, 256)), dim3(256), 0, cbl_stream(stream), total, M, K, N, idx, out);
     return cbl_status();
+}
+
+CBL_EXPORT size_t cbl_voxelize_workspace_bytes(int n) { return carve_sub(nullptr, 1, n > 0 ? n : 1).bytes; }
+
+// coord (n,3) float32 (is_f64 = 0) or float64 (is_f64 = 1), non-negative (the caller subtracts the min, data_util.py:52-53)
+// -> keys_sorted (n) u64, idx_sort (n) i32 [argsort, stable], start (n cap) / count (n cap) per voxel, num_voxels (1)
+CBL_EXPORT int cbl_voxelize(int n, int is_f64, const void* coord, double voxel_size, unsigned long long* keys_sorted, int* idx_sort,
+                            int* start, int* count, int* num_voxels, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (n < 0 || !(voxel_size > 0.0) || !num_voxels) return CBL_ERR_BAD_ARG;
+    hipStream_t st = cbl_stream(stream);
+    hipError_t e = hipMemsetAsync(num_voxels, 0, sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
+    if (n == 0) return CBL_OK;
+    if (!coord || !keys_sorted || !idx_sort || !start || !count) return CBL_ERR_BAD_ARG;
+    SubWs w = carve_sub(workspace, 1, n);
+    if (!workspace || workspace_bytes < w.bytes) return CBL_ERR_WORKSPACE;
+    const dim3 g(cbl_grid_for(n, 256, 1024)), blk(256);
+    if (is_f64) hipLaunchKernelGGL(voxel_keys_kernel<double>, g, blk, 0, st, n, reinterpret_cast<const double*>(coord), voxel_size, w.keys_in, w.vals_in);
+    else        hipLaunchKernelGGL(voxel_keys_kernel<float>, g, blk, 0, st, n, reinterpret_cast<const float*>(coord), (float)voxel_size, w.keys_in, w.vals_in);
+    size_t cb = w.cub_bytes;
+    e = hipcub::DeviceRadixSort::SortPairs(w.cub, cb, w.keys_in, keys_sorted, w.vals_in, idx_sort, n, 0, 64, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(sub_flags_kernel, g, blk, 0, st, n, keys_sorted, w.flags);
+    cb = w.cub_bytes;
+    e = hipcub::DeviceScan::InclusiveSum(w.cub, cb, w.flags, w.vox_id, n, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(voxel_runs_kernel, g, blk, 0, st, n, keys_sorted, w.flags, w.vox_id, start, count, num_voxels);
+    return cbl_status();
+}
+
+// data_util.py:62-64: indices of all points by ascending distance to coord[center] (stable); the caller keeps the first voxel_max
+CBL_EXPORT int cbl_crop_order(int n, int is_f64, const void* coord, int center, int* order, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (n < 0 || center < 0 || (n > 0 && center >= n)) return CBL_ERR_BAD_ARG;
+    if (n == 0) return CBL_OK;
+    if (!coord || !order) return CBL_ERR_BAD_ARG;
+    hipStream_t st = cbl_stream(stream);
+    SubWs w = carve_sub(workspace, 1, n);
+    if (!workspace || workspace_bytes < w.bytes) return CBL_ERR_WORKSPACE;
+    const dim3 g(cbl_grid_for(n, 256, 1024)), blk(256);
+    if (is_f64) hipLaunchKernelGGL(crop_keys_kernel<double>, g, blk, 0, st, n, reinterpret_cast<const double*>(coord), center, w.keys_in, w.vals_in);
+    else        hipLaunchKernelGGL(crop_keys_kernel<float>, g, blk, 0, st, n, reinterpret_cast<const float*>(coord), center, w.keys_in, w.vals_in);
+    size_t cb = w.cub_bytes;
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(w.cub, cb, w.keys_in, w.keys_out, w.vals_in, order, n, 0, 64, st);
+    return e == hipSuccess ? cbl_status() : (int)e;
 }

@@ -1,0 +1,64 @@
+"""Host mirror of /root/reference/pytorch/util/voxelize.py (voxelize :38-56, fnv_hash_vec :4-16) and of the nearest-voxel_max
+crop of data_prepare (/root/reference/pytorch/util/data_util.py:57-67) — the dataloader stage that runs as numpy on 16 CPU
+workers in the reference, here on the GPU so that 8 GPUs are not starved by the host."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_ws = {}
+
+
+def _workspace(n, device):
+    need = _lib.lib().cbl_voxelize_workspace_bytes(ctypes.c_int(n))
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=device)
+        _ws[key] = ws
+    return ws
+
+
+def _coord(coord):
+    if not (isinstance(coord, torch.Tensor) and coord.is_cuda and coord.dim() == 2 and coord.shape[1] == 3 and coord.is_contiguous()
+            and coord.dtype in (torch.float32, torch.float64)):
+        raise TypeError("coord: expected a contiguous (n,3) float32/float64 CUDA tensor")
+    return coord
+
+
+def voxelize(coord, voxel_size=0.05, hash_type="fnv", mode=0, rand=None):
+    """mode 1 (val): -> (idx_sort (n,) int64, count (v,) int64)         voxelize.py:53-55
+    mode 0 (train): -> idx_unique (v,) int64, one point per voxel: idx_sort[start + rand % count] with rand in [0, count.max())
+                    (the reference draws rand from np.random, :47-51; pass `rand` (v,) for a reproducible choice)."""
+    if hash_type != "fnv":
+        raise NotImplementedError("hash_type='ravel' is not used by the reference's pipelines")
+    _coord(coord)
+    n, dev = coord.shape[0], coord.device
+    keys = torch.empty(n, dtype=torch.int64, device=dev)
+    idx_sort = torch.empty(n, dtype=torch.int32, device=dev)
+    start = torch.empty(n, dtype=torch.int32, device=dev)
+    count = torch.empty(n, dtype=torch.int32, device=dev)
+    nv = torch.empty(1, dtype=torch.int32, device=dev)
+    ws = _workspace(n, dev)
+    _lib.check(_lib.lib().cbl_voxelize(ctypes.c_int(n), ctypes.c_int(1 if coord.dtype == torch.float64 else 0), _lib.ptr(coord),
+                                       ctypes.c_double(float(voxel_size)), _lib.ptr(keys), _lib.ptr(idx_sort), _lib.ptr(start), _lib.ptr(count),
+                                       _lib.ptr(nv), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(coord)), "cbl_voxelize")
+    v = int(nv.item())
+    idx_sort, start, count = idx_sort.long(), start[:v].long(), count[:v].long()
+    if mode != 0:
+        return idx_sort, count
+    if rand is None:
+        rand = torch.randint(0, int(count.max().item()), (v,), device=dev)
+    return idx_sort[start + rand.to(dev).long() % count]
+
+
+def crop_nearest(coord, center_idx, voxel_max):
+    """indices of the voxel_max points nearest to coord[center_idx] (ascending distance)      data_util.py:62-64"""
+    _coord(coord)
+    n, dev = coord.shape[0], coord.device
+    order = torch.empty(n, dtype=torch.int32, device=dev)
+    ws = _workspace(n, dev)
+    _lib.check(_lib.lib().cbl_crop_order(ctypes.c_int(n), ctypes.c_int(1 if coord.dtype == torch.float64 else 0), _lib.ptr(coord), ctypes.c_int(int(center_idx)),
+                                         _lib.ptr(order), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(coord)), "cbl_crop_order")
+    return order[:voxel_max].long()

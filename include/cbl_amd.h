@@ -214,6 +214,23 @@ int cbl_radius_neighbors(int b, int nq, int ns, const float* queries, const floa
  *     = cbl_knnquery on the flattened batch (offset = N, 2N, ...) followed by this conversion of the global int32 rows. */
 int cbl_knn_indices_to_local(int B, int M, int K, int N, const int* idx, long long* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Dataloader stage of the pytorch side (numpy on CPU workers in the reference)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* a13  voxelize + fnv_hash_vec  pytorch/util/voxelize.py:4-16, :38-56
+ *   coord (n,3) f32 or f64 (is_f64), already shifted to >= 0 (data_util.py:52-53), voxel_size
+ *   -> keys_sorted (n) u64 = sorted FNV keys, idx_sort (n) i32 = argsort(key) [stable: ascending index inside a voxel; the reference's
+ *      quicksort order inside a voxel is unspecified], start / count (capacity n) per voxel in key order, num_voxels (1).
+ *   mode 1 of the reference returns (idx_sort, count); mode 0 picks idx_sort[start + rand % count] (host mirror). */
+size_t cbl_voxelize_workspace_bytes(int n);
+int cbl_voxelize(int n, int is_f64, const void* coord, double voxel_size, unsigned long long* keys_sorted, int* idx_sort,
+                 int* start, int* count, int* num_voxels, void* workspace, size_t workspace_bytes, void* stream);
+
+/* crop to the voxel_max points nearest to a centre  pytorch/util/data_util.py:62-64
+ *   -> order (n) i32 = argsort of squared distance to coord[center] (stable); workspace as cbl_voxelize */
+int cbl_crop_order(int n, int is_f64, const void* coord, int center, int* order, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,40 @@
+"""a13 voxelize: CPU oracle vs goldens from the reference's own voxelize.py; GPU kernels vs the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import voxelize_oracle as V
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "voxelize.npz"))
+CASES = sorted({k.split("/")[0] for k in G.files})
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_matches_reference(case):
+    coord, vs = G[f"{case}/coord"], float(G[f"{case}/voxel"])
+    key, idx_sort, start, count = V.voxelize(coord, vs)
+    np.testing.assert_array_equal(key, G[f"{case}/key"])
+    np.testing.assert_array_equal(count, G[f"{case}/count"])
+    ref_sort = G[f"{case}/idx_sort"]
+    np.testing.assert_array_equal(key[idx_sort], key[ref_sort])                       # same sorted key sequence
+    for s, c in zip(start[:500], count[:500]):                                         # same index SET per voxel (quicksort order is free)
+        assert set(idx_sort[s:s + c]) == set(ref_sort[s:s + c])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_gpu_voxelize_and_crop(case):
+    import torch
+    from contrastboundary_amd import voxelize as VZ
+    coord, vs = G[f"{case}/coord"], float(G[f"{case}/voxel"])
+    key, idx_sort, start, count = V.voxelize(coord, vs)
+    c = torch.from_numpy(coord).cuda()
+    gi, gc = VZ.voxelize(c, vs, mode=1)
+    np.testing.assert_array_equal(gi.cpu().numpy(), idx_sort)
+    np.testing.assert_array_equal(gc.cpu().numpy(), count)
+    rand = np.random.default_rng(0).integers(0, count.max(), count.size)
+    gu = VZ.voxelize(c, vs, mode=0, rand=torch.from_numpy(rand))
+    np.testing.assert_array_equal(gu.cpu().numpy(), idx_sort[start + rand % count])    # voxelize.py:49-51
+    order = VZ.crop_nearest(c, 123, 2000).cpu().numpy()
+    np.testing.assert_array_equal(order, V.crop_order(coord, 123)[:2000])
