@@ -63,15 +63,11 @@ def cpu_baseline(n, c, k, seed):
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from contrastboundary_amd import distributed as D
+    world, rank, local = D.env_world()
     torch.cuda.set_device(local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")            # "nccl" is RCCL on ROCm; used for barriers/max only
+    D.init("nccl" if world > 1 else None)                   # "nccl" is RCCL on ROCm; used for barriers / max-time only
+    dist = (world > 1)
 
     from contrastboundary_amd import hotpath
     n, c, k = args.points, args.channels, args.k
@@ -90,21 +86,15 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+    D.barrier()
     ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in stages] for _ in range(args.steps)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(args.steps):
         step(ev[s])
     torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    D.barrier()
+    elapsed = D.reduce_scalar(time.perf_counter() - t0, "max")
 
     # per-stage average device time from the HIP events recorded inside the timed region (same stream as the launches)
     stage_ms = [float(np.mean([ev[s][i][0].elapsed_time(ev[s][i][1]) for s in range(args.steps)])) for i in range(len(stages))]
@@ -130,7 +120,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(n, c, k, seed=0)
         print(json.dumps(out))
     if dist:
-        dist.destroy_process_group()
+        import torch.distributed
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
