@@ -120,8 +120,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(n, c, k, seed=0)
         print(json.dumps(out))
     if dist:
-        import torch.distributed
-        torch.distributed.destroy_process_group()
+        import torch.distributed as tdist
+        tdist.destroy_process_group()
 
 
 if __name__ == "__main__":
