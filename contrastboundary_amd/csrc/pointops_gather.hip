@@ -27,7 +27,10 @@ __global__ __launch_bounds__(GB) void grouping_fwd_v4(long long rows, int c4, co
     const long long total = rows * c4;
     for (long long e = (long long)blockIdx.x * GB + threadIdx.x; e < total; e += (long long)gridDim.x * GB) {
         const long long r = e / c4; const int ch = (int)(e - r * c4);
-        out[e] = in[(long long)idx[r] * c4 + ch];
+        // the (m,K,c) output is written once and read by a later kernel: streaming (nt) store keeps the gathered source rows in L2
+        using v4 = __attribute__((ext_vector_type(4))) float;
+        const float4 v = in[(long long)idx[r] * c4 + ch];
+        __builtin_nontemporal_store(v4{v.x, v.y, v.z, v.w}, reinterpret_cast<v4*>(out + e));
     }
 }
 __global__ __launch_bounds__(GB) void grouping_fwd_s(long long rows, int c, const float* __restrict__ in,
@@ -189,6 +192,34 @@ __global__ __launch_bounds__(GB) void agg_bwd(int n, int ns, int c, int wc, cons
 
 // ---------------------------------------------------------------- F1 queryandgroup (idx given)
 // out[r, 0:3] = xyz[idx[r]] - new_xyz[r / ns] ; out[r, 3:3+c] = feat[idx[r]]     pointops.py:90-98
+// A lane owns 4 channels of one output row: 16 B gather, 16 B store.  Output rows are 4*(3+c) B long, so the store is only
+// 4-byte aligned: gfx950 global memory takes unaligned dwordx4 (the 4-byte-aligned vector type makes hipcc emit it); one extra lane per
+// row writes the centred coordinates.  Scalar kernel for channel counts that are not a multiple of 4.
+typedef float v4u __attribute__((ext_vector_type(4), aligned(4)));      // 16 B vector that may sit on any 4-byte boundary
+
+__global__ __launch_bounds__(256) void query_group_v4(unsigned rows, int ns, int c4, int use_xyz,
+                                                     const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+                                                     const float4* __restrict__ feat, const int* __restrict__ idx, float* __restrict__ out)
+{
+    const unsigned parts = (unsigned)c4 + (use_xyz ? 1u : 0u);
+    const unsigned oc = 4u * c4 + (use_xyz ? 3u : 0u);
+    const unsigned long long total = (unsigned long long)rows * parts;
+    for (unsigned long long e = (unsigned long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (unsigned long long)gridDim.x * 256) {
+        const unsigned r = (unsigned)(e / parts), part = (unsigned)(e - (unsigned long long)r * parts);
+        const unsigned src = (unsigned)idx[r];
+        float* orow = out + (size_t)r * oc;
+        if (part < (unsigned)c4) {
+            const float4 v = feat[(size_t)src * c4 + part];
+            __builtin_nontemporal_store(v4u{v.x, v.y, v.z, v.w}, reinterpret_cast<v4u*>(orow + (use_xyz ? 3 : 0) + 4 * part));   // streaming output
+        } else {
+            const unsigned q = r / (unsigned)ns;
+            orow[0] = xyz[(size_t)src * 3 + 0] - new_xyz[(size_t)q * 3 + 0];
+            orow[1] = xyz[(size_t)src * 3 + 1] - new_xyz[(size_t)q * 3 + 1];
+            orow[2] = xyz[(size_t)src * 3 + 2] - new_xyz[(size_t)q * 3 + 2];
+        }
+    }
+}
+
 __global__ __launch_bounds__(GB) void query_group(long long rows, int ns, int c, int use_xyz,
                                                   const float* __restrict__ xyz, const float* __restrict__ new_xyz,
                                                   const float* __restrict__ feat, const int* __restrict__ idx, float* __restrict__ out)
@@ -339,7 +370,11 @@ CBL_EXPORT int cbl_queryandgroup(int m, int nsample, int c, int use_xyz, const f
     CBL_CHECK_PTRS(idx, out);
     if (use_xyz) CBL_CHECK_PTRS(xyz, new_xyz);
     if (c > 0) CBL_CHECK_PTRS(feat);
-    hipLaunchKernelGGL(query_group, dim3(cbl_grid_for(rows * oc, GB)), dim3(GB), 0, cbl_stream(stream), rows, nsample, c, use_xyz, xyz, new_xyz, feat, idx, out);
+    if (c % 4 == 0 && c > 0 && cbl_host_aligned16(feat) && rows < 0xffffffffLL)
+        hipLaunchKernelGGL(query_group_v4, dim3(cbl_grid_for(rows * (c / 4 + (use_xyz ? 1 : 0)), GB)), dim3(GB), 0, cbl_stream(stream), (unsigned)rows, nsample, c / 4, use_xyz,
+                           xyz, new_xyz, reinterpret_cast<const float4*>(feat), idx, out);
+    else
+        hipLaunchKernelGGL(query_group, dim3(cbl_grid_for(rows * oc, GB)), dim3(GB), 0, cbl_stream(stream), rows, nsample, c, use_xyz, xyz, new_xyz, feat, idx, out);
     return cbl_status();
 }
 
