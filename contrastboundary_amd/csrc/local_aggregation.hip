@@ -23,65 +23,103 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 // ---------------------------------------------------------------------------------------------- KPConv forward (MFMA)
 // influence: 0 constant, 1 linear.  closest: only the nearest kernel point of each neighbour keeps its weight (:705-708).
-template <int CHUNKS>     // 16-channel chunks handled per pass (registers: 4 floats each)
+//
+// Tile mapping (v_mfma_f32_16x16x4_f32: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15], D[row = (lane>>4)*4 + r][col = lane&15]):
+//   i / row = kernel point, k = neighbour within a group of 4, and — to make the B operand ONE 16-byte load — column j of
+//   accumulator tile t stands for channel c0 + 4*j + t.  Lane (k, j) then loads the float4 f[nbr_k][c0 + 4j .. 4j+3] (16 lanes
+//   = one 256 B row segment per neighbour, 1 KiB per wave-instruction) and its four components are the B values of the four
+//   tiles; after the epilogue lane j holds channels c0 + 4j .. 4j+3 of the output, stored as one float4 (256 B per point).
+template <bool VEC>       // VEC: C % 4 == 0 and 16-byte aligned rows -> float4 path; else scalar loads with the same mapping
 __global__ __launch_bounds__(256) void kpconv_fwd_kernel(int n, int n0, int K, int C, int KP, const float* __restrict__ q,
                                                          const float* __restrict__ s, const int* __restrict__ idx, const float* __restrict__ f,
                                                          const float* __restrict__ kpts, const float* __restrict__ kw, float extent,
                                                          int influence, int closest, float* __restrict__ out)
 {
     const int lane = threadIdx.x & 63;
-    const int kp_id = lane & 15;          // A row / kernel point          (A[i = lane&15][k = lane>>4])
-    const int kq = lane >> 4;             // neighbour within a chunk of 4 (B[k = lane>>4][j = lane&15])
+    const int kp_id = lane & 15;          // A row / kernel point; also B / D column j
+    const int kq = lane >> 4;             // neighbour within a group of 4; D row block
     const int wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (gridDim.x * 256) >> 6;
     const bool kp_ok = kp_id < KP;
     const float kx = kp_ok ? kpts[3 * kp_id] : 0.f, ky = kp_ok ? kpts[3 * kp_id + 1] : 0.f, kz = kp_ok ? kpts[3 * kp_id + 2] : 0.f;
 
     for (int p = wave0; p < n; p += nwaves) {
         const float qx = q[3 * p], qy = q[3 * p + 1], qz = q[3 * p + 2];
-        for (int c0 = 0; c0 < C; c0 += 16 * CHUNKS) {
-            f32x4 acc[CHUNKS];
+        for (int c0 = 0; c0 < C; c0 += 64) {
+            f32x4 acc[4];
 #pragma unroll
-            for (int ch = 0; ch < CHUNKS; ch++) acc[ch] = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int kc = 0; kc < K; kc += 4) {
-                const int nb = kc + kq;
-                const int id = (nb < K) ? idx[(size_t)p * K + nb] : n0;
-                const bool real = id >= 0 && id < n0;
+            for (int t = 0; t < 4; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int cb = c0 + 4 * kp_id;                                                   // first of this lane's 4 channels
+            for (int k0 = 0; k0 < K; k0 += 64) {
+                // one coalesced load of up to 64 neighbour ids, then their coordinates: two dependent round trips per point
+                // instead of two per group of 4 neighbours
+                const int my_nb = k0 + lane;
+                const int my_id = (my_nb < K) ? idx[(size_t)p * K + my_nb] : n0;
+                const bool my_real = my_id >= 0 && my_id < n0;
                 // neighbour relative to the query; the shadow point sits at (1e6,1e6,1e6)  (:681-684)
-                const float rx = (real ? s[3 * id] : 1e6f) - qx, ry = (real ? s[3 * id + 1] : 1e6f) - qy, rz = (real ? s[3 * id + 2] : 1e6f) - qz;
-                const float dx = rx - kx, dy = ry - ky, dz = rz - kz;
-                const float sq = (dx * dx + dy * dy) + dz * dz;                                  // :688
-                float w = influence ? fmaxf(1.0f - sqrtf(sq) / extent, 0.0f) : 1.0f;            // :697 / :693
-                if (closest) {                                                                   // argmin over kernel points, first minimum
-                    float bs = kp_ok ? sq : INFINITY; int bi = kp_id;
+                const float mrx = (my_real ? s[3 * my_id] : 1e6f) - qx, mry = (my_real ? s[3 * my_id + 1] : 1e6f) - qy,
+                            mrz = (my_real ? s[3 * my_id + 2] : 1e6f) - qz;
+                const int kend = min(64, K - k0);
+                for (int kc = 0; kc < kend; kc += 16) {
+                    // feature rows of 4 groups of 4 neighbours are requested before any of them is consumed
+                    float bv[4][4]; float a[4];
 #pragma unroll
-                    for (int sft = 8; sft >= 1; sft >>= 1) {
-                        const float os = __shfl_xor(bs, sft, 16); const int oi = __shfl_xor(bi, sft, 16);
-                        if (os < bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
+                    for (int g = 0; g < 4; g++) {
+                        const int src = kc + 4 * g + kq;                                         // lane holding this neighbour
+                        const int id = __shfl(my_id, src & 63);
+                        const bool in = (kc + 4 * g + kq) < kend;
+                        const bool real = in && id >= 0 && id < n0;
+#pragma unroll
+                        for (int t = 0; t < 4; t++) bv[g][t] = 0.f;                              // shadow feature row = 0 (:713)
+                        if (real) {
+                            if (VEC) {
+                                if (cb < C) { const float4 v = *reinterpret_cast<const float4*>(f + (size_t)id * C + cb); bv[g][0] = v.x; bv[g][1] = v.y; bv[g][2] = v.z; bv[g][3] = v.w; }
+                            } else {
+#pragma unroll
+                                for (int t = 0; t < 4; t++) if (cb + t < C) bv[g][t] = f[(size_t)id * C + cb + t];
+                            }
+                        }
+                        const float rx = __shfl(mrx, src & 63), ry = __shfl(mry, src & 63), rz = __shfl(mrz, src & 63);
+                        const float dx = rx - kx, dy = ry - ky, dz = rz - kz;
+                        const float sq = (dx * dx + dy * dy) + dz * dz;                          // :688
+                        float w = influence ? fmaxf(1.0f - sqrtf(sq) / extent, 0.0f) : 1.0f;    // :697 / :693
+                        if (closest) {                                                           // argmin over kernel points, first minimum
+                            float bs = kp_ok ? sq : INFINITY; int bi = kp_id;
+#pragma unroll
+                            for (int sft = 8; sft >= 1; sft >>= 1) {
+                                const float os = __shfl_xor(bs, sft, 16); const int oi = __shfl_xor(bi, sft, 16);
+                                if (os < bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
+                            }
+                            if (bi != kp_id) w = 0.f;
+                        }
+                        a[g] = (kp_ok && in) ? w : 0.f;
                     }
-                    if (bi != kp_id) w = 0.f;
-                }
-                const float a = (kp_ok && nb < K) ? w : 0.f;
 #pragma unroll
-                for (int ch = 0; ch < CHUNKS; ch++) {
-                    const int c = c0 + 16 * ch + kp_id;                                          // B column = lane & 15
-                    const float bval = (real && c < C) ? f[(size_t)id * C + c] : 0.f;           // shadow feature row = 0 (:713)
-                    acc[ch] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bval, acc[ch], 0, 0, 0);  // wf = w @ f_nbr (:716)
+                    for (int g = 0; g < 4; g++)
+#pragma unroll
+                        for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g], bv[g][t], acc[t], 0, 0, 0);   // wf = w @ f_nbr (:716)
                 }
             }
-            // epilogue: out[c] = sum_kp kernel_weights[kp,c] * wf[kp,c]  (:723-727).  D: col = lane&15, row = (lane>>4)*4 + r
+            // epilogue: out[c] = sum_kp kernel_weights[kp,c] * wf[kp,c]  (:723-727); tile t, column j <-> channel cb + t
+            float res[4];
 #pragma unroll
-            for (int ch = 0; ch < CHUNKS; ch++) {
-                const int c = c0 + 16 * ch + kp_id;
+            for (int t = 0; t < 4; t++) {
                 float part = 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int row = kq * 4 + r;
-                    const float kwv = (row < KP && c < C) ? kw[(size_t)row * C + c] : 0.f;
-                    part += kwv * acc[ch][r];
+                    const float kwv = (row < KP && cb + t < C) ? kw[(size_t)row * C + cb + t] : 0.f;
+                    part += kwv * acc[t][r];
                 }
                 part += __shfl_xor(part, 16);
                 part += __shfl_xor(part, 32);
-                if (lane < 16 && c < C) out[(size_t)p * C + c] = part;
+                res[t] = part;
+            }
+            if (lane < 16) {
+                if (VEC) { if (cb < C) *reinterpret_cast<float4*>(out + (size_t)p * C + cb) = make_float4(res[0], res[1], res[2], res[3]); }
+                else {
+#pragma unroll
+                    for (int t = 0; t < 4; t++) if (cb + t < C) out[(size_t)p * C + cb + t] = res[t];
+                }
             }
         }
     }
@@ -270,9 +308,10 @@ CBL_EXPORT int cbl_kpconv_forward(int n, int n0, int K, int C, int KP, const flo
     if (!query_points || !support_points || !neighbors_indices || !features || !kernel_points || !kernel_weights || !out) return CBL_ERR_BAD_ARG;
     hipStream_t st = cbl_stream(stream);
     const dim3 grid(persistent_grid(n)), block(256);
-    if (C > 32) hipLaunchKernelGGL(kpconv_fwd_kernel<4>, grid, block, 0, st, n, n0, K, C, KP, query_points, support_points, neighbors_indices, features, kernel_points, kernel_weights, extent, influence, closest, out);
-    else if (C > 16) hipLaunchKernelGGL(kpconv_fwd_kernel<2>, grid, block, 0, st, n, n0, K, C, KP, query_points, support_points, neighbors_indices, features, kernel_points, kernel_weights, extent, influence, closest, out);
-    else hipLaunchKernelGGL(kpconv_fwd_kernel<1>, grid, block, 0, st, n, n0, K, C, KP, query_points, support_points, neighbors_indices, features, kernel_points, kernel_weights, extent, influence, closest, out);
+    if (C % 4 == 0 && cbl_host_aligned16(features) && cbl_host_aligned16(out))
+        hipLaunchKernelGGL(kpconv_fwd_kernel<true>, grid, block, 0, st, n, n0, K, C, KP, query_points, support_points, neighbors_indices, features, kernel_points, kernel_weights, extent, influence, closest, out);
+    else
+        hipLaunchKernelGGL(kpconv_fwd_kernel<false>, grid, block, 0, st, n, n0, K, C, KP, query_points, support_points, neighbors_indices, features, kernel_points, kernel_weights, extent, influence, closest, out);
     return cbl_status();
 }
 
