@@ -29,7 +29,7 @@ def get_subscene_label(stage_n, stage_i, stage_list, target, nstride, num_classe
     p_from, o_from = stage_from["p_out"], stage_from["offset"]
     stage_to = stage_list[stage_n][stage_i]
     p_to, o_to = stage_to["p_out"], stage_to["offset"]
-    neighbor_idx, _ = pointops.knnquery_raw(kr, p_from, p_to, o_from, o_to)     # :30
+    neighbor_idx, _ = pointops.knnquery_raw(kr, p_from, p_to, o_from, o_to, algo="set")     # :30; a mean over the set
     m = p_to.shape[0]
     if target.dtype != torch.int64 or not target.is_cuda or not target.is_contiguous():
         raise TypeError("target must be a contiguous int64 CUDA tensor")

@@ -67,24 +67,17 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void knn_exact_wave_kernel(
     const float* __restrict__ xyz, const float* __restrict__ new_xyz,
     const int* __restrict__ offset, const int* __restrict__ new_offset,
     int* __restrict__ idx, float* __restrict__ dist2,
-    const int* __restrict__ worklist, const int* __restrict__ worklist_count)
+    const int* __restrict__ worklist, const int* __restrict__ worklist_count, int min_work)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int w = blockIdx.x * WAVES_PER_BLOCK + wave;              // wave-uniform work item
-
-    // optional indirection: only the queries listed in worklist[0 .. *worklist_count)
-    int q;
-    if (worklist) {
-        const int n_active = *worklist_count;
-        if (w >= n_active) return;
-        q = worklist[w];
-    } else {
-        if (w >= m) return;
-        q = w;
-    }
-    q = __builtin_amdgcn_readfirstlane(q);
+    // work items: all m queries, or (worklist mode) the listed queries — the latter only when the list is longer than
+    // `min_work` (shorter lists are taken by knn_replay_kernel), walked grid-stride
+    const int n_items = worklist ? *worklist_count : m;
+    if (worklist && n_items <= min_work) return;
+    for (int w = blockIdx.x * WAVES_PER_BLOCK + wave; w < n_items; w += gridDim.x * WAVES_PER_BLOCK) {
+    const int q = __builtin_amdgcn_readfirstlane(worklist ? worklist[w] : w);
 
     const int c = cbl_cloud_of(q, new_offset, b);
     const int start = (c == 0) ? 0 : offset[c - 1];                  // :75-79
@@ -140,6 +133,183 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void knn_exact_wave_kernel(
     } else {
         for (int j = lane; j < K; j += 64) { orow[j] = h.i[j]; drow[j] = h.d[j]; }
     }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Replay kernel for the handful of queries the grid kernel could not certify: ONE 1024-lane workgroup per query.
+// The reference's result depends on the full visiting history, but a support only matters if it beats the heap root at
+// its turn, and the root at turn t is the K-th smallest distance among supports [start, t) — non-increasing in t.  So:
+//   A. wave 0 feeds the first T0 supports to the heap in order (the dense part of the history);
+//      meanwhile wave 1 computes B = the K-th smallest distance among those T0 supports (bisection on the float bits): an
+//      upper bound of the root for every later turn, hence every later support with d2 >= B is a no-op and can be dropped;
+//   B. waves 1..15 filter the remaining supports against B in parallel into per-wave LDS lists, in index order
+//      (expected n*K/T0 survivors in total);
+//   C. wave 0 feeds the lists to the heap in order, then heap-sorts.
+// Identical heap operations as the straight scan, i.e. identical ties; the 40960-support scan no longer sits on one
+// wave's memory latency.  The heap insert itself is restructured: every lane first finds its slot's larger child
+// (4 cross-lane reads), then the sift walks the root path with scalar reads of those precomputed children.
+constexpr int RP_WAVES = 16, RP_T0 = 1024, RP_LIST = 512, RP_MAX_WORK = 1024, RP_GRID = 128;
+
+__device__ __forceinline__ void heap_replace_root_fast(float& hd, int& hi, int lane, int len, float d, int id)
+{
+    const int l = 2 * lane + 1, r = l + 1;
+    const float kl = __shfl(hd, l & 63), kr = __shfl(hd, r & 63);
+    const int il = __shfl(hi, l & 63), ir = __shfl(hi, r & 63);
+    const bool right = (r < len) && (kr > kl);               // right child only when strictly larger (:27)
+    const float bk = right ? kr : kl;
+    const int bi = right ? ir : il, bc = right ? r : l;
+    int p = 0;
+    while (2 * p + 1 < len) {
+        const float k = rl_f(bk, p);
+        if (d > k) break;                                     // stop only when strictly larger (:29)
+        const int c = rl_i(bc, p), ci = rl_i(bi, p);
+        if (lane == p) { hd = k; hi = ci; }
+        p = c;
+    }
+    if (lane == p) { hd = d; hi = id; }
+}
+
+__global__ __launch_bounds__(64 * RP_WAVES) void knn_replay_kernel(
+    int b, int K, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+    const int* __restrict__ offset, const int* __restrict__ new_offset,
+    int* __restrict__ idx, float* __restrict__ dist2,
+    const int* __restrict__ worklist, const int* __restrict__ worklist_count)
+{
+    __shared__ float dA[RP_T0];
+    __shared__ float cand_d[RP_WAVES][RP_LIST];
+    __shared__ int cand_i[RP_WAVES][RP_LIST];
+    __shared__ int cand_n[RP_WAVES];
+    __shared__ float bound_s;
+    __shared__ int overflow_s;
+
+    const int n_work = *worklist_count;
+    if (n_work > RP_MAX_WORK) return;                           // long lists (lattices: every query tied) go to the wave kernel
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int work = blockIdx.x; work < n_work; work += gridDim.x) {
+    __syncthreads();                                            // previous entry's LDS lists are no longer read
+    const int q = worklist[work];
+    const int c = cbl_cloud_of(q, new_offset, b);
+    const int start = (c == 0) ? 0 : offset[c - 1], end = offset[c];
+    const int n_c = end - start;
+    const int t0 = min(n_c, RP_T0);
+    const float qx = new_xyz[3 * q + 0], qy = new_xyz[3 * q + 1], qz = new_xyz[3 * q + 2];
+
+    {   // distances of the first t0 supports, one per lane
+        const int i = start + min(tid, max(t0 - 1, 0));
+        const float d = (t0 > 0) ? cbl_dist2(qx, qy, qz, xyz[3 * i + 0], xyz[3 * i + 1], xyz[3 * i + 2]) : INFINITY;
+        dA[tid] = (tid < t0) ? d : INFINITY;
+        if (tid < RP_WAVES) cand_n[tid] = 0;
+        if (tid == 0) { overflow_s = 0; bound_s = INFINITY; }
+    }
+    __syncthreads();
+
+    float hd = 1e10f; int hi = start;                           // heap slot `lane` of wave 0 (:91-94)
+    float root = 1e10f;
+    auto feed = [&](float d2, int first_index_of_chunk, const int* ids) {
+        unsigned long long mask = __ballot(d2 < root);          // strict, :100
+        while (mask) {
+            const int l = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const float dl = rl_f(d2, l);
+            if (dl < root) {
+                const int id = ids ? ids[l] : first_index_of_chunk + l;
+                heap_replace_root_fast(hd, hi, lane, K, dl, id);
+                root = rl_f(hd, 0);
+            }
+        }
+    };
+
+    if (wave == 0) {
+        // A (wave 0): the first t0 supports, in order
+        for (int base = 0; base < t0; base += 64) feed(dA[base + lane], start + base, nullptr);
+    } else {
+        if (wave == 1 && n_c > t0) {
+            // A (wave 1): K-th smallest of dA by bisection on the bit patterns (all values >= 0)
+            unsigned v[RP_T0 / 64];
+#pragma unroll
+            for (int j = 0; j < RP_T0 / 64; j++) v[j] = __float_as_uint(dA[lane + 64 * j]);
+            unsigned lo = 0u, hi_b = 0x7f800000u;
+            while (lo < hi_b) {
+                const unsigned mid = lo + ((hi_b - lo) >> 1);
+                int cnt = 0;
+#pragma unroll
+                for (int j = 0; j < RP_T0 / 64; j++) cnt += (v[j] <= mid) ? 1 : 0;
+#pragma unroll
+                for (int sft = 32; sft >= 1; sft >>= 1) cnt += __shfl_xor(cnt, sft);
+                if (cnt >= K) hi_b = mid; else lo = mid + 1;
+            }
+            if (lane == 0) bound_s = __uint_as_float(lo);       // +inf if fewer than K finite values: nothing can be dropped
+        }
+    }
+    __syncthreads();
+
+    if (n_c > t0) {
+        // B: every wave filters its contiguous share of [t0, n_c) against the bound, keeping index order
+        const float B = bound_s;
+        const int rem = n_c - t0;
+        const int per = ((rem + RP_WAVES * 64 - 1) / (RP_WAVES * 64)) * 64;
+        const int lo_i = start + t0 + wave * per, hi_i = min(end, lo_i + per);
+        int filled = 0;
+        constexpr int U = 4;
+        for (int base = lo_i; base < hi_i; base += 64 * U) {
+            float d2[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = base + 64 * u + lane;
+                const int ic = min(i, end - 1);
+                const float d = cbl_dist2(qx, qy, qz, xyz[3 * ic + 0], xyz[3 * ic + 1], xyz[3 * ic + 2]);
+                d2[u] = (i < hi_i) ? d : INFINITY;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const bool keep = d2[u] < B;
+                const unsigned long long m = __ballot(keep);
+                const int pos = filled + __popcll(m & ((1ull << lane) - 1ull));
+                if (keep) {
+                    if (pos < RP_LIST) { cand_d[wave][pos] = d2[u]; cand_i[wave][pos] = base + 64 * u + lane; }
+                    else overflow_s = 1;
+                }
+                filled += __popcll(m);
+            }
+        }
+        if (lane == 0) cand_n[wave] = min(filled, RP_LIST);
+    }
+    __syncthreads();
+
+    if (wave != 0) continue;
+    if (n_c > t0) {
+        if (!overflow_s) {
+            // C: the survivors, wave list after wave list = ascending support index
+            for (int w = 0; w < RP_WAVES; w++) {
+                const int cn = cand_n[w];
+                for (int base = 0; base < cn; base += 64) {
+                    const int j = base + lane;
+                    const float d2 = (j < cn) ? cand_d[w][j] : INFINITY;
+                    feed(d2, 0, &cand_i[w][base]);
+                }
+            }
+        } else {
+            // a list overflowed (adversarial data, e.g. thousands of supports closer than the first 1024): plain ordered scan
+            for (int base = start + t0; base < end; base += 64) {
+                const int i = base + lane;
+                const int ic = min(i, end - 1);
+                const float d = cbl_dist2(qx, qy, qz, xyz[3 * ic + 0], xyz[3 * ic + 1], xyz[3 * ic + 2]);
+                feed((i < end) ? d : INFINITY, base, nullptr);
+            }
+        }
+    }
+    // heap_sort(), :39-48
+    for (int last = K - 1; last > 0; last--) {
+        const float d = rl_f(hd, last); const int id = rl_i(hi, last);
+        const float r0 = rl_f(hd, 0); const int i0 = rl_i(hi, 0);
+        if (lane == last) { hd = r0; hi = i0; }
+        heap_replace_root_fast(hd, hi, lane, last, d, id);
+    }
+    if (lane < K) { idx[(size_t)q * K + lane] = hi; dist2[(size_t)q * K + lane] = hd; }
+    }
 }
 
 }  // namespace
@@ -150,13 +320,21 @@ static int launch_knn_exact(int b, int m, int K, const float* xyz, const float* 
 {
     const int nq = worklist ? max_work : m;
     if (nq <= 0) return CBL_OK;
-    const dim3 grid(cbl_div_up(nq, WAVES_PER_BLOCK)), block(64 * WAVES_PER_BLOCK);
+    int min_work = 0;
+    if (worklist && K <= 64) {
+        // short lists (the normal case: a handful of tied queries): one 1024-lane workgroup per entry
+        hipLaunchKernelGGL(knn_replay_kernel, dim3(min(nq, RP_GRID)), dim3(64 * RP_WAVES), 0, st, b, K, xyz, new_xyz, offset, new_offset, idx, dist2, worklist, worklist_count);
+        if (nq <= RP_MAX_WORK) return cbl_status();
+        min_work = RP_MAX_WORK;                                 // longer lists: wave per entry (below), a no-op otherwise
+    }
+    const unsigned blocks = worklist ? (unsigned)min((long long)cbl_div_up(nq, WAVES_PER_BLOCK), 2048LL) : cbl_div_up(nq, WAVES_PER_BLOCK);
+    const dim3 grid(blocks), block(64 * WAVES_PER_BLOCK);
     if (K <= 64)
         hipLaunchKernelGGL(knn_exact_wave_kernel<true>, grid, block, 0, st,
-                           b, m, K, xyz, new_xyz, offset, new_offset, idx, dist2, worklist, worklist_count);
+                           b, m, K, xyz, new_xyz, offset, new_offset, idx, dist2, worklist, worklist_count, min_work);
     else
         hipLaunchKernelGGL(knn_exact_wave_kernel<false>, grid, block, (size_t)WAVES_PER_BLOCK * K * 8, st,
-                           b, m, K, xyz, new_xyz, offset, new_offset, idx, dist2, worklist, worklist_count);
+                           b, m, K, xyz, new_xyz, offset, new_offset, idx, dist2, worklist, worklist_count, min_work);
     return cbl_status();
 }
 

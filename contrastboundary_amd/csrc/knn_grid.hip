@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void knn_grid_group_kernel(int b, int m, int K
                                                              const int* __restrict__ offset, const int* __restrict__ new_offset,
                                                              const CblGrid* __restrict__ grids, const int* __restrict__ cell_start,
                                                              const float4* __restrict__ sorted, int* __restrict__ idx, float* __restrict__ dist2,
-                                                             int* __restrict__ worklist, int* __restrict__ counters)
+                                                             int* __restrict__ worklist, int* __restrict__ counters, int set_exact)
 {
     constexpr int QPW = 64 / G;                                     // queries per wave
     using mask_t = unsigned long long;
@@ -297,7 +297,9 @@ __global__ __launch_bounds__(256) void knn_grid_group_kernel(int b, int m, int K
     const float pd = dpp_shr1_f<G>(ed);
     const bool dup = (gl > 0) && (gl < K) && (ed == pd);
     const mask_t dm = (__ballot(dup) >> (grp * G)) & (G == 64 ? ~0ull : ((1ull << G) - 1ull));
-    const bool ok = (worst < INFINITY) && (rm != worst) && (dm == 0);
+    // set_exact: the caller only needs the reference's neighbour SET (sorted by distance); equal distances INSIDE the list
+    // leave the set unambiguous, so only a tie at the K-th boundary (or an unfilled list) still needs the replay
+    const bool ok = (worst < INFINITY) && (rm != worst) && (set_exact || dm == 0);
     if (live) {
         if (gl < K) { idx[(size_t)q * K + gl] = ei; dist2[(size_t)q * K + gl] = ed; }
         if (!ok && gl == 0) worklist[atomicAdd(counters, 1)] = q;
@@ -306,12 +308,12 @@ __global__ __launch_bounds__(256) void knn_grid_group_kernel(int b, int m, int K
 
 template <int G>
 void launch_query(bool self, int b, int m, int K, const float* new_xyz, const int* offset, const int* new_offset, const Workspace& w,
-                  int* idx, float* dist2, hipStream_t st)
+                  int* idx, float* dist2, int set_exact, hipStream_t st)
 {
     const long long waves = ((long long)m + (64 / G) - 1) / (64 / G);
     const dim3 grid(cbl_div_up(waves, 4)), block(256);
-    if (self) hipLaunchKernelGGL((knn_grid_group_kernel<G, true>), grid, block, 0, st, b, m, K, new_xyz, offset, new_offset, w.grids, w.cell_start, w.sorted, idx, dist2, w.worklist, w.counters);
-    else      hipLaunchKernelGGL((knn_grid_group_kernel<G, false>), grid, block, 0, st, b, m, K, new_xyz, offset, new_offset, w.grids, w.cell_start, w.sorted, idx, dist2, w.worklist, w.counters);
+    if (self) hipLaunchKernelGGL((knn_grid_group_kernel<G, true>), grid, block, 0, st, b, m, K, new_xyz, offset, new_offset, w.grids, w.cell_start, w.sorted, idx, dist2, w.worklist, w.counters, set_exact);
+    else      hipLaunchKernelGGL((knn_grid_group_kernel<G, false>), grid, block, 0, st, b, m, K, new_xyz, offset, new_offset, w.grids, w.cell_start, w.sorted, idx, dist2, w.worklist, w.counters, set_exact);
 }
 
 
@@ -427,7 +429,7 @@ size_t cbl_knn_grid_workspace_bytes(int b, int n, int m, int nsample)
 }
 
 int cbl_knn_grid_launch(int b, int n, int m, int nsample, const float* xyz, const float* new_xyz, const int* offset,
-                        const int* new_offset, int* idx, float* dist2, void* ws, size_t ws_bytes, hipStream_t st)
+                        const int* new_offset, int* idx, float* dist2, void* ws, size_t ws_bytes, int set_exact, hipStream_t st)
 {
     Workspace w = carve(ws, b, n, m);
     if (ws_bytes < w.bytes) return CBL_ERR_WORKSPACE;
@@ -436,9 +438,9 @@ int cbl_knn_grid_launch(int b, int n, int m, int nsample, const float* xyz, cons
     int rc = cbl_grid_build(b, n, 0.42f * (float)(nsample < 4 ? 4 : nsample), xyz, offset, ws, st);
     if (rc) return rc;
     const bool self = (new_xyz == xyz) && (m == n);
-    if (G == 16)      launch_query<16>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, st);
-    else if (G == 32) launch_query<32>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, st);
-    else              launch_query<64>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, st);
+    if (G == 16)      launch_query<16>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, set_exact, st);
+    else if (G == 32) launch_query<32>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, set_exact, st);
+    else              launch_query<64>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, set_exact, st);
     rc = cbl_status();
     if (rc) return rc;
     // exact replay of everything that was not certified (device-side count, no host sync)

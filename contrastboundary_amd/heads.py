@@ -106,7 +106,7 @@ class ContrastHead(torch.nn.Module):
             labels = target                                               # one-hot's argmax is the label itself
         else:
             labels = get_subscene_label(n, i, stage_list, target, self.nstride, self.num_classes)   # :189
-        neighbor_idx, _ = pointops.knnquery_raw(self.nsample[i], p, p, o, o)                       # :192
+        neighbor_idx, _ = pointops.knnquery_raw(self.nsample[i], p, p, o, o, algo="set")           # :192; the mining is order-invariant
         return point_contrast(features, labels, neighbor_idx, self.temperature, self.weight)
 
     def forward(self, output, target, stage_list):

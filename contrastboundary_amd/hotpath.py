@@ -68,7 +68,7 @@ def stages(scene, k=16):
     def cbl(s):
         # the CBL head of stage 0 (heads.py:185-246): its own KNN (nsample = 36), pair mining + soft-NN loss, backward to the latent
         latent = scene.latent.detach().requires_grad_(True)
-        nidx, _ = pointops.knnquery_raw(CBL_NSAMPLE, scene.xyz, scene.xyz, scene.offset, scene.offset)
+        nidx, _ = pointops.knnquery_raw(CBL_NSAMPLE, scene.xyz, scene.xyz, scene.offset, scene.offset, algo="set")
         loss = heads.point_contrast(latent, scene.labels, nidx, 1.0, 0.1)
         loss.backward()
         s["cbl_loss"], s["cbl_grad"] = loss.detach(), latent.grad

@@ -75,7 +75,8 @@ def _workspace(nbytes, device):
 
 
 def knnquery_raw(nsample, xyz, new_xyz, offset, new_offset, algo="auto"):
-    """-> idx (m,nsample) i32, dist2 (m,nsample) f32 (squared).  algo: 'auto' | 'exact' | 'grid'"""
+    """-> idx (m,nsample) i32, dist2 (m,nsample) f32 (squared).  algo: 'auto' | 'exact' | 'grid' | 'set'
+    ('set': same neighbour set and distances, order among exactly equal distances unspecified — cbl_knnquery_set)"""
     nsample = _as_int(nsample)
     if new_xyz is None:
         new_xyz = xyz
@@ -98,7 +99,8 @@ def knnquery_raw(nsample, xyz, new_xyz, offset, new_offset, algo="auto"):
         if algo == "grid" and need == 0:
             raise _lib.CblError("grid KNN not available for this problem shape")
         ws = _workspace(need, xyz.device)
-        _lib.check(L.cbl_knnquery(*args, _lib.ptr(ws), ctypes.c_size_t(ws.numel() if ws is not None else 0), st), "cbl_knnquery")
+        fn = L.cbl_knnquery_set if algo == "set" else L.cbl_knnquery
+        _lib.check(fn(*args, _lib.ptr(ws), ctypes.c_size_t(ws.numel() if ws is not None else 0), st), "cbl_knnquery")
     return idx, dist2
 
 

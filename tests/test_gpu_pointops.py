@@ -235,3 +235,18 @@ def test_full_size_properties(P):
     grouped.backward(torch.ones_like(grouped))
     deg = torch.bincount(idx.view(-1).long(), minlength=n).float()
     assert torch.equal(feat.grad, deg[:, None].expand(-1, c))
+
+
+def test_knn_set_variant(P):
+    """cbl_knnquery_set: identical distances and neighbour sets; only the order inside groups of equal distance is free"""
+    g = np.arange(9, dtype=np.float32)
+    lat = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    rng = np.random.default_rng(0)
+    rnd = rng.uniform(0, 2, (5000, 3)).astype(np.float32)
+    rnd[100:110] = rnd[50:60]                                   # duplicated points -> ties
+    for xyz, k in ((np.concatenate([lat] * 4), 7), (rnd, 16), (rnd, 36)):
+        n = len(xyz); o = dev(np.int32([n]))
+        idx, d2 = P.knnquery_raw(k, dev(xyz), dev(xyz), o, o, algo="set")
+        ridx, rd2 = O.knnquery(k, xyz, xyz, [n], [n])
+        np.testing.assert_array_equal(d2.cpu().numpy().view(np.uint32), rd2.view(np.uint32))
+        np.testing.assert_array_equal(np.sort(idx.cpu().numpy(), 1), np.sort(ridx, 1))
