@@ -33,6 +33,7 @@ struct Workspace {
     unsigned* bbox;      // [6*b] order-preserving keys of the per-cloud min / max
     int* cell_count;     // [ncap + 1]  histogram, then running fill cursor
     int* cell_start;     // [ncap + 1]  exclusive scan
+    int* cell_local;     // [ncap + 1]  tile-local exclusive scan (intermediate)
     int* tile_sum;       // [ceil((ncap + 1) / 4096)]
     int* pt_cell;        // [n]
     float4* sorted;      // [n]
@@ -55,6 +56,7 @@ Workspace carve(void* base, int b, int n, int m)
     w.bbox = reinterpret_cast<unsigned*>(take(sizeof(unsigned) * 6 * (size_t)b));
     w.cell_count = reinterpret_cast<int*>(take(sizeof(int) * ((size_t)w.ncap + 1)));
     w.cell_start = reinterpret_cast<int*>(take(sizeof(int) * ((size_t)w.ncap + 1)));
+    w.cell_local = reinterpret_cast<int*>(take(sizeof(int) * ((size_t)w.ncap + 1)));
     w.tile_sum = reinterpret_cast<int*>(take(sizeof(int) * ((size_t)w.ncap / 4096 + 2)));
     w.pt_cell = reinterpret_cast<int*>(take(sizeof(int) * (size_t)n));
     w.sorted = reinterpret_cast<float4*>(take(sizeof(float4) * (size_t)n));
@@ -94,15 +96,15 @@ __global__ __launch_bounds__(256) void grid_bbox_kernel(int b, int n, const floa
 #pragma unroll
         for (int a = 0; a < 3; a++) {
             for (int s = 32; s >= 1; s >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], s)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], s)); }
-            if (lane == 0) { atomicMin(bbox + c0 * 6 + a, f2key(lo[a])); atomicMax(bbox + c0 * 6 + 3 + a, f2key(hi[a])); }
+            // 6 atomics per wave round: ~1000 atomics on 6 addresses for a 40960-point cloud; they serialise in L2 but cost
+            // less than a cross-wave LDS stage would for clouds that straddle workgroups
+            if (lane == 0 && lo[a] <= hi[a]) { atomicMin(bbox + c0 * 6 + a, f2key(lo[a])); atomicMax(bbox + c0 * 6 + 3 + a, f2key(hi[a])); }
         }
     }
 }
 
-__global__ void grid_setup_kernel(int b, float pts_per_cell, const int* __restrict__ offset, const unsigned* __restrict__ bbox, CblGrid* __restrict__ grids)
+__device__ __forceinline__ CblGrid grid_of_cloud(int c, float pts_per_cell, const int* __restrict__ offset, const unsigned* __restrict__ bbox)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= b) return;
     const int start = c ? offset[c - 1] : 0, end = offset[c];
     float l[3] = {0.f, 0.f, 0.f}, h[3] = {0.f, 0.f, 0.f};
     if (end > start)
@@ -113,16 +115,20 @@ __global__ void grid_setup_kernel(int b, float pts_per_cell, const int* __restri
     else cbl_grid_choose(g, l, h, end - start, pts_per_cell, cap);
     g.cell_base = CELLS_PER_POINT * start + CELLS_PER_CLOUD * c;
     g.start = start; g.end = end; g.pad0 = g.pad1 = 0;
-    grids[c] = g;
+    return g;
 }
 
-// ---- 2a. histogram -------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void grid_count_kernel(int b, int n, const float* __restrict__ xyz, const int* __restrict__ offset,
-                                                         const CblGrid* __restrict__ grids, int* __restrict__ pt_cell, int* __restrict__ cell_count)
+// ---- 2a. grid parameters (derived from the bounding boxes by every workgroup, published by workgroup 0) + histogram ----
+__global__ __launch_bounds__(256) void grid_count_kernel(int b, int n, float pts_per_cell, const float* __restrict__ xyz, const int* __restrict__ offset,
+                                                         const unsigned* __restrict__ bbox, CblGrid* __restrict__ grids,
+                                                         int* __restrict__ pt_cell, int* __restrict__ cell_count)
 {
+    if (blockIdx.x == 0)
+        for (int c = threadIdx.x; c < b; c += 256) grids[c] = grid_of_cloud(c, pts_per_cell, offset, bbox);
+    int cached_c = -1; CblGrid g;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const int c = cbl_cloud_of(i, offset, b);
-        const CblGrid g = grids[c];
+        if (c != cached_c) { g = grid_of_cloud(c, pts_per_cell, offset, bbox); cached_c = c; }
         const int cell = cbl_cell_of(g, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
         pt_cell[i] = cell;
         atomicAdd(cell_count + cell, 1);
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(256) void grid_count_kernel(int b, int n, const flo
 // in cell_count.  (A single-workgroup scan is latency-bound: ~1 us per dependent L2 round trip.)
 constexpr int SCAN_TILE = 4096;
 
-__global__ __launch_bounds__(256) void grid_scan_tiles_kernel(int total, const int* __restrict__ cell_count, int* __restrict__ cell_start,
+__global__ __launch_bounds__(256) void grid_scan_tiles_kernel(int total, const int* __restrict__ cell_count, int* __restrict__ cell_start_local,
                                                               int* __restrict__ tile_sum)
 {
     __shared__ int wsum[4];
@@ -163,34 +169,29 @@ __global__ __launch_bounds__(256) void grid_scan_tiles_kernel(int total, const i
     for (int w = 0; w < wave; w++) off += wsum[w];
     if (tid == 255) tile_sum[blockIdx.x] = off + sum;
 #pragma unroll
-    for (int j = 0; j < 16; j++) if (base + j < total) cell_start[base + j] = off + v[j];
+    for (int j = 0; j < 16; j++) if (base + j < total) cell_start_local[base + j] = off + v[j];
 }
 
-__global__ __launch_bounds__(256) void grid_scan_fix_kernel(int total, int ntiles, const int* __restrict__ tile_sum,
-                                                            int* __restrict__ cell_start, int* __restrict__ cell_count)
+// ---- 2c. finish the scan (add each tile's prefix -> final cell_start) and scatter the supports into cell order ---------
+// Slot of a point = cell_start[cell] + (atomicSub(count[cell]) - 1): the histogram is consumed instead of a separate cursor array
+// (the order inside a cell is irrelevant) and ends at zero, ready for the next build.
+__global__ __launch_bounds__(256) void grid_scatter_kernel(int n, int total, int ntiles, const float* __restrict__ xyz, const int* __restrict__ pt_cell,
+                                                           const int* __restrict__ tile_sum, int* __restrict__ cell_start_local, int* __restrict__ cell_start,
+                                                           int* __restrict__ cell_count, float4* __restrict__ sorted)
 {
-    __shared__ int wsum[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int pre = 0;                                          // sum of the totals of all earlier tiles
-    for (int t = tid; t < (int)blockIdx.x; t += 256) pre += tile_sum[t];
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) pre += __shfl_xor(pre, s);
-    if (lane == 0) wsum[wave] = pre;
-    __syncthreads();
-    pre = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    const int base = blockIdx.x * SCAN_TILE + tid * 16;
-#pragma unroll
-    for (int j = 0; j < 16; j++)
-        if (base + j < total) { const int x = cell_start[base + j] + pre; cell_start[base + j] = x; cell_count[base + j] = x; }
-    (void)ntiles;
-}
-
-// ---- 2c. scatter into cell order ------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void grid_scatter_kernel(int n, const float* __restrict__ xyz, const int* __restrict__ pt_cell,
-                                                           int* __restrict__ cell_cursor, float4* __restrict__ sorted)
-{
+    extern __shared__ int tile_lds[];                      // [0, ntiles): tile totals, [ntiles, 2*ntiles): their exclusive prefix
+    int* tile_pre = tile_lds + ntiles;
+    {
+        // every workgroup rebuilds the (short) prefix of the tile totals itself: cheaper than another launch
+        for (int t = threadIdx.x; t < ntiles; t += 256) tile_lds[t] = tile_sum[t];       // independent loads, all in flight
+        __syncthreads();
+        for (int t = threadIdx.x; t < ntiles; t += 256) { int run = 0; for (int u = 0; u < t; u++) run += tile_lds[u]; tile_pre[t] = run; }
+        __syncthreads();
+    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) cell_start[i] = cell_start_local[i] + tile_pre[i / SCAN_TILE];
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const int pos = atomicAdd(cell_cursor + pt_cell[i], 1);
+        const int cell = pt_cell[i];
+        const int pos = cell_start_local[cell] + tile_pre[cell / SCAN_TILE] + atomicSub(cell_count + cell, 1) - 1;
         sorted[pos] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], __int_as_float(i));
     }
 }
@@ -239,8 +240,14 @@ __global__ __launch_bounds__(256) void knn_grid_group_kernel(int b, int m, int K
     for (int r = 1;; r++) {
         // r == 1: the 3x3x3 block around the query's cell (shells 0 and 1) as 9 full rows;
         // r >= 2: shell r — face rows take the whole x-range, interior rows only the two end cells
-        for (int dz = -r; dz <= r; dz++) {
-            for (int dy = -r; dy <= r; dy++) {
+        // rows of the (2r+1)^2 (dy,dz) square, nearest first for the initial block: the row through the query's own cell, the 4
+        // face rows, the 4 corner rows — the list fills with near candidates early, so far rows rarely pass `d2 < worst`
+        const int side = 2 * r + 1;
+        for (int ri = 0; ri < side * side; ri++) {
+            int dy, dz;
+            if (r == 1) { const int o = (int)((0xa82091645ull >> (4 * ri)) & 0xFull); dy = (o & 3) - 1; dz = (o >> 2) - 1; }   // packed order table below
+            else        { dz = ri / side - r; dy = ri % side - r; }
+            {
                 const bool full = (r == 1) || dz == -r || dz == r || dy == -r || dy == r;
                 const int nseg = full ? 1 : 2;
                 for (int sg = 0; sg < nseg; sg++) {
@@ -397,26 +404,25 @@ int cbl_bbox_keys_launch(int b, int n, const float* xyz, const int* offset, unsi
     return cbl_status();
 }
 
-__global__ void grid_init_kernel(int b, int* __restrict__ counters, unsigned* __restrict__ bbox)
+__global__ __launch_bounds__(256) void grid_init_kernel(int b, int total, int* __restrict__ counters, unsigned* __restrict__ bbox, int* __restrict__ cell_count)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 64) counters[i] = 0;
-    if (i < 6 * b) bbox[i] = ((i % 6) < 3) ? 0xffffffffu : 0u;
+    const int i0 = blockIdx.x * 256 + threadIdx.x;
+    if (i0 < 64) counters[i0] = 0;
+    if (i0 < 6 * b) bbox[i0] = ((i0 % 6) < 3) ? 0xffffffffu : 0u;
+    for (int i = i0; i < total; i += gridDim.x * 256) cell_count[i] = 0;
 }
 
 int cbl_grid_build(int b, int n, float pts_per_cell, const float* xyz, const int* offset, void* ws, hipStream_t st)
 {
+    // 5 launches: init+zero | bbox | grid params + histogram | tile scans | scan finish + scatter
     Workspace w = carve(ws, b, n, 0);
-    hipError_t e = hipMemsetAsync(w.cell_count, 0, sizeof(int) * ((size_t)w.ncap + 1), st);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(grid_init_kernel, dim3(cbl_div_up(max(64, 6 * b), 256)), dim3(256), 0, st, b, w.counters, w.bbox);
-    hipLaunchKernelGGL(grid_bbox_kernel, dim3(cbl_grid_for(n, 1024, 512)), dim3(256), 0, st, b, n, xyz, offset, w.bbox);
-    hipLaunchKernelGGL(grid_setup_kernel, dim3(cbl_div_up(b, 64)), dim3(64), 0, st, b, pts_per_cell, offset, w.bbox, w.grids);
-    hipLaunchKernelGGL(grid_count_kernel, dim3(cbl_grid_for(n, 256)), dim3(256), 0, st, b, n, xyz, offset, w.grids, w.pt_cell, w.cell_count);
     const int total = w.ncap + 1, ntiles = (total + SCAN_TILE - 1) / SCAN_TILE;
-    hipLaunchKernelGGL(grid_scan_tiles_kernel, dim3(ntiles), dim3(256), 0, st, total, w.cell_count, w.cell_start, w.tile_sum);
-    hipLaunchKernelGGL(grid_scan_fix_kernel, dim3(ntiles), dim3(256), 0, st, total, ntiles, w.tile_sum, w.cell_start, w.cell_count);
-    hipLaunchKernelGGL(grid_scatter_kernel, dim3(cbl_grid_for(n, 256)), dim3(256), 0, st, n, xyz, w.pt_cell, w.cell_count, w.sorted);
+    hipLaunchKernelGGL(grid_init_kernel, dim3(cbl_grid_for(total, 256, 512)), dim3(256), 0, st, b, total, w.counters, w.bbox, w.cell_count);
+    hipLaunchKernelGGL(grid_bbox_kernel, dim3(cbl_grid_for(n, 1024, 512)), dim3(256), 0, st, b, n, xyz, offset, w.bbox);
+    hipLaunchKernelGGL(grid_count_kernel, dim3(cbl_grid_for(n, 256)), dim3(256), 0, st, b, n, pts_per_cell, xyz, offset, w.bbox, w.grids, w.pt_cell, w.cell_count);
+    hipLaunchKernelGGL(grid_scan_tiles_kernel, dim3(ntiles), dim3(256), 0, st, total, w.cell_count, w.cell_local, w.tile_sum);
+    hipLaunchKernelGGL(grid_scatter_kernel, dim3(cbl_grid_for(n, 256)), dim3(256), 2 * sizeof(int) * (size_t)ntiles, st, n, total, ntiles, xyz, w.pt_cell,
+                       w.tile_sum, w.cell_local, w.cell_start, w.cell_count, w.sorted);
     return cbl_status();
 }
 
