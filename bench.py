@@ -98,13 +98,27 @@ def main():
 
     # per-stage average device time from the HIP events recorded inside the timed region (same stream as the launches)
     stage_ms = [float(np.mean([ev[s][i][0].elapsed_time(ev[s][i][1]) for s in range(args.steps)])) for i in range(len(stages))]
+    names = [st[0] for st in stages]
+    gbps = lambda i: stages[i][2] / (stage_ms[i] * 1e-3) / 1e9
     dom = int(np.argmax(stage_ms))
-    name, _, abytes, aflops = stages[dom]
-    ach_gbs = abytes / (stage_ms[dom] * 1e-3) / 1e9
-    roofline = {"kernel": name, "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
-                "stage_ms": {stages[i][0]: round(stage_ms[i], 4) for i in range(len(stages))},
-                "stage_algorithmic_GBps": {stages[i][0]: round(stages[i][2] / (stage_ms[i] * 1e-3) / 1e9, 1) for i in range(len(stages))}}
+    # kernel that dominates each stage (rocprofv3 --kernel-trace --stats of this same command: profiles/)
+    main_kernel = {"knnquery_k16": "knn_grid_group_kernel<16> (+ 5-launch grid build, knn_replay_kernel for tied queries)",
+                   "queryandgroup": "query_group_v4", "kpconv_fwd": "kpconv_fwd_kernel (v_mfma_f32_16x16x4_f32)",
+                   "cbl_knnquery_k36": "knn_grid_group_kernel<64> (+ 5-launch grid build)",
+                   "cbl_mining_loss_fwd": "contrast_fwd_kernel<64,8> (+ finalize)", "cbl_mining_loss_bwd": "contrast_bwd_kernel<64,8>"}
+    roofline = {"kernel": main_kernel.get(names[dom], names[dom]), "stage": names[dom], "bound": "hbm",
+                "achieved": gbps(dom), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps(dom) / HBM_PEAK_GBS, "traffic": None,
+                "note": "achieved = SURVEY 8(d) algorithmic bytes of the stage / its HIP-event time; the neighbour searches move few "
+                        "compulsory bytes (they are latency/issue bound, not HBM bound) - the HBM-bound kernel of the path is the gather, see hbm_gather",
+                "stage_ms": {names[i]: round(stage_ms[i], 4) for i in range(len(stages))},
+                "stage_algorithmic_GBps": {names[i]: round(gbps(i), 1) for i in range(len(stages))}}
+    gi = names.index("queryandgroup")
+    roofline["hbm_gather"] = {"kernel": "query_group_v4", "bound": "hbm", "achieved": gbps(gi), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": gbps(gi) / HBM_PEAK_GBS, "bytes_per_launch": stages[gi][2]}
+    ki = names.index("kpconv_fwd")
+    roofline["mfma_kpconv"] = {"kernel": "kpconv_fwd_kernel", "bound": "mfma", "achieved": stages[ki][3] / (stage_ms[ki] * 1e-3) / 1e12,
+                               "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": stages[ki][3] / (stage_ms[ki] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                               "note": "f32-input MFMA; the kernel is bound by gathering K feature rows per point, not by the matrix pipe"}
 
     if rank == 0:
         out = {

@@ -65,17 +65,23 @@ def stages(scene, k=16):
     # a15 (idx given): 12n + 12n0 + 4n0C + 4nK + 4nC bytes; flops 2nK*KP*(C + 6) + 2n*KP*C  
     st.append(("kpconv_fwd", kpconv, 12 * n + 12 * n + 4 * n * c + 4 * n * k + 4 * n * c, 2.0 * n * k * KP * (c + 6) + 2.0 * n * KP * c))
 
-    def cbl(s):
-        # the CBL head of stage 0 (heads.py:185-246): its own KNN (nsample = 36), pair mining + soft-NN loss, backward to the latent
-        latent = scene.latent.detach().requires_grad_(True)
-        nidx, _ = pointops.knnquery_raw(CBL_NSAMPLE, scene.xyz, scene.xyz, scene.offset, scene.offset, algo="set")
-        loss = heads.point_contrast(latent, scene.labels, nidx, 1.0, 0.1)
-        loss.backward()
-        s["cbl_loss"], s["cbl_grad"] = loss.detach(), latent.grad
     d = CBL_DIM
-    # a8 mining (idx given) 4n(K-1) + 4nd + 4n fwd, the same again + 4nd written bwd; + the K=36 KNN's compulsory 24n + 8n*36
-    st.append(("cbl_head_fwd_bwd", cbl, 2 * (4 * n * (CBL_NSAMPLE - 1) + 4 * n * d + 4 * n) + 4 * n * d + 24 * n + 8 * n * CBL_NSAMPLE,
-               2.0 * n * (CBL_NSAMPLE - 1) * (3 * d + 20)))
+
+    def cbl_knn(s):
+        # the CBL head of stage 0 (heads.py:185-246) searches its own neighbourhoods: nsample = 36, order-invariant consumer
+        s["cbl_idx"], _ = pointops.knnquery_raw(CBL_NSAMPLE, scene.xyz, scene.xyz, scene.offset, scene.offset, algo="set")
+    st.append(("cbl_knnquery_k%d" % CBL_NSAMPLE, cbl_knn, 24 * n + 8 * n * CBL_NSAMPLE, 8.0 * n * n))
+
+    def cbl_fwd(s):
+        s["cbl_latent"] = scene.latent.detach().requires_grad_(True)
+        s["cbl_loss"] = heads.point_contrast(s["cbl_latent"], scene.labels, s["cbl_idx"], 1.0, 0.1)
+    # a8 mining (idx given): 4n(K-1) idx + 4nd features + 4n labels in, 8n out
+    st.append(("cbl_mining_loss_fwd", cbl_fwd, 4 * n * (CBL_NSAMPLE - 1) + 4 * n * d + 4 * n + 8 * n, 1.0 * n * (CBL_NSAMPLE - 1) * (3 * d + 20)))
+
+    def cbl_bwd(s):
+        s["cbl_loss"].backward()
+        s["cbl_grad"] = s["cbl_latent"].grad
+    st.append(("cbl_mining_loss_bwd", cbl_bwd, 4 * n * (CBL_NSAMPLE - 1) + 4 * n * d + 4 * n + 4 * n * d, 1.0 * n * (CBL_NSAMPLE - 1) * (5 * d + 30)))
     return st
 
 

@@ -17,6 +17,8 @@ def run_rest(scene, idx, k):
     parts["kpconv_fwd"] = time.perf_counter() - t
     t = time.perf_counter()
     nidx, _ = O.knnquery(hotpath.CBL_NSAMPLE, scene["xyz"], scene["xyz"], scene["offset"], scene["offset"])
+    parts["cbl_knnquery_k%d" % hotpath.CBL_NSAMPLE] = time.perf_counter() - t
+    t = time.perf_counter()
     C.point_contrast(scene["latent"], np.eye(13, dtype=np.float32)[scene["labels"]], nidx, temperature=1.0, weight=0.1)
-    parts["cbl_head_fwd_bwd"] = time.perf_counter() - t
+    parts["cbl_mining_loss_fwd+bwd"] = time.perf_counter() - t
     return parts
