@@ -1,0 +1,137 @@
+"""Host mirror of the Point-Transformer blocks of the reference, /root/reference/pytorch/model/blocks.py:
+    PointTransformerLayer :14-44 (vector attention over K neighbours), TransitionDown :47-77, TransitionUp :80-109,
+    PointTransformerBlock :112-136.
+Same class names, constructor arguments, parameter / sub-module names (state_dicts are interchangeable) and numbers.  What
+changes is how the K-neighbour part runs:
+  * ONE knnquery per layer (the reference runs two identical ones, blocks.py:34-35) — pass `idx=` to share it per stage;
+  * relative coordinates come from the fused gather (cbl_queryandgroup with c = 0), `k_j - q_i` from the subtraction kernel
+    (K7) and the final `sum_k (v_j + p_r) * w` from the aggregation kernel (K9, share_planes = c % w_c): the gathered
+    (n,K,C) copies of x_k / x_v and the 4-d view/sum of blocks.py:43 are never materialised;
+  * BatchNorm over (n*K) rows is applied on the flattened view (same statistics as the reference's transpose → BN1d →
+    transpose, blocks.py:38,40, without the two transposed copies).
+Dense layers (Linear, BatchNorm, ReLU, softmax over K) stay torch (rocBLAS / elementwise): they are not neighbourhood work.
+"""
+import torch
+import torch.nn as nn
+
+from . import pointops
+
+
+def _bn_rows(bn, x):
+    """BatchNorm1d over all leading dims of x (..., C) == bn(x.transpose(1,2)).transpose(1,2) of the reference"""
+    shape = x.shape
+    return bn(x.reshape(-1, shape[-1])).view(shape)
+
+
+class PointTransformerLayer(nn.Module):
+    def __init__(self, in_planes, out_planes, share_planes=8, nsample=16):
+        super().__init__()
+        self.mid_planes = mid_planes = out_planes // 1
+        self.out_planes = out_planes
+        self.share_planes = share_planes
+        self.nsample = nsample
+        self.linear_q = nn.Linear(in_planes, mid_planes)
+        self.linear_k = nn.Linear(in_planes, mid_planes)
+        self.linear_v = nn.Linear(in_planes, out_planes)
+        self.linear_p = nn.Sequential(nn.Linear(3, 3), nn.BatchNorm1d(3), nn.ReLU(inplace=True), nn.Linear(3, out_planes))
+        self.linear_w = nn.Sequential(nn.BatchNorm1d(mid_planes), nn.ReLU(inplace=True),
+                                      nn.Linear(mid_planes, mid_planes // share_planes),
+                                      nn.BatchNorm1d(mid_planes // share_planes), nn.ReLU(inplace=True),
+                                      nn.Linear(out_planes // share_planes, out_planes // share_planes))
+        self.softmax = nn.Softmax(dim=1)
+
+    def forward(self, pxo, idx=None) -> torch.Tensor:
+        p, x, o = pxo                                                        # (n,3), (n,c), (b)
+        x_q, x_k, x_v = self.linear_q(x), self.linear_k(x), self.linear_v(x)  # :33
+        if idx is None:
+            idx, _ = pointops.knnquery(self.nsample, p, p, o, o)              # once, not twice (:34-35)
+        p_r = pointops.queryandgroup(self.nsample, p, p, p.new_zeros((p.shape[0], 0)), idx, o, o, use_xyz=True)   # (n,K,3) relative xyz
+        for i, layer in enumerate(self.linear_p):                             # :38
+            p_r = _bn_rows(layer, p_r) if i == 1 else layer(p_r)
+        k_minus_q = -pointops.subtraction(x_q.contiguous(), x_k.contiguous(), idx)     # x_k[idx] - x_q  (n,K,c)
+        n, K, c = p_r.shape
+        w = k_minus_q + p_r.view(n, K, self.out_planes // self.mid_planes, self.mid_planes).sum(2)   # :39
+        for i, layer in enumerate(self.linear_w):                             # :40
+            w = _bn_rows(layer, w) if i % 3 == 0 else layer(w)
+        w = self.softmax(w)                                                   # over K, :41
+        return pointops.aggregation(x_v.contiguous(), p_r.contiguous(), w.contiguous(), idx)   # :42-43
+
+
+class TransitionDown(nn.Module):
+    def __init__(self, in_planes, out_planes, stride=1, nsample=16):
+        super().__init__()
+        self.stride, self.nsample = stride, nsample
+        if stride != 1:
+            self.linear = nn.Linear(3 + in_planes, out_planes, bias=False)
+            self.pool = nn.MaxPool1d(nsample)
+        else:
+            self.linear = nn.Linear(in_planes, out_planes, bias=False)
+        self.bn = nn.BatchNorm1d(out_planes)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, pxo):
+        p, x, o = pxo
+        if self.stride != 1:
+            lens = torch.diff(o.cpu(), prepend=o.new_zeros(1).cpu())
+            n_o = torch.cumsum(lens // self.stride, 0).to(torch.int32).to(o.device)       # :61-66
+            idx = pointops.furthestsampling(p, o, n_o)                                     # :67
+            n_p = p[idx.long(), :]
+            x = pointops.queryandgroup(self.nsample, p, n_p, x, None, o, n_o, use_xyz=True)   # (m,K,3+c) :69
+            x = self.relu(_bn_rows(self.bn, self.linear(x)))                                # :70
+            x = x.max(1)[0]                                                                 # MaxPool1d(nsample) over K, :71
+            p, o = n_p, n_o
+        else:
+            x = self.relu(self.bn(self.linear(x)))                                          # :74
+        return [p, x, o]
+
+
+class TransitionUp(nn.Module):
+    def __init__(self, in_planes, out_planes=None):
+        super().__init__()
+        if out_planes is None:
+            self.linear1 = nn.Sequential(nn.Linear(2 * in_planes, in_planes), nn.BatchNorm1d(in_planes), nn.ReLU(inplace=True))
+            self.linear2 = nn.Sequential(nn.Linear(in_planes, in_planes), nn.ReLU(inplace=True))
+        else:
+            self.linear1 = nn.Sequential(nn.Linear(out_planes, out_planes), nn.BatchNorm1d(out_planes), nn.ReLU(inplace=True))
+            self.linear2 = nn.Sequential(nn.Linear(in_planes, out_planes), nn.BatchNorm1d(out_planes), nn.ReLU(inplace=True))
+
+    def forward(self, pxo1, pxo2=None):
+        if pxo2 is None:
+            _, x, o = pxo1                                                    # :91-103
+            ends = o.cpu().tolist()
+            x_tmp, s_i = [], 0
+            for e_i in ends:
+                cnt = e_i - s_i
+                x_b = x[s_i:e_i, :]
+                x_b = torch.cat((x_b, self.linear2(x_b.sum(0, True) / cnt).repeat(cnt, 1)), 1)
+                x_tmp.append(x_b)
+                s_i = e_i
+            x = self.linear1(torch.cat(x_tmp, 0))
+        else:
+            p1, x1, o1 = pxo1; p2, x2, o2 = pxo2                              # :105-108
+            x = self.linear1(x1) + pointops.interpolation(p2, p1, self.linear2(x2).contiguous(), o2, o1)
+        return x
+
+
+class PointTransformerBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, in_planes, planes, share_planes=8, nsample=16):
+        super().__init__()
+        self.linear1 = nn.Linear(in_planes, planes, bias=False)
+        self.bn1 = nn.BatchNorm1d(planes)
+        self.transformer2 = PointTransformerLayer(planes, planes, share_planes, nsample)
+        self.bn2 = nn.BatchNorm1d(planes)
+        self.linear3 = nn.Linear(planes, planes * self.expansion, bias=False)
+        self.bn3 = nn.BatchNorm1d(planes * self.expansion)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, pxo, idx=None):
+        p, x, o = pxo
+        identity = x
+        x = self.relu(self.bn1(self.linear1(x)))
+        x = self.relu(self.bn2(self.transformer2([p, x, o], idx)))
+        x = self.bn3(self.linear3(x))
+        x = x + identity
+        x = self.relu(x)
+        return [p, x, o]
