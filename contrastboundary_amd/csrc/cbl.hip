@@ -39,22 +39,27 @@ template <int G> __device__ __forceinline__ int group_sum_i(int v)
 
 // ---- a7: soft label = mean one-hot of the kr nearest stage-0 points ------------------------------------
 // one wave per query; lanes sweep the kr neighbours, class counts by ballot + popcount
+// n_valid: neighbour ids >= n_valid (the TF radius search's padding) and negative labels count for nothing; by_valid: divide by the
+// number of valid neighbours + 1e-12 (get_neighbor_summary 'soft', tensorflow/models/heads/head.py:117-124) instead of by kr
 __global__ __launch_bounds__(256) void subscene_label_kernel(int m, int kr, int ncls, const long long* __restrict__ target,
-                                                             const int* __restrict__ nidx, float* __restrict__ out)
+                                                             const int* __restrict__ nidx, int n_valid, int by_valid, float* __restrict__ out)
 {
     const int lane = threadIdx.x & 63;
     const int q = (blockIdx.x * 256 + threadIdx.x) >> 6;
     if (q >= m) return;
-    int mycount = 0;                                    // lane c accumulates the count of class c (ncls <= 64)
+    int mycount = 0, nvalid = 0;                        // lane c accumulates the count of class c (ncls <= 64)
     for (int base = 0; base < kr; base += 64) {
         const int j = base + lane;
-        const int lab = (j < kr) ? (int)target[nidx[(size_t)q * kr + j]] : -1;
+        const int id = (j < kr) ? nidx[(size_t)q * kr + j] : -1;
+        const int lab = (id >= 0 && id < n_valid) ? (int)target[id] : -1;
+        nvalid += __popcll(__ballot(lab >= 0));
         for (int c = 0; c < ncls; c++) {
             const int cnt = __popcll(__ballot(lab == c));
             if (lane == c) mycount += cnt;
         }
     }
-    if (lane < ncls) out[(size_t)q * ncls + lane] = (float)mycount / (float)kr;       // x.float().mean(-2), :41
+    if (lane < ncls) out[(size_t)q * ncls + lane] = by_valid ? (float)mycount / ((float)nvalid + 1e-12f)
+                                                             : (float)mycount / (float)kr;              // x.float().mean(-2), :41
 }
 
 // ---- argmax over classes, first maximal index (torch.argmax) -------------------------------------------
@@ -79,16 +84,26 @@ struct ContrastRow {
     int nbr;
 };
 
+// n_valid / tf_variant select the TF flavour of the head (tensorflow/models/heads/head.py:462-807, sample 'label', contrast
+// 'softnn'): neighbour ids >= n_valid are the radius search's shadow padding (and negative hard labels are ignored points) and
+// take no part (valid mask, :540-545, :626-640); dist = sqrt(max(sum, 1e-12)) (:184-185) instead of sqrt(sum + 1e-12); the
+// max-shift runs over every column, masked or not (:752).  A point counts if it has >= 1 valid positive and >= 1 valid negative.
 template <int G, int DV>
 __device__ __forceinline__ void contrast_row(ContrastRow<G, DV>& r, int i, int gl, int nsample, int d, const float* __restrict__ feat,
-                                             const int* __restrict__ amax, const int* __restrict__ nidx, float inv_temperature)
+                                             const int* __restrict__ amax, const int* __restrict__ nidx, float inv_temperature,
+                                             int n_valid, int tf_variant)
 {
-    const int ns = nsample - 1;                                     // self column dropped, heads.py:195-196
-    r.nb = gl < ns;
-    r.nbr = nidx[(size_t)i * nsample + 1 + (r.nb ? gl : 0)];
-    r.pos = r.nb && (amax[r.nbr] == amax[i]);                       // posmask_cnt :145-149
+    const int ns = nsample - 1;                                     // self column dropped, heads.py:195-196 / head.py:560
+    const bool col = gl < ns;
+    const int raw = nidx[(size_t)i * nsample + 1 + (col ? gl : 0)];
+    const bool real = raw >= 0 && raw < n_valid;
+    r.nbr = real ? raw : 0;
+    const int my = amax[i], nl = amax[r.nbr];
+    r.nb = col && real && (!tf_variant || (my >= 0 && nl >= 0));    // takes part in the sums
+    r.pos = r.nb && (nl == my);                                     // posmask_cnt :145-149 / head.py:538
     const int cnt = group_sum_i<G>(r.pos ? 1 : 0);
-    r.valid = cnt > 0 && cnt < ns;                                  // :212-213
+    const int nvalid = group_sum_i<G>(r.nb ? 1 : 0);
+    r.valid = cnt > 0 && cnt < nvalid;                              // :212-213 / solve_samples_mask head.py:621-640
     const float4* fi = reinterpret_cast<const float4*>(feat + (size_t)i * d);
     const float4* fj = reinterpret_cast<const float4*>(feat + (size_t)r.nbr * d);
     float acc = 0.f;
@@ -99,10 +114,19 @@ __device__ __forceinline__ void contrast_row(ContrastRow<G, DV>& r, int i, int g
 #pragma unroll
         for (int k = 0; k < 4; k++) acc += r.diff[4 * v + k] * r.diff[4 * v + k];
     }
-    r.dist = sqrtf(acc + 1e-12f);                                   // dist_l2 :116-119
-    float neg = r.nb ? -r.dist : -INFINITY;
+    r.dist = tf_variant ? sqrtf(fmaxf(acc, 1e-12f)) : sqrtf(acc + 1e-12f);   // head.py:184-185 / dist_l2 heads.py:116-119
+    // shadow columns of the TF flavour gather a zero feature row and DO enter the max-shift (head.py:752)
+    float shadow_d = 0.f;
+    if (tf_variant && col && !real) {
+        float a2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < DV; v++) { const float4 a = fi[v]; a2 += a.x * a.x; a2 += a.y * a.y; a2 += a.z * a.z; a2 += a.w * a.w; }
+        shadow_d = sqrtf(fmaxf(a2, 1e-12f));
+    }
+    float neg = r.nb ? -r.dist : ((tf_variant && col) ? (real ? -r.dist : -shadow_d) : -INFINITY);
     const float mx = group_max<G>(neg);                             // :153
-    neg = (neg - mx) * inv_temperature;                             // :154-155
+    // pytorch: shift, then / T (:153-155); TF: / T, then shift (head.py:750-752) — the same value up to rounding
+    neg = (neg - mx) * inv_temperature;
     r.e = r.nb ? expf(neg) : 0.f;
     r.P = group_sum<G>(r.pos ? r.e : 0.f);
     r.A = group_sum<G>(r.e);
@@ -110,14 +134,14 @@ __device__ __forceinline__ void contrast_row(ContrastRow<G, DV>& r, int i, int g
 
 template <int G, int DV>
 __global__ __launch_bounds__(256) void contrast_fwd_kernel(int m, int nsample, const float* __restrict__ feat, const int* __restrict__ amax,
-                                                           const int* __restrict__ nidx, float inv_temperature,
+                                                           const int* __restrict__ nidx, float inv_temperature, int n_valid, int tf_variant,
                                                            float* __restrict__ per_point, int* __restrict__ point_mask)
 {
     const int t = (blockIdx.x * 256 + threadIdx.x) / G;
     const int gl = threadIdx.x & (G - 1);
     const int i = t < m ? t : m - 1;
     ContrastRow<G, DV> r;
-    contrast_row<G, DV>(r, i, gl, nsample, DV * 4, feat, amax, nidx, inv_temperature);
+    contrast_row<G, DV>(r, i, gl, nsample, DV * 4, feat, amax, nidx, inv_temperature, n_valid, tf_variant);
     if (t < m && gl == 0) {
         per_point[t] = r.valid ? -logf(r.P / r.A + 1e-12f) : 0.f;  // contrast_softnn :161-163
         point_mask[t] = r.valid ? 1 : 0;
@@ -151,6 +175,7 @@ __global__ __launch_bounds__(1024) void contrast_finalize_kernel(int m, float we
 template <int G, int DV>
 __global__ __launch_bounds__(256) void contrast_bwd_kernel(int m, int nsample, const float* __restrict__ feat, const int* __restrict__ amax,
                                                            const int* __restrict__ nidx, float inv_temperature, float weight,
+                                                           int n_valid, int tf_variant,
                                                            const float* __restrict__ stats, const float* __restrict__ grad_loss,
                                                            float* __restrict__ grad_feat)
 {
@@ -166,12 +191,13 @@ __global__ __launch_bounds__(256) void contrast_bwd_kernel(int m, int nsample, c
     float coef = 0.f; int nbr;
     {
         ContrastRow<G, DV> r;
-        contrast_row<G, DV>(r, i, gl, nsample, D, feat, amax, nidx, inv_temperature);
+        contrast_row<G, DV>(r, i, gl, nsample, D, feat, amax, nidx, inv_temperature, n_valid, tf_variant);
         nbr = r.nbr;
         if (t < m && r.valid && r.nb) {
             const float scale = grad_loss[0] * weight / count;
             const float ratio = r.P / r.A;
             coef = scale * r.e * ((r.pos ? r.A : 0.f) - r.P) * inv_temperature / (r.A * r.A * (ratio + 1e-12f)) / r.dist;
+            if (tf_variant && r.dist <= 1e-6f) coef = 0.f;           // sqrt(max(s, 1e-12)): flat below the clamp
         }
     }
     // phase 2: groups of this wave one after the other (wave-uniform loop), lanes = (pair slot, channel)
@@ -219,12 +245,13 @@ __global__ __launch_bounds__(256) void boundary_mask_kernel(int n, int k, const 
 
 template <int G>
 int launch_contrast(bool fwd, int m, int nsample, int d, const float* feat, const int* amax, const int* nidx, float inv_t, float weight,
+                    int n_valid, int tf_variant,
                     float* per_point, int* point_mask, const float* stats, const float* grad_loss, float* grad_feat, hipStream_t st)
 {
     const dim3 grid(cbl_div_up((long long)m * G, 256)), block(256);
 #define CBL_CONTRAST_DV(DV)                                                                                                                  \
-    if (fwd) hipLaunchKernelGGL((contrast_fwd_kernel<G, DV>), grid, block, 0, st, m, nsample, feat, amax, nidx, inv_t, per_point, point_mask); \
-    else     hipLaunchKernelGGL((contrast_bwd_kernel<G, DV>), grid, block, 0, st, m, nsample, feat, amax, nidx, inv_t, weight, stats, grad_loss, grad_feat)
+    if (fwd) hipLaunchKernelGGL((contrast_fwd_kernel<G, DV>), grid, block, 0, st, m, nsample, feat, amax, nidx, inv_t, n_valid, tf_variant, per_point, point_mask); \
+    else     hipLaunchKernelGGL((contrast_bwd_kernel<G, DV>), grid, block, 0, st, m, nsample, feat, amax, nidx, inv_t, weight, n_valid, tf_variant, stats, grad_loss, grad_feat)
     switch (d) {
         case 4:  CBL_CONTRAST_DV(1); break;
         case 8:  CBL_CONTRAST_DV(2); break;
@@ -238,13 +265,14 @@ int launch_contrast(bool fwd, int m, int nsample, int d, const float* feat, cons
 }
 
 int dispatch_contrast(bool fwd, int m, int nsample, int d, const float* feat, const int* amax, const int* nidx, float temperature, float weight,
+                      int n_valid, int tf_variant,
                       float* per_point, int* point_mask, const float* stats, const float* grad_loss, float* grad_feat, hipStream_t st)
 {
     const int ns = nsample - 1;
     const float inv_t = 1.0f / temperature;
-    if (ns <= 16) return launch_contrast<16>(fwd, m, nsample, d, feat, amax, nidx, inv_t, weight, per_point, point_mask, stats, grad_loss, grad_feat, st);
-    if (ns <= 32) return launch_contrast<32>(fwd, m, nsample, d, feat, amax, nidx, inv_t, weight, per_point, point_mask, stats, grad_loss, grad_feat, st);
-    return launch_contrast<64>(fwd, m, nsample, d, feat, amax, nidx, inv_t, weight, per_point, point_mask, stats, grad_loss, grad_feat, st);
+    if (ns <= 16) return launch_contrast<16>(fwd, m, nsample, d, feat, amax, nidx, inv_t, weight, n_valid, tf_variant, per_point, point_mask, stats, grad_loss, grad_feat, st);
+    if (ns <= 32) return launch_contrast<32>(fwd, m, nsample, d, feat, amax, nidx, inv_t, weight, n_valid, tf_variant, per_point, point_mask, stats, grad_loss, grad_feat, st);
+    return launch_contrast<64>(fwd, m, nsample, d, feat, amax, nidx, inv_t, weight, n_valid, tf_variant, per_point, point_mask, stats, grad_loss, grad_feat, st);
 }
 
 }  // namespace
@@ -254,7 +282,18 @@ CBL_EXPORT int cbl_subscene_label(int m, int kr, int num_classes, const long lon
     if (m < 0 || kr <= 0 || num_classes <= 0 || num_classes > 64) return CBL_ERR_BAD_ARG;
     if (m == 0) return CBL_OK;
     if (!target || !neighbor_idx || !out) return CBL_ERR_BAD_ARG;
-    hipLaunchKernelGGL(subscene_label_kernel, dim3(cbl_div_up((long long)m * 64, 256)), dim3(256), 0, cbl_stream(stream), m, kr, num_classes, target, neighbor_idx, out);
+    hipLaunchKernelGGL(subscene_label_kernel, dim3(cbl_div_up((long long)m * 64, 256)), dim3(256), 0, cbl_stream(stream), m, kr, num_classes, target, neighbor_idx, 0x7fffffff, 0, out);
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_tf_scene_label(int m, int n_valid, int k, int num_classes, const long long* point_labels, const int* scene_neighbor, int by_valid,
+                                  float* out, void* stream)
+{
+    if (m < 0 || n_valid < 0 || k <= 0 || num_classes <= 0 || num_classes > 64) return CBL_ERR_BAD_ARG;
+    if (m == 0) return CBL_OK;
+    if (!point_labels || !scene_neighbor || !out) return CBL_ERR_BAD_ARG;
+    hipLaunchKernelGGL(subscene_label_kernel, dim3(cbl_div_up((long long)m * 64, 256)), dim3(256), 0, cbl_stream(stream), m, k, num_classes, point_labels,
+                       scene_neighbor, n_valid, by_valid, out);
     return cbl_status();
 }
 
@@ -274,10 +313,32 @@ CBL_EXPORT int cbl_point_contrast_forward(int m, int nsample, int d, const float
     if (!features || !amax || !neighbor_idx || !per_point || !point_mask || !stats || !loss) return CBL_ERR_BAD_ARG;
     if (!cbl_host_aligned16(features)) return CBL_ERR_BAD_ARG;
     hipStream_t st = cbl_stream(stream);
-    const int rc = dispatch_contrast(true, m, nsample, d, features, amax, neighbor_idx, temperature, weight, per_point, point_mask, nullptr, nullptr, nullptr, st);
+    const int rc = dispatch_contrast(true, m, nsample, d, features, amax, neighbor_idx, temperature, weight, 0x7fffffff, 0, per_point, point_mask, nullptr, nullptr, nullptr, st);
     if (rc) return rc;
     hipLaunchKernelGGL(contrast_finalize_kernel, dim3(1), dim3(1024), 0, st, m, weight, per_point, point_mask, stats, loss);
     return cbl_status();
+}
+
+CBL_EXPORT int cbl_tf_contrast_forward(int m, int n_valid, int nsample, int d, const float* features, const int* labels, const int* neighbors,
+                                       float temperature, float weight, float* per_point, int* point_mask, float* stats, float* loss, void* stream)
+{
+    if (m <= 0 || n_valid < 0 || nsample < 2 || nsample > 65 || d <= 0 || !(temperature > 0.f)) return CBL_ERR_BAD_ARG;
+    if (!features || !labels || !neighbors || !per_point || !point_mask || !stats || !loss) return CBL_ERR_BAD_ARG;
+    if (!cbl_host_aligned16(features)) return CBL_ERR_BAD_ARG;
+    hipStream_t st = cbl_stream(stream);
+    const int rc = dispatch_contrast(true, m, nsample, d, features, labels, neighbors, temperature, weight, n_valid, 1, per_point, point_mask, nullptr, nullptr, nullptr, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(contrast_finalize_kernel, dim3(1), dim3(1024), 0, st, m, weight, per_point, point_mask, stats, loss);
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_tf_contrast_backward(int m, int n_valid, int nsample, int d, const float* features, const int* labels, const int* neighbors,
+                                        float temperature, float weight, const float* stats, const float* grad_loss, float* grad_features, void* stream)
+{
+    if (m <= 0 || n_valid < 0 || nsample < 2 || nsample > 65 || d <= 0 || !(temperature > 0.f)) return CBL_ERR_BAD_ARG;
+    if (!features || !labels || !neighbors || !stats || !grad_loss || !grad_features) return CBL_ERR_BAD_ARG;
+    if (!cbl_host_aligned16(features)) return CBL_ERR_BAD_ARG;
+    return dispatch_contrast(false, m, nsample, d, features, labels, neighbors, temperature, weight, n_valid, 1, nullptr, nullptr, stats, grad_loss, grad_features, cbl_stream(stream));
 }
 
 CBL_EXPORT int cbl_point_contrast_backward(int m, int nsample, int d, const float* features, const int* amax, const int* neighbor_idx,
@@ -286,7 +347,7 @@ CBL_EXPORT int cbl_point_contrast_backward(int m, int nsample, int d, const floa
     if (m <= 0 || nsample < 2 || nsample > 65 || d <= 0 || !(temperature > 0.f)) return CBL_ERR_BAD_ARG;
     if (!features || !amax || !neighbor_idx || !stats || !grad_loss || !grad_features) return CBL_ERR_BAD_ARG;
     if (!cbl_host_aligned16(features)) return CBL_ERR_BAD_ARG;
-    return dispatch_contrast(false, m, nsample, d, features, amax, neighbor_idx, temperature, weight, nullptr, nullptr, stats, grad_loss, grad_features, cbl_stream(stream));
+    return dispatch_contrast(false, m, nsample, d, features, amax, neighbor_idx, temperature, weight, 0x7fffffff, 0, nullptr, nullptr, stats, grad_loss, grad_features, cbl_stream(stream));
 }
 
 CBL_EXPORT int cbl_boundary_mask(int n, int k, const long long* labels, const int* neighbor_idx, unsigned char* bound, unsigned char* plain, int* cnt, void* stream)

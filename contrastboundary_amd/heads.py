@@ -111,3 +111,61 @@ class ContrastHead(torch.nn.Module):
 
     def forward(self, output, target, stage_list):
         return [self.point_contrast(n, i, stage_list, target) for n, i in self.stages]              # :248-253
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# TF flavour: /root/reference/tensorflow/models/heads/head.py:462-807 (contrast_head), scene labels :25-49 / :117-131
+# ---------------------------------------------------------------------------------------------------------------------------
+class _TFContrast(Function):
+    @staticmethod
+    def forward(ctx, features, labels, neighbors, temperature, weight):
+        m, d = features.shape
+        n_valid = labels.shape[0]
+        dev = features.device
+        per_point = torch.empty(m, dtype=torch.float32, device=dev)
+        mask = torch.empty(m, dtype=torch.int32, device=dev)
+        stats = torch.empty(2, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().cbl_tf_contrast_forward(_c_int(m), _c_int(n_valid), _c_int(neighbors.shape[1]), _c_int(d), _lib.ptr(features), _lib.ptr(labels),
+                                                      _lib.ptr(neighbors), _c_float(temperature), _c_float(weight), _lib.ptr(per_point), _lib.ptr(mask),
+                                                      _lib.ptr(stats), _lib.ptr(loss), _lib.stream_of(features)), "cbl_tf_contrast_forward")
+        ctx.save_for_backward(features, labels, neighbors, stats)
+        ctx.cfg = (temperature, weight)
+        ctx.mark_non_differentiable(mask)
+        return loss.view(()), mask
+
+    @staticmethod
+    def backward(ctx, grad_loss, _gm):
+        features, labels, neighbors, stats = ctx.saved_tensors
+        temperature, weight = ctx.cfg
+        m, d = features.shape
+        g = torch.zeros_like(features)
+        gl = grad_loss.reshape(1).to(torch.float32).contiguous()
+        _lib.check(_lib.lib().cbl_tf_contrast_backward(_c_int(m), _c_int(labels.shape[0]), _c_int(neighbors.shape[1]), _c_int(d), _lib.ptr(features),
+                                                       _lib.ptr(labels), _lib.ptr(neighbors), _c_float(temperature), _c_float(weight), _lib.ptr(stats),
+                                                       _lib.ptr(gl), _lib.ptr(g), _lib.stream_of(features)), "cbl_tf_contrast_backward")
+        return g, None, None, None, None
+
+
+def tf_contrast(features, labels, neighbors, temperature=1.0, weight=0.1, return_mask=False):
+    """TF contrast_head.contrast (sample 'label', 'softnn', 'l2') for one stage: features (m,d) f32, labels (N,) hard labels of the
+    N support points of that stage (negative = ignored), neighbors (m,k) i32 radius neighbours incl. the self column, padded with N."""
+    lab = labels.to(torch.int32).contiguous()
+    loss, mask = _TFContrast.apply(features.contiguous(), lab, neighbors.contiguous(), float(temperature), float(weight))
+    return (loss, mask) if return_mask else loss
+
+
+def tf_scene_label(point_labels, scene_neighbor, num_classes, reduction="max"):
+    """get_scene_label_infer (head.py:25-49): labels of sub-sampled points from `scene_neighbor` (m,k) i32 into the stage-0 points
+    (pad = len(point_labels)); 'max' -> (m,) int64 hard labels, 'soft' -> (m,ncls) distribution over the VALID neighbours"""
+    m, k = scene_neighbor.shape
+    pl = point_labels.to(torch.int64).contiguous()
+    out = torch.empty((m, num_classes), dtype=torch.float32, device=pl.device)
+    nb = scene_neighbor.contiguous()
+    _lib.check(_lib.lib().cbl_tf_scene_label(_c_int(m), _c_int(pl.shape[0]), _c_int(k), _c_int(num_classes), _lib.ptr(pl), _lib.ptr(nb),
+                                             _c_int(0 if reduction in ("max", "cnt") else 1), _lib.ptr(out), _lib.stream_of(pl)), "cbl_tf_scene_label")
+    if reduction in ("max", "cnt"):
+        amax = torch.empty(m, dtype=torch.int32, device=pl.device)
+        _lib.check(_lib.lib().cbl_label_argmax(_c_int(m), _c_int(num_classes), _lib.ptr(out), _lib.ptr(amax), _lib.stream_of(pl)), "cbl_label_argmax")
+        return amax.long()
+    return out

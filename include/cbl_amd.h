@@ -148,6 +148,19 @@ int cbl_point_contrast_forward(int m, int nsample, int d, const float* features,
 int cbl_point_contrast_backward(int m, int nsample, int d, const float* features, const int* amax, const int* neighbor_idx,
                                 float temperature, float weight, const float* stats, const float* grad_loss, float* grad_features, void* stream);
 
+/* a16  TF contrast_head  tensorflow/models/heads/head.py:462-807 with sample 'label', contrast 'softnn', dist 'l2' on RADIUS
+ *      neighbourhoods (ids >= n_valid are the search's shadow padding; negative hard labels = ignored points):
+ *   features (m,d), labels (n_valid >= m rows, i32 hard label per point, from point_labels or cbl_tf_scene_label + cbl_label_argmax),
+ *   neighbors (m,nsample) i32 incl. the self column 0 (dropped, :560) -> per_point / point_mask / stats / loss as cbl_point_contrast_forward.
+ *   Differences from the pytorch head, all reproduced: valid mask (:540-545), dist = sqrt(max(.,1e-12)) (:184-185), max-shift over all columns (:752). */
+int cbl_tf_contrast_forward(int m, int n_valid, int nsample, int d, const float* features, const int* labels, const int* neighbors,
+                            float temperature, float weight, float* per_point, int* point_mask, float* stats, float* loss, void* stream);
+int cbl_tf_contrast_backward(int m, int n_valid, int nsample, int d, const float* features, const int* labels, const int* neighbors,
+                             float temperature, float weight, const float* stats, const float* grad_loss, float* grad_features, void* stream);
+/* get_scene_label_infer + get_neighbor_summary  head.py:25-49, :117-131: class histogram of point_labels over scene_neighbor (m,k) (pad = n_valid,
+ * label < 0 ignored) -> out (m,num_classes): counts / k (by_valid = 0; argmax of it = reduction 'max') or counts / (#valid + 1e-12) ('soft') */
+int cbl_tf_scene_label(int m, int n_valid, int k, int num_classes, const long long* point_labels, const int* scene_neighbor, int by_valid, float* out, void* stream);
+
 /* a9  get_boundary_mask  pytorch/model/basic_operators.py:69-97 (labels (n) int64, negative = invalid neighbour label)
  *   neighbor_idx (n,k) -> bound (n) u8 [any valid neighbour label differs], plain (n) u8 [all valid neighbour labels equal],
  *   cnt (n) i32 [number of differing valid neighbours]; any output may be NULL */

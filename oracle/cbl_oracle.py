@@ -94,3 +94,69 @@ def boundary_mask(labels, neighbor_label, valid_mask=None, get_plain=False, get_
         plain = plain & valid_mask if valid_mask is not None else plain
         return bound, plain
     return bound
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# TF flavour — /root/reference/tensorflow/models/heads/head.py:462-807 (contrast_head with sample 'label', contrast 'softnn',
+# dist 'l2'), get_scene_label_infer :25-49, get_neighbor_summary :117-131, calc_dist :180-195.
+# PARITY UNPINNED BY EXECUTION: TF1 graph code, TensorFlow absent from the build container; restated from the source.
+# ---------------------------------------------------------------------------------------------------------------------------
+def tf_scene_label(point_labels, scene_neighbor, num_classes, reduction="max"):
+    """labels of sub-sampled points from their stage-0 neighbours: tf_gather with shadow -1 -> one-hot (invalid -> zeros) -> sum;
+    'max' -> argmax (first maximum) (n,), 'soft' -> sum / (#valid + 1e-12) (n, ncls)"""
+    pl = np.concatenate([np.asarray(point_labels), [-1]])
+    lab = pl[scene_neighbor]                                         # shadow index == len(point_labels) -> -1
+    valid = lab >= 0
+    onehot = np.zeros(lab.shape + (num_classes,), np.float32)
+    r, c = np.nonzero(valid)
+    onehot[r, c, lab[r, c]] = 1
+    s = onehot.sum(1, dtype=np.float32)
+    if reduction in ("max", "cnt"):
+        return np.argmax(s, -1)
+    return (s / (valid.sum(-1, keepdims=True).astype(np.float32) + _EPS)).astype(np.float32)
+
+
+def tf_contrast(features, labels, neighbors, temperature=None, weight=0.1, grad=True):
+    """features (m,d); labels (N,) hard labels of the support points (N >= m; negative = ignored); neighbors (m,k) radius neighbours
+    incl. self column, padded with N.  -> loss, d loss/d features (m,d), point_mask"""
+    f = np.asarray(features, np.float32)
+    N = len(labels)
+    nbr = np.asarray(neighbors)[:, 1:]                               # exclude self-loop, :560
+    m, ns = nbr.shape
+    lab = np.concatenate([np.asarray(labels), [-1]])                 # shadow label -1, :537
+    nl = lab[np.minimum(nbr, N)]
+    me = np.asarray(labels)[:m]
+    posneg = me[:, None] == nl                                       # :538
+    valid = (nl >= 0) & (me[:, None] >= 0)                           # :540-545
+    pos_mask = posneg & valid; neg_mask = ~posneg & valid            # :621-627
+    point_mask = pos_mask.any(1) & neg_mask.any(1)                   # :629-640
+    g = np.zeros_like(f)
+    if not point_mask.any():
+        return np.float32(0.0), g, point_mask                        # false_fn :662-665
+    rows = np.nonzero(point_mask)[0]
+    fpad = np.concatenate([f, np.zeros((max(N + 1 - len(f), 1), f.shape[1]), np.float32)])   # tf_gather shadow row = zeros, :703
+    fi = f[rows]; fj = fpad[np.minimum(nbr[rows], len(fpad) - 1)]
+    diff = fi[:, None, :] - fj
+    dist = np.sqrt(np.maximum((diff * diff).sum(-1, dtype=np.float32), _EPS)).astype(np.float32)   # :184-185
+    d = -dist
+    if temperature is not None:
+        d = (d / np.float32(temperature)).astype(np.float32)         # :750-751
+    d = d - d.max(-1, keepdims=True)                                 # over ALL columns, :752
+    e = np.exp(d).astype(np.float32)
+    pm, nm = pos_mask[rows].astype(np.float32), neg_mask[rows].astype(np.float32)
+    pos = (e * pm).sum(-1, dtype=np.float32); neg = (e * nm).sum(-1, dtype=np.float32)
+    ratio = pos / (pos + neg)                                        # :759-762
+    per_point = -np.log(ratio + _EPS)                                # :766-767
+    loss = np.float32(per_point.mean(dtype=np.float32) * np.float32(weight))   # :805-806
+    if not grad:
+        return loss, g, point_mask
+    T = 1.0 if temperature is None else float(temperature)
+    e64, pm64, nm64 = e.astype(np.float64), pm.astype(np.float64), nm.astype(np.float64)
+    P, A = (e64 * pm64).sum(-1), (e64 * (pm64 + nm64)).sum(-1)
+    dl_dd = e64 * (pm64 * A[:, None] - (pm64 + nm64) * P[:, None]) / (T * (A * A)[:, None] * (P / A + 1e-12)[:, None])
+    dl_dd *= float(weight) / float(len(rows))
+    coef = (dl_dd / dist.astype(np.float64))[:, :, None] * diff.astype(np.float64)
+    g64 = np.zeros((len(fpad), f.shape[1]), np.float64)
+    np.add.at(g64, rows, coef.sum(1))
+    np.add.at(g64, np.minimum(nbr[rows], len(fpad) - 1).reshape(-1), -coef.reshape(-1, f.shape[1]))
+    return loss, g64[:len(f)].astype(np.float32), point_mask

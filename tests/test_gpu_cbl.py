@@ -117,3 +117,38 @@ def test_cbl_full_size_properties():
     l3 = heads.point_contrast(sc.feat, sc.labels, idx, 1.0, 0.3)
     assert abs(l1.item() - l2.item()) < 1e-4 and abs(3 * l1.item() - l3.item()) < 1e-4 and l1.item() > 0
     assert float(f.grad.sum(0).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("limit,d,T", [(26, 32, 1.0), (41, 16, 0.5), (12, 64, 2.0)])
+def test_tf_contrast_head_vs_oracle(limit, d, T):
+    """a16: TF contrast_head on radius neighbourhoods with shadow padding + ignored (-1) labels, vs the numpy restatement"""
+    from contrastboundary_amd import heads, tf_ops
+    from contrastboundary_amd import synthetic as S
+    xyz, lab = S.s_room(6000, seed=limit)
+    rng = np.random.default_rng(limit)
+    lab = lab.copy(); lab[rng.choice(6000, 300, replace=False)] = -1          # ignored points
+    lens = np.int32([2500, 3500])
+    nb = tf_ops.tf_batch_neighbors(dev(xyz), dev(xyz), dev(lens), dev(lens), 0.12, limit, exact_shape=False)
+    feat = (rng.normal(size=(6000, d)) * 0.5).astype(np.float32)
+    f = dev(feat).requires_grad_(True)
+    loss, mask = heads.tf_contrast(f, dev(lab), nb, T, 0.1, return_mask=True)
+    loss.backward()
+    rl, rg, rm = C.tf_contrast(feat, lab, nb.cpu().numpy(), temperature=T, weight=0.1)
+    np.testing.assert_array_equal(mask.cpu().numpy().astype(bool), rm)
+    np.testing.assert_allclose(loss.item(), rl, rtol=TOL)
+    np.testing.assert_allclose(f.grad.cpu().numpy(), rg, rtol=1e-3, atol=1e-7)
+    assert (nb.cpu().numpy() == 6000).any()                                   # the case really contains shadow entries
+
+
+def test_tf_scene_labels_vs_oracle():
+    from contrastboundary_amd import heads, tf_ops
+    from contrastboundary_amd import synthetic as S
+    xyz, lab = S.s_room(8000, seed=9)
+    lab = lab.copy(); lab[::37] = -1
+    lens = np.int32([8000])
+    sub, sl = tf_ops.tf_batch_subsampling(dev(xyz), dev(lens), 0.16)
+    nb = tf_ops.tf_batch_neighbors(sub.contiguous(), dev(xyz), sl, dev(lens), 0.16, 48, exact_shape=False)
+    hard = heads.tf_scene_label(dev(lab), nb, 13, "max")
+    soft = heads.tf_scene_label(dev(lab), nb, 13, "soft")
+    np.testing.assert_array_equal(hard.cpu().numpy(), C.tf_scene_label(lab, nb.cpu().numpy(), 13, "max"))
+    np.testing.assert_allclose(soft.cpu().numpy(), C.tf_scene_label(lab, nb.cpu().numpy(), 13, "soft"), rtol=1e-6, atol=1e-7)
