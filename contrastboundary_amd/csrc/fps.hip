@@ -1,19 +1,21 @@
 // K2: furthest point sampling, one 1024-lane workgroup (16 waves) per cloud.
 // Replaces furthestsampling_cuda_kernel  /root/reference/pytorch/lib/pointops/src/sampling/sampling_cuda_kernel.cu:14-129.
 //
-// Same sequence of samples as the reference, including ties: the reference's result depends on its
-// block size B = opt_n_threads(n_max) (cuda_utils.h:11-14) through (a) which thread owns a point
-// (t = (k-start) mod B, first maximum wins inside a thread, :57-58) and (b) the shared-memory tree
-// (:64-123), which among tied threads returns the smallest BIT-REVERSED thread id.  Here that rule is
-// an explicit 64-bit key per point, independent of the real workgroup size:
-//     key = (bits(d2) << 32) | ~((bitrev_B(t) << 22) | (k-start)/B)         (d2 >= 0 so bits order)
-// and every iteration is "update running min distance, max-reduce the key".  MI355X mapping: the
-// running distances (and, for clouds <= 16384 points, the coordinates too) stay in VGPRs for the
-// whole launch instead of round-tripping through global memory every iteration as the reference's
-// tmp[] does; the reduction is 6 cross-lane steps + one LDS exchange between the 16 waves, one
-// barrier per sample (double-buffered slots) instead of the reference's 11; the `old` read-after-
-// write race of the reference (:125 vs :60-61) does not exist because the winner is recomputed by
-// every thread from the exchanged keys.
+// Same sequence of samples as the reference, including ties: the reference's result depends on its block size
+// B = opt_n_threads(n_max) (cuda_utils.h:11-14) through (a) which thread owns a point (t = (k-start) mod B, first maximum wins
+// inside a thread, :57-58) and (b) the shared-memory tree (:64-123), which among tied threads returns the smallest BIT-REVERSED
+// thread id.  Here that rule is an explicit 64-bit key per point, independent of the real workgroup size:
+//     key = (bits(d2) << 32) | ~((bitrev_B(t) << 22) | (k-start)/B)         (d2 >= 0 so the bit pattern orders like the value)
+// and every iteration is "update running min distance, max-reduce the key".
+//
+// MI355X mapping.  FPS is latency bound: m sequential samples, each needing every point's distance to the previous sample.
+//  * The whole per-cloud state stays ON CHIP for clouds up to 40960 points: running distances in VGPRs (40 per lane), coordinates
+//    in VGPRs for the first rows, in LDS (13 rows x 1024 lanes x 12 B = 156 KiB of the CU's 160 KiB) for the next, and only the
+//    last rows are re-read from L2 each sample — issued at the top of the iteration so they land while the resident rows are
+//    processed.  (The reference round-trips tmp[] and xyz through global memory every iteration.)
+//  * The winner's COORDINATES travel with its key through the reduction (wave max by 6 cross-lane steps, one LDS slot per wave,
+//    one barrier, double-buffered), so the next iteration does not start with a dependent global load of xyz[winner].
+//  * One barrier per sample instead of the reference's 11, and no read-after-write race on the winner (:125 vs :60-61).
 #include "cbl_common.h"
 #include <math.h>
 
@@ -22,16 +24,7 @@ namespace {
 constexpr int FPS_BLOCK = 1024;
 constexpr int FPS_WAVES = FPS_BLOCK / 64;
 
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
-{
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) {
-        const unsigned long long o = __shfl_xor(v, s);
-        v = o > v ? o : v;
-    }
-    return v;
-}
-
+struct FpsSlot { unsigned long long key; float x, y, z, pad; };
 struct FpsCloud { int n0, n1, m0, m1; };
 
 __device__ __forceinline__ FpsCloud fps_cloud(const int* __restrict__ offset, const int* __restrict__ new_offset)
@@ -58,87 +51,166 @@ __device__ __forceinline__ int fps_unrank(unsigned rank, int bits)
     return (int)((j << bits) | t);
 }
 
-// all threads: exchange per-wave maxima through LDS slot set `par`, return the block-wide max key
-__device__ __forceinline__ unsigned long long block_max_key(unsigned long long key, unsigned long long (*slots)[FPS_WAVES], int par)
+// Running best of one lane.  With a 1024-lane workgroup every point a lane owns has the same reference thread id (B = 1024:
+// t = lane; B < 1024 means n_max < 1024, i.e. a single row), so inside a lane the rank order is the row order and the
+// reference's "first maximum wins" (:57-58) is a strict '>' in row order: one compare and two selects per point, no branch.
+struct FpsBest {
+    float d; int row;
+    __device__ __forceinline__ void init() { d = -1.f; row = 0; }
+    __device__ __forceinline__ void offer(float d2, int jj) { const bool up = d2 > d; d = up ? d2 : d; row = up ? jj : row; }
+};
+
+// ---- cross-lane reductions on the VALU's data-parallel primitives (no LDS traffic): xor-butterfly inside each 16-lane row
+// (quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror, row_mirror), then row_bcast:15 / row_bcast:31 to fold the 4 rows into lane 63
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dppf(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false)); }
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ unsigned dppu(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false); }
+__device__ __forceinline__ float row_max_f(float v)
 {
-    key = wave_max_u64(key);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) slots[par][wave] = key;
-    __syncthreads();
-    unsigned long long v = slots[par][lane & (FPS_WAVES - 1)];
-#pragma unroll
-    for (int s = FPS_WAVES / 2; s >= 1; s >>= 1) {
-        const unsigned long long o = __shfl_xor(v, s);
-        v = o > v ? o : v;
-    }
+    v = fmaxf(v, dppf<0xB1, 0xf>(v)); v = fmaxf(v, dppf<0x4E, 0xf>(v)); v = fmaxf(v, dppf<0x141, 0xf>(v)); v = fmaxf(v, dppf<0x140, 0xf>(v));
+    return v;                                                       // every lane of a row holds the row's max
+}
+__device__ __forceinline__ unsigned row_min_u(unsigned v)
+{
+    v = min(v, dppu<0xB1, 0xf>(v)); v = min(v, dppu<0x4E, 0xf>(v)); v = min(v, dppu<0x141, 0xf>(v)); v = min(v, dppu<0x140, 0xf>(v));
     return v;
 }
-
-// PER = points per thread kept in registers (cloud size <= PER*1024); XYZ_REG: coordinates too.
-template <int PER, bool XYZ_REG>
-__global__ __launch_bounds__(FPS_BLOCK) void fps_reg_kernel(int bits, const float* __restrict__ xyz,
-                                                            const int* __restrict__ offset, const int* __restrict__ new_offset,
-                                                            float* __restrict__ tmp, int* __restrict__ idx)
+__device__ __forceinline__ float wave_max_f(float v)
 {
-    __shared__ unsigned long long slots[2][FPS_WAVES];
+    v = row_max_f(v);
+    v = fmaxf(v, dppf<0x142, 0xa>(v));                             // rows 1,3 <- lane 15 of the row below
+    v = fmaxf(v, dppf<0x143, 0xc>(v));                             // rows 2,3 <- lane 31
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ unsigned wave_min_u(unsigned v)
+{
+    v = row_min_u(v);
+    v = min(v, dppu<0x142, 0xa>(v));
+    v = min(v, dppu<0x143, 0xc>(v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// Block-wide winner of the lexicographic (larger d2, smaller rank) maximum, with its coordinates.  `coords(row, x, y, z)` is
+// called by ONE lane per wave (the wave's winner) to fetch the coordinates of its best row.  One barrier; slots[par] alternates.
+template <class Coords>
+__device__ __forceinline__ void block_winner(const FpsBest& b, bool any, int tid, FpsSlot (*slots)[FPS_WAVES], int par, int bits,
+                                             Coords&& coords, int& win_local, float& wx, float& wy, float& wz)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    const float d = any ? b.d : -3.f;
+    const unsigned rank = any ? fps_rank(tid + b.row * FPS_BLOCK, bits) : 0xffffffffu;
+    const float wd = wave_max_f(d);
+    const unsigned wr = wave_min_u(d == wd ? rank : 0xffffffffu);
+    if (d == wd && rank == wr) {                                     // exactly one lane (ranks are unique), or lane(s) of an empty wave
+        FpsSlot s; s.key = ((unsigned long long)__float_as_uint(wd) << 32) | wr;
+        s.x = s.y = s.z = 0.f; s.pad = 0.f;
+        if (any) coords(b.row, s.x, s.y, s.z);
+        if (any || lane == 0) slots[par][wave] = s;
+    }
+    __syncthreads();
+    const FpsSlot mine = slots[par][lane & (FPS_WAVES - 1)];
+    const float sd = __uint_as_float((unsigned)(mine.key >> 32)); const unsigned sr = (unsigned)(mine.key & 0xffffffffu);
+    const float bd = row_max_f(sd);
+    const unsigned br = row_min_u(sd == bd ? sr : 0xffffffffu);
+    const int slot = __builtin_ctzll(__ballot(sd == bd && sr == br) & 0xffffull);
+    wx = slots[par][slot].x; wy = slots[par][slot].y; wz = slots[par][slot].z;
+    win_local = fps_unrank(br, bits);
+}
+
+// PER rows of 1024 points per cloud.  Rows [0,RREG): xyz in VGPRs; [RREG, RREG+RLDS): xyz in LDS; the rest re-read from L2.
+// Lanes past the end of the (single) partial row hold a clamped valid point and a running distance of -2, which can never
+// win the max, so the sample loop needs no per-lane predicates; absent rows are skipped wave-uniformly.
+template <int PER, int RREG, int RLDS>
+__global__ __launch_bounds__(FPS_BLOCK) void fps_kernel(int bits, const float* __restrict__ xyz,
+                                                        const int* __restrict__ offset, const int* __restrict__ new_offset,
+                                                        float* __restrict__ tmp, int* __restrict__ idx)
+{
+    constexpr int RGLB = PER - RREG - RLDS;                         // rows streamed from L2, in batches of <= GBATCH rows
+    constexpr int GBATCH = 7;
+    constexpr int NB = (RGLB + GBATCH - 1) / GBATCH;
+    __shared__ FpsSlot slots[2][FPS_WAVES];
+    extern __shared__ __attribute__((aligned(16))) float lds_xyz[];     // [3][RLDS][1024]
     const FpsCloud cl = fps_cloud(offset, new_offset);
     if (cl.m1 <= cl.m0) return;
     const int tid = threadIdx.x, nloc = cl.n1 - cl.n0;
     const float* __restrict__ P = xyz + (size_t)3 * cl.n0;
-
-    // Row jj of the cloud = local points [jj*1024, (jj+1)*1024).  Rows are wave-uniformly present or
-    // absent; only the last present row can be partial.  Lanes past the end of a partial row get a
-    // clamped (valid) address and a running distance of -2, which can never win the max, so the sample
-    // loop needs no per-lane predicates (40 loop-invariant lane masks would otherwise eat the SGPRs).
     const int omax = 3 * (nloc - 1);
-    float t[PER], px[XYZ_REG ? PER : 1], py[XYZ_REG ? PER : 1], pz[XYZ_REG ? PER : 1];
+
+    float t[PER];
+    float rx[RREG > 0 ? RREG : 1], ry[RREG > 0 ? RREG : 1], rz[RREG > 0 ? RREG : 1];
 #pragma unroll
     for (int jj = 0; jj < PER; jj++) {
         const int kk = tid + jj * FPS_BLOCK;
-        const bool ok = kk < nloc;
-        t[jj] = ok ? tmp[cl.n0 + kk] : -2.f;
-        if (XYZ_REG) {
-            const int o = min(3 * kk, omax);
-            px[jj] = P[o + 0]; py[jj] = P[o + 1]; pz[jj] = P[o + 2];
+        t[jj] = (kk < nloc) ? tmp[cl.n0 + kk] : -2.f;
+        const int o = min(3 * kk, omax);
+        if (jj < RREG) { rx[jj] = P[o]; ry[jj] = P[o + 1]; rz[jj] = P[o + 2]; }
+        else if (jj < RREG + RLDS) {
+            const int l = (jj - RREG) * FPS_BLOCK + tid;
+            lds_xyz[l] = P[o]; lds_xyz[RLDS * FPS_BLOCK + l] = P[o + 1]; lds_xyz[2 * RLDS * FPS_BLOCK + l] = P[o + 2];
         }
     }
-    if (tid == 0) idx[cl.m0] = cl.n0;                                     // :39
-    int last = 0;                                                          // local index of the previous sample
+    if (tid == 0) idx[cl.m0] = cl.n0;                                // :39
+    float lx = P[0], ly = P[1], lz = P[2];                           // first sample = first point of the cloud (:26 / :34)
+
+    // coordinates of row `row` of this lane, wherever they live (called by one lane per wave and sample)
+    auto coords = [&](int row, float& x, float& y, float& z) {
+        if (row < RREG) {
+#pragma unroll
+            for (int jj = 0; jj < RREG; jj++) if (jj == row) { x = rx[jj]; y = ry[jj]; z = rz[jj]; }
+        } else if (row < RREG + RLDS) {
+            const int l = (row - RREG) * FPS_BLOCK + tid;
+            x = lds_xyz[l]; y = lds_xyz[RLDS * FPS_BLOCK + l]; z = lds_xyz[2 * RLDS * FPS_BLOCK + l];
+        } else {
+            const int o = min(3 * (tid + row * FPS_BLOCK), omax);
+            x = P[o]; y = P[o + 1]; z = P[o + 2];
+        }
+    };
+
     for (int j = cl.m0 + 1; j < cl.m1; j++) {
-        const float lx = P[3 * last + 0], ly = P[3 * last + 1], lz = P[3 * last + 2];   // uniform -> scalar
-        float bd = -1.f; unsigned brank = 0xffffffffu;
-        // opaque per-iteration copy of the lane's element offset: stops the compiler from hoisting 40
-        // loop-invariant 64-bit addresses out of the sample loop (that alone spilled ~130 VGPRs)
+        FpsBest b; b.init();
+        // opaque per-iteration copy of the lane's element offset: stops hipcc from hoisting loop-invariant 64-bit addresses of
+        // every streamed row out of the sample loop (that alone spilled > 100 VGPRs)
         int eoff = 3 * tid;
         asm volatile("" : "+v"(eoff));
-#pragma unroll
-        for (int jj = 0; jj < PER; jj++) {
-            if (jj * FPS_BLOCK < nloc) {                                      // uniform: row present
-                float x, y, z;
-                if (XYZ_REG) { x = px[jj]; y = py[jj]; z = pz[jj]; }
-                else {
-                    int o = eoff + 3 * jj * FPS_BLOCK;
-                    if ((jj + 1) * FPS_BLOCK > nloc) o = min(o, omax);       // uniform: partial row
-                    x = P[o + 0]; y = P[o + 1]; z = P[o + 2];
-                }
-                const float d = cbl_dist2(x, y, z, lx, ly, lz);              // :54
-                const float d2 = fminf(d, t[jj]);                             // :55
-                t[jj] = d2;
-                if (d2 >= bd) {                                               // candidate for (d2, rank) max
-                    const unsigned r = fps_rank(tid + jj * FPS_BLOCK, bits);
-                    if (d2 > bd || r < brank) { bd = d2; brank = r; }
-                }
+        auto row_off = [&](int jj) { int o = eoff + 3 * jj * FPS_BLOCK; if ((jj + 1) * FPS_BLOCK > nloc) o = min(o, omax); return o; };
+        auto update = [&](int jj, float x, float y, float z) {
+            const float d = cbl_dist2(x, y, z, lx, ly, lz);          // :54
+            const float d2 = fminf(d, t[jj]);                        // :55
+            t[jj] = d2;
+            b.offer(d2, jj);
+        };
+        // resident rows are cut into NB+1 slices; batch k of the streamed rows is requested before slice k and consumed after it
+        constexpr int RES = RREG + RLDS;
+        auto resident = [&](int jj) {
+            if (jj * FPS_BLOCK < nloc) {
+                if (jj < RREG) update(jj, rx[jj], ry[jj], rz[jj]);
+                else { const int l = (jj - RREG) * FPS_BLOCK + tid; update(jj, lds_xyz[l], lds_xyz[RLDS * FPS_BLOCK + l], lds_xyz[2 * RLDS * FPS_BLOCK + l]); }
             }
-            // keep the scheduler from hoisting every row's loads to the top
-            if ((jj & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        };
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            float gx[GBATCH], gy[GBATCH], gz[GBATCH];
+#pragma unroll
+            for (int g = 0; g < GBATCH; g++) {
+                const int jj = RES + k * GBATCH + g;
+                if (jj < PER && jj * FPS_BLOCK < nloc) { const int o = row_off(jj); gx[g] = P[o]; gy[g] = P[o + 1]; gz[g] = P[o + 2]; }
+            }
+#pragma unroll
+            for (int jj = (RES * k) / (NB + 1); jj < (RES * (k + 1)) / (NB + 1); jj++) resident(jj);
+#pragma unroll
+            for (int g = 0; g < GBATCH; g++) {
+                const int jj = RES + k * GBATCH + g;
+                if (jj < PER && jj * FPS_BLOCK < nloc) update(jj, gx[g], gy[g], gz[g]);
+            }
+            __builtin_amdgcn_sched_barrier(0);                       // keep one batch's loads live at a time
         }
-        const unsigned long long key = (tid < nloc) ? (((unsigned long long)__float_as_uint(bd) << 32) | (unsigned)(~brank)) : 0ull;
-        const unsigned long long win = block_max_key(key, slots, j & 1);
-        last = fps_unrank(~(unsigned)(win & 0xffffffffu), bits);
-        if (tid == 0) idx[j] = cl.n0 + last;
+#pragma unroll
+        for (int jj = (RES * NB) / (NB + 1); jj < RES; jj++) resident(jj);
+        int win;
+        block_winner(b, tid < nloc, tid, slots, j & 1, bits, coords, win, lx, ly, lz);
+        if (tid == 0) idx[j] = cl.n0 + win;
     }
-    // write the running distances back (same side effect as :56).  Slots past the end hold -2; the
-    // lane id is laundered so these addresses/masks are not kept alive across the sample loop.
+    // write the running distances back (same side effect as :56).  Slots past the end hold -2; the lane id is laundered so these
+    // addresses / masks are not kept alive across the sample loop.
     int tid_o = tid;
     asm volatile("" : "+v"(tid_o));
 #pragma unroll
@@ -151,32 +223,41 @@ __global__ __launch_bounds__(FPS_BLOCK) void fps_stream_kernel(int bits, const f
                                                                const int* __restrict__ offset, const int* __restrict__ new_offset,
                                                                float* __restrict__ tmp, int* __restrict__ idx)
 {
-    __shared__ unsigned long long slots[2][FPS_WAVES];
+    __shared__ FpsSlot slots[2][FPS_WAVES];
     const FpsCloud cl = fps_cloud(offset, new_offset);
     if (cl.m1 <= cl.m0) return;
     const int tid = threadIdx.x, nloc = cl.n1 - cl.n0;
     const float* __restrict__ P = xyz + (size_t)3 * cl.n0;
     float* __restrict__ T = tmp + cl.n0;
     if (tid == 0) idx[cl.m0] = cl.n0;
-    int last = 0;
+    float lx = P[0], ly = P[1], lz = P[2];
+    auto coords = [&](int row, float& x, float& y, float& z) { const int o = 3 * (tid + row * FPS_BLOCK); x = P[o]; y = P[o + 1]; z = P[o + 2]; };
     for (int j = cl.m0 + 1; j < cl.m1; j++) {
-        const float lx = P[3 * last + 0], ly = P[3 * last + 1], lz = P[3 * last + 2];
-        float bd = -1.f; unsigned brank = 0xffffffffu; bool any = false;
-        for (int kk = tid; kk < nloc; kk += FPS_BLOCK) {
-            const float d = cbl_dist2(P[3 * kk + 0], P[3 * kk + 1], P[3 * kk + 2], lx, ly, lz);
-            const float d2 = fminf(d, T[kk]);
+        FpsBest b; b.init();
+        int row = 0;
+        for (int kk = tid; kk < nloc; kk += FPS_BLOCK, row++) {
+            const float d2 = fminf(cbl_dist2(P[3 * kk + 0], P[3 * kk + 1], P[3 * kk + 2], lx, ly, lz), T[kk]);
             T[kk] = d2;
-            if (d2 >= bd) {
-                const unsigned r = fps_rank(kk, bits);
-                if (d2 > bd || r < brank) { bd = d2; brank = r; }
-            }
-            any = true;
+            b.offer(d2, row);
         }
-        const unsigned long long key = any ? (((unsigned long long)__float_as_uint(bd) << 32) | (unsigned)(~brank)) : 0ull;
-        const unsigned long long win = block_max_key(key, slots, j & 1);
-        last = fps_unrank(~(unsigned)(win & 0xffffffffu), bits);
-        if (tid == 0) idx[j] = cl.n0 + last;
+        int win;
+        block_winner(b, tid < nloc, tid, slots, j & 1, bits, coords, win, lx, ly, lz);
+        if (tid == 0) idx[j] = cl.n0 + win;
     }
+}
+
+template <int PER, int RREG, int RLDS>
+void launch_fps(int b, int bits, const float* xyz, const int* offset, const int* new_offset, float* tmp, int* idx, hipStream_t st)
+{
+    const size_t lds = (size_t)3 * RLDS * FPS_BLOCK * sizeof(float);
+    if (lds > 48 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_kernel<PER, RREG, RLDS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL((fps_kernel<PER, RREG, RLDS>), dim3(b), dim3(FPS_BLOCK), lds, st, bits, xyz, offset, new_offset, tmp, idx);
 }
 
 }  // namespace
@@ -201,12 +282,12 @@ CBL_EXPORT int cbl_furthestsampling(int b, int n_max, const float* xyz, const in
     const int B = ref_block_threads(n_max);
     int bits = 0; while ((1 << bits) < B) bits++;
     hipStream_t st = cbl_stream(stream);
-    const dim3 grid(b), block(FPS_BLOCK);
-    if (n_max <= 1 * FPS_BLOCK)       hipLaunchKernelGGL((fps_reg_kernel<1, true>),  grid, block, 0, st, bits, xyz, offset, new_offset, tmp, idx);
-    else if (n_max <= 4 * FPS_BLOCK)  hipLaunchKernelGGL((fps_reg_kernel<4, true>),  grid, block, 0, st, bits, xyz, offset, new_offset, tmp, idx);
-    else if (n_max <= 10 * FPS_BLOCK) hipLaunchKernelGGL((fps_reg_kernel<10, true>), grid, block, 0, st, bits, xyz, offset, new_offset, tmp, idx);
-    else if (n_max <= 16 * FPS_BLOCK) hipLaunchKernelGGL((fps_reg_kernel<16, true>), grid, block, 0, st, bits, xyz, offset, new_offset, tmp, idx);
-    else if (n_max <= 40 * FPS_BLOCK) hipLaunchKernelGGL((fps_reg_kernel<40, false>), grid, block, 0, st, bits, xyz, offset, new_offset, tmp, idx);
-    else                              hipLaunchKernelGGL(fps_stream_kernel,          grid, block, 0, st, bits, xyz, offset, new_offset, tmp, idx);
+    if (n_max <= 1 * FPS_BLOCK)       launch_fps<1, 1, 0>(b, bits, xyz, offset, new_offset, tmp, idx, st);
+    else if (n_max <= 4 * FPS_BLOCK)  launch_fps<4, 4, 0>(b, bits, xyz, offset, new_offset, tmp, idx, st);
+    else if (n_max <= 10 * FPS_BLOCK) launch_fps<10, 10, 0>(b, bits, xyz, offset, new_offset, tmp, idx, st);
+    else if (n_max <= 16 * FPS_BLOCK) launch_fps<16, 16, 0>(b, bits, xyz, offset, new_offset, tmp, idx, st);
+    else if (n_max <= 27 * FPS_BLOCK) launch_fps<27, 14, 13>(b, bits, xyz, offset, new_offset, tmp, idx, st);
+    else if (n_max <= 40 * FPS_BLOCK) launch_fps<40, 6, 13>(b, bits, xyz, offset, new_offset, tmp, idx, st);
+    else                              hipLaunchKernelGGL(fps_stream_kernel, dim3(b), dim3(FPS_BLOCK), 0, st, bits, xyz, offset, new_offset, tmp, idx);
     return cbl_status();
 }
