@@ -112,9 +112,20 @@ def main():
                         "compulsory bytes (they are latency/issue bound, not HBM bound) - the HBM-bound kernel of the path is the gather, see hbm_gather",
                 "stage_ms": {names[i]: round(stage_ms[i], 4) for i in range(len(stages))},
                 "stage_algorithmic_GBps": {names[i]: round(gbps(i), 1) for i in range(len(stages))}}
+    # HBM traffic per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes of this same command with
+    # the default workload: tools/gpu_pmc.sh -> profiles/r01_pmc_traffic.json; counters cannot be read from inside the process)
+    pmc = {}
+    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(pmc_file) and (n, c, k) == (40960, 64, 16):
+        pmc = json.load(open(pmc_file))
+    pmc_kernel = {"knnquery_k16": "knn_grid_group_kernel<16, true>", "queryandgroup": "query_group_v4", "kpconv_fwd": "kpconv_fwd_kernel<true>",
+                  "cbl_knnquery_k36": "knn_grid_group_kernel<64, true>", "cbl_mining_loss_fwd": "contrast_fwd_kernel<64, 8>",
+                  "cbl_mining_loss_bwd": "contrast_bwd_kernel<64, 8>"}
+    traffic = lambda stage: pmc.get(pmc_kernel.get(stage, ""), {}).get("hbm_bytes_per_launch")
+    roofline["traffic"] = traffic(names[dom])
     gi = names.index("queryandgroup")
     roofline["hbm_gather"] = {"kernel": "query_group_v4", "bound": "hbm", "achieved": gbps(gi), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": gbps(gi) / HBM_PEAK_GBS, "bytes_per_launch": stages[gi][2]}
+                              "frac": gbps(gi) / HBM_PEAK_GBS, "bytes_per_launch": stages[gi][2], "traffic": traffic("queryandgroup")}
     ki = names.index("kpconv_fwd")
     roofline["mfma_kpconv"] = {"kernel": "kpconv_fwd_kernel", "bound": "mfma", "achieved": stages[ki][3] / (stage_ms[ki] * 1e-3) / 1e12,
                                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": stages[ki][3] / (stage_ms[ki] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
