@@ -80,6 +80,31 @@ __global__ __launch_bounds__(256) void grid_bbox_kernel(int b, int n, const floa
     const int r0 = blockIdx.x * per, r1 = min(n, r0 + per);
     const int lane = threadIdx.x & 63;
     int i = r0 + threadIdx.x;
+    if (r0 >= r1) return;
+    {   // common case: the whole slice lies in one cloud -> reduce across the workgroup in LDS, 6 atomics per workgroup
+        const int cfirst = cbl_cloud_of(r0, offset, b);
+        if (cfirst == cbl_cloud_of(r1 - 1, offset, b)) {
+            __shared__ float red[6][4];
+            float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (; i < r1; i += 256) {
+#pragma unroll
+                for (int a = 0; a < 3; a++) { const float v = xyz[3 * i + a]; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); }
+            }
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                for (int s = 32; s >= 1; s >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], s)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], s)); }
+                if (lane == 0) { red[a][threadIdx.x >> 6] = lo[a]; red[3 + a][threadIdx.x >> 6] = hi[a]; }
+            }
+            __syncthreads();
+            if (threadIdx.x < 6) {
+                const int a = threadIdx.x;
+                const float v0 = red[a][0], v1 = red[a][1], v2 = red[a][2], v3 = red[a][3];
+                if (a < 3) atomicMin(bbox + cfirst * 6 + a, f2key(fminf(fminf(v0, v1), fminf(v2, v3))));
+                else       atomicMax(bbox + cfirst * 6 + a, f2key(fmaxf(fmaxf(v0, v1), fmaxf(v2, v3))));
+            }
+            return;
+        }
+    }
     while (__any(i < r1)) {
         const bool act = i < r1;
         const int myc = act ? cbl_cloud_of(i, offset, b) : -1;
@@ -390,7 +415,11 @@ __global__ __launch_bounds__(256) void radius_group_kernel(int b, int nq, int ns
     for (int s = G / 2; s >= 1; s >>= 1) inside += __shfl_xor(inside, s, G);
     if (live) {
         if (gl < limit) out[(size_t)q * limit + gl] = (ed < INFINITY) ? ei : ns_total;     // pad with supports.size(), neighbors.cpp:328
-        if (gl == 0) { if (counts) counts[q] = inside; atomicMax(max_count, inside); }
+        if (gl == 0) {
+            if (counts) counts[q] = inside;
+            // one address for the whole launch: only groups that would raise the maximum touch it (monotone, so a stale read only costs a redundant atomic)
+            if (inside > __hip_atomic_load(max_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_count, inside);
+        }
     }
 }
 

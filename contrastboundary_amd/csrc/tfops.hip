@@ -122,9 +122,19 @@ __global__ __launch_bounds__(256) void sub_reduce_kernel(int n, const unsigned l
             }
             out_lab[(size_t)v * ldim + c] = best;
         }
-        atomicAdd(out_lengths + (int)(key >> 48), 1);
-        atomicAdd(out_total, 1);
+        // voxel counts without same-address atomics: the last head of a cloud publishes the running voxel number at the cloud's end
+        const bool last_of_cloud = (e == n) || ((keys[e] >> 48) != (key >> 48));
+        if (last_of_cloud) out_lengths[(int)(key >> 48)] = v + 1;          // cumulative for now; differenced by sub_lengths_kernel
+        if (e == n) out_total[0] = v + 1;
     }
+}
+
+// cumulative voxel counts at cloud ends -> per-cloud counts (clouds without points keep 0)
+__global__ void sub_lengths_kernel(int b, int* __restrict__ out_lengths)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    int prev = 0;
+    for (int c = 0; c < b; c++) { const int cum = out_lengths[c]; if (cum > 0) { out_lengths[c] = cum - prev; prev = cum; } }
 }
 
 // N4: local int64 indices of a dense batch from the stacked KNN result
@@ -214,6 +224,7 @@ CBL_EXPORT int cbl_grid_subsampling(int b, int n, const float* points, const int
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(sub_reduce_kernel, g, blk, 0, st, n, w.keys_out, w.vals_out, w.flags, w.vox_id, points, fdim, features, ldim, labels,
                        out_points, out_features, out_labels, out_lengths, out_total);
+    hipLaunchKernelGGL(sub_lengths_kernel, dim3(1), dim3(64), 0, st, b, out_lengths);
     return cbl_status();
 }
 

@@ -42,3 +42,12 @@ def cbl():
 rep("CBL mining+loss fwd+bwd (K=36,d=32)", timeit(cbl), 2*(4*n*35 + 4*n*32 + 4*n) + 4*n*32)
 x = torch.empty(64*1024*1024, device="cuda"); y = torch.empty_like(x)
 rep("torch d2d copy 256 MB (ceiling)", timeit(lambda: y.copy_(x)), 2*x.numel()*4)
+# ---- TF-side ops at C5 scale (N = 200000)
+from contrastboundary_amd import tf_ops, voxelize as VZ, synthetic as S
+xyz5, _ = S.s_room(200000, seed=0, scale=4.0)
+x5 = torch.from_numpy(xyz5).cuda(); l5 = torch.tensor([200000], dtype=torch.int32, device="cuda")
+print(f"{'radius r=0.1 limit 26 (N=200k)':34s} {timeit(lambda: tf_ops.tf_batch_neighbors(x5, x5, l5, l5, 0.1, 26, exact_shape=False), 10):8.1f} us")
+print(f"{'grid subsample dl=0.08 (N=200k)':34s} {timeit(lambda: tf_ops.tf_batch_subsampling(x5, l5, 0.08), 10):8.1f} us  (incl. 1 host sync)")
+print(f"{'pyramid 5 layers (N=200k)':34s} {timeit(lambda: tf_ops.segmentation_inputs_radius(x5, l5, 0.04, 5.0, 5, [26, 31, 38, 41, 39]), 5):8.1f} us")
+print(f"{'voxelize 0.04 (N=200k)':34s} {timeit(lambda: VZ.voxelize(x5, 0.04, mode=1), 10):8.1f} us  (incl. 1 host sync)")
+print(f"{'knnquery K=16 (N=200k)':34s} {timeit(lambda: pointops.knnquery_raw(16, x5, x5, torch.cumsum(l5,0,dtype=torch.int32), torch.cumsum(l5,0,dtype=torch.int32)), 10):8.1f} us")
