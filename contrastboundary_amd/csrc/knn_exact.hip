@@ -61,6 +61,38 @@ __device__ __forceinline__ void heap_replace_root(Heap& h, int len, float d, int
     h.set(parent, d, id);
 }
 
+// Ancestor chain of heap slot `lane` as a bit mask over slots (the slot itself up to, excluding, the root).
+__device__ __forceinline__ unsigned long long heap_ancestors(int lane)
+{
+    unsigned long long a = 0;
+    for (int c = lane; c >= 1; c = (c - 1) >> 1) a |= 1ull << c;
+    return a;
+}
+// reheap() without the walk: all 64 slots decide at once what they hold after (d, id) replaced the root and sank.
+//   * the sink path follows each slot's BIGGER child (right child only when strictly larger, :27).  Slot c is its parent's
+//     bigger child  <=>  `isbig` (sibling key through a one-lane DPP shift); it is ON the path  <=>  every slot of its ancestor
+//     chain is a bigger child: one ballot, then a mask compare against the precomputed chain;
+//   * keys along the path are non-increasing, so the element passes slot c's parent  <=>  !(d > key[c]) (:29), lane-local;
+//   * a reached slot takes its bigger child's entry if the element also passes it, else the element itself.
+// One LDS-crossbar round trip (the children's entries) and ~20 VALU ops, against a 6-level serial walk.
+__device__ __forceinline__ void heap_replace_root_par(float& hd, int& hi, int lane, unsigned long long anc, int len, float d, int id)
+{
+    const int l = 2 * lane + 1, r = l + 1;
+    const float kl = __shfl(hd, l & 63), kr = __shfl(hd, r & 63);
+    const int il = __shfl(hi, l & 63), ir = __shfl(hi, r & 63);
+    const bool right = (r < len) && (kr > kl);               // right child only when strictly larger (:27)
+    const float bk = right ? kr : kl;
+    const int bi = right ? ir : il;
+    const float up = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(hd), __float_as_int(hd), 0x130, 0xf, 0xf, false));   // slot lane+1
+    const float dn = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(hd), __float_as_int(hd), 0x138, 0xf, 0xf, false));   // slot lane-1
+    const bool isbig = (lane < len) && ((lane & 1) ? !((lane + 1 < len) && (up > hd)) : (hd > dn));
+    const unsigned long long big = __ballot(isbig);
+    const bool onpath = (big & anc) == anc;                  // root: empty chain
+    const bool reached = onpath && (lane == 0 || !(d > hd)); // stop only when strictly larger (:29)
+    const bool sinks = (l < len) && !(d > bk);
+    if (reached) { hd = sinks ? bk : d; hi = sinks ? bi : id; }
+}
+
 template <bool IN_LANES>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void knn_exact_wave_kernel(
     int b, int m, int K,
@@ -91,6 +123,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void knn_exact_wave_kernel(
     }
     h.init(K, 1e10f, start);                                         // :91-94
     float root = 1e10f;
+    const unsigned long long anc = heap_ancestors(lane);
+    auto replace_root = [&](int len, float d, int id) {
+        if constexpr (IN_LANES) heap_replace_root_par(h.hd, h.hi, lane, anc, len, d, id);
+        else heap_replace_root(h, len, d, id);
+    };
 
     // U chunks of 64 supports are loaded ahead of their use: a lone wave (replay mode) would otherwise pay
     // one full memory latency per 64 supports.  Chunks are still consumed strictly in index order.
@@ -114,7 +151,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void knn_exact_wave_kernel(
                 mask &= mask - 1;
                 const float dl = rl_f(d2[u], l);
                 if (dl < root) {                                     // root may have dropped since the ballot
-                    heap_replace_root(h, K, dl, base + 64 * u + l);
+                    replace_root(K, dl, base + 64 * u + l);
                     root = h.D(0);
                 }
             }
@@ -125,7 +162,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void knn_exact_wave_kernel(
     for (int last = K - 1; last > 0; last--) {
         const float d = h.D(last); const int id = h.I(last);
         h.set(last, h.D(0), h.I(0));
-        heap_replace_root(h, last, d, id);
+        replace_root(last, d, id);
     }
     int* orow = idx + (size_t)q * K; float* drow = dist2 + (size_t)q * K;
     if constexpr (IN_LANES) {
@@ -142,34 +179,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void knn_exact_wave_kernel(
 // The reference's result depends on the full visiting history, but a support only matters if it beats the heap root at
 // its turn, and the root at turn t is the K-th smallest distance among supports [start, t) — non-increasing in t.  So:
 //   A. wave 0 feeds the first T0 supports to the heap in order (the dense part of the history);
-//      meanwhile wave 1 computes B = the K-th smallest distance among those T0 supports (bisection on the float bits): an
+//      meanwhile waves 1..15 compute B = the K-th smallest distance among those T0 supports (bisection on the float bits): an
 //      upper bound of the root for every later turn, hence every later support with d2 >= B is a no-op and can be dropped;
-//   B. waves 1..15 filter the remaining supports against B in parallel into per-wave LDS lists, in index order
+//   B. still under A, waves 1..15 filter the remaining supports against B into per-wave LDS lists, in index order
 //      (expected n*K/T0 survivors in total);
 //   C. wave 0 feeds the lists to the heap in order, then heap-sorts.
 // Identical heap operations as the straight scan, i.e. identical ties; the 40960-support scan no longer sits on one
-// wave's memory latency.  The heap insert itself is restructured: every lane first finds its slot's larger child
-// (4 cross-lane reads), then the sift walks the root path with scalar reads of those precomputed children.
+// wave's memory latency.  The heap insert itself is done without a walk (heap_replace_root_par below).
 constexpr int RP_WAVES = 16, RP_T0 = 1024, RP_LIST = 512, RP_MAX_WORK = 1024, RP_GRID = 128;
-
-__device__ __forceinline__ void heap_replace_root_fast(float& hd, int& hi, int lane, int len, float d, int id)
-{
-    const int l = 2 * lane + 1, r = l + 1;
-    const float kl = __shfl(hd, l & 63), kr = __shfl(hd, r & 63);
-    const int il = __shfl(hi, l & 63), ir = __shfl(hi, r & 63);
-    const bool right = (r < len) && (kr > kl);               // right child only when strictly larger (:27)
-    const float bk = right ? kr : kl;
-    const int bi = right ? ir : il, bc = right ? r : l;
-    int p = 0;
-    while (2 * p + 1 < len) {
-        const float k = rl_f(bk, p);
-        if (d > k) break;                                     // stop only when strictly larger (:29)
-        const int c = rl_i(bc, p), ci = rl_i(bi, p);
-        if (lane == p) { hd = k; hi = ci; }
-        p = c;
-    }
-    if (lane == p) { hd = d; hi = id; }
-}
 
 __global__ __launch_bounds__(64 * RP_WAVES) void knn_replay_kernel(
     int b, int K, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
@@ -181,7 +198,6 @@ __global__ __launch_bounds__(64 * RP_WAVES) void knn_replay_kernel(
     __shared__ float cand_d[RP_WAVES][RP_LIST];
     __shared__ int cand_i[RP_WAVES][RP_LIST];
     __shared__ int cand_n[RP_WAVES];
-    __shared__ float bound_s;
     __shared__ int overflow_s;
 
     const int n_work = *worklist_count;
@@ -202,21 +218,22 @@ __global__ __launch_bounds__(64 * RP_WAVES) void knn_replay_kernel(
         const float d = (t0 > 0) ? cbl_dist2(qx, qy, qz, xyz[3 * i + 0], xyz[3 * i + 1], xyz[3 * i + 2]) : INFINITY;
         dA[tid] = (tid < t0) ? d : INFINITY;
         if (tid < RP_WAVES) cand_n[tid] = 0;
-        if (tid == 0) { overflow_s = 0; bound_s = INFINITY; }
+        if (tid == 0) overflow_s = 0;
     }
     __syncthreads();
 
     float hd = 1e10f; int hi = start;                           // heap slot `lane` of wave 0 (:91-94)
     float root = 1e10f;
-    auto feed = [&](float d2, int first_index_of_chunk, const int* ids) {
+    const unsigned long long anc = heap_ancestors(lane);
+    // feed one chunk: lane l holds candidate l's distance and support index; accepted ones enter the heap in lane order
+    auto feed = [&](float d2, int idv) {
         unsigned long long mask = __ballot(d2 < root);          // strict, :100
         while (mask) {
             const int l = __builtin_ctzll(mask);
             mask &= mask - 1;
             const float dl = rl_f(d2, l);
-            if (dl < root) {
-                const int id = ids ? ids[l] : first_index_of_chunk + l;
-                heap_replace_root_fast(hd, hi, lane, K, dl, id);
+            if (dl < root) {                                    // the root may have dropped since the ballot
+                heap_replace_root_par(hd, hi, lane, anc, K, dl, rl_i(idv, l));
                 root = rl_f(hd, 0);
             }
         }
@@ -224,36 +241,28 @@ __global__ __launch_bounds__(64 * RP_WAVES) void knn_replay_kernel(
 
     if (wave == 0) {
         // A (wave 0): the first t0 supports, in order
-        for (int base = 0; base < t0; base += 64) feed(dA[base + lane], start + base, nullptr);
-    } else {
-        if (wave == 1 && n_c > t0) {
-            // A (wave 1): K-th smallest of dA by bisection on the bit patterns (all values >= 0)
-            unsigned v[RP_T0 / 64];
+        for (int base = 0; base < t0; base += 64) feed(dA[base + lane], start + base + lane);
+    } else if (n_c > t0) {
+        // A' (waves 1..15, each for itself — cheaper than a second barrier): B = K-th smallest of dA, by bisection on the bit
+        // patterns (all values >= 0; +inf if fewer than K finite values: nothing can be dropped)
+        unsigned v[RP_T0 / 64];
 #pragma unroll
-            for (int j = 0; j < RP_T0 / 64; j++) v[j] = __float_as_uint(dA[lane + 64 * j]);
-            unsigned lo = 0u, hi_b = 0x7f800000u;
-            while (lo < hi_b) {
-                const unsigned mid = lo + ((hi_b - lo) >> 1);
-                int cnt = 0;
+        for (int j = 0; j < RP_T0 / 64; j++) v[j] = __float_as_uint(dA[lane + 64 * j]);
+        unsigned lo = 0u, hi_b = 0x7f800000u;
+        while (lo < hi_b) {
+            const unsigned mid = lo + ((hi_b - lo) >> 1);
+            int cnt = 0;
 #pragma unroll
-                for (int j = 0; j < RP_T0 / 64; j++) cnt += (v[j] <= mid) ? 1 : 0;
-#pragma unroll
-                for (int sft = 32; sft >= 1; sft >>= 1) cnt += __shfl_xor(cnt, sft);
-                if (cnt >= K) hi_b = mid; else lo = mid + 1;
-            }
-            if (lane == 0) bound_s = __uint_as_float(lo);       // +inf if fewer than K finite values: nothing can be dropped
+            for (int j = 0; j < RP_T0 / 64; j++) cnt += __popcll(__ballot(v[j] <= mid));
+            if (cnt >= K) hi_b = mid; else lo = mid + 1;
         }
-    }
-    __syncthreads();
-
-    if (n_c > t0) {
-        // B: every wave filters its contiguous share of [t0, n_c) against the bound, keeping index order
-        const float B = bound_s;
+        const float B = __uint_as_float(lo);
+        // B (waves 1..15, while wave 0 is still in A): filter a contiguous share of [t0, n_c) against the bound, keeping index order
         const int rem = n_c - t0;
-        const int per = ((rem + RP_WAVES * 64 - 1) / (RP_WAVES * 64)) * 64;
-        const int lo_i = start + t0 + wave * per, hi_i = min(end, lo_i + per);
+        const int per = ((rem + (RP_WAVES - 1) * 64 - 1) / ((RP_WAVES - 1) * 64)) * 64;
+        const int lo_i = start + t0 + (wave - 1) * per, hi_i = min(end, lo_i + per);
         int filled = 0;
-        constexpr int U = 4;
+        constexpr int U = 8;
         for (int base = lo_i; base < hi_i; base += 64 * U) {
             float d2[U];
 #pragma unroll
@@ -283,12 +292,11 @@ __global__ __launch_bounds__(64 * RP_WAVES) void knn_replay_kernel(
     if (n_c > t0) {
         if (!overflow_s) {
             // C: the survivors, wave list after wave list = ascending support index
-            for (int w = 0; w < RP_WAVES; w++) {
+            for (int w = 1; w < RP_WAVES; w++) {
                 const int cn = cand_n[w];
                 for (int base = 0; base < cn; base += 64) {
-                    const int j = base + lane;
-                    const float d2 = (j < cn) ? cand_d[w][j] : INFINITY;
-                    feed(d2, 0, &cand_i[w][base]);
+                    const int j = min(base + lane, cn - 1);
+                    feed((base + lane < cn) ? cand_d[w][j] : INFINITY, cand_i[w][j]);
                 }
             }
         } else {
@@ -297,7 +305,7 @@ __global__ __launch_bounds__(64 * RP_WAVES) void knn_replay_kernel(
                 const int i = base + lane;
                 const int ic = min(i, end - 1);
                 const float d = cbl_dist2(qx, qy, qz, xyz[3 * ic + 0], xyz[3 * ic + 1], xyz[3 * ic + 2]);
-                feed((i < end) ? d : INFINITY, base, nullptr);
+                feed((i < end) ? d : INFINITY, i);
             }
         }
     }
@@ -306,7 +314,7 @@ __global__ __launch_bounds__(64 * RP_WAVES) void knn_replay_kernel(
         const float d = rl_f(hd, last); const int id = rl_i(hi, last);
         const float r0 = rl_f(hd, 0); const int i0 = rl_i(hi, 0);
         if (lane == last) { hd = r0; hi = i0; }
-        heap_replace_root_fast(hd, hi, lane, last, d, id);
+        heap_replace_root_par(hd, hi, lane, anc, last, d, id);
     }
     if (lane < K) { idx[(size_t)q * K + lane] = hi; dist2[(size_t)q * K + lane] = hd; }
     }

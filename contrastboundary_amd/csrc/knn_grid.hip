@@ -338,6 +338,218 @@ __global__ __launch_bounds__(256) void knn_grid_group_kernel(int b, int m, int K
     }
 }
 
+// ---- 3b. 16 < K <= 64: one WAVE per query, select-then-sort over the 27-cell block --------------------------------
+// The insertion list above costs one serial step per accepted candidate (~K(1+ln(T/K)) of them).  Here the wave first loads
+// ALL T candidates of the 3x3x3 block into registers (the 9 x-rows are one virtual range: all loads independent and coalesced),
+// bisects a threshold tau with K <= #{d2 <= tau} <= 64 by ballot+popcount, compacts the survivors to one per lane through LDS
+// and sorts them with a 21-stage bitonic network (DPP / ds_swizzle exchanges).  Lanes [0,K) then hold the ascending list, all
+// other candidates feed `rejmin`, and the usual certification applies; further shells (rare) use the insertion step.
+constexpr int WV_NB = 16;                                           // candidate registers per lane: T <= 1024
+
+template <int CTRL> __device__ __forceinline__ int dppx_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+struct PermQuadXor1  { __device__ __forceinline__ int operator()(int v, int) const { return dppx_i<0xB1>(v); } };    // lane ^ 1
+struct PermQuadXor2  { __device__ __forceinline__ int operator()(int v, int) const { return dppx_i<0x4E>(v); } };    // lane ^ 2
+struct PermQuadMir   { __device__ __forceinline__ int operator()(int v, int) const { return dppx_i<0x1B>(v); } };    // lane ^ 3
+struct PermHalfMir   { __device__ __forceinline__ int operator()(int v, int) const { return dppx_i<0x141>(v); } };   // lane ^ 7
+struct PermRowMir    { __device__ __forceinline__ int operator()(int v, int) const { return dppx_i<0x140>(v); } };   // lane ^ 15
+struct PermRowRor8   { __device__ __forceinline__ int operator()(int v, int) const { return dppx_i<0x128>(v); } };   // lane ^ 8
+struct PermSwzXor4   { __device__ __forceinline__ int operator()(int v, int) const { return __builtin_amdgcn_ds_swizzle(v, 0x101f); } };
+struct PermSwzXor16  { __device__ __forceinline__ int operator()(int v, int) const { return __builtin_amdgcn_ds_swizzle(v, 0x401f); } };
+struct PermSwzMir32  { __device__ __forceinline__ int operator()(int v, int) const { return __builtin_amdgcn_ds_swizzle(v, 0x7c1f); } };   // lane ^ 31
+struct PermMir64     { __device__ __forceinline__ int operator()(int v, int lane) const { return __builtin_amdgcn_ds_bpermute((63 - lane) << 2, v); } };
+
+// compare-exchange with the partner lane: the lower lane of a pair keeps the smaller distance (ties: both keep their own)
+template <class Perm> __device__ __forceinline__ void sort_cx(float& d, int& i, bool lower, int lane, Perm perm)
+{
+    const float pd = __int_as_float(perm(__float_as_int(d), lane));
+    const int pi = perm(i, lane);
+    const bool take = lower ? (pd < d) : (pd > d);
+    d = take ? pd : d; i = take ? pi : i;
+}
+// ascending bitonic sort of one (d, i) per lane over the 64 lanes ("flip" form: every merge starts with a mirror exchange)
+__device__ __forceinline__ void wave_sort64(float& d, int& i, int lane)
+{
+    const bool l1 = !(lane & 1), l2 = !(lane & 2), l4 = !(lane & 4), l8 = !(lane & 8), l16 = !(lane & 16), l32 = !(lane & 32);
+    sort_cx(d, i, l1, lane, PermQuadXor1());
+    sort_cx(d, i, l2, lane, PermQuadMir());   sort_cx(d, i, l1, lane, PermQuadXor1());
+    sort_cx(d, i, l4, lane, PermHalfMir());   sort_cx(d, i, l2, lane, PermQuadXor2()); sort_cx(d, i, l1, lane, PermQuadXor1());
+    sort_cx(d, i, l8, lane, PermRowMir());    sort_cx(d, i, l4, lane, PermSwzXor4());  sort_cx(d, i, l2, lane, PermQuadXor2());
+    sort_cx(d, i, l1, lane, PermQuadXor1());
+    sort_cx(d, i, l16, lane, PermSwzMir32()); sort_cx(d, i, l8, lane, PermRowRor8());  sort_cx(d, i, l4, lane, PermSwzXor4());
+    sort_cx(d, i, l2, lane, PermQuadXor2());  sort_cx(d, i, l1, lane, PermQuadXor1());
+    sort_cx(d, i, l32, lane, PermMir64());    sort_cx(d, i, l16, lane, PermSwzXor16()); sort_cx(d, i, l8, lane, PermRowRor8());
+    sort_cx(d, i, l4, lane, PermSwzXor4());   sort_cx(d, i, l2, lane, PermQuadXor2()); sort_cx(d, i, l1, lane, PermQuadXor1());
+}
+__device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+template <bool SELF>
+__global__ __launch_bounds__(256) void knn_grid_wave_kernel(int b, int m, int K, const float* __restrict__ new_xyz,
+                                                            const int* __restrict__ offset, const int* __restrict__ new_offset,
+                                                            const CblGrid* __restrict__ grids, const int* __restrict__ cell_start,
+                                                            const float4* __restrict__ sorted, int* __restrict__ idx, float* __restrict__ dist2,
+                                                            int* __restrict__ worklist, int* __restrict__ counters, int set_exact)
+{
+    __shared__ float2 slots[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int t = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);      // one query per wave
+    if (t >= m) return;
+    int q; float qx, qy, qz;
+    if (SELF) { const float4 s = sorted[t]; q = __float_as_int(s.w); qx = s.x; qy = s.y; qz = s.z; }   // cell order
+    else      { q = t; qx = new_xyz[3 * q]; qy = new_xyz[3 * q + 1]; qz = new_xyz[3 * q + 2]; }
+    q = __builtin_amdgcn_readfirstlane(q);
+    const int c = cbl_cloud_of(q, SELF ? offset : new_offset, b);
+    const CblGrid g = grids[c];
+    const float uqx = cbl_u(qx, g.ox, g.inv_cs), uqy = cbl_u(qy, g.oy, g.inv_cs), uqz = cbl_u(qz, g.oz, g.inv_cs);
+    const int cx = cbl_cell_coord(uqx, g.nx), cy = cbl_cell_coord(uqy, g.ny), cz = cbl_cell_coord(uqz, g.nz);
+
+    // ---- the 9 x-rows of the 27-cell block: lane r < 9 fetches row r's support range
+    int rs = 0, rlen = 0;
+    if (lane < 9) {
+        const int y = cy + lane % 3 - 1, z = cz + lane / 3 - 1;
+        if (y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
+            const int row = g.cell_base + g.nx * (y + g.ny * z);
+            rs = cell_start[row + max(cx - 1, 0)];
+            rlen = cell_start[row + min(cx + 1, g.nx - 1) + 1] - rs;
+        }
+    }
+    int pre[9], delta[9], T = 0;                                     // wave-uniform: row r covers virtual positions [pre[r], pre[r]+len)
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+        const int s_r = __builtin_amdgcn_readlane(rs, r), l_r = __builtin_amdgcn_readlane(rlen, r);
+        pre[r] = T; delta[r] = s_r - T; T += l_r;
+    }
+
+    float ed = INFINITY; int ei = -1;                                // element `lane` of the ascending top list
+    float rejmin = INFINITY;
+    bool fast = (T >= K) && (T <= 64 * WV_NB);
+    if (fast) {
+        float d[WV_NB]; int id[WV_NB];
+#pragma unroll
+        for (int j = 0; j < WV_NB; j++) {
+            d[j] = INFINITY; id[j] = -1;
+            if (j * 64 < T) {
+                const int v = j * 64 + lane;
+                if (v < T) {
+                    int dl = delta[0];
+#pragma unroll
+                    for (int r = 1; r < 9; r++) dl = (v >= pre[r]) ? delta[r] : dl;
+                    const float4 p = sorted[v + dl];
+                    d[j] = cbl_dist2(qx, qy, qz, p.x, p.y, p.z);      // knnquery_cuda_kernel.cu:99
+                    id[j] = __float_as_int(p.w);
+                }
+            }
+        }
+        // ---- threshold: K <= #{d <= tau} <= 64
+        float tau = 3.0e38f;
+        if (T > 64) {
+            float mx = -1.f;
+#pragma unroll
+            for (int j = 0; j < WV_NB; j++) mx = fmaxf(mx, d[j] < INFINITY ? d[j] : -1.f);
+            mx = fmaxf(mx, __int_as_float(dppx_i<0xB1>(__float_as_int(mx))));
+            mx = fmaxf(mx, __int_as_float(dppx_i<0x4E>(__float_as_int(mx))));
+            mx = fmaxf(mx, __int_as_float(dppx_i<0x141>(__float_as_int(mx))));
+            mx = fmaxf(mx, __int_as_float(dppx_i<0x140>(__float_as_int(mx))));
+            float lo = -1.f, hi = fmaxf(fmaxf(rl_f(mx, 0), rl_f(mx, 16)), fmaxf(rl_f(mx, 32), rl_f(mx, 48)));
+            fast = false;
+            for (int it = 0; it < 40; it++) {
+                const float mid = it == 0 ? hi * ((float)(K + 64) * 0.6f / (float)T) : lo + (hi - lo) * 0.5f;
+                if (!(mid > lo && mid < hi)) break;                  // no float left between the brackets: ties, use the insertion path
+                int cnt = 0;
+#pragma unroll
+                for (int j = 0; j < WV_NB; j++) cnt += __popcll(__ballot(d[j] <= mid));
+                if (cnt < K) lo = mid; else if (cnt > 64) hi = mid; else { tau = mid; fast = true; break; }
+            }
+        }
+        if (fast) {
+            int base = 0;
+#pragma unroll
+            for (int j = 0; j < WV_NB; j++) {
+                if (j * 64 < T) {
+                    const bool pass = d[j] <= tau;
+                    const unsigned long long mk = __ballot(pass);
+                    if (pass) {
+                        const int slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0));
+                        slots[wv][slot] = make_float2(d[j], __int_as_float(id[j]));
+                    } else rejmin = fminf(rejmin, d[j]);
+                    base += __popcll(mk);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float sd = INFINITY; int si = -1;
+            if (lane < base) { const float2 v = slots[wv][lane]; sd = v.x; si = __float_as_int(v.y); }
+            wave_sort64(sd, si, lane);
+            if (lane < K) { ed = sd; ei = si; } else rejmin = fminf(rejmin, sd);
+        }
+    }
+
+    bool done = false;
+    int r = 1;
+    if (fast) {
+        const float bound2 = cbl_outside_bound2(g, uqx, uqy, uqz, cx, cy, cz, 1);
+        done = (bound2 == INFINITY) || (rl_f(ed, K - 1) < bound2);
+        r = 2;
+    }
+    for (; !done; r++) {
+        // r == 1: the whole 3x3x3 block as 9 full rows (only when the fast path bailed out); r >= 2: shell r
+        const int side = 2 * r + 1;
+        for (int ri = 0; ri < side * side; ri++) {
+            const int dz = ri / side - r, dy = ri % side - r;
+            const bool full = (r == 1) || dz == -r || dz == r || dy == -r || dy == r;
+            const int nseg = full ? 1 : 2;
+            for (int sg = 0; sg < nseg; sg++) {
+                int x0, x1;
+                if (full) { x0 = max(cx - r, 0); x1 = min(cx + r, g.nx - 1); }
+                else      { x0 = x1 = sg ? cx + r : cx - r; }
+                const int y = cy + dy, z = cz + dz;
+                int s = 0, e = 0;
+                if (y >= 0 && y < g.ny && z >= 0 && z < g.nz && x0 >= 0 && x1 <= g.nx - 1) {
+                    const int row = g.cell_base + g.nx * (y + g.ny * z);
+                    s = cell_start[row + x0]; e = cell_start[row + x1 + 1];
+                }
+                s = __builtin_amdgcn_readfirstlane(s); e = __builtin_amdgcn_readfirstlane(e);
+                for (int p = s; p < e; p += 64) {
+                    const int pi = p + lane;
+                    float d2 = INFINITY; int ci = -1;
+                    if (pi < e) {
+                        const float4 v = sorted[pi];
+                        d2 = cbl_dist2(qx, qy, qz, v.x, v.y, v.z);
+                        ci = __float_as_int(v.w);
+                    }
+                    const float worst = rl_f(ed, K - 1);
+                    const bool pass = d2 < worst;
+                    rejmin = fminf(rejmin, pass ? INFINITY : d2);
+                    unsigned long long gm = __ballot(pass);
+                    while (gm) {
+                        const int l = __builtin_ctzll(gm);
+                        gm &= gm - 1;
+                        const float dc = rl_f(d2, l); const int ic = __builtin_amdgcn_readlane(ci, l);
+                        const float pd = dpp_shr1_f<64>(ed); const int pidx = dpp_shr1_i<64>(ei);
+                        const bool gt = ed > dc;
+                        const bool left_gt = (lane > 0) && (pd > dc);
+                        if (lane == K - 1) rejmin = fminf(rejmin, gt ? ed : dc);
+                        if (gt) { if (left_gt) { ed = pd; ei = pidx; } else { ed = dc; ei = ic; } }
+                    }
+                }
+            }
+        }
+        const float bound2 = cbl_outside_bound2(g, uqx, uqy, uqz, cx, cy, cz, r);
+        done = (bound2 == INFINITY) || (rl_f(ed, K - 1) < bound2);
+    }
+
+    // certify (as in the group kernel)
+    const float worst = rl_f(ed, K - 1);
+    float rm = rejmin;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) rm = fminf(rm, __shfl_xor(rm, s, 64));
+    const float pd = dpp_shr1_f<64>(ed);
+    const bool dup = (lane > 0) && (lane < K) && (ed == pd);
+    const bool ok = (worst < INFINITY) && (rm != worst) && (set_exact || __ballot(dup) == 0);
+    if (lane < K) { idx[(size_t)q * K + lane] = ei; dist2[(size_t)q * K + lane] = ed; }
+    if (!ok && lane == 0) worklist[atomicAdd(counters, 1)] = q;
+}
+
 template <int G>
 void launch_query(bool self, int b, int m, int K, const float* new_xyz, const int* offset, const int* new_offset, const Workspace& w,
                   int* idx, float* dist2, int set_exact, hipStream_t st)
@@ -473,7 +685,13 @@ int cbl_knn_grid_launch(int b, int n, int m, int nsample, const float* xyz, cons
     int rc = cbl_grid_build(b, n, 0.42f * (float)(nsample < 4 ? 4 : nsample), xyz, offset, ws, st);
     if (rc) return rc;
     const bool self = (new_xyz == xyz) && (m == n);
-    if (G == 16)      launch_query<16>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, set_exact, st);
+    static const int wave_min_k = getenv("CBL_KNN_WAVE_MIN_K") ? atoi(getenv("CBL_KNN_WAVE_MIN_K")) : 17;
+    if (nsample >= wave_min_k) {
+        const dim3 grid(cbl_div_up(m, 4)), block(256);
+        if (self) hipLaunchKernelGGL(knn_grid_wave_kernel<true>, grid, block, 0, st, b, m, nsample, new_xyz, offset, new_offset, w.grids, w.cell_start, w.sorted, idx, dist2, w.worklist, w.counters, set_exact);
+        else      hipLaunchKernelGGL(knn_grid_wave_kernel<false>, grid, block, 0, st, b, m, nsample, new_xyz, offset, new_offset, w.grids, w.cell_start, w.sorted, idx, dist2, w.worklist, w.counters, set_exact);
+    }
+    else if (G == 16) launch_query<16>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, set_exact, st);
     else if (G == 32) launch_query<32>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, set_exact, st);
     else              launch_query<64>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, set_exact, st);
     rc = cbl_status();
