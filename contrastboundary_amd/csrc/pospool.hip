@@ -1,0 +1,203 @@
+// a14: PosPool — parameter-free local aggregation over radius neighbourhoods.
+// Replaces the TF1 op chain of PosPool  /root/reference/tensorflow/models/local_aggregation_operators.py:15-250
+// (shipped config config/s3dis/pospool.yaml:20-23: position_embedding 'sin_cos', reduction 'mean'):
+//     out[p, c] = reduce_k  geo[p, k, c / shared] * features[nbr(p,k), c]
+// where geo is a position embedding of the neighbour's offset (support[nbr] - query[p]) / radius (:68-73) with `mid` entries,
+// each shared by C / mid consecutive channels (:228-231), and the reduction is sum / mean (with the padding-count quirk
+// :236-242) / max (shadow entries pushed to -65535, :243-249).  Index == n0 is the shadow neighbour: zero features, point (0,0,0).
+//
+// MI355X mapping: one wave per query point, lane = channel (64 at a time), so every neighbour's feature row is ONE coalesced
+// read; the neighbour ids of the point are one coalesced read up front; the embedding value of (neighbour, channel) is
+// computed in registers from per-lane constants decoded once (which monomial / direction component / sin or cos and its
+// wavelength), nothing of shape (n, K, .) exists in memory (the reference materialises four such tensors).  HBM-bound on
+// the gathered rows: algorithmic bytes 12n + 12n0 + 4nK + 4n0C + 4nC.
+#include "cbl_common.h"
+
+namespace {
+
+enum { PE_ONE = 0, PE_XYZ, PE_DISTANCE, PE_EXP_D, PE_DIR_EXP_D, PE_DIR_D, PE_SIN_COS, PE_TWO_ORDER, PE_THREE_ORDER, PE_COUNT };
+enum { RED_SUM = 0, RED_MEAN = 1, RED_MAX = 2 };
+enum { G_ONE = 0, G_MONO, G_DIST, G_EXPD, G_DIR, G_SIN, G_COS };
+
+struct LaneGeo {            // what this lane's channel multiplies its feature with
+    int kind;
+    int ex, ey, ez;         // G_MONO: exponents of the normalised offset (x^ex y^ey z^ez); G_DIR / G_SIN / G_COS: ex = axis
+    float dm;               // G_SIN / G_COS: wavelength divisor
+};
+
+// `mid` of (embedding, C) as in :75-226; 0 if the reference's reshape (:229) cannot work for this C
+__host__ __device__ inline int pospool_mid(int pe, int C)
+{
+    switch (pe) {
+    case PE_ONE: case PE_DISTANCE: case PE_EXP_D: return 1;
+    case PE_XYZ: return C % 3 == 0 ? 3 : 0;
+    case PE_DIR_EXP_D: case PE_DIR_D: return C <= 18 ? (C % 9 == 0 ? 9 : 0) : (C % 4 == 0 ? 4 : 0);
+    case PE_SIN_COS: return (C == 9 || C % 6 == 0) ? C : 0;
+    case PE_TWO_ORDER: return C % 9 == 0 ? 9 : 0;
+    case PE_THREE_ORDER: return C == 9 ? 9 : (C % 18 == 0 ? 18 : 0);
+    }
+    return 0;
+}
+
+__device__ inline LaneGeo decode_geo(int pe, int C, int c)
+{
+    // exponent triples of [x y z xy xz yz xx yy zz | xxx yyy zzz xxy xxz yyx yyz zzx zzy]  (:146-205)
+    const unsigned char mono[18][3] = {{1,0,0},{0,1,0},{0,0,1},{1,1,0},{1,0,1},{0,1,1},{2,0,0},{0,2,0},{0,0,2},
+                                       {3,0,0},{0,3,0},{0,0,3},{2,1,0},{2,0,1},{1,2,0},{0,2,1},{1,0,2},{0,1,2}};
+    LaneGeo g{G_ONE, 0, 0, 0, 1.f};
+    const int mid = pospool_mid(pe, C);
+    if (mid <= 0 || c >= C) return g;
+    const int j = c / (C / mid);                                    // feature_map reshape [mid, shared] (:229)
+    switch (pe) {
+    case PE_ONE: break;
+    case PE_XYZ: g.kind = G_MONO; g.ex = mono[j][0]; g.ey = mono[j][1]; g.ez = mono[j][2]; break;
+    case PE_DISTANCE: g.kind = G_DIST; break;
+    case PE_EXP_D: g.kind = G_EXPD; break;
+    case PE_DIR_EXP_D: case PE_DIR_D: {
+        // mid 9: [dir, d, dir, d, d]; mid 4: [dir, d]  (:98-117)
+        const int sel = (mid == 9) ? (j < 3 ? j : j == 3 ? 3 : j < 7 ? j - 4 : 3) : j;
+        if (sel < 3) { g.kind = G_DIR; g.ex = sel; } else g.kind = (pe == PE_DIR_EXP_D) ? G_EXPD : G_DIST;
+        break; }
+    case PE_SIN_COS:
+        if (C == 9) {                                               // [sin cos](x), (y), (z), then the offset itself (:120-134)
+            if (c < 6) { g.kind = (c & 1) ? G_COS : G_SIN; g.ex = c >> 1; g.dm = 1.f; }
+            else { g.kind = G_MONO; g.ex = mono[c - 6][0]; g.ey = mono[c - 6][1]; g.ez = mono[c - 6][2]; }
+        } else {                                                    // [3, 2*feat_dim] row-major (:135-147)
+            const int fd = C / 6, a = c / (2 * fd), r = c % (2 * fd), i = r < fd ? r : r - fd;
+            g.kind = r < fd ? G_SIN : G_COS; g.ex = a;
+            g.dm = powf(1000.f, (1.0f / (float)fd) * (float)i);     // tf.pow(1.0 * wave_length, (1.0 / feat_dim) * feat_range)
+        }
+        break;
+    case PE_TWO_ORDER: case PE_THREE_ORDER: g.kind = G_MONO; g.ex = mono[j][0]; g.ey = mono[j][1]; g.ez = mono[j][2]; break;
+    }
+    return g;
+}
+
+__device__ __forceinline__ float ipow(float v, int e) { return e == 0 ? 1.f : e == 1 ? v : e == 2 ? v * v : (v * v) * v; }
+
+__device__ __forceinline__ float eval_geo(const LaneGeo& g, float rx, float ry, float rz)
+{
+    switch (g.kind) {
+    case G_MONO: return (ipow(rx, g.ex) * ipow(ry, g.ey)) * ipow(rz, g.ez);
+    case G_DIST: return sqrtf((rx * rx + ry * ry) + rz * rz);                                   // :72
+    case G_EXPD: return expf(-1.0f * sqrtf((rx * rx + ry * ry) + rz * rz));                    // :90, :99
+    case G_DIR: { const float d = sqrtf((rx * rx + ry * ry) + rz * rz);                         // :73
+                  return (g.ex == 0 ? rx : g.ex == 1 ? ry : rz) / (d + 1e-6f); }
+    case G_SIN: return sinf((100.f * (g.ex == 0 ? rx : g.ex == 1 ? ry : rz)) / g.dm);           // alpha = 100 (:124,:138)
+    case G_COS: return cosf((100.f * (g.ex == 0 ? rx : g.ex == 1 ? ry : rz)) / g.dm);
+    }
+    return 1.f;
+}
+
+constexpr int PP_KMAX = 128;      // neighbour ids / offsets of one point are staged in LDS per wave
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void pospool_kernel(int n, int n0, int K, int C, const float* __restrict__ q, const float* __restrict__ s,
+                                                      const int* __restrict__ idx, const float* __restrict__ f, float radius, int pe, int reduction,
+                                                      const int* __restrict__ padding_num, float* __restrict__ out,
+                                                      const float* __restrict__ go, float* __restrict__ gf)
+{
+    __shared__ int s_id[4][PP_KMAX];
+    __shared__ float s_rel[4][PP_KMAX][3];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (gridDim.x * 256) >> 6;
+    const int pad = (reduction == RED_MEAN) ? *padding_num : 0;
+    for (int p = wave0; p < n; p += nwaves) {
+        const float qx = q[3 * p], qy = q[3 * p + 1], qz = q[3 * p + 2];
+        int cnt = 0;
+        for (int k = lane; k < K; k += 64) {
+            const int id = idx[(size_t)p * K + k];
+            const bool real = id >= 0 && id < n0;
+            s_id[wv][k] = real ? id : -1;
+            s_rel[wv][k][0] = ((real ? s[3 * id] : 0.f) - qx) / radius;          // shadow point = (0,0,0)  (:66-70)
+            s_rel[wv][k][1] = ((real ? s[3 * id + 1] : 0.f) - qy) / radius;
+            s_rel[wv][k][2] = ((real ? s[3 * id + 2] : 0.f) - qz) / radius;
+            cnt += (id < pad) ? 1 : 0;
+        }
+        float nn = 1.f;
+        if (reduction == RED_MEAN) {
+            for (int sft = 32; sft >= 1; sft >>= 1) cnt += __shfl_xor(cnt, sft);
+            nn = (float)cnt + 1e-5f;                                              // :238-241
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int c0 = 0; c0 < C; c0 += 64) {
+            const int c = c0 + lane;
+            const bool cok = c < C;
+            const LaneGeo g = decode_geo(pe, C, c);
+            if (reduction != RED_MAX) {
+                const float gp = (BWD && cok) ? go[(size_t)p * C + c] / nn : 0.f;
+                float acc = 0.f;
+                for (int k = 0; k < K; k++) {
+                    const int id = s_id[wv][k];                                   // wave-uniform
+                    if (id < 0) continue;                                         // zero feature row: contributes nothing
+                    const float ge = eval_geo(g, s_rel[wv][k][0], s_rel[wv][k][1], s_rel[wv][k][2]);
+                    if (!BWD) acc += cok ? ge * f[(size_t)id * C + c] : 0.f;      // :230-235
+                    else if (cok) unsafeAtomicAdd(gf + (size_t)id * C + c, gp * ge);
+                }
+                if (!BWD && cok) out[(size_t)p * C + c] = acc / nn;
+            } else {
+                // max over the K entries of geo*feature (+ -65535 on shadow entries, :243-249); gradient as tf.reduce_max's:
+                // shared equally by the entries that attain the maximum
+                float m = -INFINITY; int ties = 0;
+                for (int k = 0; k < K; k++) {
+                    const int id = s_id[wv][k];
+                    const float ge = eval_geo(g, s_rel[wv][k][0], s_rel[wv][k][1], s_rel[wv][k][2]);
+                    const float v = (id >= 0) ? (cok ? ge * f[(size_t)id * C + c] : 0.f) : ge * 0.f + -65535.f;
+                    if (v > m) { m = v; ties = 1; } else if (v == m) ties++;
+                }
+                if (!BWD) { if (cok) out[(size_t)p * C + c] = m; }
+                else if (cok) {
+                    const float gp = go[(size_t)p * C + c] / (float)ties;
+                    for (int k = 0; k < K; k++) {
+                        const int id = s_id[wv][k];
+                        if (id < 0) continue;
+                        const float ge = eval_geo(g, s_rel[wv][k][0], s_rel[wv][k][1], s_rel[wv][k][2]);
+                        if (ge * f[(size_t)id * C + c] == m) unsafeAtomicAdd(gf + (size_t)id * C + c, gp * ge);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                                          // the next point overwrites the wave's LDS rows
+    }
+}
+
+inline unsigned pp_grid(int n) { return (unsigned)min((long long)cbl_div_up(n, 4), 256LL * 16); }
+
+int pospool_check(int n, int n0, int K, int C, float radius, int pe, int reduction)
+{
+    if (n < 0 || n0 < 0 || K <= 0 || K > PP_KMAX || C <= 0 || !(radius > 0.f)) return CBL_ERR_BAD_ARG;
+    if (pe < 0 || pe >= PE_COUNT || reduction < 0 || reduction > RED_MAX) return CBL_ERR_BAD_ARG;
+    if (pospool_mid(pe, C) == 0) return CBL_ERR_UNSUPPORTED;                      // the reference's reshape (:229) fails for this C
+    return CBL_OK;
+}
+
+}  // namespace
+
+CBL_EXPORT int cbl_pospool_forward(int n, int n0, int K, int C, const float* query_points, const float* support_points, const int* neighbors_indices,
+                                   const float* features, float radius, int position_embedding, int reduction, const int* padding_num,
+                                   float* out, void* stream)
+{
+    const int rc = pospool_check(n, n0, K, C, radius, position_embedding, reduction);
+    if (rc) return rc;
+    if (n == 0) return CBL_OK;
+    if (!query_points || !support_points || !neighbors_indices || !features || !out || (reduction == RED_MEAN && !padding_num)) return CBL_ERR_BAD_ARG;
+    hipLaunchKernelGGL(pospool_kernel<false>, dim3(pp_grid(n)), dim3(256), 0, cbl_stream(stream), n, n0, K, C, query_points, support_points,
+                       neighbors_indices, features, radius, position_embedding, reduction, padding_num, out, nullptr, nullptr);
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_pospool_backward(int n, int n0, int K, int C, const float* query_points, const float* support_points, const int* neighbors_indices,
+                                    const float* features, float radius, int position_embedding, int reduction, const int* padding_num,
+                                    const float* grad_out, float* grad_features, void* stream)
+{
+    const int rc = pospool_check(n, n0, K, C, radius, position_embedding, reduction);
+    if (rc) return rc;
+    if (n == 0) return CBL_OK;
+    if (!query_points || !support_points || !neighbors_indices || !features || !grad_out || !grad_features || (reduction == RED_MEAN && !padding_num))
+        return CBL_ERR_BAD_ARG;
+    hipLaunchKernelGGL(pospool_kernel<true>, dim3(pp_grid(n)), dim3(256), 0, cbl_stream(stream), n, n0, K, C, query_points, support_points,
+                       neighbors_indices, features, radius, position_embedding, reduction, padding_num, nullptr, grad_out, grad_features);
+    return cbl_status();
+}

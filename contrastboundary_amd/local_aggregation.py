@@ -110,6 +110,55 @@ def adaptive_weight(query_points, support_points, neighbors_indices, features, r
                                  1 if reduction in ("mean", "avg") else 0)
 
 
+POSPOOL_EMBEDDINGS = {"one": 0, "xyz": 1, "distance": 2, "exp_-d": 3, "direction_exp_-d": 4, "direction_d": 5, "sin_cos": 6,
+                      "two_order": 7, "three_order": 8}
+_POSPOOL_REDUCTIONS = {"sum": 0, "mean": 1, "avg": 1, "max": 2}
+
+
+class _PosPool(Function):
+    @staticmethod
+    def forward(ctx, query_points, support_points, neighbors_indices, features, radius, pe, red):
+        n, K = neighbors_indices.shape
+        n0, C = features.shape
+        L = _lib.lib()
+        pad = torch.empty(1, dtype=torch.int32, device=features.device)
+        if red == 1:
+            _lib.check(L.cbl_index_max(ctypes.c_longlong(n * K), _lib.ptr(neighbors_indices), _lib.ptr(pad), _lib.stream_of(features)), "cbl_index_max")
+        out = torch.empty((n, C), dtype=torch.float32, device=features.device)
+        _lib.check(L.cbl_pospool_forward(_i(n), _i(n0), _i(K), _i(C), _lib.ptr(query_points), _lib.ptr(support_points), _lib.ptr(neighbors_indices),
+                                         _lib.ptr(features), _f(radius), _i(pe), _i(red), _lib.ptr(pad), _lib.ptr(out), _lib.stream_of(features)),
+                   "cbl_pospool_forward")
+        ctx.save_for_backward(query_points, support_points, neighbors_indices, features, pad)
+        ctx.cfg = (radius, pe, red)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        q, s, idx, f, pad = ctx.saved_tensors
+        radius, pe, red = ctx.cfg
+        n, K = idx.shape
+        n0, C = f.shape
+        grad_out = grad_out.contiguous()
+        gf = torch.zeros_like(f)
+        _lib.check(_lib.lib().cbl_pospool_backward(_i(n), _i(n0), _i(K), _i(C), _lib.ptr(q), _lib.ptr(s), _lib.ptr(idx), _lib.ptr(f), _f(radius),
+                                                   _i(pe), _i(red), _lib.ptr(pad), _lib.ptr(grad_out), _lib.ptr(gf), _lib.stream_of(f)),
+                   "cbl_pospool_backward")
+        return None, None, None, gf, None, None, None
+
+
+def pospool(query_points, support_points, neighbors_indices, features, radius, position_embedding="sin_cos", reduction="mean"):
+    """PosPool aggregation_feature (n, C) before pool_bn / activation / output_conv
+    (tensorflow/models/local_aggregation_operators.py:15-250; options as config.pospool.position_embedding / .reduction)."""
+    _chk(query_points, torch.float32, "query_points"); _chk(support_points, torch.float32, "support_points")
+    _chk(neighbors_indices, torch.int32, "neighbors_indices"); _chk(features, torch.float32, "features")
+    if position_embedding not in POSPOOL_EMBEDDINGS:
+        raise NotImplementedError("position_embedding [{}] not supported in PosPool ".format(position_embedding))
+    if reduction not in _POSPOOL_REDUCTIONS:
+        raise NotImplementedError("Reduction {} not supported in PosPool".format(reduction))
+    return _PosPool.apply(query_points, support_points, neighbors_indices, features, float(radius), POSPOOL_EMBEDDINGS[position_embedding],
+                          _POSPOOL_REDUCTIONS[reduction])
+
+
 def ind_max_pool(x, inds):
     """basic_operators.py:155-172"""
     _chk(x, torch.float32, "x"); _chk(inds, torch.int32, "inds")

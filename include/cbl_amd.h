@@ -197,6 +197,20 @@ int cbl_adaptive_weight_backward(int n, int n0, int K, int C, const float* query
                                  const float* features, float radius, const float* fc_weight, const float* fc_bias, const int* padding_num,
                                  int reduction_mean, const float* grad_out, float* grad_features, float* grad_fc_weight, float* grad_fc_bias, void* stream);
 
+/* a14  PosPool  tensorflow/models/local_aggregation_operators.py:15-250 (shipped: config/s3dis/pospool.yaml:20-23 'sin_cos' + 'mean')
+ *   out[p,c] = reduce_k geo[p,k,c/(C/mid)] * features[nbr(p,k),c]   (before pool_bn / activation / output_conv, :251-270)
+ *   position_embedding: 0 'one' | 1 'xyz' | 2 'distance' | 3 'exp_-d' | 4 'direction_exp_-d' | 5 'direction_d' | 6 'sin_cos' |
+ *                       7 'two_order' | 8 'three_order'   ('direction' alone cannot run in the reference: mid_fdim 1 vs a 3-vector, :93-96)
+ *   reduction: 0 'sum' | 1 'mean' (nn[p] as in AdaptiveWeight, *padding_num from cbl_index_max, :236-242) | 2 'max' (:243-249)
+ *   K <= 128.  CBL_ERR_UNSUPPORTED when C does not fit the embedding (the reference's reshape :229 fails there too). */
+int cbl_pospool_forward(int n, int n0, int K, int C, const float* query_points, const float* support_points, const int* neighbors_indices,
+                        const float* features, float radius, int position_embedding, int reduction, const int* padding_num,
+                        float* out, void* stream);
+/* gradient w.r.t. features (n0,C) += (caller pre-zeroes); 'max' shares the gradient among equal maxima like tf.reduce_max */
+int cbl_pospool_backward(int n, int n0, int K, int C, const float* query_points, const float* support_points, const int* neighbors_indices,
+                         const float* features, float radius, int position_embedding, int reduction, const int* padding_num,
+                         const float* grad_out, float* grad_features, void* stream);
+
 /* ind_max_pool / ind_closest_pool  tensorflow/models/basic_operators.py:155-172 / :175-192
  *   x (n1,d), inds (n2,k) i32 (pad = n1) -> out (n2,d): max over the row's entries (shadow row = column-wise min of x; scratch_d (d) u32)
  *   / the entry of the FIRST column (shadow row = 0) */

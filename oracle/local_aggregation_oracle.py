@@ -5,6 +5,7 @@ numpy restatement of the TF-side local aggregation operators of the reference (v
                      config/s3dis/adapt.yaml:19-26: local_input_feature='dp', fc_num=1, shared_channels=1,
                      weight_softmax=False, reduction='mean' incl. the padding-count quirk :466-470)
     PseudoGrid       ...:620-746  KPConv, depthwise: influence 'linear' / 'constant', mode 'sum' / 'closest'
+    PosPool          ...:15-250   all runnable position embeddings, reductions sum / mean / max (before pool_bn / activation)
     ind_max_pool / ind_closest_pool   /root/reference/tensorflow/models/basic_operators.py:155-192
     tf_gather (shadow row)            ...:381-410
 
@@ -124,3 +125,83 @@ def ind_max_pool(x, inds):
 def ind_closest_pool(x, inds):
     """basic_operators.py:175-192: first column only, shadow row = zeros"""
     return gather_shadow(np.asarray(x, np.float32), np.asarray(inds)[:, 0], 0.0)
+
+
+def pospool(query_points, support_points, neighbors_indices, features, radius, position_embedding="sin_cos", reduction="mean"):
+    """PosPool aggregation_feature (n, C) BEFORE pool_bn / activation / output_conv (local_aggregation_operators.py:55-249)."""
+    q = np.asarray(query_points, np.float32); s = np.asarray(support_points, np.float32)
+    f = np.asarray(features, np.float32); idx = np.asarray(neighbors_indices)
+    n, K = idx.shape
+    n0, fdim = f.shape
+    nf = gather_shadow(f, idx, 0.0)                                   # :60-62
+    rel = (gather_shadow(s, idx, 0.0) - q[:, None, :]) / np.float32(radius)       # :65-70
+    dist = np.sqrt((rel * rel).sum(2, keepdims=True, dtype=np.float32)).astype(np.float32)     # :71
+    direction = (rel / (dist + np.float32(1e-6))).astype(np.float32)  # :72
+    x, y, z = rel[:, :, :1], rel[:, :, 1:2], rel[:, :, 2:3]
+    pe = position_embedding
+    if pe == "one":
+        geo, mid = np.ones_like(dist), 1
+    elif pe == "xyz":
+        geo, mid = rel, 3
+    elif pe == "distance":
+        geo, mid = dist, 1
+    elif pe == "exp_-d":
+        geo, mid = np.exp(-dist).astype(np.float32), 1
+    elif pe in ("direction_exp_-d", "direction_d"):
+        d = np.exp(-dist).astype(np.float32) if pe == "direction_exp_-d" else dist
+        if fdim <= 18:
+            geo, mid = np.concatenate([direction, d, direction, d, d], -1), 9
+        else:
+            geo, mid = np.concatenate([direction, d], -1), 4
+    elif pe == "sin_cos":
+        fd = 1 if fdim == 9 else fdim // 6
+        dim_mat = np.power(np.float32(1000.0), np.float32(1.0 / fd) * np.arange(fd, dtype=np.float32)).astype(np.float32)
+        div = (np.float32(100.0) * rel)[..., None] / dim_mat          # (n,K,3,fd)
+        emb = np.concatenate([np.sin(div), np.cos(div)], -1).astype(np.float32).reshape(n, K, 6 * fd)
+        geo = np.concatenate([emb, rel], -1) if fdim == 9 else emb
+        mid = fdim
+    elif pe in ("two_order", "three_order"):
+        second = [rel, x * y, x * z, y * z, x * x, y * y, z * z]
+        if pe == "two_order" or fdim == 9:
+            geo, mid = np.concatenate(second, -1), 9
+        else:
+            xx, yy, zz = x * x, y * y, z * z
+            third = [np.power(x, 3), np.power(y, 3), np.power(z, 3), xx * y, xx * z, yy * x, yy * z, zz * x, zz * y]
+            geo, mid = np.concatenate(second + third, -1), 18
+    else:
+        raise NotImplementedError(pe)
+    shared = fdim // mid
+    if mid * shared != fdim or geo.shape[-1] != mid:
+        raise ValueError("feature dim %d does not fit position embedding %s" % (fdim, pe))
+    agg = (geo.astype(np.float32)[..., None] * nf.reshape(n, K, mid, shared)).reshape(n, K, fdim)    # :227-231
+    if reduction == "sum":
+        out = agg.sum(1, dtype=np.float32)
+    elif reduction in ("mean", "avg"):
+        nn = (idx < idx.max()).sum(-1, keepdims=True).astype(np.float32) + np.float32(1e-5)         # :236-241
+        out = agg.sum(1, dtype=np.float32) / nn
+    elif reduction == "max":
+        out = (agg + np.where(idx == n0, np.float32(-65535.0), np.float32(0.0))[..., None]).max(1)   # :243-249
+    else:
+        raise NotImplementedError(reduction)
+    return out.astype(np.float32), geo.astype(np.float32), agg
+
+
+def pospool_grad_features(query_points, support_points, neighbors_indices, features, radius, grad_out, position_embedding="sin_cos", reduction="mean"):
+    """d sum(pospool * grad_out) / d features, float64 accumulation; 'max' as tf.reduce_max (equal maxima share the gradient)"""
+    f = np.asarray(features, np.float32); idx = np.asarray(neighbors_indices); go = np.asarray(grad_out, np.float64)
+    n, K = idx.shape
+    n0, fdim = f.shape
+    out, geo, agg = pospool(query_points, support_points, neighbors_indices, features, radius, position_embedding, reduction)
+    mid = geo.shape[-1]
+    gfull = np.repeat(geo.astype(np.float64), fdim // mid, axis=-1)    # (n,K,fdim): the factor of features[nbr, c]
+    if reduction in ("mean", "avg"):
+        go = go / ((idx < idx.max()).sum(-1, keepdims=True).astype(np.float64) + 1e-5)
+    if reduction == "max":
+        vals = agg + np.where(idx == n0, np.float32(-65535.0), np.float32(0.0))[..., None]
+        sel = (vals == out[:, None, :]).astype(np.float64)
+        coef = sel / sel.sum(1, keepdims=True) * go[:, None, :] * gfull
+    else:
+        coef = gfull * go[:, None, :]
+    g = np.zeros((n0 + 1, fdim), np.float64)
+    np.add.at(g, idx.reshape(-1), coef.reshape(-1, fdim))
+    return g[:n0].astype(np.float32)
