@@ -273,6 +273,34 @@ static int ref_block_threads(int n_max)
     return t;
 }
 
+// fps_bucket.hip
+size_t cbl_fps_bucket_workspace_bytes(int b, int n);
+int cbl_fps_bucket_launch(int b, int n, int n_max, int bits, const float* xyz, const int* offset, const int* new_offset, float* tmp, int* idx,
+                          void* ws, size_t ws_bytes, hipStream_t st);
+
+// clouds from this size on take the bucket-pruned kernel (same samples; below it the dense kernel's ~1.5 us per sample wins)
+constexpr int FPS_BUCKET_MIN_POINTS = 12288, FPS_BUCKET_MAX_POINTS = 131072;
+
+CBL_EXPORT size_t cbl_furthestsampling_workspace_bytes(int b, int n, int n_max)
+{
+    if (b <= 0 || n <= 0 || b > 65535 || n_max < FPS_BUCKET_MIN_POINTS || n_max > FPS_BUCKET_MAX_POINTS) return 0;
+    return cbl_fps_bucket_workspace_bytes(b, n);
+}
+
+CBL_EXPORT int cbl_furthestsampling_ws(int b, int n, int n_max, const float* xyz, const int* offset, const int* new_offset,
+                                       float* tmp, int* idx, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (b < 0 || n < 0 || n_max < 0) return CBL_ERR_BAD_ARG;
+    if (b == 0 || n == 0) return CBL_OK;
+    if (!xyz || !offset || !new_offset || !tmp || !idx) return CBL_ERR_BAD_ARG;
+    const size_t need = cbl_furthestsampling_workspace_bytes(b, n, n_max);
+    if (need == 0 || !workspace) return cbl_furthestsampling(b, n_max, xyz, offset, new_offset, tmp, idx, stream);
+    if (workspace_bytes < need) return CBL_ERR_WORKSPACE;
+    const int B = ref_block_threads(n_max);
+    int bits = 0; while ((1 << bits) < B) bits++;
+    return cbl_fps_bucket_launch(b, n, n_max, bits, xyz, offset, new_offset, tmp, idx, workspace, workspace_bytes, cbl_stream(stream));
+}
+
 CBL_EXPORT int cbl_furthestsampling(int b, int n_max, const float* xyz, const int* offset, const int* new_offset,
                                     float* tmp, int* idx, void* stream)
 {

@@ -7,6 +7,7 @@ import ctypes, torch
 import os
 _L = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lib", "libcbl_amd.so"))
 _L.cbl_knnquery_workspace_bytes.restype = ctypes.c_size_t
+_L.cbl_furthestsampling_workspace_bytes.restype = ctypes.c_size_t
 _p = lambda t: ctypes.c_void_p(t.data_ptr())
 _s = lambda t: ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 def _ok(rc, what):
@@ -23,7 +24,13 @@ def knnquery_cuda(m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2):    
                         _p(ws) if need else None, ctypes.c_size_t(ws.numel() if need else 0), _s(xyz)), "cbl_knnquery")
 
 def furthestsampling_cuda(b, n_max, xyz, offset, new_offset, tmp, idx):                # :14  (n_max may be a 0-dim tensor)
-    _ok(_L.cbl_furthestsampling(b, int(n_max), _p(xyz), _p(offset), _p(new_offset), _p(tmp), _p(idx), _s(xyz)), "cbl_furthestsampling")
+    n = xyz.shape[0]
+    need = _L.cbl_furthestsampling_workspace_bytes(b, n, int(n_max))                   # > 0: large clouds take the bucket-pruned kernel
+    ws = _ws.get(xyz.device)
+    if need and (ws is None or ws.numel() < need):
+        ws = _ws[xyz.device] = torch.empty(need, dtype=torch.uint8, device=xyz.device)
+    _ok(_L.cbl_furthestsampling_ws(b, n, int(n_max), _p(xyz), _p(offset), _p(new_offset), _p(tmp), _p(idx),
+                                   _p(ws) if need else None, ctypes.c_size_t(ws.numel() if need else 0), _s(xyz)), "cbl_furthestsampling_ws")
 
 def grouping_forward_cuda(m, nsample, c, input, idx, output):                          # :15
     _ok(_L.cbl_grouping_forward(m, nsample, c, _p(input), _p(idx), _p(output), _s(input)), "cbl_grouping_forward")

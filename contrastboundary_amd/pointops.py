@@ -37,28 +37,6 @@ def _as_int(v):
     return int(v.item()) if isinstance(v, torch.Tensor) else int(v)
 
 
-# ------------------------------------------------------------------------------------------------ K2
-class FurthestSampling(Function):
-    @staticmethod
-    def forward(ctx, xyz, offset, new_offset):
-        """xyz (n,3) f32, offset (b) i32, new_offset (b) i32 -> idx (m) i32          pointops.py:12-25"""
-        _req(xyz, torch.float32, "xyz", 2); _req(offset, torch.int32, "offset", 1); _req(new_offset, torch.int32, "new_offset", 1)
-        n, b = xyz.shape[0], offset.shape[0]
-        off_h = offset.cpu()                       # the reference also syncs here (n_max, new_offset[b-1].item())
-        lens = torch.diff(off_h, prepend=off_h.new_zeros(1))
-        n_max = int(lens.max().item()) if b > 0 else 0
-        m = int(new_offset[b - 1].item()) if b > 0 else 0
-        idx = torch.zeros(m, dtype=torch.int32, device=xyz.device)
-        tmp = torch.full((n,), 1e10, dtype=torch.float32, device=xyz.device)
-        rc = _lib.lib().cbl_furthestsampling(_c_int(b), _c_int(n_max), _lib.ptr(xyz), _lib.ptr(offset), _lib.ptr(new_offset),
-                                             _lib.ptr(tmp), _lib.ptr(idx), _lib.stream_of(xyz))
-        _lib.check(rc, "cbl_furthestsampling")
-        return idx
-
-
-furthestsampling = FurthestSampling.apply
-
-# ------------------------------------------------------------------------------------------------ K1
 _ws_cache = {}
 
 
@@ -74,6 +52,32 @@ def _workspace(nbytes, device):
     return ws
 
 
+# ------------------------------------------------------------------------------------------------ K2
+class FurthestSampling(Function):
+    @staticmethod
+    def forward(ctx, xyz, offset, new_offset):
+        """xyz (n,3) f32, offset (b) i32, new_offset (b) i32 -> idx (m) i32          pointops.py:12-25"""
+        _req(xyz, torch.float32, "xyz", 2); _req(offset, torch.int32, "offset", 1); _req(new_offset, torch.int32, "new_offset", 1)
+        n, b = xyz.shape[0], offset.shape[0]
+        off_h = offset.cpu()                       # the reference also syncs here (n_max, new_offset[b-1].item())
+        lens = torch.diff(off_h, prepend=off_h.new_zeros(1))
+        n_max = int(lens.max().item()) if b > 0 else 0
+        m = int(new_offset[b - 1].item()) if b > 0 else 0
+        idx = torch.zeros(m, dtype=torch.int32, device=xyz.device)
+        tmp = torch.full((n,), 1e10, dtype=torch.float32, device=xyz.device)
+        L = _lib.lib()
+        need = L.cbl_furthestsampling_workspace_bytes(_c_int(b), _c_int(n), _c_int(n_max))     # > 0: large clouds, bucket-pruned kernel
+        ws = _workspace(need, xyz.device)
+        rc = L.cbl_furthestsampling_ws(_c_int(b), _c_int(n), _c_int(n_max), _lib.ptr(xyz), _lib.ptr(offset), _lib.ptr(new_offset),
+                                       _lib.ptr(tmp), _lib.ptr(idx), _lib.ptr(ws), ctypes.c_size_t(ws.numel() if ws is not None else 0),
+                                       _lib.stream_of(xyz))
+        _lib.check(rc, "cbl_furthestsampling_ws")
+        return idx
+
+
+furthestsampling = FurthestSampling.apply
+
+# ------------------------------------------------------------------------------------------------ K1
 def knnquery_raw(nsample, xyz, new_xyz, offset, new_offset, algo="auto"):
     """-> idx (m,nsample) i32, dist2 (m,nsample) f32 (squared).  algo: 'auto' | 'exact' | 'grid' | 'set'
     ('set': same neighbour set and distances, order among exactly equal distances unspecified — cbl_knnquery_set)"""

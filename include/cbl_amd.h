@@ -82,6 +82,11 @@ int cbl_knnquery_exact(int b, int n, int m, int nsample,
  *   xyz (n,3) offset (b) new_offset (b) tmp (n) -> idx (new_offset[b-1]) i32 */
 int cbl_furthestsampling(int b, int n_max, const float* xyz, const int* offset, const int* new_offset,
                          float* tmp, int* idx, void* stream);
+/* Same op, same samples, with scratch for the spatial-bucket kernel (fps_bucket.hip) that large clouds take: `n` = total rows
+ * (= offset[b-1]); cbl_furthestsampling_workspace_bytes() == 0 means the plain entry is used and workspace may be NULL. */
+size_t cbl_furthestsampling_workspace_bytes(int b, int n, int n_max);
+int cbl_furthestsampling_ws(int b, int n, int n_max, const float* xyz, const int* offset, const int* new_offset,
+                            float* tmp, int* idx, void* workspace, size_t workspace_bytes, void* stream);
 
 /* K3/K4  grouping_{forward,backward}_cuda_launcher  grouping/grouping_cuda_kernel.h:13-14.
  *   forward : input (n,c), idx (m,nsample) -> output (m,nsample,c)        (output fully overwritten)

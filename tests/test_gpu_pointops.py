@@ -93,7 +93,7 @@ def test_fps_golden(P, name):
 
 @pytest.mark.parametrize("n,b,seed", [(900, 1, 0), (3000, 2, 1), (9000, 1, 2), (14000, 1, 3), (30000, 2, 4), (45000, 1, 5)])
 def test_fps_vs_oracle(P, n, b, seed):
-    # covers every register-resident variant (1,4,10,16,40 rows) and the streaming kernel (n_max > 40960)
+    # through the mirror: the dense kernels below 12288 points per cloud, the bucket-pruned kernel above
     rng = np.random.default_rng(seed)
     xyz = rng.uniform(0, 3, (n, 3)).astype(np.float32)
     cuts = np.sort(rng.choice(np.arange(100, n - 100), b - 1, replace=False)) if b > 1 else np.array([], int)
@@ -114,6 +114,77 @@ def test_fps_lattice_ties_all_block_sizes(P):
         idx = P.furthestsampling(dev(xyz), dev(np.int32([n])), dev(np.int32([n // 3])))
         ridx, _ = O.furthestsampling(xyz, [n], [n // 3])
         np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+
+
+def _fps_raw(xyz, offset, new_offset, bucket):
+    """direct C-ABI call: the dense kernels (cbl_furthestsampling) or the bucket-pruned one (cbl_furthestsampling_ws); -> idx, tmp"""
+    import ctypes
+    from contrastboundary_amd import _lib
+    L = _lib.lib()
+    x, o, no = dev(xyz), dev(np.int32(offset)), dev(np.int32(new_offset))
+    n, b = x.shape[0], o.shape[0]
+    n_max = int(np.max(np.diff(np.concatenate([[0], np.int32(offset)]))))
+    idx = torch.zeros(int(new_offset[-1]), dtype=torch.int32, device="cuda")
+    tmp = torch.full((n,), 1e10, dtype=torch.float32, device="cuda")
+    st = _lib.stream_of(x)
+    if bucket:
+        need = L.cbl_furthestsampling_workspace_bytes(b, n, n_max)
+        assert need > 0, "bucket kernel not selected for this size"
+        ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+        _lib.check(L.cbl_furthestsampling_ws(b, n, n_max, _lib.ptr(x), _lib.ptr(o), _lib.ptr(no), _lib.ptr(tmp), _lib.ptr(idx), _lib.ptr(ws),
+                                             ctypes.c_size_t(need), st), "cbl_furthestsampling_ws")
+    else:
+        _lib.check(L.cbl_furthestsampling(b, n_max, _lib.ptr(x), _lib.ptr(o), _lib.ptr(no), _lib.ptr(tmp), _lib.ptr(idx), st), "cbl_furthestsampling")
+    torch.cuda.synchronize()
+    return idx.cpu().numpy(), tmp.cpu().numpy()
+
+
+@pytest.mark.parametrize("n,b,seed", [(14000, 1, 3), (30000, 2, 4), (45000, 1, 5)])
+def test_fps_dense_kernels_vs_oracle(n, b, seed):
+    # the register / LDS / streaming dense variants stay reachable through the plain entry point
+    rng = np.random.default_rng(seed)
+    xyz = rng.uniform(0, 3, (n, 3)).astype(np.float32)
+    cuts = np.sort(rng.choice(np.arange(100, n - 100), b - 1, replace=False)) if b > 1 else np.array([], int)
+    offset = np.concatenate([cuts, [n]]).astype(np.int32)
+    noff = np.cumsum(np.minimum(np.diff(np.concatenate([[0], offset])) // 4, 400)).astype(np.int32)
+    idx, tmp = _fps_raw(xyz, offset, noff, bucket=False)
+    ridx, rtmp = O.furthestsampling(xyz, offset, noff)
+    np.testing.assert_array_equal(idx, ridx)
+    np.testing.assert_array_equal(tmp, rtmp)
+
+
+def test_fps_bucket_full_size_room():
+    # C2 / C4 shape: 40960 -> 10240 on the S-room scene; bucket-pruned kernel == dense kernel == oracle, running distances included
+    from contrastboundary_amd import synthetic as S
+    xyz, _ = S.s_room(40960, seed=0)
+    idx_b, tmp_b = _fps_raw(xyz, [40960], [10240], bucket=True)
+    idx_d, tmp_d = _fps_raw(xyz, [40960], [10240], bucket=False)
+    np.testing.assert_array_equal(idx_b, idx_d)
+    np.testing.assert_array_equal(tmp_b, tmp_d)
+    ridx, rtmp = O.furthestsampling(xyz, [40960], [10240])
+    np.testing.assert_array_equal(idx_b, ridx)
+    np.testing.assert_array_equal(tmp_b, rtmp)
+    assert len(np.unique(idx_b)) == 10240
+
+
+def test_fps_bucket_ties_and_ragged_batches():
+    # a 24^3 lattice (every distance tied, reference block size 1024 -> the bit-reversed thread rule decides) ...
+    g = np.arange(24, dtype=np.float32)
+    lat = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    idx, tmp = _fps_raw(lat, [len(lat)], [len(lat) // 3], bucket=True)
+    ridx, rtmp = O.furthestsampling(lat, [len(lat)], [len(lat) // 3])
+    np.testing.assert_array_equal(idx, ridx)
+    np.testing.assert_array_equal(tmp, rtmp)
+    # ... and a ragged batch: large, tiny (fewer points than a bucket), lattice, large; one cloud samples nothing new beyond its first point
+    rng = np.random.default_rng(11)
+    parts = [rng.uniform(0, 4, (15000, 3)), rng.uniform(0, 1, (37, 3)), lat[:9000], rng.normal(0, 1, (26000, 3))]
+    xyz = np.concatenate(parts).astype(np.float32)
+    offset = np.cumsum([len(p) for p in parts]).astype(np.int32)
+    noff = np.cumsum([1500, 1, 3000, 2000]).astype(np.int32)
+    idx, tmp = _fps_raw(xyz, offset, noff, bucket=True)
+    ridx, rtmp = O.furthestsampling(xyz, offset, noff)
+    np.testing.assert_array_equal(idx, ridx)
+    np.testing.assert_array_equal(tmp, rtmp)
 
 
 def test_k3_k10_golden(P):
