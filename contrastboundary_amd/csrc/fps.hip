@@ -278,8 +278,9 @@ size_t cbl_fps_bucket_workspace_bytes(int b, int n);
 int cbl_fps_bucket_launch(int b, int n, int n_max, int bits, const float* xyz, const int* offset, const int* new_offset, float* tmp, int* idx,
                           void* ws, size_t ws_bytes, hipStream_t st);
 
-// clouds from this size on take the bucket-pruned kernel (same samples; below it the dense kernel's ~1.5 us per sample wins)
-constexpr int FPS_BUCKET_MIN_POINTS = 12288, FPS_BUCKET_MAX_POINTS = 131072;
+// clouds from this size on take the bucket-pruned kernel (same samples): ~1.07 us per sample at any size, against 1.1 (<= 2560
+// points) .. 1.5 (10240) .. 6.9 us (40960) for the dense kernels; measured crossover between 2560 and 5000 points
+constexpr int FPS_BUCKET_MIN_POINTS = 3072, FPS_BUCKET_MAX_POINTS = 131072;
 
 CBL_EXPORT size_t cbl_furthestsampling_workspace_bytes(int b, int n, int n_max)
 {

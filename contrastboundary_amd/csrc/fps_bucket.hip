@@ -220,6 +220,29 @@ __global__ __launch_bounds__(1024) void fps_bucket_kernel(int bits, const float*
         return o;
     };
 
+    // two buckets at once (update only): same operations as `process`, written side by side so the two chains interleave
+    auto process2 = [&](int g1, int g2, float sx, float sy, float sz, Best& o1, Best& o2) {
+        const int i1 = n0 + FB_BUCKET * g1 + lane, i2 = n0 + FB_BUCKET * g2 + lane;
+        const bool v1 = i1 < n1, v2 = i2 < n1;
+        const int c1 = v1 ? i1 : n1 - 1, c2 = v2 ? i2 : n1 - 1;
+        const float4 p1 = sorted[c1], p2 = sorted[c2];
+        const unsigned rk1 = rank[c1], rk2 = rank[c2];
+        const float t1 = fminf(cbl_dist2(p1.x, p1.y, p1.z, sx, sy, sz), p1.w), t2 = fminf(cbl_dist2(p2.x, p2.y, p2.z, sx, sy, sz), p2.w);
+        const float d1 = v1 ? t1 : -2.f, d2 = v2 ? t2 : -2.f;
+        o1.d = wave_max_f(d1); o2.d = wave_max_f(d2);
+        unsigned long long k1 = __ballot(d1 == o1.d), k2 = __ballot(d2 == o2.d);
+        if (__popcll(k1) != 1) { const unsigned wr = wave_min_u(d1 == o1.d ? rk1 : 0xffffffffu); k1 = __ballot(d1 == o1.d && rk1 == wr); }
+        if (__popcll(k2) != 1) { const unsigned wr = wave_min_u(d2 == o2.d ? rk2 : 0xffffffffu); k2 = __ballot(d2 == o2.d && rk2 == wr); }
+        const int b1 = __builtin_ctzll(k1), b2 = __builtin_ctzll(k2);
+        o1.rank = (unsigned)__builtin_amdgcn_readlane((int)rk1, b1); o2.rank = (unsigned)__builtin_amdgcn_readlane((int)rk2, b2);
+        o1.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p1.x), b1)); o2.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p2.x), b2));
+        o1.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p1.y), b1)); o2.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p2.y), b2));
+        o1.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p1.z), b1)); o2.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p2.z), b2));
+        __builtin_amdgcn_sched_barrier(0);
+        if (v1 && t1 != p1.w) sorted[c1].w = t1;
+        if (v2 && t2 != p2.w) sorted[c2].w = t2;
+    };
+
 #pragma unroll
     for (int r = 0; r < R; r++) {
         for (int l = 0; l < 64; l++) {
@@ -248,10 +271,20 @@ __global__ __launch_bounds__(1024) void fps_bucket_kernel(int bits, const float*
             const float L = (gx * gx + gy * gy) + gz * gz;
             unsigned long long mk = __ballot(L < bm[r]);                        // unowned register sets hold bm = -3: never touched
             while (mk) {
-                const int l = __builtin_ctzll(mk);
+                // up to two touched buckets per trip: their loads and reduction chains overlap
+                const int l1 = __builtin_ctzll(mk);
                 mk &= mk - 1;
-                const Best o = process((l + 64 * r) * W + wave, sx, sy, sz, false, nullptr, nullptr);
-                if (lane == l) { bm[r] = o.d; brk[r] = o.rank; bxr[r] = o.x; byr[r] = o.y; bzr[r] = o.z; }
+                if (mk) {
+                    const int l2 = __builtin_ctzll(mk);
+                    mk &= mk - 1;
+                    Best o1, o2;
+                    process2((l1 + 64 * r) * W + wave, (l2 + 64 * r) * W + wave, sx, sy, sz, o1, o2);
+                    if (lane == l1) { bm[r] = o1.d; brk[r] = o1.rank; bxr[r] = o1.x; byr[r] = o1.y; bzr[r] = o1.z; }
+                    if (lane == l2) { bm[r] = o2.d; brk[r] = o2.rank; bxr[r] = o2.x; byr[r] = o2.y; bzr[r] = o2.z; }
+                } else {
+                    const Best o = process((l1 + 64 * r) * W + wave, sx, sy, sz, false, nullptr, nullptr);
+                    if (lane == l1) { bm[r] = o.d; brk[r] = o.rank; bxr[r] = o.x; byr[r] = o.y; bzr[r] = o.z; }
+                }
                 dirty = true;
             }
         }

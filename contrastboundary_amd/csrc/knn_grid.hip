@@ -680,20 +680,16 @@ int cbl_knn_grid_launch(int b, int n, int m, int nsample, const float* xyz, cons
 {
     Workspace w = carve(ws, b, n, m);
     if (ws_bytes < w.bytes) return CBL_ERR_WORKSPACE;
-    const int G = nsample <= 16 ? 16 : nsample <= 32 ? 32 : 64;
     // ~0.42*K points per cell if the cloud filled its bbox: the K-th neighbour is then usually inside the 27-cell block
     int rc = cbl_grid_build(b, n, 0.42f * (float)(nsample < 4 ? 4 : nsample), xyz, offset, ws, st);
     if (rc) return rc;
     const bool self = (new_xyz == xyz) && (m == n);
-    static const int wave_min_k = getenv("CBL_KNN_WAVE_MIN_K") ? atoi(getenv("CBL_KNN_WAVE_MIN_K")) : 17;
-    if (nsample >= wave_min_k) {
+    if (nsample > 16) {                                              // select-then-sort, one wave per query
         const dim3 grid(cbl_div_up(m, 4)), block(256);
         if (self) hipLaunchKernelGGL(knn_grid_wave_kernel<true>, grid, block, 0, st, b, m, nsample, new_xyz, offset, new_offset, w.grids, w.cell_start, w.sorted, idx, dist2, w.worklist, w.counters, set_exact);
         else      hipLaunchKernelGGL(knn_grid_wave_kernel<false>, grid, block, 0, st, b, m, nsample, new_xyz, offset, new_offset, w.grids, w.cell_start, w.sorted, idx, dist2, w.worklist, w.counters, set_exact);
     }
-    else if (G == 16) launch_query<16>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, set_exact, st);
-    else if (G == 32) launch_query<32>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, set_exact, st);
-    else              launch_query<64>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, set_exact, st);
+    else launch_query<16>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, set_exact, st);   // 4 queries per wave
     rc = cbl_status();
     if (rc) return rc;
     // exact replay of everything that was not certified (device-side count, no host sync)
