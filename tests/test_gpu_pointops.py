@@ -50,7 +50,8 @@ def test_knn_golden(P, name, algo):
 @pytest.mark.parametrize("algo", ["exact", "auto"])
 @pytest.mark.parametrize("n,m,b,k,seed", [(5000, 5000, 1, 16, 0), (6000, 1500, 3, 16, 1), (3000, 3000, 4, 36, 2),
                                           (2000, 700, 2, 3, 3), (2000, 2000, 1, 1, 4), (4096, 64, 2, 256, 5),
-                                          (1500, 200, 1, 400, 6)])
+                                          (1500, 200, 1, 400, 6), (8000, 2000, 2, 24, 7), (9000, 9000, 1, 64, 8), (5000, 5000, 1, 33, 9),
+                                          (6000, 900, 3, 48, 10)])
 def test_knn_vs_oracle_random(P, n, m, b, k, seed, algo):
     rng = np.random.default_rng(seed)
     xyz = rng.uniform(0, 2, (n, 3)).astype(np.float32)
@@ -321,3 +322,26 @@ def test_knn_set_variant(P):
         ridx, rd2 = O.knnquery(k, xyz, xyz, [n], [n])
         np.testing.assert_array_equal(d2.cpu().numpy().view(np.uint32), rd2.view(np.uint32))
         np.testing.assert_array_equal(np.sort(idx.cpu().numpy(), 1), np.sort(ridx, 1))
+
+
+def test_empty_and_degenerate_inputs(P):
+    """no queries, an empty cloud inside a batch, one-point clouds: nothing to compute is not an error (and not a crash)"""
+    rng = np.random.default_rng(0)
+    xyz = dev(rng.uniform(0, 1, (300, 3)).astype(np.float32))
+    o = dev(np.int32([100, 100, 300]))                                 # cloud 1 is empty
+    q = dev(rng.uniform(0, 1, (50, 3)).astype(np.float32))
+    qo = dev(np.int32([20, 20, 50]))
+    idx, d2 = P.knnquery_raw(4, xyz, q, o, qo)
+    ridx, rd2 = O.knnquery(4, xyz.cpu().numpy(), q.cpu().numpy(), [100, 100, 300], [20, 20, 50])
+    np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+    idx0, d0 = P.knnquery_raw(4, xyz, q[:0].contiguous(), o, dev(np.int32([0, 0, 0])))
+    assert idx0.shape == (0, 4) and d0.shape == (0, 4)
+    feat = dev(rng.normal(size=(300, 8)).astype(np.float32))
+    assert P.grouping(feat, idx0).shape == (0, 4, 8)
+    fidx = P.furthestsampling(xyz, o, dev(np.int32([10, 10, 40])))     # the empty cloud contributes no sample
+    ridx, _ = O.furthestsampling(xyz.cpu().numpy(), [100, 100, 300], [10, 10, 40])
+    np.testing.assert_array_equal(fidx.cpu().numpy(), ridx)
+    one = dev(np.float32([[1, 2, 3]]))
+    i1, d1 = P.knnquery_raw(3, one, one, dev(np.int32([1])), dev(np.int32([1])))
+    r1, _ = O.knnquery(3, one.cpu().numpy(), one.cpu().numpy(), [1], [1])
+    np.testing.assert_array_equal(i1.cpu().numpy(), r1)
