@@ -78,19 +78,25 @@ __device__ __forceinline__ unsigned long long heap_ancestors(int lane)
 __device__ __forceinline__ void heap_replace_root_par(float& hd, int& hi, int lane, unsigned long long anc, int len, float d, int id)
 {
     const int l = 2 * lane + 1, r = l + 1;
-    const float kl = __shfl(hd, l & 63), kr = __shfl(hd, r & 63);
-    const int il = __shfl(hi, l & 63), ir = __shfl(hi, r & 63);
-    const bool right = (r < len) && (kr > kl);               // right child only when strictly larger (:27)
-    const float bk = right ? kr : kl;
-    const int bi = right ? ir : il;
+    const int al = (l & 63) << 2, ar = (r & 63) << 2;        // ds_bpermute byte addresses (lane-constant: hoisted out of the feed loop)
+    const float kl = __int_as_float(__builtin_amdgcn_ds_bpermute(al, __float_as_int(hd)));
+    const float kr = __int_as_float(__builtin_amdgcn_ds_bpermute(ar, __float_as_int(hd)));
+    const int il = __builtin_amdgcn_ds_bpermute(al, hi), ir = __builtin_amdgcn_ds_bpermute(ar, hi);
     const float up = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(hd), __float_as_int(hd), 0x130, 0xf, 0xf, false));   // slot lane+1
     const float dn = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(hd), __float_as_int(hd), 0x138, 0xf, 0xf, false));   // slot lane-1
-    const bool isbig = (lane < len) && ((lane & 1) ? !((lane + 1 < len) && (up > hd)) : (hd > dn));
+    // branch-free: plain '&' / '|' on lane masks (two compares, the rest is scalar mask arithmetic)
+    const bool odd = lane & 1, in_heap = lane < len, has_next = lane + 1 < len;
+    const bool next_bigger = up > hd, bigger_than_prev = hd > dn;
+    const bool isbig = in_heap & ((odd & !(has_next & next_bigger)) | (!odd & bigger_than_prev));
     const unsigned long long big = __ballot(isbig);
     const bool onpath = (big & anc) == anc;                  // root: empty chain
-    const bool reached = onpath && (lane == 0 || !(d > hd)); // stop only when strictly larger (:29)
-    const bool sinks = (l < len) && !(d > bk);
-    if (reached) { hd = sinks ? bk : d; hi = sinks ? bi : id; }
+    const bool right = (r < len) & (kr > kl);                // right child only when strictly larger (:27)
+    const float bk = right ? kr : kl;
+    const int bi = right ? ir : il;
+    const bool reached = onpath & ((lane == 0) | !(d > hd)); // stop only when strictly larger (:29)
+    const bool sinks = (l < len) & !(d > bk);
+    const float nd = sinks ? bk : d; const int ni = sinks ? bi : id;
+    hd = reached ? nd : hd; hi = reached ? ni : hi;
 }
 
 template <bool IN_LANES>
