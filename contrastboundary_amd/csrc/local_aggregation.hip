@@ -256,6 +256,55 @@ __global__ __launch_bounds__(256) void adaptive_weight_kernel(int n, int n0, int
     }
 }
 
+// Forward, C % 4 == 0: one lane = 4 consecutive channels of one point (16-byte row segments), a point's C/4 lanes sit next to
+// each other so a neighbour's feature row is read as one contiguous burst, and U neighbours are in flight per lane.  The wave-per-
+// point kernel above wastes the lanes past C (C = 72 runs a second pass with 8 of 64 lanes) and has one row in flight.
+template <int U>
+__global__ __launch_bounds__(256) void adaptive_weight_fwd_v4(int n, int n0, int K, int C4, const float* __restrict__ q, const float* __restrict__ s,
+                                                              const int* __restrict__ idx, const float4* __restrict__ f, float radius,
+                                                              const float4* __restrict__ fcw, const float4* __restrict__ fcb,
+                                                              const int* __restrict__ padding_num, int reduction_mean, float4* __restrict__ out)
+{
+    const int pad = reduction_mean ? *padding_num : 0;
+    const long long total = (long long)n * C4;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int p = (int)(e / C4), cq = (int)(e - (long long)p * C4);
+        const float4 w0 = fcw[cq], w1 = fcw[C4 + cq], w2 = fcw[2 * C4 + cq], bb = fcb[cq];
+        const float qx = q[3 * p], qy = q[3 * p + 1], qz = q[3 * p + 2];
+        const int* __restrict__ row = idx + (size_t)p * K;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int cnt = 0;
+        for (int k0 = 0; k0 < K; k0 += U) {
+            int id[U]; float rx[U], ry[U], rz[U]; float4 fk[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                id[u] = (k0 + u < K) ? row[k0 + u] : n0;
+                cnt += (k0 + u < K && id[u] < pad) ? 1 : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const bool real = id[u] >= 0 && id[u] < n0;
+                const int ic = real ? id[u] : 0;
+                fk[u] = f[(size_t)ic * C4 + cq];
+                rx[u] = s[3 * ic]; ry[u] = s[3 * ic + 1]; rz[u] = s[3 * ic + 2];
+                if (!real) { fk[u] = make_float4(0.f, 0.f, 0.f, 0.f); rx[u] = ry[u] = rz[u] = 0.f; }       // shadow row / point (:360-370)
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (k0 + u < K) {
+                    const float x = (rx[u] - qx) / radius, y = (ry[u] - qy) / radius, z = (rz[u] - qz) / radius;    // :369-373
+                    acc.x += (((x * w0.x + y * w1.x) + z * w2.x) + bb.x) * fk[u].x;                      // fc_1 with bias (:426-430), :457-464
+                    acc.y += (((x * w0.y + y * w1.y) + z * w2.y) + bb.y) * fk[u].y;
+                    acc.z += (((x * w0.z + y * w1.z) + z * w2.z) + bb.z) * fk[u].z;
+                    acc.w += (((x * w0.w + y * w1.w) + z * w2.w) + bb.w) * fk[u].w;
+                }
+            }
+        }
+        const float nn = reduction_mean ? (float)cnt + 1e-5f : 1.f;
+        out[(size_t)p * C4 + cq] = make_float4(acc.x / nn, acc.y / nn, acc.z / nn, acc.w / nn);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- index pooling
 __global__ __launch_bounds__(256) void column_min_kernel(int n, int d, const float* __restrict__ x, unsigned* __restrict__ keymin)
 {
@@ -343,8 +392,15 @@ CBL_EXPORT int cbl_adaptive_weight_forward(int n, int n0, int K, int C, const fl
     if (n < 0 || n0 < 0 || K <= 0 || C <= 0 || !(radius > 0.f)) return CBL_ERR_BAD_ARG;
     if (n == 0) return CBL_OK;
     if (!query_points || !support_points || !neighbors_indices || !features || !fc_weight || !fc_bias || !out || (reduction_mean && !padding_num)) return CBL_ERR_BAD_ARG;
-    hipLaunchKernelGGL(adaptive_weight_kernel<false>, dim3(persistent_grid(n)), dim3(256), 0, cbl_stream(stream), n, n0, K, C, query_points, support_points,
-                       neighbors_indices, features, radius, fc_weight, fc_bias, padding_num, reduction_mean, out, nullptr, nullptr, nullptr, nullptr);
+    const bool vec = (C % 4 == 0) && ((((uintptr_t)features | (uintptr_t)fc_weight | (uintptr_t)fc_bias | (uintptr_t)out) & 15) == 0);
+    if (vec)
+        hipLaunchKernelGGL(adaptive_weight_fwd_v4<4>, dim3(cbl_grid_for((long long)n * (C / 4), 256)), dim3(256), 0, cbl_stream(stream), n, n0, K, C / 4,
+                           query_points, support_points, neighbors_indices, reinterpret_cast<const float4*>(features), radius,
+                           reinterpret_cast<const float4*>(fc_weight), reinterpret_cast<const float4*>(fc_bias), padding_num, reduction_mean,
+                           reinterpret_cast<float4*>(out));
+    else
+        hipLaunchKernelGGL(adaptive_weight_kernel<false>, dim3(persistent_grid(n)), dim3(256), 0, cbl_stream(stream), n, n0, K, C, query_points, support_points,
+                           neighbors_indices, features, radius, fc_weight, fc_bias, padding_num, reduction_mean, out, nullptr, nullptr, nullptr, nullptr);
     return cbl_status();
 }
 

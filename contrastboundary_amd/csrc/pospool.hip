@@ -6,11 +6,12 @@
 // each shared by C / mid consecutive channels (:228-231), and the reduction is sum / mean (with the padding-count quirk
 // :236-242) / max (shadow entries pushed to -65535, :243-249).  Index == n0 is the shadow neighbour: zero features, point (0,0,0).
 //
-// MI355X mapping: one wave per query point, lane = channel (64 at a time), so every neighbour's feature row is ONE coalesced
-// read; the neighbour ids of the point are one coalesced read up front; the embedding value of (neighbour, channel) is
-// computed in registers from per-lane constants decoded once (which monomial / direction component / sin or cos and its
-// wavelength), nothing of shape (n, K, .) exists in memory (the reference materialises four such tensors).  HBM-bound on
-// the gathered rows: algorithmic bytes 12n + 12n0 + 4nK + 4n0C + 4nC.
+// MI355X mapping.  Forward (sum / mean, C % 4 == 0): one lane = 4 consecutive channels of one point, the C/4 lanes of a point sit
+// next to each other (a neighbour's feature row is one contiguous burst) and 4 neighbours are in flight per lane.  Backward and
+// 'max': one wave per query point, lane = channel, neighbour ids / offsets staged in LDS once per point.  Either way the embedding
+// value of (neighbour, channel) is computed in registers from per-lane constants (which monomial / direction component / sin or
+// cos and its wavelength); nothing of shape (n, K, .) exists in memory (the reference materialises four such tensors).
+// Bound by the gathered rows (L2 / Infinity Cache): algorithmic bytes 12n + 12n0 + 4nK + 4n0C + 4nC.
 #include "cbl_common.h"
 
 namespace {
@@ -163,6 +164,53 @@ __global__ __launch_bounds__(256) void pospool_kernel(int n, int n0, int K, int 
     }
 }
 
+// Forward for sum / mean, C % 4 == 0: lane = 4 consecutive channels of one point, U neighbours in flight (see adaptive_weight_fwd_v4)
+template <int U>
+__global__ __launch_bounds__(256) void pospool_fwd_v4(int n, int n0, int K, int C4, const float* __restrict__ q, const float* __restrict__ s,
+                                                      const int* __restrict__ idx, const float4* __restrict__ f, float radius, int pe, int reduction,
+                                                      const int* __restrict__ padding_num, float4* __restrict__ out)
+{
+    const int pad = (reduction == RED_MEAN) ? *padding_num : 0;
+    const int C = 4 * C4;
+    const long long total = (long long)n * C4;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int p = (int)(e / C4), cq = (int)(e - (long long)p * C4);
+        const LaneGeo g0 = decode_geo(pe, C, 4 * cq), g1 = decode_geo(pe, C, 4 * cq + 1), g2 = decode_geo(pe, C, 4 * cq + 2), g3 = decode_geo(pe, C, 4 * cq + 3);
+        const float qx = q[3 * p], qy = q[3 * p + 1], qz = q[3 * p + 2];
+        const int* __restrict__ row = idx + (size_t)p * K;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int cnt = 0;
+        for (int k0 = 0; k0 < K; k0 += U) {
+            int id[U]; float rx[U], ry[U], rz[U]; float4 fk[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                id[u] = (k0 + u < K) ? row[k0 + u] : n0;
+                cnt += (k0 + u < K && id[u] < pad) ? 1 : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const bool real = id[u] >= 0 && id[u] < n0;
+                const int ic = real ? id[u] : 0;
+                fk[u] = f[(size_t)ic * C4 + cq];
+                rx[u] = s[3 * ic]; ry[u] = s[3 * ic + 1]; rz[u] = s[3 * ic + 2];
+                if (!real) id[u] = -1;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (id[u] >= 0) {                                     // shadow neighbours: zero feature row, contribute nothing
+                    const float x = (rx[u] - qx) / radius, y = (ry[u] - qy) / radius, z = (rz[u] - qz) / radius;    // :68-70
+                    acc.x += eval_geo(g0, x, y, z) * fk[u].x;         // :230-235
+                    acc.y += eval_geo(g1, x, y, z) * fk[u].y;
+                    acc.z += eval_geo(g2, x, y, z) * fk[u].z;
+                    acc.w += eval_geo(g3, x, y, z) * fk[u].w;
+                }
+            }
+        }
+        const float nn = (reduction == RED_MEAN) ? (float)cnt + 1e-5f : 1.f;      // :238-241
+        out[(size_t)p * C4 + cq] = make_float4(acc.x / nn, acc.y / nn, acc.z / nn, acc.w / nn);
+    }
+}
+
 inline unsigned pp_grid(int n) { return (unsigned)min((long long)cbl_div_up(n, 4), 256LL * 16); }
 
 int pospool_check(int n, int n0, int K, int C, float radius, int pe, int reduction)
@@ -183,8 +231,14 @@ CBL_EXPORT int cbl_pospool_forward(int n, int n0, int K, int C, const float* que
     if (rc) return rc;
     if (n == 0) return CBL_OK;
     if (!query_points || !support_points || !neighbors_indices || !features || !out || (reduction == RED_MEAN && !padding_num)) return CBL_ERR_BAD_ARG;
-    hipLaunchKernelGGL(pospool_kernel<false>, dim3(pp_grid(n)), dim3(256), 0, cbl_stream(stream), n, n0, K, C, query_points, support_points,
-                       neighbors_indices, features, radius, position_embedding, reduction, padding_num, out, nullptr, nullptr);
+    const bool vec = reduction != RED_MAX && (C % 4 == 0) && ((((uintptr_t)features | (uintptr_t)out) & 15) == 0);
+    if (vec)
+        hipLaunchKernelGGL(pospool_fwd_v4<4>, dim3(cbl_grid_for((long long)n * (C / 4), 256)), dim3(256), 0, cbl_stream(stream), n, n0, K, C / 4, query_points,
+                           support_points, neighbors_indices, reinterpret_cast<const float4*>(features), radius, position_embedding, reduction, padding_num,
+                           reinterpret_cast<float4*>(out));
+    else
+        hipLaunchKernelGGL(pospool_kernel<false>, dim3(pp_grid(n)), dim3(256), 0, cbl_stream(stream), n, n0, K, C, query_points, support_points,
+                           neighbors_indices, features, radius, position_embedding, reduction, padding_num, out, nullptr, nullptr);
     return cbl_status();
 }
 
