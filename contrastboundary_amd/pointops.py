@@ -78,12 +78,68 @@ class FurthestSampling(Function):
 furthestsampling = FurthestSampling.apply
 
 # ------------------------------------------------------------------------------------------------ K1
+class neighbor_cache:
+    """Per-forward neighbour-index cache.  The reference's network asks for the SAME neighbour search
+    many times per forward — every PointTransformerLayer of a stage runs knnquery(nsample, p, p, o, o) twice (blocks.py:34-35), the
+    decoder blocks again, 57 launches in total — because each pointops call is self-contained.  Inside
+
+        with pointops.neighbor_cache() as nc:
+            logits, stage_list = model(inputs); loss = criterion(logits, target, stage_list)
+
+    identical requests (same nsample, same coordinate / offset tensors by storage, shape and version) are answered from the
+    first result; nothing else changes, so modules keep the reference's signatures.  An 'auto' (reference-order) result also
+    serves a later 'set' request.  The cache holds references to the keyed tensors, so storage cannot be recycled under it; it
+    is dropped when the context exits.  `nc.hits` / `nc.misses` count requests."""
+    _active = None
+
+    def __init__(self):
+        self.store, self.hits, self.misses = {}, 0, 0
+
+    def __enter__(self):
+        self._prev = neighbor_cache._active
+        neighbor_cache._active = self
+        return self
+
+    def __exit__(self, *exc):
+        neighbor_cache._active = self._prev
+        self.store.clear()
+        return False
+
+    @staticmethod
+    def _key(nsample, algo, tensors):
+        return (nsample, algo) + tuple((t.data_ptr(), tuple(t.shape), t._version) for t in tensors)
+
+    def lookup(self, nsample, algo, tensors):
+        for a in ((algo, "auto") if algo == "set" else (algo,)):
+            hit = self.store.get(self._key(nsample, a, tensors))
+            if hit is not None:
+                self.hits += 1
+                return hit[0], hit[1]
+        self.misses += 1
+        return None
+
+    def insert(self, nsample, algo, tensors, idx, dist2):
+        self.store[self._key(nsample, algo, tensors)] = (idx, dist2, tensors)
+
+
 def knnquery_raw(nsample, xyz, new_xyz, offset, new_offset, algo="auto"):
     """-> idx (m,nsample) i32, dist2 (m,nsample) f32 (squared).  algo: 'auto' | 'exact' | 'grid' | 'set'
     ('set': same neighbour set and distances, order among exactly equal distances unspecified — cbl_knnquery_set)"""
     nsample = _as_int(nsample)
     if new_xyz is None:
         new_xyz = xyz
+    cache = neighbor_cache._active
+    if cache is not None:
+        hit = cache.lookup(nsample, algo, (xyz, new_xyz, offset, new_offset))
+        if hit is not None:
+            return hit
+        idx, dist2 = _knnquery_uncached(nsample, xyz, new_xyz, offset, new_offset, algo)
+        cache.insert(nsample, algo, (xyz, new_xyz, offset, new_offset), idx, dist2)
+        return idx, dist2
+    return _knnquery_uncached(nsample, xyz, new_xyz, offset, new_offset, algo)
+
+
+def _knnquery_uncached(nsample, xyz, new_xyz, offset, new_offset, algo):
     _req(xyz, torch.float32, "xyz", 2); _req(new_xyz, torch.float32, "new_xyz", 2)
     _req(offset, torch.int32, "offset", 1); _req(new_offset, torch.int32, "new_offset", 1)
     if not 1 <= nsample <= 1024:
@@ -113,6 +169,8 @@ class KNNQuery(Function):
     def forward(ctx, nsample, xyz, new_xyz, offset, new_offset):
         """-> idx (m,nsample) i32, dist (m,nsample) f32 = sqrt(dist2)                   pointops.py:32-43"""
         idx, dist2 = knnquery_raw(nsample, xyz, new_xyz, offset, new_offset)
+        if neighbor_cache._active is not None:
+            idx = idx.view(idx.shape)          # a cached result is shared by several calls: hand autograd its own tensor object
         ctx.mark_non_differentiable(idx)
         return idx, torch.sqrt(dist2)
 
