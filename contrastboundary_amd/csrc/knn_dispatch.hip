@@ -1,13 +1,19 @@
-// K1 front door: picks the grid kernel (certified, knn_grid.hip) or the brute-force kernel (knn_exact.hip).
+// K1 front door: picks the grid kernels (K <= 64, certified, knn_grid.hip), the block-select kernel (64 < K <= 1024, certified,
+// knn_select.hip) or the brute-force kernel (small problems, knn_exact.hip).
 #include "cbl_common.h"
 
 size_t cbl_knn_grid_workspace_bytes(int b, int n, int m, int nsample);     // knn_grid.hip
 int cbl_knn_grid_launch(int b, int n, int m, int nsample, const float* xyz, const float* new_xyz, const int* offset,
                         const int* new_offset, int* idx, float* dist2, void* ws, size_t ws_bytes, int set_exact, hipStream_t st);
 
+size_t cbl_knn_select_workspace_bytes(int b, int n, int m, int nsample);   // knn_select.hip
+int cbl_knn_select_launch(int b, int n, int m, int nsample, const float* xyz, const float* new_xyz, const int* offset, const int* new_offset,
+                          int* idx, float* dist2, void* ws, size_t ws_bytes, int set_exact, hipStream_t st);
+
 CBL_EXPORT size_t cbl_knnquery_workspace_bytes(int b, int n, int m, int nsample)
 {
-    return cbl_knn_grid_workspace_bytes(b, n, m, nsample);
+    const size_t g = cbl_knn_grid_workspace_bytes(b, n, m, nsample);
+    return g ? g : cbl_knn_select_workspace_bytes(b, n, m, nsample);
 }
 
 static int knnquery_impl(int b, int n, int m, int nsample, const float* xyz, const float* new_xyz,
@@ -20,6 +26,9 @@ static int knnquery_impl(int b, int n, int m, int nsample, const float* xyz, con
     const size_t need = cbl_knn_grid_workspace_bytes(b, n, m, nsample);
     if (need > 0 && workspace && workspace_bytes >= need)
         return cbl_knn_grid_launch(b, n, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, workspace, workspace_bytes, set_exact, cbl_stream(stream));
+    const size_t need_sel = cbl_knn_select_workspace_bytes(b, n, m, nsample);
+    if (need_sel > 0 && workspace && workspace_bytes >= need_sel)
+        return cbl_knn_select_launch(b, n, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, workspace, workspace_bytes, set_exact, cbl_stream(stream));
     return cbl_knnquery_exact(b, n, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, stream);
 }
 

@@ -51,7 +51,8 @@ def test_knn_golden(P, name, algo):
 @pytest.mark.parametrize("n,m,b,k,seed", [(5000, 5000, 1, 16, 0), (6000, 1500, 3, 16, 1), (3000, 3000, 4, 36, 2),
                                           (2000, 700, 2, 3, 3), (2000, 2000, 1, 1, 4), (4096, 64, 2, 256, 5),
                                           (1500, 200, 1, 400, 6), (8000, 2000, 2, 24, 7), (9000, 9000, 1, 64, 8), (5000, 5000, 1, 33, 9),
-                                          (6000, 900, 3, 48, 10)])
+                                          (6000, 900, 3, 48, 10), (20000, 300, 1, 256, 11), (12000, 500, 2, 100, 12), (9000, 64, 1, 1000, 13),
+                                          (40960, 160, 1, 256, 14)])
 def test_knn_vs_oracle_random(P, n, m, b, k, seed, algo):
     rng = np.random.default_rng(seed)
     xyz = rng.uniform(0, 2, (n, 3)).astype(np.float32)
@@ -345,3 +346,21 @@ def test_empty_and_degenerate_inputs(P):
     i1, d1 = P.knnquery_raw(3, one, one, dev(np.int32([1])), dev(np.int32([1])))
     r1, _ = O.knnquery(3, one.cpu().numpy(), one.cpu().numpy(), [1], [1])
     np.testing.assert_array_equal(i1.cpu().numpy(), r1)
+
+
+@pytest.mark.parametrize("algo", ["auto", "set"])
+def test_knn_large_k_with_ties_falls_back_to_the_reference_order(P, algo):
+    # 64 < K: block-select kernel; on a lattice every query has ties at the K-th distance, so every query is redone by the exact kernel
+    g = np.arange(17, dtype=np.float32)
+    lat = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)       # 4913 points
+    rng = np.random.default_rng(3)
+    pts = np.concatenate([lat, rng.uniform(0, 16, (3000, 3)).astype(np.float32)])
+    q = pts[rng.choice(len(pts), 200, replace=False)]
+    o, qo = np.int32([len(pts)]), np.int32([200])
+    idx, d2 = P.knnquery_raw(100, dev(pts), dev(q), dev(o), dev(qo), algo=algo)
+    ridx, rd2 = O.knnquery(100, pts, q, o, qo)
+    np.testing.assert_array_equal(d2.cpu().numpy().view(np.uint32), rd2.view(np.uint32))
+    if algo == "auto":
+        np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+    else:   # same neighbour set per query
+        np.testing.assert_array_equal(np.sort(idx.cpu().numpy(), 1), np.sort(ridx, 1))

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""C4: one training-step forward+backward of Point Transformer + CBL (7.8 M parameters, shipped config) on synthetic S-room scenes.
+python tools/bench_model.py [--n 40960] [--scenes 1] [--steps 10]   -> one JSON line (ms per step, points/s, KNN cache statistics)"""
+import argparse
+import json
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
+from contrastboundary_amd import pointtransformer_seg as M, synthetic as S  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=40960); ap.add_argument("--scenes", type=int, default=1)
+ap.add_argument("--steps", type=int, default=10); ap.add_argument("--warmup", type=int, default=3)
+ap.add_argument("--no-cache", action="store_true")
+a = ap.parse_args()
+cfg = M.Config({"base_fdim": 32, "nsample": [36, 24, 24, 24, 24], "nstride": [4, 4, 4, 4], "ignore_label": 255, "voxel_size": 0.04,
+                "contrast": {"stage": "Ua", "contrast": "softnn", "ftype": "latent", "sample": "label", "pos": "cnt", "dist": "l2", "temperature": 1, "weight": "w.1"},
+                "multi": {"stage": "Ua", "ftype": "latent", "combine": "concat"}})
+torch.manual_seed(0)
+model = M.pointtransformer_seg_repro(c=6, k=13, config=cfg).cuda().train()
+crit = M.Loss(cfg)
+opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+xs, ls = zip(*[S.s_room(a.n, seed=i) for i in range(a.scenes)])
+inputs = {"points": torch.from_numpy(np.concatenate(xs)).cuda(), "features": torch.rand(a.n * a.scenes, 3, device="cuda"),
+          "offset": torch.tensor(np.cumsum([a.n] * a.scenes), dtype=torch.int32, device="cuda")}
+target = torch.from_numpy(np.concatenate(ls)).cuda()
+
+
+def step():
+    opt.zero_grad(set_to_none=True)
+    if a.no_cache:
+        out, sl = model(inputs); loss = crit(out, target, sl); nc = None
+    else:
+        out, sl, loss, nc = M.forward_and_loss(model, crit, inputs, target)
+    loss.sum().backward()
+    opt.step()
+    return loss, nc
+
+
+for _ in range(a.warmup):
+    step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(a.steps):
+    loss, nc = step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / a.steps
+print(json.dumps({"workload": f"PointTransformerSeg+CBL train step, {a.scenes} x S-room({a.n})", "ms_per_step": dt * 1e3,
+                  "points_per_s": a.n * a.scenes / dt, "knn_requests": None if nc is None else nc.hits + nc.misses,
+                  "knn_searches": None if nc is None else nc.misses, "loss": [round(float(v), 5) for v in loss.detach().cpu()]}))
