@@ -66,3 +66,24 @@ def get_boundary_mask(labels, neighbor_label=None, neighbor_idx=None, valid_mask
         bound = bound * valid_mask if get_cnt else torch.logical_and(bound, valid_mask)
         plain = torch.logical_and(plain, valid_mask)
     return (bound, plain) if get_plain else bound
+
+
+def boundary_iou(pred, labels, neighbor_idx=None, xyz=None, offset=None, kr=None, num_classes=13, ignore_label=255):
+    """Boundary / inner-area IoU statistics of one room (tool/test.py:250-257 + :392-417), on the GPU: the kr-neighbourhood search on
+    the full-resolution cloud, the boundary / plain masks and the masked intersection-and-union histograms.
+    pred, labels (n,) int64; either neighbor_idx (n,kr) int32 or (xyz, offset, kr).
+    -> {'bound': (i, u, t), 'plain': (i, u, t)} int64 tensors of length num_classes, exactly intersectionAndUnion's triplets"""
+    if neighbor_idx is None:
+        neighbor_idx, _ = pointops.knnquery_raw(kr, xyz, xyz, offset, offset, algo="set")      # the masks only use the neighbour set
+    n, k = neighbor_idx.shape
+    if pred.dtype != torch.int64 or labels.dtype != torch.int64:
+        raise TypeError("pred and labels must be int64")
+    hist = torch.zeros((2, 3, int(num_classes)), dtype=torch.int64, device=labels.device)
+    pred_c, labels_c, nidx_c = pred.contiguous(), labels.contiguous(), neighbor_idx.contiguous()
+    _lib.check(_lib.lib().cbl_boundary_iou(_c_int(n), _c_int(k), _c_int(int(num_classes)), ctypes.c_longlong(int(ignore_label)), _lib.ptr(pred_c),
+                                           _lib.ptr(labels_c), _lib.ptr(nidx_c), _lib.ptr(hist), _lib.stream_of(labels)), "cbl_boundary_iou")
+    out = {}
+    for mi, name in enumerate(("bound", "plain")):
+        i, o, t = hist[mi, 0], hist[mi, 1], hist[mi, 2]
+        out[name] = (i, o + t - i, t)
+    return out

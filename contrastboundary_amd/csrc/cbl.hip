@@ -243,6 +243,40 @@ __global__ __launch_bounds__(256) void boundary_mask_kernel(int n, int k, const 
     if (cnt) cnt[i] = neq;
 }
 
+// ---- boundary-IoU evaluation: masks + masked intersection / output / target histograms in one pass ---------------------------
+// (tool/test.py:392-417 with get_boundary_mask basic_operators.py:69-97 and intersectionAndUnion util/common_util.py:25-37)
+// hist[mask][what][class], mask 0 = boundary points, 1 = plain points; what 0 = intersection, 1 = output area, 2 = target area
+__global__ __launch_bounds__(256) void boundary_iou_kernel(int n, int k, int ncls, long long ignore, const long long* __restrict__ pred,
+                                                           const long long* __restrict__ labels, const int* __restrict__ nidx,
+                                                           unsigned long long* __restrict__ hist)
+{
+    extern __shared__ unsigned lh[];                                // [2][3][ncls]
+    for (int e = threadIdx.x; e < 6 * ncls; e += 256) lh[e] = 0u;
+    __syncthreads();
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const long long me = labels[i];
+        bool any_neq = false, all_eq = true;
+        for (int j = 0; j < k; j++) {
+            const long long nl = labels[nidx[(size_t)i * k + j]];
+            const bool valid = nl >= 0;                             // :77
+            any_neq = any_neq || (valid && nl != me);               // :80-81
+            all_eq = all_eq && (nl == me || !valid);                // :92-93
+        }
+        const long long out = (me == ignore) ? ignore : pred[i];    // common_util.py:31
+#pragma unroll
+        for (int mk = 0; mk < 2; mk++) {
+            if (mk == 0 ? any_neq : all_eq) {
+                unsigned* h = lh + mk * 3 * ncls;
+                if (out == me && out >= 0 && out < ncls) atomicAdd(h + out, 1u);                 // :32-33
+                if (out >= 0 && out < ncls) atomicAdd(h + ncls + out, 1u);                       // :34
+                if (me >= 0 && me < ncls) atomicAdd(h + 2 * ncls + me, 1u);                      // :35
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 6 * ncls; e += 256) if (lh[e]) atomicAdd(hist + e, (unsigned long long)lh[e]);
+}
+
 template <int G>
 int launch_contrast(bool fwd, int m, int nsample, int d, const float* feat, const int* amax, const int* nidx, float inv_t, float weight,
                     int n_valid, int tf_variant,
@@ -356,5 +390,17 @@ CBL_EXPORT int cbl_boundary_mask(int n, int k, const long long* labels, const in
     if (n == 0) return CBL_OK;
     if (!labels || !neighbor_idx) return CBL_ERR_BAD_ARG;
     hipLaunchKernelGGL(boundary_mask_kernel, dim3(cbl_div_up(n, 256)), dim3(256), 0, cbl_stream(stream), n, k, labels, neighbor_idx, bound, plain, cnt);
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_boundary_iou(int n, int k, int num_classes, long long ignore_label, const long long* pred, const long long* labels,
+                                const int* neighbor_idx, unsigned long long* hist, void* stream)
+{
+    if (n < 0 || k <= 0 || num_classes <= 0 || num_classes > 2048) return CBL_ERR_BAD_ARG;
+    if (!hist) return CBL_ERR_BAD_ARG;
+    if (n == 0) return CBL_OK;
+    if (!pred || !labels || !neighbor_idx) return CBL_ERR_BAD_ARG;
+    hipLaunchKernelGGL(boundary_iou_kernel, dim3(cbl_grid_for(n, 256, 1024)), dim3(256), sizeof(unsigned) * 6 * (size_t)num_classes, cbl_stream(stream),
+                       n, k, num_classes, ignore_label, pred, labels, neighbor_idx, hist);
     return cbl_status();
 }

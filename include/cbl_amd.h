@@ -171,6 +171,13 @@ int cbl_tf_scene_label(int m, int n_valid, int k, int num_classes, const long lo
  *   cnt (n) i32 [number of differing valid neighbours]; any output may be NULL */
 int cbl_boundary_mask(int n, int k, const long long* labels, const int* neighbor_idx, unsigned char* bound, unsigned char* plain, int* cnt, void* stream);
 
+/* boundary-IoU evaluation  pytorch/tool/test.py:392-417: get_boundary_mask (above, with get_plain) followed by
+ *   intersectionAndUnion(pred[mask], label[mask], K, ignore)  util/common_util.py:25-37  for mask in (bound, plain), fused:
+ *   pred (n) i64, labels (n) i64, neighbor_idx (n,k) -> hist (2,3,num_classes) u64 += [mask bound|plain][intersection|output|target]
+ *   (caller pre-zeroes; union = output + target - intersection, :36) */
+int cbl_boundary_iou(int n, int k, int num_classes, long long ignore_label, const long long* pred, const long long* labels,
+                     const int* neighbor_idx, unsigned long long* hist, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * TF-side local aggregation over radius neighbourhoods (index == n0 selects the shadow / padding row)
  * ---------------------------------------------------------------------------------------------- */

@@ -5,6 +5,7 @@ numpy restatement of the reference's Contrastive Boundary Learning head (pytorch
     ContrastHead.point_contrast                  /root/reference/pytorch/model/heads.py:185-246
         posmask_cnt :145-149, dist_l2 :116-119, contrast_softnn :151-165
     get_boundary_mask                            /root/reference/pytorch/model/basic_operators.py:69-97
+    boundary-IoU evaluation                      /root/reference/pytorch/tool/test.py:392-417 + util/common_util.py:25-37
 Neighbour indices are inputs (the KNN itself is oracle/pointops_oracle.c).  Pinned by tests/golden/cbl_pytorch.npz and
 boundary_mask.npz, which were produced by importing and running the reference's own Python on CPU
 (tests/golden/gen_cbl_goldens.py).  float32 forward like the reference; summation ORDER differs from torch's
@@ -94,6 +95,25 @@ def boundary_mask(labels, neighbor_label, valid_mask=None, get_plain=False, get_
         plain = plain & valid_mask if valid_mask is not None else plain
         return bound, plain
     return bound
+
+
+def intersection_and_union(output, target, K, ignore_index=255):
+    """util/common_util.py:25-37"""
+    output = np.asarray(output).reshape(-1).copy(); target = np.asarray(target).reshape(-1)
+    output[target == ignore_index] = ignore_index
+    inter = output[output == target]
+    ai = np.histogram(inter, bins=np.arange(K + 1))[0]
+    ao = np.histogram(output, bins=np.arange(K + 1))[0]
+    at = np.histogram(target, bins=np.arange(K + 1))[0]
+    return ai, ao + at - ai, at
+
+
+def boundary_iou(pred, labels, neighbor_idx, num_classes, ignore_label=255):
+    """tool/test.py:392-417: (i, u, t) of the boundary points and of the plain points"""
+    labels = np.asarray(labels)
+    bound, plain = boundary_mask(labels, labels[neighbor_idx], get_plain=True)
+    return {"bound": intersection_and_union(np.asarray(pred)[bound], labels[bound], num_classes, ignore_label),
+            "plain": intersection_and_union(np.asarray(pred)[plain], labels[plain], num_classes, ignore_label)}
 
 
 # ---------------------------------------------------------------------------------------------------------------------------

@@ -102,8 +102,22 @@ def main():
     nl[::7, 2] = -1                                     # invalid neighbours
     bound, plain = ref_ops.get_boundary_mask(lab, neighbor_label=nl, get_plain=True)
     cnt = ref_ops.get_boundary_mask(lab, neighbor_label=nl, get_cnt=True)
+    # ---- boundary-IoU evaluation as tool/test.py:392-417 does it: the reference's get_boundary_mask (neighbor_idx form) and its
+    # intersectionAndUnion (util/common_util.py:25-37) on a labelled synthetic room with a noisy prediction and some ignored points
+    from util.common_util import intersectionAndUnion
+    xyz_e, lab_e = S.s_room(3000, seed=9)
+    lab_e = lab_e.copy(); lab_e[::41] = 255                              # ignore_label
+    pred_e = lab_e.copy(); flip = rng.random(3000) < 0.2; pred_e[flip] = rng.integers(0, 13, int(flip.sum())); pred_e[lab_e == 255] = 3
+    nidx_e, _ = O.knnquery(8, xyz_e, xyz_e, np.int32([3000]), np.int32([3000]))
+    b_e, p_e = ref_ops.get_boundary_mask(torch.from_numpy(lab_e), neighbor_idx=torch.from_numpy(nidx_e), get_plain=True)
+    b_e, p_e = b_e.numpy(), p_e.numpy()
+    iou = {}
+    for name, mask in (("bound", b_e), ("plain", p_e)):
+        i_, u_, t_ = intersectionAndUnion(pred_e[mask], lab_e[mask], 13, 255)
+        iou[f"iou_{name}_i"], iou[f"iou_{name}_u"], iou[f"iou_{name}_t"] = i_, u_, t_
     np.savez_compressed(os.path.join(HERE, "boundary_mask.npz"), labels=lab.numpy(), neighbor_label=nl.numpy(),
-                        bound=bound.numpy(), plain=plain.numpy(), cnt=cnt.numpy())
+                        bound=bound.numpy(), plain=plain.numpy(), cnt=cnt.numpy(),
+                        iou_xyz=xyz_e, iou_labels=lab_e, iou_pred=pred_e, iou_neighbor_idx=nidx_e, iou_bound_mask=b_e, iou_plain_mask=p_e, **iou)
 
 
 if __name__ == "__main__":

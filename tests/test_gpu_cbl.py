@@ -152,3 +152,30 @@ def test_tf_scene_labels_vs_oracle():
     soft = heads.tf_scene_label(dev(lab), nb, 13, "soft")
     np.testing.assert_array_equal(hard.cpu().numpy(), C.tf_scene_label(lab, nb.cpu().numpy(), 13, "max"))
     np.testing.assert_allclose(soft.cpu().numpy(), C.tf_scene_label(lab, nb.cpu().numpy(), 13, "soft"), rtol=1e-6, atol=1e-7)
+
+
+def test_boundary_iou_evaluation():
+    """(f) rank 3: kr-neighbourhood search + boundary / plain masks + masked intersection-and-union, one call per room"""
+    from contrastboundary_amd.basic_operators import boundary_iou
+    g = np.load(os.path.join(G, "boundary_mask.npz"))
+    # a) from the golden's neighbour indices: the reference's own numbers
+    r = boundary_iou(dev(g["iou_pred"]), dev(g["iou_labels"]), neighbor_idx=dev(g["iou_neighbor_idx"]), num_classes=13, ignore_label=255)
+    for name in ("bound", "plain"):
+        for v, key in zip(r[name], "iut"):
+            np.testing.assert_array_equal(v.cpu().numpy(), g[f"iou_{name}_{key}"])
+    # b) end to end from coordinates (the search is part of the call)
+    n = len(g["iou_labels"])
+    r2 = boundary_iou(dev(g["iou_pred"]), dev(g["iou_labels"]), xyz=dev(g["iou_xyz"]), offset=dev(np.int32([n])), kr=8, num_classes=13, ignore_label=255)
+    for name in ("bound", "plain"):
+        for a, b in zip(r[name], r2[name]):
+            assert torch.equal(a, b)
+    # c) room-sized property check: every non-ignored point is counted once in 'bound' or 'plain' targets... or in neither when it has
+    #    both no differing and (impossible) — i.e. bound and plain partition the points whose neighbour labels are all valid
+    from contrastboundary_amd import synthetic as S
+    xyz, lab = S.s_room(200000, seed=3, scale=4.0)
+    pred = lab.copy(); pred[::5] = (pred[::5] + 1) % 13
+    r3 = boundary_iou(dev(pred), dev(lab), xyz=dev(xyz), offset=dev(np.int32([200000])), kr=16, num_classes=13)
+    t_total = (r3["bound"][2] + r3["plain"][2]).cpu().numpy()
+    np.testing.assert_array_equal(t_total, np.bincount(lab, minlength=13))
+    ref = C.boundary_iou(pred[:0], lab[:0], np.zeros((0, 16), np.int64), 13)
+    assert all(int(v.sum()) == 0 for v in ref["bound"])

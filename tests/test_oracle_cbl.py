@@ -45,3 +45,14 @@ def test_boundary_mask():
     b, p = C.boundary_mask(g["labels"], g["neighbor_label"], get_plain=True)
     np.testing.assert_array_equal(b, g["bound"]); np.testing.assert_array_equal(p, g["plain"])
     np.testing.assert_array_equal(C.boundary_mask(g["labels"], g["neighbor_label"], get_cnt=True), g["cnt"])
+
+
+def test_boundary_iou_oracle_matches_reference_functions():
+    """tool/test.py:392-417: the reference's get_boundary_mask + intersectionAndUnion, run in the build container (gen_cbl_goldens.py)"""
+    g = np.load(os.path.join(G, "boundary_mask.npz"))
+    r = C.boundary_iou(g["iou_pred"], g["iou_labels"], g["iou_neighbor_idx"], 13, 255)
+    for name in ("bound", "plain"):
+        for v, key in zip(r[name], "iut"):
+            np.testing.assert_array_equal(v, g[f"iou_{name}_{key}"])
+    b, p = C.boundary_mask(g["iou_labels"], g["iou_labels"][g["iou_neighbor_idx"]], get_plain=True)
+    np.testing.assert_array_equal(b, g["iou_bound_mask"]); np.testing.assert_array_equal(p, g["iou_plain_mask"])
