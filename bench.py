@@ -105,7 +105,7 @@ def main():
     main_kernel = {"knnquery_k16": "knn_grid_group_kernel<16> (+ 5-launch grid build, knn_replay_kernel for tied queries)",
                    "queryandgroup": "query_group_v4", "kpconv_fwd": "kpconv_fwd_kernel (v_mfma_f32_16x16x4_f32)",
                    "cbl_knnquery_k36": "knn_grid_wave_kernel (select-then-sort, + 5-launch grid build)",
-                   "cbl_mining_loss_fwd": "contrast_fwd_kernel<64,8> (+ finalize)", "cbl_mining_loss_bwd": "contrast_bwd_kernel<64,8>"}
+                   "cbl_mining_loss_fwd": "contrast_bwd_kernel<64,8> in fused forward+gradient mode (+ finalize)", "cbl_mining_loss_bwd": "contrast_grad_scale_kernel"}
     roofline = {"kernel": main_kernel.get(names[dom], names[dom]), "stage": names[dom], "bound": "hbm",
                 "achieved": gbps(dom), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps(dom) / HBM_PEAK_GBS, "traffic": None,
                 "note": "achieved = SURVEY 8(d) algorithmic bytes of the stage / its HIP-event time; the neighbour searches move few "
@@ -119,8 +119,8 @@ def main():
     if os.path.exists(pmc_file) and (n, c, k) == (40960, 64, 16):
         pmc = json.load(open(pmc_file))
     pmc_kernel = {"knnquery_k16": "knn_grid_group_kernel<16, true>", "queryandgroup": "query_group_v4", "kpconv_fwd": "kpconv_fwd_kernel<true>",
-                  "cbl_knnquery_k36": "knn_grid_wave_kernel<true>", "cbl_mining_loss_fwd": "contrast_fwd_kernel<64, 8>",
-                  "cbl_mining_loss_bwd": "contrast_bwd_kernel<64, 8>"}
+                  "cbl_knnquery_k36": "knn_grid_wave_kernel<true>", "cbl_mining_loss_fwd": "contrast_bwd_kernel<64, 8>",
+                  "cbl_mining_loss_bwd": "contrast_grad_scale_kernel"}
     traffic = lambda stage: pmc.get(pmc_kernel.get(stage, ""), {}).get("hbm_bytes_per_launch")
     roofline["traffic"] = traffic(names[dom])
     gi = names.index("queryandgroup")

@@ -177,8 +177,13 @@ __global__ __launch_bounds__(256) void contrast_bwd_kernel(int m, int nsample, c
                                                            const int* __restrict__ nidx, float inv_temperature, float weight,
                                                            int n_valid, int tf_variant,
                                                            const float* __restrict__ stats, const float* __restrict__ grad_loss,
-                                                           float* __restrict__ grad_feat)
+                                                           float* __restrict__ grad_feat,
+                                                           float* __restrict__ per_point, int* __restrict__ point_mask)   // non-null: fused forward
 {
+    // Fused forward + gradient (per_point != nullptr): the point's loss term is written as in contrast_fwd_kernel and the gradient is
+    // accumulated WITHOUT its global factor g*w/count (count = number of qualifying points is only known after the whole launch);
+    // cbl_contrast_grad_scale applies the factor in the backward pass.  One gather of the neighbour rows instead of two.
+    const bool fused = per_point != nullptr;
     constexpr int D = DV * 4;                                       // channels
     constexpr int R = 64 / D;                                       // pairs per step in phase 2 (D <= 64)
     const int lane = threadIdx.x & 63;
@@ -186,15 +191,19 @@ __global__ __launch_bounds__(256) void contrast_bwd_kernel(int m, int nsample, c
     const int gl = threadIdx.x & (G - 1);
     const int i = t < m ? t : m - 1;
     const int ns = nsample - 1;
-    const float count = stats[1];
+    const float count = fused ? 1.f : stats[1];
     if (!(count > 0.f)) return;                                     // uniform: the loss was the constant 0
     float coef = 0.f; int nbr;
     {
         ContrastRow<G, DV> r;
         contrast_row<G, DV>(r, i, gl, nsample, D, feat, amax, nidx, inv_temperature, n_valid, tf_variant);
         nbr = r.nbr;
+        if (fused && t < m && gl == 0) {
+            per_point[t] = r.valid ? -logf(r.P / r.A + 1e-12f) : 0.f;   // contrast_softnn :161-163
+            point_mask[t] = r.valid ? 1 : 0;
+        }
         if (t < m && r.valid && r.nb) {
-            const float scale = grad_loss[0] * weight / count;
+            const float scale = fused ? 1.f : grad_loss[0] * weight / count;
             const float ratio = r.P / r.A;
             coef = scale * r.e * ((r.pos ? r.A : 0.f) - r.P) * inv_temperature / (r.A * r.A * (ratio + 1e-12f)) / r.dist;
             if (tf_variant && r.dist <= 1e-6f) coef = 0.f;           // sqrt(max(s, 1e-12)): flat below the clamp
@@ -285,7 +294,8 @@ int launch_contrast(bool fwd, int m, int nsample, int d, const float* feat, cons
     const dim3 grid(cbl_div_up((long long)m * G, 256)), block(256);
 #define CBL_CONTRAST_DV(DV)                                                                                                                  \
     if (fwd) hipLaunchKernelGGL((contrast_fwd_kernel<G, DV>), grid, block, 0, st, m, nsample, feat, amax, nidx, inv_t, n_valid, tf_variant, per_point, point_mask); \
-    else     hipLaunchKernelGGL((contrast_bwd_kernel<G, DV>), grid, block, 0, st, m, nsample, feat, amax, nidx, inv_t, weight, n_valid, tf_variant, stats, grad_loss, grad_feat)
+    else     hipLaunchKernelGGL((contrast_bwd_kernel<G, DV>), grid, block, 0, st, m, nsample, feat, amax, nidx, inv_t, weight, n_valid, tf_variant, stats, grad_loss, grad_feat, \
+                                per_point, point_mask)
     switch (d) {
         case 4:  CBL_CONTRAST_DV(1); break;
         case 8:  CBL_CONTRAST_DV(2); break;
@@ -382,6 +392,55 @@ CBL_EXPORT int cbl_point_contrast_backward(int m, int nsample, int d, const floa
     if (!features || !amax || !neighbor_idx || !stats || !grad_loss || !grad_features) return CBL_ERR_BAD_ARG;
     if (!cbl_host_aligned16(features)) return CBL_ERR_BAD_ARG;
     return dispatch_contrast(false, m, nsample, d, features, amax, neighbor_idx, temperature, weight, 0x7fffffff, 0, nullptr, nullptr, stats, grad_loss, grad_features, cbl_stream(stream));
+}
+
+namespace {
+// grad_features = grad_unit * (grad_loss * weight / count); all zeros when no point qualified (the loss was the constant 0)
+__global__ __launch_bounds__(256) void contrast_grad_scale_kernel(long long total, const float* __restrict__ unit, const float* __restrict__ stats,
+                                                                  const float* __restrict__ grad_loss, float weight, float* __restrict__ out)
+{
+    const float count = stats[1];
+    const float sc = count > 0.f ? grad_loss[0] * weight / count : 0.f;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) out[e] = count > 0.f ? unit[e] * sc : 0.f;
+}
+}  // namespace
+
+static int contrast_forward_grad(int m, int n_valid, int tf_variant, int nsample, int d, const float* features, const int* labels, const int* neighbors,
+                                 float temperature, float weight, float* per_point, int* point_mask, float* stats, float* loss, float* grad_unit, void* stream)
+{
+    if (m <= 0 || n_valid < 0 || nsample < 2 || nsample > 65 || d <= 0 || !(temperature > 0.f)) return CBL_ERR_BAD_ARG;
+    if (!features || !labels || !neighbors || !per_point || !point_mask || !stats || !loss || !grad_unit) return CBL_ERR_BAD_ARG;
+    if (!cbl_host_aligned16(features)) return CBL_ERR_BAD_ARG;
+    hipStream_t st = cbl_stream(stream);
+    const int rc = dispatch_contrast(false, m, nsample, d, features, labels, neighbors, temperature, weight, n_valid, tf_variant, per_point, point_mask,
+                                     nullptr, nullptr, grad_unit, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(contrast_finalize_kernel, dim3(1), dim3(1024), 0, st, m, weight, per_point, point_mask, stats, loss);
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_point_contrast_forward_grad(int m, int nsample, int d, const float* features, const int* amax, const int* neighbor_idx,
+                                               float temperature, float weight, float* per_point, int* point_mask, float* stats, float* loss,
+                                               float* grad_unit, void* stream)
+{
+    return contrast_forward_grad(m, 0x7fffffff, 0, nsample, d, features, amax, neighbor_idx, temperature, weight, per_point, point_mask, stats, loss, grad_unit, stream);
+}
+
+CBL_EXPORT int cbl_tf_contrast_forward_grad(int m, int n_valid, int nsample, int d, const float* features, const int* labels, const int* neighbors,
+                                            float temperature, float weight, float* per_point, int* point_mask, float* stats, float* loss,
+                                            float* grad_unit, void* stream)
+{
+    return contrast_forward_grad(m, n_valid, 1, nsample, d, features, labels, neighbors, temperature, weight, per_point, point_mask, stats, loss, grad_unit, stream);
+}
+
+CBL_EXPORT int cbl_contrast_grad_scale(long long total, const float* grad_unit, const float* stats, const float* grad_loss, float weight,
+                                       float* grad_features, void* stream)
+{
+    if (total < 0) return CBL_ERR_BAD_ARG;
+    if (total == 0) return CBL_OK;
+    if (!grad_unit || !stats || !grad_loss || !grad_features) return CBL_ERR_BAD_ARG;
+    hipLaunchKernelGGL(contrast_grad_scale_kernel, dim3(cbl_grid_for(total, 256, 2048)), dim3(256), 0, cbl_stream(stream), total, grad_unit, stats, grad_loss, weight, grad_features);
+    return cbl_status();
 }
 
 CBL_EXPORT int cbl_boundary_mask(int n, int k, const long long* labels, const int* neighbor_idx, unsigned char* bound, unsigned char* plain, int* cnt, void* stream)

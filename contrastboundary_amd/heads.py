@@ -32,6 +32,9 @@ def parse_stage(stage, num_layers):
 
 
 class _PointContrast(Function):
+    """Training (features need a gradient): ONE pass computes the loss terms and the gradient up to its global factor
+    (cbl_point_contrast_forward_grad), the backward pass only scales it.  Inference: forward kernel alone."""
+
     @staticmethod
     def forward(ctx, features, amax, neighbor_idx, temperature, weight):
         m, d = features.shape
@@ -41,25 +44,28 @@ class _PointContrast(Function):
         mask = torch.empty(m, dtype=torch.int32, device=dev)
         stats = torch.empty(2, dtype=torch.float32, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
-        _lib.check(_lib.lib().cbl_point_contrast_forward(_c_int(m), _c_int(nsample), _c_int(d), _lib.ptr(features), _lib.ptr(amax),
-                                                         _lib.ptr(neighbor_idx), _c_float(temperature), _c_float(weight), _lib.ptr(per_point),
-                                                         _lib.ptr(mask), _lib.ptr(stats), _lib.ptr(loss), _lib.stream_of(features)),
-                   "cbl_point_contrast_forward")
-        ctx.save_for_backward(features, amax, neighbor_idx, stats)
-        ctx.cfg = (temperature, weight)
+        L = _lib.lib()
+        if ctx.needs_input_grad[0]:
+            unit = torch.zeros_like(features)
+            _lib.check(L.cbl_point_contrast_forward_grad(_c_int(m), _c_int(nsample), _c_int(d), _lib.ptr(features), _lib.ptr(amax), _lib.ptr(neighbor_idx),
+                                                         _c_float(temperature), _c_float(weight), _lib.ptr(per_point), _lib.ptr(mask), _lib.ptr(stats),
+                                                         _lib.ptr(loss), _lib.ptr(unit), _lib.stream_of(features)), "cbl_point_contrast_forward_grad")
+            ctx.save_for_backward(unit, stats)
+        else:
+            _lib.check(L.cbl_point_contrast_forward(_c_int(m), _c_int(nsample), _c_int(d), _lib.ptr(features), _lib.ptr(amax), _lib.ptr(neighbor_idx),
+                                                    _c_float(temperature), _c_float(weight), _lib.ptr(per_point), _lib.ptr(mask), _lib.ptr(stats),
+                                                    _lib.ptr(loss), _lib.stream_of(features)), "cbl_point_contrast_forward")
+        ctx.weight = weight
         ctx.mark_non_differentiable(mask)
         return loss.view(()), mask
 
     @staticmethod
     def backward(ctx, grad_loss, _grad_mask):
-        features, amax, neighbor_idx, stats = ctx.saved_tensors
-        temperature, weight = ctx.cfg
-        m, d = features.shape
-        g = torch.zeros_like(features)
+        unit, stats = ctx.saved_tensors
+        g = torch.empty_like(unit)
         gl = grad_loss.reshape(1).to(torch.float32).contiguous()
-        _lib.check(_lib.lib().cbl_point_contrast_backward(_c_int(m), _c_int(neighbor_idx.shape[1]), _c_int(d), _lib.ptr(features), _lib.ptr(amax),
-                                                          _lib.ptr(neighbor_idx), _c_float(temperature), _c_float(weight), _lib.ptr(stats),
-                                                          _lib.ptr(gl), _lib.ptr(g), _lib.stream_of(features)), "cbl_point_contrast_backward")
+        _lib.check(_lib.lib().cbl_contrast_grad_scale(ctypes.c_longlong(unit.numel()), _lib.ptr(unit), _lib.ptr(stats), _lib.ptr(gl), _c_float(ctx.weight),
+                                                      _lib.ptr(g), _lib.stream_of(unit)), "cbl_contrast_grad_scale")
         return g, None, None, None, None
 
 
@@ -126,24 +132,26 @@ class _TFContrast(Function):
         mask = torch.empty(m, dtype=torch.int32, device=dev)
         stats = torch.empty(2, dtype=torch.float32, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
-        _lib.check(_lib.lib().cbl_tf_contrast_forward(_c_int(m), _c_int(n_valid), _c_int(neighbors.shape[1]), _c_int(d), _lib.ptr(features), _lib.ptr(labels),
-                                                      _lib.ptr(neighbors), _c_float(temperature), _c_float(weight), _lib.ptr(per_point), _lib.ptr(mask),
-                                                      _lib.ptr(stats), _lib.ptr(loss), _lib.stream_of(features)), "cbl_tf_contrast_forward")
-        ctx.save_for_backward(features, labels, neighbors, stats)
-        ctx.cfg = (temperature, weight)
+        L = _lib.lib()
+        args = (_c_int(m), _c_int(n_valid), _c_int(neighbors.shape[1]), _c_int(d), _lib.ptr(features), _lib.ptr(labels), _lib.ptr(neighbors),
+                _c_float(temperature), _c_float(weight), _lib.ptr(per_point), _lib.ptr(mask), _lib.ptr(stats), _lib.ptr(loss))
+        if ctx.needs_input_grad[0]:
+            unit = torch.zeros_like(features)
+            _lib.check(L.cbl_tf_contrast_forward_grad(*args, _lib.ptr(unit), _lib.stream_of(features)), "cbl_tf_contrast_forward_grad")
+            ctx.save_for_backward(unit, stats)
+        else:
+            _lib.check(L.cbl_tf_contrast_forward(*args, _lib.stream_of(features)), "cbl_tf_contrast_forward")
+        ctx.weight = weight
         ctx.mark_non_differentiable(mask)
         return loss.view(()), mask
 
     @staticmethod
     def backward(ctx, grad_loss, _gm):
-        features, labels, neighbors, stats = ctx.saved_tensors
-        temperature, weight = ctx.cfg
-        m, d = features.shape
-        g = torch.zeros_like(features)
+        unit, stats = ctx.saved_tensors
+        g = torch.empty_like(unit)
         gl = grad_loss.reshape(1).to(torch.float32).contiguous()
-        _lib.check(_lib.lib().cbl_tf_contrast_backward(_c_int(m), _c_int(labels.shape[0]), _c_int(neighbors.shape[1]), _c_int(d), _lib.ptr(features),
-                                                       _lib.ptr(labels), _lib.ptr(neighbors), _c_float(temperature), _c_float(weight), _lib.ptr(stats),
-                                                       _lib.ptr(gl), _lib.ptr(g), _lib.stream_of(features)), "cbl_tf_contrast_backward")
+        _lib.check(_lib.lib().cbl_contrast_grad_scale(ctypes.c_longlong(unit.numel()), _lib.ptr(unit), _lib.ptr(stats), _lib.ptr(gl), _c_float(ctx.weight),
+                                                      _lib.ptr(g), _lib.stream_of(unit)), "cbl_contrast_grad_scale")
         return g, None, None, None, None
 
 

@@ -75,13 +75,16 @@ def stages(scene, k=16):
     def cbl_fwd(s):
         s["cbl_latent"] = scene.latent.detach().requires_grad_(True)
         s["cbl_loss"] = heads.point_contrast(s["cbl_latent"], scene.labels, s["cbl_idx"], 1.0, 0.1)
-    # a8 mining (idx given): 4n(K-1) idx + 4nd features + 4n labels in, 8n out
-    st.append(("cbl_mining_loss_fwd", cbl_fwd, 4 * n * (CBL_NSAMPLE - 1) + 4 * n * d + 4 * n + 8 * n, 1.0 * n * (CBL_NSAMPLE - 1) * (3 * d + 20)))
+    # a8 mining (idx given): 4n(K-1) idx + 4nd features + 4n labels in, 8n out.  The latent needs a gradient, so this stage runs the
+    # fused forward + gradient kernel (one gather for both): + 4nd for the unscaled gradient it leaves behind
+    st.append(("cbl_mining_loss_fwd", cbl_fwd, 4 * n * (CBL_NSAMPLE - 1) + 4 * n * d + 4 * n + 8 * n + 4 * n * d,
+               1.0 * n * (CBL_NSAMPLE - 1) * (8 * d + 50)))
 
     def cbl_bwd(s):
         s["cbl_loss"].backward()
         s["cbl_grad"] = s["cbl_latent"].grad
-    st.append(("cbl_mining_loss_bwd", cbl_bwd, 4 * n * (CBL_NSAMPLE - 1) + 4 * n * d + 4 * n + 4 * n * d, 1.0 * n * (CBL_NSAMPLE - 1) * (5 * d + 30)))
+    # backward = apply grad_loss * weight / #qualifying points to the stored gradient: read 4nd, write 4nd
+    st.append(("cbl_mining_loss_bwd", cbl_bwd, 8 * n * d, 1.0 * n * d))
     return st
 
 

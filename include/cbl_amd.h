@@ -153,6 +153,19 @@ int cbl_point_contrast_forward(int m, int nsample, int d, const float* features,
 int cbl_point_contrast_backward(int m, int nsample, int d, const float* features, const int* amax, const int* neighbor_idx,
                                 float temperature, float weight, const float* stats, const float* grad_loss, float* grad_features, void* stream);
 
+/* Training path of F5 / a16: forward AND the gradient w.r.t. features in one pass over the neighbour rows.  grad_unit (m or n_valid
+ * rows x d, caller pre-zeroes) receives the gradient without its global factor grad_loss * weight / #qualifying points, which only
+ * exists after the launch (stats[1]); cbl_contrast_grad_scale applies it when the backward pass arrives:
+ *   grad_features[e] = grad_unit[e] * grad_loss[0] * weight / stats[1]   (all zeros when stats[1] == 0). */
+int cbl_point_contrast_forward_grad(int m, int nsample, int d, const float* features, const int* amax, const int* neighbor_idx,
+                                    float temperature, float weight, float* per_point, int* point_mask, float* stats, float* loss,
+                                    float* grad_unit, void* stream);
+int cbl_tf_contrast_forward_grad(int m, int n_valid, int nsample, int d, const float* features, const int* labels, const int* neighbors,
+                                 float temperature, float weight, float* per_point, int* point_mask, float* stats, float* loss,
+                                 float* grad_unit, void* stream);
+int cbl_contrast_grad_scale(long long total, const float* grad_unit, const float* stats, const float* grad_loss, float weight,
+                            float* grad_features, void* stream);
+
 /* a16  TF contrast_head  tensorflow/models/heads/head.py:462-807 with sample 'label', contrast 'softnn', dist 'l2' on RADIUS
  *      neighbourhoods (ids >= n_valid are the search's shadow padding; negative hard labels = ignored points):
  *   features (m,d), labels (n_valid >= m rows, i32 hard label per point, from point_labels or cbl_tf_scene_label + cbl_label_argmax),

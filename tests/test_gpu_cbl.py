@@ -179,3 +179,37 @@ def test_boundary_iou_evaluation():
     np.testing.assert_array_equal(t_total, np.bincount(lab, minlength=13))
     ref = C.boundary_iou(pred[:0], lab[:0], np.zeros((0, 16), np.int64), 13)
     assert all(int(v.sum()) == 0 for v in ref["bound"])
+
+
+@pytest.mark.parametrize("tf_variant", [False, True])
+def test_fused_forward_gradient_equals_the_two_pass_entries(tf_variant):
+    """cbl_*_contrast_forward_grad + cbl_contrast_grad_scale (training path of the mirrors) against cbl_*_contrast_forward / _backward"""
+    import ctypes
+    from contrastboundary_amd import _lib, pointops
+    L = _lib.lib()
+    rng = np.random.default_rng(4)
+    n, d, K = 3000, 32, 25
+    xyz = dev(rng.uniform(0, 1, (n, 3)).astype(np.float32)); o = dev(np.int32([n]))
+    feat = dev(rng.normal(size=(n, d)).astype(np.float32))
+    lab = dev(rng.integers(0, 5, n).astype(np.int32))
+    nidx, _ = pointops.knnquery_raw(K, xyz, xyz, o, o, algo="set")
+    st = _lib.stream_of(feat)
+    ci, cf = ctypes.c_int, ctypes.c_float
+    mk = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device="cuda")
+    pp1, m1, s1, l1 = mk(n), mk(n, dt=torch.int32), mk(2), mk(1)
+    pp2, m2, s2, l2 = mk(n), mk(n, dt=torch.int32), mk(2), mk(1)
+    unit = torch.zeros(n, d, device="cuda"); g1 = torch.zeros(n, d, device="cuda"); g2 = mk(n, d)
+    gl = dev(np.float32([0.7]))
+    if tf_variant:
+        pre = (ci(n), ci(n), ci(K), ci(d), _lib.ptr(feat), _lib.ptr(lab), _lib.ptr(nidx), cf(0.5), cf(0.1))
+        _lib.check(L.cbl_tf_contrast_forward(*pre, _lib.ptr(pp1), _lib.ptr(m1), _lib.ptr(s1), _lib.ptr(l1), st), "fwd")
+        _lib.check(L.cbl_tf_contrast_backward(*pre, _lib.ptr(s1), _lib.ptr(gl), _lib.ptr(g1), st), "bwd")
+        _lib.check(L.cbl_tf_contrast_forward_grad(*pre, _lib.ptr(pp2), _lib.ptr(m2), _lib.ptr(s2), _lib.ptr(l2), _lib.ptr(unit), st), "fwd_grad")
+    else:
+        pre = (ci(n), ci(K), ci(d), _lib.ptr(feat), _lib.ptr(lab), _lib.ptr(nidx), cf(0.5), cf(0.1))
+        _lib.check(L.cbl_point_contrast_forward(*pre, _lib.ptr(pp1), _lib.ptr(m1), _lib.ptr(s1), _lib.ptr(l1), st), "fwd")
+        _lib.check(L.cbl_point_contrast_backward(*pre, _lib.ptr(s1), _lib.ptr(gl), _lib.ptr(g1), st), "bwd")
+        _lib.check(L.cbl_point_contrast_forward_grad(*pre, _lib.ptr(pp2), _lib.ptr(m2), _lib.ptr(s2), _lib.ptr(l2), _lib.ptr(unit), st), "fwd_grad")
+    _lib.check(L.cbl_contrast_grad_scale(ctypes.c_longlong(n * d), _lib.ptr(unit), _lib.ptr(s2), _lib.ptr(gl), cf(0.1), _lib.ptr(g2), st), "scale")
+    assert torch.equal(pp1, pp2) and torch.equal(m1, m2) and torch.equal(l1, l2) and float(s1[1]) > 100
+    np.testing.assert_allclose(g2.cpu().numpy(), g1.cpu().numpy(), rtol=1e-4, atol=1e-6 * float(g1.abs().max()))
