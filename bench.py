@@ -118,8 +118,8 @@ def main():
     pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(pmc_file) and (n, c, k) == (40960, 64, 16):
         pmc = json.load(open(pmc_file))
-    pmc_kernel = {"knnquery_k16": "knn_grid_group_kernel<16, true>", "queryandgroup": "query_group_v4", "kpconv_fwd": "kpconv_fwd_kernel<true>",
-                  "cbl_knnquery_k36": "knn_grid_wave_kernel<true>", "cbl_mining_loss_fwd": "contrast_bwd_kernel<64, 8>",
+    pmc_kernel = {"knnquery_k16": "knn_grid_group_kernel<16, true, false>", "queryandgroup": "query_group_v4", "kpconv_fwd": "kpconv_fwd_kernel<true>",
+                  "cbl_knnquery_k36": "knn_grid_wave_kernel<true, false>", "cbl_mining_loss_fwd": "contrast_bwd_kernel<64, 8>",
                   "cbl_mining_loss_bwd": "contrast_grad_scale_kernel"}
     traffic = lambda stage: pmc.get(pmc_kernel.get(stage, ""), {}).get("hbm_bytes_per_launch")
     roofline["traffic"] = traffic(names[dom])

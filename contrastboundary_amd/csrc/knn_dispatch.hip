@@ -45,3 +45,10 @@ CBL_EXPORT int cbl_knnquery_set(int b, int n, int m, int nsample, const float* x
 {
     return knnquery_impl(b, n, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, workspace, workspace_bytes, 1, stream);
 }
+
+CBL_EXPORT int cbl_knnquery_anytie(int b, int n, int m, int nsample, const float* xyz, const float* new_xyz,
+                                   const int* offset, const int* new_offset, int* idx, float* dist2,
+                                   void* workspace, size_t workspace_bytes, void* stream)
+{
+    return knnquery_impl(b, n, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, workspace, workspace_bytes, 2, stream);
+}

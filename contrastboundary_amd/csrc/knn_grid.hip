@@ -233,7 +233,9 @@ template <> __device__ __forceinline__ float dpp_shr1_f<16>(float v) { return __
 template <> __device__ __forceinline__ float dpp_shr1_f<64>(float v) { return __int_as_float(dpp_shr1_i<64>(__float_as_int(v))); }
 template <> __device__ __forceinline__ float dpp_shr1_f<32>(float v) { return __int_as_float(dpp_shr1_i<32>(__float_as_int(v))); }
 
-template <int G, bool SELF>
+// LEX: order the list by (d2, index) instead of d2 alone — needed only by the "any tie" policy (set_exact == 2), whose result must not
+// depend on the order in which the cells were filled; the other policies replay every tie that matters and skip the extra compares.
+template <int G, bool SELF, bool LEX>
 __global__ __launch_bounds__(256) void knn_grid_group_kernel(int b, int m, int K, const float* __restrict__ new_xyz,
                                                              const int* __restrict__ offset, const int* __restrict__ new_offset,
                                                              const CblGrid* __restrict__ grids, const int* __restrict__ cell_start,
@@ -294,19 +296,19 @@ __global__ __launch_bounds__(256) void knn_grid_group_kernel(int b, int m, int K
                             d2 = cbl_dist2(qx, qy, qz, v.x, v.y, v.z);       // (new - x)^2 ..., knnquery_cuda_kernel.cu:99
                             ci = __float_as_int(v.w);
                         }
-                        const float worst = __shfl(ed, K - 1, G);
-                        const bool pass = d2 < worst;
+                        const float worst = __shfl(ed, K - 1, G); const unsigned worst_i = LEX ? (unsigned)__shfl(ei, K - 1, G) : 0u;
+                        const bool pass = d2 < worst || (LEX && d2 == worst && (unsigned)ci < worst_i);
                         rejmin = fminf(rejmin, pass ? INFINITY : d2);
                         mask_t gm = (__ballot(pass) >> (grp * G)) & (G == 64 ? ~0ull : ((1ull << G) - 1ull));
                         while (__any(gm != 0)) {                              // each group inserts its next passing candidate
                             const bool has = gm != 0;
                             const int l = has ? __builtin_ctzll(gm) : 0;
                             gm &= gm - 1;
-                            float dc = __shfl(d2, l, G); const int ic = __shfl(ci, l, G);
-                            if (!has) dc = INFINITY;
+                            float dc = __shfl(d2, l, G); int ic = __shfl(ci, l, G);
+                            if (!has) { dc = INFINITY; ic = -1; }
                             const float pd = dpp_shr1_f<G>(ed); const int pidx = dpp_shr1_i<G>(ei);   // left neighbour's element
-                            const bool gt = ed > dc;                          // strictly larger elements move right
-                            const bool left_gt = (gl > 0) && (pd > dc);
+                            const bool gt = ed > dc || (LEX && ed == dc && (unsigned)ei > (unsigned)ic);      // larger elements move right
+                            const bool left_gt = (gl > 0) && (pd > dc || (LEX && pd == dc && (unsigned)pidx > (unsigned)ic));
                             if (gl == K - 1) rejmin = fminf(rejmin, gt ? ed : dc);   // evicted element, or a candidate that lost its race
                             if (gt) { if (left_gt) { ed = pd; ei = pidx; } else { ed = dc; ei = ic; } }
                         }
@@ -331,7 +333,8 @@ __global__ __launch_bounds__(256) void knn_grid_group_kernel(int b, int m, int K
     const mask_t dm = (__ballot(dup) >> (grp * G)) & (G == 64 ? ~0ull : ((1ull << G) - 1ull));
     // set_exact: the caller only needs the reference's neighbour SET (sorted by distance); equal distances INSIDE the list
     // leave the set unambiguous, so only a tie at the K-th boundary (or an unfilled list) still needs the replay
-    const bool ok = (worst < INFINITY) && (rm != worst) && (set_exact || dm == 0);
+    // set_exact == 2 ("any tie order"): a full list is final — among candidates tied at the K-th distance the visiting order decides
+    const bool ok = (worst < INFINITY) && (set_exact == 2 || ((rm != worst) && (set_exact || dm == 0)));
     if (live) {
         if (gl < K) { idx[(size_t)q * K + gl] = ei; dist2[(size_t)q * K + gl] = ed; }
         if (!ok && gl == 0) worklist[atomicAdd(counters, 1)] = q;
@@ -358,31 +361,31 @@ struct PermSwzXor16  { __device__ __forceinline__ int operator()(int v, int) con
 struct PermSwzMir32  { __device__ __forceinline__ int operator()(int v, int) const { return __builtin_amdgcn_ds_swizzle(v, 0x7c1f); } };   // lane ^ 31
 struct PermMir64     { __device__ __forceinline__ int operator()(int v, int lane) const { return __builtin_amdgcn_ds_bpermute((63 - lane) << 2, v); } };
 
-// compare-exchange with the partner lane: the lower lane of a pair keeps the smaller distance (ties: both keep their own)
-template <class Perm> __device__ __forceinline__ void sort_cx(float& d, int& i, bool lower, int lane, Perm perm)
+// compare-exchange with the partner lane: the lower lane of a pair keeps the smaller (distance, index)
+template <bool LEX, class Perm> __device__ __forceinline__ void sort_cx(float& d, int& i, bool lower, int lane, Perm perm)
 {
     const float pd = __int_as_float(perm(__float_as_int(d), lane));
     const int pi = perm(i, lane);
-    const bool take = lower ? (pd < d) : (pd > d);
+    const bool take = lower ? (pd < d || (LEX && pd == d && (unsigned)pi < (unsigned)i)) : (pd > d || (LEX && pd == d && (unsigned)pi > (unsigned)i));
     d = take ? pd : d; i = take ? pi : i;
 }
 // ascending bitonic sort of one (d, i) per lane over the 64 lanes ("flip" form: every merge starts with a mirror exchange)
-__device__ __forceinline__ void wave_sort64(float& d, int& i, int lane)
+template <bool LEX> __device__ __forceinline__ void wave_sort64(float& d, int& i, int lane)
 {
     const bool l1 = !(lane & 1), l2 = !(lane & 2), l4 = !(lane & 4), l8 = !(lane & 8), l16 = !(lane & 16), l32 = !(lane & 32);
-    sort_cx(d, i, l1, lane, PermQuadXor1());
-    sort_cx(d, i, l2, lane, PermQuadMir());   sort_cx(d, i, l1, lane, PermQuadXor1());
-    sort_cx(d, i, l4, lane, PermHalfMir());   sort_cx(d, i, l2, lane, PermQuadXor2()); sort_cx(d, i, l1, lane, PermQuadXor1());
-    sort_cx(d, i, l8, lane, PermRowMir());    sort_cx(d, i, l4, lane, PermSwzXor4());  sort_cx(d, i, l2, lane, PermQuadXor2());
-    sort_cx(d, i, l1, lane, PermQuadXor1());
-    sort_cx(d, i, l16, lane, PermSwzMir32()); sort_cx(d, i, l8, lane, PermRowRor8());  sort_cx(d, i, l4, lane, PermSwzXor4());
-    sort_cx(d, i, l2, lane, PermQuadXor2());  sort_cx(d, i, l1, lane, PermQuadXor1());
-    sort_cx(d, i, l32, lane, PermMir64());    sort_cx(d, i, l16, lane, PermSwzXor16()); sort_cx(d, i, l8, lane, PermRowRor8());
-    sort_cx(d, i, l4, lane, PermSwzXor4());   sort_cx(d, i, l2, lane, PermQuadXor2()); sort_cx(d, i, l1, lane, PermQuadXor1());
+    sort_cx<LEX>(d, i, l1, lane, PermQuadXor1());
+    sort_cx<LEX>(d, i, l2, lane, PermQuadMir());   sort_cx<LEX>(d, i, l1, lane, PermQuadXor1());
+    sort_cx<LEX>(d, i, l4, lane, PermHalfMir());   sort_cx<LEX>(d, i, l2, lane, PermQuadXor2()); sort_cx<LEX>(d, i, l1, lane, PermQuadXor1());
+    sort_cx<LEX>(d, i, l8, lane, PermRowMir());    sort_cx<LEX>(d, i, l4, lane, PermSwzXor4());  sort_cx<LEX>(d, i, l2, lane, PermQuadXor2());
+    sort_cx<LEX>(d, i, l1, lane, PermQuadXor1());
+    sort_cx<LEX>(d, i, l16, lane, PermSwzMir32()); sort_cx<LEX>(d, i, l8, lane, PermRowRor8());  sort_cx<LEX>(d, i, l4, lane, PermSwzXor4());
+    sort_cx<LEX>(d, i, l2, lane, PermQuadXor2());  sort_cx<LEX>(d, i, l1, lane, PermQuadXor1());
+    sort_cx<LEX>(d, i, l32, lane, PermMir64());    sort_cx<LEX>(d, i, l16, lane, PermSwzXor16()); sort_cx<LEX>(d, i, l8, lane, PermRowRor8());
+    sort_cx<LEX>(d, i, l4, lane, PermSwzXor4());   sort_cx<LEX>(d, i, l2, lane, PermQuadXor2()); sort_cx<LEX>(d, i, l1, lane, PermQuadXor1());
 }
 __device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
-template <bool SELF>
+template <bool SELF, bool LEX>
 __global__ __launch_bounds__(256) void knn_grid_wave_kernel(int b, int m, int K, const float* __restrict__ new_xyz,
                                                             const int* __restrict__ offset, const int* __restrict__ new_offset,
                                                             const CblGrid* __restrict__ grids, const int* __restrict__ cell_start,
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(256) void knn_grid_wave_kernel(int b, int m, int K,
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             float sd = INFINITY; int si = -1;
             if (lane < base) { const float2 v = slots[wv][lane]; sd = v.x; si = __float_as_int(v.y); }
-            wave_sort64(sd, si, lane);
+            wave_sort64<LEX>(sd, si, lane);
             if (lane < K) { ed = sd; ei = si; } else rejmin = fminf(rejmin, sd);
         }
     }
@@ -517,8 +520,8 @@ __global__ __launch_bounds__(256) void knn_grid_wave_kernel(int b, int m, int K,
                         d2 = cbl_dist2(qx, qy, qz, v.x, v.y, v.z);
                         ci = __float_as_int(v.w);
                     }
-                    const float worst = rl_f(ed, K - 1);
-                    const bool pass = d2 < worst;
+                    const float worst = rl_f(ed, K - 1); const unsigned worst_i = LEX ? (unsigned)__builtin_amdgcn_readlane(ei, K - 1) : 0u;
+                    const bool pass = d2 < worst || (LEX && d2 == worst && (unsigned)ci < worst_i);
                     rejmin = fminf(rejmin, pass ? INFINITY : d2);
                     unsigned long long gm = __ballot(pass);
                     while (gm) {
@@ -526,8 +529,8 @@ __global__ __launch_bounds__(256) void knn_grid_wave_kernel(int b, int m, int K,
                         gm &= gm - 1;
                         const float dc = rl_f(d2, l); const int ic = __builtin_amdgcn_readlane(ci, l);
                         const float pd = dpp_shr1_f<64>(ed); const int pidx = dpp_shr1_i<64>(ei);
-                        const bool gt = ed > dc;
-                        const bool left_gt = (lane > 0) && (pd > dc);
+                        const bool gt = ed > dc || (LEX && ed == dc && (unsigned)ei > (unsigned)ic);
+                        const bool left_gt = (lane > 0) && (pd > dc || (LEX && pd == dc && (unsigned)pidx > (unsigned)ic));
                         if (lane == K - 1) rejmin = fminf(rejmin, gt ? ed : dc);
                         if (gt) { if (left_gt) { ed = pd; ei = pidx; } else { ed = dc; ei = ic; } }
                     }
@@ -545,7 +548,7 @@ __global__ __launch_bounds__(256) void knn_grid_wave_kernel(int b, int m, int K,
     for (int s = 32; s >= 1; s >>= 1) rm = fminf(rm, __shfl_xor(rm, s, 64));
     const float pd = dpp_shr1_f<64>(ed);
     const bool dup = (lane > 0) && (lane < K) && (ed == pd);
-    const bool ok = (worst < INFINITY) && (rm != worst) && (set_exact || __ballot(dup) == 0);
+    const bool ok = (worst < INFINITY) && (set_exact == 2 || ((rm != worst) && (set_exact || __ballot(dup) == 0)));
     if (lane < K) { idx[(size_t)q * K + lane] = ei; dist2[(size_t)q * K + lane] = ed; }
     if (!ok && lane == 0) worklist[atomicAdd(counters, 1)] = q;
 }
@@ -556,8 +559,11 @@ void launch_query(bool self, int b, int m, int K, const float* new_xyz, const in
 {
     const long long waves = ((long long)m + (64 / G) - 1) / (64 / G);
     const dim3 grid(cbl_div_up(waves, 4)), block(256);
-    if (self) hipLaunchKernelGGL((knn_grid_group_kernel<G, true>), grid, block, 0, st, b, m, K, new_xyz, offset, new_offset, w.grids, w.cell_start, w.sorted, idx, dist2, w.worklist, w.counters, set_exact);
-    else      hipLaunchKernelGGL((knn_grid_group_kernel<G, false>), grid, block, 0, st, b, m, K, new_xyz, offset, new_offset, w.grids, w.cell_start, w.sorted, idx, dist2, w.worklist, w.counters, set_exact);
+#define CBL_LAUNCH_GROUP(SELF_, LEX_) hipLaunchKernelGGL((knn_grid_group_kernel<G, SELF_, LEX_>), grid, block, 0, st, b, m, K, new_xyz, offset, new_offset, w.grids, \
+                                                         w.cell_start, w.sorted, idx, dist2, w.worklist, w.counters, set_exact)
+    if (set_exact == 2) { if (self) CBL_LAUNCH_GROUP(true, true); else CBL_LAUNCH_GROUP(false, true); }
+    else                { if (self) CBL_LAUNCH_GROUP(true, false); else CBL_LAUNCH_GROUP(false, false); }
+#undef CBL_LAUNCH_GROUP
 }
 
 
@@ -686,8 +692,11 @@ int cbl_knn_grid_launch(int b, int n, int m, int nsample, const float* xyz, cons
     const bool self = (new_xyz == xyz) && (m == n);
     if (nsample > 16) {                                              // select-then-sort, one wave per query
         const dim3 grid(cbl_div_up(m, 4)), block(256);
-        if (self) hipLaunchKernelGGL(knn_grid_wave_kernel<true>, grid, block, 0, st, b, m, nsample, new_xyz, offset, new_offset, w.grids, w.cell_start, w.sorted, idx, dist2, w.worklist, w.counters, set_exact);
-        else      hipLaunchKernelGGL(knn_grid_wave_kernel<false>, grid, block, 0, st, b, m, nsample, new_xyz, offset, new_offset, w.grids, w.cell_start, w.sorted, idx, dist2, w.worklist, w.counters, set_exact);
+#define CBL_LAUNCH_WAVE(SELF_, LEX_) hipLaunchKernelGGL((knn_grid_wave_kernel<SELF_, LEX_>), grid, block, 0, st, b, m, nsample, new_xyz, offset, new_offset, w.grids, \
+                                                       w.cell_start, w.sorted, idx, dist2, w.worklist, w.counters, set_exact)
+        if (set_exact == 2) { if (self) CBL_LAUNCH_WAVE(true, true); else CBL_LAUNCH_WAVE(false, true); }
+        else                { if (self) CBL_LAUNCH_WAVE(true, false); else CBL_LAUNCH_WAVE(false, false); }
+#undef CBL_LAUNCH_WAVE
     }
     else launch_query<16>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, set_exact, st);   // 4 queries per wave
     rc = cbl_status();

@@ -128,7 +128,27 @@ __global__ __launch_bounds__(SB) void knn_select_kernel(int b, int m, int K, con
             int cle = 0;
 #pragma unroll
             for (int j = 0; j < C_PER; j++) cle += __popcll(__ballot(w[j] <= kth));
-            ok = bc.sum(cle, lane, wave) == K;                       // else the K-th distance is shared with a (K+1)-th support
+            const int n_le = bc.sum(cle, lane, wave);
+            ok = (n_le == K) || set_exact == 2;                      // else the K-th distance is shared with a (K+1)-th support
+            if (ok && n_le != K) {                                   // "any tie" policy: of the supports AT the K-th distance the smallest indices stay
+                int clt = 0;
+#pragma unroll
+                for (int j = 0; j < C_PER; j++) clt += __popcll(__ballot(w[j] < kth));
+                const int need_eq = K - bc.sum(clt, lane, wave);
+                unsigned ti[C_PER];                                  // index of a tied entry, 0xffffffff otherwise
+#pragma unroll
+                for (int j = 0; j < C_PER; j++) { const int e = tid + SB * j; ti[j] = (w[j] == kth) ? (unsigned)ci[e] : 0xffffffffu; }
+                unsigned lo_i = 0u, hi_i = 0x7fffffffu;              // smallest index bound holding need_eq tied entries
+                while (lo_i < hi_i) {
+                    const unsigned mid = lo_i + ((hi_i - lo_i) >> 1);
+                    int cc = 0;
+#pragma unroll
+                    for (int j = 0; j < C_PER; j++) cc += __popcll(__ballot(ti[j] <= mid));
+                    if (bc.sum(cc, lane, wave) >= need_eq) hi_i = mid; else lo_i = mid + 1;
+                }
+#pragma unroll
+                for (int j = 0; j < C_PER; j++) if (w[j] == kth && ti[j] > lo_i) w[j] = 0xffffffffu;     // surplus ties drop out
+            }
         }
 
         // ---- 4. the K winners, sorted by (d2, index)
@@ -163,7 +183,7 @@ __global__ __launch_bounds__(SB) void knn_select_kernel(int b, int m, int K, con
                     __syncthreads();
                 }
             }
-            if (!set_exact) {                                        // equal distances inside the list: the reference's order is its heap's
+            if (set_exact == 0) {                                    // equal distances inside the list: the reference's order is its heap's
                 for (int e = tid; e + 1 < K; e += SB) if (sd[e] == sd[e + 1]) dupflag = 1;
                 __syncthreads();
                 ok = dupflag == 0;

@@ -78,6 +78,21 @@ class FurthestSampling(Function):
 furthestsampling = FurthestSampling.apply
 
 # ------------------------------------------------------------------------------------------------ K1
+_tie_policy = "reference"
+
+
+def set_knn_tie_policy(policy):
+    """'reference' (default): neighbour order and choice under exactly equal distances as the reference's heap produces them, bit for bit
+    (tied queries are replayed through that heap: costly on quantised coordinates).  'set': exact set, free order among equal
+    distances.  'anytie': exact distances, free choice among supports tied at the K-th distance; cost independent of ties.  The
+    reference's networks are invariant to both freedoms (softmax / max / mean over the K set).  Returns the previous policy."""
+    global _tie_policy
+    if policy not in ("reference", "set", "anytie"):
+        raise ValueError(policy)
+    prev, _tie_policy = _tie_policy, policy
+    return prev
+
+
 class neighbor_cache:
     """Per-forward neighbour-index cache.  The reference's network asks for the SAME neighbour search
     many times per forward — every PointTransformerLayer of a stage runs knnquery(nsample, p, p, o, o) twice (blocks.py:34-35), the
@@ -123,11 +138,15 @@ class neighbor_cache:
 
 
 def knnquery_raw(nsample, xyz, new_xyz, offset, new_offset, algo="auto"):
-    """-> idx (m,nsample) i32, dist2 (m,nsample) f32 (squared).  algo: 'auto' | 'exact' | 'grid' | 'set'
-    ('set': same neighbour set and distances, order among exactly equal distances unspecified — cbl_knnquery_set)"""
+    """-> idx (m,nsample) i32, dist2 (m,nsample) f32 (squared).  algo: 'auto' | 'exact' | 'grid' | 'set' | 'anytie'
+    ('set': same neighbour set and distances, order among exactly equal distances unspecified — cbl_knnquery_set;
+     'anytie': same distances, any of the supports tied at the K-th distance — cbl_knnquery_anytie, never replays).
+    `set_knn_tie_policy` redirects 'auto' requests of the mirrors (blocks, interpolation, heads) to one of the cheaper policies."""
     nsample = _as_int(nsample)
     if new_xyz is None:
         new_xyz = xyz
+    if algo == "auto" and _tie_policy != "reference":
+        algo = _tie_policy
     cache = neighbor_cache._active
     if cache is not None:
         hit = cache.lookup(nsample, algo, (xyz, new_xyz, offset, new_offset))
@@ -159,7 +178,7 @@ def _knnquery_uncached(nsample, xyz, new_xyz, offset, new_offset, algo):
         if algo == "grid" and need == 0:
             raise _lib.CblError("grid KNN not available for this problem shape")
         ws = _workspace(need, xyz.device)
-        fn = L.cbl_knnquery_set if algo == "set" else L.cbl_knnquery
+        fn = L.cbl_knnquery_set if algo == "set" else L.cbl_knnquery_anytie if algo == "anytie" else L.cbl_knnquery
         _lib.check(fn(*args, _lib.ptr(ws), ctypes.c_size_t(ws.numel() if ws is not None else 0), st), "cbl_knnquery")
     return idx, dist2
 

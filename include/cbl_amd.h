@@ -69,6 +69,17 @@ int cbl_knnquery_set(int b, int n, int m, int nsample,
                      const int* offset, const int* new_offset,
                      int* idx, float* dist2,
                      void* workspace, size_t workspace_bytes, void* stream);
+/* Third tie policy, for callers that are invariant to the order AND the choice among equally distant neighbours (every consumer in the
+ * reference's networks is: softmax / max / mean over the K set): exact K smallest distances, ascending, but among supports tied at
+ * the K-th distance those with the smallest indices are kept, and equal distances are listed by index: the K smallest by
+ * (distance, index), a deterministic rule of its own.  Never replays a query through the reference's heap, so its cost
+ * does not depend on ties — on coordinate grids / millimetre-quantised scans (many exactly equal distances) the reference-order
+ * variants can spend milliseconds re-running tied queries one wave at a time.  dist2 is identical to cbl_knnquery's. */
+int cbl_knnquery_anytie(int b, int n, int m, int nsample,
+                        const float* xyz, const float* new_xyz,
+                        const int* offset, const int* new_offset,
+                        int* idx, float* dist2,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* brute-force variant only (always bit-exact, O(m*n)); `algo` for tests/bench: see cbl_knnquery */
 int cbl_knnquery_exact(int b, int n, int m, int nsample,

@@ -364,3 +364,34 @@ def test_knn_large_k_with_ties_falls_back_to_the_reference_order(P, algo):
         np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
     else:   # same neighbour set per query
         np.testing.assert_array_equal(np.sort(idx.cpu().numpy(), 1), np.sort(ridx, 1))
+
+
+@pytest.mark.parametrize("K", [16, 36, 100])
+def test_knn_anytie_policy_never_replays_and_keeps_the_distances(P, K):
+    # lattice + duplicates: every query has ties.  'anytie' must give the reference's distances (bit for bit) and valid neighbours,
+    # and 'reference' must stay bit-exact on the same data
+    g = np.arange(17, dtype=np.float32)
+    lat = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    pts = np.concatenate([lat, lat[:500]])                                # + exact duplicates
+    o = np.int32([len(pts)])
+    idx, d2 = P.knnquery_raw(K, dev(pts), dev(pts), dev(o), dev(o), algo="anytie")
+    ridx, rd2 = O.knnquery(K, pts, pts, o, o)
+    np.testing.assert_array_equal(d2.cpu().numpy().view(np.uint32), rd2.view(np.uint32))
+    ii = idx.cpu().numpy().astype(np.int64)
+    dd = ((pts[ii] - pts[:, None, :]) ** 2)
+    np.testing.assert_array_equal(((dd[..., 0] + dd[..., 1]) + dd[..., 2]).astype(np.float32).view(np.uint32), rd2.view(np.uint32))   # idx really at those distances
+    assert all(len(set(r)) == K for r in ii[::97])                        # no neighbour twice
+    # the rule of its own: the K smallest by (distance, index)
+    allq = np.arange(0, len(pts), 53)
+    dq = ((pts[None, :, :] - pts[allq][:, None, :]) ** 2)
+    dq = ((dq[..., 0] + dq[..., 1]) + dq[..., 2]).astype(np.float32)
+    canon = np.lexsort((np.broadcast_to(np.arange(len(pts)), dq.shape), dq), axis=1)[:, :K]
+    np.testing.assert_array_equal(ii[allq], canon)
+    prev = P.set_knn_tie_policy("anytie")
+    try:
+        idx2, _ = P.knnquery_raw(K, dev(pts), dev(pts), dev(o), dev(o))   # 'auto' follows the policy
+        assert torch.equal(idx2, idx)
+    finally:
+        P.set_knn_tie_policy(prev)
+    idx3, _ = P.knnquery_raw(K, dev(pts), dev(pts), dev(o), dev(o))
+    np.testing.assert_array_equal(idx3.cpu().numpy(), ridx)
