@@ -127,83 +127,72 @@ class Loss(nn.Module):
 
 
 class PointTransformerSeg(nn.Module):
+    """U-shaped network: 5 encoder stages (stage s = TransitionDown with stride[s] followed by blocks[s]-1 attention blocks) and 5 decoder
+    stages (TransitionUp followed by one attention block).  Sub-module names (`enc1`..`enc5`, `dec5`..`dec1`, `head` | `cls`) and their
+    creation order follow pointtransformer_seg.py:27-70 so that parameters — by name and by seeded initialisation — are the reference's."""
+    NUM_STAGES = 5
+    STRIDE = [1, 4, 4, 4, 4]
+    NSAMPLE = [8, 16, 16, 16, 16]                                   # neighbours of the attention / down-sampling blocks (:44)
+
     def __init__(self, block, blocks, c=6, k=13, config=None):
         super().__init__()
-        self.c = c
-        self.in_planes = c
         config = config if config is not None else Config()
-        if "planes" not in config:
-            config.planes = [32, 64, 128, 256, 512]
-        planes = config.planes
-        if "share_planes" not in config:
-            config.share_planes = 8
-        share_planes = config.share_planes
-        stride, nsample = [1, 4, 4, 4, 4], [8, 16, 16, 16, 16]
-        if "stride" not in config:
-            config.stride = stride
-        if "nsample" not in config:
-            config.nsample = nsample
-        self.enc1 = self._make_enc(block, planes[0], blocks[0], share_planes, stride=stride[0], nsample=nsample[0])
-        self.enc2 = self._make_enc(block, planes[1], blocks[1], share_planes, stride=stride[1], nsample=nsample[1])
-        self.enc3 = self._make_enc(block, planes[2], blocks[2], share_planes, stride=stride[2], nsample=nsample[2])
-        self.enc4 = self._make_enc(block, planes[3], blocks[3], share_planes, stride=stride[3], nsample=nsample[3])
-        self.enc5 = self._make_enc(block, planes[4], blocks[4], share_planes, stride=stride[4], nsample=nsample[4])
-        self.dec5 = self._make_dec(block, planes[4], 2, share_planes, nsample=nsample[4], is_head=True)
-        self.dec4 = self._make_dec(block, planes[3], 2, share_planes, nsample=nsample[3])
-        self.dec3 = self._make_dec(block, planes[2], 2, share_planes, nsample=nsample[2])
-        self.dec2 = self._make_dec(block, planes[1], 2, share_planes, nsample=nsample[1])
-        self.dec1 = self._make_dec(block, planes[0], 2, share_planes, nsample=nsample[0])
+        for key, default in (("planes", [32, 64, 128, 256, 512]), ("share_planes", 8), ("stride", self.STRIDE), ("nsample", self.NSAMPLE)):
+            if key not in config:
+                config[key] = default                               # note: a CBL config carries its own (larger) `nsample` for the head only
+        self.c, self.config = c, config
+        planes, share = config.planes, config.share_planes
+        width = c                                                   # running feature width while stacking
+        for s in range(self.NUM_STAGES):                            # encoders, shallow to deep
+            out_w = planes[s] * block.expansion
+            layers = [TransitionDown(width, out_w, self.STRIDE[s], self.NSAMPLE[s])]
+            layers += [block(out_w, out_w, share, nsample=self.NSAMPLE[s]) for _ in range(blocks[s] - 1)]
+            setattr(self, f"enc{s + 1}", nn.Sequential(*layers))
+            width = out_w
+        for s in reversed(range(self.NUM_STAGES)):                  # decoders, deep to shallow; the deepest one has no coarser input
+            out_w = planes[s] * block.expansion
+            up = TransitionUp(width, None if s == self.NUM_STAGES - 1 else out_w)
+            setattr(self, f"dec{s + 1}", nn.Sequential(up, block(out_w, out_w, share, nsample=self.NSAMPLE[s])))
+            width = out_w
+        self.in_planes = width
+        config.num_layers, config.num_classes = self.NUM_STAGES, k
         self.head = self.cls = None
-        self.config = config
-        config.num_layers = 5
-        config.num_classes = k
         if "multi" in config:
             self.head = MultiHead(planes, config.multi, config)
         else:
             self.cls = nn.Sequential(nn.Linear(planes[0], planes[0]), nn.BatchNorm1d(planes[0]), nn.ReLU(inplace=True), nn.Linear(planes[0], k))
 
-    def _make_enc(self, block, planes, blocks, share_planes=8, stride=1, nsample=16):
-        layers = [TransitionDown(self.in_planes, planes * block.expansion, stride, nsample)]
-        self.in_planes = planes * block.expansion
-        for _ in range(1, blocks):
-            layers.append(block(self.in_planes, self.in_planes, share_planes, nsample=nsample))
-        return nn.Sequential(*layers)
-
-    def _make_dec(self, block, planes, blocks, share_planes=8, nsample=16, is_head=False):
-        layers = [TransitionUp(self.in_planes, None if is_head else planes * block.expansion)]
-        self.in_planes = planes * block.expansion
-        for _ in range(1, blocks):
-            layers.append(block(self.in_planes, self.in_planes, share_planes, nsample=nsample))
-        return nn.Sequential(*layers)
-
     def forward(self, inputs):
-        p0, x0, o0 = inputs["points"], inputs["features"], inputs["offset"]
+        p, x, o = inputs["points"], inputs["features"], inputs["offset"]
         if self.c == 3:
-            x0 = p0
+            x = p
         elif self.c == 6:
-            x0 = torch.cat((p0, x0), 1)
+            x = torch.cat((p, x), 1)
         elif self.c == 7:
-            x0 = torch.cat((torch.ones_like(p0[..., :1]), p0, x0), 1)
+            x = torch.cat((torch.ones_like(p[..., :1]), p, x), 1)
         else:
             raise ValueError(f"in_feature_dims c={self.c}")
-        stage_list = {"inputs": inputs}
-        p1, x1, o1 = self.enc1([p0, x0, o0])
-        p2, x2, o2 = self.enc2([p1, x1, o1])
-        p3, x3, o3 = self.enc3([p2, x2, o2])
-        p4, x4, o4 = self.enc4([p3, x3, o3])
-        p5, x5, o5 = self.enc5([p4, x4, o4])
-        stage_list["down"] = [{"p_out": p, "f_out": x, "offset": o} for p, x, o in ((p1, x1, o1), (p2, x2, o2), (p3, x3, o3), (p4, x4, o4), (p5, x5, o5))]
-        x5 = self.dec5[1:]([p5, self.dec5[0]([p5, x5, o5]), o5])[1]
-        x4 = self.dec4[1:]([p4, self.dec4[0]([p4, x4, o4], [p5, x5, o5]), o4])[1]
-        x3 = self.dec3[1:]([p3, self.dec3[0]([p3, x3, o3], [p4, x4, o4]), o3])[1]
-        x2 = self.dec2[1:]([p2, self.dec2[0]([p2, x2, o2], [p3, x3, o3]), o2])[1]
-        x1 = self.dec1[1:]([p1, self.dec1[0]([p1, x1, o1], [p2, x2, o2]), o1])[1]
-        stage_list["up"] = [{"p_out": p, "f_out": x, "offset": o} for p, x, o in ((p1, x1, o1), (p2, x2, o2), (p3, x3, o3), (p4, x4, o4), (p5, x5, o5))]
+        pxo = [p, x, o]
+        enc = []
+        for s in range(self.NUM_STAGES):                            # :97-101
+            pxo = getattr(self, f"enc{s + 1}")(pxo)
+            enc.append(pxo)
+        stage_list = {"inputs": inputs, "down": [{"p_out": q[0], "f_out": q[1], "offset": q[2]} for q in enc]}
+        feats = [None] * self.NUM_STAGES
+        for s in reversed(range(self.NUM_STAGES)):                  # :113-117
+            dec = getattr(self, f"dec{s + 1}")
+            ps, xs, os_ = enc[s]
+            if s == self.NUM_STAGES - 1:
+                fused = dec[0]([ps, xs, os_])                       # per-cloud mean context instead of an upsampled coarser stage
+            else:
+                fused = dec[0]([ps, xs, os_], [enc[s + 1][0], feats[s + 1], enc[s + 1][2]])
+            feats[s] = dec[1:]([ps, fused, os_])[1]
+        stage_list["up"] = [{"p_out": enc[s][0], "f_out": feats[s], "offset": enc[s][2]} for s in range(self.NUM_STAGES)]
         if self.head is not None:
-            x, stage_list = self.head(stage_list)
+            logits, stage_list = self.head(stage_list)
         else:
-            x = self.cls(x1)
-        return x, stage_list
+            logits = self.cls(feats[0])
+        return logits, stage_list
 
 
 def pointtransformer_seg_repro(**kwargs):
