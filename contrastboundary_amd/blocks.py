@@ -9,12 +9,14 @@ changes is how the K-neighbour part runs:
     (n,K,C) copies of x_k / x_v and the 4-d view/sum of blocks.py:43 are never materialised;
   * BatchNorm over (n*K) rows is applied on the flattened view (same statistics as the reference's transpose → BN1d →
     transpose, blocks.py:38,40, without the two transposed copies).
-Dense layers (Linear, BatchNorm, ReLU, softmax over K) stay torch (rocBLAS / elementwise): they are not neighbourhood work.
+  * the four Linear layers that act on (n*K) rows with widths 3 / C/8 (linear_p, linear_w) run as streaming kernels
+    (`dense.linear`, csrc/skinny_linear.hip): as library GEMMs they were half of a layer's time.
+The per-point dense layers (q/k/v Linear, BatchNorm, ReLU, softmax over K) stay torch (rocBLAS / elementwise).
 """
 import torch
 import torch.nn as nn
 
-from . import pointops
+from . import dense, pointops
 
 
 def _bn_rows(bn, x):
@@ -46,13 +48,13 @@ class PointTransformerLayer(nn.Module):
         if idx is None:
             idx, _ = pointops.knnquery(self.nsample, p, p, o, o)              # once, not twice (:34-35)
         p_r = pointops.queryandgroup(self.nsample, p, p, p.new_zeros((p.shape[0], 0)), idx, o, o, use_xyz=True)   # (n,K,3) relative xyz
-        for i, layer in enumerate(self.linear_p):                             # :38
-            p_r = _bn_rows(layer, p_r) if i == 1 else layer(p_r)
+        for i, layer in enumerate(self.linear_p):                             # :38; the two Linears are (n*K, 3) streaming problems
+            p_r = _bn_rows(layer, p_r) if i == 1 else dense.linear(p_r, layer.weight, layer.bias) if isinstance(layer, nn.Linear) else layer(p_r)
         k_minus_q = -pointops.subtraction(x_q.contiguous(), x_k.contiguous(), idx)     # x_k[idx] - x_q  (n,K,c)
         n, K, c = p_r.shape
         w = k_minus_q + p_r.view(n, K, self.out_planes // self.mid_planes, self.mid_planes).sum(2)   # :39
         for i, layer in enumerate(self.linear_w):                             # :40
-            w = _bn_rows(layer, w) if i % 3 == 0 else layer(w)
+            w = _bn_rows(layer, w) if i % 3 == 0 else dense.linear(w, layer.weight, layer.bias) if isinstance(layer, nn.Linear) else layer(w)
         w = self.softmax(w)                                                   # over K, :41
         return pointops.aggregation(x_v.contiguous(), p_r.contiguous(), w.contiguous(), idx)   # :42-43
 

@@ -247,6 +247,16 @@ int cbl_pospool_backward(int n, int n0, int K, int C, const float* query_points,
                          const float* features, float radius, int position_embedding, int reduction, const int* padding_num,
                          const float* grad_out, float* grad_features, void* stream);
 
+/* a4, dense part of the vector attention: nn.Linear over (n*K) rows with tiny widths — linear_p = Linear(3,3), Linear(3,C) and
+ * linear_w = Linear(C,C/8), Linear(C/8,C/8)  pytorch/model/blocks.py:23-28,38-40 — as streaming kernels instead of library GEMMs.
+ *   x (rows,cin), weight (cout,cin), bias (cout) or NULL -> y (rows,cout) = x @ weight^T + bias
+ *   backward_input:  grad_x (rows,cin) = grad_y @ weight            backward_weight: grad_weight (cout,cin) += grad_y^T @ x, grad_bias (cout) +=
+ *   (caller pre-zeroes the += outputs; grad_bias may be NULL).  cin*cout <= 4096 and cin+cout <= 200, else CBL_ERR_UNSUPPORTED. */
+int cbl_skinny_linear_forward(long long rows, int cin, int cout, const float* x, const float* weight, const float* bias, float* y, void* stream);
+int cbl_skinny_linear_backward_input(long long rows, int cin, int cout, const float* grad_y, const float* weight, float* grad_x, void* stream);
+int cbl_skinny_linear_backward_weight(long long rows, int cin, int cout, const float* x, const float* grad_y, float* grad_weight, float* grad_bias,
+                                      void* stream);
+
 /* ind_max_pool / ind_closest_pool  tensorflow/models/basic_operators.py:155-172 / :175-192
  *   x (n1,d), inds (n2,k) i32 (pad = n1) -> out (n2,d): max over the row's entries (shadow row = column-wise min of x; scratch_d (d) u32)
  *   / the entry of the FIRST column (shadow row = 0) */
