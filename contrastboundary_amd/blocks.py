@@ -74,10 +74,7 @@ class TransitionDown(nn.Module):
     def forward(self, pxo):
         p, x, o = pxo
         if self.stride != 1:
-            lens = torch.diff(o.cpu(), prepend=o.new_zeros(1).cpu())
-            n_o = torch.cumsum(lens // self.stride, 0).to(torch.int32).to(o.device)       # :61-66
-            idx = pointops.furthestsampling(p, o, n_o)                                     # :67
-            n_p = p[idx.long(), :]
+            n_p, n_o, _ = pointops.fps_downsample(p, o, self.stride)                        # :61-68
             x = pointops.queryandgroup(self.nsample, p, n_p, x, None, o, n_o, use_xyz=True)   # (m,K,3+c) :69
             x = self.relu(_bn_rows(self.bn, self.linear(x)))                                # :70
             x = x.max(1)[0]                                                                 # MaxPool1d(nsample) over K, :71
@@ -100,7 +97,7 @@ class TransitionUp(nn.Module):
     def forward(self, pxo1, pxo2=None):
         if pxo2 is None:
             _, x, o = pxo1                                                    # :91-103
-            ends = o.cpu().tolist()
+            ends = pointops.host_offsets(o)
             x_tmp, s_i = [], 0
             for e_i in ends:
                 cnt = e_i - s_i

@@ -53,26 +53,32 @@ def _workspace(nbytes, device):
 
 
 # ------------------------------------------------------------------------------------------------ K2
+def _furthestsampling_raw(xyz, offset, new_offset, n_max, m):
+    """the launch alone: n_max (longest cloud) and m (= new_offset[-1]) come from the host side, nothing synchronises"""
+    n, b = xyz.shape[0], offset.shape[0]
+    idx = torch.zeros(m, dtype=torch.int32, device=xyz.device)
+    tmp = torch.full((n,), 1e10, dtype=torch.float32, device=xyz.device)
+    L = _lib.lib()
+    need = L.cbl_furthestsampling_workspace_bytes(_c_int(b), _c_int(n), _c_int(n_max))     # > 0: large clouds, bucket-pruned kernel
+    ws = _workspace(need, xyz.device)
+    rc = L.cbl_furthestsampling_ws(_c_int(b), _c_int(n), _c_int(n_max), _lib.ptr(xyz), _lib.ptr(offset), _lib.ptr(new_offset),
+                                   _lib.ptr(tmp), _lib.ptr(idx), _lib.ptr(ws), ctypes.c_size_t(ws.numel() if ws is not None else 0),
+                                   _lib.stream_of(xyz))
+    _lib.check(rc, "cbl_furthestsampling_ws")
+    return idx
+
+
 class FurthestSampling(Function):
     @staticmethod
     def forward(ctx, xyz, offset, new_offset):
         """xyz (n,3) f32, offset (b) i32, new_offset (b) i32 -> idx (m) i32          pointops.py:12-25"""
         _req(xyz, torch.float32, "xyz", 2); _req(offset, torch.int32, "offset", 1); _req(new_offset, torch.int32, "new_offset", 1)
-        n, b = xyz.shape[0], offset.shape[0]
+        b = offset.shape[0]
         off_h = offset.cpu()                       # the reference also syncs here (n_max, new_offset[b-1].item())
         lens = torch.diff(off_h, prepend=off_h.new_zeros(1))
         n_max = int(lens.max().item()) if b > 0 else 0
         m = int(new_offset[b - 1].item()) if b > 0 else 0
-        idx = torch.zeros(m, dtype=torch.int32, device=xyz.device)
-        tmp = torch.full((n,), 1e10, dtype=torch.float32, device=xyz.device)
-        L = _lib.lib()
-        need = L.cbl_furthestsampling_workspace_bytes(_c_int(b), _c_int(n), _c_int(n_max))     # > 0: large clouds, bucket-pruned kernel
-        ws = _workspace(need, xyz.device)
-        rc = L.cbl_furthestsampling_ws(_c_int(b), _c_int(n), _c_int(n_max), _lib.ptr(xyz), _lib.ptr(offset), _lib.ptr(new_offset),
-                                       _lib.ptr(tmp), _lib.ptr(idx), _lib.ptr(ws), ctypes.c_size_t(ws.numel() if ws is not None else 0),
-                                       _lib.stream_of(xyz))
-        _lib.check(rc, "cbl_furthestsampling_ws")
-        return idx
+        return _furthestsampling_raw(xyz, offset, new_offset, n_max, m)
 
 
 furthestsampling = FurthestSampling.apply
@@ -109,6 +115,7 @@ class neighbor_cache:
 
     def __init__(self):
         self.store, self.hits, self.misses = {}, 0, 0
+        self.host = {}                                              # host copies of offset tensors, see host_offsets()
 
     def __enter__(self):
         self._prev = neighbor_cache._active
@@ -117,24 +124,91 @@ class neighbor_cache:
 
     def __exit__(self, *exc):
         neighbor_cache._active = self._prev
-        self.store.clear()
+        if not getattr(self, "keep", False):
+            self.store.clear()
+            self.host.clear()
         return False
 
     @staticmethod
-    def _key(nsample, algo, tensors):
-        return (nsample, algo) + tuple((t.data_ptr(), tuple(t.shape), t._version) for t in tensors)
+    def _key(kind, algo, tensors):
+        return (kind, algo) + tuple((t.data_ptr(), tuple(t.shape), t._version) for t in tensors)
+
+    # Entries may have been produced on ANOTHER stream (geometry prefetch, contrastboundary_amd/geometry.py): each carries the
+    # event recorded behind its producer; a consumer stream waits for it and is registered with the allocator as a user.
+    def _deliver(self, entry):
+        outs, _keys, event, stream = entry
+        cur = torch.cuda.current_stream(outs[0].device)
+        if event is not None and stream != cur:
+            cur.wait_event(event)
+            for t in outs:
+                t.record_stream(cur)
+        return outs
+
+    def _stamp(self, outs, keys):
+        dev = outs[0].device
+        if getattr(self, "record_events", False):
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            return (outs, keys, ev, torch.cuda.current_stream(dev))
+        return (outs, keys, None, None)
 
     def lookup(self, nsample, algo, tensors):
         for a in ((algo, "auto") if algo == "set" else (algo,)):
             hit = self.store.get(self._key(nsample, a, tensors))
             if hit is not None:
                 self.hits += 1
-                return hit[0], hit[1]
+                return self._deliver(hit)
         self.misses += 1
         return None
 
     def insert(self, nsample, algo, tensors, idx, dist2):
-        self.store[self._key(nsample, algo, tensors)] = (idx, dist2, tensors)
+        self.store[self._key(nsample, algo, tensors)] = self._stamp((idx, dist2), tensors)
+
+    def lookup_fps(self, stride, tensors):
+        hit = self.store.get(self._key(("fps", stride), "", tensors))
+        return None if hit is None else self._deliver(hit)
+
+    def insert_fps(self, stride, tensors, new_p, new_o, idx):
+        self.store[self._key(("fps", stride), "", tensors)] = self._stamp((new_p, new_o, idx), tensors)
+
+
+def host_offsets(o):
+    """cumulative end offsets `o` (b) as a python list.  Inside a neighbour cache the answer is remembered per tensor (the cache keeps
+    the tensor alive, so its storage cannot be recycled under the key) and offsets made by `fps_downsample` are known without asking
+    the device at all; outside a cache this is the same blocking read as the reference's `offset[i].item()` loops."""
+    cache = neighbor_cache._active
+    if cache is None:
+        return o.cpu().tolist()
+    key = (o.data_ptr(), tuple(o.shape), o._version)
+    hit = cache.host.get(key)
+    if hit is None:
+        hit = cache.host[key] = (o.cpu().tolist(), o)
+    return hit[0]
+
+
+def fps_downsample(p, o, stride):
+    """TransitionDown's sampling step (blocks.py:61-68): per cloud n_b // stride furthest-point samples.
+    -> (new_p (m,3), new_o (b) i32, idx (m) i32); cached per forward like the neighbour searches (the coordinates handed back are the
+    SAME tensor on a hit, so later searches on them hit the cache as well).  Inside a cache no step of it waits for the device."""
+    cache = neighbor_cache._active
+    if cache is not None:
+        hit = cache.lookup_fps(stride, (p, o))
+        if hit is not None:
+            return hit
+    ends = host_offsets(o)
+    lens = [e - s for s, e in zip([0] + ends[:-1], ends)]
+    new_ends, run = [], 0
+    for l in lens:
+        run += l // stride
+        new_ends.append(run)
+    staged = torch.tensor(new_ends, dtype=torch.int32).pin_memory()
+    new_o = staged.to(o.device, non_blocking=True)
+    idx = _furthestsampling_raw(p, o, new_o, max(lens) if lens else 0, run)
+    new_p = p[idx.long(), :]
+    if cache is not None:
+        cache.host[(new_o.data_ptr(), tuple(new_o.shape), new_o._version)] = (new_ends, new_o, staged)
+        cache.insert_fps(stride, (p, o), new_p, new_o, idx)
+    return new_p, new_o, idx
 
 
 def knnquery_raw(nsample, xyz, new_xyz, offset, new_offset, algo="auto"):

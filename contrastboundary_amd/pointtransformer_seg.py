@@ -200,9 +200,19 @@ def pointtransformer_seg_repro(**kwargs):
     return PointTransformerSeg(PointTransformerBlock, [2, 3, 4, 6, 3], **kwargs)
 
 
-def forward_and_loss(model, criterion, inputs, target):
-    """one training-step forward: network + criterion under ONE neighbour cache -> (logits, stage_list, loss vector, cache)"""
-    with pointops.neighbor_cache() as nc:
+def forward_and_loss(model, criterion, inputs, target, geometry=None):
+    """one training-step forward: network + criterion under ONE neighbour cache -> (logits, stage_list, loss vector, cache).
+    `geometry`: a cache being filled by `geometry.prefetch(inputs['points'], inputs['offset'], ...)` on a side stream."""
+    with (geometry if geometry is not None else pointops.neighbor_cache()) as nc:
         output, stage_list = model(inputs)
         loss = criterion(output, target, stage_list)
     return output, stage_list, loss, nc
+
+
+def prefetch_geometry(model, inputs, criterion=None):
+    """`geometry.prefetch` with this model's / criterion's settings"""
+    from . import geometry
+    cfg = model.config
+    cbl = criterion is not None and getattr(criterion, "contrast_head", None) is not None
+    return geometry.prefetch(inputs["points"], inputs["offset"], stride=model.STRIDE, nsample=model.NSAMPLE,
+                             cbl_nsample=cfg.nsample if cbl else None, nstride=cfg.nstride if cbl else None, multi_head=model.head is not None)

@@ -73,3 +73,19 @@ def test_neighbor_cache_does_not_change_the_forward():
         b, sl = model(inputs)
         lb = crit(b, target, sl)
     assert torch.equal(a, b) and torch.equal(la, lb)
+
+
+@pytest.mark.gpu
+def test_geometry_prefetch_on_a_side_stream_answers_every_request():
+    """all FPS + neighbour searches issued ahead on a side stream: the forward finds 39 + 4 requests answered, results bitwise equal"""
+    M, model, crit, g = build(CASES[1])
+    model = model.cuda().train()
+    inputs = {"points": torch.from_numpy(g("xyz")).cuda(), "features": torch.from_numpy(g("feat")).cuda(), "offset": torch.from_numpy(g("offset")).cuda()}
+    target = torch.from_numpy(g("target")).cuda()
+    with torch.no_grad():
+        a, _, la, nc0 = M.forward_and_loss(model, crit, inputs, target)
+        geom = M.prefetch_geometry(model, inputs, crit)
+        b, _, lb, nc1 = M.forward_and_loss(model, crit, inputs, target, geometry=geom)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(la, lb)
+    assert nc1.misses == 0 and nc1.hits == nc0.hits + nc0.misses

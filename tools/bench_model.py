@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=40960); ap.add_argument("--scenes", type=int, default=1)
 ap.add_argument("--steps", type=int, default=10); ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--no-cache", action="store_true")
+ap.add_argument("--prefetch", action="store_true", help="geometry (FPS + every neighbour search) of the NEXT step on a side stream, one step ahead")
 a = ap.parse_args()
 cfg = M.Config({"base_fdim": 32, "nsample": [36, 24, 24, 24, 24], "nstride": [4, 4, 4, 4], "ignore_label": 255, "voxel_size": 0.04,
                 "contrast": {"stage": "Ua", "contrast": "softnn", "ftype": "latent", "sample": "label", "pos": "cnt", "dist": "l2", "temperature": 1, "weight": "w.1"},
@@ -30,12 +31,18 @@ inputs = {"points": torch.from_numpy(np.concatenate(xs)).cuda(), "features": tor
 target = torch.from_numpy(np.concatenate(ls)).cuda()
 
 
+geom_next = [M.prefetch_geometry(model, inputs, crit) if a.prefetch else None]
+
+
 def step():
     opt.zero_grad(set_to_none=True)
     if a.no_cache:
         out, sl = model(inputs); loss = crit(out, target, sl); nc = None
     else:
-        out, sl, loss, nc = M.forward_and_loss(model, crit, inputs, target)
+        geom = geom_next[0]
+        if a.prefetch:
+            geom_next[0] = M.prefetch_geometry(model, inputs, crit)      # the data loader's next batch (here: the same scene again)
+        out, sl, loss, nc = M.forward_and_loss(model, crit, inputs, target, geometry=geom)
     loss.sum().backward()
     opt.step()
     return loss, nc
@@ -51,4 +58,4 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
 print(json.dumps({"workload": f"PointTransformerSeg+CBL train step, {a.scenes} x S-room({a.n})", "ms_per_step": dt * 1e3,
                   "points_per_s": a.n * a.scenes / dt, "knn_requests": None if nc is None else nc.hits + nc.misses,
-                  "knn_searches": None if nc is None else nc.misses, "loss": [round(float(v), 5) for v in loss.detach().cpu()]}))
+                  "knn_searches": None if nc is None else nc.misses, "geometry_prefetch": bool(a.prefetch), "loss": [round(float(v), 5) for v in loss.detach().cpu()]}))
