@@ -44,7 +44,7 @@ class PointTransformerLayer(nn.Module):
 
     def forward(self, pxo, idx=None) -> torch.Tensor:
         p, x, o = pxo                                                        # (n,3), (n,c), (b)
-        x_q, x_k, x_v = self.linear_q(x), self.linear_k(x), self.linear_v(x)  # :33
+        x_q, x_k, x_v = dense.apply(self.linear_q, x), dense.apply(self.linear_k, x), dense.apply(self.linear_v, x)  # :33
         if idx is None:
             idx, _ = pointops.knnquery(self.nsample, p, p, o, o)              # once, not twice (:34-35)
         p_r = pointops.queryandgroup(self.nsample, p, p, p.new_zeros((p.shape[0], 0)), idx, o, o, use_xyz=True)   # (n,K,3) relative xyz
@@ -76,11 +76,11 @@ class TransitionDown(nn.Module):
         if self.stride != 1:
             n_p, n_o, _ = pointops.fps_downsample(p, o, self.stride)                        # :61-68
             x = pointops.queryandgroup(self.nsample, p, n_p, x, None, o, n_o, use_xyz=True)   # (m,K,3+c) :69
-            x = self.relu(_bn_rows(self.bn, self.linear(x)))                                # :70
+            x = self.relu(_bn_rows(self.bn, dense.apply(self.linear, x)))                   # :70
             x = x.max(1)[0]                                                                 # MaxPool1d(nsample) over K, :71
             p, o = n_p, n_o
         else:
-            x = self.relu(self.bn(self.linear(x)))                                          # :74
+            x = self.relu(self.bn(dense.apply(self.linear, x)))                             # :74
         return [p, x, o]
 
 
@@ -105,10 +105,10 @@ class TransitionUp(nn.Module):
                 x_b = torch.cat((x_b, self.linear2(x_b.sum(0, True) / cnt).repeat(cnt, 1)), 1)
                 x_tmp.append(x_b)
                 s_i = e_i
-            x = self.linear1(torch.cat(x_tmp, 0))
+            x = dense.sequential(self.linear1, torch.cat(x_tmp, 0))
         else:
             p1, x1, o1 = pxo1; p2, x2, o2 = pxo2                              # :105-108
-            x = self.linear1(x1) + pointops.interpolation(p2, p1, self.linear2(x2).contiguous(), o2, o1)
+            x = dense.sequential(self.linear1, x1) + pointops.interpolation(p2, p1, dense.sequential(self.linear2, x2).contiguous(), o2, o1)
         return x
 
 
@@ -128,9 +128,9 @@ class PointTransformerBlock(nn.Module):
     def forward(self, pxo, idx=None):
         p, x, o = pxo
         identity = x
-        x = self.relu(self.bn1(self.linear1(x)))
+        x = self.relu(self.bn1(dense.apply(self.linear1, x)))
         x = self.relu(self.bn2(self.transformer2([p, x, o], idx)))
-        x = self.bn3(self.linear3(x))
+        x = self.bn3(dense.apply(self.linear3, x))
         x = x + identity
         x = self.relu(x)
         return [p, x, o]

@@ -58,3 +58,15 @@ def linear(x, weight, bias=None):
         return F.linear(x, weight, bias)
     y = _SkinnyLinear.apply(x.reshape(rows, cin).contiguous(), weight.contiguous(), None if bias is None else bias.contiguous())
     return y.view(*x.shape[:-1], cout)
+
+
+def apply(layer, x):
+    """`layer(x)` for an nn.Linear (through `linear`) or any other module"""
+    return linear(x, layer.weight, layer.bias) if isinstance(layer, torch.nn.Linear) else layer(x)
+
+
+def sequential(seq, x):
+    """`seq(x)` for an nn.Sequential of Linear / BatchNorm1d / ReLU acting on (rows, C)"""
+    for layer in seq:
+        x = apply(layer, x)
+    return x

@@ -13,7 +13,7 @@ blocks of the stage), 4 down-sampling KNNs, 4+4 interpolation KNNs and the CBL h
 import torch
 import torch.nn as nn
 
-from . import pointops
+from . import dense, pointops
 from .blocks import PointTransformerBlock, TransitionDown, TransitionUp
 from .heads import ContrastHead, parse_stage
 
@@ -70,7 +70,7 @@ class MLP(nn.Module):
         self.infer = nn.Sequential(*infer_list)
 
     def forward(self, stage, k):
-        return self.infer(stage[k])
+        return dense.sequential(self.infer, stage[k])
 
 
 class MultiHead(nn.Module):
