@@ -9,6 +9,7 @@ Unlike the reference (no checks at all), dtype / device / contigu
 failing launch raises instead of surfacing later as an asynchronous error.
 """
 import ctypes
+import threading
 
 import torch
 from torch.autograd import Function
@@ -111,23 +112,27 @@ class neighbor_cache:
     first result; nothing else changes, so modules keep the reference's signatures.  An 'auto' (reference-order) result also
     serves a later 'set' request.  The cache holds references to the keyed tensors, so storage cannot be recycled under it; it
     is dropped when the context exits.  `nc.hits` / `nc.misses` count requests."""
-    _active = None
+    _tls = threading.local()             # the active cache is per thread (nn.DataParallel replicas run the mirrors from worker threads)
 
     def __init__(self):
         self.store, self.hits, self.misses = {}, 0, 0
         self.host = {}                                              # host copies of offset tensors, see host_offsets()
 
     def __enter__(self):
-        self._prev = neighbor_cache._active
-        neighbor_cache._active = self
+        self._prev = neighbor_cache.active()
+        neighbor_cache._tls.cache = self
         return self
 
     def __exit__(self, *exc):
-        neighbor_cache._active = self._prev
+        neighbor_cache._tls.cache = self._prev
         if not getattr(self, "keep", False):
             self.store.clear()
             self.host.clear()
         return False
+
+    @staticmethod
+    def active():
+        return getattr(neighbor_cache._tls, "cache", None)
 
     @staticmethod
     def _key(kind, algo, tensors):
@@ -176,7 +181,7 @@ def host_offsets(o):
     """cumulative end offsets `o` (b) as a python list.  Inside a neighbour cache the answer is remembered per tensor (the cache keeps
     the tensor alive, so its storage cannot be recycled under the key) and offsets made by `fps_downsample` are known without asking
     the device at all; outside a cache this is the same blocking read as the reference's `offset[i].item()` loops."""
-    cache = neighbor_cache._active
+    cache = neighbor_cache.active()
     if cache is None:
         return o.cpu().tolist()
     key = (o.data_ptr(), tuple(o.shape), o._version)
@@ -190,7 +195,7 @@ def fps_downsample(p, o, stride):
     """TransitionDown's sampling step (blocks.py:61-68): per cloud n_b // stride furthest-point samples.
     -> (new_p (m,3), new_o (b) i32, idx (m) i32); cached per forward like the neighbour searches (the coordinates handed back are the
     SAME tensor on a hit, so later searches on them hit the cache as well).  Inside a cache no step of it waits for the device."""
-    cache = neighbor_cache._active
+    cache = neighbor_cache.active()
     if cache is not None:
         hit = cache.lookup_fps(stride, (p, o))
         if hit is not None:
@@ -221,7 +226,7 @@ def knnquery_raw(nsample, xyz, new_xyz, offset, new_offset, algo="auto"):
         new_xyz = xyz
     if algo == "auto" and _tie_policy != "reference":
         algo = _tie_policy
-    cache = neighbor_cache._active
+    cache = neighbor_cache.active()
     if cache is not None:
         hit = cache.lookup(nsample, algo, (xyz, new_xyz, offset, new_offset))
         if hit is not None:
@@ -262,7 +267,7 @@ class KNNQuery(Function):
     def forward(ctx, nsample, xyz, new_xyz, offset, new_offset):
         """-> idx (m,nsample) i32, dist (m,nsample) f32 = sqrt(dist2)                   pointops.py:32-43"""
         idx, dist2 = knnquery_raw(nsample, xyz, new_xyz, offset, new_offset)
-        if neighbor_cache._active is not None:
+        if neighbor_cache.active() is not None:
             idx = idx.view(idx.shape)          # a cached result is shared by several calls: hand autograd its own tensor object
         ctx.mark_non_differentiable(idx)
         return idx, torch.sqrt(dist2)
