@@ -16,8 +16,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=40960); ap.add_argument("--scenes", type=int, default=1)
 ap.add_argument("--steps", type=int, default=10); ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--no-cache", action="store_true")
+ap.add_argument("--blas", default="cublas", help="torch.backends.cuda.preferred_blas_library: 'cublas' = rocBLAS (default here: 2-20x faster than hipBLASLt on this network's small weight-gradient GEMMs), 'cublaslt' = torch's default")
 ap.add_argument("--prefetch", action="store_true", help="geometry (FPS + every neighbour search) of the NEXT step on a side stream, one step ahead")
 a = ap.parse_args()
+torch.backends.cuda.preferred_blas_library(a.blas)
 cfg = M.Config({"base_fdim": 32, "nsample": [36, 24, 24, 24, 24], "nstride": [4, 4, 4, 4], "ignore_label": 255, "voxel_size": 0.04,
                 "contrast": {"stage": "Ua", "contrast": "softnn", "ftype": "latent", "sample": "label", "pos": "cnt", "dist": "l2", "temperature": 1, "weight": "w.1"},
                 "multi": {"stage": "Ua", "ftype": "latent", "combine": "concat"}})
@@ -58,4 +60,4 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
 print(json.dumps({"workload": f"PointTransformerSeg+CBL train step, {a.scenes} x S-room({a.n})", "ms_per_step": dt * 1e3,
                   "points_per_s": a.n * a.scenes / dt, "knn_requests": None if nc is None else nc.hits + nc.misses,
-                  "knn_searches": None if nc is None else nc.misses, "geometry_prefetch": bool(a.prefetch), "loss": [round(float(v), 5) for v in loss.detach().cpu()]}))
+                  "knn_searches": None if nc is None else nc.misses, "geometry_prefetch": bool(a.prefetch), "blas": a.blas, "loss": [round(float(v), 5) for v in loss.detach().cpu()]}))
