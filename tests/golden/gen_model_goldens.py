@@ -81,6 +81,7 @@ for case, (lens, seed) in {"one_cloud_8192": ([8192], 0), "two_clouds_12000": ([
     out[f"{case}/param_abs_sum"] = np.float64(sum(float(v.double().abs().sum()) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k))
     out[f"{case}/grad_first"] = model.enc1[0].linear.weight.grad.numpy().copy()
     out[f"{case}/grad_last"] = model.head.cls.weight.grad.numpy().copy()
+    out[f"{case}/state_dict_keys"] = np.array([f"{k}:{tuple(v.shape)}" for k, v in sd.items()])
     out[f"{case}/stage_sizes"] = np.array([st["p_out"].shape[0] for st in stage_list["up"]], np.int64)
     out[f"{case}/ref_knn_calls"] = np.int64(calls["knn"])
     print(case, "loss", loss.detach().numpy(), "knn calls", calls["knn"], "stages", out[f"{case}/stage_sizes"])

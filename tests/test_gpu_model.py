@@ -40,6 +40,8 @@ def test_same_seed_gives_the_reference_parameters(case):
     s = sum(float(v.double().abs().sum()) for k, v in model.state_dict().items() if v.dtype.is_floating_point and "running" not in k)
     assert abs(s - float(g("param_abs_sum"))) < 1e-9 * float(g("param_abs_sum"))
     assert sum(p.numel() for p in model.parameters()) == 7800497
+    # same names and shapes: a reference checkpoint loads into the mirror (and back)
+    assert [f"{k}:{tuple(v.shape)}" for k, v in model.state_dict().items()] == list(g("state_dict_keys"))
 
 
 @pytest.mark.gpu
