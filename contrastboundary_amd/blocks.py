@@ -8,7 +8,8 @@ changes is how the K-neighbour part runs:
     (K7) and the final `sum_k (v_j + p_r) * w` from the aggregation kernel (K9, share_planes = c % w_c): the gathered
     (n,K,C) copies of x_k / x_v and the 4-d view/sum of blocks.py:43 are never materialised;
   * BatchNorm over (n*K) rows is applied on the flattened view (same statistics as the reference's transpose → BN1d →
-    transpose, blocks.py:38,40, without the two transposed copies).
+    transpose, blocks.py:38,40, without the two transposed copies), in train mode by the two-pass kernels of csrc/bn_rows.hip with
+    the following ReLU folded in (`dense.batch_norm`);
   * the four Linear layers that act on (n*K) rows with widths 3 / C/8 (linear_p, linear_w) run as streaming kernels
     (`dense.linear`, csrc/skinny_linear.hip): as library GEMMs they were half of a layer's time.
 The per-point dense layers (q/k/v Linear, BatchNorm, ReLU, softmax over K) stay torch (rocBLAS / elementwise).
@@ -17,12 +18,6 @@ import torch
 import torch.nn as nn
 
 from . import dense, pointops
-
-
-def _bn_rows(bn, x):
-    """BatchNorm1d over all leading dims of x (..., C) == bn(x.transpose(1,2)).transpose(1,2) of the reference"""
-    shape = x.shape
-    return bn(x.reshape(-1, shape[-1])).view(shape)
 
 
 class PointTransformerLayer(nn.Module):
@@ -48,13 +43,11 @@ class PointTransformerLayer(nn.Module):
         if idx is None:
             idx, _ = pointops.knnquery(self.nsample, p, p, o, o)              # once, not twice (:34-35)
         p_r = pointops.queryandgroup(self.nsample, p, p, p.new_zeros((p.shape[0], 0)), idx, o, o, use_xyz=True)   # (n,K,3) relative xyz
-        for i, layer in enumerate(self.linear_p):                             # :38; the two Linears are (n*K, 3) streaming problems
-            p_r = _bn_rows(layer, p_r) if i == 1 else dense.linear(p_r, layer.weight, layer.bias) if isinstance(layer, nn.Linear) else layer(p_r)
+        p_r = dense.sequential(self.linear_p, p_r)                            # :38  Linear(3,3) -> BN -> ReLU -> Linear(3,C) over (n*K) rows
         k_minus_q = -pointops.subtraction(x_q.contiguous(), x_k.contiguous(), idx)     # x_k[idx] - x_q  (n,K,c)
         n, K, c = p_r.shape
         w = k_minus_q + p_r.view(n, K, self.out_planes // self.mid_planes, self.mid_planes).sum(2)   # :39
-        for i, layer in enumerate(self.linear_w):                             # :40
-            w = _bn_rows(layer, w) if i % 3 == 0 else dense.linear(w, layer.weight, layer.bias) if isinstance(layer, nn.Linear) else layer(w)
+        w = dense.sequential(self.linear_w, w)                                # :40  BN -> ReLU -> Linear -> BN -> ReLU -> Linear
         w = self.softmax(w)                                                   # over K, :41
         return pointops.aggregation(x_v.contiguous(), p_r.contiguous(), w.contiguous(), idx)   # :42-43
 
@@ -76,11 +69,11 @@ class TransitionDown(nn.Module):
         if self.stride != 1:
             n_p, n_o, _ = pointops.fps_downsample(p, o, self.stride)                        # :61-68
             x = pointops.queryandgroup(self.nsample, p, n_p, x, None, o, n_o, use_xyz=True)   # (m,K,3+c) :69
-            x = self.relu(_bn_rows(self.bn, dense.apply(self.linear, x)))                   # :70
+            x = dense.batch_norm(dense.apply(self.linear, x), self.bn, relu=True)         # :70
             x = x.max(1)[0]                                                                 # MaxPool1d(nsample) over K, :71
             p, o = n_p, n_o
         else:
-            x = self.relu(self.bn(dense.apply(self.linear, x)))                             # :74
+            x = dense.batch_norm(dense.apply(self.linear, x), self.bn, relu=True)         # :74
         return [p, x, o]
 
 
@@ -128,9 +121,9 @@ class PointTransformerBlock(nn.Module):
     def forward(self, pxo, idx=None):
         p, x, o = pxo
         identity = x
-        x = self.relu(self.bn1(dense.apply(self.linear1, x)))
-        x = self.relu(self.bn2(self.transformer2([p, x, o], idx)))
-        x = self.bn3(dense.apply(self.linear3, x))
+        x = dense.batch_norm(dense.apply(self.linear1, x), self.bn1, relu=True)
+        x = dense.batch_norm(self.transformer2([p, x, o], idx), self.bn2, relu=True)
+        x = dense.batch_norm(dense.apply(self.linear3, x), self.bn3)
         x = x + identity
         x = self.relu(x)
         return [p, x, o]

@@ -1,0 +1,230 @@
+// a4 / a5, dense part: train-mode BatchNorm1d (+ ReLU) over (rows, C) activations with rows = n or n*K — the layers between the
+// neighbourhood kernels of the blocks (/root/reference/pytorch/model/blocks.py:25-28,38-40,70,74,126-134: BatchNorm1d after every
+// Linear, most of them followed by ReLU).  The library path runs them as statistics + transform + clamp kernels forward and
+// threshold + reduce + element kernels backward at ~1.4 TB/s; here the same mathematics is 2 streaming passes forward and 2
+// backward with the ReLU folded in:
+//   forward   pass 1: per-workgroup partial sums of x and x^2 per channel (fp32 over <= ~100 rows per lane, combined in fp64)
+//             finalize (one workgroup): mean, biased variance -> invstd; running statistics updated like nn.BatchNorm1d
+//             (momentum, unbiased variance)
+//             pass 2: y = max(0, (x - mean) * invstd * weight + bias)
+//   backward  pass 1: partial sums of g and g * xhat per channel, g = grad_y masked by (y > 0) recomputed from x
+//             finalize: grad_weight = sum g*xhat, grad_bias = sum g
+//             pass 2: grad_x = weight * invstd * (g - mean(g) - xhat * mean(g*xhat))
+// Row-major (rows, C): a lane owns VEC consecutive channels and walks rows, so every access is a coalesced row segment.
+#include "cbl_common.h"
+
+namespace {
+
+constexpr int BN_BLOCK = 256;
+constexpr int BN_MAX_BLOCKS = 512;
+
+struct BnShape { int vec, tpr, slots, nblocks; long long rows_per_block; };
+inline BnShape bn_shape(long long rows, int C)
+{
+    BnShape s;
+    s.vec = (C % 4 == 0) ? 4 : 1;
+    s.tpr = C / s.vec;                                               // lanes per row
+    s.slots = BN_BLOCK / s.tpr;                                      // rows in flight per workgroup
+    long long nb = (rows + 63) / 64;
+    s.nblocks = (int)(nb < 1 ? 1 : (nb > BN_MAX_BLOCKS ? BN_MAX_BLOCKS : nb));
+    s.rows_per_block = (rows + s.nblocks - 1) / s.nblocks;
+    return s;
+}
+
+// partial[b][0][c] = sum over the workgroup's rows of A(r,c), partial[b][1][c] = sum of B(r,c)
+//   MODE 0 (forward):  A = x, B = x*x
+//   MODE 1 (backward): A = g, B = g * xhat   with g = gy * (relu ? y > 0 : 1), xhat = (x - mean) * invstd, y = xhat * w + b
+template <int VEC, int MODE>
+__global__ __launch_bounds__(BN_BLOCK) void bn_partial_kernel(long long rows, int C, int tpr, int slots, long long rows_per_block,
+                                                              const float* __restrict__ x, const float* __restrict__ gy,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              const float* __restrict__ weight, const float* __restrict__ bias, int relu,
+                                                              float* __restrict__ partial)
+{
+    __shared__ float red[2][BN_BLOCK][VEC];
+    const int tid = threadIdx.x;
+    const int cq = tid % tpr, slot = tid / tpr;
+    const bool live = slot < slots;
+    const int c0 = cq * VEC;
+    float m[VEC], is[VEC], w[VEC], b[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; v++) {
+        m[v] = (MODE == 1) ? mean[c0 + v] : 0.f; is[v] = (MODE == 1) ? invstd[c0 + v] : 0.f;
+        w[v] = (MODE == 1 && weight) ? weight[c0 + v] : 1.f; b[v] = (MODE == 1 && bias) ? bias[c0 + v] : 0.f;
+    }
+    float a0[VEC], a1[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; v++) a0[v] = a1[v] = 0.f;
+    const long long r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    if (live) {
+        for (long long r = r0 + slot; r < r1; r += slots) {
+            float xv[VEC], gv[VEC];
+            if (VEC == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(x + r * C + c0);
+                xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+                if (MODE == 1) { const float4 u = *reinterpret_cast<const float4*>(gy + r * C + c0); gv[0] = u.x; gv[1] = u.y; gv[2] = u.z; gv[3] = u.w; }
+            } else {
+                xv[0] = x[r * C + c0];
+                if (MODE == 1) gv[0] = gy[r * C + c0];
+            }
+#pragma unroll
+            for (int v = 0; v < VEC; v++) {
+                if (MODE == 0) { a0[v] += xv[v]; a1[v] += xv[v] * xv[v]; }
+                else {
+                    const float xh = (xv[v] - m[v]) * is[v];
+                    const float g = (relu && !(xh * w[v] + b[v] > 0.f)) ? 0.f : gv[v];
+                    a0[v] += g; a1[v] += g * xh;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; v++) { red[0][tid][v] = a0[v]; red[1][tid][v] = a1[v]; }
+    __syncthreads();
+    if (live && slot == 0) {
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+            double s0 = 0.0, s1 = 0.0;
+            for (int s = 0; s < slots; s++) { s0 += (double)red[0][s * tpr + cq][v]; s1 += (double)red[1][s * tpr + cq][v]; }
+            partial[((size_t)blockIdx.x * 2 + 0) * C + c0 + v] = (float)s0;
+            partial[((size_t)blockIdx.x * 2 + 1) * C + c0 + v] = (float)s1;
+        }
+    }
+}
+
+// forward finalize: batch statistics, running statistics (nn.BatchNorm1d: momentum, unbiased variance)
+__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(long long rows, int C, int nblocks, const float* __restrict__ partial, float eps,
+                                                              float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                              float* __restrict__ mean, float* __restrict__ invstd)
+{
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < C; c += gridDim.x * 256) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int b = 0; b < nblocks; b++) { s0 += (double)partial[((size_t)b * 2) * C + c]; s1 += (double)partial[((size_t)b * 2 + 1) * C + c]; }
+        const double mu = s0 / (double)rows;
+        double var = s1 / (double)rows - mu * mu;
+        if (var < 0.0) var = 0.0;
+        mean[c] = (float)mu;
+        invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+        if (running_var) {
+            const double unbiased = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+}
+
+// backward finalize: sums -> grad_weight / grad_bias and the two means used by the element pass (coef[0][c], coef[1][c])
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(long long rows, int C, int nblocks, const float* __restrict__ partial,
+                                                              float* __restrict__ grad_weight, float* __restrict__ grad_bias, float* __restrict__ coef)
+{
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < C; c += gridDim.x * 256) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int b = 0; b < nblocks; b++) { s0 += (double)partial[((size_t)b * 2) * C + c]; s1 += (double)partial[((size_t)b * 2 + 1) * C + c]; }
+        if (grad_bias) grad_bias[c] = (float)s0;
+        if (grad_weight) grad_weight[c] = (float)s1;
+        coef[c] = (float)(s0 / (double)rows);
+        coef[C + c] = (float)(s1 / (double)rows);
+    }
+}
+
+// MODE 0: y = [relu](xhat * w + b);   MODE 1: grad_x = w * invstd * (g - coef0 - xhat * coef1)
+template <int VEC, int MODE>
+__global__ __launch_bounds__(BN_BLOCK) void bn_element_kernel(long long rows, int C, const float* __restrict__ x, const float* __restrict__ gy,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              const float* __restrict__ weight, const float* __restrict__ bias, const float* __restrict__ coef,
+                                                              int relu, float* __restrict__ out)
+{
+    const int tpr = C / VEC;
+    const long long total = rows * tpr;
+    for (long long e = (long long)blockIdx.x * BN_BLOCK + threadIdx.x; e < total; e += (long long)gridDim.x * BN_BLOCK) {
+        const int c0 = (int)(e % tpr) * VEC;
+        float xv[VEC], gv[VEC], o[VEC];
+        if (VEC == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(x + e * 4);
+            xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+            if (MODE == 1) { const float4 u = *reinterpret_cast<const float4*>(gy + e * 4); gv[0] = u.x; gv[1] = u.y; gv[2] = u.z; gv[3] = u.w; }
+        } else {
+            xv[0] = x[e];
+            if (MODE == 1) gv[0] = gy[e];
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+            const int c = c0 + v;
+            const float w = weight ? weight[c] : 1.f, b = bias ? bias[c] : 0.f;
+            const float xh = (xv[v] - mean[c]) * invstd[c];
+            const float y = xh * w + b;
+            if (MODE == 0) o[v] = (relu && !(y > 0.f)) ? 0.f : y;
+            else {
+                const float g = (relu && !(y > 0.f)) ? 0.f : gv[v];
+                o[v] = w * invstd[c] * ((g - coef[c]) - xh * coef[C + c]);
+            }
+        }
+        if (VEC == 4) *reinterpret_cast<float4*>(out + e * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        else out[e] = o[0];
+    }
+}
+
+int bn_check(long long rows, int C)
+{
+    if (rows < 0 || C <= 0) return CBL_ERR_BAD_ARG;
+    if (C > 1024 || (C % 4 != 0 && C > BN_BLOCK)) return CBL_ERR_UNSUPPORTED;
+    return CBL_OK;
+}
+
+}  // namespace
+
+// scratch: per-workgroup partial sums + (backward) the two coefficient rows
+CBL_EXPORT size_t cbl_bn_rows_workspace_bytes(long long rows, int C)
+{
+    if (bn_check(rows, C) != CBL_OK) return 0;
+    return sizeof(float) * ((size_t)BN_MAX_BLOCKS * 2 * C + 2 * (size_t)C) + 256;
+}
+
+CBL_EXPORT int cbl_bn_rows_forward(long long rows, int C, const float* x, const float* weight, const float* bias, float eps, float momentum,
+                                   float* running_mean, float* running_var, int relu, float* save_mean, float* save_invstd, float* y,
+                                   void* workspace, size_t workspace_bytes, void* stream)
+{
+    const int rc = bn_check(rows, C);
+    if (rc) return rc;
+    if (rows == 0) return CBL_OK;
+    if (!x || !save_mean || !save_invstd || !y || !workspace) return CBL_ERR_BAD_ARG;
+    if (workspace_bytes < cbl_bn_rows_workspace_bytes(rows, C)) return CBL_ERR_WORKSPACE;
+    const BnShape s = bn_shape(rows, C);
+    float* partial = reinterpret_cast<float*>(workspace);
+    hipStream_t st = cbl_stream(stream);
+    const bool vec = s.vec == 4 && cbl_host_aligned16(x) && cbl_host_aligned16(y);
+    const BnShape s1 = vec ? s : [&] { BnShape t = s; t.vec = 1; t.tpr = C; t.slots = BN_BLOCK / C; return t; }();
+    if (s1.slots < 1) return CBL_ERR_UNSUPPORTED;
+    if (vec) hipLaunchKernelGGL((bn_partial_kernel<4, 0>), dim3(s1.nblocks), dim3(BN_BLOCK), 0, st, rows, C, s1.tpr, s1.slots, s1.rows_per_block, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0, partial);
+    else     hipLaunchKernelGGL((bn_partial_kernel<1, 0>), dim3(s1.nblocks), dim3(BN_BLOCK), 0, st, rows, C, s1.tpr, s1.slots, s1.rows_per_block, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0, partial);
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(cbl_div_up(C, 256)), dim3(256), 0, st, rows, C, s1.nblocks, partial, eps, momentum, running_mean, running_var, save_mean, save_invstd);
+    const dim3 grid(cbl_grid_for(rows * (C / (vec ? 4 : 1)), BN_BLOCK, 4096));
+    if (vec) hipLaunchKernelGGL((bn_element_kernel<4, 0>), grid, dim3(BN_BLOCK), 0, st, rows, C, x, nullptr, save_mean, save_invstd, weight, bias, nullptr, relu, y);
+    else     hipLaunchKernelGGL((bn_element_kernel<1, 0>), grid, dim3(BN_BLOCK), 0, st, rows, C, x, nullptr, save_mean, save_invstd, weight, bias, nullptr, relu, y);
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_bn_rows_backward(long long rows, int C, const float* x, const float* grad_y, const float* weight, const float* bias,
+                                    const float* save_mean, const float* save_invstd, int relu, float* grad_x, float* grad_weight, float* grad_bias,
+                                    void* workspace, size_t workspace_bytes, void* stream)
+{
+    const int rc = bn_check(rows, C);
+    if (rc) return rc;
+    if (rows == 0) return CBL_OK;
+    if (!x || !grad_y || !save_mean || !save_invstd || !grad_x || !workspace) return CBL_ERR_BAD_ARG;
+    if (workspace_bytes < cbl_bn_rows_workspace_bytes(rows, C)) return CBL_ERR_WORKSPACE;
+    const BnShape s = bn_shape(rows, C);
+    float* partial = reinterpret_cast<float*>(workspace);
+    float* coef = partial + (size_t)BN_MAX_BLOCKS * 2 * C;
+    hipStream_t st = cbl_stream(stream);
+    const bool vec = s.vec == 4 && cbl_host_aligned16(x) && cbl_host_aligned16(grad_y) && cbl_host_aligned16(grad_x);
+    const BnShape s1 = vec ? s : [&] { BnShape t = s; t.vec = 1; t.tpr = C; t.slots = BN_BLOCK / C; return t; }();
+    if (s1.slots < 1) return CBL_ERR_UNSUPPORTED;
+    if (vec) hipLaunchKernelGGL((bn_partial_kernel<4, 1>), dim3(s1.nblocks), dim3(BN_BLOCK), 0, st, rows, C, s1.tpr, s1.slots, s1.rows_per_block, x, grad_y, save_mean, save_invstd, weight, bias, relu, partial);
+    else     hipLaunchKernelGGL((bn_partial_kernel<1, 1>), dim3(s1.nblocks), dim3(BN_BLOCK), 0, st, rows, C, s1.tpr, s1.slots, s1.rows_per_block, x, grad_y, save_mean, save_invstd, weight, bias, relu, partial);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cbl_div_up(C, 256)), dim3(256), 0, st, rows, C, s1.nblocks, partial, grad_weight, grad_bias, coef);
+    const dim3 grid(cbl_grid_for(rows * (C / (vec ? 4 : 1)), BN_BLOCK, 4096));
+    if (vec) hipLaunchKernelGGL((bn_element_kernel<4, 1>), grid, dim3(BN_BLOCK), 0, st, rows, C, x, grad_y, save_mean, save_invstd, weight, bias, coef, relu, grad_x);
+    else     hipLaunchKernelGGL((bn_element_kernel<1, 1>), grid, dim3(BN_BLOCK), 0, st, rows, C, x, grad_y, save_mean, save_invstd, weight, bias, coef, relu, grad_x);
+    return cbl_status();
+}

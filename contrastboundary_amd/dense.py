@@ -60,13 +60,87 @@ def linear(x, weight, bias=None):
     return y.view(*x.shape[:-1], cout)
 
 
+MIN_ROWS_BN = 4096
+
+
+class _BnRows(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, relu):
+        rows, C = x.shape
+        L = _lib.lib()
+        ws = _bn_workspace(L.cbl_bn_rows_workspace_bytes(ctypes.c_longlong(rows), ctypes.c_int(C)), x.device)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        y = torch.empty_like(x)
+        _lib.check(L.cbl_bn_rows_forward(ctypes.c_longlong(rows), ctypes.c_int(C), _lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), ctypes.c_float(eps),
+                                         ctypes.c_float(momentum), _lib.ptr(running_mean), _lib.ptr(running_var), ctypes.c_int(relu), _lib.ptr(mean),
+                                         _lib.ptr(invstd), _lib.ptr(y), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(x)), "cbl_bn_rows_forward")
+        ctx.save_for_backward(x, weight, bias, mean, invstd)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, bias, mean, invstd = ctx.saved_tensors
+        rows, C = x.shape
+        gy = gy.contiguous()
+        L = _lib.lib()
+        ws = _bn_workspace(L.cbl_bn_rows_workspace_bytes(ctypes.c_longlong(rows), ctypes.c_int(C)), x.device)
+        gx = torch.empty_like(x)
+        gw = torch.empty(C, dtype=torch.float32, device=x.device) if weight is not None else None
+        gb = torch.empty(C, dtype=torch.float32, device=x.device) if bias is not None else None
+        _lib.check(L.cbl_bn_rows_backward(ctypes.c_longlong(rows), ctypes.c_int(C), _lib.ptr(x), _lib.ptr(gy), _lib.ptr(weight), _lib.ptr(bias),
+                                          _lib.ptr(mean), _lib.ptr(invstd), ctypes.c_int(ctx.relu), _lib.ptr(gx), _lib.ptr(gw), _lib.ptr(gb),
+                                          _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(x)), "cbl_bn_rows_backward")
+        return gx, gw, gb, None, None, None, None, None
+
+
+_bn_ws = {}
+
+
+def _bn_workspace(nbytes, device):
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _bn_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _bn_ws[key] = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
+    return ws
+
+
+def batch_norm(x, bn, relu=False):
+    """`relu(bn(x))` / `bn(x)` for an nn.BatchNorm1d over the last dimension of x (..., C), every leading dimension a batch row —
+    what the reference writes as bn(x.transpose(1, 2)).transpose(1, 2) for (n, K, C) tensors (blocks.py:38,40).  Train mode with
+    running statistics and a float momentum goes through csrc/bn_rows.hip (2 passes forward, 2 backward, ReLU folded in); anything
+    else through torch with identical semantics."""
+    C = x.shape[-1]
+    rows = x.numel() // max(C, 1)
+    fused = (bn.training and x.is_cuda and x.dtype == torch.float32 and rows >= MIN_ROWS_BN and bn.track_running_stats and bn.momentum is not None
+             and (C % 4 == 0 and C <= 1024 or C <= 256))
+    if not fused:
+        y = bn(x.reshape(-1, C)).view(x.shape)
+        return F.relu(y) if relu else y
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    y = _BnRows.apply(x.reshape(rows, C).contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps), float(bn.momentum), int(relu))
+    return y.view(x.shape)
+
+
 def apply(layer, x):
     """`layer(x)` for an nn.Linear (through `linear`) or any other module"""
     return linear(x, layer.weight, layer.bias) if isinstance(layer, torch.nn.Linear) else layer(x)
 
 
 def sequential(seq, x):
-    """`seq(x)` for an nn.Sequential of Linear / BatchNorm1d / ReLU acting on (rows, C)"""
-    for layer in seq:
+    """`seq(x)` for an nn.Sequential of Linear / BatchNorm1d / ReLU acting on (..., C): Linear through `linear`, BatchNorm1d (+ a directly
+    following ReLU) through `batch_norm`"""
+    layers = list(seq)
+    i = 0
+    while i < len(layers):
+        layer = layers[i]
+        if isinstance(layer, torch.nn.BatchNorm1d):
+            fuse = i + 1 < len(layers) and isinstance(layers[i + 1], torch.nn.ReLU)
+            x = batch_norm(x, layer, relu=fuse)
+            i += 2 if fuse else 1
+            continue
         x = apply(layer, x)
+        i += 1
     return x

@@ -257,6 +257,19 @@ int cbl_skinny_linear_backward_input(long long rows, int cin, int cout, const fl
 int cbl_skinny_linear_backward_weight(long long rows, int cin, int cout, const float* x, const float* grad_y, float* grad_weight, float* grad_bias,
                                       void* stream);
 
+/* a4 / a5, dense part: train-mode nn.BatchNorm1d (+ ReLU) over (rows, C) activations, rows = n or n*K  pytorch/model/blocks.py:25-28,38-40,70,74,126-134
+ *   y = [relu]((x - mean_batch) / sqrt(var_batch + eps) * weight + bias); running_mean / running_var updated in place like torch
+ *   (momentum, unbiased variance; either may be NULL); save_mean / save_invstd (C) are kept for the backward call.  weight / bias may be NULL.
+ *   backward: grad_x (rows,C), grad_weight (C), grad_bias (C) (written, not accumulated; the last two may be NULL); `relu` masks grad_y
+ *   where the forward output was 0.  C <= 1024 (C % 4 != 0: C <= 256).  workspace: cbl_bn_rows_workspace_bytes. */
+size_t cbl_bn_rows_workspace_bytes(long long rows, int C);
+int cbl_bn_rows_forward(long long rows, int C, const float* x, const float* weight, const float* bias, float eps, float momentum,
+                        float* running_mean, float* running_var, int relu, float* save_mean, float* save_invstd, float* y,
+                        void* workspace, size_t workspace_bytes, void* stream);
+int cbl_bn_rows_backward(long long rows, int C, const float* x, const float* grad_y, const float* weight, const float* bias,
+                         const float* save_mean, const float* save_invstd, int relu, float* grad_x, float* grad_weight, float* grad_bias,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 /* ind_max_pool / ind_closest_pool  tensorflow/models/basic_operators.py:155-172 / :175-192
  *   x (n1,d), inds (n2,k) i32 (pad = n1) -> out (n2,d): max over the row's entries (shadow row = column-wise min of x; scratch_d (d) u32)
  *   / the entry of the FIRST column (shadow row = 0) */

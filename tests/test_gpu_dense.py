@@ -39,3 +39,45 @@ def test_linear_falls_back_to_torch_outside_its_range():
     assert torch.equal(dense.linear(x, w), torch.nn.functional.linear(x, w))
     x3 = torch.randn(50, 16, 3, device="cuda"); w3 = torch.randn(3, 3, device="cuda"); b3 = torch.randn(3, device="cuda")
     assert dense.linear(x3, w3, b3).shape == (50, 16, 3)
+
+
+@pytest.mark.parametrize("shape,relu", [((163840, 64), True), ((163840, 3), True), ((163840, 8), False), ((40960, 32), True),
+                                        ((10240, 16, 64), True), ((5000, 6), False), ((20000, 512), True), ((4096, 100), True)])
+def test_batch_norm_rows_matches_torch(shape, relu):
+    """dense.batch_norm (csrc/bn_rows.hip) against nn.BatchNorm1d (+ ReLU) in float64: output, input / affine gradients, running statistics"""
+    import copy
+    from contrastboundary_amd import dense
+    torch.manual_seed(shape[0] % 89)
+    C = shape[-1]
+    bn = torch.nn.BatchNorm1d(C).cuda().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5); bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
+    ref = copy.deepcopy(bn).double()
+    x = (torch.randn(*shape, device="cuda") * 1.7 + 0.3).requires_grad_(True)
+    g = torch.randn(*shape, device="cuda")
+    y = dense.batch_norm(x, bn, relu=relu)
+    y.backward(g)
+    x64 = x.detach().double().requires_grad_(True)
+    r = ref(x64.reshape(-1, C)).view(shape)
+    if relu:
+        r = torch.relu(r)
+    r.backward(g.double())
+    close = lambda a, b, tol: float((a.double() - b).abs().max()) <= tol * max(float(b.abs().max()), 1e-30)
+    assert close(y.detach(), r.detach(), 2e-5)
+    # a ReLU decision may flip where |y| ~ 1e-7: compare the gradients in L2
+    l2 = lambda a, b: float((a.double() - b).norm() / b.norm())
+    assert l2(x.grad, x64.grad) < 1e-4
+    assert l2(bn.weight.grad, ref.weight.grad) < 1e-4 and l2(bn.bias.grad, ref.bias.grad) < 1e-4
+    assert close(bn.running_mean, ref.running_mean, 1e-5) and close(bn.running_var, ref.running_var, 1e-5)
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == 1
+
+
+def test_batch_norm_eval_mode_and_small_inputs_use_torch():
+    from contrastboundary_amd import dense
+    bn = torch.nn.BatchNorm1d(16).cuda().eval()
+    x = torch.randn(10000, 16, device="cuda")
+    assert torch.equal(dense.batch_norm(x, bn, relu=True), torch.relu(bn(x)))
+    bn.train()
+    xs = torch.randn(100, 16, device="cuda")
+    bn2 = torch.nn.BatchNorm1d(16).cuda().train()
+    assert torch.allclose(dense.batch_norm(xs, bn, relu=False), bn2(xs), atol=1e-6)
