@@ -4,7 +4,7 @@
 // threshold + reduce + element kernels backward at ~1.4 TB/s; here the same mathematics is 2 streaming passes forward and 2
 // backward with the ReLU folded in:
 //   forward   pass 1: per-workgroup partial sums of x and x^2 per channel (fp32 over <= ~100 rows per lane, combined in fp64)
-//             finalize (one workgroup): mean, biased variance -> invstd; running statistics updated like nn.BatchNorm1d
+//             finalize (16 channels per workgroup): mean, biased variance -> invstd; running statistics updated like nn.BatchNorm1d
 //             (momentum, unbiased variance)
 //             pass 2: y = max(0, (x - mean) * invstd * weight + bias)
 //   backward  pass 1: partial sums of g and g * xhat per channel, g = grad_y masked by (y > 0) recomputed from x
@@ -92,14 +92,31 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_partial_kernel(long long rows, in
     }
 }
 
+// sum of the per-workgroup partials of 16 channels by one 256-lane workgroup: lane (channel cs, slice js) adds every 16th partial,
+// the 16 slices are combined through LDS in fp64.  (One lane per channel walking all partials was a 70 us dependent-load chain.)
+__device__ __forceinline__ void bn_sum_partials(int C, int nblocks, const float* __restrict__ partial, int c, int js, double (*red)[16][2],
+                                                double& s0, double& s1)
+{
+    double a0 = 0.0, a1 = 0.0;
+    if (c < C)
+        for (int b = js; b < nblocks; b += 16) { a0 += (double)partial[((size_t)b * 2) * C + c]; a1 += (double)partial[((size_t)b * 2 + 1) * C + c]; }
+    red[js][threadIdx.x & 15][0] = a0; red[js][threadIdx.x & 15][1] = a1;
+    __syncthreads();
+    s0 = s1 = 0.0;
+    if (js == 0)
+        for (int j = 0; j < 16; j++) { s0 += red[j][threadIdx.x & 15][0]; s1 += red[j][threadIdx.x & 15][1]; }
+}
+
 // forward finalize: batch statistics, running statistics (nn.BatchNorm1d: momentum, unbiased variance)
 __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(long long rows, int C, int nblocks, const float* __restrict__ partial, float eps,
                                                               float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
                                                               float* __restrict__ mean, float* __restrict__ invstd)
 {
-    for (int c = blockIdx.x * 256 + threadIdx.x; c < C; c += gridDim.x * 256) {
-        double s0 = 0.0, s1 = 0.0;
-        for (int b = 0; b < nblocks; b++) { s0 += (double)partial[((size_t)b * 2) * C + c]; s1 += (double)partial[((size_t)b * 2 + 1) * C + c]; }
+    __shared__ double red[16][16][2];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), js = threadIdx.x >> 4;
+    double s0, s1;
+    bn_sum_partials(C, nblocks, partial, c, js, red, s0, s1);
+    if (js == 0 && c < C) {
         const double mu = s0 / (double)rows;
         double var = s1 / (double)rows - mu * mu;
         if (var < 0.0) var = 0.0;
@@ -117,9 +134,11 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(long long rows, in
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(long long rows, int C, int nblocks, const float* __restrict__ partial,
                                                               float* __restrict__ grad_weight, float* __restrict__ grad_bias, float* __restrict__ coef)
 {
-    for (int c = blockIdx.x * 256 + threadIdx.x; c < C; c += gridDim.x * 256) {
-        double s0 = 0.0, s1 = 0.0;
-        for (int b = 0; b < nblocks; b++) { s0 += (double)partial[((size_t)b * 2) * C + c]; s1 += (double)partial[((size_t)b * 2 + 1) * C + c]; }
+    __shared__ double red[16][16][2];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), js = threadIdx.x >> 4;
+    double s0, s1;
+    bn_sum_partials(C, nblocks, partial, c, js, red, s0, s1);
+    if (js == 0 && c < C) {
         if (grad_bias) grad_bias[c] = (float)s0;
         if (grad_weight) grad_weight[c] = (float)s1;
         coef[c] = (float)(s0 / (double)rows);
@@ -197,7 +216,7 @@ CBL_EXPORT int cbl_bn_rows_forward(long long rows, int C, const float* x, const 
     if (s1.slots < 1) return CBL_ERR_UNSUPPORTED;
     if (vec) hipLaunchKernelGGL((bn_partial_kernel<4, 0>), dim3(s1.nblocks), dim3(BN_BLOCK), 0, st, rows, C, s1.tpr, s1.slots, s1.rows_per_block, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0, partial);
     else     hipLaunchKernelGGL((bn_partial_kernel<1, 0>), dim3(s1.nblocks), dim3(BN_BLOCK), 0, st, rows, C, s1.tpr, s1.slots, s1.rows_per_block, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0, partial);
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(cbl_div_up(C, 256)), dim3(256), 0, st, rows, C, s1.nblocks, partial, eps, momentum, running_mean, running_var, save_mean, save_invstd);
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(cbl_div_up(C, 16)), dim3(256), 0, st, rows, C, s1.nblocks, partial, eps, momentum, running_mean, running_var, save_mean, save_invstd);
     const dim3 grid(cbl_grid_for(rows * (C / (vec ? 4 : 1)), BN_BLOCK, 4096));
     if (vec) hipLaunchKernelGGL((bn_element_kernel<4, 0>), grid, dim3(BN_BLOCK), 0, st, rows, C, x, nullptr, save_mean, save_invstd, weight, bias, nullptr, relu, y);
     else     hipLaunchKernelGGL((bn_element_kernel<1, 0>), grid, dim3(BN_BLOCK), 0, st, rows, C, x, nullptr, save_mean, save_invstd, weight, bias, nullptr, relu, y);
@@ -222,7 +241,7 @@ CBL_EXPORT int cbl_bn_rows_backward(long long rows, int C, const float* x, const
     if (s1.slots < 1) return CBL_ERR_UNSUPPORTED;
     if (vec) hipLaunchKernelGGL((bn_partial_kernel<4, 1>), dim3(s1.nblocks), dim3(BN_BLOCK), 0, st, rows, C, s1.tpr, s1.slots, s1.rows_per_block, x, grad_y, save_mean, save_invstd, weight, bias, relu, partial);
     else     hipLaunchKernelGGL((bn_partial_kernel<1, 1>), dim3(s1.nblocks), dim3(BN_BLOCK), 0, st, rows, C, s1.tpr, s1.slots, s1.rows_per_block, x, grad_y, save_mean, save_invstd, weight, bias, relu, partial);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cbl_div_up(C, 256)), dim3(256), 0, st, rows, C, s1.nblocks, partial, grad_weight, grad_bias, coef);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cbl_div_up(C, 16)), dim3(256), 0, st, rows, C, s1.nblocks, partial, grad_weight, grad_bias, coef);
     const dim3 grid(cbl_grid_for(rows * (C / (vec ? 4 : 1)), BN_BLOCK, 4096));
     if (vec) hipLaunchKernelGGL((bn_element_kernel<4, 1>), grid, dim3(BN_BLOCK), 0, st, rows, C, x, grad_y, save_mean, save_invstd, weight, bias, coef, relu, grad_x);
     else     hipLaunchKernelGGL((bn_element_kernel<1, 1>), grid, dim3(BN_BLOCK), 0, st, rows, C, x, grad_y, save_mean, save_invstd, weight, bias, coef, relu, grad_x);
