@@ -24,15 +24,18 @@ def side_stream(device):
     return s
 
 
-def prefetch(points, offset, stride=(1, 4, 4, 4, 4), nsample=(8, 16, 16, 16, 16), cbl_nsample=None, nstride=None, multi_head=True, stream=None):
+def prefetch(points, offset, stride=(1, 4, 4, 4, 4), nsample=(8, 16, 16, 16, 16), cbl_nsample=None, nstride=None, multi_head=True, stream=None,
+             cache=None, after_caller=True):
     """points (n,3) f32, offset (b) i32 on the GPU -> a `pointops.neighbor_cache` being filled on `stream` (default: the device's side
     stream).  cbl_nsample / nstride: the criterion's config.nsample / config.nstride (None: no CBL searches)."""
     dev = points.device
     stream = stream if stream is not None else side_stream(dev)
-    cache = pointops.neighbor_cache()
+    if cache is None:
+        cache = pointops.neighbor_cache()
+        cache.record_events = True
     cache.keep = True                    # entries outlive the `with` used to fill them
-    cache.record_events = True
-    stream.wait_stream(torch.cuda.current_stream(dev))              # the inputs were produced on the caller's stream
+    if after_caller:
+        stream.wait_stream(torch.cuda.current_stream(dev))          # the inputs were produced on the caller's stream
     with torch.cuda.stream(stream), torch.no_grad(), cache:
         p, o = [points], [offset]
         for s in range(1, len(stride)):                             # TransitionDown of stage s (blocks.py:61-69)
@@ -54,3 +57,40 @@ def prefetch(points, offset, stride=(1, 4, 4, 4, 4), nsample=(8, 16, 16, 16, 16)
                     pointops.knnquery_raw(kr, p[0], p[s], o[0], o[s], algo="set")                 # sub-scene labels (basic_operators.py:22-30)
     cache.hits = cache.misses = 0
     return cache
+
+
+class StaticGeometry:
+    """Geometry of one batch in FIXED device tensors, for a training step captured in a hipGraph (torch.cuda.CUDAGraph): the graph bakes
+    the addresses of the index / coordinate tensors in, `refresh` recomputes them for the next batch (on a side stream) and copies the
+    results over the old ones.  Batches must have the shapes of the first one (same cloud sizes)."""
+
+    def __init__(self, points, offset, **plan):
+        self.plan = plan
+        self.points, self.offset = points, offset                   # the static input tensors (refreshed in place by the caller)
+        self.cache = pointops.neighbor_cache()
+        self.cache.ignore_version = True
+        prefetch(points, offset, stream=torch.cuda.current_stream(points.device), cache=self.cache, **plan)
+        self.ready = None
+
+    def refresh(self, stream=None):
+        """recompute for the CURRENT contents of self.points / self.offset; returns after enqueueing (self.ready = event)"""
+        dev = self.points.device
+        stream = stream if stream is not None else side_stream(dev)
+        fresh = prefetch(self.points, self.offset, stream=stream, after_caller=False, **self.plan)   # ordering is the caller's (events)
+        with torch.cuda.stream(stream), torch.no_grad():
+            old, new = list(self.cache.store.values()), list(fresh.store.values())
+            assert len(old) == len(new)
+            for (o_outs, *_), (n_outs, *_) in zip(old, new):
+                for a, b in zip(o_outs, n_outs):
+                    assert a.shape == b.shape, "StaticGeometry: the batch changed shape"
+                    a.copy_(b)
+            self.ready = torch.cuda.Event()
+            self.ready.record(stream)
+        fresh.store.clear(); fresh.host.clear()
+        return self.ready
+
+    def __enter__(self):
+        return self.cache.__enter__()
+
+    def __exit__(self, *exc):
+        return self.cache.__exit__(*exc)

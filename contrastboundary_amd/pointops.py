@@ -134,9 +134,15 @@ class neighbor_cache:
     def active():
         return getattr(neighbor_cache._tls, "cache", None)
 
-    @staticmethod
-    def _key(kind, algo, tensors):
+    ignore_version = False               # static geometry (geometry.StaticGeometry): tensors are refreshed IN PLACE between uses
+
+    def _key(self, kind, algo, tensors):
+        if self.ignore_version:
+            return (kind, algo) + tuple((t.data_ptr(), tuple(t.shape)) for t in tensors)
         return (kind, algo) + tuple((t.data_ptr(), tuple(t.shape), t._version) for t in tensors)
+
+    def _host_key(self, o):
+        return (o.data_ptr(), tuple(o.shape)) if self.ignore_version else (o.data_ptr(), tuple(o.shape), o._version)
 
     # Entries may have been produced on ANOTHER stream (geometry prefetch, contrastboundary_amd/geometry.py): each carries the
     # event recorded behind its producer; a consumer stream waits for it and is registered with the allocator as a user.
@@ -184,7 +190,7 @@ def host_offsets(o):
     cache = neighbor_cache.active()
     if cache is None:
         return o.cpu().tolist()
-    key = (o.data_ptr(), tuple(o.shape), o._version)
+    key = cache._host_key(o)
     hit = cache.host.get(key)
     if hit is None:
         hit = cache.host[key] = (o.cpu().tolist(), o)
@@ -211,7 +217,7 @@ def fps_downsample(p, o, stride):
     idx = _furthestsampling_raw(p, o, new_o, max(lens) if lens else 0, run)
     new_p = p[idx.long(), :]
     if cache is not None:
-        cache.host[(new_o.data_ptr(), tuple(new_o.shape), new_o._version)] = (new_ends, new_o, staged)
+        cache.host[cache._host_key(new_o)] = (new_ends, new_o, staged)
         cache.insert_fps(stride, (p, o), new_p, new_o, idx)
     return new_p, new_o, idx
 

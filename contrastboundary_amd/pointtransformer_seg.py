@@ -216,3 +216,71 @@ def prefetch_geometry(model, inputs, criterion=None):
     cbl = criterion is not None and getattr(criterion, "contrast_head", None) is not None
     return geometry.prefetch(inputs["points"], inputs["offset"], stride=model.STRIDE, nsample=model.NSAMPLE,
                              cbl_nsample=cfg.nsample if cbl else None, nstride=cfg.nstride if cbl else None, multi_head=model.head is not None)
+
+
+class GraphedTrainStep:
+    """forward + criterion + backward + optimizer step captured once in a hipGraph and replayed per batch — the network is ~2700 kernel
+    launches per step, which bounds an eagerly issued step by the host.  Two buffer sets (inputs, geometry, graph) alternate: while set
+    A replays, the geometry of the next batch (furthest point sampling: one workgroup on one CU) is refreshed into set B on a side
+    stream.  All batches must have the first batch's shapes (fixed points per scene, as the reference's voxel_max crop gives)."""
+
+    def __init__(self, model, criterion, optimizer, inputs, target, warmup=3):
+        from . import geometry
+        self.model, self.criterion, self.optimizer = model, criterion, optimizer
+        plan = dict(stride=model.STRIDE, nsample=model.NSAMPLE, multi_head=model.head is not None)
+        if getattr(criterion, "contrast_head", None) is not None:
+            plan.update(cbl_nsample=model.config.nsample, nstride=model.config.nstride)
+        dev = inputs["points"].device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                               # eager warm-up on a side stream (workspaces, momentum buffers, autotune)
+            for _ in range(warmup):
+                optimizer.zero_grad(set_to_none=True)
+                _, _, loss, _ = forward_and_loss(model, criterion, inputs, target)
+                loss.sum().backward()
+                optimizer.step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.sets = []
+        for _ in range(2):
+            st_in = {k: v.clone() for k, v in inputs.items()}
+            st_tg = target.clone()
+            geom = geometry.StaticGeometry(st_in["points"], st_in["offset"], **plan)
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            optimizer.zero_grad(set_to_none=True)
+            with torch.cuda.graph(graph):
+                out, _, loss, _ = forward_and_loss(model, criterion, st_in, st_tg, geometry=geom)
+                loss.sum().backward()
+                optimizer.step()
+            self.sets.append(dict(inputs=st_in, target=st_tg, geom=geom, graph=graph, loss=loss, logits=out))
+        self.turn = 0
+        self._staged = False
+
+    def stage(self, inputs, target):
+        """copy the NEXT batch into the idle buffer set and start its geometry — all on the side stream, behind nothing but the last
+        replay that read this buffer set"""
+        from . import geometry
+        s = self.sets[self.turn]
+        dev = s["target"].device
+        side = geometry.side_stream(dev)
+        if s.get("done") is not None:
+            side.wait_event(s["done"])
+        with torch.cuda.stream(side):
+            for k, v in inputs.items():
+                s["inputs"][k].copy_(v, non_blocking=True)
+            s["target"].copy_(target, non_blocking=True)
+        s["geom"].refresh(side)
+        self._staged = True
+
+    def run(self):
+        """replay the staged batch -> (loss vector, logits) living in static buffers (valid until this set is replayed again)"""
+        assert self._staged, "stage(inputs, target) first"
+        s = self.sets[self.turn]
+        cur = torch.cuda.current_stream(s["target"].device)
+        cur.wait_event(s["geom"].ready)
+        s["graph"].replay()
+        s["done"] = torch.cuda.Event()
+        s["done"].record(cur)
+        self.turn ^= 1
+        self._staged = False
+        return s["loss"], s["logits"]

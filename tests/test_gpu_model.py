@@ -91,3 +91,61 @@ def test_geometry_prefetch_on_a_side_stream_answers_every_request():
     torch.cuda.synchronize()
     assert torch.equal(a, b) and torch.equal(la, lb)
     assert nc1.misses == 0 and nc1.hits == nc0.hits + nc0.misses
+
+
+@pytest.mark.gpu
+def test_graphed_training_step_matches_eager_steps():
+    """the whole step (forward, criterion, backward, SGD) replayed from a hipGraph with double-buffered static geometry gives the same
+    training trajectory as eagerly issued steps (atomics make the two differ in the last bits only)"""
+    import copy
+    M, model, crit, g = build(CASES[0])
+    model = model.cuda().train()
+    twin = copy.deepcopy(model)
+    inputs = {"points": torch.from_numpy(g("xyz")).cuda(), "features": torch.from_numpy(g("feat")).cuda(), "offset": torch.from_numpy(g("offset")).cuda()}
+    target = torch.from_numpy(g("target")).cuda()
+    # a second batch with the same shapes: the scene mirrored in x, labels rolled
+    inputs2 = {"points": (inputs["points"] * torch.tensor([-1.0, 1.0, 1.0], device="cuda")).contiguous(), "features": inputs["features"].flip(0).contiguous(),
+               "offset": inputs["offset"].clone()}
+    target2 = target.roll(17)
+    batches = [(inputs, target), (inputs2, target2), (inputs, target), (inputs2, target2)]
+
+    opt_e = torch.optim.SGD(twin.parameters(), lr=0.002, momentum=0.9)
+    eager = []
+    for b_in, b_tg in batches:
+        opt_e.zero_grad(set_to_none=True)
+        _, _, loss, _ = M.forward_and_loss(twin, crit, b_in, b_tg)
+        loss.sum().backward()
+        opt_e.step()
+        eager.append(loss.detach().cpu().numpy())
+
+    opt_g = torch.optim.SGD(model.parameters(), lr=0.002, momentum=0.9)
+    snapshot = copy.deepcopy(model.state_dict())
+    step = M.GraphedTrainStep(model, crit, opt_g, inputs, target, warmup=1)      # its warm-up / capture steps train the model: rewind
+    model.load_state_dict(snapshot)
+    for st in opt_g.state.values():
+        if "momentum_buffer" in st and st["momentum_buffer"] is not None:
+            st["momentum_buffer"].zero_()
+    graphed = []
+    step.stage(*batches[0])
+    for i in range(len(batches)):
+        loss, _ = step.run()
+        if i + 1 < len(batches):
+            step.stage(*batches[i + 1])
+        graphed.append(loss.detach().cpu().numpy().copy())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(graphed[0], eager[0], rtol=2e-3, atol=1e-5)          # same parameters, same batch: the forward pass itself
+    for a, b in zip(graphed[1:], eager[1:]):                                        # later steps: trajectories drift apart slowly (fp32 atomics)
+        np.testing.assert_allclose(a, b, rtol=3e-2, atol=1e-4)
+    w_g, w_e = model.enc1[0].linear.weight.detach(), twin.enc1[0].linear.weight.detach()
+    assert float((w_g - w_e).norm() / w_e.norm()) < 1e-2
+    # the in-place refresh really holds the staged batch's geometry: bitwise the eagerly computed one
+    from contrastboundary_amd import geometry
+    step.stage(inputs2, target2)
+    torch.cuda.synchronize()
+    static = step.sets[step.turn]["geom"]
+    fresh = M.prefetch_geometry(model, {"points": static.points, "offset": static.offset}, crit)
+    torch.cuda.synchronize()
+    assert torch.equal(static.points, inputs2["points"])
+    for (a_outs, *_), (b_outs, *_) in zip(static.cache.store.values(), fresh.store.values()):
+        for a, b in zip(a_outs, b_outs):
+            assert torch.equal(a, b)

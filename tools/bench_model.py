@@ -17,6 +17,7 @@ ap.add_argument("--n", type=int, default=40960); ap.add_argument("--scenes", typ
 ap.add_argument("--steps", type=int, default=10); ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--no-cache", action="store_true")
 ap.add_argument("--blas", default="cublas", help="torch.backends.cuda.preferred_blas_library: 'cublas' = rocBLAS (default here: 2-20x faster than hipBLASLt on this network's small weight-gradient GEMMs), 'cublaslt' = torch's default")
+ap.add_argument("--graph", action="store_true", help="the whole training step as a replayed hipGraph, geometry double-buffered (implies prefetch)")
 ap.add_argument("--prefetch", action="store_true", help="geometry (FPS + every neighbour search) of the NEXT step on a side stream, one step ahead")
 a = ap.parse_args()
 torch.backends.cuda.preferred_blas_library(a.blas)
@@ -50,6 +51,15 @@ def step():
     return loss, nc
 
 
+if a.graph:
+    gstep = M.GraphedTrainStep(model, crit, opt, inputs, target)
+    gstep.stage(inputs, target)
+
+    def step():                                                      # replay batch t while batch t+1 is staged (here: the same scene again)
+        loss, _ = gstep.run()
+        gstep.stage(inputs, target)
+        return loss, None
+
 for _ in range(a.warmup):
     step()
 torch.cuda.synchronize()
@@ -60,4 +70,4 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
 print(json.dumps({"workload": f"PointTransformerSeg+CBL train step, {a.scenes} x S-room({a.n})", "ms_per_step": dt * 1e3,
                   "points_per_s": a.n * a.scenes / dt, "knn_requests": None if nc is None else nc.hits + nc.misses,
-                  "knn_searches": None if nc is None else nc.misses, "geometry_prefetch": bool(a.prefetch), "blas": a.blas, "loss": [round(float(v), 5) for v in loss.detach().cpu()]}))
+                  "knn_searches": None if nc is None else nc.misses, "geometry_prefetch": bool(a.prefetch or a.graph), "hipgraph": bool(a.graph), "blas": a.blas, "loss": [round(float(v), 5) for v in loss.detach().cpu()]}))
