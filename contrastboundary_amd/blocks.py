@@ -44,9 +44,11 @@ class PointTransformerLayer(nn.Module):
             idx, _ = pointops.knnquery(self.nsample, p, p, o, o)              # once, not twice (:34-35)
         p_r = pointops.queryandgroup(self.nsample, p, p, p.new_zeros((p.shape[0], 0)), idx, o, o, use_xyz=True)   # (n,K,3) relative xyz
         p_r = dense.sequential(self.linear_p, p_r)                            # :38  Linear(3,3) -> BN -> ReLU -> Linear(3,C) over (n*K) rows
-        k_minus_q = -pointops.subtraction(x_q.contiguous(), x_k.contiguous(), idx)     # x_k[idx] - x_q  (n,K,c)
+        q_minus_k = pointops.subtraction(x_q.contiguous(), x_k.contiguous(), idx)      # x_q - x_k[idx]  (n,K,c)
         n, K, c = p_r.shape
-        w = k_minus_q + p_r.view(n, K, self.out_planes // self.mid_planes, self.mid_planes).sum(2)   # :39
+        ratio = self.out_planes // self.mid_planes                            # 1 in every shipped configuration: the fold below is a no-op then
+        pe = p_r if ratio == 1 else p_r.view(n, K, ratio, self.mid_planes).sum(2)
+        w = pe - q_minus_k                                                    # x_k[idx] - x_q + p_r  (:39), one pass instead of negate + add
         w = dense.sequential(self.linear_w, w)                                # :40  BN -> ReLU -> Linear -> BN -> ReLU -> Linear
         w = self.softmax(w)                                                   # over K, :41
         return pointops.aggregation(x_v.contiguous(), p_r.contiguous(), w.contiguous(), idx)   # :42-43
