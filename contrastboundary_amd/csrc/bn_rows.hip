@@ -110,9 +110,11 @@ __device__ __forceinline__ void bn_sum_partials(int C, int nblocks, const float*
 // forward finalize: batch statistics, running statistics (nn.BatchNorm1d: momentum, unbiased variance)
 __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(long long rows, int C, int nblocks, const float* __restrict__ partial, float eps,
                                                               float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                              long long* __restrict__ num_batches_tracked,
                                                               float* __restrict__ mean, float* __restrict__ invstd)
 {
     __shared__ double red[16][16][2];
+    if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) num_batches_tracked[0] += 1;   // nn.BatchNorm1d's counter, no launch of its own
     const int c = blockIdx.x * 16 + (threadIdx.x & 15), js = threadIdx.x >> 4;
     double s0, s1;
     bn_sum_partials(C, nblocks, partial, c, js, red, s0, s1);
@@ -200,8 +202,8 @@ CBL_EXPORT size_t cbl_bn_rows_workspace_bytes(long long rows, int C)
 }
 
 CBL_EXPORT int cbl_bn_rows_forward(long long rows, int C, const float* x, const float* weight, const float* bias, float eps, float momentum,
-                                   float* running_mean, float* running_var, int relu, float* save_mean, float* save_invstd, float* y,
-                                   void* workspace, size_t workspace_bytes, void* stream)
+                                   float* running_mean, float* running_var, long long* num_batches_tracked, int relu, float* save_mean,
+                                   float* save_invstd, float* y, void* workspace, size_t workspace_bytes, void* stream)
 {
     const int rc = bn_check(rows, C);
     if (rc) return rc;
@@ -216,7 +218,7 @@ CBL_EXPORT int cbl_bn_rows_forward(long long rows, int C, const float* x, const 
     if (s1.slots < 1) return CBL_ERR_UNSUPPORTED;
     if (vec) hipLaunchKernelGGL((bn_partial_kernel<4, 0>), dim3(s1.nblocks), dim3(BN_BLOCK), 0, st, rows, C, s1.tpr, s1.slots, s1.rows_per_block, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0, partial);
     else     hipLaunchKernelGGL((bn_partial_kernel<1, 0>), dim3(s1.nblocks), dim3(BN_BLOCK), 0, st, rows, C, s1.tpr, s1.slots, s1.rows_per_block, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0, partial);
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(cbl_div_up(C, 16)), dim3(256), 0, st, rows, C, s1.nblocks, partial, eps, momentum, running_mean, running_var, save_mean, save_invstd);
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(cbl_div_up(C, 16)), dim3(256), 0, st, rows, C, s1.nblocks, partial, eps, momentum, running_mean, running_var, num_batches_tracked, save_mean, save_invstd);
     const dim3 grid(cbl_grid_for(rows * (C / (vec ? 4 : 1)), BN_BLOCK, 4096));
     if (vec) hipLaunchKernelGGL((bn_element_kernel<4, 0>), grid, dim3(BN_BLOCK), 0, st, rows, C, x, nullptr, save_mean, save_invstd, weight, bias, nullptr, relu, y);
     else     hipLaunchKernelGGL((bn_element_kernel<1, 0>), grid, dim3(BN_BLOCK), 0, st, rows, C, x, nullptr, save_mean, save_invstd, weight, bias, nullptr, relu, y);

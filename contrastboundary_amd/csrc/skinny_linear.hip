@@ -6,7 +6,8 @@
 //   forward / input gradient:  one lane per output element, weights in LDS (row stride padded), the row's inputs read through L1
 //                              (the C_out lanes of a row read the same addresses);
 //   weight / bias gradient:    a workgroup stages tiles of rows of x and dy in LDS, every lane owns a few (c_out, c_in) pairs and
-//                              accumulates over the workgroup's rows in registers, one atomic per pair and workgroup at the end.
+//                              accumulates over the workgroup's rows in registers; the <= 768 workgroup partials are summed in fp64
+//                              by a second small kernel (plain stores: no pre-zeroed outputs, no atomics).
 // fp32 FMA chains in index order; results differ from a GEMM library's by summation order only.
 #include "cbl_common.h"
 
@@ -46,10 +47,11 @@ __global__ __launch_bounds__(SL_BLOCK) void skinny_linear_kernel(long long rows,
     }
 }
 
-// dw[c, a] += sum_r dy[r, c] * x[r, a];   db[c] += sum_r dy[r, c]
+// partial[b][c*cin + a] = sum over workgroup b's rows of dy[r, c] * x[r, a];   partial[b][cin*cout + c] = sum of dy[r, c]
 constexpr int SL_TILE = 64;                                         // rows per LDS tile
+constexpr int SL_WGRAD_BLOCKS = 768;
 __global__ __launch_bounds__(SL_BLOCK) void skinny_linear_wgrad_kernel(long long rows, int cin, int cout, const float* __restrict__ x,
-                                                                       const float* __restrict__ dy, float* __restrict__ dw, float* __restrict__ db)
+                                                                       const float* __restrict__ dy, float* __restrict__ partial, int want_bias)
 {
     extern __shared__ float tile[];                                 // x tile [SL_TILE][cin + 1], dy tile [SL_TILE][cout + 1]
     const int lx = cin + 1, ly = cout + 1;
@@ -77,18 +79,38 @@ __global__ __launch_bounds__(SL_BLOCK) void skinny_linear_wgrad_kernel(long long
                 acc[j] += s;
             }
         }
-        if (db && threadIdx.x < cout) {
+        if (want_bias && threadIdx.x < cout) {
             float s = 0.f;
             for (int r = 0; r < nr; r++) s += ys[r * ly + threadIdx.x];
             accb += s;
         }
     }
+    float* mine = partial + (size_t)blockIdx.x * (npairs + cout);
 #pragma unroll
     for (int j = 0; j < PAIRS; j++) {
         const int pidx = threadIdx.x + j * SL_BLOCK;
-        if (pidx < npairs) unsafeAtomicAdd(dw + pidx, acc[j]);
+        if (pidx < npairs) mine[pidx] = acc[j];
     }
-    if (db && threadIdx.x < cout) unsafeAtomicAdd(db + threadIdx.x, accb);
+    if (threadIdx.x < cout) mine[npairs + threadIdx.x] = accb;
+}
+
+// dw / db = sum of the workgroup partials (fp64), 16 outputs x 16 slices per workgroup; plain stores: no pre-zeroed outputs, no atomics
+__global__ __launch_bounds__(256) void skinny_linear_wgrad_finalize_kernel(int npairs, int cout, int nblocks, const float* __restrict__ partial,
+                                                                           float* __restrict__ dw, float* __restrict__ db)
+{
+    __shared__ double red[16][16];
+    const int e = blockIdx.x * 16 + (threadIdx.x & 15), js = threadIdx.x >> 4, total = npairs + cout;
+    double a = 0.0;
+    if (e < total)
+        for (int b = js; b < nblocks; b += 16) a += (double)partial[(size_t)b * total + e];
+    red[js][threadIdx.x & 15] = a;
+    __syncthreads();
+    if (js == 0 && e < total) {
+        double s0 = 0.0;
+        for (int j = 0; j < 16; j++) s0 += red[j][threadIdx.x & 15];
+        if (e < npairs) dw[e] = (float)s0;
+        else if (db) db[e - npairs] = (float)s0;
+    }
 }
 
 int sl_check(long long rows, int cin, int cout)
@@ -131,15 +153,32 @@ CBL_EXPORT int cbl_skinny_linear_backward_input(long long rows, int cin, int cou
     return cbl_status();
 }
 
+CBL_EXPORT size_t cbl_skinny_linear_workspace_bytes(int cin, int cout)
+{
+    if (sl_check(0, cin, cout) != CBL_OK) return 0;
+    return sizeof(float) * (size_t)SL_WGRAD_BLOCKS * ((size_t)cin * cout + cout) + 256;
+}
+
 CBL_EXPORT int cbl_skinny_linear_backward_weight(long long rows, int cin, int cout, const float* x, const float* grad_y, float* grad_weight, float* grad_bias,
-                                                 void* stream)
+                                                 void* workspace, size_t workspace_bytes, void* stream)
 {
     const int rc = sl_check(rows, cin, cout);
     if (rc) return rc;
-    if (rows == 0) return CBL_OK;
-    if (!x || !grad_y || !grad_weight) return CBL_ERR_BAD_ARG;
+    if (!grad_weight || !workspace) return CBL_ERR_BAD_ARG;
+    if (workspace_bytes < cbl_skinny_linear_workspace_bytes(cin, cout)) return CBL_ERR_WORKSPACE;
+    hipStream_t st = cbl_stream(stream);
+    if (rows == 0) {
+        (void)hipMemsetAsync(grad_weight, 0, sizeof(float) * (size_t)cin * cout, st);
+        if (grad_bias) (void)hipMemsetAsync(grad_bias, 0, sizeof(float) * cout, st);
+        return cbl_status();
+    }
+    if (!x || !grad_y) return CBL_ERR_BAD_ARG;
     const long long ntiles = (rows + SL_TILE - 1) / SL_TILE;
-    hipLaunchKernelGGL(skinny_linear_wgrad_kernel, dim3((unsigned)min(ntiles, 1024LL)), dim3(SL_BLOCK),
-                       sizeof(float) * (size_t)SL_TILE * (cin + 1 + cout + 1), cbl_stream(stream), rows, cin, cout, x, grad_y, grad_weight, grad_bias);
+    const int nblocks = (int)min(ntiles, (long long)SL_WGRAD_BLOCKS);
+    float* partial = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(skinny_linear_wgrad_kernel, dim3(nblocks), dim3(SL_BLOCK), sizeof(float) * (size_t)SL_TILE * (cin + 1 + cout + 1), st,
+                       rows, cin, cout, x, grad_y, partial, grad_bias ? 1 : 0);
+    hipLaunchKernelGGL(skinny_linear_wgrad_finalize_kernel, dim3(cbl_div_up(cin * cout + cout, 16)), dim3(256), 0, st, cin * cout, cout, nblocks, partial,
+                       grad_weight, grad_bias);
     return cbl_status();
 }

@@ -43,10 +43,12 @@ class _SkinnyLinear(Function):
             _lib.check(L.cbl_skinny_linear_backward_input(ctypes.c_longlong(rows), ctypes.c_int(cin), ctypes.c_int(cout), _lib.ptr(gy), _lib.ptr(weight),
                                                           _lib.ptr(gx), st), "cbl_skinny_linear_backward_input")
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            gw = torch.zeros_like(weight)
-            gb = torch.zeros(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            gw = torch.empty_like(weight)
+            gb = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            ws = _bn_workspace(L.cbl_skinny_linear_workspace_bytes(ctypes.c_int(cin), ctypes.c_int(cout)), x.device)
             _lib.check(L.cbl_skinny_linear_backward_weight(ctypes.c_longlong(rows), ctypes.c_int(cin), ctypes.c_int(cout), _lib.ptr(x), _lib.ptr(gy),
-                                                           _lib.ptr(gw), _lib.ptr(gb), st), "cbl_skinny_linear_backward_weight")
+                                                           _lib.ptr(gw), _lib.ptr(gb), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), st),
+                       "cbl_skinny_linear_backward_weight")
         return gx, gw, gb
 
 
@@ -65,7 +67,7 @@ MIN_ROWS_BN = 4096
 
 class _BnRows(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, relu):
+    def forward(ctx, x, weight, bias, running_mean, running_var, num_batches_tracked, eps, momentum, relu):
         rows, C = x.shape
         L = _lib.lib()
         ws = _bn_workspace(L.cbl_bn_rows_workspace_bytes(ctypes.c_longlong(rows), ctypes.c_int(C)), x.device)
@@ -73,7 +75,8 @@ class _BnRows(Function):
         invstd = torch.empty(C, dtype=torch.float32, device=x.device)
         y = torch.empty_like(x)
         _lib.check(L.cbl_bn_rows_forward(ctypes.c_longlong(rows), ctypes.c_int(C), _lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), ctypes.c_float(eps),
-                                         ctypes.c_float(momentum), _lib.ptr(running_mean), _lib.ptr(running_var), ctypes.c_int(relu), _lib.ptr(mean),
+                                         ctypes.c_float(momentum), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(num_batches_tracked),
+                                         ctypes.c_int(relu), _lib.ptr(mean),
                                          _lib.ptr(invstd), _lib.ptr(y), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(x)), "cbl_bn_rows_forward")
         ctx.save_for_backward(x, weight, bias, mean, invstd)
         ctx.relu = relu
@@ -92,7 +95,7 @@ class _BnRows(Function):
         _lib.check(L.cbl_bn_rows_backward(ctypes.c_longlong(rows), ctypes.c_int(C), _lib.ptr(x), _lib.ptr(gy), _lib.ptr(weight), _lib.ptr(bias),
                                           _lib.ptr(mean), _lib.ptr(invstd), ctypes.c_int(ctx.relu), _lib.ptr(gx), _lib.ptr(gw), _lib.ptr(gb),
                                           _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(x)), "cbl_bn_rows_backward")
-        return gx, gw, gb, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None
 
 
 _bn_ws = {}
@@ -118,9 +121,8 @@ def batch_norm(x, bn, relu=False):
     if not fused:
         y = bn(x.reshape(-1, C)).view(x.shape)
         return F.relu(y) if relu else y
-    if bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-    y = _BnRows.apply(x.reshape(rows, C).contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps), float(bn.momentum), int(relu))
+    y = _BnRows.apply(x.reshape(rows, C).contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                      float(bn.eps), float(bn.momentum), int(relu))
     return y.view(x.shape)
 
 

@@ -250,22 +250,25 @@ int cbl_pospool_backward(int n, int n0, int K, int C, const float* query_points,
 /* a4, dense part of the vector attention: nn.Linear over (n*K) rows with tiny widths — linear_p = Linear(3,3), Linear(3,C) and
  * linear_w = Linear(C,C/8), Linear(C/8,C/8)  pytorch/model/blocks.py:23-28,38-40 — as streaming kernels instead of library GEMMs.
  *   x (rows,cin), weight (cout,cin), bias (cout) or NULL -> y (rows,cout) = x @ weight^T + bias
- *   backward_input:  grad_x (rows,cin) = grad_y @ weight            backward_weight: grad_weight (cout,cin) += grad_y^T @ x, grad_bias (cout) +=
- *   (caller pre-zeroes the += outputs; grad_bias may be NULL).  cin*cout <= 4096 and cin+cout <= 200, else CBL_ERR_UNSUPPORTED. */
+ *   backward_input:  grad_x (rows,cin) = grad_y @ weight            backward_weight: grad_weight (cout,cin) = grad_y^T @ x, grad_bias (cout) = column sums of grad_y
+ *   (grad_weight / grad_bias are written, not accumulated; grad_bias may be NULL; workspace: cbl_skinny_linear_workspace_bytes).
+ *   cin*cout <= 4096 and cin+cout <= 200, else CBL_ERR_UNSUPPORTED. */
+size_t cbl_skinny_linear_workspace_bytes(int cin, int cout);
 int cbl_skinny_linear_forward(long long rows, int cin, int cout, const float* x, const float* weight, const float* bias, float* y, void* stream);
 int cbl_skinny_linear_backward_input(long long rows, int cin, int cout, const float* grad_y, const float* weight, float* grad_x, void* stream);
 int cbl_skinny_linear_backward_weight(long long rows, int cin, int cout, const float* x, const float* grad_y, float* grad_weight, float* grad_bias,
-                                      void* stream);
+                                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* a4 / a5, dense part: train-mode nn.BatchNorm1d (+ ReLU) over (rows, C) activations, rows = n or n*K  pytorch/model/blocks.py:25-28,38-40,70,74,126-134
  *   y = [relu]((x - mean_batch) / sqrt(var_batch + eps) * weight + bias); running_mean / running_var updated in place like torch
- *   (momentum, unbiased variance; either may be NULL); save_mean / save_invstd (C) are kept for the backward call.  weight / bias may be NULL.
+ *   (momentum, unbiased variance; either may be NULL; *num_batches_tracked += 1 if not NULL); save_mean / save_invstd (C) are kept for the
+ *   backward call.  weight / bias may be NULL.
  *   backward: grad_x (rows,C), grad_weight (C), grad_bias (C) (written, not accumulated; the last two may be NULL); `relu` masks grad_y
  *   where the forward output was 0.  C <= 1024 (C % 4 != 0: C <= 256).  workspace: cbl_bn_rows_workspace_bytes. */
 size_t cbl_bn_rows_workspace_bytes(long long rows, int C);
 int cbl_bn_rows_forward(long long rows, int C, const float* x, const float* weight, const float* bias, float eps, float momentum,
-                        float* running_mean, float* running_var, int relu, float* save_mean, float* save_invstd, float* y,
-                        void* workspace, size_t workspace_bytes, void* stream);
+                        float* running_mean, float* running_var, long long* num_batches_tracked, int relu, float* save_mean, float* save_invstd,
+                        float* y, void* workspace, size_t workspace_bytes, void* stream);
 int cbl_bn_rows_backward(long long rows, int C, const float* x, const float* grad_y, const float* weight, const float* bias,
                          const float* save_mean, const float* save_invstd, int relu, float* grad_x, float* grad_weight, float* grad_bias,
                          void* workspace, size_t workspace_bytes, void* stream);
