@@ -35,7 +35,8 @@ def headers():
 
 
 def _compile(src, obj, verbose):
-    cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+    tmp = obj + ".tmp.%d" % os.getpid()
+    cmd = [HIPCC] + FLAGS + ["-c", src, "-o", tmp]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -43,6 +44,7 @@ def _compile(src, obj, verbose):
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
     if verbose and r.stderr.strip():
         print(r.stderr)
+    os.replace(tmp, obj)
 
 
 def is_stale():
@@ -53,7 +55,21 @@ def is_stale():
 
 
 def build(force=False, verbose=False):
+    """compile what is out of date and link; safe to call from several processes at once (one rank per GPU): an exclusive file lock
+    serialises them, objects and the library are written under temporary names and renamed into place"""
+    import fcntl
     os.makedirs(OBJDIR, exist_ok=True)
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not is_stale():
+                return SO                                            # another process finished the build while this one waited
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose):
     hdr_time = max([os.path.getmtime(h) for h in headers()] + [os.path.getmtime(__file__)])
     jobs, objs = [], []
     for src in sources():
@@ -66,12 +82,16 @@ def build(force=False, verbose=False):
             for f in [ex.submit(_compile, s, o, verbose) for s, o in jobs]:
                 f.result()
     if jobs or not os.path.exists(SO):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
+        tmp = SO + ".tmp.%d" % os.getpid()
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+        os.replace(tmp, SO)
+    else:
+        os.utime(SO)                                                 # up to date: stop looking stale (e.g. a header touched without changes)
     return SO
 
 
