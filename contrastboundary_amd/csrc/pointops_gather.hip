@@ -190,6 +190,39 @@ __global__ __launch_bounds__(GB) void agg_bwd(int n, int ns, int c, int wc, cons
     }
 }
 
+// Same, for the usual shapes (w_c a power of two dividing 64, c a multiple of 64 or a divisor of it): the c / w_c lanes of a point that
+// share a weight column sit at stride w_c inside ONE wave, so their contributions to gw[p,s,ch % w_c] are summed across lanes
+// first (log2 steps) and ONE lane adds them — the reference's one-atomic-per-(p,s,ch) scheme puts c / w_c = 8 atomics on every address.
+__global__ __launch_bounds__(GB) void agg_bwd_wave(int n, int ns, int c, int wc, const float* __restrict__ in,
+                                                   const float* __restrict__ pos, const float* __restrict__ w,
+                                                   const int* __restrict__ idx, const float* __restrict__ go,
+                                                   float* __restrict__ gi, float* __restrict__ gpos, float* __restrict__ gw)
+{
+    const long long total = (long long)n * c;
+    const int span = c < 64 ? c : 64;                                // lanes of this wave that belong to the same point
+    const long long e0 = (long long)blockIdx.x * GB + threadIdx.x;
+    for (long long eb = e0 - (threadIdx.x & 63); eb < total; eb += (long long)gridDim.x * GB) {       // wave-uniform trip count
+        const long long e = eb + (threadIdx.x & 63);
+        const bool live = e < total;
+        const long long p = live ? e / c : 0; const int ch = live ? (int)(e - p * c) : 0;
+        const int wch = ch % wc;
+        const float g = live ? go[e] : 0.f;
+        for (int s = 0; s < ns; s++) {
+            const long long r = p * ns + s;
+            float contrib = 0.f;
+            if (live) {
+                const long long src = (long long)idx[r] * c + ch;
+                const float gwv = g * w[r * wc + wch];
+                atomic_add_f32(gi + src, gwv);
+                gpos[r * c + ch] = gwv;
+                contrib = g * (in[src] + pos[r * c + ch]);
+            }
+            for (int st = wc; st < span; st <<= 1) contrib += __shfl_xor(contrib, st);
+            if (live && (ch % span) < wc) atomic_add_f32(gw + r * wc + wch, contrib);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- F1 queryandgroup (idx given)
 // out[r, 0:3] = xyz[idx[r]] - new_xyz[r / ns] ; out[r, 3:3+c] = feat[idx[r]]     pointops.py:90-98
 // A lane owns 4 channels of one output row: 16 B gather, 16 B store.  Output rows are 4*(3+c) B long, so the store is only
@@ -357,7 +390,11 @@ CBL_EXPORT int cbl_aggregation_backward(int n, int nsample, int c, int w_c, cons
     if ((long long)n * c == 0) return CBL_OK;
     if (w_c == 0) return CBL_ERR_BAD_ARG;
     CBL_CHECK_PTRS(input, position, weight, idx, grad_output, grad_input, grad_position, grad_weight);
-    hipLaunchKernelGGL(agg_bwd, dim3(cbl_grid_for((long long)n * c, GB)), dim3(GB), 0, cbl_stream(stream), n, nsample, c, w_c, input, position, weight, idx, grad_output, grad_input, grad_position, grad_weight);
+    const bool pow2 = (w_c & (w_c - 1)) == 0;
+    if (GB % 64 == 0 && pow2 && w_c <= 64 && c % w_c == 0 && (c % 64 == 0 || 64 % c == 0))
+        hipLaunchKernelGGL(agg_bwd_wave, dim3(cbl_grid_for((long long)n * c, GB)), dim3(GB), 0, cbl_stream(stream), n, nsample, c, w_c, input, position, weight, idx, grad_output, grad_input, grad_position, grad_weight);
+    else
+        hipLaunchKernelGGL(agg_bwd, dim3(cbl_grid_for((long long)n * c, GB)), dim3(GB), 0, cbl_stream(stream), n, nsample, c, w_c, input, position, weight, idx, grad_output, grad_input, grad_position, grad_weight);
     return cbl_status();
 }
 
