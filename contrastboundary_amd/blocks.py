@@ -17,7 +17,7 @@ The per-point dense layers (q/k/v Linear, BatchNorm, ReLU, softmax over K) stay 
 import torch
 import torch.nn as nn
 
-from . import dense, pointops
+from . import attention, dense, pointops
 
 
 class PointTransformerLayer(nn.Module):
@@ -36,6 +36,7 @@ class PointTransformerLayer(nn.Module):
                                       nn.BatchNorm1d(mid_planes // share_planes), nn.ReLU(inplace=True),
                                       nn.Linear(out_planes // share_planes, out_planes // share_planes))
         self.softmax = nn.Softmax(dim=1)
+        self.fused = True                                             # use csrc/attention.hip where it applies (attention.supported)
 
     def forward(self, pxo, idx=None) -> torch.Tensor:
         p, x, o = pxo                                                        # (n,3), (n,c), (b)
@@ -43,6 +44,15 @@ class PointTransformerLayer(nn.Module):
         if idx is None:
             idx, _ = pointops.knnquery(self.nsample, p, p, o, o)              # once, not twice (:34-35)
         p_r = pointops.queryandgroup(self.nsample, p, p, p.new_zeros((p.shape[0], 0)), idx, o, o, use_xyz=True)   # (n,K,3) relative xyz
+        if self.fused and attention.supported(self, x):
+            # the C-wide part without its (n,K,C) tensors: only p1 (n,K,3) in and w2 (n,K,C/8) out exist (csrc/attention.hip)
+            lin_pc, bn_c, lin_a = self.linear_p[3], self.linear_w[0], self.linear_w[2]
+            p1 = dense.sequential(self.linear_p[:3], p_r).contiguous()        # Linear(3,3) -> BN -> ReLU, narrow
+            w2 = attention.AttnW2.apply(x_q.contiguous(), x_k.contiguous(), p1, lin_pc.weight, lin_pc.bias, bn_c.weight, bn_c.bias, lin_a.weight, lin_a.bias,
+                                        idx, bn_c, self.training)
+            w = dense.sequential(self.linear_w[3:], w2)                       # BN -> ReLU -> Linear(C/8, C/8), narrow
+            w = self.softmax(w)                                               # over K, :41
+            return attention.AttnAgg.apply(x_v.contiguous(), p1, lin_pc.weight, lin_pc.bias, w.contiguous(), idx)
         p_r = dense.sequential(self.linear_p, p_r)                            # :38  Linear(3,3) -> BN -> ReLU -> Linear(3,C) over (n*K) rows
         q_minus_k = pointops.subtraction(x_q.contiguous(), x_k.contiguous(), idx)      # x_q - x_k[idx]  (n,K,c)
         n, K, c = p_r.shape

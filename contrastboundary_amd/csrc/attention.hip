@@ -1,0 +1,442 @@
+// a4: the C-wide part of the vector attention of PointTransformerLayer, without its (n, K, C) tensors.
+// Reference: /root/reference/pytorch/model/blocks.py:31-44
+//     p_r = linear_p(p_j - p_i)                      (n,K,C)      linear_p = Linear(3,3) BN ReLU | Linear(3,C)
+//     w   = x_k[j] - x_q[i] + p_r                    (n,K,C)
+//     w   = linear_w(w)                              (n,K,C/8)    linear_w = BN(C) ReLU Linear(C,C/8) | BN ReLU Linear(C/8,C/8)
+//     out = sum_j (x_v[j] + p_r) * softmax_j(w)      (n,C)
+// Everything left of the bars above is C wide and exists per (point, neighbour) pair; the reference (and the unfused mirror)
+// materialises p_r, w, BN(w), ReLU(BN(w)) and their gradients: ~20 passes over 42 MB tensors per layer at (10240,16,64).
+// Here the pair values live in registers and are RECOMPUTED by every pass that needs them; only the narrow tensors exist:
+//     p1 = ReLU(BN(Linear(3,3)(p_j - p_i)))  (n,K,3)   in          w2 = Linear(C,C/8)(ReLU(BN(w)))  (n,K,C/8)   out
+// and the train-mode BatchNorm(C) costs one extra statistics pass:
+//   attn_w2 forward   P1  per-channel partial sums of w and w^2 over all pairs      -> finalize (mean, invstd, running stats)
+//                     P2  w -> BN -> ReLU -> the C x C/8 product, reduced across the C lanes of the pair's group
+//   attn_w2 backward  Q1  recompute, d(ReLU(BN(w))) from grad_w2; BatchNorm's two reductions; grad of Linear(C,C/8)'s parameters
+//                     Q2  recompute, grad_w by the BatchNorm backward formula; scatter to x_k (atomics) / x_q; grads of
+//                         Linear(3,C)'s parameters and of p1 (3 group reductions per pair)
+//   attn_agg forward / backward: K9 / K10 with p_r computed on the fly from p1 (and its parameter / p1 gradients in the backward)
+// One group of C lanes (C = 32 or 64: the two full-resolution stages, where the big tensors are) owns one point and walks its K
+// neighbours; x_k / x_v rows are read as coalesced 4*C-byte segments; parameter gradients are accumulated per lane in registers
+// over a persistent group's points, combined per workgroup in LDS, written as per-workgroup partials and summed in fp64.
+#include "cbl_common.h"
+
+namespace {
+
+constexpr int AT_BLOCK = 256;
+constexpr int AT_MAX_BLOCKS = 512;
+constexpr int AT_MAXG = 8;                  // C / share_planes with C <= 64
+
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dppf(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false)); }
+// sum over the C lanes of a group, result in every lane of the group (C = 32: two groups per wave)
+template <int C> __device__ __forceinline__ float group_sum(float v)
+{
+    v += dppf<0xB1, 0xf>(v); v += dppf<0x4E, 0xf>(v); v += dppf<0x141, 0xf>(v); v += dppf<0x140, 0xf>(v);
+    const float r1 = v + dppf<0x142, 0xa>(v);
+    v = (threadIdx.x & 16) ? r1 : v;
+    if (C == 32) return __shfl(v, 31, 32);
+    const float r2 = v + dppf<0x143, 0xc>(v);
+    v = (threadIdx.x & 32) ? r2 : v;
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+struct PairParams {          // per-lane (= per-channel) constants of the C-wide chain
+    float w0, w1, w2, b;     // Linear(3, C): row c of the weight, bias
+    float mean, invstd, gamma, beta;
+};
+
+__device__ __forceinline__ float pe_of(const PairParams& q, float a0, float a1, float a2) { return ((q.b + a0 * q.w0) + a1 * q.w1) + a2 * q.w2; }
+
+// ----------------------------------------------------------------------------------------------------------- attn_w2, P1
+template <int C>
+__global__ __launch_bounds__(AT_BLOCK) void attn_w2_stats_kernel(int n, int K, const float* __restrict__ xq, const float* __restrict__ xk,
+                                                                 const int* __restrict__ idx, const float* __restrict__ p1,
+                                                                 const float* __restrict__ W3C, const float* __restrict__ b3C, float* __restrict__ partial)
+{
+    constexpr int GPB = AT_BLOCK / C;                                // groups per workgroup
+    __shared__ float red[2][AT_BLOCK];
+    const int c = threadIdx.x % C, grp = threadIdx.x / C;
+    PairParams q; q.w0 = W3C[3 * c]; q.w1 = W3C[3 * c + 1]; q.w2 = W3C[3 * c + 2]; q.b = b3C[c];
+    float s0 = 0.f, s1 = 0.f;
+    for (int i = blockIdx.x * GPB + grp; i < n; i += gridDim.x * GPB) {
+        const float xqi = xq[(size_t)i * C + c];
+        for (int k = 0; k < K; k++) {
+            const size_t r = (size_t)i * K + k;
+            const int j = idx[r];
+            const float w = pe_of(q, p1[3 * r], p1[3 * r + 1], p1[3 * r + 2]) - (xqi - xk[(size_t)j * C + c]);
+            s0 += w; s1 += w * w;
+        }
+    }
+    red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
+    __syncthreads();
+    if (grp == 0) {
+        double a0 = 0.0, a1 = 0.0;
+        for (int g = 0; g < GPB; g++) { a0 += (double)red[0][g * C + c]; a1 += (double)red[1][g * C + c]; }
+        partial[((size_t)blockIdx.x * 2) * C + c] = (float)a0;
+        partial[((size_t)blockIdx.x * 2 + 1) * C + c] = (float)a1;
+    }
+}
+
+// mean / invstd from the partials (+ running statistics, batch counter), 16 channels x 16 slices per workgroup
+__global__ __launch_bounds__(256) void attn_bn_finalize_kernel(long long rows, int C, int nblocks, const float* __restrict__ partial, float eps, float momentum,
+                                                               float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                               long long* __restrict__ num_batches_tracked, float* __restrict__ mean, float* __restrict__ invstd)
+{
+    __shared__ double red[16][16][2];
+    if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) num_batches_tracked[0] += 1;
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), js = threadIdx.x >> 4;
+    double a0 = 0.0, a1 = 0.0;
+    if (c < C)
+        for (int b = js; b < nblocks; b += 16) { a0 += (double)partial[((size_t)b * 2) * C + c]; a1 += (double)partial[((size_t)b * 2 + 1) * C + c]; }
+    red[js][threadIdx.x & 15][0] = a0; red[js][threadIdx.x & 15][1] = a1;
+    __syncthreads();
+    if (js == 0 && c < C) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int j = 0; j < 16; j++) { s0 += red[j][threadIdx.x & 15][0]; s1 += red[j][threadIdx.x & 15][1]; }
+        const double mu = s0 / (double)rows;
+        double var = s1 / (double)rows - mu * mu;
+        if (var < 0.0) var = 0.0;
+        mean[c] = (float)mu;
+        invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+        if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(rows > 1 ? var * (double)rows / (double)(rows - 1) : var);
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------- attn_w2, P2
+template <int C, int G>
+__global__ __launch_bounds__(AT_BLOCK) void attn_w2_forward_kernel(int n, int K, const float* __restrict__ xq, const float* __restrict__ xk,
+                                                                   const int* __restrict__ idx, const float* __restrict__ p1,
+                                                                   const float* __restrict__ W3C, const float* __restrict__ b3C,
+                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   const float* __restrict__ Wa, const float* __restrict__ ba, float* __restrict__ w2)
+{
+    constexpr int GPB = AT_BLOCK / C;
+    const int c = threadIdx.x % C, grp = threadIdx.x / C;
+    PairParams q; q.w0 = W3C[3 * c]; q.w1 = W3C[3 * c + 1]; q.w2 = W3C[3 * c + 2]; q.b = b3C[c];
+    q.mean = mean[c]; q.invstd = invstd[c]; q.gamma = gamma ? gamma[c] : 1.f; q.beta = beta ? beta[c] : 0.f;
+    float wa[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) wa[g] = Wa[g * C + c];
+    const float bias_g = (c < G) ? ba[c] : 0.f;
+    for (int i = blockIdx.x * GPB + grp; i < n; i += gridDim.x * GPB) {
+        const float xqi = xq[(size_t)i * C + c];
+        for (int k = 0; k < K; k++) {
+            const size_t r = (size_t)i * K + k;
+            const int j = idx[r];
+            const float w = pe_of(q, p1[3 * r], p1[3 * r + 1], p1[3 * r + 2]) - (xqi - xk[(size_t)j * C + c]);
+            const float y = (w - q.mean) * q.invstd * q.gamma + q.beta;
+            const float w1 = y > 0.f ? y : 0.f;
+            float mine = 0.f;
+#pragma unroll
+            for (int g = 0; g < G; g++) { const float t = group_sum<C>(wa[g] * w1); mine = (c == g) ? t : mine; }
+            if (c < G) w2[r * G + c] = mine + bias_g;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------- attn_w2, Q1 / Q2
+// per-workgroup partial layout (floats): [0,C) S0 | [C,2C) S1 | [2C, 2C+G*C) dWa | [.., +G) dba          (Q1)
+//                                         [0,3C) dW3C | [3C,4C) db3C                                        (Q2, agg backward)
+template <int C, int G>
+__global__ __launch_bounds__(AT_BLOCK) void attn_w2_bwd_reduce_kernel(int n, int K, const float* __restrict__ xq, const float* __restrict__ xk,
+                                                                      const int* __restrict__ idx, const float* __restrict__ p1,
+                                                                      const float* __restrict__ W3C, const float* __restrict__ b3C,
+                                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                      const float* __restrict__ Wa, const float* __restrict__ gw2, float* __restrict__ partial)
+{
+    constexpr int GPB = AT_BLOCK / C;
+    constexpr int NV = 2 + G + 1;                                    // values per lane: S0, S1, dWa[0..G), dba (lane g < G)
+    __shared__ float red[NV][AT_BLOCK];
+    const int c = threadIdx.x % C, grp = threadIdx.x / C;
+    PairParams q; q.w0 = W3C[3 * c]; q.w1 = W3C[3 * c + 1]; q.w2 = W3C[3 * c + 2]; q.b = b3C[c];
+    q.mean = mean[c]; q.invstd = invstd[c]; q.gamma = gamma ? gamma[c] : 1.f; q.beta = beta ? beta[c] : 0.f;
+    float wa[G], dwa[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) { wa[g] = Wa[g * C + c]; dwa[g] = 0.f; }
+    float s0 = 0.f, s1 = 0.f, dba = 0.f;
+    for (int i = blockIdx.x * GPB + grp; i < n; i += gridDim.x * GPB) {
+        const float xqi = xq[(size_t)i * C + c];
+        for (int k = 0; k < K; k++) {
+            const size_t r = (size_t)i * K + k;
+            const int j = idx[r];
+            const float w = pe_of(q, p1[3 * r], p1[3 * r + 1], p1[3 * r + 2]) - (xqi - xk[(size_t)j * C + c]);
+            const float xh = (w - q.mean) * q.invstd;
+            const float y = xh * q.gamma + q.beta;
+            const float w1 = y > 0.f ? y : 0.f;
+            float dw1 = 0.f;
+#pragma unroll
+            for (int g = 0; g < G; g++) { const float d = gw2[r * G + g]; dw1 += wa[g] * d; dwa[g] += d * w1; }
+            const float dy = y > 0.f ? dw1 : 0.f;
+            s0 += dy; s1 += dy * xh;
+            if (c < G) dba += gw2[r * G + c];
+        }
+    }
+    red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
+#pragma unroll
+    for (int g = 0; g < G; g++) red[2 + g][threadIdx.x] = dwa[g];
+    red[2 + G][threadIdx.x] = dba;
+    __syncthreads();
+    if (grp == 0) {
+        float* mine = partial + (size_t)blockIdx.x * (2 * C + G * C + G);
+        float t[NV];
+#pragma unroll
+        for (int v = 0; v < NV; v++) { float a = 0.f; for (int g2 = 0; g2 < GPB; g2++) a += red[v][g2 * C + c]; t[v] = a; }
+        mine[c] = t[0]; mine[C + c] = t[1];
+#pragma unroll
+        for (int g = 0; g < G; g++) mine[2 * C + g * C + c] = t[2 + g];
+        if (c < G) mine[2 * C + G * C + c] = t[2 + G];
+    }
+}
+
+// out[e] = sum_b partial[b][e] (fp64), e < nvals; 16 values x 16 slices per workgroup
+__global__ __launch_bounds__(256) void attn_sum_partials_kernel(int nvals, int nblocks, const float* __restrict__ partial, float* __restrict__ out)
+{
+    __shared__ double red[16][16];
+    const int e = blockIdx.x * 16 + (threadIdx.x & 15), js = threadIdx.x >> 4;
+    double a = 0.0;
+    if (e < nvals)
+        for (int b = js; b < nblocks; b += 16) a += (double)partial[(size_t)b * nvals + e];
+    red[js][threadIdx.x & 15] = a;
+    __syncthreads();
+    if (js == 0 && e < nvals) {
+        double s = 0.0;
+        for (int j = 0; j < 16; j++) s += red[j][threadIdx.x & 15];
+        out[e] = (float)s;
+    }
+}
+
+// Q2: sums[0..C) = S0 = grad_beta, sums[C..2C) = S1 = grad_gamma (from Q1's finalize)
+template <int C, int G>
+__global__ __launch_bounds__(AT_BLOCK) void attn_w2_bwd_apply_kernel(int n, int K, const float* __restrict__ xq, const float* __restrict__ xk,
+                                                                     const int* __restrict__ idx, const float* __restrict__ p1,
+                                                                     const float* __restrict__ W3C, const float* __restrict__ b3C,
+                                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                     const float* __restrict__ Wa, const float* __restrict__ gw2, const float* __restrict__ sums,
+                                                                     float* __restrict__ gxq, float* __restrict__ gxk, float* __restrict__ gp1,
+                                                                     float* __restrict__ partial)
+{
+    constexpr int GPB = AT_BLOCK / C;
+    __shared__ float red[4][AT_BLOCK];
+    const int c = threadIdx.x % C, grp = threadIdx.x / C;
+    PairParams q; q.w0 = W3C[3 * c]; q.w1 = W3C[3 * c + 1]; q.w2 = W3C[3 * c + 2]; q.b = b3C[c];
+    q.mean = mean[c]; q.invstd = invstd[c]; q.gamma = gamma ? gamma[c] : 1.f; q.beta = beta ? beta[c] : 0.f;
+    float wa[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) wa[g] = Wa[g * C + c];
+    const float inv_rows = 1.0f / ((float)n * (float)K);
+    const float c0 = sums[c] * inv_rows, c1 = sums[C + c] * inv_rows;
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, db = 0.f;                    // dW3C[c, 0..2], db3C[c]
+    for (int i = blockIdx.x * GPB + grp; i < n; i += gridDim.x * GPB) {
+        const float xqi = xq[(size_t)i * C + c];
+        float gq = 0.f;
+        for (int k = 0; k < K; k++) {
+            const size_t r = (size_t)i * K + k;
+            const int j = idx[r];
+            const float a0 = p1[3 * r], a1 = p1[3 * r + 1], a2 = p1[3 * r + 2];
+            const float w = pe_of(q, a0, a1, a2) - (xqi - xk[(size_t)j * C + c]);
+            const float xh = (w - q.mean) * q.invstd;
+            const float y = xh * q.gamma + q.beta;
+            float dw1 = 0.f;
+#pragma unroll
+            for (int g = 0; g < G; g++) dw1 += wa[g] * gw2[r * G + g];
+            const float dy = y > 0.f ? dw1 : 0.f;
+            const float dw = q.gamma * q.invstd * ((dy - c0) - xh * c1);          // BatchNorm backward, train mode
+            unsafeAtomicAdd(gxk + (size_t)j * C + c, dw);            // w = p_r - x_q + x_k[j]
+            gq -= dw;
+            d0 += dw * a0; d1 += dw * a1; d2 += dw * a2; db += dw;
+            const float t0 = group_sum<C>(q.w0 * dw), t1 = group_sum<C>(q.w1 * dw), t2 = group_sum<C>(q.w2 * dw);
+            if (c < 3) gp1[3 * r + c] = (c == 0) ? t0 : (c == 1) ? t1 : t2;
+        }
+        gxq[(size_t)i * C + c] = gq;
+    }
+    red[0][threadIdx.x] = d0; red[1][threadIdx.x] = d1; red[2][threadIdx.x] = d2; red[3][threadIdx.x] = db;
+    __syncthreads();
+    if (grp == 0) {
+        float* mine = partial + (size_t)blockIdx.x * (4 * C);
+        float t[4];
+#pragma unroll
+        for (int v = 0; v < 4; v++) { float a = 0.f; for (int g2 = 0; g2 < GPB; g2++) a += red[v][g2 * C + c]; t[v] = a; }
+        mine[3 * c] = t[0]; mine[3 * c + 1] = t[1]; mine[3 * c + 2] = t[2]; mine[3 * C + c] = t[3];
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------- attn_agg
+// out[i,c] = sum_k (x_v[j,c] + p_r[i,k,c]) * a[i,k,c % G]                       blocks.py:42-43 (K9 with p_r on the fly)
+template <int C, int G>
+__global__ __launch_bounds__(AT_BLOCK) void attn_agg_forward_kernel(int n, int K, const float* __restrict__ xv, const int* __restrict__ idx,
+                                                                    const float* __restrict__ p1, const float* __restrict__ W3C, const float* __restrict__ b3C,
+                                                                    const float* __restrict__ a, float* __restrict__ out)
+{
+    constexpr int GPB = AT_BLOCK / C;
+    const int c = threadIdx.x % C, grp = threadIdx.x / C;
+    PairParams q; q.w0 = W3C[3 * c]; q.w1 = W3C[3 * c + 1]; q.w2 = W3C[3 * c + 2]; q.b = b3C[c];
+    for (int i = blockIdx.x * GPB + grp; i < n; i += gridDim.x * GPB) {
+        float acc = 0.f;
+        for (int k = 0; k < K; k++) {
+            const size_t r = (size_t)i * K + k;
+            const int j = idx[r];
+            acc += (xv[(size_t)j * C + c] + pe_of(q, p1[3 * r], p1[3 * r + 1], p1[3 * r + 2])) * a[r * G + (c % G)];
+        }
+        out[(size_t)i * C + c] = acc;
+    }
+}
+
+template <int C, int G>
+__global__ __launch_bounds__(AT_BLOCK) void attn_agg_backward_kernel(int n, int K, const float* __restrict__ xv, const int* __restrict__ idx,
+                                                                     const float* __restrict__ p1, const float* __restrict__ W3C, const float* __restrict__ b3C,
+                                                                     const float* __restrict__ a, const float* __restrict__ go,
+                                                                     float* __restrict__ gxv, float* __restrict__ gp1, float* __restrict__ ga, float* __restrict__ partial)
+{
+    constexpr int GPB = AT_BLOCK / C;
+    __shared__ float red[4][AT_BLOCK];
+    const int c = threadIdx.x % C, grp = threadIdx.x / C;
+    PairParams q; q.w0 = W3C[3 * c]; q.w1 = W3C[3 * c + 1]; q.w2 = W3C[3 * c + 2]; q.b = b3C[c];
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, db = 0.f;
+    for (int i = blockIdx.x * GPB + grp; i < n; i += gridDim.x * GPB) {
+        const float g = go[(size_t)i * C + c];
+        for (int k = 0; k < K; k++) {
+            const size_t r = (size_t)i * K + k;
+            const int j = idx[r];
+            const float a0 = p1[3 * r], a1 = p1[3 * r + 1], a2 = p1[3 * r + 2];
+            const float av = a[r * G + (c % G)];
+            const float xvj = xv[(size_t)j * C + c];
+            const float dpe = g * av;                                // d out / d (x_v[j] + p_r)
+            unsafeAtomicAdd(gxv + (size_t)j * C + c, dpe);
+            d0 += dpe * a0; d1 += dpe * a1; d2 += dpe * a2; db += dpe;
+            const float t0 = group_sum<C>(q.w0 * dpe), t1 = group_sum<C>(q.w1 * dpe), t2 = group_sum<C>(q.w2 * dpe);
+            if (c < 3) gp1[3 * r + c] = (c == 0) ? t0 : (c == 1) ? t1 : t2;
+            // grad_a[i,k,g] = sum over the channels with c % G == g: the C/G lanes at stride G of this group
+            float da = g * (xvj + pe_of(q, a0, a1, a2));
+#pragma unroll
+            for (int st = G; st < C; st <<= 1) da += __shfl_xor(da, st);
+            if (c < G) ga[r * G + c] = da;
+        }
+    }
+    red[0][threadIdx.x] = d0; red[1][threadIdx.x] = d1; red[2][threadIdx.x] = d2; red[3][threadIdx.x] = db;
+    __syncthreads();
+    if (grp == 0) {
+        float* mine = partial + (size_t)blockIdx.x * (4 * C);
+        float t[4];
+#pragma unroll
+        for (int v = 0; v < 4; v++) { float s = 0.f; for (int g2 = 0; g2 < GPB; g2++) s += red[v][g2 * C + c]; t[v] = s; }
+        mine[3 * c] = t[0]; mine[3 * c + 1] = t[1]; mine[3 * c + 2] = t[2]; mine[3 * C + c] = t[3];
+    }
+}
+
+int at_check(int n, int K, int C, int G)
+{
+    if (n < 0 || K <= 0) return CBL_ERR_BAD_ARG;
+    if (!((C == 32 && G == 4) || (C == 64 && G == 8))) return CBL_ERR_UNSUPPORTED;
+    return CBL_OK;
+}
+inline int at_blocks(int n, int C) { const int gpb = AT_BLOCK / C; const long long b = ((long long)n + gpb - 1) / gpb; return (int)(b < 1 ? 1 : (b > AT_MAX_BLOCKS ? AT_MAX_BLOCKS : b)); }
+
+}  // namespace
+
+// floats of scratch: partials of the widest pass (Q1) + the summed values
+CBL_EXPORT size_t cbl_attn_workspace_bytes(int C, int G)
+{
+    const size_t per_block = (size_t)2 * C + (size_t)G * C + G;
+    return sizeof(float) * (AT_MAX_BLOCKS * per_block + per_block) + 256;
+}
+
+#define AT_DISPATCH(KERNEL, ...)                                                                                              \
+    do {                                                                                                                          \
+        if (C == 32) hipLaunchKernelGGL((KERNEL<32, 4>), dim3(nb), dim3(AT_BLOCK), 0, st, __VA_ARGS__);                           \
+        else         hipLaunchKernelGGL((KERNEL<64, 8>), dim3(nb), dim3(AT_BLOCK), 0, st, __VA_ARGS__);                           \
+    } while (0)
+
+CBL_EXPORT int cbl_attn_w2_forward(int n, int K, int C, int G, const float* x_q, const float* x_k, const int* idx, const float* p1,
+                                   const float* W3C, const float* b3C, const float* bn_weight, const float* bn_bias, float eps, float momentum,
+                                   float* running_mean, float* running_var, long long* num_batches_tracked, int training,
+                                   const float* Wa, const float* ba, float* save_mean, float* save_invstd, float* w2,
+                                   void* workspace, size_t workspace_bytes, void* stream)
+{
+    const int rc = at_check(n, K, C, G);
+    if (rc) return rc;
+    if (n == 0) return CBL_OK;
+    if (!x_q || !x_k || !idx || !p1 || !W3C || !b3C || !Wa || !ba || !save_mean || !save_invstd || !w2 || !workspace) return CBL_ERR_BAD_ARG;
+    if (workspace_bytes < cbl_attn_workspace_bytes(C, G)) return CBL_ERR_WORKSPACE;
+    hipStream_t st = cbl_stream(stream);
+    const int nb = at_blocks(n, C);
+    float* partial = reinterpret_cast<float*>(workspace);
+    if (training) {                                                   // eval mode: the caller put the running statistics into save_mean / save_invstd
+        if (C == 32) hipLaunchKernelGGL(attn_w2_stats_kernel<32>, dim3(nb), dim3(AT_BLOCK), 0, st, n, K, x_q, x_k, idx, p1, W3C, b3C, partial);
+        else         hipLaunchKernelGGL(attn_w2_stats_kernel<64>, dim3(nb), dim3(AT_BLOCK), 0, st, n, K, x_q, x_k, idx, p1, W3C, b3C, partial);
+        hipLaunchKernelGGL(attn_bn_finalize_kernel, dim3(cbl_div_up(C, 16)), dim3(256), 0, st, (long long)n * K, C, nb, partial, eps, momentum,
+                           running_mean, running_var, num_batches_tracked, save_mean, save_invstd);
+    }
+    AT_DISPATCH(attn_w2_forward_kernel, n, K, x_q, x_k, idx, p1, W3C, b3C, save_mean, save_invstd, bn_weight, bn_bias, Wa, ba, w2);
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_attn_w2_backward(int n, int K, int C, int G, const float* x_q, const float* x_k, const int* idx, const float* p1,
+                                    const float* W3C, const float* b3C, const float* bn_weight, const float* bn_bias,
+                                    const float* save_mean, const float* save_invstd, const float* Wa, const float* grad_w2,
+                                    float* grad_xq, float* grad_xk, float* grad_p1, float* grad_W3C, float* grad_b3C,
+                                    float* grad_bn_weight, float* grad_bn_bias, float* grad_Wa, float* grad_ba,
+                                    void* workspace, size_t workspace_bytes, void* stream)
+{
+    const int rc = at_check(n, K, C, G);
+    if (rc) return rc;
+    if (n == 0) return CBL_OK;
+    if (!x_q || !x_k || !idx || !p1 || !W3C || !b3C || !save_mean || !save_invstd || !Wa || !grad_w2 || !grad_xq || !grad_xk || !grad_p1 || !grad_W3C ||
+        !grad_b3C || !grad_bn_weight || !grad_bn_bias || !grad_Wa || !grad_ba || !workspace) return CBL_ERR_BAD_ARG;
+    if (workspace_bytes < cbl_attn_workspace_bytes(C, G)) return CBL_ERR_WORKSPACE;
+    hipStream_t st = cbl_stream(stream);
+    const int nb = at_blocks(n, C);
+    const int nv1 = 2 * C + G * C + G, nv2 = 4 * C;
+    float* partial = reinterpret_cast<float*>(workspace);
+    float* sums = partial + (size_t)AT_MAX_BLOCKS * nv1;
+    AT_DISPATCH(attn_w2_bwd_reduce_kernel, n, K, x_q, x_k, idx, p1, W3C, b3C, save_mean, save_invstd, bn_weight, bn_bias, Wa, grad_w2, partial);
+    hipLaunchKernelGGL(attn_sum_partials_kernel, dim3(cbl_div_up(nv1, 16)), dim3(256), 0, st, nv1, nb, partial, sums);
+    // sums = [grad_beta | grad_gamma | grad_Wa | grad_ba]
+    (void)hipMemcpyAsync(grad_bn_bias, sums, sizeof(float) * C, hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(grad_bn_weight, sums + C, sizeof(float) * C, hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(grad_Wa, sums + 2 * C, sizeof(float) * G * C, hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(grad_ba, sums + 2 * C + G * C, sizeof(float) * G, hipMemcpyDeviceToDevice, st);
+    AT_DISPATCH(attn_w2_bwd_apply_kernel, n, K, x_q, x_k, idx, p1, W3C, b3C, save_mean, save_invstd, bn_weight, bn_bias, Wa, grad_w2, sums,
+                grad_xq, grad_xk, grad_p1, partial);
+    // partial rows are [dW3C (C x 3, row-major like the weight) | db3C]: sum them straight into the two outputs
+    hipLaunchKernelGGL(attn_sum_partials_kernel, dim3(cbl_div_up(nv2, 16)), dim3(256), 0, st, nv2, nb, partial, sums);
+    (void)hipMemcpyAsync(grad_W3C, sums, sizeof(float) * 3 * C, hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(grad_b3C, sums + 3 * C, sizeof(float) * C, hipMemcpyDeviceToDevice, st);
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_attn_agg_forward(int n, int K, int C, int G, const float* x_v, const int* idx, const float* p1, const float* W3C, const float* b3C,
+                                    const float* a, float* out, void* stream)
+{
+    const int rc = at_check(n, K, C, G);
+    if (rc) return rc;
+    if (n == 0) return CBL_OK;
+    if (!x_v || !idx || !p1 || !W3C || !b3C || !a || !out) return CBL_ERR_BAD_ARG;
+    hipStream_t st = cbl_stream(stream);
+    const int nb = (int)cbl_grid_for((long long)n * C, AT_BLOCK, 4096);
+    AT_DISPATCH(attn_agg_forward_kernel, n, K, x_v, idx, p1, W3C, b3C, a, out);
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_attn_agg_backward(int n, int K, int C, int G, const float* x_v, const int* idx, const float* p1, const float* W3C, const float* b3C,
+                                     const float* a, const float* grad_out, float* grad_xv, float* grad_p1, float* grad_W3C, float* grad_b3C, float* grad_a,
+                                     void* workspace, size_t workspace_bytes, void* stream)
+{
+    const int rc = at_check(n, K, C, G);
+    if (rc) return rc;
+    if (n == 0) return CBL_OK;
+    if (!x_v || !idx || !p1 || !W3C || !b3C || !a || !grad_out || !grad_xv || !grad_p1 || !grad_W3C || !grad_b3C || !grad_a || !workspace) return CBL_ERR_BAD_ARG;
+    if (workspace_bytes < cbl_attn_workspace_bytes(C, G)) return CBL_ERR_WORKSPACE;
+    hipStream_t st = cbl_stream(stream);
+    const int nb = at_blocks(n, C);
+    const int nv2 = 4 * C;
+    float* partial = reinterpret_cast<float*>(workspace);
+    float* sums = partial + (size_t)AT_MAX_BLOCKS * (2 * C + G * C + G);
+    AT_DISPATCH(attn_agg_backward_kernel, n, K, x_v, idx, p1, W3C, b3C, a, grad_out, grad_xv, grad_p1, grad_a, partial);
+    hipLaunchKernelGGL(attn_sum_partials_kernel, dim3(cbl_div_up(nv2, 16)), dim3(256), 0, st, nv2, nb, partial, sums);
+    (void)hipMemcpyAsync(grad_W3C, sums, sizeof(float) * 3 * C, hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(grad_b3C, sums + 3 * C, sizeof(float) * C, hipMemcpyDeviceToDevice, st);
+    return cbl_status();
+}

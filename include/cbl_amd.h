@@ -247,6 +247,34 @@ int cbl_pospool_backward(int n, int n0, int K, int C, const float* query_points,
                          const float* features, float radius, int position_embedding, int reduction, const int* padding_num,
                          const float* grad_out, float* grad_features, void* stream);
 
+/* a4  PointTransformerLayer  pytorch/model/blocks.py:31-44, the C-wide part without its (n,K,C) tensors (C = 32 or 64, G = C/8):
+ *   p1 (n,K,3) = ReLU(BN(Linear(3,3)(p_j - p_i)))  [computed by the caller: narrow],  p_r = Linear(3,C)(p1) = p1 @ W3C^T + b3C  [never stored]
+ * attn_w2:  w2 (n,K,G) = Linear(C,G)( ReLU( BN_C( x_k[idx] - x_q + p_r ) ) )       (:39 and the first half of linear_w, :25-27)
+ *   training != 0: BatchNorm statistics over all n*K pairs (one extra pass), running stats / counter updated like nn.BatchNorm1d, batch mean /
+ *   invstd left in save_mean / save_invstd (C); training == 0: save_mean / save_invstd are INPUTS (the running statistics).
+ *   backward: grad_xq (n,C) written, grad_xk (n,C) += (caller pre-zeroes), grad_p1 (n,K,3), grad_W3C (C,3), grad_b3C, grad_bn_weight/bias (C),
+ *   grad_Wa (G,C), grad_ba (G) written.
+ * attn_agg: out (n,C) = sum_k (x_v[idx] + p_r) * a[.,.,c % G]                       (:42-43; K9/K10 with p_r on the fly)
+ *   backward: grad_xv (n,C) += (caller pre-zeroes), grad_p1, grad_W3C, grad_b3C, grad_a (n,K,G) written.
+ * Both Linear(3,C) gradients are partial (one from each use of p_r): the caller adds them.  workspace: cbl_attn_workspace_bytes. */
+size_t cbl_attn_workspace_bytes(int C, int G);
+int cbl_attn_w2_forward(int n, int K, int C, int G, const float* x_q, const float* x_k, const int* idx, const float* p1,
+                        const float* W3C, const float* b3C, const float* bn_weight, const float* bn_bias, float eps, float momentum,
+                        float* running_mean, float* running_var, long long* num_batches_tracked, int training,
+                        const float* Wa, const float* ba, float* save_mean, float* save_invstd, float* w2,
+                        void* workspace, size_t workspace_bytes, void* stream);
+int cbl_attn_w2_backward(int n, int K, int C, int G, const float* x_q, const float* x_k, const int* idx, const float* p1,
+                         const float* W3C, const float* b3C, const float* bn_weight, const float* bn_bias,
+                         const float* save_mean, const float* save_invstd, const float* Wa, const float* grad_w2,
+                         float* grad_xq, float* grad_xk, float* grad_p1, float* grad_W3C, float* grad_b3C,
+                         float* grad_bn_weight, float* grad_bn_bias, float* grad_Wa, float* grad_ba,
+                         void* workspace, size_t workspace_bytes, void* stream);
+int cbl_attn_agg_forward(int n, int K, int C, int G, const float* x_v, const int* idx, const float* p1, const float* W3C, const float* b3C,
+                         const float* a, float* out, void* stream);
+int cbl_attn_agg_backward(int n, int K, int C, int G, const float* x_v, const int* idx, const float* p1, const float* W3C, const float* b3C,
+                          const float* a, const float* grad_out, float* grad_xv, float* grad_p1, float* grad_W3C, float* grad_b3C, float* grad_a,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 /* a4, dense part of the vector attention: nn.Linear over (n*K) rows with tiny widths — linear_p = Linear(3,3), Linear(3,C) and
  * linear_w = Linear(C,C/8), Linear(C/8,C/8)  pytorch/model/blocks.py:23-28,38-40 — as streaming kernels instead of library GEMMs.
  *   x (rows,cin), weight (cout,cin), bias (cout) or NULL -> y (rows,cout) = x @ weight^T + bias

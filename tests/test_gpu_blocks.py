@@ -73,3 +73,34 @@ def test_transition_down_and_up(inputs):
     x2 = dev(G["down/out"]).requires_grad_(True)
     y = th([p2, x2, o2])
     np.testing.assert_allclose(y.detach().cpu().numpy(), G["uphead/out"], **TOL)
+
+
+@pytest.mark.parametrize("n,K,C", [(4096, 8, 32), (3000, 16, 64), (2500, 8, 64)])
+def test_fused_attention_equals_the_unfused_layer(n, K, C):
+    """PointTransformerLayer with the C-wide part in csrc/attention.hip (nothing of shape (n,K,C) stored) against the same layer on the
+    separate kernels (which the reference goldens above pin): output, every parameter gradient, input gradient, BatchNorm buffers"""
+    import copy
+    from contrastboundary_amd import blocks, synthetic as S
+    torch.manual_seed(n + C)
+    xyz = torch.from_numpy(S.s_room(n, seed=3)[0]).cuda(); o = torch.tensor([n // 3, n], dtype=torch.int32, device="cuda")
+    fused = blocks.PointTransformerLayer(C, C, 8, K).cuda().train()
+    with torch.no_grad():
+        for m in fused.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.3, 0.3)
+    plain = copy.deepcopy(fused); plain.fused = False
+    assert n * K >= 16384
+    x1 = torch.randn(n, C, device="cuda", requires_grad=True); x2 = x1.detach().clone().requires_grad_(True)
+    g = torch.randn(n, C, device="cuda")
+    y1 = fused([xyz, x1, o]); y1.backward(g)
+    y2 = plain([xyz, x2, o]); y2.backward(g)
+    rel = lambda a, b: float((a.double() - b.double()).norm() / max(float(b.double().norm()), 1e-30))
+    assert rel(y1, y2) < 2e-5
+    assert rel(x1.grad, x2.grad) < 2e-4
+    # biases that feed a BatchNorm directly (linear_q / linear_k / linear_p.0 / linear_w.2) shift every row alike, the BatchNorm removes the
+    # shift: their true gradient is 0 and both paths return rounding noise — hence the absolute bound relative to the largest gradient
+    gmax = max(float(pb.grad.abs().max()) for pb in plain.parameters())
+    for (name, pa), (_, pb) in zip(fused.named_parameters(), plain.named_parameters()):
+        assert pa.grad is not None and (rel(pa.grad, pb.grad) < 5e-4 or float((pa.grad - pb.grad).abs().max()) < 1e-4 * gmax), name
+    for (name, ba), (_, bb) in zip(fused.named_buffers(), plain.named_buffers()):
+        assert rel(ba.float(), bb.float()) < 1e-5, name
