@@ -23,7 +23,8 @@
 namespace {
 
 constexpr int AT_BLOCK = 256;
-constexpr int AT_MAX_BLOCKS = 512;
+constexpr int AT_MAX_BLOCKS = 1024;
+constexpr int AT_U = 4;                     // pairs whose loads are in flight together
 constexpr int AT_MAXG = 8;                  // C / share_planes with C <= 64
 
 template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dppf(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false)); }
@@ -46,6 +47,24 @@ struct PairParams {          // per-lane (= per-channel) constants of the C-wide
 
 __device__ __forceinline__ float pe_of(const PairParams& q, float a0, float a1, float a2) { return ((q.b + a0 * q.w0) + a1 * q.w1) + a2 * q.w2; }
 
+
+// the U next pairs of point i: neighbour ids, the three p1 values and this lane's x row element of each — all loads issued before any use
+struct PairBatch { int j[AT_U]; float a0[AT_U], a1[AT_U], a2[AT_U], xr[AT_U]; };
+template <int C>
+__device__ __forceinline__ void load_pairs(PairBatch& pb, int i, int k0, int K, int c, const int* __restrict__ idx, const float* __restrict__ p1,
+                                           const float* __restrict__ rows)
+{
+#pragma unroll
+    for (int u = 0; u < AT_U; u++) {
+        const int k = min(k0 + u, K - 1);                            // tail: repeat the last pair (its result is not used)
+        const size_t r = (size_t)i * K + k;
+        pb.j[u] = idx[r];
+        pb.a0[u] = p1[3 * r]; pb.a1[u] = p1[3 * r + 1]; pb.a2[u] = p1[3 * r + 2];
+    }
+#pragma unroll
+    for (int u = 0; u < AT_U; u++) pb.xr[u] = rows[(size_t)pb.j[u] * C + c];
+}
+
 // ----------------------------------------------------------------------------------------------------------- attn_w2, P1
 template <int C>
 __global__ __launch_bounds__(AT_BLOCK) void attn_w2_stats_kernel(int n, int K, const float* __restrict__ xq, const float* __restrict__ xk,
@@ -59,11 +78,15 @@ __global__ __launch_bounds__(AT_BLOCK) void attn_w2_stats_kernel(int n, int K, c
     float s0 = 0.f, s1 = 0.f;
     for (int i = blockIdx.x * GPB + grp; i < n; i += gridDim.x * GPB) {
         const float xqi = xq[(size_t)i * C + c];
-        for (int k = 0; k < K; k++) {
-            const size_t r = (size_t)i * K + k;
-            const int j = idx[r];
-            const float w = pe_of(q, p1[3 * r], p1[3 * r + 1], p1[3 * r + 2]) - (xqi - xk[(size_t)j * C + c]);
-            s0 += w; s1 += w * w;
+        for (int k0 = 0; k0 < K; k0 += AT_U) {
+            PairBatch pb; load_pairs<C>(pb, i, k0, K, c, idx, p1, xk);
+#pragma unroll
+            for (int u = 0; u < AT_U; u++) {
+                if (k0 + u < K) {
+                    const float w = pe_of(q, pb.a0[u], pb.a1[u], pb.a2[u]) - (xqi - pb.xr[u]);
+                    s0 += w; s1 += w * w;
+                }
+            }
         }
     }
     red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
@@ -85,8 +108,10 @@ __global__ __launch_bounds__(256) void attn_bn_finalize_kernel(long long rows, i
     if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) num_batches_tracked[0] += 1;
     const int c = blockIdx.x * 16 + (threadIdx.x & 15), js = threadIdx.x >> 4;
     double a0 = 0.0, a1 = 0.0;
-    if (c < C)
+    if (c < C) {
+#pragma unroll 8
         for (int b = js; b < nblocks; b += 16) { a0 += (double)partial[((size_t)b * 2) * C + c]; a1 += (double)partial[((size_t)b * 2 + 1) * C + c]; }
+    }
     red[js][threadIdx.x & 15][0] = a0; red[js][threadIdx.x & 15][1] = a1;
     __syncthreads();
     if (js == 0 && c < C) {
@@ -121,16 +146,21 @@ __global__ __launch_bounds__(AT_BLOCK) void attn_w2_forward_kernel(int n, int K,
     const float bias_g = (c < G) ? ba[c] : 0.f;
     for (int i = blockIdx.x * GPB + grp; i < n; i += gridDim.x * GPB) {
         const float xqi = xq[(size_t)i * C + c];
-        for (int k = 0; k < K; k++) {
-            const size_t r = (size_t)i * K + k;
-            const int j = idx[r];
-            const float w = pe_of(q, p1[3 * r], p1[3 * r + 1], p1[3 * r + 2]) - (xqi - xk[(size_t)j * C + c]);
-            const float y = (w - q.mean) * q.invstd * q.gamma + q.beta;
-            const float w1 = y > 0.f ? y : 0.f;
-            float mine = 0.f;
+        for (int k0 = 0; k0 < K; k0 += AT_U) {
+            PairBatch pb; load_pairs<C>(pb, i, k0, K, c, idx, p1, xk);
 #pragma unroll
-            for (int g = 0; g < G; g++) { const float t = group_sum<C>(wa[g] * w1); mine = (c == g) ? t : mine; }
-            if (c < G) w2[r * G + c] = mine + bias_g;
+            for (int u = 0; u < AT_U; u++) {
+                if (k0 + u < K) {                                    // group-uniform
+                    const size_t r = (size_t)i * K + k0 + u;
+                    const float w = pe_of(q, pb.a0[u], pb.a1[u], pb.a2[u]) - (xqi - pb.xr[u]);
+                    const float y = (w - q.mean) * q.invstd * q.gamma + q.beta;
+                    const float w1 = y > 0.f ? y : 0.f;
+                    float mine = 0.f;
+#pragma unroll
+                    for (int g = 0; g < G; g++) { const float t = group_sum<C>(wa[g] * w1); mine = (c == g) ? t : mine; }
+                    if (c < G) w2[r * G + c] = mine + bias_g;
+                }
+            }
         }
     }
 }
@@ -158,19 +188,31 @@ __global__ __launch_bounds__(AT_BLOCK) void attn_w2_bwd_reduce_kernel(int n, int
     float s0 = 0.f, s1 = 0.f, dba = 0.f;
     for (int i = blockIdx.x * GPB + grp; i < n; i += gridDim.x * GPB) {
         const float xqi = xq[(size_t)i * C + c];
-        for (int k = 0; k < K; k++) {
-            const size_t r = (size_t)i * K + k;
-            const int j = idx[r];
-            const float w = pe_of(q, p1[3 * r], p1[3 * r + 1], p1[3 * r + 2]) - (xqi - xk[(size_t)j * C + c]);
-            const float xh = (w - q.mean) * q.invstd;
-            const float y = xh * q.gamma + q.beta;
-            const float w1 = y > 0.f ? y : 0.f;
-            float dw1 = 0.f;
+        for (int k0 = 0; k0 < K; k0 += AT_U) {
+            PairBatch pb; load_pairs<C>(pb, i, k0, K, c, idx, p1, xk);
+            float gd[AT_U][G];
 #pragma unroll
-            for (int g = 0; g < G; g++) { const float d = gw2[r * G + g]; dw1 += wa[g] * d; dwa[g] += d * w1; }
-            const float dy = y > 0.f ? dw1 : 0.f;
-            s0 += dy; s1 += dy * xh;
-            if (c < G) dba += gw2[r * G + c];
+            for (int u = 0; u < AT_U; u++) {
+                const size_t r = (size_t)i * K + min(k0 + u, K - 1);
+#pragma unroll
+                for (int g = 0; g < G; g++) gd[u][g] = gw2[r * G + g];
+            }
+#pragma unroll
+            for (int u = 0; u < AT_U; u++) {
+                if (k0 + u < K) {
+                    const float w = pe_of(q, pb.a0[u], pb.a1[u], pb.a2[u]) - (xqi - pb.xr[u]);
+                    const float xh = (w - q.mean) * q.invstd;
+                    const float y = xh * q.gamma + q.beta;
+                    const float w1 = y > 0.f ? y : 0.f;
+                    float dw1 = 0.f;
+#pragma unroll
+                    for (int g = 0; g < G; g++) { dw1 += wa[g] * gd[u][g]; dwa[g] += gd[u][g] * w1; }
+                    const float dy = y > 0.f ? dw1 : 0.f;
+                    s0 += dy; s1 += dy * xh;
+#pragma unroll
+                    for (int g = 0; g < G; g++) dba += (c == g) ? gd[u][g] : 0.f;
+                }
+            }
         }
     }
     red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
@@ -196,8 +238,10 @@ __global__ __launch_bounds__(256) void attn_sum_partials_kernel(int nvals, int n
     __shared__ double red[16][16];
     const int e = blockIdx.x * 16 + (threadIdx.x & 15), js = threadIdx.x >> 4;
     double a = 0.0;
-    if (e < nvals)
+    if (e < nvals) {
+#pragma unroll 8
         for (int b = js; b < nblocks; b += 16) a += (double)partial[(size_t)b * nvals + e];
+    }
     red[js][threadIdx.x & 15] = a;
     __syncthreads();
     if (js == 0 && e < nvals) {
@@ -232,23 +276,35 @@ __global__ __launch_bounds__(AT_BLOCK) void attn_w2_bwd_apply_kernel(int n, int 
     for (int i = blockIdx.x * GPB + grp; i < n; i += gridDim.x * GPB) {
         const float xqi = xq[(size_t)i * C + c];
         float gq = 0.f;
-        for (int k = 0; k < K; k++) {
-            const size_t r = (size_t)i * K + k;
-            const int j = idx[r];
-            const float a0 = p1[3 * r], a1 = p1[3 * r + 1], a2 = p1[3 * r + 2];
-            const float w = pe_of(q, a0, a1, a2) - (xqi - xk[(size_t)j * C + c]);
-            const float xh = (w - q.mean) * q.invstd;
-            const float y = xh * q.gamma + q.beta;
-            float dw1 = 0.f;
+        for (int k0 = 0; k0 < K; k0 += AT_U) {
+            PairBatch pb; load_pairs<C>(pb, i, k0, K, c, idx, p1, xk);
+            float gd[AT_U][G];
 #pragma unroll
-            for (int g = 0; g < G; g++) dw1 += wa[g] * gw2[r * G + g];
-            const float dy = y > 0.f ? dw1 : 0.f;
-            const float dw = q.gamma * q.invstd * ((dy - c0) - xh * c1);          // BatchNorm backward, train mode
-            unsafeAtomicAdd(gxk + (size_t)j * C + c, dw);            // w = p_r - x_q + x_k[j]
-            gq -= dw;
-            d0 += dw * a0; d1 += dw * a1; d2 += dw * a2; db += dw;
-            const float t0 = group_sum<C>(q.w0 * dw), t1 = group_sum<C>(q.w1 * dw), t2 = group_sum<C>(q.w2 * dw);
-            if (c < 3) gp1[3 * r + c] = (c == 0) ? t0 : (c == 1) ? t1 : t2;
+            for (int u = 0; u < AT_U; u++) {
+                const size_t r = (size_t)i * K + min(k0 + u, K - 1);
+#pragma unroll
+                for (int g = 0; g < G; g++) gd[u][g] = gw2[r * G + g];
+            }
+#pragma unroll
+            for (int u = 0; u < AT_U; u++) {
+                if (k0 + u < K) {
+                    const size_t r = (size_t)i * K + k0 + u;
+                    const float a0 = pb.a0[u], a1 = pb.a1[u], a2 = pb.a2[u];
+                    const float w = pe_of(q, a0, a1, a2) - (xqi - pb.xr[u]);
+                    const float xh = (w - q.mean) * q.invstd;
+                    const float y = xh * q.gamma + q.beta;
+                    float dw1 = 0.f;
+#pragma unroll
+                    for (int g = 0; g < G; g++) dw1 += wa[g] * gd[u][g];
+                    const float dy = y > 0.f ? dw1 : 0.f;
+                    const float dw = q.gamma * q.invstd * ((dy - c0) - xh * c1);  // BatchNorm backward, train mode
+                    unsafeAtomicAdd(gxk + (size_t)pb.j[u] * C + c, dw);          // w = p_r - x_q + x_k[j]
+                    gq -= dw;
+                    d0 += dw * a0; d1 += dw * a1; d2 += dw * a2; db += dw;
+                    const float t0 = group_sum<C>(q.w0 * dw), t1 = group_sum<C>(q.w1 * dw), t2 = group_sum<C>(q.w2 * dw);
+                    if (c < 3) gp1[3 * r + c] = (c == 0) ? t0 : (c == 1) ? t1 : t2;
+                }
+            }
         }
         gxq[(size_t)i * C + c] = gq;
     }
@@ -275,10 +331,14 @@ __global__ __launch_bounds__(AT_BLOCK) void attn_agg_forward_kernel(int n, int K
     PairParams q; q.w0 = W3C[3 * c]; q.w1 = W3C[3 * c + 1]; q.w2 = W3C[3 * c + 2]; q.b = b3C[c];
     for (int i = blockIdx.x * GPB + grp; i < n; i += gridDim.x * GPB) {
         float acc = 0.f;
-        for (int k = 0; k < K; k++) {
-            const size_t r = (size_t)i * K + k;
-            const int j = idx[r];
-            acc += (xv[(size_t)j * C + c] + pe_of(q, p1[3 * r], p1[3 * r + 1], p1[3 * r + 2])) * a[r * G + (c % G)];
+        for (int k0 = 0; k0 < K; k0 += AT_U) {
+            PairBatch pb; load_pairs<C>(pb, i, k0, K, c, idx, p1, xv);
+            float av[AT_U];
+#pragma unroll
+            for (int u = 0; u < AT_U; u++) av[u] = a[((size_t)i * K + min(k0 + u, K - 1)) * G + (c % G)];
+#pragma unroll
+            for (int u = 0; u < AT_U; u++)
+                if (k0 + u < K) acc += (pb.xr[u] + pe_of(q, pb.a0[u], pb.a1[u], pb.a2[u])) * av[u];
         }
         out[(size_t)i * C + c] = acc;
     }
@@ -297,12 +357,19 @@ __global__ __launch_bounds__(AT_BLOCK) void attn_agg_backward_kernel(int n, int 
     float d0 = 0.f, d1 = 0.f, d2 = 0.f, db = 0.f;
     for (int i = blockIdx.x * GPB + grp; i < n; i += gridDim.x * GPB) {
         const float g = go[(size_t)i * C + c];
-        for (int k = 0; k < K; k++) {
-            const size_t r = (size_t)i * K + k;
-            const int j = idx[r];
-            const float a0 = p1[3 * r], a1 = p1[3 * r + 1], a2 = p1[3 * r + 2];
-            const float av = a[r * G + (c % G)];
-            const float xvj = xv[(size_t)j * C + c];
+        for (int k0 = 0; k0 < K; k0 += AT_U) {
+          PairBatch pb; load_pairs<C>(pb, i, k0, K, c, idx, p1, xv);
+          float avs[AT_U];
+#pragma unroll
+          for (int u = 0; u < AT_U; u++) avs[u] = a[((size_t)i * K + min(k0 + u, K - 1)) * G + (c % G)];
+#pragma unroll
+          for (int u = 0; u < AT_U; u++) {
+            if (k0 + u >= K) continue;
+            const size_t r = (size_t)i * K + k0 + u;
+            const int j = pb.j[u];
+            const float a0 = pb.a0[u], a1 = pb.a1[u], a2 = pb.a2[u];
+            const float av = avs[u];
+            const float xvj = pb.xr[u];
             const float dpe = g * av;                                // d out / d (x_v[j] + p_r)
             unsafeAtomicAdd(gxv + (size_t)j * C + c, dpe);
             d0 += dpe * a0; d1 += dpe * a1; d2 += dpe * a2; db += dpe;
@@ -313,6 +380,7 @@ __global__ __launch_bounds__(AT_BLOCK) void attn_agg_backward_kernel(int n, int 
 #pragma unroll
             for (int st = G; st < C; st <<= 1) da += __shfl_xor(da, st);
             if (c < G) ga[r * G + c] = da;
+          }
         }
     }
     red[0][threadIdx.x] = d0; red[1][threadIdx.x] = d1; red[2][threadIdx.x] = d2; red[3][threadIdx.x] = db;

@@ -98,8 +98,10 @@ __device__ __forceinline__ void bn_sum_partials(int C, int nblocks, const float*
                                                 double& s0, double& s1)
 {
     double a0 = 0.0, a1 = 0.0;
-    if (c < C)
+    if (c < C) {
+#pragma unroll 8
         for (int b = js; b < nblocks; b += 16) { a0 += (double)partial[((size_t)b * 2) * C + c]; a1 += (double)partial[((size_t)b * 2 + 1) * C + c]; }
+    }
     red[js][threadIdx.x & 15][0] = a0; red[js][threadIdx.x & 15][1] = a1;
     __syncthreads();
     s0 = s1 = 0.0;

@@ -101,8 +101,10 @@ __global__ __launch_bounds__(256) void skinny_linear_wgrad_finalize_kernel(int n
     __shared__ double red[16][16];
     const int e = blockIdx.x * 16 + (threadIdx.x & 15), js = threadIdx.x >> 4, total = npairs + cout;
     double a = 0.0;
-    if (e < total)
+    if (e < total) {
+#pragma unroll 8
         for (int b = js; b < nblocks; b += 16) a += (double)partial[(size_t)b * total + e];
+    }
     red[js][threadIdx.x & 15] = a;
     __syncthreads();
     if (js == 0 && e < total) {
