@@ -232,8 +232,10 @@ __global__ __launch_bounds__(AT_BLOCK) void attn_w2_bwd_reduce_kernel(int n, int
     }
 }
 
-// out[e] = sum_b partial[b][e] (fp64), e < nvals; 16 values x 16 slices per workgroup
-__global__ __launch_bounds__(256) void attn_sum_partials_kernel(int nvals, int nblocks, const float* __restrict__ partial, float* __restrict__ out)
+// sum_b partial[b][e] (fp64) for e < nvals, 16 values x 16 slices per workgroup; the values go to up to four destination arrays laid
+// end to end (segment s covers [seg.begin[s], seg.begin[s+1])), and — if `sums` is given — also to sums[e]
+struct SumSegments { float* dst[4]; int begin[5]; };
+__global__ __launch_bounds__(256) void attn_sum_partials_kernel(int nvals, int nblocks, const float* __restrict__ partial, SumSegments seg, float* __restrict__ sums)
 {
     __shared__ double red[16][16];
     const int e = blockIdx.x * 16 + (threadIdx.x & 15), js = threadIdx.x >> 4;
@@ -247,7 +249,10 @@ __global__ __launch_bounds__(256) void attn_sum_partials_kernel(int nvals, int n
     if (js == 0 && e < nvals) {
         double s = 0.0;
         for (int j = 0; j < 16; j++) s += red[j][threadIdx.x & 15];
-        out[e] = (float)s;
+        if (sums) sums[e] = (float)s;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            if (seg.dst[t] && e >= seg.begin[t] && e < seg.begin[t + 1]) seg.dst[t][e - seg.begin[t]] = (float)s;
     }
 }
 
@@ -460,18 +465,16 @@ CBL_EXPORT int cbl_attn_w2_backward(int n, int K, int C, int G, const float* x_q
     float* partial = reinterpret_cast<float*>(workspace);
     float* sums = partial + (size_t)AT_MAX_BLOCKS * nv1;
     AT_DISPATCH(attn_w2_bwd_reduce_kernel, n, K, x_q, x_k, idx, p1, W3C, b3C, save_mean, save_invstd, bn_weight, bn_bias, Wa, grad_w2, partial);
-    hipLaunchKernelGGL(attn_sum_partials_kernel, dim3(cbl_div_up(nv1, 16)), dim3(256), 0, st, nv1, nb, partial, sums);
-    // sums = [grad_beta | grad_gamma | grad_Wa | grad_ba]
-    (void)hipMemcpyAsync(grad_bn_bias, sums, sizeof(float) * C, hipMemcpyDeviceToDevice, st);
-    (void)hipMemcpyAsync(grad_bn_weight, sums + C, sizeof(float) * C, hipMemcpyDeviceToDevice, st);
-    (void)hipMemcpyAsync(grad_Wa, sums + 2 * C, sizeof(float) * G * C, hipMemcpyDeviceToDevice, st);
-    (void)hipMemcpyAsync(grad_ba, sums + 2 * C + G * C, sizeof(float) * G, hipMemcpyDeviceToDevice, st);
+    // Q1's sums = [grad_beta | grad_gamma | grad_Wa | grad_ba]: written to the four outputs and kept in `sums` for Q2 (BatchNorm's two means)
+    SumSegments s1; s1.dst[0] = grad_bn_bias; s1.dst[1] = grad_bn_weight; s1.dst[2] = grad_Wa; s1.dst[3] = grad_ba;
+    s1.begin[0] = 0; s1.begin[1] = C; s1.begin[2] = 2 * C; s1.begin[3] = 2 * C + G * C; s1.begin[4] = nv1;
+    hipLaunchKernelGGL(attn_sum_partials_kernel, dim3(cbl_div_up(nv1, 16)), dim3(256), 0, st, nv1, nb, partial, s1, sums);
     AT_DISPATCH(attn_w2_bwd_apply_kernel, n, K, x_q, x_k, idx, p1, W3C, b3C, save_mean, save_invstd, bn_weight, bn_bias, Wa, grad_w2, sums,
                 grad_xq, grad_xk, grad_p1, partial);
-    // partial rows are [dW3C (C x 3, row-major like the weight) | db3C]: sum them straight into the two outputs
-    hipLaunchKernelGGL(attn_sum_partials_kernel, dim3(cbl_div_up(nv2, 16)), dim3(256), 0, st, nv2, nb, partial, sums);
-    (void)hipMemcpyAsync(grad_W3C, sums, sizeof(float) * 3 * C, hipMemcpyDeviceToDevice, st);
-    (void)hipMemcpyAsync(grad_b3C, sums + 3 * C, sizeof(float) * C, hipMemcpyDeviceToDevice, st);
+    // partial rows are [dW3C (C x 3, row-major like the weight) | db3C]: summed straight into the two outputs
+    SumSegments s2; s2.dst[0] = grad_W3C; s2.dst[1] = grad_b3C; s2.dst[2] = s2.dst[3] = nullptr;
+    s2.begin[0] = 0; s2.begin[1] = 3 * C; s2.begin[2] = s2.begin[3] = s2.begin[4] = nv2;
+    hipLaunchKernelGGL(attn_sum_partials_kernel, dim3(cbl_div_up(nv2, 16)), dim3(256), 0, st, nv2, nb, partial, s2, (float*)nullptr);
     return cbl_status();
 }
 
@@ -501,10 +504,9 @@ CBL_EXPORT int cbl_attn_agg_backward(int n, int K, int C, int G, const float* x_
     const int nb = at_blocks(n, C);
     const int nv2 = 4 * C;
     float* partial = reinterpret_cast<float*>(workspace);
-    float* sums = partial + (size_t)AT_MAX_BLOCKS * (2 * C + G * C + G);
     AT_DISPATCH(attn_agg_backward_kernel, n, K, x_v, idx, p1, W3C, b3C, a, grad_out, grad_xv, grad_p1, grad_a, partial);
-    hipLaunchKernelGGL(attn_sum_partials_kernel, dim3(cbl_div_up(nv2, 16)), dim3(256), 0, st, nv2, nb, partial, sums);
-    (void)hipMemcpyAsync(grad_W3C, sums, sizeof(float) * 3 * C, hipMemcpyDeviceToDevice, st);
-    (void)hipMemcpyAsync(grad_b3C, sums + 3 * C, sizeof(float) * C, hipMemcpyDeviceToDevice, st);
+    SumSegments s2; s2.dst[0] = grad_W3C; s2.dst[1] = grad_b3C; s2.dst[2] = s2.dst[3] = nullptr;
+    s2.begin[0] = 0; s2.begin[1] = 3 * C; s2.begin[2] = s2.begin[3] = s2.begin[4] = nv2;
+    hipLaunchKernelGGL(attn_sum_partials_kernel, dim3(cbl_div_up(nv2, 16)), dim3(256), 0, st, nv2, nb, partial, s2, (float*)nullptr);
     return cbl_status();
 }
