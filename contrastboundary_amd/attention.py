@@ -1,6 +1,7 @@
 """Fused C-wide part of PointTransformerLayer's vector attention (csrc/attention.hip, /root/reference/pytorch/model/blocks.py:31-44):
 `attn_w2` and `attn_agg` as autograd Functions over the layer's own parameter tensors.  Available for the two full-resolution
-stages (C = 32 / 64 with share_planes = 8, K <= 64); `supported()` says when."""
+stages (C = 32 / 64 with share_planes = 8, K <= 64) in training mode (the BatchNorm inside is the train-mode one; evaluation takes the
+separate kernels); `supported()` says when."""
 import ctypes
 
 import torch
@@ -21,7 +22,7 @@ def _workspace(nbytes, device):
 
 def supported(layer, x):
     C = layer.out_planes
-    return (x.is_cuda and x.dtype == torch.float32 and layer.mid_planes == C and layer.share_planes == 8 and C in (32, 64)
+    return (layer.training and x.is_cuda and x.dtype == torch.float32 and layer.mid_planes == C and layer.share_planes == 8 and C in (32, 64)
             and layer.nsample <= 64 and x.shape[0] * layer.nsample >= 16384
             and isinstance(layer.linear_w[0], torch.nn.BatchNorm1d) and layer.linear_w[0].track_running_stats and layer.linear_w[0].momentum is not None)
 
