@@ -99,24 +99,14 @@ __device__ __forceinline__ void heap_replace_root_par(float& hd, int& hi, int la
     hd = reached ? nd : hd; hi = reached ? ni : hi;
 }
 
+// one query by one wave: the whole scan + heap sort (`heap_mem`: this wave's 2*K words of LDS when the heap does not fit the lanes)
 template <bool IN_LANES>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void knn_exact_wave_kernel(
-    int b, int m, int K,
-    const float* __restrict__ xyz, const float* __restrict__ new_xyz,
-    const int* __restrict__ offset, const int* __restrict__ new_offset,
-    int* __restrict__ idx, float* __restrict__ dist2,
-    const int* __restrict__ worklist, const int* __restrict__ worklist_count, int min_work)
+__device__ __forceinline__ void exact_wave_query(int q, int b, int K, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+                                                 const int* __restrict__ offset, const int* __restrict__ new_offset,
+                                                 int* __restrict__ idx, float* __restrict__ dist2, float* heap_mem)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // work items: all m queries, or (worklist mode) the listed queries — the latter only when the list is longer than
-    // `min_work` (shorter lists are taken by knn_replay_kernel), walked grid-stride
-    const int n_items = worklist ? *worklist_count : m;
-    if (worklist && n_items <= min_work) return;
-    for (int w = blockIdx.x * WAVES_PER_BLOCK + wave; w < n_items; w += gridDim.x * WAVES_PER_BLOCK) {
-    const int q = __builtin_amdgcn_readfirstlane(worklist ? worklist[w] : w);
-
+    {
     const int c = cbl_cloud_of(q, new_offset, b);
     const int start = (c == 0) ? 0 : offset[c - 1];                  // :75-79
     const int end = offset[c];                                       // :80
@@ -124,7 +114,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void knn_exact_wave_kernel(
 
     typename std::conditional<IN_LANES, LaneHeap, LdsHeap>::type h;
     if constexpr (!IN_LANES) {
-        h.d = reinterpret_cast<float*>(smem) + (size_t)wave * 2 * K;
+        h.d = heap_mem;
         h.i = reinterpret_cast<int*>(h.d + K);
     }
     h.init(K, 1e10f, start);                                         // :91-94
@@ -179,6 +169,24 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void knn_exact_wave_kernel(
     }
 }
 
+template <bool IN_LANES>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void knn_exact_wave_kernel(
+    int b, int m, int K,
+    const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+    const int* __restrict__ offset, const int* __restrict__ new_offset,
+    int* __restrict__ idx, float* __restrict__ dist2,
+    const int* __restrict__ worklist, const int* __restrict__ worklist_count)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // work items: all m queries, or (worklist mode) the listed queries, walked grid-stride
+    const int n_items = worklist ? *worklist_count : m;
+    for (int w = blockIdx.x * WAVES_PER_BLOCK + wave; w < n_items; w += gridDim.x * WAVES_PER_BLOCK) {
+        const int q = __builtin_amdgcn_readfirstlane(worklist ? worklist[w] : w);
+        exact_wave_query<IN_LANES>(q, b, K, xyz, new_xyz, offset, new_offset, idx, dist2, reinterpret_cast<float*>(smem) + (size_t)wave * 2 * K);
+    }
+}
+
 
 // ---------------------------------------------------------------------------------------------------------
 // Replay kernel for the handful of queries the grid kernel could not certify: ONE 1024-lane workgroup per query.
@@ -207,9 +215,14 @@ __global__ __launch_bounds__(64 * RP_WAVES) void knn_replay_kernel(
     __shared__ int overflow_s;
 
     const int n_work = *worklist_count;
-    if (n_work > RP_MAX_WORK) return;                           // long lists (lattices: every query tied) go to the wave kernel
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (n_work > RP_MAX_WORK) {
+        // long lists (lattices: every query tied): parallelism across entries is plentiful, every wave of the grid takes whole queries
+        for (int w = blockIdx.x * RP_WAVES + wave; w < n_work; w += gridDim.x * RP_WAVES)
+            exact_wave_query<true>(__builtin_amdgcn_readfirstlane(worklist[w]), b, K, xyz, new_xyz, offset, new_offset, idx, dist2, nullptr);
+        return;
+    }
     for (int work = blockIdx.x; work < n_work; work += gridDim.x) {
     __syncthreads();                                            // previous entry's LDS lists are no longer read
     const int q = worklist[work];
@@ -334,21 +347,19 @@ static int launch_knn_exact(int b, int m, int K, const float* xyz, const float* 
 {
     const int nq = worklist ? max_work : m;
     if (nq <= 0) return CBL_OK;
-    int min_work = 0;
     if (worklist && K <= 64) {
-        // short lists (the normal case: a handful of tied queries): one 1024-lane workgroup per entry
+        // one launch: a 1024-lane workgroup per entry for short lists (the normal case: a handful of tied queries), a wave per entry for long ones
         hipLaunchKernelGGL(knn_replay_kernel, dim3(min(nq, RP_GRID)), dim3(64 * RP_WAVES), 0, st, b, K, xyz, new_xyz, offset, new_offset, idx, dist2, worklist, worklist_count);
-        if (nq <= RP_MAX_WORK) return cbl_status();
-        min_work = RP_MAX_WORK;                                 // longer lists: wave per entry (below), a no-op otherwise
+        return cbl_status();
     }
     const unsigned blocks = worklist ? (unsigned)min((long long)cbl_div_up(nq, WAVES_PER_BLOCK), 2048LL) : cbl_div_up(nq, WAVES_PER_BLOCK);
     const dim3 grid(blocks), block(64 * WAVES_PER_BLOCK);
     if (K <= 64)
         hipLaunchKernelGGL(knn_exact_wave_kernel<true>, grid, block, 0, st,
-                           b, m, K, xyz, new_xyz, offset, new_offset, idx, dist2, worklist, worklist_count, min_work);
+                           b, m, K, xyz, new_xyz, offset, new_offset, idx, dist2, worklist, worklist_count);
     else
         hipLaunchKernelGGL(knn_exact_wave_kernel<false>, grid, block, (size_t)WAVES_PER_BLOCK * K * 8, st,
-                           b, m, K, xyz, new_xyz, offset, new_offset, idx, dist2, worklist, worklist_count, min_work);
+                           b, m, K, xyz, new_xyz, offset, new_offset, idx, dist2, worklist, worklist_count);
     return cbl_status();
 }
 
