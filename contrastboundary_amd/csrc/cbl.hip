@@ -115,6 +115,9 @@ __device__ __forceinline__ void contrast_row(ContrastRow<G, DV>& r, int i, int g
     const int cnt = group_sum_i<G>(r.pos ? 1 : 0);
     const int nvalid = group_sum_i<G>(r.nb ? 1 : 0);
     r.valid = cnt > 0 && cnt < nvalid;                              // :212-213 / solve_samples_mask head.py:621-640
+    // a point without both kinds of neighbours contributes neither loss nor gradient (:212-213, :233): its group stops before the
+    // feature gather — the labels decide, and only the boundary points (a fraction of the scene) pay for the 4*d*ns-byte gather
+    if (!r.valid) { r.dist = 1.f; r.e = 0.f; r.P = 0.f; r.A = 1.f; return; }
     const float4* fi = reinterpret_cast<const float4*>(feat + (size_t)i * d);
     const float4* fj = reinterpret_cast<const float4*>(feat + (size_t)r.nbr * d);
     float acc = 0.f;
@@ -220,7 +223,10 @@ __global__ __launch_bounds__(256) void contrast_bwd_kernel(int m, int nsample, c
             if (tf_variant && r.dist <= 1e-6f) coef = 0.f;           // sqrt(max(s, 1e-12)): flat below the clamp
         }
     }
-    // phase 2: groups of this wave one after the other (wave-uniform loop), lanes = (pair slot, channel)
+    // phase 2: groups of this wave one after the other (wave-uniform loop), lanes = (pair slot, channel).
+    // (Handing the differences of phase 1 over through LDS instead of re-gathering f_j was measured SLOWER, 100 vs 93 us: the
+    // kernel is bound by the device-scope atomics, ~225 G float atomics/s, not by the second gather, which hits L2.)
+    if (__ballot(coef != 0.f) == 0ull) return;                      // no pair of this wave carries a gradient
     const int ch = lane % D, slot = lane / D;
     for (int g = 0; g < 64 / G; g++) {
         const int pt = ((blockIdx.x * 256 + (threadIdx.x & ~63)) / G) + g;          // point of group g (wave-uniform)

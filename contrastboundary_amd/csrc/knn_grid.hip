@@ -229,9 +229,62 @@ template <int G> __device__ __forceinline__ int dpp_shr1_i(int v);
 template <> __device__ __forceinline__ int dpp_shr1_i<16>(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false); }
 template <> __device__ __forceinline__ int dpp_shr1_i<64>(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
 template <> __device__ __forceinline__ int dpp_shr1_i<32>(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }   // lane 32 receives lane 31: masked by gl > 0
+// the same shifts with bound_ctrl: the first lane of the row / wave receives 0 (the bit pattern of +0.0: below every distance)
+template <int G> __device__ __forceinline__ int dpp_shr1_zero(int v)
+{
+    if constexpr (G == 16) return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    else                   return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true);
+}
 template <> __device__ __forceinline__ float dpp_shr1_f<16>(float v) { return __int_as_float(dpp_shr1_i<16>(__float_as_int(v))); }
 template <> __device__ __forceinline__ float dpp_shr1_f<64>(float v) { return __int_as_float(dpp_shr1_i<64>(__float_as_int(v))); }
 template <> __device__ __forceinline__ float dpp_shr1_f<32>(float v) { return __int_as_float(dpp_shr1_i<32>(__float_as_int(v))); }
+
+constexpr int WV_NB = 16;                                           // candidate registers per lane: T <= 1024
+
+template <int CTRL> __device__ __forceinline__ int dppx_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }   // every lane has a source: `old` is never used
+struct PermQuadXor1  { __device__ __forceinline__ int operator()(int v, int) const { return dppx_i<0xB1>(v); } };    // lane ^ 1
+struct PermQuadXor2  { __device__ __forceinline__ int operator()(int v, int) const { return dppx_i<0x4E>(v); } };    // lane ^ 2
+struct PermQuadMir   { __device__ __forceinline__ int operator()(int v, int) const { return dppx_i<0x1B>(v); } };    // lane ^ 3
+struct PermHalfMir   { __device__ __forceinline__ int operator()(int v, int) const { return dppx_i<0x141>(v); } };   // lane ^ 7
+struct PermRowMir    { __device__ __forceinline__ int operator()(int v, int) const { return dppx_i<0x140>(v); } };   // lane ^ 15
+struct PermRowRor8   { __device__ __forceinline__ int operator()(int v, int) const { return dppx_i<0x128>(v); } };   // lane ^ 8
+struct PermSwzXor4   { __device__ __forceinline__ int operator()(int v, int) const { return __builtin_amdgcn_ds_swizzle(v, 0x101f); } };
+struct PermSwzXor16  { __device__ __forceinline__ int operator()(int v, int) const { return __builtin_amdgcn_ds_swizzle(v, 0x401f); } };
+struct PermSwzMir32  { __device__ __forceinline__ int operator()(int v, int) const { return __builtin_amdgcn_ds_swizzle(v, 0x7c1f); } };   // lane ^ 31
+struct PermMir64     { __device__ __forceinline__ int operator()(int v, int lane) const { return __builtin_amdgcn_ds_bpermute((63 - lane) << 2, v); } };
+
+// compare-exchange with the partner lane: the lower lane of a pair keeps the smaller (distance, index)
+template <bool LEX, class Perm> __device__ __forceinline__ void sort_cx(float& d, int& i, bool lower, int lane, Perm perm)
+{
+    const float pd = __int_as_float(perm(__float_as_int(d), lane));
+    const int pi = perm(i, lane);
+    if (LEX) {
+        const bool take = lower ? (pd < d || (pd == d && (unsigned)pi < (unsigned)i)) : (pd > d || (pd == d && (unsigned)pi > (unsigned)i));
+        d = take ? pd : d; i = take ? pi : i;
+    } else {
+        // min / max + "did my distance change" on the BIT PATTERNS (distances are >= +0, so they order like integers; integer
+        // min / max need no NaN canonicalisation): 5-7 VALU per stage instead of the 13 of a ?: over two float compares.
+        // On a tie both lanes keep their own (distance, index).
+        const int di = __float_as_int(d), pdi = __float_as_int(pd);
+        const int nd = lower ? min(di, pdi) : max(di, pdi);
+        i = (nd != di) ? pi : i; d = __int_as_float(nd);
+    }
+}
+// ascending bitonic sort of one (d, i) per lane over the 64 lanes ("flip" form: every merge starts with a mirror exchange)
+template <bool LEX> __device__ __forceinline__ void wave_sort64(float& d, int& i, int lane)
+{
+    const bool l1 = !(lane & 1), l2 = !(lane & 2), l4 = !(lane & 4), l8 = !(lane & 8), l16 = !(lane & 16), l32 = !(lane & 32);
+    sort_cx<LEX>(d, i, l1, lane, PermQuadXor1());
+    sort_cx<LEX>(d, i, l2, lane, PermQuadMir());   sort_cx<LEX>(d, i, l1, lane, PermQuadXor1());
+    sort_cx<LEX>(d, i, l4, lane, PermHalfMir());   sort_cx<LEX>(d, i, l2, lane, PermQuadXor2()); sort_cx<LEX>(d, i, l1, lane, PermQuadXor1());
+    sort_cx<LEX>(d, i, l8, lane, PermRowMir());    sort_cx<LEX>(d, i, l4, lane, PermSwzXor4());  sort_cx<LEX>(d, i, l2, lane, PermQuadXor2());
+    sort_cx<LEX>(d, i, l1, lane, PermQuadXor1());
+    sort_cx<LEX>(d, i, l16, lane, PermSwzMir32()); sort_cx<LEX>(d, i, l8, lane, PermRowRor8());  sort_cx<LEX>(d, i, l4, lane, PermSwzXor4());
+    sort_cx<LEX>(d, i, l2, lane, PermQuadXor2());  sort_cx<LEX>(d, i, l1, lane, PermQuadXor1());
+    sort_cx<LEX>(d, i, l32, lane, PermMir64());    sort_cx<LEX>(d, i, l16, lane, PermSwzXor16()); sort_cx<LEX>(d, i, l8, lane, PermRowRor8());
+    sort_cx<LEX>(d, i, l4, lane, PermSwzXor4());   sort_cx<LEX>(d, i, l2, lane, PermQuadXor2()); sort_cx<LEX>(d, i, l1, lane, PermQuadXor1());
+}
+__device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
 // LEX: order the list by (d2, index) instead of d2 alone — needed only by the "any tie" policy (set_exact == 2), whose result must not
 // depend on the order in which the cells were filled; the other policies replay every tie that matters and skip the extra compares.
@@ -262,6 +315,8 @@ __global__ __launch_bounds__(256) void knn_grid_group_kernel(int b, int m, int K
 
     float ed = INFINITY; int ei = -1;                               // element `gl` of the group's ascending top list
     float rejmin = INFINITY;                                        // min d2 over candidates not in the list (per lane, reduced at the end)
+    int evict = 0x7f800000;                                         // bit pattern; lane K-1's copy is the one that counts (merged below)
+    const int last_src = ((lane & ~(G - 1)) + K - 1) << 2;          // ds_bpermute address of the group's K-th list element
     bool done = !live;
 
     for (int r = 1;; r++) {
@@ -296,9 +351,30 @@ __global__ __launch_bounds__(256) void knn_grid_group_kernel(int b, int m, int K
                             d2 = cbl_dist2(qx, qy, qz, v.x, v.y, v.z);       // (new - x)^2 ..., knnquery_cuda_kernel.cu:99
                             ci = __float_as_int(v.w);
                         }
-                        const float worst = __shfl(ed, K - 1, G); const unsigned worst_i = LEX ? (unsigned)__shfl(ei, K - 1, G) : 0u;
+                        const float worst = __int_as_float(__builtin_amdgcn_ds_bpermute(last_src, __float_as_int(ed)));
+                        const unsigned worst_i = LEX ? (unsigned)__builtin_amdgcn_ds_bpermute(last_src, ei) : 0u;
                         const bool pass = d2 < worst || (LEX && d2 == worst && (unsigned)ci < worst_i);
-                        rejmin = fminf(rejmin, pass ? INFINITY : d2);
+                        rejmin = __int_as_float(min(__float_as_int(rejmin), pass ? 0x7f800000 : __float_as_int(d2)));   // bit patterns of values >= +0
+                        if constexpr (!LEX && G <= 32) {
+                            // insertion on the BIT PATTERNS of the distances (all >= +0: they order like integers):
+                            //   new e[j] = min(e[j], max(e[j-1], c))  with e[-1] = 0   — 16 VALU per step instead of 36
+                            unsigned gm = (unsigned)(__ballot(pass) >> (grp * G)) & (G == 32 ? ~0u : ((1u << G) - 1u));
+                            const int d2i = __float_as_int(d2);
+                            while (__any(gm != 0)) {                          // each group inserts its next passing candidate
+                                const bool has = gm != 0;
+                                int l; asm("v_ffbl_b32 %0, %1" : "=v"(l) : "v"(gm));      // -1 when empty: any lane, masked by `has`
+                                gm &= gm - 1;
+                                const int src = (l << 2) + grp * (G * 4);
+                                int dci = __builtin_amdgcn_ds_bpermute(src, d2i); const int ic = __builtin_amdgcn_ds_bpermute(src, ci);
+                                dci = has ? dci : 0x7f800000;
+                                const int edi = __float_as_int(ed);
+                                int pdi = dpp_shr1_zero<G>(edi), pidx = dpp_shr1_zero<G>(ei);     // left neighbour's element, 0 for the first
+                                if (G == 32) pdi = gl ? pdi : 0;
+                                evict = min(evict, max(edi, dci));            // lane K-1: the evicted element, or a candidate that lost its race
+                                ei = (edi > dci) ? ((pdi > dci) ? pidx : ic) : ei;        // larger elements move right
+                                ed = __int_as_float(min(edi, max(pdi, dci)));
+                            }
+                        } else {
                         mask_t gm = (__ballot(pass) >> (grp * G)) & (G == 64 ? ~0ull : ((1ull << G) - 1ull));
                         while (__any(gm != 0)) {                              // each group inserts its next passing candidate
                             const bool has = gm != 0;
@@ -311,6 +387,7 @@ __global__ __launch_bounds__(256) void knn_grid_group_kernel(int b, int m, int K
                             const bool left_gt = (gl > 0) && (pd > dc || (LEX && pd == dc && (unsigned)pidx > (unsigned)ic));
                             if (gl == K - 1) rejmin = fminf(rejmin, gt ? ed : dc);   // evicted element, or a candidate that lost its race
                             if (gt) { if (left_gt) { ed = pd; ei = pidx; } else { ed = dc; ei = ic; } }
+                        }
                         }
                     }
                 }
@@ -325,7 +402,7 @@ __global__ __launch_bounds__(256) void knn_grid_group_kernel(int b, int m, int K
 
     // certify: list full, K distinct distances, no outside candidate tied with the K-th  (CblTopK::certify)
     const float worst = __shfl(ed, K - 1, G);
-    float rm = rejmin;
+    float rm = fminf(rejmin, gl == K - 1 ? __int_as_float(evict) : INFINITY);
 #pragma unroll
     for (int s = G / 2; s >= 1; s >>= 1) rm = fminf(rm, __shfl_xor(rm, s, G));
     const float pd = dpp_shr1_f<G>(ed);
@@ -347,43 +424,6 @@ __global__ __launch_bounds__(256) void knn_grid_group_kernel(int b, int m, int K
 // bisects a threshold tau with K <= #{d2 <= tau} <= 64 by ballot+popcount, compacts the survivors to one per lane through LDS
 // and sorts them with a 21-stage bitonic network (DPP / ds_swizzle exchanges).  Lanes [0,K) then hold the ascending list, all
 // other candidates feed `rejmin`, and the usual certification applies; further shells (rare) use the insertion step.
-constexpr int WV_NB = 16;                                           // candidate registers per lane: T <= 1024
-
-template <int CTRL> __device__ __forceinline__ int dppx_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
-struct PermQuadXor1  { __device__ __forceinline__ int operator()(int v, int) const { return dppx_i<0xB1>(v); } };    // lane ^ 1
-struct PermQuadXor2  { __device__ __forceinline__ int operator()(int v, int) const { return dppx_i<0x4E>(v); } };    // lane ^ 2
-struct PermQuadMir   { __device__ __forceinline__ int operator()(int v, int) const { return dppx_i<0x1B>(v); } };    // lane ^ 3
-struct PermHalfMir   { __device__ __forceinline__ int operator()(int v, int) const { return dppx_i<0x141>(v); } };   // lane ^ 7
-struct PermRowMir    { __device__ __forceinline__ int operator()(int v, int) const { return dppx_i<0x140>(v); } };   // lane ^ 15
-struct PermRowRor8   { __device__ __forceinline__ int operator()(int v, int) const { return dppx_i<0x128>(v); } };   // lane ^ 8
-struct PermSwzXor4   { __device__ __forceinline__ int operator()(int v, int) const { return __builtin_amdgcn_ds_swizzle(v, 0x101f); } };
-struct PermSwzXor16  { __device__ __forceinline__ int operator()(int v, int) const { return __builtin_amdgcn_ds_swizzle(v, 0x401f); } };
-struct PermSwzMir32  { __device__ __forceinline__ int operator()(int v, int) const { return __builtin_amdgcn_ds_swizzle(v, 0x7c1f); } };   // lane ^ 31
-struct PermMir64     { __device__ __forceinline__ int operator()(int v, int lane) const { return __builtin_amdgcn_ds_bpermute((63 - lane) << 2, v); } };
-
-// compare-exchange with the partner lane: the lower lane of a pair keeps the smaller (distance, index)
-template <bool LEX, class Perm> __device__ __forceinline__ void sort_cx(float& d, int& i, bool lower, int lane, Perm perm)
-{
-    const float pd = __int_as_float(perm(__float_as_int(d), lane));
-    const int pi = perm(i, lane);
-    const bool take = lower ? (pd < d || (LEX && pd == d && (unsigned)pi < (unsigned)i)) : (pd > d || (LEX && pd == d && (unsigned)pi > (unsigned)i));
-    d = take ? pd : d; i = take ? pi : i;
-}
-// ascending bitonic sort of one (d, i) per lane over the 64 lanes ("flip" form: every merge starts with a mirror exchange)
-template <bool LEX> __device__ __forceinline__ void wave_sort64(float& d, int& i, int lane)
-{
-    const bool l1 = !(lane & 1), l2 = !(lane & 2), l4 = !(lane & 4), l8 = !(lane & 8), l16 = !(lane & 16), l32 = !(lane & 32);
-    sort_cx<LEX>(d, i, l1, lane, PermQuadXor1());
-    sort_cx<LEX>(d, i, l2, lane, PermQuadMir());   sort_cx<LEX>(d, i, l1, lane, PermQuadXor1());
-    sort_cx<LEX>(d, i, l4, lane, PermHalfMir());   sort_cx<LEX>(d, i, l2, lane, PermQuadXor2()); sort_cx<LEX>(d, i, l1, lane, PermQuadXor1());
-    sort_cx<LEX>(d, i, l8, lane, PermRowMir());    sort_cx<LEX>(d, i, l4, lane, PermSwzXor4());  sort_cx<LEX>(d, i, l2, lane, PermQuadXor2());
-    sort_cx<LEX>(d, i, l1, lane, PermQuadXor1());
-    sort_cx<LEX>(d, i, l16, lane, PermSwzMir32()); sort_cx<LEX>(d, i, l8, lane, PermRowRor8());  sort_cx<LEX>(d, i, l4, lane, PermSwzXor4());
-    sort_cx<LEX>(d, i, l2, lane, PermQuadXor2());  sort_cx<LEX>(d, i, l1, lane, PermQuadXor1());
-    sort_cx<LEX>(d, i, l32, lane, PermMir64());    sort_cx<LEX>(d, i, l16, lane, PermSwzXor16()); sort_cx<LEX>(d, i, l8, lane, PermRowRor8());
-    sort_cx<LEX>(d, i, l4, lane, PermSwzXor4());   sort_cx<LEX>(d, i, l2, lane, PermQuadXor2()); sort_cx<LEX>(d, i, l1, lane, PermQuadXor1());
-}
-__device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
 template <bool SELF, bool LEX>
 __global__ __launch_bounds__(256) void knn_grid_wave_kernel(int b, int m, int K, const float* __restrict__ new_xyz,
@@ -447,7 +487,7 @@ __global__ __launch_bounds__(256) void knn_grid_wave_kernel(int b, int m, int K,
         if (T > 64) {
             float mx = -1.f;
 #pragma unroll
-            for (int j = 0; j < WV_NB; j++) mx = fmaxf(mx, d[j] < INFINITY ? d[j] : -1.f);
+            for (int j = 0; j < WV_NB; j++) if (j * 64 < T) mx = fmaxf(mx, d[j] < INFINITY ? d[j] : -1.f);
             mx = fmaxf(mx, __int_as_float(dppx_i<0xB1>(__float_as_int(mx))));
             mx = fmaxf(mx, __int_as_float(dppx_i<0x4E>(__float_as_int(mx))));
             mx = fmaxf(mx, __int_as_float(dppx_i<0x141>(__float_as_int(mx))));
@@ -459,7 +499,7 @@ __global__ __launch_bounds__(256) void knn_grid_wave_kernel(int b, int m, int K,
                 if (!(mid > lo && mid < hi)) break;                  // no float left between the brackets: ties, use the insertion path
                 int cnt = 0;
 #pragma unroll
-                for (int j = 0; j < WV_NB; j++) cnt += __popcll(__ballot(d[j] <= mid));
+                for (int j = 0; j < WV_NB; j++) if (j * 64 < T) cnt += __popcll(__ballot(d[j] <= mid));
                 if (cnt < K) lo = mid; else if (cnt > 64) hi = mid; else { tau = mid; fast = true; break; }
             }
         }
