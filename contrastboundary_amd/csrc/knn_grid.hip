@@ -285,6 +285,17 @@ template <bool LEX> __device__ __forceinline__ void wave_sort64(float& d, int& i
     sort_cx<LEX>(d, i, l4, lane, PermSwzXor4());   sort_cx<LEX>(d, i, l2, lane, PermQuadXor2()); sort_cx<LEX>(d, i, l1, lane, PermQuadXor1());
 }
 __device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+// minimum over the G lanes of a group of a value >= +0 (or +inf), on its bit pattern: four row-local DPP steps (the partner's value
+// folds into v_min_i32 as a DPP operand), then across the rows; every lane of the group gets the result
+template <int G> __device__ __forceinline__ float group_min_nonneg(float f)
+{
+    int v = __float_as_int(f);
+    v = min(v, dppx_i<0xB1>(v)); v = min(v, dppx_i<0x4E>(v)); v = min(v, dppx_i<0x141>(v)); v = min(v, dppx_i<0x140>(v));
+    if constexpr (G == 32) v = min(v, __builtin_amdgcn_ds_swizzle(v, 0x401f));
+    if constexpr (G == 64) v = min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+                                   min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+    return __int_as_float(v);
+}
 
 // LEX: order the list by (d2, index) instead of d2 alone — needed only by the "any tie" policy (set_exact == 2), whose result must not
 // depend on the order in which the cells were filled; the other policies replay every tie that matters and skip the extra compares.
@@ -319,6 +330,19 @@ __global__ __launch_bounds__(256) void knn_grid_group_kernel(int b, int m, int K
     const int last_src = ((lane & ~(G - 1)) + K - 1) << 2;          // ds_bpermute address of the group's K-th list element
     bool done = !live;
 
+    // the support ranges of the 9 rows of the initial block, fetched by lanes 0..8 of the group in ONE round of loads (instead of nine
+    // dependent ones, row after row) and handed out by ds_bpermute below.  Row order = the packed "nearest first" table of the loop.
+    int rs9 = 0, re9 = 0;
+    if (!done && gl < 9) {
+        const int o = (int)((0xa82091645ull >> (4 * gl)) & 0xFull);
+        const int y = cy + (o & 3) - 1, z = cz + (o >> 2) - 1;
+        if (y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
+            const int row = g.cell_base + g.nx * (y + g.ny * z);
+            rs9 = cell_start[row + max(cx - 1, 0)]; re9 = cell_start[row + min(cx + 1, g.nx - 1) + 1];
+        }
+    }
+    const int grp_src = (lane & ~(G - 1)) << 2;
+
     for (int r = 1;; r++) {
         // r == 1: the 3x3x3 block around the query's cell (shells 0 and 1) as 9 full rows;
         // r >= 2: shell r — face rows take the whole x-range, interior rows only the two end cells
@@ -338,7 +362,9 @@ __global__ __launch_bounds__(256) void knn_grid_group_kernel(int b, int m, int K
                     else      { x0 = x1 = sg ? cx + r : cx - r; }
                     const int y = cy + dy, z = cz + dz;
                     int s = 0, e = 0;
-                    if (!done && y >= 0 && y < g.ny && z >= 0 && z < g.nz && x0 >= 0 && x1 <= g.nx - 1) {
+                    if (r == 1) {
+                        s = __builtin_amdgcn_ds_bpermute(grp_src + (ri << 2), rs9); e = __builtin_amdgcn_ds_bpermute(grp_src + (ri << 2), re9);
+                    } else if (!done && y >= 0 && y < g.ny && z >= 0 && z < g.nz && x0 >= 0 && x1 <= g.nx - 1) {
                         const int row = g.cell_base + g.nx * (y + g.ny * z);
                         s = cell_start[row + x0]; e = cell_start[row + x1 + 1];
                     }
@@ -360,7 +386,7 @@ __global__ __launch_bounds__(256) void knn_grid_group_kernel(int b, int m, int K
                             //   new e[j] = min(e[j], max(e[j-1], c))  with e[-1] = 0   — 16 VALU per step instead of 36
                             unsigned gm = (unsigned)(__ballot(pass) >> (grp * G)) & (G == 32 ? ~0u : ((1u << G) - 1u));
                             const int d2i = __float_as_int(d2);
-                            while (__any(gm != 0)) {                          // each group inserts its next passing candidate
+                            auto step = [&]() {                               // each group inserts its next passing candidate
                                 const bool has = gm != 0;
                                 int l; asm("v_ffbl_b32 %0, %1" : "=v"(l) : "v"(gm));      // -1 when empty: any lane, masked by `has`
                                 gm &= gm - 1;
@@ -373,6 +399,11 @@ __global__ __launch_bounds__(256) void knn_grid_group_kernel(int b, int m, int K
                                 evict = min(evict, max(edi, dci));            // lane K-1: the evicted element, or a candidate that lost its race
                                 ei = (edi > dci) ? ((pdi > dci) ? pidx : ic) : ei;        // larger elements move right
                                 ed = __int_as_float(min(edi, max(pdi, dci)));
+                            };
+                            while (__any(gm != 0)) {                          // two steps per trip: halves the loop-carried register copies
+                                step();
+                                if (!__any(gm != 0)) break;
+                                step();
                             }
                         } else {
                         mask_t gm = (__ballot(pass) >> (grp * G)) & (G == 64 ? ~0ull : ((1ull << G) - 1ull));
@@ -395,16 +426,14 @@ __global__ __launch_bounds__(256) void knn_grid_group_kernel(int b, int m, int K
         }
         // nothing outside the visited cube may enter the list or tie with its last entry (grid_core.h)
         const float bound2 = cbl_outside_bound2(g, uqx, uqy, uqz, cx, cy, cz, r);
-        const float worst = __shfl(ed, K - 1, G);
+        const float worst = __int_as_float(__builtin_amdgcn_ds_bpermute(last_src, __float_as_int(ed)));
         if (!done) done = (bound2 == INFINITY) || (worst < bound2);
         if (__all(done)) break;
     }
 
     // certify: list full, K distinct distances, no outside candidate tied with the K-th  (CblTopK::certify)
-    const float worst = __shfl(ed, K - 1, G);
-    float rm = fminf(rejmin, gl == K - 1 ? __int_as_float(evict) : INFINITY);
-#pragma unroll
-    for (int s = G / 2; s >= 1; s >>= 1) rm = fminf(rm, __shfl_xor(rm, s, G));
+    const float worst = __int_as_float(__builtin_amdgcn_ds_bpermute(last_src, __float_as_int(ed)));
+    const float rm = group_min_nonneg<G>(fminf(rejmin, gl == K - 1 ? __int_as_float(evict) : INFINITY));
     const float pd = dpp_shr1_f<G>(ed);
     const bool dup = (gl > 0) && (gl < K) && (ed == pd);
     const mask_t dm = (__ballot(dup) >> (grp * G)) & (G == 64 ? ~0ull : ((1ull << G) - 1ull));
@@ -467,35 +496,58 @@ __global__ __launch_bounds__(256) void knn_grid_wave_kernel(int b, int m, int K,
     bool fast = (T >= K) && (T <= 64 * WV_NB);
     if (fast) {
         float d[WV_NB]; int id[WV_NB];
+        // the row offsets once in vector registers: a select between a scalar and a vector under a lane mask needs two scalar
+        // operands (gfx9 allows one), so the compiler would copy the scalar into a register at every use (3 VALU per row and block, not 2)
+        int delta_v[9];
 #pragma unroll
-        for (int j = 0; j < WV_NB; j++) {
-            d[j] = INFINITY; id[j] = -1;
-            if (j * 64 < T) {
-                const int v = j * 64 + lane;
-                if (v < T) {
-                    int dl = delta[0];
+        for (int r = 0; r < 9; r++) asm volatile("v_mov_b32 %0, %1" : "=v"(delta_v[r]) : "s"(delta[r]));
+        // four blocks of 64 candidates at a time: their loads are all issued before the first distance is computed (one memory
+        // round trip per four blocks instead of one per block — the wave's lifetime was dominated by those waits); positions
+        // past T read the last candidate again (no divergent branch around the load) and are masked afterwards
 #pragma unroll
-                    for (int r = 1; r < 9; r++) dl = (v >= pre[r]) ? delta[r] : dl;
-                    const float4 p = sorted[v + dl];
-                    d[j] = cbl_dist2(qx, qy, qz, p.x, p.y, p.z);      // knnquery_cuda_kernel.cu:99
-                    id[j] = __float_as_int(p.w);
+        for (int j0 = 0; j0 < WV_NB; j0 += 4) {
+            float4 p[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if ((j0 + u) * 64 < T) {
+                    const int v = min((j0 + u) * 64 + lane, T - 1);
+                    // row of position v.  (Resolving the rows on the scalar unit with real branches was measured: VALU -24 %, but the
+                    // scalar unit — one per CU, as many issue slots as the four SIMDs together — became the bound: 61 -> 76 us.)
+                    int dl = delta_v[0];
+#pragma unroll
+                    for (int r = 1; r < 9; r++) dl = (v >= pre[r]) ? delta_v[r] : dl;
+                    p[u] = sorted[v + dl];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = j0 + u;
+                d[j] = INFINITY; id[j] = -1;
+                if (j * 64 < T) {
+                    const bool in = j * 64 + lane < T;
+                    const float dd = cbl_dist2(qx, qy, qz, p[u].x, p[u].y, p[u].z);      // knnquery_cuda_kernel.cu:99
+                    d[j] = in ? dd : INFINITY; id[j] = in ? __float_as_int(p[u].w) : -1;
                 }
             }
         }
         // ---- threshold: K <= #{d <= tau} <= 64
         float tau = 3.0e38f;
         if (T > 64) {
-            float mx = -1.f;
+            // largest finite candidate distance, on the bit patterns (values >= +0 order like integers; only the last block is ragged)
+            int mxi = 0;
 #pragma unroll
-            for (int j = 0; j < WV_NB; j++) if (j * 64 < T) mx = fmaxf(mx, d[j] < INFINITY ? d[j] : -1.f);
-            mx = fmaxf(mx, __int_as_float(dppx_i<0xB1>(__float_as_int(mx))));
-            mx = fmaxf(mx, __int_as_float(dppx_i<0x4E>(__float_as_int(mx))));
-            mx = fmaxf(mx, __int_as_float(dppx_i<0x141>(__float_as_int(mx))));
-            mx = fmaxf(mx, __int_as_float(dppx_i<0x140>(__float_as_int(mx))));
-            float lo = -1.f, hi = fmaxf(fmaxf(rl_f(mx, 0), rl_f(mx, 16)), fmaxf(rl_f(mx, 32), rl_f(mx, 48)));
+            for (int j = 0; j < WV_NB; j++) {
+                if ((j + 1) * 64 <= T) mxi = max(mxi, __float_as_int(d[j]));
+                else if (j * 64 < T)   mxi = max(mxi, d[j] < INFINITY ? __float_as_int(d[j]) : 0);
+            }
+            mxi = max(mxi, dppx_i<0xB1>(mxi)); mxi = max(mxi, dppx_i<0x4E>(mxi));
+            mxi = max(mxi, dppx_i<0x141>(mxi)); mxi = max(mxi, dppx_i<0x140>(mxi));
+            float lo = -1.f, hi = __int_as_float(max(max(__builtin_amdgcn_readlane(mxi, 0), __builtin_amdgcn_readlane(mxi, 16)),
+                                                     max(__builtin_amdgcn_readlane(mxi, 32), __builtin_amdgcn_readlane(mxi, 48))));
+            const float first = (float)(K + 64) * 0.6f * __builtin_amdgcn_rcpf((float)T);   // a guess, not part of the result
             fast = false;
             for (int it = 0; it < 40; it++) {
-                const float mid = it == 0 ? hi * ((float)(K + 64) * 0.6f / (float)T) : lo + (hi - lo) * 0.5f;
+                const float mid = it == 0 ? hi * first : lo + (hi - lo) * 0.5f;
                 if (!(mid > lo && mid < hi)) break;                  // no float left between the brackets: ties, use the insertion path
                 int cnt = 0;
 #pragma unroll
@@ -583,9 +635,7 @@ __global__ __launch_bounds__(256) void knn_grid_wave_kernel(int b, int m, int K,
 
     // certify (as in the group kernel)
     const float worst = rl_f(ed, K - 1);
-    float rm = rejmin;
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) rm = fminf(rm, __shfl_xor(rm, s, 64));
+    const float rm = group_min_nonneg<64>(rejmin);
     const float pd = dpp_shr1_f<64>(ed);
     const bool dup = (lane > 0) && (lane < K) && (ed == pd);
     const bool ok = (worst < INFINITY) && (set_exact == 2 || ((rm != worst) && (set_exact || __ballot(dup) == 0)));

@@ -15,7 +15,7 @@ for f in glob.glob("$GRAFT_REPO_ROOT/gpurun_out/pmci_$tag/**/*counter_collection
         acc[r["Kernel_Name"][:64]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 print("== $tag")
 for k, v in acc.items():
-    if "knn" not in k: continue
+    if "$tag" != "all" and "knn" not in k: continue
     print(k)
     print("   ", {c: round(sum(x) / len(x)) for c, x in sorted(v.items())})
 PY
