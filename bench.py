@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--k", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="all stages in order on one stream")
+    ap.add_argument("--side-after", default=None, help="main-stream stage after which the side stream starts (default: start of the step)")
     return ap.parse_args()
 
 
@@ -74,14 +76,9 @@ def main():
     scene = hotpath.Scene.synthetic(n, c, seed=rank, b=1)    # every rank its own scene (weak scaling)
     stages = hotpath.stages(scene, k)
     state = {}
-
-    def step(events=None):
-        for i, (_, fn, _, _) in enumerate(stages):
-            if events is not None:
-                events[i][0].record()
-            fn(state)
-            if events is not None:
-                events[i][1].record()
+    # the CBL head's neighbour search (independent of the stages before it) goes to a side stream, the rest runs in order
+    sched = hotpath.Schedule(stages, overlap=not args.no_overlap)
+    step = lambda events=None: sched.run(state, events, side_after=args.side_after)
 
     # set-up, not part of the W warm-up steps: first touches of the library, workspaces and code objects, clock ramp of a cold device
     t_settle = time.perf_counter()

@@ -168,7 +168,16 @@ __global__ __launch_bounds__(1024) void contrast_finalize_kernel(int m, float we
 {
     __shared__ float ssum[16]; __shared__ float scnt[16];
     float s = 0.f, c = 0.f;
-    for (int i = threadIdx.x; i < m; i += 1024) { s += per_point[i]; c += (float)point_mask[i]; }
+    // one workgroup, so the pass is a chain of dependent round trips: 16-byte loads, all of a thread's loads in flight at once
+    const int m4 = ((reinterpret_cast<size_t>(per_point) | reinterpret_cast<size_t>(point_mask)) & 15) ? 0 : (m >> 2);
+    const float4* pp4 = reinterpret_cast<const float4*>(per_point);
+    const int4* pm4 = reinterpret_cast<const int4*>(point_mask);
+#pragma unroll 4
+    for (int i = threadIdx.x; i < m4; i += 1024) {
+        const float4 a = pp4[i]; const int4 b = pm4[i];
+        s += (a.x + a.y) + (a.z + a.w); c += (float)(b.x + b.y + b.z + b.w);
+    }
+    for (int i = 4 * m4 + threadIdx.x; i < m; i += 1024) { s += per_point[i]; c += (float)point_mask[i]; }
     for (int k = 32; k >= 1; k >>= 1) { s += __shfl_xor(s, k); c += __shfl_xor(c, k); }
     if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = s; scnt[threadIdx.x >> 6] = c; }
     __syncthreads();
@@ -233,15 +242,29 @@ __global__ __launch_bounds__(256) void contrast_bwd_kernel(int m, int nsample, c
         if (pt >= m) break;
         const float fi = feat[(size_t)pt * D + ch];
         float acc = 0.f;
-        for (int j0 = 0; j0 < ns; j0 += R) {
-            const int j = j0 + slot;
-            const int src = g * G + (j < ns ? j : 0);
-            const float cj = __shfl(coef, src);                     // 0 for masked-out points / padding lanes
-            const int nj = __shfl(nbr, src);
-            if (j < ns && cj != 0.f) {
-                const float gch = cj * (fi - feat[(size_t)nj * D + ch]);
-                unsafeAtomicAdd(grad_feat + (size_t)nj * D + ch, -gch);
-                acc += gch;
+        // PB steps at a time: all their neighbour rows are requested before the first atomic is issued (a load cannot be moved
+        // above an atomic by the compiler, so the plain loop paid one L2 round trip per step: ns/R of them in a row)
+        constexpr int PB = 16;
+        for (int b0 = 0; b0 < ns; b0 += PB * R) {
+            float fj[PB];
+#pragma unroll
+            for (int u = 0; u < PB; u++) {
+                const int j = b0 + u * R + slot;
+                const int src = g * G + (j < ns ? j : 0);
+                const int nj = __shfl(nbr, src);
+                fj[u] = (b0 + u * R < ns) ? feat[(size_t)nj * D + ch] : 0.f;      // nbr is a valid row for every lane
+            }
+#pragma unroll
+            for (int u = 0; u < PB; u++) {
+                const int j = b0 + u * R + slot;
+                const int src = g * G + (j < ns ? j : 0);
+                const float cj = __shfl(coef, src);                 // 0 for masked-out points / padding lanes
+                const int nj = __shfl(nbr, src);
+                if (j < ns && cj != 0.f) {
+                    const float gch = cj * (fi - fj[u]);
+                    unsafeAtomicAdd(grad_feat + (size_t)nj * D + ch, -gch);
+                    acc += gch;
+                }
             }
         }
 #pragma unroll

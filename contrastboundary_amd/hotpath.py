@@ -43,6 +43,12 @@ class Scene:
         return sc
 
 
+# stages that do not depend on the stage before them: the CBL head's neighbour search needs the coordinates only, so `run_step` issues
+# it on a side stream at the start of the step, under the grid build / exact replay / gather of the main stream (those leave most
+# of the device idle: a handful of small dependent launches, two workgroups replaying tied queries)
+SIDE_STAGES = ("cbl_knnquery_k%d" % CBL_NSAMPLE,)
+
+
 def stages(scene, k=16):
     """-> list of (name, fn(state) -> None, algorithmic_bytes, algorithmic_flops); fns communicate through `state`"""
     n, c = scene.n, scene.c
@@ -89,7 +95,65 @@ def stages(scene, k=16):
 
 
 def run_once(scene, k=16, state=None):
+    """every stage in order on the current stream (the reference's schedule)"""
     state = {} if state is None else state
     for _, fn, _, _ in stages(scene, k):
         fn(state)
     return state
+
+
+class Schedule:
+    """The step as bench.py runs it: SIDE_STAGES on a side stream, everything else in order on the current stream.
+
+        sched = Schedule(stage_list);  sched.run(state, events=None)
+
+    events: optional list (one entry per stage) of (start, end) torch.cuda.Event pairs, recorded on the stream the stage runs on."""
+
+    def __init__(self, stage_list, overlap=True):
+        self.stage_list = stage_list
+        self.overlap = overlap
+        self.side = torch.cuda.Stream() if overlap else None
+        self.joined = torch.cuda.Event() if overlap else None
+
+    def run(self, state, events=None, side_after=None):
+        """side_after: name of the main-stream stage after which the side stages may start (None: at the start of the step)"""
+        main = torch.cuda.current_stream()
+        names = [st[0] for st in self.stage_list]
+        side_idx = [i for i, nm in enumerate(names) if self.overlap and nm in SIDE_STAGES]
+        fork_at = names.index(side_after) if (side_after is not None and side_idx) else -1
+
+        def launch(i):
+            if events is not None:
+                events[i][0].record()
+            self.stage_list[i][1](state)
+            if events is not None:
+                events[i][1].record()
+        produced = []
+
+        def fork():
+            # the side stream starts after everything already queued on the main stream: the previous step's consumers of the buffers
+            # it is about to overwrite, and the inputs
+            self.side.wait_stream(main)
+            before = {key: id(v) for key, v in state.items()}
+            with torch.cuda.stream(self.side):
+                for i in side_idx:
+                    launch(i)
+                self.joined.record(self.side)
+            produced.extend(v for key, v in state.items() if torch.is_tensor(v) and before.get(key) != id(v))
+        if side_idx and fork_at < 0:
+            fork()
+        waited = not side_idx
+        for i in range(len(names)):
+            if i in side_idx:
+                continue
+            if not waited and i > side_idx[-1]:                 # first consumer of a side-stream result
+                main.wait_event(self.joined)
+                for v in produced:
+                    v.record_stream(main)                           # allocated on the side stream, consumed here
+                waited = True
+            launch(i)
+            if i == fork_at:
+                fork()
+        if not waited:
+            main.wait_event(self.joined)
+        return state
