@@ -57,11 +57,14 @@ class _PointContrast(Function):
                                                     _lib.ptr(loss), _lib.stream_of(features)), "cbl_point_contrast_forward")
         ctx.weight = weight
         ctx.mark_non_differentiable(mask)
+        ctx.set_materialize_grads(False)        # no zero tensor for the (integer) mask output in backward: that was one fill launch per step
         return loss.view(()), mask
 
     @staticmethod
     def backward(ctx, grad_loss, _grad_mask):
         unit, stats = ctx.saved_tensors
+        if grad_loss is None:                                            # the loss took no part in what was differentiated
+            return None, None, None, None, None
         g = torch.empty_like(unit)
         gl = grad_loss.reshape(1).to(torch.float32).contiguous()
         _lib.check(_lib.lib().cbl_contrast_grad_scale(ctypes.c_longlong(unit.numel()), _lib.ptr(unit), _lib.ptr(stats), _lib.ptr(gl), _c_float(ctx.weight),
@@ -143,11 +146,14 @@ class _TFContrast(Function):
             _lib.check(L.cbl_tf_contrast_forward(*args, _lib.stream_of(features)), "cbl_tf_contrast_forward")
         ctx.weight = weight
         ctx.mark_non_differentiable(mask)
+        ctx.set_materialize_grads(False)        # no zero tensor for the (integer) mask output in backward: that was one fill launch per step
         return loss.view(()), mask
 
     @staticmethod
     def backward(ctx, grad_loss, _gm):
         unit, stats = ctx.saved_tensors
+        if grad_loss is None:                                            # the loss took no part in what was differentiated
+            return None, None, None, None, None
         g = torch.empty_like(unit)
         gl = grad_loss.reshape(1).to(torch.float32).contiguous()
         _lib.check(_lib.lib().cbl_contrast_grad_scale(ctypes.c_longlong(unit.numel()), _lib.ptr(unit), _lib.ptr(stats), _lib.ptr(gl), _c_float(ctx.weight),
