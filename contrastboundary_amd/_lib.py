@@ -14,6 +14,9 @@ class CblError(RuntimeError):
     pass
 
 
+ERR_UNSUPPORTED = -3            # CBL_ERR_UNSUPPORTED (cbl_amd.h)
+
+
 def declared_symbols():
     """every function name include/cbl_amd.h declares"""
     txt = open(_HEADER).read()

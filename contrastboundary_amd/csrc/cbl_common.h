@@ -48,3 +48,14 @@ __device__ __forceinline__ float cbl_dist2(float ax, float ay, float az, float b
 
 __device__ __forceinline__ bool cbl_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline bool cbl_host_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- processing order ("*_ordered" entry points) ----------------------------------------------------------------------------
+// The point-walking kernels take an optional `order`: the sequence in which the points are processed (a permutation; the cell order of
+// the neighbour search, cbl_knnquery_ordered).  Workgroup b of a launch runs on XCD b % 8 (round-robin dispatch); a kernel walks
+// VIRTUAL workgroups v = blockIdx.x, + gridDim.x, ... with gridDim.x a multiple of 8, and virtual workgroup v takes sequence slot
+// cbl_xcd_slot(v, nwg): XCD x then works on the contiguous eighth [x * per, (x + 1) * per) of the sequence — one slab of the scene,
+// whose rows stay in that XCD's 4 MB L2.  (On a device partitioned differently the mapping is merely another permutation.)
+__device__ __forceinline__ unsigned cbl_xcd_per(unsigned nwg) { return (nwg + 7u) >> 3; }
+__device__ __forceinline__ unsigned cbl_xcd_slot(unsigned v, unsigned nwg) { return (v & 7u) * cbl_xcd_per(nwg) + (v >> 3); }
+static inline unsigned cbl_round_up8(unsigned g) { return (g + 7u) & ~7u; }
+

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void grid_scan_tiles_kernel(int total, const i
 // (the order inside a cell is irrelevant) and ends at zero, ready for the next build.
 __global__ __launch_bounds__(256) void grid_scatter_kernel(int n, int total, int ntiles, const float* __restrict__ xyz, const int* __restrict__ pt_cell,
                                                            const int* __restrict__ tile_sum, int* __restrict__ cell_start_local, int* __restrict__ cell_start,
-                                                           int* __restrict__ cell_count, float4* __restrict__ sorted)
+                                                           int* __restrict__ cell_count, float4* __restrict__ sorted, int* __restrict__ order_out)
 {
     extern __shared__ int tile_lds[];                      // [0, ntiles): tile totals, [ntiles, 2*ntiles): their exclusive prefix
     int* tile_pre = tile_lds + ntiles;
@@ -218,6 +218,7 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(int n, int total, int
         const int cell = pt_cell[i];
         const int pos = cell_start_local[cell] + tile_pre[cell / SCAN_TILE] + atomicSub(cell_count + cell, 1) - 1;
         sorted[pos] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], __int_as_float(i));
+        if (order_out) order_out[pos] = i;                  // the cell order of the supports, for the consumers' processing order (cbl_knnquery_ordered)
     }
 }
 
@@ -749,7 +750,7 @@ __global__ __launch_bounds__(256) void grid_init_kernel(int b, int total, int* _
     for (int i = i0; i < total; i += gridDim.x * 256) cell_count[i] = 0;
 }
 
-int cbl_grid_build(int b, int n, float pts_per_cell, const float* xyz, const int* offset, void* ws, hipStream_t st)
+int cbl_grid_build(int b, int n, float pts_per_cell, const float* xyz, const int* offset, void* ws, hipStream_t st, int* order_out = nullptr)
 {
     // 5 launches: init+zero | bbox | grid params + histogram | tile scans | scan finish + scatter
     Workspace w = carve(ws, b, n, 0);
@@ -759,7 +760,7 @@ int cbl_grid_build(int b, int n, float pts_per_cell, const float* xyz, const int
     hipLaunchKernelGGL(grid_count_kernel, dim3(cbl_grid_for(n, 256)), dim3(256), 0, st, b, n, pts_per_cell, xyz, offset, w.bbox, w.grids, w.pt_cell, w.cell_count);
     hipLaunchKernelGGL(grid_scan_tiles_kernel, dim3(ntiles), dim3(256), 0, st, total, w.cell_count, w.cell_local, w.tile_sum);
     hipLaunchKernelGGL(grid_scatter_kernel, dim3(cbl_grid_for(n, 256)), dim3(256), 2 * sizeof(int) * (size_t)ntiles, st, n, total, ntiles, xyz, w.pt_cell,
-                       w.tile_sum, w.cell_local, w.cell_start, w.cell_count, w.sorted);
+                       w.tile_sum, w.cell_local, w.cell_start, w.cell_count, w.sorted, order_out);
     return cbl_status();
 }
 
@@ -772,12 +773,12 @@ size_t cbl_knn_grid_workspace_bytes(int b, int n, int m, int nsample)
 }
 
 int cbl_knn_grid_launch(int b, int n, int m, int nsample, const float* xyz, const float* new_xyz, const int* offset,
-                        const int* new_offset, int* idx, float* dist2, void* ws, size_t ws_bytes, int set_exact, hipStream_t st)
+                        const int* new_offset, int* idx, float* dist2, void* ws, size_t ws_bytes, int set_exact, hipStream_t st, int* order_out)
 {
     Workspace w = carve(ws, b, n, m);
     if (ws_bytes < w.bytes) return CBL_ERR_WORKSPACE;
     // ~0.42*K points per cell if the cloud filled its bbox: the K-th neighbour is then usually inside the 27-cell block
-    int rc = cbl_grid_build(b, n, 0.42f * (float)(nsample < 4 ? 4 : nsample), xyz, offset, ws, st);
+    int rc = cbl_grid_build(b, n, 0.42f * (float)(nsample < 4 ? 4 : nsample), xyz, offset, ws, st, order_out);
     if (rc) return rc;
     const bool self = (new_xyz == xyz) && (m == n);
     if (nsample > 16) {                                              // select-then-sort, one wave per query

@@ -33,16 +33,20 @@ template <bool VEC>       // VEC: C % 4 == 0 and 16-byte aligned rows -> float4 
 __global__ __launch_bounds__(256) void kpconv_fwd_kernel(int n, int n0, int K, int C, int KP, const float* __restrict__ q,
                                                          const float* __restrict__ s, const int* __restrict__ idx, const float* __restrict__ f,
                                                          const float* __restrict__ kpts, const float* __restrict__ kw, float extent,
-                                                         int influence, int closest, float* __restrict__ out)
+                                                         int influence, int closest, const int* __restrict__ order, float* __restrict__ out)
 {
     const int lane = threadIdx.x & 63;
     const int kp_id = lane & 15;          // A row / kernel point; also B / D column j
     const int kq = lane >> 4;             // neighbour within a group of 4; D row block
-    const int wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (gridDim.x * 256) >> 6;
+    const unsigned wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwg = ((unsigned)n + 3u) >> 2;
     const bool kp_ok = kp_id < KP;
     const float kx = kp_ok ? kpts[3 * kp_id] : 0.f, ky = kp_ok ? kpts[3 * kp_id + 1] : 0.f, kz = kp_ok ? kpts[3 * kp_id + 2] : 0.f;
 
-    for (int p = wave0; p < n; p += nwaves) {
+    // one point per wave and trip; with `order` the points are taken in that sequence, dealt to the XCDs in contiguous eighths (cbl_common.h)
+    for (unsigned v = blockIdx.x; v < 8 * cbl_xcd_per(nwg); v += gridDim.x) {
+        const unsigned t = (order ? cbl_xcd_slot(v, nwg) : v) * 4 + wv;
+        if (t >= (unsigned)n) continue;
+        const int p = order ? order[t] : (int)t;
         const float qx = q[3 * p], qy = q[3 * p + 1], qz = q[3 * p + 2];
         for (int c0 = 0; c0 < C; c0 += 64) {
             f32x4 acc[4];
@@ -348,20 +352,36 @@ inline unsigned persistent_grid(int n) { const long long waves = n; long long bl
 
 }  // namespace
 
-CBL_EXPORT int cbl_kpconv_forward(int n, int n0, int K, int C, int KP, const float* query_points, const float* support_points, const int* neighbors_indices,
-                                  const float* features, const float* kernel_points, const float* kernel_weights, float extent, int influence, int closest,
-                                  float* out, void* stream)
+static int kpconv_forward_impl(int n, int n0, int K, int C, int KP, const float* query_points, const float* support_points, const int* neighbors_indices,
+                               const float* features, const float* kernel_points, const float* kernel_weights, float extent, int influence, int closest,
+                               const int* order, float* out, void* stream)
 {
     if (n < 0 || n0 < 0 || K <= 0 || C <= 0 || KP <= 0 || KP > 16 || !(extent > 0.f) || influence < 0 || influence > 1) return CBL_ERR_BAD_ARG;
     if (n == 0) return CBL_OK;
     if (!query_points || !support_points || !neighbors_indices || !features || !kernel_points || !kernel_weights || !out) return CBL_ERR_BAD_ARG;
     hipStream_t st = cbl_stream(stream);
-    const dim3 grid(persistent_grid(n)), block(256);
+    const dim3 grid(cbl_round_up8(persistent_grid(n))), block(256);
     if (C % 4 == 0 && cbl_host_aligned16(features) && cbl_host_aligned16(out))
-        hipLaunchKernelGGL(kpconv_fwd_kernel<true>, grid, block, 0, st, n, n0, K, C, KP, query_points, support_points, neighbors_indices, features, kernel_points, kernel_weights, extent, influence, closest, out);
+        hipLaunchKernelGGL(kpconv_fwd_kernel<true>, grid, block, 0, st, n, n0, K, C, KP, query_points, support_points, neighbors_indices, features, kernel_points, kernel_weights, extent, influence, closest, order, out);
     else
-        hipLaunchKernelGGL(kpconv_fwd_kernel<false>, grid, block, 0, st, n, n0, K, C, KP, query_points, support_points, neighbors_indices, features, kernel_points, kernel_weights, extent, influence, closest, out);
+        hipLaunchKernelGGL(kpconv_fwd_kernel<false>, grid, block, 0, st, n, n0, K, C, KP, query_points, support_points, neighbors_indices, features, kernel_points, kernel_weights, extent, influence, closest, order, out);
     return cbl_status();
+}
+
+CBL_EXPORT int cbl_kpconv_forward(int n, int n0, int K, int C, int KP, const float* query_points, const float* support_points, const int* neighbors_indices,
+                                  const float* features, const float* kernel_points, const float* kernel_weights, float extent, int influence, int closest,
+                                  float* out, void* stream)
+{
+    return kpconv_forward_impl(n, n0, K, C, KP, query_points, support_points, neighbors_indices, features, kernel_points, kernel_weights, extent, influence, closest,
+                               nullptr, out, stream);
+}
+
+CBL_EXPORT int cbl_kpconv_forward_ordered(int n, int n0, int K, int C, int KP, const float* query_points, const float* support_points, const int* neighbors_indices,
+                                          const float* features, const float* kernel_points, const float* kernel_weights, float extent, int influence, int closest,
+                                          const int* order, float* out, void* stream)
+{
+    return kpconv_forward_impl(n, n0, K, C, KP, query_points, support_points, neighbors_indices, features, kernel_points, kernel_weights, extent, influence, closest,
+                               order, out, stream);
 }
 
 CBL_EXPORT int cbl_kpconv_backward(int n, int n0, int K, int C, int KP, const float* query_points, const float* support_points, const int* neighbors_indices,

@@ -253,6 +253,94 @@ __global__ __launch_bounds__(256) void query_group_v4(unsigned rows, int ns, int
     }
 }
 
+// use_xyz = 1: rows are 4*(3 + c) bytes long, so v4's 16-byte stores sit on 4-byte boundaries in three rows out of four.  Here a wave
+// assembles a PIECE of consecutive output rows (16-byte aligned, a multiple of 16 bytes long) in LDS — aligned 16-byte gathers of the
+// feature rows in, the centred coordinates from 3 lanes per row — and streams the piece out as ALIGNED, fully coalesced 16-byte stores.
+// No 64-bit division per element (row / part come from the lane id).
+//   order == nullptr: piece p = rows [16p, 16p + 16)
+//   order != nullptr: piece t = the ns rows of query point order[t]; `order` lists the points in a spatially coherent sequence (the
+//     cell order of the neighbour search, cbl_knnquery_ordered) and the pieces are dealt to the XCDs in CONTIGUOUS eighths (workgroup b
+//     runs on XCD b % 8): the rows one XCD gathers then come from one slab of the scene and stay in its 4 MB L2.  With the scene's
+//     own (shuffled) order every XCD reads the whole 10.5 MB feature table through the fabric: 157 MB fetched for a 190 MB kernel.
+constexpr int QG_ROWS = 16, QG_MAX_ROWS = 32;
+template <int C4T>                                                  // C4T > 0: channel count / 4 known at compile time (gathers unrolled, all in flight); 0: any
+__global__ __launch_bounds__(256) void query_group_lds(unsigned rows, int ns, int c4_rt, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+                                                       const float4* __restrict__ feat, const int* __restrict__ idx, const int* __restrict__ order,
+                                                       float* __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float qg_lds[];  // [4 waves][pr * oc]
+    const int c4 = C4T ? C4T : c4_rt;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int oc = 4 * c4 + 3;
+    const int pr = order ? ns : QG_ROWS;                            // rows per piece
+    float* piece = qg_lds + (size_t)wv * pr * oc;
+    const unsigned npieces = rows / (unsigned)pr;                   // full pieces; remaining rows (unordered mode only) by the lane loop below
+    const int nf4 = pr * c4;                                        // 16-byte feature parts per piece
+    const int nchunk = pr * oc / 4;                                 // 16-byte chunks of the output piece (pr * oc is a multiple of 4)
+    const unsigned nwg = (npieces + 3) >> 2;
+    for (unsigned wg = blockIdx.x; wg < 8 * cbl_xcd_per(nwg); wg += gridDim.x) {
+        const unsigned t = (order ? cbl_xcd_slot(wg, nwg) : wg) * 4 + wv;       // XCD-contiguous dealing of the sequence (cbl_common.h)
+        if (t >= npieces) continue;                                 // wave-uniform
+        const unsigned r0 = (order ? (unsigned)order[t] : t) * (unsigned)pr;
+        const int myidx = idx[r0 + (lane < pr ? lane : 0)];           // lane l holds the support of row l
+        // features: part f of the piece = (row f / c4, part f % c4); consecutive lanes read consecutive 16 B of a support row
+        if constexpr (C4T > 0 && (QG_ROWS * C4T) % 64 == 0) {
+            constexpr int NL = QG_MAX_ROWS * C4T / 64;
+            float4 v[NL];
+#pragma unroll
+            for (int j = 0; j < NL; j++) {
+                const int f = lane + 64 * j, row = f / C4T, part = f % C4T;
+                const int src = __shfl(myidx, row < pr ? row : 0);  // the shuffle stays outside the lane-dependent branch: every source lane is active
+                if (f < nf4) v[j] = feat[(size_t)src * C4T + part];
+            }
+#pragma unroll
+            for (int j = 0; j < NL; j++) {
+                const int f = lane + 64 * j, row = f / C4T, part = f % C4T;
+                if (f < nf4) {
+                    float* d = piece + row * oc + 3 + 4 * part;
+                    d[0] = v[j].x; d[1] = v[j].y; d[2] = v[j].z; d[3] = v[j].w;
+                }
+            }
+        } else {
+            for (int f0 = 0; f0 < nf4; f0 += 64) {                    // wave-uniform trip count
+                const int f = f0 + lane, row = f / c4, part = f - row * c4;
+                const int src = __shfl(myidx, row < pr ? row : 0);
+                if (f < nf4) {
+                    const float4 v = feat[(size_t)src * c4 + part];
+                    float* d = piece + row * oc + 3 + 4 * part;
+                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                }
+            }
+        }
+        for (int e0 = 0; e0 < 3 * pr; e0 += 64) {                   // centred coordinates: e = 3 * row + axis
+            const int e = e0 + lane, row = e / 3, a = e - 3 * row;
+            const int src = __shfl(myidx, row < pr ? row : 0);
+            if (e < 3 * pr) {
+                const unsigned q = (r0 + row) / (unsigned)ns;
+                piece[row * oc + a] = xyz[(size_t)src * 3 + a] - new_xyz[(size_t)q * 3 + a];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        typedef float v4a __attribute__((ext_vector_type(4)));          // 16-byte aligned vector (the builtin wants a plain vector type)
+        v4a* o4 = reinterpret_cast<v4a*>(out + (size_t)r0 * oc);        // piece start: a multiple of pr * oc * 4 bytes, 16-byte aligned
+        const v4a* p4 = reinterpret_cast<const v4a*>(piece);
+        for (int ch = lane; ch < nchunk; ch += 64) __builtin_nontemporal_store(p4[ch], o4 + ch);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                            // the piece is reused by the next trip
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // tail rows (rows % 16, unordered mode), element by element
+    const unsigned long long t0 = (unsigned long long)npieces * pr * oc, tot = (unsigned long long)rows * oc;
+    for (unsigned long long e = t0 + (unsigned long long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (unsigned long long)gridDim.x * 256) {
+        const unsigned r = (unsigned)(e / oc); const int ch = (int)(e - (unsigned long long)r * oc);
+        const int src = idx[r];
+        out[e] = ch < 3 ? xyz[(size_t)src * 3 + ch] - new_xyz[(size_t)(r / (unsigned)ns) * 3 + ch]
+                        : reinterpret_cast<const float*>(feat)[(size_t)src * 4 * c4 + (ch - 3)];
+    }
+}
+
 __global__ __launch_bounds__(GB) void query_group(long long rows, int ns, int c, int use_xyz,
                                                   const float* __restrict__ xyz, const float* __restrict__ new_xyz,
                                                   const float* __restrict__ feat, const int* __restrict__ idx, float* __restrict__ out)
@@ -398,7 +486,8 @@ CBL_EXPORT int cbl_aggregation_backward(int n, int nsample, int c, int w_c, cons
     return cbl_status();
 }
 
-CBL_EXPORT int cbl_queryandgroup(int m, int nsample, int c, int use_xyz, const float* xyz, const float* new_xyz, const float* feat, const int* idx, float* out, void* stream)
+static int queryandgroup_impl(int m, int nsample, int c, int use_xyz, const float* xyz, const float* new_xyz, const float* feat, const int* idx,
+                              const int* order, float* out, void* stream)
 {
     CBL_CHECK_DIMS(m, nsample, c);
     const long long rows = (long long)m * nsample;
@@ -407,12 +496,39 @@ CBL_EXPORT int cbl_queryandgroup(int m, int nsample, int c, int use_xyz, const f
     CBL_CHECK_PTRS(idx, out);
     if (use_xyz) CBL_CHECK_PTRS(xyz, new_xyz);
     if (c > 0) CBL_CHECK_PTRS(feat);
-    if (c % 4 == 0 && c > 0 && cbl_host_aligned16(feat) && rows < 0xffffffffLL)
+    const bool lds_ok = use_xyz && c % 4 == 0 && c > 0 && c <= 128 && cbl_host_aligned16(feat) && cbl_host_aligned16(out) && rows < 0xffffffffLL;
+    // the ordered form needs whole points as 16-byte aligned pieces: (nsample * (3 + c)) % 4 == 0, at most QG_MAX_ROWS rows
+    if (order && !(lds_ok && nsample <= QG_MAX_ROWS && ((long long)nsample * oc) % 4 == 0 && sizeof(float) * 4 * (size_t)nsample * oc <= 65536)) order = nullptr;
+    if (lds_ok && (order || rows >= QG_ROWS)) {
+        const int pr = order ? nsample : QG_ROWS;
+        const dim3 grid(cbl_round_up8(cbl_grid_for((rows / pr + 3) / 4 * 256, GB, 256 * 64)));
+        const size_t lds = sizeof(float) * 4 * (size_t)pr * (c + 3);
+#define CBL_QG_LDS(C4T) hipLaunchKernelGGL(query_group_lds<C4T>, grid, dim3(GB), lds, cbl_stream(stream), (unsigned)rows, nsample, c / 4, xyz, new_xyz, \
+                                           reinterpret_cast<const float4*>(feat), idx, order, out)
+        switch (c) {
+            case 32:  CBL_QG_LDS(8); break;
+            case 64:  CBL_QG_LDS(16); break;
+            case 128: CBL_QG_LDS(32); break;
+            default:  CBL_QG_LDS(0); break;
+        }
+#undef CBL_QG_LDS
+    } else if (c % 4 == 0 && c > 0 && cbl_host_aligned16(feat) && rows < 0xffffffffLL)
         hipLaunchKernelGGL(query_group_v4, dim3(cbl_grid_for(rows * (c / 4 + (use_xyz ? 1 : 0)), GB)), dim3(GB), 0, cbl_stream(stream), (unsigned)rows, nsample, c / 4, use_xyz,
                            xyz, new_xyz, reinterpret_cast<const float4*>(feat), idx, out);
     else
         hipLaunchKernelGGL(query_group, dim3(cbl_grid_for(rows * oc, GB)), dim3(GB), 0, cbl_stream(stream), rows, nsample, c, use_xyz, xyz, new_xyz, feat, idx, out);
     return cbl_status();
+}
+
+CBL_EXPORT int cbl_queryandgroup(int m, int nsample, int c, int use_xyz, const float* xyz, const float* new_xyz, const float* feat, const int* idx, float* out, void* stream)
+{
+    return queryandgroup_impl(m, nsample, c, use_xyz, xyz, new_xyz, feat, idx, nullptr, out, stream);
+}
+
+CBL_EXPORT int cbl_queryandgroup_ordered(int m, int nsample, int c, int use_xyz, const float* xyz, const float* new_xyz, const float* feat, const int* idx,
+                                         const int* order, float* out, void* stream)
+{
+    return queryandgroup_impl(m, nsample, c, use_xyz, xyz, new_xyz, feat, idx, order, out, stream);
 }
 
 CBL_EXPORT int cbl_interpolation_weights(int n, int k, const float* dist2, float* weight, float* dist, void* stream)

@@ -29,9 +29,12 @@ class _KPConv(Function):
         n0, C = features.shape
         KP = kernel_points.shape[0]
         out = torch.empty((n, C), dtype=torch.float32, device=features.device)
-        _lib.check(_lib.lib().cbl_kpconv_forward(_i(n), _i(n0), _i(K), _i(C), _i(KP), _lib.ptr(query_points), _lib.ptr(support_points),
-                                                 _lib.ptr(neighbors_indices), _lib.ptr(features), _lib.ptr(kernel_points), _lib.ptr(kernel_weights),
-                                                 _f(extent), _i(influence), _i(closest), _lib.ptr(out), _lib.stream_of(features)), "cbl_kpconv_forward")
+        from . import pointops
+        order = pointops.spatial_order(query_points)             # processing order only: same values (cbl_amd.h)
+        _lib.check(_lib.lib().cbl_kpconv_forward_ordered(_i(n), _i(n0), _i(K), _i(C), _i(KP), _lib.ptr(query_points), _lib.ptr(support_points),
+                                                         _lib.ptr(neighbors_indices), _lib.ptr(features), _lib.ptr(kernel_points), _lib.ptr(kernel_weights),
+                                                         _f(extent), _i(influence), _i(closest), _lib.ptr(order), _lib.ptr(out),
+                                                         _lib.stream_of(features)), "cbl_kpconv_forward")
         ctx.save_for_backward(query_points, support_points, neighbors_indices, features, kernel_points, kernel_weights)
         ctx.cfg = (extent, influence, closest)
         return out

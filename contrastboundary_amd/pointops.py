@@ -8,6 +8,7 @@ memory, streams and autograd plumbing only; every op body is a C-ABI call (inclu
 Unlike the reference (no checks at all), dtype / device / contiguity are validated and a
 failing launch raises instead of surfacing later as an asynchronous error.
 """
+import collections
 import ctypes
 import threading
 
@@ -51,6 +52,62 @@ def _workspace(nbytes, device):
         ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
         _ws_cache[key] = ws
     return ws
+
+
+# ------------------------------------------------------------------------------------------------ processing order
+# The grid build of a self-search sorts the supports into cells; that sequence ("cell order") is a spatially coherent processing
+# order for every kernel that walks the points and gathers their neighbours.  It is kept per geometry (the coordinate tensor) and per
+# stream, and handed to the *_ordered C entry points: the VALUES never depend on it — a stale or missing order only costs locality.
+ORDER_MIN_POINTS = 8192         # below this the tables sit in L2 anyway
+_order_registry = collections.OrderedDict()     # (data_ptr, n, version, device) -> {stream id: (order tensor, event)}
+_ORDER_REGISTRY_MAX = 16
+
+
+def _order_key(points):
+    try:
+        version = points._version
+    except RuntimeError:                                            # inference tensors do not track a version counter
+        version = -1
+    return (points.data_ptr(), points.shape[0], version, points.device)
+
+
+def _order_wanted(points, stream_id):
+    """does a self-search over `points` on this stream still have to produce the cell order?"""
+    if points.shape[0] < ORDER_MIN_POINTS or not use_spatial_order:
+        return False
+    ent = _order_registry.get(_order_key(points))
+    return ent is None or stream_id not in ent
+
+
+def _order_register(points, order, stream):
+    key = _order_key(points)
+    ent = _order_registry.setdefault(key, {})
+    ev = torch.cuda.Event()
+    ev.record(stream)
+    ent[stream.cuda_stream] = (order, ev)
+    _order_registry.move_to_end(key)
+    while len(_order_registry) > _ORDER_REGISTRY_MAX:
+        _order_registry.popitem(last=False)
+
+
+def spatial_order(points):
+    """-> int32 (n,) processing order of `points` (cell order of an earlier self-search over the same tensor), or None"""
+    if not use_spatial_order or points.shape[0] < ORDER_MIN_POINTS:
+        return None
+    ent = _order_registry.get(_order_key(points))
+    if not ent:
+        return None
+    cur = torch.cuda.current_stream(points.device)
+    hit = ent.get(cur.cuda_stream)
+    if hit is not None:
+        return hit[0]
+    order, ev = next(iter(ent.values()))                         # produced on another stream: order after it, keep it alive for this one
+    cur.wait_event(ev)
+    order.record_stream(cur)
+    return order
+
+
+use_spatial_order = True
 
 
 # ------------------------------------------------------------------------------------------------ K2
@@ -263,6 +320,18 @@ def _knnquery_uncached(nsample, xyz, new_xyz, offset, new_offset, algo):
         if algo == "grid" and need == 0:
             raise _lib.CblError("grid KNN not available for this problem shape")
         ws = _workspace(need, xyz.device)
+        cur = torch.cuda.current_stream(xyz.device)
+        self_search = new_xyz is xyz or (new_xyz.data_ptr() == xyz.data_ptr() and m == n)
+        if self_search and need and nsample <= 64 and _order_wanted(xyz, cur.cuda_stream):
+            # the grid build lists the supports cell by cell anyway: keep that sequence as the processing order of this geometry
+            order = torch.empty(n, dtype=torch.int32, device=xyz.device)
+            policy = 1 if algo == "set" else 2 if algo == "anytie" else 0
+            rc = L.cbl_knnquery_ordered(*args, _c_int(policy), _lib.ptr(order), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), st)
+            if rc == 0:
+                _order_register(xyz, order, cur)
+                return idx, dist2
+            if rc != _lib.ERR_UNSUPPORTED:
+                _lib.check(rc, "cbl_knnquery_ordered")
         fn = L.cbl_knnquery_set if algo == "set" else L.cbl_knnquery_anytie if algo == "anytie" else L.cbl_knnquery
         _lib.check(fn(*args, _lib.ptr(ws), ctypes.c_size_t(ws.numel() if ws is not None else 0), st), "cbl_knnquery")
     return idx, dist2
@@ -324,9 +393,10 @@ class _QueryAndGroup(Function):
         c = feat.shape[1]
         oc = c + (3 if use_xyz else 0)
         out = torch.empty((m, nsample, oc), dtype=torch.float32, device=feat.device)
-        _lib.check(_lib.lib().cbl_queryandgroup(_c_int(m), _c_int(nsample), _c_int(c), _c_int(1 if use_xyz else 0), _lib.ptr(xyz),
-                                                _lib.ptr(new_xyz), _lib.ptr(feat), _lib.ptr(idx), _lib.ptr(out), _lib.stream_of(feat)),
-                   "cbl_queryandgroup")
+        order = spatial_order(new_xyz) if use_xyz else None      # processing order only: same values (cbl_amd.h)
+        _lib.check(_lib.lib().cbl_queryandgroup_ordered(_c_int(m), _c_int(nsample), _c_int(c), _c_int(1 if use_xyz else 0), _lib.ptr(xyz),
+                                                        _lib.ptr(new_xyz), _lib.ptr(feat), _lib.ptr(idx), _lib.ptr(order), _lib.ptr(out),
+                                                        _lib.stream_of(feat)), "cbl_queryandgroup")
         ctx.save_for_backward(idx)
         ctx.dims = (xyz.shape[0], feat.shape[0], c, use_xyz)
         return out

@@ -81,6 +81,16 @@ int cbl_knnquery_anytie(int b, int n, int m, int nsample,
                         int* idx, float* dist2,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* cbl_knnquery / _set / _anytie (tie_policy 0 / 1 / 2) that also returns the CELL ORDER of the supports: cell_order[t] (n ints) = index
+ * of the t-th support when the supports are listed cell by cell of the search grid (x fastest, then y, z; clouds one after the other) —
+ * a by-product of the grid build (grid_scatter_kernel), written at no extra cost.  It is the processing order the *_ordered consumers
+ * take.  Only the grid path produces it: CBL_ERR_UNSUPPORTED where cbl_knnquery would use another kernel (nsample > 64, n < 2048). */
+int cbl_knnquery_ordered(int b, int n, int m, int nsample,
+                         const float* xyz, const float* new_xyz,
+                         const int* offset, const int* new_offset,
+                         int* idx, float* dist2, int tie_policy, int* cell_order,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 /* brute-force variant only (always bit-exact, O(m*n)); `algo` for tests/bench: see cbl_knnquery */
 int cbl_knnquery_exact(int b, int n, int m, int nsample,
                        const float* xyz, const float* new_xyz,
@@ -133,6 +143,13 @@ int cbl_aggregation_backward(int n, int nsample, int c, int w_c, const float* in
  *   xyz (n,3) new_xyz (m,3) feat (n,c) idx (m,nsample) -> out (m,nsample,3+c) if use_xyz else (m,nsample,c)
  *   out[m,k,0:3] = xyz[idx]-new_xyz[m]; out[m,k,3:] = feat[idx] */
 int cbl_queryandgroup(int m, int nsample, int c, int use_xyz, const float* xyz, const float* new_xyz, const float* feat, const int* idx, float* out, void* stream);
+/* Same result; `order` (m ints, a permutation of the query points; NULL = cbl_queryandgroup) is the SEQUENCE in which the points are
+ * processed.  Given a spatially coherent sequence — the cell order of the neighbour search, cbl_knnquery_ordered — consecutive
+ * workgroups gather neighbouring supports and each XCD is handed one contiguous eighth of the sequence, so the feature rows it reads
+ * stay in its own L2 instead of being re-fetched through the fabric (scenes arrive shuffled: pointops.py has no such notion, the
+ * argument changes the schedule, never the values).  Shapes the ordered kernel does not cover fall back to the plain one. */
+int cbl_queryandgroup_ordered(int m, int nsample, int c, int use_xyz, const float* xyz, const float* new_xyz, const float* feat, const int* idx,
+                              const int* order, float* out, void* stream);
 
 /* F4  interpolation weights  pointops.py:171-174: w = (1/(dist+1e-8)) / sum_k(1/(dist+1e-8)), dist = sqrt(dist2)
  *   dist2 (n,k) -> weight (n,k), dist (n,k) (dist may be NULL) */
@@ -215,6 +232,10 @@ int cbl_boundary_iou(int n, int k, int num_classes, long long ignore_label, cons
 int cbl_kpconv_forward(int n, int n0, int K, int C, int KP, const float* query_points, const float* support_points, const int* neighbors_indices,
                        const float* features, const float* kernel_points, const float* kernel_weights, float extent, int influence, int closest,
                        float* out, void* stream);
+/* same values; `order` (n ints, NULL = none) = processing sequence of the query points, see cbl_queryandgroup_ordered */
+int cbl_kpconv_forward_ordered(int n, int n0, int K, int C, int KP, const float* query_points, const float* support_points, const int* neighbors_indices,
+                               const float* features, const float* kernel_points, const float* kernel_weights, float extent, int influence, int closest,
+                               const int* order, float* out, void* stream);
 /* gradients w.r.t. features (n0,C) += and kernel_weights (KP,C) += (caller pre-zeroes; either may be NULL); K <= 64 */
 int cbl_kpconv_backward(int n, int n0, int K, int C, int KP, const float* query_points, const float* support_points, const int* neighbors_indices,
                         const float* features, const float* kernel_points, const float* kernel_weights, float extent, int influence, int closest,

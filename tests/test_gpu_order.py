@@ -1,0 +1,121 @@
+"""Processing order (`*_ordered` entry points, pointops.spatial_order): the order changes the schedule of a kernel, never its values."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _i(v):
+    return ctypes.c_int(int(v))
+
+
+def test_knnquery_ordered_returns_the_same_neighbours_and_a_cell_order():
+    from contrastboundary_amd import _lib, pointops, synthetic as S
+    n, K = 20000, 16
+    xyz_h = S.s_room(n, seed=2)[0]
+    xyz = dev(xyz_h); off = dev(np.int32([9000, n]))
+    ref_idx, ref_d2 = pointops.knnquery_raw(K, xyz, xyz, off, off, algo="grid")
+    L = _lib.lib()
+    need = L.cbl_knnquery_workspace_bytes(_i(2), _i(n), _i(n), _i(K))
+    ws = torch.empty(need + 256, dtype=torch.uint8, device="cuda")
+    for policy, algo in ((0, "grid"), (1, "set"), (2, "anytie")):
+        idx = torch.empty((n, K), dtype=torch.int32, device="cuda"); d2 = torch.empty((n, K), dtype=torch.float32, device="cuda")
+        order = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        rc = L.cbl_knnquery_ordered(_i(2), _i(n), _i(n), _i(K), _lib.ptr(xyz), _lib.ptr(xyz), _lib.ptr(off), _lib.ptr(off), _lib.ptr(idx), _lib.ptr(d2),
+                                    _i(policy), _lib.ptr(order), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(xyz))
+        assert rc == 0
+        want_idx, want_d2 = pointops.knnquery_raw(K, xyz, xyz, off, off, algo=algo)
+        assert torch.equal(idx, want_idx) and torch.equal(d2, want_d2)
+        o = order.cpu().numpy()
+        assert np.array_equal(np.sort(o), np.arange(n))                       # a permutation
+        assert o[:9000].max() < 9000 and o[9000:].min() >= 9000               # cloud after cloud
+        # spatially coherent: consecutive points of the sequence are far closer than consecutive points of the (shuffled) scene
+        step = np.linalg.norm(np.diff(xyz_h[o], axis=0), axis=1); base = np.linalg.norm(np.diff(xyz_h, axis=0), axis=1)
+        assert np.median(step) < 0.2 * np.median(base)
+    assert torch.equal(ref_idx, pointops.knnquery_raw(K, xyz, xyz, off, off)[0]) and ref_d2.shape == (n, K)
+    # shapes outside the grid path do not produce an order
+    small = xyz[:1000].contiguous(); so = dev(np.int32([1000]))
+    idx = torch.empty((1000, K), dtype=torch.int32, device="cuda"); d2 = torch.empty((1000, K), dtype=torch.float32, device="cuda")
+    rc = L.cbl_knnquery_ordered(_i(1), _i(1000), _i(1000), _i(K), _lib.ptr(small), _lib.ptr(small), _lib.ptr(so), _lib.ptr(so), _lib.ptr(idx), _lib.ptr(d2),
+                                _i(0), _lib.ptr(order), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(xyz))
+    assert rc == _lib.ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("m,k,c", [(5000, 16, 64), (3000, 8, 32), (2000, 9, 32), (1000, 32, 128), (777, 12, 20), (600, 16, 6)])
+def test_queryandgroup_ordered_equals_unordered(m, k, c):
+    """any permutation as processing order (also shapes the ordered kernel does not cover: they fall back)"""
+    from contrastboundary_amd import _lib
+    rng = np.random.default_rng(m + k + c)
+    xyz = dev(rng.uniform(size=(m, 3)).astype(np.float32)); feat = dev(rng.normal(size=(m, c)).astype(np.float32))
+    idx = dev(rng.integers(0, m, (m, k)).astype(np.int32))
+    L = _lib.lib()
+    outs = []
+    for order in (None, dev(rng.permutation(m).astype(np.int32)), dev(np.arange(m, dtype=np.int32)[::-1].copy())):
+        out = torch.full((m, k, 3 + c), np.nan, dtype=torch.float32, device="cuda")
+        rc = L.cbl_queryandgroup_ordered(_i(m), _i(k), _i(c), _i(1), _lib.ptr(xyz), _lib.ptr(xyz), _lib.ptr(feat), _lib.ptr(idx), _lib.ptr(order), _lib.ptr(out),
+                                         _lib.stream_of(xyz))
+        assert rc == 0
+        outs.append(out)
+    ref = torch.cat([xyz[idx.long()] - xyz[:, None, :], feat[idx.long()]], -1)
+    for out in outs:
+        assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("n,K,C", [(5000, 16, 64), (1234, 20, 72), (9, 16, 64)])
+def test_kpconv_forward_ordered_equals_unordered(n, K, C):
+    from contrastboundary_amd import _lib
+    rng = np.random.default_rng(n)
+    q = dev(rng.uniform(size=(n, 3)).astype(np.float32)); f = dev(rng.normal(size=(n, C)).astype(np.float32))
+    idx = dev(rng.integers(0, n + 1, (n, K)).astype(np.int32))                # n = shadow neighbour
+    kpts = dev((rng.normal(size=(15, 3)) * 0.2).astype(np.float32)); kw = dev(rng.normal(size=(15, C)).astype(np.float32))
+    L = _lib.lib()
+    outs = []
+    for order in (None, dev(rng.permutation(n).astype(np.int32))):
+        out = torch.full((n, C), np.nan, dtype=torch.float32, device="cuda")
+        rc = L.cbl_kpconv_forward_ordered(_i(n), _i(n), _i(K), _i(C), _i(15), _lib.ptr(q), _lib.ptr(q), _lib.ptr(idx), _lib.ptr(f), _lib.ptr(kpts), _lib.ptr(kw),
+                                          ctypes.c_float(0.5), _i(1), _i(0), _lib.ptr(order), _lib.ptr(out), _lib.stream_of(q))
+        assert rc == 0
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[0]).all()
+
+
+def test_python_ops_pick_the_order_up_and_values_do_not_change():
+    from contrastboundary_amd import hotpath, local_aggregation as LA, pointops
+    sc = hotpath.Scene.synthetic(16384, 64, seed=5)
+    pointops.use_spatial_order = False
+    try:
+        idx, _ = pointops.knnquery_raw(16, sc.xyz, sc.xyz, sc.offset, sc.offset)
+        g0 = pointops.queryandgroup(16, sc.xyz, sc.xyz, sc.feat, idx, sc.offset, sc.offset, use_xyz=True)
+        k0 = LA.kpconv(sc.xyz, sc.xyz, idx, sc.feat, sc.kernel_points, sc.kernel_weights, 0.12)
+    finally:
+        pointops.use_spatial_order = True
+    assert pointops.spatial_order(sc.xyz) is None                             # nothing registered while switched off
+    idx1, _ = pointops.knnquery_raw(16, sc.xyz, sc.xyz, sc.offset, sc.offset)
+    order = pointops.spatial_order(sc.xyz)
+    assert order is not None and order.shape == (16384,) and torch.equal(torch.sort(order.long())[0], torch.arange(16384, device="cuda"))
+    assert torch.equal(idx, idx1)
+    assert torch.equal(pointops.queryandgroup(16, sc.xyz, sc.xyz, sc.feat, idx, sc.offset, sc.offset, use_xyz=True), g0)
+    assert torch.equal(LA.kpconv(sc.xyz, sc.xyz, idx, sc.feat, sc.kernel_points, sc.kernel_weights, 0.12), k0)
+    # a second search over the same geometry does not produce the order again; a small cloud never does
+    before = id(pointops.spatial_order(sc.xyz))
+    pointops.knnquery_raw(36, sc.xyz, sc.xyz, sc.offset, sc.offset, algo="set")
+    assert id(pointops.spatial_order(sc.xyz)) == before
+    small = sc.xyz[:4096].contiguous(); so = torch.tensor([4096], dtype=torch.int32, device="cuda")
+    pointops.knnquery_raw(16, small, small, so, so)
+    assert pointops.spatial_order(small) is None
+    # the order follows the stream: asked from another stream it is handed over behind the producer's event
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        o2 = pointops.spatial_order(sc.xyz)
+        assert o2 is not None
+        g1 = pointops.queryandgroup(16, sc.xyz, sc.xyz, sc.feat, idx, sc.offset, sc.offset, use_xyz=True)
+    torch.cuda.synchronize()
+    assert torch.equal(g1, g0)

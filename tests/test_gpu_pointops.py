@@ -281,6 +281,22 @@ def test_queryandgroup_and_interpolation_composites(P):
         np.testing.assert_array_equal(got, O.interpolation_forward(fq, iidx, w))
 
 
+@pytest.mark.parametrize("m,k,c", [(500, 16, 64), (37, 5, 4), (129, 7, 12), (1, 3, 8), (64, 16, 128), (33, 9, 132), (50, 4, 6)])
+def test_queryandgroup_shapes(P, m, k, c):
+    """F1 with the index given: the aligned-piece kernel (16 output rows through LDS), its element-wise tail, and the fall-backs
+    (channel counts that are not a multiple of 4, wide rows)"""
+    rng = np.random.default_rng(m * 1000 + k * 10 + c)
+    n = 300
+    xyz = rng.uniform(size=(n, 3)).astype(np.float32); feat = rng.normal(size=(n, c)).astype(np.float32)
+    q = rng.uniform(size=(m, 3)).astype(np.float32)
+    idx = rng.integers(0, n, (m, k)).astype(np.int32)
+    off = np.int32([n]); noff = np.int32([m])
+    for use_xyz in (True, False):
+        out = P.queryandgroup(k, dev(xyz), dev(q), dev(feat), dev(idx), dev(off), dev(noff), use_xyz=use_xyz).cpu().numpy()
+        ref = np.concatenate([xyz[idx] - q[:, None, :], feat[idx]], -1) if use_xyz else feat[idx]      # pointops.py:90-98
+        np.testing.assert_array_equal(out, ref)
+
+
 def test_full_size_properties(P):
     """BASELINE C2 size (N=40960, K=16, C=64): size-independent properties instead of the O(N^2) oracle."""
     rng = np.random.default_rng(0)
