@@ -33,6 +33,25 @@ __global__ __launch_bounds__(GB) void grouping_fwd_v4(long long rows, int c4, co
         __builtin_nontemporal_store(v4{v.x, v.y, v.z, v.w}, reinterpret_cast<v4*>(out + e));
     }
 }
+// the same with a processing order over the m query points (cbl_common.h): 256-lane chunks of the (sequence slot, neighbour, part) space
+// are dealt to the XCDs in contiguous eighths, slot t stands for point order[t]
+__global__ __launch_bounds__(GB) void grouping_fwd_v4_ordered(unsigned m, int ns, int c4, const float4* __restrict__ in, const int* __restrict__ idx,
+                                                              const int* __restrict__ order, float4* __restrict__ out)
+{
+    const unsigned per_pt = (unsigned)ns * (unsigned)c4;
+    const unsigned long long total = (unsigned long long)m * per_pt;
+    const unsigned nch = (unsigned)((total + GB - 1) / GB);
+    for (unsigned v = blockIdx.x; v < 8 * cbl_xcd_per(nch); v += gridDim.x) {
+        const unsigned long long e = (unsigned long long)cbl_xcd_slot(v, nch) * GB + threadIdx.x;
+        if (e >= total) continue;
+        const unsigned t = (unsigned)(e / per_pt), j = (unsigned)(e - (unsigned long long)t * per_pt);
+        const unsigned k = j / (unsigned)c4, ch = j - k * (unsigned)c4;
+        const size_t r = (size_t)order[t] * ns + k;
+        using v4 = __attribute__((ext_vector_type(4))) float;
+        const float4 val = in[(size_t)idx[r] * c4 + ch];
+        __builtin_nontemporal_store(v4{val.x, val.y, val.z, val.w}, reinterpret_cast<v4*>(out + r * c4 + ch));
+    }
+}
 __global__ __launch_bounds__(GB) void grouping_fwd_s(long long rows, int c, const float* __restrict__ in,
                                                      const int* __restrict__ idx, float* __restrict__ out)
 {
@@ -112,6 +131,24 @@ __global__ __launch_bounds__(GB) void sub_fwd(long long rows, int ns, int cv, co
         }
     }
 }
+// with a processing order over the points (cbl_common.h): chunks of the (sequence slot, neighbour, part) space dealt XCD-contiguously
+__global__ __launch_bounds__(GB) void sub_fwd_v4_ordered(unsigned n, int ns, int cv, const float4* __restrict__ a, const float4* __restrict__ b2,
+                                                         const int* __restrict__ idx, const int* __restrict__ order, float4* __restrict__ out)
+{
+    const unsigned per_pt = (unsigned)ns * (unsigned)cv;
+    const unsigned long long total = (unsigned long long)n * per_pt;
+    const unsigned nch = (unsigned)((total + GB - 1) / GB);
+    for (unsigned v = blockIdx.x; v < 8 * cbl_xcd_per(nch); v += gridDim.x) {
+        const unsigned long long e = (unsigned long long)cbl_xcd_slot(v, nch) * GB + threadIdx.x;
+        if (e >= total) continue;
+        const unsigned t = (unsigned)(e / per_pt), j = (unsigned)(e - (unsigned long long)t * per_pt);
+        const unsigned k = j / (unsigned)cv, ch = j - k * (unsigned)cv;
+        const size_t p = (size_t)order[t], r = p * ns + k;
+        const float4 x = a[p * cv + ch];
+        const float4 y = b2[(size_t)idx[r] * cv + ch];
+        out[r * cv + ch] = make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w);
+    }
+}
 
 // ---------------------------------------------------------------- K8 subtraction backward
 // g1[p,:] += go[p,s,:] ; g2[idx[p,s],:] += -go[p,s,:]               subtraction_cuda_kernel.cu:18-30
@@ -163,6 +200,32 @@ __global__ __launch_bounds__(GB) void agg_fwd(int n, int ns, int cv, int wcv, co
             }
             out[e] = acc;
         }
+    }
+}
+
+// with a processing order over the points (cbl_common.h)
+__global__ __launch_bounds__(GB) void agg_fwd_v4_ordered(unsigned n, int ns, int cv, int wcv, const float4* __restrict__ in, const float4* __restrict__ pos,
+                                                         const float4* __restrict__ w, const int* __restrict__ idx, const int* __restrict__ order,
+                                                         float4* __restrict__ out)
+{
+    const unsigned long long total = (unsigned long long)n * cv;
+    const unsigned nch = (unsigned)((total + GB - 1) / GB);
+    for (unsigned v = blockIdx.x; v < 8 * cbl_xcd_per(nch); v += gridDim.x) {
+        const unsigned long long e0 = (unsigned long long)cbl_xcd_slot(v, nch) * GB + threadIdx.x;
+        if (e0 >= total) continue;
+        const unsigned t = (unsigned)(e0 / (unsigned)cv), ch = (unsigned)(e0 - (unsigned long long)t * cv);
+        const size_t p = (size_t)order[t], e = p * cv + ch;
+        const unsigned wch = ch % (unsigned)wcv;
+        float4 acc = out[e];
+        for (int s = 0; s < ns; s++) {
+            const size_t r = p * ns + s;
+            const float4 x = in[(size_t)idx[r] * cv + ch];
+            const float4 q = pos[r * cv + ch];
+            const float4 ww = w[r * wcv + wch];
+            acc.x += (x.x + q.x) * ww.x; acc.y += (x.y + q.y) * ww.y;
+            acc.z += (x.z + q.z) * ww.z; acc.w += (x.w + q.w) * ww.w;
+        }
+        out[e] = acc;
     }
 }
 
@@ -387,19 +450,32 @@ inline bool vec4_ok(int c, const void* a, const void* b, const void* d = nullptr
 #define CBL_CHECK_DIMS(...)   do { const long long _d[] = {__VA_ARGS__}; for (long long v : _d) if (v < 0) return CBL_ERR_BAD_ARG; } while (0)
 #define CBL_CHECK_PTRS(...)   do { const void* _p[] = {__VA_ARGS__}; for (const void* v : _p) if (!v) return CBL_ERR_BAD_ARG; } while (0)
 
-CBL_EXPORT int cbl_grouping_forward(int m, int nsample, int c, const float* input, const int* idx, float* output, void* stream)
+static int grouping_forward_impl(int m, int nsample, int c, const float* input, const int* idx, const int* order, float* output, void* stream)
 {
     CBL_CHECK_DIMS(m, nsample, c);
     const long long rows = (long long)m * nsample;
     if (rows * c == 0) return CBL_OK;
     CBL_CHECK_PTRS(input, idx, output);
     hipStream_t st = cbl_stream(stream);
-    if (vec4_ok(c, input, output))
+    if (order && vec4_ok(c, input, output) && rows * (c / 4) < 0xffffffffLL * GB)
+        hipLaunchKernelGGL(grouping_fwd_v4_ordered, dim3(cbl_round_up8(cbl_grid_for(rows * (c / 4), GB, 256 * 64))), dim3(GB), 0, st, (unsigned)m, nsample, c / 4,
+                           reinterpret_cast<const float4*>(input), idx, order, reinterpret_cast<float4*>(output));
+    else if (vec4_ok(c, input, output))
         hipLaunchKernelGGL(grouping_fwd_v4, dim3(cbl_grid_for(rows * (c / 4), GB)), dim3(GB), 0, st, rows, c / 4,
                            reinterpret_cast<const float4*>(input), idx, reinterpret_cast<float4*>(output));
     else
         hipLaunchKernelGGL(grouping_fwd_s, dim3(cbl_grid_for(rows * c, GB)), dim3(GB), 0, st, rows, c, input, idx, output);
     return cbl_status();
+}
+
+CBL_EXPORT int cbl_grouping_forward(int m, int nsample, int c, const float* input, const int* idx, float* output, void* stream)
+{
+    return grouping_forward_impl(m, nsample, c, input, idx, nullptr, output, stream);
+}
+
+CBL_EXPORT int cbl_grouping_forward_ordered(int m, int nsample, int c, const float* input, const int* idx, const int* order, float* output, void* stream)
+{
+    return grouping_forward_impl(m, nsample, c, input, idx, order, output, stream);
 }
 
 CBL_EXPORT int cbl_grouping_backward(int m, int nsample, int c, const float* grad_output, const int* idx, float* grad_input, void* stream)
@@ -434,18 +510,32 @@ CBL_EXPORT int cbl_interpolation_backward(int n, int c, int k, const float* grad
     return cbl_status();
 }
 
-CBL_EXPORT int cbl_subtraction_forward(int n, int nsample, int c, const float* input1, const float* input2, const int* idx, float* output, void* stream)
+static int subtraction_forward_impl(int n, int nsample, int c, const float* input1, const float* input2, const int* idx, const int* order, float* output, void* stream)
 {
     CBL_CHECK_DIMS(n, nsample, c);
     const long long rows = (long long)n * nsample;
     if (rows * c == 0) return CBL_OK;
     CBL_CHECK_PTRS(input1, input2, idx, output);
     hipStream_t st = cbl_stream(stream);
-    if (vec4_ok(c, input1, input2, output))
+    if (order && vec4_ok(c, input1, input2, output) && rows * (c / 4) < 0xffffffffLL * GB)
+        hipLaunchKernelGGL(sub_fwd_v4_ordered, dim3(cbl_round_up8(cbl_grid_for(rows * (c / 4), GB, 256 * 64))), dim3(GB), 0, st, (unsigned)n, nsample, c / 4,
+                           reinterpret_cast<const float4*>(input1), reinterpret_cast<const float4*>(input2), idx, order, reinterpret_cast<float4*>(output));
+    else if (vec4_ok(c, input1, input2, output))
         hipLaunchKernelGGL(sub_fwd<4>, dim3(cbl_grid_for(rows * (c / 4), GB)), dim3(GB), 0, st, rows, nsample, c / 4, input1, input2, idx, output);
     else
         hipLaunchKernelGGL(sub_fwd<1>, dim3(cbl_grid_for(rows * c, GB)), dim3(GB), 0, st, rows, nsample, c, input1, input2, idx, output);
     return cbl_status();
+}
+
+CBL_EXPORT int cbl_subtraction_forward(int n, int nsample, int c, const float* input1, const float* input2, const int* idx, float* output, void* stream)
+{
+    return subtraction_forward_impl(n, nsample, c, input1, input2, idx, nullptr, output, stream);
+}
+
+CBL_EXPORT int cbl_subtraction_forward_ordered(int n, int nsample, int c, const float* input1, const float* input2, const int* idx, const int* order,
+                                               float* output, void* stream)
+{
+    return subtraction_forward_impl(n, nsample, c, input1, input2, idx, order, output, stream);
 }
 
 CBL_EXPORT int cbl_subtraction_backward(int n, int nsample, int c, const int* idx, const float* grad_output, float* grad_input1, float* grad_input2, void* stream)
@@ -457,18 +547,34 @@ CBL_EXPORT int cbl_subtraction_backward(int n, int nsample, int c, const int* id
     return cbl_status();
 }
 
-CBL_EXPORT int cbl_aggregation_forward(int n, int nsample, int c, int w_c, const float* input, const float* position, const float* weight, const int* idx, float* output, void* stream)
+static int aggregation_forward_impl(int n, int nsample, int c, int w_c, const float* input, const float* position, const float* weight, const int* idx,
+                                    const int* order, float* output, void* stream)
 {
     CBL_CHECK_DIMS(n, nsample, c, w_c);
     if ((long long)n * c == 0) return CBL_OK;
     if (w_c == 0) return CBL_ERR_BAD_ARG;
     CBL_CHECK_PTRS(input, position, weight, idx, output);
     hipStream_t st = cbl_stream(stream);
-    if (vec4_ok(c, input, position, weight, output) && w_c % 4 == 0)
+    if (order && vec4_ok(c, input, position, weight, output) && w_c % 4 == 0)
+        hipLaunchKernelGGL(agg_fwd_v4_ordered, dim3(cbl_round_up8(cbl_grid_for((long long)n * (c / 4), GB, 256 * 64))), dim3(GB), 0, st, (unsigned)n, nsample, c / 4, w_c / 4,
+                           reinterpret_cast<const float4*>(input), reinterpret_cast<const float4*>(position), reinterpret_cast<const float4*>(weight), idx, order,
+                           reinterpret_cast<float4*>(output));
+    else if (vec4_ok(c, input, position, weight, output) && w_c % 4 == 0)
         hipLaunchKernelGGL(agg_fwd<4>, dim3(cbl_grid_for((long long)n * (c / 4), GB)), dim3(GB), 0, st, n, nsample, c / 4, w_c / 4, input, position, weight, idx, output);
     else
         hipLaunchKernelGGL(agg_fwd<1>, dim3(cbl_grid_for((long long)n * c, GB)), dim3(GB), 0, st, n, nsample, c, w_c, input, position, weight, idx, output);
     return cbl_status();
+}
+
+CBL_EXPORT int cbl_aggregation_forward(int n, int nsample, int c, int w_c, const float* input, const float* position, const float* weight, const int* idx, float* output, void* stream)
+{
+    return aggregation_forward_impl(n, nsample, c, w_c, input, position, weight, idx, nullptr, output, stream);
+}
+
+CBL_EXPORT int cbl_aggregation_forward_ordered(int n, int nsample, int c, int w_c, const float* input, const float* position, const float* weight, const int* idx,
+                                               const int* order, float* output, void* stream)
+{
+    return aggregation_forward_impl(n, nsample, c, w_c, input, position, weight, idx, order, output, stream);
 }
 
 CBL_EXPORT int cbl_aggregation_backward(int n, int nsample, int c, int w_c, const float* input, const float* position, const float* weight, const int* idx,

@@ -90,8 +90,18 @@ def _order_register(points, order, stream):
         _order_registry.popitem(last=False)
 
 
+def _order_alias(idx, points):
+    """the neighbour table of a self-search over `points` shares their processing order (ops that are given idx but no coordinates)"""
+    ent = _order_registry.get(_order_key(points))
+    if ent:
+        _order_registry[_order_key(idx)] = ent
+        while len(_order_registry) > _ORDER_REGISTRY_MAX:
+            _order_registry.popitem(last=False)
+
+
 def spatial_order(points):
-    """-> int32 (n,) processing order of `points` (cell order of an earlier self-search over the same tensor), or None"""
+    """-> int32 (n,) processing order of `points` (cell order of an earlier self-search over the same tensor; also keyed by the
+    neighbour table that search returned), or None"""
     if not use_spatial_order or points.shape[0] < ORDER_MIN_POINTS:
         return None
     ent = _order_registry.get(_order_key(points))
@@ -329,11 +339,14 @@ def _knnquery_uncached(nsample, xyz, new_xyz, offset, new_offset, algo):
             rc = L.cbl_knnquery_ordered(*args, _c_int(policy), _lib.ptr(order), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), st)
             if rc == 0:
                 _order_register(xyz, order, cur)
+                _order_alias(idx, xyz)
                 return idx, dist2
             if rc != _lib.ERR_UNSUPPORTED:
                 _lib.check(rc, "cbl_knnquery_ordered")
         fn = L.cbl_knnquery_set if algo == "set" else L.cbl_knnquery_anytie if algo == "anytie" else L.cbl_knnquery
         _lib.check(fn(*args, _lib.ptr(ws), ctypes.c_size_t(ws.numel() if ws is not None else 0), st), "cbl_knnquery")
+        if self_search and n >= ORDER_MIN_POINTS and use_spatial_order:
+            _order_alias(idx, xyz)
     return idx, dist2
 
 
@@ -363,8 +376,9 @@ class Grouping(Function):
         _req(input, torch.float32, "input", 2); _req(idx, torch.int32, "idx", 2)
         m, nsample, n, c = idx.shape[0], idx.shape[1], input.shape[0], input.shape[1]
         output = torch.empty((m, nsample, c), dtype=torch.float32, device=input.device)
-        _lib.check(_lib.lib().cbl_grouping_forward(_c_int(m), _c_int(nsample), _c_int(c), _lib.ptr(input), _lib.ptr(idx),
-                                                   _lib.ptr(output), _lib.stream_of(input)), "cbl_grouping_forward")
+        order = spatial_order(idx)                               # processing order only: same values (cbl_amd.h)
+        _lib.check(_lib.lib().cbl_grouping_forward_ordered(_c_int(m), _c_int(nsample), _c_int(c), _lib.ptr(input), _lib.ptr(idx), _lib.ptr(order),
+                                                           _lib.ptr(output), _lib.stream_of(input)), "cbl_grouping_forward")
         ctx.n = n
         ctx.save_for_backward(idx)
         return output
@@ -444,8 +458,9 @@ class Subtraction(Function):
         n, c = input1.shape
         nsample = idx.shape[-1]
         output = torch.empty((n, nsample, c), dtype=torch.float32, device=input1.device)
-        _lib.check(_lib.lib().cbl_subtraction_forward(_c_int(n), _c_int(nsample), _c_int(c), _lib.ptr(input1), _lib.ptr(input2),
-                                                      _lib.ptr(idx), _lib.ptr(output), _lib.stream_of(input1)), "cbl_subtraction_forward")
+        _lib.check(_lib.lib().cbl_subtraction_forward_ordered(_c_int(n), _c_int(nsample), _c_int(c), _lib.ptr(input1), _lib.ptr(input2),
+                                                              _lib.ptr(idx), _lib.ptr(spatial_order(idx)), _lib.ptr(output), _lib.stream_of(input1)),
+                   "cbl_subtraction_forward")
         ctx.save_for_backward(idx)
         ctx.n2 = input2.shape[0]
         return output
@@ -475,9 +490,9 @@ class Aggregation(Function):
         n, nsample, c = position.shape
         w_c = weight.shape[-1]
         output = torch.zeros((n, c), dtype=torch.float32, device=input.device)
-        _lib.check(_lib.lib().cbl_aggregation_forward(_c_int(n), _c_int(nsample), _c_int(c), _c_int(w_c), _lib.ptr(input), _lib.ptr(position),
-                                                      _lib.ptr(weight), _lib.ptr(idx), _lib.ptr(output), _lib.stream_of(input)),
-                   "cbl_aggregation_forward")
+        _lib.check(_lib.lib().cbl_aggregation_forward_ordered(_c_int(n), _c_int(nsample), _c_int(c), _c_int(w_c), _lib.ptr(input), _lib.ptr(position),
+                                                              _lib.ptr(weight), _lib.ptr(idx), _lib.ptr(spatial_order(idx)), _lib.ptr(output),
+                                                              _lib.stream_of(input)), "cbl_aggregation_forward")
         ctx.save_for_backward(input, position, weight, idx)
         return output
 

@@ -113,6 +113,8 @@ int cbl_furthestsampling_ws(int b, int n, int n_max, const float* xyz, const int
  *   forward : input (n,c), idx (m,nsample) -> output (m,nsample,c)        (output fully overwritten)
  *   backward: grad_output (m,nsample,c), idx -> grad_input (n,c) +=       (caller pre-zeroes) */
 int cbl_grouping_forward(int m, int nsample, int c, const float* input, const int* idx, float* output, void* stream);
+/* same values; `order` (m ints, NULL = none) = processing sequence of the m query points, see cbl_queryandgroup_ordered */
+int cbl_grouping_forward_ordered(int m, int nsample, int c, const float* input, const int* idx, const int* order, float* output, void* stream);
 int cbl_grouping_backward(int m, int nsample, int c, const float* grad_output, const int* idx, float* grad_input, void* stream);
 
 /* K5/K6  interpolation_{forward,backward}_cuda_launcher  interpolation/interpolation_cuda_kernel.h:13-14.
@@ -125,6 +127,9 @@ int cbl_interpolation_backward(int n, int c, int k, const float* grad_output, co
  *   forward : input1 (n,c), input2 (n,c), idx (n,nsample) -> output (n,nsample,c) = in1[n]-in2[idx]
  *   backward: grad_output (n,nsample,c) -> grad_input1 (n,c) +=, grad_input2 (n,c) +=  (pre-zeroed) */
 int cbl_subtraction_forward(int n, int nsample, int c, const float* input1, const float* input2, const int* idx, float* output, void* stream);
+/* same values; `order` (n ints, NULL = none) = processing sequence of the points, see cbl_queryandgroup_ordered */
+int cbl_subtraction_forward_ordered(int n, int nsample, int c, const float* input1, const float* input2, const int* idx, const int* order,
+                                    float* output, void* stream);
 int cbl_subtraction_backward(int n, int nsample, int c, const int* idx, const float* grad_output, float* grad_input1, float* grad_input2, void* stream);
 
 /* K9/K10 aggregation_{forward,backward}_cuda_launcher  aggregation/aggregation_cuda_kernel.h:13-14.
@@ -133,6 +138,9 @@ int cbl_subtraction_backward(int n, int nsample, int c, const int* idx, const fl
  *   backward: -> grad_input (n,c) += (pre-zeroed), grad_position (n,nsample,c) = (overwritten),
  *             grad_weight (n,nsample,w_c) += (pre-zeroed) */
 int cbl_aggregation_forward(int n, int nsample, int c, int w_c, const float* input, const float* position, const float* weight, const int* idx, float* output, void* stream);
+/* same values; `order` (n ints, NULL = none) = processing sequence of the points, see cbl_queryandgroup_ordered */
+int cbl_aggregation_forward_ordered(int n, int nsample, int c, int w_c, const float* input, const float* position, const float* weight, const int* idx,
+                                    const int* order, float* output, void* stream);
 int cbl_aggregation_backward(int n, int nsample, int c, int w_c, const float* input, const float* position, const float* weight, const int* idx, const float* grad_output, float* grad_input, float* grad_position, float* grad_weight, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

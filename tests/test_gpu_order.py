@@ -119,3 +119,47 @@ def test_python_ops_pick_the_order_up_and_values_do_not_change():
         g1 = pointops.queryandgroup(16, sc.xyz, sc.xyz, sc.feat, idx, sc.offset, sc.offset, use_xyz=True)
     torch.cuda.synchronize()
     assert torch.equal(g1, g0)
+
+
+@pytest.mark.parametrize("m,k,c", [(5000, 16, 64), (999, 7, 12), (300, 33, 256)])
+def test_grouping_forward_ordered_equals_unordered(m, k, c):
+    from contrastboundary_amd import _lib
+    rng = np.random.default_rng(m + c)
+    n = 2 * m
+    feat = dev(rng.normal(size=(n, c)).astype(np.float32)); idx = dev(rng.integers(0, n, (m, k)).astype(np.int32))
+    L = _lib.lib()
+    for order in (None, dev(rng.permutation(m).astype(np.int32))):
+        out = torch.full((m, k, c), np.nan, dtype=torch.float32, device="cuda")
+        assert L.cbl_grouping_forward_ordered(_i(m), _i(k), _i(c), _lib.ptr(feat), _lib.ptr(idx), _lib.ptr(order), _lib.ptr(out), _lib.stream_of(feat)) == 0
+        assert torch.equal(out, feat[idx.long()])
+
+
+def test_neighbour_table_carries_the_order():
+    from contrastboundary_amd import hotpath, pointops
+    sc = hotpath.Scene.synthetic(16384, 64, seed=6)
+    idx, _ = pointops.knnquery_raw(16, sc.xyz, sc.xyz, sc.offset, sc.offset)
+    assert pointops.spatial_order(idx) is pointops.spatial_order(sc.xyz) and pointops.spatial_order(idx) is not None
+    idx2, _ = pointops.knnquery_raw(8, sc.xyz, sc.xyz, sc.offset, sc.offset)          # order already known: the table of a later search is keyed too
+    assert pointops.spatial_order(idx2) is pointops.spatial_order(sc.xyz)
+    assert torch.equal(pointops.grouping(sc.feat, idx), sc.feat[idx.long()])
+
+
+@pytest.mark.parametrize("n,k,c,wc", [(5000, 16, 64, 8), (1000, 8, 32, 4), (333, 16, 128, 16)])
+def test_subtraction_and_aggregation_forward_ordered_equal_unordered(n, k, c, wc):
+    from contrastboundary_amd import _lib
+    rng = np.random.default_rng(n + c)
+    a = dev(rng.normal(size=(n, c)).astype(np.float32)); b = dev(rng.normal(size=(n, c)).astype(np.float32))
+    idx = dev(rng.integers(0, n, (n, k)).astype(np.int32))
+    pos = dev(rng.normal(size=(n, k, c)).astype(np.float32)); w = dev(rng.normal(size=(n, k, wc)).astype(np.float32))
+    L = _lib.lib()
+    subs, aggs = [], []
+    for order in (None, dev(rng.permutation(n).astype(np.int32))):
+        out = torch.full((n, k, c), np.nan, dtype=torch.float32, device="cuda")
+        assert L.cbl_subtraction_forward_ordered(_i(n), _i(k), _i(c), _lib.ptr(a), _lib.ptr(b), _lib.ptr(idx), _lib.ptr(order), _lib.ptr(out), _lib.stream_of(a)) == 0
+        subs.append(out)
+        o2 = torch.zeros((n, c), dtype=torch.float32, device="cuda")
+        assert L.cbl_aggregation_forward_ordered(_i(n), _i(k), _i(c), _i(wc), _lib.ptr(a), _lib.ptr(pos), _lib.ptr(w), _lib.ptr(idx), _lib.ptr(order), _lib.ptr(o2),
+                                                 _lib.stream_of(a)) == 0
+        aggs.append(o2)
+    assert torch.equal(subs[0], subs[1]) and torch.equal(subs[0], a[:, None, :] - b[idx.long()])
+    assert torch.equal(aggs[0], aggs[1])
