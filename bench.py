@@ -117,7 +117,7 @@ def main():
     dom = int(np.argmax(stage_ms))
     # kernel that dominates each stage (rocprofv3 --kernel-trace --stats of this same command: profiles/)
     main_kernel = {"knnquery_k16": "knn_grid_group_kernel<16> (+ 5-launch grid build, knn_replay_kernel for the tied queries)",
-                   "queryandgroup": "query_group_v4", "kpconv_fwd": "kpconv_fwd_kernel (v_mfma_f32_16x16x4_f32)",
+                   "queryandgroup": "query_group_lds<16> (aligned 16-row pieces through LDS, cell-order schedule)", "kpconv_fwd": "kpconv_fwd_kernel (v_mfma_f32_16x16x4_f32)",
                    "cbl_knnquery_k36": "knn_grid_wave_kernel (select-then-sort, + 5-launch grid build)",
                    "cbl_mining_loss_fwd": "contrast_bwd_kernel<64,8> in fused forward+gradient mode (+ finalize)", "cbl_mining_loss_bwd": "contrast_grad_scale_kernel"}
     roofline = {"kernel": main_kernel.get(names[dom], names[dom]), "stage": names[dom], "bound": "hbm",
@@ -132,13 +132,13 @@ def main():
     pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(pmc_file) and (n, c, k) == (40960, 64, 16):
         pmc = json.load(open(pmc_file))
-    pmc_kernel = {"knnquery_k16": "knn_grid_group_kernel<16, true, false>", "queryandgroup": "query_group_v4", "kpconv_fwd": "kpconv_fwd_kernel<true>",
+    pmc_kernel = {"knnquery_k16": "knn_grid_group_kernel<16, true, false>", "queryandgroup": "query_group_lds<16>", "kpconv_fwd": "kpconv_fwd_kernel<true>",
                   "cbl_knnquery_k36": "knn_grid_wave_kernel<true, false>", "cbl_mining_loss_fwd": "contrast_bwd_kernel<64, 8>",
                   "cbl_mining_loss_bwd": "contrast_grad_scale_kernel"}
     traffic = lambda stage: pmc.get(pmc_kernel.get(stage, ""), {}).get("hbm_bytes_per_launch")
     roofline["traffic"] = traffic(names[dom])
     gi = names.index("queryandgroup")
-    roofline["hbm_gather"] = {"kernel": "query_group_v4", "bound": "hbm", "achieved": gbps(gi), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roofline["hbm_gather"] = {"kernel": "query_group_lds<16>", "bound": "hbm", "achieved": gbps(gi), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": gbps(gi) / HBM_PEAK_GBS, "bytes_per_launch": stages[gi][2], "traffic": traffic("queryandgroup")}
     if rank == 0:
         # what this device delivers on plain streams, measured here and now (after the timed region): a fill and a copy of the size of
