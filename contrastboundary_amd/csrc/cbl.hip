@@ -102,14 +102,17 @@ struct ContrastRow {
 template <int G, int DV>
 __device__ __forceinline__ void contrast_row(ContrastRow<G, DV>& r, int i, int gl, int nsample, int d, const float* __restrict__ feat,
                                              const int* __restrict__ amax, const int* __restrict__ nidx, float inv_temperature,
-                                             int n_valid, int tf_variant)
+                                             int n_valid, int flags)
 {
+    // flags: bit 0 = TF flavour; bit 1 = `amax` points at int64 labels (the reference's torch.long targets) read through their low words,
+    // which saves the caller a conversion pass (class ids and ignore labels fit 32 bits)
+    const int tf_variant = flags & 1, ls = 1 + ((flags >> 1) & 1);
     const int ns = nsample - 1;                                     // self column dropped, heads.py:195-196 / head.py:560
     const bool col = gl < ns;
     const int raw = nidx[(size_t)i * nsample + 1 + (col ? gl : 0)];
     const bool real = raw >= 0 && raw < n_valid;
     r.nbr = real ? raw : 0;
-    const int my = amax[i], nl = amax[r.nbr];
+    const int my = amax[(size_t)i * ls], nl = amax[(size_t)r.nbr * ls];
     r.nb = col && real && (!tf_variant || (my >= 0 && nl >= 0));    // takes part in the sums
     r.pos = r.nb && (nl == my);                                     // posmask_cnt :145-149 / head.py:538
     const int cnt = group_sum_i<G>(r.pos ? 1 : 0);
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(256) void contrast_bwd_kernel(int m, int nsample, c
             const float scale = fused ? 1.f : grad_loss[0] * weight / count;
             const float ratio = r.P / r.A;
             coef = scale * r.e * ((r.pos ? r.A : 0.f) - r.P) * inv_temperature / (r.A * r.A * (ratio + 1e-12f)) / r.dist;
-            if (tf_variant && r.dist <= 1e-6f) coef = 0.f;           // sqrt(max(s, 1e-12)): flat below the clamp
+            if ((tf_variant & 1) && r.dist <= 1e-6f) coef = 0.f;     // sqrt(max(s, 1e-12)): flat below the clamp
         }
     }
     // phase 2: groups of this wave one after the other (wave-uniform loop), lanes = (pair slot, channel).
@@ -390,17 +393,30 @@ CBL_EXPORT int cbl_label_argmax(int m, int num_classes, const float* labels, int
     return cbl_status();
 }
 
-CBL_EXPORT int cbl_point_contrast_forward(int m, int nsample, int d, const float* features, const int* amax, const int* neighbor_idx,
-                                          float temperature, float weight, float* per_point, int* point_mask, float* stats, float* loss, void* stream)
+static int point_contrast_forward_impl(int m, int nsample, int d, const float* features, const int* amax, int flags, const int* neighbor_idx,
+                                       float temperature, float weight, float* per_point, int* point_mask, float* stats, float* loss, void* stream)
 {
     if (m <= 0 || nsample < 2 || nsample > 65 || d <= 0 || !(temperature > 0.f)) return CBL_ERR_BAD_ARG;
     if (!features || !amax || !neighbor_idx || !per_point || !point_mask || !stats || !loss) return CBL_ERR_BAD_ARG;
     if (!cbl_host_aligned16(features)) return CBL_ERR_BAD_ARG;
     hipStream_t st = cbl_stream(stream);
-    const int rc = dispatch_contrast(true, m, nsample, d, features, amax, neighbor_idx, temperature, weight, 0x7fffffff, 0, per_point, point_mask, nullptr, nullptr, nullptr, st);
+    const int rc = dispatch_contrast(true, m, nsample, d, features, amax, neighbor_idx, temperature, weight, 0x7fffffff, flags, per_point, point_mask, nullptr, nullptr, nullptr, st);
     if (rc) return rc;
     hipLaunchKernelGGL(contrast_finalize_kernel, dim3(1), dim3(1024), 0, st, m, weight, per_point, point_mask, stats, loss);
     return cbl_status();
+}
+
+CBL_EXPORT int cbl_point_contrast_forward(int m, int nsample, int d, const float* features, const int* amax, const int* neighbor_idx,
+                                          float temperature, float weight, float* per_point, int* point_mask, float* stats, float* loss, void* stream)
+{
+    return point_contrast_forward_impl(m, nsample, d, features, amax, 0, neighbor_idx, temperature, weight, per_point, point_mask, stats, loss, stream);
+}
+
+CBL_EXPORT int cbl_point_contrast_forward_l64(int m, int nsample, int d, const float* features, const long long* labels, const int* neighbor_idx,
+                                              float temperature, float weight, float* per_point, int* point_mask, float* stats, float* loss, void* stream)
+{
+    return point_contrast_forward_impl(m, nsample, d, features, reinterpret_cast<const int*>(labels), 2, neighbor_idx, temperature, weight, per_point, point_mask,
+                                       stats, loss, stream);
 }
 
 CBL_EXPORT int cbl_tf_contrast_forward(int m, int n_valid, int nsample, int d, const float* features, const int* labels, const int* neighbors,
@@ -464,6 +480,14 @@ CBL_EXPORT int cbl_point_contrast_forward_grad(int m, int nsample, int d, const 
                                                float* grad_unit, void* stream)
 {
     return contrast_forward_grad(m, 0x7fffffff, 0, nsample, d, features, amax, neighbor_idx, temperature, weight, per_point, point_mask, stats, loss, grad_unit, stream);
+}
+
+CBL_EXPORT int cbl_point_contrast_forward_grad_l64(int m, int nsample, int d, const float* features, const long long* labels, const int* neighbor_idx,
+                                                   float temperature, float weight, float* per_point, int* point_mask, float* stats, float* loss,
+                                                   float* grad_unit, void* stream)
+{
+    return contrast_forward_grad(m, 0x7fffffff, 2, nsample, d, features, reinterpret_cast<const int*>(labels), neighbor_idx, temperature, weight, per_point, point_mask,
+                                 stats, loss, grad_unit, stream);
 }
 
 CBL_EXPORT int cbl_tf_contrast_forward_grad(int m, int n_valid, int nsample, int d, const float* features, const int* labels, const int* neighbors,

@@ -40,6 +40,7 @@ class _PointContrast(Function):
         m, d = features.shape
         nsample = neighbor_idx.shape[1]
         dev = features.device
+        l64 = amax.dtype == torch.int64                                  # the reference's hard targets as they are: no int32 copy
         per_point = torch.empty(m, dtype=torch.float32, device=dev)
         mask = torch.empty(m, dtype=torch.int32, device=dev)
         stats = torch.empty(2, dtype=torch.float32, device=dev)
@@ -47,14 +48,16 @@ class _PointContrast(Function):
         L = _lib.lib()
         if ctx.needs_input_grad[0]:
             unit = torch.zeros_like(features)
-            _lib.check(L.cbl_point_contrast_forward_grad(_c_int(m), _c_int(nsample), _c_int(d), _lib.ptr(features), _lib.ptr(amax), _lib.ptr(neighbor_idx),
-                                                         _c_float(temperature), _c_float(weight), _lib.ptr(per_point), _lib.ptr(mask), _lib.ptr(stats),
-                                                         _lib.ptr(loss), _lib.ptr(unit), _lib.stream_of(features)), "cbl_point_contrast_forward_grad")
+            fn = L.cbl_point_contrast_forward_grad_l64 if l64 else L.cbl_point_contrast_forward_grad
+            _lib.check(fn(_c_int(m), _c_int(nsample), _c_int(d), _lib.ptr(features), _lib.ptr(amax), _lib.ptr(neighbor_idx),
+                          _c_float(temperature), _c_float(weight), _lib.ptr(per_point), _lib.ptr(mask), _lib.ptr(stats),
+                          _lib.ptr(loss), _lib.ptr(unit), _lib.stream_of(features)), "cbl_point_contrast_forward_grad")
             ctx.save_for_backward(unit, stats)
         else:
-            _lib.check(L.cbl_point_contrast_forward(_c_int(m), _c_int(nsample), _c_int(d), _lib.ptr(features), _lib.ptr(amax), _lib.ptr(neighbor_idx),
-                                                    _c_float(temperature), _c_float(weight), _lib.ptr(per_point), _lib.ptr(mask), _lib.ptr(stats),
-                                                    _lib.ptr(loss), _lib.stream_of(features)), "cbl_point_contrast_forward")
+            fn = L.cbl_point_contrast_forward_l64 if l64 else L.cbl_point_contrast_forward
+            _lib.check(fn(_c_int(m), _c_int(nsample), _c_int(d), _lib.ptr(features), _lib.ptr(amax), _lib.ptr(neighbor_idx),
+                          _c_float(temperature), _c_float(weight), _lib.ptr(per_point), _lib.ptr(mask), _lib.ptr(stats),
+                          _lib.ptr(loss), _lib.stream_of(features)), "cbl_point_contrast_forward")
         ctx.weight = weight
         ctx.mark_non_differentiable(mask)
         ctx.set_materialize_grads(False)        # no zero tensor for the (integer) mask output in backward: that was one fill launch per step
@@ -82,7 +85,7 @@ def point_contrast(features, labels, neighbor_idx, temperature=1.0, weight=0.1, 
         _lib.check(_lib.lib().cbl_label_argmax(_c_int(m), _c_int(labels.shape[1]), _lib.ptr(labels), _lib.ptr(amax), _lib.stream_of(features)),
                    "cbl_label_argmax")
     else:
-        amax = labels.to(torch.int32).contiguous()
+        amax = labels.contiguous() if labels.dtype in (torch.int64, torch.int32) else labels.to(torch.int32).contiguous()
     loss, mask = _PointContrast.apply(features.contiguous(), amax, neighbor_idx.contiguous(), float(temperature), float(weight))
     return (loss, mask) if return_mask else loss
 

@@ -196,6 +196,13 @@ int cbl_point_contrast_backward(int m, int nsample, int d, const float* features
 int cbl_point_contrast_forward_grad(int m, int nsample, int d, const float* features, const int* amax, const int* neighbor_idx,
                                     float temperature, float weight, float* per_point, int* point_mask, float* stats, float* loss,
                                     float* grad_unit, void* stream);
+/* the two point-contrast entry points taking the hard labels as the reference holds them (torch.long, heads.py:186-189: the target
+ * itself at stage 0) instead of an int32 copy: one conversion pass less per step.  Values in the int32 range (class ids, ignore labels). */
+int cbl_point_contrast_forward_l64(int m, int nsample, int d, const float* features, const long long* labels, const int* neighbor_idx,
+                                   float temperature, float weight, float* per_point, int* point_mask, float* stats, float* loss, void* stream);
+int cbl_point_contrast_forward_grad_l64(int m, int nsample, int d, const float* features, const long long* labels, const int* neighbor_idx,
+                                        float temperature, float weight, float* per_point, int* point_mask, float* stats, float* loss,
+                                        float* grad_unit, void* stream);
 int cbl_tf_contrast_forward_grad(int m, int n_valid, int nsample, int d, const float* features, const int* labels, const int* neighbors,
                                  float temperature, float weight, float* per_point, int* point_mask, float* stats, float* loss,
                                  float* grad_unit, void* stream);

@@ -119,6 +119,23 @@ def test_cbl_full_size_properties():
     assert float(f.grad.sum(0).abs().max()) < 1e-4
 
 
+def test_hard_labels_as_int64_and_int32_give_the_same_loss_and_gradient():
+    """torch.long targets go to the kernels as they are (cbl_point_contrast_forward*_l64); an int32 copy takes the original entry points"""
+    from contrastboundary_amd import heads, hotpath, pointops
+    sc = hotpath.Scene.synthetic(8192, 32, seed=4)
+    idx, _ = pointops.knnquery_raw(24, sc.xyz, sc.xyz, sc.offset, sc.offset)
+    lab64 = sc.labels.clone(); lab64[::7] = -100                               # an ignore label: compared for equality like any other id
+    res = []
+    for lab in (lab64, lab64.to(torch.int32)):
+        f = sc.latent.clone().requires_grad_(True)
+        loss = heads.point_contrast(f, lab, idx, 0.7, 0.1)
+        loss.backward()
+        with torch.no_grad():
+            res.append((loss.detach().clone(), f.grad.clone(), heads.point_contrast(sc.latent, lab, idx, 0.7, 0.1)))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][2], res[1][2]) and res[0][0].item() > 0
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-5, atol=1e-8)       # atomics: summation order only
+
+
 @pytest.mark.parametrize("limit,d,T", [(26, 32, 1.0), (41, 16, 0.5), (12, 64, 2.0)])
 def test_tf_contrast_head_vs_oracle(limit, d, T):
     """a16: TF contrast_head on radius neighbourhoods with shadow padding + ignored (-1) labels, vs the numpy restatement"""
