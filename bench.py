@@ -120,10 +120,19 @@ def main():
                    "queryandgroup": "query_group_lds<16> (aligned 16-row pieces through LDS, cell-order schedule)", "kpconv_fwd": "kpconv_fwd_kernel (v_mfma_f32_16x16x4_f32)",
                    "cbl_knnquery_k36": "knn_grid_wave_kernel (select-then-sort, + 5-launch grid build)",
                    "cbl_mining_loss_fwd": "contrast_bwd_kernel<64,8> in fused forward+gradient mode (+ finalize)", "cbl_mining_loss_bwd": "contrast_grad_scale_kernel"}
-    roofline = {"kernel": main_kernel.get(names[dom], names[dom]), "stage": names[dom], "bound": "hbm",
-                "achieved": gbps(dom), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps(dom) / HBM_PEAK_GBS, "traffic": None,
-                "note": "achieved = SURVEY 8(d) algorithmic bytes of the stage / its HIP-event time; the neighbour searches move few "
-                        "compulsory bytes (they are latency/issue bound, not HBM bound) - the HBM-bound kernel of the path is the gather, see hbm_gather",
+    # `roofline`: the HBM-bound kernel of the path — the neighbour gather (north_star: ">= 50 % of the HBM roofline on the KNN-gather kernel");
+    # its stage is that ONE kernel, so the stage's HIP-event time is the kernel's launch duration plus the launch gap.  The longest
+    # stages (the two neighbour searches, the CBL mining kernel) are issue / latency / atomic bound, not HBM bound: they are listed under
+    # `longest_stage` and in the per-stage tables with their algorithmic rates, and analysed in DESIGN.md 6.2.
+    gi = names.index("queryandgroup")
+    roofline = {"kernel": main_kernel["queryandgroup"], "stage": "queryandgroup", "bound": "hbm",
+                "achieved": gbps(gi), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps(gi) / HBM_PEAK_GBS, "traffic": None,
+                "bytes_per_launch": stages[gi][2],
+                "note": "achieved = SURVEY 8(d) algorithmic bytes of the launch / its HIP-event time inside the timed region (events on the launch "
+                        "stream, every 5th step); traffic = PMC FETCH_SIZE + WRITE_SIZE per launch (profiles/r01_pmc_traffic.json)",
+                "longest_stage": {"stage": names[dom], "kernel": main_kernel.get(names[dom], names[dom]), "ms": round(stage_ms[dom], 4),
+                                  "algorithmic_GBps": round(gbps(dom), 1),
+                                  "note": "few compulsory bytes: bound by VALU issue / memory latency / the exact replay of tied queries, not by HBM"},
                 "stage_ms": {names[i]: round(stage_ms[i], 4) for i in range(len(stages))},
                 "stage_algorithmic_GBps": {names[i]: round(gbps(i), 1) for i in range(len(stages))}}
     # HBM traffic per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes of this same command with
@@ -136,10 +145,8 @@ def main():
                   "cbl_knnquery_k36": "knn_grid_wave_kernel<true, false>", "cbl_mining_loss_fwd": "contrast_bwd_kernel<64, 8>",
                   "cbl_mining_loss_bwd": "contrast_grad_scale_kernel"}
     traffic = lambda stage: pmc.get(pmc_kernel.get(stage, ""), {}).get("hbm_bytes_per_launch")
-    roofline["traffic"] = traffic(names[dom])
-    gi = names.index("queryandgroup")
-    roofline["hbm_gather"] = {"kernel": "query_group_lds<16>", "bound": "hbm", "achieved": gbps(gi), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": gbps(gi) / HBM_PEAK_GBS, "bytes_per_launch": stages[gi][2], "traffic": traffic("queryandgroup")}
+    roofline["traffic"] = traffic("queryandgroup")
+    roofline["longest_stage"]["traffic"] = traffic(names[dom])
     if rank == 0:
         # what this device delivers on plain streams, measured here and now (after the timed region): a fill and a copy of the size of
         # the gather's output — the 8 TB/s of the spec sheet is not reachable by any kernel, these are
@@ -154,13 +161,12 @@ def main():
             return nbytes / (a.elapsed_time(b) / reps * 1e-3) / 1e9
         fill = _rate(lambda: probe.fill_(1.0), probe.numel() * 4)
         copy = _rate(lambda: probe2.copy_(probe), 2 * probe.numel() * 4)
-        roofline["hbm_gather"].update({"measured_fill_GBps": round(fill, 1), "measured_copy_GBps": round(copy, 1),
-                                       "frac_of_measured_fill": gbps(gi) / fill})
+        roofline.update({"measured_fill_GBps": round(fill, 1), "measured_copy_GBps": round(copy, 1), "frac_of_measured_fill": gbps(gi) / fill})
         del probe, probe2
     ki = names.index("kpconv_fwd")
     roofline["mfma_kpconv"] = {"kernel": "kpconv_fwd_kernel", "bound": "mfma", "achieved": stages[ki][3] / (stage_ms[ki] * 1e-3) / 1e12,
                                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": stages[ki][3] / (stage_ms[ki] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                               "note": "f32-input MFMA; the kernel is bound by gathering K feature rows per point, not by the matrix pipe"}
+                               "note": "f32-input MFMA; the kernel is bound by its vector instruction stream (influence weights, operand feed), not by the matrix pipe"}
 
     if rank == 0:
         out = {
