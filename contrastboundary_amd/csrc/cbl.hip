@@ -102,19 +102,33 @@ struct ContrastRow {
 template <int G, int DV>
 __device__ __forceinline__ void contrast_row(ContrastRow<G, DV>& r, int i, int gl, int nsample, int d, const float* __restrict__ feat,
                                              const int* __restrict__ amax, const int* __restrict__ nidx, float inv_temperature,
-                                             int n_valid, int flags)
+                                             int n_valid, int flags, float kl_thr)
 {
     // flags: bit 0 = TF flavour; bit 1 = `amax` points at int64 labels (the reference's torch.long targets) read through their low words,
-    // which saves the caller a conversion pass (class ids and ignore labels fit 32 bits)
-    const int tf_variant = flags & 1, ls = 1 + ((flags >> 1) & 1);
+    // which saves the caller a conversion pass (class ids and ignore labels fit 32 bits); bits 8..15 = ncls > 0: `amax` points at SOFT
+    // labels (n_valid x ncls floats) and a neighbour is a positive when KL(p_centre || p_neighbour) < kl_thr (sample 'labelkl<thr>')
+    const int tf_variant = flags & 1, ls = 1 + ((flags >> 1) & 1), ncls = (flags >> 8) & 0xff;
     const int ns = nsample - 1;                                     // self column dropped, heads.py:195-196 / head.py:560
     const bool col = gl < ns;
     const int raw = nidx[(size_t)i * nsample + 1 + (col ? gl : 0)];
     const bool real = raw >= 0 && raw < n_valid;
     r.nbr = real ? raw : 0;
-    const int my = amax[(size_t)i * ls], nl = amax[(size_t)r.nbr * ls];
-    r.nb = col && real && (!tf_variant || (my >= 0 && nl >= 0));    // takes part in the sums
-    r.pos = r.nb && (nl == my);                                     // posmask_cnt :145-149 / head.py:538
+    if (ncls) {
+        // collect_labels head.py:498-511 with calc_dist 'kl' :189-191: sum_c xlogy(p_i[c], p_i[c] / max(p_j[c], 1e-12)), classes in ascending
+        // order; a shadow neighbour gathers the zero row (shadow_fn=0); only the shadow mask restricts the pairs (no ignored labels: mask_c None)
+        const float* __restrict__ soft = reinterpret_cast<const float*>(amax);
+        float kl = 0.f;
+        for (int c = 0; c < ncls; c++) {
+            const float pi = soft[(size_t)i * ncls + c], pj = real ? soft[(size_t)r.nbr * ncls + c] : 0.f;
+            if (pi > 0.f) kl += pi * logf(pi / fmaxf(pj, 1e-12f));
+        }
+        r.nb = col && real;
+        r.pos = r.nb && (kl < kl_thr);                              // :511
+    } else {
+        const int my = amax[(size_t)i * ls], nl = amax[(size_t)r.nbr * ls];
+        r.nb = col && real && (!tf_variant || (my >= 0 && nl >= 0));    // takes part in the sums
+        r.pos = r.nb && (nl == my);                                 // posmask_cnt :145-149 / head.py:538
+    }
     const int cnt = group_sum_i<G>(r.pos ? 1 : 0);
     const int nvalid = group_sum_i<G>(r.nb ? 1 : 0);
     r.valid = cnt > 0 && cnt < nvalid;                              // :212-213 / solve_samples_mask head.py:621-640
@@ -151,14 +165,14 @@ __device__ __forceinline__ void contrast_row(ContrastRow<G, DV>& r, int i, int g
 
 template <int G, int DV>
 __global__ __launch_bounds__(256) void contrast_fwd_kernel(int m, int nsample, const float* __restrict__ feat, const int* __restrict__ amax,
-                                                           const int* __restrict__ nidx, float inv_temperature, int n_valid, int tf_variant,
+                                                           const int* __restrict__ nidx, float inv_temperature, int n_valid, int tf_variant, float kl_thr,
                                                            float* __restrict__ per_point, int* __restrict__ point_mask)
 {
     const int t = (blockIdx.x * 256 + threadIdx.x) / G;
     const int gl = threadIdx.x & (G - 1);
     const int i = t < m ? t : m - 1;
     ContrastRow<G, DV> r;
-    contrast_row<G, DV>(r, i, gl, nsample, DV * 4, feat, amax, nidx, inv_temperature, n_valid, tf_variant);
+    contrast_row<G, DV>(r, i, gl, nsample, DV * 4, feat, amax, nidx, inv_temperature, n_valid, tf_variant, kl_thr);
     if (t < m && gl == 0) {
         per_point[t] = r.valid ? -logf(r.P / r.A + 1e-12f) : 0.f;  // contrast_softnn :161-163
         point_mask[t] = r.valid ? 1 : 0;
@@ -201,7 +215,7 @@ __global__ __launch_bounds__(1024) void contrast_finalize_kernel(int m, float we
 template <int G, int DV>
 __global__ __launch_bounds__(256) void contrast_bwd_kernel(int m, int nsample, const float* __restrict__ feat, const int* __restrict__ amax,
                                                            const int* __restrict__ nidx, float inv_temperature, float weight,
-                                                           int n_valid, int tf_variant,
+                                                           int n_valid, int tf_variant, float kl_thr,
                                                            const float* __restrict__ stats, const float* __restrict__ grad_loss,
                                                            float* __restrict__ grad_feat,
                                                            float* __restrict__ per_point, int* __restrict__ point_mask)   // non-null: fused forward
@@ -222,7 +236,7 @@ __global__ __launch_bounds__(256) void contrast_bwd_kernel(int m, int nsample, c
     float coef = 0.f; int nbr;
     {
         ContrastRow<G, DV> r;
-        contrast_row<G, DV>(r, i, gl, nsample, D, feat, amax, nidx, inv_temperature, n_valid, tf_variant);
+        contrast_row<G, DV>(r, i, gl, nsample, D, feat, amax, nidx, inv_temperature, n_valid, tf_variant, kl_thr);
         nbr = r.nbr;
         if (fused && t < m && gl == 0) {
             per_point[t] = r.valid ? -logf(r.P / r.A + 1e-12f) : 0.f;   // contrast_softnn :161-163
@@ -331,13 +345,13 @@ __global__ __launch_bounds__(256) void boundary_iou_kernel(int n, int k, int ncl
 
 template <int G>
 int launch_contrast(bool fwd, int m, int nsample, int d, const float* feat, const int* amax, const int* nidx, float inv_t, float weight,
-                    int n_valid, int tf_variant,
+                    int n_valid, int tf_variant, float kl_thr,
                     float* per_point, int* point_mask, const float* stats, const float* grad_loss, float* grad_feat, hipStream_t st)
 {
     const dim3 grid(cbl_div_up((long long)m * G, 256)), block(256);
 #define CBL_CONTRAST_DV(DV)                                                                                                                  \
-    if (fwd) hipLaunchKernelGGL((contrast_fwd_kernel<G, DV>), grid, block, 0, st, m, nsample, feat, amax, nidx, inv_t, n_valid, tf_variant, per_point, point_mask); \
-    else     hipLaunchKernelGGL((contrast_bwd_kernel<G, DV>), grid, block, 0, st, m, nsample, feat, amax, nidx, inv_t, weight, n_valid, tf_variant, stats, grad_loss, grad_feat, \
+    if (fwd) hipLaunchKernelGGL((contrast_fwd_kernel<G, DV>), grid, block, 0, st, m, nsample, feat, amax, nidx, inv_t, n_valid, tf_variant, kl_thr, per_point, point_mask); \
+    else     hipLaunchKernelGGL((contrast_bwd_kernel<G, DV>), grid, block, 0, st, m, nsample, feat, amax, nidx, inv_t, weight, n_valid, tf_variant, kl_thr, stats, grad_loss, grad_feat, \
                                 per_point, point_mask)
     switch (d) {
         case 4:  CBL_CONTRAST_DV(1); break;
@@ -353,13 +367,13 @@ int launch_contrast(bool fwd, int m, int nsample, int d, const float* feat, cons
 
 int dispatch_contrast(bool fwd, int m, int nsample, int d, const float* feat, const int* amax, const int* nidx, float temperature, float weight,
                       int n_valid, int tf_variant,
-                      float* per_point, int* point_mask, const float* stats, const float* grad_loss, float* grad_feat, hipStream_t st)
+                      float* per_point, int* point_mask, const float* stats, const float* grad_loss, float* grad_feat, hipStream_t st, float kl_thr = 0.f)
 {
     const int ns = nsample - 1;
     const float inv_t = 1.0f / temperature;
-    if (ns <= 16) return launch_contrast<16>(fwd, m, nsample, d, feat, amax, nidx, inv_t, weight, n_valid, tf_variant, per_point, point_mask, stats, grad_loss, grad_feat, st);
-    if (ns <= 32) return launch_contrast<32>(fwd, m, nsample, d, feat, amax, nidx, inv_t, weight, n_valid, tf_variant, per_point, point_mask, stats, grad_loss, grad_feat, st);
-    return launch_contrast<64>(fwd, m, nsample, d, feat, amax, nidx, inv_t, weight, n_valid, tf_variant, per_point, point_mask, stats, grad_loss, grad_feat, st);
+    if (ns <= 16) return launch_contrast<16>(fwd, m, nsample, d, feat, amax, nidx, inv_t, weight, n_valid, tf_variant, kl_thr, per_point, point_mask, stats, grad_loss, grad_feat, st);
+    if (ns <= 32) return launch_contrast<32>(fwd, m, nsample, d, feat, amax, nidx, inv_t, weight, n_valid, tf_variant, kl_thr, per_point, point_mask, stats, grad_loss, grad_feat, st);
+    return launch_contrast<64>(fwd, m, nsample, d, feat, amax, nidx, inv_t, weight, n_valid, tf_variant, kl_thr, per_point, point_mask, stats, grad_loss, grad_feat, st);
 }
 
 }  // namespace
@@ -462,14 +476,15 @@ __global__ __launch_bounds__(256) void contrast_grad_scale_kernel(long long tota
 }  // namespace
 
 static int contrast_forward_grad(int m, int n_valid, int tf_variant, int nsample, int d, const float* features, const int* labels, const int* neighbors,
-                                 float temperature, float weight, float* per_point, int* point_mask, float* stats, float* loss, float* grad_unit, void* stream)
+                                 float temperature, float weight, float* per_point, int* point_mask, float* stats, float* loss, float* grad_unit, void* stream,
+                                 float kl_thr = 0.f)
 {
     if (m <= 0 || n_valid < 0 || nsample < 2 || nsample > 65 || d <= 0 || !(temperature > 0.f)) return CBL_ERR_BAD_ARG;
     if (!features || !labels || !neighbors || !per_point || !point_mask || !stats || !loss || !grad_unit) return CBL_ERR_BAD_ARG;
     if (!cbl_host_aligned16(features)) return CBL_ERR_BAD_ARG;
     hipStream_t st = cbl_stream(stream);
     const int rc = dispatch_contrast(false, m, nsample, d, features, labels, neighbors, temperature, weight, n_valid, tf_variant, per_point, point_mask,
-                                     nullptr, nullptr, grad_unit, st);
+                                     nullptr, nullptr, grad_unit, st, kl_thr);
     if (rc) return rc;
     hipLaunchKernelGGL(contrast_finalize_kernel, dim3(1), dim3(1024), 0, st, m, weight, per_point, point_mask, stats, loss);
     return cbl_status();
@@ -495,6 +510,31 @@ CBL_EXPORT int cbl_tf_contrast_forward_grad(int m, int n_valid, int nsample, int
                                             float* grad_unit, void* stream)
 {
     return contrast_forward_grad(m, n_valid, 1, nsample, d, features, labels, neighbors, temperature, weight, per_point, point_mask, stats, loss, grad_unit, stream);
+}
+
+// sample 'labelkl<thr>' of the TF head (config/s3dis.py:162-163, README row "ConvNet + CBL (kl)"): positives by the KL divergence of SOFT labels
+CBL_EXPORT int cbl_tf_contrast_forward_kl(int m, int n_valid, int nsample, int d, const float* features, const float* soft_labels, int num_classes,
+                                          float kl_threshold, const int* neighbors, float temperature, float weight, float* per_point, int* point_mask,
+                                          float* stats, float* loss, void* stream)
+{
+    if (m <= 0 || n_valid < 0 || nsample < 2 || nsample > 65 || d <= 0 || !(temperature > 0.f) || num_classes <= 0 || num_classes > 255) return CBL_ERR_BAD_ARG;
+    if (!features || !soft_labels || !neighbors || !per_point || !point_mask || !stats || !loss) return CBL_ERR_BAD_ARG;
+    if (!cbl_host_aligned16(features)) return CBL_ERR_BAD_ARG;
+    hipStream_t st = cbl_stream(stream);
+    const int rc = dispatch_contrast(true, m, nsample, d, features, reinterpret_cast<const int*>(soft_labels), neighbors, temperature, weight, n_valid,
+                                     1 | (num_classes << 8), per_point, point_mask, nullptr, nullptr, nullptr, st, kl_threshold);
+    if (rc) return rc;
+    hipLaunchKernelGGL(contrast_finalize_kernel, dim3(1), dim3(1024), 0, st, m, weight, per_point, point_mask, stats, loss);
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_tf_contrast_forward_grad_kl(int m, int n_valid, int nsample, int d, const float* features, const float* soft_labels, int num_classes,
+                                               float kl_threshold, const int* neighbors, float temperature, float weight, float* per_point, int* point_mask,
+                                               float* stats, float* loss, float* grad_unit, void* stream)
+{
+    if (num_classes <= 0 || num_classes > 255 || !soft_labels) return CBL_ERR_BAD_ARG;
+    return contrast_forward_grad(m, n_valid, 1 | (num_classes << 8), nsample, d, features, reinterpret_cast<const int*>(soft_labels), neighbors, temperature, weight,
+                                 per_point, point_mask, stats, loss, grad_unit, stream, kl_threshold);
 }
 
 CBL_EXPORT int cbl_contrast_grad_scale(long long total, const float* grad_unit, const float* stats, const float* grad_loss, float weight,

@@ -130,7 +130,7 @@ class ContrastHead(torch.nn.Module):
 # ---------------------------------------------------------------------------------------------------------------------------
 class _TFContrast(Function):
     @staticmethod
-    def forward(ctx, features, labels, neighbors, temperature, weight):
+    def forward(ctx, features, labels, neighbors, temperature, weight, kl_threshold=None):
         m, d = features.shape
         n_valid = labels.shape[0]
         dev = features.device
@@ -139,14 +139,21 @@ class _TFContrast(Function):
         stats = torch.empty(2, dtype=torch.float32, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         L = _lib.lib()
-        args = (_c_int(m), _c_int(n_valid), _c_int(neighbors.shape[1]), _c_int(d), _lib.ptr(features), _lib.ptr(labels), _lib.ptr(neighbors),
-                _c_float(temperature), _c_float(weight), _lib.ptr(per_point), _lib.ptr(mask), _lib.ptr(stats), _lib.ptr(loss))
+        if kl_threshold is None:
+            args = (_c_int(m), _c_int(n_valid), _c_int(neighbors.shape[1]), _c_int(d), _lib.ptr(features), _lib.ptr(labels), _lib.ptr(neighbors),
+                    _c_float(temperature), _c_float(weight), _lib.ptr(per_point), _lib.ptr(mask), _lib.ptr(stats), _lib.ptr(loss))
+            fwd, fwd_grad = L.cbl_tf_contrast_forward, L.cbl_tf_contrast_forward_grad
+        else:                                                            # sample 'labelkl<thr>': labels are (N, ncls) distributions
+            args = (_c_int(m), _c_int(n_valid), _c_int(neighbors.shape[1]), _c_int(d), _lib.ptr(features), _lib.ptr(labels), _c_int(labels.shape[1]),
+                    _c_float(kl_threshold), _lib.ptr(neighbors), _c_float(temperature), _c_float(weight), _lib.ptr(per_point), _lib.ptr(mask),
+                    _lib.ptr(stats), _lib.ptr(loss))
+            fwd, fwd_grad = L.cbl_tf_contrast_forward_kl, L.cbl_tf_contrast_forward_grad_kl
         if ctx.needs_input_grad[0]:
             unit = torch.zeros_like(features)
-            _lib.check(L.cbl_tf_contrast_forward_grad(*args, _lib.ptr(unit), _lib.stream_of(features)), "cbl_tf_contrast_forward_grad")
+            _lib.check(fwd_grad(*args, _lib.ptr(unit), _lib.stream_of(features)), "cbl_tf_contrast_forward_grad")
             ctx.save_for_backward(unit, stats)
         else:
-            _lib.check(L.cbl_tf_contrast_forward(*args, _lib.stream_of(features)), "cbl_tf_contrast_forward")
+            _lib.check(fwd(*args, _lib.stream_of(features)), "cbl_tf_contrast_forward")
         ctx.weight = weight
         ctx.mark_non_differentiable(mask)
         ctx.set_materialize_grads(False)        # no zero tensor for the (integer) mask output in backward: that was one fill launch per step
@@ -156,19 +163,26 @@ class _TFContrast(Function):
     def backward(ctx, grad_loss, _gm):
         unit, stats = ctx.saved_tensors
         if grad_loss is None:                                            # the loss took no part in what was differentiated
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         g = torch.empty_like(unit)
         gl = grad_loss.reshape(1).to(torch.float32).contiguous()
         _lib.check(_lib.lib().cbl_contrast_grad_scale(ctypes.c_longlong(unit.numel()), _lib.ptr(unit), _lib.ptr(stats), _lib.ptr(gl), _c_float(ctx.weight),
                                                       _lib.ptr(g), _lib.stream_of(unit)), "cbl_contrast_grad_scale")
-        return g, None, None, None, None
+        return g, None, None, None, None, None
 
 
-def tf_contrast(features, labels, neighbors, temperature=1.0, weight=0.1, return_mask=False):
-    """TF contrast_head.contrast (sample 'label', 'softnn', 'l2') for one stage: features (m,d) f32, labels (N,) hard labels of the
-    N support points of that stage (negative = ignored), neighbors (m,k) i32 radius neighbours incl. the self column, padded with N."""
-    lab = labels.to(torch.int32).contiguous()
-    loss, mask = _TFContrast.apply(features.contiguous(), lab, neighbors.contiguous(), float(temperature), float(weight))
+def tf_contrast(features, labels, neighbors, temperature=1.0, weight=0.1, return_mask=False, kl_threshold=None):
+    """TF contrast_head.contrast ('softnn', 'l2') for one stage: features (m,d) f32, neighbors (m,k) i32 radius neighbours incl. the self
+    column, padded with N.  sample 'label': labels (N,) hard labels of the N support points of that stage (negative = ignored);
+    sample 'labelkl<thr>' (kl_threshold=thr): labels (N,ncls) f32 label distributions (tf_scene_label(..., 'soft'); one-hot at stage 0)."""
+    if kl_threshold is None:
+        lab = labels.to(torch.int32).contiguous()
+    else:
+        lab = labels.to(torch.float32).contiguous()
+        if lab.dim() != 2 or lab.shape[1] > 255:
+            raise ValueError("labelkl: labels must be (N, ncls <= 255) distributions")
+    loss, mask = _TFContrast.apply(features.contiguous(), lab, neighbors.contiguous(), float(temperature), float(weight),
+                                   None if kl_threshold is None else float(kl_threshold))
     return (loss, mask) if return_mask else loss
 
 

@@ -206,6 +206,17 @@ int cbl_point_contrast_forward_grad_l64(int m, int nsample, int d, const float* 
 int cbl_tf_contrast_forward_grad(int m, int n_valid, int nsample, int d, const float* features, const int* labels, const int* neighbors,
                                  float temperature, float weight, float* per_point, int* point_mask, float* stats, float* loss,
                                  float* grad_unit, void* stream);
+/* TF contrast_head with sample 'labelkl<thr>' (tensorflow/models/heads/head.py:492-519, configs s3dis.py:162-163 — the README's
+ * "ConvNet + CBL (kl)" row): soft_labels (n_valid, num_classes) f32 = the sub-scene label DISTRIBUTIONS (cbl_tf_scene_label with
+ * by_valid = 1; one-hot at stage 0); neighbour j of point i is a positive iff sum_c xlogy(p_i[c], p_i[c] / max(p_j[c], 1e-12)) <
+ * kl_threshold (a shadow neighbour gathers the zero row and only the shadow mask restricts the pairs).  Everything else as
+ * cbl_tf_contrast_forward / _forward_grad.  num_classes <= 255. */
+int cbl_tf_contrast_forward_kl(int m, int n_valid, int nsample, int d, const float* features, const float* soft_labels, int num_classes,
+                               float kl_threshold, const int* neighbors, float temperature, float weight, float* per_point, int* point_mask,
+                               float* stats, float* loss, void* stream);
+int cbl_tf_contrast_forward_grad_kl(int m, int n_valid, int nsample, int d, const float* features, const float* soft_labels, int num_classes,
+                                    float kl_threshold, const int* neighbors, float temperature, float weight, float* per_point, int* point_mask,
+                                    float* stats, float* loss, float* grad_unit, void* stream);
 int cbl_contrast_grad_scale(long long total, const float* grad_unit, const float* stats, const float* grad_loss, float weight,
                             float* grad_features, void* stream);
 

@@ -136,18 +136,38 @@ def tf_scene_label(point_labels, scene_neighbor, num_classes, reduction="max"):
     return (s / (valid.sum(-1, keepdims=True).astype(np.float32) + _EPS)).astype(np.float32)
 
 
-def tf_contrast(features, labels, neighbors, temperature=None, weight=0.1, grad=True):
-    """features (m,d); labels (N,) hard labels of the support points (N >= m; negative = ignored); neighbors (m,k) radius neighbours
-    incl. self column, padded with N.  -> loss, d loss/d features (m,d), point_mask"""
+def tf_label_kl(soft_labels, neighbors):
+    """KL(p_i || p_j) of the soft labels of every (centre, neighbour) pair, calc_dist(..., dist='kl') heads/head.py:189-191 as used by
+    collect_labels :498-511: sum_c xlogy(p_i[c], p_i[c] / max(p_j[c], 1e-12)); a shadow neighbour gathers the zero row (shadow_fn=0, :505).
+    soft_labels (N,ncls) f32, neighbors (m,ns) (self column already dropped) -> (m,ns) f32"""
+    p = np.asarray(soft_labels, np.float32)
+    N = len(p)
+    ppad = np.concatenate([p, np.zeros((1, p.shape[1]), np.float32)])
+    pi = p[:len(neighbors), None, :]
+    pj = ppad[np.minimum(neighbors, N)]
+    ratio = (pi / np.maximum(pj, np.float32(_EPS))).astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        term = np.where(pi > 0, pi * np.log(ratio, where=ratio > 0, out=np.zeros_like(ratio)), np.float32(0.0)).astype(np.float32)   # xlogy(0, .) = 0
+    return term.sum(-1, dtype=np.float32)
+
+
+def tf_contrast(features, labels, neighbors, temperature=None, weight=0.1, grad=True, kl_threshold=None):
+    """features (m,d); labels (N,) hard labels of the support points (N >= m; negative = ignored) — or, with kl_threshold (sample
+    'labelkl<thr>', :492-511), (N,ncls) soft labels: a neighbour is a positive if KL(p_centre || p_neighbour) < thr; neighbors (m,k)
+    radius neighbours incl. self column, padded with N.  -> loss, d loss/d features (m,d), point_mask"""
     f = np.asarray(features, np.float32)
     N = len(labels)
     nbr = np.asarray(neighbors)[:, 1:]                               # exclude self-loop, :560
     m, ns = nbr.shape
-    lab = np.concatenate([np.asarray(labels), [-1]])                 # shadow label -1, :537
-    nl = lab[np.minimum(nbr, N)]
-    me = np.asarray(labels)[:m]
-    posneg = me[:, None] == nl                                       # :538
-    valid = (nl >= 0) & (me[:, None] >= 0)                           # :540-545
+    if kl_threshold is not None:
+        posneg = tf_label_kl(labels, nbr) < np.float32(kl_threshold)  # :511
+        valid = nbr < N                                              # mask_n of tf_gather(get_mask=bool), :505-509 (no ignored labels: mask_c is None)
+    else:
+        lab = np.concatenate([np.asarray(labels), [-1]])             # shadow label -1, :537
+        nl = lab[np.minimum(nbr, N)]
+        me = np.asarray(labels)[:m]
+        posneg = me[:, None] == nl                                   # :538
+        valid = (nl >= 0) & (me[:, None] >= 0)                       # :540-545
     pos_mask = posneg & valid; neg_mask = ~posneg & valid            # :621-627
     point_mask = pos_mask.any(1) & neg_mask.any(1)                   # :629-640
     g = np.zeros_like(f)

@@ -157,6 +157,39 @@ def test_tf_contrast_head_vs_oracle(limit, d, T):
     assert (nb.cpu().numpy() == 6000).any()                                   # the case really contains shadow entries
 
 
+@pytest.mark.parametrize("limit,d,T,thr", [(26, 32, 0.5, 0.5), (20, 64, 1.0, 0.3)])
+def test_tf_contrast_head_labelkl_vs_oracle(limit, d, T, thr):
+    """sample 'labelkl<thr>' (s3dis.py:162-163): positives by the KL divergence of the sub-scene label distributions, on a sub-sampled
+    stage (soft labels from the stage-0 points) with shadow-padded radius neighbourhoods"""
+    from contrastboundary_amd import heads, tf_ops
+    from contrastboundary_amd import synthetic as S
+    xyz, lab = S.s_room(9000, seed=limit + 1)
+    lens = np.int32([4000, 5000])
+    sub, sl = tf_ops.tf_batch_subsampling(dev(xyz), dev(lens), 0.10)
+    scene_nb = tf_ops.tf_batch_neighbors(sub.contiguous(), dev(xyz), sl, dev(lens), 0.10, 32, exact_shape=False)
+    soft = heads.tf_scene_label(dev(lab), scene_nb, 13, "soft")                 # (m, 13) distributions with small denominators
+    m = sub.shape[0]
+    nb = tf_ops.tf_batch_neighbors(sub.contiguous(), sub.contiguous(), sl, sl, 0.25, limit, exact_shape=False)
+    rng = np.random.default_rng(limit)
+    feat = (rng.normal(size=(m, d)) * 0.5).astype(np.float32)
+    f = dev(feat).requires_grad_(True)
+    loss, mask = heads.tf_contrast(f, soft, nb, T, 0.1, return_mask=True, kl_threshold=thr)
+    loss.backward()
+    soft_h, nb_h = soft.cpu().numpy(), nb.cpu().numpy()
+    kl = C.tf_label_kl(soft_h, nb_h[:, 1:])
+    assert np.abs(kl - thr).min() > 1e-4                                       # no pair sits on the threshold: logf rounding cannot flip one
+    rl, rg, rm = C.tf_contrast(feat, soft_h, nb_h, temperature=T, weight=0.1, kl_threshold=thr)
+    np.testing.assert_array_equal(mask.cpu().numpy().astype(bool), rm)
+    assert rm.any() and not rm.all()
+    np.testing.assert_allclose(loss.item(), rl, rtol=TOL)
+    np.testing.assert_allclose(f.grad.cpu().numpy(), rg, rtol=1e-3, atol=1e-7)
+    assert (nb_h == m).any()                                                   # shadow entries present
+    # inference path (no gradient): same loss
+    with torch.no_grad():
+        l2 = heads.tf_contrast(dev(feat), soft, nb, T, 0.1, kl_threshold=thr)
+    np.testing.assert_allclose(l2.item(), rl, rtol=TOL)
+
+
 def test_tf_scene_labels_vs_oracle():
     from contrastboundary_amd import heads, tf_ops
     from contrastboundary_amd import synthetic as S

@@ -56,3 +56,22 @@ def test_boundary_iou_oracle_matches_reference_functions():
             np.testing.assert_array_equal(v, g[f"iou_{name}_{key}"])
     b, p = C.boundary_mask(g["iou_labels"], g["iou_labels"][g["iou_neighbor_idx"]], get_plain=True)
     np.testing.assert_array_equal(b, g["iou_bound_mask"]); np.testing.assert_array_equal(p, g["iou_plain_mask"])
+
+
+def test_tf_label_kl_known_answers():
+    """calc_dist 'kl' (heads/head.py:189-191) as used by sample 'labelkl': hand-computed values, xlogy(0, .) = 0, zero shadow row"""
+    import numpy as np
+    from oracle import cbl_oracle as C
+    p = np.float32([[1, 0, 0], [0.5, 0.5, 0], [0, 0, 1], [0.25, 0.25, 0.5]])
+    nb = np.int64([[0, 1, 2, 4], [1, 0, 3, 4], [2, 3, 3, 0], [3, 3, 1, 2]])     # 4 = shadow (N)
+    kl = C.tf_label_kl(p, nb)
+    big = np.log(np.float32(1.0) / np.float32(1e-12))
+    want = np.float32([[0.0, np.log(2.0), big, big],
+                       [0.0, 0.5 * np.log(0.5) + 0.5 * np.log(0.5 / 1e-12), 0.5 * np.log(2.0) + 0.5 * np.log(2.0), 0.5 * np.log(0.5 / 1e-12) * 2],
+                       [0.0, np.log(2.0), np.log(2.0), big],
+                       [0.0, 0.0, 0.25 * np.log(0.5) * 2 + 0.5 * np.log(0.5 / 1e-12), 0.25 * np.log(0.25 / 1e-12) * 2 + 0.5 * np.log(0.5)]])
+    np.testing.assert_allclose(kl, want, rtol=1e-5, atol=1e-6)
+    # with the threshold: identical distributions are positives, disjoint ones never
+    f = np.random.default_rng(0).normal(size=(4, 8)).astype(np.float32)
+    loss, g, mask = C.tf_contrast(f, p, np.concatenate([np.arange(4)[:, None], nb], 1), temperature=0.5, weight=0.1, kl_threshold=0.5)
+    assert mask.tolist() == [True, True, True, True] and np.isfinite(loss) and np.isfinite(g).all()
