@@ -62,3 +62,26 @@ def crop_nearest(coord, center_idx, voxel_max):
     _lib.check(_lib.lib().cbl_crop_order(ctypes.c_int(n), ctypes.c_int(1 if coord.dtype == torch.float64 else 0), _lib.ptr(coord), ctypes.c_int(int(center_idx)),
                                          _lib.ptr(order), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(coord)), "cbl_crop_order")
     return order[:voxel_max].long()
+
+
+def test_time_crops(coord, voxel_max, potentials=None):
+    """The spatially regular crops of the reference's test loop (tool/test.py:197-215) for a cloud with more than voxel_max points:
+    until every point is covered — centre = the point of minimum potential, crop = its voxel_max nearest points, potentials of the crop
+    raised by (1 - d2 / max d2)^2.  coord (n,3) CUDA; potentials (n,) float64 (default: rand * 1e-3 like the reference, :198).
+    -> list of (voxel_max,) int64 index tensors, ascending distance.  One host synchronisation per crop (the loop's exit test)."""
+    _coord(coord)
+    n, dev = coord.shape[0], coord.device
+    pot = (torch.rand(n, dtype=torch.float64, device=dev) * 1e-3) if potentials is None else potentials.to(device=dev, dtype=torch.float64).clone()
+    covered = torch.zeros(n, dtype=torch.bool, device=dev)
+    crops, ncov = [], 0
+    while ncov != n:
+        init = int(torch.argmin(pot).item())                         # first minimum, like np.argmin
+        idx = crop_nearest(coord, init, voxel_max)
+        d = coord[idx] - coord[init]
+        dist = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        delta = torch.square(1 - dist / dist.max())
+        pot[idx] += delta.to(torch.float64)
+        covered[idx] = True
+        ncov = int(covered.sum().item())
+        crops.append(idx)
+    return crops

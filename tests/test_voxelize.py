@@ -38,3 +38,28 @@ def test_gpu_voxelize_and_crop(case):
     np.testing.assert_array_equal(gu.cpu().numpy(), idx_sort[start + rand % count])    # voxelize.py:49-51
     order = VZ.crop_nearest(c, 123, 2000).cpu().numpy()
     np.testing.assert_array_equal(order, V.crop_order(coord, 123)[:2000])
+
+
+def test_oracle_test_time_crops_cover_the_cloud():
+    rng = np.random.default_rng(3)
+    coord = rng.uniform(0, 4, (3000, 3)).astype(np.float32)
+    crops = V.test_time_crops(coord, 800, rng.random(3000) * 1e-3)
+    assert len(crops) >= 4 and all(len(c) == 800 for c in crops)
+    assert np.array_equal(np.unique(np.concatenate(crops)), np.arange(3000))          # every point covered (the loop's exit condition)
+    first = crops[0]
+    d0 = ((coord[first] - coord[first[0]]) ** 2).sum(1)
+    assert (np.diff(d0) >= 0).all()                                                    # nearest first, centre at position 0
+
+
+@pytest.mark.gpu
+def test_gpu_test_time_crops_equal_the_oracle():
+    import torch
+    from contrastboundary_amd import voxelize as VZ
+    rng = np.random.default_rng(5)
+    coord = rng.uniform(0, 5, (6000, 3)).astype(np.float32)
+    pot = rng.random(6000) * 1e-3
+    want = V.test_time_crops(coord, 1500, pot)
+    got = VZ.test_time_crops(torch.from_numpy(coord).cuda(), 1500, torch.from_numpy(pot))
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        np.testing.assert_array_equal(g.cpu().numpy(), w)
