@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--k", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="all stages in order on one stream")
+    ap.add_argument("--no-nested", action="store_true", help="every neighbour search on its own (no derivation of K=16 from the K=36 search of the same points)")
     ap.add_argument("--side-after", default=None, help="main-stream stage after which the side stream starts (default: start of the step)")
     return ap.parse_args()
 
@@ -77,8 +78,9 @@ def main():
     stages = hotpath.stages(scene, k)
     state = {}
     # the CBL head's neighbour search (independent of the stages before it) goes to a side stream, the rest runs in order
-    sched = hotpath.Schedule(stages, overlap=not args.no_overlap)
-    in_order = hotpath.Schedule(stages, overlap=False)
+    hints = () if args.no_nested else hotpath.search_hints(scene)
+    sched = hotpath.Schedule(stages, overlap=not args.no_overlap, hints=hints)
+    in_order = hotpath.Schedule(stages, overlap=False, hints=hints)
 
     def step(events=None):
         # steps that carry per-stage events (every EVENT_EVERY-th of the timed region) run in order on one stream, so that a stage's
@@ -116,7 +118,8 @@ def main():
     gbps = lambda i: stages[i][2] / (stage_ms[i] * 1e-3) / 1e9
     dom = int(np.argmax(stage_ms))
     # kernel that dominates each stage (rocprofv3 --kernel-trace --stats of this same command: profiles/)
-    main_kernel = {"knnquery_k16": "knn_grid_group_kernel<16> (+ 5-launch grid build, knn_replay_kernel for the tied queries)",
+    main_kernel = {"knnquery_k16": ("knn_grid_group_kernel<16> (+ 5-launch grid build, knn_replay_kernel for the tied queries)" if args.no_nested else
+                                    "the K=36 search of the same points (grid build + knn_grid_wave_kernel), knn_prefix_kernel, knn_replay_kernel for the tied queries"),
                    "queryandgroup": "query_group_lds<16> (aligned 16-row pieces through LDS, cell-order schedule)", "kpconv_fwd": "kpconv_fwd_kernel (v_mfma_f32_16x16x4_f32)",
                    "cbl_knnquery_k36": "knn_grid_wave_kernel (select-then-sort, + 5-launch grid build)",
                    "cbl_mining_loss_fwd": "contrast_bwd_kernel<64,8> in fused forward+gradient mode (+ finalize)", "cbl_mining_loss_bwd": "contrast_grad_scale_kernel"}
@@ -176,7 +179,10 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "S3DIS-shaped synthetic scene (S-room), N=%d, K=%d, C=%d, 1 scene per GPU per step; stages: %s"
                        % (n, k, c, " -> ".join(s[0] for s in stages)), "parallelism": "scene-per-GPU replicas x%d (no data-path collective)" % world,
-                       "schedule": ("in order on one stream" if args.no_overlap else
+                       "schedule": (("one search per geometry: the K=%d request runs the K=%d search the CBL head declared for the same points "
+                                     "(neighbor_cache hint, dropped at the end of every step) and is derived from it (cbl_knnquery_prefix, tied rows "
+                                     "replayed); the later K=%d request is a cache hit; all stages in order on one stream" % (k, hotpath.CBL_NSAMPLE, hotpath.CBL_NSAMPLE))
+                                    if hints else "in order on one stream" if args.no_overlap else
                                     "two HIP streams: %s on a side stream, the other stages in order (hotpath.Schedule); the steps that carry "
                                     "per-stage events run in order" % ", ".join(hotpath.SIDE_STAGES))},
             "roofline": roofline,

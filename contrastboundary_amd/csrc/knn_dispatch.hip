@@ -61,3 +61,56 @@ CBL_EXPORT int cbl_knnquery_ordered(int b, int n, int m, int nsample, const floa
     if (tie_policy < 0 || tie_policy > 2 || !cell_order) return CBL_ERR_BAD_ARG;
     return knnquery_impl(b, n, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, workspace, workspace_bytes, tie_policy, stream, cell_order);
 }
+
+// ---- a narrower search from a wider one over the same (supports, queries) ----------------------------------------------------
+// The K nearest neighbours are the first K of the K' > K nearest.  A row of the wider result (ascending distances, exact K' smallest —
+// every tie policy delivers that) gives the narrower result directly unless a tie decides it: equal distances among its first K entries
+// (the reference lists them in its heap's order: policy 0 only) or across the K / K+1 boundary (which of them belong to the reference's
+// set: policies 0 and 1), or a row that is not full (fewer than K supports).  Those queries go to the exact replay, the same
+// certification the grid kernels apply to their own lists.  One search instead of two for networks that look at one geometry with
+// several neighbourhood sizes (the blocks' K = 8 / 16 and the CBL head's K = 36 at a stage).
+int cbl_knn_exact_worklist(int b, int m, int K, const float* xyz, const float* new_xyz, const int* offset, const int* new_offset,
+                           int* idx, float* dist2, const int* worklist, const int* worklist_count, int max_work, hipStream_t st);   // knn_exact.hip
+
+namespace {
+__global__ __launch_bounds__(256) void knn_prefix_kernel(int m, int kb, int ks, const int* __restrict__ idx_big, const float* __restrict__ d2_big,
+                                                         int* __restrict__ idx, float* __restrict__ dist2, int set_exact,
+                                                         int* __restrict__ worklist, int* __restrict__ counter)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= m) return;
+    const int* ib = idx_big + (size_t)q * kb; const float* db = d2_big + (size_t)q * kb;
+    float prev = -1.f; bool dup = false;
+    for (int j = 0; j < ks; j++) {
+        const float d = db[j];
+        idx[(size_t)q * ks + j] = ib[j]; dist2[(size_t)q * ks + j] = d;
+        dup = dup || (d == prev);
+        prev = d;
+    }
+    const bool full = prev < 1e10f;                                 // the reference's initial heap entries are 1e10 (knnquery_cuda_kernel.cu:91-94)
+    const bool boundary = db[ks] == prev;
+    const bool ok = full && !boundary && (set_exact || !dup);
+    if (!ok) worklist[atomicAdd(counter, 1)] = q;
+}
+}  // namespace
+
+CBL_EXPORT size_t cbl_knnquery_prefix_workspace_bytes(int m) { return m < 0 ? 0 : sizeof(int) * ((size_t)m + 64); }
+
+CBL_EXPORT int cbl_knnquery_prefix(int b, int n, int m, int nsample_wide, int nsample, const float* xyz, const float* new_xyz,
+                                   const int* offset, const int* new_offset, const int* idx_wide, const float* dist2_wide,
+                                   int* idx, float* dist2, int tie_policy, void* workspace, size_t workspace_bytes, void* stream)
+{
+    (void)n;
+    if (b <= 0 || m < 0 || nsample <= 0 || nsample >= nsample_wide || nsample_wide > CBL_KNN_MAX_NSAMPLE || tie_policy < 0 || tie_policy > 1) return CBL_ERR_BAD_ARG;
+    if (m == 0) return CBL_OK;
+    if (!xyz || !new_xyz || !offset || !new_offset || !idx_wide || !dist2_wide || !idx || !dist2 || !workspace) return CBL_ERR_BAD_ARG;
+    if (workspace_bytes < cbl_knnquery_prefix_workspace_bytes(m)) return CBL_ERR_WORKSPACE;
+    hipStream_t st = cbl_stream(stream);
+    int* counter = reinterpret_cast<int*>(workspace);
+    int* worklist = counter + 64;
+    (void)hipMemsetAsync(counter, 0, sizeof(int), st);
+    hipLaunchKernelGGL(knn_prefix_kernel, dim3(cbl_div_up(m, 256)), dim3(256), 0, st, m, nsample_wide, nsample, idx_wide, dist2_wide, idx, dist2, tie_policy, worklist, counter);
+    const int rc = cbl_status();
+    if (rc) return rc;
+    return cbl_knn_exact_worklist(b, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, worklist, counter, m, st);
+}

@@ -94,6 +94,11 @@ def stages(scene, k=16):
     return st
 
 
+def search_hints(scene):
+    """the widest neighbourhood each geometry of the step is searched with: the CBL head's K = 36 on the scene's own points"""
+    return ((scene.xyz, CBL_NSAMPLE, "set"),)
+
+
 def run_once(scene, k=16, state=None):
     """every stage in order on the current stream (the reference's schedule)"""
     state = {} if state is None else state
@@ -109,14 +114,27 @@ class Schedule:
 
     events: optional list (one entry per stage) of (start, end) torch.cuda.Event pairs, recorded on the stream the stage runs on."""
 
-    def __init__(self, stage_list, overlap=True):
+    def __init__(self, stage_list, overlap=True, hints=()):
+        """hints: (xyz, nsample, algo) triples for pointops.neighbor_cache.hint — the widest search each geometry sees during the step.
+        With hints the step runs inside a neighbour cache (dropped at the end of the step: nothing is carried from step to step) and the
+        narrower searches are derived from the wide one; the side stream then has nothing left to overlap."""
         self.stage_list = stage_list
+        self.hints = tuple(hints)
+        overlap = overlap and not self.hints
         self.overlap = overlap
         self.side = torch.cuda.Stream() if overlap else None
         self.joined = torch.cuda.Event() if overlap else None
 
     def run(self, state, events=None, side_after=None):
         """side_after: name of the main-stream stage after which the side stages may start (None: at the start of the step)"""
+        if self.hints:
+            with pointops.neighbor_cache() as nc:
+                for xyz, nsample, algo in self.hints:
+                    nc.hint(xyz, nsample, algo)
+                return self._run(state, events, side_after)
+        return self._run(state, events, side_after)
+
+    def _run(self, state, events, side_after):
         main = torch.cuda.current_stream()
         names = [st[0] for st in self.stage_list]
         side_idx = [i for i, nm in enumerate(names) if self.overlap and nm in SIDE_STAGES]

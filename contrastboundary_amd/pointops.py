@@ -184,6 +184,19 @@ class neighbor_cache:
     def __init__(self):
         self.store, self.hits, self.misses = {}, 0, 0
         self.host = {}                                              # host copies of offset tensors, see host_offsets()
+        self.hints = {}                                             # geometry -> (widest nsample it will be searched with, algo), see hint()
+        self.wide = {}                                              # geometry -> (nsample, algo) of the widest result in the store
+        self.derived = 0                                            # requests answered from a wider result (cbl_knnquery_prefix)
+
+    def hint(self, xyz, nsample, algo="set", new_xyz=None, offset=None, new_offset=None):
+        """Declare that this geometry will be searched with up to `nsample` neighbours during the pass (a network knows its config:
+        the blocks' K = 8 / 16 and the CBL head's K = 36 look at the same points).  The first narrower request then runs the WIDE search
+        once (tie policy `algo`) and every narrower one is derived from it — rows decided by a tie are replayed, so the values are those
+        of the separate searches.  Without offsets the hint applies to any offsets used with these coordinates."""
+        self.hints[self._geo(xyz, xyz if new_xyz is None else new_xyz)] = (int(nsample), algo)
+
+    def _geo(self, xyz, new_xyz):
+        return (xyz.data_ptr(), tuple(xyz.shape), new_xyz.data_ptr(), tuple(new_xyz.shape))
 
     def __enter__(self):
         self._prev = neighbor_cache.active()
@@ -195,6 +208,7 @@ class neighbor_cache:
         if not getattr(self, "keep", False):
             self.store.clear()
             self.host.clear()
+            self.wide.clear()
         return False
 
     @staticmethod
@@ -241,6 +255,20 @@ class neighbor_cache:
 
     def insert(self, nsample, algo, tensors, idx, dist2):
         self.store[self._key(nsample, algo, tensors)] = self._stamp((idx, dist2), tensors)
+        geo = self._geo(tensors[0], tensors[1])
+        if algo in ("auto", "set", "grid") and nsample > self.wide.get(geo, (0, None))[0]:
+            self.wide[geo] = (nsample, algo)
+
+    def wider(self, nsample, tensors):
+        """-> (nsample_wide, idx_wide, dist2_wide) of a stored wider result over the same tensors, or None"""
+        w = self.wide.get(self._geo(tensors[0], tensors[1]))
+        if w is None or w[0] <= nsample:
+            return None
+        hit = self.store.get(self._key(w[0], w[1], tensors))
+        if hit is None:
+            return None
+        idx, dist2 = self._deliver(hit)
+        return w[0], idx, dist2
 
     def lookup_fps(self, stride, tensors):
         hit = self.store.get(self._key(("fps", stride), "", tensors))
@@ -301,13 +329,47 @@ def knnquery_raw(nsample, xyz, new_xyz, offset, new_offset, algo="auto"):
         algo = _tie_policy
     cache = neighbor_cache.active()
     if cache is not None:
-        hit = cache.lookup(nsample, algo, (xyz, new_xyz, offset, new_offset))
+        tensors = (xyz, new_xyz, offset, new_offset)
+        hit = cache.lookup(nsample, algo, tensors)
         if hit is not None:
             return hit
+        if algo in ("auto", "set"):
+            # a narrower search over a geometry that has (or, by a hint, will need) a wider one: derive it (cbl_knnquery_prefix)
+            wide = cache.wider(nsample, tensors)
+            if wide is None:
+                h = cache.hints.get(cache._geo(xyz, new_xyz))
+                if h is not None and h[0] > nsample and h[0] <= 64:
+                    wi, wd = _knnquery_uncached(h[0], xyz, new_xyz, offset, new_offset, h[1])
+                    cache.insert(h[0], h[1], tensors, wi, wd)
+                    wide = (h[0], wi, wd)
+            if wide is not None:
+                idx, dist2 = knn_prefix(nsample, wide[0], wide[1], wide[2], xyz, new_xyz, offset, new_offset, algo)
+                cache.insert(nsample, algo, tensors, idx, dist2)
+                cache.derived += 1
+                if new_xyz is xyz or (new_xyz.data_ptr() == xyz.data_ptr() and new_xyz.shape == xyz.shape):
+                    _order_alias(idx, xyz)
+                return idx, dist2
         idx, dist2 = _knnquery_uncached(nsample, xyz, new_xyz, offset, new_offset, algo)
-        cache.insert(nsample, algo, (xyz, new_xyz, offset, new_offset), idx, dist2)
+        cache.insert(nsample, algo, tensors, idx, dist2)
         return idx, dist2
     return _knnquery_uncached(nsample, xyz, new_xyz, offset, new_offset, algo)
+
+
+def knn_prefix(nsample, nsample_wide, idx_wide, dist2_wide, xyz, new_xyz, offset, new_offset, algo="auto"):
+    """the `nsample` nearest neighbours from a wider result over the same tensors (cbl_knnquery_prefix): same values as
+    knnquery_raw(nsample, ..., algo) with algo 'auto' (reference order) or 'set'"""
+    if algo not in ("auto", "set"):
+        raise ValueError("knn_prefix: algo must be 'auto' or 'set'")
+    n, m, b = xyz.shape[0], new_xyz.shape[0], offset.shape[0]
+    idx = torch.empty((m, nsample), dtype=torch.int32, device=xyz.device)
+    dist2 = torch.empty((m, nsample), dtype=torch.float32, device=xyz.device)
+    L = _lib.lib()
+    ws = _workspace(max(L.cbl_knnquery_prefix_workspace_bytes(_c_int(m)), 1), xyz.device)
+    _lib.check(L.cbl_knnquery_prefix(_c_int(b), _c_int(n), _c_int(m), _c_int(nsample_wide), _c_int(nsample), _lib.ptr(xyz), _lib.ptr(new_xyz),
+                                     _lib.ptr(offset), _lib.ptr(new_offset), _lib.ptr(idx_wide), _lib.ptr(dist2_wide), _lib.ptr(idx), _lib.ptr(dist2),
+                                     _c_int(1 if algo == "set" else 0), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(xyz)),
+               "cbl_knnquery_prefix")
+    return idx, dist2
 
 
 def _knnquery_uncached(nsample, xyz, new_xyz, offset, new_offset, algo):

@@ -91,6 +91,18 @@ int cbl_knnquery_ordered(int b, int n, int m, int nsample,
                          int* idx, float* dist2, int tie_policy, int* cell_order,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* A narrower search derived from a wider one over the SAME supports and queries: idx_wide / dist2_wide (m, nsample_wide) from
+ * cbl_knnquery (any tie policy), nsample < nsample_wide.  Rows whose first nsample entries are decided by the distances alone are copied;
+ * rows with a tie that matters under tie_policy (0: reference order, 1: reference set — as cbl_knnquery / cbl_knnquery_set) or that are
+ * not full are re-run through the reference-order replay, so idx / dist2 (m, nsample) equal what cbl_knnquery(nsample) returns, bit for
+ * bit.  One search instead of two where a network looks at one geometry with several neighbourhood sizes (pointops.neighbor_cache
+ * hints).  workspace: cbl_knnquery_prefix_workspace_bytes(m). */
+size_t cbl_knnquery_prefix_workspace_bytes(int m);
+int cbl_knnquery_prefix(int b, int n, int m, int nsample_wide, int nsample,
+                        const float* xyz, const float* new_xyz, const int* offset, const int* new_offset,
+                        const int* idx_wide, const float* dist2_wide, int* idx, float* dist2, int tie_policy,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* brute-force variant only (always bit-exact, O(m*n)); `algo` for tests/bench: see cbl_knnquery */
 int cbl_knnquery_exact(int b, int n, int m, int nsample,
                        const float* xyz, const float* new_xyz,
