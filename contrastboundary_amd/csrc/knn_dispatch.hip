@@ -92,6 +92,27 @@ __global__ __launch_bounds__(256) void knn_prefix_kernel(int m, int kb, int ks, 
     const bool ok = full && !boundary && (set_exact || !dup);
     if (!ok) worklist[atomicAdd(counter, 1)] = q;
 }
+// the same for K a power of two <= 64: K consecutive lanes per query (a row of the output is one coalesced segment), ties found by comparing
+// with the next column, gathered per query with one ballot
+template <int KS>
+__global__ __launch_bounds__(256) void knn_prefix_pow2_kernel(int m, int kb, const int* __restrict__ idx_big, const float* __restrict__ d2_big,
+                                                              int* __restrict__ idx, float* __restrict__ dist2, int set_exact,
+                                                              int* __restrict__ worklist, int* __restrict__ counter)
+{
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const long long qq = e / KS;
+    const int j = (int)(e - qq * KS);
+    const bool live = qq < m;
+    const int q = live ? (int)qq : m - 1;
+    const float d = d2_big[(size_t)q * kb + j], dn = d2_big[(size_t)q * kb + j + 1];       // j + 1 <= KS < kb
+    if (live) { idx[(size_t)q * KS + j] = idx_big[(size_t)q * kb + j]; dist2[(size_t)q * KS + j] = d; }
+    const bool last = j == KS - 1;
+    const bool bad = (d == dn && (last || !set_exact)) || (last && !(d < 1e10f));
+    const unsigned long long bm = __ballot(bad && live);
+    const unsigned long long gm = (KS == 64) ? bm : ((bm >> (lane & ~(KS - 1))) & ((1ull << KS) - 1ull));
+    if (live && j == 0 && gm != 0ull) worklist[atomicAdd(counter, 1)] = q;
+}
 }  // namespace
 
 CBL_EXPORT size_t cbl_knnquery_prefix_workspace_bytes(int m) { return m < 0 ? 0 : sizeof(int) * ((size_t)m + 64); }
@@ -109,7 +130,19 @@ CBL_EXPORT int cbl_knnquery_prefix(int b, int n, int m, int nsample_wide, int ns
     int* counter = reinterpret_cast<int*>(workspace);
     int* worklist = counter + 64;
     (void)hipMemsetAsync(counter, 0, sizeof(int), st);
-    hipLaunchKernelGGL(knn_prefix_kernel, dim3(cbl_div_up(m, 256)), dim3(256), 0, st, m, nsample_wide, nsample, idx_wide, dist2_wide, idx, dist2, tie_policy, worklist, counter);
+#define CBL_PREFIX_POW2(KS) hipLaunchKernelGGL(knn_prefix_pow2_kernel<KS>, dim3(cbl_div_up((long long)m * KS, 256)), dim3(256), 0, st, m, nsample_wide, idx_wide, dist2_wide, \
+                                               idx, dist2, tie_policy, worklist, counter)
+    switch (nsample) {
+        case 1: CBL_PREFIX_POW2(1); break;
+        case 2: CBL_PREFIX_POW2(2); break;
+        case 4: CBL_PREFIX_POW2(4); break;
+        case 8: CBL_PREFIX_POW2(8); break;
+        case 16: CBL_PREFIX_POW2(16); break;
+        case 32: CBL_PREFIX_POW2(32); break;
+        default:
+            hipLaunchKernelGGL(knn_prefix_kernel, dim3(cbl_div_up(m, 256)), dim3(256), 0, st, m, nsample_wide, nsample, idx_wide, dist2_wide, idx, dist2, tie_policy, worklist, counter);
+    }
+#undef CBL_PREFIX_POW2
     const int rc = cbl_status();
     if (rc) return rc;
     return cbl_knn_exact_worklist(b, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, worklist, counter, m, st);
