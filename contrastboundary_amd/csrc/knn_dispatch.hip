@@ -115,6 +115,47 @@ __global__ __launch_bounds__(256) void knn_prefix_pow2_kernel(int m, int kb, con
 }
 }  // namespace
 
+void cbl_knn_grid_scratch(void* ws, int b, int n, int m, int** worklist, int** zero_counter);      // knn_grid.hip
+
+static int launch_prefix(int m, int nsample_wide, int nsample, const int* idx_wide, const float* dist2_wide, int* idx, float* dist2, int tie_policy,
+                         int* worklist, int* counter, hipStream_t st)
+{
+#define CBL_PREFIX_POW2(KS) hipLaunchKernelGGL(knn_prefix_pow2_kernel<KS>, dim3(cbl_div_up((long long)m * KS, 256)), dim3(256), 0, st, m, nsample_wide, idx_wide, dist2_wide, \
+                                               idx, dist2, tie_policy, worklist, counter)
+    switch (nsample) {
+        case 1: CBL_PREFIX_POW2(1); break;
+        case 2: CBL_PREFIX_POW2(2); break;
+        case 4: CBL_PREFIX_POW2(4); break;
+        case 8: CBL_PREFIX_POW2(8); break;
+        case 16: CBL_PREFIX_POW2(16); break;
+        case 32: CBL_PREFIX_POW2(32); break;
+        default:
+            hipLaunchKernelGGL(knn_prefix_kernel, dim3(cbl_div_up(m, 256)), dim3(256), 0, st, m, nsample_wide, nsample, idx_wide, dist2_wide, idx, dist2, tie_policy, worklist, counter);
+    }
+#undef CBL_PREFIX_POW2
+    return cbl_status();
+}
+
+// the wide search and one narrower search derived from it in ONE call: the derivation reuses the grid search's scratch (its worklist array
+// and a counter the build zeroed), so no counter reset of its own is launched
+CBL_EXPORT int cbl_knnquery_nested(int b, int n, int m, int nsample_wide, int tie_policy_wide, int nsample, int tie_policy,
+                                   const float* xyz, const float* new_xyz, const int* offset, const int* new_offset,
+                                   int* idx_wide, float* dist2_wide, int* idx, float* dist2, int* cell_order,
+                                   void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (nsample <= 0 || nsample >= nsample_wide || tie_policy < 0 || tie_policy > 1 || tie_policy_wide < 0 || tie_policy_wide > 2 || !idx || !dist2) return CBL_ERR_BAD_ARG;
+    const size_t need = cbl_knn_grid_workspace_bytes(b, n, m, nsample_wide);
+    if (need == 0 || !workspace || workspace_bytes < need) return CBL_ERR_UNSUPPORTED;      // only behind the grid path (its scratch is what is reused)
+    int rc = knnquery_impl(b, n, m, nsample_wide, xyz, new_xyz, offset, new_offset, idx_wide, dist2_wide, workspace, workspace_bytes, tie_policy_wide, stream, cell_order);
+    if (rc || m == 0) return rc;
+    hipStream_t st = cbl_stream(stream);
+    int *worklist, *counter;
+    cbl_knn_grid_scratch(workspace, b, n, m, &worklist, &counter);
+    rc = launch_prefix(m, nsample_wide, nsample, idx_wide, dist2_wide, idx, dist2, tie_policy, worklist, counter, st);
+    if (rc) return rc;
+    return cbl_knn_exact_worklist(b, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, worklist, counter, m, st);
+}
+
 CBL_EXPORT size_t cbl_knnquery_prefix_workspace_bytes(int m) { return m < 0 ? 0 : sizeof(int) * ((size_t)m + 64); }
 
 CBL_EXPORT int cbl_knnquery_prefix(int b, int n, int m, int nsample_wide, int nsample, const float* xyz, const float* new_xyz,
@@ -130,19 +171,7 @@ CBL_EXPORT int cbl_knnquery_prefix(int b, int n, int m, int nsample_wide, int ns
     int* counter = reinterpret_cast<int*>(workspace);
     int* worklist = counter + 64;
     (void)hipMemsetAsync(counter, 0, sizeof(int), st);
-#define CBL_PREFIX_POW2(KS) hipLaunchKernelGGL(knn_prefix_pow2_kernel<KS>, dim3(cbl_div_up((long long)m * KS, 256)), dim3(256), 0, st, m, nsample_wide, idx_wide, dist2_wide, \
-                                               idx, dist2, tie_policy, worklist, counter)
-    switch (nsample) {
-        case 1: CBL_PREFIX_POW2(1); break;
-        case 2: CBL_PREFIX_POW2(2); break;
-        case 4: CBL_PREFIX_POW2(4); break;
-        case 8: CBL_PREFIX_POW2(8); break;
-        case 16: CBL_PREFIX_POW2(16); break;
-        case 32: CBL_PREFIX_POW2(32); break;
-        default:
-            hipLaunchKernelGGL(knn_prefix_kernel, dim3(cbl_div_up(m, 256)), dim3(256), 0, st, m, nsample_wide, nsample, idx_wide, dist2_wide, idx, dist2, tie_policy, worklist, counter);
-    }
-#undef CBL_PREFIX_POW2
+    { const int rcp = launch_prefix(m, nsample_wide, nsample, idx_wide, dist2_wide, idx, dist2, tie_policy, worklist, counter, st); if (rcp) return rcp; }
     const int rc = cbl_status();
     if (rc) return rc;
     return cbl_knn_exact_worklist(b, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, worklist, counter, m, st);

@@ -772,6 +772,14 @@ size_t cbl_knn_grid_workspace_bytes(int b, int n, int m, int nsample)
     return carve(nullptr, b, n, m).bytes;
 }
 
+// scratch of a finished grid search for a follow-up pass over its results (cbl_knnquery_nested): the worklist array and a counter that
+// grid_init_kernel zeroed and the search did not touch
+void cbl_knn_grid_scratch(void* ws, int b, int n, int m, int** worklist, int** zero_counter)
+{
+    Workspace w = carve(ws, b, n, m);
+    *worklist = w.worklist; *zero_counter = w.counters + 1;
+}
+
 int cbl_knn_grid_launch(int b, int n, int m, int nsample, const float* xyz, const float* new_xyz, const int* offset,
                         const int* new_offset, int* idx, float* dist2, void* ws, size_t ws_bytes, int set_exact, hipStream_t st, int* order_out)
 {

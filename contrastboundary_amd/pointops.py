@@ -339,6 +339,13 @@ def knnquery_raw(nsample, xyz, new_xyz, offset, new_offset, algo="auto"):
             if wide is None:
                 h = cache.hints.get(cache._geo(xyz, new_xyz))
                 if h is not None and h[0] > nsample and h[0] <= 64:
+                    both = _knnquery_nested(h[0], h[1], nsample, algo, xyz, new_xyz, offset, new_offset)
+                    if both is not None:                             # wide search + derivation in one C call
+                        wi, wd, idx, dist2 = both
+                        cache.insert(h[0], h[1], tensors, wi, wd)
+                        cache.insert(nsample, algo, tensors, idx, dist2)
+                        cache.derived += 1
+                        return idx, dist2
                     wi, wd = _knnquery_uncached(h[0], xyz, new_xyz, offset, new_offset, h[1])
                     cache.insert(h[0], h[1], tensors, wi, wd)
                     wide = (h[0], wi, wd)
@@ -370,6 +377,36 @@ def knn_prefix(nsample, nsample_wide, idx_wide, dist2_wide, xyz, new_xyz, offset
                                      _c_int(1 if algo == "set" else 0), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(xyz)),
                "cbl_knnquery_prefix")
     return idx, dist2
+
+
+def _knnquery_nested(nsample_wide, algo_wide, nsample, algo, xyz, new_xyz, offset, new_offset):
+    """cbl_knnquery_nested: -> (idx_wide, dist2_wide, idx, dist2), or None where the wide search would not take the grid path"""
+    if algo_wide not in ("auto", "set", "anytie", "grid") or algo not in ("auto", "set"):
+        return None
+    n, m, b = xyz.shape[0], new_xyz.shape[0], offset.shape[0]
+    L = _lib.lib()
+    need = L.cbl_knnquery_workspace_bytes(_c_int(b), _c_int(n), _c_int(m), _c_int(nsample_wide))
+    if need == 0 or nsample_wide > 64:
+        return None
+    dev = xyz.device
+    wi = torch.empty((m, nsample_wide), dtype=torch.int32, device=dev); wd = torch.empty((m, nsample_wide), dtype=torch.float32, device=dev)
+    idx = torch.empty((m, nsample), dtype=torch.int32, device=dev); dist2 = torch.empty((m, nsample), dtype=torch.float32, device=dev)
+    ws = _workspace(need, dev)
+    cur = torch.cuda.current_stream(dev)
+    self_search = new_xyz is xyz or (new_xyz.data_ptr() == xyz.data_ptr() and m == n)
+    order = torch.empty(n, dtype=torch.int32, device=dev) if (self_search and _order_wanted(xyz, cur.cuda_stream)) else None
+    pw = 1 if algo_wide == "set" else 2 if algo_wide == "anytie" else 0
+    rc = L.cbl_knnquery_nested(_c_int(b), _c_int(n), _c_int(m), _c_int(nsample_wide), _c_int(pw), _c_int(nsample), _c_int(1 if algo == "set" else 0),
+                               _lib.ptr(xyz), _lib.ptr(new_xyz), _lib.ptr(offset), _lib.ptr(new_offset), _lib.ptr(wi), _lib.ptr(wd), _lib.ptr(idx),
+                               _lib.ptr(dist2), _lib.ptr(order), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(xyz))
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, "cbl_knnquery_nested")
+    if order is not None:
+        _order_register(xyz, order, cur)
+    if self_search and n >= ORDER_MIN_POINTS and use_spatial_order:
+        _order_alias(wi, xyz); _order_alias(idx, xyz)
+    return wi, wd, idx, dist2
 
 
 def _knnquery_uncached(nsample, xyz, new_xyz, offset, new_offset, algo):
