@@ -84,11 +84,12 @@ __device__ __forceinline__ void heap_replace_root_par(float& hd, int& hi, int la
     const int il = __builtin_amdgcn_ds_bpermute(al, hi), ir = __builtin_amdgcn_ds_bpermute(ar, hi);
     const float up = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(hd), __float_as_int(hd), 0x130, 0xf, 0xf, false));   // slot lane+1
     const float dn = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(hd), __float_as_int(hd), 0x138, 0xf, 0xf, false));   // slot lane-1
-    // branch-free: plain '&' / '|' on lane masks (two compares, the rest is scalar mask arithmetic)
-    const bool odd = lane & 1, in_heap = lane < len, has_next = lane + 1 < len;
-    const bool next_bigger = up > hd, bigger_than_prev = hd > dn;
-    const bool isbig = in_heap & ((odd & !(has_next & next_bigger)) | (!odd & bigger_than_prev));
-    const unsigned long long big = __ballot(isbig);
+    // "is the bigger of its sibling pair" for all slots at once: two vector compares, the rest on 64-bit lane masks on the scalar unit
+    // (as bool expressions the lane-constant terms — odd, in heap, has a right sibling — were carried as 0/1 vectors: ~8 extra VALU per insert)
+    const unsigned long long m_in = len >= 64 ? ~0ull : ((1ull << len) - 1ull);    // slot < len
+    const unsigned long long m_odd = 0xAAAAAAAAAAAAAAAAull;
+    const unsigned long long nb = __ballot(up > hd), bp = __ballot(hd > dn);        // right sibling bigger / bigger than the left sibling
+    const unsigned long long big = m_in & ((m_odd & ~((m_in >> 1) & nb)) | (~m_odd & bp));
     const bool onpath = (big & anc) == anc;                  // root: empty chain
     const bool right = (r < len) & (kr > kl);                // right child only when strictly larger (:27)
     const float bk = right ? kr : kl;
