@@ -43,26 +43,52 @@ __global__ __launch_bounds__(256) void kpconv_fwd_kernel(int n, int n0, int K, i
     const float kx = kp_ok ? kpts[3 * kp_id] : 0.f, ky = kp_ok ? kpts[3 * kp_id + 1] : 0.f, kz = kp_ok ? kpts[3 * kp_id + 2] : 0.f;
 
     const float inv_extent = 1.0f / extent;
-    // one point per wave and trip; with `order` the points are taken in that sequence, dealt to the XCDs in contiguous eighths (cbl_common.h)
-    for (unsigned v = blockIdx.x; v < 8 * cbl_xcd_per(nwg); v += gridDim.x) {
+    // one point per wave and trip; with `order` the points are taken in that sequence, dealt to the XCDs in contiguous eighths (cbl_common.h).
+    // The trip is software-pipelined over its three dependent round trips (processing slot -> point id -> neighbour ids -> neighbour
+    // coordinates): while point i is gathered and multiplied, the ids of point i+1 and the point id of i+2 are in flight, and the
+    // coordinates of i+1 are requested at the end of the trip — the kernel was bound by those round trips (5 points per wave in a row).
+    const unsigned vend = 8 * cbl_xcd_per(nwg), vstep = gridDim.x;
+    auto point_at = [&](unsigned v) -> int {
+        if (v >= vend) return -1;
         const unsigned t = (order ? cbl_xcd_slot(v, nwg) : v) * 4 + wv;
-        if (t >= (unsigned)n) continue;
-        const int p = order ? order[t] : (int)t;
-        const float qx = q[3 * p], qy = q[3 * p + 1], qz = q[3 * p + 2];
+        return t < (unsigned)n ? (order ? order[t] : (int)t) : -1;
+    };
+    struct Geo { int id; float sx, sy, sz, qx, qy, qz; };
+    auto fetch_ids = [&](int pt, Geo& g) {                          // first round trip of a point: its query coordinates and neighbour ids
+        g.id = (lane < K) ? idx[(size_t)pt * K + lane] : n0;
+        g.qx = q[3 * pt]; g.qy = q[3 * pt + 1]; g.qz = q[3 * pt + 2];
+    };
+    auto fetch_xyz = [&](Geo& g) {                                  // second: the neighbours' coordinates; the shadow point sits at (1e6,1e6,1e6)  (:681-684)
+        const bool real = g.id >= 0 && g.id < n0;
+        g.sx = real ? s[3 * g.id] : 1e6f; g.sy = real ? s[3 * g.id + 1] : 1e6f; g.sz = real ? s[3 * g.id + 2] : 1e6f;
+    };
+    int p0 = point_at(blockIdx.x), p1 = point_at(blockIdx.x + vstep);
+    Geo cur = {n0, 1e6f, 1e6f, 1e6f, 0.f, 0.f, 0.f};
+    if (p0 >= 0) { fetch_ids(p0, cur); fetch_xyz(cur); }
+    for (unsigned v = blockIdx.x; v < vend; v += vstep) {
+        const int p2 = point_at(v + 2 * vstep);                     // point id two trips ahead
+        Geo nxt = {n0, 1e6f, 1e6f, 1e6f, 0.f, 0.f, 0.f};
+        if (p1 >= 0) fetch_ids(p1, nxt);                            // neighbour ids of the next point
+        const int p = p0;
+        const Geo g = cur;
+        auto advance = [&]() { if (p1 >= 0) fetch_xyz(nxt); cur = nxt; p0 = p1; p1 = p2; };
+        if (p < 0) { advance(); continue; }
+        const float qx = g.qx, qy = g.qy, qz = g.qz;
         for (int c0 = 0; c0 < C; c0 += 64) {
             f32x4 acc[4];
 #pragma unroll
             for (int t = 0; t < 4; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int cb = c0 + 4 * kp_id;                                                   // first of this lane's 4 channels
             for (int k0 = 0; k0 < K; k0 += 64) {
-                // one coalesced load of up to 64 neighbour ids, then their coordinates: two dependent round trips per point
-                // instead of two per group of 4 neighbours
-                const int my_nb = k0 + lane;
-                const int my_id = (my_nb < K) ? idx[(size_t)p * K + my_nb] : n0;
-                const bool my_real = my_id >= 0 && my_id < n0;
-                // neighbour relative to the query; the shadow point sits at (1e6,1e6,1e6)  (:681-684)
-                const float mrx = (my_real ? s[3 * my_id] : 1e6f) - qx, mry = (my_real ? s[3 * my_id + 1] : 1e6f) - qy,
-                            mrz = (my_real ? s[3 * my_id + 2] : 1e6f) - qz;
+                // up to 64 neighbour ids and their coordinates per chunk: prefetched for the first chunk, loaded here for K > 64
+                int my_id; float mrx, mry, mrz;
+                if (k0 == 0) { my_id = g.id; mrx = g.sx - qx; mry = g.sy - qy; mrz = g.sz - qz; }
+                else {
+                    const int my_nb = k0 + lane;
+                    my_id = (my_nb < K) ? idx[(size_t)p * K + my_nb] : n0;
+                    const bool my_real = my_id >= 0 && my_id < n0;
+                    mrx = (my_real ? s[3 * my_id] : 1e6f) - qx; mry = (my_real ? s[3 * my_id + 1] : 1e6f) - qy; mrz = (my_real ? s[3 * my_id + 2] : 1e6f) - qz;
+                }
                 const int kend = min(64, K - k0);
                 for (int kc = 0; kc < kend; kc += 16) {
                     // feature rows of 4 groups of 4 neighbours are requested before any of them is consumed
@@ -129,6 +155,7 @@ __global__ __launch_bounds__(256) void kpconv_fwd_kernel(int n, int n0, int K, i
                 }
             }
         }
+        advance();                                                  // coordinates of the next point's neighbours: their ids have arrived by now
     }
 }
 
@@ -363,8 +390,19 @@ static int kpconv_forward_impl(int n, int n0, int K, int C, int KP, const float*
     if (n == 0) return CBL_OK;
     if (!query_points || !support_points || !neighbors_indices || !features || !kernel_points || !kernel_weights || !out) return CBL_ERR_BAD_ARG;
     hipStream_t st = cbl_stream(stream);
-    const dim3 grid(cbl_round_up8(persistent_grid(n))), block(256);
-    if (C % 4 == 0 && cbl_host_aligned16(features) && cbl_host_aligned16(out))
+    // persistent waves: exactly as many workgroups as are resident at once (the kernel's registers allow 5 waves per SIMD, not 8: with the
+    // fixed 2048-workgroup grid 768 of them ran as a second, mostly idle round), each walking its share of the points
+    static int resident[2] = {0, 0};
+    const bool vec = C % 4 == 0 && cbl_host_aligned16(features) && cbl_host_aligned16(out);
+    if (!resident[vec]) {
+        int per_cu = 0, dev = 0, cus = 0;
+        const void* fn = vec ? reinterpret_cast<const void*>(&kpconv_fwd_kernel<true>) : reinterpret_cast<const void*>(&kpconv_fwd_kernel<false>);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        resident[vec] = per_cu * cus;
+    }
+    const dim3 grid(cbl_round_up8(min(persistent_grid(n), (unsigned)resident[vec]))), block(256);
+    if (vec)
         hipLaunchKernelGGL(kpconv_fwd_kernel<true>, grid, block, 0, st, n, n0, K, C, KP, query_points, support_points, neighbors_indices, features, kernel_points, kernel_weights, extent, influence, closest, order, out);
     else
         hipLaunchKernelGGL(kpconv_fwd_kernel<false>, grid, block, 0, st, n, n0, K, C, KP, query_points, support_points, neighbors_indices, features, kernel_points, kernel_weights, extent, influence, closest, order, out);
