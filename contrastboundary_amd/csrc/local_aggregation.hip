@@ -378,6 +378,20 @@ __global__ __launch_bounds__(256) void ind_closest_pool_kernel(int n1, int n2, i
 }
 __global__ void fill_u32_kernel(int n, unsigned v, unsigned* __restrict__ p) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
 
+// workgroups (256 lanes) of `kernel` that are resident on the device at once: persistent kernels launch no more than that — a fixed
+// 2048-workgroup grid leaves a second, partly empty round wherever the kernel's registers allow fewer than 8 waves per SIMD
+template <class F>
+inline unsigned resident_workgroups(F kernel, int& cache)
+{
+    if (!cache) {
+        int per_cu = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kernel), 256, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cache = per_cu * cus;
+    }
+    return (unsigned)cache;
+}
+
 inline unsigned persistent_grid(int n) { const long long waves = n; long long blocks = (waves + 3) / 4; if (blocks > 256 * 8) blocks = 256 * 8; if (blocks < 1) blocks = 1; return (unsigned)blocks; }
 
 }  // namespace
@@ -394,14 +408,8 @@ static int kpconv_forward_impl(int n, int n0, int K, int C, int KP, const float*
     // fixed 2048-workgroup grid 768 of them ran as a second, mostly idle round), each walking its share of the points
     static int resident[2] = {0, 0};
     const bool vec = C % 4 == 0 && cbl_host_aligned16(features) && cbl_host_aligned16(out);
-    if (!resident[vec]) {
-        int per_cu = 0, dev = 0, cus = 0;
-        const void* fn = vec ? reinterpret_cast<const void*>(&kpconv_fwd_kernel<true>) : reinterpret_cast<const void*>(&kpconv_fwd_kernel<false>);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        resident[vec] = per_cu * cus;
-    }
-    const dim3 grid(cbl_round_up8(min(persistent_grid(n), (unsigned)resident[vec]))), block(256);
+    const unsigned res = vec ? resident_workgroups(&kpconv_fwd_kernel<true>, resident[1]) : resident_workgroups(&kpconv_fwd_kernel<false>, resident[0]);
+    const dim3 grid(cbl_round_up8(min(persistent_grid(n), res))), block(256);
     if (vec)
         hipLaunchKernelGGL(kpconv_fwd_kernel<true>, grid, block, 0, st, n, n0, K, C, KP, query_points, support_points, neighbors_indices, features, kernel_points, kernel_weights, extent, influence, closest, order, out);
     else
@@ -432,7 +440,8 @@ CBL_EXPORT int cbl_kpconv_backward(int n, int n0, int K, int C, int KP, const fl
     if (n < 0 || n0 < 0 || K <= 0 || K > KPB_MAXK || C <= 0 || KP <= 0 || KP > KPB_MAXKP || !(extent > 0.f) || influence < 0 || influence > 1) return CBL_ERR_BAD_ARG;
     if (n == 0) return CBL_OK;
     if (!query_points || !support_points || !neighbors_indices || !features || !kernel_points || !kernel_weights || !grad_out) return CBL_ERR_BAD_ARG;
-    hipLaunchKernelGGL(kpconv_bwd_kernel, dim3(persistent_grid(n)), dim3(256), 0, cbl_stream(stream), n, n0, K, C, KP, query_points, support_points, neighbors_indices,
+    static int res_bwd = 0;
+    hipLaunchKernelGGL(kpconv_bwd_kernel, dim3(min(persistent_grid(n), resident_workgroups(&kpconv_bwd_kernel, res_bwd))), dim3(256), 0, cbl_stream(stream), n, n0, K, C, KP, query_points, support_points, neighbors_indices,
                        features, kernel_points, kernel_weights, extent, influence, closest, grad_out, grad_features, grad_kernel_weights);
     return cbl_status();
 }
@@ -459,9 +468,11 @@ CBL_EXPORT int cbl_adaptive_weight_forward(int n, int n0, int K, int C, const fl
                            query_points, support_points, neighbors_indices, reinterpret_cast<const float4*>(features), radius,
                            reinterpret_cast<const float4*>(fc_weight), reinterpret_cast<const float4*>(fc_bias), padding_num, reduction_mean,
                            reinterpret_cast<float4*>(out));
-    else
-        hipLaunchKernelGGL(adaptive_weight_kernel<false>, dim3(persistent_grid(n)), dim3(256), 0, cbl_stream(stream), n, n0, K, C, query_points, support_points,
+    else {
+        static int res_aw = 0;
+        hipLaunchKernelGGL(adaptive_weight_kernel<false>, dim3(min(persistent_grid(n), resident_workgroups(&adaptive_weight_kernel<false>, res_aw))), dim3(256), 0, cbl_stream(stream), n, n0, K, C, query_points, support_points,
                            neighbors_indices, features, radius, fc_weight, fc_bias, padding_num, reduction_mean, out, nullptr, nullptr, nullptr, nullptr);
+    }
     return cbl_status();
 }
 
@@ -472,7 +483,8 @@ CBL_EXPORT int cbl_adaptive_weight_backward(int n, int n0, int K, int C, const f
     if (n < 0 || n0 < 0 || K <= 0 || C <= 0 || !(radius > 0.f)) return CBL_ERR_BAD_ARG;
     if (n == 0) return CBL_OK;
     if (!query_points || !support_points || !neighbors_indices || !features || !fc_weight || !fc_bias || !grad_out || (reduction_mean && !padding_num)) return CBL_ERR_BAD_ARG;
-    hipLaunchKernelGGL(adaptive_weight_kernel<true>, dim3(persistent_grid(n)), dim3(256), 0, cbl_stream(stream), n, n0, K, C, query_points, support_points,
+    static int res_awb = 0;
+    hipLaunchKernelGGL(adaptive_weight_kernel<true>, dim3(min(persistent_grid(n), resident_workgroups(&adaptive_weight_kernel<true>, res_awb))), dim3(256), 0, cbl_stream(stream), n, n0, K, C, query_points, support_points,
                        neighbors_indices, features, radius, fc_weight, fc_bias, padding_num, reduction_mean, nullptr, grad_out, grad_features, grad_fc_weight, grad_fc_bias);
     return cbl_status();
 }
