@@ -25,7 +25,7 @@ class Scene:
         """host arrays: xyz, feat, labels, offset, kernel_points (KP,3), kernel_weights (KP,c), latent (n,CBL_DIM)"""
         import numpy as np
         from . import synthetic as S
-        xyz, labels = S.s_room(n, seed)
+        xyz, labels = S.s_room(n, seed, scale=1.0 if n <= 100000 else float(np.sqrt(n / 40000.0)))     # bigger scenes: a bigger room, same density
         rng = np.random.default_rng(seed + 1000)
         feat = rng.normal(size=(n, c)).astype(np.float32)
         off = S.offsets(n, b, seed)

@@ -37,6 +37,8 @@ def s_room(n, seed=0, scale=1.0, voxel=0.04, num_classes=13):
         lo = rng.uniform(room_lo, room_hi - size)
         boxes.append((lo, lo + size))
     areas = np.array([2 * ((h - l)[0] * (h - l)[1] + (h - l)[0] * (h - l)[2] + (h - l)[1] * (h - l)[2]) for l, h in boxes])
+    if n > 1.2 * areas.sum() / (voxel * voxel):                     # more points than the surfaces have voxels: fail now, not after 8 doublings
+        raise ValueError(f"s_room: {n} points do not fit a room of scale {scale} at voxel {voxel}; raise `scale` (~sqrt(n / 40000))")
     out_p, out_l = [], []
     want = int(n * 2.2) + 1000
     for trial in range(8):
