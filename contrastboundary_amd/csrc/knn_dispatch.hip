@@ -70,7 +70,8 @@ CBL_EXPORT int cbl_knnquery_ordered(int b, int n, int m, int nsample, const floa
 // certification the grid kernels apply to their own lists.  One search instead of two for networks that look at one geometry with
 // several neighbourhood sizes (the blocks' K = 8 / 16 and the CBL head's K = 36 at a stage).
 int cbl_knn_exact_worklist(int b, int m, int K, const float* xyz, const float* new_xyz, const int* offset, const int* new_offset,
-                           int* idx, float* dist2, const int* worklist, const int* worklist_count, int max_work, hipStream_t st);   // knn_exact.hip
+                           int* idx, float* dist2, const int* worklist, const int* worklist_count, int max_work, hipStream_t st,
+                           const void* grids, const int* cell_start, const void* sorted);   // knn_exact.hip
 
 namespace {
 __global__ __launch_bounds__(256) void knn_prefix_kernel(int m, int kb, int ks, const int* __restrict__ idx_big, const float* __restrict__ d2_big,
@@ -115,7 +116,8 @@ __global__ __launch_bounds__(256) void knn_prefix_pow2_kernel(int m, int kb, con
 }
 }  // namespace
 
-void cbl_knn_grid_scratch(void* ws, int b, int n, int m, int** worklist, int** zero_counter);      // knn_grid.hip
+void cbl_knn_grid_scratch(void* ws, int b, int n, int m, int** worklist, int** zero_counter, const void** grids, const int** cell_start,
+                          const void** sorted);      // knn_grid.hip
 
 static int launch_prefix(int m, int nsample_wide, int nsample, const int* idx_wide, const float* dist2_wide, int* idx, float* dist2, int tie_policy,
                          int* worklist, int* counter, hipStream_t st)
@@ -149,11 +151,11 @@ CBL_EXPORT int cbl_knnquery_nested(int b, int n, int m, int nsample_wide, int ti
     int rc = knnquery_impl(b, n, m, nsample_wide, xyz, new_xyz, offset, new_offset, idx_wide, dist2_wide, workspace, workspace_bytes, tie_policy_wide, stream, cell_order);
     if (rc || m == 0) return rc;
     hipStream_t st = cbl_stream(stream);
-    int *worklist, *counter;
-    cbl_knn_grid_scratch(workspace, b, n, m, &worklist, &counter);
+    int *worklist, *counter; const void *grids, *sorted; const int* cell_start;
+    cbl_knn_grid_scratch(workspace, b, n, m, &worklist, &counter, &grids, &cell_start, &sorted);
     rc = launch_prefix(m, nsample_wide, nsample, idx_wide, dist2_wide, idx, dist2, tie_policy, worklist, counter, st);
     if (rc) return rc;
-    return cbl_knn_exact_worklist(b, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, worklist, counter, m, st);
+    return cbl_knn_exact_worklist(b, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, worklist, counter, m, st, grids, cell_start, sorted);
 }
 
 CBL_EXPORT size_t cbl_knnquery_prefix_workspace_bytes(int m) { return m < 0 ? 0 : sizeof(int) * ((size_t)m + 64); }
@@ -174,5 +176,5 @@ CBL_EXPORT int cbl_knnquery_prefix(int b, int n, int m, int nsample_wide, int ns
     { const int rcp = launch_prefix(m, nsample_wide, nsample, idx_wide, dist2_wide, idx, dist2, tie_policy, worklist, counter, st); if (rcp) return rcp; }
     const int rc = cbl_status();
     if (rc) return rc;
-    return cbl_knn_exact_worklist(b, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, worklist, counter, m, st);
+    return cbl_knn_exact_worklist(b, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, worklist, counter, m, st, nullptr, nullptr, nullptr);
 }

@@ -13,6 +13,7 @@
 // CPU statement of the same.  The same kernel replays the queries the grid kernel could not certify
 // (worklist mode): m waves spread over the chip instead of one lane scanning a whole cloud.
 #include "cbl_common.h"
+#include "grid_core.h"
 #include <type_traits>
 
 namespace {
@@ -202,13 +203,22 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void knn_exact_wave_kernel(
 // Identical heap operations as the straight scan, i.e. identical ties; the 40960-support scan no longer sits on one
 // wave's memory latency.  The heap insert itself is done without a walk (heap_replace_root_par below).
 constexpr int RP_WAVES = 16, RP_T0 = 1024, RP_LIST = 512, RP_MAX_WORK = 1024, RP_GRID = 128;
+// Large clouds (n_c > RP_BIG, grid of the search available): the direct filter B stops at support RP_TS.  The root at every later turn is
+// at most B* = the K-th smallest distance among the first RP_TS supports — a TIGHT bound (the ball around the query holds ~K n_c / RP_TS
+// supports), so the later supports that can matter are enumerated from the few grid cells the ball touches instead of scanning the
+// cloud (the scan made a replay O(n_c): 0.3 ms per tied query at a million points), put into index order by a rank sort and fed last.
+constexpr int RP_TS = 32768, RP_BIG = 65536, RP_GLIST = 2048, RP_MAX_ROWS = 4096;
 
 __global__ __launch_bounds__(64 * RP_WAVES) void knn_replay_kernel(
     int b, int K, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
     const int* __restrict__ offset, const int* __restrict__ new_offset,
     int* __restrict__ idx, float* __restrict__ dist2,
-    const int* __restrict__ worklist, const int* __restrict__ worklist_count)
+    const int* __restrict__ worklist, const int* __restrict__ worklist_count,
+    const CblGrid* __restrict__ grids, const int* __restrict__ cell_start, const float4* __restrict__ sorted)
 {
+    __shared__ float g_d[2][RP_GLIST];
+    __shared__ int g_i[2][RP_GLIST];
+    __shared__ int g_count, g_over;
     __shared__ float dA[RP_T0];
     __shared__ float cand_d[RP_WAVES][RP_LIST];
     __shared__ int cand_i[RP_WAVES][RP_LIST];
@@ -231,6 +241,8 @@ __global__ __launch_bounds__(64 * RP_WAVES) void knn_replay_kernel(
     const int start = (c == 0) ? 0 : offset[c - 1], end = offset[c];
     const int n_c = end - start;
     const int t0 = min(n_c, RP_T0);
+    const bool big = grids != nullptr && n_c > RP_BIG;             // workgroup-uniform
+    const int t_star = big ? RP_TS : n_c;                          // the direct filter covers supports [t0, t_star)
     const float qx = new_xyz[3 * q + 0], qy = new_xyz[3 * q + 1], qz = new_xyz[3 * q + 2];
 
     {   // distances of the first t0 supports, one per lane
@@ -238,7 +250,7 @@ __global__ __launch_bounds__(64 * RP_WAVES) void knn_replay_kernel(
         const float d = (t0 > 0) ? cbl_dist2(qx, qy, qz, xyz[3 * i + 0], xyz[3 * i + 1], xyz[3 * i + 2]) : INFINITY;
         dA[tid] = (tid < t0) ? d : INFINITY;
         if (tid < RP_WAVES) cand_n[tid] = 0;
-        if (tid == 0) overflow_s = 0;
+        if (tid == 0) { overflow_s = 0; g_count = 0; g_over = 0; }
     }
     __syncthreads();
 
@@ -278,9 +290,9 @@ __global__ __launch_bounds__(64 * RP_WAVES) void knn_replay_kernel(
         }
         const float B = __uint_as_float(lo);
         // B (waves 1..15, while wave 0 is still in A): filter a contiguous share of [t0, n_c) against the bound, keeping index order
-        const int rem = n_c - t0;
+        const int rem = t_star - t0;
         const int per = ((rem + (RP_WAVES - 1) * 64 - 1) / ((RP_WAVES - 1) * 64)) * 64;
-        const int lo_i = start + t0 + (wave - 1) * per, hi_i = min(end, lo_i + per);
+        const int lo_i = start + t0 + (wave - 1) * per, hi_i = min(start + t_star, lo_i + per);
         int filled = 0;
         constexpr int U = 8;
         for (int base = lo_i; base < hi_i; base += 64 * U) {
@@ -308,10 +320,9 @@ __global__ __launch_bounds__(64 * RP_WAVES) void knn_replay_kernel(
     }
     __syncthreads();
 
-    if (wave != 0) continue;
-    if (n_c > t0) {
+    // C: the survivors of the direct filter, wave list after wave list = ascending support index (wave 0)
+    auto feed_lists = [&]() {
         if (!overflow_s) {
-            // C: the survivors, wave list after wave list = ascending support index
             for (int w = 1; w < RP_WAVES; w++) {
                 const int cn = cand_n[w];
                 for (int base = 0; base < cn; base += 64) {
@@ -321,14 +332,111 @@ __global__ __launch_bounds__(64 * RP_WAVES) void knn_replay_kernel(
             }
         } else {
             // a list overflowed (adversarial data, e.g. thousands of supports closer than the first 1024): plain ordered scan
-            for (int base = start + t0; base < end; base += 64) {
+            for (int base = start + t0; base < start + t_star; base += 64) {
                 const int i = base + lane;
                 const int ic = min(i, end - 1);
                 const float d = cbl_dist2(qx, qy, qz, xyz[3 * ic + 0], xyz[3 * ic + 1], xyz[3 * ic + 2]);
-                feed((i < end) ? d : INFINITY, i);
+                feed((i < start + t_star) ? d : INFINITY, i);
+            }
+        }
+    };
+    if (!big) {
+        if (wave == 0 && n_c > t0) feed_lists();
+    } else {
+        if (wave == 0) feed_lists();                                // supports [t0, RP_TS)
+        else {
+            // B* = K-th smallest distance among dA and the survivors (everything else of the first RP_TS supports is >= B): every wave for
+            // itself, values in registers; a subset (more than 2048 survivors) still gives a valid, looser bound
+            constexpr int RV = RP_T0 / 64 + 32;
+            unsigned v[RV];
+#pragma unroll
+            for (int j = 0; j < RP_T0 / 64; j++) v[j] = __float_as_uint(dA[lane + 64 * j]);
+            {
+                int w = 1, base = 0;
+#pragma unroll
+                for (int j = RP_T0 / 64; j < RV; j++) {
+                    while (w < RP_WAVES && base >= cand_n[w]) { w++; base = 0; }      // wave-uniform
+                    unsigned val = 0x7f800000u;
+                    if (w < RP_WAVES) { if (base + lane < cand_n[w]) val = __float_as_uint(cand_d[w][base + lane]); base += 64; }
+                    v[j] = val;
+                }
+            }
+            unsigned lo = 0u, hi_b = 0x7f800000u;
+            while (lo < hi_b) {
+                const unsigned mid = lo + ((hi_b - lo) >> 1);
+                int cnt = 0;
+#pragma unroll
+                for (int j = 0; j < RV; j++) cnt += __popcll(__ballot(v[j] <= mid));
+                if (cnt >= K) hi_b = mid; else lo = mid + 1;
+            }
+            const float Bs = __uint_as_float(lo);
+            // the supports of the ball sqrt(B*) with index >= RP_TS, from the grid rows the ball touches (round-robin over waves 1..15)
+            const CblGrid g = grids[c];
+            const float uqx = cbl_u(qx, g.ox, g.inv_cs), uqy = cbl_u(qy, g.oy, g.inv_cs), uqz = cbl_u(qz, g.oz, g.inv_cs);
+            const int cx = cbl_cell_coord(uqx, g.nx), cy = cbl_cell_coord(uqy, g.ny), cz = cbl_cell_coord(uqz, g.nz);
+            const float ru = sqrtf(Bs) * g.inv_cs;
+            const int rc = (ru < 1.0e6f) ? (int)ceilf(ru) + 1 : 0x3fffffff;       // one cell of margin for the rounding of the cell coordinates
+            const long long side = 2LL * rc + 1;
+            if (!(Bs < INFINITY) || side * side > RP_MAX_ROWS) { if (lane == 0) g_over = 1; }
+            else {
+                const int x0 = max(cx - rc, 0), x1 = min(cx + rc, g.nx - 1);
+                const int nrows = (int)(side * side);
+                for (int ri = wave - 1; ri < nrows; ri += RP_WAVES - 1) {
+                    const int y = cy + ri % (int)side - rc, z = cz + ri / (int)side - rc;
+                    if (y < 0 || y >= g.ny || z < 0 || z >= g.nz) continue;
+                    const int row = g.cell_base + g.nx * (y + g.ny * z);
+                    const int ps = cell_start[row + x0], pe = cell_start[row + x1 + 1];
+                    for (int pb = ps; pb < pe; pb += 64) {
+                        const int pi = min(pb + lane, pe - 1);
+                        const float4 sp = sorted[pi];
+                        const float d = cbl_dist2(qx, qy, qz, sp.x, sp.y, sp.z);        // the same floats as xyz[i]: the same distance bits
+                        const int si = __float_as_int(sp.w);
+                        const bool keep = (pb + lane < pe) && d < Bs && si >= start + RP_TS;
+                        const unsigned long long km = __ballot(keep);
+                        if (km) {
+                            int base = 0;
+                            if (lane == 0) base = atomicAdd(&g_count, __popcll(km));
+                            base = __builtin_amdgcn_readfirstlane(base);
+                            const int pos = base + __popcll(km & ((1ull << lane) - 1ull));
+                            if (keep) {
+                                if (pos < RP_GLIST) { g_d[0][pos] = d; g_i[0][pos] = si; }
+                                else g_over = 1;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // index order: rank of every entry among the entries (indices are distinct), all threads
+        const int gm = min(g_count, RP_GLIST);
+        if (!g_over) {
+            for (int e = tid; e < gm; e += 64 * RP_WAVES) {
+                const int me = g_i[0][e];
+                int rank = 0;
+                for (int j = 0; j < gm; j++) rank += (g_i[0][j] < me) ? 1 : 0;
+                g_d[1][rank] = g_d[0][e]; g_i[1][rank] = me;
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            if (!g_over) {
+                for (int base = 0; base < gm; base += 64) {
+                    const int j = min(base + lane, gm - 1);
+                    feed((base + lane < gm) ? g_d[1][j] : INFINITY, g_i[1][j]);
+                }
+            } else {
+                // the ball is too large for the lists (a bound that did not tighten): plain ordered scan of the rest
+                for (int base = start + RP_TS; base < end; base += 64) {
+                    const int i = base + lane;
+                    const int ic = min(i, end - 1);
+                    const float d = cbl_dist2(qx, qy, qz, xyz[3 * ic + 0], xyz[3 * ic + 1], xyz[3 * ic + 2]);
+                    feed((i < end) ? d : INFINITY, i);
+                }
             }
         }
     }
+    if (wave != 0) continue;
     // heap_sort(), :39-48
     for (int last = K - 1; last > 0; last--) {
         const float d = rl_f(hd, last); const int id = rl_i(hi, last);
@@ -344,13 +452,15 @@ __global__ __launch_bounds__(64 * RP_WAVES) void knn_replay_kernel(
 
 static int launch_knn_exact(int b, int m, int K, const float* xyz, const float* new_xyz, const int* offset,
                             const int* new_offset, int* idx, float* dist2,
-                            const int* worklist, const int* worklist_count, int max_work, hipStream_t st)
+                            const int* worklist, const int* worklist_count, int max_work, hipStream_t st,
+                            const CblGrid* grids = nullptr, const int* cell_start = nullptr, const float4* sorted = nullptr)
 {
     const int nq = worklist ? max_work : m;
     if (nq <= 0) return CBL_OK;
     if (worklist && K <= 64) {
         // one launch: a 1024-lane workgroup per entry for short lists (the normal case: a handful of tied queries), a wave per entry for long ones
-        hipLaunchKernelGGL(knn_replay_kernel, dim3(min(nq, RP_GRID)), dim3(64 * RP_WAVES), 0, st, b, K, xyz, new_xyz, offset, new_offset, idx, dist2, worklist, worklist_count);
+        hipLaunchKernelGGL(knn_replay_kernel, dim3(min(nq, RP_GRID)), dim3(64 * RP_WAVES), 0, st, b, K, xyz, new_xyz, offset, new_offset, idx, dist2, worklist, worklist_count,
+                           grids, cell_start, sorted);
         return cbl_status();
     }
     const unsigned blocks = worklist ? (unsigned)min((long long)cbl_div_up(nq, WAVES_PER_BLOCK), 2048LL) : cbl_div_up(nq, WAVES_PER_BLOCK);
@@ -365,11 +475,14 @@ static int launch_knn_exact(int b, int m, int K, const float* xyz, const float* 
 }
 
 // used by knn_grid.hip for the exact replay of tied queries
+// grids / cell_start / sorted: the search grid over `xyz` if the caller still has it (knn_grid.hip's workspace), else null
 int cbl_knn_exact_worklist(int b, int m, int K, const float* xyz, const float* new_xyz, const int* offset,
                            const int* new_offset, int* idx, float* dist2,
-                           const int* worklist, const int* worklist_count, int max_work, hipStream_t st)
+                           const int* worklist, const int* worklist_count, int max_work, hipStream_t st,
+                           const void* grids, const int* cell_start, const void* sorted)
 {
-    return launch_knn_exact(b, m, K, xyz, new_xyz, offset, new_offset, idx, dist2, worklist, worklist_count, max_work, st);
+    return launch_knn_exact(b, m, K, xyz, new_xyz, offset, new_offset, idx, dist2, worklist, worklist_count, max_work, st,
+                            reinterpret_cast<const CblGrid*>(grids), cell_start, reinterpret_cast<const float4*>(sorted));
 }
 
 CBL_EXPORT int cbl_knnquery_exact(int b, int n, int m, int nsample, const float* xyz, const float* new_xyz,

@@ -19,7 +19,8 @@
 
 int cbl_knn_exact_worklist(int b, int m, int K, const float* xyz, const float* new_xyz, const int* offset,
                            const int* new_offset, int* idx, float* dist2,
-                           const int* worklist, const int* worklist_count, int max_work, hipStream_t st);
+                           const int* worklist, const int* worklist_count, int max_work, hipStream_t st,
+                           const void* grids, const int* cell_start, const void* sorted);
 
 namespace {
 
@@ -774,10 +775,11 @@ size_t cbl_knn_grid_workspace_bytes(int b, int n, int m, int nsample)
 
 // scratch of a finished grid search for a follow-up pass over its results (cbl_knnquery_nested): the worklist array and a counter that
 // grid_init_kernel zeroed and the search did not touch
-void cbl_knn_grid_scratch(void* ws, int b, int n, int m, int** worklist, int** zero_counter)
+void cbl_knn_grid_scratch(void* ws, int b, int n, int m, int** worklist, int** zero_counter, const void** grids, const int** cell_start, const void** sorted)
 {
     Workspace w = carve(ws, b, n, m);
     *worklist = w.worklist; *zero_counter = w.counters + 1;
+    *grids = w.grids; *cell_start = w.cell_start; *sorted = w.sorted;
 }
 
 int cbl_knn_grid_launch(int b, int n, int m, int nsample, const float* xyz, const float* new_xyz, const int* offset,
@@ -802,7 +804,7 @@ int cbl_knn_grid_launch(int b, int n, int m, int nsample, const float* xyz, cons
     if (rc) return rc;
     // exact replay of everything that was not certified (device-side count, no host sync)
     return cbl_knn_exact_worklist(b, m, nsample, xyz, new_xyz, self ? offset : offset, self ? offset : new_offset, idx, dist2,
-                                  w.worklist, w.counters, m, st);
+                                  w.worklist, w.counters, m, st, w.grids, w.cell_start, w.sorted);
 }
 
 // N2 entry: queries (nq,3) with cumulative q_offset (b), supports (ns,3) with cumulative s_offset (b).

@@ -15,7 +15,8 @@
 #include "cbl_common.h"
 
 int cbl_knn_exact_worklist(int b, int m, int K, const float* xyz, const float* new_xyz, const int* offset, const int* new_offset,
-                           int* idx, float* dist2, const int* worklist, const int* worklist_count, int max_work, hipStream_t st);   // knn_exact.hip
+                           int* idx, float* dist2, const int* worklist, const int* worklist_count, int max_work, hipStream_t st,
+                           const void* grids, const int* cell_start, const void* sorted);   // knn_exact.hip
 
 namespace {
 
@@ -219,5 +220,5 @@ int cbl_knn_select_launch(int b, int n, int m, int nsample, const float* xyz, co
                        worklist, counters, set_exact);
     int rc = cbl_status();
     if (rc) return rc;
-    return cbl_knn_exact_worklist(b, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, worklist, counters, m, st);
+    return cbl_knn_exact_worklist(b, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, worklist, counters, m, st, nullptr, nullptr, nullptr);
 }

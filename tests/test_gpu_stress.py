@@ -81,3 +81,36 @@ def test_radius_and_subsampling_at_a_million_points():
         js = nbc[r][real[r]]
         d = np.linalg.norm(xyz[js] - q[r], axis=1)
         assert np.all(d < 0.1 + 1e-6) and np.all(np.diff(d) >= -1e-6)
+
+
+@pytest.mark.parametrize("order", ["shuffled", "sorted"])
+def test_reference_order_replay_in_large_clouds(order):
+    """clouds above 65536 supports: the replay of tied queries takes the supports beyond the first 32768 from the search grid (a tight
+    bound around the query) instead of scanning the cloud; the reference's heap order must come out all the same"""
+    import torch
+    from contrastboundary_amd import pointops
+    from tests import oracle_lib as O
+    rng = np.random.default_rng(11)
+    n_big, n_small, K = 150000, 9000, 16
+    base = rng.uniform(0, 8, (n_big - 400, 3)).astype(np.float32)
+    big = np.concatenate([base, base[rng.choice(len(base), 400, replace=False)]])      # 400 coincident pairs: zero distances, ties inside the lists
+    if order == "sorted":
+        big = big[np.lexsort((big[:, 0], big[:, 1], big[:, 2]))]                        # spatially sorted: long heap histories
+    else:
+        big = big[rng.permutation(n_big)]
+    small = rng.uniform(0, 2, (n_small, 3)).astype(np.float32)
+    xyz = np.concatenate([small, big]); off = np.int32([n_small, n_small + n_big])
+    p = torch.from_numpy(xyz).cuda(); o = torch.from_numpy(off).cuda()
+    idx, d2 = pointops.knnquery_raw(K, p, p, o, o)                                     # reference order
+    torch.cuda.synchronize()
+    idx, d2 = idx.cpu().numpy(), d2.cpu().numpy()
+    tied = np.nonzero((d2[:, 1:] == d2[:, :-1]).any(1))[0]
+    assert (tied >= n_small).sum() >= 300                                              # the tied queries are in the big cloud
+    pick = np.concatenate([tied[tied >= n_small][:60], rng.integers(n_small, n_small + n_big, 20), rng.integers(0, n_small, 10)])
+    q = xyz[pick]
+    # the oracle needs per-cloud query blocks: queries of cloud 0 first
+    order_q = np.argsort(pick >= n_small, kind="stable"); pick, q = pick[order_q], q[order_q]
+    qoff = np.int32([(pick < n_small).sum(), len(pick)])
+    ri, rd = O.knnquery(K, xyz, q, off, qoff)
+    np.testing.assert_array_equal(idx[pick], ri)
+    np.testing.assert_array_equal(d2[pick], rd)
