@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--k", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="all stages in order on one stream")
+    ap.add_argument("--no-graph", action="store_true", help="issue every step eagerly from Python instead of replaying its hipGraph")
     ap.add_argument("--no-nested", action="store_true", help="every neighbour search on its own (no derivation of K=16 from the K=36 search of the same points)")
     ap.add_argument("--side-after", default=None, help="main-stream stage after which the side stream starts (default: start of the step)")
     return ap.parse_args()
@@ -82,11 +83,15 @@ def main():
     sched = hotpath.Schedule(stages, overlap=not args.no_overlap, hints=hints)
     in_order = hotpath.Schedule(stages, overlap=False, hints=hints)
 
+    graph = [None]
+
     def step(events=None):
-        # steps that carry per-stage events (every EVENT_EVERY-th of the timed region) run in order on one stream, so that a stage's
-        # HIP-event time is that stage alone and not its share of two overlapped streams; all other steps use the two-stream schedule
+        # steps that carry per-stage events (every EVENT_EVERY-th of the timed region) are issued eagerly, in order on one stream, so that
+        # a stage's HIP-event time is that stage alone; all other steps replay the step's hipGraph (or, without it, run the schedule eagerly)
         if events is not None:
             in_order.run(state, events)
+        elif graph[0] is not None:
+            graph[0].replay()
         else:
             sched.run(state, None, side_after=args.side_after)
 
@@ -95,12 +100,37 @@ def main():
     while time.perf_counter() - t_settle < 0.5:
         step()
         torch.cuda.synchronize()
+    graph_note = "eager"
+    if not args.no_graph:
+        # the step issues ~25 launches from Python: ~0.25-0.45 ms of host time against ~0.30 ms of device time, i.e. an eagerly issued
+        # step is as fast as the host happens to be.  Captured once (same kernels, same buffers, same schedule), it is replayed with
+        # ~15 us of host time per step.  Any failure to capture leaves the eager schedule in place.
+        try:
+            gstate = {}
+            cap_stream = torch.cuda.Stream()
+            cap_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cap_stream):
+                for _ in range(3):
+                    sched.run(gstate, None, side_after=args.side_after)
+            torch.cuda.current_stream().wait_stream(cap_stream)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                sched.run(gstate, None, side_after=args.side_after)
+            g.replay()
+            torch.cuda.synchronize()
+            graph[0] = g
+            graph_note = "hipGraph replay of the step (torch.cuda.CUDAGraph over the C-ABI launches); steps with per-stage events issued eagerly"
+        except Exception as e:                                      # noqa: BLE001 - any capture problem: stay eager
+            graph[0] = None
+            graph_note = "eager (graph capture failed: %s)" % type(e).__name__
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     D.barrier()
     # per-stage HIP events on every EVENT_EVERY-th step of the timed region only: 12 event records cost ~55 us, 13 % of a step
-    EVENT_EVERY = 5 if args.steps >= 10 else 1
+    EVENT_EVERY = 10 if args.steps >= 40 else 5 if args.steps >= 10 else 1
     ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in stages] if s % EVENT_EVERY == 0 else None
           for s in range(args.steps)]
     torch.cuda.synchronize()
@@ -179,6 +209,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "S3DIS-shaped synthetic scene (S-room), N=%d, K=%d, C=%d, 1 scene per GPU per step; stages: %s"
                        % (n, k, c, " -> ".join(s[0] for s in stages)), "parallelism": "scene-per-GPU replicas x%d (no data-path collective)" % world,
+                       "issue": graph_note,
                        "schedule": (("one search per geometry: the K=%d request runs the K=%d search the CBL head declared for the same points "
                                      "(neighbor_cache hint, dropped at the end of every step) and is derived from it (cbl_knnquery_prefix, tied rows "
                                      "replayed); the later K=%d request is a cache hit; all stages in order on one stream" % (k, hotpath.CBL_NSAMPLE, hotpath.CBL_NSAMPLE))

@@ -34,3 +34,29 @@ def test_schedule_records_stage_events_on_the_stage_stream():
     sched.run(state, ev)
     torch.cuda.synchronize()
     assert all(a.elapsed_time(b) > 0.0 for a, b in ev)
+
+
+def test_step_replays_from_a_hipgraph():
+    """bench.py captures the step (nested searches, autograd backward of the CBL loss included) once and replays it"""
+    from contrastboundary_amd import hotpath
+    sc = hotpath.Scene.synthetic(16384, 32, seed=7)
+    st = hotpath.stages(sc, 16)
+    ref = hotpath.run_once(sc, 16, {})
+    sched = hotpath.Schedule(st, overlap=False, hints=hotpath.search_hints(sc))
+    gstate = {}
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            sched.run(gstate)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        sched.run(gstate)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(gstate["idx"], ref["idx"]) and torch.equal(gstate["grouped"], ref["grouped"]) and torch.equal(gstate["kpconv"], ref["kpconv"])
+    assert abs(float(gstate["cbl_loss"].detach()) - float(ref["cbl_loss"].detach())) <= 1e-5 * abs(float(ref["cbl_loss"].detach()))
+    torch.testing.assert_close(gstate["cbl_grad"], ref["cbl_grad"], rtol=1e-4, atol=1e-7)
