@@ -212,7 +212,9 @@ def main():
                        "issue": graph_note,
                        "schedule": (("one search per geometry: the K=%d request runs the K=%d search the CBL head declared for the same points "
                                      "(neighbor_cache hint, dropped at the end of every step) and is derived from it (cbl_knnquery_prefix, tied rows "
-                                     "replayed); the later K=%d request is a cache hit; all stages in order on one stream" % (k, hotpath.CBL_NSAMPLE, hotpath.CBL_NSAMPLE))
+                                     "replayed); the later K=%d request is a cache hit; %s" % (k, hotpath.CBL_NSAMPLE, hotpath.CBL_NSAMPLE,
+                                        "all stages in order on one stream" if args.no_overlap else
+                                        "the CBL branch (needs the wide result only) on a side stream beside tie replay -> gather -> KPConv; steps with per-stage events in order"))
                                     if hints else "in order on one stream" if args.no_overlap else
                                     "two HIP streams: %s on a side stream, the other stages in order (hotpath.Schedule); the steps that carry "
                                     "per-stage events run in order" % ", ".join(hotpath.SIDE_STAGES))},

@@ -108,44 +108,69 @@ def run_once(scene, k=16, state=None):
 
 
 class Schedule:
-    """The step as bench.py runs it: SIDE_STAGES on a side stream, everything else in order on the current stream.
+    """The step as bench.py runs it.
 
-        sched = Schedule(stage_list);  sched.run(state, events=None)
+        sched = Schedule(stage_list, overlap=True, hints=search_hints(scene));  sched.run(state, events=None)
+
+    * without hints: SIDE_STAGES (the CBL head's own search) on a side stream, everything else in order on the current stream;
+    * with hints (one search per geometry): the first search request runs the WIDE search and derives its own result from it; the CBL
+      branch (cache hit on the wide result -> mining + loss -> backward) only needs the wide result, so with `overlap` it runs on the side
+      stream next to the rest of the main branch (tie replay of the narrow search -> gather -> KPConv): an atomics-bound kernel beside an
+      HBM-bound and a VALU/MFMA-bound one.
 
     events: optional list (one entry per stage) of (start, end) torch.cuda.Event pairs, recorded on the stream the stage runs on."""
 
     def __init__(self, stage_list, overlap=True, hints=()):
         """hints: (xyz, nsample, algo) triples for pointops.neighbor_cache.hint — the widest search each geometry sees during the step.
-        With hints the step runs inside a neighbour cache (dropped at the end of the step: nothing is carried from step to step) and the
-        narrower searches are derived from the wide one; the side stream then has nothing left to overlap."""
+        With hints the step runs inside a neighbour cache that is dropped at the end of the step: nothing is carried from step to step."""
         self.stage_list = stage_list
         self.hints = tuple(hints)
-        overlap = overlap and not self.hints
         self.overlap = overlap
         self.side = torch.cuda.Stream() if overlap else None
         self.joined = torch.cuda.Event() if overlap else None
 
     def run(self, state, events=None, side_after=None):
-        """side_after: name of the main-stream stage after which the side stages may start (None: at the start of the step)"""
+        """side_after (schedule without hints): name of the main-stream stage after which the side stages may start (None: at the start)"""
         if self.hints:
             with pointops.neighbor_cache() as nc:
-                for xyz, nsample, algo in self.hints:
+                nc.record_events = self.overlap                     # results carry the event behind their producer: the side stream waits for
+                for xyz, nsample, algo in self.hints:               # the wide search alone, not for the narrow search's tie replay
                     nc.hint(xyz, nsample, algo)
-                return self._run(state, events, side_after)
-        return self._run(state, events, side_after)
+                return self._run_branches(state, events) if self.overlap else self._run(state, events, None, ())
+        return self._run(state, events, side_after, SIDE_STAGES if self.overlap else ())
 
-    def _run(self, state, events, side_after):
+    def _launch(self, i, state, events):
+        if events is not None:
+            events[i][0].record()
+        self.stage_list[i][1](state)
+        if events is not None:
+            events[i][1].record()
+
+    def _run_branches(self, state, events):
         main = torch.cuda.current_stream()
         names = [st[0] for st in self.stage_list]
-        side_idx = [i for i, nm in enumerate(names) if self.overlap and nm in SIDE_STAGES]
-        fork_at = names.index(side_after) if (side_after is not None and side_idx) else -1
+        side_idx = [i for i, nm in enumerate(names) if nm.startswith("cbl_")]
+        main_idx = [i for i in range(len(names)) if i not in side_idx]
+        self.side.wait_stream(main)                                 # the previous step is complete on both streams (joined below)
+        self._launch(main_idx[0], state, events)                    # the search: wide search (event), derivation, tie replay
+        before = {key: id(v) for key, v in state.items()}
+        with torch.cuda.stream(self.side):
+            for i in side_idx:                                      # cache hit on the wide result (waits for its event) -> mining + loss -> backward
+                self._launch(i, state, events)
+            self.joined.record(self.side)
+        produced = [v for key, v in state.items() if torch.is_tensor(v) and before.get(key) != id(v)]
+        for i in main_idx[1:]:
+            self._launch(i, state, events)
+        main.wait_event(self.joined)
+        for v in produced:
+            v.record_stream(main)                                   # allocated on the side stream, owned by the caller from here on
+        return state
 
-        def launch(i):
-            if events is not None:
-                events[i][0].record()
-            self.stage_list[i][1](state)
-            if events is not None:
-                events[i][1].record()
+    def _run(self, state, events, side_after, side_names):
+        main = torch.cuda.current_stream()
+        names = [st[0] for st in self.stage_list]
+        side_idx = [i for i, nm in enumerate(names) if nm in side_names]
+        fork_at = names.index(side_after) if (side_after is not None and side_idx) else -1
         produced = []
 
         def fork():
@@ -155,7 +180,7 @@ class Schedule:
             before = {key: id(v) for key, v in state.items()}
             with torch.cuda.stream(self.side):
                 for i in side_idx:
-                    launch(i)
+                    self._launch(i, state, events)
                 self.joined.record(self.side)
             produced.extend(v for key, v in state.items() if torch.is_tensor(v) and before.get(key) != id(v))
         if side_idx and fork_at < 0:
@@ -169,7 +194,7 @@ class Schedule:
                 for v in produced:
                     v.record_stream(main)                           # allocated on the side stream, consumed here
                 waited = True
-            launch(i)
+            self._launch(i, state, events)
             if i == fork_at:
                 fork()
         if not waited:

@@ -339,7 +339,8 @@ def knnquery_raw(nsample, xyz, new_xyz, offset, new_offset, algo="auto"):
             if wide is None:
                 h = cache.hints.get(cache._geo(xyz, new_xyz))
                 if h is not None and h[0] > nsample and h[0] <= 64:
-                    both = _knnquery_nested(h[0], h[1], nsample, algo, xyz, new_xyz, offset, new_offset)
+                    # one C call for both, unless consumers on other streams should be able to start behind the wide search alone
+                    both = None if getattr(cache, "record_events", False) else _knnquery_nested(h[0], h[1], nsample, algo, xyz, new_xyz, offset, new_offset)
                     if both is not None:                             # wide search + derivation in one C call
                         wi, wd, idx, dist2 = both
                         cache.insert(h[0], h[1], tensors, wi, wd)

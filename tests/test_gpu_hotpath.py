@@ -36,13 +36,15 @@ def test_schedule_records_stage_events_on_the_stage_stream():
     assert all(a.elapsed_time(b) > 0.0 for a, b in ev)
 
 
-def test_step_replays_from_a_hipgraph():
-    """bench.py captures the step (nested searches, autograd backward of the CBL loss included) once and replays it"""
+@pytest.mark.parametrize("overlap", [False, True])
+def test_step_replays_from_a_hipgraph(overlap):
+    """bench.py captures the step (nested searches, the CBL branch on a side stream, autograd backward of the CBL loss included) once
+    and replays it"""
     from contrastboundary_amd import hotpath
     sc = hotpath.Scene.synthetic(16384, 32, seed=7)
     st = hotpath.stages(sc, 16)
     ref = hotpath.run_once(sc, 16, {})
-    sched = hotpath.Schedule(st, overlap=False, hints=hotpath.search_hints(sc))
+    sched = hotpath.Schedule(st, overlap=overlap, hints=hotpath.search_hints(sc))
     gstate = {}
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
