@@ -142,7 +142,7 @@ static int launch_prefix(int m, int nsample_wide, int nsample, const int* idx_wi
 // and a counter the build zeroed), so no counter reset of its own is launched
 CBL_EXPORT int cbl_knnquery_nested(int b, int n, int m, int nsample_wide, int tie_policy_wide, int nsample, int tie_policy,
                                    const float* xyz, const float* new_xyz, const int* offset, const int* new_offset,
-                                   int* idx_wide, float* dist2_wide, int* idx, float* dist2, int* cell_order,
+                                   int* idx_wide, float* dist2_wide, int* idx, float* dist2, int* cell_order, void* event_after_wide,
                                    void* workspace, size_t workspace_bytes, void* stream)
 {
     if (nsample <= 0 || nsample >= nsample_wide || tie_policy < 0 || tie_policy > 1 || tie_policy_wide < 0 || tie_policy_wide > 2 || !idx || !dist2) return CBL_ERR_BAD_ARG;
@@ -151,6 +151,8 @@ CBL_EXPORT int cbl_knnquery_nested(int b, int n, int m, int nsample_wide, int ti
     int rc = knnquery_impl(b, n, m, nsample_wide, xyz, new_xyz, offset, new_offset, idx_wide, dist2_wide, workspace, workspace_bytes, tie_policy_wide, stream, cell_order);
     if (rc || m == 0) return rc;
     hipStream_t st = cbl_stream(stream);
+    // consumers of the WIDE result on other streams wait for this, not for the derivation and its tie replay
+    if (event_after_wide && hipEventRecord(reinterpret_cast<hipEvent_t>(event_after_wide), st) != hipSuccess) return cbl_status() ? cbl_status() : CBL_ERR_BAD_ARG;
     int *worklist, *counter; const void *grids, *sorted; const int* cell_start;
     cbl_knn_grid_scratch(workspace, b, n, m, &worklist, &counter, &grids, &cell_start, &sorted);
     rc = launch_prefix(m, nsample_wide, nsample, idx_wide, dist2_wide, idx, dist2, tie_policy, worklist, counter, st);

@@ -253,8 +253,11 @@ class neighbor_cache:
         self.misses += 1
         return None
 
-    def insert(self, nsample, algo, tensors, idx, dist2):
-        self.store[self._key(nsample, algo, tensors)] = self._stamp((idx, dist2), tensors)
+    def insert(self, nsample, algo, tensors, idx, dist2, event=None):
+        if event is not None:                                        # recorded by the producer itself (behind the part that made idx / dist2)
+            self.store[self._key(nsample, algo, tensors)] = ((idx, dist2), tensors, event, torch.cuda.current_stream(idx.device))
+        else:
+            self.store[self._key(nsample, algo, tensors)] = self._stamp((idx, dist2), tensors)
         geo = self._geo(tensors[0], tensors[1])
         if algo in ("auto", "set", "grid") and nsample > self.wide.get(geo, (0, None))[0]:
             self.wide[geo] = (nsample, algo)
@@ -339,11 +342,15 @@ def knnquery_raw(nsample, xyz, new_xyz, offset, new_offset, algo="auto"):
             if wide is None:
                 h = cache.hints.get(cache._geo(xyz, new_xyz))
                 if h is not None and h[0] > nsample and h[0] <= 64:
-                    # one C call for both, unless consumers on other streams should be able to start behind the wide search alone
-                    both = None if getattr(cache, "record_events", False) else _knnquery_nested(h[0], h[1], nsample, algo, xyz, new_xyz, offset, new_offset)
+                    # one C call for both; with cross-stream consumers the event behind the WIDE search alone is recorded inside the call
+                    ev = None
+                    if getattr(cache, "record_events", False):
+                        ev = torch.cuda.Event()
+                        ev.record(torch.cuda.current_stream(xyz.device))        # creates the handle; re-recorded inside the call
+                    both = _knnquery_nested(h[0], h[1], nsample, algo, xyz, new_xyz, offset, new_offset, ev)
                     if both is not None:                             # wide search + derivation in one C call
                         wi, wd, idx, dist2 = both
-                        cache.insert(h[0], h[1], tensors, wi, wd)
+                        cache.insert(h[0], h[1], tensors, wi, wd, event=ev)
                         cache.insert(nsample, algo, tensors, idx, dist2)
                         cache.derived += 1
                         return idx, dist2
@@ -380,7 +387,7 @@ def knn_prefix(nsample, nsample_wide, idx_wide, dist2_wide, xyz, new_xyz, offset
     return idx, dist2
 
 
-def _knnquery_nested(nsample_wide, algo_wide, nsample, algo, xyz, new_xyz, offset, new_offset):
+def _knnquery_nested(nsample_wide, algo_wide, nsample, algo, xyz, new_xyz, offset, new_offset, event=None):
     """cbl_knnquery_nested: -> (idx_wide, dist2_wide, idx, dist2), or None where the wide search would not take the grid path"""
     if algo_wide not in ("auto", "set", "anytie", "grid") or algo not in ("auto", "set"):
         return None
@@ -399,7 +406,8 @@ def _knnquery_nested(nsample_wide, algo_wide, nsample, algo, xyz, new_xyz, offse
     pw = 1 if algo_wide == "set" else 2 if algo_wide == "anytie" else 0
     rc = L.cbl_knnquery_nested(_c_int(b), _c_int(n), _c_int(m), _c_int(nsample_wide), _c_int(pw), _c_int(nsample), _c_int(1 if algo == "set" else 0),
                                _lib.ptr(xyz), _lib.ptr(new_xyz), _lib.ptr(offset), _lib.ptr(new_offset), _lib.ptr(wi), _lib.ptr(wd), _lib.ptr(idx),
-                               _lib.ptr(dist2), _lib.ptr(order), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(xyz))
+                               _lib.ptr(dist2), _lib.ptr(order), ctypes.c_void_p(event.cuda_event if event is not None else 0),
+                               _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(xyz))
     if rc == _lib.ERR_UNSUPPORTED:
         return None
     _lib.check(rc, "cbl_knnquery_nested")

@@ -104,11 +104,13 @@ int cbl_knnquery_prefix(int b, int n, int m, int nsample_wide, int nsample,
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* cbl_knnquery_ordered(nsample_wide, tie_policy_wide) followed by cbl_knnquery_prefix(nsample, tie_policy) in one call (cell_order may be
- * NULL): the derivation reuses the search's scratch, no separate workspace or counter reset.  CBL_ERR_UNSUPPORTED where the wide search
+ * NULL): the derivation reuses the search's scratch, no separate workspace or counter reset.  event_after_wide (a hipEvent_t, or NULL) is
+ * recorded on the stream between the wide search and the derivation: what a consumer of the wide result on another stream waits for.
+ * CBL_ERR_UNSUPPORTED where the wide search
  * would not take the grid path — call the two functions instead. */
 int cbl_knnquery_nested(int b, int n, int m, int nsample_wide, int tie_policy_wide, int nsample, int tie_policy,
                         const float* xyz, const float* new_xyz, const int* offset, const int* new_offset,
-                        int* idx_wide, float* dist2_wide, int* idx, float* dist2, int* cell_order,
+                        int* idx_wide, float* dist2_wide, int* idx, float* dist2, int* cell_order, void* event_after_wide,
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* brute-force variant only (always bit-exact, O(m*n)); `algo` for tests/bench: see cbl_knnquery */
