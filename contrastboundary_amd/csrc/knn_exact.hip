@@ -76,7 +76,11 @@ __device__ __forceinline__ unsigned long long heap_ancestors(int lane)
 //   * keys along the path are non-increasing, so the element passes slot c's parent  <=>  !(d > key[c]) (:29), lane-local;
 //   * a reached slot takes its bigger child's entry if the element also passes it, else the element itself.
 // One LDS-crossbar round trip (the children's entries) and ~20 VALU ops, against a 6-level serial walk.
-__device__ __forceinline__ void heap_replace_root_par(float& hd, int& hi, int lane, unsigned long long anc, int len, float d, int id)
+// The part of the step that depends on the heap alone — each slot's bigger child and whether the slot lies on the sink path —
+// and the part that depends on the element.  The replay's feed loop prepares right after every update, so the LDS round trip of the
+// preparation runs under the scalar work that finds the next accepted candidate.
+struct HeapPrep { float bk; int bi; bool onpath; };
+__device__ __forceinline__ HeapPrep heap_prepare(float hd, int hi, int lane, unsigned long long anc, int len)
 {
     const int l = 2 * lane + 1, r = l + 1;
     const int al = (l & 63) << 2, ar = (r & 63) << 2;        // ds_bpermute byte addresses (lane-constant: hoisted out of the feed loop)
@@ -91,14 +95,24 @@ __device__ __forceinline__ void heap_replace_root_par(float& hd, int& hi, int la
     const unsigned long long m_odd = 0xAAAAAAAAAAAAAAAAull;
     const unsigned long long nb = __ballot(up > hd), bp = __ballot(hd > dn);        // right sibling bigger / bigger than the left sibling
     const unsigned long long big = m_in & ((m_odd & ~((m_in >> 1) & nb)) | (~m_odd & bp));
-    const bool onpath = (big & anc) == anc;                  // root: empty chain
+    HeapPrep p;
+    p.onpath = (big & anc) == anc;                           // root: empty chain
     const bool right = (r < len) & (kr > kl);                // right child only when strictly larger (:27)
-    const float bk = right ? kr : kl;
-    const int bi = right ? ir : il;
-    const bool reached = onpath & ((lane == 0) | !(d > hd)); // stop only when strictly larger (:29)
-    const bool sinks = (l < len) & !(d > bk);
-    const float nd = sinks ? bk : d; const int ni = sinks ? bi : id;
+    p.bk = right ? kr : kl;
+    p.bi = right ? ir : il;
+    return p;
+}
+__device__ __forceinline__ void heap_apply(float& hd, int& hi, const HeapPrep& p, int lane, int len, float d, int id)
+{
+    const bool reached = p.onpath & ((lane == 0) | !(d > hd)); // stop only when strictly larger (:29)
+    const bool sinks = (2 * lane + 1 < len) & !(d > p.bk);
+    const float nd = sinks ? p.bk : d; const int ni = sinks ? p.bi : id;
     hd = reached ? nd : hd; hi = reached ? ni : hi;
+}
+__device__ __forceinline__ void heap_replace_root_par(float& hd, int& hi, int lane, unsigned long long anc, int len, float d, int id)
+{
+    const HeapPrep p = heap_prepare(hd, hi, lane, anc, len);
+    heap_apply(hd, hi, p, lane, len, d, id);
 }
 
 // one query by one wave: the whole scan + heap sort (`heap_mem`: this wave's 2*K words of LDS when the heap does not fit the lanes)
@@ -258,6 +272,7 @@ __global__ __launch_bounds__(64 * RP_WAVES) void knn_replay_kernel(
     float root = 1e10f;
     const unsigned long long anc = heap_ancestors(lane);
     // feed one chunk: lane l holds candidate l's distance and support index; accepted ones enter the heap in lane order
+    HeapPrep prep = heap_prepare(hd, hi, lane, anc, K);         // always describes the current heap while feeding
     auto feed = [&](float d2, int idv) {
         unsigned long long mask = __ballot(d2 < root);          // strict, :100
         while (mask) {
@@ -265,8 +280,9 @@ __global__ __launch_bounds__(64 * RP_WAVES) void knn_replay_kernel(
             mask &= mask - 1;
             const float dl = rl_f(d2, l);
             if (dl < root) {                                    // the root may have dropped since the ballot
-                heap_replace_root_par(hd, hi, lane, anc, K, dl, rl_i(idv, l));
+                heap_apply(hd, hi, prep, lane, K, dl, rl_i(idv, l));
                 root = rl_f(hd, 0);
+                prep = heap_prepare(hd, hi, lane, anc, K);      // its LDS round trip overlaps the search for the next candidate
             }
         }
     };
