@@ -2,7 +2,10 @@
     KNN (K=16)  ->  neighbour grouping (xyz-centred + features, (N,K,3+C))  ->  local aggregation over the K
     neighbours  ->  CBL head (neighbour search + pair mining + loss, forward and backward w.r.t. the features)
 Each stage is one or a few C-ABI launches on the current stream; `stages()` lists them with the ALGORITHMIC bytes
-/ flops of SURVEY.md §8(d) so bench.py can turn a measured duration into a roofline fraction.
+/ flops of SURVEY.md §8(d) so bench.py can turn a measured duration into a roofline fraction.  `Schedule` is how bench.py runs a step:
+one neighbour search per geometry (the K = 16 table derived from the K = 36 search the CBL head needs on the same points, tied rows
+replayed) and the CBL branch on a side stream beside the gather / KPConv branch; `run_once` is the plain in-order step with every
+search on its own — the tests hold the two against each other.
 """
 import torch
 
