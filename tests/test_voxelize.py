@@ -63,3 +63,15 @@ def test_gpu_test_time_crops_equal_the_oracle():
     assert len(got) == len(want)
     for g, w in zip(got, want):
         np.testing.assert_array_equal(g.cpu().numpy(), w)
+
+
+def test_synthetic_rooms_fail_fast_and_scale():
+    """the scene generator refuses a point count its room cannot hold (instead of doubling its sample 8 times), and the bench scenes
+    above 100k points grow the room"""
+    from contrastboundary_amd import hotpath, synthetic as S
+    with pytest.raises(ValueError):
+        S.s_room(400000, seed=0)
+    a = hotpath.Scene.synthetic_numpy(150000, 4, seed=1)
+    assert a["xyz"].shape == (150000, 3) and a["labels"].shape == (150000,) and a["xyz"].dtype == np.float32
+    b = hotpath.Scene.synthetic_numpy(4096, 4, seed=1)
+    assert b["xyz"].shape == (4096, 3) and float(b["xyz"].min()) == 0.0
