@@ -115,7 +115,7 @@ def main():
             torch.cuda.current_stream().wait_stream(cap_stream)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):     # other threads (the RCCL watchdog of a multi-rank run) may call HIP
                 sched.run(gstate, None, side_after=args.side_after)
             g.replay()
             torch.cuda.synchronize()
