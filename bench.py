@@ -130,7 +130,7 @@ def main():
     torch.cuda.synchronize()
     D.barrier()
     # per-stage HIP events on every EVENT_EVERY-th step of the timed region only: 12 event records cost ~55 us, 13 % of a step
-    EVENT_EVERY = 10 if args.steps >= 40 else 5 if args.steps >= 10 else 1
+    EVENT_EVERY = 16 if args.steps >= 48 else 10 if args.steps >= 40 else 5 if args.steps >= 10 else 1      # 4 samples of the default 50 steps
     ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in stages] if s % EVENT_EVERY == 0 else None
           for s in range(args.steps)]
     torch.cuda.synchronize()
@@ -168,7 +168,7 @@ def main():
                 "achieved": gbps(gi), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps(gi) / HBM_PEAK_GBS, "traffic": None,
                 "bytes_per_launch": stages[gi][2],
                 "note": "achieved = SURVEY 8(d) algorithmic bytes of the launch / its HIP-event time inside the timed region (events on the launch "
-                        "stream, every 5th step); traffic = PMC FETCH_SIZE + WRITE_SIZE per launch (profiles/r01_pmc_traffic.json)",
+                        "stream, on the eagerly issued steps); traffic = PMC FETCH_SIZE + WRITE_SIZE per launch (profiles/r01_pmc_traffic.json)",
                 "longest_stage": {"stage": names[dom], "kernel": main_kernel.get(names[dom], names[dom]), "ms": round(stage_ms[dom], 4),
                                   "algorithmic_GBps": round(gbps(dom), 1),
                                   "note": "few compulsory bytes: bound by VALU issue / memory latency / the exact replay of tied queries, not by HBM"},
