@@ -87,3 +87,50 @@ def test_hotpath_with_nested_searches_equals_the_plain_step():
     assert torch.equal(torch.sort(state["cbl_idx"], 1)[0], torch.sort(ref["cbl_idx"], 1)[0])
     assert torch.equal(state["grouped"], ref["grouped"]) and torch.equal(state["kpconv"], ref["kpconv"])
     assert abs(float(state["cbl_loss"].detach()) - float(ref["cbl_loss"].detach())) <= 1e-5 * abs(float(ref["cbl_loss"].detach()))
+
+
+@pytest.mark.parametrize("with_event", [False, True])
+@pytest.mark.parametrize("kind", ["room", "lattice", "duplicates", "short"])
+def test_nested_call_equals_the_two_searches(kind, with_event):
+    """cbl_knnquery_nested (wide search + derivation in one call, optional event behind the wide part) on tie-heavy and short clouds"""
+    from contrastboundary_amd import pointops, synthetic as S
+    rng = np.random.default_rng(11)
+    if kind == "room":
+        xyz = S.s_room(20000, seed=4)[0]; offs = [7000, len(xyz)]
+    elif kind == "lattice":
+        g = np.stack(np.meshgrid(np.arange(15), np.arange(15), np.arange(15), indexing="ij"), -1).reshape(-1, 3).astype(np.float32) * 0.1
+        xyz = g[rng.permutation(len(g))]; offs = [len(xyz)]
+    elif kind == "duplicates":
+        base = rng.uniform(size=(3000, 3)).astype(np.float32)
+        xyz = np.concatenate([base, base[:1500]])[rng.permutation(4500)]; offs = [1500, 4500]
+    else:                                                                      # clouds with fewer supports than K' / than K
+        xyz = rng.uniform(size=(6000, 3)).astype(np.float32); offs = [10, 30, 6000]
+    p = dev(xyz); off = dev(np.int32(offs))
+    for ks, kw, algo_w, algo in ((16, 36, "set", "auto"), (8, 16, "auto", "auto"), (12, 40, "anytie", "set")):
+        want_w = pointops.knnquery_raw(kw, p, p, off, off, algo=algo_w)
+        want = pointops.knnquery_raw(ks, p, p, off, off, algo=algo)
+        ev = None
+        if with_event:
+            ev = torch.cuda.Event(); ev.record()
+        got = pointops._knnquery_nested(kw, algo_w, ks, algo, p, p, off, off, ev)
+        assert got is not None
+        wi, wd, gi, gd = got
+        if with_event:                                                         # the wide result alone is complete behind the event
+            other = torch.cuda.Stream()
+            other.wait_event(ev)
+            with torch.cuda.stream(other):
+                wi_seen, wd_seen = wi.clone(), wd.clone()
+            other.synchronize()
+        torch.cuda.synchronize()
+        if with_event:
+            assert torch.equal(wi_seen, wi) and torch.equal(wd_seen, wd)
+        if algo == "auto":
+            assert torch.equal(gi, want[0]) and torch.equal(gd, want[1])
+        else:
+            assert _rows_as_sets_equal(gi, want[0], gd, want[1])
+        if algo_w == "auto":
+            assert torch.equal(wi, want_w[0]) and torch.equal(wd, want_w[1])
+        elif algo_w == "set":
+            assert _rows_as_sets_equal(wi, want_w[0], wd, want_w[1])
+        else:
+            assert torch.equal(wd, want_w[1])
