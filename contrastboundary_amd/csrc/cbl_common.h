@@ -59,3 +59,8 @@ __device__ __forceinline__ unsigned cbl_xcd_per(unsigned nwg) { return (nwg + 7u
 __device__ __forceinline__ unsigned cbl_xcd_slot(unsigned v, unsigned nwg) { return (v & 7u) * cbl_xcd_per(nwg) + (v >> 3); }
 static inline unsigned cbl_round_up8(unsigned g) { return (g + 7u) & ~7u; }
 
+
+// A narrower result (the first `nsample` of the wider list) that a grid search may emit along with its own (cbl_knnquery_nested):
+// filled in by the caller; `fused` comes back true where the search kernel wrote idx / dist2 and listed the rows decided by a tie
+// (its second worklist, counters[1]) — otherwise the caller derives them in a pass of its own.
+struct CblKnnNarrow { int nsample; int set_exact; int* idx; float* dist2; bool fused; };

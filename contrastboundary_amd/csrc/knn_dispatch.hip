@@ -4,7 +4,7 @@
 
 size_t cbl_knn_grid_workspace_bytes(int b, int n, int m, int nsample);     // knn_grid.hip
 int cbl_knn_grid_launch(int b, int n, int m, int nsample, const float* xyz, const float* new_xyz, const int* offset,
-                        const int* new_offset, int* idx, float* dist2, void* ws, size_t ws_bytes, int set_exact, hipStream_t st, int* order_out);
+                        const int* new_offset, int* idx, float* dist2, void* ws, size_t ws_bytes, int set_exact, hipStream_t st, int* order_out, CblKnnNarrow* narrow);
 
 size_t cbl_knn_select_workspace_bytes(int b, int n, int m, int nsample);   // knn_select.hip
 int cbl_knn_select_launch(int b, int n, int m, int nsample, const float* xyz, const float* new_xyz, const int* offset, const int* new_offset,
@@ -18,14 +18,14 @@ CBL_EXPORT size_t cbl_knnquery_workspace_bytes(int b, int n, int m, int nsample)
 
 static int knnquery_impl(int b, int n, int m, int nsample, const float* xyz, const float* new_xyz,
                          const int* offset, const int* new_offset, int* idx, float* dist2,
-                         void* workspace, size_t workspace_bytes, int set_exact, void* stream, int* order_out = nullptr)
+                         void* workspace, size_t workspace_bytes, int set_exact, void* stream, int* order_out = nullptr, CblKnnNarrow* narrow = nullptr)
 {
     if (b <= 0 || n < 0 || m < 0 || nsample <= 0 || nsample > CBL_KNN_MAX_NSAMPLE) return CBL_ERR_BAD_ARG;
     if (m == 0) return CBL_OK;
     if (!xyz || !new_xyz || !offset || !new_offset || !idx || !dist2) return CBL_ERR_BAD_ARG;
     const size_t need = cbl_knn_grid_workspace_bytes(b, n, m, nsample);
     if (need > 0 && workspace && workspace_bytes >= need)
-        return cbl_knn_grid_launch(b, n, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, workspace, workspace_bytes, set_exact, cbl_stream(stream), order_out);
+        return cbl_knn_grid_launch(b, n, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, workspace, workspace_bytes, set_exact, cbl_stream(stream), order_out, narrow);
     if (order_out) return CBL_ERR_UNSUPPORTED;                      // only the grid path sorts the supports into cells
     const size_t need_sel = cbl_knn_select_workspace_bytes(b, n, m, nsample);
     if (need_sel > 0 && workspace && workspace_bytes >= need_sel)
@@ -116,8 +116,8 @@ __global__ __launch_bounds__(256) void knn_prefix_pow2_kernel(int m, int kb, con
 }
 }  // namespace
 
-void cbl_knn_grid_scratch(void* ws, int b, int n, int m, int** worklist, int** zero_counter, const void** grids, const int** cell_start,
-                          const void** sorted);      // knn_grid.hip
+void cbl_knn_grid_scratch(void* ws, int b, int n, int m, int** worklist, int** worklist2, int** zero_counter, const void** grids,
+                          const int** cell_start, const void** sorted);      // knn_grid.hip
 
 static int launch_prefix(int m, int nsample_wide, int nsample, const int* idx_wide, const float* dist2_wide, int* idx, float* dist2, int tie_policy,
                          int* worklist, int* counter, hipStream_t st)
@@ -148,15 +148,20 @@ CBL_EXPORT int cbl_knnquery_nested(int b, int n, int m, int nsample_wide, int ti
     if (nsample <= 0 || nsample >= nsample_wide || tie_policy < 0 || tie_policy > 1 || tie_policy_wide < 0 || tie_policy_wide > 2 || !idx || !dist2) return CBL_ERR_BAD_ARG;
     const size_t need = cbl_knn_grid_workspace_bytes(b, n, m, nsample_wide);
     if (need == 0 || !workspace || workspace_bytes < need) return CBL_ERR_UNSUPPORTED;      // only behind the grid path (its scratch is what is reused)
-    int rc = knnquery_impl(b, n, m, nsample_wide, xyz, new_xyz, offset, new_offset, idx_wide, dist2_wide, workspace, workspace_bytes, tie_policy_wide, stream, cell_order);
+    // with the wave kernel (nsample_wide > 16) the narrow rows and the list of those a tie decides come out of the search itself
+    CblKnnNarrow narrow{nsample, tie_policy, idx, dist2, false};
+    int rc = knnquery_impl(b, n, m, nsample_wide, xyz, new_xyz, offset, new_offset, idx_wide, dist2_wide, workspace, workspace_bytes, tie_policy_wide, stream, cell_order, &narrow);
     if (rc || m == 0) return rc;
     hipStream_t st = cbl_stream(stream);
     // consumers of the WIDE result on other streams wait for this, not for the derivation and its tie replay
     if (event_after_wide && hipEventRecord(reinterpret_cast<hipEvent_t>(event_after_wide), st) != hipSuccess) return cbl_status() ? cbl_status() : CBL_ERR_BAD_ARG;
-    int *worklist, *counter; const void *grids, *sorted; const int* cell_start;
-    cbl_knn_grid_scratch(workspace, b, n, m, &worklist, &counter, &grids, &cell_start, &sorted);
-    rc = launch_prefix(m, nsample_wide, nsample, idx_wide, dist2_wide, idx, dist2, tie_policy, worklist, counter, st);
-    if (rc) return rc;
+    int *worklist, *worklist2, *counter; const void *grids, *sorted; const int* cell_start;
+    cbl_knn_grid_scratch(workspace, b, n, m, &worklist, &worklist2, &counter, &grids, &cell_start, &sorted);
+    if (narrow.fused) worklist = worklist2;
+    else {
+        rc = launch_prefix(m, nsample_wide, nsample, idx_wide, dist2_wide, idx, dist2, tie_policy, worklist, counter, st);
+        if (rc) return rc;
+    }
     return cbl_knn_exact_worklist(b, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, worklist, counter, m, st, grids, cell_start, sorted);
 }
 

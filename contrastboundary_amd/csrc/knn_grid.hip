@@ -39,6 +39,7 @@ struct Workspace {
     int* pt_cell;        // [n]
     float4* sorted;      // [n]
     int* worklist;       // [m]
+    int* worklist2;      // [m]  tied rows of the narrower result that rides along with a wave-kernel search (cbl_knnquery_nested)
     size_t bytes;
     int ncap;
 };
@@ -62,6 +63,7 @@ Workspace carve(void* base, int b, int n, int m)
     w.pt_cell = reinterpret_cast<int*>(take(sizeof(int) * (size_t)n));
     w.sorted = reinterpret_cast<float4*>(take(sizeof(float4) * (size_t)n));
     w.worklist = reinterpret_cast<int*>(take(sizeof(int) * (size_t)m));
+    w.worklist2 = reinterpret_cast<int*>(take(sizeof(int) * (size_t)m));
     w.bytes = off;
     return w;
 }
@@ -461,7 +463,9 @@ __global__ __launch_bounds__(256) void knn_grid_wave_kernel(int b, int m, int K,
                                                             const int* __restrict__ offset, const int* __restrict__ new_offset,
                                                             const CblGrid* __restrict__ grids, const int* __restrict__ cell_start,
                                                             const float4* __restrict__ sorted, int* __restrict__ idx, float* __restrict__ dist2,
-                                                            int* __restrict__ worklist, int* __restrict__ counters, int set_exact)
+                                                            int* __restrict__ worklist, int* __restrict__ counters, int set_exact,
+                                                            int ks, int* __restrict__ idx_n, float* __restrict__ dist2_n,
+                                                            int* __restrict__ worklist_n, int set_exact_n)
 {
     __shared__ float2 slots[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -643,6 +647,14 @@ __global__ __launch_bounds__(256) void knn_grid_wave_kernel(int b, int m, int K,
     const bool ok = (worst < INFINITY) && (set_exact == 2 || ((rm != worst) && (set_exact || __ballot(dup) == 0)));
     if (lane < K) { idx[(size_t)q * K + lane] = ei; dist2[(size_t)q * K + lane] = ed; }
     if (!ok && lane == 0) worklist[atomicAdd(counters, 1)] = q;
+    // the ks < K nearest as a result of their own (cbl_knnquery_nested): the list's distances are final whether or not its tie order
+    // is, so the first ks entries stand unless THEY are decided by a tie — equal neighbours among the first ks (reference order only),
+    // entry ks-1 tied with entry ks, or fewer than ks supports (the reference pads with 1e10, knnquery_cuda_kernel.cu:91-94)
+    if (idx_n) {
+        if (lane < ks) { idx_n[(size_t)q * ks + lane] = ei; dist2_n[(size_t)q * ks + lane] = ed; }
+        const bool bad = (lane > 0 && lane <= ks && ed == pd && (lane == ks || !set_exact_n)) || (lane == ks - 1 && !(ed < 1e10f));
+        if (__ballot(bad) != 0ull && lane == 0) worklist_n[atomicAdd(counters + 1, 1)] = q;
+    }
 }
 
 template <int G>
@@ -774,16 +786,19 @@ size_t cbl_knn_grid_workspace_bytes(int b, int n, int m, int nsample)
 }
 
 // scratch of a finished grid search for a follow-up pass over its results (cbl_knnquery_nested): the worklist array and a counter that
-// grid_init_kernel zeroed and the search did not touch
-void cbl_knn_grid_scratch(void* ws, int b, int n, int m, int** worklist, int** zero_counter, const void** grids, const int** cell_start, const void** sorted)
+// grid_init_kernel zeroed and the search did not touch; worklist2 / the same counter hold the narrow result's tied rows where the wave
+// kernel already emitted it (CblKnnNarrow::fused)
+void cbl_knn_grid_scratch(void* ws, int b, int n, int m, int** worklist, int** worklist2, int** zero_counter, const void** grids, const int** cell_start,
+                          const void** sorted)
 {
     Workspace w = carve(ws, b, n, m);
-    *worklist = w.worklist; *zero_counter = w.counters + 1;
+    *worklist = w.worklist; *worklist2 = w.worklist2; *zero_counter = w.counters + 1;
     *grids = w.grids; *cell_start = w.cell_start; *sorted = w.sorted;
 }
 
 int cbl_knn_grid_launch(int b, int n, int m, int nsample, const float* xyz, const float* new_xyz, const int* offset,
-                        const int* new_offset, int* idx, float* dist2, void* ws, size_t ws_bytes, int set_exact, hipStream_t st, int* order_out)
+                        const int* new_offset, int* idx, float* dist2, void* ws, size_t ws_bytes, int set_exact, hipStream_t st, int* order_out,
+                        CblKnnNarrow* narrow)
 {
     Workspace w = carve(ws, b, n, m);
     if (ws_bytes < w.bytes) return CBL_ERR_WORKSPACE;
@@ -793,8 +808,13 @@ int cbl_knn_grid_launch(int b, int n, int m, int nsample, const float* xyz, cons
     const bool self = (new_xyz == xyz) && (m == n);
     if (nsample > 16) {                                              // select-then-sort, one wave per query
         const dim3 grid(cbl_div_up(m, 4)), block(256);
+        // a narrower result of the same search rides along (its worklist: worklist2, counted in counters[1])
+        const int ks = narrow ? narrow->nsample : 0;
+        int* idx_n = narrow ? narrow->idx : nullptr; float* dist2_n = narrow ? narrow->dist2 : nullptr;
+        const int set_n = narrow ? narrow->set_exact : 0;
+        if (narrow) narrow->fused = true;
 #define CBL_LAUNCH_WAVE(SELF_, LEX_) hipLaunchKernelGGL((knn_grid_wave_kernel<SELF_, LEX_>), grid, block, 0, st, b, m, nsample, new_xyz, offset, new_offset, w.grids, \
-                                                       w.cell_start, w.sorted, idx, dist2, w.worklist, w.counters, set_exact)
+                                                       w.cell_start, w.sorted, idx, dist2, w.worklist, w.counters, set_exact, ks, idx_n, dist2_n, w.worklist2, set_n)
         if (set_exact == 2) { if (self) CBL_LAUNCH_WAVE(true, true); else CBL_LAUNCH_WAVE(false, true); }
         else                { if (self) CBL_LAUNCH_WAVE(true, false); else CBL_LAUNCH_WAVE(false, false); }
 #undef CBL_LAUNCH_WAVE

@@ -104,8 +104,10 @@ int cbl_knnquery_prefix(int b, int n, int m, int nsample_wide, int nsample,
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* cbl_knnquery_ordered(nsample_wide, tie_policy_wide) followed by cbl_knnquery_prefix(nsample, tie_policy) in one call (cell_order may be
- * NULL): the derivation reuses the search's scratch, no separate workspace or counter reset.  event_after_wide (a hipEvent_t, or NULL) is
- * recorded on the stream between the wide search and the derivation: what a consumer of the wide result on another stream waits for.
+ * NULL): the derivation reuses the search's scratch, no separate workspace or counter reset; for nsample_wide > 16 the search kernel
+ * itself writes the narrow rows and lists those a tie decides (no derivation pass).  event_after_wide (a hipEvent_t, or NULL) is
+ * recorded on the stream behind the wide search and before the narrow rows' tie replay: what a consumer of the wide result on another
+ * stream waits for.
  * CBL_ERR_UNSUPPORTED where the wide search
  * would not take the grid path — call the two functions instead. */
 int cbl_knnquery_nested(int b, int n, int m, int nsample_wide, int tie_policy_wide, int nsample, int tie_policy,
