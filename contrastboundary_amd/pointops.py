@@ -59,7 +59,7 @@ def _workspace(nbytes, device):
 # order for every kernel that walks the points and gathers their neighbours.  It is kept per geometry (the coordinate tensor) and per
 # stream, and handed to the *_ordered C entry points: the VALUES never depend on it — a stale or missing order only costs locality.
 ORDER_MIN_POINTS = 8192         # below this the tables sit in L2 anyway
-_order_registry = collections.OrderedDict()     # (data_ptr, n, version, device) -> {stream id: (order tensor, event)}
+_order_registry = collections.OrderedDict()     # (data_ptr, n, version, device) -> {stream id: (order tensor, stream that holds it)}
 _ORDER_REGISTRY_MAX = 16
 
 
@@ -82,12 +82,13 @@ def _order_wanted(points, stream_id):
 def _order_register(points, order, stream):
     key = _order_key(points)
     ent = _order_registry.setdefault(key, {})
-    ev = torch.cuda.Event()
-    ev.record(stream)
-    ent[stream.cuda_stream] = (order, ev)
+    ent[stream.cuda_stream] = (order, stream)                      # no event here (a record costs ~4 us of stream time): see spatial_order
     _order_registry.move_to_end(key)
     while len(_order_registry) > _ORDER_REGISTRY_MAX:
         _order_registry.popitem(last=False)
+    cache = neighbor_cache.active()
+    if cache is not None:                                            # a cached pass owns what it registers: dropped with the cache
+        cache.order_keys.append(key)
 
 
 def _order_alias(idx, points):
@@ -97,6 +98,9 @@ def _order_alias(idx, points):
         _order_registry[_order_key(idx)] = ent
         while len(_order_registry) > _ORDER_REGISTRY_MAX:
             _order_registry.popitem(last=False)
+        cache = neighbor_cache.active()
+        if cache is not None:
+            cache.order_keys.append(_order_key(idx))
 
 
 def spatial_order(points):
@@ -111,9 +115,10 @@ def spatial_order(points):
     hit = ent.get(cur.cuda_stream)
     if hit is not None:
         return hit[0]
-    order, ev = next(iter(ent.values()))                         # produced on another stream: order after it, keep it alive for this one
-    cur.wait_event(ev)
+    order, producer = next(iter(ent.values()))                   # produced on another stream: order after it, keep it alive for this one
+    cur.wait_stream(producer)
     order.record_stream(cur)
+    ent[cur.cuda_stream] = (order, cur)                             # ordered behind the producer from here on
     return order
 
 
@@ -187,6 +192,7 @@ class neighbor_cache:
         self.hints = {}                                             # geometry -> (widest nsample it will be searched with, algo), see hint()
         self.wide = {}                                              # geometry -> (nsample, algo) of the widest result in the store
         self.derived = 0                                            # requests answered from a wider result (cbl_knnquery_prefix)
+        self.order_keys = []                                        # processing orders registered during this pass (dropped with it)
 
     def hint(self, xyz, nsample, algo="set", new_xyz=None, offset=None, new_offset=None):
         """Declare that this geometry will be searched with up to `nsample` neighbours during the pass (a network knows its config:
@@ -209,6 +215,9 @@ class neighbor_cache:
             self.store.clear()
             self.host.clear()
             self.wide.clear()
+            for key in self.order_keys:
+                _order_registry.pop(key, None)
+            self.order_keys.clear()
         return False
 
     @staticmethod
