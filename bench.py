@@ -155,7 +155,7 @@ def main():
     dom = int(np.argmax(stage_ms))
     # kernel that dominates each stage (rocprofv3 --kernel-trace --stats of this same command: profiles/)
     main_kernel = {"knnquery_k16": ("knn_grid_group_kernel<16> (+ 5-launch grid build, knn_replay_kernel for the tied queries)" if args.no_nested else
-                                    "the K=36 search of the same points (grid build + knn_grid_wave_kernel), knn_prefix_kernel, knn_replay_kernel for the tied queries"),
+                                    "the K=36 search of the same points (grid build + knn_grid_wave_kernel, which also writes the K=16 rows), knn_replay_kernel for the tied queries of both"),
                    "queryandgroup": "query_group_lds<16> (aligned 16-row pieces through LDS, cell-order schedule)", "kpconv_fwd": "kpconv_fwd_kernel (v_mfma_f32_16x16x4_f32)",
                    "cbl_knnquery_k36": "knn_grid_wave_kernel (select-then-sort, + 5-launch grid build)",
                    "cbl_mining_loss_fwd": "contrast_bwd_kernel<64,8> in fused forward+gradient mode (+ finalize)", "cbl_mining_loss_bwd": "contrast_grad_scale_kernel"}
@@ -217,7 +217,7 @@ def main():
                        % (n, k, c, " -> ".join(s[0] for s in stages)), "parallelism": "scene-per-GPU replicas x%d (no data-path collective)" % world,
                        "issue": graph_note,
                        "schedule": (("one search per geometry: the K=%d request runs the K=%d search the CBL head declared for the same points "
-                                     "(neighbor_cache hint, dropped at the end of every step) and is derived from it (cbl_knnquery_prefix, tied rows "
+                                     "(neighbor_cache hint, dropped at the end of every step) and is derived from it (cbl_knnquery_nested: the first K of each list, tied rows "
                                      "replayed); the later K=%d request is a cache hit; %s" % (k, hotpath.CBL_NSAMPLE, hotpath.CBL_NSAMPLE,
                                         "all stages in order on one stream" if args.no_overlap else
                                         "the CBL branch (needs the wide result only) on a side stream beside tie replay -> gather -> KPConv; steps with per-stage events in order"))
