@@ -238,11 +238,12 @@ class neighbor_cache:
     # event recorded behind its producer; a consumer stream waits for it and is registered with the allocator as a user.
     def _deliver(self, entry):
         outs, _keys, event, stream = entry
-        cur = torch.cuda.current_stream(outs[0].device)
-        if event is not None and stream != cur:
-            cur.wait_event(event)
-            for t in outs:
-                t.record_stream(cur)
+        if event is not None:
+            cur = torch.cuda.current_stream(outs[0].device)
+            if stream != cur:
+                cur.wait_event(event)
+                for t in outs:
+                    t.record_stream(cur)
         return outs
 
     def _stamp(self, outs, keys):
