@@ -1,18 +1,28 @@
 #!/usr/bin/env python3
 """bench.py — points/sec through the KNN + group + local-aggregation + CBL block on S3DIS-shaped synthetic scenes.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--points 40960] [--channels 64] [--k 16]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--points 40960] [--channels 64] [--k 16] [--forward-only]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One "step" = one pass of the hot path (contrastboundary_amd/hotpath.py) over one scene whose inputs are already
-resident in HBM.  Scenes are independent, so N ranks run N scene replicas with no data-path collective (weak
-scaling); the timed region is bracketed by barrier + synchronize and the MAX over ranks is used.
-Rank 0 prints ONE JSON line with the driver's fields plus `roofline` (dominant kernel, HIP-event timed inside the
-timed region) and `cpu_baseline` (the CPU oracle = a port of the reference's algorithm, one thread, one scene).
+One "step" = one pass of the hot path (contrastboundary_amd/hotpath.py: search, gather, KPConv, CBL head forward + backward and — BASELINE
+config C2 "forward/backward" — the block's backward legs) over one scene whose inputs are already resident in HBM.  Scenes are independent,
+so N ranks run N scene replicas with no data-path collective (weak scaling).  `--gpus N` without a torchrun environment
+re-executes this file under torch.distributed.run with N ranks (one per device; fewer than N devices is an error); the printed `n_gpus` is the
+number of ranks that joined the process group.  Every timed step is the same thing (the step's hipGraph replayed); the timed region is
+bracketed by barrier + synchronize and the MAX over ranks is used.  Rank 0 prints ONE JSON line with the driver's fields plus
+  `roofline`      the HBM-bound neighbour gather: algorithmic bytes / HIP-event duration of its launch, events recorded on the launch stream
+                  (inside the in-order hipGraph of the step, replayed right after the timed region), PMC traffic from profiles/ if it
+                  belongs to this kernel set;
+  `forward_only`  the forward block + CBL head alone (round 1's step), timed the same way;
+  `grad_allreduce` (N > 1) the same K steps with one flat 31.2 MB fp32 all-reduce per step over RCCL beside the compute — what DDP adds to
+                  data-parallel training of the reference's network (pytorch/tool/train.py:141,181-185; 7,800,497 parameters);
+  `cpu_baseline`  (N = 1, rank 0) tests/cpu_baseline.py: the reference's own CPU KNN (oracle/_ref) and the CPU oracles on the host cores.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,9 +34,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 matrix = f32 vector peak
+GRAD_ALLREDUCE_FLOATS = 7800497   # parameters of the reference's PointTransformerSeg + heads: 31.2 MB fp32
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -34,162 +46,283 @@ def parse():
     ap.add_argument("--points", type=int, default=40960)
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--k", type=int, default=16)
+    ap.add_argument("--forward-only", action="store_true", help="headline = forward block + CBL head only (round 1's step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="all stages in order on one stream")
     ap.add_argument("--no-graph", action="store_true", help="issue every step eagerly from Python instead of replaying its hipGraph")
     ap.add_argument("--no-nested", action="store_true", help="every neighbour search on its own (no derivation of K=16 from the K=36 search of the same points)")
-    ap.add_argument("--side-after", default=None, help="main-stream stage after which the side stream starts (default: start of the step)")
-    return ap.parse_args()
+    ap.add_argument("--no-allreduce", action="store_true", help="skip the gradient all-reduce leg of a multi-rank run")
+    ap.add_argument("--no-extra", action="store_true", help="headline only: no forward_only / stage / all-reduce legs (profiling runs)")
+    ap.add_argument("--allreduce-floats", type=int, default=GRAD_ALLREDUCE_FLOATS)
+    ap.add_argument("--host-dry-run", action="store_true",
+                    help="CPU-only run of the launcher / process-group / timing / all-reduce logic over gloo (tests; not a measurement)")
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(n, c, k, seed):
-    """the oracles (ports of the reference algorithms: brute-force KNN in C, the rest numpy), 1 thread, ONE full scene"""
-    from tests import oracle_lib as O
-    from tests import oracle_hotpath
-    from contrastboundary_amd import hotpath
-    sc = hotpath.Scene.synthetic_numpy(n, c, seed)
-    xyz, feat, off = sc["xyz"], sc["feat"], sc["offset"]
-    os.environ.setdefault("OMP_NUM_THREADS", "1")
-    parts = {}
+# ------------------------------------------------------------------------------------------------ launcher
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def spawn(args, argv):
+    """`--gpus N` outside a torchrun environment: re-execute under torch.distributed.run, one rank per GPU (what the driver does itself)"""
+    if not args.host_dry_run:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.stderr.write("bench.py: --gpus %d but only %d device(s) visible; refusing to report a smaller run as n_gpus=%d\n" % (args.gpus, have, args.gpus))
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")               # dmabuf IPC (RCCL / CUDA-tensor sharing across processes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def timed_region(step, steps, warmup, sync, D):
+    """W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides; -> max over ranks of the wall time"""
+    for _ in range(warmup):
+        step()
+    sync()
+    D.barrier()
     t0 = time.perf_counter()
-    idx, _ = O.knnquery(k, xyz, xyz, off, off)
-    parts["knnquery_k%d" % k] = time.perf_counter() - t0
-    t1 = time.perf_counter()
-    g = O.grouping_forward(np.concatenate([xyz, feat], 1), idx)
-    g[..., :3] -= xyz[:, None, :]
-    parts["queryandgroup"] = time.perf_counter() - t1
-    parts.update(oracle_hotpath.run_rest(sc, idx, k))
-    total = sum(parts.values())
-    return {"value": n / total, "unit": "points/s", "cores": 1, "kind": "port",
-            "sample": "1 scene of %d points (same workload), single thread; stage seconds: %s" % (
-                n, {a: round(b, 3) for a, b in parts.items()})}
+    for _ in range(steps):
+        step()
+    sync()
+    D.barrier()
+    return D.reduce_scalar(time.perf_counter() - t0, "max")
 
 
-def main():
-    args = parse()
-    from contrastboundary_amd import distributed as D
-    world, rank, local = D.env_world()
+class GradAllReduce:
+    """one flat fp32 buffer all-reduced per step beside the compute, as DDP does with the network's gradients (train.py:181-185)"""
+
+    def __init__(self, nfloats, device):
+        import torch.distributed as dist
+        self.dist = dist
+        self.buf = torch.ones(nfloats, dtype=torch.float32, device=device)
+        self.pending = None
+
+    def start(self):
+        self.pending = self.dist.all_reduce(self.buf, op=self.dist.ReduceOp.SUM, async_op=True)
+
+    def finish(self):
+        if self.pending is not None:
+            self.pending.wait()                                      # the current stream waits for the collective (no host block on a GPU)
+            self.pending = None
+        # keep the values bounded over many steps: average like DDP
+        self.buf.mul_(1.0 / self.dist.get_world_size())
+
+
+# ------------------------------------------------------------------------------------------------ host dry run (gloo, CPU): tests only
+def host_dry_run(args, D, world, rank):
+    """the N > 1 logic of this file without a GPU: rendezvous, world-size check, barrier-bracketed timing, max over ranks, the all-reduce
+    leg, one JSON line from rank 0.  The 'step' is a fixed sleep: nothing here is a measurement."""
+    D.init("gloo")
+    import torch.distributed as dist
+    assert (dist.get_world_size() if dist.is_initialized() else 1) == args.gpus, "process group size != --gpus"
+    n = args.points
+
+    def step():
+        time.sleep(0.002)
+    elapsed = timed_region(step, args.steps, args.warmup, lambda: None, D)
+    out = {"metric": "host dry run (NOT a measurement)", "value": n * args.steps * world / elapsed, "unit": "points/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "none (host dry run over gloo)", "config": {"workload": "sleep", "parallelism": "replicas x%d" % world}}
+    if world > 1 and not args.no_allreduce:
+        ar = GradAllReduce(args.allreduce_floats, "cpu")
+
+        def step_ar():
+            ar.start(); step(); ar.finish()
+        e2 = timed_region(step_ar, args.steps, args.warmup, lambda: None, D)
+        out["grad_allreduce"] = {"value": n * args.steps * world / e2, "ms_per_step": e2 / args.steps * 1e3, "bytes": 4 * args.allreduce_floats,
+                                 "checksum": float(ar.buf[0])}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ the step
+class Step:
+    """the hot path over one resident scene as bench.py runs it: schedule + its hipGraph"""
+
+    def __init__(self, scene, k, backward, args, events=False, overlap=True):
+        from contrastboundary_amd import hotpath
+        self.stages = hotpath.stages(scene, k, backward)
+        self.names = [st[0] for st in self.stages]
+        self.hints = () if args.no_nested else hotpath.search_hints(scene)
+        self.sched = hotpath.Schedule(self.stages, overlap=overlap, hints=self.hints)
+        self.state, self.graph, self.note = {}, None, "eager"
+        self.events = None
+        if events:       # external events: recorded by event-record nodes inside the captured graph, timeable after a replay
+            self.events = [(torch.cuda.Event(enable_timing=True, external=True), torch.cuda.Event(enable_timing=True, external=True)) for _ in self.stages]
+
+    def eager(self, events=None):
+        self.sched.run(self.state, events)
+
+    def capture(self):
+        """the step issues 30-40 launches from Python, as many us of host time as the device needs: captured once (same kernels, same
+        buffers, same schedule) it is replayed with ~15 us of host time.  Raises if the capture fails (bench.py then stays eager)."""
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        gstate = {}
+        with torch.cuda.stream(cap):
+            for _ in range(3):
+                self.sched.run(gstate, None)
+        torch.cuda.current_stream().wait_stream(cap)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):     # other threads (the RCCL watchdog of a multi-rank run) may call HIP
+            self.sched.run(gstate, self.events)
+        g.replay()
+        torch.cuda.synchronize()
+        if self.events is not None:
+            t = [a.elapsed_time(b) for a, b in self.events]
+            if not all(np.isfinite(t)) or min(t) < 0 or sum(t) <= 0:
+                raise RuntimeError("events recorded inside the graph do not time")
+        self.graph, self.state = g, gstate
+        self.note = "hipGraph replay (torch.cuda.CUDAGraph over the C-ABI launches)"
+
+    def __call__(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self.sched.run(self.state, None)
+
+
+def settle(step, seconds=0.5):
+    """not part of the W warm-up steps: first touches of the library, workspaces and code objects, clock ramp of a cold device"""
+    t = time.perf_counter()
+    while time.perf_counter() - t < seconds:
+        step.eager()
+        torch.cuda.synchronize()
+
+
+def make_step(scene, k, backward, args, overlap):
+    st = Step(scene, k, backward, args, overlap=overlap)
+    settle(st)
+    if not args.no_graph:
+        try:
+            st.capture()
+        except Exception as e:                                       # noqa: BLE001 - any capture problem: stay eager, and say so
+            st.graph, st.note = None, "eager (graph capture failed: %s: %s)" % (type(e).__name__, str(e)[:80])
+            torch.cuda.synchronize()
+    return st
+
+
+def stage_times(scene, k, backward, args, reps=8):
+    """per-stage device time: the step IN ORDER on one stream (a stage's time is that stage alone), events on the launch stream.
+    First choice: events recorded by nodes of the in-order hipGraph (no host in the loop); fallback: eagerly issued in-order steps."""
+    st = Step(scene, k, backward, args, events=True, overlap=False)
+    settle(st, 0.2)
+    how = "events inside the in-order hipGraph of the step (external event-record nodes), %d replays right after the timed region" % reps
+    try:
+        if args.no_graph:
+            raise RuntimeError("--no-graph")
+        st.capture()
+        samples = []
+        for _ in range(reps):
+            st.graph.replay()
+            torch.cuda.synchronize()
+            samples.append([a.elapsed_time(b) for a, b in st.events])
+    except Exception as e:                                           # noqa: BLE001
+        how = "events around eagerly issued in-order steps, %d steps right after the timed region (in-graph events unavailable: %s)" % (reps, type(e).__name__)
+        torch.cuda.synchronize()
+        samples = []
+        for _ in range(reps):
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in st.stages]
+            st.eager(ev)
+            torch.cuda.synchronize()
+            samples.append([a.elapsed_time(b) for a, b in ev])
+    return st, [float(v) for v in np.mean(np.asarray(samples), axis=0)], how
+
+
+MAIN_KERNEL = {
+    "knnquery_k16": "grid build + knn_grid_wave_kernel (the K=36 search of the same points, which also writes the K=16 rows) + knn_replay_kernel for the tied rows",
+    "queryandgroup": "query_group_lds<16> (aligned 16-row pieces through LDS, cell-order schedule)",
+    "kpconv_fwd": "kpconv_fwd_kernel (v_mfma_f32_16x16x4_f32)",
+    "cbl_knnquery_k36": "cache hit on the wide search",
+    "cbl_neighbor_transpose": "nt_prep / nt_count / nt_bin / nt_finish (transposed K=36 table)",
+    "cbl_mining_loss_fwd": "contrast_pairs_kernel<8,5,true> + contrast_finalize_kernel",
+    "cbl_mining_loss_bwd": "contrast_gather_kernel<8>",
+    "neighbor_transpose_k16": "nt_prep / nt_count / nt_bin / nt_finish (transposed K=16 table)",
+    "queryandgroup_bwd": "grouping_bwd_csr_rows_kernel (K4 as a gather)",
+    "kpconv_bwd": "kpconv_bwd_kernel",
+}
+PMC_KERNEL = {"queryandgroup": "query_group_lds<16>", "kpconv_fwd": "kpconv_fwd_kernel<true>", "cbl_mining_loss_fwd": "contrast_pairs_kernel<8, 5, true>",
+              "cbl_mining_loss_bwd": "contrast_gather_kernel<8>", "queryandgroup_bwd": "grouping_bwd_csr_rows_kernel", "kpconv_bwd": "kpconv_bwd_kernel"}
+
+
+def run_gpu(args, D, world, rank, local):
     torch.cuda.set_device(local)
-    D.init("nccl" if world > 1 else None)                   # "nccl" is RCCL on ROCm; used for barriers / max-time only
-    dist = (world > 1)
-
+    D.init("nccl" if world > 1 else None)                           # "nccl" is RCCL on ROCm
+    if world > 1:
+        import torch.distributed as dist
+        assert dist.get_world_size() == args.gpus, "RCCL process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus)
     from contrastboundary_amd import hotpath
     n, c, k = args.points, args.channels, args.k
-    scene = hotpath.Scene.synthetic(n, c, seed=rank, b=1)    # every rank its own scene (weak scaling)
-    stages = hotpath.stages(scene, k)
-    state = {}
-    # the CBL head's neighbour search (independent of the stages before it) goes to a side stream, the rest runs in order
-    hints = () if args.no_nested else hotpath.search_hints(scene)
-    sched = hotpath.Schedule(stages, overlap=not args.no_overlap, hints=hints)
-    in_order = hotpath.Schedule(stages, overlap=False, hints=hints)
+    backward = not args.forward_only
+    scene = hotpath.Scene.synthetic(n, c, seed=rank, b=1)            # every rank its own scene (weak scaling)
+    step = make_step(scene, k, backward, args, overlap=not args.no_overlap)
+    sync = torch.cuda.synchronize
 
-    graph = [None]
+    elapsed = timed_region(step, args.steps, args.warmup, sync, D)
+    out = {
+        "metric": "points/sec through KNN+group+KPConv+CBL block, S3DIS N=40960 K=16",
+        "value": n * args.steps * world / elapsed, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "S3DIS-shaped synthetic scene (S-room), N=%d, K=%d, C=%d, 1 scene per GPU per step, %s; stages: %s"
+                   % (n, k, c, "forward + backward of the block" if backward else "forward block + CBL head", " -> ".join(step.names)),
+                   "parallelism": "scene-per-GPU replicas x%d (no data-path collective)" % world,
+                   "issue": step.note + "; every timed step is the same replay",
+                   "schedule": ("one search per geometry (the K=%d request runs the K=%d search the CBL head needs on the same points and is derived from it, tied "
+                                "rows replayed; the later request is a cache hit, the cache is dropped at the end of every step); " % (k, hotpath.CBL_NSAMPLE)
+                                if step.hints else "every search on its own; ") +
+                               ("all stages in order on one stream" if args.no_overlap else "the CBL branch on a side stream beside the main branch")},
+    }
+    if args.no_extra:
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        return finish(world)
 
-    def step(events=None):
-        # steps that carry per-stage events (every EVENT_EVERY-th of the timed region) are issued eagerly, in order on one stream, so that
-        # a stage's HIP-event time is that stage alone; all other steps replay the step's hipGraph (or, without it, run the schedule eagerly)
-        if events is not None:
-            in_order.run(state, events)
-        elif graph[0] is not None:
-            graph[0].replay()
-        else:
-            sched.run(state, None, side_after=args.side_after)
-
-    # set-up, not part of the W warm-up steps: first touches of the library, workspaces and code objects, clock ramp of a cold device
-    t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < 0.5:
-        step()
-        torch.cuda.synchronize()
-    graph_note = "eager"
-    if not args.no_graph:
-        # the step issues ~25 launches from Python: ~0.25-0.45 ms of host time against ~0.30 ms of device time, i.e. an eagerly issued
-        # step is as fast as the host happens to be.  Captured once (same kernels, same buffers, same schedule), it is replayed with
-        # ~15 us of host time per step.  Any failure to capture leaves the eager schedule in place.
-        try:
-            gstate = {}
-            cap_stream = torch.cuda.Stream()
-            cap_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(cap_stream):
-                for _ in range(3):
-                    sched.run(gstate, None, side_after=args.side_after)
-            torch.cuda.current_stream().wait_stream(cap_stream)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):     # other threads (the RCCL watchdog of a multi-rank run) may call HIP
-                sched.run(gstate, None, side_after=args.side_after)
-            g.replay()
-            torch.cuda.synchronize()
-            graph[0] = g
-            graph_note = "hipGraph replay of the step (torch.cuda.CUDAGraph over the C-ABI launches); steps with per-stage events issued eagerly"
-        except Exception as e:                                      # noqa: BLE001 - any capture problem: stay eager
-            graph[0] = None
-            graph_note = "eager (graph capture failed: %s)" % type(e).__name__
-            torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    D.barrier()
-    # per-stage HIP events on every EVENT_EVERY-th step of the timed region only: 12 event records cost ~55 us, 13 % of a step
-    EVENT_EVERY = 16 if args.steps >= 48 else 10 if args.steps >= 40 else 5 if args.steps >= 10 else 1      # 4 samples of the default 50 steps
-    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in stages] if s % EVENT_EVERY == 0 else None
-          for s in range(args.steps)]
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        step(ev[s])
-    torch.cuda.synchronize()
-    D.barrier()
-    elapsed = D.reduce_scalar(time.perf_counter() - t0, "max")
-
-    # per-stage average device time from the HIP events recorded inside the timed region (same stream as the launches)
-    timed = [e for e in ev if e is not None]
-    stage_ms = [float(np.mean([e[i][0].elapsed_time(e[i][1]) for e in timed])) for i in range(len(stages))]
-    names = [st[0] for st in stages]
-    # algorithmic bytes per stage; with the nested searches the first search stage does the work of both (the later request is a cache hit)
-    stage_bytes = [st[2] for st in stages]
-    if hints:
+    # ---- per-stage device times + roofline of the gather (in-order step, same process, right after the timed region)
+    st_in, stage_ms, how = stage_times(scene, k, backward, args)
+    names, stages = st_in.names, st_in.stages
+    stage_bytes = [s[2] for s in stages]
+    if st_in.hints:      # with the nested searches the first search stage does the work of both (the later request is a cache hit)
         first, later = names.index("knnquery_k%d" % k), names.index("cbl_knnquery_k%d" % hotpath.CBL_NSAMPLE)
         stage_bytes[first] += stage_bytes[later]
         stage_bytes[later] = 0
     gbps = lambda i: stage_bytes[i] / (stage_ms[i] * 1e-3) / 1e9
-    dom = int(np.argmax(stage_ms))
-    # kernel that dominates each stage (rocprofv3 --kernel-trace --stats of this same command: profiles/)
-    main_kernel = {"knnquery_k16": ("knn_grid_group_kernel<16> (+ 5-launch grid build, knn_replay_kernel for the tied queries)" if args.no_nested else
-                                    "the K=36 search of the same points (grid build + knn_grid_wave_kernel, which also writes the K=16 rows), knn_replay_kernel for the tied queries of both"),
-                   "queryandgroup": "query_group_lds<16> (aligned 16-row pieces through LDS, cell-order schedule)", "kpconv_fwd": "kpconv_fwd_kernel (v_mfma_f32_16x16x4_f32)",
-                   "cbl_knnquery_k36": "knn_grid_wave_kernel (select-then-sort, + 5-launch grid build)",
-                   "cbl_mining_loss_fwd": "contrast_bwd_kernel<64,8> in fused forward+gradient mode (+ finalize)", "cbl_mining_loss_bwd": "contrast_grad_scale_kernel"}
-    # `roofline`: the HBM-bound kernel of the path — the neighbour gather (north_star: ">= 50 % of the HBM roofline on the KNN-gather kernel");
-    # its stage is that ONE kernel, so the stage's HIP-event time is the kernel's launch duration plus the launch gap.  The longest
-    # stages (the two neighbour searches, the CBL mining kernel) are issue / latency / atomic bound, not HBM bound: they are listed under
-    # `longest_stage` and in the per-stage tables with their algorithmic rates, and analysed in DESIGN.md 6.2.
-    gi = names.index("queryandgroup")
-    roofline = {"kernel": main_kernel["queryandgroup"], "stage": "queryandgroup", "bound": "hbm",
-                "achieved": gbps(gi), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps(gi) / HBM_PEAK_GBS, "traffic": None,
-                "bytes_per_launch": stages[gi][2],
-                "note": "achieved = SURVEY 8(d) algorithmic bytes of the launch / its HIP-event time inside the timed region (events on the launch "
-                        "stream, on the eagerly issued steps); traffic = PMC FETCH_SIZE + WRITE_SIZE per launch (profiles/r01_pmc_traffic.json)",
-                "longest_stage": {"stage": names[dom], "kernel": main_kernel.get(names[dom], names[dom]), "ms": round(stage_ms[dom], 4),
-                                  "algorithmic_GBps": round(gbps(dom), 1),
-                                  "note": "few compulsory bytes: bound by VALU issue / memory latency / the exact replay of tied queries, not by HBM"},
-                "stage_ms": {names[i]: round(stage_ms[i], 4) for i in range(len(stages))},
-                "stage_algorithmic_GBps": {names[i]: (round(gbps(i), 1) if stage_bytes[i] else None) for i in range(len(stages))}}
-    # HBM traffic per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes of this same command with
-    # the default workload: tools/gpu_pmc.sh -> profiles/r01_pmc_traffic.json; counters cannot be read from inside the process)
     pmc = {}
-    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(pmc_file) and (n, c, k) == (40960, 64, 16):
-        pmc = json.load(open(pmc_file))
-    pmc_kernel = {"knnquery_k16": "knn_grid_group_kernel<16, true, false>", "queryandgroup": "query_group_lds<16>", "kpconv_fwd": "kpconv_fwd_kernel<true>",
-                  "cbl_knnquery_k36": "knn_grid_wave_kernel<true, false>", "cbl_mining_loss_fwd": "contrast_bwd_kernel<64, 8>",
-                  "cbl_mining_loss_bwd": "contrast_grad_scale_kernel"}
-    traffic = lambda stage: pmc.get(pmc_kernel.get(stage, ""), {}).get("hbm_bytes_per_launch")
-    roofline["traffic"] = traffic("queryandgroup")
-    roofline["longest_stage"]["traffic"] = traffic(names[dom])
+    if os.path.exists(PMC_FILE) and (n, c, k) == (40960, 64, 16):
+        pmc = json.load(open(PMC_FILE))
+    traffic = lambda stage: pmc.get(PMC_KERNEL.get(stage, ""), {}).get("hbm_bytes_per_launch")
+    gi = names.index("queryandgroup")
+    dom = int(np.argmax(stage_ms))
+    roofline = {"kernel": MAIN_KERNEL["queryandgroup"], "stage": "queryandgroup", "bound": "hbm", "achieved": gbps(gi), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": gbps(gi) / HBM_PEAK_GBS, "traffic": traffic("queryandgroup"), "bytes_per_launch": stages[gi][2],
+                "traffic_source": ("PMC FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE per launch from %s (%s)" % (os.path.relpath(PMC_FILE, ROOT), pmc.get("_meta", {}).get("kernels", "this kernel set"))
+                                   if traffic("queryandgroup") else "not measured for this kernel set (no %s)" % os.path.relpath(PMC_FILE, ROOT)),
+                "note": "achieved = SURVEY 8(d) algorithmic bytes of the launch / its HIP-event time; " + how,
+                "longest_stage": {"stage": names[dom], "kernel": MAIN_KERNEL.get(names[dom], names[dom]), "ms": round(stage_ms[dom], 4),
+                                  "algorithmic_GBps": round(gbps(dom), 1), "traffic": traffic(names[dom])},
+                "stage_ms": {names[i]: round(stage_ms[i], 4) for i in range(len(stages))},
+                "stage_sum_ms": round(float(sum(stage_ms)), 4),
+                "stage_algorithmic_GBps": {names[i]: (round(gbps(i), 1) if stage_bytes[i] else None) for i in range(len(stages))}}
+    if "queryandgroup_bwd" in names:
+        bi = names.index("queryandgroup_bwd")
+        roofline["scatter_k4"] = {"kernel": MAIN_KERNEL["queryandgroup_bwd"], "bound": "hbm", "achieved": gbps(bi), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": gbps(bi) / HBM_PEAK_GBS, "bytes_per_launch": stages[bi][2], "traffic": traffic("queryandgroup_bwd")}
+    ki = names.index("kpconv_fwd")
+    tf = stages[ki][3] / (stage_ms[ki] * 1e-3) / 1e12
+    roofline["mfma_kpconv"] = {"kernel": "kpconv_fwd_kernel", "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic("kpconv_fwd")}
     if rank == 0:
-        # what this device delivers on plain streams, measured here and now (after the timed region): a fill and a copy of the size of
-        # the gather's output — the 8 TB/s of the spec sheet is not reachable by any kernel, these are
+        # what this device delivers on plain streams, here and now: a fill and a copy of the size of the gather's output
         probe = torch.empty(stages[gi][2] // 4, dtype=torch.float32, device="cuda"); probe2 = torch.empty_like(probe)
+
         def _rate(fn, nbytes, reps=10):
             fn(); torch.cuda.synchronize()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -202,37 +335,71 @@ def main():
         copy = _rate(lambda: probe2.copy_(probe), 2 * probe.numel() * 4)
         roofline.update({"measured_fill_GBps": round(fill, 1), "measured_copy_GBps": round(copy, 1), "frac_of_measured_fill": gbps(gi) / fill})
         del probe, probe2
-    ki = names.index("kpconv_fwd")
-    roofline["mfma_kpconv"] = {"kernel": "kpconv_fwd_kernel", "bound": "mfma", "achieved": stages[ki][3] / (stage_ms[ki] * 1e-3) / 1e12,
-                               "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": stages[ki][3] / (stage_ms[ki] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                               "note": "f32-input MFMA; the kernel is bound by its vector instruction stream (influence weights, operand feed), not by the matrix pipe"}
+    out["roofline"] = roofline
 
+    # ---- the forward block alone (round 1's step), timed the same way
+    if backward:
+        fstep = make_step(scene, k, False, args, overlap=not args.no_overlap)
+        e_f = timed_region(fstep, args.steps, args.warmup, sync, D)
+        out["forward_only"] = {"value": n * args.steps * world / e_f, "ms_per_step": e_f / args.steps * 1e3, "stages": " -> ".join(fstep.names), "issue": fstep.note}
+
+    # ---- the same K steps with DDP's gradient all-reduce beside them (multi-rank runs)
+    if world > 1 and not args.no_allreduce:
+        ar = GradAllReduce(args.allreduce_floats, "cuda")
+
+        def step_ar():
+            ar.start(); step(); ar.finish()
+        e_ar = timed_region(step_ar, args.steps, args.warmup, sync, D)
+
+        def only_ar():
+            ar.start(); ar.finish()
+        e_only = timed_region(only_ar, args.steps, args.warmup, sync, D)
+        nbytes = 4 * args.allreduce_floats
+        out["grad_allreduce"] = {"value": n * args.steps * world / e_ar, "ms_per_step": e_ar / args.steps * 1e3, "bytes": nbytes,
+                                 "allreduce_alone_ms": e_only / args.steps * 1e3,
+                                 "allreduce_busbw_GBps": nbytes * 2 * (world - 1) / world / (e_only / args.steps) / 1e9,
+                                 "note": "one flat fp32 all-reduce of the reference network's 7,800,497 gradients per step over RCCL, issued beside the "
+                                         "step and joined at its end (what DDP adds, train.py:181-185); `value` above is the replica-only number"}
     if rank == 0:
-        out = {
-            "metric": "points/sec through KNN+group+KPConv+CBL block, S3DIS N=40960 K=16",
-            "value": n * args.steps * world / elapsed, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "S3DIS-shaped synthetic scene (S-room), N=%d, K=%d, C=%d, 1 scene per GPU per step; stages: %s"
-                       % (n, k, c, " -> ".join(s[0] for s in stages)), "parallelism": "scene-per-GPU replicas x%d (no data-path collective)" % world,
-                       "issue": graph_note,
-                       "schedule": (("one search per geometry: the K=%d request runs the K=%d search the CBL head declared for the same points "
-                                     "(neighbor_cache hint, dropped at the end of every step) and is derived from it (cbl_knnquery_nested: the first K of each list, tied rows "
-                                     "replayed); the later K=%d request is a cache hit; %s" % (k, hotpath.CBL_NSAMPLE, hotpath.CBL_NSAMPLE,
-                                        "all stages in order on one stream" if args.no_overlap else
-                                        "the CBL branch (needs the wide result only) on a side stream beside tie replay -> gather -> KPConv; steps with per-stage events in order"))
-                                    if hints else "in order on one stream" if args.no_overlap else
-                                    "two HIP streams: %s on a side stream, the other stages in order (hotpath.Schedule); the steps that carry "
-                                    "per-stage events run in order" % ", ".join(hotpath.SIDE_STAGES))},
-            "roofline": roofline,
-        }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, c, k, seed=0)
-        print(json.dumps(out))
-    if dist:
+            from tests import cpu_baseline
+            cb = cpu_baseline.run(n, c, k, seed=0, backward=backward)
+            # north_star: KNN + group on the GPU against the host CPU's (search stage + gather, in-order stage times)
+            gpu_kg = (stage_ms[names.index("knnquery_k%d" % k)] + stage_ms[gi]) * 1e-3
+            kg = cb["knn_plus_group_seconds"]
+            cb["knn_plus_group_speedup"] = {"gpu_seconds": gpu_kg, "vs_fastest_cpu_knn": (kg["knn_k%d_fastest_cpu" % k] + kg["queryandgroup_port"]) / gpu_kg,
+                                            "vs_port_allcores": (kg["knn_k%d_port_allcores" % k] + kg["queryandgroup_port"]) / gpu_kg,
+                                            "note": "GPU side = the step's whole search stage (it also carries the K=36 search) + the gather"}
+            out["cpu_baseline"] = cb
+        print(json.dumps(out), flush=True)
+    return finish(world)
+
+
+def finish(world):
+    if world > 1:
         import torch.distributed as tdist
-        tdist.destroy_process_group()
+        if tdist.is_initialized():
+            tdist.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn(args, argv)
+    from contrastboundary_amd import distributed as D
+    world, rank, local = D.env_world()
+    if world != args.gpus:
+        sys.stderr.write("bench.py: WORLD_SIZE=%d but --gpus %d\n" % (world, args.gpus))
+        return 2
+    if args.host_dry_run:
+        return host_dry_run(args, D, world, rank)
+    if not torch.cuda.is_available():
+        sys.stderr.write("bench.py: no GPU visible (the hot path has no CPU fallback)\n")
+        return 2
+    return run_gpu(args, D, world, rank, local)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -49,6 +49,17 @@ __device__ __forceinline__ float cbl_dist2(float ax, float ay, float az, float b
 __device__ __forceinline__ bool cbl_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline bool cbl_host_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// q = p / d for any 32-bit p and a divisor fixed per launch: umulhi(p, floor(2^32 / d)) is q or q - 1
+struct CblFastDiv { unsigned d, m; };
+static inline CblFastDiv cbl_fastdiv_make(unsigned d) { CblFastDiv f; f.d = d; f.m = d <= 1 ? 0xffffffffu : (unsigned)(0x100000000ull / d); return f; }
+__device__ __forceinline__ unsigned cbl_fastdiv(unsigned p, CblFastDiv f)
+{
+    if (f.d == 1) return p;
+    unsigned q = __umulhi(p, f.m);
+    if (p - q * f.d >= f.d) q++;
+    return q;
+}
+
 // ---- processing order ("*_ordered" entry points) ----------------------------------------------------------------------------
 // The point-walking kernels take an optional `order`: the sequence in which the points are processed (a permutation; the cell order of
 // the neighbour search, cbl_knnquery_ordered).  Workgroup b of a launch runs on XCD b % 8 (round-robin dispatch); a kernel walks

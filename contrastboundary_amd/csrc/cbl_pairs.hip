@@ -1,0 +1,269 @@
+// CBL pair mining + soft-NN loss with an ATOMIC-FREE gradient (SURVEY.md §7 hard part 6).
+//   ContrastHead.point_contrast     /root/reference/pytorch/model/heads.py:185-246  (posmask_cnt :145-149, dist_l2 :116-119, contrast_softnn :151-165)
+//   TF contrast_head                /root/reference/tensorflow/models/heads/head.py:462-807 (flags bit 0; the differences are listed in cbl.hip)
+//
+// d loss / d f_t has two halves: the pairs in which t is the CENTRE, coef_tj (f_t - f_j) over t's own neighbour list, and the pairs in which
+// t is a NEIGHBOUR, coef_it (f_t - f_i) over the points i that list t.  Round 1 scattered the second half with float atomics (16.9 M of
+// them, executed on the memory side of the fabric: 68 MB written for a 5 MB gradient).  Here
+//   pass A (contrast_pairs_kernel, one wave per point): mining, loss term, the scalar coef of every pair (m, nsample) and the centre half
+//          of the gradient, reduced in registers;
+//   pass B (contrast_gather_kernel, one wave per point): the neighbour half as a GATHER over the transposed neighbour table
+//          (cbl_neighbor_transpose), plus the centre half, times the global factor — plain stores only, no zero fill, deterministic.
+// Lane layout of both passes: a feature row of d floats is read by LR = d / 4 consecutive lanes (16 B each: one coalesced 4*d-byte
+// request per row instead of one 64 B sector per lane and float4), PP = 64 / LR rows per load instruction.
+#include "cbl_common.h"
+#include "wave_ops.h"
+
+namespace {
+
+
+// sum over the LR lanes that share a row (LR consecutive lanes, LR | 16): every one of them ends up with the total
+template <int LR> __device__ __forceinline__ float row_lanes_sum(float v)
+{
+    if (LR >= 2) v += dpp_mov_f<0xB1, 0xf>(v);                      // quad_perm [1,0,3,2]
+    if (LR >= 4) v += dpp_mov_f<0x4E, 0xf>(v);                      // quad_perm [2,3,0,1]
+    if (LR >= 8) v += dpp_mov_f<0x141, 0xf>(v);                     // row_half_mirror
+    if (LR >= 16) v += dpp_mov_f<0x140, 0xf>(v);                    // row_mirror
+    return v;
+}
+// sum over the PP = 64 / LR row slots (lanes with the same position inside their row)
+template <int LR> __device__ __forceinline__ float slots_sum(float v)
+{
+    if (LR <= 8) v += dpp_mov_f<0x128, 0xf>(v);                     // row_ror:8  (lane ^ 8 inside a row of 16)
+    if (LR <= 4) v += dpp_mov_f<0x124, 0xf>(v);                     // row_ror:4  (after ^8 every lane l holds l and l^8: rotate by 4 adds l^4, l^12)
+    if (LR <= 2) v += dpp_mov_f<0x122, 0xf>(v);
+    if (LR <= 1) v += dpp_mov_f<0x121, 0xf>(v);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+// flags: bit 0 TF flavour, bit 1 labels are int64 (read through their low words), bits 8..15 ncls > 0: soft labels + KL positives
+template <int LR, int UM, bool GRAD>
+__global__ __launch_bounds__(256) void contrast_pairs_kernel(unsigned m, int nsample, const float4* __restrict__ feat, const int* __restrict__ amax,
+                                                             const int* __restrict__ nidx, const int* __restrict__ order, float inv_temperature, int n_valid,
+                                                             int flags, float kl_thr, float* __restrict__ per_point, int* __restrict__ point_mask,
+                                                             float* __restrict__ coef, float4* __restrict__ grad_own)
+{
+    constexpr int PP = 64 / LR;
+    const int tf_variant = flags & 1, ls = 1 + ((flags >> 1) & 1), ncls = (flags >> 8) & 0xff;
+    const int ns = nsample - 1;                                     // self column dropped, heads.py:195-196 / head.py:560
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned nwg = (m + 3) >> 2;                              // 4 points per workgroup
+    for (unsigned v = blockIdx.x; v < 8 * cbl_xcd_per(nwg); v += gridDim.x) {
+        const unsigned r = cbl_xcd_slot(v, nwg) * 4 + wave;
+        if (r >= m) continue;
+        const int i = order ? order[r] : (int)r;
+        // ---- mining, lane = neighbour column
+        const bool colr = lane < ns;
+        const int raw = nidx[(size_t)i * nsample + 1 + (colr ? lane : 0)];
+        const bool real = raw >= 0 && raw < n_valid;
+        const int nbr_row = real ? raw : 0;
+        bool nb_r, pos_r;
+        if (ncls) {                                                  // collect_labels head.py:498-511, calc_dist 'kl' :189-191
+            const float* __restrict__ soft = reinterpret_cast<const float*>(amax);
+            float kl = 0.f;
+            for (int c = 0; c < ncls; c++) {
+                const float pi = soft[(size_t)i * ncls + c], pj = real ? soft[(size_t)nbr_row * ncls + c] : 0.f;
+                if (pi > 0.f) kl += pi * logf(pi / fmaxf(pj, 1e-12f));
+            }
+            nb_r = colr && real;
+            pos_r = nb_r && (kl < kl_thr);
+        } else {
+            const int my = amax[(size_t)i * ls], nl = amax[(size_t)nbr_row * ls];
+            nb_r = colr && real && (!tf_variant || (my >= 0 && nl >= 0));
+            pos_r = nb_r && (nl == my);                              // posmask_cnt :145-149 / head.py:538
+        }
+        const unsigned long long nbmask = __ballot(nb_r), posmask = __ballot(pos_r), realmask = __ballot(real);
+        const int cnt = __popcll(posmask), nvalid = __popcll(nbmask);
+        const bool valid = cnt > 0 && cnt < nvalid;                  // :212-213 / solve_samples_mask head.py:621-640 (wave-uniform)
+        if (!valid) {                                                // neither loss nor gradient: the labels decide before any feature is read
+            if (lane == 0) { per_point[i] = 0.f; point_mask[i] = 0; }
+            if (GRAD) {
+                if (lane < nsample) coef[(size_t)i * nsample + lane] = 0.f;
+                if (nsample > 64 && lane == 0) coef[(size_t)i * nsample + 64] = 0.f;
+                if (lane < LR) grad_own[(size_t)i * LR + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            continue;
+        }
+        // ---- distances, lane = (row slot s, part q of the row)
+        const int s = lane / LR, q = lane % LR;
+        const float4 fi = feat[(size_t)i * LR + q];
+        float shadow_d = 0.f;
+        if (tf_variant) shadow_d = sqrtf(fmaxf(row_lanes_sum<LR>((fi.x * fi.x + fi.y * fi.y) + (fi.z * fi.z + fi.w * fi.w)), 1e-12f));
+        float4 diff[UM]; float dist[UM], ex[UM];
+        bool isnb[UM], ispos[UM];
+        float mxl = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < UM; u++) {
+            const int j = u * PP + s;
+            const bool col = j < ns;
+            const int jj = col ? j : 0;
+            const int row = __shfl(nbr_row, jj);
+            const float4 fj = feat[(size_t)row * LR + q];
+            diff[u] = make_float4(fi.x - fj.x, fi.y - fj.y, fi.z - fj.z, fi.w - fj.w);
+            const float acc = row_lanes_sum<LR>((diff[u].x * diff[u].x + diff[u].y * diff[u].y) + (diff[u].z * diff[u].z + diff[u].w * diff[u].w));
+            dist[u] = tf_variant ? sqrtf(fmaxf(acc, 1e-12f)) : sqrtf(acc + 1e-12f);     // head.py:184-185 / dist_l2 heads.py:116-119
+            isnb[u] = col && ((nbmask >> jj) & 1ull);
+            ispos[u] = col && ((posmask >> jj) & 1ull);
+            const bool realu = (realmask >> jj) & 1ull;
+            // shadow columns of the TF flavour gather a zero feature row and DO enter the max-shift (head.py:752)
+            ex[u] = isnb[u] ? -dist[u] : ((tf_variant && col) ? (realu ? -dist[u] : -shadow_d) : -INFINITY);
+            mxl = fmaxf(mxl, ex[u]);
+        }
+        const float mx = group_max<64>(mxl);                         // :153
+        float pl = 0.f, al = 0.f;
+#pragma unroll
+        for (int u = 0; u < UM; u++) {
+            ex[u] = isnb[u] ? expf((ex[u] - mx) * inv_temperature) : 0.f;       // shift, then / T (:153-155)
+            pl += ispos[u] ? ex[u] : 0.f; al += ex[u];
+        }
+        const float P = group_sum<64>(pl) * (1.0f / LR), A = group_sum<64>(al) * (1.0f / LR);   // every pair is held by LR lanes
+        if (lane == 0) { per_point[i] = -logf(P / A + 1e-12f); point_mask[i] = 1; }              // contrast_softnn :161-163
+        if (!GRAD) continue;
+        // ---- gradient coefficients: d term / d dist_j, then / dist_j for the direction (f_i - f_j) / dist_j
+        const float ratio = P / A;
+        const float base = inv_temperature / (A * A * (ratio + 1e-12f));
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane == 0) coef[(size_t)i * nsample] = 0.f;              // the self column takes no part
+#pragma unroll
+        for (int u = 0; u < UM; u++) {
+            const int j = u * PP + s;
+            float c = isnb[u] ? ex[u] * ((ispos[u] ? A : 0.f) - P) * base / dist[u] : 0.f;
+            if (tf_variant && dist[u] <= 1e-6f) c = 0.f;            // sqrt(max(s, 1e-12)): flat below the clamp
+            if (q == 0 && j < ns) coef[(size_t)i * nsample + 1 + j] = c;
+            g.x += c * diff[u].x; g.y += c * diff[u].y; g.z += c * diff[u].z; g.w += c * diff[u].w;
+        }
+        g.x = slots_sum<LR>(g.x); g.y = slots_sum<LR>(g.y); g.z = slots_sum<LR>(g.z); g.w = slots_sum<LR>(g.w);
+        if (s == 0) grad_own[(size_t)i * LR + q] = g;
+    }
+}
+
+// pass B: grad[t] = (grad_own[t] + sum over the pairs p = (i, col) that list t of coef[p] (f_t - f_i)) * grad_loss * weight / count
+template <int LR>
+__global__ __launch_bounds__(256) void contrast_gather_kernel(unsigned m, CblFastDiv dv, const float4* __restrict__ feat, const float* __restrict__ coef,
+                                                              const float4* __restrict__ grad_own, const int* __restrict__ order,
+                                                              const int* __restrict__ inv_start, const int* __restrict__ inv_src,
+                                                              const float* __restrict__ stats, const float* __restrict__ grad_loss, float weight,
+                                                              float4* __restrict__ grad)
+{
+    constexpr int PP = 64 / LR;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = lane / LR, q = lane % LR;
+    const float count = stats[1];
+    const float scale = count > 0.f ? grad_loss[0] * weight / count : 0.f;      // torch.mean(loss) * w (:241-243); 0 when no point qualified (:233)
+    const unsigned nwg = (m + 3) >> 2;
+    for (unsigned v = blockIdx.x; v < 8 * cbl_xcd_per(nwg); v += gridDim.x) {
+        const unsigned r = cbl_xcd_slot(v, nwg) * 4 + wave;
+        if (r >= m) continue;
+        const int t = order ? order[r] : (int)r;
+        const int s0 = inv_start[r], s1 = inv_start[r + 1];
+        const float4 ft = feat[(size_t)t * LR + q];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (count > 0.f) {
+#pragma unroll 4
+            for (int base = s0; base < s1; base += PP) {
+                const int e = base + s;
+                const int p = e < s1 ? inv_src[e] : -1;
+                const float c = p >= 0 ? coef[p] : 0.f;
+                if (c != 0.f) {
+                    const unsigned i = cbl_fastdiv((unsigned)p, dv);
+                    const float4 fi = feat[(size_t)i * LR + q];
+                    acc.x += c * (ft.x - fi.x); acc.y += c * (ft.y - fi.y); acc.z += c * (ft.z - fi.z); acc.w += c * (ft.w - fi.w);
+                }
+            }
+        }
+        acc.x = slots_sum<LR>(acc.x); acc.y = slots_sum<LR>(acc.y); acc.z = slots_sum<LR>(acc.z); acc.w = slots_sum<LR>(acc.w);
+        if (s == 0) {
+            const float4 own = grad_own[(size_t)t * LR + q];
+            grad[(size_t)t * LR + q] = make_float4((own.x + acc.x) * scale, (own.y + acc.y) * scale, (own.z + acc.z) * scale, (own.w + acc.w) * scale);
+        }
+    }
+}
+
+template <int LR, int UM>
+int launch_pairs(unsigned g, hipStream_t st, int m, int nsample, const float* feat, const int* amax, const int* nidx, const int* order, float inv_t, int n_valid,
+                 int flags, float kl_thr, float* per_point, int* point_mask, float* coef, float* grad_own)
+{
+    if (coef) hipLaunchKernelGGL((contrast_pairs_kernel<LR, UM, true>), dim3(g), dim3(256), 0, st, (unsigned)m, nsample, reinterpret_cast<const float4*>(feat), amax, nidx,
+                                 order, inv_t, n_valid, flags, kl_thr, per_point, point_mask, coef, reinterpret_cast<float4*>(grad_own));
+    else hipLaunchKernelGGL((contrast_pairs_kernel<LR, UM, false>), dim3(g), dim3(256), 0, st, (unsigned)m, nsample, reinterpret_cast<const float4*>(feat), amax, nidx,
+                            order, inv_t, n_valid, flags, kl_thr, per_point, point_mask, nullptr, nullptr);
+    return cbl_status();
+}
+
+template <int LR>
+int dispatch_pairs_um(int U, unsigned g, hipStream_t st, int m, int nsample, const float* feat, const int* amax, const int* nidx, const int* order, float inv_t,
+                      int n_valid, int flags, float kl_thr, float* per_point, int* point_mask, float* coef, float* grad_own)
+{
+#define CBL_PAIRS_UM(UM_) return launch_pairs<LR, UM_>(g, st, m, nsample, feat, amax, nidx, order, inv_t, n_valid, flags, kl_thr, per_point, point_mask, coef, grad_own)
+    if (U <= 1) CBL_PAIRS_UM(1);
+    if (U <= 2) CBL_PAIRS_UM(2);
+    if (U <= 3) CBL_PAIRS_UM(3);
+    if (U <= 5) CBL_PAIRS_UM(5);
+    if (U <= 8) CBL_PAIRS_UM(8);
+    if (LR >= 16 && U <= 16) CBL_PAIRS_UM(16);
+#undef CBL_PAIRS_UM
+    return CBL_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+// deterministic reduction of the per-point terms (cbl.hip)
+int cbl_contrast_finalize_launch(int m, float weight, const float* per_point, const int* point_mask, float* stats, float* loss, hipStream_t st);
+
+CBL_EXPORT int cbl_contrast_pairs_forward(int m, int n_valid, int flags, int nsample, int d, const float* features, const void* labels, int num_classes,
+                                          float kl_threshold, const int* neighbor_idx, const int* order, float temperature, float weight,
+                                          float* per_point, int* point_mask, float* stats, float* loss, float* coef, float* grad_own, void* stream)
+{
+    if (m <= 0 || n_valid < 0 || nsample < 2 || nsample > 65 || d <= 0 || !(temperature > 0.f)) return CBL_ERR_BAD_ARG;
+    if (!features || !labels || !neighbor_idx || !per_point || !point_mask || !stats || !loss) return CBL_ERR_BAD_ARG;
+    if ((coef == nullptr) != (grad_own == nullptr)) return CBL_ERR_BAD_ARG;
+    if ((flags & ~3) || num_classes < 0 || num_classes > 255) return CBL_ERR_BAD_ARG;
+    if (!cbl_host_aligned16(features) || (grad_own && !cbl_host_aligned16(grad_own))) return CBL_ERR_BAD_ARG;
+    if (d % 4 || d > 64 || (d & (d - 1))) return CBL_ERR_UNSUPPORTED;
+    hipStream_t st = cbl_stream(stream);
+    const int fl = flags | (num_classes << 8);
+    const float inv_t = 1.0f / temperature;
+    const int* amax = reinterpret_cast<const int*>(labels);
+    const int lr = d / 4, pp = 64 / lr, U = (nsample - 1 + pp - 1) / pp;
+    unsigned g = cbl_round_up8(cbl_div_up(m, 4)); if (g > 256u * 32u) g = 256u * 32u;
+    int rc;
+#define CBL_PAIRS_LR(LR_) rc = dispatch_pairs_um<LR_>(U, g, st, m, nsample, features, amax, neighbor_idx, order, inv_t, n_valid, fl, kl_threshold, per_point, point_mask, coef, grad_own)
+    switch (lr) {
+        case 1: CBL_PAIRS_LR(1); break;
+        case 2: CBL_PAIRS_LR(2); break;
+        case 4: CBL_PAIRS_LR(4); break;
+        case 8: CBL_PAIRS_LR(8); break;
+        case 16: CBL_PAIRS_LR(16); break;
+        default: return CBL_ERR_UNSUPPORTED;
+    }
+#undef CBL_PAIRS_LR
+    if (rc) return rc;
+    return cbl_contrast_finalize_launch(m, weight, per_point, point_mask, stats, loss, st);
+}
+
+CBL_EXPORT int cbl_contrast_pairs_backward(int m, int nsample, int d, const float* features, const float* coef, const float* grad_own, const int* order,
+                                           const int* inv_start, const int* inv_src, const float* stats, const float* grad_loss, float weight,
+                                           float* grad_features, void* stream)
+{
+    if (m <= 0 || nsample < 2 || nsample > 65 || d <= 0) return CBL_ERR_BAD_ARG;
+    if (!features || !coef || !grad_own || !inv_start || !inv_src || !stats || !grad_loss || !grad_features) return CBL_ERR_BAD_ARG;
+    if (!cbl_host_aligned16(features) || !cbl_host_aligned16(grad_own) || !cbl_host_aligned16(grad_features)) return CBL_ERR_BAD_ARG;
+    if (d % 4 || d > 64 || (d & (d - 1))) return CBL_ERR_UNSUPPORTED;
+    hipStream_t st = cbl_stream(stream);
+    unsigned g = cbl_round_up8(cbl_div_up(m, 4)); if (g > 256u * 32u) g = 256u * 32u;
+    const CblFastDiv dv = cbl_fastdiv_make((unsigned)nsample);
+#define CBL_GATHER_LR(LR_) hipLaunchKernelGGL((contrast_gather_kernel<LR_>), dim3(g), dim3(256), 0, st, (unsigned)m, dv, reinterpret_cast<const float4*>(features), coef, \
+        reinterpret_cast<const float4*>(grad_own), order, inv_start, inv_src, stats, grad_loss, weight, reinterpret_cast<float4*>(grad_features))
+    switch (d / 4) {
+        case 1: CBL_GATHER_LR(1); break;
+        case 2: CBL_GATHER_LR(2); break;
+        case 4: CBL_GATHER_LR(4); break;
+        case 8: CBL_GATHER_LR(8); break;
+        case 16: CBL_GATHER_LR(16); break;
+        default: return CBL_ERR_UNSUPPORTED;
+    }
+#undef CBL_GATHER_LR
+    return cbl_status();
+}

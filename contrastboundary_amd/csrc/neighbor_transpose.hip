@@ -1,0 +1,343 @@
+// Transposed neighbour table ("CSR by target") and the scatter-add backward passes rewritten as gathers over it.
+//
+// The reference's backward kernels are scatter-adds with float atomics:
+//   grouping_backward_cuda_kernel      /root/reference/pytorch/lib/pointops/src/grouping/grouping_cuda_kernel.cu:16-25
+//   (and, through autograd's index_select backward, the neighbour half of the CBL gradient, pytorch/model/heads.py:185-246)
+// On MI355X a device-scope float atomic is executed on the memory side of the fabric (the eight XCD L2s are not coherent): measured in
+// round 1, 16.9 M lane-atomics = 68 MB of WRITE_SIZE for a 5 MB gradient.  SURVEY.md §7 hard part 6 prescribes the inverse index instead:
+// build, once per neighbour table, for every TARGET row the list of (source, column) pairs that point at it; every scatter-add then becomes
+// a gather with a segmented sum — no atomics, no zero fill, run-to-run deterministic, and (pairs kept in ascending order) the same summation
+// order as the reference's sequential loop on the CPU oracle.
+//
+// Build (no global atomics per pair, no sort): pairs are binned by TARGET TILE (64 consecutive targets of the processing order) with
+// LDS histograms — consecutive sources of the cell order point into a handful of target tiles, so a source tile issues a few dozen global
+// atomics for its 64 x nsample pairs — then every target tile orders its bin by (target, pair) in LDS.
+//   nt_prep    rank[order[r]] = r, counters zeroed
+//   nt_count   per source tile: LDS histogram over target tiles -> reserves a range in every bin it touches (one returning atomic per
+//              touched bin) and keeps the (bin, offset) list
+//   nt_bin     per source tile: exclusive scan of the bin sizes (redundantly per workgroup, a few hundred ints), then writes
+//              (target slot, pair) into its reserved ranges
+//   nt_finish  per target tile: counting sort by target in LDS, rank sort by pair inside each target's segment, writes inv_start / inv_src
+#include "cbl_common.h"
+
+namespace {
+
+constexpr int TT = 64;        // targets per target tile
+constexpr int TS = 64;        // sources per source tile
+constexpr int NB = 256;       // threads per workgroup
+constexpr int NT_MAX_TILES = 16384;    // LDS: 2 x 4 B per target tile in nt_bin
+constexpr int STAGE_CAP = 12288;       // pair ids a target tile orders in LDS (48 KB); larger bins are ordered through global scratch
+
+
+struct NtWs {
+    int* rank;          // n        (position of a point in `order`; unused without an order)
+    int* tile_cursor;   // ntt + 1  (pairs per target tile, accumulated by nt_count)
+    int* list_cursor;   // 1
+    int* tile_list_off; // nst      (where a source tile's (bin, offset) list starts)
+    int* tile_list_n;   // nst
+    int* tile_base;     // ntt + 1  (exclusive scan of tile_cursor, written by workgroup 0 of nt_bin)
+    int2* lists;        // P        ((bin, offset) records: at most one per pair)
+    int2* bins;         // P        ((target slot in its tile, pair))
+    int* scratch;       // P        (ordering space for bins beyond STAGE_CAP)
+};
+
+static size_t nt_align(size_t v) { return (v + 255) & ~(size_t)255; }
+static int nt_tiles(int n) { return (n + TT - 1) / TT; }
+static int nt_src_tiles(int m) { return (m + TS - 1) / TS; }
+
+static size_t nt_carve(NtWs& w, char* base, int m, int n, int nsample)
+{
+    const size_t P = (size_t)m * nsample;
+    const int ntt = nt_tiles(n), nst = nt_src_tiles(m);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += nt_align(bytes); return p; };
+    w.rank = (int*)take(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    w.tile_cursor = (int*)take(sizeof(int) * (size_t)(ntt + 2));       // + list_cursor right behind it: one zero fill
+    w.list_cursor = w.tile_cursor ? w.tile_cursor + ntt + 1 : nullptr;
+    w.tile_list_off = (int*)take(sizeof(int) * (size_t)(nst + 1));
+    w.tile_list_n = (int*)take(sizeof(int) * (size_t)(nst + 1));
+    w.tile_base = (int*)take(sizeof(int) * (size_t)(ntt + 2));
+    w.lists = (int2*)take(sizeof(int2) * (P ? P : 1));
+    w.bins = (int2*)take(sizeof(int2) * (P ? P : 1));
+    w.scratch = (int*)take(sizeof(int) * (P ? P : 1));
+    return off;
+}
+
+__global__ __launch_bounds__(NB) void nt_prep_kernel(int n, int nzero, const int* __restrict__ order, int* __restrict__ rank, int* __restrict__ zero)
+{
+    const int i = blockIdx.x * NB + threadIdx.x;
+    if (order && i < n) rank[order[i]] = i;
+    if (i < nzero) zero[i] = 0;
+}
+
+// the target tile of pair e of source tile `st` (or -1), and the pair's flat index p = source * ns + column
+__device__ __forceinline__ int nt_pair(unsigned e, int st, int m, int n, int ns, CblFastDiv dv, const int* __restrict__ idx, const int* __restrict__ order_src,
+                                       const int* __restrict__ rank, unsigned& p, int& slot)
+{
+    const unsigned sl = cbl_fastdiv(e, dv), col = e - sl * (unsigned)ns;
+    const int s_slot = st * TS + (int)sl;
+    const int s = order_src ? order_src[s_slot] : s_slot;
+    p = (unsigned)s * (unsigned)ns + col;
+    const int t = idx[p];
+    if ((unsigned)t >= (unsigned)n) return -1;                      // shadow / padding neighbours take no part
+    const int r = rank ? rank[t] : t;
+    slot = r & (TT - 1);
+    return r / TT;
+}
+
+__global__ __launch_bounds__(NB) void nt_count_kernel(int m, int n, int ns, int ntt, CblFastDiv dv, const int* __restrict__ idx, const int* __restrict__ order_src,
+                                                      const int* __restrict__ rank, int* __restrict__ tile_cursor, int* __restrict__ list_cursor,
+                                                      int* __restrict__ tile_list_off, int* __restrict__ tile_list_n, int2* __restrict__ lists)
+{
+    extern __shared__ int lds[];
+    int* hist = lds;                                                 // ntt
+    int2* mine = reinterpret_cast<int2*>(lds + ((ntt + 1) & ~1));    // up to min(ntt, TS * ns) records (8-byte aligned)
+    __shared__ int nmine, gbase;
+    const int st = blockIdx.x;
+    const int nsrc = min(TS, m - st * TS);
+    for (int e = threadIdx.x; e < ntt; e += NB) hist[e] = 0;
+    if (threadIdx.x == 0) nmine = 0;
+    __syncthreads();
+    const unsigned total = (unsigned)nsrc * (unsigned)ns;
+    for (unsigned e = threadIdx.x; e < total; e += NB) {
+        unsigned p; int slot;
+        const int tt = nt_pair(e, st, m, n, ns, dv, idx, order_src, rank, p, slot);
+        if (tt >= 0) atomicAdd(&hist[tt], 1);
+    }
+    __syncthreads();
+    for (int tt = threadIdx.x; tt < ntt; tt += NB) {
+        const int c = hist[tt];
+        if (c) {
+            const int off = atomicAdd(&tile_cursor[tt], c);         // this tile's range inside bin tt (relative to the bin's start)
+            mine[atomicAdd(&nmine, 1)] = make_int2(tt, off);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { gbase = atomicAdd(list_cursor, nmine); tile_list_off[st] = gbase; tile_list_n[st] = nmine; }
+    __syncthreads();
+    for (int e = threadIdx.x; e < nmine; e += NB) lists[gbase + e] = mine[e];
+}
+
+__global__ __launch_bounds__(NB) void nt_bin_kernel(int m, int n, int ns, int ntt, CblFastDiv dv, const int* __restrict__ idx, const int* __restrict__ order_src,
+                                                    const int* __restrict__ rank, const int* __restrict__ tile_cursor, const int* __restrict__ tile_list_off,
+                                                    const int* __restrict__ tile_list_n, const int2* __restrict__ lists, int* __restrict__ tile_base,
+                                                    int2* __restrict__ bins)
+{
+    extern __shared__ int lds[];
+    int* where = lds;                                                // ntt: start of bin tt, then (touched bins) start of this tile's range in it
+    int* hist = lds + ntt;                                           // ntt: running position inside the range
+    __shared__ int wave_tot[NB / 64];
+    const int st = blockIdx.x;
+    // exclusive scan of the bin sizes: thread t owns a contiguous chunk
+    const int per = (ntt + NB - 1) / NB;
+    const int c0 = threadIdx.x * per, c1 = min(ntt, c0 + per);
+    int sum = 0;
+    for (int e = c0; e < c1; e++) sum += tile_cursor[e];
+    int incl = sum;
+    for (int k = 1; k < 64; k <<= 1) { const int v = __shfl_up(incl, k); if ((threadIdx.x & 63) >= k) incl += v; }
+    if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int run = incl - sum;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) run += wave_tot[w];
+    for (int e = c0; e < c1; e++) { where[e] = run; hist[e] = 0; if (st == 0) tile_base[e] = run; run += tile_cursor[e]; }
+    if (st == 0 && threadIdx.x == NB - 1) tile_base[ntt] = run;      // the last thread's chunk ends at ntt (possibly empty): total number of pairs
+    __syncthreads();
+    const int nl = tile_list_n[st], lo = tile_list_off[st];
+    for (int e = threadIdx.x; e < nl; e += NB) { const int2 r = lists[lo + e]; where[r.x] += r.y; }
+    __syncthreads();
+    const int nsrc = min(TS, m - st * TS);
+    const unsigned total = (unsigned)nsrc * (unsigned)ns;
+    for (unsigned e = threadIdx.x; e < total; e += NB) {
+        unsigned p; int slot;
+        const int tt = nt_pair(e, st, m, n, ns, dv, idx, order_src, rank, p, slot);
+        if (tt >= 0) bins[where[tt] + atomicAdd(&hist[tt], 1)] = make_int2(slot, (int)p);
+    }
+}
+
+__global__ __launch_bounds__(NB) void nt_finish_kernel(int n, int ntt, const int* __restrict__ tile_base, const int2* __restrict__ bins, int* __restrict__ scratch,
+                                                       int* __restrict__ inv_start, int* __restrict__ inv_src)
+{
+    __shared__ int cnt[TT], lstart[TT + 1];
+    __shared__ int stage_lds[STAGE_CAP];
+    const int tt = blockIdx.x;
+    const int b0 = tile_base[tt], E = tile_base[tt + 1] - b0;
+    int* stage = E <= STAGE_CAP ? stage_lds : scratch + b0;          // flat addressing: LDS or global
+    if (threadIdx.x < TT) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < E; e += NB) atomicAdd(&cnt[bins[b0 + e].x], 1);
+    __syncthreads();
+    if (threadIdx.x < 64) {                                          // TT == 64: one wave scans the counts
+        const int c = cnt[threadIdx.x];
+        int incl = c;
+        for (int k = 1; k < 64; k <<= 1) { const int v = __shfl_up(incl, k); if ((int)threadIdx.x >= k) incl += v; }
+        lstart[threadIdx.x] = incl - c;
+        if (threadIdx.x == 63) lstart[TT] = incl;
+        const int r = tt * TT + threadIdx.x;
+        if (r < n) inv_start[r] = b0 + incl - c;
+        if (tt == ntt - 1 && threadIdx.x == 63) inv_start[n] = b0 + incl;
+        cnt[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < E; e += NB) {
+        const int2 r = bins[b0 + e];
+        stage[lstart[r.x] + atomicAdd(&cnt[r.x], 1)] = r.y;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // rank sort inside every target's segment (pair ids are distinct): ascending pairs = the reference loop's summation order
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int slot = wave; slot < TT; slot += NB / 64) {
+        const int s0 = lstart[slot], L = lstart[slot + 1] - s0;
+        for (int c = 0; c < L; c += 64) {
+            const int e = c + lane;
+            const int mine = e < L ? stage[s0 + e] : 0x7fffffff;
+            int rnk = 0;
+            for (int o = 0; o < L; o++) rnk += (stage[s0 + o] < mine) ? 1 : 0;
+            if (e < L) inv_src[b0 + s0 + rnk] = mine;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- K4 as a gather
+// grad_in[t, :] = sum over the pairs p of target t (ascending) of grad_out[p, :]          grouping_cuda_kernel.cu:16-25
+// lane = 4 channels of one target; LG = c / 4 lanes per target, 64 / LG targets per wave; sequence slots dealt to the XCDs in contiguous eighths
+template <int LG>
+__global__ __launch_bounds__(NB) void grouping_bwd_csr_kernel(unsigned n, const float4* __restrict__ go, const int* __restrict__ order,
+                                                              const int* __restrict__ inv_start, const int* __restrict__ inv_src, float4* __restrict__ gi)
+{
+    constexpr unsigned TPB = NB / LG;                                // targets per workgroup
+    const unsigned nwg = (n + TPB - 1) / TPB;
+    const unsigned g = threadIdx.x / LG, ch = threadIdx.x % LG;
+    for (unsigned v = blockIdx.x; v < 8 * cbl_xcd_per(nwg); v += gridDim.x) {
+        const unsigned r = cbl_xcd_slot(v, nwg) * TPB + g;
+        if (r >= n) continue;
+        const int s0 = inv_start[r], s1 = inv_start[r + 1];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int e = s0;
+        for (; e + 4 <= s1; e += 4) {                                // four independent row loads in flight
+            const int p0 = inv_src[e], p1 = inv_src[e + 1], p2 = inv_src[e + 2], p3 = inv_src[e + 3];
+            const float4 a = go[(size_t)p0 * LG + ch], b = go[(size_t)p1 * LG + ch], c = go[(size_t)p2 * LG + ch], d = go[(size_t)p3 * LG + ch];
+            acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+            acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+            acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += c.w;
+            acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
+        }
+        for (; e < s1; e++) { const float4 a = go[(size_t)inv_src[e] * LG + ch]; acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w; }
+        const unsigned t = order ? (unsigned)order[r] : r;
+        gi[(size_t)t * LG + ch] = acc;
+    }
+}
+
+// any channel count: lane = one channel of one target
+__global__ __launch_bounds__(NB) void grouping_bwd_csr_scalar_kernel(unsigned n, int c, const float* __restrict__ go, const int* __restrict__ order,
+                                                                     const int* __restrict__ inv_start, const int* __restrict__ inv_src, float* __restrict__ gi)
+{
+    const unsigned long long total = (unsigned long long)n * (unsigned)c;
+    for (unsigned long long e = (unsigned long long)blockIdx.x * NB + threadIdx.x; e < total; e += (unsigned long long)gridDim.x * NB) {
+        const unsigned r = (unsigned)(e / (unsigned)c), ch = (unsigned)(e - (unsigned long long)r * (unsigned)c);
+        float acc = 0.f;
+        for (int k = inv_start[r]; k < inv_start[r + 1]; k++) acc += go[(size_t)inv_src[k] * c + ch];
+        gi[(size_t)(order ? order[r] : (int)r) * c + ch] = acc;
+    }
+}
+
+// rows that are a SLICE of wider rows (the feature part of queryandgroup's (m, nsample, 3 + c) gradient: stride 3 + c floats, offset 3, so
+// no 16-byte alignment): one wave per target, lane = channel, a row is one 4*c-byte contiguous request; eight rows in flight
+__global__ __launch_bounds__(NB) void grouping_bwd_csr_rows_kernel(unsigned n, int c, int stride, int off, const float* __restrict__ go,
+                                                                   const int* __restrict__ order, const int* __restrict__ inv_start,
+                                                                   const int* __restrict__ inv_src, float* __restrict__ gi)
+{
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned nwg = (n + 3) >> 2;
+    for (unsigned v = blockIdx.x; v < 8 * cbl_xcd_per(nwg); v += gridDim.x) {
+        const unsigned r = cbl_xcd_slot(v, nwg) * 4 + wave;
+        if (r >= n) continue;
+        const int s0 = inv_start[r], s1 = inv_start[r + 1];
+        const unsigned t = order ? (unsigned)order[r] : r;
+        for (unsigned ch = lane; ch < (unsigned)c; ch += 64) {
+            float acc = 0.f;
+            int e = s0;
+            for (; e + 8 <= s1; e += 8) {
+                float x[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) x[u] = go[(size_t)inv_src[e + u] * stride + off + ch];
+#pragma unroll
+                for (int u = 0; u < 8; u++) acc += x[u];
+            }
+            for (; e < s1; e++) acc += go[(size_t)inv_src[e] * stride + off + ch];
+            gi[(size_t)t * c + ch] = acc;
+        }
+    }
+}
+
+}  // namespace
+
+CBL_EXPORT size_t cbl_neighbor_transpose_workspace_bytes(int m, int n, int nsample)
+{
+    if (m < 0 || n < 0 || nsample <= 0) return 0;
+    NtWs w;
+    return nt_carve(w, nullptr, m, n, nsample);
+}
+
+CBL_EXPORT int cbl_neighbor_transpose(int m, int n, int nsample, const int* idx, const int* order_src, const int* order_dst, int* inv_start, int* inv_src,
+                                      void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (m < 0 || n < 0 || nsample <= 0 || !inv_start) return CBL_ERR_BAD_ARG;
+    if ((long long)m * nsample > 0x7fffffffLL) return CBL_ERR_BAD_ARG;
+    hipStream_t st = cbl_stream(stream);
+    const int ntt = nt_tiles(n), nst = nt_src_tiles(m);
+    if (m == 0 || n == 0) {
+        if (hipMemsetAsync(inv_start, 0, sizeof(int) * (size_t)(n + 1), st) != hipSuccess) return cbl_status();
+        return CBL_OK;
+    }
+    if (!idx || !inv_src || !workspace) return CBL_ERR_BAD_ARG;
+    if (ntt > NT_MAX_TILES) return CBL_ERR_UNSUPPORTED;              // n > 1 M points: the scatter kernels remain
+    NtWs w;
+    if (nt_carve(w, (char*)workspace, m, n, nsample) > workspace_bytes) return CBL_ERR_WORKSPACE;
+    const CblFastDiv dv = cbl_fastdiv_make((unsigned)nsample);
+    const int nzero = ntt + 2;
+    hipLaunchKernelGGL(nt_prep_kernel, dim3(cbl_div_up(n > nzero ? n : nzero, NB)), dim3(NB), 0, st, n, nzero, order_dst, w.rank, w.tile_cursor);
+    const int* rank = order_dst ? w.rank : nullptr;
+    const long long cap = (long long)TS * nsample < ntt ? (long long)TS * nsample : ntt;
+    hipLaunchKernelGGL(nt_count_kernel, dim3(nst), dim3(NB), sizeof(int) * (size_t)((ntt + 1) & ~1) + sizeof(int2) * (size_t)cap, st, m, n, nsample, ntt, dv, idx, order_src, rank,
+                       w.tile_cursor, w.list_cursor, w.tile_list_off, w.tile_list_n, w.lists);
+    hipLaunchKernelGGL(nt_bin_kernel, dim3(nst), dim3(NB), sizeof(int) * 2 * (size_t)ntt, st, m, n, nsample, ntt, dv, idx, order_src, rank, w.tile_cursor,
+                       w.tile_list_off, w.tile_list_n, w.lists, w.tile_base, w.bins);
+    hipLaunchKernelGGL(nt_finish_kernel, dim3(ntt), dim3(NB), 0, st, n, ntt, w.tile_base, w.bins, w.scratch, inv_start, inv_src);
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_grouping_backward_csr(int n, int c, const float* grad_output, const int* order_dst, const int* inv_start, const int* inv_src,
+                                         float* grad_input, void* stream)
+{
+    if (n < 0 || c <= 0) return CBL_ERR_BAD_ARG;
+    if (n == 0) return CBL_OK;
+    if (!grad_output || !inv_start || !inv_src || !grad_input) return CBL_ERR_BAD_ARG;
+    hipStream_t st = cbl_stream(stream);
+    const bool v4 = (c % 4 == 0) && cbl_host_aligned16(grad_output) && cbl_host_aligned16(grad_input);
+    const int lg = c / 4;
+#define CBL_GBC(LG_) { const unsigned nwg = cbl_div_up(n, NB / LG_); unsigned g = cbl_round_up8(nwg); if (g > 256u * 16u) g = 256u * 16u;  \
+        hipLaunchKernelGGL((grouping_bwd_csr_kernel<LG_>), dim3(g), dim3(NB), 0, st, (unsigned)n, reinterpret_cast<const float4*>(grad_output), order_dst,  \
+                           inv_start, inv_src, reinterpret_cast<float4*>(grad_input)); return cbl_status(); }
+    if (v4) switch (lg) {
+        case 1: CBL_GBC(1) case 2: CBL_GBC(2) case 4: CBL_GBC(4) case 8: CBL_GBC(8) case 16: CBL_GBC(16) case 32: CBL_GBC(32) case 64: CBL_GBC(64)
+        default: break;
+    }
+#undef CBL_GBC
+    hipLaunchKernelGGL(grouping_bwd_csr_scalar_kernel, dim3(cbl_grid_for((long long)n * c, NB)), dim3(NB), 0, st, (unsigned)n, c, grad_output, order_dst, inv_start,
+                       inv_src, grad_input);
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_grouping_backward_csr_rows(int n, int c, int row_stride, int col_offset, const float* grad_output, const int* order_dst,
+                                              const int* inv_start, const int* inv_src, float* grad_input, void* stream)
+{
+    if (n < 0 || c <= 0 || col_offset < 0 || row_stride < col_offset + c) return CBL_ERR_BAD_ARG;
+    if (n == 0) return CBL_OK;
+    if (!grad_output || !inv_start || !inv_src || !grad_input) return CBL_ERR_BAD_ARG;
+    if (row_stride == c && col_offset == 0) return cbl_grouping_backward_csr(n, c, grad_output, order_dst, inv_start, inv_src, grad_input, stream);
+    unsigned g = cbl_round_up8(cbl_div_up(n, 4)); if (g > 256u * 32u) g = 256u * 32u;
+    hipLaunchKernelGGL(grouping_bwd_csr_rows_kernel, dim3(g), dim3(NB), 0, cbl_stream(stream), (unsigned)n, c, row_stride, col_offset, grad_output, order_dst,
+                       inv_start, inv_src, grad_input);
+    return cbl_status();
+}

@@ -32,52 +32,65 @@ def parse_stage(stage, num_layers):
 
 
 class _PointContrast(Function):
-    """Training (features need a gradient): ONE pass computes the loss terms and the gradient up to its global factor
-    (cbl_point_contrast_forward_grad), the backward pass only scales it.  Inference: forward kernel alone."""
+    """Forward: mining + loss terms (+, when the features need a gradient, the scalar coefficient of every pair and the centre half of
+    the gradient) in one pass — cbl_contrast_pairs_forward.  Backward: the neighbour half as a gather over the transposed neighbour
+    table — cbl_contrast_pairs_backward: no atomics, no zero fill, deterministic (SURVEY.md 7 hard part 6)."""
 
     @staticmethod
-    def forward(ctx, features, amax, neighbor_idx, temperature, weight):
+    def forward(ctx, features, amax, neighbor_idx, temperature, weight, transposed):
         m, d = features.shape
         nsample = neighbor_idx.shape[1]
         dev = features.device
-        l64 = amax.dtype == torch.int64                                  # the reference's hard targets as they are: no int32 copy
+        flags = 2 if amax.dtype == torch.int64 else 0                    # the reference's hard targets as they are: no int32 copy
         per_point = torch.empty(m, dtype=torch.float32, device=dev)
         mask = torch.empty(m, dtype=torch.int32, device=dev)
         stats = torch.empty(2, dtype=torch.float32, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         L = _lib.lib()
-        if ctx.needs_input_grad[0]:
-            unit = torch.zeros_like(features)
-            fn = L.cbl_point_contrast_forward_grad_l64 if l64 else L.cbl_point_contrast_forward_grad
-            _lib.check(fn(_c_int(m), _c_int(nsample), _c_int(d), _lib.ptr(features), _lib.ptr(amax), _lib.ptr(neighbor_idx),
-                          _c_float(temperature), _c_float(weight), _lib.ptr(per_point), _lib.ptr(mask), _lib.ptr(stats),
-                          _lib.ptr(loss), _lib.ptr(unit), _lib.stream_of(features)), "cbl_point_contrast_forward_grad")
-            ctx.save_for_backward(unit, stats)
+        grad = ctx.needs_input_grad[0]
+        order = inv_start = inv_src = None
+        if grad:
+            if transposed is None:
+                transposed = pointops.neighbor_transpose(neighbor_idx, m)
+            if transposed is None:
+                raise _lib.CblError("point_contrast: no transposed neighbour table for this size")
+            order, inv_start, inv_src = transposed
         else:
-            fn = L.cbl_point_contrast_forward_l64 if l64 else L.cbl_point_contrast_forward
-            _lib.check(fn(_c_int(m), _c_int(nsample), _c_int(d), _lib.ptr(features), _lib.ptr(amax), _lib.ptr(neighbor_idx),
-                          _c_float(temperature), _c_float(weight), _lib.ptr(per_point), _lib.ptr(mask), _lib.ptr(stats),
-                          _lib.ptr(loss), _lib.stream_of(features)), "cbl_point_contrast_forward")
-        ctx.weight = weight
+            order = pointops.spatial_order(neighbor_idx)
+        coef = torch.empty((m, nsample), dtype=torch.float32, device=dev) if grad else None
+        own = torch.empty((m, d), dtype=torch.float32, device=dev) if grad else None
+        _lib.check(L.cbl_contrast_pairs_forward(_c_int(m), _c_int(0x7fffffff), _c_int(flags), _c_int(nsample), _c_int(d), _lib.ptr(features), _lib.ptr(amax),
+                                                _c_int(0), _c_float(0.0), _lib.ptr(neighbor_idx), _lib.ptr(order), _c_float(temperature), _c_float(weight),
+                                                _lib.ptr(per_point), _lib.ptr(mask), _lib.ptr(stats), _lib.ptr(loss), _lib.ptr(coef), _lib.ptr(own),
+                                                _lib.stream_of(features)), "cbl_contrast_pairs_forward")
+        if grad:
+            ctx.save_for_backward(features, coef, own, stats, inv_start, inv_src, *(() if order is None else (order,)))
+        ctx.weight, ctx.nsample = weight, nsample
         ctx.mark_non_differentiable(mask)
         ctx.set_materialize_grads(False)        # no zero tensor for the (integer) mask output in backward: that was one fill launch per step
         return loss.view(()), mask
 
     @staticmethod
     def backward(ctx, grad_loss, _grad_mask):
-        unit, stats = ctx.saved_tensors
         if grad_loss is None:                                            # the loss took no part in what was differentiated
-            return None, None, None, None, None
-        g = torch.empty_like(unit)
+            return None, None, None, None, None, None
+        features, coef, own, stats, inv_start, inv_src, *rest = ctx.saved_tensors
+        order = rest[0] if rest else None
+        m, d = features.shape
+        g = torch.empty_like(features)
         gl = grad_loss.reshape(1).to(torch.float32).contiguous()
-        _lib.check(_lib.lib().cbl_contrast_grad_scale(ctypes.c_longlong(unit.numel()), _lib.ptr(unit), _lib.ptr(stats), _lib.ptr(gl), _c_float(ctx.weight),
-                                                      _lib.ptr(g), _lib.stream_of(unit)), "cbl_contrast_grad_scale")
-        return g, None, None, None, None
+        _lib.check(_lib.lib().cbl_contrast_pairs_backward(_c_int(m), _c_int(ctx.nsample), _c_int(d), _lib.ptr(features), _lib.ptr(coef), _lib.ptr(own),
+                                                          _lib.ptr(order), _lib.ptr(inv_start), _lib.ptr(inv_src), _lib.ptr(stats), _lib.ptr(gl),
+                                                          _c_float(ctx.weight), _lib.ptr(g), _lib.stream_of(features)), "cbl_contrast_pairs_backward")
+        return g, None, None, None, None, None
 
 
-def point_contrast(features, labels, neighbor_idx, temperature=1.0, weight=0.1, return_mask=False):
+def point_contrast(features, labels, neighbor_idx, temperature=1.0, weight=0.1, return_mask=False, transposed=None):
     """features (m,d) f32, labels (m,ncls) f32 soft/one-hot OR (m,) int class ids, neighbor_idx (m,nsample) i32 incl. the self column
-    -> scalar loss (device tensor, differentiable w.r.t. features)"""
+    -> scalar loss (device tensor, differentiable w.r.t. features).  transposed: pointops.neighbor_transpose(neighbor_idx, m) if the
+    caller already has it (it is looked up in / built into the active neighbour cache otherwise)."""
+    if features.shape[1] not in (4, 8, 16, 32, 64):
+        raise NotImplementedError(f"point_contrast: feature width {features.shape[1]} (the fused head covers 4, 8, 16, 32, 64)")
     m = features.shape[0]
     if labels.dim() == 2:
         amax = torch.empty(m, dtype=torch.int32, device=features.device)
@@ -86,7 +99,7 @@ def point_contrast(features, labels, neighbor_idx, temperature=1.0, weight=0.1, 
                    "cbl_label_argmax")
     else:
         amax = labels.contiguous() if labels.dtype in (torch.int64, torch.int32) else labels.to(torch.int32).contiguous()
-    loss, mask = _PointContrast.apply(features.contiguous(), amax, neighbor_idx.contiguous(), float(temperature), float(weight))
+    loss, mask = _PointContrast.apply(features.contiguous(), amax, neighbor_idx.contiguous(), float(temperature), float(weight), transposed)
     return (loss, mask) if return_mask else loss
 
 
@@ -108,6 +121,13 @@ class ContrastHead(torch.nn.Module):
         assert head_cfg.sample in ["cnt", "glb", "sub", "subspatial", "pts", "label", "vote"], f"not support sample = {head_cfg.sample}"
         if "project" in head_cfg and head_cfg.project:
             raise NotImplementedError("projection MLP before the contrast is not part of the fused path")
+        if self.ftype != "latent":
+            # 'f_out' / 'out' hand the head the stage widths (pointtransformer_seg.py: planes 32 ... 512); the fused kernels cover rows of 4 ... 64 floats
+            planes = [int(v) for v in config.planes] if "planes" in config else [32, 64, 128, 256, 512]
+            bad = [(n, i) for n, i in self.stages if planes[i] not in (4, 8, 16, 32, 64)]
+            if bad:
+                raise NotImplementedError(f"ContrastHead ftype={head_cfg.ftype!r}: stages {bad} are wider than the 64 floats per row the fused HIP "
+                                          "path covers (the shipped config contrasts the 32-d 'latent' features)")
         self.temperature = float(head_cfg.temperature) if "temperature" in head_cfg and head_cfg.temperature is not None else 1.0
         self.weight = float(head_cfg.weight[1:])                         # 'w.1' -> 0.1, heads.py:241-243
 

@@ -1,6 +1,9 @@
 """The measured hot path (BASELINE.json metric): one pass over one S3DIS-shaped scene of
     KNN (K=16)  ->  neighbour grouping (xyz-centred + features, (N,K,3+C))  ->  local aggregation over the K
     neighbours  ->  CBL head (neighbour search + pair mining + loss, forward and backward w.r.t. the features)
+    ->  (backward=True, BASELINE config C2 "forward/backward") the backward of the block: transposed neighbour table, the
+    scatter half of the grouping (K4 as a gather) and KPConv's gradients w.r.t. features and kernel weights, driven by
+    fixed synthetic upstream gradients
 Each stage is one or a few C-ABI launches on the current stream; `stages()` lists them with the ALGORITHMIC bytes
 / flops of SURVEY.md §8(d) so bench.py can turn a measured duration into a roofline fraction.  `Schedule` is how bench.py runs a step:
 one neighbour search per geometry (the K = 16 table derived from the K = 36 search the CBL head needs on the same points, tied rows
@@ -38,12 +41,28 @@ class Scene:
         return dict(xyz=xyz, feat=feat, labels=labels, offset=off, kernel_points=kpts, kernel_weights=kw, latent=latent)
 
     @staticmethod
+    def upstream_numpy(n, c, k, seed=0):
+        """the gradients the block's backward is driven with: d loss / d grouped (n,k,3+c) and d loss / d kpconv (n,c)"""
+        import numpy as np
+        rng = np.random.default_rng(seed + 2000)
+        return dict(grad_grouped=rng.normal(size=(n, k, 3 + c)).astype(np.float32), grad_kpconv=rng.normal(size=(n, c)).astype(np.float32))
+
+    @staticmethod
     def synthetic(n, c, seed=0, b=1, device="cuda"):
         a = Scene.synthetic_numpy(n, c, seed, b)
         t = lambda v: torch.from_numpy(v).to(device)
         sc = Scene(t(a["xyz"]), t(a["feat"]), t(a["labels"]), t(a["offset"]))
         sc.kernel_points, sc.kernel_weights, sc.latent = t(a["kernel_points"]), t(a["kernel_weights"]), t(a["latent"])
+        sc.seed = seed
         return sc
+
+    def upstream(self, k):
+        """device copies of upstream_numpy (made once per scene and k)"""
+        key = ("upstream", k)
+        if key not in self.__dict__:
+            a = Scene.upstream_numpy(self.n, self.c, k, getattr(self, "seed", 0))
+            self.__dict__[key] = {name: torch.from_numpy(v).to(self.xyz.device) for name, v in a.items()}
+        return self.__dict__[key]
 
 
 # stages that do not depend on the stage before them: the CBL head's neighbour search needs the coordinates only, so `run_step` issues
@@ -52,10 +71,13 @@ class Scene:
 SIDE_STAGES = ("cbl_knnquery_k%d" % CBL_NSAMPLE,)
 
 
-def stages(scene, k=16):
-    """-> list of (name, fn(state) -> None, algorithmic_bytes, algorithmic_flops); fns communicate through `state`"""
+def stages(scene, k=16, backward=False):
+    """-> list of (name, fn(state) -> None, algorithmic_bytes, algorithmic_flops); fns communicate through `state`.
+    backward: also the backward legs of the block (BASELINE config C2)."""
     n, c = scene.n, scene.c
     st = []
+    feat = scene.feat.detach().requires_grad_(True) if backward else scene.feat
+    kweights = scene.kernel_weights.detach().requires_grad_(True) if backward else scene.kernel_weights
 
     def knn(s):
         s["idx"], s["dist2"] = pointops.knnquery_raw(k, scene.xyz, scene.xyz, scene.offset, scene.offset)
@@ -63,14 +85,14 @@ def stages(scene, k=16):
     st.append(("knnquery_k%d" % k, knn, 12 * n + 12 * n + 8 * n * k, 8.0 * n * n))
 
     def group(s):
-        s["grouped"] = pointops.queryandgroup(k, scene.xyz, scene.xyz, scene.feat, s["idx"], scene.offset, scene.offset, use_xyz=True)
+        s["grouped"] = pointops.queryandgroup(k, scene.xyz, scene.xyz, feat, s["idx"], scene.offset, scene.offset, use_xyz=True)
     # a3 fused queryandgroup: 4mK + 12n + 12m + 4nC + 4mK(3+C)
     st.append(("queryandgroup", group, 4 * n * k + 12 * n + 12 * n + 4 * n * c + 4 * n * k * (3 + c), 3.0 * n * k))
 
     extent = 0.12      # KP_extent 1.0 * radius 0.1*... / density (local_aggregation_operators.py:664); ~ the K=16 neighbourhood radius here
 
     def kpconv(s):
-        s["kpconv"] = local_aggregation.kpconv(scene.xyz, scene.xyz, s["idx"], scene.feat, scene.kernel_points, scene.kernel_weights, extent)
+        s["kpconv"] = local_aggregation.kpconv(scene.xyz, scene.xyz, s["idx"], feat, scene.kernel_points, kweights, extent)
     # a15 (idx given): 12n + 12n0 + 4n0C + 4nK + 4nC bytes; flops 2nK*KP*(C + 6) + 2n*KP*C  
     st.append(("kpconv_fwd", kpconv, 12 * n + 12 * n + 4 * n * c + 4 * n * k + 4 * n * c, 2.0 * n * k * KP * (c + 6) + 2.0 * n * KP * c))
 
@@ -81,19 +103,49 @@ def stages(scene, k=16):
         s["cbl_idx"], _ = pointops.knnquery_raw(CBL_NSAMPLE, scene.xyz, scene.xyz, scene.offset, scene.offset, algo="set")
     st.append(("cbl_knnquery_k%d" % CBL_NSAMPLE, cbl_knn, 24 * n + 8 * n * CBL_NSAMPLE, 8.0 * n * n))
 
+    def cbl_transpose(s):
+        # the CBL gradient's neighbour half is a gather over the transposed K = 36 table (no atomics): 4nK idx in, 4(n+1) + 4nK out
+        s["cbl_transposed"] = pointops.neighbor_transpose(s["cbl_idx"], n)
+    st.append(("cbl_neighbor_transpose", cbl_transpose, 8 * n * CBL_NSAMPLE + 4 * (n + 1), 0.0))
+
     def cbl_fwd(s):
         s["cbl_latent"] = scene.latent.detach().requires_grad_(True)
-        s["cbl_loss"] = heads.point_contrast(s["cbl_latent"], scene.labels, s["cbl_idx"], 1.0, 0.1)
-    # a8 mining (idx given): 4n(K-1) idx + 4nd features + 4n labels in, 8n out.  The latent needs a gradient, so this stage runs the
-    # fused forward + gradient kernel (one gather for both): + 4nd for the unscaled gradient it leaves behind
-    st.append(("cbl_mining_loss_fwd", cbl_fwd, 4 * n * (CBL_NSAMPLE - 1) + 4 * n * d + 4 * n + 8 * n + 4 * n * d,
+        s["cbl_loss"] = heads.point_contrast(s["cbl_latent"], scene.labels, s["cbl_idx"], 1.0, 0.1, transposed=s["cbl_transposed"])
+    # a8 mining (idx given): 4nK idx + 4nd features + 4n labels in, 8n out; the latent needs a gradient, so the pass also leaves the pair
+    # coefficients (4nK) and the centre half of the gradient (4nd) behind
+    st.append(("cbl_mining_loss_fwd", cbl_fwd, 4 * n * CBL_NSAMPLE + 4 * n * d + 4 * n + 8 * n + 4 * n * CBL_NSAMPLE + 4 * n * d,
                1.0 * n * (CBL_NSAMPLE - 1) * (8 * d + 50)))
 
     def cbl_bwd(s):
         s["cbl_loss"].backward()
         s["cbl_grad"] = s["cbl_latent"].grad
-    # backward = apply grad_loss * weight / #qualifying points to the stored gradient: read 4nd, write 4nd
-    st.append(("cbl_mining_loss_bwd", cbl_bwd, 8 * n * d, 1.0 * n * d))
+    # backward = the neighbour half gathered over the transposed table: 4(n+1) + 4nK table, 4nK coefficients, 4nd features,
+    # 4nd centre half in, 4nd gradient out
+    st.append(("cbl_mining_loss_bwd", cbl_bwd, 4 * (n + 1) + 8 * n * CBL_NSAMPLE + 12 * n * d, 3.0 * n * (CBL_NSAMPLE - 1) * d))
+    if not backward:
+        return st
+
+    def transpose(s):
+        s["transposed"] = pointops.neighbor_transpose(s["idx"], n)
+    st.append(("neighbor_transpose_k%d" % k, transpose, 8 * n * k + 4 * (n + 1), 0.0))
+
+    def group_bwd(s):
+        # K4 (grouping_cuda_kernel.cu:16-25) for the feature columns of d loss / d grouped, as a gather over the transposed table
+        up = scene.upstream(k)
+        feat.grad = None
+        s["grouped"].backward(up["grad_grouped"])
+        s["grad_feat_group"] = feat.grad
+    # 4mK (table) + 4mKC (gradient rows read) + 4nC (written)
+    st.append(("queryandgroup_bwd", group_bwd, 4 * n * k + 4 * n * k * c + 4 * n * c, 1.0 * n * k * c))
+
+    def kpconv_bwd(s):
+        up = scene.upstream(k)
+        feat.grad = None; kweights.grad = None
+        s["kpconv"].backward(up["grad_kpconv"])
+        s["grad_feat_kpconv"], s["grad_kernel_weights"] = feat.grad, kweights.grad
+    # a15 backward (idx given): forward's inputs + the output gradient in, feature and kernel-weight gradients out; flops 2x the forward's
+    st.append(("kpconv_bwd", kpconv_bwd, 12 * n + 12 * n + 4 * n * c + 4 * n * k + 4 * n * c + 4 * n * c + 4 * KP * c,
+               2.0 * (2.0 * n * k * KP * (c + 6) + 2.0 * n * KP * c)))
     return st
 
 
@@ -102,10 +154,10 @@ def search_hints(scene):
     return ((scene.xyz, CBL_NSAMPLE, "set"),)
 
 
-def run_once(scene, k=16, state=None):
+def run_once(scene, k=16, state=None, backward=False):
     """every stage in order on the current stream (the reference's schedule)"""
     state = {} if state is None else state
-    for _, fn, _, _ in stages(scene, k):
+    for _, fn, _, _ in stages(scene, k, backward):
         fn(state)
     return state
 

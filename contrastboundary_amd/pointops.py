@@ -39,90 +39,9 @@ def _as_int(v):
     return int(v.item()) if isinstance(v, torch.Tensor) else int(v)
 
 
-_ws_cache = {}
-
-
-def _workspace(nbytes, device):
-    """per-(device, stream) scratch for the grid KNN; grown on demand, reused across calls"""
-    if nbytes == 0:
-        return None
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    ws = _ws_cache.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
-        _ws_cache[key] = ws
-    return ws
-
-
-# ------------------------------------------------------------------------------------------------ processing order
-# The grid build of a self-search sorts the supports into cells; that sequence ("cell order") is a spatially coherent processing
-# order for every kernel that walks the points and gathers their neighbours.  It is kept per geometry (the coordinate tensor) and per
-# stream, and handed to the *_ordered C entry points: the VALUES never depend on it — a stale or missing order only costs locality.
-ORDER_MIN_POINTS = 8192         # below this the tables sit in L2 anyway
-_order_registry = collections.OrderedDict()     # (data_ptr, n, version, device) -> {stream id: (order tensor, stream that holds it)}
-_ORDER_REGISTRY_MAX = 16
-
-
-def _order_key(points):
-    try:
-        version = points._version
-    except RuntimeError:                                            # inference tensors do not track a version counter
-        version = -1
-    return (points.data_ptr(), points.shape[0], version, points.device)
-
-
-def _order_wanted(points, stream_id):
-    """does a self-search over `points` on this stream still have to produce the cell order?"""
-    if points.shape[0] < ORDER_MIN_POINTS or not use_spatial_order:
-        return False
-    ent = _order_registry.get(_order_key(points))
-    return ent is None or stream_id not in ent
-
-
-def _order_register(points, order, stream):
-    key = _order_key(points)
-    ent = _order_registry.setdefault(key, {})
-    ent[stream.cuda_stream] = (order, stream)                      # no event here (a record costs ~4 us of stream time): see spatial_order
-    _order_registry.move_to_end(key)
-    while len(_order_registry) > _ORDER_REGISTRY_MAX:
-        _order_registry.popitem(last=False)
-    cache = neighbor_cache.active()
-    if cache is not None:                                            # a cached pass owns what it registers: dropped with the cache
-        cache.order_keys.append(key)
-
-
-def _order_alias(idx, points):
-    """the neighbour table of a self-search over `points` shares their processing order (ops that are given idx but no coordinates)"""
-    ent = _order_registry.get(_order_key(points))
-    if ent:
-        _order_registry[_order_key(idx)] = ent
-        while len(_order_registry) > _ORDER_REGISTRY_MAX:
-            _order_registry.popitem(last=False)
-        cache = neighbor_cache.active()
-        if cache is not None:
-            cache.order_keys.append(_order_key(idx))
-
-
-def spatial_order(points):
-    """-> int32 (n,) processing order of `points` (cell order of an earlier self-search over the same tensor; also keyed by the
-    neighbour table that search returned), or None"""
-    if not use_spatial_order or points.shape[0] < ORDER_MIN_POINTS:
-        return None
-    ent = _order_registry.get(_order_key(points))
-    if not ent:
-        return None
-    cur = torch.cuda.current_stream(points.device)
-    hit = ent.get(cur.cuda_stream)
-    if hit is not None:
-        return hit[0]
-    order, producer = next(iter(ent.values()))                   # produced on another stream: order after it, keep it alive for this one
-    cur.wait_stream(producer)
-    order.record_stream(cur)
-    ent[cur.cuda_stream] = (order, cur)                             # ordered behind the producer from here on
-    return order
-
-
-use_spatial_order = True
+from .neighbor_state import (ORDER_MIN_POINTS, _ORDER_REGISTRY_MAX, _order_alias, _order_key, _order_register, _order_registry,  # noqa: F401
+                             _order_wanted, _workspace, _ws_cache, host_offsets, neighbor_cache, spatial_order)
+from . import neighbor_state
 
 
 # ------------------------------------------------------------------------------------------------ K2
@@ -172,139 +91,6 @@ def set_knn_tie_policy(policy):
     return prev
 
 
-class neighbor_cache:
-    """Per-forward neighbour-index cache.  The reference's network asks for the SAME neighbour search
-    many times per forward — every PointTransformerLayer of a stage runs knnquery(nsample, p, p, o, o) twice (blocks.py:34-35), the
-    decoder blocks again, 57 launches in total — because each pointops call is self-contained.  Inside
-
-        with pointops.neighbor_cache() as nc:
-            logits, stage_list = model(inputs); loss = criterion(logits, target, stage_list)
-
-    identical requests (same nsample, same coordinate / offset tensors by storage, shape and version) are answered from the
-    first result; nothing else changes, so modules keep the reference's signatures.  An 'auto' (reference-order) result also
-    serves a later 'set' request.  The cache holds references to the keyed tensors, so storage cannot be recycled under it; it
-    is dropped when the context exits.  `nc.hits` / `nc.misses` count requests."""
-    _tls = threading.local()             # the active cache is per thread (nn.DataParallel replicas run the mirrors from worker threads)
-
-    def __init__(self):
-        self.store, self.hits, self.misses = {}, 0, 0
-        self.host = {}                                              # host copies of offset tensors, see host_offsets()
-        self.hints = {}                                             # geometry -> (widest nsample it will be searched with, algo), see hint()
-        self.wide = {}                                              # geometry -> (nsample, algo) of the widest result in the store
-        self.derived = 0                                            # requests answered from a wider result (cbl_knnquery_prefix)
-        self.order_keys = []                                        # processing orders registered during this pass (dropped with it)
-
-    def hint(self, xyz, nsample, algo="set", new_xyz=None, offset=None, new_offset=None):
-        """Declare that this geometry will be searched with up to `nsample` neighbours during the pass (a network knows its config:
-        the blocks' K = 8 / 16 and the CBL head's K = 36 look at the same points).  The first narrower request then runs the WIDE search
-        once (tie policy `algo`) and every narrower one is derived from it — rows decided by a tie are replayed, so the values are those
-        of the separate searches.  Without offsets the hint applies to any offsets used with these coordinates."""
-        self.hints[self._geo(xyz, xyz if new_xyz is None else new_xyz)] = (int(nsample), algo)
-
-    def _geo(self, xyz, new_xyz):
-        return (xyz.data_ptr(), tuple(xyz.shape), new_xyz.data_ptr(), tuple(new_xyz.shape))
-
-    def __enter__(self):
-        self._prev = neighbor_cache.active()
-        neighbor_cache._tls.cache = self
-        return self
-
-    def __exit__(self, *exc):
-        neighbor_cache._tls.cache = self._prev
-        if not getattr(self, "keep", False):
-            self.store.clear()
-            self.host.clear()
-            self.wide.clear()
-            for key in self.order_keys:
-                _order_registry.pop(key, None)
-            self.order_keys.clear()
-        return False
-
-    @staticmethod
-    def active():
-        return getattr(neighbor_cache._tls, "cache", None)
-
-    ignore_version = False               # static geometry (geometry.StaticGeometry): tensors are refreshed IN PLACE between uses
-
-    def _key(self, kind, algo, tensors):
-        if self.ignore_version:
-            return (kind, algo) + tuple((t.data_ptr(), tuple(t.shape)) for t in tensors)
-        return (kind, algo) + tuple((t.data_ptr(), tuple(t.shape), t._version) for t in tensors)
-
-    def _host_key(self, o):
-        return (o.data_ptr(), tuple(o.shape)) if self.ignore_version else (o.data_ptr(), tuple(o.shape), o._version)
-
-    # Entries may have been produced on ANOTHER stream (geometry prefetch, contrastboundary_amd/geometry.py): each carries the
-    # event recorded behind its producer; a consumer stream waits for it and is registered with the allocator as a user.
-    def _deliver(self, entry):
-        outs, _keys, event, stream = entry
-        if event is not None:
-            cur = torch.cuda.current_stream(outs[0].device)
-            if stream != cur:
-                cur.wait_event(event)
-                for t in outs:
-                    t.record_stream(cur)
-        return outs
-
-    def _stamp(self, outs, keys):
-        dev = outs[0].device
-        if getattr(self, "record_events", False):
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(dev))
-            return (outs, keys, ev, torch.cuda.current_stream(dev))
-        return (outs, keys, None, None)
-
-    def lookup(self, nsample, algo, tensors):
-        for a in ((algo, "auto") if algo == "set" else (algo,)):
-            hit = self.store.get(self._key(nsample, a, tensors))
-            if hit is not None:
-                self.hits += 1
-                return self._deliver(hit)
-        self.misses += 1
-        return None
-
-    def insert(self, nsample, algo, tensors, idx, dist2, event=None):
-        if event is not None:                                        # recorded by the producer itself (behind the part that made idx / dist2)
-            self.store[self._key(nsample, algo, tensors)] = ((idx, dist2), tensors, event, torch.cuda.current_stream(idx.device))
-        else:
-            self.store[self._key(nsample, algo, tensors)] = self._stamp((idx, dist2), tensors)
-        geo = self._geo(tensors[0], tensors[1])
-        if algo in ("auto", "set", "grid") and nsample > self.wide.get(geo, (0, None))[0]:
-            self.wide[geo] = (nsample, algo)
-
-    def wider(self, nsample, tensors):
-        """-> (nsample_wide, idx_wide, dist2_wide) of a stored wider result over the same tensors, or None"""
-        w = self.wide.get(self._geo(tensors[0], tensors[1]))
-        if w is None or w[0] <= nsample:
-            return None
-        hit = self.store.get(self._key(w[0], w[1], tensors))
-        if hit is None:
-            return None
-        idx, dist2 = self._deliver(hit)
-        return w[0], idx, dist2
-
-    def lookup_fps(self, stride, tensors):
-        hit = self.store.get(self._key(("fps", stride), "", tensors))
-        return None if hit is None else self._deliver(hit)
-
-    def insert_fps(self, stride, tensors, new_p, new_o, idx):
-        self.store[self._key(("fps", stride), "", tensors)] = self._stamp((new_p, new_o, idx), tensors)
-
-
-def host_offsets(o):
-    """cumulative end offsets `o` (b) as a python list.  Inside a neighbour cache the answer is remembered per tensor (the cache keeps
-    the tensor alive, so its storage cannot be recycled under the key) and offsets made by `fps_downsample` are known without asking
-    the device at all; outside a cache this is the same blocking read as the reference's `offset[i].item()` loops."""
-    cache = neighbor_cache.active()
-    if cache is None:
-        return o.cpu().tolist()
-    key = cache._host_key(o)
-    hit = cache.host.get(key)
-    if hit is None:
-        hit = cache.host[key] = (o.cpu().tolist(), o)
-    return hit[0]
-
-
 def fps_downsample(p, o, stride):
     """TransitionDown's sampling step (blocks.py:61-68): per cloud n_b // stride furthest-point samples.
     -> (new_p (m,3), new_o (b) i32, idx (m) i32); cached per forward like the neighbour searches (the coordinates handed back are the
@@ -338,6 +124,13 @@ def knnquery_raw(nsample, xyz, new_xyz, offset, new_offset, algo="auto"):
     nsample = _as_int(nsample)
     if new_xyz is None:
         new_xyz = xyz
+    # validated once, before the cache logic: the nested / derived paths below reach the kernels without passing _knnquery_uncached
+    _req(xyz, torch.float32, "xyz", 2); _req(new_xyz, torch.float32, "new_xyz", 2)
+    _req(offset, torch.int32, "offset", 1); _req(new_offset, torch.int32, "new_offset", 1)
+    if not 1 <= nsample <= 1024:
+        raise ValueError(f"nsample={nsample} outside [1, 1024] (knnquery_cuda_kernel.cu:89)")
+    if xyz.shape[1] != 3 or new_xyz.shape[1] != 3:
+        raise ValueError("xyz / new_xyz: expected (n, 3)")
     if algo == "auto" and _tie_policy != "reference":
         algo = _tie_policy
     cache = neighbor_cache.active()
@@ -423,16 +216,12 @@ def _knnquery_nested(nsample_wide, algo_wide, nsample, algo, xyz, new_xyz, offse
     _lib.check(rc, "cbl_knnquery_nested")
     if order is not None:
         _order_register(xyz, order, cur)
-    if self_search and n >= ORDER_MIN_POINTS and use_spatial_order:
+    if self_search and n >= ORDER_MIN_POINTS and neighbor_state.use_spatial_order:
         _order_alias(wi, xyz); _order_alias(idx, xyz)
     return wi, wd, idx, dist2
 
 
 def _knnquery_uncached(nsample, xyz, new_xyz, offset, new_offset, algo):
-    _req(xyz, torch.float32, "xyz", 2); _req(new_xyz, torch.float32, "new_xyz", 2)
-    _req(offset, torch.int32, "offset", 1); _req(new_offset, torch.int32, "new_offset", 1)
-    if not 1 <= nsample <= 1024:
-        raise ValueError(f"nsample={nsample} outside [1, 1024] (knnquery_cuda_kernel.cu:89)")
     n, m, b = xyz.shape[0], new_xyz.shape[0], offset.shape[0]
     # every element is written by the kernels, so no zero fill (the reference zero-fills, pointops.py:40-41)
     idx = torch.empty((m, nsample), dtype=torch.int32, device=xyz.device)
@@ -463,9 +252,61 @@ def _knnquery_uncached(nsample, xyz, new_xyz, offset, new_offset, algo):
                 _lib.check(rc, "cbl_knnquery_ordered")
         fn = L.cbl_knnquery_set if algo == "set" else L.cbl_knnquery_anytie if algo == "anytie" else L.cbl_knnquery
         _lib.check(fn(*args, _lib.ptr(ws), ctypes.c_size_t(ws.numel() if ws is not None else 0), st), "cbl_knnquery")
-        if self_search and n >= ORDER_MIN_POINTS and use_spatial_order:
+        if self_search and n >= ORDER_MIN_POINTS and neighbor_state.use_spatial_order:
             _order_alias(idx, xyz)
     return idx, dist2
+
+
+# ------------------------------------------------------------------------------------------------ transposed neighbour table
+TRANSPOSE_MIN_PAIRS = 1 << 16      # below this a scatter with atomics is as quick as building the table (unless the table is cached)
+
+
+def neighbor_transpose(idx, n, build=True):
+    """Transposed neighbour table of idx (m, nsample) over n target rows (cbl_neighbor_transpose, SURVEY.md 7 hard part 6):
+    -> (order or None, inv_start (n+1) i32, inv_src (m*nsample) i32), or None (build=False and nothing cached).
+    Segment r of inv_src lists, ascending, the flat pairs p = source * nsample + column with idx[p] == order[r] (== r without an order).
+    It depends on the table alone: it is built once per table (kept in neighbor_state's registry; a neighbour cache drops what was built
+    during its pass) and shared by every backward pass that scatters through it, also on autograd's thread; the processing order (cell
+    order of the search that made idx) only makes build and consumers local."""
+    _req(idx, torch.int32, "idx", 2)
+    hit = neighbor_state.transpose_lookup(idx)
+    if hit is not None or not build:
+        return hit
+    m, nsample = idx.shape
+    order = spatial_order(idx) if m == n else None
+    L = _lib.lib()
+    inv_start = torch.empty(n + 1, dtype=torch.int32, device=idx.device)
+    inv_src = torch.empty(max(m * nsample, 1), dtype=torch.int32, device=idx.device)
+    ws = _workspace(max(L.cbl_neighbor_transpose_workspace_bytes(_c_int(m), _c_int(n), _c_int(nsample)), 1), idx.device)
+    rc = L.cbl_neighbor_transpose(_c_int(m), _c_int(n), _c_int(nsample), _lib.ptr(idx), _lib.ptr(order), _lib.ptr(order), _lib.ptr(inv_start),
+                                  _lib.ptr(inv_src), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(idx))
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, "cbl_neighbor_transpose")
+    neighbor_state.transpose_register(idx, order, inv_start, inv_src)
+    return order, inv_start, inv_src
+
+
+def _scatter_rows(grad_rows, idx, n, col0=0, c=None):
+    """grad_in (n, c) = scatter-add of grad_rows[..., col0 : col0 + c] (grad_rows (m, nsample, width) contiguous) through idx: a gather over
+    the transposed table where that pays (or the table is already there), the reference's atomic scatter (grouping_cuda_kernel.cu:16-25) otherwise"""
+    m, nsample, width = grad_rows.shape
+    c = width - col0 if c is None else c
+    L = _lib.lib()
+    tr = neighbor_transpose(idx, n, build=(m * nsample >= TRANSPOSE_MIN_PAIRS))
+    if tr is not None:
+        order, inv_start, inv_src = tr
+        grad_in = torch.empty((n, c), dtype=torch.float32, device=grad_rows.device)
+        _lib.check(L.cbl_grouping_backward_csr_rows(_c_int(n), _c_int(c), _c_int(width), _c_int(col0), _lib.ptr(grad_rows), _lib.ptr(order),
+                                                    _lib.ptr(inv_start), _lib.ptr(inv_src), _lib.ptr(grad_in), _lib.stream_of(grad_rows)),
+                   "cbl_grouping_backward_csr_rows")
+        return grad_in
+    if col0 or c != width:
+        grad_rows = grad_rows[..., col0:col0 + c].contiguous()
+    grad_in = torch.zeros((n, c), dtype=torch.float32, device=grad_rows.device)
+    _lib.check(L.cbl_grouping_backward(_c_int(m), _c_int(nsample), _c_int(c), _lib.ptr(grad_rows), _lib.ptr(idx), _lib.ptr(grad_in),
+                                       _lib.stream_of(grad_rows)), "cbl_grouping_backward")
+    return grad_in
 
 
 class KNNQuery(Function):
@@ -505,11 +346,7 @@ class Grouping(Function):
     def backward(ctx, grad_output):
         idx, = ctx.saved_tensors
         grad_output = grad_output.contiguous()          # the reference forgets this
-        m, nsample, c = grad_output.shape
-        grad_input = torch.zeros((ctx.n, c), dtype=torch.float32, device=grad_output.device)
-        _lib.check(_lib.lib().cbl_grouping_backward(_c_int(m), _c_int(nsample), _c_int(c), _lib.ptr(grad_output), _lib.ptr(idx),
-                                                    _lib.ptr(grad_input), _lib.stream_of(grad_output)), "cbl_grouping_backward")
-        return grad_input, None
+        return _scatter_rows(grad_output, idx, ctx.n), None
 
 
 grouping = Grouping.apply
@@ -540,19 +377,14 @@ class _QueryAndGroup(Function):
         m, nsample = idx.shape
         L = _lib.lib()
         g_xyz = g_new = g_feat = None
-        gf = grad_out[..., 3:].contiguous() if use_xyz else grad_out.contiguous()
+        grad_out = grad_out.contiguous()
         if ctx.needs_input_grad[2]:
-            g_feat = torch.zeros((n_feat, c), dtype=torch.float32, device=grad_out.device)
-            _lib.check(L.cbl_grouping_backward(_c_int(m), _c_int(nsample), _c_int(c), _lib.ptr(gf), _lib.ptr(idx), _lib.ptr(g_feat),
-                                               _lib.stream_of(gf)), "cbl_grouping_backward")
+            g_feat = _scatter_rows(grad_out, idx, n_feat, 3 if use_xyz else 0, c)      # the feature columns, read where they lie
         if use_xyz and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
-            gx = grad_out[..., :3].contiguous()
             if ctx.needs_input_grad[0]:
-                g_xyz = torch.zeros((n_xyz, 3), dtype=torch.float32, device=grad_out.device)
-                _lib.check(L.cbl_grouping_backward(_c_int(m), _c_int(nsample), _c_int(3), _lib.ptr(gx), _lib.ptr(idx), _lib.ptr(g_xyz),
-                                                   _lib.stream_of(gx)), "cbl_grouping_backward")
+                g_xyz = _scatter_rows(grad_out, idx, n_xyz, 0, 3)
             if ctx.needs_input_grad[1]:
-                g_new = -gx.sum(1)
+                g_new = -grad_out[..., :3].sum(1)
         return g_xyz, g_new, g_feat, None, None
 
 

@@ -141,6 +141,27 @@ int cbl_grouping_forward(int m, int nsample, int c, const float* input, const in
 int cbl_grouping_forward_ordered(int m, int nsample, int c, const float* input, const int* idx, const int* order, float* output, void* stream);
 int cbl_grouping_backward(int m, int nsample, int c, const float* grad_output, const int* idx, float* grad_input, void* stream);
 
+/* Transposed neighbour table ("CSR by target", SURVEY.md 7 hard part 6): for every target row the pairs (source, column) of
+ * idx (m, nsample) that point at it.  Segment r = [inv_start[r], inv_start[r+1]) of inv_src lists, ASCENDING, the flat pair indices
+ * p = source * nsample + column with idx[p] == order_dst[r] (== r without an order); entries outside [0, n) (shadow padding) are left out.
+ * order_src (m) / order_dst (n): optional processing sequences of the sources / targets (the cell order of the search: the same array
+ * for a self-search); they only make the build local, the table's CONTENT is defined by order_dst alone.  It turns every scatter-add
+ * backward of the path (grouping_cuda_kernel.cu:16-25 and the index_select backward inside heads.py:185-246) into a gather with a segmented
+ * sum in the reference loop's order: no atomics, no zero fill, deterministic.  n <= 1 M (CBL_ERR_UNSUPPORTED beyond); no global atomic per pair.
+ *   -> inv_start (n+1) i32, inv_src (m*nsample) i32 (the first inv_start[n] entries are used) */
+size_t cbl_neighbor_transpose_workspace_bytes(int m, int n, int nsample);
+int cbl_neighbor_transpose(int m, int n, int nsample, const int* idx, const int* order_src, const int* order_dst, int* inv_start, int* inv_src,
+                           void* workspace, size_t workspace_bytes, void* stream);
+/* K4 grouping_backward_cuda_launcher (grouping_cuda_kernel.h:14) as a gather over the transposed table of its idx:
+ *   grad_input[order_dst[r], :] = sum over segment r of grad_output[p, :]   (written, not accumulated: no pre-zeroing; same summation order
+ *   as the reference loop run sequentially, so bit-identical to the CPU oracle) */
+int cbl_grouping_backward_csr(int n, int c, const float* grad_output, const int* order_dst, const int* inv_start, const int* inv_src,
+                              float* grad_input, void* stream);
+/* the same for rows that are a column slice of wider rows: pair p's row = grad_output[p * row_stride + col_offset .. + c) — the feature part
+ * of queryandgroup's (m, nsample, 3 + c) gradient (pointops.py:90-98: torch.cat) without first copying the slice out */
+int cbl_grouping_backward_csr_rows(int n, int c, int row_stride, int col_offset, const float* grad_output, const int* order_dst,
+                                   const int* inv_start, const int* inv_src, float* grad_input, void* stream);
+
 /* K5/K6  interpolation_{forward,backward}_cuda_launcher  interpolation/interpolation_cuda_kernel.h:13-14.
  *   forward : input (m,c), idx (n,k), weight (n,k) -> output (n,c) +=     (caller pre-zeroes)
  *   backward: grad_output (n,c), idx, weight -> grad_input (m,c) +=       (caller pre-zeroes) */
@@ -243,6 +264,21 @@ int cbl_tf_contrast_forward_grad_kl(int m, int n_valid, int nsample, int d, cons
                                     float* stats, float* loss, float* grad_unit, void* stream);
 int cbl_contrast_grad_scale(long long total, const float* grad_unit, const float* stats, const float* grad_loss, float weight,
                             float* grad_features, void* stream);
+
+/* The same head with an atomic-free gradient (flavours by `flags`: bit 0 = TF contrast_head head.py:462-807, bit 1 = labels are int64;
+ * num_classes > 0: `labels` are (n_valid, num_classes) f32 distributions and positives are KL(p_i || p_j) < kl_threshold, head.py:492-519).
+ *   forward : per_point / point_mask / stats / loss as cbl_point_contrast_forward; with coef != NULL also the scalar coefficient of every
+ *             pair, coef (m, nsample) (column 0 = 0), and the centre half of the gradient grad_own (m, d), both WITHOUT the global factor
+ *             grad_loss * weight / count;  `order` (m, NULL = none) = processing sequence, values do not depend on it
+ *   backward: grad_features[t] = (grad_own[t] + sum over the pairs p = (i, col) listing t of coef[p] (f_t - f_i)) * grad_loss * weight / count,
+ *             a gather over the transposed table of neighbor_idx (cbl_neighbor_transpose with n = m, order_dst = order)
+ * d in {4, 8, 16, 32, 64}, nsample <= 65. */
+int cbl_contrast_pairs_forward(int m, int n_valid, int flags, int nsample, int d, const float* features, const void* labels, int num_classes,
+                               float kl_threshold, const int* neighbor_idx, const int* order, float temperature, float weight,
+                               float* per_point, int* point_mask, float* stats, float* loss, float* coef, float* grad_own, void* stream);
+int cbl_contrast_pairs_backward(int m, int nsample, int d, const float* features, const float* coef, const float* grad_own, const int* order,
+                                const int* inv_start, const int* inv_src, const float* stats, const float* grad_loss, float weight,
+                                float* grad_features, void* stream);
 
 /* a16  TF contrast_head  tensorflow/models/heads/head.py:462-807 with sample 'label', contrast 'softnn', dist 'l2' on RADIUS
  *      neighbourhoods (ids >= n_valid are the search's shadow padding; negative hard labels = ignored points):

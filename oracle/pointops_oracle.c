@@ -19,6 +19,7 @@
  * Build: make -C oracle   ->  oracle/_build/liboracle.so
  */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -91,6 +92,22 @@ ORACLE_API void oracle_knnquery_range(int q0, int q1, int nsample, const float* 
     int*   val = (int*)malloc(sizeof(int) * (size_t)nsample);
     for (int q = q0; q < q1; q++) knn_one_query(q, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, key, val);
     free(key); free(val);
+}
+
+/* all queries, OpenMP schedule(static) over queries with `threads` threads (<= 0: the runtime's default): the CPU baseline of
+ * bench.py at all cores; same per-query function, so the result does not depend on the thread count */
+ORACLE_API void oracle_knnquery_omp(int m, int nsample, const float* xyz, const float* new_xyz,
+                                    const int* offset, const int* new_offset, int* idx, float* dist2, int threads)
+{
+    if (threads <= 0) threads = omp_get_max_threads();
+#pragma omp parallel num_threads(threads)
+    {
+        float* key = (float*)malloc(sizeof(float) * (size_t)nsample);
+        int*   val = (int*)malloc(sizeof(int) * (size_t)nsample);
+#pragma omp for schedule(static)
+        for (int q = 0; q < m; q++) knn_one_query(q, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, key, val);
+        free(key); free(val);
+    }
 }
 
 ORACLE_API void oracle_knnquery(int m, int nsample, const float* xyz, const float* new_xyz,

@@ -7,3 +7,11 @@ extern "C" void ref_knn_batch(const float* batch_data, long batch_size, long npt
     if (omp) cpp_knn_batch_omp(batch_data, (size_t)batch_size, (size_t)npts, 3, queries, (size_t)nqueries, (size_t)K, out);
     else cpp_knn_batch(batch_data, (size_t)batch_size, (size_t)npts, 3, queries, (size_t)nqueries, (size_t)K, out);
 }
+
+// single cloud: cpp_knn (knn_.cxx:22-44, one thread) / cpp_knn_omp (knn_.cxx:46-76, OpenMP over the queries) — the reference's own
+// CPU KNN, timed by bench.py's cpu_baseline "reference" leg
+extern "C" void ref_knn(const float* points, long npts, const float* queries, long nqueries, long K, long* out, int omp)
+{
+    if (omp) cpp_knn_omp(points, (size_t)npts, 3, queries, (size_t)nqueries, (size_t)K, out);
+    else cpp_knn(points, (size_t)npts, 3, queries, (size_t)nqueries, (size_t)K, out);
+}

@@ -48,3 +48,19 @@ def test_host_mirror_refuses_cpu_tensors():
         pointops.knnquery(2, x, x, o, o)
     with pytest.raises(_lib.CblError):
         pointops.grouping(torch.zeros(8, 4), torch.zeros(8, 2, dtype=torch.int32))
+
+
+def test_dropin_has_no_cpu_path():
+    """the drop-in module loads without a GPU (ctypes) and refuses CPU tensors loudly instead of handing their addresses to a kernel"""
+    import sys
+    import pytest
+    import torch
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "contrastboundary_amd", "dropin")
+    sys.path.insert(0, d)
+    try:
+        import pointops_cuda
+        xyz = torch.rand(64, 3); off = torch.tensor([64], dtype=torch.int32)
+        with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+            pointops_cuda.knnquery_cuda(64, 4, xyz, xyz, off, off, torch.zeros(64, 4, dtype=torch.int32), torch.zeros(64, 4))
+    finally:
+        sys.path.remove(d)

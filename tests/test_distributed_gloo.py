@@ -44,3 +44,39 @@ def test_single_process_is_identity():
     from contrastboundary_amd import distributed as D
     assert D.shard_scenes(5, 0, 1) == [0, 1, 2, 3, 4]
     assert D.aggregate_throughput(100.0, 2.0) == (50.0, 100.0, 2.0)
+
+
+# ---- bench.py's own launcher path (`--gpus N` outside a torchrun environment), world 2 over gloo on the CPU -------------------------
+def _bench(*argv, env=None):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(key, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(argv), capture_output=True, text=True, timeout=300, env=e, cwd=root)
+
+
+def test_bench_spawns_its_ranks_and_reports_the_joined_world():
+    import json
+    r = _bench("--gpus", "2", "--host-dry-run", "--steps", "5", "--warmup", "1", "--allreduce-floats", "4096")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                                  # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["warmup"] == 1 and out["scaling"] == "weak"
+    # 5 steps of >= 2 ms each between the barriers; value = units of BOTH ranks / max time
+    assert out["ms_per_step"] >= 2.0 and abs(out["value"] - 40960 * 5 * 2 / (out["ms_per_step"] * 5e-3)) < 1e-6 * out["value"]
+    # the gradient all-reduce leg ran over the process group: ones summed over 2 ranks and averaged stay 1
+    assert out["grad_allreduce"]["bytes"] == 4 * 4096 and out["grad_allreduce"]["checksum"] == 1.0
+
+
+def test_bench_refuses_more_gpus_than_devices():
+    r = _bench("--gpus", "2", "--steps", "1", "--warmup", "0")        # no GPU here: must fail loudly, never print n_gpus
+    assert r.returncode == 2 and "device(s) visible" in r.stderr and "{" not in r.stdout
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    r = _bench("--gpus", "4", "--host-dry-run", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"})
+    assert r.returncode == 2 and "WORLD_SIZE=2 but --gpus 4" in r.stderr

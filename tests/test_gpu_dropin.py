@@ -69,3 +69,62 @@ def test_reference_call_patterns(pc):
     pc.aggregation_forward_cuda(n, K, c, 4, feat, torch.from_numpy(pos_h).cuda(), torch.from_numpy(ww_h).cuda(), torch.from_numpy(sidx_h).cuda(), ao)
     np.testing.assert_array_equal(ao.cpu().numpy(), O.aggregation_forward(feat_h, pos_h, ww_h, sidx_h))
     torch.cuda.synchronize()
+
+
+def test_scalars_as_zero_dim_tensors(pc):
+    """heads.py:186/192 passes nsample = self.nsample[i] (a 0-dim tensor), basic_operators.py:22 kr = torch.prod(...): pybind takes them
+    through __index__, so must the drop-in"""
+    rng = np.random.default_rng(1)
+    n, K = 2500, 16
+    xyz_h = rng.uniform(size=(n, 3)).astype(np.float32)
+    off_h = np.int32([n])
+    xyz, offset = torch.from_numpy(xyz_h).cuda(), torch.from_numpy(off_h).cuda()
+    nsample = torch.tensor([8, K])[1]                                 # 0-dim int64 tensor, as config.nsample yields
+    idx = torch.cuda.IntTensor(n, K).zero_(); dist2 = torch.cuda.FloatTensor(n, K).zero_()
+    pc.knnquery_cuda(n, nsample, xyz, xyz, offset, offset, idx, dist2)
+    ridx, _ = O.knnquery(K, xyz_h, xyz_h, off_h, off_h)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+    kr = torch.prod(torch.tensor([4, 4]))                             # basic_operators.py:22
+    idx2 = torch.cuda.IntTensor(n, 16).zero_(); d2 = torch.cuda.FloatTensor(n, 16).zero_()
+    pc.knnquery_cuda(torch.tensor(n), kr, xyz, xyz, offset, offset, idx2, d2)
+    np.testing.assert_array_equal(idx2.cpu().numpy(), ridx)
+
+
+def test_boundary_rejects_what_the_kernels_cannot_read(pc):
+    """SURVEY 8(b) "Error convention": wrong dtype / device / layout / shape raise before any pointer is taken"""
+    n, K = 2048, 8
+    xyz = torch.rand(n, 3, device="cuda")
+    offset = torch.tensor([n], dtype=torch.int32, device="cuda")
+    idx = torch.zeros(n, K, dtype=torch.int32, device="cuda"); dist2 = torch.zeros(n, K, device="cuda")
+    pc.knnquery_cuda(n, K, xyz, xyz, offset, offset, idx, dist2)      # the well-formed call
+    with pytest.raises(TypeError, match="offset must be torch.int32"):
+        pc.knnquery_cuda(n, K, xyz, xyz, offset.long(), offset, idx, dist2)
+    with pytest.raises(ValueError, match="xyz must be contiguous"):
+        pc.knnquery_cuda(n, K, torch.rand(3, n, device="cuda").t(), xyz, offset, offset, idx, dist2)
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        pc.knnquery_cuda(n, K, xyz.cpu(), xyz, offset, offset, idx, dist2)
+    with pytest.raises(TypeError, match="xyz must be torch.float32"):
+        pc.knnquery_cuda(n, K, xyz.double(), xyz, offset, offset, idx, dist2)
+    with pytest.raises(ValueError, match="idx has shape"):
+        pc.knnquery_cuda(n, K, xyz, xyz, offset, offset, torch.zeros(n, K + 1, dtype=torch.int32, device="cuda"), dist2)
+    with pytest.raises(TypeError, match="idx must be torch.int32"):
+        pc.grouping_forward_cuda(n, K, 4, torch.rand(n, 4, device="cuda"), idx.long(), torch.zeros(n, K, 4, device="cuda"))
+    with pytest.raises(ValueError, match="output has shape"):
+        pc.grouping_forward_cuda(n, K, 4, torch.rand(n, 4, device="cuda"), idx, torch.zeros(n, K, 5, device="cuda"))
+    torch.cuda.synchronize()
+
+
+def test_one_scratch_per_stream(pc):
+    n, K = 4096, 16
+    xyz = torch.rand(n, 3, device="cuda")
+    offset = torch.tensor([n], dtype=torch.int32, device="cuda")
+    out = []
+    for st in (torch.cuda.current_stream(), torch.cuda.Stream()):
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            idx = torch.zeros(n, K, dtype=torch.int32, device="cuda"); dist2 = torch.zeros(n, K, device="cuda")
+            pc.knnquery_cuda(n, K, xyz, xyz, offset, offset, idx, dist2)
+            out.append(idx)
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], out[1])
+    assert len({key[1] for key in pc._ws}) >= 2                       # keyed by (device, stream)

@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+from contrastboundary_amd import neighbor_state
+
 pytestmark = pytest.mark.gpu
 
 
@@ -89,13 +91,13 @@ def test_kpconv_forward_ordered_equals_unordered(n, K, C):
 def test_python_ops_pick_the_order_up_and_values_do_not_change():
     from contrastboundary_amd import hotpath, local_aggregation as LA, pointops
     sc = hotpath.Scene.synthetic(16384, 64, seed=5)
-    pointops.use_spatial_order = False
+    neighbor_state.use_spatial_order = False
     try:
         idx, _ = pointops.knnquery_raw(16, sc.xyz, sc.xyz, sc.offset, sc.offset)
         g0 = pointops.queryandgroup(16, sc.xyz, sc.xyz, sc.feat, idx, sc.offset, sc.offset, use_xyz=True)
         k0 = LA.kpconv(sc.xyz, sc.xyz, idx, sc.feat, sc.kernel_points, sc.kernel_weights, 0.12)
     finally:
-        pointops.use_spatial_order = True
+        neighbor_state.use_spatial_order = True
     assert pointops.spatial_order(sc.xyz) is None                             # nothing registered while switched off
     idx1, _ = pointops.knnquery_raw(16, sc.xyz, sc.xyz, sc.offset, sc.offset)
     order = pointops.spatial_order(sc.xyz)
