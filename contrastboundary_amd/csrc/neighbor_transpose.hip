@@ -70,19 +70,29 @@ __global__ __launch_bounds__(NB) void nt_prep_kernel(int n, int nzero, const int
     if (i < nzero) zero[i] = 0;
 }
 
-// the target tile of pair e of source tile `st` (or -1), and the pair's flat index p = source * ns + column
-__device__ __forceinline__ int nt_pair(unsigned e, int st, int m, int n, int ns, CblFastDiv dv, const int* __restrict__ idx, const int* __restrict__ order_src,
-                                       const int* __restrict__ rank, unsigned& p, int& slot)
+// A source tile's pairs are walked UN pairs per thread at a time with the three dependent accesses of a pair (its neighbour id, that
+// neighbour's rank, the LDS counter) issued level by level: the kernels are chains of L2 round trips, not bandwidth.
+constexpr int UN = 4;
+
+struct NtPairs { unsigned p[UN]; int r[UN]; };                       // flat pair index and target rank (-1: padding / outside the tile)
+
+__device__ __forceinline__ void nt_load_pairs(NtPairs& q, unsigned base, unsigned total, int n, int ns, CblFastDiv dv, const int* __restrict__ src_ids,
+                                              const int* __restrict__ idx, const int* __restrict__ rank)
 {
-    const unsigned sl = cbl_fastdiv(e, dv), col = e - sl * (unsigned)ns;
-    const int s_slot = st * TS + (int)sl;
-    const int s = order_src ? order_src[s_slot] : s_slot;
-    p = (unsigned)s * (unsigned)ns + col;
-    const int t = idx[p];
-    if ((unsigned)t >= (unsigned)n) return -1;                      // shadow / padding neighbours take no part
-    const int r = rank ? rank[t] : t;
-    slot = r & (TT - 1);
-    return r / TT;
+    int t[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+        const unsigned e = base + (unsigned)u * NB + threadIdx.x;
+        const bool in = e < total;
+        const unsigned sl = cbl_fastdiv(in ? e : 0u, dv), col = (in ? e : 0u) - sl * (unsigned)ns;
+        q.p[u] = (unsigned)src_ids[sl] * (unsigned)ns + col;
+        t[u] = in ? idx[q.p[u]] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+        const bool ok = (unsigned)t[u] < (unsigned)n;                // shadow / padding neighbours take no part
+        q.r[u] = ok ? (rank ? rank[t[u]] : t[u]) : -1;
+    }
 }
 
 __global__ __launch_bounds__(NB) void nt_count_kernel(int m, int n, int ns, int ntt, CblFastDiv dv, const int* __restrict__ idx, const int* __restrict__ order_src,
@@ -92,17 +102,19 @@ __global__ __launch_bounds__(NB) void nt_count_kernel(int m, int n, int ns, int 
     extern __shared__ int lds[];
     int* hist = lds;                                                 // ntt
     int2* mine = reinterpret_cast<int2*>(lds + ((ntt + 1) & ~1));    // up to min(ntt, TS * ns) records (8-byte aligned)
-    __shared__ int nmine, gbase;
+    __shared__ int nmine, gbase, src_ids[TS];
     const int st = blockIdx.x;
     const int nsrc = min(TS, m - st * TS);
+    if ((int)threadIdx.x < TS) src_ids[threadIdx.x] = (int)threadIdx.x < nsrc ? (order_src ? order_src[st * TS + threadIdx.x] : st * TS + (int)threadIdx.x) : 0;
     for (int e = threadIdx.x; e < ntt; e += NB) hist[e] = 0;
     if (threadIdx.x == 0) nmine = 0;
     __syncthreads();
     const unsigned total = (unsigned)nsrc * (unsigned)ns;
-    for (unsigned e = threadIdx.x; e < total; e += NB) {
-        unsigned p; int slot;
-        const int tt = nt_pair(e, st, m, n, ns, dv, idx, order_src, rank, p, slot);
-        if (tt >= 0) atomicAdd(&hist[tt], 1);
+    for (unsigned base = 0; base < total; base += UN * NB) {
+        NtPairs q;
+        nt_load_pairs(q, base, total, n, ns, dv, src_ids, idx, rank);
+#pragma unroll
+        for (int u = 0; u < UN; u++) if (q.r[u] >= 0) atomicAdd(&hist[q.r[u] / TT], 1);
     }
     __syncthreads();
     for (int tt = threadIdx.x; tt < ntt; tt += NB) {
@@ -124,33 +136,71 @@ __global__ __launch_bounds__(NB) void nt_bin_kernel(int m, int n, int ns, int nt
                                                     int2* __restrict__ bins)
 {
     extern __shared__ int lds[];
-    int* where = lds;                                                // ntt: start of bin tt, then (touched bins) start of this tile's range in it
+    int* where = lds;                                                // ntt: size of bin tt -> its start -> (touched bins) start of this tile's range in it
     int* hist = lds + ntt;                                           // ntt: running position inside the range
-    __shared__ int wave_tot[NB / 64];
+    __shared__ int wave_tot[NB / 64], src_ids[TS];
     const int st = blockIdx.x;
+    const int nsrc = min(TS, m - st * TS);
+    if ((int)threadIdx.x < TS) src_ids[threadIdx.x] = (int)threadIdx.x < nsrc ? (order_src ? order_src[st * TS + threadIdx.x] : st * TS + (int)threadIdx.x) : 0;
+    for (int e = threadIdx.x; e < ntt; e += NB) { where[e] = tile_cursor[e]; hist[e] = 0; }      // coalesced; the scan below runs out of LDS
+    __syncthreads();
     // exclusive scan of the bin sizes: thread t owns a contiguous chunk
     const int per = (ntt + NB - 1) / NB;
     const int c0 = threadIdx.x * per, c1 = min(ntt, c0 + per);
     int sum = 0;
-    for (int e = c0; e < c1; e++) sum += tile_cursor[e];
+    for (int e = c0; e < c1; e++) sum += where[e];
     int incl = sum;
     for (int k = 1; k < 64; k <<= 1) { const int v = __shfl_up(incl, k); if ((threadIdx.x & 63) >= k) incl += v; }
     if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
     __syncthreads();
     int run = incl - sum;
     for (int w = 0; w < (int)(threadIdx.x >> 6); w++) run += wave_tot[w];
-    for (int e = c0; e < c1; e++) { where[e] = run; hist[e] = 0; if (st == 0) tile_base[e] = run; run += tile_cursor[e]; }
+    for (int e = c0; e < c1; e++) { const int c = where[e]; where[e] = run; if (st == 0) tile_base[e] = run; run += c; }
     if (st == 0 && threadIdx.x == NB - 1) tile_base[ntt] = run;      // the last thread's chunk ends at ntt (possibly empty): total number of pairs
     __syncthreads();
     const int nl = tile_list_n[st], lo = tile_list_off[st];
     for (int e = threadIdx.x; e < nl; e += NB) { const int2 r = lists[lo + e]; where[r.x] += r.y; }
     __syncthreads();
-    const int nsrc = min(TS, m - st * TS);
     const unsigned total = (unsigned)nsrc * (unsigned)ns;
-    for (unsigned e = threadIdx.x; e < total; e += NB) {
-        unsigned p; int slot;
-        const int tt = nt_pair(e, st, m, n, ns, dv, idx, order_src, rank, p, slot);
-        if (tt >= 0) bins[where[tt] + atomicAdd(&hist[tt], 1)] = make_int2(slot, (int)p);
+    for (unsigned base = 0; base < total; base += UN * NB) {
+        NtPairs q;
+        nt_load_pairs(q, base, total, n, ns, dv, src_ids, idx, rank);
+#pragma unroll
+        for (int u = 0; u < UN; u++)
+            if (q.r[u] >= 0) { const int tt = q.r[u] / TT; bins[where[tt] + atomicAdd(&hist[tt], 1)] = make_int2(q.r[u] & (TT - 1), (int)q.p[u]); }
+    }
+}
+
+// counting sort of a target tile's bin by target, then a rank sort by pair inside every target's segment (pair ids are distinct):
+// ascending pairs = the reference loop's summation order.  `stage` is LDS (bins up to STAGE_CAP pairs) or global scratch.
+__device__ __forceinline__ void nt_order_bin(int* __restrict__ stage, int* cnt, const int* lstart, int E, const int2* __restrict__ bin, int* __restrict__ out)
+{
+    for (int e0 = 0; e0 < E; e0 += UN * NB) {
+        int2 r[UN];
+#pragma unroll
+        for (int u = 0; u < UN; u++) { const int e = e0 + u * NB + (int)threadIdx.x; r[u] = e < E ? bin[e] : make_int2(-1, 0); }
+#pragma unroll
+        for (int u = 0; u < UN; u++) if (r[u].x >= 0) stage[lstart[r[u].x] + atomicAdd(&cnt[r[u].x], 1)] = r[u].y;
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int slot = wave; slot < TT; slot += NB / 64) {
+        const int s0 = lstart[slot], L = lstart[slot + 1] - s0;
+        for (int c = 0; c < L; c += 64) {
+            const int e = c + lane;
+            const int mine = e < L ? stage[s0 + e] : 0x7fffffff;
+            int rnk = 0, o = 0;
+            for (; o + 8 <= L; o += 8) {                             // same address for every lane: LDS broadcast reads, eight in flight
+                int v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = stage[s0 + o + u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) rnk += (v[u] < mine) ? 1 : 0;
+            }
+            for (; o < L; o++) rnk += (stage[s0 + o] < mine) ? 1 : 0;
+            if (e < L) out[s0 + rnk] = mine;
+        }
     }
 }
 
@@ -161,10 +211,15 @@ __global__ __launch_bounds__(NB) void nt_finish_kernel(int n, int ntt, const int
     __shared__ int stage_lds[STAGE_CAP];
     const int tt = blockIdx.x;
     const int b0 = tile_base[tt], E = tile_base[tt + 1] - b0;
-    int* stage = E <= STAGE_CAP ? stage_lds : scratch + b0;          // flat addressing: LDS or global
     if (threadIdx.x < TT) cnt[threadIdx.x] = 0;
     __syncthreads();
-    for (int e = threadIdx.x; e < E; e += NB) atomicAdd(&cnt[bins[b0 + e].x], 1);
+    for (int e0 = 0; e0 < E; e0 += UN * NB) {
+        int sl[UN];
+#pragma unroll
+        for (int u = 0; u < UN; u++) { const int e = e0 + u * NB + (int)threadIdx.x; sl[u] = e < E ? bins[b0 + e].x : -1; }
+#pragma unroll
+        for (int u = 0; u < UN; u++) if (sl[u] >= 0) atomicAdd(&cnt[sl[u]], 1);
+    }
     __syncthreads();
     if (threadIdx.x < 64) {                                          // TT == 64: one wave scans the counts
         const int c = cnt[threadIdx.x];
@@ -178,24 +233,8 @@ __global__ __launch_bounds__(NB) void nt_finish_kernel(int n, int ntt, const int
         cnt[threadIdx.x] = 0;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < E; e += NB) {
-        const int2 r = bins[b0 + e];
-        stage[lstart[r.x] + atomicAdd(&cnt[r.x], 1)] = r.y;
-    }
-    __threadfence_block();
-    __syncthreads();
-    // rank sort inside every target's segment (pair ids are distinct): ascending pairs = the reference loop's summation order
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int slot = wave; slot < TT; slot += NB / 64) {
-        const int s0 = lstart[slot], L = lstart[slot + 1] - s0;
-        for (int c = 0; c < L; c += 64) {
-            const int e = c + lane;
-            const int mine = e < L ? stage[s0 + e] : 0x7fffffff;
-            int rnk = 0;
-            for (int o = 0; o < L; o++) rnk += (stage[s0 + o] < mine) ? 1 : 0;
-            if (e < L) inv_src[b0 + s0 + rnk] = mine;
-        }
-    }
+    if (E <= STAGE_CAP) nt_order_bin(stage_lds, cnt, lstart, E, bins + b0, inv_src + b0);
+    else nt_order_bin(scratch + b0, cnt, lstart, E, bins + b0, inv_src + b0);
 }
 
 // ---------------------------------------------------------------- K4 as a gather

@@ -58,11 +58,11 @@ class Scene:
 
     def upstream(self, k):
         """device copies of upstream_numpy (made once per scene and k)"""
-        key = ("upstream", k)
-        if key not in self.__dict__:
+        cache = self.__dict__.setdefault("_upstream", {})
+        if k not in cache:
             a = Scene.upstream_numpy(self.n, self.c, k, getattr(self, "seed", 0))
-            self.__dict__[key] = {name: torch.from_numpy(v).to(self.xyz.device) for name, v in a.items()}
-        return self.__dict__[key]
+            cache[k] = {name: torch.from_numpy(v).to(self.xyz.device) for name, v in a.items()}
+        return cache[k]
 
 
 # stages that do not depend on the stage before them: the CBL head's neighbour search needs the coordinates only, so `run_step` issues
@@ -76,8 +76,11 @@ def stages(scene, k=16, backward=False):
     backward: also the backward legs of the block (BASELINE config C2)."""
     n, c = scene.n, scene.c
     st = []
-    feat = scene.feat.detach().requires_grad_(True) if backward else scene.feat
-    kweights = scene.kernel_weights.detach().requires_grad_(True) if backward else scene.kernel_weights
+    # leaves are made inside the step (on the stream the step runs on) and gradients are taken with torch.autograd.grad: no AccumulateGrad
+    # node that outlives a step and no .grad state, so the step can be captured in a hipGraph on any stream
+    leaf = (lambda t: t.detach().requires_grad_(True)) if backward else (lambda t: t)
+    if backward:
+        scene.upstream(k)                                             # uploaded now, not inside a step
 
     def knn(s):
         s["idx"], s["dist2"] = pointops.knnquery_raw(k, scene.xyz, scene.xyz, scene.offset, scene.offset)
@@ -85,14 +88,15 @@ def stages(scene, k=16, backward=False):
     st.append(("knnquery_k%d" % k, knn, 12 * n + 12 * n + 8 * n * k, 8.0 * n * n))
 
     def group(s):
-        s["grouped"] = pointops.queryandgroup(k, scene.xyz, scene.xyz, feat, s["idx"], scene.offset, scene.offset, use_xyz=True)
+        s["feat_leaf"], s["kw_leaf"] = leaf(scene.feat), leaf(scene.kernel_weights)
+        s["grouped"] = pointops.queryandgroup(k, scene.xyz, scene.xyz, s["feat_leaf"], s["idx"], scene.offset, scene.offset, use_xyz=True)
     # a3 fused queryandgroup: 4mK + 12n + 12m + 4nC + 4mK(3+C)
     st.append(("queryandgroup", group, 4 * n * k + 12 * n + 12 * n + 4 * n * c + 4 * n * k * (3 + c), 3.0 * n * k))
 
     extent = 0.12      # KP_extent 1.0 * radius 0.1*... / density (local_aggregation_operators.py:664); ~ the K=16 neighbourhood radius here
 
     def kpconv(s):
-        s["kpconv"] = local_aggregation.kpconv(scene.xyz, scene.xyz, s["idx"], feat, scene.kernel_points, kweights, extent)
+        s["kpconv"] = local_aggregation.kpconv(scene.xyz, scene.xyz, s["idx"], s["feat_leaf"], scene.kernel_points, s["kw_leaf"], extent)
     # a15 (idx given): 12n + 12n0 + 4n0C + 4nK + 4nC bytes; flops 2nK*KP*(C + 6) + 2n*KP*C  
     st.append(("kpconv_fwd", kpconv, 12 * n + 12 * n + 4 * n * c + 4 * n * k + 4 * n * c, 2.0 * n * k * KP * (c + 6) + 2.0 * n * KP * c))
 
@@ -117,8 +121,7 @@ def stages(scene, k=16, backward=False):
                1.0 * n * (CBL_NSAMPLE - 1) * (8 * d + 50)))
 
     def cbl_bwd(s):
-        s["cbl_loss"].backward()
-        s["cbl_grad"] = s["cbl_latent"].grad
+        s["cbl_grad"], = torch.autograd.grad(s["cbl_loss"], s["cbl_latent"])
     # backward = the neighbour half gathered over the transposed table: 4(n+1) + 4nK table, 4nK coefficients, 4nd features,
     # 4nd centre half in, 4nd gradient out
     st.append(("cbl_mining_loss_bwd", cbl_bwd, 4 * (n + 1) + 8 * n * CBL_NSAMPLE + 12 * n * d, 3.0 * n * (CBL_NSAMPLE - 1) * d))
@@ -131,18 +134,12 @@ def stages(scene, k=16, backward=False):
 
     def group_bwd(s):
         # K4 (grouping_cuda_kernel.cu:16-25) for the feature columns of d loss / d grouped, as a gather over the transposed table
-        up = scene.upstream(k)
-        feat.grad = None
-        s["grouped"].backward(up["grad_grouped"])
-        s["grad_feat_group"] = feat.grad
+        s["grad_feat_group"], = torch.autograd.grad(s["grouped"], s["feat_leaf"], scene.upstream(k)["grad_grouped"])
     # 4mK (table) + 4mKC (gradient rows read) + 4nC (written)
     st.append(("queryandgroup_bwd", group_bwd, 4 * n * k + 4 * n * k * c + 4 * n * c, 1.0 * n * k * c))
 
     def kpconv_bwd(s):
-        up = scene.upstream(k)
-        feat.grad = None; kweights.grad = None
-        s["kpconv"].backward(up["grad_kpconv"])
-        s["grad_feat_kpconv"], s["grad_kernel_weights"] = feat.grad, kweights.grad
+        s["grad_feat_kpconv"], s["grad_kernel_weights"] = torch.autograd.grad(s["kpconv"], (s["feat_leaf"], s["kw_leaf"]), scene.upstream(k)["grad_kpconv"])
     # a15 backward (idx given): forward's inputs + the output gradient in, feature and kernel-weight gradients out; flops 2x the forward's
     st.append(("kpconv_bwd", kpconv_bwd, 12 * n + 12 * n + 4 * n * c + 4 * n * k + 4 * n * c + 4 * n * c + 4 * KP * c,
                2.0 * (2.0 * n * k * KP * (c + 6) + 2.0 * n * KP * c)))

@@ -46,11 +46,29 @@ class _KPConv(Function):
         n, K = idx.shape
         n0, C = f.shape
         grad_out = grad_out.contiguous()
+        L = _lib.lib()
+        from . import pointops
+        tr = None
+        if C % 4 == 0:
+            # gather over the transposed neighbour table (no atomics); built where that pays, taken where it already exists
+            tr = pointops.neighbor_transpose(idx, n0, build=(n * K >= pointops.TRANSPOSE_MIN_PAIRS))
+        if tr is not None:
+            order, inv_start, inv_src = tr
+            gf = torch.empty_like(f) if ctx.needs_input_grad[3] else None
+            gkw = torch.empty_like(kw) if ctx.needs_input_grad[5] else None
+            need = L.cbl_kpconv_backward_csr_workspace_bytes(_i(n0), _i(C), _i(kp.shape[0])) if gkw is not None else 0
+            ws = torch.empty(max(need, 1), dtype=torch.uint8, device=f.device)
+            rc = L.cbl_kpconv_backward_csr(_i(n), _i(n0), _i(K), _i(C), _i(kp.shape[0]), _lib.ptr(q), _lib.ptr(s), _lib.ptr(f), _lib.ptr(kp), _lib.ptr(kw),
+                                           _f(extent), _i(influence), _i(closest), _lib.ptr(grad_out), _lib.ptr(order), _lib.ptr(inv_start), _lib.ptr(inv_src),
+                                           _lib.ptr(gf), _lib.ptr(gkw), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(f))
+            if rc != _lib.ERR_UNSUPPORTED:
+                _lib.check(rc, "cbl_kpconv_backward_csr")
+                return None, None, None, gf, None, gkw, None, None, None
         gf = torch.zeros_like(f) if ctx.needs_input_grad[3] else None
         gkw = torch.zeros_like(kw) if ctx.needs_input_grad[5] else None
-        _lib.check(_lib.lib().cbl_kpconv_backward(_i(n), _i(n0), _i(K), _i(C), _i(kp.shape[0]), _lib.ptr(q), _lib.ptr(s), _lib.ptr(idx), _lib.ptr(f),
-                                                  _lib.ptr(kp), _lib.ptr(kw), _f(extent), _i(influence), _i(closest), _lib.ptr(grad_out),
-                                                  _lib.ptr(gf), _lib.ptr(gkw), _lib.stream_of(f)), "cbl_kpconv_backward")
+        _lib.check(L.cbl_kpconv_backward(_i(n), _i(n0), _i(K), _i(C), _i(kp.shape[0]), _lib.ptr(q), _lib.ptr(s), _lib.ptr(idx), _lib.ptr(f),
+                                         _lib.ptr(kp), _lib.ptr(kw), _f(extent), _i(influence), _i(closest), _lib.ptr(grad_out),
+                                         _lib.ptr(gf), _lib.ptr(gkw), _lib.stream_of(f)), "cbl_kpconv_backward")
         return None, None, None, gf, None, gkw, None, None, None
 
 

@@ -327,6 +327,15 @@ int cbl_kpconv_backward(int n, int n0, int K, int C, int KP, const float* query_
                         const float* features, const float* kernel_points, const float* kernel_weights, float extent, int influence, int closest,
                         const float* grad_out, float* grad_features, float* grad_kernel_weights, void* stream);
 
+/* the same gradients as a gather over the transposed table of neighbors_indices (cbl_neighbor_transpose with n targets = n0, pairs p = i*K + k):
+ * no atomics, WRITTEN not accumulated (no pre-zeroing), deterministic.  C % 4 == 0 and 16-byte aligned rows (CBL_ERR_UNSUPPORTED otherwise: use
+ * cbl_kpconv_backward); any K.  workspace (only for grad_kernel_weights): cbl_kpconv_backward_csr_workspace_bytes. */
+size_t cbl_kpconv_backward_csr_workspace_bytes(int n0, int C, int KP);
+int cbl_kpconv_backward_csr(int n, int n0, int K, int C, int KP, const float* query_points, const float* support_points, const float* features,
+                            const float* kernel_points, const float* kernel_weights, float extent, int influence, int closest,
+                            const float* grad_out, const int* order_dst, const int* inv_start, const int* inv_src,
+                            float* grad_features, float* grad_kernel_weights, void* workspace, size_t workspace_bytes, void* stream);
+
 /* a14  AdaptiveWeight  tensorflow/models/local_aggregation_operators.py:316-500 with the shipped options
  *   (config/s3dis/adapt.yaml:19-26: local_input_feature 'dp', fc_num 1, shared_channels 1, no softmax):
  *   w[p,k,:] = ((support[nbr]-query[p])/radius) @ fc_weight (3,C) + fc_bias (C);  out[p,:] = sum_k w[p,k,:]*features[nbr]  (/ nn[p] if reduction_mean)

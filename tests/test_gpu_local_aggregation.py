@@ -130,3 +130,40 @@ def test_pospool_rejects_what_the_reference_cannot_reshape():
         L.pospool(dev(q), dev(s), dev(idx), dev(f), 0.1, "sin_cos", "mean")       # 10 is neither 9 nor a multiple of 6
     with pytest.raises(NotImplementedError):
         L.pospool(dev(q), dev(s), dev(idx), dev(f), 0.1, "direction", "mean")
+
+
+@pytest.mark.parametrize("K,C,KP,influence,mode", [(16, 64, 15, "linear", "sum"), (26, 72, 15, "linear", "sum"), (9, 16, 7, "linear", "closest"),
+                                                   (31, 144, 15, "constant", "sum"), (5, 20, 16, "linear", "sum")])
+def test_kpconv_backward_as_a_gather(K, C, KP, influence, mode):
+    """cbl_kpconv_backward_csr (transposed neighbour table, no atomics) against the numpy restatement's analytic gradients, 1e-4 of their
+    scale; also: either gradient alone, the shadow padding of the radius search, run-to-run identical bits"""
+    import ctypes
+    from contrastboundary_amd import _lib, pointops
+    q, s, idx, f, rng = make(700, 300, K, C, seed=K + 1)
+    kpts = (rng.normal(size=(KP, 3)) * 0.06).astype(np.float32); kpts[0] = 0
+    kw = rng.normal(size=(KP, C)).astype(np.float32)
+    extent = 0.09
+    go = rng.normal(size=(300, C)).astype(np.float32)
+    gf_ref, gkw_ref = LA.kpconv_grads(q, s, idx, f, kpts, kw, extent, go, influence, mode)
+    L = _lib.lib()
+    i = ctypes.c_int
+    idx_d = dev(idx)
+    tr = pointops.neighbor_transpose(idx_d, 700)
+    assert tr is not None
+    order, inv_start, inv_src = tr
+    qd, sd, fd, kpd, kwd, god = dev(q), dev(s), dev(f), dev(kpts), dev(kw), dev(go)
+    ws = torch.empty(max(L.cbl_kpconv_backward_csr_workspace_bytes(i(700), i(C), i(KP)), 1), dtype=torch.uint8, device="cuda")
+    outs = []
+    for want_f, want_w in ((True, True), (True, False), (False, True), (True, True)):
+        gf = torch.full((700, C), 7.0, device="cuda") if want_f else None      # written, not accumulated
+        gkw = torch.full((KP, C), 7.0, device="cuda") if want_w else None
+        _lib.check(L.cbl_kpconv_backward_csr(i(300), i(700), i(K), i(C), i(KP), _lib.ptr(qd), _lib.ptr(sd), _lib.ptr(fd), _lib.ptr(kpd), _lib.ptr(kwd),
+                                             ctypes.c_float(extent), i(1 if influence == "linear" else 0), i(1 if mode == "closest" else 0), _lib.ptr(god),
+                                             _lib.ptr(order), _lib.ptr(inv_start), _lib.ptr(inv_src), _lib.ptr(gf), _lib.ptr(gkw), _lib.ptr(ws),
+                                             ctypes.c_size_t(ws.numel()), _lib.stream_of(fd)), "cbl_kpconv_backward_csr")
+        if want_f:
+            np.testing.assert_allclose(gf.cpu().numpy(), gf_ref, rtol=1e-3, atol=1e-4 * np.abs(gf_ref).max())
+        if want_w:
+            np.testing.assert_allclose(gkw.cpu().numpy(), gkw_ref, rtol=1e-3, atol=1e-4 * np.abs(gkw_ref).max())
+        outs.append((gf, gkw))
+    assert torch.equal(outs[0][0], outs[3][0]) and torch.equal(outs[0][1], outs[3][1])
