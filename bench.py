@@ -11,8 +11,8 @@ re-executes this file under torch.distributed.run with N ranks (one per device; 
 number of ranks that joined the process group.  Every timed step is the same thing (the step's hipGraph replayed); the timed region is
 bracketed by barrier + synchronize and the MAX over ranks is used.  Rank 0 prints ONE JSON line with the driver's fields plus
   `roofline`      the HBM-bound neighbour gather: algorithmic bytes / HIP-event duration of its launch, events recorded on the launch stream
-                  (inside the in-order hipGraph of the step, replayed right after the timed region), PMC traffic from profiles/ if it
-                  belongs to this kernel set;
+                  (one hipGraph per stage, replayed in step order right after the timed region), PMC traffic from profiles/ if it belongs
+                  to this kernel set;
   `forward_only`  the forward block + CBL head alone (round 1's step), timed the same way;
   `grad_allreduce` (N > 1) the same K steps with one flat 31.2 MB fp32 all-reduce per step over RCCL beside the compute — what DDP adds to
                   data-parallel training of the reference's network (pytorch/tool/train.py:141,181-185; 7,800,497 parameters);
@@ -146,16 +146,13 @@ def host_dry_run(args, D, world, rank):
 class Step:
     """the hot path over one resident scene as bench.py runs it: schedule + its hipGraph"""
 
-    def __init__(self, scene, k, backward, args, events=False, overlap=True):
+    def __init__(self, scene, k, backward, args, overlap=True):
         from contrastboundary_amd import hotpath
         self.stages = hotpath.stages(scene, k, backward)
         self.names = [st[0] for st in self.stages]
         self.hints = () if args.no_nested else hotpath.search_hints(scene)
         self.sched = hotpath.Schedule(self.stages, overlap=overlap, hints=self.hints)
         self.state, self.graph, self.note = {}, None, "eager"
-        self.events = None
-        if events:       # external events: recorded by event-record nodes inside the captured graph, timeable after a replay
-            self.events = [(torch.cuda.Event(enable_timing=True, external=True), torch.cuda.Event(enable_timing=True, external=True)) for _ in self.stages]
 
     def eager(self, events=None):
         self.sched.run(self.state, events)
@@ -173,13 +170,9 @@ class Step:
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode="thread_local"):     # other threads (the RCCL watchdog of a multi-rank run) may call HIP
-            self.sched.run(gstate, self.events)
+            self.sched.run(gstate, None)
         g.replay()
         torch.cuda.synchronize()
-        if self.events is not None:
-            t = [a.elapsed_time(b) for a, b in self.events]
-            if not all(np.isfinite(t)) or min(t) < 0 or sum(t) <= 0:
-                raise RuntimeError("events recorded inside the graph do not time")
         self.graph, self.state = g, gstate
         self.note = "hipGraph replay (torch.cuda.CUDAGraph over the C-ABI launches)"
 
@@ -211,30 +204,23 @@ def make_step(scene, k, backward, args, overlap):
 
 
 def stage_times(scene, k, backward, args, reps=8):
-    """per-stage device time: the step IN ORDER on one stream (a stage's time is that stage alone), events on the launch stream.
-    First choice: events recorded by nodes of the in-order hipGraph (no host in the loop); fallback: eagerly issued in-order steps."""
-    st = Step(scene, k, backward, args, events=True, overlap=False)
+    """per-stage device time: the step IN ORDER on one stream (a stage's time is that stage alone), HIP events on the launch stream around
+    every stage.  The steps are issued eagerly behind a filler kernel (~0.6 ms of device work), so the host is a whole step ahead of the
+    device and an interval holds the stage's kernels and their launch gaps, not the host.  (ROCm has no event-record graph nodes, and one
+    hipGraph per stage costs ~20 us of replay overhead per stage: measured, dropped.)"""
+    st = Step(scene, k, backward, args, overlap=False)
     settle(st, 0.2)
-    how = "events inside the in-order hipGraph of the step (external event-record nodes), %d replays right after the timed region" % reps
-    try:
-        if args.no_graph:
-            raise RuntimeError("--no-graph")
-        st.capture()
-        samples = []
-        for _ in range(reps):
-            st.graph.replay()
-            torch.cuda.synchronize()
-            samples.append([a.elapsed_time(b) for a, b in st.events])
-    except Exception as e:                                           # noqa: BLE001
-        how = "events around eagerly issued in-order steps, %d steps right after the timed region (in-graph events unavailable: %s)" % (reps, type(e).__name__)
+    filler = torch.empty(1 << 31, dtype=torch.uint8, device="cuda")
+    samples = []
+    for _ in range(reps + 2):
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in st.stages]
+        filler.fill_(0); filler.fill_(1)
+        st.eager(ev)
         torch.cuda.synchronize()
-        samples = []
-        for _ in range(reps):
-            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in st.stages]
-            st.eager(ev)
-            torch.cuda.synchronize()
-            samples.append([a.elapsed_time(b) for a, b in ev])
-    return st, [float(v) for v in np.mean(np.asarray(samples), axis=0)], how
+        samples.append([a.elapsed_time(b) for a, b in ev])
+    del filler
+    how = "HIP events on the launch stream around every stage of eagerly issued in-order steps, each issued behind a 0.6 ms filler kernel (host ahead of the device), median of %d right after the timed region" % reps
+    return st, [float(v) for v in np.median(np.asarray(samples[2:]), axis=0)], how
 
 
 MAIN_KERNEL = {
@@ -247,10 +233,10 @@ MAIN_KERNEL = {
     "cbl_mining_loss_bwd": "contrast_gather_kernel<8>",
     "neighbor_transpose_k16": "nt_prep / nt_count / nt_bin / nt_finish (transposed K=16 table)",
     "queryandgroup_bwd": "grouping_bwd_csr_rows_kernel (K4 as a gather)",
-    "kpconv_bwd": "kpconv_bwd_kernel",
+    "kpconv_bwd": "kpconv_bwd_csr_kernel<true,true> (gather over the transposed table) + kpconv_gkw_reduce_kernel",
 }
 PMC_KERNEL = {"queryandgroup": "query_group_lds<16>", "kpconv_fwd": "kpconv_fwd_kernel<true>", "cbl_mining_loss_fwd": "contrast_pairs_kernel<8, 5, true>",
-              "cbl_mining_loss_bwd": "contrast_gather_kernel<8>", "queryandgroup_bwd": "grouping_bwd_csr_rows_kernel", "kpconv_bwd": "kpconv_bwd_kernel"}
+              "cbl_mining_loss_bwd": "contrast_gather_kernel<8>", "queryandgroup_bwd": "grouping_bwd_csr_rows_kernel", "kpconv_bwd": "kpconv_bwd_csr_kernel<true, true>"}
 
 
 def run_gpu(args, D, world, rank, local):

@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void contrast_pairs_kernel(unsigned m, int nsa
     constexpr int PP = 64 / LR;
     const int tf_variant = flags & 1, ls = 1 + ((flags >> 1) & 1), ncls = (flags >> 8) & 0xff;
     const int ns = nsample - 1;                                     // self column dropped, heads.py:195-196 / head.py:560
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform values in scalar registers: scalar loads, uniform branches
     const unsigned nwg = (m + 3) >> 2;                              // 4 points per workgroup
     for (unsigned v = blockIdx.x; v < 8 * cbl_xcd_per(nwg); v += gridDim.x) {
         const unsigned r = cbl_xcd_slot(v, nwg) * 4 + wave;
@@ -148,7 +149,8 @@ __global__ __launch_bounds__(256) void contrast_gather_kernel(unsigned m, CblFas
                                                               float4* __restrict__ grad)
 {
     constexpr int PP = 64 / LR;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int s = lane / LR, q = lane % LR;
     const float count = stats[1];
     const float scale = count > 0.f ? grad_loss[0] * weight / count : 0.f;      // torch.mean(loss) * w (:241-243); 0 when no point qualified (:233)

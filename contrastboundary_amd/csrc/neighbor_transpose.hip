@@ -286,7 +286,7 @@ __global__ __launch_bounds__(NB) void grouping_bwd_csr_rows_kernel(unsigned n, i
                                                                    const int* __restrict__ order, const int* __restrict__ inv_start,
                                                                    const int* __restrict__ inv_src, float* __restrict__ gi)
 {
-    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: scalar loads, uniform loops
     const unsigned nwg = (n + 3) >> 2;
     for (unsigned v = blockIdx.x; v < 8 * cbl_xcd_per(nwg); v += gridDim.x) {
         const unsigned r = cbl_xcd_slot(v, nwg) * 4 + wave;

@@ -48,15 +48,7 @@ class _PointContrast(Function):
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         L = _lib.lib()
         grad = ctx.needs_input_grad[0]
-        order = inv_start = inv_src = None
-        if grad:
-            if transposed is None:
-                transposed = pointops.neighbor_transpose(neighbor_idx, m)
-            if transposed is None:
-                raise _lib.CblError("point_contrast: no transposed neighbour table for this size")
-            order, inv_start, inv_src = transposed
-        else:
-            order = pointops.spatial_order(neighbor_idx)
+        order = pointops.spatial_order(neighbor_idx)                     # processing order only: the values do not depend on it
         coef = torch.empty((m, nsample), dtype=torch.float32, device=dev) if grad else None
         own = torch.empty((m, d), dtype=torch.float32, device=dev) if grad else None
         _lib.check(L.cbl_contrast_pairs_forward(_c_int(m), _c_int(0x7fffffff), _c_int(flags), _c_int(nsample), _c_int(d), _lib.ptr(features), _lib.ptr(amax),
@@ -64,7 +56,8 @@ class _PointContrast(Function):
                                                 _lib.ptr(per_point), _lib.ptr(mask), _lib.ptr(stats), _lib.ptr(loss), _lib.ptr(coef), _lib.ptr(own),
                                                 _lib.stream_of(features)), "cbl_contrast_pairs_forward")
         if grad:
-            ctx.save_for_backward(features, coef, own, stats, inv_start, inv_src, *(() if order is None else (order,)))
+            # the transposed neighbour table is only needed by the backward pass: handed in, or found in / built into the registry then
+            ctx.save_for_backward(features, coef, own, stats, neighbor_idx, *(() if transposed is None else transposed[1:] + ((transposed[0],) if transposed[0] is not None else ())))
         ctx.weight, ctx.nsample = weight, nsample
         ctx.mark_non_differentiable(mask)
         ctx.set_materialize_grads(False)        # no zero tensor for the (integer) mask output in backward: that was one fill launch per step
@@ -74,8 +67,15 @@ class _PointContrast(Function):
     def backward(ctx, grad_loss, _grad_mask):
         if grad_loss is None:                                            # the loss took no part in what was differentiated
             return None, None, None, None, None, None
-        features, coef, own, stats, inv_start, inv_src, *rest = ctx.saved_tensors
-        order = rest[0] if rest else None
+        features, coef, own, stats, neighbor_idx, *rest = ctx.saved_tensors
+        if rest:
+            inv_start, inv_src = rest[0], rest[1]
+            order = rest[2] if len(rest) > 2 else None
+        else:
+            tr = pointops.neighbor_transpose(neighbor_idx, features.shape[0])
+            if tr is None:
+                raise _lib.CblError("point_contrast: no transposed neighbour table for this size")
+            order, inv_start, inv_src = tr
         m, d = features.shape
         g = torch.empty_like(features)
         gl = grad_loss.reshape(1).to(torch.float32).contiguous()

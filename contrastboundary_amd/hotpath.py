@@ -114,7 +114,8 @@ def stages(scene, k=16, backward=False):
 
     def cbl_fwd(s):
         s["cbl_latent"] = scene.latent.detach().requires_grad_(True)
-        s["cbl_loss"] = heads.point_contrast(s["cbl_latent"], scene.labels, s["cbl_idx"], 1.0, 0.1, transposed=s["cbl_transposed"])
+        # the forward needs no transposed table; the backward finds it in the registry (and waits for the stream that builds it)
+        s["cbl_loss"] = heads.point_contrast(s["cbl_latent"], scene.labels, s["cbl_idx"], 1.0, 0.1)
     # a8 mining (idx given): 4nK idx + 4nd features + 4n labels in, 8n out; the latent needs a gradient, so the pass also leaves the pair
     # coefficients (4nK) and the centre half of the gradient (4nd) behind
     st.append(("cbl_mining_loss_fwd", cbl_fwd, 4 * n * CBL_NSAMPLE + 4 * n * d + 4 * n + 8 * n + 4 * n * CBL_NSAMPLE + 4 * n * d,
@@ -179,6 +180,7 @@ class Schedule:
         self.hints = tuple(hints)
         self.overlap = overlap
         self.side = torch.cuda.Stream() if overlap else None
+        self.aux = []                                               # streams of the transposed-table builds (made on first use)
         self.joined = torch.cuda.Event() if overlap else None
 
     def run(self, state, events=None, side_after=None):
@@ -191,6 +193,22 @@ class Schedule:
                 return self._run_branches(state, events) if self.overlap else self._run(state, events, None, ())
         return self._run(state, events, side_after, SIDE_STAGES if self.overlap else ())
 
+    def capture_stage_graphs(self, state):
+        """every stage of the in-order step as a hipGraph of its own (one memory pool, captured in step order inside one neighbour cache):
+        replayed in order they are the step, and HIP events recorded between two replays on the launch stream time ONE stage with no host
+        in the loop.  (ROCm does not allow event-record nodes inside a graph.)"""
+        pool = torch.cuda.graph_pool_handle()
+        graphs = []
+        with pointops.neighbor_cache() as nc:
+            for xyz, nsample, algo in self.hints:
+                nc.hint(xyz, nsample, algo)
+            for i in range(len(self.stage_list)):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                    self.stage_list[i][1](state)
+                graphs.append(g)
+        return graphs
+
     def _launch(self, i, state, events):
         if events is not None:
             events[i][0].record()
@@ -199,23 +217,48 @@ class Schedule:
             events[i][1].record()
 
     def _run_branches(self, state, events):
+        """the step as a small DAG over four streams:
+            main : search -> gather -> KPConv -> [K=16 table] -> grouping backward -> KPConv backward
+            side : (wide result) -> CBL mining + loss -> [K=36 table] -> CBL backward
+            aux  : the two transposed neighbour tables, each as soon as its neighbour table exists — chains of small latency-bound kernels that
+                   need a few CUs, beside the big kernels instead of in front of their consumers
+        A consumer finds its table in neighbor_state's registry and waits for the stream that built it (transpose_lookup)."""
         main = torch.cuda.current_stream()
         names = [st[0] for st in self.stage_list]
-        side_idx = [i for i, nm in enumerate(names) if nm.startswith("cbl_")]
-        main_idx = [i for i in range(len(names)) if i not in side_idx]
-        self.side.wait_stream(main)                                 # the previous step is complete on both streams (joined below)
+        tr_idx = [i for i, nm in enumerate(names) if "neighbor_transpose" in nm]
+        side_idx = [i for i, nm in enumerate(names) if nm.startswith("cbl_") and i not in tr_idx]
+        main_idx = [i for i in range(len(names)) if i not in side_idx and i not in tr_idx]
+        while len(self.aux) < len(tr_idx):
+            self.aux.append(torch.cuda.Stream())
+        self.side.wait_stream(main)                                 # the previous step is complete on every stream (joined below)
         self._launch(main_idx[0], state, events)                    # the search: wide search (event), derivation, tie replay
         before = {key: id(v) for key, v in state.items()}
+        aux_of = {i: self.aux[n] for n, i in enumerate(tr_idx)}
+        for i in tr_idx:                                            # the table of the block's own neighbour table: right behind the search
+            if not names[i].startswith("cbl_"):
+                aux_of[i].wait_stream(main)
+                with torch.cuda.stream(aux_of[i]):
+                    self._launch(i, state, events)
         with torch.cuda.stream(self.side):
             for i in side_idx:                                      # cache hit on the wide result (waits for its event) -> mining + loss -> backward
                 self._launch(i, state, events)
+                if names[i].startswith("cbl_knnquery"):             # the wide table exists on this stream from here on: its transposed table beside the mining
+                    for t in tr_idx:
+                        if names[t].startswith("cbl_"):
+                            aux_of[t].wait_stream(self.side)
+                            with torch.cuda.stream(aux_of[t]):
+                                self._launch(t, state, events)
             self.joined.record(self.side)
-        produced = [v for key, v in state.items() if torch.is_tensor(v) and before.get(key) != id(v)]
         for i in main_idx[1:]:
             self._launch(i, state, events)
         main.wait_event(self.joined)
-        for v in produced:
-            v.record_stream(main)                                   # allocated on the side stream, owned by the caller from here on
+        for i in tr_idx:
+            main.wait_stream(aux_of[i])
+        for key, v in state.items():
+            if before.get(key) != id(v):
+                for t in (v if isinstance(v, (tuple, list)) else (v,)):
+                    if torch.is_tensor(t):
+                        t.record_stream(main)                       # allocated on another stream, owned by the caller from here on
         return state
 
     def _run(self, state, events, side_after, side_names):

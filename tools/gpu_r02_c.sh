@@ -1,0 +1,22 @@
+#!/bin/bash
+set -u
+mkdir -p gpurun_out
+export TMPDIR=/tmp PYTHONPATH=$GRAFT_REPO_ROOT
+timeout 600 python -m pytest tests/test_gpu_local_aggregation.py tests/test_gpu_bench_step.py tests/test_gpu_transpose.py -m gpu -q -x --timeout=600 2>&1 | tail -5
+timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_c.json 2> gpurun_out/bench_c.err; echo "bench rc=$?"; python - <<'PY'
+import json
+d=json.load(open("gpurun_out/bench_c.json"))
+print("ms/step", d["ms_per_step"], "value", d["value"], "fwd-only ms", d["forward_only"]["ms_per_step"])
+print(d["roofline"]["note"][-220:])
+print(json.dumps(d["roofline"]["stage_ms"]))
+print("gather frac", d["roofline"]["frac"], "k4", d["roofline"]["scatter_k4"]["frac"], "mfma", d["roofline"]["mfma_kpconv"]["frac"])
+PY
+tail -3 gpurun_out/bench_c.err
+bash tools/exp/prof_one.sh r02c $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extra --steps 20 > /dev/null
+python - <<'PY'
+import csv
+rows=list(csv.DictReader(open("gpurun_out/prof_r02c/p_kernel_stats.csv")))
+for r in rows[:24]:
+    name=r["Name"].replace("(anonymous namespace)::","").replace("void ","")
+    print(f'{name[:58]:58s} calls={r["Calls"]:>5s} avg_us={float(r["AverageNs"])/1e3:8.2f} pct={float(r["Percentage"]):5.1f}')
+PY
