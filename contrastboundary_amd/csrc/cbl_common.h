@@ -74,4 +74,5 @@ static inline unsigned cbl_round_up8(unsigned g) { return (g + 7u) & ~7u; }
 // A narrower result (the first `nsample` of the wider list) that a grid search may emit along with its own (cbl_knnquery_nested):
 // filled in by the caller; `fused` comes back true where the search kernel wrote idx / dist2 and listed the rows decided by a tie
 // (its second worklist, counters[1]) — otherwise the caller derives them in a pass of its own.
-struct CblKnnNarrow { int nsample; int set_exact; int* idx; float* dist2; bool fused; };
+// `defer_replay` (in): leave the replay of the WIDE result's tied rows to the caller as well (it then runs both replays in one launch).
+struct CblKnnNarrow { int nsample; int set_exact; int* idx; float* dist2; bool fused; bool defer_replay; };

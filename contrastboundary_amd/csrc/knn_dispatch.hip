@@ -118,6 +118,10 @@ __global__ __launch_bounds__(256) void knn_prefix_pow2_kernel(int m, int kb, con
 
 void cbl_knn_grid_scratch(void* ws, int b, int n, int m, int** worklist, int** worklist2, int** zero_counter, const void** grids,
                           const int** cell_start, const void** sorted);      // knn_grid.hip
+int cbl_knn_exact_worklist2(int b, int m, const float* xyz, const float* new_xyz, const int* offset, const int* new_offset,
+                            int K1, int* idx1, float* dist2_1, const int* worklist1, const int* count1,
+                            int K2, int* idx2, float* dist2_2, const int* worklist2, const int* count2,
+                            hipStream_t st, const void* grids, const int* cell_start, const void* sorted);     // knn_exact.hip
 
 static int launch_prefix(int m, int nsample_wide, int nsample, const int* idx_wide, const float* dist2_wide, int* idx, float* dist2, int tie_policy,
                          int* worklist, int* counter, hipStream_t st)
@@ -149,16 +153,26 @@ CBL_EXPORT int cbl_knnquery_nested(int b, int n, int m, int nsample_wide, int ti
     const size_t need = cbl_knn_grid_workspace_bytes(b, n, m, nsample_wide);
     if (need == 0 || !workspace || workspace_bytes < need) return CBL_ERR_UNSUPPORTED;      // only behind the grid path (its scratch is what is reused)
     // with the wave kernel (nsample_wide > 16) the narrow rows and the list of those a tie decides come out of the search itself
-    CblKnnNarrow narrow{nsample, tie_policy, idx, dist2, false};
+    CblKnnNarrow narrow{nsample, tie_policy, idx, dist2, false, true};
     int rc = knnquery_impl(b, n, m, nsample_wide, xyz, new_xyz, offset, new_offset, idx_wide, dist2_wide, workspace, workspace_bytes, tie_policy_wide, stream, cell_order, &narrow);
     if (rc || m == 0) return rc;
     hipStream_t st = cbl_stream(stream);
-    // consumers of the WIDE result on other streams wait for this, not for the derivation and its tie replay
-    if (event_after_wide && hipEventRecord(reinterpret_cast<hipEvent_t>(event_after_wide), st) != hipSuccess) return cbl_status() ? cbl_status() : CBL_ERR_BAD_ARG;
     int *worklist, *worklist2, *counter; const void *grids, *sorted; const int* cell_start;
     cbl_knn_grid_scratch(workspace, b, n, m, &worklist, &worklist2, &counter, &grids, &cell_start, &sorted);
-    if (narrow.fused) worklist = worklist2;
-    else {
+    if (narrow.fused) {
+        // the wave kernel left both worklists behind (wide: worklist / counters[0], narrow: worklist2 / counters[1]) and skipped the wide
+        // replay: one launch replays both, different workgroups each (a replay occupies one or two workgroups: they ran one after the other before)
+        const bool self = (new_xyz == xyz) && (m == n);
+        rc = cbl_knn_exact_worklist2(b, m, xyz, new_xyz, offset, self ? offset : new_offset, nsample_wide, idx_wide, dist2_wide, worklist, counter - 1,
+                                     nsample, idx, dist2, worklist2, counter, st, grids, cell_start, sorted);
+        if (rc) return rc;
+        // consumers of the WIDE result on other streams wait for this
+        if (event_after_wide && hipEventRecord(reinterpret_cast<hipEvent_t>(event_after_wide), st) != hipSuccess) return cbl_status() ? cbl_status() : CBL_ERR_BAD_ARG;
+        return cbl_status();
+    }
+    // consumers of the WIDE result on other streams wait for this, not for the derivation and its tie replay
+    if (event_after_wide && hipEventRecord(reinterpret_cast<hipEvent_t>(event_after_wide), st) != hipSuccess) return cbl_status() ? cbl_status() : CBL_ERR_BAD_ARG;
+    {
         rc = launch_prefix(m, nsample_wide, nsample, idx_wide, dist2_wide, idx, dist2, tie_policy, worklist, counter, st);
         if (rc) return rc;
     }

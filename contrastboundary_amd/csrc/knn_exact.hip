@@ -223,13 +223,24 @@ constexpr int RP_WAVES = 16, RP_T0 = 1024, RP_LIST = 512, RP_MAX_WORK = 1024, RP
 // cloud (the scan made a replay O(n_c): 0.3 ms per tied query at a million points), put into index order by a rank sort and fed last.
 constexpr int RP_TS = 32768, RP_BIG = 65536, RP_GLIST = 2048, RP_MAX_ROWS = 4096;
 
+// A second job (K2 > 0: another result over the same clouds and queries, with its own worklist) shares the launch: even workgroups take
+// job 1, odd ones job 2.  The tied rows of a wide search and of the narrower result derived from it (cbl_knnquery_nested) are both
+// known when the search kernel ends, and a replay keeps one or two workgroups busy while 250 CUs idle: side by side, not one after the other.
 __global__ __launch_bounds__(64 * RP_WAVES) void knn_replay_kernel(
-    int b, int K, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+    int b, int K1, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
     const int* __restrict__ offset, const int* __restrict__ new_offset,
-    int* __restrict__ idx, float* __restrict__ dist2,
-    const int* __restrict__ worklist, const int* __restrict__ worklist_count,
-    const CblGrid* __restrict__ grids, const int* __restrict__ cell_start, const float4* __restrict__ sorted)
+    int* __restrict__ idx1, float* __restrict__ dist2_1,
+    const int* __restrict__ worklist1, const int* __restrict__ worklist_count1,
+    const CblGrid* __restrict__ grids, const int* __restrict__ cell_start, const float4* __restrict__ sorted,
+    int K2, int* __restrict__ idx2, float* __restrict__ dist2_2, const int* __restrict__ worklist2, const int* __restrict__ worklist_count2)
 {
+    const bool two = K2 > 0, second = two && (blockIdx.x & 1u);
+    const int bid = two ? (int)(blockIdx.x >> 1) : (int)blockIdx.x, nbl = two ? (int)(gridDim.x >> 1) : (int)gridDim.x;
+    const int K = second ? K2 : K1;
+    int* __restrict__ idx = second ? idx2 : idx1;
+    float* __restrict__ dist2 = second ? dist2_2 : dist2_1;
+    const int* __restrict__ worklist = second ? worklist2 : worklist1;
+    const int* __restrict__ worklist_count = second ? worklist_count2 : worklist_count1;
     __shared__ float g_d[2][RP_GLIST];
     __shared__ int g_i[2][RP_GLIST];
     __shared__ int g_count, g_over;
@@ -244,11 +255,11 @@ __global__ __launch_bounds__(64 * RP_WAVES) void knn_replay_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (n_work > RP_MAX_WORK) {
         // long lists (lattices: every query tied): parallelism across entries is plentiful, every wave of the grid takes whole queries
-        for (int w = blockIdx.x * RP_WAVES + wave; w < n_work; w += gridDim.x * RP_WAVES)
+        for (int w = bid * RP_WAVES + wave; w < n_work; w += nbl * RP_WAVES)
             exact_wave_query<true>(__builtin_amdgcn_readfirstlane(worklist[w]), b, K, xyz, new_xyz, offset, new_offset, idx, dist2, nullptr);
         return;
     }
-    for (int work = blockIdx.x; work < n_work; work += gridDim.x) {
+    for (int work = bid; work < n_work; work += nbl) {
     __syncthreads();                                            // previous entry's LDS lists are no longer read
     const int q = worklist[work];
     const int c = cbl_cloud_of(q, new_offset, b);
@@ -476,7 +487,7 @@ static int launch_knn_exact(int b, int m, int K, const float* xyz, const float* 
     if (worklist && K <= 64) {
         // one launch: a 1024-lane workgroup per entry for short lists (the normal case: a handful of tied queries), a wave per entry for long ones
         hipLaunchKernelGGL(knn_replay_kernel, dim3(min(nq, RP_GRID)), dim3(64 * RP_WAVES), 0, st, b, K, xyz, new_xyz, offset, new_offset, idx, dist2, worklist, worklist_count,
-                           grids, cell_start, sorted);
+                           grids, cell_start, sorted, 0, nullptr, nullptr, nullptr, nullptr);
         return cbl_status();
     }
     const unsigned blocks = worklist ? (unsigned)min((long long)cbl_div_up(nq, WAVES_PER_BLOCK), 2048LL) : cbl_div_up(nq, WAVES_PER_BLOCK);
@@ -509,4 +520,18 @@ CBL_EXPORT int cbl_knnquery_exact(int b, int n, int m, int nsample, const float*
     if (m == 0) return CBL_OK;
     if (!xyz || !new_xyz || !offset || !new_offset || !idx || !dist2) return CBL_ERR_BAD_ARG;
     return launch_knn_exact(b, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, nullptr, nullptr, 0, cbl_stream(stream));
+}
+
+// two replays over the same clouds and queries in one launch (see knn_replay_kernel): K1, K2 <= 64
+int cbl_knn_exact_worklist2(int b, int m, const float* xyz, const float* new_xyz, const int* offset, const int* new_offset,
+                            int K1, int* idx1, float* dist2_1, const int* worklist1, const int* count1,
+                            int K2, int* idx2, float* dist2_2, const int* worklist2, const int* count2,
+                            hipStream_t st, const void* grids, const int* cell_start, const void* sorted)
+{
+    if (m <= 0) return CBL_OK;
+    if (K1 > 64 || K2 > 64 || K1 <= 0 || K2 <= 0) return CBL_ERR_BAD_ARG;
+    const int per = min(m, RP_GRID);
+    hipLaunchKernelGGL(knn_replay_kernel, dim3(2 * per), dim3(64 * RP_WAVES), 0, st, b, K1, xyz, new_xyz, offset, new_offset, idx1, dist2_1, worklist1, count1,
+                       reinterpret_cast<const CblGrid*>(grids), cell_start, reinterpret_cast<const float4*>(sorted), K2, idx2, dist2_2, worklist2, count2);
+    return cbl_status();
 }

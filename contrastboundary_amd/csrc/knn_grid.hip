@@ -822,6 +822,7 @@ int cbl_knn_grid_launch(int b, int n, int m, int nsample, const float* xyz, cons
     else launch_query<16>(self, b, m, nsample, new_xyz, offset, new_offset, w, idx, dist2, set_exact, st);   // 4 queries per wave
     rc = cbl_status();
     if (rc) return rc;
+    if (narrow && narrow->fused && narrow->defer_replay) return CBL_OK;      // the caller replays both results' tied rows in one launch
     // exact replay of everything that was not certified (device-side count, no host sync)
     return cbl_knn_exact_worklist(b, m, nsample, xyz, new_xyz, self ? offset : offset, self ? offset : new_offset, idx, dist2,
                                   w.worklist, w.counters, m, st, w.grids, w.cell_start, w.sorted);

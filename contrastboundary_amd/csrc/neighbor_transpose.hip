@@ -70,13 +70,13 @@ __global__ __launch_bounds__(NB) void nt_prep_kernel(int n, int nzero, const int
     if (i < nzero) zero[i] = 0;
 }
 
-// A source tile's pairs are walked UN pairs per thread at a time with the three dependent accesses of a pair (its neighbour id, that
-// neighbour's rank, the LDS counter) issued level by level: the kernels are chains of L2 round trips, not bandwidth.
-constexpr int UN = 4;
+// A source tile's pairs are walked UN pairs per thread at a time — UN chosen so that ONE batch covers the tile (64 x nsample pairs over 256
+// threads) — with the three dependent accesses of a pair (its neighbour id, that neighbour's rank, the LDS counter) issued level by
+// level: the kernels are chains of L2 round trips, not bandwidth, and every batch is two of them.
+template <int UN> struct NtPairs { unsigned p[UN]; int r[UN]; };    // flat pair index and target rank (-1: padding / outside the tile)
 
-struct NtPairs { unsigned p[UN]; int r[UN]; };                       // flat pair index and target rank (-1: padding / outside the tile)
-
-__device__ __forceinline__ void nt_load_pairs(NtPairs& q, unsigned base, unsigned total, int n, int ns, CblFastDiv dv, const int* __restrict__ src_ids,
+template <int UN>
+__device__ __forceinline__ void nt_load_pairs(NtPairs<UN>& q, unsigned base, unsigned total, int n, int ns, CblFastDiv dv, const int* __restrict__ src_ids,
                                               const int* __restrict__ idx, const int* __restrict__ rank)
 {
     int t[UN];
@@ -95,6 +95,7 @@ __device__ __forceinline__ void nt_load_pairs(NtPairs& q, unsigned base, unsigne
     }
 }
 
+template <int UN>
 __global__ __launch_bounds__(NB) void nt_count_kernel(int m, int n, int ns, int ntt, CblFastDiv dv, const int* __restrict__ idx, const int* __restrict__ order_src,
                                                       const int* __restrict__ rank, int* __restrict__ tile_cursor, int* __restrict__ list_cursor,
                                                       int* __restrict__ tile_list_off, int* __restrict__ tile_list_n, int2* __restrict__ lists)
@@ -111,8 +112,8 @@ __global__ __launch_bounds__(NB) void nt_count_kernel(int m, int n, int ns, int 
     __syncthreads();
     const unsigned total = (unsigned)nsrc * (unsigned)ns;
     for (unsigned base = 0; base < total; base += UN * NB) {
-        NtPairs q;
-        nt_load_pairs(q, base, total, n, ns, dv, src_ids, idx, rank);
+        NtPairs<UN> q;
+        nt_load_pairs<UN>(q, base, total, n, ns, dv, src_ids, idx, rank);
 #pragma unroll
         for (int u = 0; u < UN; u++) if (q.r[u] >= 0) atomicAdd(&hist[q.r[u] / TT], 1);
     }
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(NB) void nt_count_kernel(int m, int n, int ns, int 
     for (int e = threadIdx.x; e < nmine; e += NB) lists[gbase + e] = mine[e];
 }
 
+template <int UN>
 __global__ __launch_bounds__(NB) void nt_bin_kernel(int m, int n, int ns, int ntt, CblFastDiv dv, const int* __restrict__ idx, const int* __restrict__ order_src,
                                                     const int* __restrict__ rank, const int* __restrict__ tile_cursor, const int* __restrict__ tile_list_off,
                                                     const int* __restrict__ tile_list_n, const int2* __restrict__ lists, int* __restrict__ tile_base,
@@ -163,8 +165,8 @@ __global__ __launch_bounds__(NB) void nt_bin_kernel(int m, int n, int ns, int nt
     __syncthreads();
     const unsigned total = (unsigned)nsrc * (unsigned)ns;
     for (unsigned base = 0; base < total; base += UN * NB) {
-        NtPairs q;
-        nt_load_pairs(q, base, total, n, ns, dv, src_ids, idx, rank);
+        NtPairs<UN> q;
+        nt_load_pairs<UN>(q, base, total, n, ns, dv, src_ids, idx, rank);
 #pragma unroll
         for (int u = 0; u < UN; u++)
             if (q.r[u] >= 0) { const int tt = q.r[u] / TT; bins[where[tt] + atomicAdd(&hist[tt], 1)] = make_int2(q.r[u] & (TT - 1), (int)q.p[u]); }
@@ -172,18 +174,12 @@ __global__ __launch_bounds__(NB) void nt_bin_kernel(int m, int n, int ns, int nt
 }
 
 // counting sort of a target tile's bin by target, then a rank sort by pair inside every target's segment (pair ids are distinct):
-// ascending pairs = the reference loop's summation order.  `stage` is LDS (bins up to STAGE_CAP pairs) or global scratch.
-__device__ __forceinline__ void nt_order_bin(int* __restrict__ stage, int* cnt, const int* lstart, int E, const int2* __restrict__ bin, int* __restrict__ out)
+// ascending pairs = the reference loop's summation order.  `stage` is LDS (bins up to STAGE_CAP pairs) or global scratch.  A thread keeps
+// its entries in registers between the counting pass and the placing pass when the bin is small enough (EPT per thread), else it reloads.
+constexpr int EPT = 16;
+
+__device__ __forceinline__ void nt_rank_sort(const int* __restrict__ stage, const int* lstart, int* __restrict__ out)
 {
-    for (int e0 = 0; e0 < E; e0 += UN * NB) {
-        int2 r[UN];
-#pragma unroll
-        for (int u = 0; u < UN; u++) { const int e = e0 + u * NB + (int)threadIdx.x; r[u] = e < E ? bin[e] : make_int2(-1, 0); }
-#pragma unroll
-        for (int u = 0; u < UN; u++) if (r[u].x >= 0) stage[lstart[r[u].x] + atomicAdd(&cnt[r[u].x], 1)] = r[u].y;
-    }
-    __threadfence_block();
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int slot = wave; slot < TT; slot += NB / 64) {
         const int s0 = lstart[slot], L = lstart[slot + 1] - s0;
@@ -211,14 +207,19 @@ __global__ __launch_bounds__(NB) void nt_finish_kernel(int n, int ntt, const int
     __shared__ int stage_lds[STAGE_CAP];
     const int tt = blockIdx.x;
     const int b0 = tile_base[tt], E = tile_base[tt + 1] - b0;
+    const bool in_regs = E <= EPT * NB;                              // block-uniform
     if (threadIdx.x < TT) cnt[threadIdx.x] = 0;
+    int2 r[EPT];
+    if (in_regs) {
+#pragma unroll
+        for (int u = 0; u < EPT; u++) { const int e = u * NB + (int)threadIdx.x; r[u] = e < E ? bins[b0 + e] : make_int2(-1, 0); }   // one batch of loads
+    }
     __syncthreads();
-    for (int e0 = 0; e0 < E; e0 += UN * NB) {
-        int sl[UN];
+    if (in_regs) {
 #pragma unroll
-        for (int u = 0; u < UN; u++) { const int e = e0 + u * NB + (int)threadIdx.x; sl[u] = e < E ? bins[b0 + e].x : -1; }
-#pragma unroll
-        for (int u = 0; u < UN; u++) if (sl[u] >= 0) atomicAdd(&cnt[sl[u]], 1);
+        for (int u = 0; u < EPT; u++) if (r[u].x >= 0) atomicAdd(&cnt[r[u].x], 1);
+    } else {
+        for (int e = threadIdx.x; e < E; e += NB) atomicAdd(&cnt[bins[b0 + e].x], 1);
     }
     __syncthreads();
     if (threadIdx.x < 64) {                                          // TT == 64: one wave scans the counts
@@ -227,14 +228,28 @@ __global__ __launch_bounds__(NB) void nt_finish_kernel(int n, int ntt, const int
         for (int k = 1; k < 64; k <<= 1) { const int v = __shfl_up(incl, k); if ((int)threadIdx.x >= k) incl += v; }
         lstart[threadIdx.x] = incl - c;
         if (threadIdx.x == 63) lstart[TT] = incl;
-        const int r = tt * TT + threadIdx.x;
-        if (r < n) inv_start[r] = b0 + incl - c;
+        const int row = tt * TT + threadIdx.x;
+        if (row < n) inv_start[row] = b0 + incl - c;
         if (tt == ntt - 1 && threadIdx.x == 63) inv_start[n] = b0 + incl;
         cnt[threadIdx.x] = 0;
     }
     __syncthreads();
-    if (E <= STAGE_CAP) nt_order_bin(stage_lds, cnt, lstart, E, bins + b0, inv_src + b0);
-    else nt_order_bin(scratch + b0, cnt, lstart, E, bins + b0, inv_src + b0);
+    if (E <= STAGE_CAP) {                                            // (EPT * NB <= STAGE_CAP: a register-resident bin is always staged in LDS)
+        if (in_regs) {
+#pragma unroll
+            for (int u = 0; u < EPT; u++) if (r[u].x >= 0) stage_lds[lstart[r[u].x] + atomicAdd(&cnt[r[u].x], 1)] = r[u].y;
+        } else {
+            for (int e = threadIdx.x; e < E; e += NB) { const int2 v = bins[b0 + e]; stage_lds[lstart[v.x] + atomicAdd(&cnt[v.x], 1)] = v.y; }
+        }
+        __syncthreads();
+        nt_rank_sort(stage_lds, lstart, inv_src + b0);
+    } else {
+        int* stage = scratch + b0;
+        for (int e = threadIdx.x; e < E; e += NB) { const int2 v = bins[b0 + e]; stage[lstart[v.x] + atomicAdd(&cnt[v.x], 1)] = v.y; }
+        __threadfence_block();
+        __syncthreads();
+        nt_rank_sort(stage, lstart, inv_src + b0);
+    }
 }
 
 // ---------------------------------------------------------------- K4 as a gather
@@ -338,10 +353,15 @@ CBL_EXPORT int cbl_neighbor_transpose(int m, int n, int nsample, const int* idx,
     hipLaunchKernelGGL(nt_prep_kernel, dim3(cbl_div_up(n > nzero ? n : nzero, NB)), dim3(NB), 0, st, n, nzero, order_dst, w.rank, w.tile_cursor);
     const int* rank = order_dst ? w.rank : nullptr;
     const long long cap = (long long)TS * nsample < ntt ? (long long)TS * nsample : ntt;
-    hipLaunchKernelGGL(nt_count_kernel, dim3(nst), dim3(NB), sizeof(int) * (size_t)((ntt + 1) & ~1) + sizeof(int2) * (size_t)cap, st, m, n, nsample, ntt, dv, idx, order_src, rank,
-                       w.tile_cursor, w.list_cursor, w.tile_list_off, w.tile_list_n, w.lists);
-    hipLaunchKernelGGL(nt_bin_kernel, dim3(nst), dim3(NB), sizeof(int) * 2 * (size_t)ntt, st, m, n, nsample, ntt, dv, idx, order_src, rank, w.tile_cursor,
-                       w.tile_list_off, w.tile_list_n, w.lists, w.tile_base, w.bins);
+    const size_t lds_count = sizeof(int) * (size_t)((ntt + 1) & ~1) + sizeof(int2) * (size_t)cap, lds_bin = sizeof(int) * 2 * (size_t)ntt;
+#define CBL_NT(UN_)                                                                                                                                   \
+    hipLaunchKernelGGL((nt_count_kernel<UN_>), dim3(nst), dim3(NB), lds_count, st, m, n, nsample, ntt, dv, idx, order_src, rank, w.tile_cursor,       \
+                       w.list_cursor, w.tile_list_off, w.tile_list_n, w.lists);                                                                       \
+    hipLaunchKernelGGL((nt_bin_kernel<UN_>), dim3(nst), dim3(NB), lds_bin, st, m, n, nsample, ntt, dv, idx, order_src, rank, w.tile_cursor,           \
+                       w.tile_list_off, w.tile_list_n, w.lists, w.tile_base, w.bins)
+    const int per_thread = (TS * nsample + NB - 1) / NB;             // pairs per thread of a full source tile: one batch where it fits 16
+    if (per_thread <= 4) { CBL_NT(4); } else if (per_thread <= 8) { CBL_NT(8); } else { CBL_NT(16); }
+#undef CBL_NT
     hipLaunchKernelGGL(nt_finish_kernel, dim3(ntt), dim3(NB), 0, st, n, ntt, w.tile_base, w.bins, w.scratch, inv_start, inv_src);
     return cbl_status();
 }

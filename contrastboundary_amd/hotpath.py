@@ -209,7 +209,16 @@ class Schedule:
                 graphs.append(g)
         return graphs
 
+    def _join_table(self, name, state):
+        """the stream about to run a consumer of a transposed table waits for the stream that builds it — here, on the issuing thread (the
+        consumer itself runs on autograd's thread and finds the wait already done: neighbor_state.transpose_lookup)"""
+        key = "cbl_idx" if name.startswith("cbl_") else "idx"
+        if name in ("cbl_mining_loss_bwd", "queryandgroup_bwd") and key in state:
+            pointops.neighbor_transpose(state[key], state[key].shape[0], build=False)
+
     def _launch(self, i, state, events):
+        if self.overlap:
+            self._join_table(self.stage_list[i][0], state)
         if events is not None:
             events[i][0].record()
         self.stage_list[i][1](state)
@@ -219,14 +228,16 @@ class Schedule:
     def _run_branches(self, state, events):
         """the step as a small DAG over four streams:
             main : search -> gather -> KPConv -> [K=16 table] -> grouping backward -> KPConv backward
-            side : (wide result) -> CBL mining + loss -> [K=36 table] -> CBL backward
-            aux  : the two transposed neighbour tables, each as soon as its neighbour table exists — chains of small latency-bound kernels that
-                   need a few CUs, beside the big kernels instead of in front of their consumers
+            side : (wide result) -> K=36 table -> CBL mining + loss -> CBL backward
+            aux  : the transposed table of the block's own (K=16) neighbour table, right behind the search — a chain of small latency-bound
+                   kernels that needs a few CUs, beside gather / KPConv instead of in front of its consumers
+        (Every stream forks from the step's own stream: a fork of a fork — the K=36 table on a stream of its own behind the side stream —
+        crashed hipGraph capture on ROCm 7.2.)
         A consumer finds its table in neighbor_state's registry and waits for the stream that built it (transpose_lookup)."""
         main = torch.cuda.current_stream()
         names = [st[0] for st in self.stage_list]
-        tr_idx = [i for i, nm in enumerate(names) if "neighbor_transpose" in nm]
-        side_idx = [i for i, nm in enumerate(names) if nm.startswith("cbl_") and i not in tr_idx]
+        tr_idx = [i for i, nm in enumerate(names) if "neighbor_transpose" in nm and not nm.startswith("cbl_")]
+        side_idx = [i for i, nm in enumerate(names) if nm.startswith("cbl_")]
         main_idx = [i for i in range(len(names)) if i not in side_idx and i not in tr_idx]
         while len(self.aux) < len(tr_idx):
             self.aux.append(torch.cuda.Stream())
@@ -235,19 +246,12 @@ class Schedule:
         before = {key: id(v) for key, v in state.items()}
         aux_of = {i: self.aux[n] for n, i in enumerate(tr_idx)}
         for i in tr_idx:                                            # the table of the block's own neighbour table: right behind the search
-            if not names[i].startswith("cbl_"):
-                aux_of[i].wait_stream(main)
-                with torch.cuda.stream(aux_of[i]):
-                    self._launch(i, state, events)
-        with torch.cuda.stream(self.side):
-            for i in side_idx:                                      # cache hit on the wide result (waits for its event) -> mining + loss -> backward
+            aux_of[i].wait_stream(main)
+            with torch.cuda.stream(aux_of[i]):
                 self._launch(i, state, events)
-                if names[i].startswith("cbl_knnquery"):             # the wide table exists on this stream from here on: its transposed table beside the mining
-                    for t in tr_idx:
-                        if names[t].startswith("cbl_"):
-                            aux_of[t].wait_stream(self.side)
-                            with torch.cuda.stream(aux_of[t]):
-                                self._launch(t, state, events)
+        with torch.cuda.stream(self.side):
+            for i in side_idx:                                      # cache hit on the wide result (waits for its event) -> its table -> mining + loss -> backward
+                self._launch(i, state, events)
             self.joined.record(self.side)
         for i in main_idx[1:]:
             self._launch(i, state, events)

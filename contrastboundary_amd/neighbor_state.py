@@ -101,7 +101,7 @@ use_spatial_order = True
 # autograd's device thread and must find what the forward thread built.  Unlike a processing order the VALUES of a consumer depend on
 # the table, so an entry keeps the neighbour table itself alive (its storage cannot be recycled under the key) and is only served to the
 # same storage at the same version.
-_transpose_registry = collections.OrderedDict()     # _order_key(idx) -> (idx, order or None, inv_start, inv_src, producer stream)
+_transpose_registry = collections.OrderedDict()     # _order_key(idx) -> (idx, order or None, inv_start, inv_src, producer stream, streams that waited)
 _TRANSPOSE_REGISTRY_MAX = 16
 
 
@@ -112,12 +112,13 @@ def transpose_lookup(idx):
     ent = _transpose_registry.get(_order_key(idx))
     if ent is None or ent[0].data_ptr() != idx.data_ptr() or ent[0].shape != idx.shape:
         return None
-    _, order, inv_start, inv_src, producer = ent
+    _, order, inv_start, inv_src, producer, waited = ent
     cur = torch.cuda.current_stream(idx.device)
-    if producer != cur:                                              # built on another stream: order after it, keep the tensors alive for this one
+    if producer != cur and cur.cuda_stream not in waited:            # built on another stream: order after it ONCE, keep the tensors alive for this one
         cur.wait_stream(producer)
         for t in (inv_start, inv_src) + (() if order is None else (order,)):
             t.record_stream(cur)
+        waited.add(cur.cuda_stream)
     return order, inv_start, inv_src
 
 
@@ -125,7 +126,7 @@ def transpose_register(idx, order, inv_start, inv_src):
     if _version_of(idx) < 0:
         return
     key = _order_key(idx)
-    _transpose_registry[key] = (idx, order, inv_start, inv_src, torch.cuda.current_stream(idx.device))
+    _transpose_registry[key] = (idx, order, inv_start, inv_src, torch.cuda.current_stream(idx.device), set())
     _transpose_registry.move_to_end(key)
     while len(_transpose_registry) > _TRANSPOSE_REGISTRY_MAX:
         _transpose_registry.popitem(last=False)
