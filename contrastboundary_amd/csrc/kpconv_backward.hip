@@ -1,161 +1,139 @@
-// a15 backward without atomics: KPConv's gradients as a gather over the transposed neighbour table.
+// a15 backward without atomics: KPConv's gradients as a gather over the transposed neighbour table, on the matrix cores.
 //   PseudoGrid math   /root/reference/tensorflow/models/local_aggregation_operators.py:681-728
 //     out[i,c] = sum_kp kw[kp,c] * sum_k w[i,kp,k] * f[nbr(i,k), c],   w = influence of kernel point kp on neighbour k of point i
-//   d out / d f    : grad_f[j,c]   = sum over the pairs p = (i,k) with nbr(i,k) = j of  go[i,c] * sum_kp w[p,kp] kw[kp,c]
-//   d out / d kw   : grad_kw[kp,c] = sum over ALL pairs of                              w[p,kp] * f[j,c] * go[i,c]
-// Round 1 walked the query points and scattered d out / d f with one float atomic per (pair, channel): 42 M atomics on the memory side
-// of the fabric, 298 us at N = 40960, K = 16, C = 64.  Here 16 lanes own a TARGET row j (lane = 4 channels) and walk its pairs
-// (cbl_neighbor_transpose).  For every pair the 16 lanes each compute ONE influence weight (lane q: kernel point q)
-// and the weights travel across the 16 lanes by DPP row rotation — step r hands lane q the weight of kernel point src(q, r) — into the
-// per-target sum S_j[kp,c] = sum_p w[p,kp] go[i_p,c], from which both gradients follow once per target.  grad_f is written
-// with plain 16-byte stores; grad_kw is reduced over the lanes of a wave, the waves of a workgroup (LDS) and the workgroups
-// (per-workgroup partial rows + one small reduction kernel): deterministic, no atomics anywhere.
+// Both gradients go through ONE per-target matrix:  S_j[kp,c] = sum over the pairs p = (i,k) with nbr(i,k) = j of  w[p,kp] * go[i_p,c]
+//   d out / d f  :  grad_f[j,c]   = sum_kp kw[kp,c] * S_j[kp,c]
+//   d out / d kw :  grad_kw[kp,c] = sum_j  f[j,c]   * S_j[kp,c]
+// and S_j = W_j^T (KP x pairs) . G_j (pairs x C) is a small GEMM whose contraction runs over the target's PAIRS: the forward kernel
+// transposed.  One wave owns a target row j and walks its pairs (cbl_neighbor_transpose) four per step on v_mfma_f32_16x16x4_f32
+// (M = 16 kernel points, N = 16 channels x 4 tiles, k = 4 pairs): the A operand is the influence weight, ONE per lane and step, computed
+// in registers by the lane that owns (kernel point, pair); the B operand is the gathered output-gradient row (column j of tile t stands
+// for channel 4j + t, so a lane's four B values are one 16-byte load, as in the forward kernel); S lives in 16 accumulator registers.
+// Per target the epilogue contracts S with the kernel weights (grad_f, one 16-byte store per 16 lanes) and adds f_j * S into 16
+// persistent registers (grad_kw), reduced at the end over the waves of a workgroup (LDS) and the workgroups (per-workgroup partial rows +
+// one small reduction kernel).  No atomics anywhere, written not accumulated, deterministic.
+// Round 1 walked the query points and scattered d out / d f with one float atomic per (pair, channel): 42 M atomics on the memory side of
+// the fabric, 298 us at N = 40960, K = 16, C = 64.  A first gather version on the VALU (weights rotated across 16 lanes by DPP, 128
+// accumulators per lane) was bound by instruction issue at two waves per SIMD: 70 us (tools/exp/valu_rate.hip: a wave-instruction costs
+// 3 clocks at that occupancy, a DPP one 5.5).
 #include "cbl_common.h"
 #include "wave_ops.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int KB_NB = 256;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-template <int R> __device__ __forceinline__ float rot_f(float v) { return R == 0 ? v : dpp_mov_f<0x120 + (R == 0 ? 1 : R), 0xf>(v); }
-template <int R> __device__ __forceinline__ int rot_i(int v) { return R == 0 ? v : dpp_mov_i<0x120 + (R == 0 ? 1 : R), 0xf>(v); }
-
-// Both gradients go through ONE per-target sum:  S_j[kp,c] = sum over the pairs p of target j of  w[p,kp] * go[i_p,c]
-//   grad_f[j,c]   = sum_kp kw[kp,c] * S_j[kp,c]          grad_kw[kp,c] += f[j,c] * S_j[kp,c]
-// so a pair costs KP multiply-adds per channel (not 2 KP), and the two contractions with kw / f_j are paid once per target.
-template <int R> struct RotSteps {
-    // steps R .. 15 of the rotation: S[r] += w_r * g   (w_r = the weight of kernel point src(lane, r), handed over by DPP row rotation)
-    static __device__ __forceinline__ void accumulate(float w, const float4& g, float4 (&S)[16])
-    {
-        const float wr = rot_f<R>(w);
-        S[R].x = fmaf(wr, g.x, S[R].x); S[R].y = fmaf(wr, g.y, S[R].y); S[R].z = fmaf(wr, g.z, S[R].z); S[R].w = fmaf(wr, g.w, S[R].w);
-        RotSteps<R + 1>::accumulate(w, g, S);
-    }
-    static __device__ __forceinline__ void sources(int ql, int (&srck)[16])
-    {
-        srck[R] = rot_i<R>(ql);                                      // the lane whose weight arrives at step R = its kernel point
-        RotSteps<R + 1>::sources(ql, srck);
-    }
-};
-template <> struct RotSteps<16> {
-    static __device__ __forceinline__ void accumulate(float, const float4&, float4 (&)[16]) {}
-    static __device__ __forceinline__ void sources(int, int (&)[16]) {}
-};
-
-// 16 lanes per target row (four targets per wave, sixteen per workgroup); C % 4 == 0, rows 16-byte aligned, KP <= 16.
-// A group walks its target's pairs sixteen at a time: lane e of the group fetches pair e (its query point and the offset to it) in two
-// round trips for all sixteen, then the pairs are taken one by one — broadcast inside the group (ds_bpermute, one pair ahead), one
-// influence weight per lane, the 16 rotation steps into S.  Four independent targets per wave and four gradient rows in flight per group
-// cover the L2 round trips; nothing is reduced across lanes for grad_f (each lane owns 4 channels of its target).  Every load is
-// unconditional with a clamped address and masked afterwards, and every loop has a scalar trip count: exec-masked blocks and
-// vector-controlled loops made the compiler keep three copies of the 128 accumulators.
+// one wave per target row (four per workgroup); C % 4 == 0, rows 16-byte aligned, KP <= 16.
 // partial: (gridDim.x, KP, C) per-workgroup sums of grad_kw.
-template <bool GF, bool GKW>
+template <bool GF, bool GKW, bool CLOSEST>
 __global__ __launch_bounds__(KB_NB) void kpconv_bwd_csr_kernel(unsigned n0, int C, int KP, CblFastDiv dvK, const float* __restrict__ q, const float* __restrict__ s,
                                                                const float* __restrict__ f, const float* __restrict__ kpts, const float* __restrict__ kw,
-                                                               float extent, int influence, int closest, const float* __restrict__ go,
+                                                               float extent, int influence, const float* __restrict__ go,
                                                                const int* __restrict__ order, const int* __restrict__ inv_start, const int* __restrict__ inv_src,
                                                                float* __restrict__ gf, float* __restrict__ partial)
 {
     __shared__ float red[KB_NB / 64][16][64];                        // grad_kw of the four waves: [wave][kernel point][channel of the chunk]
-    __shared__ float kw_s[16][64];                                   // kernel weights of the channel chunk (rows >= KP and channels >= C: 0)
     const int lane = threadIdx.x & 63;
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int grp = lane >> 4, ql = lane & 15;
-    const bool kp_ok = ql < KP;
-    const float kx = kp_ok ? kpts[3 * ql] : 0.f, ky = kp_ok ? kpts[3 * ql + 1] : 0.f, kz = kp_ok ? kpts[3 * ql + 2] : 0.f;
+    const int kp = lane & 15;             // A row / kernel point; also B / D column j
+    const int kq = lane >> 4;             // pair within a step of four; D row block
+    const bool kp_ok = kp < KP;
+    const float kx = kp_ok ? kpts[3 * kp] : 0.f, ky = kp_ok ? kpts[3 * kp + 1] : 0.f, kz = kp_ok ? kpts[3 * kp + 2] : 0.f;
     const float inv_extent = 1.0f / extent;
-    const unsigned nwg = (n0 + 15) >> 4;
-    int srck[16];
-    RotSteps<0>::sources(ql, srck);
+    const unsigned nwg = (n0 + 3) >> 2;
     for (int c0 = 0; c0 < C; c0 += 64) {
-        const bool cok = c0 + 4 * ql < C;
-        const int cb = cok ? c0 + 4 * ql : c0;                       // lanes beyond the last channel read the chunk's first four and contribute nothing
-        __syncthreads();
-        for (int e = threadIdx.x; e < 16 * 64; e += KB_NB) {
-            const int kp = e >> 6, cc = e & 63;
-            kw_s[kp][cc] = (kp < KP && c0 + cc < C) ? kw[(size_t)kp * C + c0 + cc] : 0.f;
+        const bool cok = c0 + 4 * kp < C;
+        const int cb = cok ? c0 + 4 * kp : c0;                       // lanes beyond the last channel read the chunk's first four and write nothing
+        // kernel weights of this lane's accumulator elements: tile t, row r <-> kernel point 4*kq + r, channel cb + t
+        float kwr[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = kq * 4 + r;
+            const float4 kv = *reinterpret_cast<const float4*>(kw + (size_t)(row < KP ? row : 0) * C + cb);
+            const bool on = row < KP && cok;
+            kwr[0][r] = on ? kv.x : 0.f; kwr[1][r] = on ? kv.y : 0.f; kwr[2][r] = on ? kv.z : 0.f; kwr[3][r] = on ? kv.w : 0.f;
         }
-        __syncthreads();
-        float4 gk[16];
+        f32x4 gk[4];
 #pragma unroll
-        for (int r = 0; r < 16; r++) gk[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < 4; t++) gk[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (unsigned v = blockIdx.x; v < 8 * cbl_xcd_per(nwg); v += gridDim.x) {
-            const unsigned tr = cbl_xcd_slot(v, nwg) * 16 + wave * 4 + grp;
-            const bool tok = tr < n0;
-            const int j = tok ? (order ? order[tr] : (int)tr) : 0;
-            const int s0 = tok ? inv_start[tr] : 0, s1 = tok ? inv_start[tr + 1] : 0;
+            const unsigned tr = cbl_xcd_slot(v, nwg) * 4 + wave;     // wave-uniform
+            if (tr >= n0) continue;
+            const int j = order ? order[tr] : (int)tr;
+            const int s0 = inv_start[tr], s1 = inv_start[tr + 1];
             const float xj = s[3 * j], yj = s[3 * j + 1], zj = s[3 * j + 2];
-            float4 S[16];
+            f32x4 acc[4];
 #pragma unroll
-            for (int r = 0; r < 16; r++) S[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-            // ONE loop over the pairs of the longest target of the wave (a scalar trip count; a second loop level around the 64 accumulators cost
-            // ~50 registers): every 16 trips lane e of a group fetches pair e of the next sixteen (its query point and the offset to it);
-            // four gradient rows in flight per group, the offset of the next pair broadcast one trip ahead
-            const int L = s1 - s0;
-            int most = L;
-            most = max(most, __shfl_xor(most, 16)); most = max(most, __shfl_xor(most, 32));
-            most = __builtin_amdgcn_readfirstlane(most);
-            int pi = 0; float rx = 0.f, ry = 0.f, rz = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
-            float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0, g3 = g0;
-            auto row = [&](int t) -> float4 {
-                const int pit = __shfl(pi, t & 15, 16);
-                return *reinterpret_cast<const float4*>(go + (size_t)pit * C + cb);         // pairs beyond L: some valid row, weight 0 below
-            };
-#pragma unroll 1
-            for (int t = 0; t < most; t++) {
-                if ((t & 15) == 0) {                                 // wave-uniform
-                    const int e = s0 + t + ql;
-                    pi = (int)cbl_fastdiv((unsigned)inv_src[e < s1 ? e : 0], dvK);             // query point of pair e (entry 0 always exists)
-                    rx = xj - q[3 * pi]; ry = yj - q[3 * pi + 1]; rz = zj - q[3 * pi + 2];     // neighbour - centre (:681-684)
-                    g0 = row(0); g1 = row(1); g2 = row(2); g3 = row(3);
-                    nx = __shfl(rx, 0, 16); ny = __shfl(ry, 0, 16); nz = __shfl(rz, 0, 16);
-                }
-                const float4 g = g0;
-                const float dx = nx - kx, dy = ny - ky, dz = nz - kz;
-                g0 = g1; g1 = g2; g2 = g3; g3 = row(t + 4);          // (rows past the sixteen are refetched at the next boundary)
-                nx = __shfl(rx, (t + 1) & 15, 16); ny = __shfl(ry, (t + 1) & 15, 16); nz = __shfl(rz, (t + 1) & 15, 16);
-                const float sq = (dx * dx + dy * dy) + dz * dz;                                  // :688
-                float w = influence ? fmaxf(1.0f - __builtin_amdgcn_sqrtf(sq) * inv_extent, 0.0f) : 1.0f;           // :697 / :693 (as the forward kernel)
-                if (closest) {                                                                   // argmin over kernel points, first minimum (:705-708)
-                    float bs = kp_ok ? sq : INFINITY; int bi = ql;
+            for (int t = 0; t < 4; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int eb = s0; eb < s1; eb += 64) {
+                // lane e holds pair eb + e: its query point and the offset of the target from it (entries past the end: clamped, weight 0 below)
+                const int e = eb + lane;
+                const int pi = (int)cbl_fastdiv((unsigned)inv_src[e < s1 ? e : s0], dvK);
+                const float3 qq = *reinterpret_cast<const float3*>(q + 3 * (size_t)pi);          // one 12-byte load per lane
+                const float rx = xj - qq.x, ry = yj - qq.y, rz = zj - qq.z;                      // neighbour - centre (:681-684)
+                const int cnt = min(64, s1 - eb);
+#pragma unroll 2
+                for (int st = 0; st < cnt; st += 4) {
+                    const int src = st + kq;                                                     // this lane's pair of the step
+                    const int pit = __shfl(pi, src);
+                    const float dx = __shfl(rx, src) - kx, dy = __shfl(ry, src) - ky, dz = __shfl(rz, src) - kz;
+                    const float4 g = *reinterpret_cast<const float4*>(go + (size_t)pit * C + cb);   // B operand: 16 lanes = one 256 B row segment per pair
+                    const float sq = (dx * dx + dy * dy) + dz * dz;                              // :688
+                    float w = influence ? fmaxf(1.0f - __builtin_amdgcn_sqrtf(sq) * inv_extent, 0.0f) : 1.0f;       // :697 / :693 (as the forward kernel)
+                    if (CLOSEST) {                                                               // argmin over kernel points, first minimum (:705-708)
+                        float bs = kp_ok ? sq : INFINITY; int bi = kp;
 #pragma unroll
-                    for (int sft = 8; sft >= 1; sft >>= 1) {
-                        const float os = __shfl_xor(bs, sft, 16); const int oi = __shfl_xor(bi, sft, 16);
-                        if (os < bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
+                        for (int sft = 8; sft >= 1; sft >>= 1) {
+                            const float os = __shfl_xor(bs, sft, 16); const int oi = __shfl_xor(bi, sft, 16);
+                            if (os < bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
+                        }
+                        w = (bi != kp) ? 0.f : w;
                     }
-                    if (bi != ql) w = 0.f;
+                    const float a = (kp_ok && src < cnt) ? w : 0.f;                             // pairs past the end of the list contribute nothing
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, g.x, acc[0], 0, 0, 0);      // S += W^T G
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, g.y, acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, g.z, acc[2], 0, 0, 0);
+                    acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, g.w, acc[3], 0, 0, 0);
                 }
-                w = (kp_ok && t < L) ? w : 0.f;                                                 // also silences the rows fetched beyond L
-                RotSteps<0>::accumulate(w, g, S);
             }
-            // the two contractions of S, once per target: grad_f with the kernel weights (LDS), grad_kw's accumulators with the target's features
-            const float4 fj = GKW ? *reinterpret_cast<const float4*>(f + (size_t)j * C + cb) : make_float4(0.f, 0.f, 0.f, 0.f);
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            // the two contractions of S, once per target: tile t, row r of this lane <-> kernel point 4*kq + r, channel cb + t
+            if (GF) {
+                float res[4];
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                if (GF) {
-                    const float4 kv = *reinterpret_cast<const float4*>(&kw_s[srck[r]][4 * ql]);
-                    acc.x = fmaf(kv.x, S[r].x, acc.x); acc.y = fmaf(kv.y, S[r].y, acc.y); acc.z = fmaf(kv.z, S[r].z, acc.z); acc.w = fmaf(kv.w, S[r].w, acc.w);
+                for (int t = 0; t < 4; t++) {
+                    float part = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) part = fmaf(kwr[t][r], acc[t][r], part);
+                    part += __shfl_xor(part, 16);
+                    part += __shfl_xor(part, 32);
+                    res[t] = part;
                 }
-                if (GKW) { gk[r].x = fmaf(fj.x, S[r].x, gk[r].x); gk[r].y = fmaf(fj.y, S[r].y, gk[r].y); gk[r].z = fmaf(fj.z, S[r].z, gk[r].z); gk[r].w = fmaf(fj.w, S[r].w, gk[r].w); }
+                if (lane < 16 && cok) *reinterpret_cast<float4*>(gf + (size_t)j * C + cb) = make_float4(res[0], res[1], res[2], res[3]);
             }
-            if (GF && tok && cok) *reinterpret_cast<float4*>(gf + (size_t)j * C + cb) = acc;
+            if (GKW) {
+                const float4 fj = *reinterpret_cast<const float4*>(f + (size_t)j * C + cb);
+                const float fv[4] = {fj.x, fj.y, fj.z, fj.w};
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) gk[t][r] = fmaf(fv[t], acc[t][r], gk[t][r]);
+            }
         }
         if (GKW) {
-            // the four groups of a wave, then the four waves of the workgroup, then one partial row block per workgroup
+            // every (kernel point, channel) of the chunk is held by exactly one lane of a wave: the four waves of the workgroup through LDS,
+            // then one partial row block per workgroup
+            __syncthreads();
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                float4 t = gk[r];
-                t.x += __shfl_xor(t.x, 16); t.y += __shfl_xor(t.y, 16); t.z += __shfl_xor(t.z, 16); t.w += __shfl_xor(t.w, 16);
-                t.x += __shfl_xor(t.x, 32); t.y += __shfl_xor(t.y, 32); t.z += __shfl_xor(t.z, 32); t.w += __shfl_xor(t.w, 32);
-                if (grp == 0) *reinterpret_cast<float4*>(&red[wave][srck[r]][4 * ql]) = t;
-            }
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) red[wave][kq * 4 + r][4 * kp + t] = gk[t][r];
             __syncthreads();
             for (int e = threadIdx.x; e < 16 * 64; e += KB_NB) {
-                const int kp = e >> 6, cc = e & 63;
-                const float sum = (red[0][kp][cc] + red[1][kp][cc]) + (red[2][kp][cc] + red[3][kp][cc]);
-                if (kp < KP && c0 + cc < C) partial[((size_t)blockIdx.x * KP + kp) * C + c0 + cc] = sum;
+                const int row = e >> 6, cc = e & 63;
+                const float sum = (red[0][row][cc] + red[1][row][cc]) + (red[2][row][cc] + red[3][row][cc]);
+                if (row < KP && c0 + cc < C) partial[((size_t)blockIdx.x * KP + row) * C + c0 + cc] = sum;
             }
         }
     }
@@ -189,8 +167,10 @@ __global__ __launch_bounds__(KB_NB) void kpconv_gkw_reduce_kernel(int nblk, int 
 
 unsigned kb_grid(int n0)
 {
-    unsigned g = cbl_round_up8(cbl_div_up(n0, 16));                    // 16 target rows per workgroup and trip
-    return g > 768u ? 768u : g;
+    unsigned g = cbl_round_up8(cbl_div_up(n0, 4));                     // 4 target rows per workgroup and trip
+    static const char* env = getenv("CBL_KB_GRID");                   // tuning knob (tools/exp/kb_probe.py): workgroups of the persistent launch
+    const unsigned cap = env ? (unsigned)atoi(env) : 1024u;
+    return g > cap ? cap : g;
 }
 
 }  // namespace
@@ -217,11 +197,17 @@ CBL_EXPORT int cbl_kpconv_backward_csr(int n, int n0, int K, int C, int KP, cons
     float* partial = reinterpret_cast<float*>(workspace);
     if (grad_kernel_weights && (!partial || workspace_bytes < cbl_kpconv_backward_csr_workspace_bytes(n0, C, KP))) return CBL_ERR_WORKSPACE;
     const CblFastDiv dv = cbl_fastdiv_make((unsigned)K);
-#define CBL_KB(GF_, GKW_) hipLaunchKernelGGL((kpconv_bwd_csr_kernel<GF_, GKW_>), dim3(g), dim3(KB_NB), 0, st, (unsigned)n0, C, KP, dv, query_points, support_points, \
-        features, kernel_points, kernel_weights, extent, influence, closest, grad_out, order_dst, inv_start, inv_src, grad_features, partial)
-    if (grad_features && grad_kernel_weights) CBL_KB(true, true);
-    else if (grad_features) CBL_KB(true, false);
-    else CBL_KB(false, true);
+#define CBL_KB(GF_, GKW_, CL_) hipLaunchKernelGGL((kpconv_bwd_csr_kernel<GF_, GKW_, CL_>), dim3(g), dim3(KB_NB), 0, st, (unsigned)n0, C, KP, dv, query_points, support_points, \
+        features, kernel_points, kernel_weights, extent, influence, grad_out, order_dst, inv_start, inv_src, grad_features, partial)
+    if (closest) {
+        if (grad_features && grad_kernel_weights) CBL_KB(true, true, true);
+        else if (grad_features) CBL_KB(true, false, true);
+        else CBL_KB(false, true, true);
+    } else {
+        if (grad_features && grad_kernel_weights) CBL_KB(true, true, false);
+        else if (grad_features) CBL_KB(true, false, false);
+        else CBL_KB(false, true, false);
+    }
 #undef CBL_KB
     if (grad_kernel_weights)
         hipLaunchKernelGGL(kpconv_gkw_reduce_kernel, dim3(cbl_div_up(KP * C, 16)), dim3(KB_NB), 0, st, (int)g, KP * C, partial, grad_kernel_weights);

@@ -60,7 +60,10 @@ __global__ __launch_bounds__(256) void kpconv_fwd_kernel(int n, int n0, int K, i
     };
     auto fetch_xyz = [&](Geo& g) {                                  // second: the neighbours' coordinates; the shadow point sits at (1e6,1e6,1e6)  (:681-684)
         const bool real = g.id >= 0 && g.id < n0;
-        g.sx = real ? s[3 * g.id] : 1e6f; g.sy = real ? s[3 * g.id + 1] : 1e6f; g.sz = real ? s[3 * g.id + 2] : 1e6f;
+        // one 12-byte load per lane (three dword loads cost the texture path three passes over the 64 scattered addresses), unconditional
+        // with a clamped row, masked afterwards
+        const float3 sp = *reinterpret_cast<const float3*>(s + 3 * (size_t)(real ? g.id : 0));
+        g.sx = real ? sp.x : 1e6f; g.sy = real ? sp.y : 1e6f; g.sz = real ? sp.z : 1e6f;
     };
     int p0 = point_at(blockIdx.x), p1 = point_at(blockIdx.x + vstep);
     Geo cur = {n0, 1e6f, 1e6f, 1e6f, 0.f, 0.f, 0.f};

@@ -126,7 +126,8 @@ __global__ __launch_bounds__(NB) void nt_count_kernel(int m, int n, int ns, int 
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) { gbase = atomicAdd(list_cursor, nmine); tile_list_off[st] = gbase; tile_list_n[st] = nmine; }
+    // a source tile's records live at its own offset (a tile touches at most as many bins as it has pairs): no cursor all tiles would queue on
+    if (threadIdx.x == 0) { gbase = st * TS * ns; tile_list_off[st] = gbase; tile_list_n[st] = nmine; }
     __syncthreads();
     for (int e = threadIdx.x; e < nmine; e += NB) lists[gbase + e] = mine[e];
 }
