@@ -163,16 +163,30 @@ __global__ __launch_bounds__(256) void contrast_gather_kernel(unsigned m, CblFas
         const float4 ft = feat[(size_t)t * LR + q];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (count > 0.f) {
-#pragma unroll 4
-            for (int base = s0; base < s1; base += PP) {
-                const int e = base + s;
-                const int p = e < s1 ? inv_src[e] : -1;
-                const float c = p >= 0 ? coef[p] : 0.f;
-                if (c != 0.f) {
-                    const unsigned i = cbl_fastdiv((unsigned)p, dv);
-                    const float4 fi = feat[(size_t)i * LR + q];
-                    acc.x += c * (ft.x - fi.x); acc.y += c * (ft.y - fi.y); acc.z += c * (ft.z - fi.z); acc.w += c * (ft.w - fi.w);
-                }
+            // lane e takes entry e of the list (its pair and that pair's coefficient) for 64 entries at a time: two round trips for all of
+            // them, then the rows of the sources are gathered PP at a time with every address already known (a third round trip in all)
+            for (int eb = s0; eb < s1; eb += 64) {
+                const int e = eb + lane;
+                const int p = inv_src[e < s1 ? e : s0];
+                const float c = e < s1 ? coef[p] : 0.f;
+                const unsigned src_pt = cbl_fastdiv((unsigned)p, dv);
+                const int cnt = min(64, s1 - eb);
+                // the 64 entries in two halves of 32, each fully unrolled: its 32 / PP row loads are issued back to back (entries past the end
+                // carry a zero coefficient and a valid source row)
+                auto half = [&](int h0) {
+#pragma unroll
+                    for (int b0 = 0; b0 < 32; b0 += PP) {
+                        const int src = h0 + b0 + s;
+                        const float ce = __shfl(c, src);             // 0 for entries past the end and for pairs without a gradient
+                        const unsigned ie = (unsigned)__shfl((int)src_pt, src);
+                        // unconditional (a row fetched for a zero coefficient adds nothing): a load inside an `if` waits inside it, one round
+                        // trip per step instead of one for all
+                        const float4 fi = feat[(size_t)ie * LR + q];
+                        acc.x += ce * (ft.x - fi.x); acc.y += ce * (ft.y - fi.y); acc.z += ce * (ft.z - fi.z); acc.w += ce * (ft.w - fi.w);
+                    }
+                };
+                half(0);
+                if (PP <= 32 && cnt > 32) half(32);               // (PP = 64: the first call already covered all 64 entries)
             }
         }
         acc.x = slots_sum<LR>(acc.x); acc.y = slots_sum<LR>(acc.y); acc.z = slots_sum<LR>(acc.z); acc.w = slots_sum<LR>(acc.w);

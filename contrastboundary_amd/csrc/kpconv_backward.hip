@@ -58,19 +58,40 @@ __global__ __launch_bounds__(KB_NB) void kpconv_bwd_csr_kernel(unsigned n0, int 
         f32x4 gk[4];
 #pragma unroll
         for (int t = 0; t < 4; t++) gk[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (unsigned v = blockIdx.x; v < 8 * cbl_xcd_per(nwg); v += gridDim.x) {
-            const unsigned tr = cbl_xcd_slot(v, nwg) * 4 + wave;     // wave-uniform
-            if (tr >= n0) continue;
-            const int j = order ? order[tr] : (int)tr;
-            const int s0 = inv_start[tr], s1 = inv_start[tr + 1];
-            const float xj = s[3 * j], yj = s[3 * j + 1], zj = s[3 * j + 2];
+        // A target is five dependent round trips (sequence slot -> row id and list bounds -> pairs and coordinates -> query coordinates ->
+        // gradient rows: ~1100 clocks each, the tables were written by other XCDs) in front of ~500 clocks of matrix work; PMC: 56 % of the
+        // wave cycles were s_waitcnt.  The first three are prefetched: the bounds two targets ahead, the first 64 pairs and the target's
+        // coordinates one target ahead (values only, nothing branches on them before their own trip).
+        const unsigned vend = 8 * cbl_xcd_per(nwg), vstep = gridDim.x;
+        auto bounds = [&](unsigned v, int& ok, int& jj, int& b0, int& b1) {
+            const unsigned tr = (v < vend ? cbl_xcd_slot(v, nwg) : 0u) * 4 + wave;
+            ok = (v < vend && tr < n0) ? 1 : 0;
+            const unsigned trc = ok ? tr : 0u;
+            jj = order ? order[trc] : (int)trc; b0 = inv_start[trc]; b1 = inv_start[trc + 1];
+        };
+        auto pairs = [&](int ok, int jj, int b0, int b1, int& pp, float& x, float& y, float& z) {
+            const int e = b0 + lane;
+            pp = inv_src[(ok && e < b1) ? e : 0];                     // entry 0 always exists; lanes past the list are masked by the weight
+            x = s[3 * jj]; y = s[3 * jj + 1]; z = s[3 * jj + 2];
+        };
+        int okA, jA, s0A, s1A, okB, jB, s0B, s1B, pB; float xB, yB, zB;
+        bounds(blockIdx.x, okB, jB, s0B, s1B);
+        pairs(okB, jB, s0B, s1B, pB, xB, yB, zB);
+        bounds(blockIdx.x + vstep, okA, jA, s0A, s1A);
+        for (unsigned v = blockIdx.x; v < vend; v += vstep) {
+            const int ok = okB, jv = jB, s0v = s0B, s1v = s1B, p0 = pB; const float xj = xB, yj = yB, zj = zB;      // this trip's target
+            okB = okA; jB = jA; s0B = s0A; s1B = s1A;
+            pairs(okB, jB, s0B, s1B, pB, xB, yB, zB);                // pairs + coordinates of the next target
+            bounds(v + 2 * vstep, okA, jA, s0A, s1A);                // bounds of the one after
+            if (!__builtin_amdgcn_readfirstlane(ok)) continue;
+            const int j = __builtin_amdgcn_readfirstlane(jv), s0 = __builtin_amdgcn_readfirstlane(s0v), s1 = __builtin_amdgcn_readfirstlane(s1v);
             f32x4 acc[4];
 #pragma unroll
             for (int t = 0; t < 4; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int eb = s0; eb < s1; eb += 64) {
                 // lane e holds pair eb + e: its query point and the offset of the target from it (entries past the end: clamped, weight 0 below)
                 const int e = eb + lane;
-                const int pi = (int)cbl_fastdiv((unsigned)inv_src[e < s1 ? e : s0], dvK);
+                const int pi = (int)cbl_fastdiv((unsigned)(eb == s0 ? p0 : inv_src[e < s1 ? e : s0]), dvK);     // the first 64 pairs were prefetched
                 const float3 qq = *reinterpret_cast<const float3*>(q + 3 * (size_t)pi);          // one 12-byte load per lane
                 const float rx = xj - qq.x, ry = yj - qq.y, rz = zj - qq.z;                      // neighbour - centre (:681-684)
                 const int cnt = min(64, s1 - eb);

@@ -19,6 +19,7 @@
 //              (target slot, pair) into its reserved ranges
 //   nt_finish  per target tile: counting sort by target in LDS, rank sort by pair inside each target's segment, writes inv_start / inv_src
 #include "cbl_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -179,11 +180,54 @@ __global__ __launch_bounds__(NB) void nt_bin_kernel(int m, int n, int ns, int nt
 // its entries in registers between the counting pass and the placing pass when the bin is small enough (EPT per thread), else it reloads.
 constexpr int EPT = 16;
 
+// ascending bitonic sort of one int per lane over the 64 lanes ("flip" form: every merge starts with a mirror exchange), exchanges on the
+// VALU's data-parallel primitives / ds_swizzle — the network of knn_grid.hip's wave_sort64, keys only
+template <int CTRL> __device__ __forceinline__ int nt_dpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ int nt_cx(int v, int partner, bool lower) { return lower ? min(v, partner) : max(v, partner); }
+__device__ __forceinline__ int nt_wave_sort64(int v, int lane)
+{
+    const bool l1 = !(lane & 1), l2 = !(lane & 2), l4 = !(lane & 4), l8 = !(lane & 8), l16 = !(lane & 16), l32 = !(lane & 32);
+#define X1(v) nt_dpp<0xB1>(v)
+#define X2(v) nt_dpp<0x4E>(v)
+#define QM(v) nt_dpp<0x1B>(v)
+#define HM(v) nt_dpp<0x141>(v)
+#define RM(v) nt_dpp<0x140>(v)
+#define R8(v) nt_dpp<0x128>(v)
+#define S4(v) __builtin_amdgcn_ds_swizzle(v, 0x101f)
+#define S16(v) __builtin_amdgcn_ds_swizzle(v, 0x401f)
+#define M32(v) __builtin_amdgcn_ds_swizzle(v, 0x7c1f)
+#define M64(v) __builtin_amdgcn_ds_bpermute((63 - lane) << 2, v)
+    v = nt_cx(v, X1(v), l1);
+    v = nt_cx(v, QM(v), l2);  v = nt_cx(v, X1(v), l1);
+    v = nt_cx(v, HM(v), l4);  v = nt_cx(v, X2(v), l2);  v = nt_cx(v, X1(v), l1);
+    v = nt_cx(v, RM(v), l8);  v = nt_cx(v, S4(v), l4);  v = nt_cx(v, X2(v), l2);  v = nt_cx(v, X1(v), l1);
+    v = nt_cx(v, M32(v), l16); v = nt_cx(v, R8(v), l8); v = nt_cx(v, S4(v), l4);  v = nt_cx(v, X2(v), l2); v = nt_cx(v, X1(v), l1);
+    v = nt_cx(v, M64(v), l32); v = nt_cx(v, S16(v), l16); v = nt_cx(v, R8(v), l8); v = nt_cx(v, S4(v), l4); v = nt_cx(v, X2(v), l2); v = nt_cx(v, X1(v), l1);
+#undef X1
+#undef X2
+#undef QM
+#undef HM
+#undef RM
+#undef R8
+#undef S4
+#undef S16
+#undef M32
+#undef M64
+    return v;
+}
+
+// every target's segment into ascending pair order (pair ids are distinct): one wave per target, the segment in registers (up to 64
+// pairs: a 21-stage exchange network; the rank sort through LDS it replaces cost 13 of the kernel's 19 us), longer segments by rank
 __device__ __forceinline__ void nt_rank_sort(const int* __restrict__ stage, const int* lstart, int* __restrict__ out)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int slot = wave; slot < TT; slot += NB / 64) {
         const int s0 = lstart[slot], L = lstart[slot + 1] - s0;
+        if (L <= 64) {                                               // wave-uniform
+            const int v = nt_wave_sort64(lane < L ? stage[s0 + lane] : 0x7fffffff, lane);
+            if (lane < L) out[s0 + lane] = v;
+            continue;
+        }
         for (int c = 0; c < L; c += 64) {
             const int e = c + lane;
             const int mine = e < L ? stage[s0 + e] : 0x7fffffff;
@@ -202,7 +246,7 @@ __device__ __forceinline__ void nt_rank_sort(const int* __restrict__ stage, cons
 }
 
 __global__ __launch_bounds__(NB) void nt_finish_kernel(int n, int ntt, const int* __restrict__ tile_base, const int2* __restrict__ bins, int* __restrict__ scratch,
-                                                       int* __restrict__ inv_start, int* __restrict__ inv_src)
+                                                       int* __restrict__ inv_start, int* __restrict__ inv_src, int debug)
 {
     __shared__ int cnt[TT], lstart[TT + 1];
     __shared__ int stage_lds[STAGE_CAP];
@@ -243,7 +287,8 @@ __global__ __launch_bounds__(NB) void nt_finish_kernel(int n, int ntt, const int
             for (int e = threadIdx.x; e < E; e += NB) { const int2 v = bins[b0 + e]; stage_lds[lstart[v.x] + atomicAdd(&cnt[v.x], 1)] = v.y; }
         }
         __syncthreads();
-        nt_rank_sort(stage_lds, lstart, inv_src + b0);
+        if (debug & 1) { for (int e = threadIdx.x; e < E; e += NB) inv_src[b0 + e] = stage_lds[e]; }      // TIMING EXPERIMENT ONLY: unsorted segments
+        else nt_rank_sort(stage_lds, lstart, inv_src + b0);
     } else {
         int* stage = scratch + b0;
         for (int e = threadIdx.x; e < E; e += NB) { const int2 v = bins[b0 + e]; stage[lstart[v.x] + atomicAdd(&cnt[v.x], 1)] = v.y; }
@@ -363,7 +408,8 @@ CBL_EXPORT int cbl_neighbor_transpose(int m, int n, int nsample, const int* idx,
     const int per_thread = (TS * nsample + NB - 1) / NB;             // pairs per thread of a full source tile: one batch where it fits 16
     if (per_thread <= 4) { CBL_NT(4); } else if (per_thread <= 8) { CBL_NT(8); } else { CBL_NT(16); }
 #undef CBL_NT
-    hipLaunchKernelGGL(nt_finish_kernel, dim3(ntt), dim3(NB), 0, st, n, ntt, w.tile_base, w.bins, w.scratch, inv_start, inv_src);
+    static const char* dbg = getenv("CBL_NT_DEBUG");                 // timing experiments (tools/exp): never set in tests or bench
+    hipLaunchKernelGGL(nt_finish_kernel, dim3(ntt), dim3(NB), 0, st, n, ntt, w.tile_base, w.bins, w.scratch, inv_start, inv_src, dbg ? atoi(dbg) : 0);
     return cbl_status();
 }
 
