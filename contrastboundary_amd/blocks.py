@@ -139,3 +139,47 @@ class PointTransformerBlock(nn.Module):
         x = x + identity
         x = self.relu(x)
         return [p, x, o]
+
+
+class MLPbyOps(nn.Module):
+    """String-configured MLP of the reference, blocks.py:194-247 ('linear', 'linearbn', 'mlp', 'mlp2', ... joined by '-'): the projection
+    in front of the contrast (heads.py:90-92) and the *_ops heads.  Same construction order and module names (`ops_func.<k>`), so a state_dict
+    of the reference loads and a model built under the same seed has the same initial parameters; the dense layers run through dense.sequential."""
+    mlp_kwargs = {"activation": "relu", "bias": True, "bn": True, "linear_bn": False}
+
+    def __init__(self, ops, fdim, d_mid=None, d_out=None, **kwargs):
+        super().__init__()
+        import re
+        ops_seq = ops.split("-") if "-" in ops else [ops]
+        d_mid = d_mid if d_mid else fdim
+        d_out = d_out if d_out else d_mid
+        layers = []
+        for op in ops_seq:
+            assert "mlp" in op or op in ["linear", "linearbn"], f"invalid ops = {op}"
+            kw = dict(self.mlp_kwargs); kw.update(kwargs)
+            num = re.search(r"\d+", op)
+            num = int(num.group()) if num else 1
+            linear = "linear" in op or not op.endswith("mlp")        # linear / linearbn / mlp2: ends with a plain Linear (:217)
+
+            def add(din, dout, kw):
+                layers.append(nn.Linear(din, dout, bias=kw["bias"]))
+                if kw["bn"]:
+                    layers.append(nn.BatchNorm1d(dout))
+                if kw["activation"] == "relu":
+                    layers.append(nn.ReLU(inplace=True))
+                elif kw["activation"] != "":
+                    raise ValueError("not support activation = " + kw["activation"])
+            for _ in range(num - 1):
+                add(fdim, d_mid, kw)
+                fdim = d_mid
+            if linear:
+                kw["activation"] = ""; kw["bn"] = False
+            cur_out = d_out if op == ops_seq[-1] else d_mid
+            add(fdim, cur_out, kw)
+            fdim = cur_out
+            if kw["linear_bn"] or "linearbn" in op:
+                layers.append(nn.BatchNorm1d(fdim))
+        self.ops_func = nn.Sequential(*layers)
+
+    def forward(self, features):
+        return dense.sequential(self.ops_func, features)

@@ -38,7 +38,10 @@ template <int LR> __device__ __forceinline__ float slots_sum(float v)
     return v;
 }
 
-// flags: bit 0 TF flavour, bit 1 labels are int64 (read through their low words), bits 8..15 ncls > 0: soft labels + KL positives
+// flags: bit 0 TF flavour, bit 1 labels are int64 (read through their low words), bit 2 contrast 'nce' instead of 'softnn'
+// (heads.py:167-183: one -log(e_j / (e_j + sum of negatives)) per POSITIVE, averaged over all positives — point_mask then holds the
+// point's number of positives; TF head.py:773-795 without 'S' / masking: -sum over positives of log(e_j / sum of valid + eps) per point),
+// bits 8..15 ncls > 0: soft labels + KL positives
 template <int LR, int UM, bool GRAD>
 __global__ __launch_bounds__(256) void contrast_pairs_kernel(unsigned m, int nsample, const float4* __restrict__ feat, const int* __restrict__ amax,
                                                              const int* __restrict__ nidx, const int* __restrict__ order, float inv_temperature, int n_valid,
@@ -46,7 +49,7 @@ __global__ __launch_bounds__(256) void contrast_pairs_kernel(unsigned m, int nsa
                                                              float* __restrict__ coef, float4* __restrict__ grad_own)
 {
     constexpr int PP = 64 / LR;
-    const int tf_variant = flags & 1, ls = 1 + ((flags >> 1) & 1), ncls = (flags >> 8) & 0xff;
+    const int tf_variant = flags & 1, ls = 1 + ((flags >> 1) & 1), nce = (flags >> 2) & 1, ncls = (flags >> 8) & 0xff;
     const int ns = nsample - 1;                                     // self column dropped, heads.py:195-196 / head.py:560
     const int lane = threadIdx.x & 63;
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform values in scalar registers: scalar loads, uniform branches
@@ -120,20 +123,50 @@ __global__ __launch_bounds__(256) void contrast_pairs_kernel(unsigned m, int nsa
             pl += ispos[u] ? ex[u] : 0.f; al += ex[u];
         }
         const float P = group_sum<64>(pl) * (1.0f / LR), A = group_sum<64>(al) * (1.0f / LR);   // every pair is held by LR lanes
-        if (lane == 0) { per_point[i] = -logf(P / A + 1e-12f); point_mask[i] = 1; }              // contrast_softnn :161-163
-        if (!GRAD) continue;
-        // ---- gradient coefficients: d term / d dist_j, then / dist_j for the direction (f_i - f_j) / dist_j
-        const float ratio = P / A;
-        const float base = inv_temperature / (A * A * (ratio + 1e-12f));
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (lane == 0) coef[(size_t)i * nsample] = 0.f;              // the self column takes no part
+        if (!nce) {
+            if (lane == 0) { per_point[i] = -logf(P / A + 1e-12f); point_mask[i] = 1; }          // contrast_softnn :161-163
+            if (!GRAD) continue;
+            // ---- gradient coefficients: d term / d dist_j, then / dist_j for the direction (f_i - f_j) / dist_j
+            const float ratio = P / A;
+            const float base = inv_temperature / (A * A * (ratio + 1e-12f));
+            if (lane == 0) coef[(size_t)i * nsample] = 0.f;          // the self column takes no part
 #pragma unroll
-        for (int u = 0; u < UM; u++) {
-            const int j = u * PP + s;
-            float c = isnb[u] ? ex[u] * ((ispos[u] ? A : 0.f) - P) * base / dist[u] : 0.f;
-            if (tf_variant && dist[u] <= 1e-6f) c = 0.f;            // sqrt(max(s, 1e-12)): flat below the clamp
-            if (q == 0 && j < ns) coef[(size_t)i * nsample + 1 + j] = c;
-            g.x += c * diff[u].x; g.y += c * diff[u].y; g.z += c * diff[u].z; g.w += c * diff[u].w;
+            for (int u = 0; u < UM; u++) {
+                const int j = u * PP + s;
+                float c = isnb[u] ? ex[u] * ((ispos[u] ? A : 0.f) - P) * base / dist[u] : 0.f;
+                if (tf_variant && dist[u] <= 1e-6f) c = 0.f;        // sqrt(max(s, 1e-12)): flat below the clamp
+                if (q == 0 && j < ns) coef[(size_t)i * nsample + 1 + j] = c;
+                g.x += c * diff[u].x; g.y += c * diff[u].y; g.z += c * diff[u].z; g.w += c * diff[u].w;
+            }
+        } else {
+            // ---- contrast 'nce'.  pytorch (heads.py:167-183): term_j = -log(e_j / (e_j + N)), N = sum of the negatives' e, one term per
+            // positive; TF (head.py:773-795): -sum over positives of log(e_j / A + eps) per point
+            const float N = A - P;
+            float tl = 0.f, ql = 0.f;
+#pragma unroll
+            for (int u = 0; u < UM; u++) {
+                if (ispos[u]) {
+                    if (tf_variant) { const float r = ex[u] / A; tl += -logf(r + 1e-12f); ql += r / (r + 1e-12f); }
+                    else            { tl += -logf(ex[u] / (ex[u] + N)); ql += 1.0f / (ex[u] + N); }
+                }
+            }
+            const float term = group_sum<64>(tl) * (1.0f / LR), Q = group_sum<64>(ql) * (1.0f / LR);
+            if (lane == 0) { per_point[i] = term; point_mask[i] = tf_variant ? 1 : cnt; }        // finalize: mean over points (TF) / over positives (pytorch)
+            if (!GRAD) continue;
+            if (lane == 0) coef[(size_t)i * nsample] = 0.f;
+#pragma unroll
+            for (int u = 0; u < UM; u++) {
+                const int j = u * PP + s;
+                float c = 0.f;
+                if (isnb[u]) {
+                    if (tf_variant) { const float r = ex[u] / A; c = inv_temperature * ((ispos[u] ? r / (r + 1e-12f) : 0.f) - r * Q) / dist[u]; }
+                    else            c = (ispos[u] ? inv_temperature * N / (ex[u] + N) : -inv_temperature * ex[u] * Q) / dist[u];
+                }
+                if (tf_variant && dist[u] <= 1e-6f) c = 0.f;
+                if (q == 0 && j < ns) coef[(size_t)i * nsample + 1 + j] = c;
+                g.x += c * diff[u].x; g.y += c * diff[u].y; g.z += c * diff[u].z; g.w += c * diff[u].w;
+            }
         }
         g.x = slots_sum<LR>(g.x); g.y = slots_sum<LR>(g.y); g.z = slots_sum<LR>(g.z); g.w = slots_sum<LR>(g.w);
         if (s == 0) grad_own[(size_t)i * LR + q] = g;
@@ -235,7 +268,7 @@ CBL_EXPORT int cbl_contrast_pairs_forward(int m, int n_valid, int flags, int nsa
     if (m <= 0 || n_valid < 0 || nsample < 2 || nsample > 65 || d <= 0 || !(temperature > 0.f)) return CBL_ERR_BAD_ARG;
     if (!features || !labels || !neighbor_idx || !per_point || !point_mask || !stats || !loss) return CBL_ERR_BAD_ARG;
     if ((coef == nullptr) != (grad_own == nullptr)) return CBL_ERR_BAD_ARG;
-    if ((flags & ~3) || num_classes < 0 || num_classes > 255) return CBL_ERR_BAD_ARG;
+    if ((flags & ~7) || num_classes < 0 || num_classes > 255) return CBL_ERR_BAD_ARG;
     if (!cbl_host_aligned16(features) || (grad_own && !cbl_host_aligned16(grad_own))) return CBL_ERR_BAD_ARG;
     if (d % 4 || d > 64 || (d & (d - 1))) return CBL_ERR_UNSUPPORTED;
     hipStream_t st = cbl_stream(stream);

@@ -95,6 +95,8 @@ __global__ __launch_bounds__(KB_NB) void kpconv_bwd_csr_kernel(unsigned n0, int 
                 const float3 qq = *reinterpret_cast<const float3*>(q + 3 * (size_t)pi);          // one 12-byte load per lane
                 const float rx = xj - qq.x, ry = yj - qq.y, rz = zj - qq.z;                      // neighbour - centre (:681-684)
                 const int cnt = min(64, s1 - eb);
+                // (four steps' rows requested before the first multiply was measured too: 113 registers, three waves per SIMD instead of four,
+                // 59 us instead of 47 — the waves cover each other's round trips better than a wave covers its own)
 #pragma unroll 2
                 for (int st = 0; st < cnt; st += 4) {
                     const int src = st + kq;                                                     // this lane's pair of the step
@@ -186,12 +188,25 @@ __global__ __launch_bounds__(KB_NB) void kpconv_gkw_reduce_kernel(int nblk, int 
     }
 }
 
+constexpr unsigned KB_MAX_GRID = 2048;                               // upper bound of the persistent launch (sizes the partial rows)
+
 unsigned kb_grid(int n0)
 {
-    unsigned g = cbl_round_up8(cbl_div_up(n0, 4));                     // 4 target rows per workgroup and trip
-    static const char* env = getenv("CBL_KB_GRID");                   // tuning knob (tools/exp/kb_probe.py): workgroups of the persistent launch
-    const unsigned cap = env ? (unsigned)atoi(env) : 1024u;
-    return g > cap ? cap : g;
+    const unsigned g = cbl_round_up8(cbl_div_up(n0, 4));             // 4 target rows per workgroup and trip
+    return g > KB_MAX_GRID ? KB_MAX_GRID : g;
+}
+
+// persistent waves: exactly as many workgroups as are resident at once (a few more would run as a second, mostly idle round)
+template <class F> unsigned kb_resident(F kernel, int& cache)
+{
+    if (!cache) {
+        int per_cu = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kernel), KB_NB, 0) != hipSuccess || per_cu <= 0) per_cu = 3;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cache = per_cu * cus;
+    }
+    static const char* env = getenv("CBL_KB_GRID");                  // tuning knob (tools/exp/kb_probe.py)
+    return env ? (unsigned)atoi(env) : (unsigned)cache;
 }
 
 }  // namespace
@@ -214,20 +229,18 @@ CBL_EXPORT int cbl_kpconv_backward_csr(int n, int n0, int K, int C, int KP, cons
         (grad_features && !cbl_host_aligned16(grad_features))) return CBL_ERR_UNSUPPORTED;
     if (!grad_features && !grad_kernel_weights) return CBL_OK;
     hipStream_t st = cbl_stream(stream);
-    const unsigned g = kb_grid(n0);
+    unsigned g = kb_grid(n0);
     float* partial = reinterpret_cast<float*>(workspace);
     if (grad_kernel_weights && (!partial || workspace_bytes < cbl_kpconv_backward_csr_workspace_bytes(n0, C, KP))) return CBL_ERR_WORKSPACE;
     const CblFastDiv dv = cbl_fastdiv_make((unsigned)K);
-#define CBL_KB(GF_, GKW_, CL_) hipLaunchKernelGGL((kpconv_bwd_csr_kernel<GF_, GKW_, CL_>), dim3(g), dim3(KB_NB), 0, st, (unsigned)n0, C, KP, dv, query_points, support_points, \
-        features, kernel_points, kernel_weights, extent, influence, grad_out, order_dst, inv_start, inv_src, grad_features, partial)
+    static int resident[2][2][2] = {};
+#define CBL_KB(GF_, GKW_, CL_) { const unsigned res = cbl_round_up8(kb_resident(&kpconv_bwd_csr_kernel<GF_, GKW_, CL_>, resident[GF_][GKW_][CL_])); if (g > res) g = res;  \
+        hipLaunchKernelGGL((kpconv_bwd_csr_kernel<GF_, GKW_, CL_>), dim3(g), dim3(KB_NB), 0, st, (unsigned)n0, C, KP, dv, query_points, support_points, \
+        features, kernel_points, kernel_weights, extent, influence, grad_out, order_dst, inv_start, inv_src, grad_features, partial); }
     if (closest) {
-        if (grad_features && grad_kernel_weights) CBL_KB(true, true, true);
-        else if (grad_features) CBL_KB(true, false, true);
-        else CBL_KB(false, true, true);
+        if (grad_features && grad_kernel_weights) { CBL_KB(true, true, true) } else if (grad_features) { CBL_KB(true, false, true) } else { CBL_KB(false, true, true) }
     } else {
-        if (grad_features && grad_kernel_weights) CBL_KB(true, true, false);
-        else if (grad_features) CBL_KB(true, false, false);
-        else CBL_KB(false, true, false);
+        if (grad_features && grad_kernel_weights) { CBL_KB(true, true, false) } else if (grad_features) { CBL_KB(true, false, false) } else { CBL_KB(false, true, false) }
     }
 #undef CBL_KB
     if (grad_kernel_weights)

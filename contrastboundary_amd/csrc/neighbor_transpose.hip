@@ -221,13 +221,23 @@ __device__ __forceinline__ int nt_wave_sort64(int v, int lane)
 __device__ __forceinline__ void nt_rank_sort(const int* __restrict__ stage, const int* lstart, int* __restrict__ out)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int slot = wave; slot < TT; slot += NB / 64) {
-        const int s0 = lstart[slot], L = lstart[slot + 1] - s0;
-        if (L <= 64) {                                               // wave-uniform
-            const int v = nt_wave_sort64(lane < L ? stage[s0 + lane] : 0x7fffffff, lane);
-            if (lane < L) out[s0 + lane] = v;
-            continue;
+    // four segments at a time per wave: the network is 21 DEPENDENT exchanges (a third of them through the LDS crossbar), four independent
+    // sorts interleaved cover each other's latency
+    for (int base = wave * (TT / (NB / 64)); base < (wave + 1) * (TT / (NB / 64)); base += 4) {
+        int v[4], s0v[4], Lv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            s0v[u] = lstart[base + u]; Lv[u] = lstart[base + u + 1] - s0v[u];
+            v[u] = (lane < Lv[u] && Lv[u] <= 64) ? stage[s0v[u] + lane] : 0x7fffffff;
         }
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = nt_wave_sort64(v[u], lane);
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (Lv[u] <= 64 && lane < Lv[u]) out[s0v[u] + lane] = v[u];
+    }
+    for (int slot = wave; slot < TT; slot += NB / 64) {              // segments longer than a wave: by rank
+        const int s0 = lstart[slot], L = lstart[slot + 1] - s0;
+        if (L <= 64) continue;
         for (int c = 0; c < L; c += 64) {
             const int e = c + lane;
             const int mine = e < L ? stage[s0 + e] : 0x7fffffff;

@@ -37,11 +37,11 @@ class _PointContrast(Function):
     table — cbl_contrast_pairs_backward: no atomics, no zero fill, deterministic (SURVEY.md 7 hard part 6)."""
 
     @staticmethod
-    def forward(ctx, features, amax, neighbor_idx, temperature, weight, transposed):
+    def forward(ctx, features, amax, neighbor_idx, temperature, weight, transposed, nce=False):
         m, d = features.shape
         nsample = neighbor_idx.shape[1]
         dev = features.device
-        flags = 2 if amax.dtype == torch.int64 else 0                    # the reference's hard targets as they are: no int32 copy
+        flags = (2 if amax.dtype == torch.int64 else 0) | (4 if nce else 0)   # int64: the reference's hard targets as they are, no int32 copy
         per_point = torch.empty(m, dtype=torch.float32, device=dev)
         mask = torch.empty(m, dtype=torch.int32, device=dev)
         stats = torch.empty(2, dtype=torch.float32, device=dev)
@@ -66,7 +66,7 @@ class _PointContrast(Function):
     @staticmethod
     def backward(ctx, grad_loss, _grad_mask):
         if grad_loss is None:                                            # the loss took no part in what was differentiated
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         features, coef, own, stats, neighbor_idx, *rest = ctx.saved_tensors
         if rest:
             inv_start, inv_src = rest[0], rest[1]
@@ -82,13 +82,16 @@ class _PointContrast(Function):
         _lib.check(_lib.lib().cbl_contrast_pairs_backward(_c_int(m), _c_int(ctx.nsample), _c_int(d), _lib.ptr(features), _lib.ptr(coef), _lib.ptr(own),
                                                           _lib.ptr(order), _lib.ptr(inv_start), _lib.ptr(inv_src), _lib.ptr(stats), _lib.ptr(gl),
                                                           _c_float(ctx.weight), _lib.ptr(g), _lib.stream_of(features)), "cbl_contrast_pairs_backward")
-        return g, None, None, None, None, None
+        return g, None, None, None, None, None, None
 
 
-def point_contrast(features, labels, neighbor_idx, temperature=1.0, weight=0.1, return_mask=False, transposed=None):
+def point_contrast(features, labels, neighbor_idx, temperature=1.0, weight=0.1, return_mask=False, transposed=None, contrast="softnn"):
     """features (m,d) f32, labels (m,ncls) f32 soft/one-hot OR (m,) int class ids, neighbor_idx (m,nsample) i32 incl. the self column
     -> scalar loss (device tensor, differentiable w.r.t. features).  transposed: pointops.neighbor_transpose(neighbor_idx, m) if the
-    caller already has it (it is looked up in / built into the active neighbour cache otherwise)."""
+    caller already has it (it is looked up in / built into the active neighbour cache otherwise).
+    contrast: 'softnn' (heads.py:151-165) or 'nce' (:167-183: one term per positive pair, mean over all of them)."""
+    if contrast not in ("softnn", "nce"):
+        raise NotImplementedError(f"point_contrast: contrast={contrast!r}")
     if features.shape[1] not in (4, 8, 16, 32, 64):
         raise NotImplementedError(f"point_contrast: feature width {features.shape[1]} (the fused head covers 4, 8, 16, 32, 64)")
     m = features.shape[0]
@@ -99,8 +102,9 @@ def point_contrast(features, labels, neighbor_idx, temperature=1.0, weight=0.1, 
                    "cbl_label_argmax")
     else:
         amax = labels.contiguous() if labels.dtype in (torch.int64, torch.int32) else labels.to(torch.int32).contiguous()
-    loss, mask = _PointContrast.apply(features.contiguous(), amax, neighbor_idx.contiguous(), float(temperature), float(weight), transposed)
-    return (loss, mask) if return_mask else loss
+    loss, mask = _PointContrast.apply(features.contiguous(), amax, neighbor_idx.contiguous(), float(temperature), float(weight), transposed,
+                                      contrast == "nce")
+    return (loss, (mask > 0).to(torch.int32) if contrast == "nce" else mask) if return_mask else loss   # ('nce' keeps the number of positives)
 
 
 class ContrastHead(torch.nn.Module):
@@ -114,14 +118,19 @@ class ContrastHead(torch.nn.Module):
         self.head_cfg, self.config = head_cfg, config
         self.stages = parse_stage(head_cfg.stage, config.num_layers)
         self.ftype = head_cfg.ftype if head_cfg.ftype not in ("out", "fout") else "f_out"
-        for key, allowed in (("dist", ("l2",)), ("pos", ("cnt",)), ("contrast", ("softnn",))):
+        # every option the REFERENCE can run: dist 'l2' (dist_kl is called with two of its four arguments, :235, and no other dist_* exists),
+        # pos 'cnt' (the only posmask_* defined, :145), contrast 'softnn' | 'nce' (:151-183), an optional projection MLP (:88-92)
+        for key, allowed in (("dist", ("l2",)), ("pos", ("cnt",)), ("contrast", ("softnn", "nce"))):
             if getattr(head_cfg, key) not in allowed:
-                raise NotImplementedError(f"ContrastHead {key}={getattr(head_cfg, key)!r}: the fused HIP path covers {allowed} "
-                                          "(the reference's shipped config)")
+                raise NotImplementedError(f"ContrastHead {key}={getattr(head_cfg, key)!r}: the reference itself only runs {allowed} "
+                                          "(heads.py:116-183: dist_kl's call passes two of its four arguments, no other posmask_* / dist_* exists)")
         assert head_cfg.sample in ["cnt", "glb", "sub", "subspatial", "pts", "label", "vote"], f"not support sample = {head_cfg.sample}"
+        self.project = None
         if "project" in head_cfg and head_cfg.project:
-            raise NotImplementedError("projection MLP before the contrast is not part of the fused path")
-        if self.ftype != "latent":
+            from .blocks import MLPbyOps
+            self.project = torch.nn.ModuleDict({f"{n}{i}": MLPbyOps(head_cfg.project, config.base_fdim * 2 ** i, d_out=config.base_fdim)
+                                                for n, i in self.stages})            # heads.py:88-92
+        if self.ftype != "latent" and self.project is None:
             # 'f_out' / 'out' hand the head the stage widths (pointtransformer_seg.py: planes 32 ... 512); the fused kernels cover rows of 4 ... 64 floats
             planes = [int(v) for v in config.planes] if "planes" in config else [32, 64, 128, 256, 512]
             bad = [(n, i) for n, i in self.stages if planes[i] not in (4, 8, 16, 32, 64)]
@@ -134,12 +143,14 @@ class ContrastHead(torch.nn.Module):
     def point_contrast(self, n, i, stage_list, target):
         stage = stage_list[n][i]
         p, features, o = stage["p_out"], stage[self.ftype], stage["offset"]
+        if self.project is not None:
+            features = self.project[f"{n}{i}"](features)                  # :187-188
         if i == 0:
             labels = target                                               # one-hot's argmax is the label itself
         else:
             labels = get_subscene_label(n, i, stage_list, target, self.nstride, self.num_classes)   # :189
         neighbor_idx, _ = pointops.knnquery_raw(self.nsample[i], p, p, o, o, algo="set")           # :192; the mining is order-invariant
-        return point_contrast(features, labels, neighbor_idx, self.temperature, self.weight)
+        return point_contrast(features, labels, neighbor_idx, self.temperature, self.weight, contrast=self.head_cfg.contrast)
 
     def forward(self, output, target, stage_list):
         return [self.point_contrast(n, i, stage_list, target) for n, i in self.stages]              # :248-253
@@ -191,10 +202,63 @@ class _TFContrast(Function):
         return g, None, None, None, None, None
 
 
-def tf_contrast(features, labels, neighbors, temperature=1.0, weight=0.1, return_mask=False, kl_threshold=None):
+class _TFContrastPairs(Function):
+    """TF flavour through the atomic-free kernels (cbl_contrast_pairs_*, flags bit 0): contrast 'nce' (head.py:773-795)"""
+
+    @staticmethod
+    def forward(ctx, features, labels, neighbors, temperature, weight, nce):
+        m, d = features.shape
+        n_valid, nsample = labels.shape[0], neighbors.shape[1]
+        if n_valid != m:
+            raise NotImplementedError("tf_contrast 'nce': labels must cover exactly the stage's own points")
+        dev = features.device
+        per_point = torch.empty(m, dtype=torch.float32, device=dev); mask = torch.empty(m, dtype=torch.int32, device=dev)
+        stats = torch.empty(2, dtype=torch.float32, device=dev); loss = torch.empty(1, dtype=torch.float32, device=dev)
+        grad = ctx.needs_input_grad[0]
+        coef = torch.empty((m, nsample), dtype=torch.float32, device=dev) if grad else None
+        own = torch.empty((m, d), dtype=torch.float32, device=dev) if grad else None
+        order = pointops.spatial_order(neighbors)
+        _lib.check(_lib.lib().cbl_contrast_pairs_forward(_c_int(m), _c_int(n_valid), _c_int(1 | (4 if nce else 0)), _c_int(nsample), _c_int(d), _lib.ptr(features),
+                                                         _lib.ptr(labels), _c_int(0), _c_float(0.0), _lib.ptr(neighbors), _lib.ptr(order), _c_float(temperature),
+                                                         _c_float(weight), _lib.ptr(per_point), _lib.ptr(mask), _lib.ptr(stats), _lib.ptr(loss), _lib.ptr(coef),
+                                                         _lib.ptr(own), _lib.stream_of(features)), "cbl_contrast_pairs_forward")
+        if grad:
+            ctx.save_for_backward(features, coef, own, stats, neighbors)
+        ctx.weight, ctx.nsample = weight, nsample
+        ctx.mark_non_differentiable(mask)
+        ctx.set_materialize_grads(False)
+        return loss.view(()), mask
+
+    @staticmethod
+    def backward(ctx, grad_loss, _gm):
+        if grad_loss is None:
+            return None, None, None, None, None, None
+        features, coef, own, stats, neighbors = ctx.saved_tensors
+        m, d = features.shape
+        tr = pointops.neighbor_transpose(neighbors, m)                   # shadow neighbours (index m) are left out of the table
+        if tr is None:
+            raise _lib.CblError("tf_contrast: no transposed neighbour table for this size")
+        order, inv_start, inv_src = tr
+        g = torch.empty_like(features)
+        gl = grad_loss.reshape(1).to(torch.float32).contiguous()
+        _lib.check(_lib.lib().cbl_contrast_pairs_backward(_c_int(m), _c_int(ctx.nsample), _c_int(d), _lib.ptr(features), _lib.ptr(coef), _lib.ptr(own),
+                                                          _lib.ptr(order), _lib.ptr(inv_start), _lib.ptr(inv_src), _lib.ptr(stats), _lib.ptr(gl),
+                                                          _c_float(ctx.weight), _lib.ptr(g), _lib.stream_of(features)), "cbl_contrast_pairs_backward")
+        return g, None, None, None, None, None
+
+
+def tf_contrast(features, labels, neighbors, temperature=1.0, weight=0.1, return_mask=False, kl_threshold=None, contrast="softnn"):
     """TF contrast_head.contrast ('softnn', 'l2') for one stage: features (m,d) f32, neighbors (m,k) i32 radius neighbours incl. the self
     column, padded with N.  sample 'label': labels (N,) hard labels of the N support points of that stage (negative = ignored);
     sample 'labelkl<thr>' (kl_threshold=thr): labels (N,ncls) f32 label distributions (tf_scene_label(..., 'soft'); one-hot at stage 0)."""
+    if contrast not in ("softnn", "nce"):
+        raise NotImplementedError(f"tf_contrast: contrast={contrast!r}")
+    if contrast == "nce":                                                # head.py:773-795 (no 'S' margin, no masking), hard labels
+        if kl_threshold is not None:
+            raise NotImplementedError("tf_contrast: 'nce' with labelkl positives")
+        loss, mask = _TFContrastPairs.apply(features.contiguous(), labels.to(torch.int32).contiguous(), neighbors.contiguous(), float(temperature),
+                                            float(weight), True)
+        return (loss, mask) if return_mask else loss
     if kl_threshold is None:
         lab = labels.to(torch.int32).contiguous()
     else:

@@ -85,3 +85,37 @@ def test_time_crops(coord, voxel_max, potentials=None):
         ncov = int(covered.sum().item())
         crops.append(idx)
     return crops
+
+
+def init_cumulate_dict(n, num_classes, device="cuda", probs_last=False):
+    """tool/test.py:313-328: the per-cloud accumulators of the test loop ('probs', optionally 'probs_last')"""
+    cum = {"probs": torch.zeros((n, num_classes), dtype=torch.float32, device=device)}
+    if probs_last:
+        cum["probs_last"] = torch.zeros((n, num_classes), dtype=torch.float32, device=device)
+    return cum
+
+
+def cumulate_probs(cum_dict, pred, inds, smooth=None, pred_type="logits"):
+    """tool/test.py:330-352: add the predictions of one batch of crops (pred (m, ncls), inds (m) = the points the rows belong to, the
+    concatenation of the crops) into cum_dict['probs'] (and overwrite 'probs_last').  Where crops of the batch overlap the indexed update
+    keeps ONE row per point — the last, as the reference's expression does on the CPU (cbl_cumulate_probs)."""
+    assert pred_type in ["logits"], f"not support pred_type = {pred_type}"
+    if "probs_1st" in cum_dict:
+        raise NotImplementedError("probs_1st: the reference raises on this path itself (tool/test.py:340)")
+    probs = cum_dict["probs"]
+    if not (probs.is_cuda and probs.dtype == torch.float32 and probs.is_contiguous()):
+        raise TypeError("cum_dict['probs']: expected a contiguous float32 CUDA tensor")
+    n, ncls = probs.shape
+    pred = pred.detach().to(torch.float32).contiguous()
+    inds = torch.as_tensor(inds, device=probs.device).to(torch.int64).contiguous()
+    m = inds.shape[0]
+    if pred.shape != (m, ncls):
+        raise ValueError(f"pred has shape {tuple(pred.shape)}, expected {(m, ncls)}")
+    scratch = torch.empty(max(n, 1), dtype=torch.int32, device=probs.device)
+    L = _lib.lib()
+    for key, mode in (("probs", 0 if smooth is None else 1), ("probs_last", 2)):
+        if key in cum_dict:
+            _lib.check(L.cbl_cumulate_probs(ctypes.c_int(n), ctypes.c_int(ncls), ctypes.c_int(m), _lib.ptr(inds), _lib.ptr(pred),
+                                            ctypes.c_float(0.0 if smooth is None else float(smooth)), ctypes.c_int(mode), _lib.ptr(cum_dict[key]),
+                                            _lib.ptr(scratch), _lib.stream_of(probs)), "cbl_cumulate_probs")
+    return cum_dict

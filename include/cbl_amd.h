@@ -298,6 +298,14 @@ int cbl_tf_scene_label(int m, int n_valid, int k, int num_classes, const long lo
  *   cnt (n) i32 [number of differing valid neighbours]; any output may be NULL */
 int cbl_boundary_mask(int n, int k, const long long* labels, const int* neighbor_idx, unsigned char* bound, unsigned char* plain, int* cnt, void* stream);
 
+/* cumulate_probs  pytorch/tool/test.py:330-352: the test loop's accumulation of a batch of crops' predictions into the cloud's per-point rows.
+ *   probs (n, num_classes) f32, inds (m) i64 point of every prediction row (the concatenated crops of the batch: duplicates where crops
+ *   overlap), pred (m, num_classes) f32;  mode 0: probs[inds] += pred, 1: probs[inds] = smooth * probs[inds] + (1 - smooth) * pred,
+ *   2: probs[inds] = pred ('probs_last').  An indexed update ASSIGNS, so for a duplicated point one row of pred counts: the LAST one, as on
+ *   the CPU (deterministic here; CUDA's index_put leaves it to the store order).  scratch_n: n ints. */
+int cbl_cumulate_probs(int n, int num_classes, int m, const long long* inds, const float* pred, float smooth, int mode, float* probs,
+                       int* scratch_n, void* stream);
+
 /* boundary-IoU evaluation  pytorch/tool/test.py:392-417: get_boundary_mask (above, with get_plain) followed by
  *   intersectionAndUnion(pred[mask], label[mask], K, ignore)  util/common_util.py:25-37  for mask in (bound, plain), fused:
  *   pred (n) i64, labels (n) i64, neighbor_idx (n,k) -> hist (2,3,num_classes) u64 += [mask bound|plain][intersection|output|target]

@@ -32,8 +32,8 @@ def one_hot_label(target, num_classes):
     return np.eye(num_classes, dtype=np.float32)[np.asarray(target)]           # stage 0: F.one_hot(...).float(), :13-17
 
 
-def point_contrast(features, labels, neighbor_idx_full, temperature=None, weight=0.1, grad=True):
-    """heads.py:185-246 for pos='cnt', dist='l2', contrast='softnn'.
+def point_contrast(features, labels, neighbor_idx_full, temperature=None, weight=0.1, grad=True, contrast="softnn"):
+    """heads.py:185-246 for pos='cnt', dist='l2', contrast='softnn' (:151-165) or 'nce' (:167-183).
     features (m,d) f32; labels (m,ncls) soft/one-hot; neighbor_idx_full (m,nsample) from knnquery (column 0 = self, dropped :196).
     -> loss (float32 scalar, 0 if no point has both a positive and a negative neighbour), d loss / d features (m,d), point_mask (m,)"""
     f = np.asarray(features, np.float32)
@@ -57,6 +57,25 @@ def point_contrast(features, labels, neighbor_idx_full, temperature=None, weight
         neg = (neg / np.float32(temperature)).astype(np.float32)                # :154-155
     e = np.exp(neg).astype(np.float32)
     pm = posmask[rows].astype(np.float32)
+    if contrast == "nce":
+        # :176-182: neg = sum of the negatives' exps; one term -log(exp_j / (exp_j + neg)) per POSITIVE pair, mean over all of them
+        negs = (e * (1 - pm)).sum(-1, dtype=np.float32)
+        terms = -np.log(e / (e + negs[:, None]))
+        npos = pm.sum()
+        loss = np.float32(terms[pm > 0].mean(dtype=np.float32) * np.float32(weight))
+        if not grad:
+            return loss, g, point_mask
+        T = 1.0 if temperature is None else float(temperature)
+        e64, pm64, N = e.astype(np.float64), pm.astype(np.float64), negs.astype(np.float64)[:, None]
+        Q = (pm64 / (e64 + N)).sum(-1, keepdims=True)
+        dl_dd = np.where(pm64 > 0, N / (e64 + N), -e64 * Q) / T * float(weight) / float(npos)
+        coef = (dl_dd / dist.astype(np.float64))[:, :, None] * diff.astype(np.float64)
+        g64 = np.zeros(f.shape, np.float64)
+        np.add.at(g64, rows, coef.sum(1))
+        np.add.at(g64, nbr[rows].reshape(-1), -coef.reshape(-1, f.shape[1]))
+        return loss, g64.astype(np.float32), point_mask
+    if contrast != "softnn":
+        raise ValueError(contrast)
     pos = (e * pm).sum(-1, dtype=np.float32)
     alls = e.sum(-1, dtype=np.float32)
     ratio = pos / alls
@@ -151,7 +170,7 @@ def tf_label_kl(soft_labels, neighbors):
     return term.sum(-1, dtype=np.float32)
 
 
-def tf_contrast(features, labels, neighbors, temperature=None, weight=0.1, grad=True, kl_threshold=None):
+def tf_contrast(features, labels, neighbors, temperature=None, weight=0.1, grad=True, kl_threshold=None, contrast="softnn"):
     """features (m,d); labels (N,) hard labels of the support points (N >= m; negative = ignored) — or, with kl_threshold (sample
     'labelkl<thr>', :492-511), (N,ncls) soft labels: a neighbour is a positive if KL(p_centre || p_neighbour) < thr; neighbors (m,k)
     radius neighbours incl. self column, padded with N.  -> loss, d loss/d features (m,d), point_mask"""
@@ -184,6 +203,23 @@ def tf_contrast(features, labels, neighbors, temperature=None, weight=0.1, grad=
     d = d - d.max(-1, keepdims=True)                                 # over ALL columns, :752
     e = np.exp(d).astype(np.float32)
     pm, nm = pos_mask[rows].astype(np.float32), neg_mask[rows].astype(np.float32)
+    if contrast == "nce":
+        # :773-795 without an 'S' margin and without masking: under = sum of the valid exps, -sum over positives of log(exp_j / under + eps)
+        under = (e * (pm + nm)).sum(-1, dtype=np.float32)
+        rr = e / under[:, None]
+        per_point = -(np.log(rr + _EPS) * pm).sum(-1, dtype=np.float32)
+        loss = np.float32(per_point.mean(dtype=np.float32) * np.float32(weight))
+        if not grad:
+            return loss, g, point_mask
+        T = 1.0 if temperature is None else float(temperature)
+        r64, pm64, vm64 = rr.astype(np.float64), pm.astype(np.float64), (pm + nm).astype(np.float64)
+        G = (pm64 * r64 / (r64 + 1e-12)).sum(-1, keepdims=True)
+        dl_dd = vm64 * (pm64 * r64 / (r64 + 1e-12) - r64 * G) / T * float(weight) / float(len(rows))
+        coef = (dl_dd / dist.astype(np.float64))[:, :, None] * diff.astype(np.float64)
+        g64 = np.zeros((len(fpad), f.shape[1]), np.float64)
+        np.add.at(g64, rows, coef.sum(1))
+        np.add.at(g64, np.minimum(nbr[rows], len(fpad) - 1).reshape(-1), -coef.reshape(-1, f.shape[1]))
+        return loss, g64[:len(f)].astype(np.float32), point_mask
     pos = (e * pm).sum(-1, dtype=np.float32); neg = (e * nm).sum(-1, dtype=np.float32)
     ratio = pos / (pos + neg)                                        # :759-762
     per_point = -np.log(ratio + _EPS)                                # :766-767

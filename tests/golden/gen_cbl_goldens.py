@@ -51,8 +51,19 @@ def main():
                    "contrast": {"stage": "Ua", "contrast": "softnn", "ftype": "latent", "sample": "label", "pos": "cnt", "dist": "l2",
                                 "temperature": 1, "weight": "w.1"}})
     out = {}
-    for case, (n0, temperature, seed) in {"default": (4096, 1, 0), "temp0p5": (2048, 0.5, 1)}.items():
+    # 'project': an MLPbyOps projection in front of the contrast (heads.py:88-92, 187-188) on the stages' own widths (ftype f_out:
+    # 32 * 2^i channels), its seeded parameters stored with the case.  (contrast 'nce', heads.py:167-183, cannot be executed: `1 - posmask`
+    # on the boolean mask of posmask_cnt raises in every torch since 1.2, and `loss[posmask]` rules out a float mask — dead code in the
+    # reference; the restatement in oracle/cbl_oracle.py reads it as the complement.)
+    for case, (n0, temperature, seed, contrast, project) in {"default": (4096, 1, 0, "softnn", None), "temp0p5": (2048, 0.5, 1, "softnn", None),
+                                                             "project": (2048, 1, 3, "softnn", "mlp2")}.items():
         cfg.contrast.temperature = temperature
+        cfg.contrast.contrast = contrast
+        cfg.contrast.ftype = "f_out" if project else "latent"
+        if project:
+            cfg.contrast.project = project
+        elif "project" in cfg.contrast:
+            cfg.contrast.pop("project")
         torch.manual_seed(seed)
         rng = np.random.default_rng(seed)
         xyz, labels = S.s_room(n0, seed=seed)
@@ -67,13 +78,17 @@ def main():
                 fidx, _ = O.furthestsampling(p, o, n_o)
                 p, o = p[fidx], n_o
             latent = torch.randn(p.shape[0], 32, dtype=torch.float32, requires_grad=True)
+            f_out = torch.randn(p.shape[0], 32 * 2 ** i, dtype=torch.float32, requires_grad=True) if project else None
             # neighbouring points get similar features so that positive/negative distances differ in scale
-            st = {"p_out": torch.from_numpy(np.ascontiguousarray(p)), "f_out": None, "offset": torch.from_numpy(np.ascontiguousarray(o)),
+            st = {"p_out": torch.from_numpy(np.ascontiguousarray(p)), "f_out": f_out, "offset": torch.from_numpy(np.ascontiguousarray(o)),
                   "latent": latent}
             stage_list["up"].append(st)
             stage_list["down"].append(st)
         target = torch.from_numpy(labels)
         head = ref_heads.ContrastHead(cfg.contrast, cfg)
+        if project:
+            for key, val in head.state_dict().items():
+                out[f"{case}/state/{key}"] = val.detach().numpy().copy()       # BatchNorm in train mode: batch statistics, as the criterion runs
         losses = head(None, target, stage_list)
         total = torch.stack([l for l in losses]).sum()
         total.backward()
@@ -86,6 +101,9 @@ def main():
             out[f"{case}/stage{i}/soft_label"] = soft.numpy()
             out[f"{case}/stage{i}/loss"] = np.float32(losses[i].item())
             out[f"{case}/stage{i}/grad_latent"] = st["latent"].grad.numpy() if st["latent"].grad is not None else np.zeros((p.shape[0], 32), np.float32)
+            if project:
+                out[f"{case}/stage{i}/f_out"] = st["f_out"].detach().numpy()
+                out[f"{case}/stage{i}/grad_f_out"] = st["f_out"].grad.numpy() if st["f_out"].grad is not None else np.zeros(tuple(st["f_out"].shape), np.float32)
         out[f"{case}/target"] = labels
         out[f"{case}/temperature"] = np.float32(temperature)
         print(case, "losses", [float(l) for l in losses])

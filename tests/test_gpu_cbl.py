@@ -263,3 +263,74 @@ def test_fused_forward_gradient_equals_the_two_pass_entries(tf_variant):
     _lib.check(L.cbl_contrast_grad_scale(ctypes.c_longlong(n * d), _lib.ptr(unit), _lib.ptr(s2), _lib.ptr(gl), cf(0.1), _lib.ptr(g2), st), "scale")
     assert torch.equal(pp1, pp2) and torch.equal(m1, m2) and torch.equal(l1, l2) and float(s1[1]) > 100
     np.testing.assert_allclose(g2.cpu().numpy(), g1.cpu().numpy(), rtol=1e-4, atol=1e-6 * float(g1.abs().max()))
+
+
+def test_contrast_head_with_projection_matches_reference():
+    """head_cfg.project (heads.py:88-92, 187-188): an MLPbyOps in front of the contrast, on the stages' own widths (32 ... 512 channels);
+    the reference's seeded parameters are loaded into the mirror (same module names), BatchNorm in train mode as the criterion runs"""
+    from contrastboundary_amd.heads import ContrastHead
+    case = "project"
+    cfg = Cfg(nsample=[36, 24, 24, 24, 24], nstride=[4, 4, 4, 4], num_classes=13, num_layers=5, voxel_size=0.04, base_fdim=32,
+              contrast=Cfg(stage="Ua", contrast="softnn", ftype="f_out", sample="label", pos="cnt", dist="l2", project="mlp2",
+                           temperature=float(CBL[f"{case}/temperature"]), weight="w.1"))
+    head = ContrastHead(cfg.contrast, cfg).cuda()
+    state = {k[len(f"{case}/state/"):]: torch.from_numpy(CBL[k]) for k in CBL.files if k.startswith(f"{case}/state/")}
+    assert set(state) == set(head.state_dict()), "module / parameter names differ from the reference's"
+    head.load_state_dict(state)
+    head.train()
+    up = [{"p_out": dev(CBL[f"{case}/stage{i}/p"]), "offset": dev(CBL[f"{case}/stage{i}/offset"]), "latent": None,
+           "f_out": dev(CBL[f"{case}/stage{i}/f_out"]).requires_grad_(True)} for i in range(5)]
+    sl = {"inputs": None, "up": up, "down": up}
+    losses = head(None, dev(CBL[f"{case}/target"]), sl)
+    torch.stack(losses).sum().backward()
+    for i in range(5):
+        np.testing.assert_allclose(losses[i].item(), CBL[f"{case}/stage{i}/loss"], rtol=1e-3, atol=1e-6)      # through Linear + train-mode BatchNorm + Linear
+        ref = CBL[f"{case}/stage{i}/grad_f_out"]
+        np.testing.assert_allclose(up[i]["f_out"].grad.cpu().numpy(), ref, rtol=2e-2, atol=2e-3 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("nsample,d,temperature", [(8, 16, 0.7), (24, 32, 1.0), (36, 32, 0.5), (40, 64, 1.3)])
+def test_point_contrast_nce_vs_oracle(nsample, d, temperature):
+    """contrast 'nce' (heads.py:167-183) — dead code in the reference itself (`1 - posmask` on a bool mask raises), so pinned by the
+    restatement only: one -log(e_j / (e_j + negatives)) per positive pair, mean over all positives"""
+    from contrastboundary_amd import heads
+    rng = np.random.default_rng(nsample + 100)
+    n = 3000
+    xyz = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    lab = (np.floor(xyz[:, 0] * 4) + 4 * np.floor(xyz[:, 1] * 3)).astype(np.int64) % 13
+    feat = (rng.normal(size=(n, d)) * 0.5).astype(np.float32)
+    off = np.int32([1200, 3000])
+    idx, _ = O.knnquery(nsample, xyz, xyz, off, off)
+    f = dev(feat).requires_grad_(True)
+    loss, mask = heads.point_contrast(f, dev(lab), dev(idx), temperature=temperature, weight=0.1, return_mask=True, contrast="nce")
+    loss.backward()
+    rloss, rgrad, rmask = C.point_contrast(feat, np.eye(13, dtype=np.float32)[lab], idx, temperature=temperature, weight=0.1, contrast="nce")
+    np.testing.assert_array_equal(mask.cpu().numpy().astype(bool), rmask)
+    np.testing.assert_allclose(loss.item(), rloss, rtol=TOL)
+    np.testing.assert_allclose(f.grad.cpu().numpy(), rgrad, rtol=1e-3, atol=1e-4 * np.abs(rgrad).max())
+
+
+@pytest.mark.parametrize("k,d", [(16, 32), (27, 16)])
+def test_tf_contrast_nce_vs_oracle(k, d):
+    """TF contrast_head with contrast 'nce' (tensorflow/models/heads/head.py:773-795, no 'S' margin, no masking) on radius neighbourhoods
+    with shadow padding and ignored labels; parity unpinned by execution (TensorFlow absent): against the restatement"""
+    from contrastboundary_amd import heads
+    rng = np.random.default_rng(k)
+    n = 2500
+    xyz = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    lab = (np.floor(xyz[:, 0] * 3) + 3 * np.floor(xyz[:, 2] * 3)).astype(np.int64) % 7
+    lab[::53] = -1                                                        # ignored points
+    feat = (rng.normal(size=(n, d)) * 0.5).astype(np.float32)
+    idx, _ = O.knnquery(k, xyz, xyz, np.int32([n]), np.int32([n]))
+    nb = idx.copy()
+    npad = rng.integers(0, k // 3, n)
+    for i in range(n):
+        if npad[i]:
+            nb[i, k - npad[i]:] = n                                       # the radius search's shadow index
+    f = dev(feat).requires_grad_(True)
+    loss, mask = heads.tf_contrast(f, dev(lab), dev(nb.astype(np.int32)), temperature=0.8, weight=0.1, return_mask=True, contrast="nce")
+    loss.backward()
+    rloss, rgrad, rmask = C.tf_contrast(feat, lab, nb, temperature=0.8, weight=0.1, contrast="nce")
+    np.testing.assert_array_equal(mask.cpu().numpy().astype(bool), rmask)
+    np.testing.assert_allclose(loss.item(), rloss, rtol=TOL)
+    np.testing.assert_allclose(f.grad.cpu().numpy(), rgrad, rtol=1e-3, atol=1e-4 * np.abs(rgrad).max())

@@ -75,3 +75,25 @@ def test_tf_label_kl_known_answers():
     f = np.random.default_rng(0).normal(size=(4, 8)).astype(np.float32)
     loss, g, mask = C.tf_contrast(f, p, np.concatenate([np.arange(4)[:, None], nb], 1), temperature=0.5, weight=0.1, kl_threshold=0.5)
     assert mask.tolist() == [True, True, True, True] and np.isfinite(loss) and np.isfinite(g).all()
+
+
+def test_nce_restatements_agree_with_finite_differences():
+    """contrast 'nce' of both flavours (pytorch heads.py:167-183 — dead code in the reference, see gen_cbl_goldens.py — and TF
+    head.py:773-795): the analytic gradients of the restatements against central differences of their own forward"""
+    import numpy as np
+    from oracle import cbl_oracle as C
+    rng = np.random.default_rng(0)
+    m, d, ns = 60, 8, 7
+    f = rng.normal(size=(m, d)).astype(np.float32)
+    hard = rng.integers(0, 3, m)
+    nbr = np.concatenate([np.arange(m)[:, None], rng.integers(0, m, (m, ns))], 1)
+    for fwd in (lambda x, grad=True: C.point_contrast(x, np.eye(3, dtype=np.float32)[hard], nbr, temperature=0.7, weight=0.1, contrast="nce", grad=grad),
+                lambda x, grad=True: C.tf_contrast(x, hard, nbr, temperature=0.7, weight=0.1, contrast="nce", grad=grad)):
+        loss, g, mask = fwd(f)
+        assert mask.any() and np.isfinite(loss) and loss > 0
+        for i in range(0, m, 9):
+            for c in range(0, d, 3):
+                fp, fm = f.copy(), f.copy()
+                fp[i, c] += 1e-2; fm[i, c] -= 1e-2
+                num = (fwd(fp, False)[0] - fwd(fm, False)[0]) / 2e-2
+                assert abs(num - g[i, c]) < 2e-5 + 2e-2 * abs(g[i, c])

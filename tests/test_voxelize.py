@@ -75,3 +75,31 @@ def test_synthetic_rooms_fail_fast_and_scale():
     assert a["xyz"].shape == (150000, 3) and a["labels"].shape == (150000,) and a["xyz"].dtype == np.float32
     b = hotpath.Scene.synthetic_numpy(4096, 4, seed=1)
     assert b["xyz"].shape == (4096, 3) and float(b["xyz"].min()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("smooth", [None, 0.8])
+def test_cumulate_probs_matches_the_reference_expression(smooth):
+    """tool/test.py:330-352.  The reference's update is numpy / torch-CPU semantics of `a[inds] += b` with duplicated inds (overlapping crops
+    of one batch): gather, add, indexed assignment — the LAST row of a duplicated point counts.  Bit-exact against that expression."""
+    import torch
+    from contrastboundary_amd import voxelize as VZ
+    rng = np.random.default_rng(3)
+    n, ncls = 5000, 13
+    cum = VZ.init_cumulate_dict(n, ncls, probs_last=True)
+    ref = np.zeros((n, ncls), np.float32); ref_last = np.zeros((n, ncls), np.float32)
+    for batch in range(3):
+        crops = [rng.choice(n, 1800, replace=False) for _ in range(3)]            # three overlapping crops per batch
+        inds = np.concatenate(crops)
+        pred = rng.normal(size=(inds.size, ncls)).astype(np.float32)
+        VZ.cumulate_probs(cum, torch.from_numpy(pred).cuda(), inds, smooth=smooth)
+        if smooth is None:
+            ref[inds, ...] += pred                                                # the reference's line 333, on the CPU
+        else:
+            ref[inds, ...] = np.float32(smooth) * ref[inds, ...] + np.float32(1 - smooth) * pred     # :335
+        ref_last[inds, ...] = pred                                                # :350
+    if smooth is None:
+        np.testing.assert_array_equal(cum["probs"].cpu().numpy(), ref)
+    else:
+        np.testing.assert_allclose(cum["probs"].cpu().numpy(), ref, rtol=1e-6, atol=1e-7)     # float(1 - smooth) on the device vs numpy's float32(1 - smooth)
+    np.testing.assert_array_equal(cum["probs_last"].cpu().numpy(), ref_last)
