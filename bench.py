@@ -223,6 +223,40 @@ def stage_times(scene, k, backward, args, reps=8):
     return st, [float(v) for v in np.median(np.asarray(samples[2:]), axis=0)], how
 
 
+def kernel_times(scene, k, backward, reps=10):
+    """launch duration of the roofline kernels, each ALONE: `reps` back-to-back launches of one stage behind a filler kernel, two HIP events
+    on the launch stream around the whole run (an event pair around a single launch costs about as much device time as a small kernel:
+    `stage_ms` carries that, these do not).  Same tensors, same processing order and same transposed table as the step."""
+    from contrastboundary_amd import hotpath, local_aggregation, pointops
+    n, c = scene.n, scene.c
+    out = {}
+    filler = torch.empty(1 << 32, dtype=torch.uint8, device="cuda")
+
+    def timed(fn):
+        fn(); fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        filler.fill_(0)                                              # ~0.6 ms: the host enqueues all `reps` launches meanwhile
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps * 1e3                        # us
+    with pointops.neighbor_cache() as nc:
+        for xyz, nsample, algo in hotpath.search_hints(scene):
+            nc.hint(xyz, nsample, algo)
+        idx, _ = pointops.knnquery_raw(k, scene.xyz, scene.xyz, scene.offset, scene.offset)
+        out["queryandgroup"] = timed(lambda: pointops.queryandgroup(k, scene.xyz, scene.xyz, scene.feat, idx, scene.offset, scene.offset, use_xyz=True))
+        out["kpconv_fwd"] = timed(lambda: local_aggregation.kpconv(scene.xyz, scene.xyz, idx, scene.feat, scene.kernel_points, scene.kernel_weights, 0.12))
+        if backward:
+            up = scene.upstream(k)
+            pointops.neighbor_transpose(idx, n)
+            out["queryandgroup_bwd"] = timed(lambda: pointops._scatter_rows(up["grad_grouped"], idx, n, 3, c))
+    del filler
+    return out
+
+
 MAIN_KERNEL = {
     "knnquery_k16": "grid build + knn_grid_wave_kernel (the K=36 search of the same points, which also writes the K=16 rows) + knn_replay_kernel for the tied rows",
     "queryandgroup": "query_group_lds<16> (aligned 16-row pieces through LDS, cell-order schedule)",
@@ -233,10 +267,10 @@ MAIN_KERNEL = {
     "cbl_mining_loss_bwd": "contrast_gather_kernel<8>",
     "neighbor_transpose_k16": "nt_prep / nt_count / nt_bin / nt_finish (transposed K=16 table)",
     "queryandgroup_bwd": "grouping_bwd_csr_rows_kernel (K4 as a gather)",
-    "kpconv_bwd": "kpconv_bwd_csr_kernel<true,true> (gather over the transposed table) + kpconv_gkw_reduce_kernel",
+    "kpconv_bwd": "kpconv_bwd_csr_kernel<true,true,false> (S = W^T G over the transposed table, v_mfma_f32_16x16x4_f32) + kpconv_gkw_reduce_kernel",
 }
 PMC_KERNEL = {"queryandgroup": "query_group_lds<16>", "kpconv_fwd": "kpconv_fwd_kernel<true>", "cbl_mining_loss_fwd": "contrast_pairs_kernel<8, 5, true>",
-              "cbl_mining_loss_bwd": "contrast_gather_kernel<8>", "queryandgroup_bwd": "grouping_bwd_csr_rows_kernel", "kpconv_bwd": "kpconv_bwd_csr_kernel<true, true>"}
+              "cbl_mining_loss_bwd": "contrast_gather_kernel<8>", "queryandgroup_bwd": "grouping_bwd_csr_rows_kernel", "kpconv_bwd": "kpconv_bwd_csr_kernel<true, true, false>"}
 
 
 def run_gpu(args, D, world, rank, local):
@@ -287,11 +321,16 @@ def run_gpu(args, D, world, rank, local):
     traffic = lambda stage: pmc.get(PMC_KERNEL.get(stage, ""), {}).get("hbm_bytes_per_launch")
     gi = names.index("queryandgroup")
     dom = int(np.argmax(stage_ms))
-    roofline = {"kernel": MAIN_KERNEL["queryandgroup"], "stage": "queryandgroup", "bound": "hbm", "achieved": gbps(gi), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": gbps(gi) / HBM_PEAK_GBS, "traffic": traffic("queryandgroup"), "bytes_per_launch": stages[gi][2],
+    kus = kernel_times(scene, k, backward)                           # us per launch of the roofline kernels, each alone
+    kgbps = lambda name: stages[names.index(name)][2] / (kus[name] * 1e-6) / 1e9
+    roofline = {"kernel": MAIN_KERNEL["queryandgroup"], "stage": "queryandgroup", "bound": "hbm", "achieved": kgbps("queryandgroup"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": kgbps("queryandgroup") / HBM_PEAK_GBS, "traffic": traffic("queryandgroup"), "bytes_per_launch": stages[gi][2],
+                "launch_us": round(kus["queryandgroup"], 2),
                 "traffic_source": ("PMC FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE per launch from %s (%s)" % (os.path.relpath(PMC_FILE, ROOT), pmc.get("_meta", {}).get("kernels", "this kernel set"))
                                    if traffic("queryandgroup") else "not measured for this kernel set (no %s)" % os.path.relpath(PMC_FILE, ROOT)),
-                "note": "achieved = SURVEY 8(d) algorithmic bytes of the launch / its HIP-event time; " + how,
+                "note": "achieved = SURVEY 8(d) algorithmic bytes of the launch / its duration = HIP events on the launch stream around 10 back-to-back "
+                        "launches of the kernel alone, issued behind a filler kernel, / 10 (same tensors, processing order and tables as the step; "
+                        "rocprofv3 --kernel-trace --stats of this command: profiles/).  stage_ms: " + how,
                 "longest_stage": {"stage": names[dom], "kernel": MAIN_KERNEL.get(names[dom], names[dom]), "ms": round(stage_ms[dom], 4),
                                   "algorithmic_GBps": round(gbps(dom), 1), "traffic": traffic(names[dom])},
                 "stage_ms": {names[i]: round(stage_ms[i], 4) for i in range(len(stages))},
@@ -299,12 +338,14 @@ def run_gpu(args, D, world, rank, local):
                 "stage_algorithmic_GBps": {names[i]: (round(gbps(i), 1) if stage_bytes[i] else None) for i in range(len(stages))}}
     if "queryandgroup_bwd" in names:
         bi = names.index("queryandgroup_bwd")
-        roofline["scatter_k4"] = {"kernel": MAIN_KERNEL["queryandgroup_bwd"], "bound": "hbm", "achieved": gbps(bi), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": gbps(bi) / HBM_PEAK_GBS, "bytes_per_launch": stages[bi][2], "traffic": traffic("queryandgroup_bwd")}
+        roofline["scatter_k4"] = {"kernel": MAIN_KERNEL["queryandgroup_bwd"], "bound": "hbm", "achieved": kgbps("queryandgroup_bwd"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": kgbps("queryandgroup_bwd") / HBM_PEAK_GBS, "bytes_per_launch": stages[bi][2], "launch_us": round(kus["queryandgroup_bwd"], 2),
+                                  "traffic": traffic("queryandgroup_bwd"),
+                                  "note": "K4 (grouping_cuda_kernel.cu:16-25) as a gather over the transposed neighbour table: no atomics (round 1: 136 us, 17 % of HBM)"}
     ki = names.index("kpconv_fwd")
-    tf = stages[ki][3] / (stage_ms[ki] * 1e-3) / 1e12
+    tf = stages[ki][3] / (kus["kpconv_fwd"] * 1e-6) / 1e12
     roofline["mfma_kpconv"] = {"kernel": "kpconv_fwd_kernel", "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic("kpconv_fwd")}
+                               "frac": tf / FP32_MFMA_PEAK_TFLOPS, "launch_us": round(kus["kpconv_fwd"], 2), "traffic": traffic("kpconv_fwd")}
     if rank == 0:
         # what this device delivers on plain streams, here and now: a fill and a copy of the size of the gather's output
         probe = torch.empty(stages[gi][2] // 4, dtype=torch.float32, device="cuda"); probe2 = torch.empty_like(probe)
@@ -319,7 +360,7 @@ def run_gpu(args, D, world, rank, local):
             return nbytes / (a.elapsed_time(b) / reps * 1e-3) / 1e9
         fill = _rate(lambda: probe.fill_(1.0), probe.numel() * 4)
         copy = _rate(lambda: probe2.copy_(probe), 2 * probe.numel() * 4)
-        roofline.update({"measured_fill_GBps": round(fill, 1), "measured_copy_GBps": round(copy, 1), "frac_of_measured_fill": gbps(gi) / fill})
+        roofline.update({"measured_fill_GBps": round(fill, 1), "measured_copy_GBps": round(copy, 1), "frac_of_measured_fill": kgbps("queryandgroup") / fill})
         del probe, probe2
     out["roofline"] = roofline
 
@@ -351,7 +392,7 @@ def run_gpu(args, D, world, rank, local):
             from tests import cpu_baseline
             cb = cpu_baseline.run(n, c, k, seed=0, backward=backward)
             # north_star: KNN + group on the GPU against the host CPU's (search stage + gather, in-order stage times)
-            gpu_kg = (stage_ms[names.index("knnquery_k%d" % k)] + stage_ms[gi]) * 1e-3
+            gpu_kg = (stage_ms[names.index("knnquery_k%d" % k)] + kus["queryandgroup"] * 1e-3) * 1e-3
             kg = cb["knn_plus_group_seconds"]
             cb["knn_plus_group_speedup"] = {"gpu_seconds": gpu_kg, "vs_fastest_cpu_knn": (kg["knn_k%d_fastest_cpu" % k] + kg["queryandgroup_port"]) / gpu_kg,
                                             "vs_port_allcores": (kg["knn_k%d_port_allcores" % k] + kg["queryandgroup_port"]) / gpu_kg,

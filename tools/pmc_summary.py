@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter_collection CSVs (two separate passes, tools/gpu_pmc.sh) -> profiles/r01_pmc_traffic.json:
+"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter_collection CSVs (two separate passes, tools/gpu_pmc.sh) -> profiles/rNN_pmc_traffic.json:
 HBM-side bytes per launch of every kernel of `bench.py`, with the gfx950 correction of MI355X_MICROARCH.md's HBM section
 (FETCH_SIZE is reported in KiB and counts 16-B-per-lane reads at half their size: x2; WRITE_SIZE in KiB, uncorrected)."""
 import collections
@@ -32,7 +32,8 @@ def main(fetch_csv, write_csv, out_json):
                 acc[short(r["Kernel_Name"])][ctr].append(float(r["Counter_Value"]))
     doc = {"_meta": {"command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline "
                                 "(two separate passes, tools/gpu_pmc.sh; summarised by tools/pmc_summary.py)",
-                     "workload": "N=40960 K=16 C=64 S-room seed 0",
+                     "workload": "N=40960 K=16 C=64 S-room seed 0, forward + backward of the block",
+                     "kernels": "the kernel set of this commit's step (contrast_pairs / contrast_gather / nt_* / grouping_bwd_csr_rows / kpconv_bwd_csr)",
                      "correction": "FETCH_SIZE x2 (gfx950 rocprofv3 reports half the bytes of 16 B/lane reads, MI355X_MICROARCH.md HBM section); "
                                    "WRITE_SIZE uncorrected; counters count fabric-side requests, Infinity-Cache hits included"}}
     for k, v in acc.items():
