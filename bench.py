@@ -236,7 +236,7 @@ def kernel_times(scene, k, backward, reps=10):
         fn(); fn()
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        filler.fill_(0)                                              # ~0.6 ms: the host enqueues all `reps` launches meanwhile
+        filler.fill_(0); filler.fill_(1)                             # ~1.2 ms: the host enqueues all `reps` launches meanwhile
         a.record()
         for _ in range(reps):
             fn()
