@@ -81,16 +81,17 @@ __global__ __launch_bounds__(256) void knn_prefix_kernel(int m, int kb, int ks, 
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= m) return;
     const int* ib = idx_big + (size_t)q * kb; const float* db = d2_big + (size_t)q * kb;
-    float prev = -1.f; bool dup = false;
+    float prev = -1.f; bool dup = false, dup0 = false;
     for (int j = 0; j < ks; j++) {
         const float d = db[j];
         idx[(size_t)q * ks + j] = ib[j]; dist2[(size_t)q * ks + j] = d;
         dup = dup || (d == prev);
+        dup0 = dup0 || (j == 1 && d == prev);                      // a tie for column 0: replayed under the set policy too (knn_grid.hip)
         prev = d;
     }
     const bool full = prev < 1e10f;                                 // the reference's initial heap entries are 1e10 (knnquery_cuda_kernel.cu:91-94)
     const bool boundary = db[ks] == prev;
-    const bool ok = full && !boundary && (set_exact || !dup);
+    const bool ok = full && !boundary && (set_exact ? !dup0 : !dup);
     if (!ok) worklist[atomicAdd(counter, 1)] = q;
 }
 // the same for K a power of two <= 64: K consecutive lanes per query (a row of the output is one coalesced segment), ties found by comparing
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void knn_prefix_pow2_kernel(int m, int kb, con
     const float d = d2_big[(size_t)q * kb + j], dn = d2_big[(size_t)q * kb + j + 1];       // j + 1 <= KS < kb
     if (live) { idx[(size_t)q * KS + j] = idx_big[(size_t)q * kb + j]; dist2[(size_t)q * KS + j] = d; }
     const bool last = j == KS - 1;
-    const bool bad = (d == dn && (last || !set_exact)) || (last && !(d < 1e10f));
+    const bool bad = (d == dn && (last || j == 0 || !set_exact)) || (last && !(d < 1e10f));        // set policy: boundary ties and a tie for column 0
     const unsigned long long bm = __ballot(bad && live);
     const unsigned long long gm = (KS == 64) ? bm : ((bm >> (lane & ~(KS - 1))) & ((1ull << KS) - 1ull));
     if (live && j == 0 && gm != 0ull) worklist[atomicAdd(counter, 1)] = q;

@@ -444,7 +444,9 @@ __global__ __launch_bounds__(256) void knn_grid_group_kernel(int b, int m, int K
     // set_exact: the caller only needs the reference's neighbour SET (sorted by distance); equal distances INSIDE the list
     // leave the set unambiguous, so only a tie at the K-th boundary (or an unfilled list) still needs the replay
     // set_exact == 2 ("any tie order"): a full list is final — among candidates tied at the K-th distance the visiting order decides
-    const bool ok = (worst < INFINITY) && (set_exact == 2 || ((rm != worst) && (set_exact || dm == 0)));
+    // (set_exact == 1 keeps ONE piece of the reference's order: which of two equidistant nearest supports is column 0 — the CBL head drops
+    //  "column 0 = the query itself", heads.py:195-196, and a coincident point would otherwise be free to take that place)
+    const bool ok = (worst < INFINITY) && (set_exact == 2 || ((rm != worst) && (set_exact ? !(dm & 2ull) : dm == 0)));
     if (live) {
         if (gl < K) { idx[(size_t)q * K + gl] = ei; dist2[(size_t)q * K + gl] = ed; }
         if (!ok && gl == 0) worklist[atomicAdd(counters, 1)] = q;
@@ -644,7 +646,7 @@ __global__ __launch_bounds__(256) void knn_grid_wave_kernel(int b, int m, int K,
     const float rm = group_min_nonneg<64>(rejmin);
     const float pd = dpp_shr1_f<64>(ed);
     const bool dup = (lane > 0) && (lane < K) && (ed == pd);
-    const bool ok = (worst < INFINITY) && (set_exact == 2 || ((rm != worst) && (set_exact || __ballot(dup) == 0)));
+    const bool ok = (worst < INFINITY) && (set_exact == 2 || ((rm != worst) && (set_exact ? !(__ballot(dup) & 2ull) : __ballot(dup) == 0)));   // set: a tie for column 0 still replays
     if (lane < K) { idx[(size_t)q * K + lane] = ei; dist2[(size_t)q * K + lane] = ed; }
     if (!ok && lane == 0) worklist[atomicAdd(counters, 1)] = q;
     // the ks < K nearest as a result of their own (cbl_knnquery_nested): the list's distances are final whether or not its tie order
@@ -652,7 +654,7 @@ __global__ __launch_bounds__(256) void knn_grid_wave_kernel(int b, int m, int K,
     // entry ks-1 tied with entry ks, or fewer than ks supports (the reference pads with 1e10, knnquery_cuda_kernel.cu:91-94)
     if (idx_n) {
         if (lane < ks) { idx_n[(size_t)q * ks + lane] = ei; dist2_n[(size_t)q * ks + lane] = ed; }
-        const bool bad = (lane > 0 && lane <= ks && ed == pd && (lane == ks || !set_exact_n)) || (lane == ks - 1 && !(ed < 1e10f));
+        const bool bad = (lane > 0 && lane <= ks && ed == pd && (lane == ks || lane == 1 || !set_exact_n)) || (lane == ks - 1 && !(ed < 1e10f));
         if (__ballot(bad) != 0ull && lane == 0) worklist_n[atomicAdd(counters + 1, 1)] = q;
     }
 }

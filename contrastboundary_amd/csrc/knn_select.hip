@@ -188,6 +188,10 @@ __global__ __launch_bounds__(SB) void knn_select_kernel(int b, int m, int K, con
                 for (int e = tid; e + 1 < K; e += SB) if (sd[e] == sd[e + 1]) dupflag = 1;
                 __syncthreads();
                 ok = dupflag == 0;
+            } else if (set_exact == 1) {                             // set policy: a tie for column 0 still takes the reference's order (knn_grid.hip)
+                if (tid == 0 && K > 1 && sd[0] == sd[1]) dupflag = 1;
+                __syncthreads();
+                ok = dupflag == 0;
             }
         }
         if (ok) {

@@ -61,9 +61,10 @@ int cbl_knnquery(int b, int n, int m, int nsample,
 size_t cbl_knnquery_workspace_bytes(int b, int n, int m, int nsample);
 
 /* Same neighbour SET per query as cbl_knnquery, rows ascending by distance, but supports at exactly equal distance may appear in
- * any order (no replay for ties inside the list; ties at the K-th boundary are still resolved exactly like the reference).
- * For consumers that are invariant to the order of equal-distance neighbours: the CBL head (heads.py:192-199 drops column 0 and
- * reduces over the rest) and the sub-scene label mean (basic_operators.py:30-41). */
+ * any order (no replay for ties inside the list; ties at the K-th boundary are still resolved exactly like the reference, and so is a
+ * tie for COLUMN 0: between two equidistant nearest supports — a query and a point coincident with it — the reference's choice stands).
+ * For consumers that are invariant to the order of equal-distance neighbours: the CBL head (heads.py:192-199 drops column 0 — "the
+ * query itself" — and reduces over the rest) and the sub-scene label mean (basic_operators.py:30-41). */
 int cbl_knnquery_set(int b, int n, int m, int nsample,
                      const float* xyz, const float* new_xyz,
                      const int* offset, const int* new_offset,

@@ -334,3 +334,29 @@ def test_tf_contrast_nce_vs_oracle(k, d):
     np.testing.assert_array_equal(mask.cpu().numpy().astype(bool), rmask)
     np.testing.assert_allclose(loss.item(), rloss, rtol=TOL)
     np.testing.assert_allclose(f.grad.cpu().numpy(), rgrad, rtol=1e-3, atol=1e-4 * np.abs(rgrad).max())
+
+
+def test_coincident_points_keep_the_reference_column_zero():
+    """A point with a coincident twin: both are at distance 0 from the query and the reference's heap decides which one is column 0 — the
+    column point_contrast drops as "the query itself" (heads.py:195-196).  The set-policy search the head uses leaves the order among
+    equal distances free EXCEPT for that column, so the head's numbers stay the reference's on clouds with duplicated coordinates."""
+    from contrastboundary_amd import heads, pointops
+    rng = np.random.default_rng(11)
+    n, K, d = 4096, 24, 32
+    xyz = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    xyz[1::5] = xyz[0:n - 1:5][: len(xyz[1::5])]                      # every fifth point gets a coincident twin
+    lab = (np.floor(xyz[:, 0] * 4) + 4 * np.floor(xyz[:, 1] * 3)).astype(np.int64) % 13
+    feat = (rng.normal(size=(n, d)) * 0.5).astype(np.float32)
+    off = np.int32([n])
+    ridx, _ = O.knnquery(K, xyz, xyz, off, off)                       # the reference's order
+    assert (ridx[:, 0] != np.arange(n)).any(), "the fixture must contain queries whose column 0 is their twin"
+    xyz_d, off_d = dev(xyz), dev(off)
+    sidx, _ = pointops.knnquery_raw(K, xyz_d, xyz_d, off_d, off_d, algo="set")
+    np.testing.assert_array_equal(sidx.cpu().numpy()[:, 0], ridx[:, 0])
+    np.testing.assert_array_equal(np.sort(sidx.cpu().numpy(), 1), np.sort(ridx, 1))
+    f = dev(feat).requires_grad_(True)
+    loss = heads.point_contrast(f, dev(lab), sidx, temperature=1.0, weight=0.1)
+    loss.backward()
+    rloss, rgrad, _ = C.point_contrast(feat, np.eye(13, dtype=np.float32)[lab], ridx, temperature=1.0, weight=0.1)
+    np.testing.assert_allclose(loss.item(), rloss, rtol=TOL)
+    np.testing.assert_allclose(f.grad.cpu().numpy(), rgrad, rtol=1e-3, atol=1e-4 * np.abs(rgrad).max())
