@@ -54,6 +54,8 @@ def parse(argv=None):
     ap.add_argument("--no-allreduce", action="store_true", help="skip the gradient all-reduce leg of a multi-rank run")
     ap.add_argument("--no-extra", action="store_true", help="headline only: no forward_only / stage / all-reduce legs (profiling runs)")
     ap.add_argument("--allreduce-floats", type=int, default=GRAD_ALLREDUCE_FLOATS)
+    ap.add_argument("--allreduce-single", action="store_true",
+                    help="tests: run the gradient all-reduce leg over a ONE-rank RCCL group (exercises the RCCL path on a 1-GPU box; not a scaling number)")
     ap.add_argument("--host-dry-run", action="store_true",
                     help="CPU-only run of the launcher / process-group / timing / all-reduce logic over gloo (tests; not a measurement)")
     return ap.parse_args(argv)
@@ -276,6 +278,10 @@ PMC_KERNEL = {"queryandgroup": "query_group_lds<16>", "kpconv_fwd": "kpconv_fwd_
 def run_gpu(args, D, world, rank, local):
     torch.cuda.set_device(local)
     D.init("nccl" if world > 1 else None)                           # "nccl" is RCCL on ROCm
+    if world == 1 and args.allreduce_single:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1)
     if world > 1:
         import torch.distributed as dist
         assert dist.get_world_size() == args.gpus, "RCCL process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus)
@@ -371,7 +377,7 @@ def run_gpu(args, D, world, rank, local):
         out["forward_only"] = {"value": n * args.steps * world / e_f, "ms_per_step": e_f / args.steps * 1e3, "stages": " -> ".join(fstep.names), "issue": fstep.note}
 
     # ---- the same K steps with DDP's gradient all-reduce beside them (multi-rank runs)
-    if world > 1 and not args.no_allreduce:
+    if (world > 1 or args.allreduce_single) and not args.no_allreduce:
         ar = GradAllReduce(args.allreduce_floats, "cuda")
 
         def step_ar():
@@ -384,7 +390,7 @@ def run_gpu(args, D, world, rank, local):
         nbytes = 4 * args.allreduce_floats
         out["grad_allreduce"] = {"value": n * args.steps * world / e_ar, "ms_per_step": e_ar / args.steps * 1e3, "bytes": nbytes,
                                  "allreduce_alone_ms": e_only / args.steps * 1e3,
-                                 "allreduce_busbw_GBps": nbytes * 2 * (world - 1) / world / (e_only / args.steps) / 1e9,
+                                 "allreduce_busbw_GBps": nbytes * 2 * (world - 1) / world / (e_only / args.steps) / 1e9, "ranks": world,
                                  "note": "one flat fp32 all-reduce of the reference network's 7,800,497 gradients per step over RCCL, issued beside the "
                                          "step and joined at its end (what DDP adds, train.py:181-185); `value` above is the replica-only number"}
     if rank == 0:
@@ -403,10 +409,9 @@ def run_gpu(args, D, world, rank, local):
 
 
 def finish(world):
-    if world > 1:
-        import torch.distributed as tdist
-        if tdist.is_initialized():
-            tdist.destroy_process_group()
+    import torch.distributed as tdist
+    if tdist.is_available() and tdist.is_initialized():
+        tdist.destroy_process_group()
     return 0
 
 
