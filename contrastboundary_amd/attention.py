@@ -22,8 +22,8 @@ def _workspace(nbytes, device):
 
 def supported(layer, x):
     C = layer.out_planes
-    return (layer.training and x.is_cuda and x.dtype == torch.float32 and layer.mid_planes == C and layer.share_planes == 8 and C in (32, 64)
-            and layer.nsample <= 64 and x.shape[0] * layer.nsample >= 16384
+    return (layer.training and x.is_cuda and x.dtype == torch.float32 and layer.mid_planes == C and layer.share_planes == 8 and C in (32, 64, 128, 256, 512)
+            and layer.nsample <= 64 and (C > 64 or x.shape[0] * layer.nsample >= 16384)
             and isinstance(layer.linear_w[0], torch.nn.BatchNorm1d) and layer.linear_w[0].track_running_stats and layer.linear_w[0].momentum is not None)
 
 

@@ -399,13 +399,305 @@ __global__ __launch_bounds__(AT_BLOCK) void attn_agg_backward_kernel(int n, int 
     }
 }
 
+// ----------------------------------------------------------------------------------------------------------- wide stages
+// C = 128 / 256 / 512 (the three coarse stages: 2560 / 640 / 160 points per 40960-point scene, share_planes = 8 -> G = C / 8).  Their
+// tensors are small; what they cost is LAUNCHES: ~75 per layer on the separate kernels, 16 of the network's 23 layers.  The same
+// passes as above with ONE point per workgroup of C lanes (lane = channel, 2 / 4 / 8 waves): per-channel work is unchanged, the sums over
+// a point's channels go wave (DPP) -> LDS -> workgroup.
+// The contractions over a point's channels go to the matrix cores: the C lanes leave the values of 16 pairs in LDS as V (16 x C, row stride
+// C + 4 so that the A-operand reads of v_mfma_f32_16x16x4_f32 hit every bank twice, the minimum for 64 lanes), each wave multiplies a slice of
+// V's columns by its register-resident slice of the weight matrix (B operand), slices are summed through LDS.
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int WT = 16;                                           // pairs per tile (the MFMA's M)
+template <int C> constexpr int wide_stride() { return C + 4; }
+
+template <int C, int STEPS>
+__device__ __forceinline__ f32x4 wide_mfma(const float* V, int step0, const float (&bw)[STEPS])
+{
+    const int lane = threadIdx.x & 63;
+    const float* a = V + (lane & 15) * wide_stride<C>() + (lane >> 4) + 4 * step0;      // A[i][kk]: lane = i + 16 kk
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < STEPS; s++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * s], bw[s], acc, 0, 0, 0);
+    return acc;                                                                          // D[4 (lane / 16) + r][lane % 16] in acc[r]
+}
+
+// (16 x C) . W3C (C x 3): the gradient of p1 = the pair's 3-vector, for 16 pairs at once.  All C/64 waves take C/(4 NW) = 16 k-steps each.
+template <int C>
+struct WideTimes3 {
+    static constexpr int NW = C / 64, STEPS = 16;
+    float bw[STEPS];
+    __device__ __forceinline__ void load(const float* __restrict__ W3C)
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, kk = lane >> 4;
+#pragma unroll
+        for (int s = 0; s < STEPS; s++) bw[s] = j < 3 ? W3C[(size_t)(4 * (wave * STEPS + s) + kk) * 3 + j] : 0.f;   // B[kk][j]: lane = j + 16 kk
+    }
+    // P: NW x 16 x 4 floats of LDS; call between two barriers
+    __device__ __forceinline__ void partial(const float* V, float* P) const
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const f32x4 acc = wide_mfma<C, STEPS>(V, wave * STEPS, bw);
+        if ((lane & 15) < 3) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) P[(wave * WT + 4 * (lane >> 4) + r) * 4 + (lane & 15)] = acc[r];
+        }
+    }
+    // after the barrier: thread e < 48 owns gp1[u = e / 3][a = e % 3]
+    __device__ __forceinline__ float total(const float* P, int e) const
+    {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; w++) t += P[(w * WT + e / 3) * 4 + e % 3];
+        return t;
+    }
+};
+
+template <int C>
+__global__ __launch_bounds__(C) void attn_w2_stats_wide_kernel(int n, int K, const float* __restrict__ xq, const float* __restrict__ xk,
+                                                               const int* __restrict__ idx, const float* __restrict__ p1,
+                                                               const float* __restrict__ W3C, const float* __restrict__ b3C, float* __restrict__ partial)
+{
+    const int c = threadIdx.x;
+    PairParams q; q.w0 = W3C[3 * c]; q.w1 = W3C[3 * c + 1]; q.w2 = W3C[3 * c + 2]; q.b = b3C[c];
+    float s0 = 0.f, s1 = 0.f;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const float xqi = xq[(size_t)i * C + c];
+        for (int k0 = 0; k0 < K; k0 += AT_U) {
+            PairBatch pb; load_pairs<C>(pb, i, k0, K, c, idx, p1, xk);
+#pragma unroll
+            for (int u = 0; u < AT_U; u++)
+                if (k0 + u < K) { const float w = pe_of(q, pb.a0[u], pb.a1[u], pb.a2[u]) - (xqi - pb.xr[u]); s0 += w; s1 += w * w; }
+        }
+    }
+    partial[((size_t)blockIdx.x * 2) * C + c] = s0;
+    partial[((size_t)blockIdx.x * 2 + 1) * C + c] = s1;
+}
+
+template <int C, int G>
+__global__ __launch_bounds__(C) void attn_w2_forward_wide_kernel(int n, int K, const float* __restrict__ xq, const float* __restrict__ xk,
+                                                                 const int* __restrict__ idx, const float* __restrict__ p1,
+                                                                 const float* __restrict__ W3C, const float* __restrict__ b3C,
+                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 const float* __restrict__ Wa, const float* __restrict__ ba, float* __restrict__ w2)
+{
+    // w2 (16 pairs x G) = w1 (16 x C) . Wa^T (C x G): G/16 column tiles x 2 halves of the k-range = C/64 waves, C/8 MFMA steps each
+    constexpr int NT = G / 16, STEPS = C / 8;
+    __shared__ float V[WT * wide_stride<C>()];
+    __shared__ float P[2 * WT * G];
+    const int c = threadIdx.x, lane = c & 63, wave = c >> 6;
+    const int tile = wave % NT, half = wave / NT;
+    PairParams q; q.w0 = W3C[3 * c]; q.w1 = W3C[3 * c + 1]; q.w2 = W3C[3 * c + 2]; q.b = b3C[c];
+    q.mean = mean[c]; q.invstd = invstd[c]; q.gamma = gamma ? gamma[c] : 1.f; q.beta = beta ? beta[c] : 0.f;
+    float bw[STEPS];
+#pragma unroll
+    for (int s = 0; s < STEPS; s++) bw[s] = Wa[(size_t)(16 * tile + (lane & 15)) * C + 4 * (half * STEPS + s) + (lane >> 4)];
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const float xqi = xq[(size_t)i * C + c];
+        for (int k0 = 0; k0 < K; k0 += WT) {
+            float xr[WT];
+#pragma unroll
+            for (int u = 0; u < WT; u++) xr[u] = xk[(size_t)idx[(size_t)i * K + min(k0 + u, K - 1)] * C + c];
+#pragma unroll
+            for (int u = 0; u < WT; u++) {
+                const size_t r = (size_t)i * K + min(k0 + u, K - 1);
+                const float w = pe_of(q, p1[3 * r], p1[3 * r + 1], p1[3 * r + 2]) - (xqi - xr[u]);
+                const float y = (w - q.mean) * q.invstd * q.gamma + q.beta;
+                V[u * wide_stride<C>() + c] = y > 0.f ? y : 0.f;
+            }
+            __syncthreads();
+            const f32x4 acc = wide_mfma<C, STEPS>(V, half * STEPS, bw);
+#pragma unroll
+            for (int r = 0; r < 4; r++) P[(half * WT + 4 * (lane >> 4) + r) * G + 16 * tile + (lane & 15)] = acc[r];
+            __syncthreads();
+            for (int e = c; e < WT * G; e += C) {
+                const int u = e / G, g = e % G;
+                if (k0 + u < K) w2[((size_t)i * K + k0) * G + e] = P[e] + P[WT * G + e] + ba[g];
+            }
+        }
+    }
+}
+
+template <int C, int G>
+__global__ __launch_bounds__(C) void attn_w2_bwd_reduce_wide_kernel(int n, int K, const float* __restrict__ xq, const float* __restrict__ xk,
+                                                                    const int* __restrict__ idx, const float* __restrict__ p1,
+                                                                    const float* __restrict__ W3C, const float* __restrict__ b3C,
+                                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                    const float* __restrict__ Wa, const float* __restrict__ gw2, float* __restrict__ partial)
+{
+    const int c = threadIdx.x;
+    PairParams q; q.w0 = W3C[3 * c]; q.w1 = W3C[3 * c + 1]; q.w2 = W3C[3 * c + 2]; q.b = b3C[c];
+    q.mean = mean[c]; q.invstd = invstd[c]; q.gamma = gamma ? gamma[c] : 1.f; q.beta = beta ? beta[c] : 0.f;
+    float wa[G], dwa[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) { wa[g] = Wa[g * C + c]; dwa[g] = 0.f; }
+    float s0 = 0.f, s1 = 0.f, dba = 0.f;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const float xqi = xq[(size_t)i * C + c];
+        for (int k = 0; k < K; k++) {
+            const size_t r = (size_t)i * K + k;
+            const int j = idx[r];
+            const float w = pe_of(q, p1[3 * r], p1[3 * r + 1], p1[3 * r + 2]) - (xqi - xk[(size_t)j * C + c]);
+            const float xh = (w - q.mean) * q.invstd;
+            const float y = xh * q.gamma + q.beta;
+            const float w1 = y > 0.f ? y : 0.f;
+            float dw1 = 0.f;
+#pragma unroll
+            for (int g = 0; g < G; g++) { const float gd = gw2[r * G + g]; dw1 += wa[g] * gd; dwa[g] += gd * w1; dba += (c == g) ? gd : 0.f; }
+            const float dy = y > 0.f ? dw1 : 0.f;
+            s0 += dy; s1 += dy * xh;
+        }
+    }
+    float* mine = partial + (size_t)blockIdx.x * (2 * C + G * C + G);
+    mine[c] = s0; mine[C + c] = s1;
+#pragma unroll
+    for (int g = 0; g < G; g++) mine[2 * C + g * C + c] = dwa[g];
+    if (c < G) mine[2 * C + G * C + c] = dba;
+}
+
+template <int C, int G>
+__global__ __launch_bounds__(C) void attn_w2_bwd_apply_wide_kernel(int n, int K, const float* __restrict__ xq, const float* __restrict__ xk,
+                                                                   const int* __restrict__ idx, const float* __restrict__ p1,
+                                                                   const float* __restrict__ W3C, const float* __restrict__ b3C,
+                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   const float* __restrict__ Wa, const float* __restrict__ gw2, const float* __restrict__ sums,
+                                                                   float* __restrict__ gxq, float* __restrict__ gxk, float* __restrict__ gp1,
+                                                                   float* __restrict__ partial)
+{
+    __shared__ float V[WT * wide_stride<C>()];
+    __shared__ float P[(C / 64) * WT * 4];
+    const int c = threadIdx.x;
+    PairParams q; q.w0 = W3C[3 * c]; q.w1 = W3C[3 * c + 1]; q.w2 = W3C[3 * c + 2]; q.b = b3C[c];
+    q.mean = mean[c]; q.invstd = invstd[c]; q.gamma = gamma ? gamma[c] : 1.f; q.beta = beta ? beta[c] : 0.f;
+    float wa[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) wa[g] = Wa[g * C + c];
+    WideTimes3<C> t3; t3.load(W3C);
+    const float inv_rows = 1.0f / ((float)n * (float)K);
+    const float c0 = sums[c] * inv_rows, c1 = sums[C + c] * inv_rows;
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, db = 0.f;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const float xqi = xq[(size_t)i * C + c];
+        float gq = 0.f;
+        for (int k0 = 0; k0 < K; k0 += WT) {
+            int jj[WT]; float xr[WT];
+#pragma unroll
+            for (int u = 0; u < WT; u++) { jj[u] = idx[(size_t)i * K + min(k0 + u, K - 1)]; xr[u] = xk[(size_t)jj[u] * C + c]; }
+#pragma unroll
+            for (int u = 0; u < WT; u++) {
+                const size_t r = (size_t)i * K + min(k0 + u, K - 1);
+                const float a0 = p1[3 * r], a1 = p1[3 * r + 1], a2 = p1[3 * r + 2];
+                const float w = pe_of(q, a0, a1, a2) - (xqi - xr[u]);
+                const float xh = (w - q.mean) * q.invstd;
+                const float y = xh * q.gamma + q.beta;
+                float dw1 = 0.f;
+#pragma unroll
+                for (int g = 0; g < G; g++) dw1 += wa[g] * gw2[r * G + g];
+                const float dy = y > 0.f ? dw1 : 0.f;
+                float dw = q.gamma * q.invstd * ((dy - c0) - xh * c1);       // BatchNorm backward, train mode
+                if (k0 + u >= K) dw = 0.f;
+                else unsafeAtomicAdd(gxk + (size_t)jj[u] * C + c, dw);        // w = p_r - x_q + x_k[j]
+                gq -= dw;
+                d0 += dw * a0; d1 += dw * a1; d2 += dw * a2; db += dw;
+                V[u * wide_stride<C>() + c] = dw;
+            }
+            __syncthreads();
+            t3.partial(V, P);
+            __syncthreads();
+            if (c < 3 * WT && k0 + c / 3 < K) gp1[3 * ((size_t)i * K + k0) + c] = t3.total(P, c);
+        }
+        gxq[(size_t)i * C + c] = gq;
+    }
+    float* mine = partial + (size_t)blockIdx.x * (4 * C);
+    mine[3 * c] = d0; mine[3 * c + 1] = d1; mine[3 * c + 2] = d2; mine[3 * C + c] = db;
+}
+
+template <int C, int G>
+__global__ __launch_bounds__(C) void attn_agg_forward_wide_kernel(int n, int K, const float* __restrict__ xv, const int* __restrict__ idx,
+                                                                  const float* __restrict__ p1, const float* __restrict__ W3C, const float* __restrict__ b3C,
+                                                                  const float* __restrict__ a, float* __restrict__ out)
+{
+    const int c = threadIdx.x;
+    PairParams q; q.w0 = W3C[3 * c]; q.w1 = W3C[3 * c + 1]; q.w2 = W3C[3 * c + 2]; q.b = b3C[c];
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        float acc = 0.f;
+        for (int k0 = 0; k0 < K; k0 += AT_U) {
+            PairBatch pb; load_pairs<C>(pb, i, k0, K, c, idx, p1, xv);
+            float av[AT_U];
+#pragma unroll
+            for (int u = 0; u < AT_U; u++) av[u] = a[((size_t)i * K + min(k0 + u, K - 1)) * G + (c % G)];
+#pragma unroll
+            for (int u = 0; u < AT_U; u++)
+                if (k0 + u < K) acc += (pb.xr[u] + pe_of(q, pb.a0[u], pb.a1[u], pb.a2[u])) * av[u];
+        }
+        out[(size_t)i * C + c] = acc;
+    }
+}
+
+template <int C, int G>
+__global__ __launch_bounds__(C) void attn_agg_backward_wide_kernel(int n, int K, const float* __restrict__ xv, const int* __restrict__ idx,
+                                                                   const float* __restrict__ p1, const float* __restrict__ W3C, const float* __restrict__ b3C,
+                                                                   const float* __restrict__ a, const float* __restrict__ go,
+                                                                   float* __restrict__ gxv, float* __restrict__ gp1, float* __restrict__ ga, float* __restrict__ partial)
+{
+    __shared__ float V[WT * wide_stride<C>()];
+    __shared__ float DA[WT * C];
+    __shared__ float P[(C / 64) * WT * 4];
+    const int c = threadIdx.x;
+    PairParams q; q.w0 = W3C[3 * c]; q.w1 = W3C[3 * c + 1]; q.w2 = W3C[3 * c + 2]; q.b = b3C[c];
+    WideTimes3<C> t3; t3.load(W3C);
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, db = 0.f;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const float g = go[(size_t)i * C + c];
+        for (int k0 = 0; k0 < K; k0 += WT) {
+            int jj[WT]; float xr[WT];
+#pragma unroll
+            for (int u = 0; u < WT; u++) { jj[u] = idx[(size_t)i * K + min(k0 + u, K - 1)]; xr[u] = xv[(size_t)jj[u] * C + c]; }
+#pragma unroll
+            for (int u = 0; u < WT; u++) {
+                const size_t r = (size_t)i * K + min(k0 + u, K - 1);
+                const float a0 = p1[3 * r], a1 = p1[3 * r + 1], a2 = p1[3 * r + 2];
+                float dpe = g * a[r * G + (c % G)];                          // d out / d (x_v[j] + p_r)
+                if (k0 + u >= K) dpe = 0.f;
+                else unsafeAtomicAdd(gxv + (size_t)jj[u] * C + c, dpe);
+                d0 += dpe * a0; d1 += dpe * a1; d2 += dpe * a2; db += dpe;
+                V[u * wide_stride<C>() + c] = dpe;
+                DA[u * C + c] = g * (xr[u] + pe_of(q, a0, a1, a2));          // grad_a[i,k,g] = sum over the channels with c % G == g
+            }
+            __syncthreads();
+            t3.partial(V, P);
+            for (int e = c; e < WT * G; e += C) {
+                const int u = e / G, gg = e % G;
+                float da = 0.f;
+#pragma unroll
+                for (int st = 0; st < C / G; st++) da += DA[u * C + gg + G * st];
+                if (k0 + u < K) ga[((size_t)i * K + k0) * G + e] = da;
+            }
+            __syncthreads();
+            if (c < 3 * WT && k0 + c / 3 < K) gp1[3 * ((size_t)i * K + k0) + c] = t3.total(P, c);
+        }
+    }
+    float* mine = partial + (size_t)blockIdx.x * (4 * C);
+    mine[3 * c] = d0; mine[3 * c + 1] = d1; mine[3 * c + 2] = d2; mine[3 * C + c] = db;
+}
+
+// partial rows per pass: one per workgroup; enough workgroups to fill 256 CUs, few enough that the (2C + GC + G)-float rows stay ~30 MB
+constexpr int at_wide_blocks(int C) { return C <= 128 ? 1024 : (C <= 256 ? 768 : 256); }
+
 int at_check(int n, int K, int C, int G)
 {
     if (n < 0 || K <= 0) return CBL_ERR_BAD_ARG;
-    if (!((C == 32 && G == 4) || (C == 64 && G == 8))) return CBL_ERR_UNSUPPORTED;
+    if (!((C == 32 && G == 4) || (C == 64 && G == 8) || (C == 128 && G == 16) || (C == 256 && G == 32) || (C == 512 && G == 64))) return CBL_ERR_UNSUPPORTED;
     return CBL_OK;
 }
-inline int at_blocks(int n, int C) { const int gpb = AT_BLOCK / C; const long long b = ((long long)n + gpb - 1) / gpb; return (int)(b < 1 ? 1 : (b > AT_MAX_BLOCKS ? AT_MAX_BLOCKS : b)); }
+inline int at_blocks(int n, int C)
+{
+    if (C > 64) return n < 1 ? 1 : (n > at_wide_blocks(C) ? at_wide_blocks(C) : n);                     // wide stages: one point per workgroup and trip
+    const int gpb = AT_BLOCK / C; const long long b = ((long long)n + gpb - 1) / gpb; return (int)(b < 1 ? 1 : (b > AT_MAX_BLOCKS ? AT_MAX_BLOCKS : b));
+}
 
 }  // namespace
 
@@ -413,13 +705,16 @@ inline int at_blocks(int n, int C) { const int gpb = AT_BLOCK / C; const long lo
 CBL_EXPORT size_t cbl_attn_workspace_bytes(int C, int G)
 {
     const size_t per_block = (size_t)2 * C + (size_t)G * C + G;
-    return sizeof(float) * (AT_MAX_BLOCKS * per_block + per_block) + 256;
+    return sizeof(float) * ((C > 64 ? at_wide_blocks(C) : AT_MAX_BLOCKS) * per_block + per_block) + 256;
 }
 
 #define AT_DISPATCH(KERNEL, ...)                                                                                              \
     do {                                                                                                                          \
-        if (C == 32) hipLaunchKernelGGL((KERNEL<32, 4>), dim3(nb), dim3(AT_BLOCK), 0, st, __VA_ARGS__);                           \
-        else         hipLaunchKernelGGL((KERNEL<64, 8>), dim3(nb), dim3(AT_BLOCK), 0, st, __VA_ARGS__);                           \
+        if (C == 32)       hipLaunchKernelGGL((KERNEL##_kernel<32, 4>), dim3(nb), dim3(AT_BLOCK), 0, st, __VA_ARGS__);            \
+        else if (C == 64)  hipLaunchKernelGGL((KERNEL##_kernel<64, 8>), dim3(nb), dim3(AT_BLOCK), 0, st, __VA_ARGS__);            \
+        else if (C == 128) hipLaunchKernelGGL((KERNEL##_wide_kernel<128, 16>), dim3(nb), dim3(128), 0, st, __VA_ARGS__);          \
+        else if (C == 256) hipLaunchKernelGGL((KERNEL##_wide_kernel<256, 32>), dim3(nb), dim3(256), 0, st, __VA_ARGS__);          \
+        else               hipLaunchKernelGGL((KERNEL##_wide_kernel<512, 64>), dim3(nb), dim3(512), 0, st, __VA_ARGS__);          \
     } while (0)
 
 CBL_EXPORT int cbl_attn_w2_forward(int n, int K, int C, int G, const float* x_q, const float* x_k, const int* idx, const float* p1,
@@ -437,12 +732,15 @@ CBL_EXPORT int cbl_attn_w2_forward(int n, int K, int C, int G, const float* x_q,
     const int nb = at_blocks(n, C);
     float* partial = reinterpret_cast<float*>(workspace);
     if (training) {                                                   // eval mode: the caller put the running statistics into save_mean / save_invstd
-        if (C == 32) hipLaunchKernelGGL(attn_w2_stats_kernel<32>, dim3(nb), dim3(AT_BLOCK), 0, st, n, K, x_q, x_k, idx, p1, W3C, b3C, partial);
-        else         hipLaunchKernelGGL(attn_w2_stats_kernel<64>, dim3(nb), dim3(AT_BLOCK), 0, st, n, K, x_q, x_k, idx, p1, W3C, b3C, partial);
+        if (C == 32)       hipLaunchKernelGGL(attn_w2_stats_kernel<32>, dim3(nb), dim3(AT_BLOCK), 0, st, n, K, x_q, x_k, idx, p1, W3C, b3C, partial);
+        else if (C == 64)  hipLaunchKernelGGL(attn_w2_stats_kernel<64>, dim3(nb), dim3(AT_BLOCK), 0, st, n, K, x_q, x_k, idx, p1, W3C, b3C, partial);
+        else if (C == 128) hipLaunchKernelGGL(attn_w2_stats_wide_kernel<128>, dim3(nb), dim3(128), 0, st, n, K, x_q, x_k, idx, p1, W3C, b3C, partial);
+        else if (C == 256) hipLaunchKernelGGL(attn_w2_stats_wide_kernel<256>, dim3(nb), dim3(256), 0, st, n, K, x_q, x_k, idx, p1, W3C, b3C, partial);
+        else               hipLaunchKernelGGL(attn_w2_stats_wide_kernel<512>, dim3(nb), dim3(512), 0, st, n, K, x_q, x_k, idx, p1, W3C, b3C, partial);
         hipLaunchKernelGGL(attn_bn_finalize_kernel, dim3(cbl_div_up(C, 16)), dim3(256), 0, st, (long long)n * K, C, nb, partial, eps, momentum,
                            running_mean, running_var, num_batches_tracked, save_mean, save_invstd);
     }
-    AT_DISPATCH(attn_w2_forward_kernel, n, K, x_q, x_k, idx, p1, W3C, b3C, save_mean, save_invstd, bn_weight, bn_bias, Wa, ba, w2);
+    AT_DISPATCH(attn_w2_forward, n, K, x_q, x_k, idx, p1, W3C, b3C, save_mean, save_invstd, bn_weight, bn_bias, Wa, ba, w2);
     return cbl_status();
 }
 
@@ -463,13 +761,13 @@ CBL_EXPORT int cbl_attn_w2_backward(int n, int K, int C, int G, const float* x_q
     const int nb = at_blocks(n, C);
     const int nv1 = 2 * C + G * C + G, nv2 = 4 * C;
     float* partial = reinterpret_cast<float*>(workspace);
-    float* sums = partial + (size_t)AT_MAX_BLOCKS * nv1;
-    AT_DISPATCH(attn_w2_bwd_reduce_kernel, n, K, x_q, x_k, idx, p1, W3C, b3C, save_mean, save_invstd, bn_weight, bn_bias, Wa, grad_w2, partial);
+    float* sums = partial + (size_t)(C > 64 ? at_wide_blocks(C) : AT_MAX_BLOCKS) * nv1;
+    AT_DISPATCH(attn_w2_bwd_reduce, n, K, x_q, x_k, idx, p1, W3C, b3C, save_mean, save_invstd, bn_weight, bn_bias, Wa, grad_w2, partial);
     // Q1's sums = [grad_beta | grad_gamma | grad_Wa | grad_ba]: written to the four outputs and kept in `sums` for Q2 (BatchNorm's two means)
     SumSegments s1; s1.dst[0] = grad_bn_bias; s1.dst[1] = grad_bn_weight; s1.dst[2] = grad_Wa; s1.dst[3] = grad_ba;
     s1.begin[0] = 0; s1.begin[1] = C; s1.begin[2] = 2 * C; s1.begin[3] = 2 * C + G * C; s1.begin[4] = nv1;
     hipLaunchKernelGGL(attn_sum_partials_kernel, dim3(cbl_div_up(nv1, 16)), dim3(256), 0, st, nv1, nb, partial, s1, sums);
-    AT_DISPATCH(attn_w2_bwd_apply_kernel, n, K, x_q, x_k, idx, p1, W3C, b3C, save_mean, save_invstd, bn_weight, bn_bias, Wa, grad_w2, sums,
+    AT_DISPATCH(attn_w2_bwd_apply, n, K, x_q, x_k, idx, p1, W3C, b3C, save_mean, save_invstd, bn_weight, bn_bias, Wa, grad_w2, sums,
                 grad_xq, grad_xk, grad_p1, partial);
     // partial rows are [dW3C (C x 3, row-major like the weight) | db3C]: summed straight into the two outputs
     SumSegments s2; s2.dst[0] = grad_W3C; s2.dst[1] = grad_b3C; s2.dst[2] = s2.dst[3] = nullptr;
@@ -486,8 +784,8 @@ CBL_EXPORT int cbl_attn_agg_forward(int n, int K, int C, int G, const float* x_v
     if (n == 0) return CBL_OK;
     if (!x_v || !idx || !p1 || !W3C || !b3C || !a || !out) return CBL_ERR_BAD_ARG;
     hipStream_t st = cbl_stream(stream);
-    const int nb = (int)cbl_grid_for((long long)n * C, AT_BLOCK, 4096);
-    AT_DISPATCH(attn_agg_forward_kernel, n, K, x_v, idx, p1, W3C, b3C, a, out);
+    const int nb = C > 64 ? (n < 1 ? 1 : (n > 2048 ? 2048 : n)) : (int)cbl_grid_for((long long)n * C, AT_BLOCK, 4096);   // no partial rows here: any grid
+    AT_DISPATCH(attn_agg_forward, n, K, x_v, idx, p1, W3C, b3C, a, out);
     return cbl_status();
 }
 
@@ -504,7 +802,7 @@ CBL_EXPORT int cbl_attn_agg_backward(int n, int K, int C, int G, const float* x_
     const int nb = at_blocks(n, C);
     const int nv2 = 4 * C;
     float* partial = reinterpret_cast<float*>(workspace);
-    AT_DISPATCH(attn_agg_backward_kernel, n, K, x_v, idx, p1, W3C, b3C, a, grad_out, grad_xv, grad_p1, grad_a, partial);
+    AT_DISPATCH(attn_agg_backward, n, K, x_v, idx, p1, W3C, b3C, a, grad_out, grad_xv, grad_p1, grad_a, partial);
     SumSegments s2; s2.dst[0] = grad_W3C; s2.dst[1] = grad_b3C; s2.dst[2] = s2.dst[3] = nullptr;
     s2.begin[0] = 0; s2.begin[1] = 3 * C; s2.begin[2] = s2.begin[3] = s2.begin[4] = nv2;
     hipLaunchKernelGGL(attn_sum_partials_kernel, dim3(cbl_div_up(nv2, 16)), dim3(256), 0, st, nv2, nb, partial, s2, (float*)nullptr);
