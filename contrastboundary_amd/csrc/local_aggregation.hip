@@ -162,6 +162,135 @@ __global__ __launch_bounds__(256) void kpconv_fwd_kernel(int n, int n0, int K, i
     }
 }
 
+// The same kernel for the shapes the networks use (C <= 64, C % 4 == 0, 16-byte rows, K <= 64), without a branch in the trip: the feature rows
+// are loaded unconditionally from a clamped row and masked afterwards (an exec-masked load per neighbour group made the compiler order every
+// group's load behind the previous group's wait), the kernel weights of the epilogue (the same for every point) are read once into registers.
+// sum over the four 16-lane rows of a wave, on the vector ALU (gfx950 v_permlane16_swap / v_permlane32_swap) instead of two ds_bpermute round trips
+__device__ __forceinline__ float rows_sum4(float x)
+{
+    const unsigned u = __float_as_uint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);            // {rows 0,0,2,2} , {rows 1,1,3,3}
+    const float y = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const unsigned w = __float_as_uint(y);
+    const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);            // {lower half twice} , {upper half twice}
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+template <bool CLOSEST, bool LINEAR, bool ONE>          // ONE: K <= 16, a single chunk of 16 neighbours: the first MFMAs start from a literal 0
+__global__ __launch_bounds__(256) void kpconv_fwd_c64_kernel(int n, int n0, int K, int C, int KP, const float* __restrict__ q,
+                                                             const float* __restrict__ s, const int* __restrict__ idx, const float* __restrict__ f,
+                                                             const float* __restrict__ kpts, const float* __restrict__ kw, float extent,
+                                                             const int* __restrict__ order, float* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int kp_id = lane & 15, kq = lane >> 4;
+    const unsigned wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwg = ((unsigned)n + 3u) >> 2;
+    const bool kp_ok = kp_id < KP;
+    const float kx = kp_ok ? kpts[3 * kp_id] : 0.f, ky = kp_ok ? kpts[3 * kp_id + 1] : 0.f, kz = kp_ok ? kpts[3 * kp_id + 2] : 0.f;
+    const float inv_extent = 1.0f / extent;
+    const int cb = 4 * kp_id;
+    const bool ch_ok = cb < C;
+    const int cbc = ch_ok ? cb : 0;
+    // epilogue operand: kernel_weights[kq * 4 + r][cb .. cb + 3], the same for every point.  Read again per point (an L1 hit) behind the MFMAs, into
+    // the registers the feature rows have just left: held across the trip they cost the sixth wave per SIMD.
+    // No masks anywhere behind the loads: accumulator rows kp >= KP and neighbours that are not real have weight 0 (A operand), channel columns
+    // >= C are never stored and never mix with others; the clamped loads only have to be readable.  (A non-finite value in row 0 of the table
+    // would reach points with shadow neighbours as 0 * inf.)
+    const float4* kw4[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) { const int row = kq * 4 + r; kw4[r] = reinterpret_cast<const float4*>(kw + (size_t)(row < KP ? row : 0) * C + cbc); }
+    const unsigned vend = 8 * cbl_xcd_per(nwg), vstep = gridDim.x;
+    auto point_at = [&](unsigned v) -> int {
+        if (v >= vend) return -1;
+        const unsigned t = (order ? cbl_xcd_slot(v, nwg) : v) * 4 + wv;
+        return t < (unsigned)n ? (order ? order[t] : (int)t) : -1;
+    };
+    // Three points in flight per wave: while point i is multiplied, the neighbour coordinates of point i+1 (its ids arrived during the previous
+    // trip) and the neighbour ids of point i+2 are on their way.
+    struct Xyz { float x, y, z, qx, qy, qz; };
+    auto load_ids = [&](int pt) -> int { return (pt >= 0 && lane < K) ? idx[(size_t)pt * K + lane] : n0; };
+    auto load_xyz = [&](int pt, int id) -> Xyz {                     // the shadow point sits at (1e6,1e6,1e6)  (:681-684)
+        Xyz g;
+        const bool real = id >= 0 && id < n0;
+        const float3 sp = *reinterpret_cast<const float3*>(s + 3 * (size_t)(real ? id : 0));       // one 12-byte load, clamped row, masked afterwards
+        g.x = real ? sp.x : 1e6f; g.y = real ? sp.y : 1e6f; g.z = real ? sp.z : 1e6f;
+        const float3 qp = *reinterpret_cast<const float3*>(q + 3 * (size_t)(pt >= 0 ? pt : 0));
+        g.qx = qp.x; g.qy = qp.y; g.qz = qp.z;
+        return g;
+    };
+    int p0 = point_at(blockIdx.x), p1 = point_at(blockIdx.x + vstep), p2 = point_at(blockIdx.x + 2 * vstep);
+    int id0 = load_ids(p0), id1 = load_ids(p1);
+    Xyz g0 = load_xyz(p0, id0);
+    for (unsigned v = blockIdx.x; v < vend; v += vstep) {
+        const int p3 = point_at(v + 3 * vstep);
+        const int p = p0;
+        if (p < 0) {                                                 // an empty slot (the XCD dealing leaves holes before the end): keep the pipeline moving
+            const int id2e = load_ids(p2); g0 = load_xyz(p1, id1);
+            p0 = p1; p1 = p2; p2 = p3; id0 = id1; id1 = id2e;
+            continue;
+        }
+        const float mrx = g0.x - g0.qx, mry = g0.y - g0.qy, mrz = g0.z - g0.qz;
+        const int id2 = load_ids(p2); const Xyz g1 = load_xyz(p1, id1);
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[t] = zero;
+        for (int kc = 0; kc < (ONE ? 16 : K); kc += 16) {
+            float4 bv[4]; float a[4]; bool real4[4];
+#pragma unroll
+            for (int gi = 0; gi < 4; gi++) {
+                const int src = kc + 4 * gi + kq;
+                const int id = __shfl(id0, src & 63);
+                const bool real = src < K && id >= 0 && id < n0;
+                const float4 v4 = *reinterpret_cast<const float4*>(f + (size_t)(real ? id : 0) * C + cbc);
+                bv[gi] = v4; real4[gi] = real;
+            }
+            // all four row loads leave before anything waits: left alone, the scheduler saves registers by issuing the third and fourth load
+            // behind the first MFMAs and waits for each at once — two more exposed round trips per point
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int gi = 0; gi < 4; gi++) {
+                const int src = kc + 4 * gi + kq;
+                const float rx = __shfl(mrx, src & 63), ry = __shfl(mry, src & 63), rz = __shfl(mrz, src & 63);
+                const float dx = rx - kx, dy = ry - ky, dz = rz - kz;
+                const float sq = (dx * dx + dy * dy) + dz * dz;                          // :688
+                float w = LINEAR ? fmaxf(1.0f - __builtin_amdgcn_sqrtf(sq) * inv_extent, 0.0f) : 1.0f;    // :697 / :693
+                if (CLOSEST) {
+                    float bs = kp_ok ? sq : INFINITY; int bi = kp_id;
+#pragma unroll
+                    for (int sft = 8; sft >= 1; sft >>= 1) {
+                        const float os = __shfl_xor(bs, sft, 16); const int oi = __shfl_xor(bi, sft, 16);
+                        if (os < bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
+                    }
+                    if (bi != kp_id) w = 0.f;
+                }
+                a[gi] = (kp_ok && real4[gi]) ? w : 0.f;                                 // shadow feature row = 0 (:713): its weight is
+            }
+#pragma unroll
+            for (int gi = 0; gi < 4; gi++) {
+                const bool first = ONE && gi == 0;
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gi], bv[gi].x, first ? zero : acc[0], 0, 0, 0);   // wf = w @ f_nbr (:716)
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gi], bv[gi].y, first ? zero : acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gi], bv[gi].z, first ? zero : acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gi], bv[gi].w, first ? zero : acc[3], 0, 0, 0);
+            }
+        }
+        float kwr[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const float4 k4 = *kw4[r]; kwr[r][0] = k4.x; kwr[r][1] = k4.y; kwr[r][2] = k4.z; kwr[r][3] = k4.w; }
+        float res[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            float part = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; r++) part += kwr[r][t] * acc[t][r];               // :723-727
+            res[t] = rows_sum4(part);
+        }
+        if (lane < 16 && ch_ok) *reinterpret_cast<float4*>(out + (size_t)p * C + cb) = make_float4(res[0], res[1], res[2], res[3]);
+        p0 = p1; p1 = p2; p2 = p3; id0 = id1; id1 = id2; g0 = g1;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- KPConv backward (VALU)
 // grad_features[nbr_k, c] += go[c] * sum_kp w[kp,k] * kw[kp,c]      grad_kw[kp,c] += go[c] * sum_k w[kp,k] * f[nbr_k, c]
 // one wave per point; lanes first build w (KP x K) in LDS, then lane = channel.
@@ -411,6 +540,18 @@ static int kpconv_forward_impl(int n, int n0, int K, int C, int KP, const float*
     // fixed 2048-workgroup grid 768 of them ran as a second, mostly idle round), each walking its share of the points
     static int resident[2] = {0, 0};
     const bool vec = C % 4 == 0 && cbl_host_aligned16(features) && cbl_host_aligned16(out);
+    static int resident64[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool c64 = vec && C <= 64 && K <= 64 && cbl_host_aligned16(kernel_weights);
+#define CBL_KPF(CL, LI, ON) do { const dim3 grid(cbl_round_up8(min(persistent_grid(n), resident_workgroups(&kpconv_fwd_c64_kernel<CL, LI, ON>, resident64[4 * CL + 2 * LI + ON])))); \
+        hipLaunchKernelGGL((kpconv_fwd_c64_kernel<CL, LI, ON>), grid, dim3(256), 0, st, n, n0, K, C, KP, query_points, support_points, neighbors_indices, features, \
+                           kernel_points, kernel_weights, extent, order, out); return cbl_status(); } while (0)
+#define CBL_KPF2(CL, LI) do { if (K <= 16) CBL_KPF(CL, LI, true); else CBL_KPF(CL, LI, false); } while (0)
+    if (c64) {
+        if (closest) { if (influence) CBL_KPF2(true, true); else CBL_KPF2(true, false); }
+        else         { if (influence) CBL_KPF2(false, true); else CBL_KPF2(false, false); }
+    }
+#undef CBL_KPF2
+#undef CBL_KPF
     const unsigned res = vec ? resident_workgroups(&kpconv_fwd_kernel<true>, resident[1]) : resident_workgroups(&kpconv_fwd_kernel<false>, resident[0]);
     const dim3 grid(cbl_round_up8(min(persistent_grid(n), res))), block(256);
     if (vec)
