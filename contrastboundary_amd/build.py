@@ -34,9 +34,10 @@ def headers():
     return hs
 
 
-# per-file flags.  -fno-slp-vectorize: the SLP vectoriser pairs scalar f32 multiply-adds into v_pk_fma_f32, which issues at half the rate of
-# two v_fma_f32 on gfx950 (MI355X_MICROARCH.md: "packed f32 VALU ... an anti-lever"); measured on the KPConv backward kernel (tools/exp/kb_probe.py)
-EXTRA_FLAGS = {}
+# per-file flags.  local_aggregation.hip: MFMA results in VGPRs (gfx950 has one unified file): the KPConv kernels read every accumulator once per
+# point in their epilogue, which through AGPRs is a v_accvgpr_read each (+ a v_accvgpr_write to zero it) on a kernel that is bound by its VALU issue slots
+# (tried and dropped here: -fno-slp-vectorize, which raised the register count of the KPConv backward)
+EXTRA_FLAGS = {"local_aggregation.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _compile(src, obj, verbose):

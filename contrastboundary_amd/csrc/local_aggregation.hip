@@ -182,32 +182,39 @@ __global__ __launch_bounds__(256) void kpconv_fwd_c64_kernel(int n, int n0, int 
                                                              const float* __restrict__ kpts, const float* __restrict__ kw, float extent,
                                                              const int* __restrict__ order, float* __restrict__ out)
 {
+    // epilogue operand kernel_weights (KP x C), the same for every point: once per workgroup into LDS (a ds_read is ~100 clocks behind the MFMAs, a
+    // global read of the same L1-resident rows ~500; held in registers across the trip they cost two waves per SIMD)
+    __shared__ float4 kw_s[16 * 16];
+    {
+        const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+        kw_s[threadIdx.x] = (row < KP && 4 * col < C) ? *reinterpret_cast<const float4*>(kw + (size_t)row * C + 4 * col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int kp_id = lane & 15, kq = lane >> 4;
     const unsigned wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwg = ((unsigned)n + 3u) >> 2;
     const bool kp_ok = kp_id < KP;
     const float kx = kp_ok ? kpts[3 * kp_id] : 0.f, ky = kp_ok ? kpts[3 * kp_id + 1] : 0.f, kz = kp_ok ? kpts[3 * kp_id + 2] : 0.f;
     const float inv_extent = 1.0f / extent;
+    const float m2kx = -2.f * kx, m2ky = -2.f * ky, m2kz = -2.f * kz, k2 = (kx * kx + ky * ky) + kz * kz;
     const int cb = 4 * kp_id;
     const bool ch_ok = cb < C;
-    const int cbc = ch_ok ? cb : 0;
-    // epilogue operand: kernel_weights[kq * 4 + r][cb .. cb + 3], the same for every point.  Read again per point (an L1 hit) behind the MFMAs, into
-    // the registers the feature rows have just left: held across the trip they cost the sixth wave per SIMD.
-    // No masks anywhere behind the loads: accumulator rows kp >= KP and neighbours that are not real have weight 0 (A operand), channel columns
-    // >= C are never stored and never mix with others; the clamped loads only have to be readable.  (A non-finite value in row 0 of the table
-    // would reach points with shadow neighbours as 0 * inf.)
-    const float4* kw4[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) { const int row = kq * 4 + r; kw4[r] = reinterpret_cast<const float4*>(kw + (size_t)(row < KP ? row : 0) * C + cbc); }
+    const char* fbytes = reinterpret_cast<const char*>(f);
+    const unsigned row_bytes = 4u * (unsigned)C, col_bytes = 4u * (unsigned)(ch_ok ? cb : 0);
+    // No masks behind the loads: accumulator rows kp >= KP and neighbours that are not real have weight 0 (A operand), channel columns >= C are never
+    // stored and never mix with others; the clamped loads only have to be readable.  (A non-finite value in row 0 of the table would reach points with
+    // shadow neighbours as 0 * inf.)
     const unsigned vend = 8 * cbl_xcd_per(nwg), vstep = gridDim.x;
     auto point_at = [&](unsigned v) -> int {
         if (v >= vend) return -1;
         const unsigned t = (order ? cbl_xcd_slot(v, nwg) : v) * 4 + wv;
         return t < (unsigned)n ? (order ? order[t] : (int)t) : -1;
     };
-    // Three points in flight per wave: while point i is multiplied, the neighbour coordinates of point i+1 (its ids arrived during the previous
-    // trip) and the neighbour ids of point i+2 are on their way.
+    // Three points in flight per wave, every load one trip ahead of its use: while point i is multiplied, the feature rows and the neighbour
+    // coordinates of point i+1 (its ids arrived during the previous trip) and the neighbour ids of point i+2 are on their way.  The kernel is bound by
+    // these round trips, not by its instruction stream (PMC: halving the vector instructions moved it by 3 %).
     struct Xyz { float x, y, z, qx, qy, qz; };
+    struct Rows { float4 v[4]; bool real[4]; };
     auto load_ids = [&](int pt) -> int { return (pt >= 0 && lane < K) ? idx[(size_t)pt * K + lane] : n0; };
     auto load_xyz = [&](int pt, int id) -> Xyz {                     // the shadow point sits at (1e6,1e6,1e6)  (:681-684)
         Xyz g;
@@ -218,76 +225,101 @@ __global__ __launch_bounds__(256) void kpconv_fwd_c64_kernel(int n, int n0, int 
         g.qx = qp.x; g.qy = qp.y; g.qz = qp.z;
         return g;
     };
+    auto load_rows = [&](int ids, int kc) -> Rows {                  // 16 neighbours' rows: lane (kq, j) takes channels 4j.. of neighbours kc + 4 gi + kq
+        Rows r;
+#pragma unroll
+        for (int gi = 0; gi < 4; gi++) {
+            const int id = __shfl(ids, (kc + 4 * gi + kq) & 63);     // lanes >= K hold the shadow id
+            r.real[gi] = id >= 0 && id < n0;
+            r.v[gi] = *reinterpret_cast<const float4*>(fbytes + ((unsigned)(r.real[gi] ? id : 0) * row_bytes + col_bytes));   // 32-bit offsets: n0 * C * 4 < 2^32 (host)
+        }
+        return r;
+    };
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    auto chunk = [&](const Rows& rows, int kc, float mrx, float mry, float mrz, float mr2, f32x4 (&acc)[4], bool first) {
+        float a[4];
+#pragma unroll
+        for (int gi = 0; gi < 4; gi++) {
+            const int src = (kc + 4 * gi + kq) & 63;
+            const float rx = __shfl(mrx, src), ry = __shfl(mry, src), rz = __shfl(mrz, src);
+            float sq;
+            if (CLOSEST) {                                           // the argmin compares sq exactly: the reference's association (:688)
+                const float dx = rx - kx, dy = ry - ky, dz = rz - kz;
+                sq = (dx * dx + dy * dy) + dz * dz;
+            } else {
+                // |r - k|^2 = |r|^2 + |k|^2 - 2 r.k as one add + three fma; r and k are offsets within one neighbourhood (a few extents), so the
+                // cancellation costs ~1e-6 relative to extent^2: the contract is 1e-4
+                const float r2 = __shfl(mr2, src);
+                sq = fmaxf(__builtin_fmaf(m2kx, rx, __builtin_fmaf(m2ky, ry, __builtin_fmaf(m2kz, rz, r2 + k2))), 0.f);
+            }
+            float w = LINEAR ? fmaxf(1.0f - __builtin_amdgcn_sqrtf(sq) * inv_extent, 0.0f) : 1.0f;    // :697 / :693
+            if (CLOSEST) {                                           // argmin over kernel points, first minimum
+                float bs = kp_ok ? sq : INFINITY; int bi = kp_id;
+#pragma unroll
+                for (int sft = 8; sft >= 1; sft >>= 1) {
+                    const float os = __shfl_xor(bs, sft, 16); const int oi = __shfl_xor(bi, sft, 16);
+                    if (os < bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
+                }
+                if (bi != kp_id) w = 0.f;
+            }
+            a[gi] = (kp_ok && rows.real[gi]) ? w : 0.f;              // shadow feature row = 0 (:713): its weight is
+        }
+#pragma unroll
+        for (int gi = 0; gi < 4; gi++) {
+            const bool z = first && gi == 0;
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gi], rows.v[gi].x, z ? zero : acc[0], 0, 0, 0);   // wf = w @ f_nbr (:716)
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gi], rows.v[gi].y, z ? zero : acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gi], rows.v[gi].z, z ? zero : acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gi], rows.v[gi].w, z ? zero : acc[3], 0, 0, 0);
+        }
+    };
     int p0 = point_at(blockIdx.x), p1 = point_at(blockIdx.x + vstep), p2 = point_at(blockIdx.x + 2 * vstep);
     int id0 = load_ids(p0), id1 = load_ids(p1);
     Xyz g0 = load_xyz(p0, id0);
+    Rows r0 = load_rows(id0, 0);
     for (unsigned v = blockIdx.x; v < vend; v += vstep) {
         const int p3 = point_at(v + 3 * vstep);
         const int p = p0;
-        if (p < 0) {                                                 // an empty slot (the XCD dealing leaves holes before the end): keep the pipeline moving
-            const int id2e = load_ids(p2); g0 = load_xyz(p1, id1);
-            p0 = p1; p1 = p2; p2 = p3; id0 = id1; id1 = id2e;
-            continue;
-        }
-        const float mrx = g0.x - g0.qx, mry = g0.y - g0.qy, mrz = g0.z - g0.qz;
-        const int id2 = load_ids(p2); const Xyz g1 = load_xyz(p1, id1);
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        f32x4 acc[4];
+        // next point's rows and coordinates, the ids of the one after: all requested before anything of this point is waited for
+        const int id2 = load_ids(p2); const Xyz g1 = load_xyz(p1, id1); const Rows r1 = load_rows(id1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (p >= 0) {                                                // (an empty slot: the XCD dealing leaves holes before the end)
+            const float mrx = g0.x - g0.qx, mry = g0.y - g0.qy, mrz = g0.z - g0.qz;
+            const float mr2 = (mrx * mrx + mry * mry) + mrz * mrz;
+            f32x4 acc[4];
 #pragma unroll
-        for (int t = 0; t < 4; t++) acc[t] = zero;
-        for (int kc = 0; kc < (ONE ? 16 : K); kc += 16) {
-            float4 bv[4]; float a[4]; bool real4[4];
-#pragma unroll
-            for (int gi = 0; gi < 4; gi++) {
-                const int src = kc + 4 * gi + kq;
-                const int id = __shfl(id0, src & 63);
-                const bool real = src < K && id >= 0 && id < n0;
-                const float4 v4 = *reinterpret_cast<const float4*>(f + (size_t)(real ? id : 0) * C + cbc);
-                bv[gi] = v4; real4[gi] = real;
-            }
-            // all four row loads leave before anything waits: left alone, the scheduler saves registers by issuing the third and fourth load
-            // behind the first MFMAs and waits for each at once — two more exposed round trips per point
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int gi = 0; gi < 4; gi++) {
-                const int src = kc + 4 * gi + kq;
-                const float rx = __shfl(mrx, src & 63), ry = __shfl(mry, src & 63), rz = __shfl(mrz, src & 63);
-                const float dx = rx - kx, dy = ry - ky, dz = rz - kz;
-                const float sq = (dx * dx + dy * dy) + dz * dz;                          // :688
-                float w = LINEAR ? fmaxf(1.0f - __builtin_amdgcn_sqrtf(sq) * inv_extent, 0.0f) : 1.0f;    // :697 / :693
-                if (CLOSEST) {
-                    float bs = kp_ok ? sq : INFINITY; int bi = kp_id;
-#pragma unroll
-                    for (int sft = 8; sft >= 1; sft >>= 1) {
-                        const float os = __shfl_xor(bs, sft, 16); const int oi = __shfl_xor(bi, sft, 16);
-                        if (os < bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
+            for (int t = 0; t < 4; t++) acc[t] = zero;
+            chunk(r0, 0, mrx, mry, mrz, mr2, acc, true);
+            if (!ONE) {
+                for (int k0 = 0; k0 < K; k0 += 64) {                  // K > 16: the remaining chunks, loaded where they are used
+                    int ids = id0; float cx = mrx, cy = mry, cz = mrz, c2 = mr2;
+                    if (k0 > 0) {
+                        ids = (k0 + lane < K) ? idx[(size_t)p * K + k0 + lane] : n0;
+                        const bool real = ids >= 0 && ids < n0;
+                        const float3 sp = *reinterpret_cast<const float3*>(s + 3 * (size_t)(real ? ids : 0));
+                        cx = (real ? sp.x : 1e6f) - g0.qx; cy = (real ? sp.y : 1e6f) - g0.qy; cz = (real ? sp.z : 1e6f) - g0.qz;
+                        c2 = (cx * cx + cy * cy) + cz * cz;
                     }
-                    if (bi != kp_id) w = 0.f;
+                    for (int kc = (k0 == 0 ? 16 : 0); kc < min(64, K - k0); kc += 16) {
+                        const Rows rr = load_rows(ids, kc);
+                        chunk(rr, kc, cx, cy, cz, c2, acc, false);
+                    }
                 }
-                a[gi] = (kp_ok && real4[gi]) ? w : 0.f;                                 // shadow feature row = 0 (:713): its weight is
+            }
+            float res[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) res[t] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {                            // out[c] = sum_kp kernel_weights[kp,c] * wf[kp,c]  (:723-727); tile t, column j <-> channel cb + t
+                const float4 k4 = kw_s[(kq * 4 + r) * 16 + kp_id];
+                res[0] = __builtin_fmaf(k4.x, acc[0][r], res[0]); res[1] = __builtin_fmaf(k4.y, acc[1][r], res[1]);
+                res[2] = __builtin_fmaf(k4.z, acc[2][r], res[2]); res[3] = __builtin_fmaf(k4.w, acc[3][r], res[3]);
             }
 #pragma unroll
-            for (int gi = 0; gi < 4; gi++) {
-                const bool first = ONE && gi == 0;
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gi], bv[gi].x, first ? zero : acc[0], 0, 0, 0);   // wf = w @ f_nbr (:716)
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gi], bv[gi].y, first ? zero : acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gi], bv[gi].z, first ? zero : acc[2], 0, 0, 0);
-                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gi], bv[gi].w, first ? zero : acc[3], 0, 0, 0);
-            }
+            for (int t = 0; t < 4; t++) res[t] = rows_sum4(res[t]);
+            if (lane < 16 && ch_ok) *reinterpret_cast<float4*>(out + (size_t)p * C + cb) = make_float4(res[0], res[1], res[2], res[3]);
         }
-        float kwr[4][4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) { const float4 k4 = *kw4[r]; kwr[r][0] = k4.x; kwr[r][1] = k4.y; kwr[r][2] = k4.z; kwr[r][3] = k4.w; }
-        float res[4];
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            float part = 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; r++) part += kwr[r][t] * acc[t][r];               // :723-727
-            res[t] = rows_sum4(part);
-        }
-        if (lane < 16 && ch_ok) *reinterpret_cast<float4*>(out + (size_t)p * C + cb) = make_float4(res[0], res[1], res[2], res[3]);
-        p0 = p1; p1 = p2; p2 = p3; id0 = id1; id1 = id2; g0 = g1;
+        p0 = p1; p1 = p2; p2 = p3; id0 = id1; id1 = id2; g0 = g1; r0 = r1;
     }
 }
 
@@ -541,7 +573,7 @@ static int kpconv_forward_impl(int n, int n0, int K, int C, int KP, const float*
     static int resident[2] = {0, 0};
     const bool vec = C % 4 == 0 && cbl_host_aligned16(features) && cbl_host_aligned16(out);
     static int resident64[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool c64 = vec && C <= 64 && K <= 64 && cbl_host_aligned16(kernel_weights);
+    const bool c64 = vec && C <= 64 && cbl_host_aligned16(kernel_weights) && (unsigned long long)n0 * C * 4ull < (1ull << 32);
 #define CBL_KPF(CL, LI, ON) do { const dim3 grid(cbl_round_up8(min(persistent_grid(n), resident_workgroups(&kpconv_fwd_c64_kernel<CL, LI, ON>, resident64[4 * CL + 2 * LI + ON])))); \
         hipLaunchKernelGGL((kpconv_fwd_c64_kernel<CL, LI, ON>), grid, dim3(256), 0, st, n, n0, K, C, KP, query_points, support_points, neighbors_indices, features, \
                            kernel_points, kernel_weights, extent, order, out); return cbl_status(); } while (0)
