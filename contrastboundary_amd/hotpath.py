@@ -181,6 +181,7 @@ class Schedule:
         self.overlap = overlap
         self.side = torch.cuda.Stream() if overlap else None
         self.aux = []                                               # streams of the transposed-table builds (made on first use)
+        self.rest = None                                            # run_group: the stream of everything behind the search on the main branch
         self.joined = torch.cuda.Event() if overlap else None
 
     def run(self, state, events=None, side_after=None):
@@ -264,6 +265,56 @@ class Schedule:
                     if torch.is_tensor(t):
                         t.record_stream(main)                       # allocated on another stream, owned by the caller from here on
         return state
+
+    def run_group(self, states):
+        """len(states) consecutive steps issued as ONE dependency graph, software-pipelined: the step's own stream carries nothing but the
+        searches (grid build, wide search, tie replay: a chain of mostly small latency-bound launches, a third of an in-order step during
+        which most of the GPU idles), one after the other; everything a search feeds runs on branch streams behind that search's event
+            rest : gather -> KPConv -> [K=16 table] -> grouping backward -> KPConv backward
+            side : CBL mining + loss -> [K=36 table] -> CBL backward
+            aux  : one stream per transposed table
+        so the search of step i+1 runs beside the gather / KPConv / backward kernels of step i.  Steps are independent scenes (here: the same
+        resident scene, every step with its own outputs in states[i]); every step still runs inside its own neighbour cache, dropped when the
+        step has been issued.  Every branch stream forks from the step's own stream (a fork of a fork crashes hipGraph capture on ROCm 7.2);
+        what a branch reads from another stream's allocations stays referenced from the step's state until the group is done."""
+        assert self.hints and self.overlap
+        main = torch.cuda.current_stream()
+        names = [st[0] for st in self.stage_list]
+        is_tr = lambda nm: "neighbor_transpose" in nm
+        search_idx = [i for i, nm in enumerate(names) if "knnquery" in nm]                 # the block's search, then the CBL head's request (cache hit)
+        tr_idx = [i for i, nm in enumerate(names) if is_tr(nm)]
+        side_idx = [i for i, nm in enumerate(names) if nm.startswith("cbl_") and i not in search_idx and i not in tr_idx]
+        rest_idx = [i for i in range(len(names)) if i not in search_idx and i not in tr_idx and i not in side_idx]
+        if getattr(self, "rest", None) is None:
+            self.rest = torch.cuda.Stream()
+        while len(self.aux) < len(tr_idx):
+            self.aux.append(torch.cuda.Stream())
+        branches = [self.rest, self.side] + self.aux[:len(tr_idx)]
+        for b in branches:
+            b.wait_stream(main)                                     # fork: everything queued before the group is complete for every branch
+        for state in states:
+            with pointops.neighbor_cache() as nc:
+                nc.record_events = False                            # the branches wait for the whole search stage (its event below)
+                for xyz, nsample, algo in self.hints:
+                    nc.hint(xyz, nsample, algo)
+                for i in search_idx:
+                    self.stage_list[i][1](state)
+                state["_order"] = pointops.spatial_order(state["idx"])          # kept alive for the branches (allocated on this stream)
+                found = torch.cuda.Event()
+                found.record(main)
+                for n, i in enumerate(tr_idx):
+                    self.aux[n].wait_event(found)
+                    with torch.cuda.stream(self.aux[n]):
+                        self.stage_list[i][1](state)
+                for stream, idxs in ((self.side, side_idx), (self.rest, rest_idx)):
+                    stream.wait_event(found)
+                    with torch.cuda.stream(stream):
+                        for i in idxs:
+                            self._join_table(names[i], state)       # the consumer's stream waits for the stream that builds its table
+                            self.stage_list[i][1](state)
+        for b in branches:
+            main.wait_stream(b)                                     # join
+        return states
 
     def _run(self, state, events, side_after, side_names):
         main = torch.cuda.current_stream()
