@@ -49,9 +49,8 @@ def parse(argv=None):
     ap.add_argument("--forward-only", action="store_true", help="headline = forward block + CBL head only (round 1's step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="all stages in order on one stream")
-    ap.add_argument("--group", type=int, default=0,
-                    help="steps issued as one software-pipelined dependency graph (search of step i+1 beside the rest of step i); 0 = the largest of "
-                         "10, 5, 4, 2, 1 that divides --steps; 1 = every step on its own")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="every step on its own (one hipGraph per step) instead of consecutive steps software-pipelined: the search of step i+1 beside the rest of step i")
     ap.add_argument("--no-graph", action="store_true", help="issue every step eagerly from Python instead of replaying its hipGraph")
     ap.add_argument("--no-nested", action="store_true", help="every neighbour search on its own (no derivation of K=16 from the K=36 search of the same points)")
     ap.add_argument("--no-allreduce", action="store_true", help="skip the gradient all-reduce leg of a multi-rank run")
@@ -84,16 +83,14 @@ def spawn(args, argv):
 
 
 def timed_region(step, steps, warmup, sync, D):
-    """W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides; -> max over ranks of the wall time.
-    A call of `step` is `step.group` steps (1 unless the steps are issued as pipelined groups; K is a multiple of the group then)."""
-    per_call = getattr(step, "group", 1)
-    assert steps % per_call == 0
-    for _ in range(-(-warmup // per_call)):
+    """W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides; -> max over ranks of the wall time
+    (sync = torch.cuda.synchronize: the whole device, whatever streams the steps run on)"""
+    for _ in range(warmup):
         step()
     sync()
     D.barrier()
     t0 = time.perf_counter()
-    for _ in range(steps // per_call):
+    for _ in range(steps):
         step()
     sync()
     D.barrier()
@@ -151,58 +148,67 @@ def host_dry_run(args, D, world, rank):
 
 # ------------------------------------------------------------------------------------------------ the step
 class Step:
-    """the hot path over one resident scene as bench.py runs it: schedule + its hipGraph.
-    group > 1: one call = `group` consecutive steps issued as one software-pipelined dependency graph (hotpath.Schedule.run_group: the search
-    of step i+1 beside the gather / KPConv / backward kernels of step i); every step has its own outputs (self.states[i])."""
+    """the hot path over one resident scene as bench.py runs it: schedule + its hipGraph(s).
+    pipeline: consecutive steps software-pipelined over three streams, one linear hipGraph per chain (hotpath.Pipeline: the search of step i+1
+    beside the gather / KPConv / backward kernels of step i); steps alternate between two output slots (self.states)."""
 
-    def __init__(self, scene, k, backward, args, overlap=True, group=1):
+    def __init__(self, scene, k, backward, args, overlap=True, pipeline=False):
         from contrastboundary_amd import hotpath
         self.stages = hotpath.stages(scene, k, backward)
         self.names = [st[0] for st in self.stages]
         self.hints = () if args.no_nested else hotpath.search_hints(scene)
         self.sched = hotpath.Schedule(self.stages, overlap=overlap, hints=self.hints)
-        self.group = group if (group > 1 and overlap and self.hints) else 1
-        self.states = [{} for _ in range(self.group)]
+        self.pipeline = bool(pipeline and overlap and self.hints)
+        self.pipe = None
+        self.states = [{}]
         self.graph, self.note = None, "eager"
 
     @property
     def state(self):
         return self.states[-1]
 
-    def _issue(self, states, events=None):
-        if self.group > 1:
-            self.sched.run_group(states)
-        else:
-            self.sched.run(states[0], events)
-
     def eager(self, events=None):
-        self._issue(self.states, events)
+        self.sched.run(self.states[0], events)
 
     def capture(self):
         """the step issues 30-40 launches from Python, as many us of host time as the device needs: captured once (same kernels, same
         buffers, same schedule) it is replayed with ~15 us of host time.  Raises if the capture fails (bench.py then stays eager)."""
+        if self.pipeline:
+            from contrastboundary_amd import hotpath
+            pipe = hotpath.Pipeline(self.sched)
+            pipe.capture()
+            self.pipe, self.states = pipe, pipe.states
+            self.note = ("hipGraph replay (torch.cuda.CUDAGraph over the C-ABI launches), one linear graph per segment (search | tables | gather, KPConv | their "
+                         "backward | CBL forward | CBL backward) on four streams, consecutive steps software-pipelined over two output slots")
+            return
         cap = torch.cuda.Stream()
         cap.wait_stream(torch.cuda.current_stream())
-        gstates = [{} for _ in range(self.group)]
+        gstate = {}
         with torch.cuda.stream(cap):
             for _ in range(3):
-                self._issue(gstates)
+                self.sched.run(gstate, None)
         torch.cuda.current_stream().wait_stream(cap)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode="thread_local"):     # other threads (the RCCL watchdog of a multi-rank run) may call HIP
-            self._issue(gstates)
+            self.sched.run(gstate, None)
         g.replay()
         torch.cuda.synchronize()
-        self.graph, self.states = g, gstates
-        self.note = "hipGraph replay (torch.cuda.CUDAGraph over the C-ABI launches)" + (
-            "; %d steps per graph, software-pipelined" % self.group if self.group > 1 else "")
+        self.graph, self.states = g, [gstate]
+        self.note = "hipGraph replay (torch.cuda.CUDAGraph over the C-ABI launches)"
 
     def __call__(self):
-        if self.graph is not None:
+        if self.pipe is not None:
+            self.pipe.step()
+        elif self.graph is not None:
             self.graph.replay()
         else:
-            self._issue(self.states)
+            self.sched.run(self.states[0], None)
+
+    def join(self):
+        """the current stream waits for every step issued so far (the pipeline runs on streams of its own)"""
+        if self.pipe is not None:
+            self.pipe.join()
 
 
 def settle(step, seconds=0.5):
@@ -213,8 +219,8 @@ def settle(step, seconds=0.5):
         torch.cuda.synchronize()
 
 
-def make_step(scene, k, backward, args, overlap, group=1):
-    st = Step(scene, k, backward, args, overlap=overlap, group=group)
+def make_step(scene, k, backward, args, overlap, pipeline=False):
+    st = Step(scene, k, backward, args, overlap=overlap, pipeline=pipeline and not args.no_graph)
     settle(st)
     if not args.no_graph:
         try:
@@ -309,10 +315,8 @@ def run_gpu(args, D, world, rank, local):
     n, c, k = args.points, args.channels, args.k
     backward = not args.forward_only
     scene = hotpath.Scene.synthetic(n, c, seed=rank, b=1)            # every rank its own scene (weak scaling)
-    group = args.group if args.group > 0 else next(g for g in (10, 5, 4, 2, 1) if args.steps % g == 0)
-    if args.steps % group or args.no_overlap or args.no_nested:
-        group = 1
-    step = make_step(scene, k, backward, args, overlap=not args.no_overlap, group=group)
+    pipeline = not (args.no_pipeline or args.no_overlap or args.no_nested or args.no_graph)
+    step = make_step(scene, k, backward, args, overlap=not args.no_overlap, pipeline=pipeline)
     sync = torch.cuda.synchronize
 
     elapsed = timed_region(step, args.steps, args.warmup, sync, D)
@@ -329,10 +333,10 @@ def run_gpu(args, D, world, rank, local):
                                 "rows replayed; the later request is a cache hit, the cache is dropped at the end of every step); " % (k, hotpath.CBL_NSAMPLE)
                                 if step.hints else "every search on its own; ") +
                                ("all stages in order on one stream" if args.no_overlap else "the CBL branch on a side stream beside the main branch") +
-                               ("; %d consecutive steps issued as one dependency graph: the step's own stream carries the searches one after the other, "
-                                "everything behind a search runs on branch streams, so the search of step i+1 (grid build, wide search, tie replay: mostly "
-                                "small latency-bound launches) runs beside the gather / KPConv / backward kernels of step i; every step has its own outputs"
-                                % step.group if step.group > 1 else "")},
+                               ("; consecutive steps software-pipelined: one stream carries the searches one after the other, everything behind a search runs "
+                                "on three branch streams, so the search of step i+1 (grid build, wide search, tie replay: mostly small latency-bound launches) "
+                                "runs beside the gather / KPConv / backward kernels of step i; steps alternate between two output slots"
+                                if step.pipe is not None else "")},
     }
     if args.no_extra:
         if rank == 0:
@@ -399,7 +403,7 @@ def run_gpu(args, D, world, rank, local):
 
     # ---- the forward block alone (round 1's step), timed the same way
     if backward:
-        fstep = make_step(scene, k, False, args, overlap=not args.no_overlap, group=group)
+        fstep = make_step(scene, k, False, args, overlap=not args.no_overlap, pipeline=pipeline)
         e_f = timed_region(fstep, args.steps, args.warmup, sync, D)
         out["forward_only"] = {"value": n * args.steps * world / e_f, "ms_per_step": e_f / args.steps * 1e3, "stages": " -> ".join(fstep.names), "issue": fstep.note}
 
@@ -407,11 +411,8 @@ def run_gpu(args, D, world, rank, local):
     if (world > 1 or args.allreduce_single) and not args.no_allreduce:
         ar = GradAllReduce(args.allreduce_floats, "cuda")
 
-        def step_ar():                                               # one all-reduce per step: `group` of them beside a group of steps
-            for _ in range(step.group):
-                ar.start()
-            step(); ar.finish()
-        step_ar.group = step.group
+        def step_ar():
+            ar.start(); step(); step.join(); ar.finish()
         e_ar = timed_region(step_ar, args.steps, args.warmup, sync, D)
 
         def only_ar():

@@ -181,7 +181,6 @@ class Schedule:
         self.overlap = overlap
         self.side = torch.cuda.Stream() if overlap else None
         self.aux = []                                               # streams of the transposed-table builds (made on first use)
-        self.rest = None                                            # run_group: the stream of everything behind the search on the main branch
         self.joined = torch.cuda.Event() if overlap else None
 
     def run(self, state, events=None, side_after=None):
@@ -266,56 +265,6 @@ class Schedule:
                         t.record_stream(main)                       # allocated on another stream, owned by the caller from here on
         return state
 
-    def run_group(self, states):
-        """len(states) consecutive steps issued as ONE dependency graph, software-pipelined: the step's own stream carries nothing but the
-        searches (grid build, wide search, tie replay: a chain of mostly small latency-bound launches, a third of an in-order step during
-        which most of the GPU idles), one after the other; everything a search feeds runs on branch streams behind that search's event
-            rest : gather -> KPConv -> [K=16 table] -> grouping backward -> KPConv backward
-            side : CBL mining + loss -> [K=36 table] -> CBL backward
-            aux  : one stream per transposed table
-        so the search of step i+1 runs beside the gather / KPConv / backward kernels of step i.  Steps are independent scenes (here: the same
-        resident scene, every step with its own outputs in states[i]); every step still runs inside its own neighbour cache, dropped when the
-        step has been issued.  Every branch stream forks from the step's own stream (a fork of a fork crashes hipGraph capture on ROCm 7.2);
-        what a branch reads from another stream's allocations stays referenced from the step's state until the group is done."""
-        assert self.hints and self.overlap
-        main = torch.cuda.current_stream()
-        names = [st[0] for st in self.stage_list]
-        is_tr = lambda nm: "neighbor_transpose" in nm
-        search_idx = [i for i, nm in enumerate(names) if "knnquery" in nm]                 # the block's search, then the CBL head's request (cache hit)
-        tr_idx = [i for i, nm in enumerate(names) if is_tr(nm)]
-        side_idx = [i for i, nm in enumerate(names) if nm.startswith("cbl_") and i not in search_idx and i not in tr_idx]
-        rest_idx = [i for i in range(len(names)) if i not in search_idx and i not in tr_idx and i not in side_idx]
-        if getattr(self, "rest", None) is None:
-            self.rest = torch.cuda.Stream()
-        while len(self.aux) < len(tr_idx):
-            self.aux.append(torch.cuda.Stream())
-        branches = [self.rest, self.side] + self.aux[:len(tr_idx)]
-        for b in branches:
-            b.wait_stream(main)                                     # fork: everything queued before the group is complete for every branch
-        for state in states:
-            with pointops.neighbor_cache() as nc:
-                nc.record_events = False                            # the branches wait for the whole search stage (its event below)
-                for xyz, nsample, algo in self.hints:
-                    nc.hint(xyz, nsample, algo)
-                for i in search_idx:
-                    self.stage_list[i][1](state)
-                state["_order"] = pointops.spatial_order(state["idx"])          # kept alive for the branches (allocated on this stream)
-                found = torch.cuda.Event()
-                found.record(main)
-                for n, i in enumerate(tr_idx):
-                    self.aux[n].wait_event(found)
-                    with torch.cuda.stream(self.aux[n]):
-                        self.stage_list[i][1](state)
-                for stream, idxs in ((self.side, side_idx), (self.rest, rest_idx)):
-                    stream.wait_event(found)
-                    with torch.cuda.stream(stream):
-                        for i in idxs:
-                            self._join_table(names[i], state)       # the consumer's stream waits for the stream that builds its table
-                            self.stage_list[i][1](state)
-        for b in branches:
-            main.wait_stream(b)                                     # join
-        return states
-
     def _run(self, state, events, side_after, side_names):
         main = torch.cuda.current_stream()
         names = [st[0] for st in self.stage_list]
@@ -350,3 +299,153 @@ class Schedule:
         if not waited:
             main.wait_event(self.joined)
         return state
+
+
+def concurrent_streams(count, candidates=12, spin_cycles=2_000_000):
+    """`count` HIP streams that really run side by side.  The runtime multiplexes streams onto a few hardware queues (4 per process by default) in
+    creation order, so two fresh streams can share a queue and then execute strictly one after the other — measured: the search chain and the
+    branch it was supposed to overlap landed on one queue and the pipeline ran in order.  The mapping cannot be queried, so it is observed: a
+    one-thread spin kernel on two streams takes T if they have queues of their own and 2T if they share one."""
+    def together(a, b):
+        torch.cuda.synchronize()
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        cur = torch.cuda.current_stream()
+        t0.record(cur)
+        for s in (a, b):
+            s.wait_event(t0)
+            with torch.cuda.stream(s):
+                torch.cuda._sleep(spin_cycles)
+        for s in (a, b):
+            cur.wait_stream(s)
+        t1.record(cur)
+        torch.cuda.synchronize()
+        return t0.elapsed_time(t1)
+    pool = [torch.cuda.Stream() for _ in range(candidates)]
+    with torch.cuda.stream(pool[0]):
+        torch.cuda._sleep(spin_cycles)
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(pool[0]):
+        t0.record(); torch.cuda._sleep(spin_cycles); t1.record()
+    torch.cuda.synchronize()
+    alone = t0.elapsed_time(t1)
+    chosen = [pool[0]]
+    for s in pool[1:]:
+        if len(chosen) == count:
+            break
+        if all(together(c, s) < 1.5 * alone for c in chosen):
+            chosen.append(s)
+    if len(chosen) < count:                                         # fewer independent queues than asked for: the rest share
+        chosen += [p for p in pool if p not in chosen][:count - len(chosen)]
+    return chosen
+
+
+class Pipeline:
+    """Consecutive steps software-pipelined over four HIP streams, every segment of a step replayed from a linear hipGraph of its own:
+
+        search : nothing but the searches, one step after the other (grid build, wide search, tie replay: a chain of mostly small
+                 latency-bound launches, a third of an in-order step, during which most of the GPU idles)          -> event `found`
+        tables : K=16 table (-> `t16`), K=36 table (-> `t36`): latency-bound chains of small kernels               behind `found`
+        rest   : gather -> KPConv | (after `t16`) grouping backward -> KPConv backward                             behind `found`
+        side   : CBL mining + loss | (after `t36`) CBL backward                                                    behind `found`
+
+    so the search of step i+1 runs beside the gather / KPConv / backward kernels of step i, and no chain is longer than ~150 us of kernels.
+    Steps are independent scenes (in bench.py: the same resident scene); a step writes into one of two slots (its neighbour tables, orders,
+    outputs: self.states[slot]) and the search of step i+2 waits for every other stream's part of step i before it overwrites their slot.  A step
+    runs inside its own neighbour cache, which only exists while the step is captured.
+
+    Why linear graphs on real streams and not one graph with branches: a replayed hipGraph is spread over at most four hardware queues by the
+    runtime (ROCm 7.2; DEBUG_HIP_FORCE_GRAPH_QUEUES above 4 aborts), and which branch lands on which queue is the runtime's choice — measured on a
+    10-step graph, every second step's search was put on the queue of the previous step's backward kernels, which serialised exactly what this
+    schedule overlaps (step period alternating 190 / 490 us).  A linear graph stays on the queue of the stream it is launched on, and the streams
+    are chosen so that they have queues of their own (concurrent_streams).  Graphs do not share a memory pool: they run concurrently."""
+
+    SLOTS = 2
+    STREAMS = ("search", "tables", "rest", "side")
+
+    def __init__(self, sched):
+        assert sched.hints, "the pipeline is built on the one-search-per-geometry schedule"
+        self.sched = sched
+        names = [st[0] for st in sched.stage_list]
+        ix = lambda pred: [i for i, nm in enumerate(names) if pred(nm)]
+        search = ix(lambda nm: "knnquery" in nm)                    # the block's search, then the CBL head's request (cache hit)
+        t16 = ix(lambda nm: "neighbor_transpose" in nm and not nm.startswith("cbl_"))
+        t36 = ix(lambda nm: "neighbor_transpose" in nm and nm.startswith("cbl_"))
+        cbl = [i for i in ix(lambda nm: nm.startswith("cbl_")) if i not in search and i not in t36]
+        block = [i for i in range(len(names)) if i not in search + t16 + t36 + cbl]
+        bwd = lambda i: names[i].endswith("_bwd")
+        # (name, stream, stages, events waited for, event recorded behind it) in issue order
+        segs = [("search", "search", search, (), "found"),
+                ("t16", "tables", t16, ("found",), "t16"),
+                ("fwd", "rest", [i for i in block if not bwd(i)], ("found",), None),
+                ("cblfwd", "side", [i for i in cbl if not bwd(i)], ("found",), None),
+                ("t36", "tables", t36, ("found",), "t36"),
+                ("bwd", "rest", [i for i in block if bwd(i)], ("t16",) if t16 else (), None),
+                ("cblbwd", "side", [i for i in cbl if bwd(i)], ("t36",) if t36 else (), None)]
+        self.segments = [sg for sg in segs if sg[2]]
+        self.streams = dict(zip(self.STREAMS, concurrent_streams(len(self.STREAMS))))        # streams with hardware queues of their own
+        self.states = [{} for _ in range(self.SLOTS)]
+        self.graphs = [dict() for _ in range(self.SLOTS)]
+        self.events = [{nm: torch.cuda.Event() for nm in ("found", "t16", "t36")} for _ in range(self.SLOTS)]
+        self.done = [{c: torch.cuda.Event() for c in self.STREAMS[1:]} for _ in range(self.SLOTS)]
+        self.count = 0
+
+    def _segment(self, seg, state):
+        for i in seg[2]:
+            self.sched.stage_list[i][1](state)
+        if seg[0] == "search":
+            state["_order"] = pointops.spatial_order(state["idx"])                          # kept alive for the branches
+
+    def capture(self):
+        from . import neighbor_state
+        for slot in range(self.SLOTS):
+            for graphed in (False, True):                           # once eagerly (workspaces of the streams, code objects), then captured
+                state = {}
+                with pointops.neighbor_cache() as nc, neighbor_state.streams_ordered_by_caller():
+                    nc.record_events = False
+                    for xyz, nsample, algo in self.sched.hints:
+                        nc.hint(xyz, nsample, algo)
+                    for seg in self.segments:                       # in dependency order, the device idle between two segments
+                        stream = self.streams[seg[1]]
+                        torch.cuda.synchronize()
+                        if graphed:
+                            g = torch.cuda.CUDAGraph()
+                            with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+                                self._segment(seg, state)
+                            self.graphs[slot][seg[0]] = g
+                        else:
+                            with torch.cuda.stream(stream):
+                                self._segment(seg, state)
+                torch.cuda.synchronize()
+            self.states[slot] = state
+        self.count = 0
+        for _ in range(2 * self.SLOTS):                             # every graph has run, in pipeline order
+            self.step()
+        torch.cuda.synchronize()
+
+    def step(self):
+        """issue one step: one graph launch per segment; returns at once"""
+        slot = self.count % self.SLOTS
+        S, ev = self.streams, self.events[slot]
+        if self.count >= self.SLOTS:
+            for c in self.STREAMS[1:]:
+                S["search"].wait_event(self.done[slot][c])          # the step that used this slot last is through with it
+        else:
+            S["search"].wait_stream(torch.cuda.current_stream())    # whatever prepared the inputs
+        self.count += 1
+        for name, sname, _, waits, record in self.segments:
+            stream = S[sname]
+            for w in waits:
+                stream.wait_event(ev[w])
+            with torch.cuda.stream(stream):
+                self.graphs[slot][name].replay()
+                if record is not None:
+                    ev[record].record()
+        for c in self.STREAMS[1:]:
+            self.done[slot][c].record(S[c])
+
+    def join(self):
+        """the caller's stream waits for everything issued so far"""
+        cur = torch.cuda.current_stream()
+        for c in self.STREAMS:
+            cur.wait_stream(self.streams[c])

@@ -74,6 +74,21 @@ def _order_alias(idx, points):
             cache.order_keys.append(_order_key(idx))
 
 
+class streams_ordered_by_caller:
+    """inside: lookups of processing orders and transposed tables hand out what they have without ordering the current stream behind the stream
+    that produced it — for callers that sequence their streams themselves (hotpath.Pipeline captures every chain of a step as a hipGraph of its
+    own; a wait on another stream's live event has no place inside such a capture).  Module-wide, not thread-local: autograd's thread must see it."""
+    active = 0
+
+    def __enter__(self):
+        streams_ordered_by_caller.active += 1
+        return self
+
+    def __exit__(self, *exc):
+        streams_ordered_by_caller.active -= 1
+        return False
+
+
 def spatial_order(points):
     """-> int32 (n,) processing order of `points` (cell order of an earlier self-search over the same tensor; also keyed by the
     neighbour table that search returned), or None"""
@@ -87,6 +102,8 @@ def spatial_order(points):
     if hit is not None:
         return hit[0]
     order, producer = next(iter(ent.values()))                   # produced on another stream: order after it, keep it alive for this one
+    if streams_ordered_by_caller.active:
+        return order
     cur.wait_stream(producer)
     order.record_stream(cur)
     ent[cur.cuda_stream] = (order, cur)                             # ordered behind the producer from here on
@@ -114,7 +131,7 @@ def transpose_lookup(idx):
         return None
     _, order, inv_start, inv_src, producer, waited = ent
     cur = torch.cuda.current_stream(idx.device)
-    if producer != cur and cur.cuda_stream not in waited:            # built on another stream: order after it ONCE, keep the tensors alive for this one
+    if producer != cur and cur.cuda_stream not in waited and not streams_ordered_by_caller.active:   # built on another stream: order after it ONCE, keep the tensors alive for this one
         cur.wait_stream(producer)
         for t in (inv_start, inv_src) + (() if order is None else (order,)):
             t.record_stream(cur)

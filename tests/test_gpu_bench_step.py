@@ -64,27 +64,26 @@ def check_state(s, o, backward):
         assert np.allclose(gk, o["g_kw"], rtol=1e-4, atol=1e-4 * np.abs(o["g_kw"]).max()), "KPConv kernel-weight gradient beyond 1e-4"
 
 
-@pytest.mark.parametrize("backward,group", [(True, 5), (False, 5), (True, 1), (False, 1)])
-def test_the_step_bench_times_against_the_oracles(oracle, backward, group):
-    """group = 5: what `python bench.py` replays by default (--steps 50 -> groups of 10; same code path): consecutive steps as one
-    software-pipelined dependency graph — EVERY step of the group is checked, after several replays (a step reading a neighbour table, an order
-    or a transposed table that the next step's search has already overwritten would show up here)."""
+@pytest.mark.parametrize("backward,pipeline", [(True, True), (False, True), (True, False), (False, False)])
+def test_the_step_bench_times_against_the_oracles(oracle, backward, pipeline):
+    """pipeline = True: what `python bench.py` runs by default — consecutive steps software-pipelined over three streams (the search of step i+1
+    beside the rest of step i), alternating between two output slots: BOTH slots are checked after an odd number of steps (a step reading a
+    neighbour table, an order or a transposed table that the next search has already overwritten would show up here)."""
     import bench
     from contrastboundary_amd import hotpath
     args = bench.parse([])
     scene = hotpath.Scene.synthetic(N, C, seed=0, b=1)
-    step = bench.Step(scene, K, backward, args, overlap=True, group=group)
-    assert step.group == group
+    step = bench.Step(scene, K, backward, args, overlap=True, pipeline=pipeline)
     bench.settle(step, 0.1)
-    step.capture()                                                    # the hipGraph bench.py replays; a failed capture fails the test
-    assert step.graph is not None
-    for _ in range(3):
+    step.capture()                                                    # the hipGraph(s) bench.py replays; a failed capture fails the test
+    assert (step.pipe is not None) if pipeline else (step.graph is not None)
+    for _ in range(7):
         step()                                                        # what the timed region calls
     torch.cuda.synchronize()
-    assert len(step.states) == group
+    assert len(step.states) == (2 if pipeline else 1)
     for st in step.states:
         check_state(st, oracle, backward)
-    if group > 1:
+    if pipeline:
         return
     # the in-order step with events inside its graph (where the per-stage times come from) computes the same thing
     st_in, ms, how = bench.stage_times(scene, K, backward, args, reps=2)
