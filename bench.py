@@ -412,8 +412,8 @@ def run_gpu(args, D, world, rank, local):
     if (world > 1 or args.allreduce_single) and not args.no_allreduce:
         ar = GradAllReduce(args.allreduce_floats, "cuda")
 
-        def step_ar():
-            ar.start(); step(); step.join(); ar.finish()
+        def step_ar():                                               # all-reduce of step i's gradients behind step i, beside step i+1 (as DDP's buckets)
+            step(); step.join(); ar.finish(); ar.start()
         e_ar = timed_region(step_ar, args.steps, args.warmup, sync, D)
 
         def only_ar():
@@ -423,8 +423,9 @@ def run_gpu(args, D, world, rank, local):
         out["grad_allreduce"] = {"value": n * args.steps * world / e_ar, "ms_per_step": e_ar / args.steps * 1e3, "bytes": nbytes,
                                  "allreduce_alone_ms": e_only / args.steps * 1e3,
                                  "allreduce_busbw_GBps": nbytes * 2 * (world - 1) / world / (e_only / args.steps) / 1e9, "ranks": world,
-                                 "note": "one flat fp32 all-reduce of the reference network's 7,800,497 gradients per step over RCCL, issued beside the "
-                                         "step and joined at its end (what DDP adds, train.py:181-185); `value` above is the replica-only number"}
+                                 "note": "one flat fp32 all-reduce of the reference network's 7,800,497 gradients per step over RCCL, started behind step i and "
+                                         "joined behind step i+1, i.e. running beside the next step (what DDP adds, train.py:181-185); `value` above is the "
+                                         "replica-only number"}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             from tests import cpu_baseline
