@@ -380,6 +380,55 @@ __global__ __launch_bounds__(NB) void grouping_bwd_csr_rows_kernel(unsigned n, i
     }
 }
 
+// The other scatter-adds of the path in the same form.  K6 (interpolation_cuda_kernel.cu:20-33) and the grad_input part of K10
+// (aggregation_cuda_kernel.cu:22-39) add  rows[source] * weight[pair]  into the pair's target, K8 (subtraction_cuda_kernel.cu:18-30) adds
+// -rows[pair]: one wave per target, lane = channel, the target's pairs in ascending order (= the reference loop run sequentially: bit-exact
+// against the CPU oracle), eight rows in flight.
+template <bool PAIR_ROWS, bool WEIGHT>
+__global__ __launch_bounds__(NB) void scatter_as_gather_kernel(unsigned n, int c, CblFastDiv dv, int wc, float sign, const float* __restrict__ rows,
+                                                               const float* __restrict__ w, const int* __restrict__ order,
+                                                               const int* __restrict__ inv_start, const int* __restrict__ inv_src, float* __restrict__ gi)
+{
+    const unsigned lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned nwg = (n + 3) >> 2;
+    for (unsigned v = blockIdx.x; v < 8 * cbl_xcd_per(nwg); v += gridDim.x) {
+        const unsigned r = cbl_xcd_slot(v, nwg) * 4 + wave;
+        if (r >= n) continue;
+        const int s0 = inv_start[r], s1 = inv_start[r + 1];
+        const unsigned t = order ? (unsigned)order[r] : r;
+        for (unsigned ch = lane; ch < (unsigned)c; ch += 64) {
+            const unsigned wch = WEIGHT ? ch % (unsigned)wc : 0u;
+            auto term = [&](int e) -> float {
+                const unsigned p = (unsigned)inv_src[e];
+                const float x = rows[(size_t)(PAIR_ROWS ? p : cbl_fastdiv(p, dv)) * c + ch];
+                return WEIGHT ? x * w[(size_t)p * wc + wch] : x;
+            };
+            float acc = 0.f;
+            int e = s0;
+            for (; e + 8 <= s1; e += 8) {
+                float x[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) x[u] = term(e + u);
+#pragma unroll
+                for (int u = 0; u < 8; u++) acc += x[u];
+            }
+            for (; e < s1; e++) acc += term(e);
+            gi[(size_t)t * c + ch] = sign * acc;
+        }
+    }
+}
+
+// g1[p, ch] += sum over s of go[p, s, ch]   (the per-row half of K8: no table needed, fixed order)
+__global__ __launch_bounds__(256) void rows_sum_kernel(long long total, int ns, int c, const float* __restrict__ go, float* __restrict__ g1)
+{
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long p = e / c; const int ch = (int)(e - p * c);
+        float acc = g1[e];
+        for (int s = 0; s < ns; s++) acc += go[((size_t)p * ns + s) * c + ch];
+        g1[e] = acc;
+    }
+}
+
 }  // namespace
 
 CBL_EXPORT size_t cbl_neighbor_transpose_workspace_bytes(int m, int n, int nsample)
@@ -455,5 +504,38 @@ CBL_EXPORT int cbl_grouping_backward_csr_rows(int n, int c, int row_stride, int 
     unsigned g = cbl_round_up8(cbl_div_up(n, 4)); if (g > 256u * 32u) g = 256u * 32u;
     hipLaunchKernelGGL(grouping_bwd_csr_rows_kernel, dim3(g), dim3(NB), 0, cbl_stream(stream), (unsigned)n, c, row_stride, col_offset, grad_output, order_dst,
                        inv_start, inv_src, grad_input);
+    return cbl_status();
+}
+
+// K6 / the grad_input part of K10 as a gather: grad_input[t, ch] = sum over the pairs p = (source, column) that list t, ascending, of
+// rows[source, ch] * weight[p, ch % w_c]   (K6: nsample = 3, w_c = 1, interpolation_cuda_kernel.cu:20-33; K10: aggregation_cuda_kernel.cu:22-39).
+// grad_input is written, not accumulated.
+CBL_EXPORT int cbl_weighted_scatter_csr(int n, int nsample, int c, int w_c, const float* rows, const float* weight, const int* order_dst,
+                                        const int* inv_start, const int* inv_src, float* grad_input, void* stream)
+{
+    if (n < 0 || nsample <= 0 || c <= 0 || w_c <= 0) return CBL_ERR_BAD_ARG;
+    if (n == 0) return CBL_OK;
+    if (!rows || !weight || !inv_start || !inv_src || !grad_input) return CBL_ERR_BAD_ARG;
+    unsigned g = cbl_round_up8(cbl_div_up(n, 4)); if (g > 256u * 32u) g = 256u * 32u;
+    hipLaunchKernelGGL((scatter_as_gather_kernel<false, true>), dim3(g), dim3(NB), 0, cbl_stream(stream), (unsigned)n, c, cbl_fastdiv_make((unsigned)nsample), w_c, 1.0f,
+                       rows, weight, order_dst, inv_start, inv_src, grad_input);
+    return cbl_status();
+}
+
+// K8 (subtraction_cuda_kernel.cu:18-30) without atomics: grad_input1[p] += sum_s grad_output[p, s] (accumulated, as the reference does into its
+// zero-filled tensor), grad_input2[t] = -(sum over the pairs that list t, ascending) (written)
+CBL_EXPORT int cbl_subtraction_backward_csr(int m, int n2, int nsample, int c, const float* grad_output, const int* order_dst, const int* inv_start,
+                                            const int* inv_src, float* grad_input1, float* grad_input2, void* stream)
+{
+    if (m < 0 || n2 < 0 || nsample <= 0 || c <= 0) return CBL_ERR_BAD_ARG;
+    if (!grad_output || !inv_start || !inv_src || !grad_input1 || !grad_input2) return CBL_ERR_BAD_ARG;
+    hipStream_t st = cbl_stream(stream);
+    if (m > 0)
+        hipLaunchKernelGGL(rows_sum_kernel, dim3(cbl_grid_for((long long)m * c, 256)), dim3(256), 0, st, (long long)m * c, nsample, c, grad_output, grad_input1);
+    if (n2 > 0) {
+        unsigned g = cbl_round_up8(cbl_div_up(n2, 4)); if (g > 256u * 32u) g = 256u * 32u;
+        hipLaunchKernelGGL((scatter_as_gather_kernel<true, false>), dim3(g), dim3(NB), 0, st, (unsigned)n2, c, cbl_fastdiv_make(1u), 1, -1.0f,
+                           grad_output, nullptr, order_dst, inv_start, inv_src, grad_input2);
+    }
     return cbl_status();
 }

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(GB) void agg_bwd(int n, int ns, int c, int wc, cons
             const long long src = (long long)idx[r] * c + ch;
             const float wv = w[r * wc + wch];
             const float gwv = g * wv;
-            atomic_add_f32(gi + src, gwv);
+            if (gi) atomic_add_f32(gi + src, gwv);                   // gi == nullptr: the caller gathers it over the transposed table instead
             gpos[r * c + ch] = gwv;
             atomic_add_f32(gw + r * wc + wch, g * (in[src] + pos[r * c + ch]));
         }
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(GB) void agg_bwd_wave(int n, int ns, int c, int wc,
             if (live) {
                 const long long src = (long long)idx[r] * c + ch;
                 const float gwv = g * w[r * wc + wch];
-                atomic_add_f32(gi + src, gwv);
+                if (gi) atomic_add_f32(gi + src, gwv);
                 gpos[r * c + ch] = gwv;
                 contrib = g * (in[src] + pos[r * c + ch]);
             }
@@ -583,7 +583,7 @@ CBL_EXPORT int cbl_aggregation_backward(int n, int nsample, int c, int w_c, cons
     CBL_CHECK_DIMS(n, nsample, c, w_c);
     if ((long long)n * c == 0) return CBL_OK;
     if (w_c == 0) return CBL_ERR_BAD_ARG;
-    CBL_CHECK_PTRS(input, position, weight, idx, grad_output, grad_input, grad_position, grad_weight);
+    CBL_CHECK_PTRS(input, position, weight, idx, grad_output, grad_position, grad_weight);   // grad_input may be NULL: cbl_weighted_scatter_csr writes it
     const bool pow2 = (w_c & (w_c - 1)) == 0;
     if (GB % 64 == 0 && pow2 && w_c <= 64 && c % w_c == 0 && (c % 64 == 0 || 64 % c == 0))
         hipLaunchKernelGGL(agg_bwd_wave, dim3(cbl_grid_for((long long)n * c, GB)), dim3(GB), 0, cbl_stream(stream), n, nsample, c, w_c, input, position, weight, idx, grad_output, grad_input, grad_position, grad_weight);

@@ -421,6 +421,14 @@ class Subtraction(Function):
         grad_output = grad_output.contiguous()
         n, nsample, c = grad_output.shape
         g1 = torch.zeros((n, c), dtype=torch.float32, device=grad_output.device)
+        tr = neighbor_transpose(idx, ctx.n2, build=(n * nsample >= TRANSPOSE_MIN_PAIRS))
+        if tr is not None:                                           # K8 as a gather over the transposed table: no atomics (cbl_amd.h)
+            order, inv_start, inv_src = tr
+            g2 = torch.empty((ctx.n2, c), dtype=torch.float32, device=grad_output.device)
+            _lib.check(_lib.lib().cbl_subtraction_backward_csr(_c_int(n), _c_int(ctx.n2), _c_int(nsample), _c_int(c), _lib.ptr(grad_output), _lib.ptr(order),
+                                                               _lib.ptr(inv_start), _lib.ptr(inv_src), _lib.ptr(g1), _lib.ptr(g2),
+                                                               _lib.stream_of(grad_output)), "cbl_subtraction_backward_csr")
+            return g1, g2, None
         g2 = torch.zeros((ctx.n2, c), dtype=torch.float32, device=grad_output.device)
         _lib.check(_lib.lib().cbl_subtraction_backward(_c_int(n), _c_int(nsample), _c_int(c), _lib.ptr(idx), _lib.ptr(grad_output),
                                                        _lib.ptr(g1), _lib.ptr(g2), _lib.stream_of(grad_output)), "cbl_subtraction_backward")
@@ -453,9 +461,21 @@ class Aggregation(Function):
         n, nsample, c = position.shape
         w_c = weight.shape[-1]
         dev = grad_output.device
-        gi = torch.zeros((input.shape[0], c), dtype=torch.float32, device=dev)
         gp = torch.zeros((n, nsample, c), dtype=torch.float32, device=dev)
         gw = torch.zeros((n, nsample, w_c), dtype=torch.float32, device=dev)
+        tr = neighbor_transpose(idx, input.shape[0], build=(n * nsample >= TRANSPOSE_MIN_PAIRS))
+        if tr is not None:                                           # grad_input of K10 as a gather over the transposed table, the per-pair outputs as before
+            order, inv_start, inv_src = tr
+            L = _lib.lib()
+            gi = torch.empty((input.shape[0], c), dtype=torch.float32, device=dev)
+            _lib.check(L.cbl_aggregation_backward(_c_int(n), _c_int(nsample), _c_int(c), _c_int(w_c), _lib.ptr(input), _lib.ptr(position), _lib.ptr(weight),
+                                                  _lib.ptr(idx), _lib.ptr(grad_output), None, _lib.ptr(gp), _lib.ptr(gw), _lib.stream_of(grad_output)),
+                       "cbl_aggregation_backward")
+            _lib.check(L.cbl_weighted_scatter_csr(_c_int(input.shape[0]), _c_int(nsample), _c_int(c), _c_int(w_c), _lib.ptr(grad_output), _lib.ptr(weight),
+                                                  _lib.ptr(order), _lib.ptr(inv_start), _lib.ptr(inv_src), _lib.ptr(gi), _lib.stream_of(grad_output)),
+                       "cbl_weighted_scatter_csr")
+            return gi, gp, gw, None
+        gi = torch.zeros((input.shape[0], c), dtype=torch.float32, device=dev)
         _lib.check(_lib.lib().cbl_aggregation_backward(_c_int(n), _c_int(nsample), _c_int(c), _c_int(w_c), _lib.ptr(input), _lib.ptr(position),
                                                        _lib.ptr(weight), _lib.ptr(idx), _lib.ptr(grad_output), _lib.ptr(gi), _lib.ptr(gp),
                                                        _lib.ptr(gw), _lib.stream_of(grad_output)), "cbl_aggregation_backward")
@@ -495,6 +515,14 @@ class Interpolation(Function):
         idx, weight = ctx.saved_tensors
         grad_output = grad_output.contiguous()
         n, c = grad_output.shape
+        tr = neighbor_transpose(idx, ctx.m, build=(n * ctx.k >= TRANSPOSE_MIN_PAIRS))
+        if tr is not None:                                           # K6 as a gather over the transposed table: no atomics (cbl_amd.h)
+            order, inv_start, inv_src = tr
+            grad_input = torch.empty((ctx.m, c), dtype=torch.float32, device=grad_output.device)
+            _lib.check(_lib.lib().cbl_weighted_scatter_csr(_c_int(ctx.m), _c_int(ctx.k), _c_int(c), _c_int(1), _lib.ptr(grad_output), _lib.ptr(weight),
+                                                           _lib.ptr(order), _lib.ptr(inv_start), _lib.ptr(inv_src), _lib.ptr(grad_input),
+                                                           _lib.stream_of(grad_output)), "cbl_weighted_scatter_csr")
+            return None, None, grad_input, None, None, None
         grad_input = torch.zeros((ctx.m, c), dtype=torch.float32, device=grad_output.device)
         _lib.check(_lib.lib().cbl_interpolation_backward(_c_int(n), _c_int(c), _c_int(ctx.k), _lib.ptr(grad_output), _lib.ptr(idx),
                                                          _lib.ptr(weight), _lib.ptr(grad_input), _lib.stream_of(grad_output)),

@@ -162,6 +162,17 @@ int cbl_grouping_backward_csr(int n, int c, const float* grad_output, const int*
  * of queryandgroup's (m, nsample, 3 + c) gradient (pointops.py:90-98: torch.cat) without first copying the slice out */
 int cbl_grouping_backward_csr_rows(int n, int c, int row_stride, int col_offset, const float* grad_output, const int* order_dst,
                                    const int* inv_start, const int* inv_src, float* grad_input, void* stream);
+/* The remaining scatter-adds of the path as gathers over the same table (no atomics, ascending pair order = the reference loops run sequentially:
+ * bit-exact against the CPU oracle, run-to-run deterministic).
+ * cbl_weighted_scatter_csr: grad_input[t, ch] = sum over the pairs p = (source, column) listing t of rows[source, ch] * weight[p, ch % w_c]
+ *   - K6, interpolation_cuda_kernel.cu:20-33 (rows = grad_output (m, c), weight (m, 3), nsample = 3, w_c = 1);
+ *   - the grad_input part of K10, aggregation_cuda_kernel.cu:22-39 (rows = grad_output (n, c), weight (n, nsample, w_c)); the other two outputs
+ *     come from cbl_aggregation_backward called with grad_input = NULL.
+ * cbl_subtraction_backward_csr: K8, subtraction_cuda_kernel.cu:18-30: grad_input1 (m, c) accumulated (+= sum over s), grad_input2 (n2, c) written. */
+int cbl_weighted_scatter_csr(int n, int nsample, int c, int w_c, const float* rows, const float* weight, const int* order_dst, const int* inv_start,
+                             const int* inv_src, float* grad_input, void* stream);
+int cbl_subtraction_backward_csr(int m, int n2, int nsample, int c, const float* grad_output, const int* order_dst, const int* inv_start,
+                                 const int* inv_src, float* grad_input1, float* grad_input2, void* stream);
 
 /* K5/K6  interpolation_{forward,backward}_cuda_launcher  interpolation/interpolation_cuda_kernel.h:13-14.
  *   forward : input (m,c), idx (n,k), weight (n,k) -> output (n,c) +=     (caller pre-zeroes)
