@@ -4,11 +4,14 @@ import re
 import subprocess
 import sys
 
-ROOT = __file__.rsplit("/tools/", 1)[0]
+import os
+ROOT = os.path.abspath(__file__).rsplit("/tools/", 1)[0]
+sys.path.insert(0, ROOT)
+from contrastboundary_amd import build as B                         # the library's own flags, per-file extras included
+
 for src in sys.argv[1:]:
-    r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics",
-                        f"-I{ROOT}/include", f"-I{ROOT}/contrastboundary_amd/csrc", "-Rpass-analysis=kernel-resource-usage",
-                        "-c", src, "-o", "/dev/null"], capture_output=True, text=True)
+    r = subprocess.run([B.HIPCC] + B.FLAGS + B.EXTRA_FLAGS.get(os.path.basename(src), []) +
+                       ["-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"], capture_output=True, text=True)
     cur = None
     for line in r.stderr.splitlines():
         m = re.search(r"remark:\s+(.*?)\s*\[-Rpass", line)
