@@ -205,8 +205,7 @@ template <class F> unsigned kb_resident(F kernel, int& cache)
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
         cache = per_cu * cus;
     }
-    static const char* env = getenv("CBL_KB_GRID");                  // tuning knob (tools/exp/kb_probe.py)
-    return env ? (unsigned)atoi(env) : (unsigned)cache;
+    return (unsigned)cache;
 }
 
 }  // namespace

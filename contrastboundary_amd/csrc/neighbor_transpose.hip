@@ -256,7 +256,7 @@ __device__ __forceinline__ void nt_rank_sort(const int* __restrict__ stage, cons
 }
 
 __global__ __launch_bounds__(NB) void nt_finish_kernel(int n, int ntt, const int* __restrict__ tile_base, const int2* __restrict__ bins, int* __restrict__ scratch,
-                                                       int* __restrict__ inv_start, int* __restrict__ inv_src, int debug)
+                                                       int* __restrict__ inv_start, int* __restrict__ inv_src)
 {
     __shared__ int cnt[TT], lstart[TT + 1];
     __shared__ int stage_lds[STAGE_CAP];
@@ -297,8 +297,7 @@ __global__ __launch_bounds__(NB) void nt_finish_kernel(int n, int ntt, const int
             for (int e = threadIdx.x; e < E; e += NB) { const int2 v = bins[b0 + e]; stage_lds[lstart[v.x] + atomicAdd(&cnt[v.x], 1)] = v.y; }
         }
         __syncthreads();
-        if (debug & 1) { for (int e = threadIdx.x; e < E; e += NB) inv_src[b0 + e] = stage_lds[e]; }      // TIMING EXPERIMENT ONLY: unsorted segments
-        else nt_rank_sort(stage_lds, lstart, inv_src + b0);
+        nt_rank_sort(stage_lds, lstart, inv_src + b0);
     } else {
         int* stage = scratch + b0;
         for (int e = threadIdx.x; e < E; e += NB) { const int2 v = bins[b0 + e]; stage[lstart[v.x] + atomicAdd(&cnt[v.x], 1)] = v.y; }
@@ -467,8 +466,7 @@ CBL_EXPORT int cbl_neighbor_transpose(int m, int n, int nsample, const int* idx,
     const int per_thread = (TS * nsample + NB - 1) / NB;             // pairs per thread of a full source tile: one batch where it fits 16
     if (per_thread <= 4) { CBL_NT(4); } else if (per_thread <= 8) { CBL_NT(8); } else { CBL_NT(16); }
 #undef CBL_NT
-    static const char* dbg = getenv("CBL_NT_DEBUG");                 // timing experiments (tools/exp): never set in tests or bench
-    hipLaunchKernelGGL(nt_finish_kernel, dim3(ntt), dim3(NB), 0, st, n, ntt, w.tile_base, w.bins, w.scratch, inv_start, inv_src, dbg ? atoi(dbg) : 0);
+    hipLaunchKernelGGL(nt_finish_kernel, dim3(ntt), dim3(NB), 0, st, n, ntt, w.tile_base, w.bins, w.scratch, inv_start, inv_src);
     return cbl_status();
 }
 

@@ -193,22 +193,6 @@ class Schedule:
                 return self._run_branches(state, events) if self.overlap else self._run(state, events, None, ())
         return self._run(state, events, side_after, SIDE_STAGES if self.overlap else ())
 
-    def capture_stage_graphs(self, state):
-        """every stage of the in-order step as a hipGraph of its own (one memory pool, captured in step order inside one neighbour cache):
-        replayed in order they are the step, and HIP events recorded between two replays on the launch stream time ONE stage with no host
-        in the loop.  (ROCm does not allow event-record nodes inside a graph.)"""
-        pool = torch.cuda.graph_pool_handle()
-        graphs = []
-        with pointops.neighbor_cache() as nc:
-            for xyz, nsample, algo in self.hints:
-                nc.hint(xyz, nsample, algo)
-            for i in range(len(self.stage_list)):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
-                    self.stage_list[i][1](state)
-                graphs.append(g)
-        return graphs
-
     def _join_table(self, name, state):
         """the stream about to run a consumer of a transposed table waits for the stream that builds it — here, on the issuing thread (the
         consumer itself runs on autograd's thread and finds the wait already done: neighbor_state.transpose_lookup)"""

@@ -22,6 +22,6 @@ def run(wf, ww, o):
     return lambda: _lib.check(L.cbl_kpconv_backward_csr(i(n), i(n), i(K), i(C), i(KP), _lib.ptr(sc.xyz), _lib.ptr(sc.xyz), _lib.ptr(sc.feat), _lib.ptr(sc.kernel_points),
         _lib.ptr(sc.kernel_weights), ctypes.c_float(0.12), i(1), i(0), _lib.ptr(go), _lib.ptr(o), _lib.ptr(s if o is not None else s_n), _lib.ptr(src if o is not None else src_n),
         _lib.ptr(gf if wf else None), _lib.ptr(gkw if ww else None), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(go)), "kb")
-print("grid", os.environ.get("CBL_KB_GRID", "768"), " gf+gkw %.1f us   gf only %.1f us   gkw only %.1f us" % (timeit(run(True, True, order)), timeit(run(True, False, order)), timeit(run(False, True, order))))
+print("grid", "resident", " gf+gkw %.1f us   gf only %.1f us   gkw only %.1f us" % (timeit(run(True, True, order)), timeit(run(True, False, order)), timeit(run(False, True, order))))
 deg = (s[1:] - s[:-1]).float()
 print("in-degree mean %.1f max %d  >16: %.2f  >32: %.3f" % (deg.mean().item(), int(deg.max()), (deg > 16).float().mean().item(), (deg > 32).float().mean().item()))
