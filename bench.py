@@ -329,7 +329,7 @@ def run_gpu(args, D, world, rank, local):
         "config": {"workload": "S3DIS-shaped synthetic scene (S-room), N=%d, K=%d, C=%d, 1 scene per GPU per step, %s; stages: %s"
                    % (n, k, c, "forward + backward of the block" if backward else "forward block + CBL head", " -> ".join(step.names)),
                    "parallelism": "scene-per-GPU replicas x%d (no data-path collective)" % world,
-                   "issue": step.note + "; every timed step is the same replay",
+                   "issue": step.note + ("; every timed step is the same replay" if (step.graph is not None or step.pipe is not None) else "; every timed step is issued from Python"),
                    "schedule": ("one search per geometry (the K=%d request runs the K=%d search the CBL head needs on the same points and is derived from it, tied "
                                 "rows replayed; the later request is a cache hit, the cache is dropped at the end of every step); " % (k, hotpath.CBL_NSAMPLE)
                                 if step.hints else "every search on its own; ") +
