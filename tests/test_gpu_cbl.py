@@ -360,3 +360,30 @@ def test_coincident_points_keep_the_reference_column_zero():
     rloss, rgrad, _ = C.point_contrast(feat, np.eye(13, dtype=np.float32)[lab], ridx, temperature=1.0, weight=0.1)
     np.testing.assert_allclose(loss.item(), rloss, rtol=TOL)
     np.testing.assert_allclose(f.grad.cpu().numpy(), rgrad, rtol=1e-3, atol=1e-4 * np.abs(rgrad).max())
+
+
+@pytest.mark.parametrize("d", [8, 32])
+def test_point_contrast_with_hub_targets_vs_oracle(d):
+    """targets listed by far more than 64 pairs (several 64-entry chunks of the transposed table per target, most of them with a
+    coefficient), beside targets nobody lists: the gather-form gradient against the oracle, and run-to-run identical"""
+    from contrastboundary_amd import heads
+    rng = np.random.default_rng(d)
+    n, nsample = 6000, 24
+    lab = rng.integers(0, 5, n).astype(np.int64)
+    feat = (rng.normal(size=(n, d)) * 0.5).astype(np.float32)
+    idx = rng.integers(100, n, size=(n, nsample)).astype(np.int32)        # rows 0..99 are listed by nobody ...
+    idx[:, 0] = np.arange(n)                                              # (column 0 = the point itself, dropped by the head)
+    idx[:, 1] = 7                                                         # ... except hub 7: listed by every point,
+    idx[::3, 2] = 11                                                      # hub 11 by every third,
+    idx[::50, 3] = 13                                                     # hub 13 by 120 points
+    grads = []
+    for _ in range(2):
+        f = dev(feat).requires_grad_(True)
+        loss, mask = heads.point_contrast(f, dev(lab), dev(idx), temperature=0.9, weight=0.1, return_mask=True)
+        loss.backward()
+        grads.append(f.grad.cpu().numpy())
+    rloss, rgrad, rmask = C.point_contrast(feat, np.eye(5, dtype=np.float32)[lab], idx, temperature=0.9, weight=0.1)
+    np.testing.assert_array_equal(mask.cpu().numpy().astype(bool), rmask)
+    np.testing.assert_allclose(loss.item(), rloss, rtol=TOL)
+    np.testing.assert_allclose(grads[0], rgrad, rtol=1e-3, atol=1e-4 * np.abs(rgrad).max())
+    assert np.array_equal(grads[0], grads[1])
