@@ -30,7 +30,10 @@ def make(n0, n, K, C, seed, pad_frac=0.2):
 
 
 @pytest.mark.parametrize("K,C,KP,influence,mode", [(16, 64, 15, "linear", "sum"), (26, 72, 15, "linear", "sum"), (9, 16, 7, "linear", "closest"),
-                                                   (31, 144, 15, "constant", "sum"), (5, 20, 16, "linear", "sum")])
+                                                   (31, 144, 15, "constant", "sum"), (5, 20, 16, "linear", "sum"),
+                                                   # the C <= 64 kernel beyond one chunk of 16 neighbours, with a constant influence, beyond 64 neighbours
+                                                   (26, 64, 15, "linear", "sum"), (40, 32, 15, "constant", "sum"), (70, 48, 13, "linear", "closest"),
+                                                   (100, 64, 15, "linear", "sum"), (16, 8, 15, "constant", "closest")])
 def test_kpconv(K, C, KP, influence, mode):
     from contrastboundary_amd import local_aggregation as L
     q, s, idx, f, rng = make(700, 300, K, C, seed=K)
@@ -43,6 +46,11 @@ def test_kpconv(K, C, KP, influence, mode):
     scale = np.abs(ref).max()
     np.testing.assert_allclose(out.detach().cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * scale)
     go = rng.normal(size=ref.shape).astype(np.float32)
+    if K > 64:                                                       # the backward kernels take K <= 64 (the reference's K_lim is <= 41): loud, not wrong
+        from contrastboundary_amd._lib import CblError
+        with pytest.raises(CblError):
+            out.backward(dev(go))
+        return
     out.backward(dev(go))
     gf, gkw = LA.kpconv_grads(q, s, idx, f, kpts, kw, extent, go, influence, mode)
     np.testing.assert_allclose(ft.grad.cpu().numpy(), gf, rtol=1e-3, atol=1e-4 * np.abs(gf).max())
