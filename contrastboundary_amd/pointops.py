@@ -8,9 +8,7 @@ memory, streams and autograd plumbing only; every op body is a C-ABI call (inclu
 Unlike the reference (no checks at all), dtype / device / contiguity are validated and a
 failing launch raises instead of surfacing later as an asynchronous error.
 """
-import collections
 import ctypes
-import threading
 
 import torch
 from torch.autograd import Function
