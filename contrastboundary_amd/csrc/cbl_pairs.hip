@@ -69,6 +69,17 @@ __global__ __launch_bounds__(256) void contrast_pairs_kernel(unsigned m, int nsa
         const int raw = nidx[(size_t)i * nsample + 1 + (colr ? lane : 0)];
         const bool real = raw >= 0 && raw < n_valid;
         const int nbr_row = real ? raw : 0;
+        // the neighbours' rows are requested HERE, together with their labels (both need nothing but the ids): whether the point has a loss at all is
+        // only known a round trip later, and 63 % of the S-room scene's points have none — their rows are fetched for nothing, but a point that has
+        // one no longer pays labels and rows one after the other
+        const int s = lane / LR, q = lane % LR;
+        float4 fjv[UM];
+#pragma unroll
+        for (int u = 0; u < UM; u++) {
+            const int j = u * PP + s;
+            fjv[u] = feat[(size_t)__shfl(nbr_row, j < ns ? j : 0) * LR + q];
+        }
+        const float4 fi = feat[(size_t)i * LR + q];
         bool nb_r, pos_r;
         if (ncls) {                                                  // collect_labels head.py:498-511, calc_dist 'kl' :189-191
             const float* __restrict__ soft = reinterpret_cast<const float*>(amax);
@@ -97,8 +108,6 @@ __global__ __launch_bounds__(256) void contrast_pairs_kernel(unsigned m, int nsa
             continue;
         }
         // ---- distances, lane = (row slot s, part q of the row)
-        const int s = lane / LR, q = lane % LR;
-        const float4 fi = feat[(size_t)i * LR + q];
         float shadow_d = 0.f;
         if (tf_variant) shadow_d = sqrtf(fmaxf(row_lanes_sum<LR>((fi.x * fi.x + fi.y * fi.y) + (fi.z * fi.z + fi.w * fi.w)), 1e-12f));
         float4 diff[UM]; float dist[UM], ex[UM];
@@ -109,8 +118,7 @@ __global__ __launch_bounds__(256) void contrast_pairs_kernel(unsigned m, int nsa
             const int j = u * PP + s;
             const bool col = j < ns;
             const int jj = col ? j : 0;
-            const int row = __shfl(nbr_row, jj);
-            const float4 fj = feat[(size_t)row * LR + q];
+            const float4 fj = fjv[u];
             diff[u] = make_float4(fi.x - fj.x, fi.y - fj.y, fi.z - fj.z, fi.w - fj.w);
             const float acc = row_lanes_sum<LR>((diff[u].x * diff[u].x + diff[u].y * diff[u].y) + (diff[u].z * diff[u].z + diff[u].w * diff[u].w));
             dist[u] = fast_sqrt(tf_variant ? fmaxf(acc, 1e-12f) : acc + 1e-12f);     // head.py:184-185 / dist_l2 heads.py:116-119
