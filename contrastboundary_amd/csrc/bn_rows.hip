@@ -187,6 +187,135 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_element_kernel(long long rows, in
     }
 }
 
+// ---- small problems (rows <= 4096: the three coarse stages of the network, n = 2560 / 640 / 160): ONE kernel per direction.  The three-launch
+// scheme above costs three graph nodes of 5-11 us each for tensors that fit a few registers per lane: here a workgroup owns 4 channels (one
+// float4 column), lane t holds rows t, t + 256, ... (<= 16 of them) in registers, so x is read once, the statistics are reduced inside the
+// workgroup (fp32 per wave, fp64 across waves, like the partial sums above) and the second pass runs from registers.
+constexpr int BN_SMALL_ROWS = 4096, BN_SMALL_PER = BN_SMALL_ROWS / BN_BLOCK;
+
+__device__ __forceinline__ float bn_wave_sum(float v)
+{
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s);
+    return v;
+}
+
+// sums[k] over the workgroup for k < NV, every thread gets the totals (as double)
+template <int NV>
+__device__ __forceinline__ void bn_block_sums(const float (&v)[NV], double (&tot)[NV], double (*red)[NV])
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; k++) { const float w = bn_wave_sum(v[k]); if (lane == 0) red[wave][k] = (double)w; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; k++) tot[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(BN_BLOCK) void bn_small_fwd_kernel(int rows, int C, const float* __restrict__ x, const float* __restrict__ weight,
+                                                                const float* __restrict__ bias, float eps, float momentum,
+                                                                float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                long long* __restrict__ num_batches_tracked, int relu,
+                                                                float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ y)
+{
+    __shared__ double red[4][8];
+    const int c0 = blockIdx.x * 4;
+    if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) num_batches_tracked[0] += 1;
+    float4 xv[BN_SMALL_PER];
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < BN_SMALL_PER; k++) {
+        const int r = k * BN_BLOCK + (int)threadIdx.x;
+        xv[k] = r < rows ? *reinterpret_cast<const float4*>(x + (size_t)r * C + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s[0] += xv[k].x; s[1] += xv[k].y; s[2] += xv[k].z; s[3] += xv[k].w;
+        s[4] += xv[k].x * xv[k].x; s[5] += xv[k].y * xv[k].y; s[6] += xv[k].z * xv[k].z; s[7] += xv[k].w * xv[k].w;
+    }
+    double tot[8];
+    bn_block_sums<8>(s, tot, red);
+    float mu[4], is[4], w[4], b[4];
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        const double m = tot[v] / (double)rows;
+        double var = tot[4 + v] / (double)rows - m * m;
+        if (var < 0.0) var = 0.0;
+        mu[v] = (float)m; is[v] = (float)(1.0 / sqrt(var + (double)eps));
+        w[v] = weight ? weight[c0 + v] : 1.f; b[v] = bias ? bias[c0 + v] : 0.f;
+        if (threadIdx.x == 0) {
+            mean[c0 + v] = mu[v]; invstd[c0 + v] = is[v];
+            if (running_mean) running_mean[c0 + v] = (1.f - momentum) * running_mean[c0 + v] + momentum * mu[v];
+            if (running_var) {
+                const double unbiased = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
+                running_var[c0 + v] = (1.f - momentum) * running_var[c0 + v] + momentum * (float)unbiased;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < BN_SMALL_PER; k++) {
+        const int r = k * BN_BLOCK + (int)threadIdx.x;
+        if (r < rows) {
+            const float in[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w};
+            float o[4];
+#pragma unroll
+            for (int v = 0; v < 4; v++) { const float yv = ((in[v] - mu[v]) * is[v]) * w[v] + b[v]; o[v] = (relu && !(yv > 0.f)) ? 0.f : yv; }
+            *reinterpret_cast<float4*>(y + (size_t)r * C + c0) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(BN_BLOCK) void bn_small_bwd_kernel(int rows, int C, const float* __restrict__ x, const float* __restrict__ gy,
+                                                                const float* __restrict__ weight, const float* __restrict__ bias,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
+                                                                float* __restrict__ gx, float* __restrict__ grad_weight, float* __restrict__ grad_bias)
+{
+    __shared__ double red[4][8];
+    const int c0 = blockIdx.x * 4;
+    float mu[4], is[4], w[4], b[4];
+#pragma unroll
+    for (int v = 0; v < 4; v++) { mu[v] = mean[c0 + v]; is[v] = invstd[c0 + v]; w[v] = weight ? weight[c0 + v] : 1.f; b[v] = bias ? bias[c0 + v] : 0.f; }
+    float4 xh[BN_SMALL_PER], g[BN_SMALL_PER];                       // xhat and the (ReLU-masked) incoming gradient
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < BN_SMALL_PER; k++) {
+        const int r = k * BN_BLOCK + (int)threadIdx.x;
+        float a[4] = {0.f, 0.f, 0.f, 0.f}, gg[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < rows) {
+            const float4 xr = *reinterpret_cast<const float4*>(x + (size_t)r * C + c0), gr = *reinterpret_cast<const float4*>(gy + (size_t)r * C + c0);
+            const float in[4] = {xr.x, xr.y, xr.z, xr.w}, gi[4] = {gr.x, gr.y, gr.z, gr.w};
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                a[v] = (in[v] - mu[v]) * is[v];
+                const float yv = a[v] * w[v] + b[v];
+                gg[v] = (relu && !(yv > 0.f)) ? 0.f : gi[v];
+            }
+        }
+        xh[k] = make_float4(a[0], a[1], a[2], a[3]); g[k] = make_float4(gg[0], gg[1], gg[2], gg[3]);
+#pragma unroll
+        for (int v = 0; v < 4; v++) { s[v] += gg[v]; s[4 + v] += gg[v] * a[v]; }
+    }
+    double tot[8];
+    bn_block_sums<8>(s, tot, red);
+    float k0[4], k1[4];
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        k0[v] = (float)(tot[v] / (double)rows); k1[v] = (float)(tot[4 + v] / (double)rows);
+        if (threadIdx.x == 0) { if (grad_bias) grad_bias[c0 + v] = (float)tot[v]; if (grad_weight) grad_weight[c0 + v] = (float)tot[4 + v]; }
+    }
+#pragma unroll
+    for (int k = 0; k < BN_SMALL_PER; k++) {
+        const int r = k * BN_BLOCK + (int)threadIdx.x;
+        if (r < rows) {
+            const float a[4] = {xh[k].x, xh[k].y, xh[k].z, xh[k].w}, gg[4] = {g[k].x, g[k].y, g[k].z, g[k].w};
+            float o[4];
+#pragma unroll
+            for (int v = 0; v < 4; v++) o[v] = w[v] * is[v] * ((gg[v] - k0[v]) - a[v] * k1[v]);
+            *reinterpret_cast<float4*>(gx + (size_t)r * C + c0) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+inline bool bn_small(long long rows, int C) { return rows <= BN_SMALL_ROWS && C % 4 == 0; }
+
 int bn_check(long long rows, int C)
 {
     if (rows < 0 || C <= 0) return CBL_ERR_BAD_ARG;
@@ -215,6 +344,11 @@ CBL_EXPORT int cbl_bn_rows_forward(long long rows, int C, const float* x, const 
     const BnShape s = bn_shape(rows, C);
     float* partial = reinterpret_cast<float*>(workspace);
     hipStream_t st = cbl_stream(stream);
+    if (bn_small(rows, C) && cbl_host_aligned16(x) && cbl_host_aligned16(y)) {
+        hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(C / 4), dim3(BN_BLOCK), 0, st, (int)rows, C, x, weight, bias, eps, momentum, running_mean, running_var,
+                           num_batches_tracked, relu, save_mean, save_invstd, y);
+        return cbl_status();
+    }
     const bool vec = s.vec == 4 && cbl_host_aligned16(x) && cbl_host_aligned16(y);
     const BnShape s1 = vec ? s : [&] { BnShape t = s; t.vec = 1; t.tpr = C; t.slots = BN_BLOCK / C; return t; }();
     if (s1.slots < 1) return CBL_ERR_UNSUPPORTED;
@@ -240,6 +374,11 @@ CBL_EXPORT int cbl_bn_rows_backward(long long rows, int C, const float* x, const
     float* partial = reinterpret_cast<float*>(workspace);
     float* coef = partial + (size_t)BN_MAX_BLOCKS * 2 * C;
     hipStream_t st = cbl_stream(stream);
+    if (bn_small(rows, C) && cbl_host_aligned16(x) && cbl_host_aligned16(grad_y) && cbl_host_aligned16(grad_x)) {
+        hipLaunchKernelGGL(bn_small_bwd_kernel, dim3(C / 4), dim3(BN_BLOCK), 0, st, (int)rows, C, x, grad_y, weight, bias, save_mean, save_invstd, relu,
+                           grad_x, grad_weight, grad_bias);
+        return cbl_status();
+    }
     const bool vec = s.vec == 4 && cbl_host_aligned16(x) && cbl_host_aligned16(grad_y) && cbl_host_aligned16(grad_x);
     const BnShape s1 = vec ? s : [&] { BnShape t = s; t.vec = 1; t.tpr = C; t.slots = BN_BLOCK / C; return t; }();
     if (s1.slots < 1) return CBL_ERR_UNSUPPORTED;

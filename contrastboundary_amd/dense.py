@@ -62,7 +62,7 @@ def linear(x, weight, bias=None):
     return y.view(*x.shape[:-1], cout)
 
 
-MIN_ROWS_BN = 4096
+MIN_ROWS_BN = 64            # below this torch's own kernels; up to 4096 rows csrc/bn_rows.hip runs ONE kernel per direction, above it two streaming passes
 
 
 class _BnRows(Function):

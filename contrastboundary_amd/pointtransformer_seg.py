@@ -220,11 +220,18 @@ def prefetch_geometry(model, inputs, criterion=None):
 
 class GraphedTrainStep:
     """forward + criterion + backward + optimizer step captured once in a hipGraph and replayed per batch — the network is ~2700 kernel
-    launches per step, which bounds an eagerly issued step by the host.  Two buffer sets (inputs, geometry, graph) alternate: while set
-    A replays, the geometry of the next batch (furthest point sampling: one workgroup on one CU) is refreshed into set B on a side
-    stream.  All batches must have the first batch's shapes (fixed points per scene, as the reference's voxel_max crop gives)."""
+    launches per step, which bounds an eagerly issued step by the host.  depth + 1 buffer sets (inputs, geometry, graph) rotate: while one set
+    replays, the geometry of the next `depth` batches (furthest point sampling: one workgroup on one CU, ~1 us per sample whatever the cloud)
+    is refreshed into the other sets on `depth` side streams.  depth = 2 because one batch's geometry (17 ms per 40960-point scene, a serial
+    chain) takes as long as the step itself: with a single batch in flight the step waited for it (measured: 3 ms of kernel time removed from
+    the step changed nothing); two chains side by side deliver a batch every 8.5 ms.  All batches must have the first batch's shapes (fixed
+    points per scene, as the reference's voxel_max crop gives).
 
-    def __init__(self, model, criterion, optimizer, inputs, target, warmup=3):
+        step = GraphedTrainStep(model, criterion, optimizer, first_inputs, first_target)
+        step.stage(batch0); step.stage(batch1)                  # `depth` batches ahead
+        for t in ...: loss, logits = step.run(); step.stage(batch[t + 2])"""
+
+    def __init__(self, model, criterion, optimizer, inputs, target, warmup=3, depth=2):
         from . import geometry
         self.model, self.criterion, self.optimizer = model, criterion, optimizer
         plan = dict(stride=model.STRIDE, nsample=model.NSAMPLE, multi_head=model.head is not None)
@@ -240,8 +247,11 @@ class GraphedTrainStep:
                 loss.sum().backward()
                 optimizer.step()
         torch.cuda.current_stream(dev).wait_stream(side)
+        self.depth = min(2, max(1, int(depth)))                       # (three geometry chains in flight hung the device once: not offered)
+        from . import hotpath
+        self.geo_streams = hotpath.concurrent_streams(self.depth + 1)[1:] if self.depth > 1 else [None]     # (None: the device's side stream)
         self.sets = []
-        for _ in range(2):
+        for _ in range(self.depth + 1):
             st_in = {k: v.clone() for k, v in inputs.items()}
             st_tg = target.clone()
             geom = geometry.StaticGeometry(st_in["points"], st_in["offset"], **plan)
@@ -253,16 +263,16 @@ class GraphedTrainStep:
                 loss.sum().backward()
                 optimizer.step()
             self.sets.append(dict(inputs=st_in, target=st_tg, geom=geom, graph=graph, loss=loss, logits=out))
-        self.turn = 0
-        self._staged = False
+        self.run_turn = self.stage_turn = self.staged = 0
 
     def stage(self, inputs, target):
         """copy the NEXT batch into the idle buffer set and start its geometry — all on the side stream, behind nothing but the last
         replay that read this buffer set"""
         from . import geometry
-        s = self.sets[self.turn]
+        assert self.staged < len(self.sets), "every buffer set holds a staged batch: run() first"
+        s = self.sets[self.stage_turn]
         dev = s["target"].device
-        side = geometry.side_stream(dev)
+        side = self.geo_streams[self.stage_turn % len(self.geo_streams)] or geometry.side_stream(dev)
         if s.get("done") is not None:
             side.wait_event(s["done"])
         with torch.cuda.stream(side):
@@ -270,17 +280,18 @@ class GraphedTrainStep:
                 s["inputs"][k].copy_(v, non_blocking=True)
             s["target"].copy_(target, non_blocking=True)
         s["geom"].refresh(side)
-        self._staged = True
+        self.stage_turn = (self.stage_turn + 1) % len(self.sets)
+        self.staged += 1
 
     def run(self):
         """replay the staged batch -> (loss vector, logits) living in static buffers (valid until this set is replayed again)"""
-        assert self._staged, "stage(inputs, target) first"
-        s = self.sets[self.turn]
+        assert self.staged > 0, "stage(inputs, target) first"
+        s = self.sets[self.run_turn]
         cur = torch.cuda.current_stream(s["target"].device)
         cur.wait_event(s["geom"].ready)
         s["graph"].replay()
         s["done"] = torch.cuda.Event()
         s["done"].record(cur)
-        self.turn ^= 1
-        self._staged = False
+        self.run_turn = (self.run_turn + 1) % len(self.sets)
+        self.staged -= 1
         return s["loss"], s["logits"]

@@ -42,7 +42,10 @@ def test_linear_falls_back_to_torch_outside_its_range():
 
 
 @pytest.mark.parametrize("shape,relu", [((163840, 64), True), ((163840, 3), True), ((163840, 8), False), ((40960, 32), True),
-                                        ((10240, 16, 64), True), ((5000, 6), False), ((20000, 512), True), ((4096, 100), True)])
+                                        ((10240, 16, 64), True), ((5000, 6), False), ((20000, 512), True), ((4096, 100), True),
+                                        # rows <= 4096: one kernel per direction (the coarse stages of the network)
+                                        ((2560, 128), True), ((640, 256), False), ((160, 512), True), ((4096, 32), True), ((100, 16), True), ((257, 4), False),
+                                        ((3000, 6), True)])
 def test_batch_norm_rows_matches_torch(shape, relu):
     """dense.batch_norm (csrc/bn_rows.hip) against nn.BatchNorm1d (+ ReLU) in float64: output, input / affine gradients, running statistics"""
     import copy
@@ -78,6 +81,6 @@ def test_batch_norm_eval_mode_and_small_inputs_use_torch():
     x = torch.randn(10000, 16, device="cuda")
     assert torch.equal(dense.batch_norm(x, bn, relu=True), torch.relu(bn(x)))
     bn.train()
-    xs = torch.randn(100, 16, device="cuda")
+    xs = torch.randn(40, 16, device="cuda")
     bn2 = torch.nn.BatchNorm1d(16).cuda().train()
     assert torch.allclose(dense.batch_norm(xs, bn, relu=False), bn2(xs), atol=1e-6)

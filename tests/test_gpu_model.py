@@ -126,11 +126,12 @@ def test_graphed_training_step_matches_eager_steps():
         if "momentum_buffer" in st and st["momentum_buffer"] is not None:
             st["momentum_buffer"].zero_()
     graphed = []
-    step.stage(*batches[0])
+    for b in batches[:step.depth]:                                                  # `depth` batches staged ahead of the one that runs
+        step.stage(*b)
     for i in range(len(batches)):
         loss, _ = step.run()
-        if i + 1 < len(batches):
-            step.stage(*batches[i + 1])
+        if i + step.depth < len(batches):
+            step.stage(*batches[i + step.depth])
         graphed.append(loss.detach().cpu().numpy().copy())
     torch.cuda.synchronize()
     np.testing.assert_allclose(graphed[0], eager[0], rtol=2e-3, atol=1e-5)          # same parameters, same batch: the forward pass itself
@@ -142,7 +143,7 @@ def test_graphed_training_step_matches_eager_steps():
     from contrastboundary_amd import geometry
     step.stage(inputs2, target2)
     torch.cuda.synchronize()
-    static = step.sets[step.turn]["geom"]
+    static = step.sets[(step.stage_turn - 1) % len(step.sets)]["geom"]
     fresh = M.prefetch_geometry(model, {"points": static.points, "offset": static.offset}, crit)
     torch.cuda.synchronize()
     assert torch.equal(static.points, inputs2["points"])
