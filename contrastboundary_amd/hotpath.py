@@ -285,11 +285,12 @@ class Schedule:
         return state
 
 
-def concurrent_streams(count, candidates=12, spin_cycles=2_000_000):
+def concurrent_streams(count, candidates=12, spin_cycles=2_000_000, beside=None):
     """`count` HIP streams that really run side by side.  The runtime multiplexes streams onto a few hardware queues (4 per process by default) in
     creation order, so two fresh streams can share a queue and then execute strictly one after the other — measured: the search chain and the
     branch it was supposed to overlap landed on one queue and the pipeline ran in order.  The mapping cannot be queried, so it is observed: a
-    one-thread spin kernel on two streams takes T if they have queues of their own and 2T if they share one."""
+    one-thread spin kernel on two streams takes T if they have queues of their own and 2T if they share one.
+    beside: stream(s) the chosen ones must ALSO run beside (e.g. the stream the caller's own work is on); not part of the result."""
     def together(a, b):
         torch.cuda.synchronize()
         t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -313,11 +314,12 @@ def concurrent_streams(count, candidates=12, spin_cycles=2_000_000):
         t0.record(); torch.cuda._sleep(spin_cycles); t1.record()
     torch.cuda.synchronize()
     alone = t0.elapsed_time(t1)
-    chosen = [pool[0]]
-    for s in pool[1:]:
+    fixed = [] if beside is None else (list(beside) if isinstance(beside, (list, tuple)) else [beside])
+    chosen = []
+    for s in pool:
         if len(chosen) == count:
             break
-        if all(together(c, s) < 1.5 * alone for c in chosen):
+        if all(together(c, s) < 1.5 * alone for c in fixed + chosen):
             chosen.append(s)
     if len(chosen) < count:                                         # fewer independent queues than asked for: the rest share
         chosen += [p for p in pool if p not in chosen][:count - len(chosen)]

@@ -249,7 +249,10 @@ class GraphedTrainStep:
         torch.cuda.current_stream(dev).wait_stream(side)
         self.depth = min(2, max(1, int(depth)))                       # (three geometry chains in flight hung the device once: not offered)
         from . import hotpath
-        self.geo_streams = hotpath.concurrent_streams(self.depth + 1)[1:] if self.depth > 1 else [None]     # (None: the device's side stream)
+        # streams with hardware queues of their own, also beside the stream the step replays on (two fresh streams can share a queue, or the step's)
+        from . import geometry
+        first = geometry.side_stream(dev)
+        self.geo_streams = [first] + (hotpath.concurrent_streams(self.depth - 1, beside=[torch.cuda.current_stream(dev), first]) if self.depth > 1 else [])
         self.sets = []
         for _ in range(self.depth + 1):
             st_in = {k: v.clone() for k, v in inputs.items()}
@@ -272,7 +275,7 @@ class GraphedTrainStep:
         assert self.staged < len(self.sets), "every buffer set holds a staged batch: run() first"
         s = self.sets[self.stage_turn]
         dev = s["target"].device
-        side = self.geo_streams[self.stage_turn % len(self.geo_streams)] or geometry.side_stream(dev)
+        side = self.geo_streams[self.stage_turn % len(self.geo_streams)]
         if s.get("done") is not None:
             side.wait_event(s["done"])
         with torch.cuda.stream(side):
