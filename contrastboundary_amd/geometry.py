@@ -86,6 +86,14 @@ class StaticGeometry:
                     a.copy_(b)
             self.ready = torch.cuda.Event()
             self.ready.record(stream)
+        # what the scratch pass registered (orders / tables keyed by its temporaries) leaves the registries with it: they are bounded LRUs, and
+        # entries piling up here once pushed the STATIC geometry's orders out — freed while captured graphs still read them
+        from . import neighbor_state
+        for key in fresh.order_keys:
+            neighbor_state._order_registry.pop(key, None)
+        for key in fresh.transpose_keys:
+            neighbor_state._transpose_registry.pop(key, None)
+        fresh.order_keys.clear(); fresh.transpose_keys.clear(); fresh.order_refs.clear()
         fresh.store.clear(); fresh.host.clear()
         return self.ready
 

@@ -60,6 +60,9 @@ def _order_register(points, order, stream):
     cache = neighbor_cache.active()
     if cache is not None:                                            # a cached pass owns what it registers: dropped with the cache
         cache.order_keys.append(key)
+        # ... and keeps the tensor alive as long as it lives itself: the registry is a bounded LRU, and a consumer may have baked the
+        # order's address into a captured hipGraph (geometry.StaticGeometry keeps its cache for exactly that long)
+        cache.order_refs.append(order)
 
 
 def _order_alias(idx, points):
@@ -174,6 +177,7 @@ class neighbor_cache:
         self.wide = {}                                              # geometry -> (nsample, algo) of the widest result in the store
         self.derived = 0                                            # requests answered from a wider result (cbl_knnquery_prefix)
         self.order_keys = []                                        # processing orders registered during this pass (dropped with it)
+        self.order_refs = []                                        # ... the tensors themselves, alive as long as this cache is
         self.transpose_keys = []                                    # transposed neighbour tables registered during this pass (dropped with it)
 
     def hint(self, xyz, nsample, algo="set", new_xyz=None, offset=None, new_offset=None):
@@ -200,6 +204,7 @@ class neighbor_cache:
             for key in self.order_keys:
                 _order_registry.pop(key, None)
             self.order_keys.clear()
+            self.order_refs.clear()
             for key in self.transpose_keys:
                 _transpose_registry.pop(key, None)
             self.transpose_keys.clear()

@@ -44,3 +44,32 @@ def test_small_clouds_never_ask_for_an_order():
     from contrastboundary_amd import pointops
     pts = torch.zeros(pointops.ORDER_MIN_POINTS - 1, 3)
     assert not pointops._order_wanted(pts, 1)
+
+
+def test_a_kept_cache_keeps_its_orders_alive_past_their_eviction():
+    """the registry is a bounded LRU; a cache that outlives its pass (keep = True: geometry.StaticGeometry, whose orders' addresses are baked
+    into captured hipGraphs) must hold the tensors itself — they were once freed under a replaying graph when later passes filled the registry"""
+    import weakref
+    from contrastboundary_amd import pointops
+    pointops._order_registry.clear()
+    s = _Stream(5)
+    cache = pointops.neighbor_cache()
+    cache.keep = True
+    pts = torch.zeros(pointops.ORDER_MIN_POINTS, 3)
+    with cache:
+        order = torch.arange(pointops.ORDER_MIN_POINTS, dtype=torch.int32)
+        pointops._order_register(pts, order, s)
+        alive = weakref.ref(order)
+        del order
+    assert len(pointops._order_registry) == 1                          # kept: still registered after the pass
+    keep = []
+    for i in range(pointops._ORDER_REGISTRY_MAX + 2):                  # later passes push it out of the registry ...
+        q = torch.zeros(pointops.ORDER_MIN_POINTS + 1 + i, 3)
+        keep.append(q)
+        pointops._order_register(q, torch.zeros(q.shape[0], dtype=torch.int32), s)
+    assert pointops._order_wanted(pts, s.cuda_stream)
+    assert alive() is not None                                         # ... the tensor itself lives as long as the cache does
+    del cache
+    import gc; gc.collect()
+    assert alive() is None
+    pointops._order_registry.clear()
