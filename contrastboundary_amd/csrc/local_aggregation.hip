@@ -201,9 +201,8 @@ __global__ __launch_bounds__(256) void kpconv_fwd_c64_kernel(int n, int n0, int 
     const bool ch_ok = cb < C;
     const char* fbytes = reinterpret_cast<const char*>(f);
     const unsigned row_bytes = 4u * (unsigned)C, col_bytes = 4u * (unsigned)(ch_ok ? cb : 0);
-    // No masks behind the loads: accumulator rows kp >= KP and neighbours that are not real have weight 0 (A operand), channel columns >= C are never
-    // stored and never mix with others; the clamped loads only have to be readable.  (A non-finite value in row 0 of the table would reach points with
-    // shadow neighbours as 0 * inf.)
+    // Accumulator rows kp >= KP have weight 0 (A operand), channel columns >= C are never stored and never mix with others, the rows of neighbours
+    // that are not real are zeroed behind the (clamped, unconditional) load: the loads only have to be readable.
     const unsigned vend = 8 * cbl_xcd_per(nwg), vstep = gridDim.x;
     auto point_at = [&](unsigned v) -> int {
         if (v >= vend) return -1;
@@ -267,10 +266,13 @@ __global__ __launch_bounds__(256) void kpconv_fwd_c64_kernel(int n, int n0, int 
 #pragma unroll
         for (int gi = 0; gi < 4; gi++) {
             const bool z = first && gi == 0;
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gi], rows.v[gi].x, z ? zero : acc[0], 0, 0, 0);   // wf = w @ f_nbr (:716)
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gi], rows.v[gi].y, z ? zero : acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gi], rows.v[gi].z, z ? zero : acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gi], rows.v[gi].w, z ? zero : acc[3], 0, 0, 0);
+            // a neighbour that is not real reads the clamped row 0 of the table: its weight is already 0, the row is zeroed as well so that a
+            // non-finite value there cannot leak (0 * inf) — four selects per group on a kernel that is not bound by its vector instructions
+            const bool rl = rows.real[gi];
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gi], rl ? rows.v[gi].x : 0.f, z ? zero : acc[0], 0, 0, 0);   // wf = w @ f_nbr (:716)
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gi], rl ? rows.v[gi].y : 0.f, z ? zero : acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gi], rl ? rows.v[gi].z : 0.f, z ? zero : acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gi], rl ? rows.v[gi].w : 0.f, z ? zero : acc[3], 0, 0, 0);
         }
     };
     int p0 = point_at(blockIdx.x), p1 = point_at(blockIdx.x + vstep), p2 = point_at(blockIdx.x + 2 * vstep);

@@ -175,3 +175,21 @@ def test_kpconv_backward_as_a_gather(K, C, KP, influence, mode):
             np.testing.assert_allclose(gkw.cpu().numpy(), gkw_ref, rtol=1e-3, atol=1e-4 * np.abs(gkw_ref).max())
         outs.append((gf, gkw))
     assert torch.equal(outs[0][0], outs[3][0]) and torch.equal(outs[0][1], outs[3][1])
+
+
+def test_kpconv_shadow_neighbours_do_not_read_row_zero():
+    """a neighbour that is not real (shadow index n0) contributes the reference's zero feature row (local_aggregation_operators.py:713) whatever the
+    table holds: the kernels load from a clamped row 0 unconditionally, and a non-finite value there must not leak as 0 * inf"""
+    from contrastboundary_amd import local_aggregation as L
+    q, s, idx, f, rng = make(600, 300, 12, 32, seed=3)
+    idx = idx.copy(); idx[::3, -4:] = 300                              # shadow neighbours on every third point
+    kpts = (rng.normal(size=(15, 3)) * 0.06).astype(np.float32); kpts[0] = 0
+    kw = rng.normal(size=(15, 32)).astype(np.float32)
+    ref = LA.kpconv(q, s, idx, f, kpts, kw, 0.09, "constant", "sum")
+    f_bad = f.copy(); f_bad[0] = np.inf
+    used0 = (idx == 0).any(1)                                          # points that really list row 0 become non-finite, nobody else
+    for influence in ("constant", "linear"):
+        out = L.kpconv(dev(q), dev(s), dev(idx), dev(f_bad), dev(kpts), dev(kw), 0.09, influence, "sum").cpu().numpy()
+        assert np.isfinite(out[~used0]).all()
+    out = L.kpconv(dev(q), dev(s), dev(idx), dev(f_bad), dev(kpts), dev(kw), 0.09, "constant", "sum").cpu().numpy()
+    np.testing.assert_allclose(out[~used0], ref[~used0], rtol=1e-4, atol=1e-4 * np.abs(ref).max())
