@@ -8,11 +8,13 @@ One "step" = one pass of the hot path (contrastboundary_amd/hotpath.py: search, 
 config C2 "forward/backward" — the block's backward legs) over one scene whose inputs are already resident in HBM.  Scenes are independent,
 so N ranks run N scene replicas with no data-path collective (weak scaling).  `--gpus N` without a torchrun environment
 re-executes this file under torch.distributed.run with N ranks (one per device; fewer than N devices is an error); the printed `n_gpus` is the
-number of ranks that joined the process group.  Every timed step is the same thing (the step's hipGraph replayed); the timed region is
-bracketed by barrier + synchronize and the MAX over ranks is used.  Rank 0 prints ONE JSON line with the driver's fields plus
-  `roofline`      the HBM-bound neighbour gather: algorithmic bytes / HIP-event duration of its launch, events recorded on the launch stream
-                  (one hipGraph per stage, replayed in step order right after the timed region), PMC traffic from profiles/ if it belongs
-                  to this kernel set;
+number of ranks that joined the process group.  Every timed step is the same thing: the step's hipGraphs replayed, consecutive steps
+software-pipelined (hotpath.Pipeline: the search of step i+1 beside the gather / KPConv / backward kernels of step i; `--no-pipeline`: one
+graph per step, every step on its own).  The timed region is bracketed by barrier + synchronize (the whole device) and the MAX over ranks is
+used.  Rank 0 prints ONE JSON line with the driver's fields plus
+  `roofline`      the HBM-bound neighbour gather: algorithmic bytes / HIP-event duration of its launch alone (back-to-back launches behind a
+                  filler kernel, events on the launch stream), with the K4 gather and the KPConv kernel beside it, the in-order per-stage
+                  times, PMC traffic from profiles/ if it belongs to this kernel set;
   `forward_only`  the forward block + CBL head alone (round 1's step), timed the same way;
   `grad_allreduce` (N > 1) the same K steps with one flat 31.2 MB fp32 all-reduce per step over RCCL beside the compute — what DDP adds to
                   data-parallel training of the reference's network (pytorch/tool/train.py:141,181-185; 7,800,497 parameters);
