@@ -306,6 +306,8 @@ def concurrent_streams(count, candidates=12, spin_cycles=2_000_000, beside=None)
         torch.cuda.synchronize()
         return t0.elapsed_time(t1)
     pool = [torch.cuda.Stream() for _ in range(candidates)]
+    if not hasattr(torch.cuda, "_sleep"):                           # no spin kernel to observe with: take the streams as they come
+        return pool[:count]
     with torch.cuda.stream(pool[0]):
         torch.cuda._sleep(spin_cycles)
     torch.cuda.synchronize()
