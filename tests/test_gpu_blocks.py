@@ -75,7 +75,8 @@ def test_transition_down_and_up(inputs):
     np.testing.assert_allclose(y.detach().cpu().numpy(), G["uphead/out"], **TOL)
 
 
-@pytest.mark.parametrize("n,K,C", [(4096, 8, 32), (3000, 16, 64), (2500, 8, 64), (2560, 16, 128), (640, 16, 256), (160, 16, 512), (37, 5, 128), (300, 16, 512)])
+@pytest.mark.parametrize("n,K,C", [(4096, 8, 32), (3000, 16, 64), (2500, 8, 64), (2560, 16, 128), (640, 16, 256), (160, 16, 512), (37, 5, 128), (300, 16, 512),
+                                   (300, 24, 128), (200, 40, 256), (150, 33, 512), (2000, 20, 64)])          # more than one 16-pair tile per point
 def test_fused_attention_equals_the_unfused_layer(n, K, C):
     """PointTransformerLayer with the C-wide part in csrc/attention.hip (nothing of shape (n,K,C) stored) against the same layer on the
     separate kernels (which the reference goldens above pin): output, every parameter gradient, input gradient, BatchNorm buffers"""
