@@ -27,6 +27,7 @@ constexpr int TT = 64;        // targets per target tile
 constexpr int TS = 64;        // sources per source tile
 constexpr int NB = 256;       // threads per workgroup
 constexpr int NT_MAX_TILES = 16384;    // LDS: 2 x 4 B per target tile in nt_bin
+constexpr int NT_SCAN_SPLIT = 2048;    // above this many target tiles the scan of the bin sizes gets a launch of its own (nt_scan_kernel)
 constexpr int STAGE_CAP = 12288;       // pair ids a target tile orders in LDS (48 KB); larger bins are ordered through global scratch
 
 
@@ -133,7 +134,29 @@ __global__ __launch_bounds__(NB) void nt_count_kernel(int m, int n, int ns, int 
     for (int e = threadIdx.x; e < nmine; e += NB) lists[gbase + e] = mine[e];
 }
 
-template <int UN>
+// exclusive scan of the bin sizes by ONE workgroup (ntt <= NT_MAX_TILES = 16 per lane of 1024): only launched for large tables, where every
+// source-tile workgroup scanning all bin sizes itself (nt_bin_kernel<UN, false>) is a term quadratic in the number of tiles — nothing at 640
+// tiles, 3 of 10 ms of a million-point step
+__global__ __launch_bounds__(1024) void nt_scan_kernel(int ntt, const int* __restrict__ tile_cursor, int* __restrict__ tile_base)
+{
+    __shared__ int wave_tot[16];
+    constexpr int PER = NT_MAX_TILES / 1024;
+    const int c0 = threadIdx.x * PER;
+    int v[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { v[k] = (c0 + k < ntt) ? tile_cursor[c0 + k] : 0; sum += v[k]; }
+    int incl = sum;
+    for (int k = 1; k < 64; k <<= 1) { const int o = __shfl_up(incl, k); if ((int)(threadIdx.x & 63) >= k) incl += o; }
+    if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int run = incl - sum;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) run += wave_tot[w];
+#pragma unroll
+    for (int k = 0; k < PER; k++) { if (c0 + k < ntt) tile_base[c0 + k] = run; run += v[k]; }
+    if (threadIdx.x == 1023) tile_base[ntt] = run;                   // (its chunk ends at or past ntt: the total number of pairs)
+}
+
+template <int UN, bool SCANNED>
 __global__ __launch_bounds__(NB) void nt_bin_kernel(int m, int n, int ns, int ntt, CblFastDiv dv, const int* __restrict__ idx, const int* __restrict__ order_src,
                                                     const int* __restrict__ rank, const int* __restrict__ tile_cursor, const int* __restrict__ tile_list_off,
                                                     const int* __restrict__ tile_list_n, const int2* __restrict__ lists, int* __restrict__ tile_base,
@@ -146,6 +169,11 @@ __global__ __launch_bounds__(NB) void nt_bin_kernel(int m, int n, int ns, int nt
     const int st = blockIdx.x;
     const int nsrc = min(TS, m - st * TS);
     if ((int)threadIdx.x < TS) src_ids[threadIdx.x] = (int)threadIdx.x < nsrc ? (order_src ? order_src[st * TS + threadIdx.x] : st * TS + (int)threadIdx.x) : 0;
+    if (SCANNED) {                                                   // tile_base holds the scan (nt_scan_kernel): only the bins this tile touches are set up
+        const int nl0 = tile_list_n[st], lo0 = tile_list_off[st];
+        for (int e = threadIdx.x; e < nl0; e += NB) { const int2 r = lists[lo0 + e]; where[r.x] = tile_base[r.x] + r.y; hist[r.x] = 0; }
+        __syncthreads();
+    } else {
     for (int e = threadIdx.x; e < ntt; e += NB) { where[e] = tile_cursor[e]; hist[e] = 0; }      // coalesced; the scan below runs out of LDS
     __syncthreads();
     // exclusive scan of the bin sizes: thread t owns a contiguous chunk
@@ -165,6 +193,7 @@ __global__ __launch_bounds__(NB) void nt_bin_kernel(int m, int n, int ns, int nt
     const int nl = tile_list_n[st], lo = tile_list_off[st];
     for (int e = threadIdx.x; e < nl; e += NB) { const int2 r = lists[lo + e]; where[r.x] += r.y; }
     __syncthreads();
+    }
     const unsigned total = (unsigned)nsrc * (unsigned)ns;
     for (unsigned base = 0; base < total; base += UN * NB) {
         NtPairs<UN> q;
@@ -461,8 +490,13 @@ CBL_EXPORT int cbl_neighbor_transpose(int m, int n, int nsample, const int* idx,
 #define CBL_NT(UN_)                                                                                                                                   \
     hipLaunchKernelGGL((nt_count_kernel<UN_>), dim3(nst), dim3(NB), lds_count, st, m, n, nsample, ntt, dv, idx, order_src, rank, w.tile_cursor,       \
                        w.list_cursor, w.tile_list_off, w.tile_list_n, w.lists);                                                                       \
-    hipLaunchKernelGGL((nt_bin_kernel<UN_>), dim3(nst), dim3(NB), lds_bin, st, m, n, nsample, ntt, dv, idx, order_src, rank, w.tile_cursor,           \
-                       w.tile_list_off, w.tile_list_n, w.lists, w.tile_base, w.bins)
+    if (ntt > NT_SCAN_SPLIT) {                                                                                                                        \
+        hipLaunchKernelGGL(nt_scan_kernel, dim3(1), dim3(1024), 0, st, ntt, w.tile_cursor, w.tile_base);                                              \
+        hipLaunchKernelGGL((nt_bin_kernel<UN_, true>), dim3(nst), dim3(NB), lds_bin, st, m, n, nsample, ntt, dv, idx, order_src, rank, w.tile_cursor, \
+                           w.tile_list_off, w.tile_list_n, w.lists, w.tile_base, w.bins);                                                             \
+    } else                                                                                                                                            \
+        hipLaunchKernelGGL((nt_bin_kernel<UN_, false>), dim3(nst), dim3(NB), lds_bin, st, m, n, nsample, ntt, dv, idx, order_src, rank, w.tile_cursor, \
+                           w.tile_list_off, w.tile_list_n, w.lists, w.tile_base, w.bins)
     const int per_thread = (TS * nsample + NB - 1) / NB;             // pairs per thread of a full source tile: one batch where it fits 16
     if (per_thread <= 4) { CBL_NT(4); } else if (per_thread <= 8) { CBL_NT(8); } else { CBL_NT(16); }
 #undef CBL_NT

@@ -66,6 +66,18 @@ def test_transpose_random(m, n, ns):
         check(rng.integers(0, n, size=(m, ns)), n, order=perm)
 
 
+def test_transpose_of_a_large_table():
+    """more than 2048 target tiles: the scan of the bin sizes runs as a launch of its own (below that every source tile scans them itself)"""
+    rng = np.random.default_rng(11)
+    m = n = 200000
+    ns = 8
+    base = np.arange(m)[:, None]
+    idx = (base + rng.integers(-3000, 3000, size=(m, ns))) % n              # neighbours near the source in index space, a few far ones
+    idx[::97, 0] = rng.integers(0, n, size=idx[::97, 0].shape)
+    check(idx, n)
+    check(idx, n, order=rng.permutation(n))
+
+
 def test_transpose_padding_and_sources_in_another_order():
     rng = np.random.default_rng(1)
     m, n, ns = 3000, 2000, 24
