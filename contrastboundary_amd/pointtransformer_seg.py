@@ -247,7 +247,7 @@ class GraphedTrainStep:
                 loss.sum().backward()
                 optimizer.step()
         torch.cuda.current_stream(dev).wait_stream(side)
-        self.depth = min(2, max(1, int(depth)))                       # (three geometry chains in flight hung the device once: not offered)
+        self.depth = min(3, max(1, int(depth)))
         from . import hotpath
         # streams with hardware queues of their own, also beside the stream the step replays on (two fresh streams can share a queue, or the step's)
         from . import geometry

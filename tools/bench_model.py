@@ -18,7 +18,7 @@ ap.add_argument("--steps", type=int, default=10); ap.add_argument("--warmup", ty
 ap.add_argument("--no-cache", action="store_true")
 ap.add_argument("--blas", default="cublas", help="torch.backends.cuda.preferred_blas_library: 'cublas' = rocBLAS (default here: 2-20x faster than hipBLASLt on this network's small weight-gradient GEMMs), 'cublaslt' = torch's default")
 ap.add_argument("--graph", action="store_true", help="the whole training step as a replayed hipGraph, geometry double-buffered (implies prefetch)")
-ap.add_argument("--depth", type=int, default=2, help="--graph: batches whose geometry is in flight ahead of the running step, 1 or 2 (buffer sets = depth + 1)")
+ap.add_argument("--depth", type=int, default=2, help="--graph: batches whose geometry is in flight ahead of the running step, 1..3 (buffer sets = depth + 1)")
 ap.add_argument("--prefetch", action="store_true", help="geometry (FPS + every neighbour search) of the NEXT step on a side stream, one step ahead")
 a = ap.parse_args()
 torch.backends.cuda.preferred_blas_library(a.blas)
