@@ -12,6 +12,7 @@
 //             pass 2: grad_x = weight * invstd * (g - mean(g) - xhat * mean(g*xhat))
 // Row-major (rows, C): a lane owns VEC consecutive channels and walks rows, so every access is a coalesced row segment.
 #include "cbl_common.h"
+#include "wave_ops.h"
 
 namespace {
 
@@ -193,12 +194,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_element_kernel(long long rows, in
 // workgroup (fp32 per wave, fp64 across waves, like the partial sums above) and the second pass runs from registers.
 constexpr int BN_SMALL_ROWS = 4096, BN_SMALL_PER = BN_SMALL_ROWS / BN_BLOCK;
 
-__device__ __forceinline__ float bn_wave_sum(float v)
-{
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s);
-    return v;
-}
+__device__ __forceinline__ float bn_wave_sum(float v) { return group_sum<64>(v); }    // DPP steps: six ds_bpermute round trips per value were most of the kernel
 
 // sums[k] over the workgroup for k < NV, every thread gets the totals (as double)
 template <int NV>
@@ -239,7 +235,9 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_small_fwd_kernel(int rows, int C,
         const double m = tot[v] / (double)rows;
         double var = tot[4 + v] / (double)rows - m * m;
         if (var < 0.0) var = 0.0;
-        mu[v] = (float)m; is[v] = (float)(1.0 / sqrt(var + (double)eps));
+        mu[v] = (float)m;
+        // 1 / sqrt in fp32 with one Newton step on the hardware estimate (the fp64 divide + square root were ~250 instructions per workgroup)
+        const float vf = (float)var + eps; float rs = __builtin_amdgcn_rsqf(vf); rs = rs * (1.5f - 0.5f * vf * rs * rs); is[v] = rs;
         w[v] = weight ? weight[c0 + v] : 1.f; b[v] = bias ? bias[c0 + v] : 0.f;
         if (threadIdx.x == 0) {
             mean[c0 + v] = mu[v]; invstd[c0 + v] = is[v];
