@@ -75,14 +75,26 @@ class AttnW2(Function):
 
 
 class AttnAgg(Function):
+    """out[i] = sum_k (x_v[idx[i,k]] + p_r[i,k]) * a[i,k]   (blocks.py:42-43) with p_r = Linear(3,C)(p1) formed on the fly.
+    softmax = True: `a` are the LOGITS (n,K,G) and the softmax over K (blocks.py:41) runs inside the kernels — forward writes the weights for
+    the backward pass, backward returns the gradient of the logits: no softmax launches of torch's, forward or backward."""
+
     @staticmethod
-    def forward(ctx, x_v, p1, W3C, b3C, a, idx):
+    def forward(ctx, x_v, p1, W3C, b3C, a, idx, softmax=False):
         n, C = x_v.shape
         K, G = idx.shape[1], a.shape[2]
         out = torch.empty((n, C), dtype=torch.float32, device=x_v.device)
-        _lib.check(_lib.lib().cbl_attn_agg_forward(_i(n), _i(K), _i(C), _i(G), _lib.ptr(x_v), _lib.ptr(idx), _lib.ptr(p1), _lib.ptr(W3C), _lib.ptr(b3C),
-                                                   _lib.ptr(a), _lib.ptr(out), _lib.stream_of(x_v)), "cbl_attn_agg_forward")
+        L = _lib.lib()
+        if softmax:
+            weights = torch.empty_like(a)
+            _lib.check(L.cbl_attn_agg_softmax_forward(_i(n), _i(K), _i(C), _i(G), _lib.ptr(x_v), _lib.ptr(idx), _lib.ptr(p1), _lib.ptr(W3C), _lib.ptr(b3C),
+                                                      _lib.ptr(a), _lib.ptr(weights), _lib.ptr(out), _lib.stream_of(x_v)), "cbl_attn_agg_softmax_forward")
+            a = weights
+        else:
+            _lib.check(L.cbl_attn_agg_forward(_i(n), _i(K), _i(C), _i(G), _lib.ptr(x_v), _lib.ptr(idx), _lib.ptr(p1), _lib.ptr(W3C), _lib.ptr(b3C),
+                                              _lib.ptr(a), _lib.ptr(out), _lib.stream_of(x_v)), "cbl_attn_agg_forward")
         ctx.save_for_backward(x_v, p1, W3C, b3C, a, idx)
+        ctx.softmax = bool(softmax)
         return out
 
     @staticmethod
@@ -96,7 +108,8 @@ class AttnAgg(Function):
         e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         g_xv, g_p1, g_W3C, g_b3C, g_a = torch.zeros(n, C, dtype=torch.float32, device=dev), e(n, K, 3), e(C, 3), e(C), e(n, K, G)
         g_out = g_out.contiguous()
-        _lib.check(L.cbl_attn_agg_backward(_i(n), _i(K), _i(C), _i(G), _lib.ptr(x_v), _lib.ptr(idx), _lib.ptr(p1), _lib.ptr(W3C), _lib.ptr(b3C), _lib.ptr(a),
-                                           _lib.ptr(g_out), _lib.ptr(g_xv), _lib.ptr(g_p1), _lib.ptr(g_W3C), _lib.ptr(g_b3C), _lib.ptr(g_a), _lib.ptr(ws),
-                                           ctypes.c_size_t(ws.numel()), _lib.stream_of(x_v)), "cbl_attn_agg_backward")
-        return g_xv, g_p1, g_W3C, g_b3C, g_a, None
+        fn, what = (L.cbl_attn_agg_softmax_backward, "cbl_attn_agg_softmax_backward") if ctx.softmax else (L.cbl_attn_agg_backward, "cbl_attn_agg_backward")
+        _lib.check(fn(_i(n), _i(K), _i(C), _i(G), _lib.ptr(x_v), _lib.ptr(idx), _lib.ptr(p1), _lib.ptr(W3C), _lib.ptr(b3C), _lib.ptr(a),
+                      _lib.ptr(g_out), _lib.ptr(g_xv), _lib.ptr(g_p1), _lib.ptr(g_W3C), _lib.ptr(g_b3C), _lib.ptr(g_a), _lib.ptr(ws),
+                      ctypes.c_size_t(ws.numel()), _lib.stream_of(x_v)), what)
+        return g_xv, g_p1, g_W3C, g_b3C, g_a, None, None

@@ -51,8 +51,8 @@ class PointTransformerLayer(nn.Module):
             w2 = attention.AttnW2.apply(x_q.contiguous(), x_k.contiguous(), p1, lin_pc.weight, lin_pc.bias, bn_c.weight, bn_c.bias, lin_a.weight, lin_a.bias,
                                         idx, bn_c, self.training)
             w = dense.sequential(self.linear_w[3:], w2)                       # BN -> ReLU -> Linear(C/8, C/8), narrow
-            w = self.softmax(w)                                               # over K, :41
-            return attention.AttnAgg.apply(x_v.contiguous(), p1, lin_pc.weight, lin_pc.bias, w.contiguous(), idx)
+            # softmax over K (:41) inside the aggregation kernels, forward and backward
+            return attention.AttnAgg.apply(x_v.contiguous(), p1, lin_pc.weight, lin_pc.bias, w.contiguous(), idx, True)
         p_r = dense.sequential(self.linear_p, p_r)                            # :38  Linear(3,3) -> BN -> ReLU -> Linear(3,C) over (n*K) rows
         q_minus_k = pointops.subtraction(x_q.contiguous(), x_k.contiguous(), idx)      # x_q - x_k[idx]  (n,K,c)
         n, K, c = p_r.shape

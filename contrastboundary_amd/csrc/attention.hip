@@ -326,21 +326,42 @@ __global__ __launch_bounds__(AT_BLOCK) void attn_w2_bwd_apply_kernel(int n, int 
 
 // ----------------------------------------------------------------------------------------------------------- attn_agg
 // out[i,c] = sum_k (x_v[j,c] + p_r[i,k,c]) * a[i,k,c % G]                       blocks.py:42-43 (K9 with p_r on the fly)
+// softmax over the K neighbours of point i for group column g (blocks.py:41), fused into the aggregation: max and sum from the logits
+// (K reads each, L1 hits), the weights themselves are formed where they are used
+struct SoftmaxCol { float m, inv; };
+__device__ __forceinline__ SoftmaxCol softmax_col(const float* __restrict__ lg, int i, int K, int G, int g)
+{
+    const float* col = lg + (size_t)i * K * G + g;
+    float m = -INFINITY;
+    for (int k = 0; k < K; k++) m = fmaxf(m, col[(size_t)k * G]);
+    float ssum = 0.f;
+    for (int k = 0; k < K; k++) ssum += __builtin_amdgcn_exp2f((col[(size_t)k * G] - m) * 1.44269504088896340736f);
+    SoftmaxCol r; r.m = m; r.inv = 1.0f / ssum;
+    return r;
+}
+__device__ __forceinline__ float softmax_w(const SoftmaxCol& sc, float logit) { return __builtin_amdgcn_exp2f((logit - sc.m) * 1.44269504088896340736f) * sc.inv; }
+
 template <int C, int G>
 __global__ __launch_bounds__(AT_BLOCK) void attn_agg_forward_kernel(int n, int K, const float* __restrict__ xv, const int* __restrict__ idx,
                                                                     const float* __restrict__ p1, const float* __restrict__ W3C, const float* __restrict__ b3C,
-                                                                    const float* __restrict__ a, float* __restrict__ out)
+                                                                    const float* __restrict__ a, float* __restrict__ a_out, float* __restrict__ out)
 {
+    // a_out != nullptr: `a` holds the LOGITS; the softmax over K is applied here and its result written to a_out for the backward pass
     constexpr int GPB = AT_BLOCK / C;
     const int c = threadIdx.x % C, grp = threadIdx.x / C;
     PairParams q; q.w0 = W3C[3 * c]; q.w1 = W3C[3 * c + 1]; q.w2 = W3C[3 * c + 2]; q.b = b3C[c];
     for (int i = blockIdx.x * GPB + grp; i < n; i += gridDim.x * GPB) {
+        SoftmaxCol sc = {0.f, 1.f};
+        if (a_out) sc = softmax_col(a, i, K, G, c % G);
         float acc = 0.f;
         for (int k0 = 0; k0 < K; k0 += AT_U) {
             PairBatch pb; load_pairs<C>(pb, i, k0, K, c, idx, p1, xv);
             float av[AT_U];
 #pragma unroll
-            for (int u = 0; u < AT_U; u++) av[u] = a[((size_t)i * K + min(k0 + u, K - 1)) * G + (c % G)];
+            for (int u = 0; u < AT_U; u++) {
+                av[u] = a[((size_t)i * K + min(k0 + u, K - 1)) * G + (c % G)];
+                if (a_out) { av[u] = softmax_w(sc, av[u]); if (c < G && k0 + u < K) a_out[((size_t)i * K + k0 + u) * G + c] = av[u]; }
+            }
 #pragma unroll
             for (int u = 0; u < AT_U; u++)
                 if (k0 + u < K) acc += (pb.xr[u] + pe_of(q, pb.a0[u], pb.a1[u], pb.a2[u])) * av[u];
@@ -353,8 +374,11 @@ template <int C, int G>
 __global__ __launch_bounds__(AT_BLOCK) void attn_agg_backward_kernel(int n, int K, const float* __restrict__ xv, const int* __restrict__ idx,
                                                                      const float* __restrict__ p1, const float* __restrict__ W3C, const float* __restrict__ b3C,
                                                                      const float* __restrict__ a, const float* __restrict__ go,
-                                                                     float* __restrict__ gxv, float* __restrict__ gp1, float* __restrict__ ga, float* __restrict__ partial)
+                                                                     float* __restrict__ gxv, float* __restrict__ gp1, float* __restrict__ ga, float* __restrict__ partial,
+                                                                     int softmax)
 {
+    // softmax: `a` is the softmax output saved by the forward pass and `ga` receives the gradient of the LOGITS,
+    // a[k] (da[k] - sum_k' a[k'] da[k']): the lanes c < G of a point's group hold column g = c and finish it when the point's pairs are done
     constexpr int GPB = AT_BLOCK / C;
     __shared__ float red[4][AT_BLOCK];
     const int c = threadIdx.x % C, grp = threadIdx.x / C;
@@ -362,6 +386,7 @@ __global__ __launch_bounds__(AT_BLOCK) void attn_agg_backward_kernel(int n, int 
     float d0 = 0.f, d1 = 0.f, d2 = 0.f, db = 0.f;
     for (int i = blockIdx.x * GPB + grp; i < n; i += gridDim.x * GPB) {
         const float g = go[(size_t)i * C + c];
+        float dot = 0.f;
         for (int k0 = 0; k0 < K; k0 += AT_U) {
           PairBatch pb; load_pairs<C>(pb, i, k0, K, c, idx, p1, xv);
           float avs[AT_U];
@@ -384,9 +409,11 @@ __global__ __launch_bounds__(AT_BLOCK) void attn_agg_backward_kernel(int n, int 
             float da = g * (xvj + pe_of(q, a0, a1, a2));
 #pragma unroll
             for (int st = G; st < C; st <<= 1) da += __shfl_xor(da, st);
-            if (c < G) ga[r * G + c] = da;
+            if (c < G) { ga[r * G + c] = da; dot += av * da; }
           }
         }
+        if (softmax && c < G)                                        // this lane wrote ga[.., c] itself: reads see its own stores
+            for (int k = 0; k < K; k++) { const size_t r = (size_t)i * K + k; ga[r * G + c] = a[r * G + c] * (ga[r * G + c] - dot); }
     }
     red[0][threadIdx.x] = d0; red[1][threadIdx.x] = d1; red[2][threadIdx.x] = d2; red[3][threadIdx.x] = db;
     __syncthreads();
@@ -618,17 +645,22 @@ __global__ __launch_bounds__(C) void attn_w2_bwd_apply_wide_kernel(int n, int K,
 template <int C, int G>
 __global__ __launch_bounds__(C) void attn_agg_forward_wide_kernel(int n, int K, const float* __restrict__ xv, const int* __restrict__ idx,
                                                                   const float* __restrict__ p1, const float* __restrict__ W3C, const float* __restrict__ b3C,
-                                                                  const float* __restrict__ a, float* __restrict__ out)
+                                                                  const float* __restrict__ a, float* __restrict__ a_out, float* __restrict__ out)
 {
     const int c = threadIdx.x;
     PairParams q; q.w0 = W3C[3 * c]; q.w1 = W3C[3 * c + 1]; q.w2 = W3C[3 * c + 2]; q.b = b3C[c];
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        SoftmaxCol sc = {0.f, 1.f};
+        if (a_out) sc = softmax_col(a, i, K, G, c % G);             // (as in the narrow kernel)
         float acc = 0.f;
         for (int k0 = 0; k0 < K; k0 += AT_U) {
             PairBatch pb; load_pairs<C>(pb, i, k0, K, c, idx, p1, xv);
             float av[AT_U];
 #pragma unroll
-            for (int u = 0; u < AT_U; u++) av[u] = a[((size_t)i * K + min(k0 + u, K - 1)) * G + (c % G)];
+            for (int u = 0; u < AT_U; u++) {
+                av[u] = a[((size_t)i * K + min(k0 + u, K - 1)) * G + (c % G)];
+                if (a_out) { av[u] = softmax_w(sc, av[u]); if (c < G && k0 + u < K) a_out[((size_t)i * K + k0 + u) * G + c] = av[u]; }
+            }
 #pragma unroll
             for (int u = 0; u < AT_U; u++)
                 if (k0 + u < K) acc += (pb.xr[u] + pe_of(q, pb.a0[u], pb.a1[u], pb.a2[u])) * av[u];
@@ -641,7 +673,8 @@ template <int C, int G>
 __global__ __launch_bounds__(C) void attn_agg_backward_wide_kernel(int n, int K, const float* __restrict__ xv, const int* __restrict__ idx,
                                                                    const float* __restrict__ p1, const float* __restrict__ W3C, const float* __restrict__ b3C,
                                                                    const float* __restrict__ a, const float* __restrict__ go,
-                                                                   float* __restrict__ gxv, float* __restrict__ gp1, float* __restrict__ ga, float* __restrict__ partial)
+                                                                   float* __restrict__ gxv, float* __restrict__ gp1, float* __restrict__ ga, float* __restrict__ partial,
+                                                                   int softmax)
 {
     __shared__ float V[WT * wide_stride<C>()];
     __shared__ float DA[WT * C];
@@ -652,6 +685,7 @@ __global__ __launch_bounds__(C) void attn_agg_backward_wide_kernel(int n, int K,
     float d0 = 0.f, d1 = 0.f, d2 = 0.f, db = 0.f;
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         const float g = go[(size_t)i * C + c];
+        float dotp = 0.f;                                            // softmax: this thread's share of sum_k a[k, g] da[k, g], g = c % G
         for (int k0 = 0; k0 < K; k0 += WT) {
             int jj[WT]; float xr[WT];
 #pragma unroll
@@ -674,10 +708,21 @@ __global__ __launch_bounds__(C) void attn_agg_backward_wide_kernel(int n, int K,
                 float da = 0.f;
 #pragma unroll
                 for (int st = 0; st < C / G; st++) da += DA[u * C + gg + G * st];
-                if (k0 + u < K) ga[((size_t)i * K + k0) * G + e] = da;
+                if (k0 + u < K) { ga[((size_t)i * K + k0) * G + e] = da; dotp += a[((size_t)i * K + k0) * G + e] * da; }
             }
             __syncthreads();
             if (c < 3 * WT && k0 + c / 3 < K) gp1[3 * ((size_t)i * K + k0) + c] = t3.total(P, c);
+        }
+        if (softmax) {                                               // gradient of the logits: a (da - sum over the point's pairs of a da), column by column
+            DA[c] = dotp;                                            // (every thread's entries e = c, c + C, .. share the column c % G: G divides C)
+            __syncthreads();
+            float dot = 0.f;
+#pragma unroll
+            for (int st = 0; st < C / G; st++) dot += DA[(c % G) + G * st];
+            for (int k0 = 0; k0 < K; k0 += WT)
+                for (int e = c; e < WT * G; e += C)
+                    if (k0 + e / G < K) { const size_t at = ((size_t)i * K + k0) * G + e; ga[at] = a[at] * (ga[at] - dot); }   // written by this thread above
+            __syncthreads();
         }
     }
     float* mine = partial + (size_t)blockIdx.x * (4 * C);
@@ -776,8 +821,8 @@ CBL_EXPORT int cbl_attn_w2_backward(int n, int K, int C, int G, const float* x_q
     return cbl_status();
 }
 
-CBL_EXPORT int cbl_attn_agg_forward(int n, int K, int C, int G, const float* x_v, const int* idx, const float* p1, const float* W3C, const float* b3C,
-                                    const float* a, float* out, void* stream)
+static int attn_agg_forward_impl(int n, int K, int C, int G, const float* x_v, const int* idx, const float* p1, const float* W3C, const float* b3C,
+                                 const float* a, float* a_out, float* out, void* stream)
 {
     const int rc = at_check(n, K, C, G);
     if (rc) return rc;
@@ -785,13 +830,28 @@ CBL_EXPORT int cbl_attn_agg_forward(int n, int K, int C, int G, const float* x_v
     if (!x_v || !idx || !p1 || !W3C || !b3C || !a || !out) return CBL_ERR_BAD_ARG;
     hipStream_t st = cbl_stream(stream);
     const int nb = C > 64 ? (n < 1 ? 1 : (n > 2048 ? 2048 : n)) : (int)cbl_grid_for((long long)n * C, AT_BLOCK, 4096);   // no partial rows here: any grid
-    AT_DISPATCH(attn_agg_forward, n, K, x_v, idx, p1, W3C, b3C, a, out);
+    AT_DISPATCH(attn_agg_forward, n, K, x_v, idx, p1, W3C, b3C, a, a_out, out);
     return cbl_status();
 }
 
-CBL_EXPORT int cbl_attn_agg_backward(int n, int K, int C, int G, const float* x_v, const int* idx, const float* p1, const float* W3C, const float* b3C,
-                                     const float* a, const float* grad_out, float* grad_xv, float* grad_p1, float* grad_W3C, float* grad_b3C, float* grad_a,
-                                     void* workspace, size_t workspace_bytes, void* stream)
+CBL_EXPORT int cbl_attn_agg_forward(int n, int K, int C, int G, const float* x_v, const int* idx, const float* p1, const float* W3C, const float* b3C,
+                                    const float* a, float* out, void* stream)
+{
+    return attn_agg_forward_impl(n, K, C, G, x_v, idx, p1, W3C, b3C, a, nullptr, out, stream);
+}
+
+// the same with the softmax over the K neighbours (blocks.py:41) inside: `logits` (n, K, G) in, the softmax weights out to `a` (n, K, G) for the
+// backward pass (cbl_attn_agg_softmax_backward), `out` as cbl_attn_agg_forward would give for those weights
+CBL_EXPORT int cbl_attn_agg_softmax_forward(int n, int K, int C, int G, const float* x_v, const int* idx, const float* p1, const float* W3C, const float* b3C,
+                                            const float* logits, float* a, float* out, void* stream)
+{
+    if (!a) return CBL_ERR_BAD_ARG;
+    return attn_agg_forward_impl(n, K, C, G, x_v, idx, p1, W3C, b3C, logits, a, out, stream);
+}
+
+static int attn_agg_backward_impl(int n, int K, int C, int G, const float* x_v, const int* idx, const float* p1, const float* W3C, const float* b3C,
+                                  const float* a, const float* grad_out, float* grad_xv, float* grad_p1, float* grad_W3C, float* grad_b3C, float* grad_a,
+                                  void* workspace, size_t workspace_bytes, int softmax, void* stream)
 {
     const int rc = at_check(n, K, C, G);
     if (rc) return rc;
@@ -802,9 +862,25 @@ CBL_EXPORT int cbl_attn_agg_backward(int n, int K, int C, int G, const float* x_
     const int nb = at_blocks(n, C);
     const int nv2 = 4 * C;
     float* partial = reinterpret_cast<float*>(workspace);
-    AT_DISPATCH(attn_agg_backward, n, K, x_v, idx, p1, W3C, b3C, a, grad_out, grad_xv, grad_p1, grad_a, partial);
+    AT_DISPATCH(attn_agg_backward, n, K, x_v, idx, p1, W3C, b3C, a, grad_out, grad_xv, grad_p1, grad_a, partial, softmax);
     SumSegments s2; s2.dst[0] = grad_W3C; s2.dst[1] = grad_b3C; s2.dst[2] = s2.dst[3] = nullptr;
     s2.begin[0] = 0; s2.begin[1] = 3 * C; s2.begin[2] = s2.begin[3] = s2.begin[4] = nv2;
     hipLaunchKernelGGL(attn_sum_partials_kernel, dim3(cbl_div_up(nv2, 16)), dim3(256), 0, st, nv2, nb, partial, s2, (float*)nullptr);
     return cbl_status();
+}
+
+CBL_EXPORT int cbl_attn_agg_backward(int n, int K, int C, int G, const float* x_v, const int* idx, const float* p1, const float* W3C, const float* b3C,
+                                     const float* a, const float* grad_out, float* grad_xv, float* grad_p1, float* grad_W3C, float* grad_b3C, float* grad_a,
+                                     void* workspace, size_t workspace_bytes, void* stream)
+{
+    return attn_agg_backward_impl(n, K, C, G, x_v, idx, p1, W3C, b3C, a, grad_out, grad_xv, grad_p1, grad_W3C, grad_b3C, grad_a, workspace, workspace_bytes, 0, stream);
+}
+
+// backward of cbl_attn_agg_softmax_forward: `a` = the softmax weights it wrote, grad_logits (n, K, G) = a (da - sum over K of a da)
+CBL_EXPORT int cbl_attn_agg_softmax_backward(int n, int K, int C, int G, const float* x_v, const int* idx, const float* p1, const float* W3C, const float* b3C,
+                                             const float* a, const float* grad_out, float* grad_xv, float* grad_p1, float* grad_W3C, float* grad_b3C,
+                                             float* grad_logits, void* workspace, size_t workspace_bytes, void* stream)
+{
+    return attn_agg_backward_impl(n, K, C, G, x_v, idx, p1, W3C, b3C, a, grad_out, grad_xv, grad_p1, grad_W3C, grad_b3C, grad_logits, workspace, workspace_bytes, 1,
+                                  stream);
 }

@@ -410,6 +410,13 @@ int cbl_attn_agg_forward(int n, int K, int C, int G, const float* x_v, const int
 int cbl_attn_agg_backward(int n, int K, int C, int G, const float* x_v, const int* idx, const float* p1, const float* W3C, const float* b3C,
                           const float* a, const float* grad_out, float* grad_xv, float* grad_p1, float* grad_W3C, float* grad_b3C, float* grad_a,
                           void* workspace, size_t workspace_bytes, void* stream);
+/* The same pair with the softmax over the K neighbours (pytorch/model/blocks.py:41) inside: forward takes the logits (n, K, G) and writes the softmax
+ * weights to `a` (kept for the backward pass), backward returns the gradient of the logits, a (da - sum over K of a da). */
+int cbl_attn_agg_softmax_forward(int n, int K, int C, int G, const float* x_v, const int* idx, const float* p1, const float* W3C, const float* b3C,
+                                 const float* logits, float* a, float* out, void* stream);
+int cbl_attn_agg_softmax_backward(int n, int K, int C, int G, const float* x_v, const int* idx, const float* p1, const float* W3C, const float* b3C,
+                                  const float* a, const float* grad_out, float* grad_xv, float* grad_p1, float* grad_W3C, float* grad_b3C,
+                                  float* grad_logits, void* workspace, size_t workspace_bytes, void* stream);
 
 /* a4, dense part of the vector attention: nn.Linear over (n*K) rows with tiny widths — linear_p = Linear(3,3), Linear(3,C) and
  * linear_w = Linear(C,C/8), Linear(C/8,C/8)  pytorch/model/blocks.py:23-28,38-40 — as streaming kernels instead of library GEMMs.

@@ -107,3 +107,28 @@ def test_fused_attention_equals_the_unfused_layer(n, K, C):
         assert pa.grad is not None and (rel(pa.grad, pb.grad) < 5e-4 or float((pa.grad - pb.grad).abs().max()) < 1e-4 * gmax), name
     for (name, ba), (_, bb) in zip(fused.named_buffers(), plain.named_buffers()):
         assert rel(ba.float(), bb.float()) < 1e-5, name
+
+
+@pytest.mark.parametrize("n,K,C", [(3000, 16, 64), (2000, 8, 32), (500, 16, 128), (300, 24, 256), (150, 16, 512), (40, 5, 128)])
+def test_aggregation_with_the_softmax_inside_equals_softmax_then_aggregation(n, K, C):
+    """cbl_attn_agg_softmax_{forward,backward} (softmax over K inside the kernels, blocks.py:41-43) against torch's softmax followed by the same
+    aggregation kernels: output, and the gradients of logits, values, relative-position vectors and the Linear(3, C) parameters"""
+    from contrastboundary_amd import attention, synthetic as S, pointops
+    torch.manual_seed(n + K)
+    G = C // 8
+    xyz = torch.from_numpy(S.s_room(n, seed=1)[0]).cuda(); o = torch.tensor([n], dtype=torch.int32, device="cuda")
+    idx, _ = pointops.knnquery(K, xyz, xyz, o, o)
+    mk = lambda *s: torch.randn(*s, device="cuda")
+    base = dict(x_v=mk(n, C), p1=mk(n, K, 3), W=mk(C, 3) * 0.3, b=mk(C) * 0.1, w=mk(n, K, G) * 2.0)
+    g_out = mk(n, C)
+    res = []
+    for fused in (True, False):
+        t = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        a = t["w"] if fused else torch.softmax(t["w"], dim=1)
+        out = attention.AttnAgg.apply(t["x_v"], t["p1"], t["W"], t["b"], a.contiguous(), idx, fused)
+        out.backward(g_out)
+        res.append((out.detach(), {k: v.grad for k, v in t.items()}))
+    rel = lambda a, b: float((a.double() - b.double()).norm() / max(float(b.double().norm()), 1e-30))
+    assert rel(res[0][0], res[1][0]) < 1e-5
+    for k in base:
+        assert rel(res[0][1][k], res[1][1][k]) < (2e-4 if k in ("x_v",) else 1e-4), k      # x_v: fp32 atomics in both, different order
