@@ -19,6 +19,7 @@ ap.add_argument("--no-cache", action="store_true")
 ap.add_argument("--blas", default="cublas", help="torch.backends.cuda.preferred_blas_library: 'cublas' = rocBLAS (default here: 2-20x faster than hipBLASLt on this network's small weight-gradient GEMMs), 'cublaslt' = torch's default")
 ap.add_argument("--graph", action="store_true", help="the whole training step as a replayed hipGraph, geometry double-buffered (implies prefetch)")
 ap.add_argument("--depth", type=int, default=2, help="--graph: batches whose geometry is in flight ahead of the running step, 1..3 (buffer sets = depth + 1)")
+ap.add_argument("--foreach-sgd", action="store_true", help="torch.optim.SGD's default foreach implementation instead of fused=True (the same update in ~3 kernels instead of ~32)")
 ap.add_argument("--prefetch", action="store_true", help="geometry (FPS + every neighbour search) of the NEXT step on a side stream, one step ahead")
 a = ap.parse_args()
 torch.backends.cuda.preferred_blas_library(a.blas)
@@ -28,7 +29,7 @@ cfg = M.Config({"base_fdim": 32, "nsample": [36, 24, 24, 24, 24], "nstride": [4,
 torch.manual_seed(0)
 model = M.pointtransformer_seg_repro(c=6, k=13, config=cfg).cuda().train()
 crit = M.Loss(cfg)
-opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4, fused=not a.foreach_sgd)
 xs, ls = zip(*[S.s_room(a.n, seed=i) for i in range(a.scenes)])
 inputs = {"points": torch.from_numpy(np.concatenate(xs)).cuda(), "features": torch.rand(a.n * a.scenes, 3, device="cuda"),
           "offset": torch.tensor(np.cumsum([a.n] * a.scenes), dtype=torch.int32, device="cuda")}
