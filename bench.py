@@ -45,9 +45,12 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--points", type=int, default=40960)
+    ap.add_argument("--points", type=int, default=None, help="points per scene (default: 40960 for the block, 200000 for the ConvNet workload)")
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--k", type=int, default=16)
+    ap.add_argument("--workload", choices=("block", "convnet"), default="block",
+                    help="block: BASELINE's headline (KNN + group + KPConv + CBL, N=40960); convnet: config C5 / the per-scene work of C3 "
+                         "(radius + grid pyramid of a 200000-point cloud, AdaptiveWeight forward + backward on its 5 layers, TF-side CBL)")
     ap.add_argument("--forward-only", action="store_true", help="headline = forward block + CBL head only (round 1's step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="all stages in order on one stream")
@@ -62,7 +65,10 @@ def parse(argv=None):
                     help="tests: run the gradient all-reduce leg over a ONE-rank RCCL group (exercises the RCCL path on a 1-GPU box; not a scaling number)")
     ap.add_argument("--host-dry-run", action="store_true",
                     help="CPU-only run of the launcher / process-group / timing / all-reduce logic over gloo (tests; not a measurement)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.points is None:
+        args.points = 200000 if args.workload == "convnet" else 40960
+    return args
 
 
 # ------------------------------------------------------------------------------------------------ launcher
@@ -410,6 +416,13 @@ def run_gpu(args, D, world, rank, local):
         e_f = timed_region(fstep, args.steps, args.warmup, sync, D)
         out["forward_only"] = {"value": n * args.steps * world / e_f, "ms_per_step": e_f / args.steps * 1e3, "stages": " -> ".join(fstep.names), "issue": fstep.note}
 
+    # ---- every step on its own (one hipGraph per step, no overlap between consecutive steps): the per-scene latency of the block
+    if step.pipe is not None:
+        nstep = make_step(scene, k, backward, args, overlap=True, pipeline=False)
+        e_n = timed_region(nstep, args.steps, args.warmup, sync, D)
+        out["no_pipeline"] = {"value": n * args.steps * world / e_n, "ms_per_step": e_n / args.steps * 1e3, "issue": nstep.note,
+                              "note": "the headline value is pipelined THROUGHPUT (the search of step i+1 beside the rest of step i); this is one step at a time"}
+
     # ---- the same K steps with DDP's gradient all-reduce beside them (multi-rank runs)
     if (world > 1 or args.allreduce_single) and not args.no_allreduce:
         ar = GradAllReduce(args.allreduce_floats, "cuda")
@@ -443,6 +456,109 @@ def run_gpu(args, D, world, rank, local):
     return finish(world)
 
 
+# ------------------------------------------------------------------------------------------------ ConvNet workload (BASELINE configs C5 / C3)
+def run_convnet(args, D, world, rank, local):
+    """python bench.py --workload convnet: one step = the radius / grid pyramid of one resident N-point cloud (13 radius searches + 4 grid
+    subsamplings), AdaptiveWeight forward + backward on its 5 layers at C = 72 ... 1152, scene labels and the TF-side CBL forward + backward
+    on every layer (contrastboundary_amd/convnet_path.py).  Issued eagerly: the layer sizes are data dependent (one host sync per grid
+    subsampling, as the TF op's dynamic output shape)."""
+    torch.cuda.set_device(local)
+    D.init("nccl" if world > 1 else None)
+    if world > 1:
+        import torch.distributed as dist
+        assert dist.get_world_size() == args.gpus, "RCCL process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus)
+    from contrastboundary_amd import convnet_path as CP, local_aggregation as LA, tf_ops
+    n = args.points
+    backward = not args.forward_only
+    scene = CP.ConvNetScene(n, seed=rank, b=1)
+    stage_list = CP.stages(scene, backward=backward)
+    names = [s[0] for s in stage_list]
+    state = {}
+
+    def step():
+        CP.run_once(scene, state, stage_list=stage_list)
+    t = time.perf_counter()
+    while time.perf_counter() - t < 0.5:                              # settle: code objects, workspaces, clocks
+        step(); torch.cuda.synchronize()
+    elapsed = timed_region(step, args.steps, args.warmup, torch.cuda.synchronize, D)
+    pyr = state["pyr"]
+    sizes = [int(p.shape[0]) for p in pyr["points"]]
+    widths = [int(nb.shape[1]) for nb in pyr["neighbors"]]
+    out = {"metric": "points/sec through radius+grid pyramid, AdaptiveWeight fwd+bwd (5 layers) and TF-side CBL, ConvNet N=%d" % n,
+           "value": n * args.steps * world / elapsed, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": elapsed / args.steps * 1e3, "host_issue_ms_per_step": timed_region.issue_s / args.steps * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "ConvNet per-scene work (BASELINE configs C5 / C3): S-room scaled to %d points, dl0=%.2f, density %.0f, %d layers, "
+                                  "limits %s; layer sizes %s, neighbour widths %s, AdaptiveWeight widths %s, CBL on a %d-d latent; stages: %s"
+                                  % (n, CP.DL0, CP.DENSITY, scene.layers, CP.LIMITS[:scene.layers], sizes, widths, scene.widths, CP.CBL_DIM, " -> ".join(names)),
+                      "parallelism": "scene-per-GPU replicas x%d (no data-path collective)" % world,
+                      "issue": "eager (data-dependent layer sizes: one host sync per grid subsampling, like the TF op's dynamic shape)"}}
+    if args.no_extra:
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        return finish(world)
+
+    # ---- per-stage device times: HIP events on the launch stream around every stage of in-order steps
+    samples = []
+    for _ in range(7):
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in stage_list]
+        for (a, b), (_, fn, _, _) in zip(ev, stage_list):
+            a.record(); fn(state); b.record()
+        torch.cuda.synchronize()
+        samples.append([a.elapsed_time(b) for a, b in ev])
+    stage_ms = [float(v) for v in np.median(np.asarray(samples[2:]), axis=0)]
+    stage_bytes = [int(s[2](state)) for s in stage_list]
+
+    # ---- the two roofline kernels, each alone: back-to-back launches behind a filler, two events around the run
+    filler = torch.empty(1 << 32, dtype=torch.uint8, device="cuda")
+
+    def alone(fn, reps=10):
+        fn(); fn(); torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        filler.fill_(0); filler.fill_(1)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record(); torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps * 1e3                         # us
+    pts0, len0, nb0 = pyr["points"][0], pyr["batches_len"][0], pyr["neighbors"][0]
+    r0 = CP.DL0 * CP.DENSITY / 2.0
+    arr0 = scene.layer_arrays(0, sizes[0])
+    c0, k0 = scene.widths[0], widths[0]
+    us_radius = alone(lambda: tf_ops.tf_batch_neighbors(pts0, pts0, len0, len0, r0, CP.LIMITS[0], exact_shape=False))
+    us_aw = alone(lambda: LA.adaptive_weight(pts0, pts0, nb0, arr0["feat"], r0, scene.fc_weight[0], scene.fc_bias[0], "mean"))
+    f_l = arr0["feat"].detach().requires_grad_(True); w_l = scene.fc_weight[0].detach().requires_grad_(True); b_l = scene.fc_bias[0].detach().requires_grad_(True)
+    o_l = LA.adaptive_weight(pts0, pts0, nb0, f_l, r0, w_l, b_l, "mean")
+    us_aw_bwd = alone(lambda: torch.autograd.grad(o_l, (f_l, w_l, b_l), arr0["grad"], retain_graph=True)) if backward else None
+    del filler
+    rb = CP.radius_bytes(sizes[0], sizes[0], CP.LIMITS[0])
+    ab = CP.adaptive_weight_bytes(sizes[0], sizes[0], k0, c0)
+    gb = lambda nbytes, us: nbytes / (us * 1e-6) / 1e9
+    roofline = {"kernel": "radius_group_kernel (layer 0: %d queries x %d supports, r=%.2f, limit %d) incl. its grid build" % (sizes[0], sizes[0], r0, CP.LIMITS[0]),
+                "stage": "radius search of layer 0", "bound": "hbm", "achieved": gb(rb, us_radius), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": gb(rb, us_radius) / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": rb, "launch_us": round(us_radius, 2),
+                "note": "achieved = SURVEY 8(d) N2 bytes (12 Nq + 12 Ns + 4 Nq limit) / HIP-event duration of 10 back-to-back calls of the search alone / 10",
+                "adaptive_weight": {"kernel": "adaptive_weight forward, layer 0 (n=%d, K=%d, C=%d)" % (sizes[0], k0, c0), "bound": "hbm", "achieved": gb(ab, us_aw),
+                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb(ab, us_aw) / HBM_PEAK_GBS, "bytes_per_launch": ab, "launch_us": round(us_aw, 2),
+                                    "gathered_bytes_per_launch": 4 * sizes[0] * k0 * c0,
+                                    "gathered_GBps": gb(4 * sizes[0] * k0 * c0, us_aw),
+                                    "note": "SURVEY 8(d) a14 bytes 12n + 12n0 + 4 n0 C + 4 n K + 4 n C; gathered = the n K C floats the kernel pulls through L2"},
+                "stage_ms": {names[i]: round(stage_ms[i], 4) for i in range(len(names))},
+                "stage_sum_ms": round(float(sum(stage_ms)), 4),
+                "stage_algorithmic_GBps": {names[i]: round(stage_bytes[i] / (stage_ms[i] * 1e-3) / 1e9, 1) for i in range(len(names)) if stage_ms[i] > 0}}
+    if us_aw_bwd is not None:
+        bb = ab + 4 * sizes[0] * c0
+        roofline["adaptive_weight_bwd"] = {"bound": "hbm", "achieved": gb(bb, us_aw_bwd), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb(bb, us_aw_bwd) / HBM_PEAK_GBS,
+                                           "bytes_per_launch": bb, "launch_us": round(us_aw_bwd, 2)}
+    out["roofline"] = roofline
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            from tests import cpu_baseline
+            out["cpu_baseline"] = cpu_baseline.run_convnet(n, seed=0, gpu_pyramid_ms=stage_ms[0])
+        print(json.dumps(out), flush=True)
+    return finish(world)
+
+
 def finish(world):
     import torch.distributed as tdist
     if tdist.is_available() and tdist.is_initialized():
@@ -465,7 +581,7 @@ def main(argv=None):
     if not torch.cuda.is_available():
         sys.stderr.write("bench.py: no GPU visible (the hot path has no CPU fallback)\n")
         return 2
-    return run_gpu(args, D, world, rank, local)
+    return (run_convnet if args.workload == "convnet" else run_gpu)(args, D, world, rank, local)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,170 @@
+"""The ConvNet side of the hot path as one measured step (BASELINE configs C3 / C5: "ScanNet-scale scene N~200k points, radius-query +
+multi-scale grid subsampling stress", and the per-scene work of "S3DIS full train, ConvNet + CBL"):
+
+    pyramid     tf_segmentation_inputs_radius, tensorflow/datasets/base.py:767-842: per layer the radius neighbours (N2,
+                tf_neighbors/neighbors/neighbors.cpp:213-336, cropped to neighborhood_limits 26/31/38/41/39, config/s3dis.py:87), the grid-subsampled
+                next layer (N1, grid_subsampling.cpp:114), pooling and upsampling indices: 13 radius searches + 4 grid subsamplings
+    aggregation AdaptiveWeight (local_aggregation_operators.py:316-500) forward + backward on every layer at the ConvNet's widths
+                C = 72, 144, 288, 576, 1152 (first_features_dim 72, config/s3dis/adapt.yaml:16-18)
+    labels      scene labels of the sub-sampled layers through the pools (heads/head.py:25-49)
+    CBL         contrast_head (heads/head.py:462-807; 'softnn', 'l2', sample 'label') forward + backward on the radius neighbourhoods of every layer
+
+Shapes are data dependent (the number of voxels a layer keeps), so a step carries the host syncs the TF ops' dynamic shapes carry and is issued
+eagerly; `stages()` lists the stages with the ALGORITHMIC bytes of SURVEY.md 8(d), evaluated on the sizes the step produced.
+"""
+import numpy as np
+import torch
+
+from . import heads, local_aggregation as LA, tf_ops
+
+LIMITS = [26, 31, 38, 41, 39]          # neighborhood_limits (config/s3dis.py:87)
+WIDTHS = [72, 144, 288, 576, 1152]     # local-aggregation widths per layer (first_features_dim 72, doubling)
+DL0 = 0.04                             # first_subsampling_dl
+DENSITY = 5.0                          # density_parameter -> r0 = dl * density / 2 = 0.1
+NUM_LAYERS = 5
+CBL_DIM = 32
+NUM_CLASSES = 13
+
+
+class ConvNetScene:
+    """device-resident synthetic cloud + the trainable tensors of one AdaptiveWeight per layer + CBL latents.
+    Per-layer features / latents are generated for the LARGEST possible layer size (n points) and sliced to the layer's size inside the step."""
+
+    def __init__(self, n, seed=0, b=1, device="cuda", layers=NUM_LAYERS, widths=WIDTHS):
+        a = ConvNetScene.synthetic_numpy(n, seed, b, layers, widths)
+        t = lambda v: torch.from_numpy(v).to(device)
+        self.n, self.seed, self.b, self.layers, self.widths = n, seed, b, layers, list(widths[:layers])
+        self.points, self.lengths, self.labels = t(a["points"]), t(a["lengths"]), t(a["labels"])
+        self.fc_weight = [t(w) for w in a["fc_weight"]]
+        self.fc_bias = [t(w) for w in a["fc_bias"]]
+        self.seeds = a["seeds"]
+        self.device = device
+        self._per_layer = {}
+
+    @staticmethod
+    def synthetic_numpy(n, seed=0, b=1, layers=NUM_LAYERS, widths=WIDTHS):
+        from . import synthetic as S
+        # the S-room scaled so that the surface density stays that of the 40960-point room
+        xyz, labels = S.s_room(n, seed, scale=max(1.0, float(np.sqrt(n / 12500.0))))
+        lens = np.diff(np.concatenate([[0], S.offsets(n, b, seed)])).astype(np.int32)
+        rng = np.random.default_rng(seed + 500)
+        fcw = [(rng.normal(size=(3, c)) * 0.5).astype(np.float32) for c in widths[:layers]]
+        fcb = [rng.normal(size=(c,)).astype(np.float32) for c in widths[:layers]]
+        return dict(points=xyz, lengths=lens, labels=labels.astype(np.int64), fc_weight=fcw, fc_bias=fcb, seeds=[seed + 600 + l for l in range(layers)])
+
+    @staticmethod
+    def layer_arrays_numpy(seed, rows, c):
+        """features (rows,c), upstream gradient (rows,c), latent (rows,CBL_DIM) of one layer: a function of (seed, rows, c) only, so the oracle
+        side of a test regenerates exactly what the device holds"""
+        rng = np.random.default_rng(seed)
+        return dict(feat=rng.normal(size=(rows, c)).astype(np.float32), grad=rng.normal(size=(rows, c)).astype(np.float32),
+                    latent=rng.normal(size=(rows, CBL_DIM)).astype(np.float32))
+
+    def layer_arrays(self, l, rows):
+        """device copies for layer l with `rows` points (made once per size: the pyramid of a resident scene does not change)"""
+        key = (l, rows)
+        if key not in self._per_layer:
+            a = ConvNetScene.layer_arrays_numpy(self.seeds[l], rows, self.widths[l])
+            self._per_layer[key] = {k: torch.from_numpy(v).to(self.device) for k, v in a.items()}
+        return self._per_layer[key]
+
+
+def radius_bytes(nq, ns, limit):
+    """SURVEY 8(d) N2 (+ crop): 12 Nq + 12 Ns + 4 Nq limit"""
+    return 12 * nq + 12 * ns + 4 * nq * limit
+
+
+def grid_bytes(n, m, b):
+    """12 N read + 12 M written + 4 B"""
+    return 12 * n + 12 * m + 4 * b
+
+
+def adaptive_weight_bytes(n, n0, k, c):
+    """SURVEY 8(d) a14 (idx given): 12 n + 12 n0 + 4 n0 C + 4 n K + 4 n C"""
+    return 12 * n + 12 * n0 + 4 * n0 * c + 4 * n * k + 4 * n * c
+
+
+def adaptive_weight_flops(n, k, c):
+    """2 n K (3 C) + 2 n K C"""
+    return 2.0 * n * k * 3 * c + 2.0 * n * k * c
+
+
+def pyramid_bytes(pyr):
+    """algorithmic bytes of the 13 radius searches + 4 grid subsamplings of a built pyramid"""
+    total = 0
+    L = len(pyr["points"])
+    for l in range(L):
+        n = pyr["points"][l].shape[0]
+        total += radius_bytes(n, n, pyr["neighbors"][l].shape[1])
+        if l + 1 < L:
+            m = pyr["points"][l + 1].shape[0]
+            total += grid_bytes(n, m, pyr["batches_len"][l].shape[0])
+            total += radius_bytes(m, n, pyr["pools"][l].shape[1]) + radius_bytes(n, m, pyr["upsamples"][l + 1].shape[1])
+    return total
+
+
+def stages(scene, backward=True, cbl=True):
+    """-> list of (name, fn(state), bytes_fn(state) -> algorithmic bytes, flops_fn(state)); fns communicate through `state`"""
+    st = []
+    L = scene.layers
+    limits = LIMITS[:L]
+    leaf = (lambda t: t.detach().requires_grad_(True)) if backward else (lambda t: t)
+
+    def pyramid(s):
+        s["pyr"] = tf_ops.segmentation_inputs_radius(scene.points, scene.lengths, DL0, DENSITY, L, limits + [limits[-1]])
+    st.append(("pyramid_radius_grid", pyramid, lambda s: pyramid_bytes(s["pyr"]), lambda s: 0.0))
+
+    for l in range(L):
+        def aw_fwd(s, l=l):
+            pyr = s["pyr"]
+            q, nb = pyr["points"][l], pyr["neighbors"][l]
+            arr = scene.layer_arrays(l, q.shape[0])
+            s["aw_in%d" % l] = (leaf(arr["feat"]), leaf(scene.fc_weight[l]), leaf(scene.fc_bias[l]))
+            f, w, b = s["aw_in%d" % l]
+            s["aw_out%d" % l] = LA.adaptive_weight(q, q, nb, f, DL0 * DENSITY / 2.0 * 2 ** l, w, b, "mean")
+
+        def aw_dims(s, l=l):
+            n, k = s["pyr"]["neighbors"][l].shape
+            return n, k, scene.widths[l]
+        st.append(("adaptive_weight_fwd_l%d" % l, aw_fwd, lambda s, d=aw_dims: adaptive_weight_bytes(d(s)[0], d(s)[0], d(s)[1], d(s)[2]),
+                   lambda s, d=aw_dims: adaptive_weight_flops(*d(s))))
+        if backward:
+            def aw_bwd(s, l=l):
+                arr = scene.layer_arrays(l, s["aw_out%d" % l].shape[0])
+                s["aw_grads%d" % l] = torch.autograd.grad(s["aw_out%d" % l], s["aw_in%d" % l], arr["grad"])
+            # forward's inputs + the output gradient in, feature gradient + parameter gradients out
+            st.append(("adaptive_weight_bwd_l%d" % l, aw_bwd,
+                       lambda s, d=aw_dims: adaptive_weight_bytes(d(s)[0], d(s)[0], d(s)[1], d(s)[2]) + 4 * d(s)[0] * d(s)[2] + 16 * d(s)[2],
+                       lambda s, d=aw_dims: 2.0 * adaptive_weight_flops(*d(s))))
+    if not cbl:
+        return st
+
+    def scene_labels(s):
+        # labels of layer l from the labels of layer l-1 through the pooling indices ('max' = argmax of the neighbour histogram, head.py:25-49)
+        lab = [scene.labels]
+        for l in range(1, L):
+            lab.append(heads.tf_scene_label(lab[-1], s["pyr"]["pools"][l - 1], NUM_CLASSES, "max"))
+        s["labels"] = lab
+    st.append(("scene_labels", scene_labels,
+               lambda s: sum(4 * p.numel() + 8 * p.shape[0] + 8 * s["pyr"]["points"][l].shape[0] for l, p in enumerate(s["pyr"]["pools"][:L - 1])), lambda s: 0.0))
+
+    for l in range(L):
+        def cbl_fb(s, l=l):
+            nb = s["pyr"]["neighbors"][l]
+            arr = scene.layer_arrays(l, nb.shape[0])
+            lat = arr["latent"].detach().requires_grad_(True)
+            loss, mask = heads.tf_contrast(lat, s["labels"][l], nb, 1.0, 0.1, return_mask=True)
+            s["cbl_loss%d" % l], s["cbl_mask%d" % l] = loss, mask
+            s["cbl_grad%d" % l], = torch.autograd.grad(loss, lat)
+        # a16 mining (idx given): 4 n K idx + 4 n d features + 4 n labels in; the gradient 4 n d out
+        st.append(("tf_cbl_fwd_bwd_l%d" % l, cbl_fb, lambda s, l=l: 4 * s["pyr"]["neighbors"][l].numel() + s["pyr"]["neighbors"][l].shape[0] * (8 * CBL_DIM + 4),
+                   lambda s, l=l: 1.0 * s["pyr"]["neighbors"][l].numel() * (3 * CBL_DIM + 20)))
+    return st
+
+
+def run_once(scene, state=None, backward=True, cbl=True, stage_list=None):
+    """every stage in order on the current stream"""
+    state = {} if state is None else state
+    for _, fn, _, _ in (stage_list if stage_list is not None else stages(scene, backward, cbl)):
+        fn(state)
+    return state

@@ -97,8 +97,9 @@ def stages(scene, k=16, backward=False):
 
     def kpconv(s):
         s["kpconv"] = local_aggregation.kpconv(scene.xyz, scene.xyz, s["idx"], s["feat_leaf"], scene.kernel_points, s["kw_leaf"], extent)
-    # a15 (idx given): 12n + 12n0 + 4n0C + 4nK + 4nC bytes; flops 2nK*KP*(C + 6) + 2n*KP*C  
-    st.append(("kpconv_fwd", kpconv, 12 * n + 12 * n + 4 * n * c + 4 * n * k + 4 * n * c, 2.0 * n * k * KP * (c + 6) + 2.0 * n * KP * c))
+    # a15 (idx given): 12n + 12n0 + 4n0C + 4nK + 4nC bytes; flops 2 n KP K C + 2 n KP C  (the influence weights' own
+    # arithmetic, ~6 flops per (neighbour, kernel point), is not counted)
+    st.append(("kpconv_fwd", kpconv, 12 * n + 12 * n + 4 * n * c + 4 * n * k + 4 * n * c, 2.0 * n * k * KP * c + 2.0 * n * KP * c))
 
     d = CBL_DIM
 
@@ -143,7 +144,7 @@ def stages(scene, k=16, backward=False):
         s["grad_feat_kpconv"], s["grad_kernel_weights"] = torch.autograd.grad(s["kpconv"], (s["feat_leaf"], s["kw_leaf"]), scene.upstream(k)["grad_kpconv"])
     # a15 backward (idx given): forward's inputs + the output gradient in, feature and kernel-weight gradients out; flops 2x the forward's
     st.append(("kpconv_bwd", kpconv_bwd, 12 * n + 12 * n + 4 * n * c + 4 * n * k + 4 * n * c + 4 * n * c + 4 * KP * c,
-               2.0 * (2.0 * n * k * KP * (c + 6) + 2.0 * n * KP * c)))
+               2.0 * (2.0 * n * k * KP * c + 2.0 * n * KP * c)))
     return st
 
 

@@ -231,9 +231,12 @@ class GraphedTrainStep:
         step.stage(batch0); step.stage(batch1)                  # `depth` batches ahead
         for t in ...: loss, logits = step.run(); step.stage(batch[t + 2])"""
 
-    def __init__(self, model, criterion, optimizer, inputs, target, warmup=3, depth=2):
+    def __init__(self, model, criterion, optimizer, inputs, target, warmup=3, depth=2, reducer=None):
+        """reducer: a distributed.GradientReducer over the model's parameters (data-parallel runs).  The captured graph then ends behind the
+        backward pass (gradients accumulate into the reducer's flat buffer, zeroed at the top of the graph); run() issues the bucketed all-reduce
+        behind the replay and the optimizer step behind that, eagerly."""
         from . import geometry
-        self.model, self.criterion, self.optimizer = model, criterion, optimizer
+        self.model, self.criterion, self.optimizer, self.reducer = model, criterion, optimizer, reducer
         plan = dict(stride=model.STRIDE, nsample=model.NSAMPLE, multi_head=model.head is not None)
         if getattr(criterion, "contrast_head", None) is not None:
             plan.update(cbl_nsample=model.config.nsample, nstride=model.config.nstride)
@@ -242,9 +245,14 @@ class GraphedTrainStep:
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):                               # eager warm-up on a side stream (workspaces, momentum buffers, autotune)
             for _ in range(warmup):
-                optimizer.zero_grad(set_to_none=True)
+                if reducer is None:
+                    optimizer.zero_grad(set_to_none=True)
+                else:
+                    reducer.zero_grad()
                 _, _, loss, _ = forward_and_loss(model, criterion, inputs, target)
                 loss.sum().backward()
+                if reducer is not None:
+                    reducer.finish()
                 optimizer.step()
         torch.cuda.current_stream(dev).wait_stream(side)
         self.depth = min(3, max(1, int(depth)))
@@ -260,11 +268,20 @@ class GraphedTrainStep:
             geom = geometry.StaticGeometry(st_in["points"], st_in["offset"], **plan)
             torch.cuda.synchronize(dev)
             graph = torch.cuda.CUDAGraph()
-            optimizer.zero_grad(set_to_none=True)
-            with torch.cuda.graph(graph):
-                out, _, loss, _ = forward_and_loss(model, criterion, st_in, st_tg, geometry=geom)
-                loss.sum().backward()
-                optimizer.step()
+            if reducer is None:
+                optimizer.zero_grad(set_to_none=True)
+                with torch.cuda.graph(graph):
+                    out, _, loss, _ = forward_and_loss(model, criterion, st_in, st_tg, geometry=geom)
+                    loss.sum().backward()
+                    optimizer.step()
+            else:
+                for h in reducer.handles:                           # no collective inside a capture: the buckets go out behind the replay
+                    h.remove()
+                reducer.handles = []
+                with torch.cuda.graph(graph):
+                    reducer.zero_grad()
+                    out, _, loss, _ = forward_and_loss(model, criterion, st_in, st_tg, geometry=geom)
+                    loss.sum().backward()
             self.sets.append(dict(inputs=st_in, target=st_tg, geom=geom, graph=graph, loss=loss, logits=out))
         self.run_turn = self.stage_turn = self.staged = 0
 
@@ -278,10 +295,13 @@ class GraphedTrainStep:
         side = self.geo_streams[self.stage_turn % len(self.geo_streams)]
         if s.get("done") is not None:
             side.wait_event(s["done"])
+        side.wait_stream(torch.cuda.current_stream(dev))            # the caller's batch may still be in flight on its stream (H2D copy, augmentation)
         with torch.cuda.stream(side):
             for k, v in inputs.items():
                 s["inputs"][k].copy_(v, non_blocking=True)
+                v.record_stream(side)
             s["target"].copy_(target, non_blocking=True)
+            target.record_stream(side)
         s["geom"].refresh(side)
         self.stage_turn = (self.stage_turn + 1) % len(self.sets)
         self.staged += 1
@@ -293,6 +313,9 @@ class GraphedTrainStep:
         cur = torch.cuda.current_stream(s["target"].device)
         cur.wait_event(s["geom"].ready)
         s["graph"].replay()
+        if self.reducer is not None:
+            self.reducer.reduce_all()                               # every bucket, in order, behind the replay; averaged on this stream
+            self.optimizer.step()
         s["done"] = torch.cuda.Event()
         s["done"].record(cur)
         self.run_turn = (self.run_turn + 1) % len(self.sets)

@@ -1,0 +1,45 @@
+"""One data-parallel training step of the reference's network (BASELINE configs C3 / C4 "8 GPUs"): one process per GPU, every
+rank its own scenes (DistributedSampler's role, /root/reference/pytorch/tool/train.py:238), the model replicated, gradients averaged with a
+bucketed all-reduce that runs beside the backward pass (what DistributedDataParallel does there, train.py:181-185), then the optimizer step.
+
+    trainer = DataParallelTrainer(model, criterion, optimizer)           # after dist.init_process_group; world 1 works too (no collective)
+    loss = trainer.step(inputs, target)
+
+`forward_loss(model, criterion, inputs, target) -> loss tensor` is the network-specific part; the default is the Point Transformer + CBL
+step (pointtransformer_seg.forward_and_loss).  With graph=True the forward + backward is a replayed hipGraph (pointtransformer_seg.GraphedTrainStep
+with a reducer): no autograd hook fires during a replay, so the buckets are issued right behind it, in order.
+"""
+import torch
+
+from . import distributed as D
+
+
+def _pt_forward_loss(model, criterion, inputs, target):
+    from . import pointtransformer_seg as M
+    return M.forward_and_loss(model, criterion, inputs, target)[2]
+
+
+class DataParallelTrainer:
+    def __init__(self, model, criterion, optimizer, bucket_bytes=8 << 20, forward_loss=None, broadcast=True):
+        self.model, self.criterion, self.optimizer = model, criterion, optimizer
+        self.forward_loss = forward_loss or _pt_forward_loss
+        if broadcast:
+            D.broadcast_parameters(model)                           # rank 0's initial weights everywhere
+        self.reducer = D.GradientReducer(model.parameters(), bucket_bytes=bucket_bytes)
+        self.world = self.reducer.world
+
+    def step(self, inputs, target):
+        """zero -> forward -> backward (buckets all-reduced as they complete) -> wait + average -> optimizer step; returns the loss vector"""
+        self.reducer.zero_grad()
+        loss = self.forward_loss(self.model, self.criterion, inputs, target)
+        loss.sum().backward()
+        self.reducer.finish()
+        self.optimizer.step()
+        return loss.detach()
+
+    def describe(self):
+        r = self.reducer
+        return {"gradient_bytes": r.flat.numel() * r.flat.element_size(), "buckets": len(r.buckets),
+                "bucket_bytes": [(e - s) * r.flat.element_size() for s, e, _ in r.buckets], "ranks": r.world,
+                "overlap": "bucket k's all-reduce is started by autograd's post-accumulate hooks when its last gradient is written (reverse parameter order), "
+                           "and joined before the optimizer step"}

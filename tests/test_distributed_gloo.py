@@ -80,3 +80,103 @@ def test_bench_refuses_more_gpus_than_devices():
 def test_bench_refuses_a_world_that_is_not_gpus():
     r = _bench("--gpus", "4", "--host-dry-run", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"})
     assert r.returncode == 2 and "WORLD_SIZE=2 but --gpus 4" in r.stderr
+
+
+# ---- data-parallel training: the gradient reducer (DDP's role, train.py:181-185) and tools/bench_model.py's rank logic ---------------
+class _Tiny(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.net = torch.nn.Sequential(torch.nn.Linear(5, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+        self.unused = torch.nn.Linear(4, 4)                           # never takes part in the forward: its bucket must still be reduced (zeros)
+
+    def forward(self, x):
+        return self.net(x)
+
+
+def _tiny_model(seed):
+    torch.manual_seed(seed)
+    return _Tiny()
+
+
+def _rank_batch(rank):
+    g = torch.Generator().manual_seed(100 + rank)
+    return torch.randn(32, 5, generator=g), torch.randn(32, 3, generator=g)
+
+
+def _reducer_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from contrastboundary_amd import distributed as D
+    D.init("gloo")
+    model = _tiny_model(7 + rank)                                     # different per rank: broadcast_parameters equalises
+    D.broadcast_parameters(model)
+    red = D.GradientReducer(model.parameters(), bucket_bytes=128)     # 32 floats per bucket -> several buckets, some spanning parameters
+    launched = []
+    orig = red._launch
+    red._launch = lambda k: (launched.append(k), orig(k))[1]
+    x, y = _rank_batch(rank)
+    grads = []
+    for it in range(2):                                               # twice: the views must survive zero_grad, the bucket order must repeat
+        red.zero_grad()
+        ((model(x) - y) ** 2).mean().backward()
+        red.finish()
+        grads.append(torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone())
+    views = all(p.grad.data_ptr() >= red.flat.data_ptr() and p.grad.data_ptr() < red.flat.data_ptr() + 4 * red.flat.numel() for p in model.parameters())
+    out.put((rank, grads[0], grads[1], launched, len(red.buckets), views))
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_gradient_reducer_averages_real_gradients_over_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reducer_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    # single-process truth: rank 0's weights, each rank's batch, gradients averaged
+    ref = []
+    for rank in range(2):
+        m = _tiny_model(7)
+        x, y = _rank_batch(rank)
+        ((m(x) - y) ** 2).mean().backward()
+        ref.append(torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in m.parameters()]))
+    want = (ref[0] + ref[1]) / 2
+    for rank, g0, g1, launched, nbuckets, views in res:
+        assert torch.allclose(g0, want, rtol=1e-6, atol=1e-7) and torch.equal(g0, g1)
+        assert launched == list(range(nbuckets)) * 2 and nbuckets >= 3         # strictly in bucket order, every step, on every rank
+        assert views                                                          # .grad stayed a view of the flat buffer
+    assert torch.equal(res[0][1], res[1][1])                                  # bitwise the same on both ranks
+
+
+def test_gradient_reducer_single_process_is_identity():
+    from contrastboundary_amd import distributed as D
+    m = _tiny_model(3)
+    red = D.GradientReducer(m.parameters(), bucket_bytes=128)
+    x, y = _rank_batch(0)
+    red.zero_grad(); ((m(x) - y) ** 2).mean().backward(); red.finish()
+    got = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+    m2 = _tiny_model(3)
+    ((m2(x) - y) ** 2).mean().backward()
+    want = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in m2.parameters()])
+    assert torch.equal(got, want)
+
+
+def test_bench_model_deals_scenes_and_keeps_replicas_identical():
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(key, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "bench_model.py"), "--gpus", "2", "--host-dry-run", "--scenes", "3", "--steps", "4", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=e, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scenes_of_rank0"] == [0, 2, 4]          # 6 scenes dealt round-robin over 2 ranks
+    assert out["replicas_identical"] is True                                   # started different, broadcast + averaged gradients keep them equal
+    assert out["grad_allreduce"]["ranks"] == 2 and out["grad_allreduce"]["buckets"] >= 2
