@@ -285,9 +285,12 @@ class GraphedTrainStep:
             self.sets.append(dict(inputs=st_in, target=st_tg, geom=geom, graph=graph, loss=loss, logits=out))
         self.run_turn = self.stage_turn = self.staged = 0
 
-    def stage(self, inputs, target):
-        """copy the NEXT batch into the idle buffer set and start its geometry — all on the side stream, behind nothing but the last
-        replay that read this buffer set"""
+    def stage(self, inputs, target, ready=None):
+        """copy the NEXT batch into the idle buffer set and start its geometry — all on the side stream, behind the last replay that read
+        this buffer set and behind `ready`: an event recorded by the caller behind whatever produces `inputs` / `target` (a non-blocking H2D
+        copy, GPU augmentation).  Without `ready` the batch must already be complete (the side stream deliberately does NOT wait for the
+        caller's current stream: the previous step's replay is queued there, and waiting for it would put the geometry behind the step it is
+        meant to run beside)."""
         from . import geometry
         assert self.staged < len(self.sets), "every buffer set holds a staged batch: run() first"
         s = self.sets[self.stage_turn]
@@ -295,7 +298,8 @@ class GraphedTrainStep:
         side = self.geo_streams[self.stage_turn % len(self.geo_streams)]
         if s.get("done") is not None:
             side.wait_event(s["done"])
-        side.wait_stream(torch.cuda.current_stream(dev))            # the caller's batch may still be in flight on its stream (H2D copy, augmentation)
+        if ready is not None:
+            side.wait_event(ready)
         with torch.cuda.stream(side):
             for k, v in inputs.items():
                 s["inputs"][k].copy_(v, non_blocking=True)
