@@ -411,3 +411,23 @@ def test_knn_anytie_policy_never_replays_and_keeps_the_distances(P, K):
         P.set_knn_tie_policy(prev)
     idx3, _ = P.knnquery_raw(K, dev(pts), dev(pts), dev(o), dev(o))
     np.testing.assert_array_equal(idx3.cpu().numpy(), ridx)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fps_speculative_rounds_vs_dense_kernels(seed):
+    """the bucket kernel's speculative rounds (several samples per barrier, validated prefix by prefix) against the dense kernels — an
+    independent implementation of the same arg-max sequence — on ragged batches of rooms and uniform clouds: indices and final tmp bit-exact"""
+    from contrastboundary_amd import synthetic as S
+    rng = np.random.default_rng(100 + seed)
+    b = int(rng.integers(1, 5))
+    sizes = [int(rng.integers(3072, 30000)) for _ in range(b)]
+    clouds = []
+    for i, n in enumerate(sizes):
+        clouds.append(S.s_room(n, seed=10 * seed + i)[0] if (seed + i) % 2 == 0 else S.s_uniform(n, seed=10 * seed + i))
+    xyz = np.concatenate(clouds).astype(np.float32)
+    offset = np.cumsum(sizes).astype(np.int32)
+    noff = np.cumsum([max(1, int(n / rng.choice([2, 4, 4, 7]))) for n in sizes]).astype(np.int32)
+    idx_b, tmp_b = _fps_raw(xyz, offset, noff, bucket=True)
+    idx_d, tmp_d = _fps_raw(xyz, offset, noff, bucket=False)
+    np.testing.assert_array_equal(idx_b, idx_d)
+    np.testing.assert_array_equal(tmp_b.view(np.uint32), tmp_d.view(np.uint32))
