@@ -505,6 +505,132 @@ __global__ __launch_bounds__(256) void adaptive_weight_fwd_v4(int n, int n0, int
     }
 }
 
+// ---------------------------------------------------------------------------------------------- AdaptiveWeight backward as a gather
+// Both gradients go through ONE per-target quantity (the forward transposed, as in kpconv_backward.hip):
+//     S_j[a, c] = sum over the pairs p = (i, k) with nbr(i, k) = j of  r_a(i, j) * go[i, c] / nn[i],   r = ((s_j - q_i) / radius, 1)   (a = x, y, z, 1)
+//     d out / d f   :  grad_f[j, c]  = sum_a fcw'[a, c] * S_j[a, c]          (fcw' = the three rows of fc_weight and fc_bias)
+//     d out / d fcw':  grad_w[a, c]  = sum_j f[j, c] * S_j[a, c]
+// One lane owns four consecutive channels of one target row; the lanes of a target sit next to each other (its gradient rows are read as
+// contiguous bursts), a workgroup walks `tpb` targets at a time over the transposed table in its processing order.  No atomics, written not
+// accumulated, deterministic: the parameter gradients are summed per lane, then over the lanes of a workgroup that hold the same channels
+// (LDS), then over the workgroups (partial rows + aw_param_reduce_kernel).  Round 2 scattered d out / d f with one float atomic per (pair,
+// channel): 0.9 - 2.6 ms per layer of the ConvNet at N = 200 000 (profiles/r03_bench_convnet_baseline.json).
+__global__ __launch_bounds__(256) void aw_inv_count_kernel(int n, int K, const int* __restrict__ idx, const int* __restrict__ padding_num,
+                                                           int reduction_mean, float* __restrict__ inv_nn)
+{
+    const int pad = reduction_mean ? *padding_num : 0;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
+        int cnt = 0;
+        if (reduction_mean)
+            for (int k = 0; k < K; k++) cnt += idx[(size_t)p * K + k] < pad ? 1 : 0;
+        inv_nn[p] = reduction_mean ? 1.0f / ((float)cnt + 1e-5f) : 1.0f;       // :466-470
+    }
+}
+
+// L = lanes per target in this launch (a chunk of at most 256 float4 columns starting at column c4_0), tpb = 256 / L targets per trip.
+// partial: (gridDim.x, 4, C) per-workgroup sums of (grad_fcw rows 0..2, grad_fcb).
+template <bool GF, bool GP>
+__global__ __launch_bounds__(256) void aw_bwd_csr_kernel(unsigned n0, int C4, int c4_0, int L, CblFastDiv dvK, const float* __restrict__ q, const float* __restrict__ s,
+                                                        const float4* __restrict__ f, float inv_radius, const float4* __restrict__ fcw, const float4* __restrict__ fcb,
+                                                        const float* __restrict__ inv_nn, const float4* __restrict__ go,
+                                                        const int* __restrict__ order, const int* __restrict__ inv_start, const int* __restrict__ inv_src,
+                                                        float4* __restrict__ gf, float* __restrict__ partial)
+{
+    __shared__ float4 red[4][256];
+    const int tpb = 256 / L;
+    const int ts = threadIdx.x / L, cl = threadIdx.x - ts * L;       // target slot of the trip, column within the chunk
+    const bool on = ts < tpb;
+    const int cq = c4_0 + cl;
+    float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0, w2 = w0, bb = w0;
+    if (on) { w0 = fcw[cq]; w1 = fcw[C4 + cq]; w2 = fcw[2 * C4 + cq]; bb = fcb[cq]; }
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;        // parameter gradients of this lane's four channels
+    const unsigned ntrips = (n0 + tpb - 1) / tpb;
+    const unsigned vend = 8 * cbl_xcd_per(ntrips);
+    for (unsigned v = blockIdx.x; v < vend; v += gridDim.x) {
+        const unsigned tr = cbl_xcd_slot(v, ntrips) * tpb + ts;
+        if (!on || tr >= n0) continue;
+        const int j = order ? order[tr] : (int)tr;
+        const int e0 = inv_start[tr], e1 = inv_start[tr + 1];
+        const float sx = s[3 * (size_t)j], sy = s[3 * (size_t)j + 1], sz = s[3 * (size_t)j + 2];
+        float4 S0 = make_float4(0.f, 0.f, 0.f, 0.f), S1 = S0, S2 = S0, S3 = S0;
+        int e = e0;
+        for (; e + 4 <= e1; e += 4) {                                 // four pairs in flight per lane
+            int pi[4]; float4 g[4]; float rx[4], ry[4], rz[4], sc[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) pi[u] = (int)cbl_fastdiv((unsigned)inv_src[e + u], dvK);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                g[u] = go[(size_t)pi[u] * C4 + cq];
+                rx[u] = q[3 * (size_t)pi[u]]; ry[u] = q[3 * (size_t)pi[u] + 1]; rz[u] = q[3 * (size_t)pi[u] + 2];
+                sc[u] = inv_nn[pi[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float x = (sx - rx[u]) * inv_radius, y = (sy - ry[u]) * inv_radius, z = (sz - rz[u]) * inv_radius;
+                const float4 gs = make_float4(g[u].x * sc[u], g[u].y * sc[u], g[u].z * sc[u], g[u].w * sc[u]);
+                S0.x += x * gs.x; S0.y += x * gs.y; S0.z += x * gs.z; S0.w += x * gs.w;
+                S1.x += y * gs.x; S1.y += y * gs.y; S1.z += y * gs.z; S1.w += y * gs.w;
+                S2.x += z * gs.x; S2.y += z * gs.y; S2.z += z * gs.z; S2.w += z * gs.w;
+                S3.x += gs.x; S3.y += gs.y; S3.z += gs.z; S3.w += gs.w;
+            }
+        }
+        for (; e < e1; e++) {
+            const int pi = (int)cbl_fastdiv((unsigned)inv_src[e], dvK);
+            const float4 g = go[(size_t)pi * C4 + cq];
+            const float sc = inv_nn[pi];
+            const float x = (sx - q[3 * (size_t)pi]) * inv_radius, y = (sy - q[3 * (size_t)pi + 1]) * inv_radius, z = (sz - q[3 * (size_t)pi + 2]) * inv_radius;
+            const float4 gs = make_float4(g.x * sc, g.y * sc, g.z * sc, g.w * sc);
+            S0.x += x * gs.x; S0.y += x * gs.y; S0.z += x * gs.z; S0.w += x * gs.w;
+            S1.x += y * gs.x; S1.y += y * gs.y; S1.z += y * gs.z; S1.w += y * gs.w;
+            S2.x += z * gs.x; S2.y += z * gs.y; S2.z += z * gs.z; S2.w += z * gs.w;
+            S3.x += gs.x; S3.y += gs.y; S3.z += gs.z; S3.w += gs.w;
+        }
+        if (GF)
+            gf[(size_t)j * C4 + cq] = make_float4(((w0.x * S0.x + w1.x * S1.x) + w2.x * S2.x) + bb.x * S3.x, ((w0.y * S0.y + w1.y * S1.y) + w2.y * S2.y) + bb.y * S3.y,
+                                                  ((w0.z * S0.z + w1.z * S1.z) + w2.z * S2.z) + bb.z * S3.z, ((w0.w * S0.w + w1.w * S1.w) + w2.w * S2.w) + bb.w * S3.w);
+        if (GP) {
+            const float4 fj = f[(size_t)j * C4 + cq];
+            a0.x += fj.x * S0.x; a0.y += fj.y * S0.y; a0.z += fj.z * S0.z; a0.w += fj.w * S0.w;
+            a1.x += fj.x * S1.x; a1.y += fj.y * S1.y; a1.z += fj.z * S1.z; a1.w += fj.w * S1.w;
+            a2.x += fj.x * S2.x; a2.y += fj.y * S2.y; a2.z += fj.z * S2.z; a2.w += fj.w * S2.w;
+            a3.x += fj.x * S3.x; a3.y += fj.y * S3.y; a3.z += fj.z * S3.z; a3.w += fj.w * S3.w;
+        }
+    }
+    if (GP) {
+        // the tpb lanes that hold the same four channels, in slot order (deterministic), then one partial row block per workgroup
+        red[0][threadIdx.x] = a0; red[1][threadIdx.x] = a1; red[2][threadIdx.x] = a2; red[3][threadIdx.x] = a3;
+        __syncthreads();
+        if (threadIdx.x < L) {
+            for (int a = 0; a < 4; a++) {
+                float4 sum = red[a][threadIdx.x];
+                for (int t = 1; t < tpb; t++) { const float4 o = red[a][t * L + threadIdx.x]; sum.x += o.x; sum.y += o.y; sum.z += o.z; sum.w += o.w; }
+                reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * 4 + a) * (size_t)(4 * C4))[c4_0 + threadIdx.x] = sum;
+            }
+        }
+    }
+}
+
+// grad_fcw / grad_fcb [e] = sum over the workgroups' partial rows, in a fixed order: 16 threads per element, each a 16th of the workgroups
+__global__ __launch_bounds__(256) void aw_param_reduce_kernel(int nblk, int C, const float* __restrict__ partial, float* __restrict__ gfcw, float* __restrict__ gfcb)
+{
+    __shared__ float part[16][16];
+    const int total = 4 * C;
+    const int el = threadIdx.x & 15, pt = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;
+    const int per = (nblk + 15) / 16, b0 = pt * per, b1 = min(nblk, b0 + per);
+    float acc = 0.f;
+    if (e < total)
+        for (int b = b0; b < b1; b++) acc += partial[(size_t)b * total + e];
+    part[pt][el] = acc;
+    __syncthreads();
+    if (pt == 0 && e < total) {
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) sum += part[k][el];
+        if (e < 3 * C) { if (gfcw) gfcw[e] = sum; } else if (gfcb) gfcb[e - 3 * C] = sum;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- index pooling
 __global__ __launch_bounds__(256) void column_min_kernel(int n, int d, const float* __restrict__ x, unsigned* __restrict__ keymin)
 {
@@ -664,6 +790,57 @@ CBL_EXPORT int cbl_adaptive_weight_backward(int n, int n0, int K, int C, const f
     static int res_awb = 0;
     hipLaunchKernelGGL(adaptive_weight_kernel<true>, dim3(min(persistent_grid(n), resident_workgroups(&adaptive_weight_kernel<true>, res_awb))), dim3(256), 0, cbl_stream(stream), n, n0, K, C, query_points, support_points,
                        neighbors_indices, features, radius, fc_weight, fc_bias, padding_num, reduction_mean, nullptr, grad_out, grad_features, grad_fc_weight, grad_fc_bias);
+    return cbl_status();
+}
+
+constexpr unsigned AW_MAX_GRID = 2048;
+static unsigned aw_csr_grid(int n0, int L)
+{
+    const int tpb = 256 / L;
+    const unsigned g = cbl_round_up8(cbl_div_up(n0, tpb));
+    return g > AW_MAX_GRID ? AW_MAX_GRID : g;
+}
+
+CBL_EXPORT size_t cbl_adaptive_weight_backward_csr_workspace_bytes(int n, int n0, int C)
+{
+    if (n <= 0 || n0 <= 0 || C <= 0) return 0;
+    return sizeof(float) * ((size_t)n + 256 + (size_t)AW_MAX_GRID * 4 * (size_t)C);           // 1 / nn per query point + per-workgroup partial rows
+}
+
+CBL_EXPORT int cbl_adaptive_weight_backward_csr(int n, int n0, int K, int C, const float* query_points, const float* support_points, const int* neighbors_indices,
+                                                const float* features, float radius, const float* fc_weight, const float* fc_bias, const int* padding_num,
+                                                int reduction_mean, const float* grad_out, const int* order_dst, const int* inv_start, const int* inv_src,
+                                                float* grad_features, float* grad_fc_weight, float* grad_fc_bias, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (n < 0 || n0 < 0 || K <= 0 || C <= 0 || !(radius > 0.f)) return CBL_ERR_BAD_ARG;
+    if (n == 0 || n0 == 0) return CBL_OK;
+    if (!query_points || !support_points || !neighbors_indices || !features || !fc_weight || !fc_bias || !grad_out || !inv_start || !inv_src ||
+        (reduction_mean && !padding_num)) return CBL_ERR_BAD_ARG;
+    if (C % 4 || !cbl_host_aligned16(features) || !cbl_host_aligned16(grad_out) || !cbl_host_aligned16(fc_weight) || !cbl_host_aligned16(fc_bias) ||
+        (grad_features && !cbl_host_aligned16(grad_features))) return CBL_ERR_UNSUPPORTED;
+    const bool gp = grad_fc_weight || grad_fc_bias;
+    if (!grad_features && !gp) return CBL_OK;
+    if (!workspace || workspace_bytes < cbl_adaptive_weight_backward_csr_workspace_bytes(n, n0, C)) return CBL_ERR_WORKSPACE;
+    hipStream_t st = cbl_stream(stream);
+    float* inv_nn = reinterpret_cast<float*>(workspace);
+    float* partial = inv_nn + (((size_t)n + 255) & ~(size_t)255);
+    hipLaunchKernelGGL(aw_inv_count_kernel, dim3(cbl_grid_for(n, 256)), dim3(256), 0, st, n, K, neighbors_indices, padding_num, reduction_mean, inv_nn);
+    const int C4 = C / 4;
+    const CblFastDiv dv = cbl_fastdiv_make((unsigned)K);
+    // columns in chunks of at most 256 float4 lanes; every chunk walks the table once with grid `g` (the same for all: the partial rows line up)
+    const int chunks = (C4 + 255) / 256;
+    const int Lmax = (C4 + chunks - 1) / chunks;
+    const unsigned g = aw_csr_grid(n0, Lmax);
+    for (int c4_0 = 0; c4_0 < C4; c4_0 += Lmax) {
+        const int L = min(Lmax, C4 - c4_0);
+#define CBL_AWB(GF_, GP_) hipLaunchKernelGGL((aw_bwd_csr_kernel<GF_, GP_>), dim3(g), dim3(256), 0, st, (unsigned)n0, C4, c4_0, L, dv, query_points, support_points, \
+        reinterpret_cast<const float4*>(features), 1.0f / radius, reinterpret_cast<const float4*>(fc_weight), reinterpret_cast<const float4*>(fc_bias), inv_nn, \
+        reinterpret_cast<const float4*>(grad_out), order_dst, inv_start, inv_src, reinterpret_cast<float4*>(grad_features), partial)
+        if (grad_features && gp) CBL_AWB(true, true); else if (grad_features) CBL_AWB(true, false); else CBL_AWB(false, true);
+#undef CBL_AWB
+    }
+    if (gp)
+        hipLaunchKernelGGL(aw_param_reduce_kernel, dim3(cbl_div_up(4 * C, 16)), dim3(256), 0, st, (int)g, C, partial, grad_fc_weight, grad_fc_bias);
     return cbl_status();
 }
 

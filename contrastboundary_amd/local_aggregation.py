@@ -111,12 +111,32 @@ class _AdaptiveWeight(Function):
         n, K = idx.shape
         n0, C = f.shape
         grad_out = grad_out.contiguous()
-        gf = torch.zeros_like(f) if ctx.needs_input_grad[3] else None
-        gw = torch.zeros_like(w) if ctx.needs_input_grad[4] else None
-        gb = torch.zeros_like(b) if ctx.needs_input_grad[5] else None
-        _lib.check(_lib.lib().cbl_adaptive_weight_backward(_i(n), _i(n0), _i(K), _i(C), _lib.ptr(q), _lib.ptr(s), _lib.ptr(idx), _lib.ptr(f), _f(radius),
-                                                           _lib.ptr(w), _lib.ptr(b), _lib.ptr(pad), _i(reduction_mean), _lib.ptr(grad_out),
-                                                           _lib.ptr(gf), _lib.ptr(gw), _lib.ptr(gb), _lib.stream_of(f)), "cbl_adaptive_weight_backward")
+        L = _lib.lib()
+        need_f, need_w, need_b = ctx.needs_input_grad[3], ctx.needs_input_grad[4], ctx.needs_input_grad[5]
+        from . import pointops
+        tr = None
+        if C % 4 == 0:
+            # gather over the transposed neighbour table (no atomics, deterministic); built where that pays, taken where it already exists
+            tr = pointops.neighbor_transpose(idx, n0, build=(n * K >= pointops.TRANSPOSE_MIN_PAIRS))
+        if tr is not None:
+            order, inv_start, inv_src = tr
+            gf = torch.empty_like(f) if need_f else None
+            gw = torch.empty_like(w) if need_w else None
+            gb = torch.empty_like(b) if need_b else None
+            ws = torch.empty(L.cbl_adaptive_weight_backward_csr_workspace_bytes(_i(n), _i(n0), _i(C)), dtype=torch.uint8, device=f.device)
+            rc = L.cbl_adaptive_weight_backward_csr(_i(n), _i(n0), _i(K), _i(C), _lib.ptr(q), _lib.ptr(s), _lib.ptr(idx), _lib.ptr(f), _f(radius), _lib.ptr(w),
+                                                    _lib.ptr(b), _lib.ptr(pad), _i(reduction_mean), _lib.ptr(grad_out), _lib.ptr(order), _lib.ptr(inv_start),
+                                                    _lib.ptr(inv_src), _lib.ptr(gf), _lib.ptr(gw), _lib.ptr(gb), _lib.ptr(ws), ctypes.c_size_t(ws.numel()),
+                                                    _lib.stream_of(f))
+            if rc != _lib.ERR_UNSUPPORTED:
+                _lib.check(rc, "cbl_adaptive_weight_backward_csr")
+                return None, None, None, gf, gw, gb, None, None
+        gf = torch.zeros_like(f) if need_f else None
+        gw = torch.zeros_like(w) if need_w else None
+        gb = torch.zeros_like(b) if need_b else None
+        _lib.check(L.cbl_adaptive_weight_backward(_i(n), _i(n0), _i(K), _i(C), _lib.ptr(q), _lib.ptr(s), _lib.ptr(idx), _lib.ptr(f), _f(radius),
+                                                  _lib.ptr(w), _lib.ptr(b), _lib.ptr(pad), _i(reduction_mean), _lib.ptr(grad_out),
+                                                  _lib.ptr(gf), _lib.ptr(gw), _lib.ptr(gb), _lib.stream_of(f)), "cbl_adaptive_weight_backward")
         return None, None, None, gf, gw, gb, None, None
 
 

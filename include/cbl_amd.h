@@ -369,6 +369,16 @@ int cbl_adaptive_weight_backward(int n, int n0, int K, int C, const float* query
                                  const float* features, float radius, const float* fc_weight, const float* fc_bias, const int* padding_num,
                                  int reduction_mean, const float* grad_out, float* grad_features, float* grad_fc_weight, float* grad_fc_bias, void* stream);
 
+/* the same gradients as a gather over the transposed table of neighbors_indices (cbl_neighbor_transpose with n targets = n0, pairs p = i*K + k; shadow
+ * neighbours are not in the table): no atomics, WRITTEN not accumulated (no pre-zeroing), deterministic — what tf.gather's gradient does for the reference
+ * (local_aggregation_operators.py:360-484 under tf.gradients).  C % 4 == 0 and 16-byte aligned rows (CBL_ERR_UNSUPPORTED otherwise: use
+ * cbl_adaptive_weight_backward). */
+size_t cbl_adaptive_weight_backward_csr_workspace_bytes(int n, int n0, int C);
+int cbl_adaptive_weight_backward_csr(int n, int n0, int K, int C, const float* query_points, const float* support_points, const int* neighbors_indices,
+                                     const float* features, float radius, const float* fc_weight, const float* fc_bias, const int* padding_num,
+                                     int reduction_mean, const float* grad_out, const int* order_dst, const int* inv_start, const int* inv_src,
+                                     float* grad_features, float* grad_fc_weight, float* grad_fc_bias, void* workspace, size_t workspace_bytes, void* stream);
+
 /* a14  PosPool  tensorflow/models/local_aggregation_operators.py:15-250 (shipped: config/s3dis/pospool.yaml:20-23 'sin_cos' + 'mean')
  *   out[p,c] = reduce_k geo[p,k,c/(C/mid)] * features[nbr(p,k),c]   (before pool_bn / activation / output_conv, :251-270)
  *   position_embedding: 0 'one' | 1 'xyz' | 2 'distance' | 3 'exp_-d' | 4 'direction_exp_-d' | 5 'direction_d' | 6 'sin_cos' |

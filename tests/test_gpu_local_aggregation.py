@@ -75,6 +75,40 @@ def test_adaptive_weight(K, C, reduction):
     np.testing.assert_allclose(bt.grad.cpu().numpy(), gb, rtol=1e-3, atol=1e-4 * np.abs(gb).max())
 
 
+@pytest.mark.parametrize("n0,n,K,C,reduction", [(3000, 2600, 26, 72, "mean"), (2000, 2000, 31, 144, "mean"), (900, 700, 38, 288, "sum"),
+                                                 (500, 400, 41, 576, "mean"), (300, 260, 39, 1152, "mean"), (800, 800, 9, 8, "mean")])
+def test_adaptive_weight_backward_as_a_gather(n0, n, K, C, reduction):
+    """the backward over the transposed neighbour table (no atomics): every lane / chunk geometry of the kernel (C/4 = 18, 36, 72, 144, 2 x 144, 2
+    lanes per target), query set != support set, shadow padding; values against the restatement, run-to-run bitwise identical"""
+    from contrastboundary_amd import local_aggregation as L, pointops
+    q, s, idx, f, rng = make(n0, n, K, C, seed=C + K)
+    W = (rng.normal(size=(3, C)) * 0.5).astype(np.float32); b = rng.normal(size=(C,)).astype(np.float32)
+    radius = 0.1
+    go = rng.normal(size=(n, C)).astype(np.float32)
+    grads = []
+    idx_d = dev(idx)
+    assert pointops.neighbor_transpose(idx_d, n0) is not None       # the table exists: the backward takes the gather path whatever the size
+    for _ in range(2):
+        ft = dev(f).requires_grad_(True); Wt = dev(W).requires_grad_(True); bt = dev(b).requires_grad_(True)
+        out = L.adaptive_weight(dev(q), dev(s), idx_d, ft, radius, Wt, bt, reduction)
+        out.backward(dev(go))
+        grads.append((ft.grad.cpu().numpy(), Wt.grad.cpu().numpy(), bt.grad.cpu().numpy()))
+    gf, gW, gb = LA.adaptive_weight_grads(q, s, idx, f, radius, W, b, go, reduction)
+    np.testing.assert_allclose(grads[0][0], gf, rtol=1e-4, atol=1e-4 * np.abs(gf).max())
+    np.testing.assert_allclose(grads[0][1], gW, rtol=1e-4, atol=1e-4 * np.abs(gW).max())
+    np.testing.assert_allclose(grads[0][2], gb, rtol=1e-4, atol=1e-4 * np.abs(gb).max())
+    for a, c in zip(grads[0], grads[1]):
+        np.testing.assert_array_equal(a.view(np.uint32), c.view(np.uint32))      # no atomics: deterministic
+    # only the feature gradient / only the parameter gradients
+    ft = dev(f).requires_grad_(True)
+    L.adaptive_weight(dev(q), dev(s), idx_d, ft, radius, dev(W), dev(b), reduction).backward(dev(go))
+    np.testing.assert_array_equal(ft.grad.cpu().numpy().view(np.uint32), grads[0][0].view(np.uint32))
+    Wt = dev(W).requires_grad_(True); bt = dev(b).requires_grad_(True)
+    L.adaptive_weight(dev(q), dev(s), idx_d, dev(f), radius, Wt, bt, reduction).backward(dev(go))
+    np.testing.assert_array_equal(Wt.grad.cpu().numpy().view(np.uint32), grads[0][1].view(np.uint32))
+    np.testing.assert_array_equal(bt.grad.cpu().numpy().view(np.uint32), grads[0][2].view(np.uint32))
+
+
 def test_adaptive_weight_mean_quirk_without_padding():
     # no row is padded -> padding_num = max(idx) is a REAL index and rows containing it count one neighbour less (:466-470)
     from contrastboundary_amd import local_aggregation as L
