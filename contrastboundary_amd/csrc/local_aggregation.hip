@@ -456,21 +456,31 @@ __global__ __launch_bounds__(256) void adaptive_weight_kernel(int n, int n0, int
     }
 }
 
-// Forward, C % 4 == 0: one lane = 4 consecutive channels of one point (16-byte row segments), a point's C/4 lanes sit next to
-// each other so a neighbour's feature row is read as one contiguous burst, and U neighbours are in flight per lane.  The wave-per-
-// point kernel above wastes the lanes past C (C = 72 runs a second pass with 8 of 64 lanes) and has one row in flight.
+// Forward, C % 4 == 0: one lane = 4 consecutive channels of one point (16-byte row segments), a point's L = C/4 lanes sit next to each other so a
+// neighbour's feature row is read as one contiguous burst, U neighbours are in flight per lane, and a workgroup takes tpb = 256 / L points per trip.
+// Trips are dealt to the XCDs in contiguous eighths of the processing sequence (`order`, or the row order: the pyramid's points leave the grid
+// subsampling sorted by voxel key), so a support row is pulled into ONE XCD's L2 instead of all eight (round 2: plain grid-stride over n * C/4).
+// The wave-per-point kernel above wastes the lanes past C (C = 72 runs a second pass with 8 of 64 lanes) and has one row in flight.
 template <int U>
-__global__ __launch_bounds__(256) void adaptive_weight_fwd_v4(int n, int n0, int K, int C4, const float* __restrict__ q, const float* __restrict__ s,
-                                                              const int* __restrict__ idx, const float4* __restrict__ f, float radius,
+__global__ __launch_bounds__(256) void adaptive_weight_fwd_v4(unsigned n, int n0, int K, int C4, int c4_0, int L, const float* __restrict__ q, const float* __restrict__ s,
+                                                              const int* __restrict__ idx, const float4* __restrict__ f, float inv_radius,
                                                               const float4* __restrict__ fcw, const float4* __restrict__ fcb,
-                                                              const int* __restrict__ padding_num, int reduction_mean, float4* __restrict__ out)
+                                                              const int* __restrict__ padding_num, int reduction_mean, const int* __restrict__ order,
+                                                              float4* __restrict__ out)
 {
     const int pad = reduction_mean ? *padding_num : 0;
-    const long long total = (long long)n * C4;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const int p = (int)(e / C4), cq = (int)(e - (long long)p * C4);
-        const float4 w0 = fcw[cq], w1 = fcw[C4 + cq], w2 = fcw[2 * C4 + cq], bb = fcb[cq];
-        const float qx = q[3 * p], qy = q[3 * p + 1], qz = q[3 * p + 2];
+    const int tpb = 256 / L;
+    const int ts = threadIdx.x / L, cl = threadIdx.x - ts * L;
+    if (ts >= tpb) return;
+    const int cq = c4_0 + cl;
+    const float4 w0 = fcw[cq], w1 = fcw[C4 + cq], w2 = fcw[2 * C4 + cq], bb = fcb[cq];
+    const unsigned ntrips = (n + tpb - 1) / tpb;
+    const unsigned vend = 8 * cbl_xcd_per(ntrips);
+    for (unsigned v = blockIdx.x; v < vend; v += gridDim.x) {
+        const unsigned tr = cbl_xcd_slot(v, ntrips) * tpb + ts;
+        if (tr >= n) continue;
+        const int p = order ? order[tr] : (int)tr;
+        const float qx = q[3 * (size_t)p], qy = q[3 * (size_t)p + 1], qz = q[3 * (size_t)p + 2];
         const int* __restrict__ row = idx + (size_t)p * K;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         int cnt = 0;
@@ -486,13 +496,13 @@ __global__ __launch_bounds__(256) void adaptive_weight_fwd_v4(int n, int n0, int
                 const bool real = id[u] >= 0 && id[u] < n0;
                 const int ic = real ? id[u] : 0;
                 fk[u] = f[(size_t)ic * C4 + cq];
-                rx[u] = s[3 * ic]; ry[u] = s[3 * ic + 1]; rz[u] = s[3 * ic + 2];
+                rx[u] = s[3 * (size_t)ic]; ry[u] = s[3 * (size_t)ic + 1]; rz[u] = s[3 * (size_t)ic + 2];
                 if (!real) { fk[u] = make_float4(0.f, 0.f, 0.f, 0.f); rx[u] = ry[u] = rz[u] = 0.f; }       // shadow row / point (:360-370)
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 if (k0 + u < K) {
-                    const float x = (rx[u] - qx) / radius, y = (ry[u] - qy) / radius, z = (rz[u] - qz) / radius;    // :369-373
+                    const float x = (rx[u] - qx) * inv_radius, y = (ry[u] - qy) * inv_radius, z = (rz[u] - qz) * inv_radius;    // :369-373 (one rounded reciprocal instead of three divisions per pair: within 1 ulp of them)
                     acc.x += (((x * w0.x + y * w1.x) + z * w2.x) + bb.x) * fk[u].x;                      // fc_1 with bias (:426-430), :457-464
                     acc.y += (((x * w0.y + y * w1.y) + z * w2.y) + bb.y) * fk[u].y;
                     acc.z += (((x * w0.z + y * w1.z) + z * w2.z) + bb.z) * fk[u].z;
@@ -759,25 +769,47 @@ CBL_EXPORT int cbl_index_max(long long total, const int* idx, int* out_max, void
     return cbl_status();
 }
 
-CBL_EXPORT int cbl_adaptive_weight_forward(int n, int n0, int K, int C, const float* query_points, const float* support_points, const int* neighbors_indices,
-                                           const float* features, float radius, const float* fc_weight, const float* fc_bias, const int* padding_num,
-                                           int reduction_mean, float* out, void* stream)
+static int adaptive_weight_forward_impl(int n, int n0, int K, int C, const float* query_points, const float* support_points, const int* neighbors_indices,
+                                        const float* features, float radius, const float* fc_weight, const float* fc_bias, const int* padding_num,
+                                        int reduction_mean, const int* order, float* out, void* stream)
 {
     if (n < 0 || n0 < 0 || K <= 0 || C <= 0 || !(radius > 0.f)) return CBL_ERR_BAD_ARG;
     if (n == 0) return CBL_OK;
     if (!query_points || !support_points || !neighbors_indices || !features || !fc_weight || !fc_bias || !out || (reduction_mean && !padding_num)) return CBL_ERR_BAD_ARG;
     const bool vec = (C % 4 == 0) && ((((uintptr_t)features | (uintptr_t)fc_weight | (uintptr_t)fc_bias | (uintptr_t)out) & 15) == 0);
-    if (vec)
-        hipLaunchKernelGGL(adaptive_weight_fwd_v4<4>, dim3(cbl_grid_for((long long)n * (C / 4), 256)), dim3(256), 0, cbl_stream(stream), n, n0, K, C / 4,
-                           query_points, support_points, neighbors_indices, reinterpret_cast<const float4*>(features), radius,
-                           reinterpret_cast<const float4*>(fc_weight), reinterpret_cast<const float4*>(fc_bias), padding_num, reduction_mean,
-                           reinterpret_cast<float4*>(out));
+    if (vec) {
+        const int C4 = C / 4, chunks = (C4 + 255) / 256, Lmax = (C4 + chunks - 1) / chunks;
+        for (int c4_0 = 0; c4_0 < C4; c4_0 += Lmax) {
+            const int L = min(Lmax, C4 - c4_0);
+            const unsigned g = min(cbl_round_up8(cbl_div_up(n, 256 / L)), 8192u);
+            hipLaunchKernelGGL(adaptive_weight_fwd_v4<4>, dim3(g), dim3(256), 0, cbl_stream(stream), (unsigned)n, n0, K, C4, c4_0, L,
+                               query_points, support_points, neighbors_indices, reinterpret_cast<const float4*>(features), 1.0f / radius,
+                               reinterpret_cast<const float4*>(fc_weight), reinterpret_cast<const float4*>(fc_bias), padding_num, reduction_mean, order,
+                               reinterpret_cast<float4*>(out));
+        }
+    }
     else {
         static int res_aw = 0;
         hipLaunchKernelGGL(adaptive_weight_kernel<false>, dim3(min(persistent_grid(n), resident_workgroups(&adaptive_weight_kernel<false>, res_aw))), dim3(256), 0, cbl_stream(stream), n, n0, K, C, query_points, support_points,
                            neighbors_indices, features, radius, fc_weight, fc_bias, padding_num, reduction_mean, out, nullptr, nullptr, nullptr, nullptr);
     }
     return cbl_status();
+}
+
+CBL_EXPORT int cbl_adaptive_weight_forward(int n, int n0, int K, int C, const float* query_points, const float* support_points, const int* neighbors_indices,
+                                           const float* features, float radius, const float* fc_weight, const float* fc_bias, const int* padding_num,
+                                           int reduction_mean, float* out, void* stream)
+{
+    return adaptive_weight_forward_impl(n, n0, K, C, query_points, support_points, neighbors_indices, features, radius, fc_weight, fc_bias, padding_num,
+                                        reduction_mean, nullptr, out, stream);
+}
+
+CBL_EXPORT int cbl_adaptive_weight_forward_ordered(int n, int n0, int K, int C, const float* query_points, const float* support_points, const int* neighbors_indices,
+                                                   const float* features, float radius, const float* fc_weight, const float* fc_bias, const int* padding_num,
+                                                   int reduction_mean, const int* order, float* out, void* stream)
+{
+    return adaptive_weight_forward_impl(n, n0, K, C, query_points, support_points, neighbors_indices, features, radius, fc_weight, fc_bias, padding_num,
+                                        reduction_mean, order, out, stream);
 }
 
 CBL_EXPORT int cbl_adaptive_weight_backward(int n, int n0, int K, int C, const float* query_points, const float* support_points, const int* neighbors_indices,

@@ -97,9 +97,11 @@ class _AdaptiveWeight(Function):
         if reduction_mean:
             _lib.check(L.cbl_index_max(ctypes.c_longlong(n * K), _lib.ptr(neighbors_indices), _lib.ptr(pad), _lib.stream_of(features)), "cbl_index_max")
         out = torch.empty((n, C), dtype=torch.float32, device=features.device)
-        _lib.check(L.cbl_adaptive_weight_forward(_i(n), _i(n0), _i(K), _i(C), _lib.ptr(query_points), _lib.ptr(support_points), _lib.ptr(neighbors_indices),
-                                                 _lib.ptr(features), _f(radius), _lib.ptr(fc_weight), _lib.ptr(fc_bias), _lib.ptr(pad), _i(reduction_mean),
-                                                 _lib.ptr(out), _lib.stream_of(features)), "cbl_adaptive_weight_forward")
+        from . import pointops
+        order = pointops.spatial_order(query_points)             # processing order only: same values (None: the rows as they are)
+        _lib.check(L.cbl_adaptive_weight_forward_ordered(_i(n), _i(n0), _i(K), _i(C), _lib.ptr(query_points), _lib.ptr(support_points), _lib.ptr(neighbors_indices),
+                                                         _lib.ptr(features), _f(radius), _lib.ptr(fc_weight), _lib.ptr(fc_bias), _lib.ptr(pad), _i(reduction_mean),
+                                                         _lib.ptr(order), _lib.ptr(out), _lib.stream_of(features)), "cbl_adaptive_weight_forward")
         ctx.save_for_backward(query_points, support_points, neighbors_indices, features, fc_weight, fc_bias, pad)
         ctx.cfg = (radius, reduction_mean)
         return out

@@ -364,6 +364,10 @@ int cbl_index_max(long long total, const int* idx, int* out_max, void* stream);
 int cbl_adaptive_weight_forward(int n, int n0, int K, int C, const float* query_points, const float* support_points, const int* neighbors_indices,
                                 const float* features, float radius, const float* fc_weight, const float* fc_bias, const int* padding_num,
                                 int reduction_mean, float* out, void* stream);
+/* same values; `order` (n ints, NULL = none) = processing sequence of the query points, see cbl_queryandgroup_ordered */
+int cbl_adaptive_weight_forward_ordered(int n, int n0, int K, int C, const float* query_points, const float* support_points, const int* neighbors_indices,
+                                        const float* features, float radius, const float* fc_weight, const float* fc_bias, const int* padding_num,
+                                        int reduction_mean, const int* order, float* out, void* stream);
 /* gradients: features (n0,C) +=, fc_weight (3,C) +=, fc_bias (C) +=  (caller pre-zeroes; any may be NULL) */
 int cbl_adaptive_weight_backward(int n, int n0, int K, int C, const float* query_points, const float* support_points, const int* neighbors_indices,
                                  const float* features, float radius, const float* fc_weight, const float* fc_bias, const int* padding_num,
