@@ -11,6 +11,7 @@ The 7.8 M parameters are NOT stored: the model is built under torch.manual_seed(
 modules in the same order, reproduces them from the seed (a parameter checksum is stored to prove it).  Stored per case: inputs,
 target, logits, the (1+5,) loss vector, the gradients of loss.sum() w.r.t. two parameter tensors (first and last layer), and the
 number of knnquery calls the reference made."""
+import copy
 import os
 import sys
 import types
@@ -84,7 +85,20 @@ for case, (lens, seed) in {"one_cloud_8192": ([8192], 0), "two_clouds_12000": ([
     out[f"{case}/state_dict_keys"] = np.array([f"{k}:{tuple(v.shape)}" for k, v in sd.items()])
     out[f"{case}/stage_sizes"] = np.array([st["p_out"].shape[0] for st in stage_list["up"]], np.int64)
     out[f"{case}/ref_knn_calls"] = np.int64(calls["knn"])
-    print(case, "loss", loss.detach().numpy(), "knn calls", calls["knn"], "stages", out[f"{case}/stage_sizes"])
+    # the same model, inputs and indices in float64 (`*64`): the summation-order-free value the 1e-4 parity bound is tested against
+    torch.cuda.FloatTensor = torch.DoubleTensor
+    m64 = copy.deepcopy(model).double(); m64.zero_grad(); m64.train()
+    # running statistics were advanced by the fp32 pass above: train-mode BatchNorm normalises with batch statistics, so they do not enter the outputs
+    in64 = {"points": inputs["points"].double(), "features": inputs["features"].double(), "offset": inputs["offset"]}
+    lg64, sl64 = m64(in64)
+    ls64 = crit(lg64, target, sl64)
+    ls64.sum().backward()
+    torch.cuda.FloatTensor = torch.FloatTensor
+    out[f"{case}/logits64"] = lg64.detach().numpy().astype(np.float32); out[f"{case}/loss64"] = ls64.detach().numpy().astype(np.float64)
+    out[f"{case}/grad_first64"] = m64.enc1[0].linear.weight.grad.numpy().astype(np.float32)
+    out[f"{case}/grad_last64"] = m64.head.cls.weight.grad.numpy().astype(np.float32)
+    print(case, "fp32 vs fp64 reference: logits", float(np.abs(out[f"{case}/logits"] - out[f"{case}/logits64"]).max()), "loss", np.abs(out[f"{case}/loss"] - out[f"{case}/loss64"]).max())
+    print(case, "loss", loss.detach().numpy(), "knn calls", int(out[f"{case}/ref_knn_calls"]), "stages", out[f"{case}/stage_sizes"])
 
 np.savez_compressed(os.path.join(HERE, "model_pytorch.npz"), **out)
 print("wrote", os.path.join(HERE, "model_pytorch.npz"), os.path.getsize(os.path.join(HERE, "model_pytorch.npz")) // 1024, "KiB")

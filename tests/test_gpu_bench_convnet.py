@@ -55,7 +55,7 @@ def test_convnet_step_against_the_oracles():
         rl, rg, rm = C.tf_contrast(arr["latent"], labels[lay], nb, temperature=1.0, weight=0.1)
         assert abs(state["cbl_loss%d" % lay].item() - rl) < 1e-4 * max(1.0, abs(rl))
         np.testing.assert_array_equal(cpu(state["cbl_mask%d" % lay]) > 0, rm > 0)
-        np.testing.assert_allclose(cpu(state["cbl_grad%d" % lay]), rg, rtol=1e-3, atol=1e-4 * max(np.abs(rg).max(), 1e-12))
+        np.testing.assert_allclose(cpu(state["cbl_grad%d" % lay]), rg, rtol=1e-4, atol=1e-4 * max(np.abs(rg).max(), 1e-12))
         if lay == CP.NUM_LAYERS - 1:
             break
         pp, pl = O.grid_subsampling(p, l, 2 * dl)

@@ -8,7 +8,16 @@ import torch
 
 pytestmark = pytest.mark.gpu
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "blocks_pytorch.npz"))
-TOL = dict(rtol=2e-4, atol=2e-4)        # fp32 BatchNorm statistics over n*K rows, different reduction order
+TOL = dict(rtol=2e-4, atol=2e-4)        # against the reference's fp32 run: two fp32 BatchNorm reductions in different orders
+
+
+def close64(got, ref64, what):
+    """north_star's bound, against the reference modules run in float64 (`*64` goldens): |got - ref| <= 1e-4 (|ref| + scale of the tensor)"""
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    ref = np.asarray(ref64, dtype=np.float64)
+    err = np.abs(got - ref)
+    bound = 1e-4 * (np.abs(ref) + np.abs(ref).max())
+    assert (err <= bound).all(), f"{what}: {int((err > bound).sum())} of {err.size} entries beyond 1e-4, worst {float((err / bound).max()):.2f}x the bound"
 
 
 def dev(a):
@@ -45,8 +54,10 @@ def test_point_transformer_layer_and_block(name, inputs):
     y = mod([p, x, o])
     y = y[1] if isinstance(y, list) else y
     np.testing.assert_allclose(y.detach().cpu().numpy(), G[f"{name}/out"], **TOL)
+    close64(y, G[f"{name}/out64"], f"{name} output")
     (y * g).sum().backward()
     grads_close(x.grad, G[f"{name}/grad_x"])
+    close64(x.grad, G[f"{name}/grad_x64"], f"{name} input gradient")
 
 
 def test_transition_down_and_up(inputs):
@@ -58,8 +69,10 @@ def test_transition_down_and_up(inputs):
     np.testing.assert_array_equal(p2.cpu().numpy(), G["down/p"])                   # FPS picks the same points
     np.testing.assert_array_equal(o2.cpu().numpy(), G["down/offset"])
     np.testing.assert_allclose(y2.detach().cpu().numpy(), G["down/out"], **TOL)
+    close64(y2, G["down/out64"], "TransitionDown output")
     (y2 * dev(G["down/g"])).sum().backward()
     grads_close(x.grad, G["down/grad_x"])
+    close64(x.grad, G["down/grad_x64"], "TransitionDown input gradient")
 
     tu = load(B.TransitionUp(64, 32), "up")
     x1 = dev(G["x"]).requires_grad_(True); x2 = dev(G["down/out"]).requires_grad_(True)
@@ -132,3 +145,29 @@ def test_aggregation_with_the_softmax_inside_equals_softmax_then_aggregation(n, 
     assert rel(res[0][0], res[1][0]) < 1e-5
     for k in base:
         assert rel(res[0][1][k], res[1][1][k]) < (2e-4 if k in ("x_v",) else 1e-4), k      # x_v: fp32 atomics in both, different order
+
+
+@pytest.mark.parametrize("c", [128, 256, 512])
+def test_wide_layers_against_the_reference_layer(c):
+    """a4 at the widths of the deeper stages (the fused wide path, MFMA through LDS-staged pair tiles) against the REFERENCE's
+    PointTransformerLayer run on CPU (tests/golden/gen_blocks_wide_goldens.py); weights and inputs are re-created from the stored seeds and
+    checked against the fixture's checksums first.  Bound: 1e-4 against the reference layer run in float64."""
+    from contrastboundary_amd import blocks as B
+    W = np.load(os.path.join(os.path.dirname(__file__), "golden", "blocks_wide_pytorch.npz"))
+    pre = f"c{c}"
+    cc, n, seed = [int(v) for v in W[f"{pre}/meta"]]
+    torch.manual_seed(seed)
+    layer = B.PointTransformerLayer(cc, cc, 8, 16)
+    sd = layer.state_dict()
+    names = [str(k) for k in W[f"{pre}/sd_names"]]
+    assert sorted(sd.keys()) == names
+    np.testing.assert_allclose([float(sd[k].double().sum()) for k in names], W[f"{pre}/sd_sums"], rtol=0, atol=1e-9)   # the reference's initial weights
+    gen = torch.Generator().manual_seed(1000 + seed)
+    x = torch.randn(n, cc, generator=gen); g = torch.randn(n, cc, generator=gen)
+    np.testing.assert_allclose([float(x.double().sum()), float(g.double().sum())], W[f"{pre}/xg_sums"], rtol=0, atol=1e-9)
+    layer = layer.cuda().train()
+    xd = x.cuda().requires_grad_(True)
+    y = layer([dev(W[f"{pre}/p"]), xd, dev(W[f"{pre}/offset"])])
+    close64(y, W[f"{pre}/out64"], f"C={c} layer output")
+    (y * g.cuda()).sum().backward()
+    close64(xd.grad, W[f"{pre}/grad_x64"], f"C={c} layer input gradient")

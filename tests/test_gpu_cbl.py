@@ -74,7 +74,7 @@ def test_point_contrast_vs_oracle(nsample, d):
     rloss, rgrad, rmask = C.point_contrast(feat, np.eye(13, dtype=np.float32)[lab], idx, temperature=0.7, weight=0.1)
     np.testing.assert_array_equal(mask.cpu().numpy().astype(bool), rmask)
     np.testing.assert_allclose(loss.item(), rloss, rtol=TOL)
-    np.testing.assert_allclose(f.grad.cpu().numpy(), rgrad, rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(f.grad.cpu().numpy(), rgrad, rtol=1e-4, atol=1e-4 * np.abs(rgrad).max())
 
 
 def test_no_boundary_point_gives_zero_loss_and_zero_grad():
@@ -153,7 +153,7 @@ def test_tf_contrast_head_vs_oracle(limit, d, T):
     rl, rg, rm = C.tf_contrast(feat, lab, nb.cpu().numpy(), temperature=T, weight=0.1)
     np.testing.assert_array_equal(mask.cpu().numpy().astype(bool), rm)
     np.testing.assert_allclose(loss.item(), rl, rtol=TOL)
-    np.testing.assert_allclose(f.grad.cpu().numpy(), rg, rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(f.grad.cpu().numpy(), rg, rtol=1e-4, atol=1e-4 * np.abs(rg).max())
     assert (nb.cpu().numpy() == 6000).any()                                   # the case really contains shadow entries
 
 
@@ -182,7 +182,7 @@ def test_tf_contrast_head_labelkl_vs_oracle(limit, d, T, thr):
     np.testing.assert_array_equal(mask.cpu().numpy().astype(bool), rm)
     assert rm.any() and not rm.all()
     np.testing.assert_allclose(loss.item(), rl, rtol=TOL)
-    np.testing.assert_allclose(f.grad.cpu().numpy(), rg, rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(f.grad.cpu().numpy(), rg, rtol=1e-4, atol=1e-4 * np.abs(rg).max())
     assert (nb_h == m).any()                                                   # shadow entries present
     # inference path (no gradient): same loss
     with torch.no_grad():
@@ -307,7 +307,7 @@ def test_point_contrast_nce_vs_oracle(nsample, d, temperature):
     rloss, rgrad, rmask = C.point_contrast(feat, np.eye(13, dtype=np.float32)[lab], idx, temperature=temperature, weight=0.1, contrast="nce")
     np.testing.assert_array_equal(mask.cpu().numpy().astype(bool), rmask)
     np.testing.assert_allclose(loss.item(), rloss, rtol=TOL)
-    np.testing.assert_allclose(f.grad.cpu().numpy(), rgrad, rtol=1e-3, atol=1e-4 * np.abs(rgrad).max())
+    np.testing.assert_allclose(f.grad.cpu().numpy(), rgrad, rtol=1e-4, atol=1e-4 * np.abs(rgrad).max())
 
 
 @pytest.mark.parametrize("k,d", [(16, 32), (27, 16)])
@@ -333,7 +333,7 @@ def test_tf_contrast_nce_vs_oracle(k, d):
     rloss, rgrad, rmask = C.tf_contrast(feat, lab, nb, temperature=0.8, weight=0.1, contrast="nce")
     np.testing.assert_array_equal(mask.cpu().numpy().astype(bool), rmask)
     np.testing.assert_allclose(loss.item(), rloss, rtol=TOL)
-    np.testing.assert_allclose(f.grad.cpu().numpy(), rgrad, rtol=1e-3, atol=1e-4 * np.abs(rgrad).max())
+    np.testing.assert_allclose(f.grad.cpu().numpy(), rgrad, rtol=1e-4, atol=1e-4 * np.abs(rgrad).max())
 
 
 def test_coincident_points_keep_the_reference_column_zero():
@@ -359,7 +359,7 @@ def test_coincident_points_keep_the_reference_column_zero():
     loss.backward()
     rloss, rgrad, _ = C.point_contrast(feat, np.eye(13, dtype=np.float32)[lab], ridx, temperature=1.0, weight=0.1)
     np.testing.assert_allclose(loss.item(), rloss, rtol=TOL)
-    np.testing.assert_allclose(f.grad.cpu().numpy(), rgrad, rtol=1e-3, atol=1e-4 * np.abs(rgrad).max())
+    np.testing.assert_allclose(f.grad.cpu().numpy(), rgrad, rtol=1e-4, atol=1e-4 * np.abs(rgrad).max())
 
 
 @pytest.mark.parametrize("d", [8, 32])
@@ -385,5 +385,5 @@ def test_point_contrast_with_hub_targets_vs_oracle(d):
     rloss, rgrad, rmask = C.point_contrast(feat, np.eye(5, dtype=np.float32)[lab], idx, temperature=0.9, weight=0.1)
     np.testing.assert_array_equal(mask.cpu().numpy().astype(bool), rmask)
     np.testing.assert_allclose(loss.item(), rloss, rtol=TOL)
-    np.testing.assert_allclose(grads[0], rgrad, rtol=1e-3, atol=1e-4 * np.abs(rgrad).max())
+    np.testing.assert_allclose(grads[0], rgrad, rtol=1e-4, atol=1e-4 * np.abs(rgrad).max())
     assert np.array_equal(grads[0], grads[1])

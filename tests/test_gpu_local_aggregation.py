@@ -53,8 +53,8 @@ def test_kpconv(K, C, KP, influence, mode):
         return
     out.backward(dev(go))
     gf, gkw = LA.kpconv_grads(q, s, idx, f, kpts, kw, extent, go, influence, mode)
-    np.testing.assert_allclose(ft.grad.cpu().numpy(), gf, rtol=1e-3, atol=1e-4 * np.abs(gf).max())
-    np.testing.assert_allclose(kwt.grad.cpu().numpy(), gkw, rtol=1e-3, atol=1e-4 * np.abs(gkw).max())
+    np.testing.assert_allclose(ft.grad.cpu().numpy(), gf, rtol=1e-4, atol=1e-4 * np.abs(gf).max())
+    np.testing.assert_allclose(kwt.grad.cpu().numpy(), gkw, rtol=1e-4, atol=1e-4 * np.abs(gkw).max())
 
 
 @pytest.mark.parametrize("K,C,reduction", [(26, 72, "mean"), (16, 64, "mean"), (41, 100, "sum")])
@@ -70,9 +70,9 @@ def test_adaptive_weight(K, C, reduction):
     go = rng.normal(size=ref.shape).astype(np.float32)
     out.backward(dev(go))
     gf, gW, gb = LA.adaptive_weight_grads(q, s, idx, f, radius, W, b, go, reduction)
-    np.testing.assert_allclose(ft.grad.cpu().numpy(), gf, rtol=1e-3, atol=1e-4 * np.abs(gf).max())
-    np.testing.assert_allclose(Wt.grad.cpu().numpy(), gW, rtol=1e-3, atol=1e-4 * np.abs(gW).max())
-    np.testing.assert_allclose(bt.grad.cpu().numpy(), gb, rtol=1e-3, atol=1e-4 * np.abs(gb).max())
+    np.testing.assert_allclose(ft.grad.cpu().numpy(), gf, rtol=1e-4, atol=1e-4 * np.abs(gf).max())
+    np.testing.assert_allclose(Wt.grad.cpu().numpy(), gW, rtol=1e-4, atol=1e-4 * np.abs(gW).max())
+    np.testing.assert_allclose(bt.grad.cpu().numpy(), gb, rtol=1e-4, atol=1e-4 * np.abs(gb).max())
 
 
 @pytest.mark.parametrize("n0,n,K,C,reduction", [(3000, 2600, 26, 72, "mean"), (2000, 2000, 31, 144, "mean"), (900, 700, 38, 288, "sum"),
@@ -162,7 +162,7 @@ def test_pospool(pe, C, reduction, K):
     go = rng.normal(size=ref.shape).astype(np.float32)
     out.backward(dev(go))
     gf = LA.pospool_grad_features(q, s, idx, f, radius, go, pe, reduction)
-    np.testing.assert_allclose(ft.grad.cpu().numpy(), gf, rtol=1e-3, atol=1e-4 * max(np.abs(gf).max(), 1.0))
+    np.testing.assert_allclose(ft.grad.cpu().numpy(), gf, rtol=1e-4, atol=1e-4 * max(np.abs(gf).max(), 1.0))
 
 
 def test_pospool_rejects_what_the_reference_cannot_reshape():
@@ -204,9 +204,9 @@ def test_kpconv_backward_as_a_gather(K, C, KP, influence, mode):
                                              _lib.ptr(order), _lib.ptr(inv_start), _lib.ptr(inv_src), _lib.ptr(gf), _lib.ptr(gkw), _lib.ptr(ws),
                                              ctypes.c_size_t(ws.numel()), _lib.stream_of(fd)), "cbl_kpconv_backward_csr")
         if want_f:
-            np.testing.assert_allclose(gf.cpu().numpy(), gf_ref, rtol=1e-3, atol=1e-4 * np.abs(gf_ref).max())
+            np.testing.assert_allclose(gf.cpu().numpy(), gf_ref, rtol=1e-4, atol=1e-4 * np.abs(gf_ref).max())
         if want_w:
-            np.testing.assert_allclose(gkw.cpu().numpy(), gkw_ref, rtol=1e-3, atol=1e-4 * np.abs(gkw_ref).max())
+            np.testing.assert_allclose(gkw.cpu().numpy(), gkw_ref, rtol=1e-4, atol=1e-4 * np.abs(gkw_ref).max())
         outs.append((gf, gkw))
     assert torch.equal(outs[0][0], outs[3][0]) and torch.equal(outs[0][1], outs[3][1])
 

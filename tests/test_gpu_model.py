@@ -1,8 +1,9 @@
 """GPU parity of the full network + criterion (C4: Point Transformer + CBL) against the reference's own model run on CPU
 (tests/golden/model_pytorch.npz, made by gen_model_goldens.py: reference code + CPU oracle KNN / FPS).  The mirror is built under
 the same seed, which reproduces the reference's 7.8 M initial parameters (checked by checksum).  Indices (FPS, KNN) are bit-exact,
-so the two runs differ only by float summation order in the dense layers: logits / losses within 2e-3 relative, parameter
-gradients within 2 % in L2 (ReLU / max-pool ties can flip single entries)."""
+so the two runs differ only by float summation order in the dense layers.  Against the reference's fp32 run: logits / losses within 2e-3
+relative, parameter gradients within 2 % in L2 (ReLU / max-pool ties can flip single entries); against the reference run in FLOAT64 (`*64`
+goldens): every logit and loss term within 1e-4."""
 import os
 
 import numpy as np
@@ -58,6 +59,17 @@ def test_network_and_criterion_match_reference(case):
     np.testing.assert_allclose(loss.detach().cpu().numpy(), g("loss"), rtol=2e-3, atol=1e-5)
     assert rel_l2(model.enc1[0].linear.weight.grad.cpu().numpy(), g("grad_first")) < 2e-2
     assert rel_l2(model.head.cls.weight.grad.cpu().numpy(), g("grad_last")) < 2e-2
+    # against the reference network run in float64 on the same inputs and indices (`*64`): north_star's 1e-4 on what the network outputs.
+    # Every logit within 1e-4 of the logits' scale, every loss term within 1e-4 relative.  The parameter gradients pass through ~60 ReLU /
+    # max-pool / BatchNorm layers: an activation within rounding of zero flips its mask between two fp32 runs (the reference's own fp32 run
+    # differs from its fp64 run the same way: 1.6e-3 in L2 on the first layer's weight gradient, 3e-6 on the classifier's), so the first
+    # layer's gradient (measured 0.85e-2: a handful of flipped masks among 60 layers, amplified by the BatchNorm backward) is held to 2e-2 in L2
+    # as against the fp32 run, and the last layer's to 1e-4.
+    lg = logits.detach().cpu().numpy().astype(np.float64)
+    assert np.abs(lg - g("logits64")).max() <= 1e-4 * np.abs(g("logits64")).max(), float(np.abs(lg - g("logits64")).max() / np.abs(g("logits64")).max())
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), g("loss64"), rtol=1e-4, atol=1e-6)
+    assert rel_l2(model.enc1[0].linear.weight.grad.cpu().numpy(), g("grad_first64")) < 2e-2
+    assert rel_l2(model.head.cls.weight.grad.cpu().numpy(), g("grad_last64")) < 1e-4
     # neighbour cache: the reference issued 57 knnquery launches for this step; the mirror's blocks ask 39 times (one search per
     # layer instead of two) and 26 of those are distinct: 5 self + 4 down + 4 up (k=3) + 4 multi-head (k=1) + 5 CBL + 4 sub-scene
     assert int(g("ref_knn_calls")) == 57

@@ -123,3 +123,33 @@ def test_oracle_knn_batch_equals_pointops_knn_on_tie_free_data():
     a = O.knn_batch(pts, pts, 5)
     idx, _ = O.knnquery(5, pts.reshape(-1, 3), pts.reshape(-1, 3), [500, 1000], [500, 1000])
     np.testing.assert_array_equal(a.reshape(-1, 5) + np.repeat([0, 500], 500)[:, None], idx)
+
+
+@need
+@pytest.mark.parametrize("K", [16, 36])
+def test_oracle_knnquery_on_the_bench_scene_against_the_compiled_reference_kdtree(K):
+    """the scene bench.py times (S-room, 40960 points, seed 0): the restatement of knnquery_cuda_kernel.cu:65-111 (every query, all host cores)
+    against the reference's own kd-tree KNN compiled from /root/reference (knn_.cxx cpp_knn_omp -> oracle/_ref/libref_knn.so).  Rows whose K-th and
+    (K+1)-th neighbours are at exactly the same squared distance are decided by a tie rule (heap order vs kd-tree traversal): everywhere else the
+    two must list the same neighbours in the same order, and on tied rows the same multiset of distances."""
+    from contrastboundary_amd import hotpath
+    sc = hotpath.Scene.synthetic_numpy(40960, 64, 0)
+    xyz, off = sc["xyz"], sc["offset"]
+    n = len(xyz)
+    idx = np.zeros((n, K), np.int32); d2 = np.zeros((n, K), np.float32)
+    O.lib().oracle_knnquery_omp(n, K, O.P(xyz), O.P(xyz), O.P(off), O.P(off), O.P(idx), O.P(d2), 0)
+    ref = np.zeros((n, K), np.int64)
+    knn.ref_knn(O.P(xyz), ctypes.c_long(n), O.P(xyz), ctypes.c_long(n), ctypes.c_long(K), O.P(ref), 1)
+    same = (idx == ref).all(1)
+    # distances of the reference's lists, computed with the kernel's own expression
+    d = xyz[ref] - xyz[:, None, :]
+    rd2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+    np.testing.assert_array_equal(np.sort(rd2, 1).view(np.uint32), d2.view(np.uint32))      # the same K smallest distances for EVERY query
+    diff = np.flatnonzero(~same)
+    # a differing row must contain a tie: two of its K+1 smallest distances are equal (inside the list, or between its last entry and the next point)
+    if len(diff):
+        q = xyz[diff]
+        dx = xyz[None, :, 0] - q[:, None, 0]; dy = xyz[None, :, 1] - q[:, None, 1]; dz = xyz[None, :, 2] - q[:, None, 2]
+        full = np.sort((dx * dx + dy * dy) + dz * dz, 1)[:, :K + 1]
+        assert ((full[:, 1:] == full[:, :-1]).any(1)).all(), "rows differ from the reference kd-tree without a tie among their K+1 nearest"
+    assert same.mean() > 0.99
