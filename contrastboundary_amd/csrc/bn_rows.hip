@@ -215,25 +215,40 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_small_fwd_kernel(int rows, int C,
                                                                 long long* __restrict__ num_batches_tracked, int relu,
                                                                 float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ y)
 {
-    __shared__ double red[4][8];
+    __shared__ double red[4][4];
     const int c0 = blockIdx.x * 4;
     if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) num_batches_tracked[0] += 1;
     float4 xv[BN_SMALL_PER];
-    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < BN_SMALL_PER; k++) {
         const int r = k * BN_BLOCK + (int)threadIdx.x;
         xv[k] = r < rows ? *reinterpret_cast<const float4*>(x + (size_t)r * C + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
         s[0] += xv[k].x; s[1] += xv[k].y; s[2] += xv[k].z; s[3] += xv[k].w;
-        s[4] += xv[k].x * xv[k].x; s[5] += xv[k].y * xv[k].y; s[6] += xv[k].z * xv[k].z; s[7] += xv[k].w * xv[k].w;
     }
-    double tot[8];
-    bn_block_sums<8>(s, tot, red);
+    // two passes over the rows (they sit in registers): the variance as the mean of squared deviations, not E[x^2] - mean^2, which loses every
+    // digit once |mean| >> std (what torch's Welford update avoids as well)
+    double tot[4], tot2[4];
+    bn_block_sums<4>(s, tot, red);
+    float mf[4];
+#pragma unroll
+    for (int v = 0; v < 4; v++) mf[v] = (float)(tot[v] / (double)rows);
+    float s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < BN_SMALL_PER; k++) {
+        const int r = k * BN_BLOCK + (int)threadIdx.x;
+        if (r < rows) {
+            const float dx = xv[k].x - mf[0], dy = xv[k].y - mf[1], dz = xv[k].z - mf[2], dw = xv[k].w - mf[3];
+            s2[0] += dx * dx; s2[1] += dy * dy; s2[2] += dz * dz; s2[3] += dw * dw;
+        }
+    }
+    bn_block_sums<4>(s2, tot2, red);
     float mu[4], is[4], w[4], b[4];
 #pragma unroll
     for (int v = 0; v < 4; v++) {
         const double m = tot[v] / (double)rows;
-        double var = tot[4 + v] / (double)rows - m * m;
+        // sum (x - mf)^2 = sum (x - m)^2 + rows (m - mf)^2: the float rounding of the mean is taken back out
+        double var = tot2[v] / (double)rows - (m - (double)mf[v]) * (m - (double)mf[v]);
         if (var < 0.0) var = 0.0;
         mu[v] = (float)m;
         // 1 / sqrt in fp32 with one Newton step on the hardware estimate (the fp64 divide + square root were ~250 instructions per workgroup)

@@ -278,6 +278,40 @@ int dispatch_pairs_um(int U, unsigned g, hipStream_t st, int m, int nsample, con
     return CBL_ERR_UNSUPPORTED;
 }
 
+// pass B without a transposed table (scenes beyond its 1 M-row limit): grad = grad_own * scale, then one float atomic per (pair with a coefficient,
+// channel) — the reference's own index_select backward.  Not deterministic in the last bits; used only where the gather form is unavailable.
+__global__ __launch_bounds__(256) void contrast_own_scale_kernel(long long total4, const float4* __restrict__ grad_own, const float* __restrict__ stats,
+                                                                 const float* __restrict__ grad_loss, float weight, float4* __restrict__ grad)
+{
+    const float count = stats[1];
+    const float scale = count > 0.f ? grad_loss[0] * weight / count : 0.f;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long long)gridDim.x * 256) {
+        const float4 o = grad_own[e];
+        grad[e] = make_float4(o.x * scale, o.y * scale, o.z * scale, o.w * scale);
+    }
+}
+__global__ __launch_bounds__(256) void contrast_scatter_kernel(long long pairs, int lr, CblFastDiv dv, int n_valid, const float4* __restrict__ feat,
+                                                               const float* __restrict__ coef, const int* __restrict__ nidx, const float* __restrict__ stats,
+                                                               const float* __restrict__ grad_loss, float weight, float* __restrict__ grad)
+{
+    const float count = stats[1];
+    if (!(count > 0.f)) return;
+    const float scale = grad_loss[0] * weight / count;
+    const long long total = pairs * lr;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long p = e / lr; const int q = (int)(e - p * lr);
+        const float c = coef[p];
+        if (c == 0.f) continue;
+        const int t = nidx[p];
+        if (t < 0 || t >= n_valid) continue;
+        const long long i = (long long)cbl_fastdiv((unsigned)p, dv);
+        const float4 ft = feat[(size_t)t * lr + q], fi = feat[(size_t)i * lr + q];
+        float* g = grad + ((size_t)t * lr + q) * 4;
+        unsafeAtomicAdd(g, scale * (c * (ft.x - fi.x))); unsafeAtomicAdd(g + 1, scale * (c * (ft.y - fi.y)));
+        unsafeAtomicAdd(g + 2, scale * (c * (ft.z - fi.z))); unsafeAtomicAdd(g + 3, scale * (c * (ft.w - fi.w)));
+    }
+}
+
 }  // namespace
 
 // deterministic reduction of the per-point terms (cbl.hip)
@@ -336,5 +370,22 @@ CBL_EXPORT int cbl_contrast_pairs_backward(int m, int nsample, int d, const floa
         default: return CBL_ERR_UNSUPPORTED;
     }
 #undef CBL_GATHER_LR
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_contrast_pairs_backward_atomic(int m, int n_valid, int nsample, int d, const float* features, const float* coef, const float* grad_own,
+                                                  const int* neighbor_idx, const float* stats, const float* grad_loss, float weight,
+                                                  float* grad_features, void* stream)
+{
+    if (m <= 0 || nsample < 2 || nsample > 65 || d <= 0) return CBL_ERR_BAD_ARG;
+    if (!features || !coef || !grad_own || !neighbor_idx || !stats || !grad_loss || !grad_features) return CBL_ERR_BAD_ARG;
+    if (!cbl_host_aligned16(features) || !cbl_host_aligned16(grad_own) || !cbl_host_aligned16(grad_features)) return CBL_ERR_BAD_ARG;
+    if (d % 4 || d > 64 || (long long)m * nsample > 0x7fffffffll) return CBL_ERR_UNSUPPORTED;
+    hipStream_t st = cbl_stream(stream);
+    const long long total4 = (long long)m * (d / 4), pairs = (long long)m * nsample;
+    hipLaunchKernelGGL(contrast_own_scale_kernel, dim3(cbl_grid_for(total4, 256)), dim3(256), 0, st, total4, reinterpret_cast<const float4*>(grad_own), stats, grad_loss,
+                       weight, reinterpret_cast<float4*>(grad_features));
+    hipLaunchKernelGGL(contrast_scatter_kernel, dim3(cbl_grid_for(pairs * (d / 4), 256)), dim3(256), 0, st, pairs, d / 4, cbl_fastdiv_make((unsigned)nsample),
+                       n_valid < m ? n_valid : m, reinterpret_cast<const float4*>(features), coef, neighbor_idx, stats, grad_loss, weight, grad_features);
     return cbl_status();
 }

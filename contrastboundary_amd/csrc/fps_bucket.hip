@@ -16,7 +16,9 @@
 // sample on average); the t values, and therefore the arg-max sequence, are identical by construction.  One barrier and one L2
 // round trip per sample.
 #include "cbl_common.h"
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 #include <math.h>
 
 int cbl_bbox_keys_launch(int b, int n, const float* xyz, const int* offset, unsigned* bbox, hipStream_t st);   // knn_grid.hip
@@ -52,7 +54,7 @@ FbWs carve_fb(void* base, int b, int n)
     w.sorted = reinterpret_cast<float4*>(take(16 * (size_t)n));
     w.rank = reinterpret_cast<unsigned*>(take(4 * (size_t)n));
     size_t sort_bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, w.keys_in, w.keys_out, w.vals_in, w.vals_out, n > 0 ? n : 1);
+    (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, w.keys_in, w.keys_out, w.vals_in, w.vals_out, (size_t)(n > 0 ? n : 1));
     w.cub_bytes = sort_bytes;
     w.cub = take(w.cub_bytes + 256);
     w.bytes = off;
@@ -350,7 +352,7 @@ int cbl_fps_bucket_launch(int b, int n, int n_max, int bits, const float* xyz, c
     if (rc) return rc;
     hipLaunchKernelGGL(fb_keys_kernel, g, blk, 0, st, b, n, xyz, offset, w.bbox, w.keys_in, w.vals_in);
     size_t cb = w.cub_bytes;
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(w.cub, cb, w.keys_in, w.keys_out, w.vals_in, w.vals_out, n, 0, 48, st);
+    hipError_t e = rocprim::radix_sort_pairs(w.cub, cb, w.keys_in, w.keys_out, w.vals_in, w.vals_out, (size_t)n, 0u, 48u, st);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(fb_gather_kernel, g, blk, 0, st, b, n, bits, xyz, offset, tmp, w.keys_out, w.vals_out, w.sorted, w.rank);
     if (nb_max <= 1024) hipLaunchKernelGGL(fps_bucket_kernel<1>, dim3(b), dim3(1024), 0, st, bits, xyz, offset, new_offset, w.sorted, w.rank, idx);

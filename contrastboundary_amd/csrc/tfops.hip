@@ -12,7 +12,9 @@
 // the order the hash map accumulates them in — so barycentres are bit-identical to the reference; voxels come out in
 // ascending key order per cloud (the reference's order is libstdc++'s hash iteration order, i.e. unspecified).
 #include "cbl_common.h"
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 size_t cbl_radius_workspace_bytes_impl(int b, int ns);
 int cbl_bbox_keys_launch(int b, int n, const float* xyz, const int* offset, unsigned* bbox, hipStream_t st);   // knn_grid.hip
@@ -48,8 +50,8 @@ SubWs carve_sub(void* base, int b, int n)
     w.flags = reinterpret_cast<int*>(take(4 * (size_t)n));
     w.vox_id = reinterpret_cast<int*>(take(4 * (size_t)n));
     size_t sort_bytes = 0, scan_bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, w.keys_in, w.keys_out, w.vals_in, w.vals_out, n > 0 ? n : 1);
-    (void)hipcub::DeviceScan::InclusiveSum(nullptr, scan_bytes, w.flags, w.vox_id, n > 0 ? n : 1);
+    (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, w.keys_in, w.keys_out, w.vals_in, w.vals_out, (size_t)(n > 0 ? n : 1));
+    (void)rocprim::inclusive_scan(nullptr, scan_bytes, w.flags, w.vox_id, (size_t)(n > 0 ? n : 1), rocprim::plus<int>());
     w.cub_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
     w.cub = take(w.cub_bytes + 256);
     w.bytes = off;
@@ -216,11 +218,11 @@ CBL_EXPORT int cbl_grid_subsampling(int b, int n, const float* points, const int
     if (rc) return rc;
     hipLaunchKernelGGL(sub_keys_kernel, g, blk, 0, st, b, n, dl, points, offset, w.bbox, w.keys_in, w.vals_in);
     size_t cb = w.cub_bytes;
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(w.cub, cb, w.keys_in, w.keys_out, w.vals_in, w.vals_out, n, 0, 64, st);
+    hipError_t e = rocprim::radix_sort_pairs(w.cub, cb, w.keys_in, w.keys_out, w.vals_in, w.vals_out, (size_t)n, 0u, 64u, st);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(sub_flags_kernel, g, blk, 0, st, n, w.keys_out, w.flags);
     cb = w.cub_bytes;
-    e = hipcub::DeviceScan::InclusiveSum(w.cub, cb, w.flags, w.vox_id, n, st);
+    e = rocprim::inclusive_scan(w.cub, cb, w.flags, w.vox_id, (size_t)n, rocprim::plus<int>(), st);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(sub_reduce_kernel, g, blk, 0, st, n, w.keys_out, w.vals_out, w.flags, w.vox_id, points, fdim, features, ldim, labels,
                        out_points, out_features, out_labels, out_lengths, out_total);
@@ -269,11 +271,11 @@ CBL_EXPORT int cbl_voxelize(int n, int is_f64, const void* coord, double voxel_s
     if (is_f64) hipLaunchKernelGGL(voxel_keys_kernel<double>, g, blk, 0, st, n, reinterpret_cast<const double*>(coord), voxel_size, w.keys_in, w.vals_in);
     else        hipLaunchKernelGGL(voxel_keys_kernel<float>, g, blk, 0, st, n, reinterpret_cast<const float*>(coord), (float)voxel_size, w.keys_in, w.vals_in);
     size_t cb = w.cub_bytes;
-    e = hipcub::DeviceRadixSort::SortPairs(w.cub, cb, w.keys_in, keys_sorted, w.vals_in, idx_sort, n, 0, 64, st);
+    e = rocprim::radix_sort_pairs(w.cub, cb, w.keys_in, keys_sorted, w.vals_in, idx_sort, (size_t)n, 0u, 64u, st);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(sub_flags_kernel, g, blk, 0, st, n, keys_sorted, w.flags);
     cb = w.cub_bytes;
-    e = hipcub::DeviceScan::InclusiveSum(w.cub, cb, w.flags, w.vox_id, n, st);
+    e = rocprim::inclusive_scan(w.cub, cb, w.flags, w.vox_id, (size_t)n, rocprim::plus<int>(), st);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(voxel_runs_kernel, g, blk, 0, st, n, keys_sorted, w.flags, w.vox_id, start, count, num_voxels);
     return cbl_status();
@@ -292,6 +294,6 @@ CBL_EXPORT int cbl_crop_order(int n, int is_f64, const void* coord, int center, 
     if (is_f64) hipLaunchKernelGGL(crop_keys_kernel<double>, g, blk, 0, st, n, reinterpret_cast<const double*>(coord), center, w.keys_in, w.vals_in);
     else        hipLaunchKernelGGL(crop_keys_kernel<float>, g, blk, 0, st, n, reinterpret_cast<const float*>(coord), center, w.keys_in, w.vals_in);
     size_t cb = w.cub_bytes;
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(w.cub, cb, w.keys_in, w.keys_out, w.vals_in, order, n, 0, 64, st);
+    hipError_t e = rocprim::radix_sort_pairs(w.cub, cb, w.keys_in, w.keys_out, w.vals_in, order, (size_t)n, 0u, 64u, st);
     return e == hipSuccess ? cbl_status() : (int)e;
 }

@@ -73,8 +73,8 @@ class _PointContrast(Function):
             order = rest[2] if len(rest) > 2 else None
         else:
             tr = pointops.neighbor_transpose(neighbor_idx, features.shape[0])
-            if tr is None:
-                raise _lib.CblError("point_contrast: no transposed neighbour table for this size")
+            if tr is None:                                           # beyond the table's size limit: the reference's own scatter, with atomics
+                return _pairs_backward_atomic(features, coef, own, stats, neighbor_idx, grad_loss, ctx.weight, ctx.nsample), None, None, None, None, None, None
             order, inv_start, inv_src = tr
         m, d = features.shape
         g = torch.empty_like(features)
@@ -83,6 +83,17 @@ class _PointContrast(Function):
                                                           _lib.ptr(order), _lib.ptr(inv_start), _lib.ptr(inv_src), _lib.ptr(stats), _lib.ptr(gl),
                                                           _c_float(ctx.weight), _lib.ptr(g), _lib.stream_of(features)), "cbl_contrast_pairs_backward")
         return g, None, None, None, None, None, None
+
+
+def _pairs_backward_atomic(features, coef, own, stats, neighbor_idx, grad_loss, weight, nsample):
+    """cbl_contrast_pairs_backward_atomic: the neighbour half of the CBL gradient scattered with float atomics (no transposed table: > 1 M rows)"""
+    m, d = features.shape
+    g = torch.empty_like(features)
+    gl = grad_loss.reshape(1).to(torch.float32).contiguous()
+    _lib.check(_lib.lib().cbl_contrast_pairs_backward_atomic(_c_int(m), _c_int(m), _c_int(nsample), _c_int(d), _lib.ptr(features), _lib.ptr(coef), _lib.ptr(own),
+                                                             _lib.ptr(neighbor_idx), _lib.ptr(stats), _lib.ptr(gl), _c_float(weight), _lib.ptr(g),
+                                                             _lib.stream_of(features)), "cbl_contrast_pairs_backward_atomic")
+    return g
 
 
 def point_contrast(features, labels, neighbor_idx, temperature=1.0, weight=0.1, return_mask=False, transposed=None, contrast="softnn"):
@@ -237,7 +248,7 @@ class _TFContrastPairs(Function):
         m, d = features.shape
         tr = pointops.neighbor_transpose(neighbors, m)                   # shadow neighbours (index m) are left out of the table
         if tr is None:
-            raise _lib.CblError("tf_contrast: no transposed neighbour table for this size")
+            return _pairs_backward_atomic(features, coef, own, stats, neighbors, grad_loss, ctx.weight, ctx.nsample), None, None, None, None, None
         order, inv_start, inv_src = tr
         g = torch.empty_like(features)
         gl = grad_loss.reshape(1).to(torch.float32).contiguous()

@@ -122,7 +122,7 @@ use_spatial_order = True
 # the table, so an entry keeps the neighbour table itself alive (its storage cannot be recycled under the key) and is only served to the
 # same storage at the same version.
 _transpose_registry = collections.OrderedDict()     # _order_key(idx) -> (idx, order or None, inv_start, inv_src, producer stream, streams that waited)
-_TRANSPOSE_REGISTRY_MAX = 16
+_TRANSPOSE_REGISTRY_MAX = 64                    # one training step of the reference network uses ~25 distinct tables (5 stages x {blocks, CBL, interpolation, ...})
 
 
 def transpose_lookup(idx):
@@ -132,7 +132,7 @@ def transpose_lookup(idx):
     ent = _transpose_registry.get(_order_key(idx))
     if ent is None or ent[0].data_ptr() != idx.data_ptr() or ent[0].shape != idx.shape:
         return None
-    _, order, inv_start, inv_src, producer, waited = ent
+    _, order, inv_start, inv_src, producer, waited = ent[:6]
     cur = torch.cuda.current_stream(idx.device)
     if producer != cur and cur.cuda_stream not in waited and not streams_ordered_by_caller.active:   # built on another stream: order after it ONCE, keep the tensors alive for this one
         cur.wait_stream(producer)
@@ -146,13 +146,23 @@ def transpose_register(idx, order, inv_start, inv_src):
     if _version_of(idx) < 0:
         return
     key = _order_key(idx)
-    _transpose_registry[key] = (idx, order, inv_start, inv_src, torch.cuda.current_stream(idx.device), set())
+    cache = neighbor_cache.active()
+    _transpose_registry[key] = (idx, order, inv_start, inv_src, torch.cuda.current_stream(idx.device), set(), cache is not None)
     _transpose_registry.move_to_end(key)
     while len(_transpose_registry) > _TRANSPOSE_REGISTRY_MAX:
         _transpose_registry.popitem(last=False)
-    cache = neighbor_cache.active()
     if cache is not None:                                            # a cached pass owns what it registers: dropped with the cache
         cache.transpose_keys.append(key)
+
+
+def release_unowned_transposes():
+    """Tables built outside any neighbour cache — in a backward pass: autograd's thread has no active cache, and the forward's `with` has
+    exited by then — are only bounded by the registry's LRU; each pins its neighbour table, inv_start, inv_src and order (~12 bytes per pair).
+    A training loop calls this once per step, behind backward (train_step.DataParallelTrainer.step does); returns the number dropped."""
+    dead = [k for k, ent in _transpose_registry.items() if not ent[6]]
+    for k in dead:
+        _transpose_registry.pop(k, None)
+    return len(dead)
 
 
 

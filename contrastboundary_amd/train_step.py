@@ -33,6 +33,8 @@ class DataParallelTrainer:
         self.reducer.zero_grad()
         loss = self.forward_loss(self.model, self.criterion, inputs, target)
         loss.sum().backward()
+        from . import neighbor_state
+        neighbor_state.release_unowned_transposes()                 # tables the backward built for itself (no neighbour cache on autograd's thread)
         self.reducer.finish()
         self.optimizer.step()
         return loss.detach()

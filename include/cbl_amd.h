@@ -292,6 +292,12 @@ int cbl_contrast_pairs_backward(int m, int nsample, int d, const float* features
                                 const int* inv_start, const int* inv_src, const float* stats, const float* grad_loss, float weight,
                                 float* grad_features, void* stream);
 
+/* the same gradient where no transposed table exists (more than 1 M rows): grad_own scaled, then one float atomic per (pair with a coefficient,
+ * channel) — the scatter of the reference's index_select backward (heads.py:185-246 under autograd); last bits depend on the order of the atomics */
+int cbl_contrast_pairs_backward_atomic(int m, int n_valid, int nsample, int d, const float* features, const float* coef, const float* grad_own,
+                                       const int* neighbor_idx, const float* stats, const float* grad_loss, float weight,
+                                       float* grad_features, void* stream);
+
 /* a16  TF contrast_head  tensorflow/models/heads/head.py:462-807 with sample 'label', contrast 'softnn', dist 'l2' on RADIUS
  *      neighbourhoods (ids >= n_valid are the search's shadow padding; negative hard labels = ignored points):
  *   features (m,d), labels (n_valid >= m rows, i32 hard label per point, from point_labels or cbl_tf_scene_label + cbl_label_argmax),

@@ -387,3 +387,44 @@ def test_point_contrast_with_hub_targets_vs_oracle(d):
     np.testing.assert_allclose(loss.item(), rloss, rtol=TOL)
     np.testing.assert_allclose(grads[0], rgrad, rtol=1e-4, atol=1e-4 * np.abs(rgrad).max())
     assert np.array_equal(grads[0], grads[1])
+
+
+def test_point_contrast_beyond_the_transposed_table_limit_scatters_with_atomics():
+    """more than 1 M rows: cbl_neighbor_transpose is unsupported there, the gradient's neighbour half falls back to the atomic scatter
+    (cbl_contrast_pairs_backward_atomic).  (a) the fallback entry equals the gather entry at a size where both exist; (b) a 1.1 M-point
+    head trains: loss and gradient against the oracle on a sample of rows."""
+    import ctypes
+    from contrastboundary_amd import _lib, heads, pointops
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    # (a) both entries on the same (coef, own)
+    m, ns, d = 20000, 12, 16
+    feat = rng.normal(size=(m, d)).astype(np.float32)
+    nb = rng.integers(0, m, (m, ns)).astype(np.int32); nb[:, 0] = np.arange(m)
+    coef = (rng.normal(size=(m, ns)) * (rng.uniform(size=(m, ns)) < 0.4)).astype(np.float32); coef[:, 0] = 0
+    own = rng.normal(size=(m, d)).astype(np.float32)
+    stats = np.float32([3.0, 500.0]); gl = np.float32([0.7])
+    f_d, nb_d, c_d, o_d, s_d, g_d = dev(feat), dev(nb), dev(coef), dev(own), dev(stats), dev(gl)
+    order, inv_start, inv_src = pointops.neighbor_transpose(nb_d, m)
+    ga = torch.empty_like(f_d); gb = torch.empty_like(f_d)
+    st = _lib.stream_of(f_d)
+    _lib.check(L.cbl_contrast_pairs_backward(m, ns, d, _lib.ptr(f_d), _lib.ptr(c_d), _lib.ptr(o_d), _lib.ptr(order), _lib.ptr(inv_start), _lib.ptr(inv_src),
+                                             _lib.ptr(s_d), _lib.ptr(g_d), ctypes.c_float(0.1), _lib.ptr(ga), st), "gather")
+    _lib.check(L.cbl_contrast_pairs_backward_atomic(m, m, ns, d, _lib.ptr(f_d), _lib.ptr(c_d), _lib.ptr(o_d), _lib.ptr(nb_d), _lib.ptr(s_d), _lib.ptr(g_d),
+                                                    ctypes.c_float(0.1), _lib.ptr(gb), st), "atomic")
+    a, b = ga.cpu().numpy(), gb.cpu().numpy()
+    np.testing.assert_allclose(b, a, rtol=1e-4, atol=1e-5 * np.abs(a).max())
+    # (b) 1.1 M points through autograd
+    m, ns, d = 1_100_000, 6, 4
+    feat = rng.normal(size=(m, d)).astype(np.float32)
+    lab = rng.integers(0, 3, m).astype(np.int64)
+    nb = (np.arange(m)[:, None] + np.concatenate([[0], rng.integers(1, 50, ns - 1)])[None, :]) % m
+    nb = nb.astype(np.int32)
+    nb_d = dev(nb)
+    assert pointops.neighbor_transpose(nb_d, m) is None                # no table at this size
+    f = dev(feat).requires_grad_(True)
+    loss = heads.point_contrast(f, dev(lab), nb_d, 1.0, 0.1)
+    loss.backward()
+    rloss, rgrad, _ = C.point_contrast(feat, np.eye(3, dtype=np.float32)[lab], nb, temperature=1.0, weight=0.1)
+    assert abs(loss.item() - rloss) < 1e-4 * max(1.0, abs(rloss))
+    np.testing.assert_allclose(f.grad.cpu().numpy(), rgrad, rtol=1e-4, atol=1e-4 * np.abs(rgrad).max())

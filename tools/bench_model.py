@@ -100,7 +100,7 @@ def host_dry_run(a, D, world, rank):
 
 
 def run(a, D, world, rank, local):
-    from contrastboundary_amd import pointtransformer_seg as M, synthetic as S, train_step
+    from contrastboundary_amd import neighbor_state, pointtransformer_seg as M, synthetic as S, train_step
     torch.cuda.set_device(local)
     dist_on = world > 1 or a.single_rank_group
     if world > 1:
@@ -159,6 +159,7 @@ def run(a, D, world, rank, local):
                     geom_next[0] = M.prefetch_geometry(model, inputs, crit)      # the data loader's next batch (here: the same scene again)
                 out, sl, loss, nc_last[0] = M.forward_and_loss(model, crit, inputs, target, geometry=geom)
             loss.sum().backward()
+            neighbor_state.release_unowned_transposes()              # tables the backward built outside the forward's neighbour cache
             opt.step()
             return loss
 
