@@ -51,6 +51,9 @@ def parse(argv=None):
     ap.add_argument("--workload", choices=("block", "convnet"), default="block",
                     help="block: BASELINE's headline (KNN + group + KPConv + CBL, N=40960); convnet: config C5 / the per-scene work of C3 "
                          "(radius + grid pyramid of a 200000-point cloud, AdaptiveWeight forward + backward on its 5 layers, TF-side CBL)")
+    ap.add_argument("--block", choices=("kpconv", "pt"), default="kpconv",
+                    help="local aggregation of the block: kpconv = BASELINE's headline (KNN + group + KPConv + CBL); pt = the Point Transformer's vector "
+                         "attention layer in its place (BASELINE.md: a1 + a3 + a4 + a8, pytorch/model/blocks.py:31-44)")
     ap.add_argument("--forward-only", action="store_true", help="headline = forward block + CBL head only (round 1's step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="all stages in order on one stream")
@@ -163,7 +166,7 @@ class Step:
 
     def __init__(self, scene, k, backward, args, overlap=True, pipeline=False):
         from contrastboundary_amd import hotpath
-        self.stages = hotpath.stages(scene, k, backward)
+        self.stages = (hotpath.stages_pt if getattr(args, "block", "kpconv") == "pt" else hotpath.stages)(scene, k, backward)
         self.names = [st[0] for st in self.stages]
         self.hints = () if args.no_nested else hotpath.search_hints(scene)
         self.sched = hotpath.Schedule(self.stages, overlap=overlap, hints=self.hints)
@@ -221,11 +224,18 @@ class Step:
 
 
 def settle(step, seconds=0.5):
-    """not part of the W warm-up steps: first touches of the library, workspaces and code objects, clock ramp of a cold device"""
+    """not part of the W warm-up steps: first touches of the library, workspaces and code objects, clock ramp of a cold device.
+    On a side stream: autograd creates a parameter's gradient accumulator on the stream of its first use and keeps it while a graph holds it —
+    one created on the default stream makes a later hipGraph capture of the backward pass synchronise with the default stream (a crash on
+    ROCm 7.2; the Point Transformer block's layer has parameters, the KPConv block's leaves are made per step)."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
     t = time.perf_counter()
-    while time.perf_counter() - t < seconds:
-        step.eager()
-        torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        while time.perf_counter() - t < seconds:
+            step.eager()
+            torch.cuda.synchronize()
+    torch.cuda.current_stream().wait_stream(side)
 
 
 def make_step(scene, k, backward, args, overlap, pipeline=False):
@@ -559,6 +569,82 @@ def run_convnet(args, D, world, rank, local):
     return finish(world)
 
 
+# ------------------------------------------------------------------------------------------------ Point Transformer block (a1 + a3 + a4 + a8)
+def run_pt(args, D, world, rank, local):
+    """python bench.py --block pt: the block with the Point Transformer's vector-attention layer (pytorch/model/blocks.py:31-44) as its local
+    aggregation — KNN -> PointTransformerLayer (q/k/v, linear_p, attention over the K neighbours, softmax, aggregation; forward + backward
+    w.r.t. features and all parameters) -> CBL head.  Same issue modes, timing and checks as the KPConv block; `roofline` is the layer's forward
+    (its attn_* kernels + the dense q/k/v) against SURVEY 8(d)'s a4 bytes / flops, timed alone as a replayed hipGraph."""
+    torch.cuda.set_device(local)
+    D.init("nccl" if world > 1 else None)
+    if world > 1:
+        import torch.distributed as dist
+        assert dist.get_world_size() == args.gpus
+    torch.backends.cuda.preferred_blas_library("cublas")             # rocBLAS for the q/k/v Linear layers (tools/bench_model.py: 2-20x hipBLASLt here)
+    from contrastboundary_amd import hotpath
+    n, c, k = args.points, args.channels, args.k
+    backward = not args.forward_only
+    scene = hotpath.Scene.synthetic(n, c, seed=rank, b=1)
+    pipeline = not (args.no_pipeline or args.no_overlap or args.no_nested or args.no_graph)
+    step = make_step(scene, k, backward, args, overlap=not args.no_overlap, pipeline=pipeline)
+    sync = torch.cuda.synchronize
+    elapsed = timed_region(step, args.steps, args.warmup, sync, D)
+    out = {"metric": "points/sec through KNN+group+PointTransformer(vector attention)+CBL block, S3DIS N=%d K=%d" % (n, k),
+           "value": n * args.steps * world / elapsed, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": elapsed / args.steps * 1e3, "host_issue_ms_per_step": timed_region.issue_s / args.steps * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "S3DIS-shaped synthetic scene (S-room), N=%d, K=%d, C=%d, 1 scene per GPU per step, %s; stages: %s"
+                                  % (n, k, c, "forward + backward of the block" if backward else "forward block + CBL head", " -> ".join(step.names)),
+                      "block": "Point Transformer layer (blocks.py:31-44: share_planes 8, train-mode BatchNorms, seeded weights) in place of KPConv",
+                      "parallelism": "scene-per-GPU replicas x%d (no data-path collective)" % world, "issue": step.note}}
+    if args.no_extra:
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        return finish(world)
+    st_in, stage_ms, how = stage_times(scene, k, backward, args)
+    names, stages = st_in.names, st_in.stages
+    # the layer's forward alone: one hipGraph of it, replayed back to back between two HIP events
+    layer = hotpath.pt_layer(scene)
+    from contrastboundary_amd import pointops
+    with pointops.neighbor_cache():
+        idx, _ = pointops.knnquery_raw(k, scene.xyz, scene.xyz, scene.offset, scene.offset)
+    cap = torch.cuda.Stream(); cap.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cap), torch.no_grad():
+        for _ in range(3):
+            layer([scene.xyz, scene.feat, scene.offset], idx=idx)
+    torch.cuda.current_stream().wait_stream(cap); sync()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g), torch.no_grad():
+        y = layer([scene.xyz, scene.feat, scene.offset], idx=idx)
+    g.replay(); sync()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(20):
+        g.replay()
+    b.record(); sync()
+    us = a.elapsed_time(b) / 20 * 1e3
+    li = names.index("pt_layer_fwd")
+    nbytes, flops = stages[li][2], stages[li][3]
+    out["roofline"] = {"kernel": "PointTransformerLayer forward: q/k/v Linear (rocBLAS), linear_p, attn_w2 statistics + forward, narrow linear_w, attn_agg with softmax",
+                       "stage": "pt_layer_fwd", "bound": "hbm", "achieved": nbytes / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": nbytes, "launch_us": round(us, 2),
+                       "flops_per_launch": flops, "achieved_TFLOPs": flops / (us * 1e-6) / 1e12, "frac_of_f32_mfma_peak": flops / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                       "note": "SURVEY 8(d) a4 (idx given): bytes 12n + 12nC + 4nK + 4nC, flops 2nK(9 + 3C + C^2/8 + C^2/64) + 6nC^2; duration = 20 replays of a "
+                               "hipGraph of the layer's forward alone between two HIP events / 20.  stage_ms: " + how,
+                       "stage_ms": {names[i]: round(stage_ms[i], 4) for i in range(len(stages))}, "stage_sum_ms": round(float(sum(stage_ms)), 4)}
+    if backward:
+        fstep = make_step(scene, k, False, args, overlap=not args.no_overlap, pipeline=pipeline)
+        e_f = timed_region(fstep, args.steps, args.warmup, sync, D)
+        out["forward_only"] = {"value": n * args.steps * world / e_f, "ms_per_step": e_f / args.steps * 1e3, "stages": " -> ".join(fstep.names)}
+    if step.pipe is not None:
+        nstep = make_step(scene, k, backward, args, overlap=True, pipeline=False)
+        e_n = timed_region(nstep, args.steps, args.warmup, sync, D)
+        out["no_pipeline"] = {"value": n * args.steps * world / e_n, "ms_per_step": e_n / args.steps * 1e3, "issue": nstep.note}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    return finish(world)
+
+
 def finish(world):
     import torch.distributed as tdist
     if tdist.is_available() and tdist.is_initialized():
@@ -581,7 +667,7 @@ def main(argv=None):
     if not torch.cuda.is_available():
         sys.stderr.write("bench.py: no GPU visible (the hot path has no CPU fallback)\n")
         return 2
-    return (run_convnet if args.workload == "convnet" else run_gpu)(args, D, world, rank, local)
+    return (run_convnet if args.workload == "convnet" else run_pt if args.block == "pt" else run_gpu)(args, D, world, rank, local)
 
 
 if __name__ == "__main__":

@@ -148,6 +148,74 @@ def stages(scene, k=16, backward=False):
     return st
 
 
+def pt_layer(scene, seed=0):
+    """the block's PointTransformerLayer (blocks.py:14-44; C -> C, share_planes 8, nsample K) with seeded weights, on the scene's device, train mode"""
+    from . import blocks
+    cache = scene.__dict__.setdefault("_pt_layer", {})
+    if seed not in cache:
+        torch.manual_seed(1234 + seed)
+        cache[seed] = blocks.PointTransformerLayer(scene.c, scene.c, 8, 16).to(scene.xyz.device).train()
+    return cache[seed]
+
+
+def stages_pt(scene, k=16, backward=False):
+    """The block with the Point Transformer's local aggregation (BASELINE.md 3 / SURVEY 8(d): a1 + a3 + a4 + a8) instead of KPConv:
+        KNN (K=16) -> relative-xyz grouping (n,K,3) (what blocks.py:36-37 gathers; the (n,K,C) gathers of x_k / x_v happen inside the fused kernels)
+        -> PointTransformerLayer: q/k/v Linear, linear_p, vector attention over the K neighbours, softmax, aggregation (blocks.py:31-44)
+        -> CBL head as in `stages` -> (backward) the layer's backward w.r.t. its input features and all its parameters, driven by a fixed
+        upstream gradient.
+    Same (name, fn, bytes, flops) tuples as `stages`; names keep the conventions Schedule / Pipeline split a step by."""
+    n, c = scene.n, scene.c
+    layer = pt_layer(scene)
+    layer.nsample = k
+    params = [p for p in layer.parameters()]
+    st = []
+    if backward:
+        scene.upstream(k)
+
+    def knn(s):
+        s["idx"], s["dist2"] = pointops.knnquery_raw(k, scene.xyz, scene.xyz, scene.offset, scene.offset)
+    st.append(("knnquery_k%d" % k, knn, 12 * n + 12 * n + 8 * n * k, 8.0 * n * n))
+
+    def layer_fwd(s):
+        s["feat_leaf"] = scene.feat.detach().requires_grad_(True) if backward else scene.feat
+        s["pt_out"] = layer([scene.xyz, s["feat_leaf"], scene.offset], idx=s["idx"])
+    # a4 fused PT layer (idx given), SURVEY 8(d): p 12n, x_q / x_k / x_v 12nC, idx 4nK, out 4nC;
+    # flops 2 n K (9 + 3C + C^2/8 + C^2/64) + 6 n C^2
+    st.append(("pt_layer_fwd", layer_fwd, 12 * n + 12 * n * c + 4 * n * k + 4 * n * c,
+               2.0 * n * k * (9 + 3 * c + c * c / 8.0 + c * c / 64.0) + 6.0 * n * c * c))
+
+    d = CBL_DIM
+
+    def cbl_knn(s):
+        s["cbl_idx"], _ = pointops.knnquery_raw(CBL_NSAMPLE, scene.xyz, scene.xyz, scene.offset, scene.offset, algo="set")
+    st.append(("cbl_knnquery_k%d" % CBL_NSAMPLE, cbl_knn, 24 * n + 8 * n * CBL_NSAMPLE, 8.0 * n * n))
+
+    def cbl_transpose(s):
+        s["cbl_transposed"] = pointops.neighbor_transpose(s["cbl_idx"], n)
+    st.append(("cbl_neighbor_transpose", cbl_transpose, 8 * n * CBL_NSAMPLE + 4 * (n + 1), 0.0))
+
+    def cbl_fwd(s):
+        s["cbl_latent"] = scene.latent.detach().requires_grad_(True)
+        s["cbl_loss"] = heads.point_contrast(s["cbl_latent"], scene.labels, s["cbl_idx"], 1.0, 0.1)
+    st.append(("cbl_mining_loss_fwd", cbl_fwd, 4 * n * CBL_NSAMPLE + 4 * n * d + 4 * n + 8 * n + 4 * n * CBL_NSAMPLE + 4 * n * d,
+               1.0 * n * (CBL_NSAMPLE - 1) * (8 * d + 50)))
+
+    def cbl_bwd(s):
+        s["cbl_grad"], = torch.autograd.grad(s["cbl_loss"], s["cbl_latent"])
+    st.append(("cbl_mining_loss_bwd", cbl_bwd, 4 * (n + 1) + 8 * n * CBL_NSAMPLE + 12 * n * d, 3.0 * n * (CBL_NSAMPLE - 1) * d))
+    if not backward:
+        return st
+
+    def layer_bwd(s):
+        grads = torch.autograd.grad(s["pt_out"], [s["feat_leaf"]] + params, scene.upstream(k)["grad_kpconv"])
+        s["grad_feat_pt"], s["grad_params_pt"] = grads[0], grads[1:]
+    # backward: the forward's inputs + the output gradient in, the feature gradient and the parameter gradients out; ~2x the forward's flops
+    st.append(("pt_layer_bwd", layer_bwd, 12 * n + 12 * n * c + 4 * n * k + 4 * n * c + 4 * n * c + 4 * sum(p.numel() for p in params),
+               2.0 * (2.0 * n * k * (9 + 3 * c + c * c / 8.0 + c * c / 64.0) + 6.0 * n * c * c)))
+    return st
+
+
 def search_hints(scene):
     """the widest neighbourhood each geometry of the step is searched with: the CBL head's K = 36 on the scene's own points"""
     return ((scene.xyz, CBL_NSAMPLE, "set"),)
