@@ -185,6 +185,12 @@ class Step:
     def capture(self):
         """the step issues 30-40 launches from Python, as many us of host time as the device needs: captured once (same kernels, same
         buffers, same schedule) it is replayed with ~15 us of host time.  Raises if the capture fails (bench.py then stays eager)."""
+        # what the eager runs left behind goes first: autograd keeps a parameter's gradient accumulator (and the stream it was created on — here the
+        # default stream) for as long as a graph of an earlier step is referenced, and a capture of the backward pass that meets such a node
+        # synchronises with the default stream (a crash on ROCm 7.2).  The Point Transformer block's layer has parameters; KPConv's leaves are per step.
+        import gc
+        self.states = [{}]
+        gc.collect()
         if self.pipeline:
             from contrastboundary_amd import hotpath
             pipe = hotpath.Pipeline(self.sched)
@@ -224,18 +230,11 @@ class Step:
 
 
 def settle(step, seconds=0.5):
-    """not part of the W warm-up steps: first touches of the library, workspaces and code objects, clock ramp of a cold device.
-    On a side stream: autograd creates a parameter's gradient accumulator on the stream of its first use and keeps it while a graph holds it —
-    one created on the default stream makes a later hipGraph capture of the backward pass synchronise with the default stream (a crash on
-    ROCm 7.2; the Point Transformer block's layer has parameters, the KPConv block's leaves are made per step)."""
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
+    """not part of the W warm-up steps: first touches of the library, workspaces and code objects, clock ramp of a cold device"""
     t = time.perf_counter()
-    with torch.cuda.stream(side):
-        while time.perf_counter() - t < seconds:
-            step.eager()
-            torch.cuda.synchronize()
-    torch.cuda.current_stream().wait_stream(side)
+    while time.perf_counter() - t < seconds:
+        step.eager()
+        torch.cuda.synchronize()
 
 
 def make_step(scene, k, backward, args, overlap, pipeline=False):

@@ -13,11 +13,8 @@ _ws = {}
 
 
 def _workspace(nbytes, device):
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    ws = _ws.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = _ws[key] = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
-    return ws
+    from .neighbor_state import scratch
+    return scratch(_ws, "attn", nbytes, device)
 
 
 def supported(layer, x):

@@ -19,6 +19,7 @@
 // neighbours; x_k / x_v rows are read as coalesced 4*C-byte segments; parameter gradients are accumulated per lane in registers
 // over a persistent group's points, combined per workgroup in LDS, written as per-workgroup partials and summed in fp64.
 #include "cbl_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -160,6 +161,83 @@ __global__ __launch_bounds__(AT_BLOCK) void attn_w2_forward_kernel(int n, int K,
                     for (int g = 0; g < G; g++) { const float t = group_sum<C>(wa[g] * w1); mine = (c == g) ? t : mine; }
                     if (c < G) w2[r * G + c] = mine + bias_g;
                 }
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------- attn_w2, P2 on the matrix cores
+// C = 32 / 64.  The kernel above reduces every output of the C x C/8 product across the C lanes of a pair with DPP adds (8 group sums of ~10
+// instructions per pair: 233 us at (40960, 16, 64), bound by the vector ALU).  Here ONE WAVE owns a tile of 16 pairs of a point — the pairs are the
+// M rows of v_mfma_f32_16x16x4_f32 — and lane (pair = l % 16, quarter = l / 16) owns the CONTIGUOUS quarter of the pair's channels: its x_k
+// segment is C/4 floats of one row (16-byte loads), the per-channel constants are read from LDS (every lane of a quarter reads the same words: broadcast),
+// step t of the contraction feeds y[pair][quarter C/4 + t] as the A operand against Wa[g][quarter C/4 + t] (B operand, in registers); the
+// (16 pairs x C/8) result leaves the accumulator as rows of w2.  K = 8 (stage 0): a tile holds the 8 pairs of TWO points.
+using at_f32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <int C>
+__global__ __launch_bounds__(AT_BLOCK) void attn_w2_forward_mfma_kernel(int n, int K, const float* __restrict__ xq, const float* __restrict__ xk,
+                                                                        const int* __restrict__ idx, const float* __restrict__ p1,
+                                                                        const float* __restrict__ W3C, const float* __restrict__ b3C,
+                                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                        const float* __restrict__ Wa, const float* __restrict__ ba, float* __restrict__ w2)
+{
+    constexpr int G = C / 8, CH = C / 4;
+    // per-channel constants in LDS (all lanes of a quarter read the same words: broadcast): {w0, w1, w2, b}, {mean, invstd, gamma, beta}
+    __shared__ float4 prm[C][2];
+    const int lane = threadIdx.x & 63, pr = lane & 15, kq = lane >> 4;
+    for (int c = threadIdx.x; c < C; c += AT_BLOCK) {
+        prm[c][0] = make_float4(W3C[3 * c], W3C[3 * c + 1], W3C[3 * c + 2], b3C[c]);
+        prm[c][1] = make_float4(mean[c], invstd[c], gamma ? gamma[c] : 1.f, beta ? beta[c] : 0.f);
+    }
+    __syncthreads();
+    float bw[CH];
+#pragma unroll
+    for (int t = 0; t < CH; t++) bw[t] = pr < G ? Wa[(size_t)pr * C + CH * kq + t] : 0.f;      // B[k][j]: lane = j + 16 k
+    const float bias_g = pr < G ? ba[pr] : 0.f;
+    // a tile = 16 consecutive (point, neighbour) pairs of the flat (n * K) list when K divides 16 (K = 8: two points), else 16 pairs of one point
+    const bool flat = (16 % K) == 0;
+    const int tiles_per_point = flat ? 1 : (K + 15) / 16;
+    const long long ntiles = flat ? ((long long)n * K + 15) / 16 : (long long)n * tiles_per_point;
+    const long long npairs = (long long)n * K;
+    for (long long tile = (long long)blockIdx.x * (AT_BLOCK / 64) + (threadIdx.x >> 6); tile < ntiles; tile += (long long)gridDim.x * (AT_BLOCK / 64)) {
+        // this lane's pair (the A row pr) and the four rows 4 kq + r it will write
+        long long pair; bool valid;
+        if (flat) { pair = tile * 16 + pr; valid = pair < npairs; }
+        else { const long long i = tile / tiles_per_point; const int k = (int)(tile - i * tiles_per_point) * 16 + pr; valid = k < K; pair = i * K + min(k, K - 1); }
+        const long long pc = valid ? pair : npairs - 1;
+        const long long i = pc / K;
+        const int j = idx[pc];
+        const float a0 = p1[3 * pc], a1 = p1[3 * pc + 1], a2 = p1[3 * pc + 2];
+        const float4* xkr = reinterpret_cast<const float4*>(xk + (size_t)j * C + CH * kq);
+        const float4* xqr = reinterpret_cast<const float4*>(xq + (size_t)i * C + CH * kq);
+        float4 kv[CH / 4], qv[CH / 4];
+#pragma unroll
+        for (int v = 0; v < CH / 4; v++) { kv[v] = xkr[v]; qv[v] = xqr[v]; }
+        at_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int v = 0; v < CH / 4; v++) {
+            const float kx[4] = {kv[v].x, kv[v].y, kv[v].z, kv[v].w}, qx[4] = {qv[v].x, qv[v].y, qv[v].z, qv[v].w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int t = 4 * v + e;
+                const float4 pa = prm[CH * kq + t][0], pb = prm[CH * kq + t][1];
+                // the arithmetic of the other passes, operation for operation (the ReLU mask must be the same bit pattern in all of them)
+                const float w = (((pa.w + a0 * pa.x) + a1 * pa.y) + a2 * pa.z) - (qx[e] - kx[e]);
+                const float y = (w - pb.x) * pb.y * pb.z + pb.w;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(y > 0.f ? y : 0.f, bw[t], acc, 0, 0, 0);
+            }
+        }
+        // D[4 (lane / 16) + r][lane % 16] = w2 of pair row 4 kq + r, column g = pr
+        if (pr < G) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = 4 * kq + r;
+                long long op; bool ok;
+                if (flat) { op = tile * 16 + row; ok = op < npairs; }
+                else { const long long i2 = tile / tiles_per_point; const int k2 = (int)(tile - i2 * tiles_per_point) * 16 + row; ok = k2 < K; op = i2 * K + k2; }
+                if (ok) w2[op * G + pr] = acc[r] + bias_g;
             }
         }
     }
@@ -784,6 +862,13 @@ CBL_EXPORT int cbl_attn_w2_forward(int n, int K, int C, int G, const float* x_q,
         else               hipLaunchKernelGGL(attn_w2_stats_wide_kernel<512>, dim3(nb), dim3(512), 0, st, n, K, x_q, x_k, idx, p1, W3C, b3C, partial);
         hipLaunchKernelGGL(attn_bn_finalize_kernel, dim3(cbl_div_up(C, 16)), dim3(256), 0, st, (long long)n * K, C, nb, partial, eps, momentum,
                            running_mean, running_var, num_batches_tracked, save_mean, save_invstd);
+    }
+    if ((C == 32 || C == 64) && cbl_host_aligned16(x_q) && cbl_host_aligned16(x_k)) {
+        const long long tiles = (16 % K) == 0 ? ((long long)n * K + 15) / 16 : (long long)n * ((K + 15) / 16);
+        const unsigned g = (unsigned)min((tiles + 3) / 4, (long long)8192);
+        if (C == 32) hipLaunchKernelGGL(attn_w2_forward_mfma_kernel<32>, dim3(g), dim3(AT_BLOCK), 0, st, n, K, x_q, x_k, idx, p1, W3C, b3C, save_mean, save_invstd, bn_weight, bn_bias, Wa, ba, w2);
+        else         hipLaunchKernelGGL(attn_w2_forward_mfma_kernel<64>, dim3(g), dim3(AT_BLOCK), 0, st, n, K, x_q, x_k, idx, p1, W3C, b3C, save_mean, save_invstd, bn_weight, bn_bias, Wa, ba, w2);
+        return cbl_status();
     }
     AT_DISPATCH(attn_w2_forward, n, K, x_q, x_k, idx, p1, W3C, b3C, save_mean, save_invstd, bn_weight, bn_bias, Wa, ba, w2);
     return cbl_status();

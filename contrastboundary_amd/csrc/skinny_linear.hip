@@ -10,6 +10,7 @@
 //                              by a second small kernel (plain stores: no pre-zeroed outputs, no atomics).
 // fp32 FMA chains in index order; results differ from a GEMM library's by summation order only.
 #include "cbl_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -115,6 +116,146 @@ __global__ __launch_bounds__(256) void skinny_linear_wgrad_finalize_kernel(int n
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// Widths 16 / 32 / 48 / 64 on the matrix cores (v_mfma_f32_16x16x4_f32: exact f32, the f32 vector rate with 1/16 of the instructions).
+// The q / k / v Linear(C, C) layers of the two full-resolution stages (C = 32, 64) run over n = 10^4 .. 10^5 rows: the streaming kernel above
+// spends 26 us on 40960 x 64 x 64 (0.8 TB/s of its 21 MB), its weight gradient 41 us.
+//   out (rows, ND) = in (rows, KD) . B,  B[k][n] = WT ? W[k * ND + n] : W[n * KD + k]     (forward: W (cout, cin), WT = false; input gradient: WT = true)
+// One wave owns 16 rows per trip: lane (row = l % 16, kq = l / 16) loads the CONTIGUOUS quarter kq of its row (KD/4 floats, 16-byte loads — the
+// contraction index may be walked in any order, so step s of lane-quarter kq stands for k = kq KD/4 + s) and feeds it as the A operand; the B
+// operands of all ND/16 column tiles sit in registers for the whole launch; the next trip's rows are requested before this trip's MFMAs.
+using rl_f32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <int KD, int ND, bool WT>
+__global__ __launch_bounds__(256) void row_linear_mfma_kernel(long long rows, const float* __restrict__ in, const float* __restrict__ W, const float* __restrict__ bias,
+                                                              float* __restrict__ out)
+{
+    constexpr int KC = KD / 4, NT = ND / 16;
+    const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
+    float bw[NT][KC];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int s2 = 0; s2 < KC; s2++) {
+            const int k = KC * kq + s2, n = 16 * t + row;
+            bw[t][s2] = WT ? W[(size_t)k * ND + n] : W[(size_t)n * KD + k];
+        }
+    float bv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) bv[t] = bias ? bias[16 * t + row] : 0.f;
+    const long long ntiles = (rows + 15) / 16;
+    const long long stride = (long long)gridDim.x * 4;
+    long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    float4 a[KC / 4];
+    auto load = [&](long long tl) {
+        const long long r = min(tl * 16 + row, rows - 1);
+        const float4* src = reinterpret_cast<const float4*>(in + r * KD + KC * kq);
+#pragma unroll
+        for (int v = 0; v < KC / 4; v++) a[v] = src[v];
+    };
+    if (tile < ntiles) load(tile);
+    for (; tile < ntiles; tile += stride) {
+        float av[KC];
+#pragma unroll
+        for (int v = 0; v < KC / 4; v++) { av[4 * v] = a[v].x; av[4 * v + 1] = a[v].y; av[4 * v + 2] = a[v].z; av[4 * v + 3] = a[v].w; }
+        if (tile + stride < ntiles) load(tile + stride);
+        rl_f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = rl_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < KC; s2++)
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bw[t][s2], acc[t], 0, 0, 0);
+        // D[4 (lane / 16) + r][lane % 16] in acc[t][r]
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const long long orow = tile * 16 + 4 * kq + r;
+            if (orow < rows) {
+#pragma unroll
+                for (int t = 0; t < NT; t++) out[orow * ND + 16 * t + row] = acc[t][r] + bv[t];
+            }
+        }
+    }
+}
+
+// grad_weight (COUT, CIN) = grad_y^T . x and grad_bias = column sums of grad_y: the contraction runs over the ROWS, four per MFMA step
+// (A[m][k] = grad_y[r0 + k][16 tm + m], B[k][n] = x[r0 + k][16 tn + n]: 64-byte row segments per 16 lanes).  A wave walks its share of the rows with
+// all (COUT/16) x (CIN/16) tiles of the result in registers; waves -> LDS -> one partial per workgroup, summed by the finalize kernel above.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void row_linear_wgrad_mfma_kernel(long long rows, const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ partial,
+                                                                    int want_bias)
+{
+    constexpr int MT = COUT / 16, NTI = CIN / 16;
+    __shared__ float red[4][COUT * CIN + COUT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, kq = lane >> 4;
+    rl_f32x4 acc[MT][NTI];
+#pragma unroll
+    for (int tm = 0; tm < MT; tm++)
+#pragma unroll
+        for (int tn = 0; tn < NTI; tn++) acc[tm][tn] = rl_f32x4{0.f, 0.f, 0.f, 0.f};
+    float sb[MT];
+#pragma unroll
+    for (int tm = 0; tm < MT; tm++) sb[tm] = 0.f;
+    const long long nsteps = (rows + 3) / 4;
+    const long long gw = (long long)gridDim.x * 4;
+    for (long long st = (long long)blockIdx.x * 4 + wave; st < nsteps; st += gw) {
+        const long long r = st * 4 + kq;
+        const bool ok = r < rows;
+        const long long rc = ok ? r : rows - 1;
+        float a[MT], b[NTI];
+#pragma unroll
+        for (int tm = 0; tm < MT; tm++) { a[tm] = gy[rc * COUT + 16 * tm + col]; a[tm] = ok ? a[tm] : 0.f; sb[tm] += a[tm]; }
+#pragma unroll
+        for (int tn = 0; tn < NTI; tn++) b[tn] = x[rc * CIN + 16 * tn + col];
+#pragma unroll
+        for (int tm = 0; tm < MT; tm++)
+#pragma unroll
+            for (int tn = 0; tn < NTI; tn++) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+    }
+    // D[m = 4 (lane / 16) + r][n = lane % 16] of tile (tm, tn) = grad_weight[16 tm + m][16 tn + n]
+#pragma unroll
+    for (int tm = 0; tm < MT; tm++)
+#pragma unroll
+        for (int tn = 0; tn < NTI; tn++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) red[wave][(16 * tm + 4 * kq + r) * CIN + 16 * tn + col] = acc[tm][tn][r];
+#pragma unroll
+    for (int tm = 0; tm < MT; tm++) {
+        float v = sb[tm];
+        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        if (kq == 0) red[wave][COUT * CIN + 16 * tm + col] = v;
+    }
+    __syncthreads();
+    float* mine = partial + (size_t)blockIdx.x * (COUT * CIN + COUT);
+    for (int e = threadIdx.x; e < COUT * CIN + COUT; e += 256) {
+        const float sum = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        if (e < COUT * CIN || want_bias) mine[e] = sum;
+    }
+}
+
+inline bool rl_mfma_ok(int cin, int cout) { return cin % 16 == 0 && cout % 16 == 0 && cin <= 64 && cout <= 64 && cin >= 16 && cout >= 16; }
+
+template <bool WT>
+int rl_launch(long long rows, int kd, int nd, const float* in, const float* W, const float* bias, float* out, hipStream_t st)
+{
+    const long long tiles = (rows + 15) / 16;
+    const dim3 grid((unsigned)min((tiles + 3) / 4, (long long)2048)), blk(256);
+#define CBL_RL(KD_, ND_) if (kd == KD_ && nd == ND_) { hipLaunchKernelGGL((row_linear_mfma_kernel<KD_, ND_, WT>), grid, blk, 0, st, rows, in, W, bias, out); return cbl_status(); }
+    CBL_RL(16, 16) CBL_RL(16, 32) CBL_RL(16, 48) CBL_RL(16, 64) CBL_RL(32, 16) CBL_RL(32, 32) CBL_RL(32, 48) CBL_RL(32, 64)
+    CBL_RL(48, 16) CBL_RL(48, 32) CBL_RL(48, 48) CBL_RL(48, 64) CBL_RL(64, 16) CBL_RL(64, 32) CBL_RL(64, 48) CBL_RL(64, 64)
+#undef CBL_RL
+    return CBL_ERR_UNSUPPORTED;
+}
+
+int rl_wgrad_launch(long long rows, int cin, int cout, const float* x, const float* gy, float* partial, int want_bias, int nblocks, hipStream_t st)
+{
+#define CBL_RLW(CI_, CO_) if (cin == CI_ && cout == CO_) { hipLaunchKernelGGL((row_linear_wgrad_mfma_kernel<CI_, CO_>), dim3(nblocks), dim3(256), 0, st, rows, x, gy, partial, want_bias); return cbl_status(); }
+    CBL_RLW(16, 16) CBL_RLW(16, 32) CBL_RLW(16, 48) CBL_RLW(16, 64) CBL_RLW(32, 16) CBL_RLW(32, 32) CBL_RLW(32, 48) CBL_RLW(32, 64)
+    CBL_RLW(48, 16) CBL_RLW(48, 32) CBL_RLW(48, 48) CBL_RLW(48, 64) CBL_RLW(64, 16) CBL_RLW(64, 32) CBL_RLW(64, 48) CBL_RLW(64, 64)
+#undef CBL_RLW
+    return CBL_ERR_UNSUPPORTED;
+}
+
 int sl_check(long long rows, int cin, int cout)
 {
     if (rows < 0 || cin <= 0 || cout <= 0) return CBL_ERR_BAD_ARG;
@@ -130,6 +271,7 @@ CBL_EXPORT int cbl_skinny_linear_forward(long long rows, int cin, int cout, cons
     if (rc) return rc;
     if (rows == 0) return CBL_OK;
     if (!x || !weight || !y) return CBL_ERR_BAD_ARG;
+    if (rl_mfma_ok(cin, cout) && cbl_host_aligned16(x)) return rl_launch<false>(rows, cin, cout, x, weight, bias, y, cbl_stream(stream));
     const dim3 grid(cbl_grid_for(rows * cout, SL_BLOCK, 2048));
     const size_t lds = sizeof(float) * (size_t)cout * (cin + 1);
     if (cin % 4 == 0 && cbl_host_aligned16(x))
@@ -145,6 +287,7 @@ CBL_EXPORT int cbl_skinny_linear_backward_input(long long rows, int cin, int cou
     if (rc) return rc;
     if (rows == 0) return CBL_OK;
     if (!grad_y || !weight || !grad_x) return CBL_ERR_BAD_ARG;
+    if (rl_mfma_ok(cin, cout) && cbl_host_aligned16(grad_y)) return rl_launch<true>(rows, cout, cin, grad_y, weight, nullptr, grad_x, cbl_stream(stream));
     // dx = dy @ W: the same kernel with the roles of c_in / c_out swapped and W read transposed
     const dim3 grid(cbl_grid_for(rows * cin, SL_BLOCK, 2048));
     const size_t lds = sizeof(float) * (size_t)cin * (cout + 1);
@@ -178,6 +321,14 @@ CBL_EXPORT int cbl_skinny_linear_backward_weight(long long rows, int cin, int co
     const long long ntiles = (rows + SL_TILE - 1) / SL_TILE;
     const int nblocks = (int)min(ntiles, (long long)SL_WGRAD_BLOCKS);
     float* partial = reinterpret_cast<float*>(workspace);
+    if (rl_mfma_ok(cin, cout)) {
+        const int nb = (int)min((rows + 63) / 64, (long long)SL_WGRAD_BLOCKS);
+        const int rc2 = rl_wgrad_launch(rows, cin, cout, x, grad_y, partial, grad_bias ? 1 : 0, nb, st);
+        if (rc2) return rc2;
+        hipLaunchKernelGGL(skinny_linear_wgrad_finalize_kernel, dim3(cbl_div_up(cin * cout + cout, 16)), dim3(256), 0, st, cin * cout, cout, nb, partial,
+                           grad_weight, grad_bias);
+        return cbl_status();
+    }
     hipLaunchKernelGGL(skinny_linear_wgrad_kernel, dim3(nblocks), dim3(SL_BLOCK), sizeof(float) * (size_t)SL_TILE * (cin + 1 + cout + 1), st,
                        rows, cin, cout, x, grad_y, partial, grad_bias ? 1 : 0);
     hipLaunchKernelGGL(skinny_linear_wgrad_finalize_kernel, dim3(cbl_div_up(cin * cout + cout, 16)), dim3(256), 0, st, cin * cout, cout, nblocks, partial,

@@ -102,11 +102,8 @@ _bn_ws = {}
 
 
 def _bn_workspace(nbytes, device):
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    ws = _bn_ws.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = _bn_ws[key] = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
-    return ws
+    from .neighbor_state import scratch
+    return scratch(_bn_ws, "bn", nbytes, device)
 
 
 def batch_norm(x, bn, relu=False):

@@ -10,16 +10,27 @@ import torch
 _ws_cache = {}
 
 
+def scratch(cache, key, nbytes, device, grow=1.0):
+    """Scratch bytes for one launch on the current stream.  Eagerly: one buffer per (key, device, stream handle), grown on demand and reused — launches
+    on a stream are ordered, so they may share it.  While the stream is CAPTURING: a fresh buffer per call.  A captured launch bakes the address
+    in, and the graph is later replayed on whatever stream its owner chooses, concurrently with eager work on other streams — torch hands out its
+    32 pooled streams round-robin, so a stream object created later can carry the very handle the graph was captured on and would share (race
+    on) or regrow (free) the cached buffer under the replaying graph: seen as an illegal address in the graphed training step once enough tests
+    had drawn streams from the pool.  Allocated during capture the buffer belongs to the graph's private pool for the graph's lifetime."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
+    k = (key, device, torch.cuda.current_stream(device).cuda_stream)
+    ws = cache.get(k)
+    if ws is None or ws.numel() < nbytes:
+        ws = cache[k] = torch.empty(int(nbytes * grow) + 256, dtype=torch.uint8, device=device)
+    return ws
+
+
 def _workspace(nbytes, device):
-    """per-(device, stream) scratch for the grid KNN; grown on demand, reused across calls"""
+    """per-(device, stream) scratch for the grid KNN; grown on demand, reused across calls (see `scratch`)"""
     if nbytes == 0:
         return None
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    ws = _ws_cache.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
-        _ws_cache[key] = ws
-    return ws
+    return scratch(_ws_cache, "knn", nbytes, device, grow=1.25)
 
 
 # ------------------------------------------------------------------------------------------------ processing order

@@ -18,12 +18,8 @@ _ws = {}
 
 
 def _workspace(kind, nbytes, device):
-    key = (kind, device, torch.cuda.current_stream(device).cuda_stream)
-    ws = _ws.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
-        _ws[key] = ws
-    return ws
+    from .neighbor_state import scratch
+    return scratch(_ws, kind, nbytes, device, grow=1.25)
 
 
 def _chk(t, dtype, name, dim):

@@ -12,12 +12,8 @@ _ws = {}
 
 def _workspace(n, device):
     need = _lib.lib().cbl_voxelize_workspace_bytes(ctypes.c_int(n))
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    ws = _ws.get(key)
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=device)
-        _ws[key] = ws
-    return ws
+    from .neighbor_state import scratch
+    return scratch(_ws, "voxelize", need, device, grow=1.25)
 
 
 def _coord(coord):

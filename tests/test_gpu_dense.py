@@ -9,7 +9,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("rows,cin,cout,bias", [(163840, 3, 3, True), (163840, 3, 64, True), (163840, 64, 8, True), (163840, 8, 8, True),
                                                 (40960, 128, 16, True), (327680, 3, 32, True), (327680, 32, 4, False), (20001, 7, 5, True),
-                                                (9000, 64, 64, True)])
+                                                (9000, 64, 64, True),
+                                                # widths that are multiples of 16 (<= 64) run on the matrix cores: q / k / v of the two full-resolution stages
+                                                (40960, 64, 64, True), (40961, 32, 32, True), (10243, 16, 48, False), (8200, 48, 16, True), (9999, 64, 32, True)])
 def test_skinny_linear_matches_torch(rows, cin, cout, bias):
     from contrastboundary_amd import dense
     torch.manual_seed(rows % 97 + cin)
