@@ -27,6 +27,15 @@ def supported(layer, x):
 _i, _f = ctypes.c_int, ctypes.c_float
 
 
+def _table(idx, n, C):
+    """transposed neighbour table of a self-search's idx (n targets) for the gather-form backward passes of the two full-resolution widths; built
+    where that pays (the layers of a stage share one idx: one table per stage and step), taken where it exists, None otherwise (atomics)"""
+    if C > 64:
+        return None
+    from . import pointops
+    return pointops.neighbor_transpose(idx, n, build=(idx.numel() >= pointops.TRANSPOSE_MIN_PAIRS))
+
+
 class AttnW2(Function):
     @staticmethod
     def forward(ctx, x_q, x_k, p1, W3C, b3C, bn_w, bn_b, Wa, ba, idx, bn, training):
@@ -60,9 +69,20 @@ class AttnW2(Function):
         dev = x_q.device
         ws = _workspace(L.cbl_attn_workspace_bytes(_i(C), _i(G)), dev)
         e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        g_xq, g_xk, g_p1 = e(n, C), torch.zeros(n, C, dtype=torch.float32, device=dev), e(n, K, 3)
         g_W3C, g_b3C, g_bw, g_bb, g_Wa, g_ba = e(C, 3), e(C), e(C), e(C), e(G, C), e(G)
         g_w2 = g_w2.contiguous()
+        tr = _table(idx, n, C)
+        if tr is not None:                                          # the x_k scatter as a gather over the transposed table: no atomics
+            order, inv_start, inv_src = tr
+            g_xq, g_xk, g_p1 = e(n, C), e(n, C), e(n, K, 3)
+            _lib.check(L.cbl_attn_w2_backward_csr(_i(n), _i(K), _i(C), _i(G), _lib.ptr(x_q), _lib.ptr(x_k), _lib.ptr(idx), _lib.ptr(p1), _lib.ptr(W3C), _lib.ptr(b3C),
+                                                  _lib.ptr(bn_w), _lib.ptr(bn_b), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(Wa), _lib.ptr(g_w2),
+                                                  _lib.ptr(order), _lib.ptr(inv_start), _lib.ptr(inv_src),
+                                                  _lib.ptr(g_xq), _lib.ptr(g_xk), _lib.ptr(g_p1), _lib.ptr(g_W3C), _lib.ptr(g_b3C), _lib.ptr(g_bw), _lib.ptr(g_bb),
+                                                  _lib.ptr(g_Wa), _lib.ptr(g_ba), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(x_q)),
+                       "cbl_attn_w2_backward_csr")
+            return g_xq, g_xk, g_p1, g_W3C, g_b3C, g_bw, g_bb, g_Wa, g_ba, None, None, None
+        g_xq, g_xk, g_p1 = e(n, C), torch.zeros(n, C, dtype=torch.float32, device=dev), e(n, K, 3)
         _lib.check(L.cbl_attn_w2_backward(_i(n), _i(K), _i(C), _i(G), _lib.ptr(x_q), _lib.ptr(x_k), _lib.ptr(idx), _lib.ptr(p1), _lib.ptr(W3C), _lib.ptr(b3C),
                                           _lib.ptr(bn_w), _lib.ptr(bn_b), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(Wa), _lib.ptr(g_w2),
                                           _lib.ptr(g_xq), _lib.ptr(g_xk), _lib.ptr(g_p1), _lib.ptr(g_W3C), _lib.ptr(g_b3C), _lib.ptr(g_bw), _lib.ptr(g_bb),
@@ -103,8 +123,17 @@ class AttnAgg(Function):
         dev = x_v.device
         ws = _workspace(L.cbl_attn_workspace_bytes(_i(C), _i(G)), dev)
         e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        g_xv, g_p1, g_W3C, g_b3C, g_a = torch.zeros(n, C, dtype=torch.float32, device=dev), e(n, K, 3), e(C, 3), e(C), e(n, K, G)
         g_out = g_out.contiguous()
+        tr = _table(idx, n, C)
+        if tr is not None:                                          # the x_v scatter as a gather over the transposed table: no atomics
+            order, inv_start, inv_src = tr
+            g_xv, g_p1, g_W3C, g_b3C, g_a = e(n, C), e(n, K, 3), e(C, 3), e(C), e(n, K, G)
+            _lib.check(L.cbl_attn_agg_backward_csr(_i(n), _i(K), _i(C), _i(G), _lib.ptr(x_v), _lib.ptr(idx), _lib.ptr(p1), _lib.ptr(W3C), _lib.ptr(b3C), _lib.ptr(a),
+                                                   _lib.ptr(g_out), _lib.ptr(order), _lib.ptr(inv_start), _lib.ptr(inv_src), _lib.ptr(g_xv), _lib.ptr(g_p1),
+                                                   _lib.ptr(g_W3C), _lib.ptr(g_b3C), _lib.ptr(g_a), _lib.ptr(ws), ctypes.c_size_t(ws.numel()),
+                                                   _i(1 if ctx.softmax else 0), _lib.stream_of(x_v)), "cbl_attn_agg_backward_csr")
+            return g_xv, g_p1, g_W3C, g_b3C, g_a, None, None
+        g_xv, g_p1, g_W3C, g_b3C, g_a = torch.zeros(n, C, dtype=torch.float32, device=dev), e(n, K, 3), e(C, 3), e(C), e(n, K, G)
         fn, what = (L.cbl_attn_agg_softmax_backward, "cbl_attn_agg_softmax_backward") if ctx.softmax else (L.cbl_attn_agg_backward, "cbl_attn_agg_backward")
         _lib.check(fn(_i(n), _i(K), _i(C), _i(G), _lib.ptr(x_v), _lib.ptr(idx), _lib.ptr(p1), _lib.ptr(W3C), _lib.ptr(b3C), _lib.ptr(a),
                       _lib.ptr(g_out), _lib.ptr(g_xv), _lib.ptr(g_p1), _lib.ptr(g_W3C), _lib.ptr(g_b3C), _lib.ptr(g_a), _lib.ptr(ws),

@@ -381,7 +381,7 @@ __global__ __launch_bounds__(AT_BLOCK) void attn_w2_bwd_apply_kernel(int n, int 
                     for (int g = 0; g < G; g++) dw1 += wa[g] * gd[u][g];
                     const float dy = y > 0.f ? dw1 : 0.f;
                     const float dw = q.gamma * q.invstd * ((dy - c0) - xh * c1);  // BatchNorm backward, train mode
-                    unsafeAtomicAdd(gxk + (size_t)pb.j[u] * C + c, dw);          // w = p_r - x_q + x_k[j]
+                    if (gxk) unsafeAtomicAdd(gxk + (size_t)pb.j[u] * C + c, dw);     // w = p_r - x_q + x_k[j]  (NULL: gathered by attn_w2_gxk_csr_kernel)
                     gq -= dw;
                     d0 += dw * a0; d1 += dw * a1; d2 += dw * a2; db += dw;
                     const float t0 = group_sum<C>(q.w0 * dw), t1 = group_sum<C>(q.w1 * dw), t2 = group_sum<C>(q.w2 * dw);
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(AT_BLOCK) void attn_agg_backward_kernel(int n, int 
             const float av = avs[u];
             const float xvj = pb.xr[u];
             const float dpe = g * av;                                // d out / d (x_v[j] + p_r)
-            unsafeAtomicAdd(gxv + (size_t)j * C + c, dpe);
+            if (gxv) unsafeAtomicAdd(gxv + (size_t)j * C + c, dpe);     // NULL: gathered by attn_agg_gxv_csr_kernel
             d0 += dpe * a0; d1 += dpe * a1; d2 += dpe * a2; db += dpe;
             const float t0 = group_sum<C>(q.w0 * dpe), t1 = group_sum<C>(q.w1 * dpe), t2 = group_sum<C>(q.w2 * dpe);
             if (c < 3) gp1[3 * r + c] = (c == 0) ? t0 : (c == 1) ? t1 : t2;
@@ -501,6 +501,98 @@ __global__ __launch_bounds__(AT_BLOCK) void attn_agg_backward_kernel(int n, int 
 #pragma unroll
         for (int v = 0; v < 4; v++) { float s = 0.f; for (int g2 = 0; g2 < GPB; g2++) s += red[v][g2 * C + c]; t[v] = s; }
         mine[3 * c] = t[0]; mine[3 * c + 1] = t[1]; mine[3 * c + 2] = t[2]; mine[3 * C + c] = t[3];
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------- the two scatters as gathers
+// d loss / d x_k[j] and d loss / d x_v[j] are sums over the pairs (i, k) that list j.  The kernels above add them with one float atomic per
+// (pair, channel): 42 M atomics per pass at (40960, 16, 64), executed on the memory side of the fabric, run-to-run different in the last bits.
+// Over the transposed neighbour table (cbl_neighbor_transpose: for every target row the ascending list of its pairs) they are gathers:
+//   x_v : grad_xv[j, c] = sum over j's pairs p = (i, k) of a[p, c % G] * grad_out[i, c]                       — nothing to recompute
+//   x_k : grad_xk[j, c] = sum over j's pairs of dw[p, c], the BatchNorm-backward value the apply pass forms per pair: recomputed here from
+//         x_q[i], p1[p], grad_w2[p, :] and x_k[j] (the target's own row, read once) with the apply pass's arithmetic, operation for operation
+// One group of C lanes (lane = channel) owns a target and walks its list; plain stores, no zero fill, deterministic.
+template <int C, int G>
+__global__ __launch_bounds__(AT_BLOCK) void attn_agg_gxv_csr_kernel(unsigned n, CblFastDiv dvK, const float* __restrict__ a, const float* __restrict__ go,
+                                                                    const int* __restrict__ order, const int* __restrict__ inv_start, const int* __restrict__ inv_src,
+                                                                    float* __restrict__ gxv)
+{
+    constexpr int GPB = AT_BLOCK / C;
+    const int c = threadIdx.x % C, grp = threadIdx.x / C;
+    const unsigned ntrips = (n + GPB - 1) / GPB;
+    for (unsigned v = blockIdx.x; v < 8 * cbl_xcd_per(ntrips); v += gridDim.x) {
+        const unsigned tr = cbl_xcd_slot(v, ntrips) * GPB + grp;
+        if (tr >= n) continue;
+        const int j = order ? order[tr] : (int)tr;
+        const int e0 = inv_start[tr], e1 = inv_start[tr + 1];
+        float acc = 0.f;
+        int e = e0;
+        for (; e + AT_U <= e1; e += AT_U) {
+            int p[AT_U]; float av[AT_U], gv[AT_U];
+#pragma unroll
+            for (int u = 0; u < AT_U; u++) p[u] = inv_src[e + u];
+#pragma unroll
+            for (int u = 0; u < AT_U; u++) { av[u] = a[(size_t)p[u] * G + (c % G)]; gv[u] = go[(size_t)cbl_fastdiv((unsigned)p[u], dvK) * C + c]; }
+#pragma unroll
+            for (int u = 0; u < AT_U; u++) acc += gv[u] * av[u];
+        }
+        for (; e < e1; e++) { const int p = inv_src[e]; acc += go[(size_t)cbl_fastdiv((unsigned)p, dvK) * C + c] * a[(size_t)p * G + (c % G)]; }
+        gxv[(size_t)j * C + c] = acc;
+    }
+}
+
+template <int C, int G>
+__global__ __launch_bounds__(AT_BLOCK) void attn_w2_gxk_csr_kernel(unsigned n, int K, CblFastDiv dvK, const float* __restrict__ xq, const float* __restrict__ xk,
+                                                                   const float* __restrict__ p1, const float* __restrict__ W3C, const float* __restrict__ b3C,
+                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   const float* __restrict__ Wa, const float* __restrict__ gw2, const float* __restrict__ sums,
+                                                                   const int* __restrict__ order, const int* __restrict__ inv_start, const int* __restrict__ inv_src,
+                                                                   float* __restrict__ gxk)
+{
+    constexpr int GPB = AT_BLOCK / C;
+    const int c = threadIdx.x % C, grp = threadIdx.x / C;
+    PairParams q; q.w0 = W3C[3 * c]; q.w1 = W3C[3 * c + 1]; q.w2 = W3C[3 * c + 2]; q.b = b3C[c];
+    q.mean = mean[c]; q.invstd = invstd[c]; q.gamma = gamma ? gamma[c] : 1.f; q.beta = beta ? beta[c] : 0.f;
+    float wa[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) wa[g] = Wa[g * C + c];
+    const float inv_rows = 1.0f / ((float)n * (float)K);
+    const float c0 = sums[c] * inv_rows, c1 = sums[C + c] * inv_rows;
+    const unsigned ntrips = (n + GPB - 1) / GPB;
+    for (unsigned v = blockIdx.x; v < 8 * cbl_xcd_per(ntrips); v += gridDim.x) {
+        const unsigned tr = cbl_xcd_slot(v, ntrips) * GPB + grp;
+        if (tr >= n) continue;
+        const int j = order ? order[tr] : (int)tr;
+        const int e0 = inv_start[tr], e1 = inv_start[tr + 1];
+        const float xkj = xk[(size_t)j * C + c];
+        float acc = 0.f;
+        for (int eb = e0; eb < e1; eb += AT_U) {
+            int p[AT_U]; float xqi[AT_U], a0[AT_U], a1[AT_U], a2[AT_U], gd[AT_U][G];
+#pragma unroll
+            for (int u = 0; u < AT_U; u++) p[u] = inv_src[min(eb + u, e1 - 1)];
+#pragma unroll
+            for (int u = 0; u < AT_U; u++) {
+                xqi[u] = xq[(size_t)cbl_fastdiv((unsigned)p[u], dvK) * C + c];
+                a0[u] = p1[3 * (size_t)p[u]]; a1[u] = p1[3 * (size_t)p[u] + 1]; a2[u] = p1[3 * (size_t)p[u] + 2];
+#pragma unroll
+                for (int g = 0; g < G; g++) gd[u][g] = gw2[(size_t)p[u] * G + g];
+            }
+#pragma unroll
+            for (int u = 0; u < AT_U; u++) {
+                if (eb + u < e1) {
+                    const float w = pe_of(q, a0[u], a1[u], a2[u]) - (xqi[u] - xkj);
+                    const float xh = (w - q.mean) * q.invstd;
+                    const float y = xh * q.gamma + q.beta;
+                    float dw1 = 0.f;
+#pragma unroll
+                    for (int g = 0; g < G; g++) dw1 += wa[g] * gd[u][g];
+                    const float dy = y > 0.f ? dw1 : 0.f;
+                    acc += q.gamma * q.invstd * ((dy - c0) - xh * c1);             // BatchNorm backward, train mode: the apply pass's dw
+                }
+            }
+        }
+        gxk[(size_t)j * C + c] = acc;
     }
 }
 
@@ -951,6 +1043,72 @@ static int attn_agg_backward_impl(int n, int K, int C, int G, const float* x_v, 
     SumSegments s2; s2.dst[0] = grad_W3C; s2.dst[1] = grad_b3C; s2.dst[2] = s2.dst[3] = nullptr;
     s2.begin[0] = 0; s2.begin[1] = 3 * C; s2.begin[2] = s2.begin[3] = s2.begin[4] = nv2;
     hipLaunchKernelGGL(attn_sum_partials_kernel, dim3(cbl_div_up(nv2, 16)), dim3(256), 0, st, nv2, nb, partial, s2, (float*)nullptr);
+    return cbl_status();
+}
+
+// the same backward passes with the two scatters (grad_xk, grad_xv) as gathers over the transposed table of idx (C = 32 / 64; CBL_ERR_UNSUPPORTED
+// otherwise: the wide stages are small and keep their atomics): grad_xk / grad_xv are WRITTEN (no pre-zeroing), no atomics anywhere, deterministic
+CBL_EXPORT int cbl_attn_w2_backward_csr(int n, int K, int C, int G, const float* x_q, const float* x_k, const int* idx, const float* p1,
+                                        const float* W3C, const float* b3C, const float* bn_weight, const float* bn_bias,
+                                        const float* save_mean, const float* save_invstd, const float* Wa, const float* grad_w2,
+                                        const int* order, const int* inv_start, const int* inv_src,
+                                        float* grad_xq, float* grad_xk, float* grad_p1, float* grad_W3C, float* grad_b3C,
+                                        float* grad_bn_weight, float* grad_bn_bias, float* grad_Wa, float* grad_ba,
+                                        void* workspace, size_t workspace_bytes, void* stream)
+{
+    const int rc = at_check(n, K, C, G);
+    if (rc) return rc;
+    if (C > 64) return CBL_ERR_UNSUPPORTED;
+    if (n == 0) return CBL_OK;
+    if (!x_q || !x_k || !idx || !p1 || !W3C || !b3C || !save_mean || !save_invstd || !Wa || !grad_w2 || !grad_xq || !grad_xk || !grad_p1 || !grad_W3C ||
+        !grad_b3C || !grad_bn_weight || !grad_bn_bias || !grad_Wa || !grad_ba || !workspace || !inv_start || !inv_src) return CBL_ERR_BAD_ARG;
+    if (workspace_bytes < cbl_attn_workspace_bytes(C, G)) return CBL_ERR_WORKSPACE;
+    hipStream_t st = cbl_stream(stream);
+    const int nb = at_blocks(n, C);
+    const int nv1 = 2 * C + G * C + G, nv2 = 4 * C;
+    float* partial = reinterpret_cast<float*>(workspace);
+    float* sums = partial + (size_t)AT_MAX_BLOCKS * nv1;
+    AT_DISPATCH(attn_w2_bwd_reduce, n, K, x_q, x_k, idx, p1, W3C, b3C, save_mean, save_invstd, bn_weight, bn_bias, Wa, grad_w2, partial);
+    SumSegments s1; s1.dst[0] = grad_bn_bias; s1.dst[1] = grad_bn_weight; s1.dst[2] = grad_Wa; s1.dst[3] = grad_ba;
+    s1.begin[0] = 0; s1.begin[1] = C; s1.begin[2] = 2 * C; s1.begin[3] = 2 * C + G * C; s1.begin[4] = nv1;
+    hipLaunchKernelGGL(attn_sum_partials_kernel, dim3(cbl_div_up(nv1, 16)), dim3(256), 0, st, nv1, nb, partial, s1, sums);
+    AT_DISPATCH(attn_w2_bwd_apply, n, K, x_q, x_k, idx, p1, W3C, b3C, save_mean, save_invstd, bn_weight, bn_bias, Wa, grad_w2, sums,
+                grad_xq, (float*)nullptr, grad_p1, partial);
+    SumSegments s2; s2.dst[0] = grad_W3C; s2.dst[1] = grad_b3C; s2.dst[2] = s2.dst[3] = nullptr;
+    s2.begin[0] = 0; s2.begin[1] = 3 * C; s2.begin[2] = s2.begin[3] = s2.begin[4] = nv2;
+    hipLaunchKernelGGL(attn_sum_partials_kernel, dim3(cbl_div_up(nv2, 16)), dim3(256), 0, st, nv2, nb, partial, s2, (float*)nullptr);
+    const CblFastDiv dv = cbl_fastdiv_make((unsigned)K);
+    const unsigned g = cbl_round_up8((unsigned)cbl_grid_for((long long)n * C, AT_BLOCK, 8192));
+    if (C == 32) hipLaunchKernelGGL((attn_w2_gxk_csr_kernel<32, 4>), dim3(g), dim3(AT_BLOCK), 0, st, (unsigned)n, K, dv, x_q, x_k, p1, W3C, b3C, save_mean, save_invstd, bn_weight, bn_bias, Wa, grad_w2, sums, order, inv_start, inv_src, grad_xk);
+    else         hipLaunchKernelGGL((attn_w2_gxk_csr_kernel<64, 8>), dim3(g), dim3(AT_BLOCK), 0, st, (unsigned)n, K, dv, x_q, x_k, p1, W3C, b3C, save_mean, save_invstd, bn_weight, bn_bias, Wa, grad_w2, sums, order, inv_start, inv_src, grad_xk);
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_attn_agg_backward_csr(int n, int K, int C, int G, const float* x_v, const int* idx, const float* p1, const float* W3C, const float* b3C,
+                                         const float* a, const float* grad_out, const int* order, const int* inv_start, const int* inv_src,
+                                         float* grad_xv, float* grad_p1, float* grad_W3C, float* grad_b3C, float* grad_a,
+                                         void* workspace, size_t workspace_bytes, int softmax, void* stream)
+{
+    const int rc = at_check(n, K, C, G);
+    if (rc) return rc;
+    if (C > 64) return CBL_ERR_UNSUPPORTED;
+    if (n == 0) return CBL_OK;
+    if (!x_v || !idx || !p1 || !W3C || !b3C || !a || !grad_out || !grad_xv || !grad_p1 || !grad_W3C || !grad_b3C || !grad_a || !workspace || !inv_start || !inv_src)
+        return CBL_ERR_BAD_ARG;
+    if (workspace_bytes < cbl_attn_workspace_bytes(C, G)) return CBL_ERR_WORKSPACE;
+    hipStream_t st = cbl_stream(stream);
+    const int nb = at_blocks(n, C);
+    const int nv2 = 4 * C;
+    float* partial = reinterpret_cast<float*>(workspace);
+    AT_DISPATCH(attn_agg_backward, n, K, x_v, idx, p1, W3C, b3C, a, grad_out, (float*)nullptr, grad_p1, grad_a, partial, softmax);
+    SumSegments s2; s2.dst[0] = grad_W3C; s2.dst[1] = grad_b3C; s2.dst[2] = s2.dst[3] = nullptr;
+    s2.begin[0] = 0; s2.begin[1] = 3 * C; s2.begin[2] = s2.begin[3] = s2.begin[4] = nv2;
+    hipLaunchKernelGGL(attn_sum_partials_kernel, dim3(cbl_div_up(nv2, 16)), dim3(256), 0, st, nv2, nb, partial, s2, (float*)nullptr);
+    // (with softmax the kernel above has replaced grad_a by the gradient of the logits; the gather needs the softmax WEIGHTS `a`, which are its input)
+    const CblFastDiv dv = cbl_fastdiv_make((unsigned)K);
+    const unsigned g = cbl_round_up8((unsigned)cbl_grid_for((long long)n * C, AT_BLOCK, 8192));
+    if (C == 32) hipLaunchKernelGGL((attn_agg_gxv_csr_kernel<32, 4>), dim3(g), dim3(AT_BLOCK), 0, st, (unsigned)n, dv, a, grad_out, order, inv_start, inv_src, grad_xv);
+    else         hipLaunchKernelGGL((attn_agg_gxv_csr_kernel<64, 8>), dim3(g), dim3(AT_BLOCK), 0, st, (unsigned)n, dv, a, grad_out, order, inv_start, inv_src, grad_xv);
     return cbl_status();
 }
 

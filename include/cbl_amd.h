@@ -438,6 +438,21 @@ int cbl_attn_agg_softmax_backward(int n, int K, int C, int G, const float* x_v, 
                                   const float* a, const float* grad_out, float* grad_xv, float* grad_p1, float* grad_W3C, float* grad_b3C,
                                   float* grad_logits, void* workspace, size_t workspace_bytes, void* stream);
 
+/* the two backward passes with their scatters (grad_xk / grad_xv: sums over the pairs that list a row as neighbour — the index_select backward of
+ * blocks.py:35-36,43 under autograd) as gathers over the transposed table of idx (cbl_neighbor_transpose with n targets = n): no atomics, grad_xk /
+ * grad_xv WRITTEN not accumulated, run-to-run deterministic.  C = 32 / 64 (CBL_ERR_UNSUPPORTED for the wide stages).  softmax: as the two entries above. */
+int cbl_attn_w2_backward_csr(int n, int K, int C, int G, const float* x_q, const float* x_k, const int* idx, const float* p1,
+                             const float* W3C, const float* b3C, const float* bn_weight, const float* bn_bias,
+                             const float* save_mean, const float* save_invstd, const float* Wa, const float* grad_w2,
+                             const int* order, const int* inv_start, const int* inv_src,
+                             float* grad_xq, float* grad_xk, float* grad_p1, float* grad_W3C, float* grad_b3C,
+                             float* grad_bn_weight, float* grad_bn_bias, float* grad_Wa, float* grad_ba,
+                             void* workspace, size_t workspace_bytes, void* stream);
+int cbl_attn_agg_backward_csr(int n, int K, int C, int G, const float* x_v, const int* idx, const float* p1, const float* W3C, const float* b3C,
+                              const float* a, const float* grad_out, const int* order, const int* inv_start, const int* inv_src,
+                              float* grad_xv, float* grad_p1, float* grad_W3C, float* grad_b3C, float* grad_a,
+                              void* workspace, size_t workspace_bytes, int softmax, void* stream);
+
 /* a4, dense part of the vector attention: nn.Linear over (n*K) rows with tiny widths — linear_p = Linear(3,3), Linear(3,C) and
  * linear_w = Linear(C,C/8), Linear(C/8,C/8)  pytorch/model/blocks.py:23-28,38-40 — as streaming kernels instead of library GEMMs.
  *   x (rows,cin), weight (cout,cin), bias (cout) or NULL -> y (rows,cout) = x @ weight^T + bias
