@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 matrix = f32 vector peak
 GRAD_ALLREDUCE_FLOATS = 7800497   # parameters of the reference's PointTransformerSeg + heads: 31.2 MB fp32
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")     # collected by tools/gpu_r03_final.sh; its _meta.commit names the kernel set
 
 
 def parse(argv=None):
@@ -381,7 +381,8 @@ def run_gpu(args, D, world, rank, local):
     roofline = {"kernel": MAIN_KERNEL["queryandgroup"], "stage": "queryandgroup", "bound": "hbm", "achieved": kgbps("queryandgroup"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": kgbps("queryandgroup") / HBM_PEAK_GBS, "traffic": traffic("queryandgroup"), "bytes_per_launch": stages[gi][2],
                 "launch_us": round(kus["queryandgroup"], 2),
-                "traffic_source": ("PMC FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE per launch from %s (%s)" % (os.path.relpath(PMC_FILE, ROOT), pmc.get("_meta", {}).get("kernels", "this kernel set"))
+                "traffic_source": ("PMC FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE per launch from %s, collected at commit %s (%s)"
+                                   % (os.path.relpath(PMC_FILE, ROOT), pmc.get("_meta", {}).get("commit", "?"), pmc.get("_meta", {}).get("kernels", "this kernel set"))
                                    if traffic("queryandgroup") else "not measured for this kernel set (no %s)" % os.path.relpath(PMC_FILE, ROOT)),
                 "note": "achieved = SURVEY 8(d) algorithmic bytes of the launch / its duration = HIP events on the launch stream around 10 back-to-back "
                         "launches of the kernel alone, issued behind a filler kernel, / 10 (same tensors, processing order and tables as the step; "
