@@ -51,11 +51,12 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 template <int LR, int UM, bool GRAD>
 __global__ __launch_bounds__(256) void contrast_pairs_kernel(unsigned m, int nsample, const float4* __restrict__ feat, const int* __restrict__ amax,
                                                              const int* __restrict__ nidx, const int* __restrict__ order, float inv_temperature, int n_valid,
-                                                             int flags, float kl_thr, float* __restrict__ per_point, int* __restrict__ point_mask,
-                                                             float* __restrict__ coef, float4* __restrict__ grad_own)
+                                                             int flags, float kl_thr, const unsigned char* __restrict__ roles,
+                                                             const unsigned char* __restrict__ sample_valid, float* __restrict__ per_point,
+                                                             int* __restrict__ point_mask, float* __restrict__ coef, float4* __restrict__ grad_own)
 {
     constexpr int PP = 64 / LR;
-    const int tf_variant = flags & 1, ls = 1 + ((flags >> 1) & 1), nce = (flags >> 2) & 1, ncls = (flags >> 8) & 0xff;
+    const int tf_variant = flags & 1, ls = 1 + ((flags >> 1) & 1), nce = (flags >> 2) & 1, sep = (flags >> 3) & 1, ncls = (flags >> 8) & 0xff;
     const int ns = nsample - 1;                                     // self column dropped, heads.py:195-196 / head.py:560
     const int lane = threadIdx.x & 63;
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform values in scalar registers: scalar loads, uniform branches
@@ -95,6 +96,13 @@ __global__ __launch_bounds__(256) void contrast_pairs_kernel(unsigned m, int nsa
             nb_r = colr && real && (!tf_variant || (my >= 0 && nl >= 0));
             pos_r = nb_r && (nl == my);                              // posmask_cnt :145-149 / head.py:538
         }
+        if (roles) {                                                 // sample_labels head.py:560-625: columns that are not label-mined (wave-uniform branch)
+            const int role = colr ? roles[lane] : 0;
+            if (role) {                                              // 'nn<k>': positive, 'rand<n>': negative, both valid whatever they point at (:603-617);
+                nb_r = colr && (role != CBL_ROLE_NEG_REJECT || !sample_valid || sample_valid[(size_t)i * ns + lane] != 0);   // 'rand<n>R': unless it is one of the neighbours
+                pos_r = nb_r && role == CBL_ROLE_POS;
+            }
+        }
         const unsigned long long nbmask = __ballot(nb_r), posmask = __ballot(pos_r), realmask = __ballot(real);
         const int cnt = __popcll(posmask), nvalid = __popcll(nbmask);
         const bool valid = cnt > 0 && cnt < nvalid;                  // :212-213 / solve_samples_mask head.py:621-640 (wave-uniform)
@@ -124,9 +132,10 @@ __global__ __launch_bounds__(256) void contrast_pairs_kernel(unsigned m, int nsa
             dist[u] = fast_sqrt(tf_variant ? fmaxf(acc, 1e-12f) : acc + 1e-12f);     // head.py:184-185 / dist_l2 heads.py:116-119
             isnb[u] = col && ((nbmask >> jj) & 1ull);
             ispos[u] = col && ((posmask >> jj) & 1ull);
-            const bool realu = (realmask >> jj) & 1ull;
-            // shadow columns of the TF flavour gather a zero feature row and DO enter the max-shift (head.py:752)
-            ex[u] = isnb[u] ? -dist[u] : ((tf_variant && col) ? (realu ? -dist[u] : -shadow_d) : -INFINITY);
+            // shadow columns of the TF flavour gather a zero feature row (tf_gather, basic_operators.py:381-410): they DO enter the max-shift
+            // (head.py:752), and an 'nn<k>' column keeps them as a positive
+            if (tf_variant && !((realmask >> jj) & 1ull)) { dist[u] = shadow_d; diff[u] = fi; }
+            ex[u] = (isnb[u] || (tf_variant && col)) ? -dist[u] : -INFINITY;
             mxl = fmaxf(mxl, ex[u]);
         }
         const float mx = group_max<64>(mxl);                         // :153
@@ -139,16 +148,19 @@ __global__ __launch_bounds__(256) void contrast_pairs_kernel(unsigned m, int nsa
         const float P = group_sum<64>(pl) * (1.0f / LR), A = group_sum<64>(al) * (1.0f / LR);   // every pair is held by LR lanes
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!nce) {
-            if (lane == 0) { per_point[i] = -logf(P / A + 1e-12f); point_mask[i] = 1; }          // contrast_softnn :161-163
+            // margin 'S' (head.py:759-760): pos / max(neg, eps) instead of pos / (pos + neg)
+            const float Nn = A - P, Nc = fmaxf(Nn, 1e-12f);
+            const float ratio = sep ? P / Nc : P / A;
+            if (lane == 0) { per_point[i] = -logf(ratio + 1e-12f); point_mask[i] = 1; }          // contrast_softnn :161-163
             if (!GRAD) continue;
             // ---- gradient coefficients: d term / d dist_j, then / dist_j for the direction (f_i - f_j) / dist_j
-            const float ratio = P / A;
-            const float base = inv_temperature / (A * A * (ratio + 1e-12f));
+            const float base = sep ? inv_temperature / (ratio + 1e-12f) : inv_temperature / (A * A * (ratio + 1e-12f));
+            const float xpos = sep ? 1.0f / Nc : A - P, xneg = sep ? (Nn > 1e-12f ? -P / (Nc * Nc) : 0.f) : -P;
             if (lane == 0) coef[(size_t)i * nsample] = 0.f;          // the self column takes no part
 #pragma unroll
             for (int u = 0; u < UM; u++) {
                 const int j = u * PP + s;
-                float c = isnb[u] ? ex[u] * ((ispos[u] ? A : 0.f) - P) * base * fast_rcp(dist[u]) : 0.f;
+                float c = isnb[u] ? ex[u] * (ispos[u] ? xpos : xneg) * base * fast_rcp(dist[u]) : 0.f;
                 if (tf_variant && dist[u] <= 1e-6f) c = 0.f;        // sqrt(max(s, 1e-12)): flat below the clamp
                 if (q == 0 && j < ns) coef[(size_t)i * nsample + 1 + j] = c;
                 g.x += c * diff[u].x; g.y += c * diff[u].y; g.z += c * diff[u].z; g.w += c * diff[u].w;
@@ -161,8 +173,12 @@ __global__ __launch_bounds__(256) void contrast_pairs_kernel(unsigned m, int nsa
 #pragma unroll
             for (int u = 0; u < UM; u++) {
                 if (ispos[u]) {
-                    if (tf_variant) { const float r = ex[u] / A; tl += -logf(r + 1e-12f); ql += r / (r + 1e-12f); }
-                    else            { tl += -logf(ex[u] / (ex[u] + N)); ql += 1.0f / (ex[u] + N); }
+                    if (tf_variant && sep) {                        // 'S': under_j = e_j + N (head.py:783-785), eps inside the log (:793)
+                        const float un = ex[u] + N, r = ex[u] / un;
+                        tl += -logf(r + 1e-12f); ql += ex[u] / ((r + 1e-12f) * un * un);
+                    }
+                    else if (tf_variant) { const float r = ex[u] / A; tl += -logf(r + 1e-12f); ql += r / (r + 1e-12f); }
+                    else                 { tl += -logf(ex[u] / (ex[u] + N)); ql += 1.0f / (ex[u] + N); }
                 }
             }
             const float term = group_sum<64>(tl) * (1.0f / LR), Q = group_sum<64>(ql) * (1.0f / LR);
@@ -174,8 +190,12 @@ __global__ __launch_bounds__(256) void contrast_pairs_kernel(unsigned m, int nsa
                 const int j = u * PP + s;
                 float c = 0.f;
                 if (isnb[u]) {
-                    if (tf_variant) { const float r = ex[u] / A; c = inv_temperature * ((ispos[u] ? r / (r + 1e-12f) : 0.f) - r * Q) / dist[u]; }
-                    else            c = (ispos[u] ? inv_temperature * N / (ex[u] + N) : -inv_temperature * ex[u] * Q) / dist[u];
+                    if (tf_variant && sep) {
+                        const float un = ex[u] + N, r = ex[u] / un;
+                        c = (ispos[u] ? inv_temperature * ex[u] * N / ((r + 1e-12f) * un * un) : -inv_temperature * ex[u] * Q) / dist[u];
+                    }
+                    else if (tf_variant) { const float r = ex[u] / A; c = inv_temperature * ((ispos[u] ? r / (r + 1e-12f) : 0.f) - r * Q) / dist[u]; }
+                    else                 c = (ispos[u] ? inv_temperature * N / (ex[u] + N) : -inv_temperature * ex[u] * Q) / dist[u];
                 }
                 if (tf_variant && dist[u] <= 1e-6f) c = 0.f;
                 if (q == 0 && j < ns) coef[(size_t)i * nsample + 1 + j] = c;
@@ -254,20 +274,21 @@ __global__ __launch_bounds__(256) void contrast_gather_kernel(unsigned m, CblFas
 
 template <int LR, int UM>
 int launch_pairs(unsigned g, hipStream_t st, int m, int nsample, const float* feat, const int* amax, const int* nidx, const int* order, float inv_t, int n_valid,
-                 int flags, float kl_thr, float* per_point, int* point_mask, float* coef, float* grad_own)
+                 int flags, float kl_thr, const unsigned char* roles, const unsigned char* sample_valid, float* per_point, int* point_mask, float* coef, float* grad_own)
 {
     if (coef) hipLaunchKernelGGL((contrast_pairs_kernel<LR, UM, true>), dim3(g), dim3(256), 0, st, (unsigned)m, nsample, reinterpret_cast<const float4*>(feat), amax, nidx,
-                                 order, inv_t, n_valid, flags, kl_thr, per_point, point_mask, coef, reinterpret_cast<float4*>(grad_own));
+                                 order, inv_t, n_valid, flags, kl_thr, roles, sample_valid, per_point, point_mask, coef, reinterpret_cast<float4*>(grad_own));
     else hipLaunchKernelGGL((contrast_pairs_kernel<LR, UM, false>), dim3(g), dim3(256), 0, st, (unsigned)m, nsample, reinterpret_cast<const float4*>(feat), amax, nidx,
-                            order, inv_t, n_valid, flags, kl_thr, per_point, point_mask, nullptr, nullptr);
+                            order, inv_t, n_valid, flags, kl_thr, roles, sample_valid, per_point, point_mask, nullptr, nullptr);
     return cbl_status();
 }
 
 template <int LR>
 int dispatch_pairs_um(int U, unsigned g, hipStream_t st, int m, int nsample, const float* feat, const int* amax, const int* nidx, const int* order, float inv_t,
-                      int n_valid, int flags, float kl_thr, float* per_point, int* point_mask, float* coef, float* grad_own)
+                      int n_valid, int flags, float kl_thr, const unsigned char* roles, const unsigned char* sample_valid, float* per_point, int* point_mask,
+                      float* coef, float* grad_own)
 {
-#define CBL_PAIRS_UM(UM_) return launch_pairs<LR, UM_>(g, st, m, nsample, feat, amax, nidx, order, inv_t, n_valid, flags, kl_thr, per_point, point_mask, coef, grad_own)
+#define CBL_PAIRS_UM(UM_) return launch_pairs<LR, UM_>(g, st, m, nsample, feat, amax, nidx, order, inv_t, n_valid, flags, kl_thr, roles, sample_valid, per_point, point_mask, coef, grad_own)
     if (U <= 1) CBL_PAIRS_UM(1);
     if (U <= 2) CBL_PAIRS_UM(2);
     if (U <= 3) CBL_PAIRS_UM(3);
@@ -317,14 +338,20 @@ __global__ __launch_bounds__(256) void contrast_scatter_kernel(long long pairs, 
 // deterministic reduction of the per-point terms (cbl.hip)
 int cbl_contrast_finalize_launch(int m, float weight, const float* per_point, const int* point_mask, float* stats, float* loss, hipStream_t st);
 
-CBL_EXPORT int cbl_contrast_pairs_forward(int m, int n_valid, int flags, int nsample, int d, const float* features, const void* labels, int num_classes,
-                                          float kl_threshold, const int* neighbor_idx, const int* order, float temperature, float weight,
-                                          float* per_point, int* point_mask, float* stats, float* loss, float* coef, float* grad_own, void* stream)
+// sample strings beyond 'label' (head.py:560-625): sample_idx (m, nsample) = the self column followed by the concatenated sample columns,
+// roles (nsample - 1) u8 per column (0 label-mined, 1 'nn' positive, 2 'rand' negative, 3 'rand..R' negative unless sample_valid says otherwise),
+// sample_valid (m, nsample - 1) u8 read for role-3 columns only (NULL if there is none)
+CBL_EXPORT int cbl_contrast_pairs_forward_samples(int m, int n_valid, int flags, int nsample, int d, const float* features, const void* labels, int num_classes,
+                                                  float kl_threshold, const int* sample_idx, const unsigned char* roles, const unsigned char* sample_valid,
+                                                  const int* order, float temperature, float weight, float* per_point, int* point_mask, float* stats,
+                                                  float* loss, float* coef, float* grad_own, void* stream)
 {
     if (m <= 0 || n_valid < 0 || nsample < 2 || nsample > 65 || d <= 0 || !(temperature > 0.f)) return CBL_ERR_BAD_ARG;
-    if (!features || !labels || !neighbor_idx || !per_point || !point_mask || !stats || !loss) return CBL_ERR_BAD_ARG;
+    if (!features || !labels || !sample_idx || !per_point || !point_mask || !stats || !loss) return CBL_ERR_BAD_ARG;
     if ((coef == nullptr) != (grad_own == nullptr)) return CBL_ERR_BAD_ARG;
-    if ((flags & ~7) || num_classes < 0 || num_classes > 255) return CBL_ERR_BAD_ARG;
+    if ((flags & ~15) || num_classes < 0 || num_classes > 255) return CBL_ERR_BAD_ARG;
+    if ((roles || sample_valid) && !(flags & 1)) return CBL_ERR_BAD_ARG;              // sample roles belong to the TF head
+    const int* neighbor_idx = sample_idx;
     if (!cbl_host_aligned16(features) || (grad_own && !cbl_host_aligned16(grad_own))) return CBL_ERR_BAD_ARG;
     if (d % 4 || d > 64 || (d & (d - 1))) return CBL_ERR_UNSUPPORTED;
     hipStream_t st = cbl_stream(stream);
@@ -334,7 +361,7 @@ CBL_EXPORT int cbl_contrast_pairs_forward(int m, int n_valid, int flags, int nsa
     const int lr = d / 4, pp = 64 / lr, U = (nsample - 1 + pp - 1) / pp;
     unsigned g = cbl_round_up8(cbl_div_up(m, 4)); if (g > 256u * 32u) g = 256u * 32u;
     int rc;
-#define CBL_PAIRS_LR(LR_) rc = dispatch_pairs_um<LR_>(U, g, st, m, nsample, features, amax, neighbor_idx, order, inv_t, n_valid, fl, kl_threshold, per_point, point_mask, coef, grad_own)
+#define CBL_PAIRS_LR(LR_) rc = dispatch_pairs_um<LR_>(U, g, st, m, nsample, features, amax, neighbor_idx, order, inv_t, n_valid, fl, kl_threshold, roles, sample_valid, per_point, point_mask, coef, grad_own)
     switch (lr) {
         case 1: CBL_PAIRS_LR(1); break;
         case 2: CBL_PAIRS_LR(2); break;
@@ -346,6 +373,14 @@ CBL_EXPORT int cbl_contrast_pairs_forward(int m, int n_valid, int flags, int nsa
 #undef CBL_PAIRS_LR
     if (rc) return rc;
     return cbl_contrast_finalize_launch(m, weight, per_point, point_mask, stats, loss, st);
+}
+
+CBL_EXPORT int cbl_contrast_pairs_forward(int m, int n_valid, int flags, int nsample, int d, const float* features, const void* labels, int num_classes,
+                                          float kl_threshold, const int* neighbor_idx, const int* order, float temperature, float weight,
+                                          float* per_point, int* point_mask, float* stats, float* loss, float* coef, float* grad_own, void* stream)
+{
+    return cbl_contrast_pairs_forward_samples(m, n_valid, flags, nsample, d, features, labels, num_classes, kl_threshold, neighbor_idx, nullptr, nullptr, order,
+                                              temperature, weight, per_point, point_mask, stats, loss, coef, grad_own, stream);
 }
 
 CBL_EXPORT int cbl_contrast_pairs_backward(int m, int nsample, int d, const float* features, const float* coef, const float* grad_own, const int* order,

@@ -397,12 +397,20 @@ __global__ __launch_bounds__(256) void kpconv_bwd_kernel(int n, int n0, int K, i
 // ---------------------------------------------------------------------------------------------- AdaptiveWeight
 // agg[p,c] = (1/nn[p]) * sum_k (rel[p,k,:] . fcw[:,c] + fcb[c]) * f[nbr_k, c],  rel = (s[nbr] - q[p]) / radius, shadow point = 0
 // nn[p] = #{k : idx[p,k] < max(idx)} + 1e-5  ("mean" reduction, :466-470);  reduction_mean = 0 -> plain sum
-__global__ __launch_bounds__(256) void index_max_kernel(long long total, const int* __restrict__ idx, int* __restrict__ out)
+// one atomic per workgroup (a same-address atomicMax per wave was the whole cost: 4096 of them serialised in L2, 46 us for 5 M indices), 16-byte loads
+__global__ __launch_bounds__(256) void index_max_kernel(long long total, int vec, const int* __restrict__ idx, int* __restrict__ out)
 {
+    __shared__ int red[4];
     int m = -2147483647 - 1;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) m = max(m, idx[e]);
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x, stride = (long long)gridDim.x * 256;
+    const long long t4 = vec ? (total >> 2) : 0;
+    const int4* __restrict__ v = reinterpret_cast<const int4*>(idx);
+    for (long long e = gid; e < t4; e += stride) { const int4 x = v[e]; m = max(m, max(max(x.x, x.y), max(x.z, x.w))); }
+    for (long long e = 4 * t4 + gid; e < total; e += stride) m = max(m, idx[e]);
     for (int s = 32; s >= 1; s >>= 1) m = max(m, __shfl_xor(m, s));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, max(max(red[0], red[1]), max(red[2], red[3])));
 }
 
 template <bool BWD>
@@ -620,23 +628,33 @@ __global__ __launch_bounds__(256) void aw_bwd_csr_kernel(unsigned n0, int C4, in
     }
 }
 
-// grad_fcw / grad_fcb [e] = sum over the workgroups' partial rows, in a fixed order: 16 threads per element, each a 16th of the workgroups
-__global__ __launch_bounds__(256) void aw_param_reduce_kernel(int nblk, int C, const float* __restrict__ partial, float* __restrict__ gfcw, float* __restrict__ gfcb)
+// grad_fcw / grad_fcb [e] = sum over the workgroups' partial rows, in a fixed order: 64 threads per element, each a 64th of the workgroups (16 threads
+// per element in a 256-thread workgroup left 4 C / 16 = 18 workgroups at C = 72 walking 128 rows each: 40 us)
+constexpr int AWR_GROUPS = 64;
+__global__ __launch_bounds__(16 * AWR_GROUPS) void aw_param_reduce_kernel(int nblk, int C, const float* __restrict__ partial, float* __restrict__ gfcw,
+                                                                          float* __restrict__ gfcb)
 {
-    __shared__ float part[16][16];
+    __shared__ float part[AWR_GROUPS][16];
     const int total = 4 * C;
     const int el = threadIdx.x & 15, pt = threadIdx.x >> 4;
     const int e = blockIdx.x * 16 + el;
-    const int per = (nblk + 15) / 16, b0 = pt * per, b1 = min(nblk, b0 + per);
+    const int per = (nblk + AWR_GROUPS - 1) / AWR_GROUPS, b0 = pt * per, b1 = min(nblk, b0 + per);
     float acc = 0.f;
-    if (e < total)
-        for (int b = b0; b < b1; b++) acc += partial[(size_t)b * total + e];
+    if (e < total) {
+        int b = b0;
+        for (; b + 4 <= b1; b += 4) {                                 // four rows in flight
+            const float v0 = partial[(size_t)b * total + e], v1 = partial[(size_t)(b + 1) * total + e], v2 = partial[(size_t)(b + 2) * total + e],
+                        v3 = partial[(size_t)(b + 3) * total + e];
+            acc += v0; acc += v1; acc += v2; acc += v3;
+        }
+        for (; b < b1; b++) acc += partial[(size_t)b * total + e];
+    }
     part[pt][el] = acc;
     __syncthreads();
     if (pt == 0 && e < total) {
         float sum = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; k++) sum += part[k][el];
+        for (int k = 0; k < AWR_GROUPS; k++) sum += part[k][el];
         if (e < 3 * C) { if (gfcw) gfcw[e] = sum; } else if (gfcb) gfcb[e - 3 * C] = sum;
     }
 }
@@ -765,7 +783,8 @@ CBL_EXPORT int cbl_index_max(long long total, const int* idx, int* out_max, void
     if (total <= 0 || !idx || !out_max) return CBL_ERR_BAD_ARG;
     hipStream_t st = cbl_stream(stream);
     hipLaunchKernelGGL(fill_u32_kernel, dim3(1), dim3(64), 0, st, 1, 0x80000000u, reinterpret_cast<unsigned*>(out_max));   // INT_MIN
-    hipLaunchKernelGGL(index_max_kernel, dim3(cbl_grid_for(total, 256, 1024)), dim3(256), 0, st, total, idx, out_max);
+    const int vec = (reinterpret_cast<uintptr_t>(idx) & 15) == 0;
+    hipLaunchKernelGGL(index_max_kernel, dim3(cbl_grid_for((total + 3) / 4, 256, 512)), dim3(256), 0, st, total, vec, idx, out_max);
     return cbl_status();
 }
 
@@ -872,7 +891,7 @@ CBL_EXPORT int cbl_adaptive_weight_backward_csr(int n, int n0, int K, int C, con
 #undef CBL_AWB
     }
     if (gp)
-        hipLaunchKernelGGL(aw_param_reduce_kernel, dim3(cbl_div_up(4 * C, 16)), dim3(256), 0, st, (int)g, C, partial, grad_fc_weight, grad_fc_bias);
+        hipLaunchKernelGGL(aw_param_reduce_kernel, dim3(cbl_div_up(4 * C, 16)), dim3(16 * AWR_GROUPS), 0, st, (int)g, C, partial, grad_fc_weight, grad_fc_bias);
     return cbl_status();
 }
 

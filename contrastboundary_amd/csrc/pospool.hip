@@ -211,6 +211,66 @@ __global__ __launch_bounds__(256) void pospool_fwd_v4(int n, int n0, int K, int 
     }
 }
 
+// ---------------------------------------------------------------- backward (sum / mean) as a gather over the transposed neighbour table
+// d out / d f[t, c] = sum over the pairs (p, k) that list t (ascending) of go[p, c] / nn[p] * geo(p, k, c): the reference's tf.gather gradient
+// (local_aggregation_operators.py:228-242 under TF autodiff) written, not accumulated — no float atomics, no zero fill, deterministic.
+// lane = 4 channels of one target, L lanes per target (a chunk of at most 256 float4 columns), 256 / L targets per trip, trips dealt to the XCDs
+// in contiguous eighths of the processing order (as aw_bwd_csr_kernel, local_aggregation.hip).
+__global__ __launch_bounds__(256) void pospool_inv_count_kernel(int n, int K, const int* __restrict__ idx, const int* __restrict__ padding_num,
+                                                                int reduction, float* __restrict__ inv_nn)
+{
+    const int pad = (reduction == RED_MEAN) ? *padding_num : 0;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
+        int cnt = 0;
+        if (reduction == RED_MEAN)
+            for (int k = 0; k < K; k++) cnt += idx[(size_t)p * K + k] < pad ? 1 : 0;
+        inv_nn[p] = (reduction == RED_MEAN) ? 1.0f / ((float)cnt + 1e-5f) : 1.0f;        // :238-241
+    }
+}
+
+__global__ __launch_bounds__(256) void pospool_bwd_csr_kernel(unsigned n0, int C4, int c4_0, int L, CblFastDiv dvK, const float* __restrict__ q,
+                                                              const float* __restrict__ s, float radius, int pe, const float* __restrict__ inv_nn,
+                                                              const float4* __restrict__ go, const int* __restrict__ order,
+                                                              const int* __restrict__ inv_start, const int* __restrict__ inv_src, float4* __restrict__ gf)
+{
+    const int tpb = 256 / L;
+    const int ts = threadIdx.x / L, cl = threadIdx.x - ts * L;
+    if (ts >= tpb) return;
+    const int cq = c4_0 + cl, C = 4 * C4;
+    const LaneGeo g0 = decode_geo(pe, C, 4 * cq), g1 = decode_geo(pe, C, 4 * cq + 1), g2 = decode_geo(pe, C, 4 * cq + 2), g3 = decode_geo(pe, C, 4 * cq + 3);
+    const unsigned ntrips = (n0 + tpb - 1) / tpb;
+    const unsigned vend = 8 * cbl_xcd_per(ntrips);
+    for (unsigned v = blockIdx.x; v < vend; v += gridDim.x) {
+        const unsigned tr = cbl_xcd_slot(v, ntrips) * tpb + ts;
+        if (tr >= n0) continue;
+        const int j = order ? order[tr] : (int)tr;
+        const int e0 = inv_start[tr], e1 = inv_start[tr + 1];
+        const float sx = s[3 * (size_t)j], sy = s[3 * (size_t)j + 1], sz = s[3 * (size_t)j + 2];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        constexpr int U = 4;                                          // pairs in flight per lane
+        for (int eb = e0; eb < e1; eb += U) {
+            int pi[U]; float4 g[U]; float rx[U], ry[U], rz[U], sc[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) pi[u] = (int)cbl_fastdiv((unsigned)inv_src[min(eb + u, e1 - 1)], dvK);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                g[u] = go[(size_t)pi[u] * C4 + cq];
+                rx[u] = q[3 * (size_t)pi[u]]; ry[u] = q[3 * (size_t)pi[u] + 1]; rz[u] = q[3 * (size_t)pi[u] + 2];
+                sc[u] = (eb + u < e1) ? inv_nn[pi[u]] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const float x = (sx - rx[u]) / radius, y = (sy - ry[u]) / radius, z = (sz - rz[u]) / radius;      // :68-70
+                acc.x += (g[u].x * sc[u]) * eval_geo(g0, x, y, z);
+                acc.y += (g[u].y * sc[u]) * eval_geo(g1, x, y, z);
+                acc.z += (g[u].z * sc[u]) * eval_geo(g2, x, y, z);
+                acc.w += (g[u].w * sc[u]) * eval_geo(g3, x, y, z);
+            }
+        }
+        gf[(size_t)j * C4 + cq] = acc;
+    }
+}
+
 inline unsigned pp_grid(int n) { return (unsigned)min((long long)cbl_div_up(n, 4), 256LL * 16); }
 
 int pospool_check(int n, int n0, int K, int C, float radius, int pe, int reduction)
@@ -253,5 +313,36 @@ CBL_EXPORT int cbl_pospool_backward(int n, int n0, int K, int C, const float* qu
         return CBL_ERR_BAD_ARG;
     hipLaunchKernelGGL(pospool_kernel<true>, dim3(pp_grid(n)), dim3(256), 0, cbl_stream(stream), n, n0, K, C, query_points, support_points,
                        neighbors_indices, features, radius, position_embedding, reduction, padding_num, nullptr, grad_out, grad_features);
+    return cbl_status();
+}
+
+CBL_EXPORT size_t cbl_pospool_backward_csr_workspace_bytes(int n) { return (((size_t)(n > 0 ? n : 0) + 255) & ~(size_t)255) * sizeof(float); }
+
+CBL_EXPORT int cbl_pospool_backward_csr(int n, int n0, int K, int C, const float* query_points, const float* support_points, const int* neighbors_indices,
+                                        float radius, int position_embedding, int reduction, const int* padding_num, const float* grad_out,
+                                        const int* order_dst, const int* inv_start, const int* inv_src, float* grad_features,
+                                        void* workspace, size_t workspace_bytes, void* stream)
+{
+    const int rc = pospool_check(n, n0, K, C, radius, position_embedding, reduction);
+    if (rc) return rc;
+    if (reduction == RED_MAX || C % 4) return CBL_ERR_UNSUPPORTED;                 // 'max' shares a gradient among ties of a row: cbl_pospool_backward
+    if (n == 0 || n0 == 0) return CBL_OK;
+    if (!query_points || !support_points || !neighbors_indices || !grad_out || !grad_features || !inv_start || !inv_src || !workspace ||
+        (reduction == RED_MEAN && !padding_num)) return CBL_ERR_BAD_ARG;
+    if (workspace_bytes < cbl_pospool_backward_csr_workspace_bytes(n) || !cbl_host_aligned16(grad_out) || !cbl_host_aligned16(grad_features)) return CBL_ERR_BAD_ARG;
+    hipStream_t st = cbl_stream(stream);
+    float* inv_nn = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(pospool_inv_count_kernel, dim3(cbl_grid_for(n, 256)), dim3(256), 0, st, n, K, neighbors_indices, padding_num, reduction, inv_nn);
+    const int C4 = C / 4;
+    const CblFastDiv dv = cbl_fastdiv_make((unsigned)K);
+    const int chunks = (C4 + 255) / 256;
+    const int Lmax = (C4 + chunks - 1) / chunks;
+    for (int c4_0 = 0; c4_0 < C4; c4_0 += Lmax) {
+        const int L = min(Lmax, C4 - c4_0);
+        unsigned g = cbl_round_up8(cbl_div_up(n0, 256 / L)); if (g > 2048u) g = 2048u;
+        hipLaunchKernelGGL(pospool_bwd_csr_kernel, dim3(g), dim3(256), 0, st, (unsigned)n0, C4, c4_0, L, dv, query_points, support_points, radius,
+                           position_embedding, inv_nn, reinterpret_cast<const float4*>(grad_out), order_dst, inv_start, inv_src,
+                           reinterpret_cast<float4*>(grad_features));
+    }
     return cbl_status();
 }

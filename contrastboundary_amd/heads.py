@@ -214,27 +214,33 @@ class _TFContrast(Function):
 
 
 class _TFContrastPairs(Function):
-    """TF flavour through the atomic-free kernels (cbl_contrast_pairs_*, flags bit 0): contrast 'nce' (head.py:773-795)"""
+    """TF flavour through the atomic-free kernels (cbl_contrast_pairs_*, flags bit 0): contrast 'nce' (head.py:773-795), the sample strings beyond
+    'label' (head.py:560-625) and the 'S' margin (:759-760, :783-785)"""
 
     @staticmethod
-    def forward(ctx, features, labels, neighbors, temperature, weight, nce):
+    def forward(ctx, features, labels, samples, temperature, weight, nce, separate=False, roles=None, sample_valid=None, kl_threshold=None):
         m, d = features.shape
-        n_valid, nsample = labels.shape[0], neighbors.shape[1]
+        n_valid, nsample = labels.shape[0], samples.shape[1]
         if n_valid != m:
-            raise NotImplementedError("tf_contrast 'nce': labels must cover exactly the stage's own points")
+            raise NotImplementedError("tf_contrast through the pair kernels: labels must cover exactly the stage's own points")
+        if nsample > 65:
+            raise NotImplementedError(f"tf_contrast: {nsample - 1} sample columns (at most 64)")
         dev = features.device
         per_point = torch.empty(m, dtype=torch.float32, device=dev); mask = torch.empty(m, dtype=torch.int32, device=dev)
         stats = torch.empty(2, dtype=torch.float32, device=dev); loss = torch.empty(1, dtype=torch.float32, device=dev)
         grad = ctx.needs_input_grad[0]
         coef = torch.empty((m, nsample), dtype=torch.float32, device=dev) if grad else None
         own = torch.empty((m, d), dtype=torch.float32, device=dev) if grad else None
-        order = pointops.spatial_order(neighbors)
-        _lib.check(_lib.lib().cbl_contrast_pairs_forward(_c_int(m), _c_int(n_valid), _c_int(1 | (4 if nce else 0)), _c_int(nsample), _c_int(d), _lib.ptr(features),
-                                                         _lib.ptr(labels), _c_int(0), _c_float(0.0), _lib.ptr(neighbors), _lib.ptr(order), _c_float(temperature),
-                                                         _c_float(weight), _lib.ptr(per_point), _lib.ptr(mask), _lib.ptr(stats), _lib.ptr(loss), _lib.ptr(coef),
-                                                         _lib.ptr(own), _lib.stream_of(features)), "cbl_contrast_pairs_forward")
+        order = pointops.spatial_order(samples)
+        ncls = 0 if kl_threshold is None else labels.shape[1]
+        flags = 1 | (4 if nce else 0) | (8 if separate else 0)
+        _lib.check(_lib.lib().cbl_contrast_pairs_forward_samples(
+            _c_int(m), _c_int(n_valid), _c_int(flags), _c_int(nsample), _c_int(d), _lib.ptr(features), _lib.ptr(labels), _c_int(ncls),
+            _c_float(0.0 if kl_threshold is None else kl_threshold), _lib.ptr(samples), _lib.ptr(roles), _lib.ptr(sample_valid), _lib.ptr(order),
+            _c_float(temperature), _c_float(weight), _lib.ptr(per_point), _lib.ptr(mask), _lib.ptr(stats), _lib.ptr(loss), _lib.ptr(coef), _lib.ptr(own),
+            _lib.stream_of(features)), "cbl_contrast_pairs_forward_samples")
         if grad:
-            ctx.save_for_backward(features, coef, own, stats, neighbors)
+            ctx.save_for_backward(features, coef, own, stats, samples)
         ctx.weight, ctx.nsample = weight, nsample
         ctx.mark_non_differentiable(mask)
         ctx.set_materialize_grads(False)
@@ -242,40 +248,102 @@ class _TFContrastPairs(Function):
 
     @staticmethod
     def backward(ctx, grad_loss, _gm):
+        none = (None,) * 9
         if grad_loss is None:
-            return None, None, None, None, None, None
-        features, coef, own, stats, neighbors = ctx.saved_tensors
+            return (None,) + none
+        features, coef, own, stats, samples = ctx.saved_tensors
         m, d = features.shape
-        tr = pointops.neighbor_transpose(neighbors, m)                   # shadow neighbours (index m) are left out of the table
+        tr = pointops.neighbor_transpose(samples, m)                     # shadow neighbours (index m) are left out of the table
         if tr is None:
-            return _pairs_backward_atomic(features, coef, own, stats, neighbors, grad_loss, ctx.weight, ctx.nsample), None, None, None, None, None
+            return (_pairs_backward_atomic(features, coef, own, stats, samples, grad_loss, ctx.weight, ctx.nsample),) + none
         order, inv_start, inv_src = tr
         g = torch.empty_like(features)
         gl = grad_loss.reshape(1).to(torch.float32).contiguous()
         _lib.check(_lib.lib().cbl_contrast_pairs_backward(_c_int(m), _c_int(ctx.nsample), _c_int(d), _lib.ptr(features), _lib.ptr(coef), _lib.ptr(own),
                                                           _lib.ptr(order), _lib.ptr(inv_start), _lib.ptr(inv_src), _lib.ptr(stats), _lib.ptr(gl),
                                                           _c_float(ctx.weight), _lib.ptr(g), _lib.stream_of(features)), "cbl_contrast_pairs_backward")
-        return g, None, None, None, None, None
+        return (g,) + none
 
 
-def tf_contrast(features, labels, neighbors, temperature=1.0, weight=0.1, return_mask=False, kl_threshold=None, contrast="softnn"):
-    """TF contrast_head.contrast ('softnn', 'l2') for one stage: features (m,d) f32, neighbors (m,k) i32 radius neighbours incl. the self
+ROLE_LABEL, ROLE_POS, ROLE_NEG, ROLE_NEG_REJECT = 0, 1, 2, 3               # include/cbl_amd.h CBL_ROLE_*
+
+
+def tf_sample_columns(neighbors, sample, rand_idx=None, batches_len=None, generator=None):
+    """contrast_head.sample_labels (head.py:551-625) as arrays for cbl_contrast_pairs_forward_samples: neighbors (m,k) i32 incl. the self column
+    -> samples (m, 1 + S) i32 (self column, then the '-'-joined segments), roles (S,) u8, sample_valid (m,S) u8 or None.
+    'label*' = the neighbour columns, 'nn<k>' = the first k of them, 'rand<n>[R]' = n uniform draws per point from its own cloud (:568-596;
+    batches_len (B,) = points per cloud, one cloud if None) — or the caller's rand_idx (list of (m,n) tensors, one per rand segment), since no
+    generator here replays tf.random.uniform; 'R' marks the draws that hit one of the point's neighbours (:611-615)."""
+    m = neighbors.shape[0]
+    nbr = neighbors[:, 1:]
+    rand_idx = list(rand_idx) if rand_idx is not None else []
+    cols, roles, reject = [neighbors[:, :1]], [], []
+    for seg in sample.split("-"):
+        if seg.startswith("label"):
+            cur, role = nbr, ROLE_LABEL
+        elif seg.startswith("nn"):
+            k = int(seg[2:])
+            if k > nbr.shape[1]:
+                raise ValueError(f"sample {seg!r}: only {nbr.shape[1]} neighbour columns")            # 'assume enough neighbor', :565
+            cur, role = nbr[:, :k], ROLE_POS
+        elif seg.startswith("rand"):
+            n_neg = int("".join(ch for ch in seg[4:] if ch.isdigit()))
+            if rand_idx:
+                cur = rand_idx.pop(0).to(device=neighbors.device, dtype=torch.int32)
+                if tuple(cur.shape) != (m, n_neg):
+                    raise ValueError(f"sample {seg!r}: rand_idx of shape {tuple(cur.shape)}, expected {(m, n_neg)}")
+            else:
+                lens = [m] if batches_len is None else [int(v) for v in batches_len.tolist()]
+                if sum(lens) != m:
+                    raise ValueError("batches_len does not add up to the number of points")
+                parts, start = [], 0
+                for nb_ in lens:                                                                        # per-cloud draw, :574-589
+                    parts.append(torch.randint(0, max(nb_, 1), (nb_, n_neg), device=neighbors.device, generator=generator, dtype=torch.int32) + start)
+                    start += nb_
+                cur = torch.cat(parts)
+            role = ROLE_NEG_REJECT if "R" in seg else ROLE_NEG
+        else:
+            raise NotImplementedError(f"not supported sample = {seg} in {sample}")                      # :598-599
+        cols.append(cur); roles += [role] * cur.shape[1]
+        reject.append((cur[:, :, None] != nbr[:, None, :]).all(-1) if role == ROLE_NEG_REJECT else None)
+    samples = torch.cat(cols, 1).contiguous()
+    roles_t = torch.tensor(roles, dtype=torch.uint8, device=neighbors.device)
+    valid = None
+    if any(r is not None for r in reject):
+        valid = torch.cat([torch.ones(c.shape, dtype=torch.uint8, device=neighbors.device) if r is None else r.to(torch.uint8)
+                           for c, r in zip(cols[1:], reject)], 1).contiguous()
+    return samples, roles_t, valid
+
+
+def tf_contrast(features, labels, neighbors, temperature=1.0, weight=0.1, return_mask=False, kl_threshold=None, contrast="softnn", sample="label",
+                margin=None, rand_idx=None, batches_len=None, generator=None):
+    """TF contrast_head.contrast ('softnn' | 'nce', dist 'l2') for one stage: features (m,d) f32, neighbors (m,k) i32 radius neighbours incl. the self
     column, padded with N.  sample 'label': labels (N,) hard labels of the N support points of that stage (negative = ignored);
-    sample 'labelkl<thr>' (kl_threshold=thr): labels (N,ncls) f32 label distributions (tf_scene_label(..., 'soft'); one-hot at stage 0)."""
+    sample 'labelkl<thr>' (kl_threshold=thr): labels (N,ncls) f32 label distributions (tf_scene_label(..., 'soft'); one-hot at stage 0);
+    sample with 'nn<k>' / 'rand<n>[R]' segments: tf_sample_columns; margin: a string holding 'S' (pos / neg kept separate, head.py:759-760 /
+    :783-785) and / or 'T<float>' (temperature, :740-743)."""
     if contrast not in ("softnn", "nce"):
         raise NotImplementedError(f"tf_contrast: contrast={contrast!r}")
-    if contrast == "nce":                                                # head.py:773-795 (no 'S' margin, no masking), hard labels
-        if kl_threshold is not None:
-            raise NotImplementedError("tf_contrast: 'nce' with labelkl positives")
-        loss, mask = _TFContrastPairs.apply(features.contiguous(), labels.to(torch.int32).contiguous(), neighbors.contiguous(), float(temperature),
-                                            float(weight), True)
-        return (loss, mask) if return_mask else loss
+    separate = False
+    if margin:
+        separate = "S" in margin
+        if "T" in margin:
+            temperature = float(margin[margin.index("T") + 1:])
+    plain_sample = all(seg.startswith("label") for seg in sample.split("-")) and "-" not in sample
     if kl_threshold is None:
         lab = labels.to(torch.int32).contiguous()
     else:
         lab = labels.to(torch.float32).contiguous()
         if lab.dim() != 2 or lab.shape[1] > 255:
             raise ValueError("labelkl: labels must be (N, ncls <= 255) distributions")
+    if contrast == "nce" or separate or not plain_sample:               # the pair kernels: every option of the head
+        if plain_sample:
+            samples, roles, valid = neighbors.contiguous(), None, None
+        else:
+            samples, roles, valid = tf_sample_columns(neighbors, sample, rand_idx, batches_len, generator)
+        loss, mask = _TFContrastPairs.apply(features.contiguous(), lab, samples, float(temperature), float(weight), contrast == "nce", separate, roles,
+                                            valid, None if kl_threshold is None else float(kl_threshold))
+        return (loss, mask) if return_mask else loss
     loss, mask = _TFContrast.apply(features.contiguous(), lab, neighbors.contiguous(), float(temperature), float(weight),
                                    None if kl_threshold is None else float(kl_threshold))
     return (loss, mask) if return_mask else loss

@@ -182,6 +182,21 @@ class _PosPool(Function):
         n, K = idx.shape
         n0, C = f.shape
         grad_out = grad_out.contiguous()
+        L = _lib.lib()
+        if red != 2 and C % 4 == 0:
+            # 'sum' / 'mean': a gather over the transposed neighbour table (no atomics, deterministic), built where that pays, taken where it exists
+            from . import pointops
+            tr = pointops.neighbor_transpose(idx, n0, build=(n * K >= pointops.TRANSPOSE_MIN_PAIRS))
+            if tr is not None:
+                order, inv_start, inv_src = tr
+                gf = torch.empty_like(f)
+                ws = torch.empty(L.cbl_pospool_backward_csr_workspace_bytes(_i(n)), dtype=torch.uint8, device=f.device)
+                rc = L.cbl_pospool_backward_csr(_i(n), _i(n0), _i(K), _i(C), _lib.ptr(q), _lib.ptr(s), _lib.ptr(idx), _f(radius), _i(pe), _i(red), _lib.ptr(pad),
+                                                _lib.ptr(grad_out), _lib.ptr(order), _lib.ptr(inv_start), _lib.ptr(inv_src), _lib.ptr(gf), _lib.ptr(ws),
+                                                ctypes.c_size_t(ws.numel()), _lib.stream_of(f))
+                if rc != _lib.ERR_UNSUPPORTED:
+                    _lib.check(rc, "cbl_pospool_backward_csr")
+                    return None, None, None, gf, None, None, None
         gf = torch.zeros_like(f)
         _lib.check(_lib.lib().cbl_pospool_backward(_i(n), _i(n0), _i(K), _i(C), _lib.ptr(q), _lib.ptr(s), _lib.ptr(idx), _lib.ptr(f), _f(radius),
                                                    _i(pe), _i(red), _lib.ptr(pad), _lib.ptr(grad_out), _lib.ptr(gf), _lib.stream_of(f)),

@@ -90,12 +90,23 @@ def tf_batch_neighbors(queries, supports, q_batches, s_batches, radius, limit=No
     _lib.check(L.cbl_radius_neighbors(_i(b), _i(nq), _i(ns), _lib.ptr(queries), _lib.ptr(supports), _lib.ptr(q_off), _lib.ptr(s_off),
                                       _f(radius), _i(lim), _lib.ptr(out), _lib.ptr(counts), _lib.ptr(mc), _lib.ptr(ws), ctypes.c_size_t(ws.numel()),
                                       _lib.stream_of(queries)), "cbl_radius_neighbors")
+    if exact_shape == "defer":
+        return out, mc                         # the caller trims (trim_neighbor_widths): many searches, one host sync
     if limit is None or exact_shape:
         width = int(mc.item())
         if limit is None and width > 64:
             raise _lib.CblError(f"largest neighbourhood has {width} points; pass limit= (the reference crops to neighborhood_limits anyway)")
         out = out[:, :min(width, lim)].contiguous()
     return out
+
+
+def trim_neighbor_widths(pending):
+    """[(neighbors (Nq, limit), largest-neighbourhood scalar)] from tf_batch_neighbors(..., exact_shape='defer') -> the tables at the widths the
+    reference's slicing gives (min(limit, largest neighbourhood)); ONE device-to-host copy for all of them"""
+    if not pending:
+        return []
+    widths = torch.cat([mc for _, mc in pending]).tolist()
+    return [out if w >= out.shape[1] else out[:, :w].contiguous() for (out, _), w in zip(pending, widths)]
 
 
 def tf_knn_search(points, queries, k):
@@ -134,18 +145,24 @@ def segmentation_inputs_radius(stacked_points, stacks_lengths, first_subsampling
     r = dl * float(density_parameter) / 2.0                                  # :784-786
     pts, lens = stacked_points, stacks_lengths
     out = {"points": [], "neighbors": [], "pools": [], "upsamples": [torch.zeros((0, 1), dtype=torch.int32, device=pts.device)], "batches_len": []}
+    # Host synchronisation: the sub-sampled point count of every layer is data dependent (one sync per layer, as the TF op's dynamic shape), the
+    # widths of the 13 neighbour tables are read back together at the end; a layer's self-search is enqueued BEFORE its sub-sampling's sync, so
+    # the device has work while the host waits for the count.  (A sync per search left the device idle 2 of the pyramid's 3.6 ms at N = 200 000.)
+    pending = []                                                             # (key, table, largest neighbourhood) in the reference's order
     for dt in range(num_layers - 1):                                         # :795-812
         lim = int(neighborhood_limits[dt])
-        neighbors = tf_batch_neighbors(pts, pts, lens, lens, r, lim)
+        pending.append(("neighbors", tf_batch_neighbors(pts, pts, lens, lens, r, lim, exact_shape="defer")))
         pool_pts, pool_lens = tf_batch_subsampling(pts, lens, 2 * dl)
-        pools = tf_batch_neighbors(pool_pts, pts, pool_lens, lens, r, lim)
-        ups = tf_batch_neighbors(pts, pool_pts, lens, pool_lens, 2 * r, lim)
-        out["points"].append(pts); out["neighbors"].append(neighbors); out["pools"].append(pools); out["upsamples"].append(ups)
-        out["batches_len"].append(lens)
-        pts, lens = pool_pts.contiguous(), pool_lens
+        pool_pts = pool_pts.contiguous()
+        pending.append(("pools", tf_batch_neighbors(pool_pts, pts, pool_lens, lens, r, lim, exact_shape="defer")))
+        pending.append(("upsamples", tf_batch_neighbors(pts, pool_pts, lens, pool_lens, 2 * r, lim, exact_shape="defer")))
+        out["points"].append(pts); out["batches_len"].append(lens)
+        pts, lens = pool_pts, pool_lens
         r *= 2; dl *= 2
     out["points"].append(pts)                                                # :815-820
-    out["neighbors"].append(tf_batch_neighbors(pts, pts, lens, lens, r, int(neighborhood_limits[num_layers - 1])))
+    pending.append(("neighbors", tf_batch_neighbors(pts, pts, lens, lens, r, int(neighborhood_limits[num_layers - 1]), exact_shape="defer")))
+    for (key, _), table in zip(pending, trim_neighbor_widths([p for _, p in pending])):
+        out[key].append(table)
     out["pools"].append(torch.zeros((0, 1), dtype=torch.int32, device=pts.device))
     out["batches_len"].append(lens)
     return out

@@ -288,6 +288,24 @@ int cbl_contrast_grad_scale(long long total, const float* grad_unit, const float
 int cbl_contrast_pairs_forward(int m, int n_valid, int flags, int nsample, int d, const float* features, const void* labels, int num_classes,
                                float kl_threshold, const int* neighbor_idx, const int* order, float temperature, float weight,
                                float* per_point, int* point_mask, float* stats, float* loss, float* coef, float* grad_own, void* stream);
+/* TF contrast_head with the sample strings beyond 'label' and the 'S' margin (tensorflow/models/heads/head.py:560-625 sample_labels, :759-760 and
+ * :783-785 margin 'S'): as cbl_contrast_pairs_forward with flags bit 0 set, and
+ *   sample_idx (m, nsample) = the self column followed by the '-'-concatenated sample columns (neighbour columns for 'label', the first k
+ *       neighbours for 'nn<k>', the caller's random draws for 'rand<n>' — the reference draws them with tf.random.uniform per cloud, :579-596);
+ *   roles (nsample - 1) u8 per column after the self column: 0 = mined from the labels (:598-600, valid mask :540-545), CBL_ROLE_POS = 'nn' (always a
+ *       positive, also when it is a shadow neighbour: that gathers the zero row), CBL_ROLE_NEG = 'rand' (always a negative), CBL_ROLE_NEG_REJECT =
+ *       'rand<n>R' (a negative unless sample_valid (m, nsample - 1) u8 is 0 there: the draw is one of the point's neighbours, :611-615); NULL = all 0;
+ *   flags bit 3 = margin 'S': softnn pos / max(neg, eps) instead of pos / (pos + neg); nce: under_j = e_j + sum of the negatives instead of the sum of
+ *       all valid exps.  (bit 2 = 'nce', bit 1 = int64 labels as before.)
+ * coef / grad_own feed cbl_contrast_pairs_backward over the transposed table of sample_idx (or _backward_atomic) unchanged. */
+#define CBL_ROLE_LABEL 0
+#define CBL_ROLE_POS 1
+#define CBL_ROLE_NEG 2
+#define CBL_ROLE_NEG_REJECT 3
+int cbl_contrast_pairs_forward_samples(int m, int n_valid, int flags, int nsample, int d, const float* features, const void* labels, int num_classes,
+                                       float kl_threshold, const int* sample_idx, const unsigned char* roles, const unsigned char* sample_valid,
+                                       const int* order, float temperature, float weight, float* per_point, int* point_mask, float* stats,
+                                       float* loss, float* coef, float* grad_own, void* stream);
 int cbl_contrast_pairs_backward(int m, int nsample, int d, const float* features, const float* coef, const float* grad_own, const int* order,
                                 const int* inv_start, const int* inv_src, const float* stats, const float* grad_loss, float weight,
                                 float* grad_features, void* stream);
@@ -402,6 +420,14 @@ int cbl_pospool_forward(int n, int n0, int K, int C, const float* query_points, 
 int cbl_pospool_backward(int n, int n0, int K, int C, const float* query_points, const float* support_points, const int* neighbors_indices,
                          const float* features, float radius, int position_embedding, int reduction, const int* padding_num,
                          const float* grad_out, float* grad_features, void* stream);
+/* the same gradient for 'sum' / 'mean' as a gather over the transposed neighbour table of neighbors_indices (cbl_neighbor_transpose with n = n0: shadow
+ * entries are not in it): grad_features (n0, C) is WRITTEN (no zero fill, no float atomics, deterministic).  C % 4 == 0; 'max' -> CBL_ERR_UNSUPPORTED
+ * (use cbl_pospool_backward).  workspace: cbl_pospool_backward_csr_workspace_bytes(n). */
+size_t cbl_pospool_backward_csr_workspace_bytes(int n);
+int cbl_pospool_backward_csr(int n, int n0, int K, int C, const float* query_points, const float* support_points, const int* neighbors_indices,
+                             float radius, int position_embedding, int reduction, const int* padding_num, const float* grad_out,
+                             const int* order_dst, const int* inv_start, const int* inv_src, float* grad_features,
+                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* a4  PointTransformerLayer  pytorch/model/blocks.py:31-44, the C-wide part without its (n,K,C) tensors (C = 32 or 64, G = C/8):
  *   p1 (n,K,3) = ReLU(BN(Linear(3,3)(p_j - p_i)))  [computed by the caller: narrow],  p_r = Linear(3,C)(p1) = p1 @ W3C^T + b3C  [never stored]

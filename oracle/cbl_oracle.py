@@ -170,31 +170,79 @@ def tf_label_kl(soft_labels, neighbors):
     return term.sum(-1, dtype=np.float32)
 
 
-def tf_contrast(features, labels, neighbors, temperature=None, weight=0.1, grad=True, kl_threshold=None, contrast="softnn"):
-    """features (m,d); labels (N,) hard labels of the support points (N >= m; negative = ignored) — or, with kl_threshold (sample
-    'labelkl<thr>', :492-511), (N,ncls) soft labels: a neighbour is a positive if KL(p_centre || p_neighbour) < thr; neighbors (m,k)
-    radius neighbours incl. self column, padded with N.  -> loss, d loss/d features (m,d), point_mask"""
-    f = np.asarray(features, np.float32)
+def tf_samples(labels, neighbors, m, sample="label", rand_idx=None, kl_threshold=None):
+    """sample_labels (head.py:551-625) for radius neighbourhoods: -> sample_idx (m,S), pos_mask, neg_mask (m,S) bool BEFORE the point mask.
+    sample = '-'-joined segments: 'label' | 'labelkl<thr>' (kl_threshold) -> the neighbour columns, positives mined from the labels (collect_labels
+    :485-547) and the valid mask of :540-545; 'nn<k>' -> the first k neighbour columns, all positives (:564-566, :603-604); 'rand<n>[R]' -> the
+    caller's draws rand_idx (one (m,n) array per rand segment, in order: the reference draws tf.random.uniform per cloud, :568-596, which nothing
+    here can replay), all negatives (:605-606), with 'R' invalid where the draw is one of the point's neighbours (:611-615).  Segments without a mask
+    of their own are valid everywhere — also where an 'nn' column is a shadow neighbour and where the centre's label is ignored (:616-617)."""
     N = len(labels)
     nbr = np.asarray(neighbors)[:, 1:]                               # exclude self-loop, :560
-    m, ns = nbr.shape
-    if kl_threshold is not None:
-        posneg = tf_label_kl(labels, nbr) < np.float32(kl_threshold)  # :511
-        valid = nbr < N                                              # mask_n of tf_gather(get_mask=bool), :505-509 (no ignored labels: mask_c is None)
-    else:
-        lab = np.concatenate([np.asarray(labels), [-1]])             # shadow label -1, :537
-        nl = lab[np.minimum(nbr, N)]
-        me = np.asarray(labels)[:m]
-        posneg = me[:, None] == nl                                   # :538
-        valid = (nl >= 0) & (me[:, None] >= 0)                       # :540-545
-    pos_mask = posneg & valid; neg_mask = ~posneg & valid            # :621-627
+    rand_idx = list(rand_idx) if rand_idx is not None else []
+    idxs, posnegs, valids = [], [], []
+    for seg in sample.split("-"):
+        if seg.startswith("label"):
+            cur = nbr
+            if kl_threshold is not None:
+                posneg = tf_label_kl(labels, nbr) < np.float32(kl_threshold)      # :511
+                valid = nbr < N                                      # mask_n of tf_gather(get_mask=bool), :505-509 (no ignored labels: mask_c is None)
+            else:
+                lab = np.concatenate([np.asarray(labels), [-1]])     # shadow label -1, :537
+                nl = lab[np.minimum(nbr, N)]
+                me = np.asarray(labels)[:m]
+                posneg = me[:, None] == nl                           # :538
+                valid = (nl >= 0) & (me[:, None] >= 0)               # :540-545
+        elif seg.startswith("nn"):
+            cur = nbr[:, :int(seg[2:])]
+            posneg = np.ones(cur.shape, bool); valid = np.ones(cur.shape, bool)
+        elif seg.startswith("rand"):
+            n_neg = int("".join(ch for ch in seg[4:] if ch.isdigit()))
+            cur = np.asarray(rand_idx.pop(0))
+            assert cur.shape == (m, n_neg), (cur.shape, seg)
+            posneg = np.zeros(cur.shape, bool)
+            valid = (cur[:, :, None] != nbr[:, None, :]).all(-1) if "R" in seg else np.ones(cur.shape, bool)
+        else:
+            raise NotImplementedError(seg)                           # :598-599
+        idxs.append(cur); posnegs.append(posneg); valids.append(valid)
+    idx = np.concatenate(idxs, 1); posneg = np.concatenate(posnegs, 1); valid = np.concatenate(valids, 1)
+    return idx, posneg & valid, ~posneg & valid                      # :621-627
+
+
+def tf_contrast_terms64(f64, idx, pos_mask, neg_mask, rows, n_rows_pad, temperature, contrast, separate):
+    """per-point loss terms of calc_loss_from_dist (head.py:729-795) in float64 — the function whose gradient tf_contrast states analytically
+    (tests differentiate it numerically)"""
+    fpad = np.concatenate([f64, np.zeros((n_rows_pad, f64.shape[1]))])
+    diff = f64[rows][:, None, :] - fpad[np.minimum(idx[rows], len(fpad) - 1)]
+    dist = np.sqrt(np.maximum((diff * diff).sum(-1), 1e-12))
+    d = -dist / (1.0 if temperature is None else float(temperature))
+    e = np.exp(d - d.max(-1, keepdims=True))
+    pm, nm = pos_mask[rows].astype(np.float64), neg_mask[rows].astype(np.float64)
+    P, Nn = (e * pm).sum(-1), (e * nm).sum(-1)
+    if contrast == "nce":
+        under = e + Nn[:, None] if separate else (P + Nn)[:, None]
+        return -(np.log(e / under + 1e-12) * pm).sum(-1)
+    return -np.log((P / np.maximum(Nn, 1e-12) if separate else P / (P + Nn)) + 1e-12)
+
+
+def tf_contrast(features, labels, neighbors, temperature=None, weight=0.1, grad=True, kl_threshold=None, contrast="softnn", sample="label",
+                rand_idx=None, separate=False):
+    """features (m,d); labels (N,) hard labels of the support points (N >= m; negative = ignored) — or, with kl_threshold (sample
+    'labelkl<thr>', :492-511), (N,ncls) soft labels: a neighbour is a positive if KL(p_centre || p_neighbour) < thr; neighbors (m,k)
+    radius neighbours incl. self column, padded with N; sample / rand_idx: tf_samples; separate = margin 'S' (:759-760, :783-785).
+    -> loss, d loss/d features (m,d), point_mask"""
+    f = np.asarray(features, np.float32)
+    N = len(labels)
+    m = len(f)
+    idx, pos_mask, neg_mask = tf_samples(labels, neighbors, m, sample, rand_idx, kl_threshold)
     point_mask = pos_mask.any(1) & neg_mask.any(1)                   # :629-640
     g = np.zeros_like(f)
     if not point_mask.any():
         return np.float32(0.0), g, point_mask                        # false_fn :662-665
     rows = np.nonzero(point_mask)[0]
     fpad = np.concatenate([f, np.zeros((max(N + 1 - len(f), 1), f.shape[1]), np.float32)])   # tf_gather shadow row = zeros, :703
-    fi = f[rows]; fj = fpad[np.minimum(nbr[rows], len(fpad) - 1)]
+    nb = np.minimum(idx[rows], len(fpad) - 1)
+    fi = f[rows]; fj = fpad[nb]
     diff = fi[:, None, :] - fj
     dist = np.sqrt(np.maximum((diff * diff).sum(-1, dtype=np.float32), _EPS)).astype(np.float32)   # :184-185
     d = -dist
@@ -203,36 +251,44 @@ def tf_contrast(features, labels, neighbors, temperature=None, weight=0.1, grad=
     d = d - d.max(-1, keepdims=True)                                 # over ALL columns, :752
     e = np.exp(d).astype(np.float32)
     pm, nm = pos_mask[rows].astype(np.float32), neg_mask[rows].astype(np.float32)
-    if contrast == "nce":
-        # :773-795 without an 'S' margin and without masking: under = sum of the valid exps, -sum over positives of log(exp_j / under + eps)
-        under = (e * (pm + nm)).sum(-1, dtype=np.float32)
-        rr = e / under[:, None]
-        per_point = -(np.log(rr + _EPS) * pm).sum(-1, dtype=np.float32)
-        loss = np.float32(per_point.mean(dtype=np.float32) * np.float32(weight))
-        if not grad:
-            return loss, g, point_mask
-        T = 1.0 if temperature is None else float(temperature)
-        r64, pm64, vm64 = rr.astype(np.float64), pm.astype(np.float64), (pm + nm).astype(np.float64)
-        G = (pm64 * r64 / (r64 + 1e-12)).sum(-1, keepdims=True)
-        dl_dd = vm64 * (pm64 * r64 / (r64 + 1e-12) - r64 * G) / T * float(weight) / float(len(rows))
-        coef = (dl_dd / dist.astype(np.float64))[:, :, None] * diff.astype(np.float64)
-        g64 = np.zeros((len(fpad), f.shape[1]), np.float64)
-        np.add.at(g64, rows, coef.sum(1))
-        np.add.at(g64, np.minimum(nbr[rows], len(fpad) - 1).reshape(-1), -coef.reshape(-1, f.shape[1]))
-        return loss, g64[:len(f)].astype(np.float32), point_mask
+    T = 1.0 if temperature is None else float(temperature)
+    e64, pm64, nm64 = e.astype(np.float64), pm.astype(np.float64), nm.astype(np.float64)
     pos = (e * pm).sum(-1, dtype=np.float32); neg = (e * nm).sum(-1, dtype=np.float32)
-    ratio = pos / (pos + neg)                                        # :759-762
-    per_point = -np.log(ratio + _EPS)                                # :766-767
+    if contrast == "nce":
+        # :773-795 without masking: -sum over positives of log(exp_j / under + eps); under = the sum of the valid exps, or with 'S' exp_j + the negatives
+        under = e + neg[:, None] if separate else np.broadcast_to((e * (pm + nm)).sum(-1, dtype=np.float32)[:, None], e.shape)
+        rr = e / under
+        per_point = -(np.log(rr + _EPS) * pm).sum(-1, dtype=np.float32)
+        r64, u64 = rr.astype(np.float64), under.astype(np.float64)
+        if separate:                                                 # d term / d e_j of a positive, d term / d (sum of negatives)
+            dl_de = -pm64 * (u64 - e64) / ((r64 + 1e-12) * u64 * u64)
+            dl_de = dl_de + nm64 * (pm64 * e64 / ((r64 + 1e-12) * u64 * u64)).sum(-1, keepdims=True)
+            dl_dd = -dl_de * e64 / T
+        else:
+            G = (pm64 * r64 / (r64 + 1e-12)).sum(-1, keepdims=True)
+            dl_dd = (pm64 + nm64) * (pm64 * r64 / (r64 + 1e-12) - r64 * G) / T
+    elif contrast == "softnn":
+        ratio = pos / np.maximum(neg, _EPS) if separate else pos / (pos + neg)      # :759-762
+        per_point = -np.log(ratio + _EPS)                            # :766-767
+        P, Nn = (e64 * pm64).sum(-1), (e64 * nm64).sum(-1)
+        if separate:
+            Nc = np.maximum(Nn, 1e-12)
+            R = P / Nc
+            dr_de = pm64 / Nc[:, None] - nm64 * (np.where(Nn > 1e-12, P / (Nc * Nc), 0.0))[:, None]
+        else:
+            A = P + Nn
+            R = P / A
+            dr_de = (pm64 * A[:, None] - (pm64 + nm64) * P[:, None]) / (A * A)[:, None]
+        dl_dd = e64 * dr_de / (T * (R + 1e-12)[:, None])
+    else:
+        raise NotImplementedError(contrast)
     loss = np.float32(per_point.mean(dtype=np.float32) * np.float32(weight))   # :805-806
     if not grad:
         return loss, g, point_mask
-    T = 1.0 if temperature is None else float(temperature)
-    e64, pm64, nm64 = e.astype(np.float64), pm.astype(np.float64), nm.astype(np.float64)
-    P, A = (e64 * pm64).sum(-1), (e64 * (pm64 + nm64)).sum(-1)
-    dl_dd = e64 * (pm64 * A[:, None] - (pm64 + nm64) * P[:, None]) / (T * (A * A)[:, None] * (P / A + 1e-12)[:, None])
-    dl_dd *= float(weight) / float(len(rows))
+    dl_dd = dl_dd * (float(weight) / float(len(rows)))
     coef = (dl_dd / dist.astype(np.float64))[:, :, None] * diff.astype(np.float64)
+    coef[dist <= 1e-6] = 0.0                                         # sqrt(max(s, 1e-12)) is flat below the clamp
     g64 = np.zeros((len(fpad), f.shape[1]), np.float64)
     np.add.at(g64, rows, coef.sum(1))
-    np.add.at(g64, np.minimum(nbr[rows], len(fpad) - 1).reshape(-1), -coef.reshape(-1, f.shape[1]))
+    np.add.at(g64, nb.reshape(-1), -coef.reshape(-1, f.shape[1]))
     return loss, g64[:len(f)].astype(np.float32), point_mask

@@ -64,3 +64,16 @@ def test_dropin_has_no_cpu_path():
             pointops_cuda.knnquery_cuda(64, 4, xyz, xyz, off, off, torch.zeros(64, 4, dtype=torch.int32), torch.zeros(64, 4))
     finally:
         sys.path.remove(d)
+
+
+def test_every_module_of_the_package_imports():
+    """a syntax error in a module only the GPU tests import must not wait for the GPU box to be seen"""
+    import importlib
+    import pkgutil
+    import contrastboundary_amd
+    names = [m.name for m in pkgutil.walk_packages(contrastboundary_amd.__path__, "contrastboundary_amd.")]
+    assert len(names) >= 15, names
+    for name in names:
+        importlib.import_module(name)
+    for name in ("bench", "__graft_entry__"):
+        importlib.import_module(name)

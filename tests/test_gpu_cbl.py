@@ -336,6 +336,81 @@ def test_tf_contrast_nce_vs_oracle(k, d):
     np.testing.assert_allclose(f.grad.cpu().numpy(), rgrad, rtol=1e-4, atol=1e-4 * np.abs(rgrad).max())
 
 
+def _tf_radius_case(seed, n, k, d):
+    """radius-search-shaped neighbourhoods: kNN rows with a random number of trailing shadow entries (index n), some ignored labels"""
+    rng = np.random.default_rng(seed)
+    xyz = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    lab = (np.floor(xyz[:, 0] * 3) + 3 * np.floor(xyz[:, 2] * 3)).astype(np.int64) % 7
+    lab[::53] = -1                                                        # ignored points
+    feat = (rng.normal(size=(n, d)) * 0.5).astype(np.float32)
+    lens = np.int32([n // 3, n - n // 3])
+    off = np.cumsum(lens).astype(np.int32)
+    idx, _ = O.knnquery(k, xyz, xyz, off, off)
+    nb = idx.copy()
+    npad = rng.integers(0, k // 3, n)
+    for i in range(n):
+        if npad[i]:
+            nb[i, k - npad[i]:] = n                                       # the radius search's shadow index
+    nb[::97, 2:] = n                                                      # sparse spots: one real neighbour, the rest shadow
+    return rng, feat, lab, nb.astype(np.int32), lens
+
+
+@pytest.mark.parametrize("sample,nr", [("label", ()), ("nn4-rand12", (12,)), ("label-rand8R", (8,)), ("nn2-label-rand6", (6,)), ("label-nn3-rand5-rand4R", (5, 4))])
+@pytest.mark.parametrize("contrast", ["softnn", "nce"])
+@pytest.mark.parametrize("separate", [False, True])
+def test_tf_contrast_samples_and_margin_vs_oracle(sample, nr, contrast, separate):
+    """TF contrast_head's sample strings beyond 'label' ('nn<k>', 'rand<n>', 'rand<n>R', head.py:560-625) and the 'S' margin of both contrasts
+    (:759-760, :783-785), with shadow padding (an 'nn' column may be a shadow: a positive at the zero row) and ignored labels; the random draws are
+    handed in (tf.random.uniform cannot be replayed).  Parity unpinned by execution (TensorFlow absent): against the restatement, whose gradient
+    tests/test_oracle_cbl.py checks against finite differences."""
+    from contrastboundary_amd import heads
+    n, k, d = 2400, 14, 32
+    rng, feat, lab, nb, lens = _tf_radius_case(len(sample) + 7 * len(nr), n, k, d)
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    cloud = np.repeat(np.arange(len(lens)), lens)
+    rand = []
+    for r in nr:
+        draw = (rng.random((n, r)) * lens[cloud][:, None]).astype(np.int64) + starts[cloud][:, None]
+        draw[:, 0] = np.where(rng.random(n) < 0.3, nb[:, 1], draw[:, 0])   # some draws ARE neighbours (what 'R' rejects)
+        draw = np.minimum(draw, n - 1)
+        rand.append(draw.astype(np.int32))
+    f = dev(feat).requires_grad_(True)
+    loss, mask = heads.tf_contrast(f, dev(lab), dev(nb), temperature=0.8, weight=0.1, return_mask=True, contrast=contrast, sample=sample,
+                                   margin="S" if separate else None, rand_idx=[dev(r) for r in rand])
+    loss.backward()
+    rloss, rgrad, rmask = C.tf_contrast(feat, lab, nb, temperature=0.8, weight=0.1, contrast=contrast, sample=sample, rand_idx=rand, separate=separate)
+    assert rmask.any() and not rmask.all() or "nn" in sample
+    np.testing.assert_array_equal(mask.cpu().numpy().astype(bool), rmask)
+    np.testing.assert_allclose(loss.item(), rloss, rtol=TOL)
+    np.testing.assert_allclose(f.grad.cpu().numpy(), rgrad, rtol=1e-4, atol=1e-4 * np.abs(rgrad).max())
+    if "nn" in sample:
+        assert (nb[:, 1:1 + int(sample.split("nn")[1][0])] == n).any()                     # a shadow 'nn' column is part of the case
+
+
+def test_tf_contrast_margin_temperature_and_internal_draws():
+    """margin 'T<float>' sets the temperature (head.py:740-743); without rand_idx the draws come from the caller's generator, per cloud (:574-589)"""
+    from contrastboundary_amd import heads
+    n, k, d = 2400, 14, 16
+    rng, feat, lab, nb, lens = _tf_radius_case(3, n, k, d)
+    f = dev(feat)
+    a = heads.tf_contrast(f, dev(lab), dev(nb), temperature=1.0, margin="ST.5", contrast="softnn")
+    b = heads.tf_contrast(f, dev(lab), dev(nb), temperature=0.5, margin="S", contrast="softnn")
+    assert a.item() == b.item()
+    r = C.tf_contrast(feat, lab, nb, temperature=0.5, weight=0.1, separate=True, grad=False)[0]
+    np.testing.assert_allclose(a.item(), r, rtol=TOL)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    samples, roles, valid = heads.tf_sample_columns(dev(nb), "nn3-rand16R", batches_len=dev(lens), generator=g)
+    assert samples.shape == (n, 1 + 3 + 16) and roles.tolist() == [1] * 3 + [3] * 16 and valid.shape == (n, 19)
+    draws = samples[:, 4:].cpu().numpy()
+    assert (draws[:lens[0]] < lens[0]).all() and (draws[lens[0]:] >= lens[0]).all() and (draws < n).all()   # every point draws from its own cloud
+    want = (draws[:, :, None] != nb[:, None, 1:]).all(-1)
+    np.testing.assert_array_equal(valid[:, 3:].cpu().numpy().astype(bool), want)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    loss = heads.tf_contrast(f, dev(lab), dev(nb), temperature=0.8, sample="nn3-rand16R", batches_len=dev(lens), generator=g)
+    rl = C.tf_contrast(feat, lab, nb, temperature=0.8, weight=0.1, sample="nn3-rand16R", rand_idx=[draws], grad=False)[0]
+    np.testing.assert_allclose(loss.item(), rl, rtol=TOL)
+
+
 def test_coincident_points_keep_the_reference_column_zero():
     """A point with a coincident twin: both are at distance 0 from the query and the reference's heap decides which one is column 0 — the
     column point_contrast drops as "the query itself" (heads.py:195-196).  The set-policy search the head uses leaves the order among

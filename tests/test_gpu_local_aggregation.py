@@ -165,6 +165,39 @@ def test_pospool(pe, C, reduction, K):
     np.testing.assert_allclose(ft.grad.cpu().numpy(), gf, rtol=1e-4, atol=1e-4 * max(np.abs(gf).max(), 1.0))
 
 
+@pytest.mark.parametrize("n0,n,K,C,pe,reduction", [(3000, 2600, 26, 72, "sin_cos", "mean"), (2000, 2000, 31, 144, "sin_cos", "sum"), (900, 700, 38, 288, "xyz", "mean"),
+                                                    (300, 260, 39, 1152, "sin_cos", "mean"), (800, 800, 9, 8, "one", "mean"), (600, 600, 12, 64, "direction_d", "mean"), (700, 700, 41, 72, "three_order", "sum")])
+def test_pospool_backward_as_a_gather(n0, n, K, C, pe, reduction):
+    """'sum' / 'mean' backward over the transposed neighbour table (no atomics): the lane / chunk geometries of the kernel, query set != support set,
+    shadow padding; values against the restatement, bitwise identical from run to run, and equal (1e-4) to the scatter entry it replaces"""
+    import ctypes
+    from contrastboundary_amd import _lib, local_aggregation as L, pointops
+    q, s, idx, f, rng = make(n0, n, K, C, seed=C + K)
+    radius = 0.1
+    go = rng.normal(size=(n, C)).astype(np.float32)
+    idx_d = dev(idx)
+    assert pointops.neighbor_transpose(idx_d, n0) is not None       # the table exists: the backward takes the gather path whatever the size
+    grads = []
+    for _ in range(2):
+        ft = dev(f).requires_grad_(True)
+        L.pospool(dev(q), dev(s), idx_d, ft, radius, pe, reduction).backward(dev(go))
+        grads.append(ft.grad.cpu().numpy())
+    gf = LA.pospool_grad_features(q, s, idx, f, radius, go, pe, reduction)
+    np.testing.assert_allclose(grads[0], gf, rtol=1e-4, atol=1e-4 * max(np.abs(gf).max(), 1.0))
+    np.testing.assert_array_equal(grads[0].view(np.uint32), grads[1].view(np.uint32))
+    # the scatter entry (float atomics) on the same inputs
+    lib = _lib.lib()
+    i, fl = ctypes.c_int, ctypes.c_float
+    pad = torch.empty(1, dtype=torch.int32, device="cuda")
+    _lib.check(lib.cbl_index_max(ctypes.c_longlong(n * K), _lib.ptr(idx_d), _lib.ptr(pad), _lib.stream_of(idx_d)), "cbl_index_max")
+    qd, sd, fd, god = dev(q), dev(s), dev(f), dev(go)
+    sc = torch.zeros(n0, C, device="cuda")
+    _lib.check(lib.cbl_pospool_backward(i(n), i(n0), i(K), i(C), _lib.ptr(qd), _lib.ptr(sd), _lib.ptr(idx_d), _lib.ptr(fd), fl(radius),
+                                        i(L.POSPOOL_EMBEDDINGS[pe]), i({"sum": 0, "mean": 1}[reduction]), _lib.ptr(pad), _lib.ptr(god), _lib.ptr(sc),
+                                        _lib.stream_of(fd)), "cbl_pospool_backward")
+    np.testing.assert_allclose(grads[0], sc.cpu().numpy(), rtol=1e-4, atol=1e-4 * max(np.abs(gf).max(), 1.0))
+
+
 def test_pospool_rejects_what_the_reference_cannot_reshape():
     from contrastboundary_amd import local_aggregation as L
     q, s, idx, f, rng = make(100, 50, 8, 10, seed=1)

@@ -97,3 +97,71 @@ def test_nce_restatements_agree_with_finite_differences():
                 fp[i, c] += 1e-2; fm[i, c] -= 1e-2
                 num = (fwd(fp, False)[0] - fwd(fm, False)[0]) / 2e-2
                 assert abs(num - g[i, c]) < 2e-5 + 2e-2 * abs(g[i, c])
+
+
+def _tf_sample_case(seed=0, m=60, d=8, ns=9):
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    f = rng.normal(size=(m, d)).astype(np.float32)
+    hard = rng.integers(0, 3, m); hard[::11] = -1                     # ignored centres / neighbours
+    nbr = np.concatenate([np.arange(m)[:, None], rng.integers(0, m, (m, ns))], 1)
+    nbr[rng.random((m, ns + 1)) < 0.15] = m                           # shadow padding of the radius search
+    nbr[:, 0] = np.arange(m)
+    return rng, f, hard, nbr
+
+
+def test_tf_sample_strings_and_masks():
+    """sample_labels (head.py:551-625): what each segment contributes to the index / positive / negative arrays"""
+    import numpy as np
+    from oracle import cbl_oracle as C
+    rng, f, hard, nbr = _tf_sample_case()
+    m, ns = len(f), nbr.shape[1] - 1
+    r1, r2 = rng.integers(0, m, (m, 5)), rng.integers(0, m, (m, 4))
+    idx, pos, neg = C.tf_samples(hard, nbr, m, "label-nn3-rand5-rand4R", [r1, r2])
+    assert idx.shape == (m, ns + 3 + 5 + 4)
+    np.testing.assert_array_equal(idx[:, :ns], nbr[:, 1:]); np.testing.assert_array_equal(idx[:, ns:ns + 3], nbr[:, 1:4])
+    np.testing.assert_array_equal(idx[:, ns + 3:ns + 8], r1); np.testing.assert_array_equal(idx[:, ns + 8:], r2)
+    assert pos[:, ns:ns + 3].all() and not neg[:, ns:ns + 3].any()                       # 'nn': positives, shadow or not
+    assert neg[:, ns + 3:ns + 8].all() and not pos[:, ns + 3:].any()                     # 'rand': negatives
+    rej = (r2[:, :, None] == nbr[:, None, 1:]).any(-1)
+    np.testing.assert_array_equal(neg[:, ns + 8:], ~rej)                                 # 'R': a draw that is a neighbour is not a pair
+    assert rej.any()
+    lab = np.concatenate([hard, [-1]])[np.minimum(nbr[:, 1:], m)]
+    ok = (lab >= 0) & (hard[:, None] >= 0)
+    np.testing.assert_array_equal(pos[:, :ns], ok & (lab == hard[:, None])); np.testing.assert_array_equal(neg[:, :ns], ok & (lab != hard[:, None]))
+    # the 'label' string alone is the function every earlier test used
+    l0 = C.tf_contrast(f, hard, nbr, temperature=0.7)
+    l1 = C.tf_contrast(f, hard, nbr, temperature=0.7, sample="label")
+    assert l0[0] == l1[0] and np.array_equal(l0[1], l1[1])
+
+
+def test_tf_sample_and_margin_gradients_agree_with_finite_differences():
+    """'nn<k>' / 'rand<n>' / 'rand<n>R' samples (head.py:560-625) and the 'S' margin of both contrasts (:759-760, :783-785): the float32 forward of
+    the restatement against its float64 twin, and the stated gradient against central differences of the twin"""
+    import numpy as np
+    from oracle import cbl_oracle as C
+    rng, f, hard, nbr = _tf_sample_case(1)
+    m, d = f.shape
+    N = len(hard)
+    for sample, nr in (("label", ()), ("nn3-rand6", (6,)), ("label-rand5R", (5,)), ("nn2-label-rand4", (4,))):
+        rand = [rng.integers(0, m, (m, n)) for n in nr]
+        for contrast in ("softnn", "nce"):
+            for sep in (False, True):
+                kw = dict(temperature=0.7, weight=0.1, contrast=contrast, sample=sample, rand_idx=rand, separate=sep)
+                loss, g, mask = C.tf_contrast(f, hard, nbr, **kw)
+                assert mask.any() and np.isfinite(loss) and np.isfinite(g).all(), (sample, contrast, sep)
+                idx, pos, neg = C.tf_samples(hard, nbr, m, sample, rand)
+                rows = np.nonzero(mask)[0]
+
+                def loss64(x):
+                    return C.tf_contrast_terms64(x, idx, pos, neg, rows, max(N + 1 - m, 1), 0.7, contrast, sep).mean() * 0.1
+                f64 = f.astype(np.float64)
+                assert abs(loss64(f64) - loss) <= 1e-5 * abs(loss), (sample, contrast, sep)
+                worst = 0.0
+                for i in range(0, m, 7):
+                    for c in range(0, d, 3):
+                        fp, fm = f64.copy(), f64.copy()
+                        fp[i, c] += 1e-5; fm[i, c] -= 1e-5
+                        num = (loss64(fp) - loss64(fm)) / 2e-5
+                        worst = max(worst, abs(num - g[i, c]) / (1e-7 + 1e-4 * max(abs(g[i, c]), np.abs(g).max() * 1e-2)))
+                assert worst < 1.0, (sample, contrast, sep, worst)
