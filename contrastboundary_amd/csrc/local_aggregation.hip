@@ -492,13 +492,20 @@ __global__ __launch_bounds__(256) void adaptive_weight_fwd_v4(unsigned n, int n0
         const int* __restrict__ row = idx + (size_t)p * K;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         int cnt = 0;
+        // the ids of the NEXT batch are requested before this batch's rows: id -> row is a chain of two memory round trips per batch, and with
+        // the ids one batch ahead only the first batch pays both
+        int idn[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int v_ = row[min(u, K - 1)]; idn[u] = (u < K) ? v_ : n0; }      // clamped, unconditional loads
         for (int k0 = 0; k0 < K; k0 += U) {
             int id[U]; float rx[U], ry[U], rz[U]; float4 fk[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                id[u] = (k0 + u < K) ? row[k0 + u] : n0;
+                id[u] = idn[u];
                 cnt += (k0 + u < K && id[u] < pad) ? 1 : 0;
             }
+#pragma unroll
+            for (int u = 0; u < U; u++) { const int v_ = row[min(k0 + U + u, K - 1)]; idn[u] = (k0 + U + u < K) ? v_ : n0; }
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const bool real = id[u] >= 0 && id[u] < n0;
@@ -520,6 +527,86 @@ __global__ __launch_bounds__(256) void adaptive_weight_fwd_v4(unsigned n, int n0
         }
         const float nn = reduction_mean ? (float)cnt + 1e-5f : 1.f;
         out[(size_t)p * C4 + cq] = make_float4(acc.x / nn, acc.y / nn, acc.z / nn, acc.w / nn);
+    }
+}
+
+// v5: the v4 kernel measured VALU-issue bound, not memory bound (wave-instructions x 4 clk / SIMD = ~95 of its 121 us at N = 200 000, C = 72; more rows
+// in flight made it slower): ~40 vector instructions per (neighbour, four channels), two thirds of them overhead every lane of a point repeats (ids,
+// addresses, the offset vector, shadow selects).  Here a lane owns CPL float4 columns (8 or 12 channels), so that overhead is paid once per 8 / 12
+// channels; the fully connected layer moves out of the loop — out[p,c] = w0[c] S0 + w1[c] S1 + w2[c] S2 + b[c] S3 with
+// S_a[p,c] = sum_k r_a(p,k) f[nbr_k, c], r = (offset / radius, 1): three multiply-adds and one add per (neighbour, channel), written as fmaf (the
+// translation unit is compiled with -ffp-contract=off) — and a shadow neighbour is a zero multiplier instead of selects on the row.
+template <int CPL, int U>
+__global__ __launch_bounds__(256) void adaptive_weight_fwd_v5(unsigned n, int n0, int K, int C4, int c4_0, int L, const float* __restrict__ q, const float* __restrict__ s,
+                                                              const int* __restrict__ idx, const float4* __restrict__ f, float inv_radius,
+                                                              const float4* __restrict__ fcw, const float4* __restrict__ fcb,
+                                                              const int* __restrict__ padding_num, int reduction_mean, const int* __restrict__ order,
+                                                              float4* __restrict__ out)
+{
+    const int pad = reduction_mean ? *padding_num : 0;
+    const int tpb = 256 / L;
+    const int ts = threadIdx.x / L, cl = threadIdx.x - ts * L;
+    if (ts >= tpb) return;
+    const int cq = c4_0 + cl * CPL;                                    // this lane's first float4 column
+    const unsigned ntrips = (n + tpb - 1) / tpb;
+    const unsigned vend = 8 * cbl_xcd_per(ntrips);
+    for (unsigned v = blockIdx.x; v < vend; v += gridDim.x) {
+        const unsigned tr = cbl_xcd_slot(v, ntrips) * tpb + ts;
+        if (tr >= n) continue;
+        const int p = order ? order[tr] : (int)tr;
+        const float qx = q[3 * (size_t)p], qy = q[3 * (size_t)p + 1], qz = q[3 * (size_t)p + 2];
+        const int* __restrict__ row = idx + (size_t)p * K;
+        float4 S0[CPL], S1[CPL], S2[CPL], S3[CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; j++) S0[j] = S1[j] = S2[j] = S3[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        int cnt = 0;
+        int idn[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int v_ = row[min(u, K - 1)]; idn[u] = (u < K) ? v_ : n0; }      // ids one batch ahead (see v4)
+        for (int k0 = 0; k0 < K; k0 += U) {
+            int id[U]; float rx[U], ry[U], rz[U]; float4 fk[U][CPL];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                id[u] = idn[u];
+                cnt += (k0 + u < K && id[u] < pad) ? 1 : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) { const int v_ = row[min(k0 + U + u, K - 1)]; idn[u] = (k0 + U + u < K) ? v_ : n0; }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const bool real = id[u] >= 0 && id[u] < n0;
+                const int ic = real ? id[u] : 0;
+                const float4* __restrict__ fr = f + (size_t)ic * C4 + cq;
+#pragma unroll
+                for (int j = 0; j < CPL; j++) fk[u][j] = fr[j];
+                rx[u] = s[3 * (size_t)ic]; ry[u] = s[3 * (size_t)ic + 1]; rz[u] = s[3 * (size_t)ic + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const bool real = id[u] >= 0 && id[u] < n0;          // shadow (and past-the-row) neighbours: zero feature row = zero multipliers (:360-370)
+                const float one = real ? 1.f : 0.f;
+                const float x = real ? (rx[u] - qx) * inv_radius : 0.f, y = real ? (ry[u] - qy) * inv_radius : 0.f, z = real ? (rz[u] - qz) * inv_radius : 0.f;
+#pragma unroll
+                for (int j = 0; j < CPL; j++) {
+                    const float4 fv = fk[u][j];
+                    S0[j] = make_float4(fmaf(x, fv.x, S0[j].x), fmaf(x, fv.y, S0[j].y), fmaf(x, fv.z, S0[j].z), fmaf(x, fv.w, S0[j].w));
+                    S1[j] = make_float4(fmaf(y, fv.x, S1[j].x), fmaf(y, fv.y, S1[j].y), fmaf(y, fv.z, S1[j].z), fmaf(y, fv.w, S1[j].w));
+                    S2[j] = make_float4(fmaf(z, fv.x, S2[j].x), fmaf(z, fv.y, S2[j].y), fmaf(z, fv.z, S2[j].z), fmaf(z, fv.w, S2[j].w));
+                    S3[j] = make_float4(fmaf(one, fv.x, S3[j].x), fmaf(one, fv.y, S3[j].y), fmaf(one, fv.z, S3[j].z), fmaf(one, fv.w, S3[j].w));
+                }
+            }
+        }
+        const float inv_nn = reduction_mean ? 1.0f / ((float)cnt + 1e-5f) : 1.f;
+#pragma unroll
+        for (int j = 0; j < CPL; j++) {
+            const float4 w0 = fcw[cq + j], w1 = fcw[C4 + cq + j], w2 = fcw[2 * C4 + cq + j], bb = fcb[cq + j];
+            float4 o;
+            o.x = fmaf(bb.x, S3[j].x, fmaf(w2.x, S2[j].x, fmaf(w1.x, S1[j].x, w0.x * S0[j].x))) * inv_nn;
+            o.y = fmaf(bb.y, S3[j].y, fmaf(w2.y, S2[j].y, fmaf(w1.y, S1[j].y, w0.y * S0[j].y))) * inv_nn;
+            o.z = fmaf(bb.z, S3[j].z, fmaf(w2.z, S2[j].z, fmaf(w1.z, S1[j].z, w0.z * S0[j].z))) * inv_nn;
+            o.w = fmaf(bb.w, S3[j].w, fmaf(w2.w, S2[j].w, fmaf(w1.w, S1[j].w, w0.w * S0[j].w))) * inv_nn;
+            out[(size_t)p * C4 + cq + j] = o;
+        }
     }
 }
 
@@ -547,7 +634,9 @@ __global__ __launch_bounds__(256) void aw_inv_count_kernel(int n, int K, const i
 
 // L = lanes per target in this launch (a chunk of at most 256 float4 columns starting at column c4_0), tpb = 256 / L targets per trip.
 // partial: (gridDim.x, 4, C) per-workgroup sums of (grad_fcw rows 0..2, grad_fcb).
-template <bool GF, bool GP>
+// A lane owns CPL float4 columns of one target (8 or 12 channels: the pair id, its source row address, the offset vector and the 1 / nn factor are paid
+// once per 8 / 12 channels — the kernel is VALU-issue bound like the forward), multiply-adds written as fmaf (-ffp-contract=off).
+template <bool GF, bool GP, int UB, int CPL>
 __global__ __launch_bounds__(256) void aw_bwd_csr_kernel(unsigned n0, int C4, int c4_0, int L, CblFastDiv dvK, const float* __restrict__ q, const float* __restrict__ s,
                                                         const float4* __restrict__ f, float inv_radius, const float4* __restrict__ fcw, const float4* __restrict__ fcb,
                                                         const float* __restrict__ inv_nn, const float4* __restrict__ go,
@@ -556,12 +645,14 @@ __global__ __launch_bounds__(256) void aw_bwd_csr_kernel(unsigned n0, int C4, in
 {
     __shared__ float4 red[4][256];
     const int tpb = 256 / L;
-    const int ts = threadIdx.x / L, cl = threadIdx.x - ts * L;       // target slot of the trip, column within the chunk
+    const int ts = threadIdx.x / L, cl = threadIdx.x - ts * L;       // target slot of the trip, lane within the target
     const bool on = ts < tpb;
-    const int cq = c4_0 + cl;
-    float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0, w2 = w0, bb = w0;
-    if (on) { w0 = fcw[cq]; w1 = fcw[C4 + cq]; w2 = fcw[2 * C4 + cq]; bb = fcb[cq]; }
-    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;        // parameter gradients of this lane's four channels
+    const int cq = c4_0 + cl * CPL;                                  // this lane's first float4 column
+    float4 A[4][CPL];                                                // parameter gradients of this lane's channels
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int c = 0; c < CPL; c++) A[a][c] = make_float4(0.f, 0.f, 0.f, 0.f);
     const unsigned ntrips = (n0 + tpb - 1) / tpb;
     const unsigned vend = 8 * cbl_xcd_per(ntrips);
     for (unsigned v = blockIdx.x; v < vend; v += gridDim.x) {
@@ -570,59 +661,76 @@ __global__ __launch_bounds__(256) void aw_bwd_csr_kernel(unsigned n0, int C4, in
         const int j = order ? order[tr] : (int)tr;
         const int e0 = inv_start[tr], e1 = inv_start[tr + 1];
         const float sx = s[3 * (size_t)j], sy = s[3 * (size_t)j + 1], sz = s[3 * (size_t)j + 2];
-        float4 S0 = make_float4(0.f, 0.f, 0.f, 0.f), S1 = S0, S2 = S0, S3 = S0;
-        int e = e0;
-        for (; e + 4 <= e1; e += 4) {                                 // four pairs in flight per lane
-            int pi[4]; float4 g[4]; float rx[4], ry[4], rz[4], sc[4];
+        float4 S0[CPL], S1[CPL], S2[CPL], S3[CPL];
 #pragma unroll
-            for (int u = 0; u < 4; u++) pi[u] = (int)cbl_fastdiv((unsigned)inv_src[e + u], dvK);
+        for (int c = 0; c < CPL; c++) S0[c] = S1[c] = S2[c] = S3[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e1 > e0) {
+            // UB pairs in flight per lane; the pair ids of the NEXT batch are requested before this batch's rows (pair -> source row is a chain
+            // of two round trips, the ids one batch ahead leave one)
+            int pn[UB];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                g[u] = go[(size_t)pi[u] * C4 + cq];
-                rx[u] = q[3 * (size_t)pi[u]]; ry[u] = q[3 * (size_t)pi[u] + 1]; rz[u] = q[3 * (size_t)pi[u] + 2];
-                sc[u] = inv_nn[pi[u]];
-            }
+            for (int u = 0; u < UB; u++) pn[u] = inv_src[min(e0 + u, e1 - 1)];
+            for (int e = e0; e < e1; e += UB) {
+                int pi[UB]; float4 g[UB][CPL]; float rx[UB], ry[UB], rz[UB], sc[UB];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const float x = (sx - rx[u]) * inv_radius, y = (sy - ry[u]) * inv_radius, z = (sz - rz[u]) * inv_radius;
-                const float4 gs = make_float4(g[u].x * sc[u], g[u].y * sc[u], g[u].z * sc[u], g[u].w * sc[u]);
-                S0.x += x * gs.x; S0.y += x * gs.y; S0.z += x * gs.z; S0.w += x * gs.w;
-                S1.x += y * gs.x; S1.y += y * gs.y; S1.z += y * gs.z; S1.w += y * gs.w;
-                S2.x += z * gs.x; S2.y += z * gs.y; S2.z += z * gs.z; S2.w += z * gs.w;
-                S3.x += gs.x; S3.y += gs.y; S3.z += gs.z; S3.w += gs.w;
+                for (int u = 0; u < UB; u++) pi[u] = (int)cbl_fastdiv((unsigned)pn[u], dvK);
+#pragma unroll
+                for (int u = 0; u < UB; u++) pn[u] = inv_src[min(e + UB + u, e1 - 1)];
+#pragma unroll
+                for (int u = 0; u < UB; u++) {
+                    const float4* __restrict__ gr = go + (size_t)pi[u] * C4 + cq;
+#pragma unroll
+                    for (int c = 0; c < CPL; c++) g[u][c] = gr[c];
+                    rx[u] = q[3 * (size_t)pi[u]]; ry[u] = q[3 * (size_t)pi[u] + 1]; rz[u] = q[3 * (size_t)pi[u] + 2];
+                    sc[u] = inv_nn[pi[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < UB; u++) {
+                    const bool in = e + u < e1;                       // (uniform over the lanes of a target); past the list: zero multipliers
+                    const float w = in ? sc[u] : 0.f;
+                    const float x = (sx - rx[u]) * inv_radius * w, y = (sy - ry[u]) * inv_radius * w, z = (sz - rz[u]) * inv_radius * w;
+#pragma unroll
+                    for (int c = 0; c < CPL; c++) {
+                        const float4 gv = g[u][c];
+                        S0[c] = make_float4(fmaf(x, gv.x, S0[c].x), fmaf(x, gv.y, S0[c].y), fmaf(x, gv.z, S0[c].z), fmaf(x, gv.w, S0[c].w));
+                        S1[c] = make_float4(fmaf(y, gv.x, S1[c].x), fmaf(y, gv.y, S1[c].y), fmaf(y, gv.z, S1[c].z), fmaf(y, gv.w, S1[c].w));
+                        S2[c] = make_float4(fmaf(z, gv.x, S2[c].x), fmaf(z, gv.y, S2[c].y), fmaf(z, gv.z, S2[c].z), fmaf(z, gv.w, S2[c].w));
+                        S3[c] = make_float4(fmaf(w, gv.x, S3[c].x), fmaf(w, gv.y, S3[c].y), fmaf(w, gv.z, S3[c].z), fmaf(w, gv.w, S3[c].w));
+                    }
+                }
             }
         }
-        for (; e < e1; e++) {
-            const int pi = (int)cbl_fastdiv((unsigned)inv_src[e], dvK);
-            const float4 g = go[(size_t)pi * C4 + cq];
-            const float sc = inv_nn[pi];
-            const float x = (sx - q[3 * (size_t)pi]) * inv_radius, y = (sy - q[3 * (size_t)pi + 1]) * inv_radius, z = (sz - q[3 * (size_t)pi + 2]) * inv_radius;
-            const float4 gs = make_float4(g.x * sc, g.y * sc, g.z * sc, g.w * sc);
-            S0.x += x * gs.x; S0.y += x * gs.y; S0.z += x * gs.z; S0.w += x * gs.w;
-            S1.x += y * gs.x; S1.y += y * gs.y; S1.z += y * gs.z; S1.w += y * gs.w;
-            S2.x += z * gs.x; S2.y += z * gs.y; S2.z += z * gs.z; S2.w += z * gs.w;
-            S3.x += gs.x; S3.y += gs.y; S3.z += gs.z; S3.w += gs.w;
-        }
-        if (GF)
-            gf[(size_t)j * C4 + cq] = make_float4(((w0.x * S0.x + w1.x * S1.x) + w2.x * S2.x) + bb.x * S3.x, ((w0.y * S0.y + w1.y * S1.y) + w2.y * S2.y) + bb.y * S3.y,
-                                                  ((w0.z * S0.z + w1.z * S1.z) + w2.z * S2.z) + bb.z * S3.z, ((w0.w * S0.w + w1.w * S1.w) + w2.w * S2.w) + bb.w * S3.w);
-        if (GP) {
-            const float4 fj = f[(size_t)j * C4 + cq];
-            a0.x += fj.x * S0.x; a0.y += fj.y * S0.y; a0.z += fj.z * S0.z; a0.w += fj.w * S0.w;
-            a1.x += fj.x * S1.x; a1.y += fj.y * S1.y; a1.z += fj.z * S1.z; a1.w += fj.w * S1.w;
-            a2.x += fj.x * S2.x; a2.y += fj.y * S2.y; a2.z += fj.z * S2.z; a2.w += fj.w * S2.w;
-            a3.x += fj.x * S3.x; a3.y += fj.y * S3.y; a3.z += fj.z * S3.z; a3.w += fj.w * S3.w;
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            if (GF) {
+                const float4 w0 = fcw[cq + c], w1 = fcw[C4 + cq + c], w2 = fcw[2 * C4 + cq + c], bb = fcb[cq + c];
+                gf[(size_t)j * C4 + cq + c] = make_float4(fmaf(bb.x, S3[c].x, fmaf(w2.x, S2[c].x, fmaf(w1.x, S1[c].x, w0.x * S0[c].x))),
+                                                          fmaf(bb.y, S3[c].y, fmaf(w2.y, S2[c].y, fmaf(w1.y, S1[c].y, w0.y * S0[c].y))),
+                                                          fmaf(bb.z, S3[c].z, fmaf(w2.z, S2[c].z, fmaf(w1.z, S1[c].z, w0.z * S0[c].z))),
+                                                          fmaf(bb.w, S3[c].w, fmaf(w2.w, S2[c].w, fmaf(w1.w, S1[c].w, w0.w * S0[c].w))));
+            }
+            if (GP) {
+                const float4 fj = f[(size_t)j * C4 + cq + c];
+                A[0][c] = make_float4(fmaf(fj.x, S0[c].x, A[0][c].x), fmaf(fj.y, S0[c].y, A[0][c].y), fmaf(fj.z, S0[c].z, A[0][c].z), fmaf(fj.w, S0[c].w, A[0][c].w));
+                A[1][c] = make_float4(fmaf(fj.x, S1[c].x, A[1][c].x), fmaf(fj.y, S1[c].y, A[1][c].y), fmaf(fj.z, S1[c].z, A[1][c].z), fmaf(fj.w, S1[c].w, A[1][c].w));
+                A[2][c] = make_float4(fmaf(fj.x, S2[c].x, A[2][c].x), fmaf(fj.y, S2[c].y, A[2][c].y), fmaf(fj.z, S2[c].z, A[2][c].z), fmaf(fj.w, S2[c].w, A[2][c].w));
+                A[3][c] = make_float4(fmaf(fj.x, S3[c].x, A[3][c].x), fmaf(fj.y, S3[c].y, A[3][c].y), fmaf(fj.z, S3[c].z, A[3][c].z), fmaf(fj.w, S3[c].w, A[3][c].w));
+            }
         }
     }
     if (GP) {
-        // the tpb lanes that hold the same four channels, in slot order (deterministic), then one partial row block per workgroup
-        red[0][threadIdx.x] = a0; red[1][threadIdx.x] = a1; red[2][threadIdx.x] = a2; red[3][threadIdx.x] = a3;
-        __syncthreads();
-        if (threadIdx.x < L) {
-            for (int a = 0; a < 4; a++) {
-                float4 sum = red[a][threadIdx.x];
-                for (int t = 1; t < tpb; t++) { const float4 o = red[a][t * L + threadIdx.x]; sum.x += o.x; sum.y += o.y; sum.z += o.z; sum.w += o.w; }
-                reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * 4 + a) * (size_t)(4 * C4))[c4_0 + threadIdx.x] = sum;
+        // the tpb lanes that hold the same channels, in slot order (deterministic), then one partial row block per workgroup; one column set at a time
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            __syncthreads();
+            red[0][threadIdx.x] = A[0][c]; red[1][threadIdx.x] = A[1][c]; red[2][threadIdx.x] = A[2][c]; red[3][threadIdx.x] = A[3][c];
+            __syncthreads();
+            if (threadIdx.x < L) {
+                for (int a = 0; a < 4; a++) {
+                    float4 sum = red[a][threadIdx.x];
+                    for (int t = 1; t < tpb; t++) { const float4 o = red[a][t * L + threadIdx.x]; sum.x += o.x; sum.y += o.y; sum.z += o.z; sum.w += o.w; }
+                    reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * 4 + a) * (size_t)(4 * C4))[c4_0 + threadIdx.x * CPL + c] = sum;
+                }
             }
         }
     }
@@ -788,6 +896,12 @@ CBL_EXPORT int cbl_index_max(long long total, const int* idx, int* out_max, void
     return cbl_status();
 }
 
+
+// float4 columns per lane (measured at N = 200 000, C = 72 .. 1152, profiles/r03_aw_lane_width_sweep.md): the forward is quickest with 3 where C / 4
+// divides by 3 (the ConvNet's 72 * 2^l), the backward with 2; two neighbours / pairs in flight per lane in both (4 and 8 cost occupancy: slower)
+static int aw_cpl_for(int c4) { return c4 % 3 == 0 ? 3 : (c4 % 2 == 0 ? 2 : 1); }
+static int aw_cpl_bwd(int c4) { return c4 % 2 == 0 ? 2 : (c4 % 3 == 0 ? 3 : 1); }
+
 static int adaptive_weight_forward_impl(int n, int n0, int K, int C, const float* query_points, const float* support_points, const int* neighbors_indices,
                                         const float* features, float radius, const float* fc_weight, const float* fc_bias, const int* padding_num,
                                         int reduction_mean, const int* order, float* out, void* stream)
@@ -796,15 +910,32 @@ static int adaptive_weight_forward_impl(int n, int n0, int K, int C, const float
     if (n == 0) return CBL_OK;
     if (!query_points || !support_points || !neighbors_indices || !features || !fc_weight || !fc_bias || !out || (reduction_mean && !padding_num)) return CBL_ERR_BAD_ARG;
     const bool vec = (C % 4 == 0) && ((((uintptr_t)features | (uintptr_t)fc_weight | (uintptr_t)fc_bias | (uintptr_t)out) & 15) == 0);
-    if (vec) {
+    const int C4v = C / 4;
+    if (vec && aw_cpl_for(C4v) > 1) {
+        const int cpl = aw_cpl_for(C4v);
+        const int Lall = C4v / cpl, chunks = (Lall + 255) / 256, Lmax = (Lall + chunks - 1) / chunks;
+        for (int l0 = 0; l0 < Lall; l0 += Lmax) {
+            const int L = min(Lmax, Lall - l0);
+            const unsigned g = min(cbl_round_up8(cbl_div_up(n, 256 / L)), 8192u);
+#define CBL_AWF5(CPL_, U_) hipLaunchKernelGGL((adaptive_weight_fwd_v5<CPL_, U_>), dim3(g), dim3(256), 0, cbl_stream(stream), (unsigned)n, n0, K, C4v, l0 * cpl, L, \
+                               query_points, support_points, neighbors_indices, reinterpret_cast<const float4*>(features), 1.0f / radius, \
+                               reinterpret_cast<const float4*>(fc_weight), reinterpret_cast<const float4*>(fc_bias), padding_num, reduction_mean, order, \
+                               reinterpret_cast<float4*>(out))
+            if (cpl == 3) CBL_AWF5(3, 2); else CBL_AWF5(2, 2);
+#undef CBL_AWF5
+        }
+    }
+    else if (vec) {
         const int C4 = C / 4, chunks = (C4 + 255) / 256, Lmax = (C4 + chunks - 1) / chunks;
         for (int c4_0 = 0; c4_0 < C4; c4_0 += Lmax) {
             const int L = min(Lmax, C4 - c4_0);
             const unsigned g = min(cbl_round_up8(cbl_div_up(n, 256 / L)), 8192u);
-            hipLaunchKernelGGL(adaptive_weight_fwd_v4<4>, dim3(g), dim3(256), 0, cbl_stream(stream), (unsigned)n, n0, K, C4, c4_0, L,
-                               query_points, support_points, neighbors_indices, reinterpret_cast<const float4*>(features), 1.0f / radius,
-                               reinterpret_cast<const float4*>(fc_weight), reinterpret_cast<const float4*>(fc_bias), padding_num, reduction_mean, order,
-                               reinterpret_cast<float4*>(out));
+#define CBL_AWF(U_) hipLaunchKernelGGL(adaptive_weight_fwd_v4<U_>, dim3(g), dim3(256), 0, cbl_stream(stream), (unsigned)n, n0, K, C4, c4_0, L, \
+                               query_points, support_points, neighbors_indices, reinterpret_cast<const float4*>(features), 1.0f / radius, \
+                               reinterpret_cast<const float4*>(fc_weight), reinterpret_cast<const float4*>(fc_bias), padding_num, reduction_mean, order, \
+                               reinterpret_cast<float4*>(out))
+            CBL_AWF(2);
+#undef CBL_AWF
         }
     }
     else {
@@ -878,17 +1009,21 @@ CBL_EXPORT int cbl_adaptive_weight_backward_csr(int n, int n0, int K, int C, con
     hipLaunchKernelGGL(aw_inv_count_kernel, dim3(cbl_grid_for(n, 256)), dim3(256), 0, st, n, K, neighbors_indices, padding_num, reduction_mean, inv_nn);
     const int C4 = C / 4;
     const CblFastDiv dv = cbl_fastdiv_make((unsigned)K);
-    // columns in chunks of at most 256 float4 lanes; every chunk walks the table once with grid `g` (the same for all: the partial rows line up)
-    const int chunks = (C4 + 255) / 256;
-    const int Lmax = (C4 + chunks - 1) / chunks;
+    // lanes own cpl float4 columns; lanes in chunks of at most 256 per target; every chunk walks the table once with grid `g` (the same for all: the
+    // partial rows line up)
+    const int cpl = aw_cpl_bwd(C4);
+    const int Lall = C4 / cpl, chunks = (Lall + 255) / 256;
+    const int Lmax = (Lall + chunks - 1) / chunks;
     const unsigned g = aw_csr_grid(n0, Lmax);
-    for (int c4_0 = 0; c4_0 < C4; c4_0 += Lmax) {
-        const int L = min(Lmax, C4 - c4_0);
-#define CBL_AWB(GF_, GP_) hipLaunchKernelGGL((aw_bwd_csr_kernel<GF_, GP_>), dim3(g), dim3(256), 0, st, (unsigned)n0, C4, c4_0, L, dv, query_points, support_points, \
+    for (int l0 = 0; l0 < Lall; l0 += Lmax) {
+        const int L = min(Lmax, Lall - l0);
+#define CBL_AWB2(GF_, GP_, UB_, CPL_) hipLaunchKernelGGL((aw_bwd_csr_kernel<GF_, GP_, UB_, CPL_>), dim3(g), dim3(256), 0, st, (unsigned)n0, C4, l0 * cpl, L, dv, query_points, support_points, \
         reinterpret_cast<const float4*>(features), 1.0f / radius, reinterpret_cast<const float4*>(fc_weight), reinterpret_cast<const float4*>(fc_bias), inv_nn, \
         reinterpret_cast<const float4*>(grad_out), order_dst, inv_start, inv_src, reinterpret_cast<float4*>(grad_features), partial)
+#define CBL_AWB(GF_, GP_) do { if (cpl == 3) CBL_AWB2(GF_, GP_, 2, 3); else if (cpl == 2) CBL_AWB2(GF_, GP_, 2, 2); else CBL_AWB2(GF_, GP_, 2, 1); } while (0)
         if (grad_features && gp) CBL_AWB(true, true); else if (grad_features) CBL_AWB(true, false); else CBL_AWB(false, true);
 #undef CBL_AWB
+#undef CBL_AWB2
     }
     if (gp)
         hipLaunchKernelGGL(aw_param_reduce_kernel, dim3(cbl_div_up(4 * C, 16)), dim3(16 * AWR_GROUPS), 0, st, (int)g, C, partial, grad_fc_weight, grad_fc_bias);

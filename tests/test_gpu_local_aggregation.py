@@ -75,6 +75,36 @@ def test_adaptive_weight(K, C, reduction):
     np.testing.assert_allclose(bt.grad.cpu().numpy(), gb, rtol=1e-4, atol=1e-4 * np.abs(gb).max())
 
 
+@pytest.mark.parametrize("C,K,coherent,reduction", [(72, 26, True, "mean"), (72, 26, False, "mean"), (144, 31, True, "mean"), (288, 38, True, "sum"), (64, 20, True, "mean"),
+                                                    (1152, 39, True, "mean"), (72, 64, False, "mean")])
+def test_adaptive_weight_forward_at_pyramid_widths(C, K, coherent, reduction):
+    """the forward at the ConvNet's widths (lanes own 12 channels where C/4 divides by 3, else 8: adaptive_weight_fwd_v5; the fully connected layer
+    factored out of the neighbour loop), queries in cell order and in random order, shadow padding, a partial last trip, K up to 64"""
+    from contrastboundary_amd import local_aggregation as L
+    n0, n = 5000, 4500 + 5
+    rng = np.random.default_rng(C + K)
+    s = rng.uniform(0, 1, (n0, 3)).astype(np.float32)
+    q = s[rng.choice(n0, n, replace=False)] + rng.normal(0, 0.01, (n, 3)).astype(np.float32)
+    if coherent:
+        cell = np.floor(q / 0.12).astype(np.int64)
+        q = q[np.lexsort((cell[:, 2], cell[:, 1], cell[:, 0]))]
+    idx = np.empty((n, K), np.int32)
+    for a in range(0, n, 500):
+        d = ((s[None, :, :] - q[a:a + 500, None, :]) ** 2).sum(-1)
+        idx[a:a + 500] = np.argsort(d, 1)[:, :K]
+    npad = rng.integers(0, K // 4 + 1, n)
+    for i in range(n):
+        if npad[i]:
+            idx[i, K - npad[i]:] = n0
+    f = rng.normal(size=(n0, C)).astype(np.float32)
+    W = (rng.normal(size=(3, C)) * 0.5).astype(np.float32); b = rng.normal(size=(C,)).astype(np.float32)
+    out = L.adaptive_weight(dev(q), dev(s), dev(idx), dev(f), 0.1, dev(W), dev(b), reduction)
+    ref = LA.adaptive_weight(q, s, idx, f, 0.1, W, b, reduction)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+    out2 = L.adaptive_weight(dev(q), dev(s), dev(idx), dev(f), 0.1, dev(W), dev(b), reduction)
+    np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32), out2.cpu().numpy().view(np.uint32))
+
+
 @pytest.mark.parametrize("n0,n,K,C,reduction", [(3000, 2600, 26, 72, "mean"), (2000, 2000, 31, 144, "mean"), (900, 700, 38, 288, "sum"),
                                                  (500, 400, 41, 576, "mean"), (300, 260, 39, 1152, "mean"), (800, 800, 9, 8, "mean")])
 def test_adaptive_weight_backward_as_a_gather(n0, n, K, C, reduction):
