@@ -37,8 +37,9 @@ def headers():
 # per-file flags.  local_aggregation.hip: MFMA results in VGPRs (gfx950 has one unified file): the KPConv kernels read every accumulator once per
 # point in their epilogue, which through AGPRs is a v_accvgpr_read each (+ a v_accvgpr_write to zero it) on a kernel that is bound by its VALU issue slots
 # (tried and dropped here: -fno-slp-vectorize, which raised the register count of the KPConv backward)
+# (tried in round 3: -ffp-contract=fast for the float-output translation units — no kernel got faster (the hot multiply-adds that matter are written as
+# fmaf where a kernel is VALU bound, local_aggregation.hip), and KPConv's 'closest' kernel-point choice flips on fused distances)
 EXTRA_FLAGS = {"local_aggregation.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
-
 
 def _compile(src, obj, verbose):
     tmp = obj + ".tmp.%d" % os.getpid()

@@ -448,6 +448,22 @@ __global__ __launch_bounds__(AT_BLOCK) void attn_agg_forward_kernel(int n, int K
     }
 }
 
+// sum over the first G lanes of a 16-lane row (G = 4, 8, 16): every one of them ends up with the total
+template <int G> __device__ __forceinline__ float low_lanes_sum(float v)
+{
+    static_assert(G == 4 || G == 8 || G == 16, "group width");
+    v += dppf<0xB1, 0xf>(v);                                         // quad_perm [1,0,3,2]
+    v += dppf<0x4E, 0xf>(v);                                         // quad_perm [2,3,0,1]
+    if (G >= 8) v += dppf<0x141, 0xf>(v);                       // row_half_mirror
+    if (G >= 16) v += dppf<0x140, 0xf>(v);                      // row_mirror
+    return v;
+}
+
+// Per pair the kernel needs two contractions of the point's output gradient g[c] = grad_out[i, c]:
+//   grad_p1[pair, a] = sum_c w_a[c] g[c] a[pair, c % G]          = sum_g a[pair, g] T_a[g]
+//   grad_a[pair, g]  = sum_{c = g mod G} g[c] (x_v[j, c] + pe_c)  = sum_{c = g mod G} g[c] x_v[j, c]  +  B[g] + p1_0 T_0[g] + p1_1 T_1[g] + p1_2 T_2[g]
+// with T_a[g] = sum_{c = g mod G} w_a[c] g[c] and B[g] = sum_{c = g mod G} b[c] g[c] — functions of the POINT, formed once per point (round 2 ran three
+// 64-lane reductions per pair for grad_p1: 3 x 16 per point): per pair one strided sum for the gathered row and a G-lane sum for grad_p1 remain.
 template <int C, int G>
 __global__ __launch_bounds__(AT_BLOCK) void attn_agg_backward_kernel(int n, int K, const float* __restrict__ xv, const int* __restrict__ idx,
                                                                      const float* __restrict__ p1, const float* __restrict__ W3C, const float* __restrict__ b3C,
@@ -464,6 +480,9 @@ __global__ __launch_bounds__(AT_BLOCK) void attn_agg_backward_kernel(int n, int 
     float d0 = 0.f, d1 = 0.f, d2 = 0.f, db = 0.f;
     for (int i = blockIdx.x * GPB + grp; i < n; i += gridDim.x * GPB) {
         const float g = go[(size_t)i * C + c];
+        float T0 = q.w0 * g, T1 = q.w1 * g, T2 = q.w2 * g, Bg = q.b * g;      // -> sums over this lane's residue class c mod G (every lane of the class holds them)
+#pragma unroll
+        for (int st = G; st < C; st <<= 1) { T0 += __shfl_xor(T0, st); T1 += __shfl_xor(T1, st); T2 += __shfl_xor(T2, st); Bg += __shfl_xor(Bg, st); }
         float dot = 0.f;
         for (int k0 = 0; k0 < K; k0 += AT_U) {
           PairBatch pb; load_pairs<C>(pb, i, k0, K, c, idx, p1, xv);
@@ -477,16 +496,17 @@ __global__ __launch_bounds__(AT_BLOCK) void attn_agg_backward_kernel(int n, int 
             const int j = pb.j[u];
             const float a0 = pb.a0[u], a1 = pb.a1[u], a2 = pb.a2[u];
             const float av = avs[u];
-            const float xvj = pb.xr[u];
             const float dpe = g * av;                                // d out / d (x_v[j] + p_r)
             if (gxv) unsafeAtomicAdd(gxv + (size_t)j * C + c, dpe);     // NULL: gathered by attn_agg_gxv_csr_kernel
             d0 += dpe * a0; d1 += dpe * a1; d2 += dpe * a2; db += dpe;
-            const float t0 = group_sum<C>(q.w0 * dpe), t1 = group_sum<C>(q.w1 * dpe), t2 = group_sum<C>(q.w2 * dpe);
+            // grad_p1: the lanes c < G hold a[pair, c] and T_a[c]
+            const float t0 = low_lanes_sum<G>(av * T0), t1 = low_lanes_sum<G>(av * T1), t2 = low_lanes_sum<G>(av * T2);
             if (c < 3) gp1[3 * r + c] = (c == 0) ? t0 : (c == 1) ? t1 : t2;
-            // grad_a[i,k,g] = sum over the channels with c % G == g: the C/G lanes at stride G of this group
-            float da = g * (xvj + pe_of(q, a0, a1, a2));
+            // grad_a[i,k,g]: the gathered row's part over the C/G lanes at stride G, the positional part from the point's sums
+            float da = g * pb.xr[u];
 #pragma unroll
             for (int st = G; st < C; st <<= 1) da += __shfl_xor(da, st);
+            da += ((Bg + a0 * T0) + a1 * T1) + a2 * T2;
             if (c < G) { ga[r * G + c] = da; dot += av * da; }
           }
         }
