@@ -834,11 +834,12 @@ int cbl_knn_grid_launch(int b, int n, int m, int nsample, const float* xyz, cons
 size_t cbl_radius_workspace_bytes_impl(int b, int ns) { return (b > 0 && ns >= 0) ? carve(nullptr, b, ns, 0).bytes : 0; }
 
 int cbl_radius_launch(int b, int nq, int ns, const float* queries, const float* supports, const int* q_offset, const int* s_offset,
-                      float radius, int limit, int* out, int* counts, int* max_count, void* ws, size_t ws_bytes, hipStream_t st)
+                      float radius, int limit, int* out, int* counts, int* max_count, void* ws, size_t ws_bytes, hipStream_t st, bool grid_is_built)
 {
     Workspace w = carve(ws, b, ns, 0);
     if (ws_bytes < w.bytes) return CBL_ERR_WORKSPACE;
-    int rc = cbl_grid_build(b, ns, -radius, supports, s_offset, ws, st);
+    // grid_is_built: the workspace still holds the grid of exactly these supports, offsets and radius (an earlier search on this stream built it)
+    int rc = grid_is_built ? CBL_OK : cbl_grid_build(b, ns, -radius, supports, s_offset, ws, st);
     if (rc) return rc;
     hipError_t e = hipMemsetAsync(max_count, 0, sizeof(int), st);
     if (e != hipSuccess) return (int)e;

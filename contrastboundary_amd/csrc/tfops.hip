@@ -19,7 +19,7 @@
 size_t cbl_radius_workspace_bytes_impl(int b, int ns);
 int cbl_bbox_keys_launch(int b, int n, const float* xyz, const int* offset, unsigned* bbox, hipStream_t st);   // knn_grid.hip
 int cbl_radius_launch(int b, int nq, int ns, const float* queries, const float* supports, const int* q_offset, const int* s_offset,
-                      float radius, int limit, int* out, int* counts, int* max_count, void* ws, size_t ws_bytes, hipStream_t st);
+                      float radius, int limit, int* out, int* counts, int* max_count, void* ws, size_t ws_bytes, hipStream_t st, bool grid_is_built);
 
 namespace {
 
@@ -239,7 +239,23 @@ CBL_EXPORT int cbl_radius_neighbors(int b, int nq, int ns, const float* queries,
     if (!max_count) return CBL_ERR_BAD_ARG;
     if (nq == 0) return (int)hipMemsetAsync(max_count, 0, sizeof(int), cbl_stream(stream));
     if (!queries || !supports || !q_offset || !s_offset || !out || !workspace) return CBL_ERR_BAD_ARG;
-    return cbl_radius_launch(b, nq, ns, queries, supports, q_offset, s_offset, radius, limit, out, counts, max_count, workspace, workspace_bytes, cbl_stream(stream));
+    return cbl_radius_launch(b, nq, ns, queries, supports, q_offset, s_offset, radius, limit, out, counts, max_count, workspace, workspace_bytes, cbl_stream(stream),
+                             false);
+}
+
+// the same search over a workspace whose grid an earlier cbl_radius_neighbors / _reuse call built for the SAME supports, s_offset and radius (the pyramid
+// builder searches every layer's points two or three times: as the supports of its own neighbourhoods, of the pooling and of the previous layer's
+// upsampling, datasets/base.py:795-812): grid_is_built != 0 skips the 5-launch build
+CBL_EXPORT int cbl_radius_neighbors_reuse(int b, int nq, int ns, const float* queries, const float* supports, const int* q_offset, const int* s_offset,
+                                          float radius, int limit, int* out, int* counts, int* max_count, void* workspace, size_t workspace_bytes,
+                                          int grid_is_built, void* stream)
+{
+    if (b <= 0 || nq < 0 || ns < 0 || !(radius > 0.f) || limit <= 0 || limit > 64) return CBL_ERR_BAD_ARG;
+    if (!max_count) return CBL_ERR_BAD_ARG;
+    if (nq == 0) return (int)hipMemsetAsync(max_count, 0, sizeof(int), cbl_stream(stream));      // (no grid is built: the next call must not claim one)
+    if (!queries || !supports || !q_offset || !s_offset || !out || !workspace) return CBL_ERR_BAD_ARG;
+    return cbl_radius_launch(b, nq, ns, queries, supports, q_offset, s_offset, radius, limit, out, counts, max_count, workspace, workspace_bytes, cbl_stream(stream),
+                             grid_is_built != 0);
 }
 
 CBL_EXPORT int cbl_knn_indices_to_local(int B, int M, int K, int N, const int* idx, long long* out, void* stream)

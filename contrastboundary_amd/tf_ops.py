@@ -71,11 +71,26 @@ def grid_subsampling(points, features=None, labels=None, sampleDl=0.1, verbose=0
     return res[0] if len(res) == 1 else tuple(res)
 
 
-def tf_batch_neighbors(queries, supports, q_batches, s_batches, radius, limit=None, exact_shape=True):
+class RadiusGrid:
+    """the search grid of one support set at one radius, kept between searches: tf_batch_neighbors(..., grid=g) builds it on first use and skips the
+    5-launch build afterwards.  Valid for the same supports tensor (unchanged), batches and radius, on the stream that built it."""
+
+    def __init__(self, supports, s_batches, radius):
+        self.key = (supports.data_ptr(), supports.shape[0], supports._version, s_batches.data_ptr(), float(radius))
+        self.supports, self.s_batches = supports, s_batches              # keep the storage (and so the key) alive
+        nbytes = _lib.lib().cbl_radius_neighbors_workspace_bytes(_i(s_batches.shape[0]), _i(supports.shape[0]))
+        self.ws = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=supports.device)
+        self.built = False
+
+    def matches(self, supports, s_batches, radius):
+        return self.key == (supports.data_ptr(), supports.shape[0], supports._version, s_batches.data_ptr(), float(radius))
+
+
+def tf_batch_neighbors(queries, supports, q_batches, s_batches, radius, limit=None, exact_shape=True, grid=None):
     """BatchOrderedNeighbors: -> neighbors (Nq, width) i32 sorted by distance, padded with Ns  (tf_ops.py:165-168).
     limit=None: width = the largest neighbourhood, like the TF op (needs one host sync and, above 64, is unsupported);
     limit=L: the callers' crop big_neighborhood_filter (datasets/base.py:756-765) fused in; exact_shape also trims the width to
-    min(L, largest neighbourhood) as the reference's slicing would."""
+    min(L, largest neighbourhood) as the reference's slicing would ('defer': see trim_neighbor_widths); grid: a RadiusGrid of these supports."""
     _chk(queries, torch.float32, "queries", 2); _chk(supports, torch.float32, "supports", 2)
     _chk(q_batches, torch.int32, "q_batches", 1); _chk(s_batches, torch.int32, "s_batches", 1)
     nq, ns, b = queries.shape[0], supports.shape[0], q_batches.shape[0]
@@ -85,11 +100,19 @@ def tf_batch_neighbors(queries, supports, q_batches, s_batches, radius, limit=No
     out = torch.empty((nq, lim), dtype=torch.int32, device=dev)
     counts = torch.empty(nq, dtype=torch.int32, device=dev)
     mc = torch.empty(1, dtype=torch.int32, device=dev)
-    ws = _workspace("radius", L.cbl_radius_neighbors_workspace_bytes(_i(b), _i(ns)), dev)
     q_off, s_off = _offsets(q_batches), _offsets(s_batches)   # both alive until the launch is enqueued (two temporaries would share one block)
-    _lib.check(L.cbl_radius_neighbors(_i(b), _i(nq), _i(ns), _lib.ptr(queries), _lib.ptr(supports), _lib.ptr(q_off), _lib.ptr(s_off),
-                                      _f(radius), _i(lim), _lib.ptr(out), _lib.ptr(counts), _lib.ptr(mc), _lib.ptr(ws), ctypes.c_size_t(ws.numel()),
-                                      _lib.stream_of(queries)), "cbl_radius_neighbors")
+    if grid is not None:
+        if not grid.matches(supports, s_batches, radius):
+            raise ValueError("tf_batch_neighbors: the RadiusGrid belongs to other supports / batches / radius")
+        _lib.check(L.cbl_radius_neighbors_reuse(_i(b), _i(nq), _i(ns), _lib.ptr(queries), _lib.ptr(supports), _lib.ptr(q_off), _lib.ptr(s_off),
+                                                _f(radius), _i(lim), _lib.ptr(out), _lib.ptr(counts), _lib.ptr(mc), _lib.ptr(grid.ws),
+                                                ctypes.c_size_t(grid.ws.numel()), _i(1 if grid.built else 0), _lib.stream_of(queries)), "cbl_radius_neighbors_reuse")
+        grid.built = grid.built or nq > 0
+    else:
+        ws = _workspace("radius", L.cbl_radius_neighbors_workspace_bytes(_i(b), _i(ns)), dev)
+        _lib.check(L.cbl_radius_neighbors(_i(b), _i(nq), _i(ns), _lib.ptr(queries), _lib.ptr(supports), _lib.ptr(q_off), _lib.ptr(s_off),
+                                          _f(radius), _i(lim), _lib.ptr(out), _lib.ptr(counts), _lib.ptr(mc), _lib.ptr(ws), ctypes.c_size_t(ws.numel()),
+                                          _lib.stream_of(queries)), "cbl_radius_neighbors")
     if exact_shape == "defer":
         return out, mc                         # the caller trims (trim_neighbor_widths): many searches, one host sync
     if limit is None or exact_shape:
@@ -149,18 +172,22 @@ def segmentation_inputs_radius(stacked_points, stacks_lengths, first_subsampling
     # widths of the 13 neighbour tables are read back together at the end; a layer's self-search is enqueued BEFORE its sub-sampling's sync, so
     # the device has work while the host waits for the count.  (A sync per search left the device idle 2 of the pyramid's 3.6 ms at N = 200 000.)
     pending = []                                                             # (key, table, largest neighbourhood) in the reference's order
+    # every layer's points are the supports of two or three searches at ONE radius (their own neighbourhoods, the pooling, the previous layer's
+    # upsampling): 13 searches over 5 distinct grids, each built once
+    grid = RadiusGrid(pts, lens, r)
     for dt in range(num_layers - 1):                                         # :795-812
         lim = int(neighborhood_limits[dt])
-        pending.append(("neighbors", tf_batch_neighbors(pts, pts, lens, lens, r, lim, exact_shape="defer")))
+        pending.append(("neighbors", tf_batch_neighbors(pts, pts, lens, lens, r, lim, exact_shape="defer", grid=grid)))
         pool_pts, pool_lens = tf_batch_subsampling(pts, lens, 2 * dl)
         pool_pts = pool_pts.contiguous()
-        pending.append(("pools", tf_batch_neighbors(pool_pts, pts, pool_lens, lens, r, lim, exact_shape="defer")))
-        pending.append(("upsamples", tf_batch_neighbors(pts, pool_pts, lens, pool_lens, 2 * r, lim, exact_shape="defer")))
+        pending.append(("pools", tf_batch_neighbors(pool_pts, pts, pool_lens, lens, r, lim, exact_shape="defer", grid=grid)))
+        grid = RadiusGrid(pool_pts, pool_lens, 2 * r)
+        pending.append(("upsamples", tf_batch_neighbors(pts, pool_pts, lens, pool_lens, 2 * r, lim, exact_shape="defer", grid=grid)))
         out["points"].append(pts); out["batches_len"].append(lens)
         pts, lens = pool_pts, pool_lens
         r *= 2; dl *= 2
     out["points"].append(pts)                                                # :815-820
-    pending.append(("neighbors", tf_batch_neighbors(pts, pts, lens, lens, r, int(neighborhood_limits[num_layers - 1]), exact_shape="defer")))
+    pending.append(("neighbors", tf_batch_neighbors(pts, pts, lens, lens, r, int(neighborhood_limits[num_layers - 1]), exact_shape="defer", grid=grid)))
     for (key, _), table in zip(pending, trim_neighbor_widths([p for _, p in pending])):
         out[key].append(table)
     out["pools"].append(torch.zeros((0, 1), dtype=torch.int32, device=pts.device))

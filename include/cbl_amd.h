@@ -540,6 +540,13 @@ int cbl_grid_subsampling(int b, int n, const float* points, const int* offset, f
 size_t cbl_radius_neighbors_workspace_bytes(int b, int ns);
 int cbl_radius_neighbors(int b, int nq, int ns, const float* queries, const float* supports, const int* q_offset, const int* s_offset,
                          float radius, int limit, int* out, int* counts, int* max_count, void* workspace, size_t workspace_bytes, void* stream);
+/* the same search when `workspace` still holds the grid an earlier cbl_radius_neighbors / _reuse call on this stream built for the SAME supports,
+ * s_offset and radius (grid_is_built != 0: the 5-launch grid build is skipped; 0: as cbl_radius_neighbors).  The pyramid builder
+ * (tensorflow/datasets/base.py:795-812) searches every layer's points two or three times with one radius: 13 searches, 5 distinct grids.
+ * A call with nq = 0 builds nothing. */
+int cbl_radius_neighbors_reuse(int b, int nq, int ns, const float* queries, const float* supports, const int* q_offset, const int* s_offset,
+                               float radius, int limit, int* out, int* counts, int* max_count, void* workspace, size_t workspace_bytes,
+                               int grid_is_built, void* stream);
 
 /* N4  cpp_knn_batch_omp  tensorflow/ops/nearest_neighbors/knn_.cxx:104-135: dense batch (B,N,3) x (B,M,3) -> (B,M,K) int64 LOCAL indices.
  *     = cbl_knnquery on the flattened batch (offset = N, 2N, ...) followed by this conversion of the global int32 rows. */

@@ -84,6 +84,30 @@ def test_pyramid_builder_c5_shape():
         p, l, r, dl = pp, pl, r * 2, dl * 2
 
 
+def test_radius_grid_is_built_once_and_reused():
+    """RadiusGrid: one support set searched three times at one radius (different query sets, different limits) with a single grid build — the tables of
+    the plain calls; a grid of other supports / another radius is refused"""
+    from contrastboundary_amd import tf_ops
+    xyz, _ = S.s_room(24000, seed=11, scale=1.4)
+    lens = np.int32([10000, 14000])
+    s_d, l_d = dev(xyz), dev(lens)
+    sub, sub_l = tf_ops.tf_batch_subsampling(s_d, l_d, 0.08)
+    sub = sub.contiguous()
+    g = tf_ops.RadiusGrid(s_d, l_d, 0.1)
+    assert not g.built
+    for q, ql, lim in ((s_d, l_d, 26), (sub, sub_l, 31), (s_d, l_d, 12)):
+        got = tf_ops.tf_batch_neighbors(q, s_d, ql, l_d, 0.1, lim, exact_shape=False, grid=g)
+        assert g.built
+        want = tf_ops.tf_batch_neighbors(q, s_d, ql, l_d, 0.1, lim, exact_shape=False)
+        np.testing.assert_array_equal(got.cpu().numpy(), want.cpu().numpy())
+    ref, _, _ = O.radius_neighbors(sub.cpu().numpy(), xyz, sub_l.cpu().numpy(), lens, 0.1, 31)
+    np.testing.assert_array_equal(tf_ops.tf_batch_neighbors(sub, s_d, sub_l, l_d, 0.1, 31, exact_shape=False, grid=g).cpu().numpy(), ref)
+    with pytest.raises(ValueError):
+        tf_ops.tf_batch_neighbors(s_d, s_d, l_d, l_d, 0.2, 26, grid=g)
+    with pytest.raises(ValueError):
+        tf_ops.tf_batch_neighbors(s_d, sub, l_d, sub_l, 0.1, 26, grid=g)
+
+
 def test_c5_full_size_properties():
     """N = 200000 (BASELINE config C5): radius rows sorted & within radius, counts consistent, grid subsampling idempotent"""
     from contrastboundary_amd import tf_ops
