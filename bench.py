@@ -552,6 +552,11 @@ def run_convnet(args, D, world, rank, local):
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb(ab, us_aw) / HBM_PEAK_GBS, "bytes_per_launch": ab, "launch_us": round(us_aw, 2),
                                     "gathered_bytes_per_launch": 4 * sizes[0] * k0 * c0,
                                     "gathered_GBps": gb(4 * sizes[0] * k0 * c0, us_aw),
+                                    "flops_per_launch": CP.adaptive_weight_flops(sizes[0], k0, c0),
+                                    "achieved_TFLOPs": CP.adaptive_weight_flops(sizes[0], k0, c0) / (us_aw * 1e-6) / 1e12,
+                                    "frac_of_f32_vector_peak": CP.adaptive_weight_flops(sizes[0], k0, c0) / (us_aw * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                    "measured_bound": "VALU issue slots, not memory (profiles/r03_aw_lane_width_sweep.md: more rows in flight per lane made it slower; "
+                                                      "instruction count x 4 clk / SIMD accounts for the time)",
                                     "note": "SURVEY 8(d) a14 bytes 12n + 12n0 + 4 n0 C + 4 n K + 4 n C; gathered = the n K C floats the kernel pulls through L2"},
                 "stage_ms": {names[i]: round(stage_ms[i], 4) for i in range(len(names))},
                 "stage_sum_ms": round(float(sum(stage_ms)), 4),

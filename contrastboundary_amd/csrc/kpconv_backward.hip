@@ -197,15 +197,18 @@ unsigned kb_grid(int n0)
 }
 
 // persistent waves: exactly as many workgroups as are resident at once (a few more would run as a second, mostly idle round)
-template <class F> unsigned kb_resident(F kernel, int& cache)
+constexpr int KB_MAX_DEVICES = 16;
+template <class F> unsigned kb_resident(F kernel, int (&cache)[KB_MAX_DEVICES])
 {
-    if (!cache) {
-        int per_cu = 0, dev = 0, cus = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= KB_MAX_DEVICES) dev = 0;       // one process per GPU: normally device 0 of its visible set
+    if (!cache[dev]) {
+        int per_cu = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kernel), KB_NB, 0) != hipSuccess || per_cu <= 0) per_cu = 3;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        cache = per_cu * cus;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cache[dev] = per_cu * cus;
     }
-    return (unsigned)cache;
+    return (unsigned)cache[dev];
 }
 
 }  // namespace
@@ -232,7 +235,7 @@ CBL_EXPORT int cbl_kpconv_backward_csr(int n, int n0, int K, int C, int KP, cons
     float* partial = reinterpret_cast<float*>(workspace);
     if (grad_kernel_weights && (!partial || workspace_bytes < cbl_kpconv_backward_csr_workspace_bytes(n0, C, KP))) return CBL_ERR_WORKSPACE;
     const CblFastDiv dv = cbl_fastdiv_make((unsigned)K);
-    static int resident[2][2][2] = {};
+    static int resident[2][2][2][KB_MAX_DEVICES] = {};
 #define CBL_KB(GF_, GKW_, CL_) { const unsigned res = cbl_round_up8(kb_resident(&kpconv_bwd_csr_kernel<GF_, GKW_, CL_>, resident[GF_][GKW_][CL_])); if (g > res) g = res;  \
         hipLaunchKernelGGL((kpconv_bwd_csr_kernel<GF_, GKW_, CL_>), dim3(g), dim3(KB_NB), 0, st, (unsigned)n0, C, KP, dv, query_points, support_points, \
         features, kernel_points, kernel_weights, extent, influence, grad_out, order_dst, inv_start, inv_src, grad_features, partial); }

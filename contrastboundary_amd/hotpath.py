@@ -458,7 +458,7 @@ class Pipeline:
         for slot in range(self.SLOTS):
             for graphed in (False, True):                           # once eagerly (workspaces of the streams, code objects), then captured
                 state = {}
-                with pointops.neighbor_cache() as nc, neighbor_state.streams_ordered_by_caller():
+                with pointops.neighbor_cache() as nc, neighbor_state.streams_ordered_by_caller(self.streams.values()):
                     nc.record_events = False
                     for xyz, nsample, algo in self.sched.hints:
                         nc.hint(xyz, nsample, algo)

@@ -89,18 +89,31 @@ def _order_alias(idx, points):
 
 
 class streams_ordered_by_caller:
-    """inside: lookups of processing orders and transposed tables hand out what they have without ordering the current stream behind the stream
-    that produced it — for callers that sequence their streams themselves (hotpath.Pipeline captures every chain of a step as a hipGraph of its
-    own; a wait on another stream's live event has no place inside such a capture).  Module-wide, not thread-local: autograd's thread must see it."""
-    active = 0
+    """inside: lookups of processing orders and transposed tables made ON THE GIVEN STREAMS hand out what they have without ordering the current stream
+    behind the stream that produced it — for callers that sequence those streams themselves (hotpath.Pipeline captures every chain of a step as a
+    hipGraph of its own; a wait on another stream's live event has no place inside such a capture).  Scoped by stream handle, not by thread: autograd's
+    thread runs a backward op on the stream of its forward op and must see the same answer, while other threads' work on other streams (a prefetch, a
+    second trainer) keeps its wait_stream / record_stream."""
+    _streams = collections.Counter()                                # cuda_stream handle -> nesting depth
+
+    def __init__(self, streams):
+        self.handles = [s.cuda_stream for s in streams]
 
     def __enter__(self):
-        streams_ordered_by_caller.active += 1
+        for h in self.handles:
+            streams_ordered_by_caller._streams[h] += 1
         return self
 
     def __exit__(self, *exc):
-        streams_ordered_by_caller.active -= 1
+        for h in self.handles:
+            streams_ordered_by_caller._streams[h] -= 1
+            if streams_ordered_by_caller._streams[h] <= 0:
+                del streams_ordered_by_caller._streams[h]
         return False
+
+    @staticmethod
+    def applies(stream):
+        return stream.cuda_stream in streams_ordered_by_caller._streams
 
 
 def spatial_order(points):
@@ -116,7 +129,7 @@ def spatial_order(points):
     if hit is not None:
         return hit[0]
     order, producer = next(iter(ent.values()))                   # produced on another stream: order after it, keep it alive for this one
-    if streams_ordered_by_caller.active:
+    if streams_ordered_by_caller.applies(cur):
         return order
     cur.wait_stream(producer)
     order.record_stream(cur)
@@ -145,7 +158,7 @@ def transpose_lookup(idx):
         return None
     _, order, inv_start, inv_src, producer, waited = ent[:6]
     cur = torch.cuda.current_stream(idx.device)
-    if producer != cur and cur.cuda_stream not in waited and not streams_ordered_by_caller.active:   # built on another stream: order after it ONCE, keep the tensors alive for this one
+    if producer != cur and cur.cuda_stream not in waited and not streams_ordered_by_caller.applies(cur):   # built on another stream: order after it ONCE, keep the tensors alive for this one
         cur.wait_stream(producer)
         for t in (inv_start, inv_src) + (() if order is None else (order,)):
             t.record_stream(cur)
