@@ -18,12 +18,13 @@ namespace {
 
 enum { PE_ONE = 0, PE_XYZ, PE_DISTANCE, PE_EXP_D, PE_DIR_EXP_D, PE_DIR_D, PE_SIN_COS, PE_TWO_ORDER, PE_THREE_ORDER, PE_COUNT };
 enum { RED_SUM = 0, RED_MEAN = 1, RED_MAX = 2 };
-enum { G_ONE = 0, G_MONO, G_DIST, G_EXPD, G_DIR, G_SIN, G_COS };
+enum { G_ONE = 0, G_MONO, G_DIST, G_EXPD, G_DIR, G_SIN };
 
 struct LaneGeo {            // what this lane's channel multiplies its feature with
     int kind;
     int ex, ey, ez;         // G_MONO: exponents of the normalised offset (x^ex y^ey z^ez); G_DIR / G_SIN / G_COS: ex = axis
     float dm;               // G_SIN / G_COS: wavelength divisor
+    float ph;               // G_SIN: phase in turns (0.25 = the cosine: cos x = sin(x + pi/2), one code path for both halves of the embedding)
 };
 
 // `mid` of (embedding, C) as in :75-226; 0 if the reference's reshape (:229) cannot work for this C
@@ -45,7 +46,7 @@ __device__ inline LaneGeo decode_geo(int pe, int C, int c)
     // exponent triples of [x y z xy xz yz xx yy zz | xxx yyy zzz xxy xxz yyx yyz zzx zzy]  (:146-205)
     const unsigned char mono[18][3] = {{1,0,0},{0,1,0},{0,0,1},{1,1,0},{1,0,1},{0,1,1},{2,0,0},{0,2,0},{0,0,2},
                                        {3,0,0},{0,3,0},{0,0,3},{2,1,0},{2,0,1},{1,2,0},{0,2,1},{1,0,2},{0,1,2}};
-    LaneGeo g{G_ONE, 0, 0, 0, 1.f};
+    LaneGeo g{G_ONE, 0, 0, 0, 1.f, 0.f};
     const int mid = pospool_mid(pe, C);
     if (mid <= 0 || c >= C) return g;
     const int j = c / (C / mid);                                    // feature_map reshape [mid, shared] (:229)
@@ -61,11 +62,11 @@ __device__ inline LaneGeo decode_geo(int pe, int C, int c)
         break; }
     case PE_SIN_COS:
         if (C == 9) {                                               // [sin cos](x), (y), (z), then the offset itself (:120-134)
-            if (c < 6) { g.kind = (c & 1) ? G_COS : G_SIN; g.ex = c >> 1; g.dm = 1.f; }
+            if (c < 6) { g.kind = G_SIN; g.ph = (c & 1) ? 0.25f : 0.f; g.ex = c >> 1; g.dm = 1.f; }
             else { g.kind = G_MONO; g.ex = mono[c - 6][0]; g.ey = mono[c - 6][1]; g.ez = mono[c - 6][2]; }
         } else {                                                    // [3, 2*feat_dim] row-major (:135-147)
             const int fd = C / 6, a = c / (2 * fd), r = c % (2 * fd), i = r < fd ? r : r - fd;
-            g.kind = r < fd ? G_SIN : G_COS; g.ex = a;
+            g.kind = G_SIN; g.ph = r < fd ? 0.f : 0.25f; g.ex = a;
             g.dm = powf(1000.f, (1.0f / (float)fd) * (float)i);     // tf.pow(1.0 * wave_length, (1.0 / feat_dim) * feat_range)
         }
         break;
@@ -84,8 +85,9 @@ __device__ __forceinline__ float eval_geo(const LaneGeo& g, float rx, float ry, 
     case G_EXPD: return expf(-1.0f * sqrtf((rx * rx + ry * ry) + rz * rz));                    // :90, :99
     case G_DIR: { const float d = sqrtf((rx * rx + ry * ry) + rz * rz);                         // :73
                   return (g.ex == 0 ? rx : g.ex == 1 ? ry : rz) / (d + 1e-6f); }
-    case G_SIN: return sinf((100.f * (g.ex == 0 ? rx : g.ex == 1 ? ry : rz)) / g.dm);           // alpha = 100 (:124,:138)
-    case G_COS: return cosf((100.f * (g.ex == 0 ? rx : g.ex == 1 ? ry : rz)) / g.dm);
+    // alpha = 100 (:124,:138).  v_sin_f32 on the argument in turns, reduced by v_fract: the argument reaches 100 rad, where one fp32 ulp of it is
+    // already 8e-6 rad — the library sinf / cosf (a ~50-instruction path per channel and neighbour) buys nothing beyond that
+    case G_SIN: return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(((100.f * (g.ex == 0 ? rx : g.ex == 1 ? ry : rz)) / g.dm) * 0.15915494309189535f + g.ph));
     }
     return 1.f;
 }
@@ -164,40 +166,77 @@ __global__ __launch_bounds__(256) void pospool_kernel(int n, int n0, int K, int 
     }
 }
 
-// Forward for sum / mean, C % 4 == 0: lane = 4 consecutive channels of one point, U neighbours in flight (see adaptive_weight_fwd_v4)
-template <int U>
-__global__ __launch_bounds__(256) void pospool_fwd_v4(int n, int n0, int K, int C4, const float* __restrict__ q, const float* __restrict__ s,
+// Forward for sum / mean, C % 4 == 0: lane = 4 consecutive channels of one point, L = C/4 lanes per point (a chunk of at most 256 columns), 256 / L points per
+// trip, trips dealt to the XCDs in contiguous eighths — as adaptive_weight_fwd_v4.  A lane's four embedding descriptors are decoded ONCE (round 2 decoded them
+// per work item of a grid-stride loop: four powf per item for 'sin_cos'); ids one batch ahead of the rows.
+// SINCOS (the shipped 'sin_cos' embedding with C % 12 == 0, so that a lane's four channels share their axis): value = sin(2 pi (v_axis * scale_c + phase_c))
+// with scale_c = 100 / (dm_c 2 pi), one multiply-add, v_fract and v_sin_f32 per (neighbour, channel); offsets by one reciprocal of the radius.
+struct SinCosLane { int axis; float sc[4], ph[4]; };
+__device__ inline SinCosLane sincos_lane(int C, int cq)
+{
+    SinCosLane t;
+    const LaneGeo g0 = decode_geo(PE_SIN_COS, C, 4 * cq);
+    t.axis = g0.ex;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const LaneGeo g = decode_geo(PE_SIN_COS, C, 4 * cq + j); t.sc[j] = (100.f / g.dm) * 0.15915494309189535f; t.ph[j] = g.ph; }
+    return t;
+}
+__device__ __forceinline__ float sin_turns(float t) { return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(t)); }
+
+template <int U, bool SINCOS>
+__global__ __launch_bounds__(256) void pospool_fwd_v4(unsigned n, int n0, int K, int C4, int c4_0, int L, const float* __restrict__ q, const float* __restrict__ s,
                                                       const int* __restrict__ idx, const float4* __restrict__ f, float radius, int pe, int reduction,
                                                       const int* __restrict__ padding_num, float4* __restrict__ out)
 {
     const int pad = (reduction == RED_MEAN) ? *padding_num : 0;
     const int C = 4 * C4;
-    const long long total = (long long)n * C4;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const int p = (int)(e / C4), cq = (int)(e - (long long)p * C4);
-        const LaneGeo g0 = decode_geo(pe, C, 4 * cq), g1 = decode_geo(pe, C, 4 * cq + 1), g2 = decode_geo(pe, C, 4 * cq + 2), g3 = decode_geo(pe, C, 4 * cq + 3);
-        const float qx = q[3 * p], qy = q[3 * p + 1], qz = q[3 * p + 2];
+    const int tpb = 256 / L;
+    const int ts = threadIdx.x / L, cl = threadIdx.x - ts * L;
+    if (ts >= tpb) return;
+    const int cq = c4_0 + cl;
+    const LaneGeo g0 = decode_geo(pe, C, 4 * cq), g1 = decode_geo(pe, C, 4 * cq + 1), g2 = decode_geo(pe, C, 4 * cq + 2), g3 = decode_geo(pe, C, 4 * cq + 3);
+    SinCosLane sl = {};
+    if (SINCOS) sl = sincos_lane(C, cq);
+    const float inv_radius = 1.0f / radius;
+    const unsigned ntrips = (n + tpb - 1) / tpb;
+    const unsigned vend = 8 * cbl_xcd_per(ntrips);
+    for (unsigned v = blockIdx.x; v < vend; v += gridDim.x) {
+        const unsigned p = cbl_xcd_slot(v, ntrips) * tpb + ts;
+        if (p >= n) continue;
+        const float qx = q[3 * (size_t)p], qy = q[3 * (size_t)p + 1], qz = q[3 * (size_t)p + 2];
         const int* __restrict__ row = idx + (size_t)p * K;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         int cnt = 0;
+        int idn[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int v_ = row[min(u, K - 1)]; idn[u] = (u < K) ? v_ : n0; }
         for (int k0 = 0; k0 < K; k0 += U) {
             int id[U]; float rx[U], ry[U], rz[U]; float4 fk[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                id[u] = (k0 + u < K) ? row[k0 + u] : n0;
+                id[u] = idn[u];
                 cnt += (k0 + u < K && id[u] < pad) ? 1 : 0;
             }
+#pragma unroll
+            for (int u = 0; u < U; u++) { const int v_ = row[min(k0 + U + u, K - 1)]; idn[u] = (k0 + U + u < K) ? v_ : n0; }
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const bool real = id[u] >= 0 && id[u] < n0;
                 const int ic = real ? id[u] : 0;
                 fk[u] = f[(size_t)ic * C4 + cq];
-                rx[u] = s[3 * ic]; ry[u] = s[3 * ic + 1]; rz[u] = s[3 * ic + 2];
+                rx[u] = s[3 * (size_t)ic]; ry[u] = s[3 * (size_t)ic + 1]; rz[u] = s[3 * (size_t)ic + 2];
                 if (!real) id[u] = -1;
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                if (id[u] >= 0) {                                     // shadow neighbours: zero feature row, contribute nothing
+                if (id[u] < 0) continue;                              // shadow neighbours: zero feature row, contribute nothing
+                if (SINCOS) {
+                    const float vax = ((sl.axis == 0 ? rx[u] - qx : sl.axis == 1 ? ry[u] - qy : rz[u] - qz)) * inv_radius;
+                    acc.x = fmaf(sin_turns(fmaf(vax, sl.sc[0], sl.ph[0])), fk[u].x, acc.x);
+                    acc.y = fmaf(sin_turns(fmaf(vax, sl.sc[1], sl.ph[1])), fk[u].y, acc.y);
+                    acc.z = fmaf(sin_turns(fmaf(vax, sl.sc[2], sl.ph[2])), fk[u].z, acc.z);
+                    acc.w = fmaf(sin_turns(fmaf(vax, sl.sc[3], sl.ph[3])), fk[u].w, acc.w);
+                } else {
                     const float x = (rx[u] - qx) / radius, y = (ry[u] - qy) / radius, z = (rz[u] - qz) / radius;    // :68-70
                     acc.x += eval_geo(g0, x, y, z) * fk[u].x;         // :230-235
                     acc.y += eval_geo(g1, x, y, z) * fk[u].y;
@@ -228,6 +267,7 @@ __global__ __launch_bounds__(256) void pospool_inv_count_kernel(int n, int K, co
     }
 }
 
+template <bool SINCOS>
 __global__ __launch_bounds__(256) void pospool_bwd_csr_kernel(unsigned n0, int C4, int c4_0, int L, CblFastDiv dvK, const float* __restrict__ q,
                                                               const float* __restrict__ s, float radius, int pe, const float* __restrict__ inv_nn,
                                                               const float4* __restrict__ go, const int* __restrict__ order,
@@ -238,6 +278,9 @@ __global__ __launch_bounds__(256) void pospool_bwd_csr_kernel(unsigned n0, int C
     if (ts >= tpb) return;
     const int cq = c4_0 + cl, C = 4 * C4;
     const LaneGeo g0 = decode_geo(pe, C, 4 * cq), g1 = decode_geo(pe, C, 4 * cq + 1), g2 = decode_geo(pe, C, 4 * cq + 2), g3 = decode_geo(pe, C, 4 * cq + 3);
+    SinCosLane sl = {};
+    if (SINCOS) sl = sincos_lane(C, cq);
+    const float inv_radius = 1.0f / radius;
     const unsigned ntrips = (n0 + tpb - 1) / tpb;
     const unsigned vend = 8 * cbl_xcd_per(ntrips);
     for (unsigned v = blockIdx.x; v < vend; v += gridDim.x) {
@@ -260,6 +303,14 @@ __global__ __launch_bounds__(256) void pospool_bwd_csr_kernel(unsigned n0, int C
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
+                if (SINCOS) {
+                    const float vax = ((sl.axis == 0 ? sx - rx[u] : sl.axis == 1 ? sy - ry[u] : sz - rz[u])) * inv_radius;
+                    acc.x = fmaf(g[u].x * sc[u], sin_turns(fmaf(vax, sl.sc[0], sl.ph[0])), acc.x);
+                    acc.y = fmaf(g[u].y * sc[u], sin_turns(fmaf(vax, sl.sc[1], sl.ph[1])), acc.y);
+                    acc.z = fmaf(g[u].z * sc[u], sin_turns(fmaf(vax, sl.sc[2], sl.ph[2])), acc.z);
+                    acc.w = fmaf(g[u].w * sc[u], sin_turns(fmaf(vax, sl.sc[3], sl.ph[3])), acc.w);
+                    continue;
+                }
                 const float x = (sx - rx[u]) / radius, y = (sy - ry[u]) / radius, z = (sz - rz[u]) / radius;      // :68-70
                 acc.x += (g[u].x * sc[u]) * eval_geo(g0, x, y, z);
                 acc.y += (g[u].y * sc[u]) * eval_geo(g1, x, y, z);
@@ -292,10 +343,18 @@ CBL_EXPORT int cbl_pospool_forward(int n, int n0, int K, int C, const float* que
     if (n == 0) return CBL_OK;
     if (!query_points || !support_points || !neighbors_indices || !features || !out || (reduction == RED_MEAN && !padding_num)) return CBL_ERR_BAD_ARG;
     const bool vec = reduction != RED_MAX && (C % 4 == 0) && ((((uintptr_t)features | (uintptr_t)out) & 15) == 0);
-    if (vec)
-        hipLaunchKernelGGL(pospool_fwd_v4<4>, dim3(cbl_grid_for((long long)n * (C / 4), 256)), dim3(256), 0, cbl_stream(stream), n, n0, K, C / 4, query_points,
-                           support_points, neighbors_indices, reinterpret_cast<const float4*>(features), radius, position_embedding, reduction, padding_num,
-                           reinterpret_cast<float4*>(out));
+    if (vec) {
+        const int C4 = C / 4, chunks = (C4 + 255) / 256, Lmax = (C4 + chunks - 1) / chunks;
+        for (int c4_0 = 0; c4_0 < C4; c4_0 += Lmax) {
+            const int L = min(Lmax, C4 - c4_0);
+            unsigned g = cbl_round_up8(cbl_div_up(n, 256 / L)); if (g > 8192u) g = 8192u;
+#define CBL_PPF(SC_) hipLaunchKernelGGL((pospool_fwd_v4<2, SC_>), dim3(g), dim3(256), 0, cbl_stream(stream), (unsigned)n, n0, K, C4, c4_0, L, query_points, support_points, \
+                               neighbors_indices, reinterpret_cast<const float4*>(features), radius, position_embedding, reduction, padding_num, \
+                               reinterpret_cast<float4*>(out))
+            if (position_embedding == PE_SIN_COS && C % 12 == 0) CBL_PPF(true); else CBL_PPF(false);
+#undef CBL_PPF
+        }
+    }
     else
         hipLaunchKernelGGL(pospool_kernel<false>, dim3(pp_grid(n)), dim3(256), 0, cbl_stream(stream), n, n0, K, C, query_points, support_points,
                            neighbors_indices, features, radius, position_embedding, reduction, padding_num, out, nullptr, nullptr);
@@ -340,9 +399,11 @@ CBL_EXPORT int cbl_pospool_backward_csr(int n, int n0, int K, int C, const float
     for (int c4_0 = 0; c4_0 < C4; c4_0 += Lmax) {
         const int L = min(Lmax, C4 - c4_0);
         unsigned g = cbl_round_up8(cbl_div_up(n0, 256 / L)); if (g > 2048u) g = 2048u;
-        hipLaunchKernelGGL(pospool_bwd_csr_kernel, dim3(g), dim3(256), 0, st, (unsigned)n0, C4, c4_0, L, dv, query_points, support_points, radius,
-                           position_embedding, inv_nn, reinterpret_cast<const float4*>(grad_out), order_dst, inv_start, inv_src,
-                           reinterpret_cast<float4*>(grad_features));
+#define CBL_PPB(SC_) hipLaunchKernelGGL(pospool_bwd_csr_kernel<SC_>, dim3(g), dim3(256), 0, st, (unsigned)n0, C4, c4_0, L, dv, query_points, support_points, radius, \
+                           position_embedding, inv_nn, reinterpret_cast<const float4*>(grad_out), order_dst, inv_start, inv_src, \
+                           reinterpret_cast<float4*>(grad_features))
+        if (position_embedding == PE_SIN_COS && C % 12 == 0) CBL_PPB(true); else CBL_PPB(false);
+#undef CBL_PPB
     }
     return cbl_status();
 }
