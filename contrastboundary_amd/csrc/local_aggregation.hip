@@ -794,6 +794,72 @@ __global__ __launch_bounds__(256) void ind_max_pool_kernel(int n1, int n2, int k
         out[e] = m;
     }
 }
+// column minima for d % 4 == 0 with every lane busy (the kernel above leaves 184 of 256 lanes idle at d = 72): lane = 4 columns, 256 / L rows per step,
+// running minima in registers, the row slots of a workgroup folded in LDS, four atomicMin per lane of slot 0
+__global__ __launch_bounds__(256) void column_min_v4_kernel(unsigned n, int D4, int c4_0, int L, const float4* __restrict__ x, unsigned* __restrict__ keymin)
+{
+    __shared__ float4 red[256];
+    const int tpb = 256 / L;
+    const int ts = threadIdx.x / L, cl = threadIdx.x - ts * L;
+    const bool on = ts < tpb;
+    const int cq = c4_0 + cl;
+    float4 m = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+    if (on)
+        for (unsigned r = blockIdx.x * tpb + ts; r < n; r += gridDim.x * tpb) {
+            const float4 v = x[(size_t)r * D4 + cq];
+            m.x = fminf(m.x, v.x); m.y = fminf(m.y, v.y); m.z = fminf(m.z, v.z); m.w = fminf(m.w, v.w);
+        }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    if (threadIdx.x < L) {
+        for (int t = 1; t < tpb; t++) { const float4 o = red[t * L + threadIdx.x]; m.x = fminf(m.x, o.x); m.y = fminf(m.y, o.y); m.z = fminf(m.z, o.z); m.w = fminf(m.w, o.w); }
+        const float mv[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const unsigned u = __float_as_uint(mv[j]); atomicMin(keymin + 4 * cq + j, (u & 0x80000000u) ? ~u : (u | 0x80000000u)); }
+    }
+}
+
+// d % 4 == 0: lane = 4 channels of one pooled row, L = d/4 lanes per row (a chunk of at most 256 columns), 256 / L rows per trip dealt to the XCDs in contiguous
+// eighths, U rows in flight with their ids one batch ahead (the kernel above: one channel per lane, a 64-bit division per element, one row in flight)
+template <int U>
+__global__ __launch_bounds__(256) void ind_max_pool_v4_kernel(unsigned n2, int n1, int k, int D4, int c4_0, int L, const float4* __restrict__ x,
+                                                              const int* __restrict__ inds, const unsigned* __restrict__ keymin, float4* __restrict__ out)
+{
+    const int tpb = 256 / L;
+    const int ts = threadIdx.x / L, cl = threadIdx.x - ts * L;
+    if (ts >= tpb) return;
+    const int cq = c4_0 + cl;
+    float sh[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const unsigned key = keymin[4 * cq + j]; sh[j] = __uint_as_float((key & 0x80000000u) ? (key & 0x7fffffffu) : ~key); }
+    const unsigned ntrips = (n2 + tpb - 1) / tpb;
+    const unsigned vend = 8 * cbl_xcd_per(ntrips);
+    for (unsigned v = blockIdx.x; v < vend; v += gridDim.x) {
+        const unsigned r = cbl_xcd_slot(v, ntrips) * tpb + ts;
+        if (r >= n2) continue;
+        const int* __restrict__ row = inds + (size_t)r * k;
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        int idn[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) idn[u] = row[min(u, k - 1)];
+        for (int k0 = 0; k0 < k; k0 += U) {
+            int id[U]; float4 xr[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) id[u] = idn[u];
+#pragma unroll
+            for (int u = 0; u < U; u++) idn[u] = row[min(k0 + U + u, k - 1)];        // past the row: the last entry again (max is idempotent)
+#pragma unroll
+            for (int u = 0; u < U; u++) { const bool real = id[u] >= 0 && id[u] < n1; xr[u] = x[(size_t)(real ? id[u] : 0) * D4 + cq]; }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const bool real = id[u] >= 0 && id[u] < n1;
+                m.x = fmaxf(m.x, real ? xr[u].x : sh[0]); m.y = fmaxf(m.y, real ? xr[u].y : sh[1]);
+                m.z = fmaxf(m.z, real ? xr[u].z : sh[2]); m.w = fmaxf(m.w, real ? xr[u].w : sh[3]);
+            }
+        }
+        out[(size_t)r * D4 + cq] = m;
+    }
+}
 __global__ __launch_bounds__(256) void ind_closest_pool_kernel(int n1, int n2, int k, int d, const float* __restrict__ x, const int* __restrict__ inds,
                                                                float* __restrict__ out)
 {
@@ -1037,8 +1103,22 @@ CBL_EXPORT int cbl_ind_max_pool(int n1, int n2, int k, int d, const float* x, co
     if (!x || !inds || !scratch_d || !out) return CBL_ERR_BAD_ARG;
     hipStream_t st = cbl_stream(stream);
     hipLaunchKernelGGL(fill_u32_kernel, dim3(cbl_div_up(d, 256)), dim3(256), 0, st, d, 0xffffffffu, scratch_d);
-    hipLaunchKernelGGL(column_min_kernel, dim3(cbl_div_up(d, 256), (unsigned)min(n1, 512)), dim3(256), 0, st, n1, d, x, scratch_d);
-    hipLaunchKernelGGL(ind_max_pool_kernel, dim3(cbl_grid_for((long long)n2 * d, 256)), dim3(256), 0, st, n1, n2, k, d, x, inds, scratch_d, out);
+    const bool vec = d % 4 == 0 && ((((uintptr_t)x | (uintptr_t)out) & 15) == 0);
+    if (!vec) hipLaunchKernelGGL(column_min_kernel, dim3(cbl_div_up(d, 256), (unsigned)min(n1, 512)), dim3(256), 0, st, n1, d, x, scratch_d);
+    if (vec) {
+        const int D4 = d / 4, chunks = (D4 + 255) / 256, Lmax = (D4 + chunks - 1) / chunks;
+        for (int c4_0 = 0; c4_0 < D4 && n1 > 0; c4_0 += Lmax) {
+            const int L = min(Lmax, D4 - c4_0);
+            hipLaunchKernelGGL(column_min_v4_kernel, dim3(min(cbl_div_up(n1, 256 / L), 64)), dim3(256), 0, st, (unsigned)n1, D4, c4_0, L, reinterpret_cast<const float4*>(x), scratch_d);
+        }
+        for (int c4_0 = 0; c4_0 < D4; c4_0 += Lmax) {
+            const int L = min(Lmax, D4 - c4_0);
+            const unsigned g = min(cbl_round_up8(cbl_div_up(n2, 256 / L)), 8192u);
+            hipLaunchKernelGGL(ind_max_pool_v4_kernel<4>, dim3(g), dim3(256), 0, st, (unsigned)n2, n1, k, D4, c4_0, L, reinterpret_cast<const float4*>(x), inds, scratch_d,
+                               reinterpret_cast<float4*>(out));
+        }
+    }
+    else hipLaunchKernelGGL(ind_max_pool_kernel, dim3(cbl_grid_for((long long)n2 * d, 256)), dim3(256), 0, st, n1, n2, k, d, x, inds, scratch_d, out);
     return cbl_status();
 }
 

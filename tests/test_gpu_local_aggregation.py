@@ -148,12 +148,17 @@ def test_adaptive_weight_mean_quirk_without_padding():
     np.testing.assert_allclose(out.cpu().numpy(), LA.adaptive_weight(q, s, idx, f, 0.2, W, b, "mean"), rtol=1e-4, atol=1e-5)
 
 
-def test_index_pooling():
+@pytest.mark.parametrize("n1,n2,k,d", [(500, 200, 9, 37), (5000, 3000, 26, 72), (900, 400, 31, 1152), (700, 700, 5, 8), (3000, 1, 41, 144)])
+def test_index_pooling(n1, n2, k, d):
+    """ind_max_pool / ind_closest_pool (basic_operators.py:155-192), bit for bit: the one-channel-per-lane kernel (d = 37) and the float4 kernel with its
+    column chunks (d = 1152: two chunks of 144 lanes), rows that are all shadow, k not a multiple of the rows in flight"""
     from contrastboundary_amd import local_aggregation as L
-    rng = np.random.default_rng(0)
-    x = rng.normal(size=(500, 37)).astype(np.float32)
-    inds = rng.integers(0, 501, (200, 9)).astype(np.int32)          # 500 == shadow
-    inds[0, :] = 500
+    rng = np.random.default_rng(n1 + d)
+    x = rng.normal(size=(n1, d)).astype(np.float32)
+    inds = rng.integers(0, n1 + 1, (n2, k)).astype(np.int32)          # n1 == shadow
+    inds[0, :] = n1
+    if n2 > 3:
+        inds[3, 1:] = n1
     np.testing.assert_array_equal(L.ind_max_pool(dev(x), dev(inds)).cpu().numpy(), LA.ind_max_pool(x, inds))
     np.testing.assert_array_equal(L.ind_closest_pool(dev(x), dev(inds)).cpu().numpy(), LA.ind_closest_pool(x, inds))
 
