@@ -28,13 +28,30 @@ def _chk(t, dtype, name, dim):
     return t
 
 
+_offset_cache = {}                    # (data_ptr, version, n, stream) -> (lengths tensor kept alive: its address cannot be reused under the key, offsets)
+
+
 def _offsets(lengths):
-    return torch.cumsum(lengths, 0, dtype=torch.int32)
+    """cumulative offsets of per-cloud lengths; the pyramid builder asks for the same five length vectors thirty times per scene"""
+    key = (lengths.data_ptr(), lengths._version, lengths.shape[0], torch.cuda.current_stream(lengths.device).cuda_stream if lengths.is_cuda else 0)
+    hit = _offset_cache.get(key)
+    if hit is not None and hit[0] is lengths:
+        return hit[1]
+    off = torch.cumsum(lengths, 0, dtype=torch.int32)
+    if len(_offset_cache) >= 16:
+        _offset_cache.pop(next(iter(_offset_cache)))
+    _offset_cache[key] = (lengths, off)
+    return off
 
 
-def tf_batch_subsampling(points, batches_len, sampleDl, features=None, labels=None):
-    """BatchGridSubsampling: (points (N,3), batches_len (B,) i32, sampleDl) -> (sub_points (M,3), sub_batches_len (B,))  tf_ops.py:158-163.
-    With features (N,d) / labels (N,l) i32 also returns their per-voxel mean / majority (grid_subsampling.compute flavour)."""
+class _PendingSubsampling:
+    """a grid subsampling whose kernels are enqueued and whose output size is on its way to the host (pinned buffer + event)"""
+    __slots__ = ("out_p", "out_f", "out_l", "out_len", "total_host", "event", "keep")
+
+
+def tf_batch_subsampling_launch(points, batches_len, sampleDl, features=None, labels=None):
+    """first half of tf_batch_subsampling: enqueue the kernels and an asynchronous copy of the output size; work enqueued AFTER this call (that does not
+    need the result) keeps the device busy while tf_batch_subsampling_finish waits for the size only"""
     _chk(points, torch.float32, "points", 2); _chk(batches_len, torch.int32, "batches_len", 1)
     n, b = points.shape[0], batches_len.shape[0]
     L = _lib.lib()
@@ -43,22 +60,40 @@ def tf_batch_subsampling(points, batches_len, sampleDl, features=None, labels=No
     ldim = labels.shape[1] if labels is not None else 0
     if features is not None: _chk(features, torch.float32, "features", 2)
     if labels is not None: _chk(labels, torch.int32, "labels", 2)
-    out_p = torch.empty((n, 3), dtype=torch.float32, device=dev)
-    out_f = torch.empty((n, fdim), dtype=torch.float32, device=dev) if fdim else None
-    out_l = torch.empty((n, ldim), dtype=torch.int32, device=dev) if ldim else None
-    out_len = torch.empty(b, dtype=torch.int32, device=dev)
+    pend = _PendingSubsampling()
+    pend.out_p = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    pend.out_f = torch.empty((n, fdim), dtype=torch.float32, device=dev) if fdim else None
+    pend.out_l = torch.empty((n, ldim), dtype=torch.int32, device=dev) if ldim else None
+    pend.out_len = torch.empty(b, dtype=torch.int32, device=dev)
     total = torch.empty(1, dtype=torch.int32, device=dev)
     need = L.cbl_grid_subsampling_workspace_bytes(_i(b), _i(n))
     ws = _workspace("sub", need, dev)
     offset = _offsets(batches_len)            # keep alive across the call: its raw pointer is what travels through the C ABI
     _lib.check(L.cbl_grid_subsampling(_i(b), _i(n), _lib.ptr(points), _lib.ptr(offset), _f(sampleDl), _i(fdim), _lib.ptr(features),
-                                      _i(ldim), _lib.ptr(labels), _lib.ptr(out_p), _lib.ptr(out_f), _lib.ptr(out_l), _lib.ptr(out_len), _lib.ptr(total),
-                                      _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(points)), "cbl_grid_subsampling")
-    m = int(total.item())                     # data-dependent output size: one sync, like the TF op's dynamic shape
-    res = [out_p[:m], out_len]
-    if fdim: res.append(out_f[:m])
-    if ldim: res.append(out_l[:m])
+                                      _i(ldim), _lib.ptr(labels), _lib.ptr(pend.out_p), _lib.ptr(pend.out_f), _lib.ptr(pend.out_l), _lib.ptr(pend.out_len),
+                                      _lib.ptr(total), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(points)), "cbl_grid_subsampling")
+    pend.total_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+    pend.total_host.copy_(total, non_blocking=True)
+    pend.event = torch.cuda.Event()
+    pend.event.record()
+    pend.keep = (total, offset)
+    return pend
+
+
+def tf_batch_subsampling_finish(pend):
+    """second half: wait for the output size (data-dependent: one host wait, like the TF op's dynamic shape) and cut the outputs to it"""
+    pend.event.synchronize()
+    m = int(pend.total_host[0])
+    res = [pend.out_p[:m], pend.out_len]
+    if pend.out_f is not None: res.append(pend.out_f[:m])
+    if pend.out_l is not None: res.append(pend.out_l[:m])
     return tuple(res)
+
+
+def tf_batch_subsampling(points, batches_len, sampleDl, features=None, labels=None):
+    """BatchGridSubsampling: (points (N,3), batches_len (B,) i32, sampleDl) -> (sub_points (M,3), sub_batches_len (B,))  tf_ops.py:158-163.
+    With features (N,d) / labels (N,l) i32 also returns their per-voxel mean / majority (grid_subsampling.compute flavour)."""
+    return tf_batch_subsampling_finish(tf_batch_subsampling_launch(points, batches_len, sampleDl, features, labels))
 
 
 def grid_subsampling(points, features=None, labels=None, sampleDl=0.1, verbose=0):
@@ -168,17 +203,19 @@ def segmentation_inputs_radius(stacked_points, stacks_lengths, first_subsampling
     r = dl * float(density_parameter) / 2.0                                  # :784-786
     pts, lens = stacked_points, stacks_lengths
     out = {"points": [], "neighbors": [], "pools": [], "upsamples": [torch.zeros((0, 1), dtype=torch.int32, device=pts.device)], "batches_len": []}
-    # Host synchronisation: the sub-sampled point count of every layer is data dependent (one sync per layer, as the TF op's dynamic shape), the
-    # widths of the 13 neighbour tables are read back together at the end; a layer's self-search is enqueued BEFORE its sub-sampling's sync, so
-    # the device has work while the host waits for the count.  (A sync per search left the device idle 2 of the pyramid's 3.6 ms at N = 200 000.)
+    # Host synchronisation: the sub-sampled point count of every layer is data dependent (one host wait per layer, as the TF op's dynamic shape): it is
+    # copied to pinned memory behind an event, the layer's self-search is enqueued behind it, and the host waits for the event only — the search is
+    # still running when the next launches arrive.  The widths of the 13 neighbour tables are read back together at the end.  (A sync per search left
+    # the device idle 2 of the pyramid's 3.6 ms at N = 200 000.)
     pending = []                                                             # (key, table, largest neighbourhood) in the reference's order
     # every layer's points are the supports of two or three searches at ONE radius (their own neighbourhoods, the pooling, the previous layer's
     # upsampling): 13 searches over 5 distinct grids, each built once
     grid = RadiusGrid(pts, lens, r)
     for dt in range(num_layers - 1):                                         # :795-812
         lim = int(neighborhood_limits[dt])
+        sub = tf_batch_subsampling_launch(pts, lens, 2 * dl)                   # its size travels to the host while the self-search below runs
         pending.append(("neighbors", tf_batch_neighbors(pts, pts, lens, lens, r, lim, exact_shape="defer", grid=grid)))
-        pool_pts, pool_lens = tf_batch_subsampling(pts, lens, 2 * dl)
+        pool_pts, pool_lens = tf_batch_subsampling_finish(sub)
         pool_pts = pool_pts.contiguous()
         pending.append(("pools", tf_batch_neighbors(pool_pts, pts, pool_lens, lens, r, lim, exact_shape="defer", grid=grid)))
         grid = RadiusGrid(pool_pts, pool_lens, 2 * r)
