@@ -1109,7 +1109,7 @@ CBL_EXPORT int cbl_ind_max_pool(int n1, int n2, int k, int d, const float* x, co
         const int D4 = d / 4, chunks = (D4 + 255) / 256, Lmax = (D4 + chunks - 1) / chunks;
         for (int c4_0 = 0; c4_0 < D4 && n1 > 0; c4_0 += Lmax) {
             const int L = min(Lmax, D4 - c4_0);
-            hipLaunchKernelGGL(column_min_v4_kernel, dim3(min(cbl_div_up(n1, 256 / L), 64)), dim3(256), 0, st, (unsigned)n1, D4, c4_0, L, reinterpret_cast<const float4*>(x), scratch_d);
+            hipLaunchKernelGGL(column_min_v4_kernel, dim3(min(cbl_div_up(n1, 256 / L), 256)), dim3(256), 0, st, (unsigned)n1, D4, c4_0, L, reinterpret_cast<const float4*>(x), scratch_d);
         }
         for (int c4_0 = 0; c4_0 < D4; c4_0 += Lmax) {
             const int L = min(Lmax, D4 - c4_0);
