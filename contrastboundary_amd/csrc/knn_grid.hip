@@ -700,6 +700,9 @@ __global__ __launch_bounds__(256) void radius_group_kernel(int b, int nq, int ns
     float ed = INFINITY; int ei = 0x7fffffff;
     int inside = 0;
     const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+    // the list's current worst entry (slot limit - 1), group-uniform: re-read only after an insertion (it was two cross-lane reads per 32 candidates,
+    // and most batches insert nothing: the kernel sits at 0.84 of the vector issue slots, profiles/r03_pmc_convnet.json)
+    float wd = INFINITY; int wi = 0x7fffffff;
     for (int dz = -1; dz <= 1; dz++) {
         for (int dy = -1; dy <= 1; dy++) {
             const int y = cy + dy, z = cz + dz;
@@ -710,17 +713,15 @@ __global__ __launch_bounds__(256) void radius_group_kernel(int b, int nq, int ns
             }
             for (int p = s; __any(p < e); p += G) {
                 const int pi = p + gl;
-                float d2 = INFINITY; int ci = 0x7fffffff;
-                if (pi < e) {
-                    const float4 v = sorted[pi];
-                    d2 = cbl_dist2(qx, qy, qz, v.x, v.y, v.z);       // (query - support)^2 summed over x,y,z like L2_Simple_Adaptor
-                    ci = __float_as_int(v.w);
-                }
+                const bool have = pi < e;
+                const float4 v = sorted[have ? pi : (e > s ? e - 1 : 0)];     // clamped, unconditional: no branch around the load
+                const float d2 = have ? cbl_dist2(qx, qy, qz, v.x, v.y, v.z) : INFINITY;      // (query - support)^2 summed over x,y,z like L2_Simple_Adaptor
+                const int ci = have ? __float_as_int(v.w) : 0x7fffffff;
                 const bool in_ball = d2 < r2;
                 inside += in_ball ? 1 : 0;
-                const float wd = __shfl(ed, limit - 1, G); const int wi = __shfl(ei, limit - 1, G);
                 const bool pass = in_ball && (d2 < wd || (d2 == wd && ci < wi));
                 mask_t gm = (__ballot(pass) >> (grp * G)) & (G == 64 ? ~0ull : ((1ull << G) - 1ull));
+                if (!__any(gm != 0)) continue;
                 while (__any(gm != 0)) {
                     const bool has = gm != 0;
                     const int l = has ? __builtin_ctzll(gm) : 0;
@@ -732,6 +733,7 @@ __global__ __launch_bounds__(256) void radius_group_kernel(int b, int nq, int ns
                     const bool left_gt = (gl > 0) && (pd > dc || (pd == dc && pidx > ic));
                     if (gt) { if (left_gt) { ed = pd; ei = pidx; } else { ed = dc; ei = ic; } }
                 }
+                wd = __shfl(ed, limit - 1, G); wi = __shfl(ei, limit - 1, G);
             }
         }
     }
