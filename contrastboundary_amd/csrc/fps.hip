@@ -122,7 +122,7 @@ __device__ __forceinline__ void block_winner(const FpsBest& b, bool any, int tid
 template <int PER, int RREG, int RLDS>
 __global__ __launch_bounds__(FPS_BLOCK) void fps_kernel(int bits, const float* __restrict__ xyz,
                                                         const int* __restrict__ offset, const int* __restrict__ new_offset,
-                                                        float* __restrict__ tmp, int* __restrict__ idx)
+                                                        float* __restrict__ tmp, int* __restrict__ idx, const int* __restrict__ prefix_cert)
 {
     constexpr int RGLB = PER - RREG - RLDS;                         // rows streamed from L2, in batches of <= GBATCH rows
     constexpr int GBATCH = 7;
@@ -131,6 +131,7 @@ __global__ __launch_bounds__(FPS_BLOCK) void fps_kernel(int bits, const float* _
     extern __shared__ __attribute__((aligned(16))) float lds_xyz[];     // [3][RLDS][1024]
     const FpsCloud cl = fps_cloud(offset, new_offset);
     if (cl.m1 <= cl.m0) return;
+    if (prefix_cert && prefix_cert[blockIdx.x] >= cl.m1 - cl.m0) return;       // this cloud's samples are a certified prefix (fps_prefix_kernel wrote them)
     const int tid = threadIdx.x, nloc = cl.n1 - cl.n0;
     const float* __restrict__ P = xyz + (size_t)3 * cl.n0;
     const int omax = 3 * (nloc - 1);
@@ -221,11 +222,12 @@ __global__ __launch_bounds__(FPS_BLOCK) void fps_kernel(int bits, const float* _
 // any cloud size: running distances stay in tmp[] (L2-resident), as in the reference
 __global__ __launch_bounds__(FPS_BLOCK) void fps_stream_kernel(int bits, const float* __restrict__ xyz,
                                                                const int* __restrict__ offset, const int* __restrict__ new_offset,
-                                                               float* __restrict__ tmp, int* __restrict__ idx)
+                                                               float* __restrict__ tmp, int* __restrict__ idx, const int* __restrict__ prefix_cert)
 {
     __shared__ FpsSlot slots[2][FPS_WAVES];
     const FpsCloud cl = fps_cloud(offset, new_offset);
     if (cl.m1 <= cl.m0) return;
+    if (prefix_cert && prefix_cert[blockIdx.x] >= cl.m1 - cl.m0) return;
     const int tid = threadIdx.x, nloc = cl.n1 - cl.n0;
     const float* __restrict__ P = xyz + (size_t)3 * cl.n0;
     float* __restrict__ T = tmp + cl.n0;
@@ -246,8 +248,25 @@ __global__ __launch_bounds__(FPS_BLOCK) void fps_stream_kernel(int bits, const f
     }
 }
 
+// FPS of an FPS sequence is its prefix.  Let A = (s_0, s_1, ...) be the samples of a cloud P in sampling order.  Sampling A again picks s_0 (the
+// first row), and at every later step the point of P that the first run picked — the maximiser over P of the running distance — lies in A and has the
+// same running distance there (same samples, same order, same arithmetic, both runs starting from 1e10), so it is the maximiser over A as well, PROVIDED
+// the maximum over P was attained by one point only (with ties the reference's rank rule decides, and ranks are positions, which differ between P and A).
+// cert[c] = number of leading samples of cloud c that were unique maxima (written by the run that produced A): a request for m <= cert[c] samples of A is
+// answered with 0 .. m-1 and the certificate is handed on; anything else runs the sampler.
+__global__ __launch_bounds__(256) void fps_prefix_kernel(int b, const int* __restrict__ offset, const int* __restrict__ new_offset,
+                                                         const int* __restrict__ cert_in, int* __restrict__ idx, int* __restrict__ cert_out)
+{
+    const FpsCloud cl = fps_cloud(offset, new_offset);
+    const int m = cl.m1 - cl.m0;
+    const bool ok = cert_in && m > 0 && cert_in[blockIdx.x] >= m;
+    if (ok)
+        for (int j = threadIdx.x; j < m; j += 256) idx[cl.m0 + j] = cl.n0 + j;
+    if (threadIdx.x == 0 && cert_out) cert_out[blockIdx.x] = ok ? cert_in[blockIdx.x] : 0;     // 0 = no certificate (the sampler may overwrite it)
+}
+
 template <int PER, int RREG, int RLDS>
-void launch_fps(int b, int bits, const float* xyz, const int* offset, const int* new_offset, float* tmp, int* idx, hipStream_t st)
+void launch_fps(int b, int bits, const float* xyz, const int* offset, const int* new_offset, float* tmp, int* idx, const int* prefix_cert, hipStream_t st)
 {
     const size_t lds = (size_t)3 * RLDS * FPS_BLOCK * sizeof(float);
     if (lds > 48 * 1024) {
@@ -257,7 +276,7 @@ void launch_fps(int b, int bits, const float* xyz, const int* offset, const int*
             attr_set = true;
         }
     }
-    hipLaunchKernelGGL((fps_kernel<PER, RREG, RLDS>), dim3(b), dim3(FPS_BLOCK), lds, st, bits, xyz, offset, new_offset, tmp, idx);
+    hipLaunchKernelGGL((fps_kernel<PER, RREG, RLDS>), dim3(b), dim3(FPS_BLOCK), lds, st, bits, xyz, offset, new_offset, tmp, idx, prefix_cert);
 }
 
 }  // namespace
@@ -276,7 +295,7 @@ static int ref_block_threads(int n_max)
 // fps_bucket.hip
 size_t cbl_fps_bucket_workspace_bytes(int b, int n);
 int cbl_fps_bucket_launch(int b, int n, int n_max, int bits, const float* xyz, const int* offset, const int* new_offset, float* tmp, int* idx,
-                          void* ws, size_t ws_bytes, hipStream_t st);
+                          void* ws, size_t ws_bytes, hipStream_t st, const int* prefix_cert, int* cert_out);
 
 // clouds from this size on take the bucket-pruned kernel (same samples): ~1.07 us per sample at any size, against 1.1 (<= 2560
 // points) .. 1.5 (10240) .. 6.9 us (40960) for the dense kernels; measured crossover between 2560 and 5000 points
@@ -286,6 +305,38 @@ CBL_EXPORT size_t cbl_furthestsampling_workspace_bytes(int b, int n, int n_max)
 {
     if (b <= 0 || n <= 0 || b > 65535 || n_max < FPS_BUCKET_MIN_POINTS || n_max > FPS_BUCKET_MAX_POINTS) return 0;
     return cbl_fps_bucket_workspace_bytes(b, n);
+}
+
+static int fps_dense_launch(int b, int n_max, const float* xyz, const int* offset, const int* new_offset, float* tmp, int* idx, const int* prefix_cert,
+                            hipStream_t st)
+{
+    const int B = ref_block_threads(n_max);
+    int bits = 0; while ((1 << bits) < B) bits++;
+    if (n_max <= 1 * FPS_BLOCK)       launch_fps<1, 1, 0>(b, bits, xyz, offset, new_offset, tmp, idx, prefix_cert, st);
+    else if (n_max <= 4 * FPS_BLOCK)  launch_fps<4, 4, 0>(b, bits, xyz, offset, new_offset, tmp, idx, prefix_cert, st);
+    else if (n_max <= 10 * FPS_BLOCK) launch_fps<10, 10, 0>(b, bits, xyz, offset, new_offset, tmp, idx, prefix_cert, st);
+    else if (n_max <= 16 * FPS_BLOCK) launch_fps<16, 16, 0>(b, bits, xyz, offset, new_offset, tmp, idx, prefix_cert, st);
+    else if (n_max <= 27 * FPS_BLOCK) launch_fps<27, 14, 13>(b, bits, xyz, offset, new_offset, tmp, idx, prefix_cert, st);
+    else if (n_max <= 40 * FPS_BLOCK) launch_fps<40, 6, 13>(b, bits, xyz, offset, new_offset, tmp, idx, prefix_cert, st);
+    else                              hipLaunchKernelGGL(fps_stream_kernel, dim3(b), dim3(FPS_BLOCK), 0, st, bits, xyz, offset, new_offset, tmp, idx, prefix_cert);
+    return cbl_status();
+}
+
+// the sampler for CHAINS of samplings (the network's four TransitionDown stages each sample the previous stage's samples): see fps_prefix_kernel
+CBL_EXPORT int cbl_furthestsampling_chain(int b, int n, int n_max, const float* xyz, const int* offset, const int* new_offset, float* tmp, int* idx,
+                                          const int* cert_in, int* cert_out, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (b < 0 || n < 0 || n_max < 0) return CBL_ERR_BAD_ARG;
+    if (b == 0 || n == 0) return CBL_OK;
+    if (!xyz || !offset || !new_offset || !tmp || !idx || !cert_out) return CBL_ERR_BAD_ARG;
+    hipStream_t st = cbl_stream(stream);
+    hipLaunchKernelGGL(fps_prefix_kernel, dim3(b), dim3(256), 0, st, b, offset, new_offset, cert_in, idx, cert_out);
+    const size_t need = cbl_furthestsampling_workspace_bytes(b, n, n_max);
+    if (need == 0 || !workspace) return fps_dense_launch(b, n_max, xyz, offset, new_offset, tmp, idx, cert_in, st);
+    if (workspace_bytes < need) return CBL_ERR_WORKSPACE;
+    const int B = ref_block_threads(n_max);
+    int bits = 0; while ((1 << bits) < B) bits++;
+    return cbl_fps_bucket_launch(b, n, n_max, bits, xyz, offset, new_offset, tmp, idx, workspace, workspace_bytes, st, cert_in, cert_out);
 }
 
 CBL_EXPORT int cbl_furthestsampling_ws(int b, int n, int n_max, const float* xyz, const int* offset, const int* new_offset,
@@ -299,7 +350,7 @@ CBL_EXPORT int cbl_furthestsampling_ws(int b, int n, int n_max, const float* xyz
     if (workspace_bytes < need) return CBL_ERR_WORKSPACE;
     const int B = ref_block_threads(n_max);
     int bits = 0; while ((1 << bits) < B) bits++;
-    return cbl_fps_bucket_launch(b, n, n_max, bits, xyz, offset, new_offset, tmp, idx, workspace, workspace_bytes, cbl_stream(stream));
+    return cbl_fps_bucket_launch(b, n, n_max, bits, xyz, offset, new_offset, tmp, idx, workspace, workspace_bytes, cbl_stream(stream), nullptr, nullptr);
 }
 
 CBL_EXPORT int cbl_furthestsampling(int b, int n_max, const float* xyz, const int* offset, const int* new_offset,
@@ -308,15 +359,5 @@ CBL_EXPORT int cbl_furthestsampling(int b, int n_max, const float* xyz, const in
     if (b < 0 || n_max < 0) return CBL_ERR_BAD_ARG;
     if (b == 0) return CBL_OK;
     if (!xyz || !offset || !new_offset || !tmp || !idx) return CBL_ERR_BAD_ARG;
-    const int B = ref_block_threads(n_max);
-    int bits = 0; while ((1 << bits) < B) bits++;
-    hipStream_t st = cbl_stream(stream);
-    if (n_max <= 1 * FPS_BLOCK)       launch_fps<1, 1, 0>(b, bits, xyz, offset, new_offset, tmp, idx, st);
-    else if (n_max <= 4 * FPS_BLOCK)  launch_fps<4, 4, 0>(b, bits, xyz, offset, new_offset, tmp, idx, st);
-    else if (n_max <= 10 * FPS_BLOCK) launch_fps<10, 10, 0>(b, bits, xyz, offset, new_offset, tmp, idx, st);
-    else if (n_max <= 16 * FPS_BLOCK) launch_fps<16, 16, 0>(b, bits, xyz, offset, new_offset, tmp, idx, st);
-    else if (n_max <= 27 * FPS_BLOCK) launch_fps<27, 14, 13>(b, bits, xyz, offset, new_offset, tmp, idx, st);
-    else if (n_max <= 40 * FPS_BLOCK) launch_fps<40, 6, 13>(b, bits, xyz, offset, new_offset, tmp, idx, st);
-    else                              hipLaunchKernelGGL(fps_stream_kernel, dim3(b), dim3(FPS_BLOCK), 0, st, bits, xyz, offset, new_offset, tmp, idx);
-    return cbl_status();
+    return fps_dense_launch(b, n_max, xyz, offset, new_offset, tmp, idx, nullptr, cbl_stream(stream));
 }

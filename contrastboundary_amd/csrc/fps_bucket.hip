@@ -169,10 +169,13 @@ struct FbSlot { float d; unsigned rank; float x, y, z; float pad[3]; };      // 
 // distance / rank / coordinates all live in the owner lane's registers, and the owner WAVE is also the one that reprocesses the
 // bucket — so a sample needs no queue, no LDS atomics and ONE barrier: test own buckets -> reprocess the touched ones (ids that
 // are neighbours in Morton order sit in different waves) -> wave best -> LDS slot -> barrier -> every wave reduces the 16 slots.
-template <int R>
+// CERT: also certify which leading samples were unique maxima (the prefix certificate of fps.hip); compiled out otherwise — the bookkeeping costs ~9 % of
+// the kernel, and only the head of a sampling chain needs it
+template <int R, bool CERT>
 __global__ __launch_bounds__(1024) void fps_bucket_kernel(int bits, const float* __restrict__ xyz, const int* __restrict__ offset,
                                                           const int* __restrict__ new_offset, float4* __restrict__ sorted,
-                                                          const unsigned* __restrict__ rank, int* __restrict__ idx)
+                                                          const unsigned* __restrict__ rank, int* __restrict__ idx,
+                                                          const int* __restrict__ prefix_cert, int* __restrict__ cert_out)
 {
     constexpr int W = 16;
     __shared__ FbSlot slots[2][W];
@@ -180,17 +183,21 @@ __global__ __launch_bounds__(1024) void fps_bucket_kernel(int bits, const float*
     const int n0 = c ? offset[c - 1] : 0, n1 = offset[c];
     const int m0 = c ? new_offset[c - 1] : 0, m1 = new_offset[c];
     if (m1 <= m0 || n1 <= n0) return;
+    if (prefix_cert && prefix_cert[c] >= m1 - m0) return;                       // a certified prefix (fps.hip fps_prefix_kernel wrote the samples)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nloc = n1 - n0, NB = (nloc + FB_BUCKET - 1) / FB_BUCKET;
 
     float lo[R][3], hi[R][3], bm[R], bxr[R], byr[R], bzr[R];
     unsigned brk[R];
+    // uniqueness of every arg-max, for the prefix certificate (fps.hip): bt = "this bucket's maximum is attained by more than one of its points"; the same
+    // question is carried through the wave's best and the block's best, and the first sample whose maximum was not unique is remembered
+    int bt[R];
 #pragma unroll
-    for (int r = 0; r < R; r++) { bm[r] = -3.f; brk[r] = 0xffffffffu; bxr[r] = byr[r] = bzr[r] = 0.f;
+    for (int r = 0; r < R; r++) { bm[r] = -3.f; brk[r] = 0xffffffffu; bxr[r] = byr[r] = bzr[r] = 0.f; bt[r] = 0;
                                   lo[r][0] = lo[r][1] = lo[r][2] = 0.f; hi[r][0] = hi[r][1] = hi[r][2] = 0.f; }
 
     // the wave recomputes bucket g against sample (sx,sy,sz) (first: no update, also the box); result wave-uniform
-    struct Best { float d; unsigned rank; float x, y, z; };
+    struct Best { float d; unsigned rank; float x, y, z; int tie; };
     auto process = [&](int g, float sx, float sy, float sz, bool first, float* blo, float* bhi) -> Best {
         const int i = n0 + FB_BUCKET * g + lane;
         const bool valid = i < n1;
@@ -203,6 +210,7 @@ __global__ __launch_bounds__(1024) void fps_bucket_kernel(int bits, const float*
         Best o;
         o.d = wave_max_f(dv);
         unsigned long long mk = __ballot(dv == o.d);
+        o.tie = CERT ? (__popcll(mk) != 1) : 0;
         if (__popcll(mk) != 1) {                                                 // equal maxima: smallest reference rank wins
             const unsigned wr = wave_min_u(dv == o.d ? rk : 0xffffffffu);
             mk = __ballot(dv == o.d && rk == wr);
@@ -233,6 +241,7 @@ __global__ __launch_bounds__(1024) void fps_bucket_kernel(int bits, const float*
         const float d1 = v1 ? t1 : -2.f, d2 = v2 ? t2 : -2.f;
         o1.d = wave_max_f(d1); o2.d = wave_max_f(d2);
         unsigned long long k1 = __ballot(d1 == o1.d), k2 = __ballot(d2 == o2.d);
+        o1.tie = CERT ? (__popcll(k1) != 1) : 0; o2.tie = CERT ? (__popcll(k2) != 1) : 0;
         if (__popcll(k1) != 1) { const unsigned wr = wave_min_u(d1 == o1.d ? rk1 : 0xffffffffu); k1 = __ballot(d1 == o1.d && rk1 == wr); }
         if (__popcll(k2) != 1) { const unsigned wr = wave_min_u(d2 == o2.d ? rk2 : 0xffffffffu); k2 = __ballot(d2 == o2.d && rk2 == wr); }
         const int b1 = __builtin_ctzll(k1), b2 = __builtin_ctzll(k2);
@@ -252,15 +261,19 @@ __global__ __launch_bounds__(1024) void fps_bucket_kernel(int bits, const float*
             if (g >= NB) break;
             float blo[3], bhi[3];
             const Best o = process(g, 0.f, 0.f, 0.f, true, blo, bhi);
-            if (lane == l) { bm[r] = o.d; brk[r] = o.rank; bxr[r] = o.x; byr[r] = o.y; bzr[r] = o.z;
+            if (lane == l) { bm[r] = o.d; brk[r] = o.rank; bxr[r] = o.x; byr[r] = o.y; bzr[r] = o.z; bt[r] = o.tie;
 #pragma unroll
                              for (int a = 0; a < 3; a++) { lo[r][a] = blo[a]; hi[r][a] = bhi[a]; } }
         }
     }
     float sx = xyz[3 * (size_t)n0], sy = xyz[3 * (size_t)n0 + 1], sz = xyz[3 * (size_t)n0 + 2];   // first sample = first point (:26 / :34)
     int myidx = n0;                                                              // wave 15 collects 64 results per coalesced store (:39)
-    Best wb; wb.d = -3.f; wb.rank = 0xffffffffu; wb.x = wb.y = wb.z = 0.f;       // this wave's best over its buckets
+    Best wb; wb.d = -3.f; wb.rank = 0xffffffffu; wb.x = wb.y = wb.z = 0.f; wb.tie = 0;       // this wave's best over its buckets
     bool dirty = true;
+    int first_tie = 0x7fffffff;                                                  // first sample (counted in the cloud) whose maximum was not unique
+    // only the first half of the samples is certified: the next stage of a chain asks for a fraction of them (1/4 in the reference's network), and the
+    // bookkeeping sits on the sample's critical path (all of it: 10.9 -> 12.1 ms for 40960 -> 10240)
+    const int track_n = (CERT && cert_out) ? (m1 - m0 + 1) >> 1 : 0;
 
     for (int j = m0 + 1; j < m1; j++) {
         // S1 + S2: own buckets that can change are reprocessed right away
@@ -281,24 +294,26 @@ __global__ __launch_bounds__(1024) void fps_bucket_kernel(int bits, const float*
                     mk &= mk - 1;
                     Best o1, o2;
                     process2((l1 + 64 * r) * W + wave, (l2 + 64 * r) * W + wave, sx, sy, sz, o1, o2);
-                    if (lane == l1) { bm[r] = o1.d; brk[r] = o1.rank; bxr[r] = o1.x; byr[r] = o1.y; bzr[r] = o1.z; }
-                    if (lane == l2) { bm[r] = o2.d; brk[r] = o2.rank; bxr[r] = o2.x; byr[r] = o2.y; bzr[r] = o2.z; }
+                    if (lane == l1) { bm[r] = o1.d; brk[r] = o1.rank; bxr[r] = o1.x; byr[r] = o1.y; bzr[r] = o1.z; bt[r] = o1.tie; }
+                    if (lane == l2) { bm[r] = o2.d; brk[r] = o2.rank; bxr[r] = o2.x; byr[r] = o2.y; bzr[r] = o2.z; bt[r] = o2.tie; }
                 } else {
                     const Best o = process((l1 + 64 * r) * W + wave, sx, sy, sz, false, nullptr, nullptr);
-                    if (lane == l1) { bm[r] = o.d; brk[r] = o.rank; bxr[r] = o.x; byr[r] = o.y; bzr[r] = o.z; }
+                    if (lane == l1) { bm[r] = o.d; brk[r] = o.rank; bxr[r] = o.x; byr[r] = o.y; bzr[r] = o.z; bt[r] = o.tie; }
                 }
                 dirty = true;
             }
         }
         if (dirty) {                                                             // wave-uniform
-            float d = bm[0]; unsigned rk = brk[0]; float x = bxr[0], y = byr[0], z = bzr[0];
+            float d = bm[0]; unsigned rk = brk[0]; float x = bxr[0], y = byr[0], z = bzr[0]; int lt = bt[0];
 #pragma unroll
             for (int r = 1; r < R; r++) {
                 const bool up = bm[r] > d || (bm[r] == d && brk[r] < rk);
+                if (CERT) lt = (bm[r] == d) ? 1 : (up ? bt[r] : lt);             // two of this lane's buckets at the same maximum: not unique
                 d = up ? bm[r] : d; rk = up ? brk[r] : rk; x = up ? bxr[r] : x; y = up ? byr[r] : y; z = up ? bzr[r] : z;
             }
             wb.d = wave_max_f(d);
             unsigned long long mk = __ballot(d == wb.d);
+            wb.tie = CERT && (j - m0 < track_n) && ((__popcll(mk) != 1) || (__ballot(d == wb.d && lt) != 0ull));
             if (__popcll(mk) != 1) {
                 const unsigned wr = wave_min_u(d == wb.d ? rk : 0xffffffffu);
                 mk = __ballot(d == wb.d && rk == wr);
@@ -311,19 +326,21 @@ __global__ __launch_bounds__(1024) void fps_bucket_kernel(int bits, const float*
             dirty = false;
         }
         const int par = j & 1;
-        if (lane == 0) { FbSlot s; s.d = wb.d; s.rank = wb.rank; s.x = wb.x; s.y = wb.y; s.z = wb.z; s.pad[0] = s.pad[1] = s.pad[2] = 0.f; slots[par][wave] = s; }
+        if (lane == 0) { FbSlot s; s.d = wb.d; s.rank = wb.rank; s.x = wb.x; s.y = wb.y; s.z = wb.z; s.pad[0] = (CERT && wb.tie) ? 1.f : 0.f; s.pad[1] = s.pad[2] = 0.f; slots[par][wave] = s; }
         __syncthreads();
         // S3: every wave reduces the 16 slots (each row of 16 lanes holds all of them)
         const int sl = lane & (W - 1);
         const float sd = slots[par][sl].d; const unsigned sr = slots[par][sl].rank;
         const float bd = row_max_f(sd);
         unsigned mk16 = (unsigned)__ballot(sd == bd) & 0xffffu;
+        const bool block_tie = __popc(mk16) != 1;
         if (__popc(mk16) != 1) {
             const unsigned br = row_min_u(sd == bd ? sr : 0xffffffffu);
             mk16 = (unsigned)__ballot(sd == bd && sr == br) & 0xffffu;
         }
         const int slot = __builtin_ctz(mk16);
         sx = slots[par][slot].x; sy = slots[par][slot].y; sz = slots[par][slot].z;
+        if (CERT && j - m0 < track_n && first_tie == 0x7fffffff && (block_tie || slots[par][slot].pad[0] != 0.f)) first_tie = j - m0;
         if (wave == W - 1) {
             const int jj = j - m0;
             const int win = n0 + fb_unrank(slots[par][slot].rank, bits);
@@ -332,6 +349,7 @@ __global__ __launch_bounds__(1024) void fps_bucket_kernel(int bits, const float*
         }
     }
     if (m1 - m0 == 1 && tid == 0) idx[m0] = n0;
+    if (CERT && tid == 0 && cert_out) cert_out[c] = min(first_tie, track_n);             // samples 0 .. cert-1 were unique maxima (at most the tracked half)
 }
 
 }  // namespace
@@ -340,7 +358,7 @@ size_t cbl_fps_bucket_workspace_bytes(int b, int n) { return (b > 0 && n > 0) ? 
 
 // n = total rows, n_max = largest cloud.  Returns CBL_ERR_UNSUPPORTED when the bucket tables would not fit one workgroup's LDS.
 int cbl_fps_bucket_launch(int b, int n, int n_max, int bits, const float* xyz, const int* offset, const int* new_offset, float* tmp, int* idx,
-                          void* ws, size_t ws_bytes, hipStream_t st)
+                          void* ws, size_t ws_bytes, hipStream_t st, const int* prefix_cert, int* cert_out)
 {
     const int nb_max = (n_max + FB_BUCKET - 1) / FB_BUCKET;
     if (nb_max > FB_MAX_BUCKETS || b > 65535) return CBL_ERR_UNSUPPORTED;
@@ -355,8 +373,10 @@ int cbl_fps_bucket_launch(int b, int n, int n_max, int bits, const float* xyz, c
     hipError_t e = rocprim::radix_sort_pairs(w.cub, cb, w.keys_in, w.keys_out, w.vals_in, w.vals_out, (size_t)n, 0u, 48u, st);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(fb_gather_kernel, g, blk, 0, st, b, n, bits, xyz, offset, tmp, w.keys_out, w.vals_out, w.sorted, w.rank);
-    if (nb_max <= 1024) hipLaunchKernelGGL(fps_bucket_kernel<1>, dim3(b), dim3(1024), 0, st, bits, xyz, offset, new_offset, w.sorted, w.rank, idx);
-    else                hipLaunchKernelGGL(fps_bucket_kernel<2>, dim3(b), dim3(1024), 0, st, bits, xyz, offset, new_offset, w.sorted, w.rank, idx);
+    if (nb_max <= 1024) { if (cert_out) hipLaunchKernelGGL((fps_bucket_kernel<1, true>), dim3(b), dim3(1024), 0, st, bits, xyz, offset, new_offset, w.sorted, w.rank, idx, prefix_cert, cert_out);
+                          else          hipLaunchKernelGGL((fps_bucket_kernel<1, false>), dim3(b), dim3(1024), 0, st, bits, xyz, offset, new_offset, w.sorted, w.rank, idx, prefix_cert, cert_out); }
+    else                { if (cert_out) hipLaunchKernelGGL((fps_bucket_kernel<2, true>), dim3(b), dim3(1024), 0, st, bits, xyz, offset, new_offset, w.sorted, w.rank, idx, prefix_cert, cert_out);
+                          else          hipLaunchKernelGGL((fps_bucket_kernel<2, false>), dim3(b), dim3(1024), 0, st, bits, xyz, offset, new_offset, w.sorted, w.rank, idx, prefix_cert, cert_out); }
     hipLaunchKernelGGL(fb_writeback_kernel, g, blk, 0, st, n, w.vals_out, w.sorted, tmp);
     return cbl_status();
 }

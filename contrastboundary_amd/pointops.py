@@ -43,14 +43,22 @@ from . import neighbor_state
 
 
 # ------------------------------------------------------------------------------------------------ K2
-def _furthestsampling_raw(xyz, offset, new_offset, n_max, m):
-    """the launch alone: n_max (longest cloud) and m (= new_offset[-1]) come from the host side, nothing synchronises"""
+def _furthestsampling_raw(xyz, offset, new_offset, n_max, m, cert_in=None, want_cert=False):
+    """the launch alone: n_max (longest cloud) and m (= new_offset[-1]) come from the host side, nothing synchronises.
+    want_cert / cert_in: cbl_furthestsampling_chain (-> idx, cert): sampling the samples of an earlier run is its prefix where that run certified it"""
     n, b = xyz.shape[0], offset.shape[0]
     idx = torch.zeros(m, dtype=torch.int32, device=xyz.device)
     tmp = torch.full((n,), 1e10, dtype=torch.float32, device=xyz.device)
     L = _lib.lib()
     need = L.cbl_furthestsampling_workspace_bytes(_c_int(b), _c_int(n), _c_int(n_max))     # > 0: large clouds, bucket-pruned kernel
     ws = _workspace(need, xyz.device)
+    if want_cert or cert_in is not None:
+        cert = torch.empty(b, dtype=torch.int32, device=xyz.device)
+        rc = L.cbl_furthestsampling_chain(_c_int(b), _c_int(n), _c_int(n_max), _lib.ptr(xyz), _lib.ptr(offset), _lib.ptr(new_offset), _lib.ptr(tmp),
+                                          _lib.ptr(idx), _lib.ptr(cert_in), _lib.ptr(cert), _lib.ptr(ws),
+                                          ctypes.c_size_t(ws.numel() if ws is not None else 0), _lib.stream_of(xyz))
+        _lib.check(rc, "cbl_furthestsampling_chain")
+        return idx, cert
     rc = L.cbl_furthestsampling_ws(_c_int(b), _c_int(n), _c_int(n_max), _lib.ptr(xyz), _lib.ptr(offset), _lib.ptr(new_offset),
                                    _lib.ptr(tmp), _lib.ptr(idx), _lib.ptr(ws), ctypes.c_size_t(ws.numel() if ws is not None else 0),
                                    _lib.stream_of(xyz))
@@ -89,6 +97,9 @@ def set_knn_tie_policy(policy):
     return prev
 
 
+fps_prefix_chain = True      # False: every stage runs the sampler (measurement / tests)
+
+
 def fps_downsample(p, o, stride):
     """TransitionDown's sampling step (blocks.py:61-68): per cloud n_b // stride furthest-point samples.
     -> (new_p (m,3), new_o (b) i32, idx (m) i32); cached per forward like the neighbour searches (the coordinates handed back are the
@@ -106,8 +117,13 @@ def fps_downsample(p, o, stride):
         new_ends.append(run)
     staged = torch.tensor(new_ends, dtype=torch.int32).pin_memory()
     new_o = staged.to(o.device, non_blocking=True)
-    idx = _furthestsampling_raw(p, o, new_o, max(lens) if lens else 0, run)
+    # the samples of an FPS run, sampled again, are that run's prefix where it certified its arg-maxima as unique (cbl_furthestsampling_chain): the
+    # certificate rides on the sampled tensor itself (same object, same version, same number of clouds), so only a genuine chain can use it
+    tag = getattr(p, "_fps_certificate", None)
+    cert_in = tag[0] if (fps_prefix_chain and tag is not None and tag[1] == p._version and tag[0].shape[0] == o.shape[0]) else None
+    idx, cert = _furthestsampling_raw(p, o, new_o, max(lens) if lens else 0, run, cert_in=cert_in, want_cert=True)
     new_p = p[idx.long(), :]
+    new_p._fps_certificate = (cert, new_p._version)
     if cache is not None:
         cache.host[cache._host_key(new_o)] = (new_ends, new_o, staged)
         cache.insert_fps(stride, (p, o), new_p, new_o, idx)

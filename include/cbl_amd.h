@@ -133,6 +133,17 @@ int cbl_furthestsampling(int b, int n_max, const float* xyz, const int* offset, 
 size_t cbl_furthestsampling_workspace_bytes(int b, int n, int n_max);
 int cbl_furthestsampling_ws(int b, int n, int n_max, const float* xyz, const int* offset, const int* new_offset,
                             float* tmp, int* idx, void* workspace, size_t workspace_bytes, void* stream);
+/* The sampler for CHAINS of samplings (the network samples 40960 -> 10240 -> 2560 -> 640 -> 160, every stage from the previous stage's samples in
+ * sampling order, pytorch/model/blocks.py:61-68): furthest point sampling of an FPS sequence is its prefix whenever every arg-max of the first run was
+ * attained by one point only (with equal maxima the reference's rank rule decides, and ranks are positions).
+ *   cert_out (b) i32: number of leading samples of every cloud that were unique maxima, counted up to half of the cloud's samples (a later stage asks
+ *            for a fraction of them; 0 = no certificate: kernels without the check);
+ *   cert_in  (b) i32 or NULL: the certificate of the run that PRODUCED xyz (xyz = that run's samples, in order, unmodified).  A cloud with
+ *            cert_in[c] >= its requested sample count gets idx = its first rows and cert_out[c] = cert_in[c] (tmp is left untouched for it);
+ *            every other cloud is sampled as by cbl_furthestsampling_ws.
+ * Both runs start from the reference wrapper's distances (tmp = 1e10 everywhere, pointops.py:16-24).  Exactness under ties: tests/test_gpu_pointops.py. */
+int cbl_furthestsampling_chain(int b, int n, int n_max, const float* xyz, const int* offset, const int* new_offset, float* tmp, int* idx,
+                               const int* cert_in, int* cert_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* K3/K4  grouping_{forward,backward}_cuda_launcher  grouping/grouping_cuda_kernel.h:13-14.
  *   forward : input (n,c), idx (m,nsample) -> output (m,nsample,c)        (output fully overwritten)

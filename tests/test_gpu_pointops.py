@@ -155,6 +155,99 @@ def test_fps_dense_kernels_vs_oracle(n, b, seed):
     np.testing.assert_array_equal(tmp, rtmp)
 
 
+def _fps_chain(xyz, offset, strides, chain):
+    """TransitionDown's sampling step applied stage after stage (pointops.fps_downsample) -> [(idx, new_offset, certificate)] per stage"""
+    from contrastboundary_amd import pointops
+    prev, pointops.fps_prefix_chain = pointops.fps_prefix_chain, chain
+    try:
+        p, o, out = dev(xyz), dev(np.int32(offset)), []
+        for st in strides:
+            new_p, new_o, idx = pointops.fps_downsample(p, o, st)
+            out.append((idx.cpu().numpy(), new_o.cpu().numpy(), new_p._fps_certificate[0].cpu().numpy()))
+            p, o = new_p, new_o
+        return out
+    finally:
+        pointops.fps_prefix_chain = prev
+
+
+def _oracle_chain(xyz, offset, strides):
+    pts, off, out = xyz, np.int32(offset), []
+    for st in strides:
+        lens = np.diff(np.concatenate([[0], off]))
+        noff = np.cumsum(lens // st).astype(np.int32)
+        idx, _ = O.furthestsampling(pts, off, noff)
+        out.append((idx, noff))
+        pts, off = pts[idx], noff
+    return out
+
+
+def test_fps_chain_of_the_network_is_answered_by_prefixes():
+    """the four sampling stages of the network (40960 -> 10240 -> 2560 -> 640 -> 160, blocks.py:61-68), two clouds: every stage bit for bit the oracle's FPS of
+    that stage's input; on float data no arg-max is tied, so stage 1 certifies all of its samples and stages 2-4 are prefixes (their certificate is stage
+    1's, handed on: the dense kernels behind stages 3 and 4 would have written 0)"""
+    from contrastboundary_amd import synthetic as S
+    xyz = np.concatenate([S.s_room(40960, seed=0)[0], S.s_room(20000, seed=1)[0]])
+    offset, strides = [40960, 60960], [4, 4, 4, 4]
+    want = _oracle_chain(xyz, offset, strides)
+    got = _fps_chain(xyz, offset, strides, chain=True)
+    plain = _fps_chain(xyz, offset, strides, chain=False)
+    for (ridx, rnoff), (idx, noff, cert), (pidx, _, pcert) in zip(want, got, plain):
+        np.testing.assert_array_equal(noff, rnoff)
+        np.testing.assert_array_equal(idx, ridx)
+        np.testing.assert_array_equal(pidx, ridx)
+    m1 = np.diff(np.concatenate([[0], got[0][1]]))
+    np.testing.assert_array_equal(got[0][2], (m1 + 1) // 2)                   # the tracked half of stage 1's picks were unique maxima (first real ties: picks 6135 / 4900)
+    for stage in got[1:]:
+        np.testing.assert_array_equal(stage[2], (m1 + 1) // 2)                # handed on: these stages did not run a sampler
+    assert (plain[2][2] == 0).all() and (plain[3][2] == 0).all()              # without the chain the dense kernels run and certify nothing
+
+
+def test_fps_chain_under_ties_runs_the_sampler():
+    """a lattice ties every distance: the certificate ends at the first tied pick and the later stages sample for real, still the oracle's samples"""
+    g = np.arange(24, dtype=np.float32)
+    lat = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    rng = np.random.default_rng(0)
+    xyz = np.concatenate([lat, rng.uniform(0, 3, (9000, 3)).astype(np.float32)])
+    offset, strides = [len(lat), len(lat) + 9000], [3, 3, 3]
+    want = _oracle_chain(xyz, offset, strides)
+    got = _fps_chain(xyz, offset, strides, chain=True)
+    for (ridx, rnoff), (idx, noff, cert) in zip(want, got):
+        np.testing.assert_array_equal(idx, ridx)
+    assert got[0][2][0] < 8                                                   # the lattice cloud ties within its first picks
+    assert got[0][2][1] >= 1000                                               # the float cloud of the same batch is certified far enough for stage 2 ...
+    assert got[1][2][1] == got[0][2][1]                                       # ... and handed on, while the lattice cloud beside it was sampled again
+
+
+def test_fps_certificate_ends_exactly_at_the_first_tied_pick():
+    """two coincident points tie when they become the maximum: the certificate is that pick's index; a request up to it is a prefix, one more runs the
+    sampler — both the oracle's answer"""
+    from contrastboundary_amd import pointops
+    rng = np.random.default_rng(3)
+    xyz = rng.uniform(0, 2, (20000, 3)).astype(np.float32)
+    n, m1 = len(xyz), 6000
+    pre, _ = O.furthestsampling(xyz, [n], [m1])
+    spare = int(np.setdiff1d(np.arange(n), pre)[0])                           # a point the run never picks ...
+    xyz[spare] = xyz[pre[1500]]                                               # ... becomes the twin of pick 1500: both reach the maximum together, there
+    ridx1, _ = O.furthestsampling(xyz, [n], [m1])
+    np.testing.assert_array_equal(ridx1[:1500], pre[:1500])
+    hit = np.nonzero((ridx1 == pre[1500]) | (ridx1 == spare))[0]
+    assert len(hit) and hit[0] == 1500                                        # inside the tracked half (3000)
+    jstar = int(hit[0])
+    idx1, cert1 = pointops._furthestsampling_raw(dev(xyz), dev(np.int32([n])), dev(np.int32([m1])), n, m1, want_cert=True)
+    np.testing.assert_array_equal(idx1.cpu().numpy(), ridx1)
+    assert cert1.cpu().tolist() == [jstar]
+    p1 = dev(xyz[ridx1])
+    for m2 in (jstar, jstar + 1):
+        ridx2, _ = O.furthestsampling(xyz[ridx1], [m1], [m2])
+        idx2, cert2 = pointops._furthestsampling_raw(p1, dev(np.int32([m1])), dev(np.int32([m2])), m1, m2, cert_in=cert1, want_cert=True)
+        np.testing.assert_array_equal(idx2.cpu().numpy(), ridx2)
+        if m2 == jstar:
+            np.testing.assert_array_equal(ridx2, np.arange(jstar))               # the prefix property itself, on the oracle
+            assert cert2.cpu().tolist() == [jstar]                             # handed on
+        else:
+            assert cert2.cpu().tolist()[0] <= jstar + 1                       # sampled for real (the pair ties again at the same pick)
+
+
 def test_fps_bucket_full_size_room():
     # C2 / C4 shape: 40960 -> 10240 on the S-room scene; bucket-pruned kernel == dense kernel == oracle, running distances included
     from contrastboundary_amd import synthetic as S

@@ -23,4 +23,20 @@ for _ in range(5):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(); pointops.furthestsampling(p, o, no); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
 out["4 x 40960->10240"] = round(float(np.median(ts[1:])), 3)
+# the network's four stages as its TransitionDown blocks run them (pointops.fps_downsample): with the prefix certificates of cbl_furthestsampling_chain, and with
+# every stage sampled
+xyz, _ = S.s_room(40960, 0)
+for chain in (True, False):
+    pointops.fps_prefix_chain = chain
+    ts = []
+    for _ in range(6):
+        p = torch.from_numpy(xyz).cuda(); o = torch.tensor([40960], dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(4):
+            p, o, _ = pointops.fps_downsample(p, o, 4)
+        b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+    out["chain 40960->160, %s" % ("prefix certificates" if chain else "every stage sampled")] = round(float(np.median(ts[2:])), 3)
+pointops.fps_prefix_chain = True
 print(json.dumps(out))
