@@ -120,10 +120,10 @@ def fps_downsample(p, o, stride):
     # the samples of an FPS run, sampled again, are that run's prefix where it certified its arg-maxima as unique (cbl_furthestsampling_chain): the
     # certificate rides on the sampled tensor itself (same object, same version, same number of clouds), so only a genuine chain can use it
     tag = getattr(p, "_fps_certificate", None)
-    cert_in = tag[0] if (fps_prefix_chain and tag is not None and tag[1] == p._version and tag[0].shape[0] == o.shape[0]) else None
+    cert_in = tag[0] if (fps_prefix_chain and tag is not None and tag[1] == p._version and tag[2] is o and tag[3] == o._version) else None
     idx, cert = _furthestsampling_raw(p, o, new_o, max(lens) if lens else 0, run, cert_in=cert_in, want_cert=True)
     new_p = p[idx.long(), :]
-    new_p._fps_certificate = (cert, new_p._version)
+    new_p._fps_certificate = (cert, new_p._version, new_o, new_o._version)   # valid for exactly these rows and these cloud boundaries
     if cache is not None:
         cache.host[cache._host_key(new_o)] = (new_ends, new_o, staged)
         cache.insert_fps(stride, (p, o), new_p, new_o, idx)
