@@ -645,6 +645,12 @@ def run_pt(args, D, world, rank, local):
         nstep = make_step(scene, k, backward, args, overlap=True, pipeline=False)
         e_n = timed_region(nstep, args.steps, args.warmup, sync, D)
         out["no_pipeline"] = {"value": n * args.steps * world / e_n, "ms_per_step": e_n / args.steps * 1e3, "issue": nstep.note}
+        if e_n < elapsed:
+            # this block's backward is one long chain: two steps in flight contend more than they overlap (measured 1.45 vs 1.38 ms).  The line
+            # reports the faster issue mode and keeps the other beside it.
+            out["pipelined"] = {"value": out["value"], "ms_per_step": out["ms_per_step"], "issue": out["config"].get("issue")}
+            out["value"], out["ms_per_step"] = out["no_pipeline"]["value"], out["no_pipeline"]["ms_per_step"]
+            out["config"]["issue"] = nstep.note + " (one step at a time: faster than the software pipeline for this block)"
     if rank == 0:
         print(json.dumps(out), flush=True)
     return finish(world)
