@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void pospool_fwd_v4(unsigned n, int n0, int K,
                     acc.z = fmaf(sin_turns(fmaf(vax, sl.sc[2], sl.ph[2])), fk[u].z, acc.z);
                     acc.w = fmaf(sin_turns(fmaf(vax, sl.sc[3], sl.ph[3])), fk[u].w, acc.w);
                 } else {
-                    const float x = (rx[u] - qx) / radius, y = (ry[u] - qy) / radius, z = (rz[u] - qz) / radius;    // :68-70
+                    const float x = (rx[u] - qx) * inv_radius, y = (ry[u] - qy) * inv_radius, z = (rz[u] - qz) * inv_radius;    // :68-70 (one rounded reciprocal, within 1 ulp of the three divisions)
                     acc.x += eval_geo(g0, x, y, z) * fk[u].x;         // :230-235
                     acc.y += eval_geo(g1, x, y, z) * fk[u].y;
                     acc.z += eval_geo(g2, x, y, z) * fk[u].z;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void pospool_bwd_csr_kernel(unsigned n0, int C
                     acc.w = fmaf(g[u].w * sc[u], sin_turns(fmaf(vax, sl.sc[3], sl.ph[3])), acc.w);
                     continue;
                 }
-                const float x = (sx - rx[u]) / radius, y = (sy - ry[u]) / radius, z = (sz - rz[u]) / radius;      // :68-70
+                const float x = (sx - rx[u]) * inv_radius, y = (sy - ry[u]) * inv_radius, z = (sz - rz[u]) * inv_radius;      // :68-70
                 acc.x += (g[u].x * sc[u]) * eval_geo(g0, x, y, z);
                 acc.y += (g[u].y * sc[u]) * eval_geo(g1, x, y, z);
                 acc.z += (g[u].z * sc[u]) * eval_geo(g2, x, y, z);
