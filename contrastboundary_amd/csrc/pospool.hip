@@ -183,7 +183,8 @@ __device__ inline SinCosLane sincos_lane(int C, int cq)
 }
 __device__ __forceinline__ float sin_turns(float t) { return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(t)); }
 
-template <int U, bool SINCOS>
+// MODE 0: any embedding (eval_geo per channel); 1: 'sin_cos' (C % 12 == 0); 2: 'xyz' (C % 12 == 0: a lane's four channels multiply with ONE offset component)
+template <int U, int MODE>
 __global__ __launch_bounds__(256) void pospool_fwd_v4(unsigned n, int n0, int K, int C4, int c4_0, int L, const float* __restrict__ q, const float* __restrict__ s,
                                                       const int* __restrict__ idx, const float4* __restrict__ f, float radius, int pe, int reduction,
                                                       const int* __restrict__ padding_num, float4* __restrict__ out)
@@ -196,7 +197,8 @@ __global__ __launch_bounds__(256) void pospool_fwd_v4(unsigned n, int n0, int K,
     const int cq = c4_0 + cl;
     const LaneGeo g0 = decode_geo(pe, C, 4 * cq), g1 = decode_geo(pe, C, 4 * cq + 1), g2 = decode_geo(pe, C, 4 * cq + 2), g3 = decode_geo(pe, C, 4 * cq + 3);
     SinCosLane sl = {};
-    if (SINCOS) sl = sincos_lane(C, cq);
+    if (MODE == 1) sl = sincos_lane(C, cq);
+    if (MODE == 2) sl.axis = g0.ex ? 0 : (g0.ey ? 1 : 2);            // 'xyz': the monomial of this lane's channels is x, y or z
     const float inv_radius = 1.0f / radius;
     const unsigned ntrips = (n + tpb - 1) / tpb;
     const unsigned vend = 8 * cbl_xcd_per(ntrips);
@@ -230,7 +232,10 @@ __global__ __launch_bounds__(256) void pospool_fwd_v4(unsigned n, int n0, int K,
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 if (id[u] < 0) continue;                              // shadow neighbours: zero feature row, contribute nothing
-                if (SINCOS) {
+                if (MODE == 2) {
+                    const float vax = ((sl.axis == 0 ? rx[u] - qx : sl.axis == 1 ? ry[u] - qy : rz[u] - qz)) * inv_radius;
+                    acc.x = fmaf(vax, fk[u].x, acc.x); acc.y = fmaf(vax, fk[u].y, acc.y); acc.z = fmaf(vax, fk[u].z, acc.z); acc.w = fmaf(vax, fk[u].w, acc.w);
+                } else if (MODE == 1) {
                     const float vax = ((sl.axis == 0 ? rx[u] - qx : sl.axis == 1 ? ry[u] - qy : rz[u] - qz)) * inv_radius;
                     acc.x = fmaf(sin_turns(fmaf(vax, sl.sc[0], sl.ph[0])), fk[u].x, acc.x);
                     acc.y = fmaf(sin_turns(fmaf(vax, sl.sc[1], sl.ph[1])), fk[u].y, acc.y);
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(256) void pospool_inv_count_kernel(int n, int K, co
     }
 }
 
-template <bool SINCOS>
+template <int MODE>
 __global__ __launch_bounds__(256) void pospool_bwd_csr_kernel(unsigned n0, int C4, int c4_0, int L, CblFastDiv dvK, const float* __restrict__ q,
                                                               const float* __restrict__ s, float radius, int pe, const float* __restrict__ inv_nn,
                                                               const float4* __restrict__ go, const int* __restrict__ order,
@@ -279,7 +284,8 @@ __global__ __launch_bounds__(256) void pospool_bwd_csr_kernel(unsigned n0, int C
     const int cq = c4_0 + cl, C = 4 * C4;
     const LaneGeo g0 = decode_geo(pe, C, 4 * cq), g1 = decode_geo(pe, C, 4 * cq + 1), g2 = decode_geo(pe, C, 4 * cq + 2), g3 = decode_geo(pe, C, 4 * cq + 3);
     SinCosLane sl = {};
-    if (SINCOS) sl = sincos_lane(C, cq);
+    if (MODE == 1) sl = sincos_lane(C, cq);
+    if (MODE == 2) sl.axis = g0.ex ? 0 : (g0.ey ? 1 : 2);
     const float inv_radius = 1.0f / radius;
     const unsigned ntrips = (n0 + tpb - 1) / tpb;
     const unsigned vend = 8 * cbl_xcd_per(ntrips);
@@ -303,7 +309,12 @@ __global__ __launch_bounds__(256) void pospool_bwd_csr_kernel(unsigned n0, int C
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                if (SINCOS) {
+                if (MODE == 2) {
+                    const float vax = ((sl.axis == 0 ? sx - rx[u] : sl.axis == 1 ? sy - ry[u] : sz - rz[u])) * inv_radius * sc[u];
+                    acc.x = fmaf(g[u].x, vax, acc.x); acc.y = fmaf(g[u].y, vax, acc.y); acc.z = fmaf(g[u].z, vax, acc.z); acc.w = fmaf(g[u].w, vax, acc.w);
+                    continue;
+                }
+                if (MODE == 1) {
                     const float vax = ((sl.axis == 0 ? sx - rx[u] : sl.axis == 1 ? sy - ry[u] : sz - rz[u])) * inv_radius;
                     acc.x = fmaf(g[u].x * sc[u], sin_turns(fmaf(vax, sl.sc[0], sl.ph[0])), acc.x);
                     acc.y = fmaf(g[u].y * sc[u], sin_turns(fmaf(vax, sl.sc[1], sl.ph[1])), acc.y);
@@ -351,7 +362,7 @@ CBL_EXPORT int cbl_pospool_forward(int n, int n0, int K, int C, const float* que
 #define CBL_PPF(SC_) hipLaunchKernelGGL((pospool_fwd_v4<2, SC_>), dim3(g), dim3(256), 0, cbl_stream(stream), (unsigned)n, n0, K, C4, c4_0, L, query_points, support_points, \
                                neighbors_indices, reinterpret_cast<const float4*>(features), radius, position_embedding, reduction, padding_num, \
                                reinterpret_cast<float4*>(out))
-            if (position_embedding == PE_SIN_COS && C % 12 == 0) CBL_PPF(true); else CBL_PPF(false);
+            if (position_embedding == PE_SIN_COS && C % 12 == 0) CBL_PPF(1); else if (position_embedding == PE_XYZ && C % 12 == 0) CBL_PPF(2); else CBL_PPF(0);
 #undef CBL_PPF
         }
     }
@@ -402,7 +413,7 @@ CBL_EXPORT int cbl_pospool_backward_csr(int n, int n0, int K, int C, const float
 #define CBL_PPB(SC_) hipLaunchKernelGGL(pospool_bwd_csr_kernel<SC_>, dim3(g), dim3(256), 0, st, (unsigned)n0, C4, c4_0, L, dv, query_points, support_points, radius, \
                            position_embedding, inv_nn, reinterpret_cast<const float4*>(grad_out), order_dst, inv_start, inv_src, \
                            reinterpret_cast<float4*>(grad_features))
-        if (position_embedding == PE_SIN_COS && C % 12 == 0) CBL_PPB(true); else CBL_PPB(false);
+        if (position_embedding == PE_SIN_COS && C % 12 == 0) CBL_PPB(1); else if (position_embedding == PE_XYZ && C % 12 == 0) CBL_PPB(2); else CBL_PPB(0);
 #undef CBL_PPB
     }
     return cbl_status();
