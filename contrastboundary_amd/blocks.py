@@ -17,7 +17,7 @@ The per-point dense layers (q/k/v Linear, BatchNorm, ReLU, softmax over K) stay 
 import torch
 import torch.nn as nn
 
-from . import attention, dense, pointops
+from . import attention, dense, pointops, pt_layer
 
 
 class PointTransformerLayer(nn.Module):
@@ -36,13 +36,16 @@ class PointTransformerLayer(nn.Module):
                                       nn.BatchNorm1d(mid_planes // share_planes), nn.ReLU(inplace=True),
                                       nn.Linear(out_planes // share_planes, out_planes // share_planes))
         self.softmax = nn.Softmax(dim=1)
-        self.fused = True                                             # use csrc/attention.hip where it applies (attention.supported)
+        self.fused = True                                             # True: csrc/pt_layer.hip (C = 32 / 64, K = 8 / 16) else csrc/attention.hip where it applies; "split": attention.hip only; False: separate kernels
 
     def forward(self, pxo, idx=None) -> torch.Tensor:
         p, x, o = pxo                                                        # (n,3), (n,c), (b)
         x_q, x_k, x_v = dense.apply(self.linear_q, x), dense.apply(self.linear_k, x), dense.apply(self.linear_v, x)  # :33
         if idx is None:
             idx, _ = pointops.knnquery(self.nsample, p, p, o, o)              # once, not twice (:34-35)
+        if self.fused and self.fused != "split" and pt_layer.supported(self, x):
+            # the two full-resolution shapes: everything behind the three projections as one pass structure (csrc/pt_layer.hip)
+            return pt_layer.attention(self, p, x_q, x_k, x_v, idx)
         p_r = pointops.queryandgroup(self.nsample, p, p, p.new_zeros((p.shape[0], 0)), idx, o, o, use_xyz=True)   # (n,K,3) relative xyz
         if self.fused and attention.supported(self, x):
             # the C-wide part without its (n,K,C) tensors: only p1 (n,K,3) in and w2 (n,K,C/8) out exist (csrc/attention.hip)

@@ -1,0 +1,925 @@
+// a4: PointTransformerLayer's vector attention (C = 32 / 64, K = 8 / 16: the two full-resolution stages), one pass structure for the whole layer.
+// Reference: /root/reference/pytorch/model/blocks.py:31-44 (train-mode BatchNorms), with x_q / x_k / x_v = the three Linear layers' outputs (:33):
+//     p_r = p_j - p_i ; p0 = Linear(3,3)(p_r) ; p1 = ReLU(BN_p(p0))                              (n,K,3)
+//     pe  = Linear(3,C)(p1)                                                                       (n,K,C)   never stored
+//     w   = x_k[j] - x_q[i] + pe ; w1 = ReLU(BN_c(w)) ; w2 = Linear(C,G)(w1), G = C/8             (n,K,G)
+//     w3  = ReLU(BN_g(w2)) ; logits = Linear(G,G)(w3) ; a = softmax over K                        (n,K,G)
+//     out = sum_k (x_v[j] + pe) * a[.., c % G]                                                    (n,C)
+// The three train-mode BatchNorms are global synchronisation points; between them the layer is five passes over the (point, neighbour)
+// pairs in which every C-wide pair value lives in registers and is RECOMPUTED where it is needed again:
+//   forward   pchain (p_r, p0 + BN_p sums) | wstats (p1, BN_c sums) | w2 (+ BN_g sums) | softmax (narrow) | agg
+//   backward  agg_bwd (d logits) | narrow_bwd (d w2 before BN_g, its sums) | reduce (d w2, BN_c sums, d Wa) | apply (d x_q, d p1, d W3C)
+//             | pchain_bwd | target (d x_k, d x_v as gathers over the transposed neighbour table: no atomics)
+// A TILE is 16 consecutive pairs of the flat (n K) list (K = 16: one point, K = 8: two points) = the 16 rows / columns of
+// v_mfma_f32_16x16x4_f32; one wave owns a tile per trip.  With lo = lane % 16, hi = lane / 16 the kernels use two register layouts:
+//   "pair-major"    lane (lo, hi) holds pair slot lo, channels 16 ct + 4 hi + v   (16-byte loads of a row; the contraction index of an MFMA step
+//                   is hi, so sums over CHANNELS run on the matrix cores: w2 = Wa . w1)
+//   "channel-major" lane (lo, hi) holds channel 16 ct + lo of pair slots 4 hi + v (64-byte row segments; this is the D layout of the
+//                   instruction, and a D register fed back as the B operand contracts over PAIRS: the weight gradients d Wa, d W3C accumulate
+//                   in MFMA accumulators over all tiles of a wave with no vector instruction)
+// pe (a 4-term contraction with [p1, 1]) is ONE MFMA per 16 channels in either layout (operands swapped), its C input carrying x_k - x_q
+// (or x_v), so the chain w = ((((x_k - x_q) + W0 p1_0) + W1 p1_1) + W2 p1_2) + b has the same bits in every pass (the ReLU masks agree);
+// the target pass rebuilds it with fmaf in the same order.  Tiles are walked in the search's cell order, an XCD taking a contiguous eighth.
+// BatchNorm sums: per-workgroup partial rows, reduced in double by the finalize kernels in a fixed order (deterministic, no atomics).
+#include "cbl_common.h"
+#include <pt_wave.h>
+
+namespace {
+
+constexpr int PT_BLOCK = 512;                       // 8 waves; two workgroups per CU at <= 128 registers
+constexpr int PT_WPB = PT_BLOCK / 64;
+constexpr int PT_MAX_ROWS = 512;                    // partial rows of a pass = its workgroups
+constexpr int PT_NARROW_BLOCK = 256;
+
+// forward constants (floats) written by the finalize kernels, kept for the backward pass
+constexpr int PT_CST_P = 0;                         // [4][4]  scale, shift, mean, invstd of BN_p (3 channels)
+constexpr int PT_CST_C = 16;                        // [4][64] BN_c
+constexpr int PT_CST_G = 272;                       // [4][8]  BN_g
+constexpr int PT_FS_P = 304;                        // raw sums of the p chain: p0 [3], p0^2 [3], p_r [3], p0[a] p_r[b] [9]
+constexpr int PT_FS_G = 336;                        // raw sums of w2 [8]
+constexpr int PT_CST_FLOATS = 352;
+// backward constants: d x = A1 d y + A2 x + A3 per channel (BatchNorm backward with the batch means folded in)
+constexpr int PT_BC_G = 0;                          // [3][8]
+constexpr int PT_BC_C = 24;                         // [3][64]
+constexpr int PT_BC_FLOATS = 216;
+
+__device__ __forceinline__ float pt_row_sum(float v)            // over the 16 lanes of a row, result in every lane
+{
+    v += pt_quad_xor1(v); v += pt_quad_xor2(v); v += pt_half_mirror(v); v += pt_row_mirror(v);
+    return v;
+}
+__device__ __forceinline__ float pt_wave_sum(float v) { v = pt_row_sum(v); v += pt_xor16(v); v += pt_xor32(v); return v; }
+template <int K> __device__ __forceinline__ float pt_group_sum(float v)      // over K = 8 / 16 consecutive lanes
+{
+    v += pt_quad_xor1(v); v += pt_quad_xor2(v); v += pt_half_mirror(v);
+    if (K == 16) v += pt_row_mirror(v);
+    return v;
+}
+template <int K> __device__ __forceinline__ float pt_group_max(float v)
+{
+    v = fmaxf(v, pt_quad_xor1(v)); v = fmaxf(v, pt_quad_xor2(v)); v = fmaxf(v, pt_half_mirror(v));
+    if (K == 16) v = fmaxf(v, pt_row_mirror(v));
+    return v;
+}
+// sum over the pair slots of one point held channel-major: the rows hi of the point (K = 16: all four, K = 8: the two of its half)
+template <int K> __device__ __forceinline__ float pt_point_sum(float v)
+{
+    v += pt_xor16(v);
+    if (K == 16) v += pt_xor32(v);
+    return v;
+}
+
+// ---- tile geometry -------------------------------------------------------------------------------------------------------------------
+// slot s of tile t is pair (point = order[t * (16 / K) + s / K], k = s % K)
+struct PtSlot { int i; long long p; bool valid; };
+template <int K> __device__ __forceinline__ PtSlot pt_slot(unsigned tile, int s, int n, const int* __restrict__ order)
+{
+    const unsigned rank = tile * (16 / K) + (unsigned)(s / K);
+    PtSlot r;
+    r.valid = rank < (unsigned)n;
+    const unsigned rc = r.valid ? rank : (unsigned)(n - 1);
+    r.i = order ? order[rc] : (int)rc;
+    r.p = (long long)r.i * K + (s % K);
+    return r;
+}
+
+#define PT_TILE_LOOP(tile, ntiles)                                                                              \
+    const unsigned ntrips_ = ((ntiles) + PT_WPB - 1) / PT_WPB;                                                  \
+    for (unsigned v_ = blockIdx.x; v_ < 8u * cbl_xcd_per(ntrips_); v_ += gridDim.x)                             \
+        if (const unsigned tile = cbl_xcd_slot(v_, ntrips_) * PT_WPB + (threadIdx.x >> 6); tile < (ntiles))
+
+// ---- p chain: p_r, p0 and the sums of BN_p (lane = pair) ------------------------------------------------------------------------------
+// partial row: p0 [3] | p0^2 [3] | p_r [3] | p0[a] p_r[b] [9]   (the last two feed the Linear(3,3) gradient without another pass, pchain_bwd)
+__global__ __launch_bounds__(PT_NARROW_BLOCK) void pt_pchain_kernel(long long npairs, CblFastDiv dvK, const float* __restrict__ xyz, const int* __restrict__ idx,
+                                                                    const float* __restrict__ Wp, const float* __restrict__ bp, float* __restrict__ p_r,
+                                                                    float* __restrict__ p0, float* __restrict__ partial)
+{
+    __shared__ float red[PT_NARROW_BLOCK / 64][18];
+    float w[9], b[3], acc[18];
+#pragma unroll
+    for (int t = 0; t < 9; t++) w[t] = Wp[t];
+#pragma unroll
+    for (int t = 0; t < 3; t++) b[t] = bp[t];
+#pragma unroll
+    for (int t = 0; t < 18; t++) acc[t] = 0.f;
+    for (long long p = (long long)blockIdx.x * PT_NARROW_BLOCK + threadIdx.x; p < npairs; p += (long long)gridDim.x * PT_NARROW_BLOCK) {
+        const unsigned i = cbl_fastdiv((unsigned)p, dvK);
+        const int j = idx[p];
+        float r[3], q[3];
+#pragma unroll
+        for (int t = 0; t < 3; t++) r[t] = xyz[3 * (size_t)j + t] - xyz[3 * (size_t)i + t];
+#pragma unroll
+        for (int a = 0; a < 3; a++) q[a] = fmaf(w[3 * a + 2], r[2], fmaf(w[3 * a + 1], r[1], fmaf(w[3 * a], r[0], b[a])));
+#pragma unroll
+        for (int t = 0; t < 3; t++) { p_r[3 * p + t] = r[t]; p0[3 * p + t] = q[t]; acc[t] += q[t]; acc[3 + t] = fmaf(q[t], q[t], acc[3 + t]); acc[6 + t] += r[t]; }
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int t = 0; t < 3; t++) acc[9 + 3 * a + t] = fmaf(q[a], r[t], acc[9 + 3 * a + t]);
+    }
+#pragma unroll
+    for (int t = 0; t < 18; t++) { const float s = pt_wave_sum(acc[t]); if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][t] = s; }
+    __syncthreads();
+    if (threadIdx.x < 18) {
+        float s = 0.f;
+        for (int wv = 0; wv < PT_NARROW_BLOCK / 64; wv++) s += red[wv][threadIdx.x];
+        partial[(size_t)blockIdx.x * 18 + threadIdx.x] = s;
+    }
+}
+
+// ---- BatchNorm finalize: partial rows -> scale / shift / mean / invstd per channel (+ running statistics) ------------------------------
+// channel c sums partial[row * stride + off0 + c] and [.. off1 + c] over the rows in double, 16 channels x 16 row slices per workgroup
+__global__ __launch_bounds__(256) void pt_bn_finalize_kernel(int nrows, int stride, int off0, int off1, int Cn, long long rows, const float* __restrict__ partial,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                                                             float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                             long long* __restrict__ num_batches_tracked, float* __restrict__ cst, int cst_stride,
+                                                             float* __restrict__ raw0)
+{
+    __shared__ double red[16][16][2];
+    if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) num_batches_tracked[0] += 1;
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
+    double a0 = 0.0, a1 = 0.0;
+    if (c < Cn)
+        for (int r = sl; r < nrows; r += 16) { a0 += (double)partial[(size_t)r * stride + off0 + c]; a1 += (double)partial[(size_t)r * stride + off1 + c]; }
+    red[sl][cl][0] = a0; red[sl][cl][1] = a1;
+    __syncthreads();
+    if (sl == 0 && c < Cn) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int j = 0; j < 16; j++) { s0 += red[j][cl][0]; s1 += red[j][cl][1]; }
+        const double mu = s0 / (double)rows;
+        double var = s1 / (double)rows - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float scale = gamma[c] * invstd;
+        cst[c] = scale;
+        cst[cst_stride + c] = beta[c] - (float)mu * scale;
+        cst[2 * cst_stride + c] = (float)mu;
+        cst[3 * cst_stride + c] = invstd;
+        if (raw0) raw0[c] = (float)s0;
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+        if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(rows > 1 ? var * (double)rows / (double)(rows - 1) : var);
+    }
+}
+
+// BatchNorm backward finalize: S1 = sum dy, S2 = sum dy xhat  ->  dx = A1 dy + A2 x + A3;  d gamma = S2, d beta = S1
+// (dx = gamma invstd (dy - S1/N - xhat S2/N), xhat = (x - mean) invstd).   lin_bias_grad (optional): the gradient of a bias that feeds this
+// BatchNorm directly, sum over rows of dx = A1 S1 + A2 sum(x) + N A3 — analytically 0, returned as the rounding noise the unfused layer returns
+__global__ __launch_bounds__(256) void pt_bn_bwd_finalize_kernel(int nrows, int stride, int off0, int off1, int Cn, long long rows, const float* __restrict__ partial,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ cst, int cst_stride,
+                                                                 float* __restrict__ bc, int bc_stride, float* __restrict__ g_gamma, float* __restrict__ g_beta,
+                                                                 const float* __restrict__ raw_x, float* __restrict__ lin_bias_grad)
+{
+    __shared__ double red[16][16][2];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
+    double a0 = 0.0, a1 = 0.0;
+    if (c < Cn)
+        for (int r = sl; r < nrows; r += 16) { a0 += (double)partial[(size_t)r * stride + off0 + c]; a1 += (double)partial[(size_t)r * stride + off1 + c]; }
+    red[sl][cl][0] = a0; red[sl][cl][1] = a1;
+    __syncthreads();
+    if (sl == 0 && c < Cn) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int j = 0; j < 16; j++) { s1 += red[j][cl][0]; s2 += red[j][cl][1]; }
+        const double mean = (double)cst[2 * cst_stride + c], invstd = (double)cst[3 * cst_stride + c];
+        const double A1 = (double)gamma[c] * invstd, m1 = s1 / (double)rows, m2 = s2 / (double)rows;
+        const double A2 = -A1 * m2 * invstd, A3 = A1 * (m2 * invstd * mean - m1);
+        bc[c] = (float)A1; bc[bc_stride + c] = (float)A2; bc[2 * bc_stride + c] = (float)A3;
+        g_gamma[c] = (float)s2; g_beta[c] = (float)s1;
+        if (lin_bias_grad) lin_bias_grad[c] = (float)(A1 * s1 + A2 * (double)raw_x[c] + (double)rows * A3);
+    }
+}
+
+// plain column sums of partial rows (parameter gradients): out[seg.dst + t] = sum over rows of partial[row * stride + off + t]
+struct PtSumSeg { const float* src; float* dst; int nrows, stride, off, count; };
+struct PtSumSegs { PtSumSeg s[6]; int n; };
+__global__ __launch_bounds__(256) void pt_sum_rows_kernel(PtSumSegs segs)
+{
+    __shared__ double red[16][16];
+    int b = blockIdx.x;
+    for (int q = 0; q < segs.n; q++) {
+        const PtSumSeg sg = segs.s[q];
+        const int nb = (sg.count + 15) / 16;
+        if (b >= nb) { b -= nb; continue; }
+        const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4, c = b * 16 + cl;
+        double a = 0.0;
+        if (c < sg.count) for (int r = sl; r < sg.nrows; r += 16) a += (double)sg.src[(size_t)r * sg.stride + sg.off + c];
+        red[sl][cl] = a;
+        __syncthreads();
+        if (sl == 0 && c < sg.count) { double s = 0.0; for (int j = 0; j < 16; j++) s += red[j][cl]; sg.dst[c] = (float)s; }
+        return;
+    }
+}
+
+// ---- the C-wide pair chain ------------------------------------------------------------------------------------------------------------
+// Per-lane constant of the pe product: element (channel 16 ct + lo, d = hi) of [W3C | b3C]; the A operand of the pair-major form
+// (D[channel][pair]) and the B operand of the channel-major form (D[pair][channel]) are the same lane mapping.
+template <int C> struct PtPe { float w[C / 16]; };
+template <int C> __device__ __forceinline__ PtPe<C> pt_pe_load(const float* __restrict__ W3C, const float* __restrict__ b3C, int lo, int hi)
+{
+    PtPe<C> r;
+#pragma unroll
+    for (int ct = 0; ct < C / 16; ct++) r.w[ct] = hi < 3 ? W3C[3 * (16 * ct + lo) + hi] : b3C[16 * ct + lo];
+    return r;
+}
+
+// ---- BN_c statistics of w (pair-major); writes p1 ---------------------------------------------------------------------------------------
+// partial row: sum w [C] | sum w^2 [C]
+template <int C, int K>
+__global__ __launch_bounds__(PT_BLOCK) void pt_wstats_kernel(int n, const int* __restrict__ order, const float* __restrict__ xq, const float* __restrict__ xk,
+                                                             const int* __restrict__ idx, const float* __restrict__ p0, const float* __restrict__ cst,
+                                                             const float* __restrict__ W3C, const float* __restrict__ b3C, float* __restrict__ p1,
+                                                             float* __restrict__ partial)
+{
+    constexpr int CT = C / 16;
+    __shared__ float red[PT_WPB][2 * C];
+    const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4, wave = threadIdx.x >> 6;
+    const PtPe<C> pe = pt_pe_load<C>(W3C, b3C, lo, hi);
+    const float psc = hi < 3 ? cst[PT_CST_P + hi] : 0.f, psh = hi < 3 ? cst[PT_CST_P + 4 + hi] : 1.f;
+    float s0[CT][4], s1[CT][4];
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) { s0[ct][v] = 0.f; s1[ct][v] = 0.f; }
+    const unsigned ntiles = (unsigned)(((long long)n * K + 15) / 16);
+    PT_TILE_LOOP(tile, ntiles) {
+        const PtSlot sa = pt_slot<K>(tile, lo, n, order);
+        const int j = idx[sa.p];
+        // p1 of (pair, d = hi): this lane's B operand; hi = 3 carries the 1 that multiplies the bias
+        float p1x = 1.f;
+        if (hi < 3) { p1x = fmaxf(fmaf(p0[3 * sa.p + hi], psc, psh), 0.f); if (sa.valid) p1[3 * sa.p + hi] = p1x; }
+        const float4* kr = reinterpret_cast<const float4*>(xk + (size_t)j * C + 4 * hi);
+        const float4* qr = reinterpret_cast<const float4*>(xq + (size_t)sa.i * C + 4 * hi);
+        float4 kv[CT], qv[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) { kv[ct] = kr[4 * ct]; qv[ct] = qr[4 * ct]; }
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+            pt_f32x4 w = pt_vec4(kv[ct].x - qv[ct].x, kv[ct].y - qv[ct].y, kv[ct].z - qv[ct].z, kv[ct].w - qv[ct].w);
+            w = pt_mfma(pe.w[ct], p1x, w);
+            if (sa.valid) {
+#pragma unroll
+                for (int v = 0; v < 4; v++) { s0[ct][v] += w[v]; s1[ct][v] = fmaf(w[v], w[v], s1[ct][v]); }
+            }
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const float a = pt_row_sum(s0[ct][v]), b = pt_row_sum(s1[ct][v]);
+            if (lo == 0) { red[wave][16 * ct + 4 * hi + v] = a; red[wave][C + 16 * ct + 4 * hi + v] = b; }
+        }
+    __syncthreads();
+    if (threadIdx.x < 2 * C) {
+        float s = 0.f;
+        for (int wv = 0; wv < PT_WPB; wv++) s += red[wv][threadIdx.x];
+        partial[(size_t)blockIdx.x * (2 * C) + threadIdx.x] = s;
+    }
+}
+
+// ---- w2 = Wa . ReLU(BN_c(w)) + ba (pair-major, the C -> G contraction on the matrix cores) + the sums of BN_g ----------------------------
+// partial row: sum w2 [G] | sum w2^2 [G]
+template <int C, int K>
+__global__ __launch_bounds__(PT_BLOCK) void pt_w2_kernel(int n, const int* __restrict__ order, const float* __restrict__ xq, const float* __restrict__ xk,
+                                                         const int* __restrict__ idx, const float* __restrict__ p1, const float* __restrict__ cst,
+                                                         const float* __restrict__ W3C, const float* __restrict__ b3C, const float* __restrict__ Wa,
+                                                         const float* __restrict__ ba, float* __restrict__ w2, float* __restrict__ partial)
+{
+    constexpr int CT = C / 16, G = C / 8;
+    __shared__ float red[PT_WPB][2 * G];
+    const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4, wave = threadIdx.x >> 6;
+    const PtPe<C> pe = pt_pe_load<C>(W3C, b3C, lo, hi);
+    float4 sc[CT], sh[CT], wb[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) {
+        sc[ct] = *reinterpret_cast<const float4*>(cst + PT_CST_C + 16 * ct + 4 * hi);
+        sh[ct] = *reinterpret_cast<const float4*>(cst + PT_CST_C + 64 + 16 * ct + 4 * hi);
+        wb[ct] = lo < G ? *reinterpret_cast<const float4*>(Wa + (size_t)lo * C + 16 * ct + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);   // B[k = hi][col = g]
+    }
+    const float bias = lo < G ? ba[lo] : 0.f;
+    float t0 = 0.f, t1 = 0.f;
+    const unsigned ntiles = (unsigned)(((long long)n * K + 15) / 16);
+    PT_TILE_LOOP(tile, ntiles) {
+        const PtSlot sa = pt_slot<K>(tile, lo, n, order);
+        const PtSlot sd = pt_slot<K>(tile, 4 * hi, n, order);
+        const int j = idx[sa.p];
+        const float p1x = hi < 3 ? p1[3 * sa.p + hi] : 1.f;
+        const float4* kr = reinterpret_cast<const float4*>(xk + (size_t)j * C + 4 * hi);
+        const float4* qr = reinterpret_cast<const float4*>(xq + (size_t)sa.i * C + 4 * hi);
+        float4 kv[CT], qv[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) { kv[ct] = kr[4 * ct]; qv[ct] = qr[4 * ct]; }
+        pt_f32x4 o0 = pt_vec4(bias, bias, bias, bias), o1 = pt_vec4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+            pt_f32x4 w = pt_vec4(kv[ct].x - qv[ct].x, kv[ct].y - qv[ct].y, kv[ct].z - qv[ct].z, kv[ct].w - qv[ct].w);
+            w = pt_mfma(pe.w[ct], p1x, w);
+            o0 = pt_mfma(fmaxf(fmaf(w[0], sc[ct].x, sh[ct].x), 0.f), wb[ct].x, o0);
+            o1 = pt_mfma(fmaxf(fmaf(w[1], sc[ct].y, sh[ct].y), 0.f), wb[ct].y, o1);
+            o0 = pt_mfma(fmaxf(fmaf(w[2], sc[ct].z, sh[ct].z), 0.f), wb[ct].z, o0);
+            o1 = pt_mfma(fmaxf(fmaf(w[3], sc[ct].w, sh[ct].w), 0.f), wb[ct].w, o1);
+        }
+        // D[pair slot 4 hi + v][g = lo]
+        if (lo < G && sd.valid) {
+#pragma unroll
+            for (int v = 0; v < 4; v++) { const float r = o0[v] + o1[v]; w2[(sd.p + v) * G + lo] = r; t0 += r; t1 = fmaf(r, r, t1); }
+        }
+    }
+    t0 += pt_xor16(t0); t0 += pt_xor32(t0); t1 += pt_xor16(t1); t1 += pt_xor32(t1);
+    if (hi == 0 && lo < G) { red[wave][lo] = t0; red[wave][G + lo] = t1; }
+    __syncthreads();
+    if (threadIdx.x < 2 * G) {
+        float s = 0.f;
+        for (int wv = 0; wv < PT_WPB; wv++) s += red[wv][threadIdx.x];
+        partial[(size_t)blockIdx.x * (2 * G) + threadIdx.x] = s;
+    }
+}
+
+// ---- narrow forward: a = softmax over K of Linear(G,G)(ReLU(BN_g(w2)))   (lane = pair; the K pairs of a point are K consecutive lanes) ----
+template <int G, int K>
+__global__ __launch_bounds__(PT_NARROW_BLOCK) void pt_softmax_kernel(long long npairs, const float* __restrict__ w2, const float* __restrict__ cst,
+                                                                     const float* __restrict__ Wb, const float* __restrict__ bb, float* __restrict__ a)
+{
+    float sc[G], sh[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) { sc[g] = cst[PT_CST_G + g]; sh[g] = cst[PT_CST_G + 8 + g]; }
+    const long long span = (npairs + 63) & ~63ll;                   // whole waves: the group moves need every lane
+    for (long long pp = (long long)blockIdx.x * PT_NARROW_BLOCK + threadIdx.x; pp < span; pp += (long long)gridDim.x * PT_NARROW_BLOCK) {
+        const bool valid = pp < npairs;
+        const long long p = valid ? pp : npairs - 1;
+        float x[G], l[G];
+#pragma unroll
+        for (int q = 0; q < G / 4; q++) {
+            const float4 t = *reinterpret_cast<const float4*>(w2 + p * G + 4 * q);
+            x[4 * q] = t.x; x[4 * q + 1] = t.y; x[4 * q + 2] = t.z; x[4 * q + 3] = t.w;
+        }
+#pragma unroll
+        for (int g = 0; g < G; g++) x[g] = fmaxf(fmaf(x[g], sc[g], sh[g]), 0.f);
+#pragma unroll
+        for (int o = 0; o < G; o++) {
+            float s = bb[o];
+#pragma unroll
+            for (int g = 0; g < G; g++) s = fmaf(Wb[o * G + g], x[g], s);
+            const float m = pt_group_max<K>(s);
+            const float e = expf(s - m);
+            l[o] = e / pt_group_sum<K>(e);
+        }
+        if (valid) {
+#pragma unroll
+            for (int q = 0; q < G / 4; q++) *reinterpret_cast<float4*>(a + p * G + 4 * q) = make_float4(l[4 * q], l[4 * q + 1], l[4 * q + 2], l[4 * q + 3]);
+        }
+    }
+}
+
+// ---- aggregation (channel-major): out[i, c] = sum_k (x_v[j] + pe) a[.., c % G] ---------------------------------------------------------
+// BWD: also d logits = a (d a - sum_k a d a) with d a[k, g] = sum over c = g (mod G) of d out[c] (x_v[j, c] + pe[c])
+template <int C, int K, bool BWD>
+__global__ __launch_bounds__(PT_BLOCK) void pt_agg_kernel(int n, const int* __restrict__ order, const float* __restrict__ xv, const int* __restrict__ idx,
+                                                          const float* __restrict__ p1, const float* __restrict__ W3C, const float* __restrict__ b3C,
+                                                          const float* __restrict__ a, float* __restrict__ out, const float* __restrict__ gout,
+                                                          float* __restrict__ glogit)
+{
+    constexpr int CT = C / 16, G = C / 8;
+    const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+    const PtPe<C> pe = pt_pe_load<C>(W3C, b3C, lo, hi);
+    const unsigned ntiles = (unsigned)(((long long)n * K + 15) / 16);
+    PT_TILE_LOOP(tile, ntiles) {
+        const PtSlot sa = pt_slot<K>(tile, lo, n, order);
+        const PtSlot sd = pt_slot<K>(tile, 4 * hi, n, order);
+        const float p1x = hi < 3 ? p1[3 * sa.p + hi] : 1.f;                      // A[pair slot lo][d = hi]
+        const int4 j4 = *reinterpret_cast<const int4*>(idx + sd.p);
+        const int jv[4] = {j4.x, j4.y, j4.z, j4.w};
+        float av[4];
+#pragma unroll
+        for (int v = 0; v < 4; v++) av[v] = a[(sd.p + v) * G + (lo % G)];
+        pt_f32x4 val[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+            val[ct] = pt_vec4(xv[(size_t)jv[0] * C + 16 * ct + lo], xv[(size_t)jv[1] * C + 16 * ct + lo], xv[(size_t)jv[2] * C + 16 * ct + lo],
+                              xv[(size_t)jv[3] * C + 16 * ct + lo]);
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) val[ct] = pt_mfma(p1x, pe.w[ct], val[ct]);           // x_v[j] + pe of (slot 4 hi + v, channel 16 ct + lo)
+        if (!BWD) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++) {
+                float o = fmaf(av[3], val[ct][3], fmaf(av[2], val[ct][2], fmaf(av[1], val[ct][1], av[0] * val[ct][0])));
+                o = pt_point_sum<K>(o);
+                if (sd.valid && (K == 16 ? hi == 0 : (hi & 1) == 0)) out[(size_t)sd.i * C + 16 * ct + lo] = o;
+            }
+        } else {
+            float ga[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++) {
+                const float go = gout[(size_t)sd.i * C + 16 * ct + lo];
+#pragma unroll
+                for (int v = 0; v < 4; v++) ga[v] = fmaf(go, val[ct][v], ga[v]);
+            }
+            float dot = 0.f;
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                ga[v] += pt_row_ror8(ga[v]);                                     // the lanes lo = g (mod G)
+                if (G == 4) ga[v] += pt_row_ror4(ga[v]);
+                dot = fmaf(av[v], ga[v], dot);
+            }
+            dot = pt_point_sum<K>(dot);
+            if (lo < G && sd.valid) {
+#pragma unroll
+                for (int v = 0; v < 4; v++) glogit[(sd.p + v) * G + lo] = av[v] * (ga[v] - dot);
+            }
+        }
+    }
+}
+
+// ---- narrow backward (lane = pair): d w2 BEFORE BN_g's backward, its two sums, d Wb, d bb ------------------------------------------------
+// partial row: S1 [G] | S2 [G] | d Wb [G][G] | d bb [G]
+template <int G>
+__global__ __launch_bounds__(PT_NARROW_BLOCK) void pt_narrow_bwd_kernel(long long npairs, const float* __restrict__ w2, const float* __restrict__ cst,
+                                                                        const float* __restrict__ Wb, const float* __restrict__ glogit, float* __restrict__ pre,
+                                                                        float* __restrict__ partial)
+{
+    constexpr int W = 3 * G + G * G;
+    __shared__ float red[PT_NARROW_BLOCK / 64][W];
+    float sc[G], sh[G], is[G], nm[G], acc[W];
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        sc[g] = cst[PT_CST_G + g]; sh[g] = cst[PT_CST_G + 8 + g]; is[g] = cst[PT_CST_G + 24 + g]; nm[g] = -cst[PT_CST_G + 16 + g] * is[g];
+    }
+#pragma unroll
+    for (int t = 0; t < W; t++) acc[t] = 0.f;
+    for (long long p = (long long)blockIdx.x * PT_NARROW_BLOCK + threadIdx.x; p < npairs; p += (long long)gridDim.x * PT_NARROW_BLOCK) {
+        float x[G], gl[G], y[G];
+#pragma unroll
+        for (int q = 0; q < G / 4; q++) {
+            const float4 t = *reinterpret_cast<const float4*>(w2 + p * G + 4 * q), u = *reinterpret_cast<const float4*>(glogit + p * G + 4 * q);
+            x[4 * q] = t.x; x[4 * q + 1] = t.y; x[4 * q + 2] = t.z; x[4 * q + 3] = t.w;
+            gl[4 * q] = u.x; gl[4 * q + 1] = u.y; gl[4 * q + 2] = u.z; gl[4 * q + 3] = u.w;
+        }
+        float out[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            y[g] = fmaf(x[g], sc[g], sh[g]);
+            float s = 0.f;
+#pragma unroll
+            for (int o = 0; o < G; o++) s = fmaf(Wb[o * G + g], gl[o], s);
+            const float d = y[g] > 0.f ? s : 0.f;
+            out[g] = d;
+            acc[g] += d; acc[G + g] = fmaf(d, fmaf(x[g], is[g], nm[g]), acc[G + g]);
+        }
+#pragma unroll
+        for (int o = 0; o < G; o++) {
+#pragma unroll
+            for (int g = 0; g < G; g++) acc[2 * G + o * G + g] = fmaf(gl[o], fmaxf(y[g], 0.f), acc[2 * G + o * G + g]);
+            acc[2 * G + G * G + o] += gl[o];
+        }
+#pragma unroll
+        for (int q = 0; q < G / 4; q++) *reinterpret_cast<float4*>(pre + p * G + 4 * q) = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+    }
+#pragma unroll
+    for (int t = 0; t < W; t++) { const float s = pt_wave_sum(acc[t]); if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][t] = s; }
+    __syncthreads();
+    for (int t = threadIdx.x; t < W; t += PT_NARROW_BLOCK) {
+        float s = 0.f;
+        for (int wv = 0; wv < PT_NARROW_BLOCK / 64; wv++) s += red[wv][t];
+        partial[(size_t)blockIdx.x * W + t] = s;
+    }
+}
+
+// ---- the two C-wide backward passes (channel-major) -----------------------------------------------------------------------------------
+// REDUCE: d w2 = BN_g backward of `pre` (written for the later passes); d y1 = mask . Wa^T d w2; sums S1 = sum d y1, S2 = sum d y1 what per channel;
+//         d Wa[g, c] = sum over pairs of d w2[g] w1[c] in MFMA accumulators.        partial row: S1 [C] | S2 [C] | d Wa [G][C]
+// APPLY:  d w = A1 d y1 + A2 w + A3; d x_q = - sum_k d w; d pe = d w + d out . a; d p1 = W3C^T d pe; d [W3C | b3C] = sum over pairs of d pe (x) [p1, 1].
+//         partial row: d W3C [C][3] | d b3C [C]
+template <int C, int K, bool APPLY>
+__global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* __restrict__ order, const float* __restrict__ xq, const float* __restrict__ xk,
+                                                             const int* __restrict__ idx, const float* __restrict__ p1, const float* __restrict__ cst,
+                                                             const float* __restrict__ bc, const float* __restrict__ W3C, const float* __restrict__ b3C,
+                                                             const float* __restrict__ Wa, const float* __restrict__ w2, const float* __restrict__ pre,
+                                                             float* __restrict__ gw2, const float* __restrict__ a, const float* __restrict__ gout,
+                                                             float* __restrict__ gxq, float* __restrict__ gp1, float* __restrict__ partial)
+{
+    constexpr int CT = C / 16, G = C / 8;
+    constexpr int W = APPLY ? 4 * C : 2 * C + G * C;
+    __shared__ float red[PT_WPB][W];
+    const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4, wave = threadIdx.x >> 6;
+    const PtPe<C> pe = pt_pe_load<C>(W3C, b3C, lo, hi);
+    float sc[CT], sh[CT], k1[CT], k2[CT], k3[CT], wa0[CT], wa1[CT], w3[CT][3];
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) {
+        const int c = 16 * ct + lo;
+        sc[ct] = cst[PT_CST_C + c]; sh[ct] = cst[PT_CST_C + 64 + c];
+        if (APPLY) {
+            k1[ct] = bc[PT_BC_C + c]; k2[ct] = bc[PT_BC_C + 64 + c]; k3[ct] = bc[PT_BC_C + 128 + c];
+#pragma unroll
+            for (int d = 0; d < 3; d++) w3[ct][d] = W3C[3 * c + d];
+        } else {
+            k1[ct] = cst[PT_CST_C + 192 + c];                                    // invstd
+            k2[ct] = -cst[PT_CST_C + 128 + c] * k1[ct];                          // - mean invstd
+        }
+        wa0[ct] = hi < G ? Wa[(size_t)hi * C + c] : 0.f;                         // B[k = g][col = channel]
+        wa1[ct] = G == 8 ? Wa[(size_t)(hi + 4) * C + c] : 0.f;
+    }
+    // BN_g backward constants of the narrow values this lane forms: g = hi, hi + 4 (pair-major operand of d y) and g = lo (operand of d Wa)
+    float ga1[3] = {0.f, 0.f, 0.f}, ga2[3] = {0.f, 0.f, 0.f}, ga3[3] = {0.f, 0.f, 0.f};
+    if (!APPLY) {
+        const int gs[3] = {hi, hi + 4, lo};
+#pragma unroll
+        for (int t = 0; t < 3; t++)
+            if (gs[t] < G) { ga1[t] = bc[PT_BC_G + gs[t]]; ga2[t] = bc[PT_BC_G + 8 + gs[t]]; ga3[t] = bc[PT_BC_G + 16 + gs[t]]; }
+    }
+    float s1[CT], s2[CT];
+    pt_f32x4 accw[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) { s1[ct] = 0.f; s2[ct] = 0.f; accw[ct] = pt_vec4(0.f, 0.f, 0.f, 0.f); }
+    const unsigned ntiles = (unsigned)(((long long)n * K + 15) / 16);
+    PT_TILE_LOOP(tile, ntiles) {
+        const PtSlot sa = pt_slot<K>(tile, lo, n, order);
+        const PtSlot sd = pt_slot<K>(tile, 4 * hi, n, order);
+        const float p1x = hi < 3 ? p1[3 * sa.p + hi] : 1.f;
+        // d w2 of (pair slot lo, g = hi / hi + 4): the A operand of d y = d w2 . Wa
+        float da0 = 0.f, da1 = 0.f;
+        if (APPLY) {
+            if (sa.valid && hi < G) da0 = gw2[sa.p * G + hi];
+            if (sa.valid && G == 8) da1 = gw2[sa.p * G + hi + 4];
+        } else {
+            if (sa.valid && hi < G) { da0 = fmaf(ga1[0], pre[sa.p * G + hi], fmaf(ga2[0], w2[sa.p * G + hi], ga3[0])); gw2[sa.p * G + hi] = da0; }
+            if (sa.valid && G == 8) { da1 = fmaf(ga1[1], pre[sa.p * G + hi + 4], fmaf(ga2[1], w2[sa.p * G + hi + 4], ga3[1])); gw2[sa.p * G + hi + 4] = da1; }
+        }
+        const int4 j4 = *reinterpret_cast<const int4*>(idx + sd.p);
+        const int jv[4] = {j4.x, j4.y, j4.z, j4.w};
+        pt_f32x4 w[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+            const float q = xq[(size_t)sd.i * C + 16 * ct + lo];
+            w[ct] = pt_vec4(xk[(size_t)jv[0] * C + 16 * ct + lo] - q, xk[(size_t)jv[1] * C + 16 * ct + lo] - q, xk[(size_t)jv[2] * C + 16 * ct + lo] - q,
+                            xk[(size_t)jv[3] * C + 16 * ct + lo] - q);
+        }
+        // the narrow operands held per (slot 4 hi + v): REDUCE d w2[.., g = lo] (A of d Wa), APPLY [p1, 1][.., d = lo] (A of d W3C) and a[.., lo % G]
+        float nv[4], av[4];
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            nv[v] = 0.f; av[v] = 0.f;
+            if (APPLY) {
+                if (sd.valid) { nv[v] = lo < 3 ? p1[3 * (sd.p + v) + lo] : (lo == 3 ? 1.f : 0.f); av[v] = a[(sd.p + v) * G + (lo % G)]; }
+            } else {
+                if (sd.valid && lo < G) nv[v] = fmaf(ga1[2], pre[(sd.p + v) * G + lo], fmaf(ga2[2], w2[(sd.p + v) * G + lo], ga3[2]));
+            }
+        }
+        float t3[4][3];
+#pragma unroll
+        for (int v = 0; v < 4; v++) { t3[v][0] = 0.f; t3[v][1] = 0.f; t3[v][2] = 0.f; }
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+            w[ct] = pt_mfma(p1x, pe.w[ct], w[ct]);
+            pt_f32x4 gy = pt_mfma(da0, wa0[ct], pt_vec4(0.f, 0.f, 0.f, 0.f));
+            if (G == 8) gy = pt_mfma(da1, wa1[ct], gy);
+            const float go = APPLY ? gout[(size_t)sd.i * C + 16 * ct + lo] : 0.f;
+            float sq = 0.f;
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const float y = fmaf(w[ct][v], sc[ct], sh[ct]);
+                const float g1 = y > 0.f ? gy[v] : 0.f;
+                if (APPLY) {
+                    const float dw = sd.valid ? fmaf(k1[ct], g1, fmaf(k2[ct], w[ct][v], k3[ct])) : 0.f;
+                    sq += dw;
+                    const float dpe = fmaf(go, av[v], dw);
+#pragma unroll
+                    for (int d = 0; d < 3; d++) t3[v][d] = fmaf(w3[ct][d], dpe, t3[v][d]);
+                    accw[ct] = pt_mfma(nv[v], dpe, accw[ct]);                   // D[d][channel] += [p1, 1][slot][d] d pe[slot][channel]
+                } else {
+                    if (sd.valid) { s1[ct] += g1; s2[ct] = fmaf(g1, fmaf(w[ct][v], k1[ct], k2[ct]), s2[ct]); }
+                    accw[ct] = pt_mfma(nv[v], fmaxf(y, 0.f), accw[ct]);          // D[g][channel] += d w2[slot][g] w1[slot][channel]
+                }
+            }
+            if (APPLY) {
+                sq = pt_point_sum<K>(sq);
+                if (sd.valid && (K == 16 ? hi == 0 : (hi & 1) == 0)) gxq[(size_t)sd.i * C + 16 * ct + lo] = -sq;
+            }
+        }
+        if (APPLY) {
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const float r0 = pt_row_sum(t3[v][0]), r1 = pt_row_sum(t3[v][1]), r2 = pt_row_sum(t3[v][2]);
+                if (sd.valid && lo < 3) gp1[3 * (sd.p + v) + lo] = lo == 0 ? r0 : (lo == 1 ? r1 : r2);
+            }
+        }
+    }
+    // workgroup partial row
+    if (APPLY) {
+        // accw: D[d = 4 hi + v][channel 16 ct + lo], rows d < 4 live in hi = 0; stored as torch lays out Linear(3, C): weight [c][d], then the bias
+        if (hi == 0) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++) {
+#pragma unroll
+                for (int v = 0; v < 3; v++) red[wave][3 * (16 * ct + lo) + v] = accw[ct][v];
+                red[wave][3 * C + 16 * ct + lo] = accw[ct][3];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+            float a1 = s1[ct] + pt_xor16(s1[ct]), a2 = s2[ct] + pt_xor16(s2[ct]);
+            a1 += pt_xor32(a1); a2 += pt_xor32(a2);
+            if (hi == 0) { red[wave][16 * ct + lo] = a1; red[wave][C + 16 * ct + lo] = a2; }
+#pragma unroll
+            for (int v = 0; v < 4; v++)
+                if (4 * hi + v < G) red[wave][2 * C + (4 * hi + v) * C + 16 * ct + lo] = accw[ct][v];
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < W; t += PT_BLOCK) {
+        float s = 0.f;
+        for (int wv = 0; wv < PT_WPB; wv++) s += red[wv][t];
+        partial[(size_t)blockIdx.x * W + t] = s;
+    }
+}
+
+// ---- p chain backward (lane = pair): the sums BN_p's backward and Linear(3,3)'s gradient need -------------------------------------------
+// partial row: T1[a] = sum d, T2[a] = sum d p0hat[a], T3[a][b] = sum d[a] p_r[b]   with d = (p1 > 0) d p1
+__global__ __launch_bounds__(PT_NARROW_BLOCK) void pt_pchain_bwd_kernel(long long npairs, const float* __restrict__ p_r, const float* __restrict__ p0,
+                                                                        const float* __restrict__ p1, const float* __restrict__ gp1, const float* __restrict__ cst,
+                                                                        float* __restrict__ partial)
+{
+    __shared__ float red[PT_NARROW_BLOCK / 64][15];
+    float is[3], nm[3], acc[15];
+#pragma unroll
+    for (int t = 0; t < 3; t++) { is[t] = cst[PT_CST_P + 12 + t]; nm[t] = -cst[PT_CST_P + 8 + t] * is[t]; }
+#pragma unroll
+    for (int t = 0; t < 15; t++) acc[t] = 0.f;
+    for (long long p = (long long)blockIdx.x * PT_NARROW_BLOCK + threadIdx.x; p < npairs; p += (long long)gridDim.x * PT_NARROW_BLOCK) {
+        float d[3], r[3];
+#pragma unroll
+        for (int t = 0; t < 3; t++) { d[t] = p1[3 * p + t] > 0.f ? gp1[3 * p + t] : 0.f; r[t] = p_r[3 * p + t]; }
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            acc[a] += d[a]; acc[3 + a] = fmaf(d[a], fmaf(p0[3 * p + a], is[a], nm[a]), acc[3 + a]);
+#pragma unroll
+            for (int b = 0; b < 3; b++) acc[6 + 3 * a + b] = fmaf(d[a], r[b], acc[6 + 3 * a + b]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 15; t++) { const float s = pt_wave_sum(acc[t]); if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][t] = s; }
+    __syncthreads();
+    if (threadIdx.x < 15) {
+        float s = 0.f;
+        for (int wv = 0; wv < PT_NARROW_BLOCK / 64; wv++) s += red[wv][threadIdx.x];
+        partial[(size_t)blockIdx.x * 15 + threadIdx.x] = s;
+    }
+}
+
+// one workgroup: gradients of Linear(3,3) and BN_p from the backward sums T and the forward sums (BatchNorm's backward is linear in d)
+__global__ __launch_bounds__(64) void pt_pchain_epilogue_kernel(int nrows, const float* __restrict__ partial, long long rows, const float* __restrict__ cst,
+                                                                const float* __restrict__ gamma_p, float* __restrict__ g_Wp, float* __restrict__ g_bp,
+                                                                float* __restrict__ g_gamma_p, float* __restrict__ g_beta_p)
+{
+    __shared__ double T[15];
+    if (threadIdx.x < 15) {
+        double s = 0.0;
+        for (int r = 0; r < nrows; r++) s += (double)partial[(size_t)r * 15 + threadIdx.x];
+        T[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        const double N = (double)rows, mean = (double)cst[PT_CST_P + 8 + a], invstd = (double)cst[PT_CST_P + 12 + a];
+        const double A = (double)gamma_p[a] * invstd, m1 = T[a] / N, m2 = T[3 + a] / N;
+        g_gamma_p[a] = (float)T[3 + a]; g_beta_p[a] = (float)T[a];
+        const double sum_p0 = (double)cst[PT_FS_P + a];
+        // d p0 = A (d - m1 - p0hat m2):   sum d p0 = A (T1 - N m1 - m2 sum p0hat),   sum d p0[a] p_r[b] = A (T3 - m1 R[b] - m2 Q[a][b])
+        g_bp[a] = (float)(A * (T[a] - N * m1 - m2 * invstd * (sum_p0 - N * mean)));
+        for (int b = 0; b < 3; b++) {
+            const double R = (double)cst[PT_FS_P + 6 + b], X = (double)cst[PT_FS_P + 9 + 3 * a + b];
+            g_Wp[3 * a + b] = (float)(A * (T[6 + 3 * a + b] - m1 * R - m2 * invstd * (X - mean * R)));
+        }
+    }
+}
+
+// copies the raw forward sums of the p chain next to the constants (the epilogue above reads them in the backward pass)
+__global__ __launch_bounds__(64) void pt_pchain_raw_kernel(int nrows, const float* __restrict__ partial, float* __restrict__ cst)
+{
+    if (threadIdx.x < 18) {
+        double s = 0.0;
+        for (int r = 0; r < nrows; r++) s += (double)partial[(size_t)r * 18 + threadIdx.x];
+        cst[PT_FS_P + threadIdx.x] = (float)s;
+    }
+}
+
+// ---- target pass: d x_k[j] and d x_v[j] as gathers over the transposed neighbour table -----------------------------------------------
+// C / 4 lanes own a target row (lane = 4 channels); the pairs that list the target are walked in ascending order; the chain of a pair is
+// rebuilt from the target's own x_k row, x_q[i], p1 and d w2 with the fmaf order of the matrix instruction (same w bits, same ReLU mask).
+template <int C, int K>
+__global__ __launch_bounds__(256) void pt_target_kernel(unsigned n, const int* __restrict__ order, const int* __restrict__ inv_start, const int* __restrict__ inv_src,
+                                                        const float* __restrict__ xq, const float* __restrict__ xk, const float* __restrict__ p1,
+                                                        const float* __restrict__ cst, const float* __restrict__ bc, const float* __restrict__ W3C,
+                                                        const float* __restrict__ b3C, const float* __restrict__ Wa, const float* __restrict__ gw2,
+                                                        const float* __restrict__ a, const float* __restrict__ gout, float* __restrict__ gxk, float* __restrict__ gxv)
+{
+    constexpr int LPR = C / 4, G = C / 8, TPB = 256 / LPR;
+    const int m = threadIdx.x % LPR, grp = threadIdx.x / LPR, c0 = 4 * m;
+    float w0[4], w1[4], w2c[4], wbias[4], sc[4], sh[4], k1[4], k2[4], k3[4], wa[G][4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int c = c0 + e;
+        w0[e] = W3C[3 * c]; w1[e] = W3C[3 * c + 1]; w2c[e] = W3C[3 * c + 2]; wbias[e] = b3C[c];
+        sc[e] = cst[PT_CST_C + c]; sh[e] = cst[PT_CST_C + 64 + c];
+        k1[e] = bc[PT_BC_C + c]; k2[e] = bc[PT_BC_C + 64 + c]; k3[e] = bc[PT_BC_C + 128 + c];
+#pragma unroll
+        for (int g = 0; g < G; g++) wa[g][e] = Wa[(size_t)g * C + c];
+    }
+    const unsigned ntrips = (n + TPB - 1) / TPB;
+    for (unsigned v = blockIdx.x; v < 8u * cbl_xcd_per(ntrips); v += gridDim.x) {
+        const unsigned tr = cbl_xcd_slot(v, ntrips) * TPB + grp;
+        if (tr >= n) continue;
+        const int j = order ? order[tr] : (int)tr;
+        const int e0 = inv_start[tr], e1 = inv_start[tr + 1];
+        const float4 kj = *reinterpret_cast<const float4*>(xk + (size_t)j * C + c0);
+        const float kx[4] = {kj.x, kj.y, kj.z, kj.w};
+        float ak[4] = {0.f, 0.f, 0.f, 0.f}, av[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int e = e0; e < e1; e++) {
+            const unsigned p = (unsigned)inv_src[e];
+            const unsigned i = p / (unsigned)K;
+            const float4 q4 = *reinterpret_cast<const float4*>(xq + (size_t)i * C + c0);
+            const float4 g4 = *reinterpret_cast<const float4*>(gout + (size_t)i * C + c0);
+            const float4 a4 = *reinterpret_cast<const float4*>(a + (size_t)p * G + (c0 % G));
+            const float b0 = p1[3 * (size_t)p], b1 = p1[3 * (size_t)p + 1], b2 = p1[3 * (size_t)p + 2];
+            float dv[G];
+#pragma unroll
+            for (int q = 0; q < G / 4; q++) {
+                const float4 t = *reinterpret_cast<const float4*>(gw2 + (size_t)p * G + 4 * q);
+                dv[4 * q] = t.x; dv[4 * q + 1] = t.y; dv[4 * q + 2] = t.z; dv[4 * q + 3] = t.w;
+            }
+            const float qx[4] = {q4.x, q4.y, q4.z, q4.w}, gx[4] = {g4.x, g4.y, g4.z, g4.w}, ax[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+            for (int e4 = 0; e4 < 4; e4++) {
+                float w = kx[e4] - qx[e4];
+                w = fmaf(w0[e4], b0, w); w = fmaf(w1[e4], b1, w); w = fmaf(w2c[e4], b2, w); w = fmaf(wbias[e4], 1.f, w);
+                float gy = 0.f;
+#pragma unroll
+                for (int g = 0; g < G; g++) gy = fmaf(dv[g], wa[g][e4], gy);
+                const float g1 = fmaf(w, sc[e4], sh[e4]) > 0.f ? gy : 0.f;
+                ak[e4] += fmaf(k1[e4], g1, fmaf(k2[e4], w, k3[e4]));
+                av[e4] = fmaf(gx[e4], ax[e4], av[e4]);
+            }
+        }
+        *reinterpret_cast<float4*>(gxk + (size_t)j * C + c0) = make_float4(ak[0], ak[1], ak[2], ak[3]);
+        *reinterpret_cast<float4*>(gxv + (size_t)j * C + c0) = make_float4(av[0], av[1], av[2], av[3]);
+    }
+}
+
+// one wave: D = A . B + C on the matrix instruction, and the same tile as the k-ordered fmaf chain the target pass uses (self-test of the
+// assumption that both produce the same bits, on which the agreement of the passes' ReLU masks rests)
+__global__ __launch_bounds__(64) void pt_chain_selftest_kernel(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ Cin,
+                                                               float* __restrict__ d_mfma, float* __restrict__ d_fma)
+{
+    const int lane = threadIdx.x, lo = lane & 15, hi = lane >> 4;
+    pt_f32x4 c = pt_vec4(Cin[(4 * hi) * 16 + lo], Cin[(4 * hi + 1) * 16 + lo], Cin[(4 * hi + 2) * 16 + lo], Cin[(4 * hi + 3) * 16 + lo]);
+    const pt_f32x4 d = pt_mfma(A[lo * 4 + hi], B[hi * 16 + lo], c);                // A (16 x 4) row-major, B (4 x 16) row-major, C / D (16 x 16) row-major
+    for (int v = 0; v < 4; v++) {
+        const int row = 4 * hi + v;
+        float t = Cin[row * 16 + lo];
+        for (int k = 0; k < 4; k++) t = fmaf(A[row * 4 + k], B[k * 16 + lo], t);
+        d_mfma[row * 16 + lo] = d[v];
+        d_fma[row * 16 + lo] = t;
+    }
+}
+
+unsigned pt_tile_grid(long long ntiles)
+{
+    const long long trips = (ntiles + PT_WPB - 1) / PT_WPB;
+    long long g = trips < PT_MAX_ROWS ? trips : PT_MAX_ROWS;
+    g = (g + 7) & ~7ll;
+    return (unsigned)(g < 8 ? 8 : g);
+}
+unsigned pt_pair_grid(long long npairs)
+{
+    long long g = (npairs + PT_NARROW_BLOCK - 1) / PT_NARROW_BLOCK;
+    if (g > PT_MAX_ROWS) g = PT_MAX_ROWS;
+    return (unsigned)(g < 1 ? 1 : g);
+}
+
+// workspace (floats): partial rows of every pass + the backward's narrow tensors
+struct PtWs { float *part_a, *part_b, *part_c, *part_d, *bc, *glogit, *pre, *gw2, *gp1; size_t floats; };
+PtWs pt_workspace(float* base, int n, int K, int C)
+{
+    const size_t np = (size_t)n * K, G = C / 8;
+    PtWs w; size_t o = 0;
+    auto take = [&](size_t cnt) { float* p = base ? base + o : nullptr; o += (cnt + 63) & ~(size_t)63; return p; };
+    w.part_a = take((size_t)PT_MAX_ROWS * (2 * C + G * C));      // wstats, w2, reduce
+    w.part_b = take((size_t)PT_MAX_ROWS * (4 * C));              // pchain, apply
+    w.part_c = take((size_t)PT_MAX_ROWS * (3 * G + G * G));      // narrow backward
+    w.part_d = take((size_t)PT_MAX_ROWS * 16);                   // pchain backward
+    w.bc = take(PT_BC_FLOATS);
+    w.glogit = take(np * G); w.pre = take(np * G); w.gw2 = take(np * G); w.gp1 = take(np * 3);
+    w.floats = o;
+    return w;
+}
+
+bool pt_shape_ok(int n, int K, int C) { return n >= 1 && (K == 8 || K == 16) && (C == 32 || C == 64) && (long long)n * K < (1ll << 31); }
+
+}  // namespace
+
+CBL_EXPORT size_t cbl_pt_layer_workspace_bytes(int n, int K, int C)
+{
+    if (!pt_shape_ok(n, K, C)) return 0;
+    return pt_workspace(nullptr, n, K, C).floats * sizeof(float);
+}
+CBL_EXPORT int cbl_pt_layer_consts_floats(void) { return PT_CST_FLOATS; }
+
+CBL_EXPORT int cbl_pt_layer_selftest_chain(const float* A, const float* B, const float* C, float* d_mfma, float* d_fma, void* stream)
+{
+    hipLaunchKernelGGL(pt_chain_selftest_kernel, dim3(1), dim3(64), 0, cbl_stream(stream), A, B, C, d_mfma, d_fma);
+    return cbl_status();
+}
+
+#define PT_DISPATCH(CALL)                                     \
+    if (C == 64 && K == 16) { CALL(64, 16); }                 \
+    else if (C == 64 && K == 8) { CALL(64, 8); }              \
+    else if (C == 32 && K == 16) { CALL(32, 16); }            \
+    else { CALL(32, 8); }
+
+CBL_EXPORT int cbl_pt_layer_forward(int n, int K, int C, const float* xyz, const float* x_q, const float* x_k, const float* x_v, const int* idx, const int* order,
+                                    const float* Wp, const float* bp, const float* gamma_p, const float* beta_p, const float* W3C, const float* b3C,
+                                    const float* gamma_c, const float* beta_c, const float* Wa, const float* ba, const float* gamma_g, const float* beta_g,
+                                    const float* Wb, const float* bb, const float* eps3, const float* momentum3, float* const* running_mean3,
+                                    float* const* running_var3, long long* const* num_batches3, float* p_r, float* p0, float* p1, float* w2, float* a, float* out,
+                                    float* consts, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!pt_shape_ok(n, K, C)) return CBL_ERR_UNSUPPORTED;
+    if (!cbl_host_aligned16(x_q) || !cbl_host_aligned16(x_k) || !cbl_host_aligned16(x_v) || !cbl_host_aligned16(w2) || !cbl_host_aligned16(a) ||
+        !cbl_host_aligned16(idx) || !cbl_host_aligned16(consts) || !cbl_host_aligned16(Wa))
+        return CBL_ERR_BAD_ARG;
+    if (workspace_bytes < cbl_pt_layer_workspace_bytes(n, K, C)) return CBL_ERR_WORKSPACE;
+    const PtWs ws = pt_workspace(static_cast<float*>(workspace), n, K, C);
+    hipStream_t st = cbl_stream(stream);
+    const long long np = (long long)n * K;
+    const int G = C / 8;
+    const unsigned gp = pt_pair_grid(np), gt = pt_tile_grid((np + 15) / 16);
+    float* rm[3] = {nullptr, nullptr, nullptr}; float* rv[3] = {nullptr, nullptr, nullptr}; long long* nb[3] = {nullptr, nullptr, nullptr};
+    for (int t = 0; t < 3; t++) { if (running_mean3) rm[t] = running_mean3[t]; if (running_var3) rv[t] = running_var3[t]; if (num_batches3) nb[t] = num_batches3[t]; }
+
+    hipLaunchKernelGGL(pt_pchain_kernel, dim3(gp), dim3(PT_NARROW_BLOCK), 0, st, np, cbl_fastdiv_make((unsigned)K), xyz, idx, Wp, bp, p_r, p0, ws.part_b);
+    hipLaunchKernelGGL(pt_bn_finalize_kernel, dim3(1), dim3(256), 0, st, (int)gp, 18, 0, 3, 3, np, ws.part_b, gamma_p, beta_p, eps3[0], momentum3[0], rm[0], rv[0],
+                       nb[0], consts + PT_CST_P, 4, (float*)nullptr);
+    hipLaunchKernelGGL(pt_pchain_raw_kernel, dim3(1), dim3(64), 0, st, (int)gp, ws.part_b, consts);
+#define PT_WSTATS(CC, KK) hipLaunchKernelGGL((pt_wstats_kernel<CC, KK>), dim3(gt), dim3(PT_BLOCK), 0, st, n, order, x_q, x_k, idx, p0, consts, W3C, b3C, p1, ws.part_a)
+    PT_DISPATCH(PT_WSTATS)
+    hipLaunchKernelGGL(pt_bn_finalize_kernel, dim3(cbl_div_up(C, 16)), dim3(256), 0, st, (int)gt, 2 * C, 0, C, C, np, ws.part_a, gamma_c, beta_c, eps3[1], momentum3[1],
+                       rm[1], rv[1], nb[1], consts + PT_CST_C, 64, (float*)nullptr);
+#define PT_W2(CC, KK) hipLaunchKernelGGL((pt_w2_kernel<CC, KK>), dim3(gt), dim3(PT_BLOCK), 0, st, n, order, x_q, x_k, idx, p1, consts, W3C, b3C, Wa, ba, w2, ws.part_a)
+    PT_DISPATCH(PT_W2)
+    hipLaunchKernelGGL(pt_bn_finalize_kernel, dim3(1), dim3(256), 0, st, (int)gt, 2 * G, 0, G, G, np, ws.part_a, gamma_g, beta_g, eps3[2], momentum3[2], rm[2], rv[2],
+                       nb[2], consts + PT_CST_G, 8, consts + PT_FS_G);
+#define PT_SOFTMAX(GG, KK) hipLaunchKernelGGL((pt_softmax_kernel<GG, KK>), dim3(gp), dim3(PT_NARROW_BLOCK), 0, st, np, w2, consts, Wb, bb, a)
+    if (G == 8 && K == 16) { PT_SOFTMAX(8, 16); } else if (G == 8) { PT_SOFTMAX(8, 8); } else if (K == 16) { PT_SOFTMAX(4, 16); } else { PT_SOFTMAX(4, 8); }
+#define PT_AGG(CC, KK) hipLaunchKernelGGL((pt_agg_kernel<CC, KK, false>), dim3(gt), dim3(PT_BLOCK), 0, st, n, order, x_v, idx, p1, W3C, b3C, a, out, (const float*)nullptr, (float*)nullptr)
+    PT_DISPATCH(PT_AGG)
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_pt_layer_backward(int n, int K, int C, const float* x_q, const float* x_k, const float* x_v, const int* idx, const int* order,
+                                     const int* inv_start, const int* inv_src, const float* gamma_p, const float* W3C, const float* b3C, const float* gamma_c,
+                                     const float* Wa, const float* gamma_g, const float* Wb, const float* p_r, const float* p0, const float* p1, const float* w2,
+                                     const float* a, const float* consts, const float* grad_out, float* g_xq, float* g_xk, float* g_xv, float* g_Wp, float* g_bp,
+                                     float* g_gamma_p, float* g_beta_p, float* g_W3C, float* g_b3C, float* g_gamma_c, float* g_beta_c, float* g_Wa, float* g_ba,
+                                     float* g_gamma_g, float* g_beta_g, float* g_Wb, float* g_bb, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!pt_shape_ok(n, K, C)) return CBL_ERR_UNSUPPORTED;
+    if (!cbl_host_aligned16(x_q) || !cbl_host_aligned16(x_k) || !cbl_host_aligned16(x_v) || !cbl_host_aligned16(w2) || !cbl_host_aligned16(a) ||
+        !cbl_host_aligned16(idx) || !cbl_host_aligned16(grad_out) || !cbl_host_aligned16(g_xk) || !cbl_host_aligned16(g_xv))
+        return CBL_ERR_BAD_ARG;
+    if (workspace_bytes < cbl_pt_layer_workspace_bytes(n, K, C)) return CBL_ERR_WORKSPACE;
+    const PtWs ws = pt_workspace(static_cast<float*>(workspace), n, K, C);
+    hipStream_t st = cbl_stream(stream);
+    const long long np = (long long)n * K;
+    const int G = C / 8, WN = 3 * G + G * G;
+    const unsigned gp = pt_pair_grid(np), gt = pt_tile_grid((np + 15) / 16);
+
+#define PT_AGGB(CC, KK) hipLaunchKernelGGL((pt_agg_kernel<CC, KK, true>), dim3(gt), dim3(PT_BLOCK), 0, st, n, order, x_v, idx, p1, W3C, b3C, a, (float*)nullptr, grad_out, ws.glogit)
+    PT_DISPATCH(PT_AGGB)
+    if (G == 8) hipLaunchKernelGGL(pt_narrow_bwd_kernel<8>, dim3(gp), dim3(PT_NARROW_BLOCK), 0, st, np, w2, consts, Wb, ws.glogit, ws.pre, ws.part_c);
+    else        hipLaunchKernelGGL(pt_narrow_bwd_kernel<4>, dim3(gp), dim3(PT_NARROW_BLOCK), 0, st, np, w2, consts, Wb, ws.glogit, ws.pre, ws.part_c);
+    hipLaunchKernelGGL(pt_bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, (int)gp, WN, 0, G, G, np, ws.part_c, gamma_g, consts + PT_CST_G, 8, ws.bc + PT_BC_G, 8,
+                       g_gamma_g, g_beta_g, consts + PT_FS_G, g_ba);
+#define PT_REDUCE(CC, KK) hipLaunchKernelGGL((pt_w2_bwd_kernel<CC, KK, false>), dim3(gt), dim3(PT_BLOCK), 0, st, n, order, x_q, x_k, idx, p1, consts, ws.bc, W3C, b3C, Wa, w2, ws.pre, ws.gw2, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, ws.part_a)
+    PT_DISPATCH(PT_REDUCE)
+    hipLaunchKernelGGL(pt_bn_bwd_finalize_kernel, dim3(cbl_div_up(C, 16)), dim3(256), 0, st, (int)gt, 2 * C + G * C, 0, C, C, np, ws.part_a, gamma_c, consts + PT_CST_C, 64,
+                       ws.bc + PT_BC_C, 64, g_gamma_c, g_beta_c, (const float*)nullptr, (float*)nullptr);
+#define PT_APPLY(CC, KK) hipLaunchKernelGGL((pt_w2_bwd_kernel<CC, KK, true>), dim3(gt), dim3(PT_BLOCK), 0, st, n, order, x_q, x_k, idx, p1, consts, ws.bc, W3C, b3C, Wa, w2, ws.pre, ws.gw2, a, grad_out, g_xq, ws.gp1, ws.part_b)
+    PT_DISPATCH(PT_APPLY)
+    hipLaunchKernelGGL(pt_pchain_bwd_kernel, dim3(gp), dim3(PT_NARROW_BLOCK), 0, st, np, p_r, p0, p1, ws.gp1, consts, ws.part_d);
+    hipLaunchKernelGGL(pt_pchain_epilogue_kernel, dim3(1), dim3(64), 0, st, (int)gp, ws.part_d, np, consts, gamma_p, g_Wp, g_bp, g_gamma_p, g_beta_p);
+    {
+        const unsigned tg = cbl_round_up8(cbl_grid_for(((long long)n + (256 / (C / 4)) - 1) / (256 / (C / 4)), 1, 2048));
+#define PT_TARGET(CC, KK) hipLaunchKernelGGL((pt_target_kernel<CC, KK>), dim3(tg), dim3(256), 0, st, (unsigned)n, order, inv_start, inv_src, x_q, x_k, p1, consts, ws.bc, W3C, b3C, Wa, ws.gw2, a, grad_out, g_xk, g_xv)
+        PT_DISPATCH(PT_TARGET)
+    }
+    PtSumSegs segs;
+    segs.n = 5;
+    segs.s[0] = PtSumSeg{ws.part_a, g_Wa, (int)gt, 2 * C + G * C, 2 * C, G * C};
+    segs.s[1] = PtSumSeg{ws.part_b, g_W3C, (int)gt, 4 * C, 0, 3 * C};
+    segs.s[2] = PtSumSeg{ws.part_b, g_b3C, (int)gt, 4 * C, 3 * C, C};
+    segs.s[3] = PtSumSeg{ws.part_c, g_Wb, (int)gp, WN, 2 * G, G * G};
+    segs.s[4] = PtSumSeg{ws.part_c, g_bb, (int)gp, WN, 2 * G + G * G, G};
+    unsigned nblk = 0;
+    for (int q = 0; q < segs.n; q++) nblk += (unsigned)((segs.s[q].count + 15) / 16);
+    hipLaunchKernelGGL(pt_sum_rows_kernel, dim3(nblk), dim3(256), 0, st, segs);
+    return cbl_status();
+}

@@ -1,0 +1,97 @@
+"""PointTransformerLayer's vector attention as one pass structure (csrc/pt_layer.hip, /root/reference/pytorch/model/blocks.py:34-44):
+everything of the layer behind its q / k / v Linear layers — linear_p, the BatchNorm / Linear stack linear_w, the softmax over K and the
+aggregation — as ONE autograd Function over the layer's own parameter tensors, for the two full-resolution shapes (C = 32 | 64 with
+share_planes = 8, K = 8 | 16) in training mode.  Five forward and six backward passes over the (point, neighbour) pairs, nothing of shape
+(n, K, C) stored, no atomics (the x_k / x_v gradients are gathers over the transposed neighbour table), run-to-run deterministic.
+`supported()` says when; other shapes and evaluation take attention.py's kernels."""
+import ctypes
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+
+_ws = {}
+MAX_POINTS = 1 << 20                                   # the transposed table's limit (neighbor_transpose.hip NT_MAX_TILES)
+
+
+def _workspace(nbytes, device):
+    from .neighbor_state import scratch
+    return scratch(_ws, "pt_layer", nbytes, device)
+
+
+def _bn_ok(bn):
+    return (isinstance(bn, torch.nn.BatchNorm1d) and bn.affine and bn.track_running_stats and bn.momentum is not None and bn.weight.dtype == torch.float32)
+
+
+def supported(layer, x):
+    C = layer.out_planes
+    return (layer.training and x.is_cuda and x.dtype == torch.float32 and layer.mid_planes == C and layer.share_planes == 8 and C in (32, 64)
+            and int(layer.nsample) in (8, 16) and 16 <= x.shape[0] <= MAX_POINTS
+            and _bn_ok(layer.linear_p[1]) and _bn_ok(layer.linear_w[0]) and _bn_ok(layer.linear_w[3]))
+
+
+_i, _f = ctypes.c_int, ctypes.c_float
+_P = _lib.ptr
+
+
+class PTAttention(Function):
+    """out (n, C) = vector attention of blocks.py:34-44 given x_q / x_k / x_v (n, C), the coordinates and the layer's neighbour table.
+    Parameter order: linear_p[0].weight/.bias, linear_p[1].weight/.bias, linear_p[3].weight/.bias, linear_w[0].weight/.bias,
+    linear_w[2].weight/.bias, linear_w[3].weight/.bias, linear_w[5].weight/.bias."""
+
+    @staticmethod
+    def forward(ctx, p, x_q, x_k, x_v, idx, bns, *params):
+        from . import pointops
+        n, C = x_q.shape
+        K, G = idx.shape[1], C // 8
+        L = _lib.lib()
+        dev = x_q.device
+        x_q, x_k, x_v, p = x_q.contiguous(), x_k.contiguous(), x_v.contiguous(), p.contiguous()
+        params = [t.contiguous() for t in params]
+        order = pointops.spatial_order(idx)
+        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        p_r, p0, p1, w2, a, out = e(n, K, 3), e(n, K, 3), e(n, K, 3), e(n, K, G), e(n, K, G), e(n, C)
+        consts = e(L.cbl_pt_layer_consts_floats())
+        ws = _workspace(L.cbl_pt_layer_workspace_bytes(_i(n), _i(K), _i(C)), dev)
+        eps3 = (_f * 3)(*[float(b.eps) for b in bns])
+        mom3 = (_f * 3)(*[float(b.momentum) for b in bns])
+        arr = lambda ts: (ctypes.c_void_p * 3)(*[t.data_ptr() for t in ts])
+        _lib.check(L.cbl_pt_layer_forward(_i(n), _i(K), _i(C), _P(p), _P(x_q), _P(x_k), _P(x_v), _P(idx), _P(order), *[_P(t) for t in params], eps3, mom3,
+                                          arr([b.running_mean for b in bns]), arr([b.running_var for b in bns]), arr([b.num_batches_tracked for b in bns]),
+                                          _P(p_r), _P(p0), _P(p1), _P(w2), _P(a), _P(out), _P(consts), _P(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(x_q)),
+                   "cbl_pt_layer_forward")
+        ctx.save_for_backward(x_q, x_k, x_v, idx, p_r, p0, p1, w2, a, consts, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        from . import pointops
+        x_q, x_k, x_v, idx, p_r, p0, p1, w2, a, consts = ctx.saved_tensors[:10]
+        Wp, bp, gamma_p, beta_p, W3C, b3C, gamma_c, beta_c, Wa, ba, gamma_g, beta_g, Wb, bb = params = ctx.saved_tensors[10:]
+        n, C = x_q.shape
+        K = idx.shape[1]
+        L = _lib.lib()
+        dev = x_q.device
+        tr = pointops.neighbor_transpose(idx, n, build=True)
+        if tr is None:
+            raise _lib.CblError("pt_layer backward needs the transposed neighbour table (n <= %d)" % MAX_POINTS)
+        order, inv_start, inv_src = tr
+        g_out = g_out.contiguous()
+        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        g_xq, g_xk, g_xv = e(n, C), e(n, C), e(n, C)
+        g_params = [torch.empty_like(t) for t in params]
+        ws = _workspace(L.cbl_pt_layer_workspace_bytes(_i(n), _i(K), _i(C)), dev)
+        _lib.check(L.cbl_pt_layer_backward(_i(n), _i(K), _i(C), _P(x_q), _P(x_k), _P(x_v), _P(idx), _P(order), _P(inv_start), _P(inv_src), _P(gamma_p), _P(W3C),
+                                           _P(b3C), _P(gamma_c), _P(Wa), _P(gamma_g), _P(Wb), _P(p_r), _P(p0), _P(p1), _P(w2), _P(a), _P(consts), _P(g_out),
+                                           _P(g_xq), _P(g_xk), _P(g_xv), *[_P(t) for t in g_params], _P(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(x_q)),
+                   "cbl_pt_layer_backward")
+        return (None, g_xq, g_xk, g_xv, None, None, *g_params)
+
+
+def attention(layer, p, x_q, x_k, x_v, idx):
+    """the fused part of `layer` (a blocks.PointTransformerLayer) on its q / k / v projections"""
+    lp, lw = layer.linear_p, layer.linear_w
+    bns = (lp[1], lw[0], lw[3])
+    return PTAttention.apply(p, x_q, x_k, x_v, idx, bns, lp[0].weight, lp[0].bias, lp[1].weight, lp[1].bias, lp[3].weight, lp[3].bias,
+                             lw[0].weight, lw[0].bias, lw[2].weight, lw[2].bias, lw[3].weight, lw[3].bias, lw[5].weight, lw[5].bias)

@@ -490,6 +490,37 @@ int cbl_attn_agg_backward_csr(int n, int K, int C, int G, const float* x_v, cons
                               float* grad_xv, float* grad_p1, float* grad_W3C, float* grad_b3C, float* grad_a,
                               void* workspace, size_t workspace_bytes, int softmax, void* stream);
 
+/* a4  PointTransformerLayer  pytorch/model/blocks.py:31-44 as ONE pass structure (round 4): everything of the layer behind its three per-point
+ *     Linear layers (blocks.py:33), train-mode BatchNorms, C = 32 | 64 (share_planes 8, G = C/8), K = 8 | 16 (the two full-resolution stages).
+ *     Replaces, for those shapes, the call sequence queryandgroup -> linear_p -> subtraction -> linear_w -> softmax -> aggregation
+ *     (pointops_api.cpp:12-23 functions 7-10 plus torch's Linear / BatchNorm1d / Softmax over (n,K,C) tensors).
+ *   forward   xyz (n,3), x_q / x_k / x_v (n,C) = linear_q/k/v(x), idx (n,K) of the layer's self-search, order (n) = the search's cell order or NULL;
+ *             parameters in the reference's layout: linear_p[0] Wp (3,3) bp (3), linear_p[1] gamma_p beta_p (3), linear_p[3] W3C (C,3) b3C (C),
+ *             linear_w[0] gamma_c beta_c (C), linear_w[2] Wa (G,C) ba (G), linear_w[3] gamma_g beta_g (G), linear_w[5] Wb (G,G) bb (G);
+ *             eps3 / momentum3: HOST arrays of 3 floats (BN_p, BN_c, BN_g); running_mean3 / running_var3 / num_batches3: HOST arrays of 3 device
+ *             pointers (entries or the arrays may be NULL), updated as torch's train-mode BatchNorm1d does
+ *             -> out (n,C);  kept for the backward pass: p_r, p0, p1 (n,K,3), w2, a (n,K,G), consts (cbl_pt_layer_consts_floats() floats).
+ *   backward  + the transposed neighbour table of idx (cbl_neighbor_transpose: inv_start (n+1) by rank of `order`, inv_src), grad_out (n,C)
+ *             -> g_xq, g_xk, g_xv (n,C) written (not accumulated, no atomics), and the 14 parameter gradients in the parameters' layouts.
+ *   All sums in a fixed order: run-to-run deterministic.  CBL_ERR_UNSUPPORTED for other shapes (callers take the cbl_attn_* kernels above). */
+size_t cbl_pt_layer_workspace_bytes(int n, int K, int C);
+int cbl_pt_layer_consts_floats(void);
+/* self-test of the numerical assumption the passes' agreeing ReLU masks rest on: one v_mfma_f32_16x16x4_f32 tile D = A (16,4) . B (4,16) + C (16,16)
+ * (row-major device arrays) next to the k-ordered fmaf chain of the same tile; callers compare the two outputs bit for bit. */
+int cbl_pt_layer_selftest_chain(const float* A, const float* B, const float* C, float* d_mfma, float* d_fma, void* stream);
+int cbl_pt_layer_forward(int n, int K, int C, const float* xyz, const float* x_q, const float* x_k, const float* x_v, const int* idx, const int* order,
+                         const float* Wp, const float* bp, const float* gamma_p, const float* beta_p, const float* W3C, const float* b3C,
+                         const float* gamma_c, const float* beta_c, const float* Wa, const float* ba, const float* gamma_g, const float* beta_g,
+                         const float* Wb, const float* bb, const float* eps3, const float* momentum3, float* const* running_mean3,
+                         float* const* running_var3, long long* const* num_batches3, float* p_r, float* p0, float* p1, float* w2, float* a, float* out,
+                         float* consts, void* workspace, size_t workspace_bytes, void* stream);
+int cbl_pt_layer_backward(int n, int K, int C, const float* x_q, const float* x_k, const float* x_v, const int* idx, const int* order,
+                          const int* inv_start, const int* inv_src, const float* gamma_p, const float* W3C, const float* b3C, const float* gamma_c,
+                          const float* Wa, const float* gamma_g, const float* Wb, const float* p_r, const float* p0, const float* p1, const float* w2,
+                          const float* a, const float* consts, const float* grad_out, float* g_xq, float* g_xk, float* g_xv, float* g_Wp, float* g_bp,
+                          float* g_gamma_p, float* g_beta_p, float* g_W3C, float* g_b3C, float* g_gamma_c, float* g_beta_c, float* g_Wa, float* g_ba,
+                          float* g_gamma_g, float* g_beta_g, float* g_Wb, float* g_bb, void* workspace, size_t workspace_bytes, void* stream);
+
 /* a4, dense part of the vector attention: nn.Linear over (n*K) rows with tiny widths — linear_p = Linear(3,3), Linear(3,C) and
  * linear_w = Linear(C,C/8), Linear(C/8,C/8)  pytorch/model/blocks.py:23-28,38-40 — as streaming kernels instead of library GEMMs.
  *   x (rows,cin), weight (cout,cin), bias (cout) or NULL -> y (rows,cout) = x @ weight^T + bias

@@ -1,0 +1,158 @@
+// TEST INFRASTRUCTURE (not product code): a host stand-in for <hip/hip_runtime.h> that lets g++ compile one of OUR OWN kernel files
+// (contrastboundary_amd/csrc/pt_layer.hip) for the CPU and run it with wave semantics: every thread of a workgroup is a ucontext fibre,
+// cross-lane operations (MFMA, DPP, bpermute) and barriers are rendezvous points at which the fibres of a wave / workgroup meet.
+// Only what that file and cbl_common.h use is provided.  Used by tests/test_pt_layer_host.py on small shapes.
+#pragma once
+#include <ucontext.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
+
+typedef int hipError_t;
+constexpr hipError_t hipSuccess = 0;
+typedef void* hipStream_t;
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+
+using std::max;
+using std::min;
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
+static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
+
+namespace emul {
+
+constexpr int WAVE = 64;
+struct Wave {
+    int alive = 0, arrived = 0; unsigned gen = 0;
+    float in[WAVE][8]; float out[WAVE][4]; bool present[WAVE];
+};
+struct Fiber {
+    ucontext_t ctx; dim3 tid; int lin = 0, wave = 0, lane = 0; bool done = false; char* stack = nullptr;
+};
+struct State {
+    ucontext_t main_ctx;
+    std::vector<Fiber> fibers; std::vector<Wave> waves;
+    Fiber* cur = nullptr;
+    dim3 block_idx, block_dim, grid_dim;
+    int block_alive = 0, block_arrived = 0; unsigned block_gen = 0;
+    const std::function<void()>* body = nullptr;
+    size_t stack_bytes = 96 * 1024;
+};
+inline State& S() { static State s; return s; }
+
+inline void yield() { State& s = S(); swapcontext(&s.cur->ctx, &s.main_ctx); }
+
+inline void trampoline()
+{
+    State& s = S();
+    (*s.body)();
+    Fiber* f = s.cur;
+    f->done = true;
+    s.waves[f->wave].alive--;
+    s.block_alive--;
+    swapcontext(&f->ctx, &s.main_ctx);
+}
+
+// every alive lane of the calling wave deposits `np` floats; when all have, `compute(wave)` fills wave.out; each lane then takes its `nr` results
+template <class F>
+inline void wave_collective(const float* payload, int np, float* result, int nr, F compute)
+{
+    State& s = S(); Fiber* f = s.cur; Wave& w = s.waves[f->wave];
+    const unsigned g = w.gen;
+    for (int i = 0; i < np; i++) w.in[f->lane][i] = payload[i];
+    w.present[f->lane] = true; w.arrived++;
+    while (w.gen == g) {
+        if (w.arrived == w.alive) {
+            for (int l = 0; l < WAVE; l++) if (!w.present[l]) for (int i = 0; i < 8; i++) w.in[l][i] = 0.f;
+            compute(w);
+            w.arrived = 0; for (int l = 0; l < WAVE; l++) w.present[l] = false;
+            w.gen++;
+            break;
+        }
+        yield();
+    }
+    for (int i = 0; i < nr; i++) result[i] = w.out[f->lane][i];
+}
+
+inline void block_barrier()
+{
+    State& s = S();
+    const unsigned g = s.block_gen;
+    s.block_arrived++;
+    while (s.block_gen == g) {
+        if (s.block_arrived == s.block_alive) { s.block_arrived = 0; s.block_gen++; break; }
+        yield();
+    }
+}
+
+inline void launch(dim3 grid, dim3 block, const std::function<void()>& body)
+{
+    State& s = S();
+    const int nt = (int)(block.x * block.y * block.z);
+    const int nw = (nt + WAVE - 1) / WAVE;
+    if ((int)s.fibers.size() < nt) {
+        const size_t old = s.fibers.size();
+        s.fibers.resize(nt);
+        for (size_t i = old; i < s.fibers.size(); i++) s.fibers[i].stack = (char*)std::malloc(s.stack_bytes);
+    }
+    s.body = &body; s.block_dim = block; s.grid_dim = grid;
+    for (unsigned bz = 0; bz < grid.z; bz++) for (unsigned by = 0; by < grid.y; by++) for (unsigned bx = 0; bx < grid.x; bx++) {
+        s.block_idx = dim3(bx, by, bz);
+        s.waves.assign(nw, Wave());
+        for (auto& w : s.waves) for (int l = 0; l < WAVE; l++) w.present[l] = false;
+        s.block_alive = nt; s.block_arrived = 0; s.block_gen = 0;
+        for (int t = 0; t < nt; t++) {
+            Fiber& f = s.fibers[t];
+            f.lin = t; f.wave = t / WAVE; f.lane = t % WAVE; f.done = false;
+            f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+            s.waves[f.wave].alive++;
+            getcontext(&f.ctx);
+            f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = s.stack_bytes; f.ctx.uc_link = &s.main_ctx;
+            makecontext(&f.ctx, (void (*)())trampoline, 0);
+        }
+        int remaining = nt; long rounds = 0;
+        while (remaining > 0) {
+            remaining = 0;
+            for (int t = 0; t < nt; t++) {
+                Fiber& f = s.fibers[t];
+                if (f.done) continue;
+                s.cur = &f;
+                swapcontext(&s.main_ctx, &f.ctx);
+                if (!f.done) remaining++;
+            }
+            if (++rounds > 50000000) { std::fprintf(stderr, "emul: no progress (divergent rendezvous?)\n"); std::abort(); }
+        }
+    }
+    s.cur = nullptr;
+}
+
+}  // namespace emul
+
+#define threadIdx (emul::S().cur->tid)
+#define blockIdx (emul::S().block_idx)
+#define blockDim (emul::S().block_dim)
+#define gridDim (emul::S().grid_dim)
+static inline void __syncthreads() { emul::block_barrier(); }
+#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) emul::launch((grid), (block), [&]() { kern(__VA_ARGS__); })

@@ -1,0 +1,89 @@
+"""GPU: PointTransformerLayer through csrc/pt_layer.hip (row a4, /root/reference/pytorch/model/blocks.py:31-44) at the two full-resolution
+shapes, against the same layer on the separate kernels (`fused = False`, which tests/test_gpu_blocks.py pins to the reference's goldens) and
+against the round-3 split kernels; determinism; the matrix-instruction / fmaf-chain bit equality the passes' ReLU masks rest on."""
+import copy
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / max(float(b.double().norm()), 1e-30))
+
+
+def layers(C, K, seed):
+    from contrastboundary_amd import blocks
+    torch.manual_seed(seed)
+    fused = blocks.PointTransformerLayer(C, C, 8, K).cuda().train()
+    with torch.no_grad():
+        for m in fused.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.3, 0.3)
+    return fused
+
+
+def run(layer, xyz, x, o, g):
+    x = x.detach().clone().requires_grad_(True)
+    y = layer([xyz, x, o])
+    y.backward(g)
+    return y.detach(), x.grad, [p.grad for p in layer.parameters()], [b.detach().clone().float() for b in layer.buffers()]
+
+
+def test_matrix_instruction_equals_the_fmaf_chain():
+    from contrastboundary_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(0)
+    for scale in (1.0, 1e-3, 37.0):
+        A, B, C = torch.randn(16, 4, device="cuda") * scale, torch.randn(4, 16, device="cuda"), torch.randn(16, 16, device="cuda") * scale
+        d1, d2 = torch.empty(16, 16, device="cuda"), torch.empty(16, 16, device="cuda")
+        _lib.check(L.cbl_pt_layer_selftest_chain(_lib.ptr(A), _lib.ptr(B), _lib.ptr(C), _lib.ptr(d1), _lib.ptr(d2), _lib.stream_of(A)), "selftest")
+        assert torch.equal(d1.view(torch.int32), d2.view(torch.int32))
+        ref = (A.double() @ B.double() + C.double())
+        assert rel(d1, ref) < 1e-6
+
+
+@pytest.mark.parametrize("n,K,C", [(4096, 16, 64), (4099, 8, 32), (2501, 8, 64), (1000, 16, 32), (20000, 16, 64)])
+def test_layer_equals_the_unfused_layer(n, K, C):
+    from contrastboundary_amd import pt_layer, synthetic as S
+    xyz = torch.from_numpy(S.s_room(n, seed=3)[0]).cuda(); o = torch.tensor([n // 3, n], dtype=torch.int32, device="cuda")
+    fused = layers(C, K, n + C)
+    plain = copy.deepcopy(fused); plain.fused = False
+    assert pt_layer.supported(fused, torch.empty(n, C, device="cuda"))
+    torch.manual_seed(1)
+    x = torch.randn(n, C, device="cuda"); g = torch.randn(n, C, device="cuda")
+    y1, gx1, gp1, b1 = run(fused, xyz, x, o, g)
+    y2, gx2, gp2, b2 = run(plain, xyz, x, o, g)
+    assert rel(y1, y2) < 2e-5
+    assert float((y1 - y2).abs().max()) <= 1e-4 * (float(y2.abs().max()) + 1.0)
+    assert rel(gx1, gx2) < 2e-4
+    gmax = max(float(p.abs().max()) for p in gp2)
+    for (name, _), pa, pb in zip(fused.named_parameters(), gp1, gp2):
+        assert pa is not None and (rel(pa, pb) < 5e-4 or float((pa - pb).abs().max()) < 1e-4 * gmax), (name, rel(pa, pb))
+    for (name, _), ba, bb in zip(fused.named_buffers(), b1, b2):
+        assert rel(ba, bb) < 1e-5, name
+
+
+@pytest.mark.parametrize("n,K,C", [(40960, 16, 64), (40960, 8, 32)])
+def test_full_resolution_stage_against_the_split_kernels_and_deterministic(n, K, C):
+    """the bench / network shapes: against round 3's kernels (csrc/attention.hip), and two runs bit-identical (no atomics anywhere)"""
+    from contrastboundary_amd import synthetic as S
+    xyz = torch.from_numpy(S.s_room(n, seed=0)[0]).cuda(); o = torch.tensor([n], dtype=torch.int32, device="cuda")
+    fused = layers(C, K, 7)
+    split = copy.deepcopy(fused); split.fused = "split"
+    again = copy.deepcopy(fused)
+    torch.manual_seed(2)
+    x = torch.randn(n, C, device="cuda"); g = torch.randn(n, C, device="cuda")
+    y1, gx1, gp1, _ = run(fused, xyz, x, o, g)
+    y2, gx2, gp2, _ = run(split, xyz, x, o, g)
+    y3, gx3, gp3, _ = run(again, xyz, x, o, g)
+    assert rel(y1, y2) < 2e-5 and rel(gx1, gx2) < 2e-4
+    gmax = max(float(p.abs().max()) for p in gp2)
+    for (name, _), pa, pb in zip(fused.named_parameters(), gp1, gp2):
+        assert rel(pa, pb) < 5e-4 or float((pa - pb).abs().max()) < 1e-4 * gmax, (name, rel(pa, pb))
+    assert torch.equal(y1, y3) and torch.equal(gx1, gx3)
+    for pa, pc in zip(gp1, gp3):
+        assert torch.equal(pa, pc)

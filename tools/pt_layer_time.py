@@ -1,0 +1,65 @@
+"""Per-kernel and per-pass timing of the Point-Transformer layer (csrc/pt_layer.hip) at a stage shape, eager, HIP events:
+    python tools/pt_layer_time.py [n K C]      -> one JSON line (layer forward / backward, new path and round 3's split kernels)"""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from contrastboundary_amd import blocks, pointops, synthetic as S  # noqa: E402
+
+
+def timed(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e3
+
+
+def main():
+    n, K, C = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (40960, 16, 64)
+    xyz = torch.from_numpy(S.s_room(n, seed=0)[0]).cuda(); o = torch.tensor([n], dtype=torch.int32, device="cuda")
+    torch.manual_seed(0)
+    x = torch.randn(n, C, device="cuda"); g = torch.randn(n, C, device="cuda")
+    idx, _ = pointops.knnquery(K, xyz, xyz, o, o)
+    out = {"n": n, "K": K, "C": C}
+    for mode in (True, "split"):
+        layer = blocks.PointTransformerLayer(C, C, 8, K).cuda().train(); layer.fused = mode
+        params = list(layer.parameters())
+        state = {}
+
+        def fwd():
+            state["x"] = x.detach().requires_grad_(True)
+            state["y"] = layer([xyz, state["x"], o], idx=idx)
+
+        def bwd():
+            torch.autograd.grad(state["y"], [state["x"]] + params, g, retain_graph=True)
+
+        def both():
+            fwd(); torch.autograd.grad(state["y"], [state["x"]] + params, g)
+
+        fwd(); bwd()
+        tag = "new" if mode is True else "split"
+        out[tag] = {"fwd_us": round(timed(fwd), 1), "bwd_us": round(timed(bwd), 1), "fwd_bwd_us": round(timed(both), 1)}
+        # graph replay of forward + backward: what the bench step sees
+        gr = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            both(); both()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(gr, stream=s):
+                both()
+        torch.cuda.synchronize()
+        out[tag]["graph_fwd_bwd_us"] = round(timed(gr.replay), 1)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
