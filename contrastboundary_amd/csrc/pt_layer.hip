@@ -128,57 +128,73 @@ __global__ __launch_bounds__(PT_NARROW_BLOCK) void pt_pchain_kernel(long long np
 }
 
 // ---- BatchNorm finalize: partial rows -> scale / shift / mean / invstd per channel (+ running statistics) ------------------------------
-// channel c sums partial[row * stride + off0 + c] and [.. off1 + c] over the rows in double, 16 channels x 16 row slices per workgroup
-__global__ __launch_bounds__(256) void pt_bn_finalize_kernel(int nrows, int stride, int off0, int off1, int Cn, long long rows, const float* __restrict__ partial,
-                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
-                                                             float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                             long long* __restrict__ num_batches_tracked, float* __restrict__ cst, int cst_stride,
-                                                             float* __restrict__ raw0)
+// Workgroup b owns columns 16 b .. 16 b + 15, its 1024 threads = 16 columns x 64 row slices; sums in double, fixed order.
+//   column c < n_bn : BatchNorm channel c from the sums at partial[row * stride + off0 + c] and [.. off1 + c]
+//   column c < n_raw: the plain sum of partial[row * stride + c], kept at raw_out[c] (forward sums the backward pass needs)
+constexpr int PT_FIN_THREADS = 1024;
+__global__ __launch_bounds__(PT_FIN_THREADS) void pt_bn_finalize_kernel(int nrows, int stride, const float* __restrict__ partial, int n_bn, int off0, int off1,
+                                                                        long long rows, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                                        float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                        long long* __restrict__ num_batches_tracked, float* __restrict__ cst, int cst_stride,
+                                                                        int n_raw, float* __restrict__ raw_out)
 {
-    __shared__ double red[16][16][2];
+    __shared__ double red[64][16][3];
     if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) num_batches_tracked[0] += 1;
     const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
-    double a0 = 0.0, a1 = 0.0;
-    if (c < Cn)
-        for (int r = sl; r < nrows; r += 16) { a0 += (double)partial[(size_t)r * stride + off0 + c]; a1 += (double)partial[(size_t)r * stride + off1 + c]; }
-    red[sl][cl][0] = a0; red[sl][cl][1] = a1;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int r = sl; r < nrows; r += 64) {
+        const float* row = partial + (size_t)r * stride;
+        if (c < n_bn) { a0 += (double)row[off0 + c]; a1 += (double)row[off1 + c]; }
+        if (c < n_raw) a2 += (double)row[c];
+    }
+    red[sl][cl][0] = a0; red[sl][cl][1] = a1; red[sl][cl][2] = a2;
     __syncthreads();
-    if (sl == 0 && c < Cn) {
-        double s0 = 0.0, s1 = 0.0;
-        for (int j = 0; j < 16; j++) { s0 += red[j][cl][0]; s1 += red[j][cl][1]; }
-        const double mu = s0 / (double)rows;
-        double var = s1 / (double)rows - mu * mu;
-        if (var < 0.0) var = 0.0;
-        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float scale = gamma[c] * invstd;
-        cst[c] = scale;
-        cst[cst_stride + c] = beta[c] - (float)mu * scale;
-        cst[2 * cst_stride + c] = (float)mu;
-        cst[3 * cst_stride + c] = invstd;
-        if (raw0) raw0[c] = (float)s0;
-        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
-        if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(rows > 1 ? var * (double)rows / (double)(rows - 1) : var);
+    double tot = 0.0;
+    if (sl < 3) for (int j = 0; j < 64; j++) tot += red[j][cl][sl];      // slice t totals quantity t of the column
+    __syncthreads();
+    if (sl < 3) red[0][cl][sl] = tot;
+    __syncthreads();
+    if (sl == 0) {
+        if (c < n_raw) raw_out[c] = (float)red[0][cl][2];
+        if (c < n_bn) {
+            const double mu = red[0][cl][0] / (double)rows;
+            double var = red[0][cl][1] / (double)rows - mu * mu;
+            if (var < 0.0) var = 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+            const float scale = gamma[c] * invstd;
+            cst[c] = scale;
+            cst[cst_stride + c] = beta[c] - (float)mu * scale;
+            cst[2 * cst_stride + c] = (float)mu;
+            cst[3 * cst_stride + c] = invstd;
+            if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+            if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(rows > 1 ? var * (double)rows / (double)(rows - 1) : var);
+        }
     }
 }
 
 // BatchNorm backward finalize: S1 = sum dy, S2 = sum dy xhat  ->  dx = A1 dy + A2 x + A3;  d gamma = S2, d beta = S1
 // (dx = gamma invstd (dy - S1/N - xhat S2/N), xhat = (x - mean) invstd).   lin_bias_grad (optional): the gradient of a bias that feeds this
 // BatchNorm directly, sum over rows of dx = A1 S1 + A2 sum(x) + N A3 — analytically 0, returned as the rounding noise the unfused layer returns
-__global__ __launch_bounds__(256) void pt_bn_bwd_finalize_kernel(int nrows, int stride, int off0, int off1, int Cn, long long rows, const float* __restrict__ partial,
-                                                                 const float* __restrict__ gamma, const float* __restrict__ cst, int cst_stride,
-                                                                 float* __restrict__ bc, int bc_stride, float* __restrict__ g_gamma, float* __restrict__ g_beta,
-                                                                 const float* __restrict__ raw_x, float* __restrict__ lin_bias_grad)
+__global__ __launch_bounds__(PT_FIN_THREADS) void pt_bn_bwd_finalize_kernel(int nrows, int stride, int off0, int off1, int Cn, long long rows,
+                                                                            const float* __restrict__ partial, const float* __restrict__ gamma,
+                                                                            const float* __restrict__ cst, int cst_stride, float* __restrict__ bc, int bc_stride,
+                                                                            float* __restrict__ g_gamma, float* __restrict__ g_beta,
+                                                                            const float* __restrict__ raw_x, float* __restrict__ lin_bias_grad)
 {
-    __shared__ double red[16][16][2];
+    __shared__ double red[64][16][2];
     const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
     double a0 = 0.0, a1 = 0.0;
     if (c < Cn)
-        for (int r = sl; r < nrows; r += 16) { a0 += (double)partial[(size_t)r * stride + off0 + c]; a1 += (double)partial[(size_t)r * stride + off1 + c]; }
+        for (int r = sl; r < nrows; r += 64) { a0 += (double)partial[(size_t)r * stride + off0 + c]; a1 += (double)partial[(size_t)r * stride + off1 + c]; }
     red[sl][cl][0] = a0; red[sl][cl][1] = a1;
     __syncthreads();
+    double tot = 0.0;
+    if (sl < 2) for (int j = 0; j < 64; j++) tot += red[j][cl][sl];
+    __syncthreads();
+    if (sl < 2) red[0][cl][sl] = tot;
+    __syncthreads();
     if (sl == 0 && c < Cn) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int j = 0; j < 16; j++) { s1 += red[j][cl][0]; s2 += red[j][cl][1]; }
+        const double s1 = red[0][cl][0], s2 = red[0][cl][1];
         const double mean = (double)cst[2 * cst_stride + c], invstd = (double)cst[3 * cst_stride + c];
         const double A1 = (double)gamma[c] * invstd, m1 = s1 / (double)rows, m2 = s2 / (double)rows;
         const double A2 = -A1 * m2 * invstd, A3 = A1 * (m2 * invstd * mean - m1);
@@ -191,9 +207,9 @@ __global__ __launch_bounds__(256) void pt_bn_bwd_finalize_kernel(int nrows, int 
 // plain column sums of partial rows (parameter gradients): out[seg.dst + t] = sum over rows of partial[row * stride + off + t]
 struct PtSumSeg { const float* src; float* dst; int nrows, stride, off, count; };
 struct PtSumSegs { PtSumSeg s[6]; int n; };
-__global__ __launch_bounds__(256) void pt_sum_rows_kernel(PtSumSegs segs)
+__global__ __launch_bounds__(PT_FIN_THREADS) void pt_sum_rows_kernel(PtSumSegs segs)
 {
-    __shared__ double red[16][16];
+    __shared__ double red[64][16];
     int b = blockIdx.x;
     for (int q = 0; q < segs.n; q++) {
         const PtSumSeg sg = segs.s[q];
@@ -201,10 +217,10 @@ __global__ __launch_bounds__(256) void pt_sum_rows_kernel(PtSumSegs segs)
         if (b >= nb) { b -= nb; continue; }
         const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4, c = b * 16 + cl;
         double a = 0.0;
-        if (c < sg.count) for (int r = sl; r < sg.nrows; r += 16) a += (double)sg.src[(size_t)r * sg.stride + sg.off + c];
+        if (c < sg.count) for (int r = sl; r < sg.nrows; r += 64) a += (double)sg.src[(size_t)r * sg.stride + sg.off + c];
         red[sl][cl] = a;
         __syncthreads();
-        if (sl == 0 && c < sg.count) { double s = 0.0; for (int j = 0; j < 16; j++) s += red[j][cl]; sg.dst[c] = (float)s; }
+        if (sl == 0 && c < sg.count) { double s = 0.0; for (int j = 0; j < 64; j++) s += red[j][cl]; sg.dst[c] = (float)s; }
         return;
     }
 }
@@ -666,16 +682,18 @@ __global__ __launch_bounds__(PT_NARROW_BLOCK) void pt_pchain_bwd_kernel(long lon
 }
 
 // one workgroup: gradients of Linear(3,3) and BN_p from the backward sums T and the forward sums (BatchNorm's backward is linear in d)
-__global__ __launch_bounds__(64) void pt_pchain_epilogue_kernel(int nrows, const float* __restrict__ partial, long long rows, const float* __restrict__ cst,
-                                                                const float* __restrict__ gamma_p, float* __restrict__ g_Wp, float* __restrict__ g_bp,
-                                                                float* __restrict__ g_gamma_p, float* __restrict__ g_beta_p)
+__global__ __launch_bounds__(PT_FIN_THREADS) void pt_pchain_epilogue_kernel(int nrows, const float* __restrict__ partial, long long rows, const float* __restrict__ cst,
+                                                                            const float* __restrict__ gamma_p, float* __restrict__ g_Wp, float* __restrict__ g_bp,
+                                                                            float* __restrict__ g_gamma_p, float* __restrict__ g_beta_p)
 {
-    __shared__ double T[15];
-    if (threadIdx.x < 15) {
-        double s = 0.0;
-        for (int r = 0; r < nrows; r++) s += (double)partial[(size_t)r * 15 + threadIdx.x];
-        T[threadIdx.x] = s;
-    }
+    __shared__ double red[64][16];
+    __shared__ double T[16];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    double acc = 0.0;
+    if (cl < 15) for (int r = sl; r < nrows; r += 64) acc += (double)partial[(size_t)r * 15 + cl];
+    red[sl][cl] = acc;
+    __syncthreads();
+    if (sl == 0) { double s = 0.0; for (int j = 0; j < 64; j++) s += red[j][cl]; T[cl] = s; }
     __syncthreads();
     if (threadIdx.x < 3) {
         const int a = threadIdx.x;
@@ -689,16 +707,6 @@ __global__ __launch_bounds__(64) void pt_pchain_epilogue_kernel(int nrows, const
             const double R = (double)cst[PT_FS_P + 6 + b], X = (double)cst[PT_FS_P + 9 + 3 * a + b];
             g_Wp[3 * a + b] = (float)(A * (T[6 + 3 * a + b] - m1 * R - m2 * invstd * (X - mean * R)));
         }
-    }
-}
-
-// copies the raw forward sums of the p chain next to the constants (the epilogue above reads them in the backward pass)
-__global__ __launch_bounds__(64) void pt_pchain_raw_kernel(int nrows, const float* __restrict__ partial, float* __restrict__ cst)
-{
-    if (threadIdx.x < 18) {
-        double s = 0.0;
-        for (int r = 0; r < nrows; r++) s += (double)partial[(size_t)r * 18 + threadIdx.x];
-        cst[PT_FS_P + threadIdx.x] = (float)s;
     }
 }
 
@@ -856,17 +864,16 @@ CBL_EXPORT int cbl_pt_layer_forward(int n, int K, int C, const float* xyz, const
     for (int t = 0; t < 3; t++) { if (running_mean3) rm[t] = running_mean3[t]; if (running_var3) rv[t] = running_var3[t]; if (num_batches3) nb[t] = num_batches3[t]; }
 
     hipLaunchKernelGGL(pt_pchain_kernel, dim3(gp), dim3(PT_NARROW_BLOCK), 0, st, np, cbl_fastdiv_make((unsigned)K), xyz, idx, Wp, bp, p_r, p0, ws.part_b);
-    hipLaunchKernelGGL(pt_bn_finalize_kernel, dim3(1), dim3(256), 0, st, (int)gp, 18, 0, 3, 3, np, ws.part_b, gamma_p, beta_p, eps3[0], momentum3[0], rm[0], rv[0],
-                       nb[0], consts + PT_CST_P, 4, (float*)nullptr);
-    hipLaunchKernelGGL(pt_pchain_raw_kernel, dim3(1), dim3(64), 0, st, (int)gp, ws.part_b, consts);
+    hipLaunchKernelGGL(pt_bn_finalize_kernel, dim3(2), dim3(PT_FIN_THREADS), 0, st, (int)gp, 18, ws.part_b, 3, 0, 3, np, gamma_p, beta_p, eps3[0], momentum3[0],
+                       rm[0], rv[0], nb[0], consts + PT_CST_P, 4, 18, consts + PT_FS_P);
 #define PT_WSTATS(CC, KK) hipLaunchKernelGGL((pt_wstats_kernel<CC, KK>), dim3(gt), dim3(PT_BLOCK), 0, st, n, order, x_q, x_k, idx, p0, consts, W3C, b3C, p1, ws.part_a)
     PT_DISPATCH(PT_WSTATS)
-    hipLaunchKernelGGL(pt_bn_finalize_kernel, dim3(cbl_div_up(C, 16)), dim3(256), 0, st, (int)gt, 2 * C, 0, C, C, np, ws.part_a, gamma_c, beta_c, eps3[1], momentum3[1],
-                       rm[1], rv[1], nb[1], consts + PT_CST_C, 64, (float*)nullptr);
+    hipLaunchKernelGGL(pt_bn_finalize_kernel, dim3(cbl_div_up(C, 16)), dim3(PT_FIN_THREADS), 0, st, (int)gt, 2 * C, ws.part_a, C, 0, C, np, gamma_c, beta_c, eps3[1],
+                       momentum3[1], rm[1], rv[1], nb[1], consts + PT_CST_C, 64, 0, (float*)nullptr);
 #define PT_W2(CC, KK) hipLaunchKernelGGL((pt_w2_kernel<CC, KK>), dim3(gt), dim3(PT_BLOCK), 0, st, n, order, x_q, x_k, idx, p1, consts, W3C, b3C, Wa, ba, w2, ws.part_a)
     PT_DISPATCH(PT_W2)
-    hipLaunchKernelGGL(pt_bn_finalize_kernel, dim3(1), dim3(256), 0, st, (int)gt, 2 * G, 0, G, G, np, ws.part_a, gamma_g, beta_g, eps3[2], momentum3[2], rm[2], rv[2],
-                       nb[2], consts + PT_CST_G, 8, consts + PT_FS_G);
+    hipLaunchKernelGGL(pt_bn_finalize_kernel, dim3(1), dim3(PT_FIN_THREADS), 0, st, (int)gt, 2 * G, ws.part_a, G, 0, G, np, gamma_g, beta_g, eps3[2], momentum3[2],
+                       rm[2], rv[2], nb[2], consts + PT_CST_G, 8, G, consts + PT_FS_G);
 #define PT_SOFTMAX(GG, KK) hipLaunchKernelGGL((pt_softmax_kernel<GG, KK>), dim3(gp), dim3(PT_NARROW_BLOCK), 0, st, np, w2, consts, Wb, bb, a)
     if (G == 8 && K == 16) { PT_SOFTMAX(8, 16); } else if (G == 8) { PT_SOFTMAX(8, 8); } else if (K == 16) { PT_SOFTMAX(4, 16); } else { PT_SOFTMAX(4, 8); }
 #define PT_AGG(CC, KK) hipLaunchKernelGGL((pt_agg_kernel<CC, KK, false>), dim3(gt), dim3(PT_BLOCK), 0, st, n, order, x_v, idx, p1, W3C, b3C, a, out, (const float*)nullptr, (float*)nullptr)
@@ -896,16 +903,16 @@ CBL_EXPORT int cbl_pt_layer_backward(int n, int K, int C, const float* x_q, cons
     PT_DISPATCH(PT_AGGB)
     if (G == 8) hipLaunchKernelGGL(pt_narrow_bwd_kernel<8>, dim3(gp), dim3(PT_NARROW_BLOCK), 0, st, np, w2, consts, Wb, ws.glogit, ws.pre, ws.part_c);
     else        hipLaunchKernelGGL(pt_narrow_bwd_kernel<4>, dim3(gp), dim3(PT_NARROW_BLOCK), 0, st, np, w2, consts, Wb, ws.glogit, ws.pre, ws.part_c);
-    hipLaunchKernelGGL(pt_bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, (int)gp, WN, 0, G, G, np, ws.part_c, gamma_g, consts + PT_CST_G, 8, ws.bc + PT_BC_G, 8,
+    hipLaunchKernelGGL(pt_bn_bwd_finalize_kernel, dim3(1), dim3(PT_FIN_THREADS), 0, st, (int)gp, WN, 0, G, G, np, ws.part_c, gamma_g, consts + PT_CST_G, 8, ws.bc + PT_BC_G, 8,
                        g_gamma_g, g_beta_g, consts + PT_FS_G, g_ba);
 #define PT_REDUCE(CC, KK) hipLaunchKernelGGL((pt_w2_bwd_kernel<CC, KK, false>), dim3(gt), dim3(PT_BLOCK), 0, st, n, order, x_q, x_k, idx, p1, consts, ws.bc, W3C, b3C, Wa, w2, ws.pre, ws.gw2, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, ws.part_a)
     PT_DISPATCH(PT_REDUCE)
-    hipLaunchKernelGGL(pt_bn_bwd_finalize_kernel, dim3(cbl_div_up(C, 16)), dim3(256), 0, st, (int)gt, 2 * C + G * C, 0, C, C, np, ws.part_a, gamma_c, consts + PT_CST_C, 64,
+    hipLaunchKernelGGL(pt_bn_bwd_finalize_kernel, dim3(cbl_div_up(C, 16)), dim3(PT_FIN_THREADS), 0, st, (int)gt, 2 * C + G * C, 0, C, C, np, ws.part_a, gamma_c, consts + PT_CST_C, 64,
                        ws.bc + PT_BC_C, 64, g_gamma_c, g_beta_c, (const float*)nullptr, (float*)nullptr);
 #define PT_APPLY(CC, KK) hipLaunchKernelGGL((pt_w2_bwd_kernel<CC, KK, true>), dim3(gt), dim3(PT_BLOCK), 0, st, n, order, x_q, x_k, idx, p1, consts, ws.bc, W3C, b3C, Wa, w2, ws.pre, ws.gw2, a, grad_out, g_xq, ws.gp1, ws.part_b)
     PT_DISPATCH(PT_APPLY)
     hipLaunchKernelGGL(pt_pchain_bwd_kernel, dim3(gp), dim3(PT_NARROW_BLOCK), 0, st, np, p_r, p0, p1, ws.gp1, consts, ws.part_d);
-    hipLaunchKernelGGL(pt_pchain_epilogue_kernel, dim3(1), dim3(64), 0, st, (int)gp, ws.part_d, np, consts, gamma_p, g_Wp, g_bp, g_gamma_p, g_beta_p);
+    hipLaunchKernelGGL(pt_pchain_epilogue_kernel, dim3(1), dim3(PT_FIN_THREADS), 0, st, (int)gp, ws.part_d, np, consts, gamma_p, g_Wp, g_bp, g_gamma_p, g_beta_p);
     {
         const unsigned tg = cbl_round_up8(cbl_grid_for(((long long)n + (256 / (C / 4)) - 1) / (256 / (C / 4)), 1, 2048));
 #define PT_TARGET(CC, KK) hipLaunchKernelGGL((pt_target_kernel<CC, KK>), dim3(tg), dim3(256), 0, st, (unsigned)n, order, inv_start, inv_src, x_q, x_k, p1, consts, ws.bc, W3C, b3C, Wa, ws.gw2, a, grad_out, g_xk, g_xv)
@@ -920,6 +927,6 @@ CBL_EXPORT int cbl_pt_layer_backward(int n, int K, int C, const float* x_q, cons
     segs.s[4] = PtSumSeg{ws.part_c, g_bb, (int)gp, WN, 2 * G + G * G, G};
     unsigned nblk = 0;
     for (int q = 0; q < segs.n; q++) nblk += (unsigned)((segs.s[q].count + 15) / 16);
-    hipLaunchKernelGGL(pt_sum_rows_kernel, dim3(nblk), dim3(256), 0, st, segs);
+    hipLaunchKernelGGL(pt_sum_rows_kernel, dim3(nblk), dim3(PT_FIN_THREADS), 0, st, segs);
     return cbl_status();
 }
