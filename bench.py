@@ -63,6 +63,8 @@ def parse(argv=None):
     ap.add_argument("--no-nested", action="store_true", help="every neighbour search on its own (no derivation of K=16 from the K=36 search of the same points)")
     ap.add_argument("--no-allreduce", action="store_true", help="skip the gradient all-reduce leg of a multi-rank run")
     ap.add_argument("--no-extra", action="store_true", help="headline only: no forward_only / stage / all-reduce legs (profiling runs)")
+    ap.add_argument("--no-legs", action="store_true",
+                    help="default line only: skip the `pt_block` (config C4) and `convnet` (configs C5 / C3 per scene) legs the 1-GPU default run appends")
     ap.add_argument("--allreduce-floats", type=int, default=GRAD_ALLREDUCE_FLOATS)
     ap.add_argument("--allreduce-single", action="store_true",
                     help="tests: run the gradient all-reduce leg over a ONE-rank RCCL group (exercises the RCCL path on a 1-GPU box; not a scaling number)")
@@ -451,6 +453,10 @@ def run_gpu(args, D, world, rank, local):
                                  "note": "one flat fp32 all-reduce of the reference network's 7,800,497 gradients per step over RCCL, started behind step i and "
                                          "joined behind step i+1, i.e. running beside the next step (what DDP adds, train.py:181-185); `value` above is the "
                                          "replica-only number"}
+    if rank == 0 and world == 1 and not args.no_legs and (n, c, k) == (40960, 64, 16) and backward:
+        del step
+        torch.cuda.empty_cache()
+        out.update(workload_legs(args))
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             from tests import cpu_baseline
@@ -465,6 +471,54 @@ def run_gpu(args, D, world, rank, local):
         print(json.dumps(out), flush=True)
     return finish(world)
 
+
+
+# ------------------------------------------------------------------------------------------------ C4 / C5 legs of the default line
+def workload_legs(args):
+    """The driver only ever runs the default command line, so the 1-GPU default run also measures BASELINE's other two single-GPU configurations —
+    C4 (`--block pt`: the Point Transformer's vector-attention block) and C5 / C3-per-scene (`--workload convnet`) — each in a process of its own
+    (own graphs, caches, scene) with the same timing contract, and appends a compact object per leg: {metric, value, ms_per_step, steps, roofline ...}.
+    A leg that fails is reported as {"error": ...} and does not take the headline down."""
+    import subprocess
+
+    def leg(extra, pick):
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-cpu-baseline", "--no-legs"] + extra
+        env = dict(os.environ)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not lines:
+                return {"error": "rc %d: %s" % (r.returncode, (r.stderr or "").strip()[-300:]), "command": " ".join(cmd[1:])}
+            d = json.loads(lines[-1])
+            o = {k: d[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "host_issue_ms_per_step", "dtype") if k in d}
+            o["workload"] = d.get("config", {}).get("workload")
+            o["issue"] = d.get("config", {}).get("issue")
+            o["command"] = "python bench.py " + " ".join(extra)
+            o.update(pick(d))
+            return o
+        except Exception as e:                                       # noqa: BLE001 — a leg must not take the headline down
+            return {"error": repr(e)[:300], "command": " ".join(cmd[1:])}
+
+    def pick_pt(d):
+        r = d.get("roofline", {})
+        return {"roofline": {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "bytes_per_launch", "launch_us", "flops_per_launch",
+                                                  "achieved_TFLOPs", "frac_of_f32_mfma_peak", "layer_bwd_us", "stage_ms") if k in r},
+                "forward_only_ms_per_step": d.get("forward_only", {}).get("ms_per_step"),
+                "pipelined_ms_per_step": d.get("pipelined", {}).get("ms_per_step")}
+
+    def pick_convnet(d):
+        r = d.get("roofline", {})
+        keep = {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "bytes_per_launch", "launch_us", "stage_ms", "stage_sum_ms") if k in r}
+        for sub in ("adaptive_weight", "adaptive_weight_bwd"):
+            if sub in r:
+                keep[sub] = {k: r[sub].get(k) for k in ("frac", "achieved", "launch_us", "bytes_per_launch", "frac_of_f32_vector_peak") if k in r[sub]}
+        return {"roofline": keep}
+
+    steps = str(min(args.steps, 30)); warm = str(min(args.warmup, 5))
+    return {"pt_block": leg(["--block", "pt", "--steps", steps, "--warmup", warm], pick_pt),
+            "convnet": leg(["--workload", "convnet", "--steps", str(min(args.steps, 20)), "--warmup", str(min(args.warmup, 3))], pick_convnet)}
 
 # ------------------------------------------------------------------------------------------------ ConvNet workload (BASELINE configs C5 / C3)
 def run_convnet(args, D, world, rank, local):

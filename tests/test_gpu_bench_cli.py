@@ -35,6 +35,12 @@ def test_bench_json_contract_and_rccl_allreduce_leg():
     assert "backward" in out["config"]["workload"] and "forward_only" in out
     ar = out["grad_allreduce"]                                        # one flat fp32 buffer of the network's 7,800,497 gradients per step over RCCL
     assert ar["bytes"] == 4 * 7800497 and ar["ranks"] == 1 and ar["ms_per_step"] > 0 and ar["allreduce_alone_ms"] > 0
+    # the default line carries BASELINE's other single-GPU configurations as legs (each measured in a process of its own)
+    pt, cn = out["pt_block"], out["convnet"]
+    assert "error" not in pt and "error" not in cn, (pt, cn)
+    assert "PointTransformer" in pt["metric"] and pt["ms_per_step"] > 0 and abs(pt["value"] - 40960 / (pt["ms_per_step"] * 1e-3)) < 1e-6 * pt["value"]
+    assert pt["roofline"]["frac_of_f32_mfma_peak"] > 0 and pt["roofline"]["frac"] > 0
+    assert "ConvNet" in cn["metric"] and cn["ms_per_step"] > 0 and cn["roofline"]["frac"] > 0 and "adaptive_weight" in cn["roofline"]
 
 
 def test_bench_under_torchrun_environment():
