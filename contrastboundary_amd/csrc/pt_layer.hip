@@ -70,23 +70,45 @@ template <int K> __device__ __forceinline__ float pt_point_sum(float v)
 }
 
 // ---- tile geometry -------------------------------------------------------------------------------------------------------------------
-// slot s of tile t is pair (point = order[t * (16 / K) + s / K], k = s % K)
-struct PtSlot { int i; long long p; bool valid; };
-template <int K> __device__ __forceinline__ PtSlot pt_slot(unsigned tile, int s, int n, const int* __restrict__ order)
+// slot s of tile t is pair (point = order[t * (16 / K) + s / K], k = s % K).  A lane needs two slots: lo (pair-major operands) and 4 hi .. 4 hi + 3
+// (channel-major values; K is a multiple of 4, so the four share a point).
+struct PtS0 { int iA, iD, pA, pD; bool vA, vD, live; };
+template <int K> __device__ __forceinline__ PtS0 pt_stage0(unsigned tile, unsigned ntiles, int n, const int* __restrict__ order, int lo, int hi)
 {
-    const unsigned rank = tile * (16 / K) + (unsigned)(s / K);
-    PtSlot r;
-    r.valid = rank < (unsigned)n;
-    const unsigned rc = r.valid ? rank : (unsigned)(n - 1);
-    r.i = order ? order[rc] : (int)rc;
-    r.p = (long long)r.i * K + (s % K);
+    PtS0 r;
+    r.live = tile < ntiles;
+    const unsigned t = r.live ? tile : ntiles - 1;                   // a tile beyond the range: harmless addresses, nothing computed
+    const unsigned ra = t * (16 / K) + (unsigned)(lo / K), rd = t * (16 / K) + (unsigned)((4 * hi) / K);
+    r.vA = r.live && ra < (unsigned)n; r.vD = r.live && rd < (unsigned)n;
+    const unsigned ca = ra < (unsigned)n ? ra : (unsigned)(n - 1), cd = rd < (unsigned)n ? rd : (unsigned)(n - 1);
+    r.iA = order ? order[ca] : (int)ca;
+    r.iD = (K == 16) ? r.iA : (order ? order[cd] : (int)cd);
+    r.pA = r.iA * K + (lo % K);
+    r.pD = r.iD * K + ((4 * hi) % K);
     return r;
 }
 
-#define PT_TILE_LOOP(tile, ntiles)                                                                              \
-    const unsigned ntrips_ = ((ntiles) + PT_WPB - 1) / PT_WPB;                                                  \
-    for (unsigned v_ = blockIdx.x; v_ < 8u * cbl_xcd_per(ntrips_); v_ += gridDim.x)                             \
-        if (const unsigned tile = cbl_xcd_slot(v_, ntrips_) * PT_WPB + (threadIdx.x >> 6); tile < (ntiles))
+// Software pipeline of a tile pass.  A tile's loads form a chain of three dependent levels — order[rank] -> the pair's neighbour id and narrow
+// values -> the gathered rows — and a wave that walks its tiles one after the other pays the three latencies per tile (measured: 0.6 - 0.76 of
+// all wave cycles parked on memory, 3 us per tile).  Here every level of a LATER tile is requested before the current tile is computed:
+// level 0 three tiles ahead, level 1 two, level 2 one; the wave waits for nothing it has not requested a whole tile's compute earlier.
+template <class L0, class L1, class L2, class CP>
+__device__ __forceinline__ void pt_pipeline(unsigned ntiles, L0 load0, L1 load1, L2 load2, CP compute)
+{
+    const unsigned ntrips = (ntiles + PT_WPB - 1) / PT_WPB, vend = 8u * cbl_xcd_per(ntrips), step = gridDim.x, wave = threadIdx.x >> 6;
+    auto tile_of = [&](unsigned v) -> unsigned { return v < vend ? cbl_xcd_slot(v, ntrips) * PT_WPB + wave : 0xffffffffu; };
+    unsigned v = blockIdx.x;
+    auto a0 = load0(tile_of(v)); auto a1 = load0(tile_of(v + step)); auto a2 = load0(tile_of(v + 2 * step));
+    auto b0 = load1(a0); auto b1 = load1(a1);
+    auto c0 = load2(a0, b0);
+    for (; v < vend; v += step) {
+        auto c1 = load2(a1, b1);
+        auto b2 = load1(a2);
+        auto a3 = load0(tile_of(v + 3 * step));
+        if (a0.live) compute(a0, b0, c0);
+        a0 = a1; a1 = a2; a2 = a3; b0 = b1; b1 = b2; c0 = c1;
+    }
+}
 
 // ---- p chain: p_r, p0 and the sums of BN_p (lane = pair) ------------------------------------------------------------------------------
 // partial row: p0 [3] | p0^2 [3] | p_r [3] | p0[a] p_r[b] [9]   (the last two feed the Linear(3,3) gradient without another pass, pchain_bwd)
@@ -239,6 +261,17 @@ template <int C> __device__ __forceinline__ PtPe<C> pt_pe_load(const float* __re
 
 // ---- BN_c statistics of w (pair-major); writes p1 ---------------------------------------------------------------------------------------
 // partial row: sum w [C] | sum w^2 [C]
+template <int CT> struct PtRowsPM { float4 k[CT], q[CT]; };          // pair-major rows: x_k[j] and x_q[i], channels 16 ct + 4 hi ..
+template <int C> __device__ __forceinline__ PtRowsPM<C / 16> pt_rows_pm(const float* __restrict__ xk, const float* __restrict__ xq, int j, int i, int hi)
+{
+    PtRowsPM<C / 16> r;
+    const float4* kr = reinterpret_cast<const float4*>(xk + (size_t)j * C + 4 * hi);
+    const float4* qr = reinterpret_cast<const float4*>(xq + (size_t)i * C + 4 * hi);
+#pragma unroll
+    for (int ct = 0; ct < C / 16; ct++) { r.k[ct] = kr[4 * ct]; r.q[ct] = qr[4 * ct]; }
+    return r;
+}
+
 template <int C, int K>
 __global__ __launch_bounds__(PT_BLOCK) void pt_wstats_kernel(int n, const int* __restrict__ order, const float* __restrict__ xq, const float* __restrict__ xk,
                                                              const int* __restrict__ idx, const float* __restrict__ p0, const float* __restrict__ cst,
@@ -256,27 +289,25 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_wstats_kernel(int n, const int* _
 #pragma unroll
         for (int v = 0; v < 4; v++) { s0[ct][v] = 0.f; s1[ct][v] = 0.f; }
     const unsigned ntiles = (unsigned)(((long long)n * K + 15) / 16);
-    PT_TILE_LOOP(tile, ntiles) {
-        const PtSlot sa = pt_slot<K>(tile, lo, n, order);
-        const int j = idx[sa.p];
-        // p1 of (pair, d = hi): this lane's B operand; hi = 3 carries the 1 that multiplies the bias
-        float p1x = 1.f;
-        if (hi < 3) { p1x = fmaxf(fmaf(p0[3 * sa.p + hi], psc, psh), 0.f); if (sa.valid) p1[3 * sa.p + hi] = p1x; }
-        const float4* kr = reinterpret_cast<const float4*>(xk + (size_t)j * C + 4 * hi);
-        const float4* qr = reinterpret_cast<const float4*>(xq + (size_t)sa.i * C + 4 * hi);
-        float4 kv[CT], qv[CT];
+    struct S1 { int j; float p0v; };
+    pt_pipeline(ntiles,
+        [&](unsigned tile) { return pt_stage0<K>(tile, ntiles, n, order, lo, hi); },
+        [&](const PtS0& a) { S1 b; b.j = idx[a.pA]; b.p0v = hi < 3 ? p0[3 * (size_t)a.pA + hi] : 0.f; return b; },
+        [&](const PtS0& a, const S1& b) { return pt_rows_pm<C>(xk, xq, b.j, a.iA, hi); },
+        [&](const PtS0& a, const S1& b, const PtRowsPM<CT>& r) {
+            // p1 of (pair, d = hi): this lane's B operand; hi = 3 carries the 1 that multiplies the bias
+            const float p1x = fmaxf(fmaf(b.p0v, psc, psh), 0.f);
+            if (hi < 3 && a.vA) p1[3 * (size_t)a.pA + hi] = p1x;
 #pragma unroll
-        for (int ct = 0; ct < CT; ct++) { kv[ct] = kr[4 * ct]; qv[ct] = qr[4 * ct]; }
+            for (int ct = 0; ct < CT; ct++) {
+                pt_f32x4 w = pt_vec4(r.k[ct].x - r.q[ct].x, r.k[ct].y - r.q[ct].y, r.k[ct].z - r.q[ct].z, r.k[ct].w - r.q[ct].w);
+                w = pt_mfma(pe.w[ct], p1x, w);
+                if (a.vA) {
 #pragma unroll
-        for (int ct = 0; ct < CT; ct++) {
-            pt_f32x4 w = pt_vec4(kv[ct].x - qv[ct].x, kv[ct].y - qv[ct].y, kv[ct].z - qv[ct].z, kv[ct].w - qv[ct].w);
-            w = pt_mfma(pe.w[ct], p1x, w);
-            if (sa.valid) {
-#pragma unroll
-                for (int v = 0; v < 4; v++) { s0[ct][v] += w[v]; s1[ct][v] = fmaf(w[v], w[v], s1[ct][v]); }
+                    for (int v = 0; v < 4; v++) { s0[ct][v] += w[v]; s1[ct][v] = fmaf(w[v], w[v], s1[ct][v]); }
+                }
             }
-        }
-    }
+        });
 #pragma unroll
     for (int ct = 0; ct < CT; ct++)
 #pragma unroll
@@ -302,44 +333,41 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_kernel(int n, const int* __res
 {
     constexpr int CT = C / 16, G = C / 8;
     __shared__ float red[PT_WPB][2 * G];
+    __shared__ float4 bnc[2][C / 4];                                 // scale / shift of BN_c: read per use (every lane of a row reads the same words)
     const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4, wave = threadIdx.x >> 6;
+    if (threadIdx.x < C / 2) bnc[threadIdx.x / (C / 4)][threadIdx.x % (C / 4)] = *reinterpret_cast<const float4*>(cst + PT_CST_C + 64 * (threadIdx.x / (C / 4)) + 4 * (threadIdx.x % (C / 4)));
     const PtPe<C> pe = pt_pe_load<C>(W3C, b3C, lo, hi);
-    float4 sc[CT], sh[CT], wb[CT];
+    float4 wb[CT];
 #pragma unroll
-    for (int ct = 0; ct < CT; ct++) {
-        sc[ct] = *reinterpret_cast<const float4*>(cst + PT_CST_C + 16 * ct + 4 * hi);
-        sh[ct] = *reinterpret_cast<const float4*>(cst + PT_CST_C + 64 + 16 * ct + 4 * hi);
+    for (int ct = 0; ct < CT; ct++)
         wb[ct] = lo < G ? *reinterpret_cast<const float4*>(Wa + (size_t)lo * C + 16 * ct + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);   // B[k = hi][col = g]
-    }
     const float bias = lo < G ? ba[lo] : 0.f;
     float t0 = 0.f, t1 = 0.f;
+    __syncthreads();
     const unsigned ntiles = (unsigned)(((long long)n * K + 15) / 16);
-    PT_TILE_LOOP(tile, ntiles) {
-        const PtSlot sa = pt_slot<K>(tile, lo, n, order);
-        const PtSlot sd = pt_slot<K>(tile, 4 * hi, n, order);
-        const int j = idx[sa.p];
-        const float p1x = hi < 3 ? p1[3 * sa.p + hi] : 1.f;
-        const float4* kr = reinterpret_cast<const float4*>(xk + (size_t)j * C + 4 * hi);
-        const float4* qr = reinterpret_cast<const float4*>(xq + (size_t)sa.i * C + 4 * hi);
-        float4 kv[CT], qv[CT];
+    struct S1 { int j; float p1x; };
+    pt_pipeline(ntiles,
+        [&](unsigned tile) { return pt_stage0<K>(tile, ntiles, n, order, lo, hi); },
+        [&](const PtS0& a) { S1 b; b.j = idx[a.pA]; b.p1x = hi < 3 ? p1[3 * (size_t)a.pA + hi] : 1.f; return b; },
+        [&](const PtS0& a, const S1& b) { return pt_rows_pm<C>(xk, xq, b.j, a.iA, hi); },
+        [&](const PtS0& a, const S1& b, const PtRowsPM<CT>& r) {
+            pt_f32x4 o0 = pt_vec4(bias, bias, bias, bias), o1 = pt_vec4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int ct = 0; ct < CT; ct++) { kv[ct] = kr[4 * ct]; qv[ct] = qr[4 * ct]; }
-        pt_f32x4 o0 = pt_vec4(bias, bias, bias, bias), o1 = pt_vec4(0.f, 0.f, 0.f, 0.f);
+            for (int ct = 0; ct < CT; ct++) {
+                pt_f32x4 w = pt_vec4(r.k[ct].x - r.q[ct].x, r.k[ct].y - r.q[ct].y, r.k[ct].z - r.q[ct].z, r.k[ct].w - r.q[ct].w);
+                w = pt_mfma(pe.w[ct], b.p1x, w);
+                const float4 sc = bnc[0][4 * ct + hi], sh = bnc[1][4 * ct + hi];
+                o0 = pt_mfma(fmaxf(fmaf(w[0], sc.x, sh.x), 0.f), wb[ct].x, o0);
+                o1 = pt_mfma(fmaxf(fmaf(w[1], sc.y, sh.y), 0.f), wb[ct].y, o1);
+                o0 = pt_mfma(fmaxf(fmaf(w[2], sc.z, sh.z), 0.f), wb[ct].z, o0);
+                o1 = pt_mfma(fmaxf(fmaf(w[3], sc.w, sh.w), 0.f), wb[ct].w, o1);
+            }
+            // D[pair slot 4 hi + v][g = lo]
+            if (lo < G && a.vD) {
 #pragma unroll
-        for (int ct = 0; ct < CT; ct++) {
-            pt_f32x4 w = pt_vec4(kv[ct].x - qv[ct].x, kv[ct].y - qv[ct].y, kv[ct].z - qv[ct].z, kv[ct].w - qv[ct].w);
-            w = pt_mfma(pe.w[ct], p1x, w);
-            o0 = pt_mfma(fmaxf(fmaf(w[0], sc[ct].x, sh[ct].x), 0.f), wb[ct].x, o0);
-            o1 = pt_mfma(fmaxf(fmaf(w[1], sc[ct].y, sh[ct].y), 0.f), wb[ct].y, o1);
-            o0 = pt_mfma(fmaxf(fmaf(w[2], sc[ct].z, sh[ct].z), 0.f), wb[ct].z, o0);
-            o1 = pt_mfma(fmaxf(fmaf(w[3], sc[ct].w, sh[ct].w), 0.f), wb[ct].w, o1);
-        }
-        // D[pair slot 4 hi + v][g = lo]
-        if (lo < G && sd.valid) {
-#pragma unroll
-            for (int v = 0; v < 4; v++) { const float r = o0[v] + o1[v]; w2[(sd.p + v) * G + lo] = r; t0 += r; t1 = fmaf(r, r, t1); }
-        }
-    }
+                for (int v = 0; v < 4; v++) { const float x = o0[v] + o1[v]; w2[(size_t)(a.pD + v) * G + lo] = x; t0 += x; t1 = fmaf(x, x, t1); }
+            }
+        });
     t0 += pt_xor16(t0); t0 += pt_xor32(t0); t1 += pt_xor16(t1); t1 += pt_xor32(t1);
     if (hi == 0 && lo < G) { red[wave][lo] = t0; red[wave][G + lo] = t1; }
     __syncthreads();
@@ -398,51 +426,59 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_agg_kernel(int n, const int* __re
     const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
     const PtPe<C> pe = pt_pe_load<C>(W3C, b3C, lo, hi);
     const unsigned ntiles = (unsigned)(((long long)n * K + 15) / 16);
-    PT_TILE_LOOP(tile, ntiles) {
-        const PtSlot sa = pt_slot<K>(tile, lo, n, order);
-        const PtSlot sd = pt_slot<K>(tile, 4 * hi, n, order);
-        const float p1x = hi < 3 ? p1[3 * sa.p + hi] : 1.f;                      // A[pair slot lo][d = hi]
-        const int4 j4 = *reinterpret_cast<const int4*>(idx + sd.p);
-        const int jv[4] = {j4.x, j4.y, j4.z, j4.w};
-        float av[4];
+    struct S1 { int4 j; float p1x; float av[4]; };
+    struct S2 { pt_f32x4 val[CT]; float go[CT]; };
+    pt_pipeline(ntiles,
+        [&](unsigned tile) { return pt_stage0<K>(tile, ntiles, n, order, lo, hi); },
+        [&](const PtS0& t) {
+            S1 b;
+            b.j = *reinterpret_cast<const int4*>(idx + t.pD);
+            b.p1x = hi < 3 ? p1[3 * (size_t)t.pA + hi] : 1.f;                     // A[pair slot lo][d = hi]
 #pragma unroll
-        for (int v = 0; v < 4; v++) av[v] = a[(sd.p + v) * G + (lo % G)];
-        pt_f32x4 val[CT];
-#pragma unroll
-        for (int ct = 0; ct < CT; ct++)
-            val[ct] = pt_vec4(xv[(size_t)jv[0] * C + 16 * ct + lo], xv[(size_t)jv[1] * C + 16 * ct + lo], xv[(size_t)jv[2] * C + 16 * ct + lo],
-                              xv[(size_t)jv[3] * C + 16 * ct + lo]);
-#pragma unroll
-        for (int ct = 0; ct < CT; ct++) val[ct] = pt_mfma(p1x, pe.w[ct], val[ct]);           // x_v[j] + pe of (slot 4 hi + v, channel 16 ct + lo)
-        if (!BWD) {
+            for (int v = 0; v < 4; v++) b.av[v] = a[(size_t)(t.pD + v) * G + (lo % G)];
+            return b;
+        },
+        [&](const PtS0& t, const S1& b) {
+            S2 r;
 #pragma unroll
             for (int ct = 0; ct < CT; ct++) {
-                float o = fmaf(av[3], val[ct][3], fmaf(av[2], val[ct][2], fmaf(av[1], val[ct][1], av[0] * val[ct][0])));
-                o = pt_point_sum<K>(o);
-                if (sd.valid && (K == 16 ? hi == 0 : (hi & 1) == 0)) out[(size_t)sd.i * C + 16 * ct + lo] = o;
+                r.val[ct] = pt_vec4(xv[(size_t)b.j.x * C + 16 * ct + lo], xv[(size_t)b.j.y * C + 16 * ct + lo], xv[(size_t)b.j.z * C + 16 * ct + lo],
+                                    xv[(size_t)b.j.w * C + 16 * ct + lo]);
+                r.go[ct] = BWD ? gout[(size_t)t.iD * C + 16 * ct + lo] : 0.f;
             }
-        } else {
-            float ga[4] = {0.f, 0.f, 0.f, 0.f};
+            return r;
+        },
+        [&](const PtS0& t, const S1& b, const S2& r) {
+            pt_f32x4 val[CT];
 #pragma unroll
-            for (int ct = 0; ct < CT; ct++) {
-                const float go = gout[(size_t)sd.i * C + 16 * ct + lo];
+            for (int ct = 0; ct < CT; ct++) val[ct] = pt_mfma(b.p1x, pe.w[ct], r.val[ct]);           // x_v[j] + pe of (slot 4 hi + v, channel 16 ct + lo)
+            if (!BWD) {
 #pragma unroll
-                for (int v = 0; v < 4; v++) ga[v] = fmaf(go, val[ct][v], ga[v]);
+                for (int ct = 0; ct < CT; ct++) {
+                    float o = fmaf(b.av[3], val[ct][3], fmaf(b.av[2], val[ct][2], fmaf(b.av[1], val[ct][1], b.av[0] * val[ct][0])));
+                    o = pt_point_sum<K>(o);
+                    if (t.vD && (K == 16 ? hi == 0 : (hi & 1) == 0)) out[(size_t)t.iD * C + 16 * ct + lo] = o;
+                }
+            } else {
+                float ga[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+                    for (int v = 0; v < 4; v++) ga[v] = fmaf(r.go[ct], val[ct][v], ga[v]);
+                float dot = 0.f;
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    ga[v] += pt_row_ror8(ga[v]);                                     // the lanes lo = g (mod G)
+                    if (G == 4) ga[v] += pt_row_ror4(ga[v]);
+                    dot = fmaf(b.av[v], ga[v], dot);
+                }
+                dot = pt_point_sum<K>(dot);
+                if (lo < G && t.vD) {
+#pragma unroll
+                    for (int v = 0; v < 4; v++) glogit[(size_t)(t.pD + v) * G + lo] = b.av[v] * (ga[v] - dot);
+                }
             }
-            float dot = 0.f;
-#pragma unroll
-            for (int v = 0; v < 4; v++) {
-                ga[v] += pt_row_ror8(ga[v]);                                     // the lanes lo = g (mod G)
-                if (G == 4) ga[v] += pt_row_ror4(ga[v]);
-                dot = fmaf(av[v], ga[v], dot);
-            }
-            dot = pt_point_sum<K>(dot);
-            if (lo < G && sd.valid) {
-#pragma unroll
-                for (int v = 0; v < 4; v++) glogit[(sd.p + v) * G + lo] = av[v] * (ga[v] - dot);
-            }
-        }
-    }
+        });
 }
 
 // ---- narrow backward (lane = pair): d w2 BEFORE BN_g's backward, its two sums, d Wb, d bb ------------------------------------------------
@@ -522,6 +558,7 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
     for (int ct = 0; ct < CT; ct++) {
         const int c = 16 * ct + lo;
         sc[ct] = cst[PT_CST_C + c]; sh[ct] = cst[PT_CST_C + 64 + c];
+        k3[ct] = 0.f; w3[ct][0] = 0.f; w3[ct][1] = 0.f; w3[ct][2] = 0.f;
         if (APPLY) {
             k1[ct] = bc[PT_BC_C + c]; k2[ct] = bc[PT_BC_C + 64 + c]; k3[ct] = bc[PT_BC_C + 128 + c];
 #pragma unroll
@@ -546,78 +583,100 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
 #pragma unroll
     for (int ct = 0; ct < CT; ct++) { s1[ct] = 0.f; s2[ct] = 0.f; accw[ct] = pt_vec4(0.f, 0.f, 0.f, 0.f); }
     const unsigned ntiles = (unsigned)(((long long)n * K + 15) / 16);
-    PT_TILE_LOOP(tile, ntiles) {
-        const PtSlot sa = pt_slot<K>(tile, lo, n, order);
-        const PtSlot sd = pt_slot<K>(tile, 4 * hi, n, order);
-        const float p1x = hi < 3 ? p1[3 * sa.p + hi] : 1.f;
-        // d w2 of (pair slot lo, g = hi / hi + 4): the A operand of d y = d w2 . Wa
-        float da0 = 0.f, da1 = 0.f;
-        if (APPLY) {
-            if (sa.valid && hi < G) da0 = gw2[sa.p * G + hi];
-            if (sa.valid && G == 8) da1 = gw2[sa.p * G + hi + 4];
-        } else {
-            if (sa.valid && hi < G) { da0 = fmaf(ga1[0], pre[sa.p * G + hi], fmaf(ga2[0], w2[sa.p * G + hi], ga3[0])); gw2[sa.p * G + hi] = da0; }
-            if (sa.valid && G == 8) { da1 = fmaf(ga1[1], pre[sa.p * G + hi + 4], fmaf(ga2[1], w2[sa.p * G + hi + 4], ga3[1])); gw2[sa.p * G + hi + 4] = da1; }
-        }
-        const int4 j4 = *reinterpret_cast<const int4*>(idx + sd.p);
-        const int jv[4] = {j4.x, j4.y, j4.z, j4.w};
-        pt_f32x4 w[CT];
-#pragma unroll
-        for (int ct = 0; ct < CT; ct++) {
-            const float q = xq[(size_t)sd.i * C + 16 * ct + lo];
-            w[ct] = pt_vec4(xk[(size_t)jv[0] * C + 16 * ct + lo] - q, xk[(size_t)jv[1] * C + 16 * ct + lo] - q, xk[(size_t)jv[2] * C + 16 * ct + lo] - q,
-                            xk[(size_t)jv[3] * C + 16 * ct + lo] - q);
-        }
-        // the narrow operands held per (slot 4 hi + v): REDUCE d w2[.., g = lo] (A of d Wa), APPLY [p1, 1][.., d = lo] (A of d W3C) and a[.., lo % G]
-        float nv[4], av[4];
-#pragma unroll
-        for (int v = 0; v < 4; v++) {
-            nv[v] = 0.f; av[v] = 0.f;
+    // level 1: neighbour ids and the narrow values.  REDUCE: `pre` / w2 at (slot lo, g = hi | hi + 4) -> x0..x3 and at (slot 4 hi + v, g = lo) -> u / y;
+    // APPLY: d w2 at (slot lo, g = hi | hi + 4) -> x0, x1; [p1, 1] at (slot 4 hi + v, d = lo) -> u; a at (slot 4 hi + v, lo % G) -> y
+    struct S1 { int4 j; float p1x, x0, x1, x2, x3; float u[4], y[4]; };
+    struct S2 { pt_f32x4 k[CT]; float q[CT], go[CT]; };
+    pt_pipeline(ntiles,
+        [&](unsigned tile) { return pt_stage0<K>(tile, ntiles, n, order, lo, hi); },
+        [&](const PtS0& t) {
+            S1 b;
+            b.j = *reinterpret_cast<const int4*>(idx + t.pD);
+            b.p1x = hi < 3 ? p1[3 * (size_t)t.pA + hi] : 1.f;
+            b.x0 = b.x1 = b.x2 = b.x3 = 0.f;
+            const size_t ra = (size_t)t.pA * G;
             if (APPLY) {
-                if (sd.valid) { nv[v] = lo < 3 ? p1[3 * (sd.p + v) + lo] : (lo == 3 ? 1.f : 0.f); av[v] = a[(sd.p + v) * G + (lo % G)]; }
+                if (hi < G) b.x0 = gw2[ra + hi];
+                if (G == 8) b.x1 = gw2[ra + hi + 4];
             } else {
-                if (sd.valid && lo < G) nv[v] = fmaf(ga1[2], pre[(sd.p + v) * G + lo], fmaf(ga2[2], w2[(sd.p + v) * G + lo], ga3[2]));
+                if (hi < G) { b.x0 = pre[ra + hi]; b.x2 = w2[ra + hi]; }
+                if (G == 8) { b.x1 = pre[ra + hi + 4]; b.x3 = w2[ra + hi + 4]; }
             }
-        }
-        float t3[4][3];
-#pragma unroll
-        for (int v = 0; v < 4; v++) { t3[v][0] = 0.f; t3[v][1] = 0.f; t3[v][2] = 0.f; }
-#pragma unroll
-        for (int ct = 0; ct < CT; ct++) {
-            w[ct] = pt_mfma(p1x, pe.w[ct], w[ct]);
-            pt_f32x4 gy = pt_mfma(da0, wa0[ct], pt_vec4(0.f, 0.f, 0.f, 0.f));
-            if (G == 8) gy = pt_mfma(da1, wa1[ct], gy);
-            const float go = APPLY ? gout[(size_t)sd.i * C + 16 * ct + lo] : 0.f;
-            float sq = 0.f;
 #pragma unroll
             for (int v = 0; v < 4; v++) {
-                const float y = fmaf(w[ct][v], sc[ct], sh[ct]);
-                const float g1 = y > 0.f ? gy[v] : 0.f;
-                if (APPLY) {
-                    const float dw = sd.valid ? fmaf(k1[ct], g1, fmaf(k2[ct], w[ct][v], k3[ct])) : 0.f;
-                    sq += dw;
-                    const float dpe = fmaf(go, av[v], dw);
+                const size_t rd = (size_t)(t.pD + v);
+                if (APPLY) { b.u[v] = lo < 3 ? p1[3 * rd + lo] : (lo == 3 ? 1.f : 0.f); b.y[v] = a[rd * G + (lo % G)]; }
+                else { b.u[v] = lo < G ? pre[rd * G + lo] : 0.f; b.y[v] = lo < G ? w2[rd * G + lo] : 0.f; }
+            }
+            return b;
+        },
+        [&](const PtS0& t, const S1& b) {
+            S2 r;
 #pragma unroll
-                    for (int d = 0; d < 3; d++) t3[v][d] = fmaf(w3[ct][d], dpe, t3[v][d]);
-                    accw[ct] = pt_mfma(nv[v], dpe, accw[ct]);                   // D[d][channel] += [p1, 1][slot][d] d pe[slot][channel]
-                } else {
-                    if (sd.valid) { s1[ct] += g1; s2[ct] = fmaf(g1, fmaf(w[ct][v], k1[ct], k2[ct]), s2[ct]); }
-                    accw[ct] = pt_mfma(nv[v], fmaxf(y, 0.f), accw[ct]);          // D[g][channel] += d w2[slot][g] w1[slot][channel]
+            for (int ct = 0; ct < CT; ct++) {
+                r.k[ct] = pt_vec4(xk[(size_t)b.j.x * C + 16 * ct + lo], xk[(size_t)b.j.y * C + 16 * ct + lo], xk[(size_t)b.j.z * C + 16 * ct + lo],
+                                  xk[(size_t)b.j.w * C + 16 * ct + lo]);
+                r.q[ct] = xq[(size_t)t.iD * C + 16 * ct + lo];
+                r.go[ct] = APPLY ? gout[(size_t)t.iD * C + 16 * ct + lo] : 0.f;
+            }
+            return r;
+        },
+        [&](const PtS0& t, const S1& b, const S2& r) {
+            // d w2 of (pair slot lo, g = hi / hi + 4): the A operand of d y = d w2 . Wa
+            float da0 = 0.f, da1 = 0.f;
+            if (APPLY) {
+                if (t.vA) { da0 = b.x0; da1 = b.x1; }
+            } else {
+                const size_t ra = (size_t)t.pA * G;
+                if (t.vA && hi < G) { da0 = fmaf(ga1[0], b.x0, fmaf(ga2[0], b.x2, ga3[0])); gw2[ra + hi] = da0; }
+                if (t.vA && G == 8) { da1 = fmaf(ga1[1], b.x1, fmaf(ga2[1], b.x3, ga3[1])); gw2[ra + hi + 4] = da1; }
+            }
+            // the narrow operands per (slot 4 hi + v): REDUCE d w2[.., g = lo] (A of d Wa), APPLY [p1, 1][.., d = lo] (A of d W3C) and a[.., lo % G]
+            float nv[4], av[4];
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                if (APPLY) { nv[v] = t.vD ? b.u[v] : 0.f; av[v] = t.vD ? b.y[v] : 0.f; }
+                else { nv[v] = (t.vD && lo < G) ? fmaf(ga1[2], b.u[v], fmaf(ga2[2], b.y[v], ga3[2])) : 0.f; av[v] = 0.f; }
+            }
+            float t3[4][3];
+#pragma unroll
+            for (int v = 0; v < 4; v++) { t3[v][0] = 0.f; t3[v][1] = 0.f; t3[v][2] = 0.f; }
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++) {
+                pt_f32x4 w = pt_vec4(r.k[ct][0] - r.q[ct], r.k[ct][1] - r.q[ct], r.k[ct][2] - r.q[ct], r.k[ct][3] - r.q[ct]);
+                w = pt_mfma(b.p1x, pe.w[ct], w);
+                pt_f32x4 gy = pt_mfma(da0, wa0[ct], pt_vec4(0.f, 0.f, 0.f, 0.f));
+                if (G == 8) gy = pt_mfma(da1, wa1[ct], gy);
+                float sq = 0.f;
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const float y = fmaf(w[v], sc[ct], sh[ct]);
+                    const float g1 = y > 0.f ? gy[v] : 0.f;
+                    if (APPLY) {
+                        const float dw = t.vD ? fmaf(k1[ct], g1, fmaf(k2[ct], w[v], k3[ct])) : 0.f;
+                        sq += dw;
+                        const float dpe = fmaf(r.go[ct], av[v], dw);
+#pragma unroll
+                        for (int d = 0; d < 3; d++) t3[v][d] = fmaf(w3[ct][d], dpe, t3[v][d]);
+                        accw[ct] = pt_mfma(nv[v], dpe, accw[ct]);               // D[d][channel] += [p1, 1][slot][d] d pe[slot][channel]
+                    } else {
+                        if (t.vD) { s1[ct] += g1; s2[ct] = fmaf(g1, fmaf(w[v], k1[ct], k2[ct]), s2[ct]); }
+                        accw[ct] = pt_mfma(nv[v], fmaxf(y, 0.f), accw[ct]);      // D[g][channel] += d w2[slot][g] w1[slot][channel]
+                    }
+                }
+                if (APPLY) {
+                    sq = pt_point_sum<K>(sq);
+                    if (t.vD && (K == 16 ? hi == 0 : (hi & 1) == 0)) gxq[(size_t)t.iD * C + 16 * ct + lo] = -sq;
                 }
             }
             if (APPLY) {
-                sq = pt_point_sum<K>(sq);
-                if (sd.valid && (K == 16 ? hi == 0 : (hi & 1) == 0)) gxq[(size_t)sd.i * C + 16 * ct + lo] = -sq;
-            }
-        }
-        if (APPLY) {
 #pragma unroll
-            for (int v = 0; v < 4; v++) {
-                const float r0 = pt_row_sum(t3[v][0]), r1 = pt_row_sum(t3[v][1]), r2 = pt_row_sum(t3[v][2]);
-                if (sd.valid && lo < 3) gp1[3 * (sd.p + v) + lo] = lo == 0 ? r0 : (lo == 1 ? r1 : r2);
+                for (int v = 0; v < 4; v++) {
+                    const float r0 = pt_row_sum(t3[v][0]), r1 = pt_row_sum(t3[v][1]), r2 = pt_row_sum(t3[v][2]);
+                    if (t.vD && lo < 3) gp1[3 * (size_t)(t.pD + v) + lo] = lo == 0 ? r0 : (lo == 1 ? r1 : r2);
+                }
             }
-        }
-    }
+        });
     // workgroup partial row
     if (APPLY) {
         // accw: D[d = 4 hi + v][channel 16 ct + lo], rows d < 4 live in hi = 0; stored as torch lays out Linear(3, C): weight [c][d], then the bias
