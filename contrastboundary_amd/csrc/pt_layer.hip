@@ -91,7 +91,9 @@ template <int K> __device__ __forceinline__ PtS0 pt_stage0(unsigned tile, unsign
 // Software pipeline of a tile pass.  A tile's loads form a chain of three dependent levels — order[rank] -> the pair's neighbour id and narrow
 // values -> the gathered rows — and a wave that walks its tiles one after the other pays the three latencies per tile (measured: 0.6 - 0.76 of
 // all wave cycles parked on memory, 3 us per tile).  Here every level of a LATER tile is requested before the current tile is computed:
-// level 0 three tiles ahead, level 1 two, level 2 one; the wave waits for nothing it has not requested a whole tile's compute earlier.
+// level 0 three tiles ahead, level 1 two, level 2 (the rows) one.  Two tiles per trip of the loop, so that the two row buffers alternate
+// without register copies (a copy of a just-requested value would wait for it); inside a phase the small levels are requested BEFORE the rows:
+// memory returns in request order, so rotating the small values at the end of the trip waits for them only, the rows stay in flight.
 template <class L0, class L1, class L2, class CP>
 __device__ __forceinline__ void pt_pipeline(unsigned ntiles, L0 load0, L1 load1, L2 load2, CP compute)
 {
@@ -101,12 +103,16 @@ __device__ __forceinline__ void pt_pipeline(unsigned ntiles, L0 load0, L1 load1,
     auto a0 = load0(tile_of(v)); auto a1 = load0(tile_of(v + step)); auto a2 = load0(tile_of(v + 2 * step));
     auto b0 = load1(a0); auto b1 = load1(a1);
     auto c0 = load2(a0, b0);
-    for (; v < vend; v += step) {
-        auto c1 = load2(a1, b1);
-        auto b2 = load1(a2);
+    for (; v < vend; v += 2 * step) {
         auto a3 = load0(tile_of(v + 3 * step));
+        auto b2 = load1(a2);
+        auto c1 = load2(a1, b1);
         if (a0.live) compute(a0, b0, c0);
-        a0 = a1; a1 = a2; a2 = a3; b0 = b1; b1 = b2; c0 = c1;
+        auto a4 = load0(tile_of(v + 4 * step));
+        auto b3 = load1(a3);
+        c0 = load2(a2, b2);
+        if (a1.live) compute(a1, b1, c1);
+        a0 = a2; a1 = a3; a2 = a4; b0 = b2; b1 = b3;
     }
 }
 

