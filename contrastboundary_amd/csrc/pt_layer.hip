@@ -116,6 +116,49 @@ __device__ __forceinline__ void pt_pipeline(unsigned ntiles, L0 load0, L1 load1,
     }
 }
 
+// ---- LDS staging of a tile's rows --------------------------------------------------------------------------------------------------------
+// The matrix instruction wants lane l to hold an element of pair slot l % 16: loading a gathered row in that layout makes every four adjacent
+// lanes touch four different rows — the texture path then spends a cycle per LANE instead of per 64 bytes (measured: the first version of these
+// passes sat at ~45 cycles per 16-byte gather instruction, 0.16 VALU utilisation, with every load already prefetched).  So the rows travel as
+// rows: 16 lanes fetch the 16 consecutive 16-byte pieces of one row (four rows per instruction, whole 128-byte lines), the pieces wait in
+// registers while the previous tile is computed, are written to a padded LDS tile of the wave, and each pass reads the tile back in the layout
+// its arithmetic wants (pair-major: one ds_read_b128 per 16 channels; channel-major: ds_read_b32).  Rows 16.. hold the rows of the tile's own
+// point(s): x_q[i] and / or d out[i].
+constexpr int PT_ROWF = 68;                         // floats per staged row: 64 + 4 (rows land 4 banks apart: conflict-free 16-byte reads down a column)
+constexpr int PT_TROWS = 20;                        // 16 neighbour rows, 2 x up to 2 point rows
+template <int NX> struct PtStaged { float4 k[4]; float4 x[NX > 0 ? NX : 1]; };
+
+// lane (lo, hi): piece lo of the rows of slots 4 hi .. 4 hi + 3 (ids j) and, in the first lane row of a point, of that point's rows in x0 / x1
+template <int C, int K, int NX>
+__device__ __forceinline__ PtStaged<NX> pt_stage_rows(const float* __restrict__ rows, const int4& j, const float* __restrict__ x0, const float* __restrict__ x1,
+                                                      int iD, int lo, int hi)
+{
+    PtStaged<NX> r;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool on = lo < C / 4;                                      // C = 32: a row is 8 pieces
+    const bool head = on && ((4 * hi) % K) == 0;
+    r.k[0] = on ? *reinterpret_cast<const float4*>(rows + (size_t)j.x * C + 4 * lo) : zero;
+    r.k[1] = on ? *reinterpret_cast<const float4*>(rows + (size_t)j.y * C + 4 * lo) : zero;
+    r.k[2] = on ? *reinterpret_cast<const float4*>(rows + (size_t)j.z * C + 4 * lo) : zero;
+    r.k[3] = on ? *reinterpret_cast<const float4*>(rows + (size_t)j.w * C + 4 * lo) : zero;
+    r.x[0] = zero;
+    if (NX >= 1 && head) r.x[0] = *reinterpret_cast<const float4*>(x0 + (size_t)iD * C + 4 * lo);
+    if (NX >= 2) { r.x[1] = zero; if (head) r.x[1] = *reinterpret_cast<const float4*>(x1 + (size_t)iD * C + 4 * lo); }
+    return r;
+}
+template <int K, int NX>
+__device__ __forceinline__ void pt_stage_store(float (*T)[PT_ROWF], const PtStaged<NX>& r, int lo, int hi)
+{
+    pt_wave_sync();                                                  // the previous tile's reads are done
+#pragma unroll
+    for (int it = 0; it < 4; it++) *reinterpret_cast<float4*>(&T[4 * hi + it][4 * lo]) = r.k[it];
+    if (((4 * hi) % K) == 0) {
+#pragma unroll
+        for (int x = 0; x < NX; x++) *reinterpret_cast<float4*>(&T[16 + 2 * x + (4 * hi) / K][4 * lo]) = r.x[x];
+    }
+    pt_wave_sync();
+}
+
 // ---- p chain: p_r, p0 and the sums of BN_p (lane = pair) ------------------------------------------------------------------------------
 // partial row: p0 [3] | p0^2 [3] | p_r [3] | p0[a] p_r[b] [9]   (the last two feed the Linear(3,3) gradient without another pass, pchain_bwd)
 __global__ __launch_bounds__(PT_NARROW_BLOCK) void pt_pchain_kernel(long long npairs, CblFastDiv dvK, const float* __restrict__ xyz, const int* __restrict__ idx,
@@ -267,17 +310,6 @@ template <int C> __device__ __forceinline__ PtPe<C> pt_pe_load(const float* __re
 
 // ---- BN_c statistics of w (pair-major); writes p1 ---------------------------------------------------------------------------------------
 // partial row: sum w [C] | sum w^2 [C]
-template <int CT> struct PtRowsPM { float4 k[CT], q[CT]; };          // pair-major rows: x_k[j] and x_q[i], channels 16 ct + 4 hi ..
-template <int C> __device__ __forceinline__ PtRowsPM<C / 16> pt_rows_pm(const float* __restrict__ xk, const float* __restrict__ xq, int j, int i, int hi)
-{
-    PtRowsPM<C / 16> r;
-    const float4* kr = reinterpret_cast<const float4*>(xk + (size_t)j * C + 4 * hi);
-    const float4* qr = reinterpret_cast<const float4*>(xq + (size_t)i * C + 4 * hi);
-#pragma unroll
-    for (int ct = 0; ct < C / 16; ct++) { r.k[ct] = kr[4 * ct]; r.q[ct] = qr[4 * ct]; }
-    return r;
-}
-
 template <int C, int K>
 __global__ __launch_bounds__(PT_BLOCK) void pt_wstats_kernel(int n, const int* __restrict__ order, const float* __restrict__ xq, const float* __restrict__ xk,
                                                              const int* __restrict__ idx, const float* __restrict__ p0, const float* __restrict__ cst,
@@ -285,8 +317,9 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_wstats_kernel(int n, const int* _
                                                              float* __restrict__ partial)
 {
     constexpr int CT = C / 16;
-    __shared__ float red[PT_WPB][2 * C];
+    __shared__ float tile[PT_WPB][PT_TROWS][PT_ROWF];
     const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4, wave = threadIdx.x >> 6;
+    float (*T)[PT_ROWF] = tile[wave];
     const PtPe<C> pe = pt_pe_load<C>(W3C, b3C, lo, hi);
     const float psc = hi < 3 ? cst[PT_CST_P + hi] : 0.f, psh = hi < 3 ? cst[PT_CST_P + 4 + hi] : 1.f;
     float s0[CT][4], s1[CT][4];
@@ -295,18 +328,20 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_wstats_kernel(int n, const int* _
 #pragma unroll
         for (int v = 0; v < 4; v++) { s0[ct][v] = 0.f; s1[ct][v] = 0.f; }
     const unsigned ntiles = (unsigned)(((long long)n * K + 15) / 16);
-    struct S1 { int j; float p0v; };
+    struct S1 { int4 j; float p0v; };
     pt_pipeline(ntiles,
-        [&](unsigned tile) { return pt_stage0<K>(tile, ntiles, n, order, lo, hi); },
-        [&](const PtS0& a) { S1 b; b.j = idx[a.pA]; b.p0v = hi < 3 ? p0[3 * (size_t)a.pA + hi] : 0.f; return b; },
-        [&](const PtS0& a, const S1& b) { return pt_rows_pm<C>(xk, xq, b.j, a.iA, hi); },
-        [&](const PtS0& a, const S1& b, const PtRowsPM<CT>& r) {
+        [&](unsigned tl) { return pt_stage0<K>(tl, ntiles, n, order, lo, hi); },
+        [&](const PtS0& a) { S1 b; b.j = *reinterpret_cast<const int4*>(idx + a.pD); b.p0v = hi < 3 ? p0[3 * (size_t)a.pA + hi] : 0.f; return b; },
+        [&](const PtS0& a, const S1& b) { return pt_stage_rows<C, K, 1>(xk, b.j, xq, nullptr, a.iD, lo, hi); },
+        [&](const PtS0& a, const S1& b, const PtStaged<1>& r) {
+            pt_stage_store<K, 1>(T, r, lo, hi);
             // p1 of (pair, d = hi): this lane's B operand; hi = 3 carries the 1 that multiplies the bias
             const float p1x = fmaxf(fmaf(b.p0v, psc, psh), 0.f);
             if (hi < 3 && a.vA) p1[3 * (size_t)a.pA + hi] = p1x;
 #pragma unroll
             for (int ct = 0; ct < CT; ct++) {
-                pt_f32x4 w = pt_vec4(r.k[ct].x - r.q[ct].x, r.k[ct].y - r.q[ct].y, r.k[ct].z - r.q[ct].z, r.k[ct].w - r.q[ct].w);
+                const float4 kv = *reinterpret_cast<const float4*>(&T[lo][16 * ct + 4 * hi]), qv = *reinterpret_cast<const float4*>(&T[16 + lo / K][16 * ct + 4 * hi]);
+                pt_f32x4 w = pt_vec4(kv.x - qv.x, kv.y - qv.y, kv.z - qv.z, kv.w - qv.w);
                 w = pt_mfma(pe.w[ct], p1x, w);
                 if (a.vA) {
 #pragma unroll
@@ -314,17 +349,19 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_wstats_kernel(int n, const int* _
                 }
             }
         });
+    __syncthreads();                                                 // the tiles are done with: their LDS carries the workgroup's partial row now
+    float* red = &tile[0][0][0];
 #pragma unroll
     for (int ct = 0; ct < CT; ct++)
 #pragma unroll
         for (int v = 0; v < 4; v++) {
             const float a = pt_row_sum(s0[ct][v]), b = pt_row_sum(s1[ct][v]);
-            if (lo == 0) { red[wave][16 * ct + 4 * hi + v] = a; red[wave][C + 16 * ct + 4 * hi + v] = b; }
+            if (lo == 0) { red[wave * 2 * C + 16 * ct + 4 * hi + v] = a; red[wave * 2 * C + C + 16 * ct + 4 * hi + v] = b; }
         }
     __syncthreads();
     if (threadIdx.x < 2 * C) {
         float s = 0.f;
-        for (int wv = 0; wv < PT_WPB; wv++) s += red[wv][threadIdx.x];
+        for (int wv = 0; wv < PT_WPB; wv++) s += red[wv * 2 * C + threadIdx.x];
         partial[(size_t)blockIdx.x * (2 * C) + threadIdx.x] = s;
     }
 }
@@ -338,35 +375,38 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_kernel(int n, const int* __res
                                                          const float* __restrict__ ba, float* __restrict__ w2, float* __restrict__ partial)
 {
     constexpr int CT = C / 16, G = C / 8;
+    __shared__ float tile[PT_WPB][PT_TROWS][PT_ROWF];
     __shared__ float red[PT_WPB][2 * G];
-    __shared__ float4 bnc[2][C / 4];                                 // scale / shift of BN_c: read per use (every lane of a row reads the same words)
     const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4, wave = threadIdx.x >> 6;
-    if (threadIdx.x < C / 2) bnc[threadIdx.x / (C / 4)][threadIdx.x % (C / 4)] = *reinterpret_cast<const float4*>(cst + PT_CST_C + 64 * (threadIdx.x / (C / 4)) + 4 * (threadIdx.x % (C / 4)));
+    float (*T)[PT_ROWF] = tile[wave];
     const PtPe<C> pe = pt_pe_load<C>(W3C, b3C, lo, hi);
-    float4 wb[CT];
+    float4 sc[CT], sh[CT], wb[CT];
 #pragma unroll
-    for (int ct = 0; ct < CT; ct++)
+    for (int ct = 0; ct < CT; ct++) {
+        sc[ct] = *reinterpret_cast<const float4*>(cst + PT_CST_C + 16 * ct + 4 * hi);
+        sh[ct] = *reinterpret_cast<const float4*>(cst + PT_CST_C + 64 + 16 * ct + 4 * hi);
         wb[ct] = lo < G ? *reinterpret_cast<const float4*>(Wa + (size_t)lo * C + 16 * ct + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);   // B[k = hi][col = g]
+    }
     const float bias = lo < G ? ba[lo] : 0.f;
     float t0 = 0.f, t1 = 0.f;
-    __syncthreads();
     const unsigned ntiles = (unsigned)(((long long)n * K + 15) / 16);
-    struct S1 { int j; float p1x; };
+    struct S1 { int4 j; float p1x; };
     pt_pipeline(ntiles,
-        [&](unsigned tile) { return pt_stage0<K>(tile, ntiles, n, order, lo, hi); },
-        [&](const PtS0& a) { S1 b; b.j = idx[a.pA]; b.p1x = hi < 3 ? p1[3 * (size_t)a.pA + hi] : 1.f; return b; },
-        [&](const PtS0& a, const S1& b) { return pt_rows_pm<C>(xk, xq, b.j, a.iA, hi); },
-        [&](const PtS0& a, const S1& b, const PtRowsPM<CT>& r) {
+        [&](unsigned tl) { return pt_stage0<K>(tl, ntiles, n, order, lo, hi); },
+        [&](const PtS0& a) { S1 b; b.j = *reinterpret_cast<const int4*>(idx + a.pD); b.p1x = hi < 3 ? p1[3 * (size_t)a.pA + hi] : 1.f; return b; },
+        [&](const PtS0& a, const S1& b) { return pt_stage_rows<C, K, 1>(xk, b.j, xq, nullptr, a.iD, lo, hi); },
+        [&](const PtS0& a, const S1& b, const PtStaged<1>& r) {
+            pt_stage_store<K, 1>(T, r, lo, hi);
             pt_f32x4 o0 = pt_vec4(bias, bias, bias, bias), o1 = pt_vec4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int ct = 0; ct < CT; ct++) {
-                pt_f32x4 w = pt_vec4(r.k[ct].x - r.q[ct].x, r.k[ct].y - r.q[ct].y, r.k[ct].z - r.q[ct].z, r.k[ct].w - r.q[ct].w);
+                const float4 kv = *reinterpret_cast<const float4*>(&T[lo][16 * ct + 4 * hi]), qv = *reinterpret_cast<const float4*>(&T[16 + lo / K][16 * ct + 4 * hi]);
+                pt_f32x4 w = pt_vec4(kv.x - qv.x, kv.y - qv.y, kv.z - qv.z, kv.w - qv.w);
                 w = pt_mfma(pe.w[ct], b.p1x, w);
-                const float4 sc = bnc[0][4 * ct + hi], sh = bnc[1][4 * ct + hi];
-                o0 = pt_mfma(fmaxf(fmaf(w[0], sc.x, sh.x), 0.f), wb[ct].x, o0);
-                o1 = pt_mfma(fmaxf(fmaf(w[1], sc.y, sh.y), 0.f), wb[ct].y, o1);
-                o0 = pt_mfma(fmaxf(fmaf(w[2], sc.z, sh.z), 0.f), wb[ct].z, o0);
-                o1 = pt_mfma(fmaxf(fmaf(w[3], sc.w, sh.w), 0.f), wb[ct].w, o1);
+                o0 = pt_mfma(fmaxf(fmaf(w[0], sc[ct].x, sh[ct].x), 0.f), wb[ct].x, o0);
+                o1 = pt_mfma(fmaxf(fmaf(w[1], sc[ct].y, sh[ct].y), 0.f), wb[ct].y, o1);
+                o0 = pt_mfma(fmaxf(fmaf(w[2], sc[ct].z, sh[ct].z), 0.f), wb[ct].z, o0);
+                o1 = pt_mfma(fmaxf(fmaf(w[3], sc[ct].w, sh[ct].w), 0.f), wb[ct].w, o1);
             }
             // D[pair slot 4 hi + v][g = lo]
             if (lo < G && a.vD) {
@@ -428,14 +468,15 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_agg_kernel(int n, const int* __re
                                                           const float* __restrict__ a, float* __restrict__ out, const float* __restrict__ gout,
                                                           float* __restrict__ glogit)
 {
-    constexpr int CT = C / 16, G = C / 8;
-    const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+    constexpr int CT = C / 16, G = C / 8, NX = BWD ? 1 : 0;
+    __shared__ float tile[PT_WPB][PT_TROWS][PT_ROWF];
+    const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4, wave = threadIdx.x >> 6;
+    float (*T)[PT_ROWF] = tile[wave];
     const PtPe<C> pe = pt_pe_load<C>(W3C, b3C, lo, hi);
     const unsigned ntiles = (unsigned)(((long long)n * K + 15) / 16);
     struct S1 { int4 j; float p1x; float av[4]; };
-    struct S2 { pt_f32x4 val[CT]; float go[CT]; };
     pt_pipeline(ntiles,
-        [&](unsigned tile) { return pt_stage0<K>(tile, ntiles, n, order, lo, hi); },
+        [&](unsigned tl) { return pt_stage0<K>(tl, ntiles, n, order, lo, hi); },
         [&](const PtS0& t) {
             S1 b;
             b.j = *reinterpret_cast<const int4*>(idx + t.pD);
@@ -444,20 +485,15 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_agg_kernel(int n, const int* __re
             for (int v = 0; v < 4; v++) b.av[v] = a[(size_t)(t.pD + v) * G + (lo % G)];
             return b;
         },
-        [&](const PtS0& t, const S1& b) {
-            S2 r;
-#pragma unroll
-            for (int ct = 0; ct < CT; ct++) {
-                r.val[ct] = pt_vec4(xv[(size_t)b.j.x * C + 16 * ct + lo], xv[(size_t)b.j.y * C + 16 * ct + lo], xv[(size_t)b.j.z * C + 16 * ct + lo],
-                                    xv[(size_t)b.j.w * C + 16 * ct + lo]);
-                r.go[ct] = BWD ? gout[(size_t)t.iD * C + 16 * ct + lo] : 0.f;
-            }
-            return r;
-        },
-        [&](const PtS0& t, const S1& b, const S2& r) {
+        [&](const PtS0& t, const S1& b) { return pt_stage_rows<C, K, NX>(xv, b.j, gout, nullptr, t.iD, lo, hi); },
+        [&](const PtS0& t, const S1& b, const PtStaged<NX>& r) {
+            pt_stage_store<K, NX>(T, r, lo, hi);
             pt_f32x4 val[CT];
 #pragma unroll
-            for (int ct = 0; ct < CT; ct++) val[ct] = pt_mfma(b.p1x, pe.w[ct], r.val[ct]);           // x_v[j] + pe of (slot 4 hi + v, channel 16 ct + lo)
+            for (int ct = 0; ct < CT; ct++) {
+                val[ct] = pt_vec4(T[4 * hi][16 * ct + lo], T[4 * hi + 1][16 * ct + lo], T[4 * hi + 2][16 * ct + lo], T[4 * hi + 3][16 * ct + lo]);
+                val[ct] = pt_mfma(b.p1x, pe.w[ct], val[ct]);                       // x_v[j] + pe of (slot 4 hi + v, channel 16 ct + lo)
+            }
             if (!BWD) {
 #pragma unroll
                 for (int ct = 0; ct < CT; ct++) {
@@ -468,9 +504,11 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_agg_kernel(int n, const int* __re
             } else {
                 float ga[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ct = 0; ct < CT; ct++)
+                for (int ct = 0; ct < CT; ct++) {
+                    const float go = T[16 + (4 * hi) / K][16 * ct + lo];
 #pragma unroll
-                    for (int v = 0; v < 4; v++) ga[v] = fmaf(r.go[ct], val[ct][v], ga[v]);
+                    for (int v = 0; v < 4; v++) ga[v] = fmaf(go, val[ct][v], ga[v]);
+                }
                 float dot = 0.f;
 #pragma unroll
                 for (int v = 0; v < 4; v++) {
@@ -556,8 +594,10 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
 {
     constexpr int CT = C / 16, G = C / 8;
     constexpr int W = APPLY ? 4 * C : 2 * C + G * C;
-    __shared__ float red[PT_WPB][W];
+    constexpr int TILEF = PT_TROWS * PT_ROWF;
+    __shared__ float lds[PT_WPB * (W > TILEF ? W : TILEF)];          // the waves' staged tiles, then the workgroup's partial row
     const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4, wave = threadIdx.x >> 6;
+    float (*T)[PT_ROWF] = reinterpret_cast<float (*)[PT_ROWF]>(lds + wave * TILEF);
     const PtPe<C> pe = pt_pe_load<C>(W3C, b3C, lo, hi);
     float sc[CT], sh[CT], k1[CT], k2[CT], k3[CT], wa0[CT], wa1[CT], w3[CT][3];
 #pragma unroll
@@ -592,9 +632,9 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
     // level 1: neighbour ids and the narrow values.  REDUCE: `pre` / w2 at (slot lo, g = hi | hi + 4) -> x0..x3 and at (slot 4 hi + v, g = lo) -> u / y;
     // APPLY: d w2 at (slot lo, g = hi | hi + 4) -> x0, x1; [p1, 1] at (slot 4 hi + v, d = lo) -> u; a at (slot 4 hi + v, lo % G) -> y
     struct S1 { int4 j; float p1x, x0, x1, x2, x3; float u[4], y[4]; };
-    struct S2 { pt_f32x4 k[CT]; float q[CT], go[CT]; };
+    constexpr int NX = APPLY ? 2 : 1;
     pt_pipeline(ntiles,
-        [&](unsigned tile) { return pt_stage0<K>(tile, ntiles, n, order, lo, hi); },
+        [&](unsigned tl) { return pt_stage0<K>(tl, ntiles, n, order, lo, hi); },
         [&](const PtS0& t) {
             S1 b;
             b.j = *reinterpret_cast<const int4*>(idx + t.pD);
@@ -616,18 +656,9 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
             }
             return b;
         },
-        [&](const PtS0& t, const S1& b) {
-            S2 r;
-#pragma unroll
-            for (int ct = 0; ct < CT; ct++) {
-                r.k[ct] = pt_vec4(xk[(size_t)b.j.x * C + 16 * ct + lo], xk[(size_t)b.j.y * C + 16 * ct + lo], xk[(size_t)b.j.z * C + 16 * ct + lo],
-                                  xk[(size_t)b.j.w * C + 16 * ct + lo]);
-                r.q[ct] = xq[(size_t)t.iD * C + 16 * ct + lo];
-                r.go[ct] = APPLY ? gout[(size_t)t.iD * C + 16 * ct + lo] : 0.f;
-            }
-            return r;
-        },
-        [&](const PtS0& t, const S1& b, const S2& r) {
+        [&](const PtS0& t, const S1& b) { return pt_stage_rows<C, K, NX>(xk, b.j, xq, gout, t.iD, lo, hi); },
+        [&](const PtS0& t, const S1& b, const PtStaged<NX>& r) {
+            pt_stage_store<K, NX>(T, r, lo, hi);
             // d w2 of (pair slot lo, g = hi / hi + 4): the A operand of d y = d w2 . Wa
             float da0 = 0.f, da1 = 0.f;
             if (APPLY) {
@@ -649,7 +680,8 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
             for (int v = 0; v < 4; v++) { t3[v][0] = 0.f; t3[v][1] = 0.f; t3[v][2] = 0.f; }
 #pragma unroll
             for (int ct = 0; ct < CT; ct++) {
-                pt_f32x4 w = pt_vec4(r.k[ct][0] - r.q[ct], r.k[ct][1] - r.q[ct], r.k[ct][2] - r.q[ct], r.k[ct][3] - r.q[ct]);
+                const float q = T[16 + (4 * hi) / K][16 * ct + lo], go = APPLY ? T[18 + (4 * hi) / K][16 * ct + lo] : 0.f;
+                pt_f32x4 w = pt_vec4(T[4 * hi][16 * ct + lo] - q, T[4 * hi + 1][16 * ct + lo] - q, T[4 * hi + 2][16 * ct + lo] - q, T[4 * hi + 3][16 * ct + lo] - q);
                 w = pt_mfma(b.p1x, pe.w[ct], w);
                 pt_f32x4 gy = pt_mfma(da0, wa0[ct], pt_vec4(0.f, 0.f, 0.f, 0.f));
                 if (G == 8) gy = pt_mfma(da1, wa1[ct], gy);
@@ -661,7 +693,7 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
                     if (APPLY) {
                         const float dw = t.vD ? fmaf(k1[ct], g1, fmaf(k2[ct], w[v], k3[ct])) : 0.f;
                         sq += dw;
-                        const float dpe = fmaf(r.go[ct], av[v], dw);
+                        const float dpe = fmaf(go, av[v], dw);
 #pragma unroll
                         for (int d = 0; d < 3; d++) t3[v][d] = fmaf(w3[ct][d], dpe, t3[v][d]);
                         accw[ct] = pt_mfma(nv[v], dpe, accw[ct]);               // D[d][channel] += [p1, 1][slot][d] d pe[slot][channel]
@@ -684,6 +716,8 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
             }
         });
     // workgroup partial row
+    __syncthreads();                                                 // every wave is done with its tile
+    float (*red)[W] = reinterpret_cast<float (*)[W]>(lds);
     if (APPLY) {
         // accw: D[d = 4 hi + v][channel 16 ct + lo], rows d < 4 live in hi = 0; stored as torch lays out Linear(3, C): weight [c][d], then the bias
         if (hi == 0) {

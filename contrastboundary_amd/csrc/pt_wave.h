@@ -25,3 +25,6 @@ __device__ __forceinline__ float pt_row_ror8(float v) { return pt_dpp<0x128>(v);
 // value of the lane 16 / 32 away (another row of the wave)
 __device__ __forceinline__ float pt_xor16(float v) { return __shfl_xor(v, 16, 64); }
 __device__ __forceinline__ float pt_xor32(float v) { return __shfl_xor(v, 32, 64); }
+// all lanes of the wave have executed what precedes (LDS traffic of one wave is processed in program order; this only stops the compiler from
+// moving LDS accesses across it — and gives the host stand-in of this header its rendezvous point)
+__device__ __forceinline__ void pt_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }

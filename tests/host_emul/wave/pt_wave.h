@@ -35,3 +35,4 @@ static inline float pt_row_ror4(float v) { return pt_lane_move(v, [](int l) { re
 static inline float pt_row_ror8(float v) { return pt_lane_move(v, [](int l) { return (l & ~15) | ((l - 8) & 15); }); }
 static inline float pt_xor16(float v) { return pt_lane_move(v, [](int l) { return l ^ 16; }); }
 static inline float pt_xor32(float v) { return pt_lane_move(v, [](int l) { return l ^ 32; }); }
+static inline void pt_wave_sync() { float z = 0.f, r; emul::wave_collective(&z, 1, &r, 1, [](emul::Wave&) {}); }
