@@ -126,35 +126,36 @@ __device__ __forceinline__ void pt_pipeline(unsigned ntiles, L0 load0, L1 load1,
 // point(s): x_q[i] and / or d out[i].
 constexpr int PT_ROWF = 68;                         // floats per staged row: 64 + 4 (rows land 4 banks apart: conflict-free 16-byte reads down a column)
 constexpr int PT_TROWS = 20;                        // 16 neighbour rows, 2 x up to 2 point rows
-template <int NX> struct PtStaged { float4 k[4]; float4 x[NX > 0 ? NX : 1]; };
+template <int NX> struct PtStaged { float4 k0, k1, k2, k3, x0, x1; };     // named members: an array here ends up in scratch memory (measured)
 
 // lane (lo, hi): piece lo of the rows of slots 4 hi .. 4 hi + 3 (ids j) and, in the first lane row of a point, of that point's rows in x0 / x1
 template <int C, int K, int NX>
-__device__ __forceinline__ PtStaged<NX> pt_stage_rows(const float* __restrict__ rows, const int4& j, const float* __restrict__ x0, const float* __restrict__ x1,
+__device__ __forceinline__ PtStaged<NX> pt_stage_rows(const float* __restrict__ rows, const int4& j, const float* __restrict__ xa, const float* __restrict__ xb,
                                                       int iD, int lo, int hi)
 {
     PtStaged<NX> r;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool on = lo < C / 4;                                      // C = 32: a row is 8 pieces
-    const bool head = on && ((4 * hi) % K) == 0;
-    r.k[0] = on ? *reinterpret_cast<const float4*>(rows + (size_t)j.x * C + 4 * lo) : zero;
-    r.k[1] = on ? *reinterpret_cast<const float4*>(rows + (size_t)j.y * C + 4 * lo) : zero;
-    r.k[2] = on ? *reinterpret_cast<const float4*>(rows + (size_t)j.z * C + 4 * lo) : zero;
-    r.k[3] = on ? *reinterpret_cast<const float4*>(rows + (size_t)j.w * C + 4 * lo) : zero;
-    r.x[0] = zero;
-    if (NX >= 1 && head) r.x[0] = *reinterpret_cast<const float4*>(x0 + (size_t)iD * C + 4 * lo);
-    if (NX >= 2) { r.x[1] = zero; if (head) r.x[1] = *reinterpret_cast<const float4*>(x1 + (size_t)iD * C + 4 * lo); }
+    const int piece = lo < C / 4 ? lo : 0;                           // C = 32: a row is 8 pieces; the upper lanes fetch piece 0 again (never read back)
+    r.k0 = *reinterpret_cast<const float4*>(rows + (size_t)j.x * C + 4 * piece);
+    r.k1 = *reinterpret_cast<const float4*>(rows + (size_t)j.y * C + 4 * piece);
+    r.k2 = *reinterpret_cast<const float4*>(rows + (size_t)j.z * C + 4 * piece);
+    r.k3 = *reinterpret_cast<const float4*>(rows + (size_t)j.w * C + 4 * piece);
+    r.x0 = zero; r.x1 = zero;
+    if (NX >= 1 && ((4 * hi) % K) == 0) r.x0 = *reinterpret_cast<const float4*>(xa + (size_t)iD * C + 4 * piece);
+    if (NX >= 2 && ((4 * hi) % K) == 0) r.x1 = *reinterpret_cast<const float4*>(xb + (size_t)iD * C + 4 * piece);
     return r;
 }
 template <int K, int NX>
 __device__ __forceinline__ void pt_stage_store(float (*T)[PT_ROWF], const PtStaged<NX>& r, int lo, int hi)
 {
     pt_wave_sync();                                                  // the previous tile's reads are done
-#pragma unroll
-    for (int it = 0; it < 4; it++) *reinterpret_cast<float4*>(&T[4 * hi + it][4 * lo]) = r.k[it];
+    *reinterpret_cast<float4*>(&T[4 * hi][4 * lo]) = r.k0;
+    *reinterpret_cast<float4*>(&T[4 * hi + 1][4 * lo]) = r.k1;
+    *reinterpret_cast<float4*>(&T[4 * hi + 2][4 * lo]) = r.k2;
+    *reinterpret_cast<float4*>(&T[4 * hi + 3][4 * lo]) = r.k3;
     if (((4 * hi) % K) == 0) {
-#pragma unroll
-        for (int x = 0; x < NX; x++) *reinterpret_cast<float4*>(&T[16 + 2 * x + (4 * hi) / K][4 * lo]) = r.x[x];
+        if (NX >= 1) *reinterpret_cast<float4*>(&T[16 + (4 * hi) / K][4 * lo]) = r.x0;
+        if (NX >= 2) *reinterpret_cast<float4*>(&T[18 + (4 * hi) / K][4 * lo]) = r.x1;
     }
     pt_wave_sync();
 }

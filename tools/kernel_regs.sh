@@ -9,7 +9,7 @@ for l in sys.stdin:
     if m:
         name=subprocess.run(['c++filt',m.group(1)],capture_output=True,text=True).stdout.strip().replace('(anonymous namespace)::','').replace('void ','').split('(')[0]
         row={}
-    for key,tag in (('    VGPRs: ','vgpr'),('VGPRs Spill: ','spill'),('LDS Size [bytes/block]: ','lds'),('Occupancy [waves/SIMD]: ','occ'),('AGPRs: ','agpr')):
+    for key,tag in (('    VGPRs: ','vgpr'),('VGPRs Spill: ','spill'),('LDS Size [bytes/block]: ','lds'),('Occupancy [waves/SIMD]: ','occ'),('AGPRs: ','agpr'),('ScratchSize [bytes/lane]: ','scratch')):
         if key in l: row[tag]=int(l.split(key)[1].split()[0])
-    if 'LDS Size' in l: print('%-52s vgpr %3d agpr %3d spill %3d occ %d lds %6d' % (name[:52],row.get('vgpr',0),row.get('agpr',0),row.get('spill',0),row.get('occ',0),row.get('lds',0)))
+    if 'LDS Size' in l: print('%-52s vgpr %3d agpr %3d spill %3d occ %d lds %6d scratch %d' % (name[:52],row.get('vgpr',0),row.get('agpr',0),row.get('spill',0),row.get('occ',0),row.get('lds',0),row.get('scratch',0)))
 "
