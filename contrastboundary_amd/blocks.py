@@ -40,7 +40,7 @@ class PointTransformerLayer(nn.Module):
 
     def forward(self, pxo, idx=None) -> torch.Tensor:
         p, x, o = pxo                                                        # (n,3), (n,c), (b)
-        x_q, x_k, x_v = dense.apply(self.linear_q, x), dense.apply(self.linear_k, x), dense.apply(self.linear_v, x)  # :33
+        x_q, x_k, x_v = dense.triple_linear(x, self.linear_q, self.linear_k, self.linear_v)                        # :33, one launch per direction
         if idx is None:
             idx, _ = pointops.knnquery(self.nsample, p, p, o, o)              # once, not twice (:34-35)
         if self.fused and self.fused != "split" and pt_layer.supported(self, x):

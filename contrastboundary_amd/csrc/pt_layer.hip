@@ -26,7 +26,7 @@
 
 namespace {
 
-constexpr int PT_BLOCK = 512;                       // 8 waves; two workgroups per CU at <= 128 registers
+constexpr int PT_BLOCK = 512;                       // 8 waves (256-thread workgroups measured no faster: the passes are bound by their waves' serial instruction streams)
 constexpr int PT_WPB = PT_BLOCK / 64;
 constexpr int PT_MAX_ROWS = 512;                    // partial rows of a pass = its workgroups
 constexpr int PT_NARROW_BLOCK = 256;

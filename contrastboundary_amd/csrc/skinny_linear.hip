@@ -233,6 +233,175 @@ __global__ __launch_bounds__(256) void row_linear_wgrad_mfma_kernel(long long ro
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// The three projections of PointTransformerLayer (blocks.py:33: x_q, x_k, x_v = linear_q(x), linear_k(x), linear_v(x); C = 32 / 64) as ONE launch
+// per direction: forward with blockIdx.y = the projection; input gradient d x = d x_q Wq + d x_k Wk + d x_v Wv accumulated in the MFMA accumulators
+// of one pass over the three gradient tensors (weights in LDS: 3 C^2 operands do not fit the registers), weight / bias gradients with
+// blockIdx.y = the projection.  (Three Linear layers cost 3 + 3 + 6 launches and two adds: ~130 us of a 500 us layer step at (40960, 64).)
+struct RlTriple { const float* in[3]; const float* w[3]; const float* b[3]; float* out[3]; };
+
+template <int C>
+__global__ __launch_bounds__(256) void triple_linear_forward_kernel(long long rows, const float* __restrict__ in, RlTriple t3)
+{
+    constexpr int KC = C / 4, NT = C / 16;
+    const float* __restrict__ W = t3.w[blockIdx.y]; const float* __restrict__ bias = t3.b[blockIdx.y]; float* __restrict__ out = t3.out[blockIdx.y];
+    const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
+    float bw[NT][KC];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int s2 = 0; s2 < KC; s2++) bw[t][s2] = W[(size_t)(16 * t + row) * C + KC * kq + s2];
+    float bv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) bv[t] = bias ? bias[16 * t + row] : 0.f;
+    const long long ntiles = (rows + 15) / 16;
+    const long long stride = (long long)gridDim.x * 4;
+    long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    float4 a[KC / 4];
+    auto load = [&](long long tl) {
+        const long long r = min(tl * 16 + row, rows - 1);
+        const float4* src = reinterpret_cast<const float4*>(in + r * C + KC * kq);
+#pragma unroll
+        for (int v = 0; v < KC / 4; v++) a[v] = src[v];
+    };
+    if (tile < ntiles) load(tile);
+    for (; tile < ntiles; tile += stride) {
+        float av[KC];
+#pragma unroll
+        for (int v = 0; v < KC / 4; v++) { av[4 * v] = a[v].x; av[4 * v + 1] = a[v].y; av[4 * v + 2] = a[v].z; av[4 * v + 3] = a[v].w; }
+        if (tile + stride < ntiles) load(tile + stride);
+        rl_f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = rl_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < KC; s2++)
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bw[t][s2], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const long long orow = tile * 16 + 4 * kq + r;
+            if (orow < rows) {
+#pragma unroll
+                for (int t = 0; t < NT; t++) out[orow * C + 16 * t + row] = acc[t][r] + bv[t];
+            }
+        }
+    }
+}
+
+// d x (rows, C) = sum over the three projections of d y_p (rows, C) . W_p (C, C): one accumulator set per 16-row tile, B operands from LDS
+// (W_p[k][n] at row stride C + 1: the four k-quarters of a wave land on different banks)
+template <int C>
+__global__ __launch_bounds__(256) void triple_linear_dgrad_kernel(long long rows, RlTriple t3, float* __restrict__ gx)
+{
+    constexpr int KC = C / 4, NT = C / 16, LD = C + 1;
+    __shared__ float wl[3 * C * LD];
+    for (int e = threadIdx.x; e < 3 * C * C; e += 256) { const int p = e / (C * C), k = (e / C) % C, n = e % C; wl[(p * C + k) * LD + n] = t3.w[p][(size_t)k * C + n]; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
+    const long long ntiles = (rows + 15) / 16;
+    for (long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); tile < ntiles; tile += (long long)gridDim.x * 4) {
+        const long long r = min(tile * 16 + row, rows - 1);
+        float4 a[3][KC / 4];
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            const float4* src = reinterpret_cast<const float4*>(t3.in[p] + r * C + KC * kq);
+#pragma unroll
+            for (int v = 0; v < KC / 4; v++) a[p][v] = src[v];
+        }
+        rl_f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = rl_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int v = 0; v < KC / 4; v++) {
+                const float av[4] = {a[p][v].x, a[p][v].y, a[p][v].z, a[p][v].w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float* wrow = wl + (p * C + KC * kq + 4 * v + e) * LD + row;
+#pragma unroll
+                    for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], wrow[16 * t], acc[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const long long orow = tile * 16 + 4 * kq + rr;
+            if (orow < rows) {
+#pragma unroll
+                for (int t = 0; t < NT; t++) gx[orow * C + 16 * t + row] = acc[t][rr];
+            }
+        }
+    }
+}
+
+// weight / bias gradients of the three projections: row_linear_wgrad_mfma_kernel's pass with blockIdx.y = the projection (partials side by side)
+template <int C>
+__global__ __launch_bounds__(256) void triple_linear_wgrad_kernel(long long rows, const float* __restrict__ x, RlTriple t3, float* __restrict__ partial)
+{
+    constexpr int MT = C / 16, NTI = C / 16, WIDTH = C * C + C;
+    __shared__ float red[4][WIDTH];
+    const float* __restrict__ gy = t3.in[blockIdx.y];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, kq = lane >> 4;
+    rl_f32x4 acc[MT][NTI];
+#pragma unroll
+    for (int tm = 0; tm < MT; tm++)
+#pragma unroll
+        for (int tn = 0; tn < NTI; tn++) acc[tm][tn] = rl_f32x4{0.f, 0.f, 0.f, 0.f};
+    float sb[MT];
+#pragma unroll
+    for (int tm = 0; tm < MT; tm++) sb[tm] = 0.f;
+    const long long nsteps = (rows + 3) / 4;
+    const long long gw = (long long)gridDim.x * 4;
+    for (long long st = (long long)blockIdx.x * 4 + wave; st < nsteps; st += gw) {
+        const long long r = st * 4 + kq;
+        const bool ok = r < rows;
+        const long long rc = ok ? r : rows - 1;
+        float a[MT], b[NTI];
+#pragma unroll
+        for (int tm = 0; tm < MT; tm++) { a[tm] = gy[rc * C + 16 * tm + col]; a[tm] = ok ? a[tm] : 0.f; sb[tm] += a[tm]; }
+#pragma unroll
+        for (int tn = 0; tn < NTI; tn++) b[tn] = x[rc * C + 16 * tn + col];
+#pragma unroll
+        for (int tm = 0; tm < MT; tm++)
+#pragma unroll
+            for (int tn = 0; tn < NTI; tn++) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+    }
+#pragma unroll
+    for (int tm = 0; tm < MT; tm++)
+#pragma unroll
+        for (int tn = 0; tn < NTI; tn++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) red[wave][(16 * tm + 4 * kq + r) * C + 16 * tn + col] = acc[tm][tn][r];
+#pragma unroll
+    for (int tm = 0; tm < MT; tm++) {
+        float v = sb[tm];
+        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        if (kq == 0) red[wave][C * C + 16 * tm + col] = v;
+    }
+    __syncthreads();
+    float* mine = partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * WIDTH;
+    for (int e = threadIdx.x; e < WIDTH; e += 256) mine[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+}
+
+__global__ __launch_bounds__(1024) void triple_linear_wgrad_finalize_kernel(int C, int nblocks, const float* __restrict__ partial, RlTriple t3)
+{
+    __shared__ double red[64][16];
+    const int width = C * C + C, e = blockIdx.x * 16 + (threadIdx.x & 15), js = threadIdx.x >> 4;
+    const float* src = partial + (size_t)blockIdx.y * nblocks * width;
+    double a = 0.0;
+    if (e < width) for (int b = js; b < nblocks; b += 64) a += (double)src[(size_t)b * width + e];
+    red[js][threadIdx.x & 15] = a;
+    __syncthreads();
+    if (js == 0 && e < width) {
+        double s0 = 0.0;
+        for (int j = 0; j < 64; j++) s0 += red[j][threadIdx.x & 15];
+        if (e < C * C) t3.out[blockIdx.y][e] = (float)s0;
+        else if (t3.b[blockIdx.y]) const_cast<float*>(t3.b[blockIdx.y])[e - C * C] = (float)s0;
+    }
+}
+
+constexpr int TL_WGRAD_BLOCKS = 256;
+
 inline bool rl_mfma_ok(int cin, int cout) { return cin % 16 == 0 && cout % 16 == 0 && cin <= 64 && cout <= 64 && cin >= 16 && cout >= 16; }
 
 template <bool WT>
@@ -333,5 +502,48 @@ CBL_EXPORT int cbl_skinny_linear_backward_weight(long long rows, int cin, int co
                        rows, cin, cout, x, grad_y, partial, grad_bias ? 1 : 0);
     hipLaunchKernelGGL(skinny_linear_wgrad_finalize_kernel, dim3(cbl_div_up(cin * cout + cout, 16)), dim3(256), 0, st, cin * cout, cout, nblocks, partial,
                        grad_weight, grad_bias);
+    return cbl_status();
+}
+
+// ---- the three projections of PointTransformerLayer as one launch per direction (blocks.py:33; C = 32 | 64) ----
+CBL_EXPORT size_t cbl_triple_linear_workspace_bytes(int C)
+{
+    if (C != 32 && C != 64) return 0;
+    return sizeof(float) * 3 * (size_t)TL_WGRAD_BLOCKS * ((size_t)C * C + C) + 256;
+}
+
+CBL_EXPORT int cbl_triple_linear_forward(long long rows, int C, const float* x, const float* const* weight3, const float* const* bias3, float* const* y3, void* stream)
+{
+    if (C != 32 && C != 64) return CBL_ERR_UNSUPPORTED;
+    if (rows <= 0 || !x || !weight3 || !y3 || !cbl_host_aligned16(x)) return CBL_ERR_BAD_ARG;
+    RlTriple t3;
+    for (int p = 0; p < 3; p++) { t3.in[p] = x; t3.w[p] = weight3[p]; t3.b[p] = bias3 ? bias3[p] : nullptr; t3.out[p] = y3[p]; }
+    const long long tiles = (rows + 15) / 16;
+    const dim3 grid((unsigned)min((tiles + 3) / 4, (long long)1024), 3), blk(256);
+    if (C == 64) hipLaunchKernelGGL(triple_linear_forward_kernel<64>, grid, blk, 0, cbl_stream(stream), rows, x, t3);
+    else         hipLaunchKernelGGL(triple_linear_forward_kernel<32>, grid, blk, 0, cbl_stream(stream), rows, x, t3);
+    return cbl_status();
+}
+
+/* grad_x = sum_p grad_y3[p] . weight3[p];  grad_weight3[p] = grad_y3[p]^T . x, grad_bias3[p] = column sums of grad_y3[p] (entries of grad_bias3 may be NULL) */
+CBL_EXPORT int cbl_triple_linear_backward(long long rows, int C, const float* x, const float* const* weight3, const float* const* grad_y3, float* grad_x,
+                                          float* const* grad_weight3, float* const* grad_bias3, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (C != 32 && C != 64) return CBL_ERR_UNSUPPORTED;
+    if (rows <= 0 || !x || !weight3 || !grad_y3 || !grad_x || !grad_weight3 || !workspace) return CBL_ERR_BAD_ARG;
+    if (workspace_bytes < cbl_triple_linear_workspace_bytes(C)) return CBL_ERR_WORKSPACE;
+    for (int p = 0; p < 3; p++) if (!cbl_host_aligned16(grad_y3[p])) return CBL_ERR_BAD_ARG;
+    hipStream_t st = cbl_stream(stream);
+    RlTriple t3;
+    for (int p = 0; p < 3; p++) { t3.in[p] = grad_y3[p]; t3.w[p] = weight3[p]; t3.b[p] = grad_bias3 ? grad_bias3[p] : nullptr; t3.out[p] = grad_weight3[p]; }
+    const long long tiles = (rows + 15) / 16;
+    const dim3 grid((unsigned)min((tiles + 3) / 4, (long long)2048)), blk(256);
+    if (C == 64) hipLaunchKernelGGL(triple_linear_dgrad_kernel<64>, grid, blk, 0, st, rows, t3, grad_x);
+    else         hipLaunchKernelGGL(triple_linear_dgrad_kernel<32>, grid, blk, 0, st, rows, t3, grad_x);
+    float* partial = reinterpret_cast<float*>(workspace);
+    const int nb = (int)min((rows + 63) / 64, (long long)TL_WGRAD_BLOCKS);
+    if (C == 64) hipLaunchKernelGGL(triple_linear_wgrad_kernel<64>, dim3(nb, 3), blk, 0, st, rows, x, t3, partial);
+    else         hipLaunchKernelGGL(triple_linear_wgrad_kernel<32>, dim3(nb, 3), blk, 0, st, rows, x, t3, partial);
+    hipLaunchKernelGGL(triple_linear_wgrad_finalize_kernel, dim3(cbl_div_up(C * C + C, 16), 3), dim3(1024), 0, st, C, nb, partial, t3);
     return cbl_status();
 }

@@ -62,6 +62,47 @@ def linear(x, weight, bias=None):
     return y.view(*x.shape[:-1], cout)
 
 
+class _TripleLinear(Function):
+    """x_q, x_k, x_v = linear_q(x), linear_k(x), linear_v(x)  (blocks.py:33) as one launch per direction (cbl_triple_linear_*, C = 32 | 64)"""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv):
+        rows, C = x.shape
+        L = _lib.lib()
+        ys = [torch.empty((rows, C), dtype=torch.float32, device=x.device) for _ in range(3)]
+        arr = lambda ts: (ctypes.c_void_p * 3)(*[0 if t is None else t.data_ptr() for t in ts])
+        _lib.check(L.cbl_triple_linear_forward(ctypes.c_longlong(rows), ctypes.c_int(C), _lib.ptr(x), arr([wq, wk, wv]), arr([bq, bk, bv]), arr(ys), _lib.stream_of(x)),
+                   "cbl_triple_linear_forward")
+        ctx.save_for_backward(x, wq, wk, wv)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, gq, gk, gv):
+        x, wq, wk, wv = ctx.saved_tensors
+        rows, C = x.shape
+        L = _lib.lib()
+        gys = [g.contiguous() for g in (gq, gk, gv)]
+        gx = torch.empty_like(x)
+        gws = [torch.empty_like(w) for w in (wq, wk, wv)]
+        gbs = [torch.empty(C, dtype=torch.float32, device=x.device) for _ in range(3)]
+        arr = lambda ts: (ctypes.c_void_p * 3)(*[t.data_ptr() for t in ts])
+        ws = _bn_workspace(L.cbl_triple_linear_workspace_bytes(ctypes.c_int(C)), x.device)
+        _lib.check(L.cbl_triple_linear_backward(ctypes.c_longlong(rows), ctypes.c_int(C), _lib.ptr(x), arr([wq, wk, wv]), arr(gys), _lib.ptr(gx), arr(gws), arr(gbs),
+                                                _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(x)), "cbl_triple_linear_backward")
+        return gx, gws[0], gbs[0], gws[1], gbs[1], gws[2], gbs[2]
+
+
+def triple_linear(x, lq, lk, lv):
+    """(lq(x), lk(x), lv(x)) for three nn.Linear(C, C) with biases: one launch per direction at C = 32 | 64 on >= MIN_ROWS rows, `linear` x 3 otherwise"""
+    C = x.shape[-1]
+    ok = (x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and C in (32, 64) and x.shape[0] >= MIN_ROWS
+          and all(l.weight.shape == (C, C) and l.bias is not None and l.weight.dtype == torch.float32 for l in (lq, lk, lv)))
+    if not ok:
+        return apply(lq, x), apply(lk, x), apply(lv, x)
+    return _TripleLinear.apply(x.contiguous(), lq.weight.contiguous(), lq.bias.contiguous(), lk.weight.contiguous(), lk.bias.contiguous(),
+                               lv.weight.contiguous(), lv.bias.contiguous())
+
+
 MIN_ROWS_BN = 64            # below this torch's own kernels; up to 4096 rows csrc/bn_rows.hip runs ONE kernel per direction, above it two streaming passes
 
 

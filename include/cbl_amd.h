@@ -533,6 +533,16 @@ int cbl_skinny_linear_backward_input(long long rows, int cin, int cout, const fl
 int cbl_skinny_linear_backward_weight(long long rows, int cin, int cout, const float* x, const float* grad_y, float* grad_weight, float* grad_bias,
                                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* a4: the three per-point projections of the layer, x_q, x_k, x_v = linear_q(x), linear_k(x), linear_v(x)  pytorch/model/blocks.py:33 (nn.Linear(C, C) x 3,
+ *     C = 32 | 64), one launch per direction.  weight3 / bias3 / y3 / grad_*3: HOST arrays of 3 device pointers (q, k, v).
+ *   forward   y3[p] (rows, C) = x . weight3[p]^T + bias3[p]
+ *   backward  grad_x = sum_p grad_y3[p] . weight3[p] (one pass, accumulated in the MFMA accumulators: no partial tensors, no adds);
+ *             grad_weight3[p] (C, C) = grad_y3[p]^T . x; grad_bias3[p] (C) = column sums (array or entries may be NULL).  Written, not accumulated. */
+size_t cbl_triple_linear_workspace_bytes(int C);
+int cbl_triple_linear_forward(long long rows, int C, const float* x, const float* const* weight3, const float* const* bias3, float* const* y3, void* stream);
+int cbl_triple_linear_backward(long long rows, int C, const float* x, const float* const* weight3, const float* const* grad_y3, float* grad_x,
+                               float* const* grad_weight3, float* const* grad_bias3, void* workspace, size_t workspace_bytes, void* stream);
+
 /* a4 / a5, dense part: train-mode nn.BatchNorm1d (+ ReLU) over (rows, C) activations, rows = n or n*K  pytorch/model/blocks.py:25-28,38-40,70,74,126-134
  *   y = [relu]((x - mean_batch) / sqrt(var_batch + eps) * weight + bias); running_mean / running_var updated in place like torch
  *   (momentum, unbiased variance; either may be NULL; *num_batches_tracked += 1 if not NULL); save_mean / save_invstd (C) are kept for the

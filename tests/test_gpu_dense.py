@@ -86,3 +86,29 @@ def test_batch_norm_eval_mode_and_small_inputs_use_torch():
     xs = torch.randn(40, 16, device="cuda")
     bn2 = torch.nn.BatchNorm1d(16).cuda().train()
     assert torch.allclose(dense.batch_norm(xs, bn, relu=False), bn2(xs), atol=1e-6)
+
+
+@pytest.mark.parametrize("rows,C", [(40960, 64), (10000, 32), (8193, 64)])
+def test_triple_linear_equals_three_linear_layers(rows, C):
+    """cbl_triple_linear_* (blocks.py:33: the q / k / v projections, one launch per direction) against torch's F.linear in float64"""
+    import torch.nn as nn
+    from contrastboundary_amd import dense
+    torch.manual_seed(rows)
+    ls = [nn.Linear(C, C).cuda() for _ in range(3)]
+    x = torch.randn(rows, C, device="cuda", requires_grad=True)
+    gs = [torch.randn(rows, C, device="cuda") for _ in range(3)]
+    ys = dense.triple_linear(x, *ls)
+    torch.autograd.backward(ys, gs)
+    got = [y.detach() for y in ys], x.grad.clone(), [l.weight.grad.clone() for l in ls], [l.bias.grad.clone() for l in ls]
+    x64 = x.detach().double().requires_grad_(True)
+    ws = [l.weight.detach().double().requires_grad_(True) for l in ls]; bs = [l.bias.detach().double().requires_grad_(True) for l in ls]
+    ys64 = [torch.nn.functional.linear(x64, w, b) for w, b in zip(ws, bs)]
+    torch.autograd.backward(ys64, [g.double() for g in gs])
+    rel = lambda a, b: float((a.double() - b).norm() / b.norm())
+    for y, y64 in zip(got[0], ys64):
+        assert rel(y, y64.detach()) < 1e-6
+    assert rel(got[1], x64.grad) < 1e-6
+    for gw, w in zip(got[2], ws):
+        assert rel(gw, w.grad) < 1e-5
+    for gb, b in zip(got[3], bs):
+        assert rel(gb, b.grad) < 1e-5

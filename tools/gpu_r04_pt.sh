@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/r04pt
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_pt_layer.py tests/test_gpu_blocks.py tests/test_gpu_bench_step_pt.py -q -x -s --timeout=600 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+timeout 900 python -m pytest tests/test_gpu_pt_layer.py tests/test_gpu_dense.py tests/test_gpu_blocks.py tests/test_gpu_bench_step_pt.py -q -x -s --timeout=600 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
 grep -v "^$" $O/pytest.log | tail -30
 timeout 300 python tools/pt_layer_time.py 40960 16 64 > $O/time_40960_16_64.json 2> $O/time_a.err; cat $O/time_40960_16_64.json; tail -3 $O/time_a.err
 timeout 300 python tools/pt_layer_time.py 40960 8 32 > $O/time_40960_8_32.json 2> $O/time_b.err; cat $O/time_40960_8_32.json; tail -3 $O/time_b.err
