@@ -288,41 +288,51 @@ __global__ __launch_bounds__(256) void triple_linear_forward_kernel(long long ro
     }
 }
 
-// d x (rows, C) = sum over the three projections of d y_p (rows, C) . W_p (C, C): one accumulator set per 16-row tile, B operands from LDS
-// (W_p[k][n] at row stride C + 1: the four k-quarters of a wave land on different banks)
+// d x (rows, C) = sum over the three projections of d y_p (rows, C) . W_p (C, C): one accumulator set per 16-row tile.  One wave per SIMD
+// (a workgroup per CU, the whole register file): the 3 C^2 / 64 B operands of a lane stay in registers for the launch, the next tile's
+// rows are requested before this tile's 3 C / 4 x C / 16 MFMAs.  (A first version with the weights in LDS and a tile per wave spent its time in
+// its prologue: 49 us for 0.5 M MFMAs.)
 template <int C>
-__global__ __launch_bounds__(256) void triple_linear_dgrad_kernel(long long rows, RlTriple t3, float* __restrict__ gx)
+__global__ __launch_bounds__(256, 1) void triple_linear_dgrad_kernel(long long rows, RlTriple t3, float* __restrict__ gx)
 {
-    constexpr int KC = C / 4, NT = C / 16, LD = C + 1;
-    __shared__ float wl[3 * C * LD];
-    for (int e = threadIdx.x; e < 3 * C * C; e += 256) { const int p = e / (C * C), k = (e / C) % C, n = e % C; wl[(p * C + k) * LD + n] = t3.w[p][(size_t)k * C + n]; }
-    __syncthreads();
+    constexpr int KC = C / 4, NT = C / 16;
     const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
-    const long long ntiles = (rows + 15) / 16;
-    for (long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); tile < ntiles; tile += (long long)gridDim.x * 4) {
-        const long long r = min(tile * 16 + row, rows - 1);
-        float4 a[3][KC / 4];
+    float bw[3][KC][NT];                                             // B[k][n] = W_p[k][n], k = KC kq + s (the contraction runs over the projection's outputs)
+#pragma unroll
+    for (int p = 0; p < 3; p++)
+#pragma unroll
+        for (int s2 = 0; s2 < KC; s2++)
+#pragma unroll
+            for (int t = 0; t < NT; t++) bw[p][s2][t] = t3.w[p][(size_t)(KC * kq + s2) * C + 16 * t + row];
+    const long long ntiles = (rows + 15) / 16, stride = (long long)gridDim.x * 4;
+    long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    float4 a[3][KC / 4];
+    auto load = [&](long long tl) {
+        const long long r = min(tl * 16 + row, rows - 1);
 #pragma unroll
         for (int p = 0; p < 3; p++) {
             const float4* src = reinterpret_cast<const float4*>(t3.in[p] + r * C + KC * kq);
 #pragma unroll
             for (int v = 0; v < KC / 4; v++) a[p][v] = src[v];
         }
+    };
+    if (tile < ntiles) load(tile);
+    for (; tile < ntiles; tile += stride) {
+        float av[3][KC];
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int v = 0; v < KC / 4; v++) { av[p][4 * v] = a[p][v].x; av[p][4 * v + 1] = a[p][v].y; av[p][4 * v + 2] = a[p][v].z; av[p][4 * v + 3] = a[p][v].w; }
+        if (tile + stride < ntiles) load(tile + stride);
         rl_f32x4 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; t++) acc[t] = rl_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int p = 0; p < 3; p++)
 #pragma unroll
-            for (int v = 0; v < KC / 4; v++) {
-                const float av[4] = {a[p][v].x, a[p][v].y, a[p][v].z, a[p][v].w};
+            for (int s2 = 0; s2 < KC; s2++)
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const float* wrow = wl + (p * C + KC * kq + 4 * v + e) * LD + row;
-#pragma unroll
-                    for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], wrow[16 * t], acc[t], 0, 0, 0);
-                }
-            }
+                for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[p][s2], bw[p][s2][t], acc[t], 0, 0, 0);
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
             const long long orow = tile * 16 + 4 * kq + rr;
@@ -519,7 +529,7 @@ CBL_EXPORT int cbl_triple_linear_forward(long long rows, int C, const float* x, 
     RlTriple t3;
     for (int p = 0; p < 3; p++) { t3.in[p] = x; t3.w[p] = weight3[p]; t3.b[p] = bias3 ? bias3[p] : nullptr; t3.out[p] = y3[p]; }
     const long long tiles = (rows + 15) / 16;
-    const dim3 grid((unsigned)min((tiles + 3) / 4, (long long)1024), 3), blk(256);
+    const dim3 grid((unsigned)min((tiles + 3) / 4, (long long)172), 3), blk(256);      // ~2 workgroups per CU: the 64 B operands of a lane are loaded once per wave
     if (C == 64) hipLaunchKernelGGL(triple_linear_forward_kernel<64>, grid, blk, 0, cbl_stream(stream), rows, x, t3);
     else         hipLaunchKernelGGL(triple_linear_forward_kernel<32>, grid, blk, 0, cbl_stream(stream), rows, x, t3);
     return cbl_status();
@@ -537,7 +547,7 @@ CBL_EXPORT int cbl_triple_linear_backward(long long rows, int C, const float* x,
     RlTriple t3;
     for (int p = 0; p < 3; p++) { t3.in[p] = grad_y3[p]; t3.w[p] = weight3[p]; t3.b[p] = grad_bias3 ? grad_bias3[p] : nullptr; t3.out[p] = grad_weight3[p]; }
     const long long tiles = (rows + 15) / 16;
-    const dim3 grid((unsigned)min((tiles + 3) / 4, (long long)2048)), blk(256);
+    const dim3 grid((unsigned)min((tiles + 3) / 4, (long long)256)), blk(256);
     if (C == 64) hipLaunchKernelGGL(triple_linear_dgrad_kernel<64>, grid, blk, 0, st, rows, t3, grad_x);
     else         hipLaunchKernelGGL(triple_linear_dgrad_kernel<32>, grid, blk, 0, st, rows, t3, grad_x);
     float* partial = reinterpret_cast<float*>(workspace);
