@@ -684,7 +684,7 @@ def run_pt(args, D, world, rank, local):
     us = a.elapsed_time(b) / 20 * 1e3
     li = names.index("pt_layer_fwd")
     nbytes, flops = stages[li][2], stages[li][3]
-    out["roofline"] = {"kernel": "PointTransformerLayer forward: q/k/v Linear (rocBLAS), linear_p, attn_w2 statistics + forward, narrow linear_w, attn_agg with softmax",
+    out["roofline"] = {"kernel": "PointTransformerLayer forward (csrc/pt_layer.hip + cbl_triple_linear): q/k/v projections (1 launch), p chain, BN_c statistics, w2 on MFMA tiles, softmax, aggregation; 3 BatchNorm finalizes",
                        "stage": "pt_layer_fwd", "bound": "hbm", "achieved": nbytes / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": nbytes, "launch_us": round(us, 2),
                        "flops_per_launch": flops, "achieved_TFLOPs": flops / (us * 1e-6) / 1e12, "frac_of_f32_mfma_peak": flops / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
