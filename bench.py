@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 matrix = f32 vector peak
 GRAD_ALLREDUCE_FLOATS = 7800497   # parameters of the reference's PointTransformerSeg + heads: 31.2 MB fp32
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")     # collected by tools/gpu_r03_final.sh; its _meta.commit names the kernel set
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")     # collected by tools/gpu_r04_final.sh; its _meta.commit names the kernel set
 
 
 def parse(argv=None):
@@ -63,6 +63,7 @@ def parse(argv=None):
     ap.add_argument("--no-nested", action="store_true", help="every neighbour search on its own (no derivation of K=16 from the K=36 search of the same points)")
     ap.add_argument("--no-allreduce", action="store_true", help="skip the gradient all-reduce leg of a multi-rank run")
     ap.add_argument("--no-extra", action="store_true", help="headline only: no forward_only / stage / all-reduce legs (profiling runs)")
+    ap.add_argument("--no-gather-200k", action="store_true", help="skip the HBM-certain gather measurement (N = 200 000: 857 MB per launch) of the roofline object")
     ap.add_argument("--no-legs", action="store_true",
                     help="default line only: skip the `pt_block` (config C4) and `convnet` (configs C5 / C3 per scene) legs the 1-GPU default run appends")
     ap.add_argument("--allreduce-floats", type=int, default=GRAD_ALLREDUCE_FLOATS)
@@ -281,13 +282,15 @@ def kernel_times(scene, k, backward, reps=10):
     filler = torch.empty(1 << 32, dtype=torch.uint8, device="cuda")
 
     def timed(fn):
-        fn(); fn()
+        # the outputs of the last three launches stay referenced: consecutive launches write DIFFERENT buffers (the caching allocator would
+        # otherwise hand every launch the buffer the previous one just freed, and a 190 MB output re-written in place sits in the 256 MB Infinity Cache)
+        ring = [fn(), fn(), None]
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         filler.fill_(0); filler.fill_(1)                             # ~1.2 ms: the host enqueues all `reps` launches meanwhile
         a.record()
-        for _ in range(reps):
-            fn()
+        for r in range(reps):
+            ring[(r + 2) % 3] = fn()
         b.record()
         torch.cuda.synchronize()
         return a.elapsed_time(b) / reps * 1e3                        # us
@@ -303,6 +306,47 @@ def kernel_times(scene, k, backward, reps=10):
             out["queryandgroup_bwd"] = timed(lambda: pointops._scatter_rows(up["grad_grouped"], idx, n, 3, c))
     del filler
     return out
+
+
+def gather_200k(n=200000, c=64, k=16, reps=10):
+    """The gather at a size that is HBM for certain: S-room scaled to n = 200 000 points (same density), K = 16, C = 64 — output 4 n K (3 + C)
+    = 857 MB per launch, past the 256 MiB Infinity Cache, consecutive launches alternating between three output buffers.  Returns the roofline
+    entry: achieved = SURVEY 8(d) a3 bytes / HIP-event duration per launch, beside a fill of the same size measured the same way."""
+    from contrastboundary_amd import hotpath, pointops
+    scene = hotpath.Scene.synthetic(n, c, seed=7, b=1)
+    with pointops.neighbor_cache():
+        idx, _ = pointops.knnquery_raw(k, scene.xyz, scene.xyz, scene.offset, scene.offset)
+        fn = lambda: pointops.queryandgroup(k, scene.xyz, scene.xyz, scene.feat, idx, scene.offset, scene.offset, use_xyz=True)
+        ring = [fn(), fn(), fn()]
+        torch.cuda.synchronize()
+
+        def run(f):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for r in range(reps):
+                f(r)
+            b.record(); torch.cuda.synchronize()
+            return a.elapsed_time(b) / reps * 1e3
+
+        def gather(r):
+            ring[r % 3] = None
+            ring[r % 3] = fn()
+        us = run(gather)
+        us_fill = run(lambda r: ring[r % 3].fill_(1.0))
+    nbytes = 4 * n * k + 12 * n + 12 * n + 4 * n * c + 4 * n * k * (3 + c)
+    out_bytes = 4 * n * k * (3 + c)
+    pmc = {}
+    if os.path.exists(PMC_FILE):
+        pmc = json.load(open(PMC_FILE)).get("gather_200k", {})
+    traffic = pmc.get("hbm_bytes_per_launch")
+    del ring
+    torch.cuda.empty_cache()
+    return {"kernel": MAIN_KERNEL["queryandgroup"], "workload": "S-room scaled to N=%d (same density), K=%d, C=%d: %d MB per launch, three output buffers in rotation" % (n, k, c, nbytes // 1000000),
+            "bound": "hbm", "achieved": nbytes / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "bytes_per_launch": nbytes, "launch_us": round(us, 2), "traffic": traffic,
+            "traffic_over_bytes": (round(traffic / nbytes, 3) if traffic else None),
+            "fill_same_size_GBps": round(out_bytes / (us_fill * 1e-6) / 1e9, 1), "frac_of_fill": round((nbytes / us) / (out_bytes / us_fill), 3),
+            "note": "past the Infinity Cache (256 MiB): FETCH_SIZE / WRITE_SIZE of this launch are HBM traffic; `traffic` from %s when collected" % os.path.relpath(PMC_FILE, ROOT)}
 
 
 MAIN_KERNEL = {
@@ -420,6 +464,11 @@ def run_gpu(args, D, world, rank, local):
         copy = _rate(lambda: probe2.copy_(probe), 2 * probe.numel() * 4)
         roofline.update({"measured_fill_GBps": round(fill, 1), "measured_copy_GBps": round(copy, 1), "frac_of_measured_fill": kgbps("queryandgroup") / fill})
         del probe, probe2
+        if not args.no_gather_200k:
+            try:
+                roofline["gather_200k"] = gather_200k()
+            except Exception as e:                                   # noqa: BLE001 — an extra measurement must not take the headline down
+                roofline["gather_200k"] = {"error": repr(e)[:300]}
     out["roofline"] = roofline
 
     # ---- the forward block alone (round 1's step), timed the same way
