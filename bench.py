@@ -108,8 +108,19 @@ def timed_region(step, steps, warmup, sync, D):
         step()
     timed_region.issue_s = time.perf_counter() - t0                  # host time to ISSUE the K steps (diagnostic: equal to the wall time = host bound)
     sync()
+    mine = time.perf_counter() - t0                                  # this rank's own K steps, before the closing barrier
     D.barrier()
-    return D.reduce_scalar(time.perf_counter() - t0, "max")
+    total = time.perf_counter() - t0
+    timed_region.per_rank_ms = (D.reduce_scalar(mine, "min") / steps * 1e3, D.reduce_scalar(mine, "max") / steps * 1e3)
+    return D.reduce_scalar(total, "max")
+
+
+def rank_spread(D):
+    """{"rccl_ranks": ranks of the process group, "backend", "ms_per_step_min_rank" / "_max_rank": the fastest and the slowest rank's own time per step
+    of the LAST timed region (before its closing barrier)} — the multi-GPU line's evidence that N processes took part and how evenly"""
+    ranks, backend = D.group_ranks()
+    lo, hi = getattr(timed_region, "per_rank_ms", (None, None))
+    return {"rccl_ranks": ranks, "backend": backend, "ms_per_step_min_rank": lo, "ms_per_step_max_rank": hi}
 
 
 class GradAllReduce:
@@ -143,9 +154,11 @@ def host_dry_run(args, D, world, rank):
     def step():
         time.sleep(0.002)
     elapsed = timed_region(step, args.steps, args.warmup, lambda: None, D)
-    out = {"metric": "host dry run (NOT a measurement)", "value": n * args.steps * world / elapsed, "unit": "points/s", "n_gpus": world, "steps": args.steps,
+    out = {"ranks": rank_spread(D), "metric": "host dry run (NOT a measurement)", "value": n * args.steps * world / elapsed, "unit": "points/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32", "data": "none (host dry run over gloo)", "config": {"workload": "sleep", "parallelism": "replicas x%d" % world}}
+           "dtype": "f32", "data": "none (host dry run over gloo)",
+           "config": {"workload": "sleep standing in for %s" % ("the ConvNet scene step" if args.workload == "convnet" else "the %s block" % args.block),
+                      "parallelism": "replicas x%d" % world}}
     if world > 1 and not args.no_allreduce:
         ar = GradAllReduce(args.allreduce_floats, "cpu")
 
@@ -384,7 +397,9 @@ def run_gpu(args, D, world, rank, local):
     sync = torch.cuda.synchronize
 
     elapsed = timed_region(step, args.steps, args.warmup, sync, D)
+    spread = rank_spread(D)
     out = {
+        "ranks": spread,
         "metric": "points/sec through KNN+group+KPConv+CBL block, S3DIS N=40960 K=16",
         "value": n * args.steps * world / elapsed, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "host_issue_ms_per_step": timed_region.issue_s / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -594,10 +609,11 @@ def run_convnet(args, D, world, rank, local):
     while time.perf_counter() - t < 0.5:                              # settle: code objects, workspaces, clocks
         step(); torch.cuda.synchronize()
     elapsed = timed_region(step, args.steps, args.warmup, torch.cuda.synchronize, D)
+    spread = rank_spread(D)
     pyr = state["pyr"]
     sizes = [int(p.shape[0]) for p in pyr["points"]]
     widths = [int(nb.shape[1]) for nb in pyr["neighbors"]]
-    out = {"metric": "points/sec through radius+grid pyramid, AdaptiveWeight fwd+bwd (5 layers) and TF-side CBL, ConvNet N=%d" % n,
+    out = {"ranks": spread, "metric": "points/sec through radius+grid pyramid, AdaptiveWeight fwd+bwd (5 layers) and TF-side CBL, ConvNet N=%d" % n,
            "value": n * args.steps * world / elapsed, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": elapsed / args.steps * 1e3, "host_issue_ms_per_step": timed_region.issue_s / args.steps * 1e3, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -697,7 +713,7 @@ def run_pt(args, D, world, rank, local):
     step = make_step(scene, k, backward, args, overlap=not args.no_overlap, pipeline=pipeline)
     sync = torch.cuda.synchronize
     elapsed = timed_region(step, args.steps, args.warmup, sync, D)
-    out = {"metric": "points/sec through KNN+group+PointTransformer(vector attention)+CBL block, S3DIS N=%d K=%d" % (n, k),
+    out = {"ranks": rank_spread(D), "metric": "points/sec through KNN+group+PointTransformer(vector attention)+CBL block, S3DIS N=%d K=%d" % (n, k),
            "value": n * args.steps * world / elapsed, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": elapsed / args.steps * 1e3, "host_issue_ms_per_step": timed_region.issue_s / args.steps * 1e3, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

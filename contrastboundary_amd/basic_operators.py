@@ -41,6 +41,27 @@ def get_subscene_label(stage_n, stage_i, stage_list, target, nstride, num_classe
     return out
 
 
+def get_subscene_features(stage_n, stage_i, stage_list, x, nstride, kr=None, extend=False, return_neighbor=False):
+    """(m, c) float32 = mean over the kr nearest stage-0 points of their rows of `x` (n, c), any per-point features; `x.float()` itself for
+    stage 0.                                                            basic_operators.py:16-50 (get_subscene_label is its one-hot case)"""
+    if stage_i == 0 and not extend:
+        return x.float()                                                                 # :17-18
+    if kr is None:
+        i = 1 if stage_i == 0 and extend else stage_i
+        kr = int(torch.prod(torch.as_tensor(nstride)[:i]).item())                      # :22
+    kr = _as_int(kr)
+    stage_from = stage_list["up"][0]
+    p_from, o_from = stage_from["p_out"], stage_from["offset"]
+    stage_to = stage_list[stage_n][stage_i]
+    p_to, o_to = stage_to["p_out"], stage_to["offset"]
+    neighbor_idx, _ = pointops.knnquery_raw(kr, p_from, p_to, o_from, o_to, algo="set")     # :30; a mean over the set
+    weight = torch.full((p_to.shape[0], kr), 1.0 / kr, dtype=torch.float32, device=p_to.device)
+    out = pointops.WeightedGather.apply(x.float().contiguous(), neighbor_idx, weight)      # :44-45 without the (m, kr, c) gather
+    if return_neighbor:
+        return out, neighbor_idx.view(-1).long(), kr
+    return out
+
+
 def get_boundary_mask(labels, neighbor_label=None, neighbor_idx=None, valid_mask=None, get_plain=False, get_cnt=False):
     """basic_operators.py:69-97.  `neighbor_idx` (n,k) int32 is the native path; a precomputed `neighbor_label` is accepted for
     signature parity and handled with the same comparisons in torch."""

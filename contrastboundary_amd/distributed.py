@@ -43,8 +43,16 @@ def reduce_scalar(value, op="max", device=None):
     if device is None:
         device = "cuda" if dist.get_backend() == "nccl" else "cpu"
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.MIN if op == "min" else dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def group_ranks():
+    """number of ranks of the initialised default process group (1 when there is none) and its backend name"""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_backend()
+    return 1, None
 
 
 def aggregate_throughput(units_this_rank, elapsed_this_rank):
@@ -104,8 +112,14 @@ class GradientReducer:
         self.works = []
         self.handles = []
         if hooks:
-            for i, p in enumerate(self.params):
-                self.handles.append(p.register_post_accumulate_grad_hook(lambda _p, i=i: self._arrived(i)))
+            self.rehook()
+
+    def rehook(self):
+        """(re-)register the post-accumulate hooks that start a bucket's all-reduce during an eager backward — a GraphedTrainStep removes them
+        for its capture (no collective inside a hipGraph); a reducer that goes back to eager steps afterwards calls this to get the overlap back"""
+        self.remove()
+        for i, p in enumerate(self.params):
+            self.handles.append(p.register_post_accumulate_grad_hook(lambda _p, i=i: self._arrived(i)))
 
     # ---- collective issue
     def _launch(self, k):
@@ -170,3 +184,24 @@ def broadcast_parameters(module, src=0):
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t.data, src)
+
+
+def broadcast_buffers(modules, src=0):
+    """rank `src`'s BUFFERS (BatchNorm running statistics, batch counters) on every rank: DistributedDataParallel re-broadcasts them at the start of
+    every forward (broadcast_buffers=True, its default, which the reference keeps: train.py:181-189), so every rank validates and checkpoints the same
+    running statistics.  One flat buffer per dtype: a handful of small collectives per call."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    bufs = [b for m in modules for b in m.buffers()]
+    n = 0
+    with torch.no_grad():
+        for dt in sorted({b.dtype for b in bufs}, key=str):
+            group = [b for b in bufs if b.dtype == dt]
+            flat = torch.cat([b.reshape(-1) for b in group])
+            dist.broadcast(flat, src)
+            pos = 0
+            for b in group:
+                b.copy_(flat[pos:pos + b.numel()].view_as(b)); pos += b.numel()
+            n += len(group)
+    return n

@@ -547,6 +547,34 @@ class Interpolation(Function):
 interpolation2 = Interpolation.apply
 
 
+class WeightedGather(Function):
+    """output[i] = sum_k weight[i, k] input[idx[i, k]] for a GIVEN neighbour table — K5 / K6 (interpolation_cuda_kernel.cu) behind a table the caller
+    already has (basic_operators.get_subscene_features: the mean over the kr nearest stage-0 points, weight = 1 / kr)"""
+
+    @staticmethod
+    def forward(ctx, input, idx, weight):
+        _req(input, torch.float32, "input", 2); _req(idx, torch.int32, "idx", 2); _req(weight, torch.float32, "weight", 2)
+        n, k = idx.shape
+        c, m = input.shape[1], input.shape[0]
+        output = torch.zeros((n, c), dtype=torch.float32, device=input.device)
+        _lib.check(_lib.lib().cbl_interpolation_forward(_c_int(n), _c_int(c), _c_int(k), _lib.ptr(input), _lib.ptr(idx), _lib.ptr(weight),
+                                                        _lib.ptr(output), _lib.stream_of(input)), "cbl_interpolation_forward")
+        ctx.m, ctx.k = m, k
+        ctx.save_for_backward(idx, weight)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        idx, weight = ctx.saved_tensors
+        grad_output = grad_output.contiguous()
+        n, c = grad_output.shape
+        grad_input = torch.zeros((ctx.m, c), dtype=torch.float32, device=grad_output.device)
+        _lib.check(_lib.lib().cbl_interpolation_backward(_c_int(n), _c_int(c), _c_int(ctx.k), _lib.ptr(grad_output), _lib.ptr(idx),
+                                                         _lib.ptr(weight), _lib.ptr(grad_input), _lib.stream_of(grad_output)),
+                   "cbl_interpolation_backward")
+        return grad_input, None, None
+
+
 def interpolation(xyz, new_xyz, feat, offset, new_offset, k=3):
     """pure-torch composite in the reference (pointops.py:164-178); same values, one gather kernel here"""
     return Interpolation.apply(xyz, new_xyz, feat, offset, new_offset, k)

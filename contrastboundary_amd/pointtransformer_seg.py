@@ -275,7 +275,7 @@ class GraphedTrainStep:
                     loss.sum().backward()
                     optimizer.step()
             else:
-                for h in reducer.handles:                           # no collective inside a capture: the buckets go out behind the replay
+                for h in reducer.handles:                           # no collective inside a capture: the buckets go out behind the replay (reducer.rehook() for eager use afterwards)
                     h.remove()
                 reducer.handles = []
                 with torch.cuda.graph(graph):
@@ -303,9 +303,11 @@ class GraphedTrainStep:
         with torch.cuda.stream(side):
             for k, v in inputs.items():
                 s["inputs"][k].copy_(v, non_blocking=True)
-                v.record_stream(side)
+                if v.is_cuda:                                        # a pinned host batch has no stream to be kept alive for (the caller keeps it until `ready`)
+                    v.record_stream(side)
             s["target"].copy_(target, non_blocking=True)
-            target.record_stream(side)
+            if target.is_cuda:
+                target.record_stream(side)
         s["geom"].refresh(side)
         self.stage_turn = (self.stage_turn + 1) % len(self.sets)
         self.staged += 1

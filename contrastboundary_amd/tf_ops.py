@@ -106,6 +106,21 @@ def grid_subsampling(points, features=None, labels=None, sampleDl=0.1, verbose=0
     return res[0] if len(res) == 1 else tuple(res)
 
 
+def tf_grid_subsampling(points, sampleDl):
+    """the NON-batch TF op GridSubsampling(points, dl) -> sub_points  (tf_custom_ops/tf_subsampling/tf_subsampling.cpp:8-20 over
+    grid_subsampling.cpp:6-112): the batch op on one cloud (same barycentres, same order)"""
+    lens = torch.tensor([points.shape[0]], dtype=torch.int32, device=points.device)
+    return tf_batch_subsampling(points, lens, sampleDl)[0]
+
+
+def tf_ordered_neighbors(queries, supports, radius, limit=None):
+    """the NON-batch TF op OrderedNeighbors(queries, supports, radius) -> neighbors (Nq, width) i32, ascending by distance, padded with Ns
+    (tf_custom_ops/tf_neighbors/tf_neighbors.cpp:8-62 over neighbors.cpp:58-208): the batch op on one cloud"""
+    q_len = torch.tensor([queries.shape[0]], dtype=torch.int32, device=queries.device)
+    s_len = torch.tensor([supports.shape[0]], dtype=torch.int32, device=queries.device)
+    return tf_batch_neighbors(queries, supports, q_len, s_len, radius, limit=limit)
+
+
 class RadiusGrid:
     """the search grid of one support set at one radius, kept between searches: tf_batch_neighbors(..., grid=g) builds it on first use and skips the
     5-launch build afterwards.  Valid for the same supports tensor (unchanged), batches and radius, on the stream that built it."""

@@ -20,16 +20,25 @@ def _pt_forward_loss(model, criterion, inputs, target):
 
 
 class DataParallelTrainer:
-    def __init__(self, model, criterion, optimizer, bucket_bytes=8 << 20, forward_loss=None, broadcast=True):
+    def __init__(self, model, criterion, optimizer, bucket_bytes=8 << 20, forward_loss=None, broadcast=True, sync_buffers=True):
+        """The criterion is a module too: the reference wraps it in DistributedDataParallel whenever it has trainable parameters (the CBL head's
+        `project` MLP, train.py:189), so its parameters are broadcast and averaged with the model's, and — sync_buffers, DDP's broadcast_buffers
+        default — rank 0's buffers (BatchNorm running statistics) are re-broadcast at the start of every step, model's and criterion's alike."""
         self.model, self.criterion, self.optimizer = model, criterion, optimizer
         self.forward_loss = forward_loss or _pt_forward_loss
+        self.modules = [model] + ([criterion] if isinstance(criterion, torch.nn.Module) else [])
         if broadcast:
-            D.broadcast_parameters(model)                           # rank 0's initial weights everywhere
-        self.reducer = D.GradientReducer(model.parameters(), bucket_bytes=bucket_bytes)
+            for m in self.modules:
+                D.broadcast_parameters(m)                           # rank 0's initial weights (and buffers) everywhere
+        params = [p for m in self.modules for p in m.parameters()]
+        self.reducer = D.GradientReducer(params, bucket_bytes=bucket_bytes)
         self.world = self.reducer.world
+        self.sync_buffers = sync_buffers
 
     def step(self, inputs, target):
-        """zero -> forward -> backward (buckets all-reduced as they complete) -> wait + average -> optimizer step; returns the loss vector"""
+        """buffers from rank 0 -> zero -> forward -> backward (buckets all-reduced as they complete) -> wait + average -> optimizer step; returns the loss vector"""
+        if self.sync_buffers:
+            D.broadcast_buffers(self.modules)
         self.reducer.zero_grad()
         loss = self.forward_loss(self.model, self.criterion, inputs, target)
         loss.sum().backward()

@@ -589,6 +589,9 @@ int cbl_grid_subsampling(int b, int n, const float* points, const int* offset, f
  *   queries (nq,3) / q_offset (b), supports (ns,3) / s_offset (b), radius, limit (<= 64)
  *   -> out (nq,limit) i32: the supports with d2 < radius^2 (strict), ascending by (d2, index), global row ids, padded with ns;
  *      counts (nq, may be NULL) true number inside the ball; max_count (1) = the reference's output width before the crop. */
+/* The reference's NON-batch TF ops — GridSubsampling(points, dl) (tf_subsampling.cpp:8-20 over grid_subsampling.cpp:6-112) and
+ * OrderedNeighbors(queries, supports, radius) (tf_neighbors.cpp:8-62 over neighbors.cpp:58-208) — are the batch entries with b = 1
+ * (offset = {n}): same barycentres / neighbour order.  Host mirrors: tf_ops.tf_grid_subsampling, tf_ops.tf_ordered_neighbors. */
 size_t cbl_radius_neighbors_workspace_bytes(int b, int ns);
 int cbl_radius_neighbors(int b, int nq, int ns, const float* queries, const float* supports, const int* q_offset, const int* s_offset,
                          float radius, int limit, int* out, int* counts, int* max_count, void* workspace, size_t workspace_bytes, void* stream);

@@ -3,6 +3,8 @@ throughput = sum(units) / max(time).  (The kernels themselves need a GPU; ranks 
 import os
 import socket
 
+import pytest
+
 import torch
 import torch.multiprocessing as mp
 
@@ -86,6 +88,61 @@ def test_bench_spawns_its_ranks_and_reports_the_joined_world():
     assert out["ms_per_step"] >= 2.0 and abs(out["value"] - 40960 * 5 * 2 / (out["ms_per_step"] * 5e-3)) < 1e-6 * out["value"]
     # the gradient all-reduce leg ran over the process group: ones summed over 2 ranks and averaged stay 1
     assert out["grad_allreduce"]["bytes"] == 4 * 4096 and out["grad_allreduce"]["checksum"] == 1.0
+    # who took part, and how evenly: the group's size and backend, the fastest / slowest rank's own time per step
+    rk = out["ranks"]
+    assert rk["rccl_ranks"] == 2 and rk["backend"] == "gloo" and 2.0 <= rk["ms_per_step_min_rank"] <= rk["ms_per_step_max_rank"] <= out["ms_per_step"] + 1e-6
+
+
+@rendezvous_retry
+@pytest.mark.parametrize("extra,what", [(["--workload", "convnet"], "ConvNet"), (["--block", "pt"], "pt block")])
+def test_bench_launcher_with_the_other_workloads(extra, what):
+    """`bench.py --gpus N --workload convnet` / `--block pt`: the same spawn / rendezvous / timing path as the headline (the driver's scaling runs
+    use the default line; these are one command away from a curve of their own)"""
+    import json
+    r = _bench("--gpus", "2", "--host-dry-run", "--steps", "3", "--warmup", "1", "--no-allreduce", *extra)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks"]["rccl_ranks"] == 2 and what in out["config"]["workload"]
+    if extra[0] == "--workload":
+        assert abs(out["value"] - 200000 * 3 * 2 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]          # the ConvNet scene's default size
+
+
+def _cold_build_worker(i, libdir, q):
+    """one of N ranks that all find the library stale at start-up (torchrun with cold ranks): every one calls build(); the file lock serialises them"""
+    import time
+    from contrastboundary_amd import build as B
+    t = time.time()
+    so = B.build()
+    q.put((i, os.path.exists(so), time.time() - t))
+
+
+def test_eight_cold_ranks_build_the_library_once():
+    """build.py's flock: 8 processes that all call build() at once on a stale library (a header touched) — one compiles / links, the others wait and
+    find it fresh; nobody sees a half-written .so (objects and library are renamed into place)"""
+    import ctypes
+    from contrastboundary_amd import build as B
+    B.build()
+    hdr = os.path.join(B.CSRC, "wave_ops.h")
+    st = os.stat(hdr)
+    try:
+        os.utime(hdr)                                                 # every object that includes a header is stale now ... as far as mtimes go
+        assert B.is_stale()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_cold_build_worker, args=(i, B.LIBDIR, q)) for i in range(8)]
+        [p.start() for p in procs]
+        res = [q.get(timeout=900) for _ in range(8)]
+        [p.join(60) for p in procs]
+        assert all(p.exitcode == 0 for p in procs) and all(ok for _, ok, _ in res)
+        assert not B.is_stale()
+        L = ctypes.CDLL(B.SO)                                         # loads: a complete library
+        L.cbl_version.restype = ctypes.c_char_p
+        assert b"cbl_amd" in L.cbl_version()
+    finally:
+        os.utime(hdr, (st.st_atime, st.st_mtime))
+        B.build()
 
 
 def test_bench_refuses_more_gpus_than_devices():
@@ -198,3 +255,65 @@ def test_bench_model_deals_scenes_and_keeps_replicas_identical():
     assert out["n_gpus"] == 2 and out["scenes_of_rank0"] == [0, 2, 4]          # 6 scenes dealt round-robin over 2 ranks
     assert out["replicas_identical"] is True                                   # started different, broadcast + averaged gradients keep them equal
     assert out["grad_allreduce"]["ranks"] == 2 and out["grad_allreduce"]["buckets"] >= 2
+    assert out["ranks"]["rccl_ranks"] == 2 and out["ranks"]["ms_per_step_min_rank"] <= out["ranks"]["ms_per_step_max_rank"]
+
+
+# ---- the data-parallel trainer: criterion parameters averaged with the model's, buffers re-broadcast per step (DDP's roles, train.py:181-189) ----
+class _Crit(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.scale = torch.nn.Parameter(torch.ones(3))                # a trainable criterion parameter (the CBL head's `project` MLP in the reference)
+        self.bn = torch.nn.BatchNorm1d(3)                             # ... and buffers of its own
+
+    def forward(self, out, y):
+        return ((self.bn(out) * self.scale - y) ** 2).mean().unsqueeze(0)
+
+
+class _BnNet(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.net = torch.nn.Sequential(torch.nn.Linear(5, 8), torch.nn.BatchNorm1d(8), torch.nn.ReLU(), torch.nn.Linear(8, 3))
+
+    def forward(self, x):
+        return self.net(x)
+
+
+def _trainer_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from contrastboundary_amd import distributed as D, train_step
+    D.init("gloo")
+    torch.manual_seed(50 + rank)                                      # different initial weights per rank
+    model, crit = _BnNet(), _Crit()
+    opt = torch.optim.SGD(list(model.parameters()) + list(crit.parameters()), lr=0.1)
+    seen = []
+    tr = train_step.DataParallelTrainer(model, crit, opt, bucket_bytes=64, forward_loss=lambda m, c, x, y: c(m(x), y))
+    x, y = _rank_batch(rank)
+    for _ in range(3):
+        tr.step(x, y)
+        seen.append(torch.cat([b.reshape(-1).float() for m in (model, crit) for b in m.buffers()]).clone())
+    D.broadcast_buffers([model, crit])                                # what the next step would start from
+    params = torch.cat([p.detach().reshape(-1) for m in (model, crit) for p in m.parameters()])
+    bufs = torch.cat([b.reshape(-1).float() for m in (model, crit) for b in m.buffers()])
+    tr.reducer.remove(); n0 = len(tr.reducer.handles); tr.reducer.rehook(); n1 = len(tr.reducer.handles)
+    out.put((rank, params.numpy().copy(), bufs.numpy().copy(), len(tr.reducer.params), seen[-1].numpy().copy(), n0, n1))
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+@rendezvous_retry
+def test_trainer_averages_criterion_parameters_and_broadcasts_buffers():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    (_, p0, b0, n0, own0, h0, h1), (_, p1, b1, n1, own1, _, _) = res
+    assert n0 == n1 == 9                                              # 6 model parameters and the criterion's 3 (scale, bn.weight, bn.bias) in one reducer
+    import numpy as np
+    assert np.array_equal(p0, p1)                                     # every parameter — the criterion's included — identical on both ranks after 3 steps
+    assert np.array_equal(b0, b1)                                     # after the broadcast: rank 0's running statistics everywhere
+    assert not np.array_equal(own0, own1)                             # ... which the ranks' own batches had moved apart within the step
+    assert h0 == 0 and h1 == n0                                       # hooks can be re-registered after a capture removed them

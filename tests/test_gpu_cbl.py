@@ -503,3 +503,22 @@ def test_point_contrast_beyond_the_transposed_table_limit_scatters_with_atomics(
     rloss, rgrad, _ = C.point_contrast(feat, np.eye(3, dtype=np.float32)[lab], nb, temperature=1.0, weight=0.1)
     assert abs(loss.item() - rloss) < 1e-4 * max(1.0, abs(rloss))
     np.testing.assert_allclose(f.grad.cpu().numpy(), rgrad, rtol=1e-4, atol=1e-4 * np.abs(rgrad).max())
+
+
+def test_subscene_features_of_float_rows_match_reference():
+    """get_subscene_features (basic_operators.py:16-50) on arbitrary per-point features, against the reference's own function run on CPU
+    (tests/golden/gen_subscene_features_goldens.py): a mean over kr gathered rows — 1e-6 (the reference sums then divides, the kernel weights by 1/kr)"""
+    from contrastboundary_amd.basic_operators import get_subscene_features
+    F = np.load(os.path.join(os.path.dirname(__file__), "golden", "subscene_features.npz"))
+    sl = make_stage_list("default")
+    x = dev(F["x"])
+    for i in range(5):
+        got = get_subscene_features("up", i, sl, x, [4, 4, 4, 4])
+        np.testing.assert_allclose(got.cpu().numpy(), F[f"stage{i}"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(get_subscene_features("up", 0, sl, x, [4, 4, 4, 4], extend=True).cpu().numpy(), F["stage0_extend"], rtol=1e-5, atol=1e-6)
+    got, nidx, kr = get_subscene_features("up", 2, sl, x, [4, 4, 4, 4], kr=5, return_neighbor=True)
+    np.testing.assert_allclose(got.cpu().numpy(), F["stage2_kr5"], rtol=1e-5, atol=1e-6)
+    assert kr == 5 and nidx.numel() == got.shape[0] * 5
+    xg = x.clone().requires_grad_(True)                              # differentiable w.r.t. the features, as the torch composite is
+    get_subscene_features("up", 1, sl, xg, [4, 4, 4, 4]).sum().backward()
+    assert abs(float(xg.grad.sum()) - sl["up"][1]["p_out"].shape[0] * x.shape[1]) < 1e-2

@@ -126,3 +126,45 @@ def test_c5_full_size_properties():
     assert int(sl2[0]) <= int(sl[0]) and int(sl[0]) < 200000
     # a barycentre stays inside its voxel, so re-sampling on the same grid keeps one point per voxel unless the origin shifts
     assert int(sl2[0]) >= int(0.9 * int(sl[0]))
+
+
+def test_non_batch_ops_are_the_batch_ops_on_one_cloud():
+    """GridSubsampling / OrderedNeighbors (the reference's non-batch TF ops, tf_subsampling.cpp:8-20, tf_neighbors.cpp:8-62) = the batch entries with b = 1"""
+    from contrastboundary_amd import tf_ops
+    xyz, _ = S.s_room(9000, seed=8)
+    one = np.int32([9000])
+    sp = tf_ops.tf_grid_subsampling(dev(xyz), 0.08)
+    rp, _ = O.grid_subsampling(xyz, one, 0.08)
+    np.testing.assert_array_equal(sp.cpu().numpy().view(np.uint32), rp.view(np.uint32))
+    q = xyz[::5].copy()
+    got = tf_ops.tf_ordered_neighbors(dev(q), dev(xyz), 0.1).cpu().numpy()
+    ref, _, mc = O.radius_neighbors(q, xyz, np.int32([len(q)]), one, 0.1, 64)
+    np.testing.assert_array_equal(got, ref[:, :mc])
+
+
+def test_c5_full_size_layer0_against_the_compiled_reference():
+    """BASELINE config C5 at FULL size (N = 200 000): layer 0 of the pyramid builder — the self neighbours, the sub-sampled points and the pooling
+    neighbours — against the reference's own nanoflann search (oracle/_ref/libref_tfops.so, compiled from /root/reference/tensorflow/ops/tf_custom_ops;
+    0.8 s per search where the brute-force restatement needs 50) and the pinned grid-subsampling oracle.  Rows must hold the same neighbours at the same
+    distances; order may differ only inside groups of exactly equal distance (std::sort's tie order is unspecified)."""
+    from contrastboundary_amd import tf_ops
+    from tests.test_oracle_tfops import ref_radius, rows_equal_mod_ties, tf
+    if tf is None:
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    xyz, _ = S.s_room(200000, seed=0, scale=4.0)
+    lens = np.int32([200000])
+    limits = [26, 31, 38, 41, 39]
+    pyr = tf_ops.segmentation_inputs_radius(dev(xyz), dev(lens), 0.04, 5.0, 5, limits)
+    refn, mc = ref_radius(0, xyz, xyz, lens, lens, 0.1)
+    w = min(mc, limits[0])
+    got = pyr["neighbors"][0].cpu().numpy()
+    assert got.shape == (200000, w)
+    full = tf_ops.tf_batch_neighbors(dev(xyz), dev(xyz), dev(lens), dev(lens), 0.1, max(mc, 1), exact_shape=False).cpu().numpy()
+    rows_equal_mod_ties(full[:, :mc], refn, xyz, xyz, 200000)               # the whole neighbourhoods, before the crop
+    np.testing.assert_array_equal(got, full[:, :w])                           # the crop (datasets/base.py:756-765) = the first columns
+    pp, pl = O.grid_subsampling(xyz, lens, 0.08)
+    np.testing.assert_array_equal(pyr["points"][1].cpu().numpy().view(np.uint32), pp.view(np.uint32))
+    refp, mcp = ref_radius(0, pp, xyz, pl, lens, 0.1)
+    fullp = tf_ops.tf_batch_neighbors(dev(pp), dev(xyz), dev(pl), dev(lens), 0.1, max(mcp, 1), exact_shape=False).cpu().numpy()
+    rows_equal_mod_ties(fullp[:, :mcp], refp, pp, xyz, 200000)
+    np.testing.assert_array_equal(pyr["pools"][0].cpu().numpy(), fullp[:, :min(mcp, limits[0])])

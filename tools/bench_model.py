@@ -67,8 +67,14 @@ def timed(step, a, sync, D):
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = step()
-    sync(); D.barrier()
-    return D.reduce_scalar(time.perf_counter() - t0, "max"), out
+    sync()
+    mine = time.perf_counter() - t0                                  # this rank's own steps, before the closing barrier
+    D.barrier()
+    total = time.perf_counter() - t0
+    ranks, backend = D.group_ranks()
+    timed.ranks = {"rccl_ranks": ranks, "backend": backend, "ms_per_step_min_rank": D.reduce_scalar(mine, "min") / a.steps * 1e3,
+                   "ms_per_step_max_rank": D.reduce_scalar(mine, "max") / a.steps * 1e3}
+    return D.reduce_scalar(total, "max"), out
 
 
 def host_dry_run(a, D, world, rank):
@@ -92,7 +98,7 @@ def host_dry_run(a, D, world, rank):
     if dist.is_initialized():
         dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     if rank == 0:
-        print(json.dumps({"workload": "host dry run (NOT a measurement)", "n_gpus": world, "scenes_of_rank0": mine, "ms_per_step": elapsed / a.steps * 1e3,
+        print(json.dumps({"workload": "host dry run (NOT a measurement)", "n_gpus": world, "ranks": timed.ranks, "scenes_of_rank0": mine, "ms_per_step": elapsed / a.steps * 1e3,
                           "replicas_identical": bool(torch.equal(lo, hi)), "grad_allreduce": tr.describe(), "loss": float(loss.sum())}), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
@@ -166,7 +172,7 @@ def run(a, D, world, rank, local):
     elapsed, loss = timed(step, a, torch.cuda.synchronize, D)
     dt = elapsed / a.steps
     nc = nc_last[0]
-    out = {"workload": f"PointTransformerSeg+CBL train step, {a.scenes} x S-room({a.n}) per rank", "n_gpus": world, "ms_per_step": dt * 1e3,
+    out = {"workload": f"PointTransformerSeg+CBL train step, {a.scenes} x S-room({a.n}) per rank", "n_gpus": world, "ranks": timed.ranks, "ms_per_step": dt * 1e3,
            "points_per_s": a.n * a.scenes * world / dt, "scaling": "weak", "scenes_of_rank0": mine,
            "knn_requests": None if nc is None else nc.hits + nc.misses, "knn_searches": None if nc is None else nc.misses,
            "geometry_prefetch": bool(a.prefetch or a.graph), "hipgraph": bool(a.graph), "blas": a.blas,
