@@ -316,7 +316,7 @@ def tf_sample_columns(neighbors, sample, rand_idx=None, batches_len=None, genera
 
 
 def tf_contrast(features, labels, neighbors, temperature=1.0, weight=0.1, return_mask=False, kl_threshold=None, contrast="softnn", sample="label",
-                margin=None, rand_idx=None, batches_len=None, generator=None):
+                margin=None, rand_idx=None, batches_len=None, generator=None, atomic_scatter=False):
     """TF contrast_head.contrast ('softnn' | 'nce', dist 'l2') for one stage: features (m,d) f32, neighbors (m,k) i32 radius neighbours incl. the self
     column, padded with N.  sample 'label': labels (N,) hard labels of the N support points of that stage (negative = ignored);
     sample 'labelkl<thr>' (kl_threshold=thr): labels (N,ncls) f32 label distributions (tf_scene_label(..., 'soft'); one-hot at stage 0);
@@ -336,7 +336,10 @@ def tf_contrast(features, labels, neighbors, temperature=1.0, weight=0.1, return
         lab = labels.to(torch.float32).contiguous()
         if lab.dim() != 2 or lab.shape[1] > 255:
             raise ValueError("labelkl: labels must be (N, ncls <= 255) distributions")
-    if contrast == "nce" or separate or not plain_sample:               # the pair kernels: every option of the head
+    # Every configuration takes the pair kernels: mining + loss + per-pair coefficients in one pass, the neighbour half of the gradient as a gather
+    # over the transposed table of `neighbors` (the table AdaptiveWeight's backward builds for the same tensor: cached, not rebuilt) — no float
+    # atomics, run-to-run deterministic.  `atomic_scatter=True` keeps round 1's kernels reachable (cbl_tf_contrast_*: gradient by row atomics).
+    if not atomic_scatter or contrast == "nce" or separate or not plain_sample:
         if plain_sample:
             samples, roles, valid = neighbors.contiguous(), None, None
         else:

@@ -136,9 +136,11 @@ def test_hard_labels_as_int64_and_int32_give_the_same_loss_and_gradient():
     torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-5, atol=1e-8)       # atomics: summation order only
 
 
+@pytest.mark.parametrize("atomic", [False, True])
 @pytest.mark.parametrize("limit,d,T", [(26, 32, 1.0), (41, 16, 0.5), (12, 64, 2.0)])
-def test_tf_contrast_head_vs_oracle(limit, d, T):
-    """a16: TF contrast_head on radius neighbourhoods with shadow padding + ignored (-1) labels, vs the numpy restatement"""
+def test_tf_contrast_head_vs_oracle(limit, d, T, atomic):
+    """a16: TF contrast_head on radius neighbourhoods with shadow padding + ignored (-1) labels, vs the numpy restatement; the default route (pair
+    kernels, gradient as a gather) and round 1's kernels (`atomic_scatter`)"""
     from contrastboundary_amd import heads, tf_ops
     from contrastboundary_amd import synthetic as S
     xyz, lab = S.s_room(6000, seed=limit)
@@ -148,7 +150,7 @@ def test_tf_contrast_head_vs_oracle(limit, d, T):
     nb = tf_ops.tf_batch_neighbors(dev(xyz), dev(xyz), dev(lens), dev(lens), 0.12, limit, exact_shape=False)
     feat = (rng.normal(size=(6000, d)) * 0.5).astype(np.float32)
     f = dev(feat).requires_grad_(True)
-    loss, mask = heads.tf_contrast(f, dev(lab), nb, T, 0.1, return_mask=True)
+    loss, mask = heads.tf_contrast(f, dev(lab), nb, T, 0.1, return_mask=True, atomic_scatter=atomic)
     loss.backward()
     rl, rg, rm = C.tf_contrast(feat, lab, nb.cpu().numpy(), temperature=T, weight=0.1)
     np.testing.assert_array_equal(mask.cpu().numpy().astype(bool), rm)
@@ -157,8 +159,9 @@ def test_tf_contrast_head_vs_oracle(limit, d, T):
     assert (nb.cpu().numpy() == 6000).any()                                   # the case really contains shadow entries
 
 
+@pytest.mark.parametrize("atomic", [False, True])
 @pytest.mark.parametrize("limit,d,T,thr", [(26, 32, 0.5, 0.5), (20, 64, 1.0, 0.3)])
-def test_tf_contrast_head_labelkl_vs_oracle(limit, d, T, thr):
+def test_tf_contrast_head_labelkl_vs_oracle(limit, d, T, thr, atomic):
     """sample 'labelkl<thr>' (s3dis.py:162-163): positives by the KL divergence of the sub-scene label distributions, on a sub-sampled
     stage (soft labels from the stage-0 points) with shadow-padded radius neighbourhoods"""
     from contrastboundary_amd import heads, tf_ops
@@ -173,7 +176,7 @@ def test_tf_contrast_head_labelkl_vs_oracle(limit, d, T, thr):
     rng = np.random.default_rng(limit)
     feat = (rng.normal(size=(m, d)) * 0.5).astype(np.float32)
     f = dev(feat).requires_grad_(True)
-    loss, mask = heads.tf_contrast(f, soft, nb, T, 0.1, return_mask=True, kl_threshold=thr)
+    loss, mask = heads.tf_contrast(f, soft, nb, T, 0.1, return_mask=True, kl_threshold=thr, atomic_scatter=atomic)
     loss.backward()
     soft_h, nb_h = soft.cpu().numpy(), nb.cpu().numpy()
     kl = C.tf_label_kl(soft_h, nb_h[:, 1:])
@@ -186,7 +189,7 @@ def test_tf_contrast_head_labelkl_vs_oracle(limit, d, T, thr):
     assert (nb_h == m).any()                                                   # shadow entries present
     # inference path (no gradient): same loss
     with torch.no_grad():
-        l2 = heads.tf_contrast(dev(feat), soft, nb, T, 0.1, kl_threshold=thr)
+        l2 = heads.tf_contrast(dev(feat), soft, nb, T, 0.1, kl_threshold=thr, atomic_scatter=atomic)
     np.testing.assert_allclose(l2.item(), rl, rtol=TOL)
 
 
