@@ -86,7 +86,15 @@ def test_neighbor_cache_does_not_change_the_forward():
         a, _, la, _ = M.forward_and_loss(model, crit, inputs, target)
         b, sl = model(inputs)
         lb = crit(b, target, sl)
-    assert torch.equal(a, b) and torch.equal(la, lb)
+        c, sl2 = model(inputs)
+        lc = crit(c, target, sl2)
+    # the same pass twice: bit-identical (no atomics anywhere in the forward)
+    assert torch.equal(b, c) and torch.equal(lb, lc)
+    # with the cache the widest search of a geometry runs first and its cell order becomes the processing order; without it the layer's own (narrower)
+    # search does — another permutation, hence another summation order of the BatchNorm statistics in csrc/pt_layer.hip: equal up to fp32 rounding
+    # (same indices, same values; measured 5e-7 on the first layer, 1e-5 on the logits)
+    scale = float(b.abs().max())
+    assert float((a - b).abs().max()) <= 1e-4 * scale and torch.allclose(la, lb, rtol=1e-4, atol=1e-6)
 
 
 @pytest.mark.gpu
