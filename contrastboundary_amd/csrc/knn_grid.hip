@@ -675,19 +675,41 @@ void launch_query(bool self, int b, int m, int K, const float* new_xyz, const in
 
 // ---- N2: sorted radius neighbours, cropped to `limit` and padded with Ns -------------------------------------------
 // Replaces batch_nanoflann_neighbors (tensorflow/ops/tf_custom_ops/tf_neighbors/neighbors/neighbors.cpp:213-336) plus the
-// callers' crop to neighborhood_limits (tensorflow/datasets/base.py:756-765).  Same group-per-query structure as the KNN
-// kernel: the group keeps the `limit` nearest candidates with d2 < r^2 (strict, nanoflann.hpp:249-253) in ascending
-// (d2, index) order; one pass over the 27-cell block suffices because the grid's cell edge is >= radius
-// (cbl_grid_choose_radius).  counts[q] = true number of supports inside the ball (the reference's row length before padding).
+// callers' crop to neighborhood_limits (tensorflow/datasets/base.py:756-765).  A group of G >= limit lanes per query; one pass over the
+// 27-cell block suffices because the grid's cell edge is >= radius (cbl_grid_choose_radius).  counts[q] = true number of supports inside
+// the ball (the reference's row length before padding).
+// COLLECT, THEN RANK (round 4).  Round 3 kept the `limit` nearest in an ordered list across the lanes and inserted every in-ball candidate
+// with a cross-lane shift (a serial chain of ~20 vector instructions and two LDS-crossbar reads per candidate: 0.84 of the vector issue
+// slots).  Now the sweep only COLLECTS the supports with d2 < r^2 (strict, nanoflann.hpp:249-253) — their 64-bit keys (d2 bits, index) are
+// compacted into a list of the group in LDS, up to 2 G of them — and the order is established afterwards by a rank count: a lane holds up
+// to two of the keys and counts, over one broadcast read per list entry, how many keys are smaller; the rank IS the output column, so the
+// result is stored straight from where it sits (no sort network, no permutation).  d2 >= +0, so the keys order like (d2, index): the
+// canonical order of the oracle.  A ball with more than 2 G supports (never seen on the bench scenes) is selected by repeated minimum.
+template <int G>
+__device__ __forceinline__ unsigned long long group_min_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int s = G / 2; s >= 1; s >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)v, s, G), hi = __shfl_xor((unsigned)(v >> 32), s, G);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
 template <int G>
 __global__ __launch_bounds__(256) void radius_group_kernel(int b, int nq, int ns_total, int limit, float r2, const float* __restrict__ queries,
                                                            const int* __restrict__ q_offset, const CblGrid* __restrict__ grids,
                                                            const int* __restrict__ cell_start, const float4* __restrict__ sorted,
                                                            int* __restrict__ out, int* __restrict__ counts, int* __restrict__ max_count)
 {
-    constexpr int QPW = 64 / G;
+    constexpr int QPW = 64 / G, CAP = 2 * G;
     using mask_t = unsigned long long;
+    using key_t = unsigned long long;
+    constexpr key_t NONE = ~0ull;
+    __shared__ key_t slots[4 * QPW][CAP];
     const int lane = threadIdx.x & 63, gl = lane & (G - 1), grp = lane / G;
+    key_t* S = slots[(threadIdx.x >> 6) * QPW + grp];
     const int wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const int t = wave_global * QPW + grp;
     const bool live = t < nq;
@@ -697,55 +719,76 @@ __global__ __launch_bounds__(256) void radius_group_kernel(int b, int nq, int ns
     const CblGrid g = grids[c];
     const int cx = cbl_cell_coord(cbl_u(qx, g.ox, g.inv_cs), g.nx), cy = cbl_cell_coord(cbl_u(qy, g.oy, g.inv_cs), g.ny),
               cz = cbl_cell_coord(cbl_u(qz, g.oz, g.inv_cs), g.nz);
-    float ed = INFINITY; int ei = 0x7fffffff;
-    int inside = 0;
     const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
-    // the list's current worst entry (slot limit - 1), group-uniform: re-read only after an insertion (it was two cross-lane reads per 32 candidates,
-    // and most batches insert nothing: the kernel sits at 0.84 of the vector issue slots, profiles/r03_pmc_convnet.json)
-    float wd = INFINITY; int wi = 0x7fffffff;
-    for (int dz = -1; dz <= 1; dz++) {
-        for (int dy = -1; dy <= 1; dy++) {
-            const int y = cy + dy, z = cz + dz;
-            int s = 0, e = 0;
-            if (live && g.end > g.start && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
-                const int row = g.cell_base + g.nx * (y + g.ny * z);
-                s = cell_start[row + x0]; e = cell_start[row + x1 + 1];
-            }
-            for (int p = s; __any(p < e); p += G) {
-                const int pi = p + gl;
-                const bool have = pi < e;
-                const float4 v = sorted[have ? pi : (e > s ? e - 1 : 0)];     // clamped, unconditional: no branch around the load
-                const float d2 = have ? cbl_dist2(qx, qy, qz, v.x, v.y, v.z) : INFINITY;      // (query - support)^2 summed over x,y,z like L2_Simple_Adaptor
-                const int ci = have ? __float_as_int(v.w) : 0x7fffffff;
-                const bool in_ball = d2 < r2;
-                inside += in_ball ? 1 : 0;
-                const bool pass = in_ball && (d2 < wd || (d2 == wd && ci < wi));
-                mask_t gm = (__ballot(pass) >> (grp * G)) & (G == 64 ? ~0ull : ((1ull << G) - 1ull));
-                if (!__any(gm != 0)) continue;
-                while (__any(gm != 0)) {
-                    const bool has = gm != 0;
-                    const int l = has ? __builtin_ctzll(gm) : 0;
-                    gm &= gm - 1;
-                    float dc = __shfl(d2, l, G); const int ic = __shfl(ci, l, G);
-                    if (!has) dc = INFINITY;
-                    const float pd = dpp_shr1_f<G>(ed); const int pidx = dpp_shr1_i<G>(ei);
-                    const bool gt = has && (ed > dc || (ed == dc && ei > ic));           // canonical (d2, index) order
-                    const bool left_gt = (gl > 0) && (pd > dc || (pd == dc && pidx > ic));
-                    if (gt) { if (left_gt) { ed = pd; ei = pidx; } else { ed = dc; ei = ic; } }
-                }
-                wd = __shfl(ed, limit - 1, G); wi = __shfl(ei, limit - 1, G);
-            }
+    const mask_t below = (1ull << gl) - 1ull, gmask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
+    // row r = 3 (dz + 1) + (dy + 1) of the block: its candidates are one contiguous range of the cell-sorted supports
+    auto row_range = [&](int r, int& s, int& e) {
+        const int y = cy + (r % 3) - 1, z = cz + (r / 3) - 1;
+        s = 0; e = 0;
+        if (live && g.end > g.start && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
+            const int row = g.cell_base + g.nx * (y + g.ny * z);
+            s = cell_start[row + x0]; e = cell_start[row + x1 + 1];
+        }
+    };
+    auto key_at = [&](int pi, int s, int e) -> key_t {              // the candidate's key, NONE outside the range / the ball
+        const bool have = pi < e;
+        const float4 v = sorted[have ? pi : (e > s ? e - 1 : 0)];    // clamped, unconditional: no branch around the load
+        const float d2 = cbl_dist2(qx, qy, qz, v.x, v.y, v.z);       // (query - support)^2 summed over x,y,z like L2_Simple_Adaptor
+        return (have && d2 < r2) ? (((key_t)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(v.w)) : NONE;
+    };
+    int inside = 0;
+    for (int r = 0; r < 9; r++) {
+        int s, e;
+        row_range(r, s, e);
+        for (int p = s; __any(p < e); p += G) {
+            const key_t key = key_at(p + gl, s, e);
+            const bool in_ball = key != NONE;
+            if (!__any(in_ball)) continue;
+            const mask_t gm = (__ballot(in_ball) >> (grp * G)) & gmask;
+            const int slot = inside + __popcll(gm & below);
+            if (in_ball && slot < CAP) S[slot] = key;
+            inside += __popcll(gm);
         }
     }
-#pragma unroll
-    for (int s = G / 2; s >= 1; s >>= 1) inside += __shfl_xor(inside, s, G);
-    if (live) {
-        if (gl < limit) out[(size_t)q * limit + gl] = (ed < INFINITY) ? ei : ns_total;     // pad with supports.size(), neighbors.cpp:328
-        if (gl == 0) {
-            if (counts) counts[q] = inside;
-            // one address for the whole launch: only groups that would raise the maximum touch it (monotone, so a stale read only costs a redundant atomic)
-            if (inside > __hip_atomic_load(max_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_count, inside);
+    const bool over = inside > CAP;                                  // group-uniform
+    if (!over) {
+        const int n = inside;
+        const key_t ka = gl < n ? S[gl] : NONE, kb = gl + G < n ? S[gl + G] : NONE;
+        int ra = 0, rb = 0;
+        for (int k = 0; __any(k < n); k++) {
+            const key_t kk = S[k < n ? k : 0];
+            const bool on = k < n;
+            ra += (on && kk < ka) ? 1 : 0; rb += (on && kk < kb) ? 1 : 0;
         }
+        if (live) {
+            if (ka != NONE && ra < limit) out[(size_t)q * limit + ra] = (int)(unsigned)ka;
+            if (kb != NONE && rb < limit) out[(size_t)q * limit + rb] = (int)(unsigned)kb;
+            if (gl >= n && gl < limit) out[(size_t)q * limit + gl] = ns_total;          // pad with supports.size(), neighbors.cpp:328 (limit <= G)
+        }
+    }
+    if (__any(over)) {
+        // more supports in the ball than the list holds: column p = the smallest key above column p - 1's, one sweep per column
+        key_t prev = 0; bool first = true;
+        for (int col = 0; col < limit; col++) {
+            key_t best = NONE;
+            for (int r = 0; r < 9; r++) {
+                int s, e;
+                row_range(r, s, e);
+                if (!over) e = s;
+                for (int p = s; __any(p < e); p += G) {
+                    const key_t key = key_at(p + gl, s, e);
+                    if ((first || key > prev) && key < best) best = key;
+                }
+            }
+            best = group_min_u64<G>(best);
+            if (over && live && gl == 0) out[(size_t)q * limit + col] = best == NONE ? ns_total : (int)(unsigned)best;
+            if (best != NONE) { prev = best; first = false; } else { prev = NONE; first = false; }
+        }
+    }
+    if (live && gl == 0) {
+        if (counts) counts[q] = inside;
+        // one address for the whole launch: only groups that would raise the maximum touch it (monotone, so a stale read only costs a redundant atomic)
+        if (inside > __hip_atomic_load(max_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_count, inside);
     }
 }
 

@@ -168,3 +168,19 @@ def test_c5_full_size_layer0_against_the_compiled_reference():
     fullp = tf_ops.tf_batch_neighbors(dev(pp), dev(xyz), dev(pl), dev(lens), 0.1, max(mcp, 1), exact_shape=False).cpu().numpy()
     rows_equal_mod_ties(fullp[:, :mcp], refp, pp, xyz, 200000)
     np.testing.assert_array_equal(pyr["pools"][0].cpu().numpy(), fullp[:, :min(mcp, limits[0])])
+
+
+@pytest.mark.parametrize("limit", [12, 26, 41, 64])
+def test_radius_neighbors_in_dense_balls(limit):
+    """balls that hold far more supports than the search's list (2 G keys per query group): the repeated-minimum path, and the mixed case where only
+    some queries of a wave overflow; bit-exact against the oracle like the sparse cases"""
+    from contrastboundary_amd import tf_ops
+    rng = np.random.default_rng(limit)
+    dense = rng.uniform(0.0, 0.25, (4000, 3)).astype(np.float32)              # ~270 supports within 0.1 of an interior point
+    sparse = (rng.uniform(0.0, 3.0, (3000, 3)) + np.float32([1.0, 0.0, 0.0])).astype(np.float32)
+    xyz = np.concatenate([dense, sparse])[rng.permutation(7000)].copy()       # dense and sparse queries interleaved inside the waves
+    lens = np.int32([7000])
+    got = tf_ops.tf_batch_neighbors(dev(xyz), dev(xyz), dev(lens), dev(lens), 0.1, limit, exact_shape=False).cpu().numpy()
+    ref, counts, mc = O.radius_neighbors(xyz, xyz, lens, lens, 0.1, limit)
+    assert mc > 128 and (counts < 10).any()
+    np.testing.assert_array_equal(got, ref)
