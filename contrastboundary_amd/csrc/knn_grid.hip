@@ -711,102 +711,122 @@ __device__ __forceinline__ unsigned long long radius_key_lds(int t, int total, i
     return (have && d2 < r2) ? (((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(v.w)) : ~0ull;
 }
 
-template <int G>
+// U queries per group and kernel instance, level by level: every level of the dependent chain (query coordinates -> grid parameters -> the nine row
+// bounds -> the candidates) is requested for all U queries before any of them is waited for.  The kernel is bound by that chain (0.57 of the wave
+// cycles parked on memory at full occupancy, the vector ALU at 0.5): U = 2 halves the round trips per query.
+template <int G, int U>
 __global__ __launch_bounds__(256) void radius_group_kernel(int b, int nq, int ns_total, int limit, float r2, const float* __restrict__ queries,
                                                            const int* __restrict__ q_offset, const CblGrid* __restrict__ grids,
                                                            const int* __restrict__ cell_start, const float4* __restrict__ sorted,
                                                            int* __restrict__ out, int* __restrict__ counts, int* __restrict__ max_count)
 {
-    constexpr int QPW = 64 / G, CAP = 2 * G;
+    constexpr int QPW = 64 / G, CAP = 2 * G, NBF = G >= 64 ? 2 : 4;  // NBF batches of a query's range are requested at once
     using mask_t = unsigned long long;
     using key_t = unsigned long long;
     constexpr key_t NONE = ~0ull;
     __shared__ key_t slots[4 * QPW][CAP];
-    __shared__ int otabs[4 * QPW][12];
+    __shared__ int otabs[4 * QPW][U][12];
     const int lane = threadIdx.x & 63, gl = lane & (G - 1), grp = lane / G;
     key_t* S = slots[(threadIdx.x >> 6) * QPW + grp];
     const int wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6;
-    const int t = wave_global * QPW + grp;
-    const bool live = t < nq;
-    const int q = live ? t : nq - 1;
-    const float qx = queries[3 * q], qy = queries[3 * q + 1], qz = queries[3 * q + 2];
-    const int c = cbl_cloud_of(q, q_offset, b);
-    const CblGrid g = grids[c];
-    const int cx = cbl_cell_coord(cbl_u(qx, g.ox, g.inv_cs), g.nx), cy = cbl_cell_coord(cbl_u(qy, g.oy, g.inv_cs), g.ny),
-              cz = cbl_cell_coord(cbl_u(qz, g.oz, g.inv_cs), g.nz);
-    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
     const mask_t below = (1ull << gl) - 1ull, gmask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
+    int q[U]; bool live[U]; float qx[U], qy[U], qz[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int t = (wave_global * QPW + grp) * U + u;
+        live[u] = t < nq; q[u] = live[u] ? t : nq - 1;
+        qx[u] = queries[3 * q[u]]; qy[u] = queries[3 * q[u] + 1]; qz[u] = queries[3 * q[u] + 2];
+    }
     // The block's candidates as ONE virtual range: row r = 3 (dz + 1) + (dy + 1) is a contiguous range [s_r, e_r) of the cell-sorted supports;
-    // lane r of the group fetches its row's two bounds (nine independent pairs of loads instead of nine dependent rounds: the sweep was 0.68 of
-    // its wave cycles parked on memory), the lengths are prefix-summed across the lanes, and position t of the concatenation maps to support
-    // t + off_r with r the last row whose start cum_r is <= t.  Batches of the range are independent loads.
-    int rs = 0, re = 0;
-    if (gl < 9) {
-        const int y = cy + (gl % 3) - 1, z = cz + (gl / 3) - 1;
-        if (live && g.end > g.start && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
-            const int row = g.cell_base + g.nx * (y + g.ny * z);
-            rs = cell_start[row + x0]; re = cell_start[row + x1 + 1];
+    // lane r of the group fetches its row's two bounds (nine independent pairs of loads instead of nine dependent rounds), the lengths are
+    // prefix-summed across the lanes, and position t of the concatenation maps to support t + off_r with r the last row whose start is <= t.
+    int rs[U], re[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int c = cbl_cloud_of(q[u], q_offset, b);
+        const CblGrid g = grids[c];
+        const int cx = cbl_cell_coord(cbl_u(qx[u], g.ox, g.inv_cs), g.nx), cy = cbl_cell_coord(cbl_u(qy[u], g.oy, g.inv_cs), g.ny),
+                  cz = cbl_cell_coord(cbl_u(qz[u], g.oz, g.inv_cs), g.nz);
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+        rs[u] = 0; re[u] = 0;
+        if (gl < 9) {
+            const int y = cy + (gl % 3) - 1, z = cz + (gl / 3) - 1;
+            if (live[u] && g.end > g.start && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
+                const int row = g.cell_base + g.nx * (y + g.ny * z);
+                rs[u] = cell_start[row + x0]; re[u] = cell_start[row + x1 + 1];
+            }
         }
     }
-    // nine (start of the row in the virtual range, offset to the supports) pairs as plain locals
-    int c1, c2, c3, c4, c5, c6, c7, c8, total, o0, o1, o2, o3, o4, o5, o6, o7, o8;
-    {
+    // starts of the rows in the virtual range as plain locals, the offsets in a table of the group in LDS
+    int c1[U], c2[U], c3[U], c4[U], c5[U], c6[U], c7[U], c8[U], total[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        int* otab = otabs[(threadIdx.x >> 6) * QPW + grp][u];
         int acc = 0;
-#define CBL_ROW(r, cnext, orow) { const int sr = __shfl(rs, r, G), er = __shfl(re, r, G); orow = sr - acc; acc += er - sr; cnext = acc; }
-        CBL_ROW(0, c1, o0) CBL_ROW(1, c2, o1) CBL_ROW(2, c3, o2) CBL_ROW(3, c4, o3) CBL_ROW(4, c5, o4) CBL_ROW(5, c6, o5) CBL_ROW(6, c7, o6) CBL_ROW(7, c8, o7)
-        CBL_ROW(8, total, o8)                                        // total: group-uniform
+#define CBL_ROW(r, cnext) { const int sr = __shfl(rs[u], r, G), er = __shfl(re[u], r, G); if (gl == 0) otab[r] = sr - acc; acc += er - sr; cnext = acc; }
+        CBL_ROW(0, c1[u]) CBL_ROW(1, c2[u]) CBL_ROW(2, c3[u]) CBL_ROW(3, c4[u]) CBL_ROW(4, c5[u]) CBL_ROW(5, c6[u]) CBL_ROW(6, c7[u]) CBL_ROW(7, c8[u])
+        CBL_ROW(8, total[u])                                         // total: group-uniform
 #undef CBL_ROW
     }
-    int* otab = otabs[(threadIdx.x >> 6) * QPW + grp];
-    if (gl == 0) { otab[0] = o0; otab[1] = o1; otab[2] = o2; otab[3] = o3; otab[4] = o4; otab[5] = o5; otab[6] = o6; otab[7] = o7; otab[8] = o8; }
-#define CBL_KEY(t) radius_key_lds((t), total, c1, c2, c3, c4, c5, c6, c7, c8, otab, qx, qy, qz, r2, sorted)
-    int inside = 0;
-    for (int t0 = 0; __any(t0 < total); t0 += 2 * G) {               // two batches per trip: their loads are in flight together
-        const key_t k0 = CBL_KEY(t0 + gl), k1 = CBL_KEY(t0 + G + gl);
+#define CBL_KEY(u, t) radius_key_lds((t), total[u], c1[u], c2[u], c3[u], c4[u], c5[u], c6[u], c7[u], c8[u], otabs[(threadIdx.x >> 6) * QPW + grp][u], qx[u], qy[u], qz[u], r2, sorted)
+    key_t first[U][NBF];
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const key_t key = u ? k1 : k0;
+    for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int k = 0; k < NBF; k++) first[u][k] = CBL_KEY(u, k * G + gl);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        int inside = 0;
+        auto collect = [&](key_t key) __attribute__((always_inline)) {
             const bool in_ball = key != NONE;
             const mask_t gm = (__ballot(in_ball) >> (grp * G)) & gmask;
             const int slot = inside + __popcll(gm & below);
             if (in_ball && slot < CAP) S[slot] = key;
             inside += __popcll(gm);
-        }
-    }
-    const bool over = inside > CAP;                                  // group-uniform
-    if (!over) {
-        const int n = inside;
-        const key_t ka = gl < n ? S[gl] : NONE, kb = gl + G < n ? S[gl + G] : NONE;
-        int ra = 0, rb = 0;
-        for (int k = 0; __any(k < n); k++) {
-            const key_t kk = S[k < n ? k : 0];
-            const bool on = k < n;
-            ra += (on && kk < ka) ? 1 : 0; rb += (on && kk < kb) ? 1 : 0;
-        }
-        if (live) {
-            if (ka != NONE && ra < limit) out[(size_t)q * limit + ra] = (int)(unsigned)ka;
-            if (kb != NONE && rb < limit) out[(size_t)q * limit + rb] = (int)(unsigned)kb;
-            if (gl >= n && gl < limit) out[(size_t)q * limit + gl] = ns_total;          // pad with supports.size(), neighbors.cpp:328 (limit <= G)
-        }
-    }
-    if (__any(over)) {
-        // more supports in the ball than the list holds: column p = the smallest key above column p - 1's, one sweep per column
-        key_t prev = 0; bool first = true;
-        for (int col = 0; col < limit; col++) {
-            key_t best = NONE;
-            for (int t0 = 0; __any(over && t0 < total); t0 += G) {
-                const key_t key = CBL_KEY(t0 + gl);
-                if ((first || key > prev) && key < best) best = key;
+        };
+#pragma unroll
+        for (int k = 0; k < NBF; k++) collect(first[u][k]);
+        for (int t0 = NBF * G; __any(t0 < total[u]); t0 += G) collect(CBL_KEY(u, t0 + gl));
+        const bool over = inside > CAP;                              // group-uniform
+        if (!over) {
+            const int n = inside;
+            const key_t ka = gl < n ? S[gl] : NONE, kb = gl + G < n ? S[gl + G] : NONE;
+            int ra = 0, rb = 0;
+            for (int k = 0; __any(k < n); k += 4) {                 // four broadcast reads in flight per trip (the unused tail of the list holds stale keys: masked)
+                key_t kk[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) kk[j] = S[min(k + j, CAP - 1)];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const bool on = k + j < n;
+                    ra += (on && kk[j] < ka) ? 1 : 0; rb += (on && kk[j] < kb) ? 1 : 0;
+                }
             }
-            best = group_min_u64<G>(best);
-            if (over && live && gl == 0) out[(size_t)q * limit + col] = best == NONE ? ns_total : (int)(unsigned)best;
-            if (best != NONE) { prev = best; first = false; } else { prev = NONE; first = false; }
+            if (live[u]) {
+                if (ka != NONE && ra < limit) out[(size_t)q[u] * limit + ra] = (int)(unsigned)ka;
+                if (kb != NONE && rb < limit) out[(size_t)q[u] * limit + rb] = (int)(unsigned)kb;
+                if (gl >= n && gl < limit) out[(size_t)q[u] * limit + gl] = ns_total;   // pad with supports.size(), neighbors.cpp:328 (limit <= G)
+            }
         }
-    }
-    if (live && gl == 0) {
-        if (counts) counts[q] = inside;
-        // one address for the whole launch: only groups that would raise the maximum touch it (monotone, so a stale read only costs a redundant atomic)
-        if (inside > __hip_atomic_load(max_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_count, inside);
+        if (__any(over)) {
+            // more supports in the ball than the list holds: column p = the smallest key above column p - 1's, one sweep per column
+            key_t prev = 0; bool none_yet = true;
+            for (int col = 0; col < limit; col++) {
+                key_t best = NONE;
+                for (int t0 = 0; __any(over && t0 < total[u]); t0 += G) {
+                    const key_t key = CBL_KEY(u, t0 + gl);
+                    if ((none_yet || key > prev) && key < best) best = key;
+                }
+                best = group_min_u64<G>(best);
+                if (over && live[u] && gl == 0) out[(size_t)q[u] * limit + col] = best == NONE ? ns_total : (int)(unsigned)best;
+                prev = best; none_yet = false;
+            }
+        }
+        if (live[u] && gl == 0) {
+            if (counts) counts[q[u]] = inside;
+            // one address for the whole launch: only groups that would raise the maximum touch it (monotone, so a stale read only costs a redundant atomic)
+            if (inside > __hip_atomic_load(max_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_count, inside);
+        }
     }
 #undef CBL_KEY
 }
@@ -911,8 +931,14 @@ int cbl_radius_launch(int b, int nq, int ns, const float* queries, const float* 
     const long long waves = ((long long)nq + (64 / G) - 1) / (64 / G);
     const dim3 grid(cbl_div_up(waves, 4)), block(256);
     const float r2 = radius * radius;                               // neighbors.cpp:230
-#define CBL_RAD(G_) hipLaunchKernelGGL((radius_group_kernel<G_>), grid, block, 0, st, b, nq, ns, limit, r2, queries, q_offset, w.grids, w.cell_start, w.sorted, out, counts, max_count)
-    if (G == 16) CBL_RAD(16); else if (G == 32) CBL_RAD(32); else CBL_RAD(64);
+    // queries per group and kernel instance: 2 where that still leaves >= 8 rounds of resident waves (200 000 queries: 129 -> 112 us; at 90 000
+    // queries the shorter wave list costs more than the overlapped round trips save: 71 -> 83 us)
+    const int ru = (long long)nq / ((64 / G) * 2) >= 49152 ? 2 : 1;
+    const long long waves_u = ((long long)nq + (64 / G) * ru - 1) / ((64 / G) * ru);
+    const dim3 grid_u(cbl_div_up(waves_u, 4));
+#define CBL_RAD(G_, U_) hipLaunchKernelGGL((radius_group_kernel<G_, U_>), grid_u, block, 0, st, b, nq, ns, limit, r2, queries, q_offset, w.grids, w.cell_start, w.sorted, out, counts, max_count)
+    if (ru == 2) { if (G == 16) CBL_RAD(16, 2); else if (G == 32) CBL_RAD(32, 2); else CBL_RAD(64, 2); }
+    else         { if (G == 16) CBL_RAD(16, 1); else if (G == 32) CBL_RAD(32, 1); else CBL_RAD(64, 1); }
 #undef CBL_RAD
     return cbl_status();
 }
