@@ -986,7 +986,8 @@ CBL_EXPORT int cbl_pt_layer_forward(int n, int K, int C, const float* xyz, const
     PT_DISPATCH(PT_W2)
     hipLaunchKernelGGL(pt_bn_finalize_kernel, dim3(1), dim3(PT_FIN_THREADS), 0, st, (int)gt, 2 * G, ws.part_a, G, 0, G, np, gamma_g, beta_g, eps3[2], momentum3[2],
                        rm[2], rv[2], nb[2], consts + PT_CST_G, 8, G, consts + PT_FS_G);
-#define PT_SOFTMAX(GG, KK) hipLaunchKernelGGL((pt_softmax_kernel<GG, KK>), dim3(gp), dim3(PT_NARROW_BLOCK), 0, st, np, w2, consts, Wb, bb, a)
+    const unsigned gs = cbl_grid_for(np, PT_NARROW_BLOCK, 1 << 16);   // a pair per thread, all in flight (no partial rows here: no cap)
+#define PT_SOFTMAX(GG, KK) hipLaunchKernelGGL((pt_softmax_kernel<GG, KK>), dim3(gs), dim3(PT_NARROW_BLOCK), 0, st, np, w2, consts, Wb, bb, a)
     if (G == 8 && K == 16) { PT_SOFTMAX(8, 16); } else if (G == 8) { PT_SOFTMAX(8, 8); } else if (K == 16) { PT_SOFTMAX(4, 16); } else { PT_SOFTMAX(4, 8); }
 #define PT_AGG(CC, KK) hipLaunchKernelGGL((pt_agg_kernel<CC, KK, false>), dim3(gt), dim3(PT_BLOCK), 0, st, n, order, x_v, idx, p1, W3C, b3C, a, out, (const float*)nullptr, (float*)nullptr)
     PT_DISPATCH(PT_AGG)
