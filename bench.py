@@ -345,7 +345,12 @@ def gather_200k(n=200000, c=64, k=16, reps=10):
             ring[r % 3] = None
             ring[r % 3] = fn()
         us = run(gather)
-        us_fill = run(lambda r: ring[r % 3].fill_(1.0))
+        fills = [torch.empty_like(ring[0]) for _ in range(3)]        # a fill of the same size, measured the same way (three buffers in rotation)
+        for f in fills:
+            f.fill_(0.0)
+        torch.cuda.synchronize()
+        us_fill = run(lambda r: fills[r % 3].fill_(1.0))
+        del fills
     nbytes = 4 * n * k + 12 * n + 12 * n + 4 * n * c + 4 * n * k * (3 + c)
     out_bytes = 4 * n * k * (3 + c)
     pmc = {}
