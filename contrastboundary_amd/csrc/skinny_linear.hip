@@ -240,22 +240,24 @@ __global__ __launch_bounds__(256) void row_linear_wgrad_mfma_kernel(long long ro
 // blockIdx.y = the projection.  (Three Linear layers cost 3 + 3 + 6 launches and two adds: ~130 us of a 500 us layer step at (40960, 64).)
 struct RlTriple { const float* in[3]; const float* w[3]; const float* b[3]; float* out[3]; };
 
+// One wave per SIMD (a workgroup per CU, the whole register file): the 3 C^2 / 64 B operands of a lane stay in registers for the launch, a
+// 16-row tile of x is loaded once for the three projections, the next tile's rows are requested before this tile's MFMAs.  (With blockIdx.y =
+// the projection every wave loaded 64 operands for ~5 tiles of work: 24 us at (40960, 64).)
 template <int C>
-__global__ __launch_bounds__(256) void triple_linear_forward_kernel(long long rows, const float* __restrict__ in, RlTriple t3)
+__global__ __launch_bounds__(256, 1) void triple_linear_forward_kernel(long long rows, const float* __restrict__ in, RlTriple t3)
 {
     constexpr int KC = C / 4, NT = C / 16;
-    const float* __restrict__ W = t3.w[blockIdx.y]; const float* __restrict__ bias = t3.b[blockIdx.y]; float* __restrict__ out = t3.out[blockIdx.y];
     const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
-    float bw[NT][KC];
+    float bw[3][KC][NT], bv[3][NT];                                  // B[k][n] = W_p[n][k], k = KC kq + s
 #pragma unroll
-    for (int t = 0; t < NT; t++)
+    for (int p = 0; p < 3; p++)
 #pragma unroll
-        for (int s2 = 0; s2 < KC; s2++) bw[t][s2] = W[(size_t)(16 * t + row) * C + KC * kq + s2];
-    float bv[NT];
+        for (int t = 0; t < NT; t++) {
 #pragma unroll
-    for (int t = 0; t < NT; t++) bv[t] = bias ? bias[16 * t + row] : 0.f;
-    const long long ntiles = (rows + 15) / 16;
-    const long long stride = (long long)gridDim.x * 4;
+            for (int s2 = 0; s2 < KC; s2++) bw[p][s2][t] = t3.w[p][(size_t)(16 * t + row) * C + KC * kq + s2];
+            bv[p][t] = t3.b[p] ? t3.b[p][16 * t + row] : 0.f;
+        }
+    const long long ntiles = (rows + 15) / 16, stride = (long long)gridDim.x * 4;
     long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     float4 a[KC / 4];
     auto load = [&](long long tl) {
@@ -270,19 +272,23 @@ __global__ __launch_bounds__(256) void triple_linear_forward_kernel(long long ro
 #pragma unroll
         for (int v = 0; v < KC / 4; v++) { av[4 * v] = a[v].x; av[4 * v + 1] = a[v].y; av[4 * v + 2] = a[v].z; av[4 * v + 3] = a[v].w; }
         if (tile + stride < ntiles) load(tile + stride);
-        rl_f32x4 acc[NT];
 #pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = rl_f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < 3; p++) {
+            rl_f32x4 acc[NT];
 #pragma unroll
-        for (int s2 = 0; s2 < KC; s2++)
+            for (int t = 0; t < NT; t++) acc[t] = rl_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bw[t][s2], acc[t], 0, 0, 0);
+            for (int s2 = 0; s2 < KC; s2++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const long long orow = tile * 16 + 4 * kq + r;
-            if (orow < rows) {
+                for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bw[p][s2][t], acc[t], 0, 0, 0);
+            float* __restrict__ out = t3.out[p];
 #pragma unroll
-                for (int t = 0; t < NT; t++) out[orow * C + 16 * t + row] = acc[t][r] + bv[t];
+            for (int r = 0; r < 4; r++) {
+                const long long orow = tile * 16 + 4 * kq + r;
+                if (orow < rows) {
+#pragma unroll
+                    for (int t = 0; t < NT; t++) out[orow * C + 16 * t + row] = acc[t][r] + bv[p][t];
+                }
             }
         }
     }
@@ -529,7 +535,7 @@ CBL_EXPORT int cbl_triple_linear_forward(long long rows, int C, const float* x, 
     RlTriple t3;
     for (int p = 0; p < 3; p++) { t3.in[p] = x; t3.w[p] = weight3[p]; t3.b[p] = bias3 ? bias3[p] : nullptr; t3.out[p] = y3[p]; }
     const long long tiles = (rows + 15) / 16;
-    const dim3 grid((unsigned)min((tiles + 3) / 4, (long long)172), 3), blk(256);      // ~2 workgroups per CU: the 64 B operands of a lane are loaded once per wave
+    const dim3 grid((unsigned)min((tiles + 3) / 4, (long long)256)), blk(256);
     if (C == 64) hipLaunchKernelGGL(triple_linear_forward_kernel<64>, grid, blk, 0, cbl_stream(stream), rows, x, t3);
     else         hipLaunchKernelGGL(triple_linear_forward_kernel<32>, grid, blk, 0, cbl_stream(stream), rows, x, t3);
     return cbl_status();
