@@ -164,10 +164,17 @@ __device__ __forceinline__ void pt_stage_store(float (*T)[PT_ROWF], const PtStag
 // partial row: p0 [3] | p0^2 [3] | p_r [3] | p0[a] p_r[b] [9]   (the last two feed the Linear(3,3) gradient without another pass, pchain_bwd)
 __global__ __launch_bounds__(PT_NARROW_BLOCK) void pt_pchain_kernel(long long npairs, CblFastDiv dvK, const float* __restrict__ xyz, const int* __restrict__ idx,
                                                                     const float* __restrict__ Wp, const float* __restrict__ bp, float* __restrict__ p_r,
-                                                                    float* __restrict__ p0, float* __restrict__ partial)
+                                                                    float* __restrict__ p0, float* __restrict__ partial, const float* __restrict__ cst_eval,
+                                                                    float* __restrict__ p1)
 {
+    // cst_eval (evaluation mode: BN_p's constants are known before the pass): p1 = ReLU(BN_p(p0)) is written here and no statistics pass follows
     __shared__ float red[PT_NARROW_BLOCK / 64][18];
     float w[9], b[3], acc[18];
+    float esc[3] = {0.f, 0.f, 0.f}, esh[3] = {0.f, 0.f, 0.f};
+    if (cst_eval) {
+#pragma unroll
+        for (int t = 0; t < 3; t++) { esc[t] = cst_eval[PT_CST_P + t]; esh[t] = cst_eval[PT_CST_P + 4 + t]; }
+    }
 #pragma unroll
     for (int t = 0; t < 9; t++) w[t] = Wp[t];
 #pragma unroll
@@ -184,6 +191,10 @@ __global__ __launch_bounds__(PT_NARROW_BLOCK) void pt_pchain_kernel(long long np
         for (int a = 0; a < 3; a++) q[a] = fmaf(w[3 * a + 2], r[2], fmaf(w[3 * a + 1], r[1], fmaf(w[3 * a], r[0], b[a])));
 #pragma unroll
         for (int t = 0; t < 3; t++) { p_r[3 * p + t] = r[t]; p0[3 * p + t] = q[t]; acc[t] += q[t]; acc[3 + t] = fmaf(q[t], q[t], acc[3 + t]); acc[6 + t] += r[t]; }
+        if (cst_eval) {
+#pragma unroll
+            for (int t = 0; t < 3; t++) p1[3 * p + t] = fmaxf(fmaf(q[t], esc[t], esh[t]), 0.f);
+        }
 #pragma unroll
         for (int a = 0; a < 3; a++)
 #pragma unroll
@@ -975,7 +986,7 @@ CBL_EXPORT int cbl_pt_layer_forward(int n, int K, int C, const float* xyz, const
     float* rm[3] = {nullptr, nullptr, nullptr}; float* rv[3] = {nullptr, nullptr, nullptr}; long long* nb[3] = {nullptr, nullptr, nullptr};
     for (int t = 0; t < 3; t++) { if (running_mean3) rm[t] = running_mean3[t]; if (running_var3) rv[t] = running_var3[t]; if (num_batches3) nb[t] = num_batches3[t]; }
 
-    hipLaunchKernelGGL(pt_pchain_kernel, dim3(gp), dim3(PT_NARROW_BLOCK), 0, st, np, cbl_fastdiv_make((unsigned)K), xyz, idx, Wp, bp, p_r, p0, ws.part_b);
+    hipLaunchKernelGGL(pt_pchain_kernel, dim3(gp), dim3(PT_NARROW_BLOCK), 0, st, np, cbl_fastdiv_make((unsigned)K), xyz, idx, Wp, bp, p_r, p0, ws.part_b, (const float*)nullptr, (float*)nullptr);
     hipLaunchKernelGGL(pt_bn_finalize_kernel, dim3(2), dim3(PT_FIN_THREADS), 0, st, (int)gp, 18, ws.part_b, 3, 0, 3, np, gamma_p, beta_p, eps3[0], momentum3[0],
                        rm[0], rv[0], nb[0], consts + PT_CST_P, 4, 18, consts + PT_FS_P);
 #define PT_WSTATS(CC, KK) hipLaunchKernelGGL((pt_wstats_kernel<CC, KK>), dim3(gt), dim3(PT_BLOCK), 0, st, n, order, x_q, x_k, idx, p0, consts, W3C, b3C, p1, ws.part_a)
@@ -990,6 +1001,56 @@ CBL_EXPORT int cbl_pt_layer_forward(int n, int K, int C, const float* xyz, const
 #define PT_SOFTMAX(GG, KK) hipLaunchKernelGGL((pt_softmax_kernel<GG, KK>), dim3(gs), dim3(PT_NARROW_BLOCK), 0, st, np, w2, consts, Wb, bb, a)
     if (G == 8 && K == 16) { PT_SOFTMAX(8, 16); } else if (G == 8) { PT_SOFTMAX(8, 8); } else if (K == 16) { PT_SOFTMAX(4, 16); } else { PT_SOFTMAX(4, 8); }
 #define PT_AGG(CC, KK) hipLaunchKernelGGL((pt_agg_kernel<CC, KK, false>), dim3(gt), dim3(PT_BLOCK), 0, st, n, order, x_v, idx, p1, W3C, b3C, a, out, (const float*)nullptr, (float*)nullptr)
+    PT_DISPATCH(PT_AGG)
+    return cbl_status();
+}
+
+namespace {
+// evaluation mode: the three BatchNorms' constants from their running statistics (scale = gamma / sqrt(var + eps), shift = beta - mean scale)
+__global__ __launch_bounds__(128) void pt_eval_consts_kernel(int C, int G, const float* __restrict__ gp, const float* __restrict__ bp, const float* __restrict__ gc,
+                                                             const float* __restrict__ bc, const float* __restrict__ gg, const float* __restrict__ bg,
+                                                             const float* __restrict__ mp, const float* __restrict__ vp, const float* __restrict__ mc,
+                                                             const float* __restrict__ vc, const float* __restrict__ mg, const float* __restrict__ vg,
+                                                             float ep, float ec, float eg, float* __restrict__ cst)
+{
+    const int t = threadIdx.x;
+    auto put = [&](float* base, int stride, int c, float gamma, float beta, float mean, float var, float eps) {
+        const float invstd = (float)(1.0 / sqrt((double)var + (double)eps)), scale = gamma * invstd;
+        base[c] = scale; base[stride + c] = beta - mean * scale; base[2 * stride + c] = mean; base[3 * stride + c] = invstd;
+    };
+    if (t < 3) put(cst + PT_CST_P, 4, t, gp[t], bp[t], mp[t], vp[t], ep);
+    if (t < C) put(cst + PT_CST_C, 64, t, gc[t], bc[t], mc[t], vc[t], ec);
+    if (t < G) put(cst + PT_CST_G, 8, t, gg[t], bg[t], mg[t], vg[t], eg);
+}
+}  // namespace
+
+/* evaluation mode of the same layer (model.eval(): BatchNorm1d normalises with its running statistics, blocks.py:38-40 under nn.Module.eval): no statistics
+ * passes, no buffers touched — p chain, w2, softmax, aggregation; outputs as cbl_pt_layer_forward (w2 / a / p1 are scratch of the caller). */
+CBL_EXPORT int cbl_pt_layer_forward_eval(int n, int K, int C, const float* xyz, const float* x_q, const float* x_k, const float* x_v, const int* idx, const int* order,
+                                         const float* Wp, const float* bp, const float* gamma_p, const float* beta_p, const float* W3C, const float* b3C,
+                                         const float* gamma_c, const float* beta_c, const float* Wa, const float* ba, const float* gamma_g, const float* beta_g,
+                                         const float* Wb, const float* bb, const float* eps3, const float* const* running_mean3, const float* const* running_var3,
+                                         float* p_r, float* p0, float* p1, float* w2, float* a, float* out, float* consts, void* workspace, size_t workspace_bytes,
+                                         void* stream)
+{
+    if (!pt_shape_ok(n, K, C)) return CBL_ERR_UNSUPPORTED;
+    if (!running_mean3 || !running_var3 || !eps3) return CBL_ERR_BAD_ARG;
+    if (!cbl_host_aligned16(x_q) || !cbl_host_aligned16(x_k) || !cbl_host_aligned16(x_v) || !cbl_host_aligned16(w2) || !cbl_host_aligned16(a) ||
+        !cbl_host_aligned16(idx) || !cbl_host_aligned16(consts) || !cbl_host_aligned16(Wa))
+        return CBL_ERR_BAD_ARG;
+    if (workspace_bytes < cbl_pt_layer_workspace_bytes(n, K, C)) return CBL_ERR_WORKSPACE;
+    const PtWs ws = pt_workspace(static_cast<float*>(workspace), n, K, C);
+    hipStream_t st = cbl_stream(stream);
+    const long long np = (long long)n * K;
+    const int G = C / 8;
+    const unsigned gp = pt_pair_grid(np), gt = pt_tile_grid((np + 15) / 16);
+    hipLaunchKernelGGL(pt_eval_consts_kernel, dim3(1), dim3(128), 0, st, C, G, gamma_p, beta_p, gamma_c, beta_c, gamma_g, beta_g, running_mean3[0], running_var3[0],
+                       running_mean3[1], running_var3[1], running_mean3[2], running_var3[2], eps3[0], eps3[1], eps3[2], consts);
+    hipLaunchKernelGGL(pt_pchain_kernel, dim3(gp), dim3(PT_NARROW_BLOCK), 0, st, np, cbl_fastdiv_make((unsigned)K), xyz, idx, Wp, bp, p_r, p0, ws.part_b,
+                       (const float*)consts, p1);
+    PT_DISPATCH(PT_W2)
+    const unsigned gs = cbl_grid_for(np, PT_NARROW_BLOCK, 1 << 16);
+    if (G == 8 && K == 16) { PT_SOFTMAX(8, 16); } else if (G == 8) { PT_SOFTMAX(8, 8); } else if (K == 16) { PT_SOFTMAX(4, 16); } else { PT_SOFTMAX(4, 8); }
     PT_DISPATCH(PT_AGG)
     return cbl_status();
 }

@@ -25,8 +25,11 @@ def _bn_ok(bn):
 
 
 def supported(layer, x):
+    """training mode (forward + backward), or evaluation mode under torch.no_grad() (the reference's test loop, tool/test.py:217-240: running statistics,
+    no backward pass); evaluation WITH gradients takes the other paths"""
     C = layer.out_planes
-    return (layer.training and x.is_cuda and x.dtype == torch.float32 and layer.mid_planes == C and layer.share_planes == 8 and C in (32, 64)
+    mode_ok = layer.training or not torch.is_grad_enabled()
+    return (mode_ok and x.is_cuda and x.dtype == torch.float32 and layer.mid_planes == C and layer.share_planes == 8 and C in (32, 64)
             and int(layer.nsample) in (8, 16) and 16 <= x.shape[0] <= MAX_POINTS
             and _bn_ok(layer.linear_p[1]) and _bn_ok(layer.linear_w[0]) and _bn_ok(layer.linear_w[3]))
 
@@ -89,9 +92,35 @@ class PTAttention(Function):
         return (None, g_xq, g_xk, g_xv, None, None, *g_params)
 
 
+def _forward_eval(p, x_q, x_k, x_v, idx, bns, params):
+    """evaluation mode: cbl_pt_layer_forward_eval (running statistics, nothing kept for a backward pass)"""
+    from . import pointops
+    n, C = x_q.shape
+    K, G = idx.shape[1], C // 8
+    L = _lib.lib()
+    dev = x_q.device
+    x_q, x_k, x_v, p = x_q.contiguous(), x_k.contiguous(), x_v.contiguous(), p.contiguous()
+    params = [t.contiguous() for t in params]
+    order = pointops.spatial_order(idx)
+    e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    p_r, p0, p1, w2, a, out = e(n, K, 3), e(n, K, 3), e(n, K, 3), e(n, K, G), e(n, K, G), e(n, C)
+    consts = e(L.cbl_pt_layer_consts_floats())
+    ws = _workspace(L.cbl_pt_layer_workspace_bytes(_i(n), _i(K), _i(C)), dev)
+    eps3 = (_f * 3)(*[float(b.eps) for b in bns])
+    arr = lambda ts: (ctypes.c_void_p * 3)(*[t.data_ptr() for t in ts])
+    _lib.check(L.cbl_pt_layer_forward_eval(_i(n), _i(K), _i(C), _P(p), _P(x_q), _P(x_k), _P(x_v), _P(idx), _P(order), *[_P(t) for t in params], eps3,
+                                           arr([b.running_mean for b in bns]), arr([b.running_var for b in bns]),
+                                           _P(p_r), _P(p0), _P(p1), _P(w2), _P(a), _P(out), _P(consts), _P(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(x_q)),
+               "cbl_pt_layer_forward_eval")
+    return out
+
+
 def attention(layer, p, x_q, x_k, x_v, idx):
     """the fused part of `layer` (a blocks.PointTransformerLayer) on its q / k / v projections"""
     lp, lw = layer.linear_p, layer.linear_w
     bns = (lp[1], lw[0], lw[3])
+    if not layer.training:
+        return _forward_eval(p, x_q, x_k, x_v, idx, bns, [lp[0].weight, lp[0].bias, lp[1].weight, lp[1].bias, lp[3].weight, lp[3].bias, lw[0].weight, lw[0].bias,
+                                                          lw[2].weight, lw[2].bias, lw[3].weight, lw[3].bias, lw[5].weight, lw[5].bias])
     return PTAttention.apply(p, x_q, x_k, x_v, idx, bns, lp[0].weight, lp[0].bias, lp[1].weight, lp[1].bias, lp[3].weight, lp[3].bias,
                              lw[0].weight, lw[0].bias, lw[2].weight, lw[2].bias, lw[3].weight, lw[3].bias, lw[5].weight, lw[5].bias)

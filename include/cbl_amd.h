@@ -514,6 +514,14 @@ int cbl_pt_layer_forward(int n, int K, int C, const float* xyz, const float* x_q
                          const float* Wb, const float* bb, const float* eps3, const float* momentum3, float* const* running_mean3,
                          float* const* running_var3, long long* const* num_batches3, float* p_r, float* p0, float* p1, float* w2, float* a, float* out,
                          float* consts, void* workspace, size_t workspace_bytes, void* stream);
+/* the layer in evaluation mode (nn.Module.eval(): the three BatchNorm1d normalise with their running statistics): no statistics passes, no buffer is
+ * touched.  eps3: HOST array of 3 floats; running_mean3 / running_var3: HOST arrays of 3 device pointers (BN_p, BN_c, BN_g).  Scratch as the training entry. */
+int cbl_pt_layer_forward_eval(int n, int K, int C, const float* xyz, const float* x_q, const float* x_k, const float* x_v, const int* idx, const int* order,
+                              const float* Wp, const float* bp, const float* gamma_p, const float* beta_p, const float* W3C, const float* b3C,
+                              const float* gamma_c, const float* beta_c, const float* Wa, const float* ba, const float* gamma_g, const float* beta_g,
+                              const float* Wb, const float* bb, const float* eps3, const float* const* running_mean3, const float* const* running_var3,
+                              float* p_r, float* p0, float* p1, float* w2, float* a, float* out, float* consts, void* workspace, size_t workspace_bytes,
+                              void* stream);
 int cbl_pt_layer_backward(int n, int K, int C, const float* x_q, const float* x_k, const float* x_v, const int* idx, const int* order,
                           const int* inv_start, const int* inv_src, const float* gamma_p, const float* W3C, const float* b3C, const float* gamma_c,
                           const float* Wa, const float* gamma_g, const float* Wb, const float* p_r, const float* p0, const float* p1, const float* w2,

@@ -112,3 +112,26 @@ def test_full_resolution_stage_against_the_unfused_layer_and_deterministic(n, K,
     assert torch.equal(y1, y3) and torch.equal(gx1, gx3)
     for pa, pc in zip(gp1, gp3):
         assert torch.equal(pa, pc)
+
+
+@pytest.mark.parametrize("n,K,C", [(40960, 16, 64), (9001, 8, 32)])
+def test_evaluation_mode_uses_the_running_statistics(n, K, C):
+    """model.eval() under torch.no_grad(): cbl_pt_layer_forward_eval against the layer on the separate kernels in evaluation mode (torch's eval BatchNorm1d),
+    after a few training passes have moved the running statistics away from their initial values; the buffers are not touched"""
+    from contrastboundary_amd import pt_layer, synthetic as S
+    xyz = torch.from_numpy(S.s_room(n, seed=5)[0]).cuda(); o = torch.tensor([n], dtype=torch.int32, device="cuda")
+    fused = layers(C, K, 11)
+    torch.manual_seed(3)
+    x = torch.randn(n, C, device="cuda")
+    for _ in range(3):
+        fused([xyz, x * (1.0 + 0.1 * _), o])                          # training passes: running statistics move
+    plain = copy.deepcopy(fused); plain.fused = False
+    fused.eval(); plain.eval()
+    before = [b.clone() for b in fused.buffers()]
+    with torch.no_grad():
+        assert pt_layer.supported(fused, x)
+        y1 = fused([xyz, x, o]); y2 = plain([xyz, x, o])
+    assert rel(y1, y2) < 2e-5 and float((y1 - y2).abs().max()) <= 1e-4 * (float(y2.abs().max()) + 1.0)
+    for b0, b1 in zip(before, fused.buffers()):
+        assert torch.equal(b0, b1)
+    assert not pt_layer.supported(fused, x)                           # evaluation WITH gradients enabled: the other paths
