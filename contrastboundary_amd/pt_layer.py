@@ -1,9 +1,10 @@
 """PointTransformerLayer's vector attention as one pass structure (csrc/pt_layer.hip, /root/reference/pytorch/model/blocks.py:34-44):
 everything of the layer behind its q / k / v Linear layers — linear_p, the BatchNorm / Linear stack linear_w, the softmax over K and the
 aggregation — as ONE autograd Function over the layer's own parameter tensors, for the two full-resolution shapes (C = 32 | 64 with
-share_planes = 8, K = 8 | 16) in training mode.  Five forward and six backward passes over the (point, neighbour) pairs, nothing of shape
-(n, K, C) stored, no atomics (the x_k / x_v gradients are gathers over the transposed neighbour table), run-to-run deterministic.
-`supported()` says when; other shapes and evaluation take attention.py's kernels."""
+share_planes = 8, K = 8 | 16).  Training mode: five forward and six backward passes over the (point, neighbour) pairs, nothing of shape
+(n, K, C) stored, no atomics (the x_k / x_v gradients are gathers over the transposed neighbour table), run-to-run deterministic.  Evaluation mode
+under torch.no_grad(): cbl_pt_layer_forward_eval (running statistics, no statistics passes).  `supported()` says when; other shapes, and evaluation
+with gradients enabled, take attention.py's kernels."""
 import ctypes
 
 import torch
