@@ -61,13 +61,28 @@ __global__ __launch_bounds__(256) void contrast_pairs_kernel(unsigned m, int nsa
     const int lane = threadIdx.x & 63;
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform values in scalar registers: scalar loads, uniform branches
     const unsigned nwg = (m + 3) >> 2;                              // 4 points per workgroup
-    for (unsigned v = blockIdx.x; v < 8 * cbl_xcd_per(nwg); v += gridDim.x) {
-        const unsigned r = cbl_xcd_slot(v, nwg) * 4 + wave;
-        if (r >= m) continue;
-        const int i = order ? order[r] : (int)r;
+    // A point is three dependent round trips (sequence slot -> point id -> its neighbour ids -> their labels and rows) in front of ~300 clocks of
+    // arithmetic; the first two are prefetched: the point id two trips ahead, its neighbour ids one trip ahead (values only: nothing branches on
+    // them before their own trip).  Measured and not kept: labels (one trip ahead) deciding whether a point's rows are requested at all (39 us
+    // against 35), labels and rows one trip ahead (38 us): both cost the fifth wave per SIMD, and the waves cover each other's round trips
+    // better than a wave covers its own.
+    const unsigned vend = 8 * cbl_xcd_per(nwg), vstep = gridDim.x;
+    const bool colr = lane < ns;
+    auto point_of = [&](unsigned v) -> int {
+        const unsigned r = (v < vend ? cbl_xcd_slot(v, nwg) : 0u) * 4 + wave;
+        const bool ok = v < vend && r < m;
+        const int pt = order ? order[ok ? r : 0u] : (int)r;
+        return __builtin_amdgcn_readfirstlane(ok ? pt : -1);
+    };
+    auto ids_of = [&](int pt) -> int { return nidx[(size_t)(pt < 0 ? 0 : pt) * nsample + 1 + (colr ? lane : 0)]; };
+    int iB = point_of(blockIdx.x);
+    int rawB = ids_of(iB);
+    int iA = point_of(blockIdx.x + vstep);
+    for (unsigned v = blockIdx.x; v < vend; v += vstep) {
+        const int i = __builtin_amdgcn_readfirstlane(iB), raw = rawB;
+        iB = iA; rawB = ids_of(iB); iA = point_of(v + 2 * vstep);
+        if (i < 0) continue;
         // ---- mining, lane = neighbour column
-        const bool colr = lane < ns;
-        const int raw = nidx[(size_t)i * nsample + 1 + (colr ? lane : 0)];
         const bool real = raw >= 0 && raw < n_valid;
         const int nbr_row = real ? raw : 0;
         // the neighbours' rows are requested HERE, together with their labels (both need nothing but the ids): whether the point has a loss at all is

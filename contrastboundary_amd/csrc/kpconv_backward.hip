@@ -35,6 +35,8 @@ __global__ __launch_bounds__(KB_NB) void kpconv_bwd_csr_kernel(unsigned n0, int 
                                                                float* __restrict__ gf, float* __restrict__ partial)
 {
     __shared__ float red[KB_NB / 64][16][64];                        // grad_kw of the four waves: [wave][kernel point][channel of the chunk]
+    __shared__ float4 kw_lds[16][16];                                // kernel weights of the chunk: [kernel point][channel quad]
+    __shared__ float4 pairs_lds[KB_NB / 64][64];                     // per wave: (query point id, offset of the target from it) of the 64 pairs in hand
     const int lane = threadIdx.x & 63;
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kp = lane & 15;             // A row / kernel point; also B / D column j
@@ -46,15 +48,15 @@ __global__ __launch_bounds__(KB_NB) void kpconv_bwd_csr_kernel(unsigned n0, int 
     for (int c0 = 0; c0 < C; c0 += 64) {
         const bool cok = c0 + 4 * kp < C;
         const int cb = cok ? c0 + 4 * kp : c0;                       // lanes beyond the last channel read the chunk's first four and write nothing
-        // kernel weights of this lane's accumulator elements: tile t, row r <-> kernel point 4*kq + r, channel cb + t
-        float kwr[4][4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int row = kq * 4 + r;
-            const float4 kv = *reinterpret_cast<const float4*>(kw + (size_t)(row < KP ? row : 0) * C + cb);
-            const bool on = row < KP && cok;
-            kwr[0][r] = on ? kv.x : 0.f; kwr[1][r] = on ? kv.y : 0.f; kwr[2][r] = on ? kv.z : 0.f; kwr[3][r] = on ? kv.w : 0.f;
+        // kernel weights of a lane's accumulator elements (tile t, row r <-> kernel point 4*kq + r, channel cb + t) wait in LDS for the epilogue
+        // of a target (sixteen registers less: four waves per SIMD), zero where the kernel point or the channel does not exist
+        __syncthreads();
+        {
+            const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+            const bool on = row < KP && c0 + 4 * col < C;
+            kw_lds[row][col] = on ? *reinterpret_cast<const float4*>(kw + (size_t)row * C + c0 + 4 * col) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        __syncthreads();
         f32x4 gk[4];
 #pragma unroll
         for (int t = 0; t < 4; t++) gk[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -95,43 +97,62 @@ __global__ __launch_bounds__(KB_NB) void kpconv_bwd_csr_kernel(unsigned n0, int 
                 const float3 qq = *reinterpret_cast<const float3*>(q + 3 * (size_t)pi);          // one 12-byte load per lane
                 const float rx = xj - qq.x, ry = yj - qq.y, rz = zj - qq.z;                      // neighbour - centre (:681-684)
                 const int cnt = min(64, s1 - eb);
-                // (four steps' rows requested before the first multiply was measured too: 113 registers, three waves per SIMD instead of four,
-                // 59 us instead of 47 — the waves cover each other's round trips better than a wave covers its own)
-#pragma unroll 2
-                for (int st = 0; st < cnt; st += 4) {
-                    const int src = st + kq;                                                     // this lane's pair of the step
-                    const int pit = __shfl(pi, src);
-                    const float dx = __shfl(rx, src) - kx, dy = __shfl(ry, src) - ky, dz = __shfl(rz, src) - kz;
-                    const float4 g = *reinterpret_cast<const float4*>(go + (size_t)pit * C + cb);   // B operand: 16 lanes = one 256 B row segment per pair
-                    const float sq = (dx * dx + dy * dy) + dz * dz;                              // :688
-                    float w = influence ? fmaxf(1.0f - __builtin_amdgcn_sqrtf(sq) * inv_extent, 0.0f) : 1.0f;       // :697 / :693 (as the forward kernel)
-                    if (CLOSEST) {                                                               // argmin over kernel points, first minimum (:705-708)
-                        float bs = kp_ok ? sq : INFINITY; int bi = kp;
+                // one LDS round instead of four lane exchanges per step: lane e parks pair e, the step's lanes read the pair they multiply
+                __builtin_amdgcn_wave_barrier();
+                pairs_lds[wave][lane] = make_float4(__int_as_float(pi), rx, ry, rz);
+                __builtin_amdgcn_wave_barrier();
+                // Sixteen pairs (four MFMA steps) per batch: the four gradient rows of a lane are requested together, behind one round of
+                // lane exchanges, and the weights are computed while they travel.  (One step at a time — exchange, wait, row, wait, multiply —
+                // was a chain of ~1100 clocks per step, four to five per target, at four waves per SIMD: 46 us.)  Steps past the end of the
+                // list re-read its last pair and multiply by zero.
+                for (int sb = 0; sb < cnt; sb += 16) {
+                    float4 g[4], pr[4]; float a[4];
 #pragma unroll
-                        for (int sft = 8; sft >= 1; sft >>= 1) {
-                            const float os = __shfl_xor(bs, sft, 16); const int oi = __shfl_xor(bi, sft, 16);
-                            if (os < bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
+                    for (int u = 0; u < 4; u++) pr[u] = pairs_lds[wave][min(sb + 4 * u + kq, cnt - 1)];    // this lane's pair of step u
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        g[u] = *reinterpret_cast<const float4*>(go + (size_t)((unsigned)__float_as_int(pr[u].x) * (unsigned)C + (unsigned)cb));   // B operand: 16 lanes = one 256 B row segment per pair (32-bit element index: n C < 2^32 is checked by the launcher)
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int src = sb + 4 * u + kq;
+                        const float dx = pr[u].y - kx, dy = pr[u].z - ky, dz = pr[u].w - kz;
+                        const float sq = (dx * dx + dy * dy) + dz * dz;                          // :688
+                        float w = influence ? fmaxf(1.0f - __builtin_amdgcn_sqrtf(sq) * inv_extent, 0.0f) : 1.0f;       // :697 / :693 (as the forward kernel)
+                        if (CLOSEST) {                                                           // argmin over kernel points, first minimum (:705-708)
+                            float bs = kp_ok ? sq : INFINITY; int bi = kp;
+#pragma unroll
+                            for (int sft = 8; sft >= 1; sft >>= 1) {
+                                const float os = __shfl_xor(bs, sft, 16); const int oi = __shfl_xor(bi, sft, 16);
+                                if (os < bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
+                            }
+                            w = (bi != kp) ? 0.f : w;
                         }
-                        w = (bi != kp) ? 0.f : w;
+                        a[u] = (kp_ok && src < cnt) ? w : 0.f;                                   // pairs past the end of the list contribute nothing
                     }
-                    const float a = (kp_ok && src < cnt) ? w : 0.f;                             // pairs past the end of the list contribute nothing
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, g.x, acc[0], 0, 0, 0);      // S += W^T G
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, g.y, acc[1], 0, 0, 0);
-                    acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, g.z, acc[2], 0, 0, 0);
-                    acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, g.w, acc[3], 0, 0, 0);
+                    // every step is multiplied, also one past the end of the list (zero weights): a branch around the matrix instructions makes the
+                    // compiler carry the sixteen accumulators through vector registers (32 moves per step)
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], g[u].x, acc[0], 0, 0, 0);          // S += W^T G
+                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], g[u].y, acc[1], 0, 0, 0);
+                        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], g[u].z, acc[2], 0, 0, 0);
+                        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], g[u].w, acc[3], 0, 0, 0);
+                    }
                 }
             }
             // the two contractions of S, once per target: tile t, row r of this lane <-> kernel point 4*kq + r, channel cb + t
             if (GF) {
-                float res[4];
+                float res[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float4 kv = kw_lds[kq * 4 + r][kp];
+                    res[0] = fmaf(kv.x, acc[0][r], res[0]); res[1] = fmaf(kv.y, acc[1][r], res[1]);
+                    res[2] = fmaf(kv.z, acc[2][r], res[2]); res[3] = fmaf(kv.w, acc[3][r], res[3]);
+                }
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
-                    float part = 0.f;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) part = fmaf(kwr[t][r], acc[t][r], part);
-                    part += __shfl_xor(part, 16);
-                    part += __shfl_xor(part, 32);
-                    res[t] = part;
+                    res[t] += __shfl_xor(res[t], 16);
+                    res[t] += __shfl_xor(res[t], 32);
                 }
                 if (lane < 16 && cok) *reinterpret_cast<float4*>(gf + (size_t)j * C + cb) = make_float4(res[0], res[1], res[2], res[3]);
             }
@@ -230,6 +251,7 @@ CBL_EXPORT int cbl_kpconv_backward_csr(int n, int n0, int K, int C, int KP, cons
     if (C % 4 || !cbl_host_aligned16(features) || !cbl_host_aligned16(grad_out) || !cbl_host_aligned16(kernel_weights) ||
         (grad_features && !cbl_host_aligned16(grad_features))) return CBL_ERR_UNSUPPORTED;
     if (!grad_features && !grad_kernel_weights) return CBL_OK;
+    if ((unsigned long long)n * (unsigned long long)C >= (1ull << 32)) return CBL_ERR_UNSUPPORTED;     // 32-bit element index of a gradient row
     hipStream_t st = cbl_stream(stream);
     unsigned g = kb_grid(n0);
     float* partial = reinterpret_cast<float*>(workspace);

@@ -418,11 +418,14 @@ class Pipeline:
     are chosen so that they have queues of their own (concurrent_streams).  Graphs do not share a memory pool: they run concurrently."""
 
     SLOTS = 2
-    STREAMS = ("search", "tables", "rest", "side")
+    LAYOUT = "tables"                                               # which of the layouts below; CBL_PIPELINE_LAYOUT / CBL_PIPELINE_SLOTS override (experiments)
 
-    def __init__(self, sched):
+    def __init__(self, sched, layout=None, slots=None):
+        import os
         assert sched.hints, "the pipeline is built on the one-search-per-geometry schedule"
         self.sched = sched
+        self.layout = layout or os.environ.get("CBL_PIPELINE_LAYOUT", self.LAYOUT)
+        self.SLOTS = int(slots or os.environ.get("CBL_PIPELINE_SLOTS", self.SLOTS))
         names = [st[0] for st in sched.stage_list]
         ix = lambda pred: [i for i, nm in enumerate(names) if pred(nm)]
         search = ix(lambda nm: "knnquery" in nm)                    # the block's search, then the CBL head's request (cache hit)
@@ -431,19 +434,42 @@ class Pipeline:
         cbl = [i for i in ix(lambda nm: nm.startswith("cbl_")) if i not in search and i not in t36]
         block = [i for i in range(len(names)) if i not in search + t16 + t36 + cbl]
         bwd = lambda i: names[i].endswith("_bwd")
-        # (name, stream, stages, events waited for, event recorded behind it) in issue order
-        segs = [("search", "search", search, (), "found"),
-                ("t16", "tables", t16, ("found",), "t16"),
-                ("fwd", "rest", [i for i in block if not bwd(i)], ("found",), None),
-                ("cblfwd", "side", [i for i in cbl if not bwd(i)], ("found",), None),
-                ("t36", "tables", t36, ("found",), "t36"),
-                ("bwd", "rest", [i for i in block if bwd(i)], ("t16",) if t16 else (), None),
-                ("cblbwd", "side", [i for i in cbl if bwd(i)], ("t36",) if t36 else (), None)]
+        fwd_b, bwd_b = [i for i in block if not bwd(i)], [i for i in block if bwd(i)]
+        fwd_c, bwd_c = [i for i in cbl if not bwd(i)], [i for i in cbl if bwd(i)]
+        # (name, stream, stages in issue order, events waited for, event recorded behind it) in issue order
+        if self.layout == "tables":
+            self.STREAMS = ("search", "tables", "rest", "side")
+            segs = [("search", "search", search, (), "found"),
+                    ("t16", "tables", t16, ("found",), "t16"),
+                    ("fwd", "rest", fwd_b, ("found",), None),
+                    ("cblfwd", "side", fwd_c, ("found",), None),
+                    ("t36", "tables", t36, ("found",), "t36"),
+                    ("bwd", "rest", bwd_b, ("t16",) if t16 else (), None),
+                    ("cblbwd", "side", bwd_c, ("t36",) if t36 else (), None)]
+        elif self.layout == "split":
+            # the block's backward on a stream of its own behind its table: the backward kernels of step i run beside the forward kernels of
+            # step i+1; every table is built on the stream that consumes it (no table stream, no table events)
+            self.STREAMS = ("search", "fwd", "bwd", "side")
+            segs = [("search", "search", search, (), "found"),
+                    ("fwd", "fwd", fwd_b, ("found",), "fdone"),
+                    ("cbl", "side", fwd_c + t36 + bwd_c, ("found",), None),
+                    ("bwd", "bwd", t16 + bwd_b, ("fdone",), None)]
+        elif self.layout == "split_early":
+            # as "split", the K = 16 table in front of the forward's end (its own graph, behind `found`)
+            self.STREAMS = ("search", "fwd", "bwd", "side")
+            segs = [("search", "search", search, (), "found"),
+                    ("fwd", "fwd", fwd_b, ("found",), "fdone"),
+                    ("cbl", "side", fwd_c + t36 + bwd_c, ("found",), None),
+                    ("t16", "bwd", t16, ("found",), None),
+                    ("bwd", "bwd", bwd_b, ("fdone",), None)]
+        else:
+            raise ValueError("unknown pipeline layout %r" % self.layout)
         self.segments = [sg for sg in segs if sg[2]]
         self.streams = dict(zip(self.STREAMS, concurrent_streams(len(self.STREAMS))))        # streams with hardware queues of their own
         self.states = [{} for _ in range(self.SLOTS)]
         self.graphs = [dict() for _ in range(self.SLOTS)]
-        self.events = [{nm: torch.cuda.Event() for nm in ("found", "t16", "t36")} for _ in range(self.SLOTS)]
+        recorded = sorted({sg[4] for sg in self.segments if sg[4]})
+        self.events = [{nm: torch.cuda.Event() for nm in recorded} for _ in range(self.SLOTS)]
         self.done = [{c: torch.cuda.Event() for c in self.STREAMS[1:]} for _ in range(self.SLOTS)]
         self.count = 0
 
