@@ -177,15 +177,16 @@ def host_dry_run(args, D, world, rank):
 # ------------------------------------------------------------------------------------------------ the step
 class Step:
     """the hot path over one resident scene as bench.py runs it: schedule + its hipGraph(s).
-    pipeline: consecutive steps software-pipelined over three streams, one linear hipGraph per chain (hotpath.Pipeline: the search of step i+1
-    beside the gather / KPConv / backward kernels of step i); steps alternate between two output slots (self.states)."""
+    pipeline: consecutive steps software-pipelined over four streams, one linear hipGraph per chain (hotpath.Pipeline: the search of step i+1
+    beside the forward kernels of step i and the backward kernels of step i-1); steps rotate through the pipeline's output slots (self.states)."""
 
     def __init__(self, scene, k, backward, args, overlap=True, pipeline=False):
         from contrastboundary_amd import hotpath
-        self.stages = (hotpath.stages_pt if getattr(args, "block", "kpconv") == "pt" else hotpath.stages)(scene, k, backward)
+        self.block = getattr(args, "block", "kpconv")
+        self.stages = (hotpath.stages_pt if self.block == "pt" else hotpath.stages)(scene, k, backward)
         self.names = [st[0] for st in self.stages]
         self.hints = () if args.no_nested else hotpath.search_hints(scene)
-        self.sched = hotpath.Schedule(self.stages, overlap=overlap, hints=self.hints)
+        self.sched = hotpath.Schedule(self.stages, overlap=overlap, hints=self.hints, aux_tables=getattr(args, "block", "kpconv") != "pt")
         self.pipeline = bool(pipeline and overlap and self.hints)
         self.pipe = None
         self.states = [{}]
@@ -209,11 +210,13 @@ class Step:
         gc.collect()
         if self.pipeline:
             from contrastboundary_amd import hotpath
-            pipe = hotpath.Pipeline(self.sched)
+            # KPConv block: the backward on a stream of its own, three slots; Point Transformer block: also the K = 16 table behind the forward kernels
+            # (its backward chain is the longest), two slots — both measured against the other layouts in one call (hotpath.Pipeline)
+            pipe = hotpath.Pipeline(self.sched, layout=os.environ.get("CBL_PIPELINE_LAYOUT") or ("split_fwd" if self.block == "pt" else "split"),
+                                    slots=os.environ.get("CBL_PIPELINE_SLOTS") or (2 if self.block == "pt" else 3))
             pipe.capture()
             self.pipe, self.states = pipe, pipe.states
-            self.note = ("hipGraph replay (torch.cuda.CUDAGraph over the C-ABI launches), one linear graph per segment (search | tables | gather, KPConv | their "
-                         "backward | CBL forward | CBL backward) on four streams, consecutive steps software-pipelined over two output slots")
+            self.note = "hipGraph replay (torch.cuda.CUDAGraph over the C-ABI launches), " + pipe.describe()
             return
         cap = torch.cuda.Stream()
         cap.wait_stream(torch.cuda.current_stream())
@@ -418,8 +421,8 @@ def run_gpu(args, D, world, rank, local):
                                 if step.hints else "every search on its own; ") +
                                ("all stages in order on one stream" if args.no_overlap else "the CBL branch on a side stream beside the main branch") +
                                ("; consecutive steps software-pipelined: one stream carries the searches one after the other, everything behind a search runs "
-                                "on three branch streams, so the search of step i+1 (grid build, wide search, tie replay: mostly small latency-bound launches) "
-                                "runs beside the gather / KPConv / backward kernels of step i; steps alternate between two output slots"
+                                "on three branch streams (forward | backward behind its table | CBL), so the search of step i+1 (grid build, wide search, tie "
+                                "replay: mostly small latency-bound launches) runs beside the forward kernels of step i and the backward kernels of step i-1"
                                 if step.pipe is not None else "")},
     }
     if args.no_extra:

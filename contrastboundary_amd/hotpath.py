@@ -207,6 +207,11 @@ def stages_pt(scene, k=16, backward=False):
     if not backward:
         return st
 
+    def transpose(s):
+        # the layer's d x_k / d x_v are gathers over the transposed K = 16 table (pt_layer.PTAttention.backward finds it in the registry)
+        s["transposed"] = pointops.neighbor_transpose(s["idx"], n)
+    st.append(("neighbor_transpose_k%d" % k, transpose, 8 * n * k + 4 * (n + 1), 0.0))
+
     def layer_bwd(s):
         grads = torch.autograd.grad(s["pt_out"], [s["feat_leaf"]] + params, scene.upstream(k)["grad_kpconv"])
         s["grad_feat_pt"], s["grad_params_pt"] = grads[0], grads[1:]
@@ -242,10 +247,14 @@ class Schedule:
 
     events: optional list (one entry per stage) of (start, end) torch.cuda.Event pairs, recorded on the stream the stage runs on."""
 
-    def __init__(self, stage_list, overlap=True, hints=()):
+    def __init__(self, stage_list, overlap=True, hints=(), aux_tables=True):
         """hints: (xyz, nsample, algo) triples for pointops.neighbor_cache.hint — the widest search each geometry sees during the step.
-        With hints the step runs inside a neighbour cache that is dropped at the end of the step: nothing is carried from step to step."""
+        With hints the step runs inside a neighbour cache that is dropped at the end of the step: nothing is carried from step to step.
+        aux_tables: the block's own transposed table on a stream of its own right behind the search (False: in stage order on the main stream —
+        measured faster for the Point Transformer block's one-step-at-a-time graph, 0.68 against 0.705 ms: a third branch in the replayed graph
+        costs that block more than the 40 us of table build it takes off the backward chain)."""
         self.stage_list = stage_list
+        self.aux_tables = aux_tables
         self.hints = tuple(hints)
         self.overlap = overlap
         self.side = torch.cuda.Stream() if overlap else None
@@ -266,7 +275,7 @@ class Schedule:
         """the stream about to run a consumer of a transposed table waits for the stream that builds it — here, on the issuing thread (the
         consumer itself runs on autograd's thread and finds the wait already done: neighbor_state.transpose_lookup)"""
         key = "cbl_idx" if name.startswith("cbl_") else "idx"
-        if name in ("cbl_mining_loss_bwd", "queryandgroup_bwd") and key in state:
+        if name in ("cbl_mining_loss_bwd", "queryandgroup_bwd", "pt_layer_bwd") and key in state:
             pointops.neighbor_transpose(state[key], state[key].shape[0], build=False)
 
     def _launch(self, i, state, events):
@@ -289,7 +298,7 @@ class Schedule:
         A consumer finds its table in neighbor_state's registry and waits for the stream that built it (transpose_lookup)."""
         main = torch.cuda.current_stream()
         names = [st[0] for st in self.stage_list]
-        tr_idx = [i for i, nm in enumerate(names) if "neighbor_transpose" in nm and not nm.startswith("cbl_")]
+        tr_idx = [i for i, nm in enumerate(names) if "neighbor_transpose" in nm and not nm.startswith("cbl_")] if self.aux_tables else []
         side_idx = [i for i, nm in enumerate(names) if nm.startswith("cbl_")]
         main_idx = [i for i in range(len(names)) if i not in side_idx and i not in tr_idx]
         while len(self.aux) < len(tr_idx):
@@ -398,27 +407,39 @@ def concurrent_streams(count, candidates=12, spin_cycles=2_000_000, beside=None)
 
 
 class Pipeline:
-    """Consecutive steps software-pipelined over four HIP streams, every segment of a step replayed from a linear hipGraph of its own:
+    """Consecutive steps software-pipelined over four HIP streams, every segment of a step replayed from a linear hipGraph of its own.  Layout
+    "split" (round 4, the default):
 
         search : nothing but the searches, one step after the other (grid build, wide search, tie replay: a chain of mostly small
                  latency-bound launches, a third of an in-order step, during which most of the GPU idles)          -> event `found`
-        tables : K=16 table (-> `t16`), K=36 table (-> `t36`): latency-bound chains of small kernels               behind `found`
+        fwd    : gather -> KPConv (or the attention layer's forward)                                    behind `found`, -> event `fdone`
+        bwd    : K=16 table -> grouping backward -> KPConv backward (or the layer's backward)                      behind `fdone`
+        side   : CBL mining + loss -> K=36 table -> CBL backward                                                   behind `found`
+
+    so the search of step i+1 runs beside the forward kernels of step i and the backward kernels of step i-1: every table is built on the
+    stream that consumes it (no table stream, no table events), and no stream carries more than ~150 us of kernels per step.  "split_fwd" builds
+    the K=16 table behind the forward kernels on THEIR stream (the Point Transformer block: its backward chain is the longest).  Layout
+    "tables" is round 2's: tables on a stream of their own, forward and backward of the block on one stream (`rest`) —
+
+        tables : K=16 table (-> `t16`), K=36 table (-> `t36`)                                                       behind `found`
         rest   : gather -> KPConv | (after `t16`) grouping backward -> KPConv backward                             behind `found`
         side   : CBL mining + loss | (after `t36`) CBL backward                                                    behind `found`
 
-    so the search of step i+1 runs beside the gather / KPConv / backward kernels of step i, and no chain is longer than ~150 us of kernels.
-    Steps are independent scenes (in bench.py: the same resident scene); a step writes into one of two slots (its neighbour tables, orders,
-    outputs: self.states[slot]) and the search of step i+2 waits for every other stream's part of step i before it overwrites their slot.  A step
-    runs inside its own neighbour cache, which only exists while the step is captured.
+    — which serialises the backward of step i with the forward of step i+1: 0.310 ms per step against 0.297 ("split", three slots) for the
+    KPConv block, 0.68 (one step at a time was faster) against 0.56 ms ("split_fwd") for the Point Transformer block, same box, same kernels.
+    Steps are independent scenes (in bench.py: the same resident scene); a step writes into one of SLOTS slots (its neighbour tables, orders,
+    outputs: self.states[slot]) and the search of step i+SLOTS waits for every other stream's part of step i before it overwrites their slot.  A
+    step runs inside its own neighbour cache, which only exists while the step is captured.
 
     Why linear graphs on real streams and not one graph with branches: a replayed hipGraph is spread over at most four hardware queues by the
     runtime (ROCm 7.2; DEBUG_HIP_FORCE_GRAPH_QUEUES above 4 aborts), and which branch lands on which queue is the runtime's choice — measured on a
     10-step graph, every second step's search was put on the queue of the previous step's backward kernels, which serialised exactly what this
     schedule overlaps (step period alternating 190 / 490 us).  A linear graph stays on the queue of the stream it is launched on, and the streams
-    are chosen so that they have queues of their own (concurrent_streams).  Graphs do not share a memory pool: they run concurrently."""
+    are chosen so that they have queues of their own (concurrent_streams; a fifth stream shares a queue: GPU_MAX_HW_QUEUES=8 made the step
+    slower, 0.37-0.47 ms).  Graphs do not share a memory pool: they run concurrently."""
 
-    SLOTS = 2
-    LAYOUT = "tables"                                               # which of the layouts below; CBL_PIPELINE_LAYOUT / CBL_PIPELINE_SLOTS override (experiments)
+    SLOTS = 3
+    LAYOUT = "split"                                                # which of the layouts below; CBL_PIPELINE_LAYOUT / CBL_PIPELINE_SLOTS override (experiments)
 
     def __init__(self, sched, layout=None, slots=None):
         import os
@@ -462,6 +483,13 @@ class Pipeline:
                     ("cbl", "side", fwd_c + t36 + bwd_c, ("found",), None),
                     ("t16", "bwd", t16, ("found",), None),
                     ("bwd", "bwd", bwd_b, ("fdone",), None)]
+        elif self.layout == "split_fwd":
+            # as "split", the K = 16 table behind the forward kernels on THEIR stream: off the backward chain, which is the longest
+            self.STREAMS = ("search", "fwd", "bwd", "side")
+            segs = [("search", "search", search, (), "found"),
+                    ("fwd", "fwd", fwd_b + t16, ("found",), "fdone"),
+                    ("cbl", "side", fwd_c + t36 + bwd_c, ("found",), None),
+                    ("bwd", "bwd", bwd_b, ("fdone",), None)]
         else:
             raise ValueError("unknown pipeline layout %r" % self.layout)
         self.segments = [sg for sg in segs if sg[2]]
@@ -472,6 +500,12 @@ class Pipeline:
         self.events = [{nm: torch.cuda.Event() for nm in recorded} for _ in range(self.SLOTS)]
         self.done = [{c: torch.cuda.Event() for c in self.STREAMS[1:]} for _ in range(self.SLOTS)]
         self.count = 0
+
+    def describe(self):
+        """the layout in words (bench.py's `config.issue`)"""
+        chains = " | ".join("%s: %s" % (sg[1], "+".join(self.sched.stage_list[i][0] for i in sg[2])) for sg in self.segments)
+        return ("layout '%s': one linear graph per segment on %d streams (stream: stages — %s), consecutive steps software-pipelined over %d output slots"
+                % (self.layout, len(self.STREAMS), chains, self.SLOTS))
 
     def _segment(self, seg, state):
         for i in seg[2]:

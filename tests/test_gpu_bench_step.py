@@ -66,9 +66,10 @@ def check_state(s, o, backward):
 
 @pytest.mark.parametrize("backward,pipeline", [(True, True), (False, True), (True, False), (False, False)])
 def test_the_step_bench_times_against_the_oracles(oracle, backward, pipeline):
-    """pipeline = True: what `python bench.py` runs by default — consecutive steps software-pipelined over three streams (the search of step i+1
-    beside the rest of step i), alternating between two output slots: BOTH slots are checked after an odd number of steps (a step reading a
-    neighbour table, an order or a transposed table that the next search has already overwritten would show up here)."""
+    """pipeline = True: what `python bench.py` runs by default — consecutive steps software-pipelined over four streams (the search of step i+1
+    beside the forward of step i and the backward of step i-1), rotating through the pipeline's output slots: EVERY slot is checked after a
+    number of steps that is not a multiple of the slot count (a step reading a neighbour table, an order or a transposed table that a later
+    search has already overwritten would show up here)."""
     import bench
     from contrastboundary_amd import hotpath
     args = bench.parse([])
@@ -80,7 +81,7 @@ def test_the_step_bench_times_against_the_oracles(oracle, backward, pipeline):
     for _ in range(7):
         step()                                                        # what the timed region calls
     torch.cuda.synchronize()
-    assert len(step.states) == (2 if pipeline else 1)
+    assert len(step.states) == (step.pipe.SLOTS if pipeline else 1)
     for st in step.states:
         check_state(st, oracle, backward)
     if pipeline:
