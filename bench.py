@@ -578,7 +578,8 @@ def workload_legs(args):
         return {"roofline": {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "bytes_per_launch", "launch_us", "flops_per_launch",
                                                   "achieved_TFLOPs", "frac_of_f32_mfma_peak", "layer_bwd_us", "stage_ms") if k in r},
                 "forward_only_ms_per_step": d.get("forward_only", {}).get("ms_per_step"),
-                "pipelined_ms_per_step": d.get("pipelined", {}).get("ms_per_step")}
+                "no_pipeline_ms_per_step": (d.get("no_pipeline") or {}).get("ms_per_step"),
+                "pipelined_ms_per_step": (d.get("pipelined") or {}).get("ms_per_step")}
 
     def pick_convnet(d):
         r = d.get("roofline", {})
@@ -586,7 +587,8 @@ def workload_legs(args):
         for sub in ("adaptive_weight", "adaptive_weight_bwd"):
             if sub in r:
                 keep[sub] = {k: r[sub].get(k) for k in ("frac", "achieved", "launch_us", "bytes_per_launch", "frac_of_f32_vector_peak") if k in r[sub]}
-        return {"roofline": keep}
+        return {"roofline": keep, "no_pipeline_ms_per_step": (d.get("no_pipeline") or {}).get("ms_per_step"),
+                "pipelined_ms_per_step": (d.get("pipelined") or {}).get("ms_per_step")}
 
     steps = str(min(args.steps, 30)); warm = str(min(args.warmup, 5))
     return {"pt_block": leg(["--block", "pt", "--steps", steps, "--warmup", warm], pick_pt),
@@ -617,6 +619,34 @@ def run_convnet(args, D, world, rank, local):
     while time.perf_counter() - t < 0.5:                              # settle: code objects, workspaces, clocks
         step(); torch.cuda.synchronize()
     elapsed = timed_region(step, args.steps, args.warmup, torch.cuda.synchronize, D)
+    in_order = {"ms_per_step": elapsed / args.steps * 1e3, "value": n * args.steps * world / elapsed,
+                "host_issue_ms_per_step": timed_region.issue_s / args.steps * 1e3, "issue": "eager, every stage in order on one stream and one host thread"}
+    pipelined = None
+    if not args.no_pipeline:
+        # the pyramid is input-pipeline work (tf.data workers + prefetch in the reference): a loader thread builds the NEXT step's pyramid through the
+        # native per-layer calls (no interpreter lock held) on a stream of its own, beside the layers of this step.  Every step still builds one pyramid
+        # and runs one model pass; the timed region closes after the loader has issued, and the device has finished, everything (K + 1 pyramids started
+        # inside or before it, K of them consumed: the first was built before t0, the last is waited for).
+        loader = CP.PyramidLoader(scene)
+        p_stages = CP.stages(scene, backward=backward, loader=loader)
+        p_state = {}
+
+        def p_step():
+            CP.run_once(scene, p_state, stage_list=p_stages)
+
+        def p_sync():
+            loader.drain(); torch.cuda.synchronize()
+        for _ in range(3):
+            p_step()
+        p_sync()
+        e_p = timed_region(p_step, args.steps, args.warmup, p_sync, D)
+        pipelined = {"ms_per_step": e_p / args.steps * 1e3, "value": n * args.steps * world / e_p,
+                     "host_issue_ms_per_step": timed_region.issue_s / args.steps * 1e3,
+                     "issue": "eager on two host threads: a loader thread builds the next step's pyramid (one native cbl_pyramid_layer call per layer, stream of "
+                              "its own) beside this step's layers (convnet_path.PyramidLoader)"}
+        loader.close()
+        if e_p < elapsed:
+            elapsed = e_p
     spread = rank_spread(D)
     pyr = state["pyr"]
     sizes = [int(p.shape[0]) for p in pyr["points"]]
@@ -624,12 +654,13 @@ def run_convnet(args, D, world, rank, local):
     out = {"ranks": spread, "metric": "points/sec through radius+grid pyramid, AdaptiveWeight fwd+bwd (5 layers) and TF-side CBL, ConvNet N=%d" % n,
            "value": n * args.steps * world / elapsed, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": elapsed / args.steps * 1e3, "host_issue_ms_per_step": timed_region.issue_s / args.steps * 1e3, "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "no_pipeline": in_order, "pipelined": pipelined,
            "config": {"workload": "ConvNet per-scene work (BASELINE configs C5 / C3): S-room scaled to %d points, dl0=%.2f, density %.0f, %d layers, "
                                   "limits %s; layer sizes %s, neighbour widths %s, AdaptiveWeight widths %s, CBL on a %d-d latent; stages: %s"
                                   % (n, CP.DL0, CP.DENSITY, scene.layers, CP.LIMITS[:scene.layers], sizes, widths, scene.widths, CP.CBL_DIM, " -> ".join(names)),
                       "parallelism": "scene-per-GPU replicas x%d (no data-path collective)" % world,
-                      "issue": "eager (data-dependent layer sizes: one host sync per grid subsampling, like the TF op's dynamic shape)"}}
+                      "issue": ((pipelined["issue"] if pipelined is not None and pipelined["ms_per_step"] <= in_order["ms_per_step"] else in_order["issue"])
+                                + "; data-dependent layer sizes: one host wait per grid subsampling, like the TF op's dynamic shape")}}
     if args.no_extra:
         if rank == 0:
             print(json.dumps(out), flush=True)

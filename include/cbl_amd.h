@@ -611,6 +611,22 @@ int cbl_radius_neighbors_reuse(int b, int nq, int ns, const float* queries, cons
                                float radius, int limit, int* out, int* counts, int* max_count, void* workspace, size_t workspace_bytes,
                                int grid_is_built, void* stream);
 
+/* One layer of the pyramid builder tf_segmentation_inputs_radius (tensorflow/datasets/base.py:795-812; last layer :815-820) as one host call:
+ *   neighbors = N2(points, points, r) cropped to limit; (pool_points, pool_lengths) = N1(points, sample_dl); pools = N2(pool_points, points, r);
+ *   upsamples = N2(points, pool_points, 2 r) — the same kernels in the same order as the separate entries (bit-identical tables), issued by native
+ *   host code: no interpreter between the ~30 launches, and the layer's one data-dependent host wait (the sub-sampled point count, returned in
+ *   *host_pool_points — pinned memory makes the copy asynchronous) inside the call, so a loader thread can run it beside the training thread.
+ *   lengths (b) are per-cloud point counts (the TF side's convention).  sample_dl = 0: last layer, only `neighbors` (the pool / upsample / next-grid
+ *   arguments may be NULL).  grid_ws holds (grid_is_built != 0) or receives the grid of (points, r); next_grid_ws receives the grid of
+ *   (pool_points, 2 r) — the next layer's grid_ws with grid_is_built = 1; both cbl_radius_neighbors_workspace_bytes(b, n) bytes.
+ *   pool_points / pools have capacity n rows; max_counts (3, device) = the three searches' largest neighbourhoods (neighbors, pools, upsamples). */
+size_t cbl_pyramid_layer_workspace_bytes(int b, int n);
+int cbl_pyramid_layer(int b, int n, const float* points, const int* lengths, float radius, float sample_dl, int limit,
+                      void* grid_ws, size_t grid_ws_bytes, int grid_is_built,
+                      int* neighbors, float* pool_points, int* pool_lengths, int* pools, int* upsamples,
+                      void* next_grid_ws, size_t next_grid_ws_bytes, int* max_counts, int* host_pool_points,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
 /* N4  cpp_knn_batch_omp  tensorflow/ops/nearest_neighbors/knn_.cxx:104-135: dense batch (B,N,3) x (B,M,3) -> (B,M,K) int64 LOCAL indices.
  *     = cbl_knnquery on the flattened batch (offset = N, 2N, ...) followed by this conversion of the global int32 rows. */
 int cbl_knn_indices_to_local(int B, int M, int K, int N, const int* idx, long long* out, void* stream);

@@ -62,13 +62,17 @@ def test_knn_batch():
     np.testing.assert_array_equal(got, O.knn_batch(pts, qs, 9))
 
 
-def test_pyramid_builder_c5_shape():
-    """BASELINE config C5 (scaled down for the oracle): 5-layer radius pyramid with the S3DIS limits, every tensor vs the oracle chain"""
+@pytest.mark.parametrize("native", [True, False])
+def test_pyramid_builder_c5_shape(native):
+    """BASELINE config C5 (scaled down for the oracle): 5-layer radius pyramid with the S3DIS limits, every tensor vs the oracle chain;
+    native = one cbl_pyramid_layer call per layer (the default), False = the op-by-op builder"""
     from contrastboundary_amd import tf_ops
     xyz, _ = S.s_room(30000, seed=6, scale=1.5)
     lens = np.int32([14000, 16000])
     limits = [26, 31, 38, 41, 39]                                               # config/s3dis.py:83-87
-    pyr = tf_ops.segmentation_inputs_radius(dev(xyz), dev(lens), 0.04, 5.0, 5, limits)
+    pyr = tf_ops.segmentation_inputs_radius(dev(xyz), dev(lens), 0.04, 5.0, 5, limits, native=native)
+    assert len(pyr["points"]) == len(pyr["neighbors"]) == len(pyr["pools"]) == len(pyr["upsamples"]) == len(pyr["batches_len"]) == 5
+    assert pyr["pools"][4].shape == (0, 1) and pyr["upsamples"][0].shape == (0, 1)
     p, l, r, dl = xyz, lens, 0.1, 0.04
     for dt in range(5):
         np.testing.assert_array_equal(pyr["points"][dt].cpu().numpy().view(np.uint32), p.view(np.uint32))
@@ -82,6 +86,37 @@ def test_pyramid_builder_c5_shape():
         refu, _, mcu = O.radius_neighbors(p, pp, l, pl, 2 * r, limits[dt])
         np.testing.assert_array_equal(pyr["upsamples"][dt + 1].cpu().numpy(), refu[:, :min(mcu, limits[dt])])
         p, l, r, dl = pp, pl, r * 2, dl * 2
+
+
+def test_native_pyramid_equals_the_op_by_op_builder_and_survives_a_loader_thread():
+    """cbl_pyramid_layer issues the kernels of the separate entries in the same order: identical tables, lengths and points (bitwise) at a larger size, one
+    cloud and three; and convnet_path.PyramidLoader (a loader thread + stream building the next pyramid beside the caller) hands out the same pyramid"""
+    from contrastboundary_amd import convnet_path as CP, tf_ops
+    for n, lens in ((120000, [120000]), (90000, [20000, 45000, 25000])):
+        xyz, _ = S.s_room(n, seed=3, scale=max(1.0, float(np.sqrt(n / 12500.0))))
+        p, l = dev(xyz), dev(np.int32(lens))
+        a = tf_ops.segmentation_inputs_radius(p, l, 0.04, 5.0, 5, CP.LIMITS + [CP.LIMITS[-1]], native=True)
+        b = tf_ops.segmentation_inputs_radius(p, l, 0.04, 5.0, 5, CP.LIMITS + [CP.LIMITS[-1]], native=False)
+        for key in ("points", "neighbors", "pools", "upsamples", "batches_len"):
+            assert len(a[key]) == len(b[key])
+            for ta, tb in zip(a[key], b[key]):
+                assert ta.shape == tb.shape and ta.dtype == tb.dtype and ta.is_contiguous(), key
+                assert torch.equal(ta.view(torch.int32) if ta.dtype == torch.float32 else ta, tb.view(torch.int32) if tb.dtype == torch.float32 else tb), key
+    scene = CP.ConvNetScene(60000, seed=1, b=1)
+    want = tf_ops.segmentation_inputs_radius(scene.points, scene.lengths, CP.DL0, CP.DENSITY, scene.layers, CP.LIMITS + [CP.LIMITS[-1]], native=False)
+    loader = CP.PyramidLoader(scene)
+    try:
+        for _ in range(3):                                                      # take() with nothing pending, then two prefetched ones
+            got = loader.take()
+            loader.submit()
+            busy = torch.randn(1 << 22, device="cuda").sin_().sum()             # the caller's own work beside the loader
+            for key in ("points", "neighbors", "pools", "upsamples", "batches_len"):
+                for ta, tb in zip(got[key], want[key]):
+                    assert ta.shape == tb.shape and torch.equal(ta.view(torch.int32) if ta.dtype == torch.float32 else ta,
+                                                                tb.view(torch.int32) if tb.dtype == torch.float32 else tb), key
+            assert torch.isfinite(busy)
+    finally:
+        loader.close()
 
 
 def test_radius_grid_is_built_once_and_reused():
