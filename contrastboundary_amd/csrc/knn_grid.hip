@@ -228,19 +228,25 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(int n, int total, int
 // ---- 2d. the exported cell order made run-to-run deterministic: inside a cell the scatter above places points in the order their
 // atomics happen to retire.  No search result depends on that, and neither does any VALUE downstream — except through rounding where a
 // consumer SUMS in processing order (the fused attention layer's BatchNorm statistics, pt_layer.hip): the same step then differed from run
-// to run in the last bit, which a few SGD steps amplify (measured: 6e-7 on the loss at step 0, 3e-2 at step 3).  Sorting each cell's
-// handful of ids costs one small launch; cells beyond 256 points (degenerate clouds) are left as they are.
-__global__ __launch_bounds__(256) void grid_order_canon_kernel(int cells, const int* __restrict__ cell_start, int* __restrict__ order)
+// to run in the last bit, which a few SGD steps amplify (measured: 6e-7 on the loss at step 0, 3e-2 at step 3).  One thread per point: its
+// rank among the ids of its cell (read from the scattered copies: ~15 independent loads) is its slot.  Cells beyond 1024 points (degenerate
+// clouds) keep the scatter's order.  (A thread per CELL sorting its segment in place was 350 us: a chain of dependent global accesses.)
+__global__ __launch_bounds__(256) void grid_order_canon_kernel(int n, const int* __restrict__ pt_cell, const int* __restrict__ cell_start,
+                                                               const float4* __restrict__ sorted, int* __restrict__ order)
 {
-    for (int c = blockIdx.x * 256 + threadIdx.x; c < cells; c += gridDim.x * 256) {
-        const int s = cell_start[c], e = cell_start[c + 1];
-        if (e - s < 2 || e - s > 256) continue;
-        for (int i = s + 1; i < e; i++) {
-            const int v = order[i];
-            int j = i - 1;
-            while (j >= s && order[j] > v) { order[j + 1] = order[j]; j--; }
-            order[j + 1] = v;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int cell = pt_cell[i];
+        const int s = cell_start[cell], e = cell_start[cell + 1];
+        if (e - s < 2 || e - s > 1024) continue;
+        int rank = 0;
+        for (int j = s; j < e; j += 8) {                          // eight independent loads per trip (entries past the end: the last one again, not counted)
+            int v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = __float_as_int(sorted[min(j + u, e - 1)].w);
+#pragma unroll
+            for (int u = 0; u < 8; u++) rank += (j + u < e && v[u] < i) ? 1 : 0;
         }
+        order[s + rank] = i;
     }
 }
 
@@ -880,7 +886,7 @@ int cbl_grid_build(int b, int n, float pts_per_cell, const float* xyz, const int
     hipLaunchKernelGGL(grid_scatter_kernel, dim3(cbl_grid_for(n, 256)), dim3(256), 2 * sizeof(int) * (size_t)ntiles, st, n, total, ntiles, xyz, w.pt_cell,
                        w.tile_sum, w.cell_local, w.cell_start, w.cell_count, w.sorted, order_out);
     if (order_out)
-        hipLaunchKernelGGL(grid_order_canon_kernel, dim3(cbl_grid_for(total - 1, 256)), dim3(256), 0, st, total - 1, w.cell_start, order_out);
+        hipLaunchKernelGGL(grid_order_canon_kernel, dim3(cbl_grid_for(n, 256)), dim3(256), 0, st, n, w.pt_cell, w.cell_start, w.sorted, order_out);
     return cbl_status();
 }
 
