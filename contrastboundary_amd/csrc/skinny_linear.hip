@@ -8,7 +8,11 @@
 //   weight / bias gradient:    a workgroup stages tiles of rows of x and dy in LDS, every lane owns a few (c_out, c_in) pairs and
 //                              accumulates over the workgroup's rows in registers; the <= 768 workgroup partials are summed in fp64
 //                              by a second small kernel (plain stores: no pre-zeroed outputs, no atomics).
-// fp32 FMA chains in index order; results differ from a GEMM library's by summation order only.
+// Widths outside 16 / 32 / 48 / 64: fp32 FMA chains in index order.  Widths 16 / 32 / 48 / 64 (row_linear_mfma_kernel, row_linear_wgrad_mfma_kernel, the
+// triple_linear kernels): v_mfma_f32_16x16x4_f32 chains — the contraction index is walked four at a time in the MFMA's own order (a row's quarters per
+// lane), the weight gradient sums the rows four per step and the waves' partial tiles through LDS in wave order.  Either way the results differ from a GEMM
+// library's by summation order only (tests: 1e-4 of the largest element).  row_linear_wgrad_mfma_kernel<64,64> keeps 4 x (4096 + 64) floats = 65 KB of LDS
+// (gfx950: 160 KB per CU, two workgroups per CU; the kernel is for this architecture only).
 #include "cbl_common.h"
 #include <stdlib.h>
 

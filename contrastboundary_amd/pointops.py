@@ -118,7 +118,9 @@ def fps_downsample(p, o, stride):
     staged = torch.tensor(new_ends, dtype=torch.int32).pin_memory()
     new_o = staged.to(o.device, non_blocking=True)
     # the samples of an FPS run, sampled again, are that run's prefix where it certified its arg-maxima as unique (cbl_furthestsampling_chain): the
-    # certificate rides on the sampled tensor itself (same object, same version, same number of clouds), so only a genuine chain can use it
+    # certificate rides on the sampled tensor itself (same object, same version, same number of clouds), so only a genuine chain can use it.
+    # (`_version` counts torch's in-place operations only: a caller that rewrites the sampled coordinates through a raw pointer — the C ABI, another
+    # library — must drop the attribute itself; nothing in this package writes a sampled tensor in place.)
     tag = getattr(p, "_fps_certificate", None)
     cert_in = tag[0] if (fps_prefix_chain and tag is not None and tag[1] == p._version and tag[2] is o and tag[3] == o._version) else None
     idx, cert = _furthestsampling_raw(p, o, new_o, max(lens) if lens else 0, run, cert_in=cert_in, want_cert=True)

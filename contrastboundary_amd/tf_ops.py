@@ -28,19 +28,33 @@ def _chk(t, dtype, name, dim):
     return t
 
 
-_offset_cache = {}                    # (data_ptr, version, n, stream) -> (lengths tensor kept alive: its address cannot be reused under the key, offsets)
+_offset_cache = {}                    # id(lengths) -> (lengths tensor kept alive, offsets); only while a pyramid is being built (see below)
+_offset_cache_on = [0]
+
+
+class _offsets_cached:
+    """Inside this block `_offsets` remembers the cumulative sums of the length vectors it has seen: the op-by-op pyramid builder asks for the same five
+    vectors thirty times per scene.  Only there: the vectors a builder handles are written once (by the subsampling that produced them) and read afterwards —
+    outside it a caller may rewrite a lengths buffer in place through the C ABI, which no tensor version counter sees, so nothing is remembered."""
+
+    def __enter__(self):
+        _offset_cache_on[0] += 1
+
+    def __exit__(self, *exc):
+        _offset_cache_on[0] -= 1
+        if not _offset_cache_on[0]:
+            _offset_cache.clear()
 
 
 def _offsets(lengths):
-    """cumulative offsets of per-cloud lengths; the pyramid builder asks for the same five length vectors thirty times per scene"""
-    key = (lengths.data_ptr(), lengths._version, lengths.shape[0], torch.cuda.current_stream(lengths.device).cuda_stream if lengths.is_cuda else 0)
-    hit = _offset_cache.get(key)
-    if hit is not None and hit[0] is lengths:
-        return hit[1]
+    """cumulative offsets of per-cloud lengths"""
+    if not _offset_cache_on[0]:
+        return torch.cumsum(lengths, 0, dtype=torch.int32)
+    hit = _offset_cache.get(id(lengths))
+    if hit is not None and hit[0] is lengths and hit[1] == lengths._version:
+        return hit[2]
     off = torch.cumsum(lengths, 0, dtype=torch.int32)
-    if len(_offset_cache) >= 16:
-        _offset_cache.pop(next(iter(_offset_cache)))
-    _offset_cache[key] = (lengths, off)
+    _offset_cache[id(lengths)] = (lengths, lengths._version, off)
     return off
 
 
@@ -266,6 +280,12 @@ def segmentation_inputs_radius(stacked_points, stacks_lengths, first_subsampling
     native (default): one cbl_pyramid_layer call per layer; False: the same kernels issued op by op from here (identical tables)."""
     if native:
         return _segmentation_inputs_radius_native(stacked_points, stacks_lengths, first_subsampling_dl, density_parameter, num_layers, neighborhood_limits)
+    with _offsets_cached():
+        return _segmentation_inputs_radius_ops(stacked_points, stacks_lengths, first_subsampling_dl, density_parameter, num_layers, neighborhood_limits)
+
+
+def _segmentation_inputs_radius_ops(stacked_points, stacks_lengths, first_subsampling_dl, density_parameter, num_layers, neighborhood_limits):
+    """the pyramid op by op (the same kernels as the native builder, issued from here)"""
     dl = float(first_subsampling_dl)
     r = dl * float(density_parameter) / 2.0                                  # :784-786
     pts, lens = stacked_points, stacks_lengths

@@ -61,14 +61,20 @@ def test_deferred_widths_are_trimmed_like_the_reference_slices():
 
 
 def test_cumulative_offsets_are_cached_per_tensor_and_version():
+    """only while a pyramid is built op by op (a lengths buffer rewritten through the C ABI bumps no version counter, so nothing is remembered
+    outside the builder, whose vectors are written once); inside: per tensor object and version"""
     from contrastboundary_amd import tf_ops
     lens = torch.tensor([3, 4, 5], dtype=torch.int32)
-    o1 = tf_ops._offsets(lens)
-    assert o1.tolist() == [3, 7, 12] and tf_ops._offsets(lens) is o1
-    lens[1] = 6                                                            # in-place edit bumps the version: recomputed
-    assert tf_ops._offsets(lens).tolist() == [3, 9, 14]
-    other = torch.tensor([3, 6, 5], dtype=torch.int32)
-    assert tf_ops._offsets(other) is not tf_ops._offsets(lens)
+    o0 = tf_ops._offsets(lens)
+    assert o0.tolist() == [3, 7, 12] and tf_ops._offsets(lens) is not o0      # outside the builder: recomputed every time
+    with tf_ops._offsets_cached():
+        o1 = tf_ops._offsets(lens)
+        assert o1.tolist() == [3, 7, 12] and tf_ops._offsets(lens) is o1
+        lens[1] = 6                                                        # in-place edit bumps the version: recomputed
+        assert tf_ops._offsets(lens).tolist() == [3, 9, 14]
+        other = torch.tensor([3, 6, 5], dtype=torch.int32)
+        assert tf_ops._offsets(other) is not tf_ops._offsets(lens)
+    assert not tf_ops._offset_cache                                        # dropped with the block
 
 
 def test_capture_flag_is_scoped_to_its_streams():
