@@ -90,3 +90,26 @@ def test_the_step_bench_times_against_the_oracles(oracle, backward, pipeline):
     st_in, ms, how = bench.stage_times(scene, K, backward, args, reps=2)
     assert len(ms) == len(st_in.stages) and all(np.isfinite(ms)) and min(ms) >= 0
     check_state(st_in.state, oracle, backward)
+
+
+@pytest.mark.parametrize("layout,slots", [("tables", 2), ("split", 2), ("split_early", 3), ("split_fwd", 3)])
+def test_every_pipeline_layout_computes_the_step(oracle, layout, slots):
+    """hotpath.Pipeline's stream layouts differ in what runs beside what, never in what is computed: every slot of every layout against the oracles
+    (the default, "split" with three slots, is the pipeline case of the test above)"""
+    import bench
+    from contrastboundary_amd import hotpath
+    args = bench.parse([])
+    scene = hotpath.Scene.synthetic(N, C, seed=0, b=1)
+    step = bench.Step(scene, K, True, args, overlap=True, pipeline=False)
+    bench.settle(step, 0.1)
+    pipe = hotpath.Pipeline(step.sched, layout=layout, slots=slots)
+    pipe.capture()
+    assert pipe.layout == layout and pipe.SLOTS == slots and len(pipe.states) == slots
+    for _ in range(2 * slots + 1):
+        pipe.step()
+    pipe.join()
+    torch.cuda.synchronize()
+    for st in pipe.states:
+        check_state(st, oracle, True)
+    with pytest.raises(ValueError):
+        hotpath.Pipeline(step.sched, layout="no such layout")

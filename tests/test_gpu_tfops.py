@@ -219,3 +219,31 @@ def test_radius_neighbors_in_dense_balls(limit):
     ref, counts, mc = O.radius_neighbors(xyz, xyz, lens, lens, 0.1, limit)
     assert mc > 128 and (counts < 10).any()
     np.testing.assert_array_equal(got, ref)
+
+
+def test_pyramid_layer_rejects_bad_arguments():
+    """cbl_pyramid_layer's argument checks (include/cbl_amd.h): error codes, nothing launched"""
+    import ctypes
+    from contrastboundary_amd import _lib
+    L = _lib.lib()
+    n, b, lim = 5000, 1, 26
+    xyz, _ = S.s_room(n, seed=2)
+    p, l = dev(xyz), dev(np.int32([n]))
+    e = lambda shape, dt=torch.int32: torch.empty(shape, dtype=dt, device="cuda")
+    gws = e(max(int(L.cbl_radius_neighbors_workspace_bytes(ctypes.c_int(b), ctypes.c_int(n))), 1), torch.uint8)
+    ws = e(int(L.cbl_pyramid_layer_workspace_bytes(ctypes.c_int(b), ctypes.c_int(n))), torch.uint8)
+    nb, mc = e((n, lim)), e(3)
+    P, I, F, Z = _lib.ptr, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+    st = _lib.stream_of(p)
+
+    def call(radius=0.1, dl=0.0, limit=lim, ws_bytes=None, nbp=nb):
+        return L.cbl_pyramid_layer(I(b), I(n), P(p), P(l), F(radius), F(dl), I(limit), P(gws), Z(gws.numel()), I(0), P(nbp), P(None), P(None), P(None), P(None),
+                                   P(None), Z(0), P(mc), ctypes.c_void_p(0), P(ws), Z(ws.numel() if ws_bytes is None else ws_bytes), st)
+    assert call() == 0                                                          # last layer: only `neighbors` is needed
+    torch.cuda.synchronize()
+    ref, _, m = O.radius_neighbors(xyz, xyz, np.int32([n]), np.int32([n]), 0.1, lim)
+    np.testing.assert_array_equal(nb.cpu().numpy(), ref)
+    assert int(mc[0]) == m
+    assert call(limit=65) == -1 and call(limit=0) == -1 and call(radius=0.0) == -1 and call(nbp=None) == -1      # CBL_ERR_BAD_ARG
+    assert call(dl=0.08) == -1                                                  # a layer that subsamples needs its pool / upsample / next-grid outputs
+    assert call(ws_bytes=16) == -2                                              # CBL_ERR_WORKSPACE
