@@ -693,8 +693,7 @@ static int queryandgroup_impl(int m, int nsample, int c, int use_xyz, const floa
     const bool lds_ok = use_xyz && c % 4 == 0 && c > 0 && c <= 128 && cbl_host_aligned16(feat) && cbl_host_aligned16(out) && rows < 0xffffffffLL;
     // the ordered form needs whole points as 16-byte aligned pieces: (nsample * (3 + c)) % 4 == 0, at most QG_MAX_ROWS rows
     if (order && !(lds_ok && nsample <= QG_MAX_ROWS && ((long long)nsample * oc) % 4 == 0 && sizeof(float) * 4 * (size_t)nsample * oc <= 65536)) order = nullptr;
-    static const bool qg_pipe = !(getenv("CBL_QG_PIPE") && getenv("CBL_QG_PIPE")[0] == '0');      // experiment switch
-    if (qg_pipe && lds_ok && order && (c == 32 || c == 64) && (nsample == 8 || nsample == 16)) {
+    if (lds_ok && order && (c == 32 || c == 64) && (nsample == 8 || nsample == 16)) {
         // the networks' full-resolution shapes: persistent waves (as many workgroups as are resident at once), pieces = whole points
         const unsigned npieces = (unsigned)m, nwg = (npieces + 3) / 4;
         static int resident[4][16] = {};                                // workgroups resident at once, per kernel and device
@@ -707,8 +706,7 @@ static int queryandgroup_impl(int m, int nsample, int c, int use_xyz, const floa
                 if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
                 resident[slot][dev] = per_cu * cus;
             }
-            static const int qg_pct = getenv("CBL_QG_PCT") ? atoi(getenv("CBL_QG_PCT")) : 100;                 // experiment: share of the resident count
-            const unsigned g = cbl_round_up8((unsigned)((long long)resident[slot][dev] * qg_pct / 100));
+            const unsigned g = cbl_round_up8((unsigned)resident[slot][dev]);
             return g < cbl_round_up8(nwg) ? g : cbl_round_up8(nwg);
         };
 #define CBL_QG_PIPE(C4T, PR, SLOT) hipLaunchKernelGGL((query_group_lds_pipe<C4T, PR>), dim3(grid_of(reinterpret_cast<const void*>(&query_group_lds_pipe<C4T, PR>), SLOT)), dim3(GB), 0, \
