@@ -36,7 +36,7 @@ def lib():
             _build.build()          # raises if hipcc is absent or a source does not compile
         if not os.path.exists(_SO):
             raise CblError("libcbl_amd.so is missing: run `python -m contrastboundary_amd.build`")
-        _lib = ctypes.CDLL(_SO)
+        _lib = ctypes.CDLL(os.environ.get("CBL_AMD_LIB") or _SO)      # CBL_AMD_LIB: another build of the same library (kernel experiments)
         _lib.cbl_version.restype = ctypes.c_char_p
         for name in declared_symbols():
             fn = getattr(_lib, name, None)
