@@ -26,6 +26,31 @@ static inline unsigned cbl_grid_for(long long work_items, int block, int max_blo
     return (unsigned)g;
 }
 
+// Workgroups of `kernel` that are resident at once on the current device (occupancy x compute units), for persistent launches: a kernel that walks its
+// work with a grid-stride loop is launched with at most this many workgroups, so a wave takes several trips (what it fetches a trip ahead gets used) and
+// the dispatcher is not kept busy with thousands of one-trip workgroups while other streams' kernels wait for slots.  Cached per (kernel, LDS, device).
+static inline unsigned cbl_resident_blocks(const void* kernel, int block, size_t dynamic_lds = 0)
+{
+    struct Entry { const void* fn; size_t lds; int dev; unsigned n; };
+    static Entry cache[48] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    for (int i = 0; i < 48 && cache[i].fn; i++)
+        if (cache[i].fn == kernel && cache[i].lds == dynamic_lds && cache[i].dev == dev) return cache[i].n;
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, dynamic_lds) != hipSuccess || per_cu <= 0) per_cu = 4;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const unsigned n = ((unsigned)(per_cu * cus) + 7u) & ~7u;           // a multiple of the 8 XCDs
+    for (int i = 0; i < 48; i++)
+        if (!cache[i].fn) { cache[i].lds = dynamic_lds; cache[i].dev = dev; cache[i].n = n; cache[i].fn = kernel; break; }
+    return n;
+}
+template <class F> static inline unsigned cbl_persistent_grid(unsigned wanted, F kernel, int block, size_t dynamic_lds = 0)
+{
+    const unsigned r = cbl_resident_blocks(reinterpret_cast<const void*>(kernel), block, dynamic_lds);
+    return wanted < r ? wanted : r;
+}
+
 // cloud of a stacked row: first c with row < ends[c]  (knnquery_cuda_kernel.cu:51-62 does this by
 // linear scan; binary search gives the same answer for non-decreasing ends, empty clouds included)
 __device__ __forceinline__ int cbl_cloud_of(int row, const int* __restrict__ ends, int b)

@@ -291,6 +291,7 @@ template <int LR, int UM>
 int launch_pairs(unsigned g, hipStream_t st, int m, int nsample, const float* feat, const int* amax, const int* nidx, const int* order, float inv_t, int n_valid,
                  int flags, float kl_thr, const unsigned char* roles, const unsigned char* sample_valid, float* per_point, int* point_mask, float* coef, float* grad_own)
 {
+    g = coef ? cbl_persistent_grid(g, &contrast_pairs_kernel<LR, UM, true>, 256) : cbl_persistent_grid(g, &contrast_pairs_kernel<LR, UM, false>, 256);
     if (coef) hipLaunchKernelGGL((contrast_pairs_kernel<LR, UM, true>), dim3(g), dim3(256), 0, st, (unsigned)m, nsample, reinterpret_cast<const float4*>(feat), amax, nidx,
                                  order, inv_t, n_valid, flags, kl_thr, roles, sample_valid, per_point, point_mask, coef, reinterpret_cast<float4*>(grad_own));
     else hipLaunchKernelGGL((contrast_pairs_kernel<LR, UM, false>), dim3(g), dim3(256), 0, st, (unsigned)m, nsample, reinterpret_cast<const float4*>(feat), amax, nidx,
@@ -409,7 +410,7 @@ CBL_EXPORT int cbl_contrast_pairs_backward(int m, int nsample, int d, const floa
     hipStream_t st = cbl_stream(stream);
     unsigned g = cbl_round_up8(cbl_div_up(m, 4)); if (g > 256u * 32u) g = 256u * 32u;
     const CblFastDiv dv = cbl_fastdiv_make((unsigned)nsample);
-#define CBL_GATHER_LR(LR_) hipLaunchKernelGGL((contrast_gather_kernel<LR_>), dim3(g), dim3(256), 0, st, (unsigned)m, dv, reinterpret_cast<const float4*>(features), coef, \
+#define CBL_GATHER_LR(LR_) hipLaunchKernelGGL((contrast_gather_kernel<LR_>), dim3(cbl_persistent_grid(g, &contrast_gather_kernel<LR_>, 256)), dim3(256), 0, st, (unsigned)m, dv, reinterpret_cast<const float4*>(features), coef, \
         reinterpret_cast<const float4*>(grad_own), order, inv_start, inv_src, stats, grad_loss, weight, reinterpret_cast<float4*>(grad_features))
     switch (d / 4) {
         case 1: CBL_GATHER_LR(1); break;
