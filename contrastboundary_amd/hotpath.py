@@ -439,7 +439,7 @@ class Pipeline:
     slower, 0.37-0.47 ms).  Graphs do not share a memory pool: they run concurrently."""
 
     SLOTS = 3
-    LAYOUT = "split"                                                # which of the layouts below; CBL_PIPELINE_LAYOUT / CBL_PIPELINE_SLOTS override (experiments)
+    LAYOUT = "split_t36_first"                                            # which of the layouts below; CBL_PIPELINE_LAYOUT / CBL_PIPELINE_SLOTS override (experiments)
 
     def __init__(self, sched, layout=None, slots=None):
         import os
@@ -490,6 +490,43 @@ class Pipeline:
                     ("fwd", "fwd", fwd_b + t16, ("found",), "fdone"),
                     ("cbl", "side", fwd_c + t36 + bwd_c, ("found",), None),
                     ("bwd", "bwd", bwd_b, ("fdone",), None)]
+        elif self.layout == "split_side_late":
+            # as "split", the CBL chain behind the forward kernels (the wave search of the next step then overlaps gather / KPConv only): pins the fast regime too
+            self.STREAMS = ("search", "fwd", "bwd", "side")
+            segs = [("search", "search", search, (), "found"),
+                    ("fwd", "fwd", fwd_b, ("found",), "fdone"),
+                    ("cbl", "side", fwd_c + t36 + bwd_c, ("fdone",), None),
+                    ("bwd", "bwd", t16 + bwd_b, ("fdone",), None)]
+        elif self.layout == "split_t36_first":
+            # The default.  As "split", the K=36 table in front of the CBL forward.  "split" has two stable regimes, 0.270 and 0.290 ms per step, picked by the
+            # timing of the first steps after an idle device (4 : 3 over processes, and from block to block inside one); with the table's small kernels — not the
+            # full-device pair kernel — beside the start of the next wave search and the gather, every run is the fast one (6 of 6, three and four slots).
+            self.STREAMS = ("search", "fwd", "bwd", "side")
+            segs = [("search", "search", search, (), "found"),
+                    ("fwd", "fwd", fwd_b, ("found",), "fdone"),
+                    ("cbl", "side", t36 + fwd_c + bwd_c, ("found",), None),
+                    ("bwd", "bwd", t16 + bwd_b, ("fdone",), None)]
+        elif self.layout == "split_fwd_t36_first":
+            self.STREAMS = ("search", "fwd", "bwd", "side")
+            segs = [("search", "search", search, (), "found"),
+                    ("fwd", "fwd", fwd_b + t16, ("found",), "fdone"),
+                    ("cbl", "side", t36 + fwd_c + bwd_c, ("found",), None),
+                    ("bwd", "bwd", bwd_b, ("fdone",), None)]
+        elif self.layout == "three":
+            # three chains for three hardware queues (a process has four, the default stream keeps one: a kernel trace of "split" showed the search and the
+            # forward chain on ONE queue, one behind the other): search | forward, then the CBL branch | the block's backward behind its table
+            self.STREAMS = ("search", "main", "bwd")
+            segs = [("search", "search", search, (), "found"),
+                    ("fwd", "main", fwd_b, ("found",), "fdone"),
+                    ("cbl", "main", fwd_c + t36 + bwd_c, (), None),
+                    ("bwd", "bwd", t16 + bwd_b, ("fdone",), None)]
+        elif self.layout == "three_cbl_first":
+            self.STREAMS = ("search", "main", "bwd")
+            segs = [("search", "search", search, (), "found"),
+                    ("cblfwd", "main", fwd_c, ("found",), None),
+                    ("fwd", "main", fwd_b, (), "fdone"),
+                    ("cbl", "main", t36 + bwd_c, (), None),
+                    ("bwd", "bwd", t16 + bwd_b, ("fdone",), None)]
         else:
             raise ValueError("unknown pipeline layout %r" % self.layout)
         self.segments = [sg for sg in segs if sg[2]]
@@ -504,8 +541,11 @@ class Pipeline:
     def describe(self):
         """the layout in words (bench.py's `config.issue`)"""
         chains = " | ".join("%s: %s" % (sg[1], "+".join(self.sched.stage_list[i][0] for i in sg[2])) for sg in self.segments)
+        tuned = getattr(self, "tuning", None)
         return ("layout '%s': one linear graph per segment on %d streams (stream: stages — %s), consecutive steps software-pipelined over %d output slots"
-                % (self.layout, len(self.STREAMS), chains, self.SLOTS))
+                % (self.layout, len(self.STREAMS), chains, self.SLOTS)
+                + ("; chains dealt to the hardware queues by a timed trial of the %d assignments (best %.4f, worst %.4f, as created %.4f ms per step)"
+                   % (tuned["assignments_tried"], tuned["best_ms"], tuned["worst_ms"], tuned["as_created_ms"]) if tuned else ""))
 
     def _segment(self, seg, state):
         for i in seg[2]:
@@ -538,6 +578,40 @@ class Pipeline:
         self.count = 0
         for _ in range(2 * self.SLOTS):                             # every graph has run, in pipeline order
             self.step()
+        torch.cuda.synchronize()
+        import os
+        if os.environ.get("CBL_PIPELINE_TUNE", "0") == "1":        # opt-in: the assignment did not decide the regime (see tune)
+            self.tune()
+
+    def tune(self, short=16, long=96, finalists=4):
+        """Re-deal the chains to the streams after capture (a replayed graph runs on the stream it is launched on): every assignment is timed over a few
+        steps, the best few again over more, the fastest kept (~0.4 s).  Written when the same build on the same box ran the step in 0.270 or in 0.291 ms
+        from process to process; the assignment turned out NOT to be the cause — blocks of steps inside one process, same assignment, fall into either regime
+        (tools/pipeline_regimes.py): the pipeline has two stable alignments of its chains, picked by the timing of the first steps after an idle device.  What
+        pins the fast one is in the layout (the CBL chain's table in front of its pair kernel: "split_t36_first").  Kept as an opt-in (CBL_PIPELINE_TUNE=1)."""
+        import itertools
+        import time
+        names = list(self.STREAMS)
+        base = [self.streams[nm] for nm in names]
+
+        def trial(perm, steps):
+            self.streams = {nm: base[i] for nm, i in zip(names, perm)}
+            self.count = 0
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step()
+            self.join()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / steps * 1e3
+        first = {perm: trial(perm, short) for perm in itertools.permutations(range(len(base)))}
+        ranked = sorted(first, key=first.get)
+        second = {perm: min(trial(perm, long), trial(perm, long)) for perm in ranked[:finalists]}
+        best = min(second, key=second.get)
+        self.streams = {nm: base[i] for nm, i in zip(names, best)}
+        self.count = 0
+        self.tuning = {"assignments_tried": len(first), "best_ms": round(second[best], 4), "worst_ms": round(max(first.values()), 4),
+                       "as_created_ms": round(first[tuple(range(len(base)))], 4)}
         torch.cuda.synchronize()
 
     def step(self):
