@@ -372,7 +372,7 @@ def gather_200k(n=200000, c=64, k=16, reps=10):
 
 MAIN_KERNEL = {
     "knnquery_k16": "grid build + knn_grid_wave_kernel (the K=36 search of the same points, which also writes the K=16 rows) + knn_replay_kernel for the tied rows",
-    "queryandgroup": "query_group_lds<16> (aligned 16-row pieces through LDS, cell-order schedule)",
+    "queryandgroup": "query_group_lds_pipe<16, 16> (persistent waves, whole points as aligned pieces through LDS, next rows requested before the stores, cell-order schedule)",
     "kpconv_fwd": "kpconv_fwd_c64_kernel (v_mfma_f32_16x16x4_f32; branch-free, rows prefetched one point ahead)",
     "cbl_knnquery_k36": "cache hit on the wide search",
     "cbl_neighbor_transpose": "nt_prep / nt_count / nt_bin / nt_finish (transposed K=36 table)",
@@ -382,7 +382,7 @@ MAIN_KERNEL = {
     "queryandgroup_bwd": "grouping_bwd_csr_rows_kernel (K4 as a gather)",
     "kpconv_bwd": "kpconv_bwd_csr_kernel<true,true,false> (S = W^T G over the transposed table, v_mfma_f32_16x16x4_f32) + kpconv_gkw_reduce_kernel",
 }
-PMC_KERNEL = {"queryandgroup": "query_group_lds<16>", "kpconv_fwd": "kpconv_fwd_c64_kernel<false, true, true>", "cbl_mining_loss_fwd": "contrast_pairs_kernel<8, 5, true>",
+PMC_KERNEL = {"queryandgroup": "query_group_lds_pipe<16, 16>", "kpconv_fwd": "kpconv_fwd_c64_kernel<false, true, true>", "cbl_mining_loss_fwd": "contrast_pairs_kernel<8, 5, true>",
               "cbl_mining_loss_bwd": "contrast_gather_kernel<8>", "queryandgroup_bwd": "grouping_bwd_csr_rows_kernel", "kpconv_bwd": "kpconv_bwd_csr_kernel<true, true, false>"}
 
 
