@@ -34,6 +34,11 @@ typedef int hipError_t;
 constexpr hipError_t hipSuccess = 0;
 typedef void* hipStream_t;
 static inline hipError_t hipGetLastError() { return hipSuccess; }
+// what cbl_common.h's launch helpers ask the runtime (one "device" with 256 compute units, four workgroups of any kernel resident per unit)
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 0 };
+static inline hipError_t hipGetDevice(int* dev) { *dev = 0; return hipSuccess; }
+static inline hipError_t hipDeviceGetAttribute(int* value, hipDeviceAttribute_t, int) { *value = 256; return hipSuccess; }
+static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* blocks, const void*, int, size_t) { *blocks = 4; return hipSuccess; }
 
 using std::max;
 using std::min;
