@@ -210,10 +210,10 @@ class Step:
         gc.collect()
         if self.pipeline:
             from contrastboundary_amd import hotpath
-            # KPConv block: the backward on a stream of its own, the CBL chain's table first; Point Transformer block: also the K = 16 table behind the forward
-            # kernels (its backward chain is the longest); three slots — all measured against the other layouts in one call (hotpath.Pipeline)
-            pipe = hotpath.Pipeline(self.sched, layout=os.environ.get("CBL_PIPELINE_LAYOUT") or ("split_fwd_t36_first" if self.block == "pt" else "split_t36_first"),
-                                    slots=os.environ.get("CBL_PIPELINE_SLOTS") or 3)
+            # KPConv block: the backward on a stream of its own, the CBL chain's table first, three slots; Point Transformer block (its backward chain is 0.46 of
+            # the 0.55 ms): consecutive steps' backward chains on two streams in turn, four slots — all measured against the other layouts in one call (hotpath.Pipeline)
+            pipe = hotpath.Pipeline(self.sched, layout=os.environ.get("CBL_PIPELINE_LAYOUT") or ("alt_bwd" if self.block == "pt" else "split_t36_first"),
+                                    slots=os.environ.get("CBL_PIPELINE_SLOTS") or (4 if self.block == "pt" else 3))
             pipe.capture()
             self.pipe, self.states = pipe, pipe.states
             self.note = "hipGraph replay (torch.cuda.CUDAGraph over the C-ABI launches), " + pipe.describe()

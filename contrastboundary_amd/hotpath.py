@@ -512,6 +512,15 @@ class Pipeline:
                     ("fwd", "fwd", fwd_b + t16, ("found",), "fdone"),
                     ("cbl", "side", t36 + fwd_c + bwd_c, ("found",), None),
                     ("bwd", "bwd", bwd_b, ("fdone",), None)]
+        elif self.layout == "alt_bwd":
+            # for a block whose backward chain is longer than everything else of the step together (the Point Transformer block: 0.46 of 0.56 ms): consecutive
+            # steps' backward chains on TWO streams in turn ("bwd*": by step parity), so that they overlap; the searches and the CBL chain share the fourth
+            # stream.  PT block 0.549 -> 0.505 ms (four slots; the CBL chain on the forward stream instead: 0.55); the KPConv block LOSES with it (0.348)
+            self.STREAMS = ("search", "fwd", "bwd0", "bwd1")
+            segs = [("search", "search", search, (), "found"),
+                    ("fwd", "fwd", fwd_b + t16, ("found",), "fdone"),
+                    ("cbl", "search", t36 + fwd_c + bwd_c, (), None),
+                    ("bwd", "bwd*", bwd_b, ("fdone",), None)]
         elif self.layout == "three":
             # three chains for three hardware queues (a process has four, the default stream keeps one: a kernel trace of "split" showed the search and the
             # forward chain on ONE queue, one behind the other): search | forward, then the CBL branch | the block's backward behind its table
@@ -563,7 +572,7 @@ class Pipeline:
                     for xyz, nsample, algo in self.sched.hints:
                         nc.hint(xyz, nsample, algo)
                     for seg in self.segments:                       # in dependency order, the device idle between two segments
-                        stream = self.streams[seg[1]]
+                        stream = self.streams[seg[1].replace("*", "0")]
                         torch.cuda.synchronize()
                         if graphed:
                             g = torch.cuda.CUDAGraph()
@@ -625,7 +634,7 @@ class Pipeline:
             S["search"].wait_stream(torch.cuda.current_stream())    # whatever prepared the inputs
         self.count += 1
         for name, sname, _, waits, record in self.segments:
-            stream = S[sname]
+            stream = S[sname.replace("*", str((self.count - 1) & 1))]  # "bwd*": two streams in turn
             for w in waits:
                 stream.wait_event(ev[w])
             with torch.cuda.stream(stream):
