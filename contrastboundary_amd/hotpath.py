@@ -407,26 +407,23 @@ def concurrent_streams(count, candidates=12, spin_cycles=2_000_000, beside=None)
 
 
 class Pipeline:
-    """Consecutive steps software-pipelined over four HIP streams, every segment of a step replayed from a linear hipGraph of its own.  Layout
-    "split" (round 4, the default):
+    """Consecutive steps software-pipelined over four HIP streams, every segment of a step replayed from a linear hipGraph of its own.  Default layout
+    ("split_t36_first", round 4):
 
         search : nothing but the searches, one step after the other (grid build, wide search, tie replay: a chain of mostly small
                  latency-bound launches, a third of an in-order step, during which most of the GPU idles)          -> event `found`
         fwd    : gather -> KPConv (or the attention layer's forward)                                    behind `found`, -> event `fdone`
         bwd    : K=16 table -> grouping backward -> KPConv backward (or the layer's backward)                      behind `fdone`
-        side   : CBL mining + loss -> K=36 table -> CBL backward                                                   behind `found`
+        side   : K=36 table -> CBL mining + loss -> CBL backward                                                   behind `found`
 
     so the search of step i+1 runs beside the forward kernels of step i and the backward kernels of step i-1: every table is built on the
-    stream that consumes it (no table stream, no table events), and no stream carries more than ~150 us of kernels per step.  "split_fwd" builds
-    the K=16 table behind the forward kernels on THEIR stream (the Point Transformer block: its backward chain is the longest).  Layout
-    "tables" is round 2's: tables on a stream of their own, forward and backward of the block on one stream (`rest`) —
-
-        tables : K=16 table (-> `t16`), K=36 table (-> `t36`)                                                       behind `found`
-        rest   : gather -> KPConv | (after `t16`) grouping backward -> KPConv backward                             behind `found`
-        side   : CBL mining + loss | (after `t36`) CBL backward                                                    behind `found`
-
-    — which serialises the backward of step i with the forward of step i+1: 0.310 ms per step against 0.297 ("split", three slots) for the
-    KPConv block, 0.68 (one step at a time was faster) against 0.56 ms ("split_fwd") for the Point Transformer block, same box, same kernels.
+    stream that consumes it (no table stream, no table events), and no stream carries more than ~150 us of kernels per step.  The ORDER inside the CBL
+    chain matters: with the pair kernel first ("split") the pipeline has two stable alignments, 0.270 and 0.290 ms per step, picked by the timing of the
+    first steps after an idle device; with the table's small kernels first every run is the fast one.  "alt_bwd" (the Point Transformer
+    block, whose backward chain is 0.46 of its 0.55 ms): consecutive steps' backward chains on two streams in turn, searches and CBL chain sharing one.
+    "tables" is round 2's layout: tables on a stream of their own, forward and backward of the block on one stream (`rest`), which serialises the backward of
+    step i with the forward of step i+1: 0.310 ms per step against 0.272 for the KPConv block, 0.68 (one step at a time was faster) against 0.505 ms for
+    the Point Transformer block, same box, same kernels.  The other layouts are measured alternatives.
     Steps are independent scenes (in bench.py: the same resident scene); a step writes into one of SLOTS slots (its neighbour tables, orders,
     outputs: self.states[slot]) and the search of step i+SLOTS waits for every other stream's part of step i before it overwrites their slot.  A
     step runs inside its own neighbour cache, which only exists while the step is captured.
@@ -475,14 +472,6 @@ class Pipeline:
                     ("fwd", "fwd", fwd_b, ("found",), "fdone"),
                     ("cbl", "side", fwd_c + t36 + bwd_c, ("found",), None),
                     ("bwd", "bwd", t16 + bwd_b, ("fdone",), None)]
-        elif self.layout == "split_early":
-            # as "split", the K = 16 table in front of the forward's end (its own graph, behind `found`)
-            self.STREAMS = ("search", "fwd", "bwd", "side")
-            segs = [("search", "search", search, (), "found"),
-                    ("fwd", "fwd", fwd_b, ("found",), "fdone"),
-                    ("cbl", "side", fwd_c + t36 + bwd_c, ("found",), None),
-                    ("t16", "bwd", t16, ("found",), None),
-                    ("bwd", "bwd", bwd_b, ("fdone",), None)]
         elif self.layout == "split_fwd":
             # as "split", the K = 16 table behind the forward kernels on THEIR stream: off the backward chain, which is the longest
             self.STREAMS = ("search", "fwd", "bwd", "side")
@@ -528,13 +517,6 @@ class Pipeline:
             segs = [("search", "search", search, (), "found"),
                     ("fwd", "main", fwd_b, ("found",), "fdone"),
                     ("cbl", "main", fwd_c + t36 + bwd_c, (), None),
-                    ("bwd", "bwd", t16 + bwd_b, ("fdone",), None)]
-        elif self.layout == "three_cbl_first":
-            self.STREAMS = ("search", "main", "bwd")
-            segs = [("search", "search", search, (), "found"),
-                    ("cblfwd", "main", fwd_c, ("found",), None),
-                    ("fwd", "main", fwd_b, (), "fdone"),
-                    ("cbl", "main", t36 + bwd_c, (), None),
                     ("bwd", "bwd", t16 + bwd_b, ("fdone",), None)]
         else:
             raise ValueError("unknown pipeline layout %r" % self.layout)

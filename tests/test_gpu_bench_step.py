@@ -92,8 +92,7 @@ def test_the_step_bench_times_against_the_oracles(oracle, backward, pipeline):
     check_state(st_in.state, oracle, backward)
 
 
-@pytest.mark.parametrize("layout,slots", [("tables", 2), ("split", 3), ("split_early", 3), ("split_fwd", 3), ("split_side_late", 2), ("split_fwd_t36_first", 3),
-                                          ("three", 2), ("three_cbl_first", 3), ("alt_bwd", 4)])
+@pytest.mark.parametrize("layout,slots", [("tables", 2), ("split", 3), ("split_fwd", 3), ("split_side_late", 2), ("split_fwd_t36_first", 3), ("three", 2), ("alt_bwd", 4)])
 def test_every_pipeline_layout_computes_the_step(oracle, layout, slots):
     """hotpath.Pipeline's stream layouts differ in what runs beside what, never in what is computed: every slot of every layout against the oracles
     (the default, "split_t36_first" with three slots, is the pipeline case of the test above)"""

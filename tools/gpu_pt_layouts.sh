@@ -9,5 +9,6 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.4f' % d['ms_pe
     done; echo " <- ${3:-pt} $1 slots $2"
 }
 run alt_bwd 4
-run alt_bwd_cbl_on_fwd 4
-run alt_bwd_cbl_on_fwd 3
+run alt_main 4
+run alt_main 3
+run alt_main 4 kpconv
