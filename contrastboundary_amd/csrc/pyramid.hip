@@ -102,3 +102,34 @@ CBL_EXPORT int cbl_pyramid_layer(int b, int n, const float* points, const int* l
                                     next_grid_ws_bytes, 0, stream);
     return rc;
 }
+
+// The whole pyramid in one call: cbl_pyramid_layer for layer 0 .. num_layers-1, every layer's outputs at the capacity of layer 0 (n rows; a layer never has
+// more points than the one above it), the sizes handed from layer to layer on the host.  One call per scene means a loader thread needs the interpreter
+// twice per pyramid (allocate, trim) instead of a dozen times.  Arrays are indexed by layer: neighbors[l] (n, limits[l]); pool_points[l] (n, 3),
+// pool_lengths[l] (b), pools[l] (n, limits[l]), upsamples[l] (n, limits[l]) for l < num_layers - 1; grid_ws[l] one search-grid workspace per layer;
+// max_counts (3 num_layers, device); host_sizes (num_layers, host — pinned recommended): points per layer, host_sizes[0] = n.
+CBL_EXPORT int cbl_pyramid(int b, int n, const float* points, const int* lengths, float radius0, float dl0, int num_layers, const int* limits,
+                           void* const* grid_ws, size_t grid_ws_bytes, int* const* neighbors, float* const* pool_points, int* const* pool_lengths,
+                           int* const* pools, int* const* upsamples, int* max_counts, int* host_sizes, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (num_layers <= 0 || num_layers > 16 || !limits || !grid_ws || !neighbors || !max_counts || !host_sizes) return CBL_ERR_BAD_ARG;
+    if (num_layers > 1 && (!pool_points || !pool_lengths || !pools || !upsamples)) return CBL_ERR_BAD_ARG;
+    const float* pts = points;
+    const int* lens = lengths;
+    int n_l = n;
+    float r = radius0, dl = dl0;
+    host_sizes[0] = n;
+    for (int l = 0; l < num_layers; l++) {
+        const bool last = l == num_layers - 1;
+        const int rc = cbl_pyramid_layer(b, n_l, pts, lens, r, last ? 0.f : 2.0f * dl, limits[l], grid_ws[l], grid_ws_bytes, l > 0 ? 1 : 0, neighbors[l],
+                                         last ? nullptr : pool_points[l], last ? nullptr : pool_lengths[l], last ? nullptr : pools[l],
+                                         last ? nullptr : upsamples[l], last ? nullptr : grid_ws[l + 1], last ? 0 : grid_ws_bytes, max_counts + 3 * l,
+                                         last ? nullptr : host_sizes + l + 1, workspace, workspace_bytes, stream);
+        if (rc) return rc;
+        if (last) break;
+        pts = pool_points[l]; lens = pool_lengths[l]; n_l = host_sizes[l + 1];
+        r *= 2.0f; dl *= 2.0f;
+    }
+    return CBL_OK;
+}
+

@@ -225,50 +225,42 @@ get_tf_func = TF_OPS.get_tf_func
 
 
 def _segmentation_inputs_radius_native(stacked_points, stacks_lengths, first_subsampling_dl, density_parameter, num_layers, neighborhood_limits):
-    """the pyramid through cbl_pyramid_layer: one native call per layer (the calls hold no Python lock: a loader thread can build the next scene's
-    pyramid beside the thread that issues the current scene's layers — convnet_path.PyramidLoader)"""
+    """the pyramid through cbl_pyramid: ONE native call per scene (cbl_pyramid_layer per layer inside it; the call holds no Python lock, so a loader thread
+    can build the next scene's pyramid beside the thread that issues the current scene's layers — convnet_path.PyramidLoader).  Every layer's outputs are
+    allocated at layer 0's capacity (a layer never has more points than the one above it) and cut to size afterwards."""
     _chk(stacked_points, torch.float32, "stacked_points", 2); _chk(stacks_lengths, torch.int32, "stacks_lengths", 1)
     L = _lib.lib()
     dev = stacked_points.device
     dl = float(first_subsampling_dl)
     r = dl * float(density_parameter) / 2.0                                  # :784-786
-    pts, lens = stacked_points, stacks_lengths
-    b = lens.shape[0]
-    out = {"points": [], "neighbors": [], "pools": [], "upsamples": [torch.zeros((0, 1), dtype=torch.int32, device=dev)], "batches_len": []}
+    n, b, nl = stacked_points.shape[0], stacks_lengths.shape[0], int(num_layers)
+    lims = [int(neighborhood_limits[l]) for l in range(nl)]
     e = lambda shape, dt=torch.int32: torch.empty(shape, dtype=dt, device=dev)
-    grid_bytes = lambda n: max(int(L.cbl_radius_neighbors_workspace_bytes(_i(b), _i(n))), 1)
-    host = torch.empty(1, dtype=torch.int32, pin_memory=True)
-    mcs = e(3 * num_layers)
-    grid_ws, built = e(grid_bytes(pts.shape[0]), torch.uint8), 0
-    stream = _lib.stream_of(stacked_points)
-    tables = []                                                              # (key, table, index of its largest-neighbourhood scalar) in the reference's order
-    for layer in range(num_layers):
-        n, last = pts.shape[0], layer == num_layers - 1
-        lim = int(neighborhood_limits[layer])
-        ws = _workspace("pyramid", L.cbl_pyramid_layer_workspace_bytes(_i(b), _i(n)), dev)
-        nb = e((n, lim))
-        if last:
-            pool_p = pool_l = pools = ups = next_ws = None
-        else:
-            pool_p, pool_l, pools, ups, next_ws = e((n, 3), torch.float32), e(b), e((n, lim)), e((n, lim)), e(grid_bytes(n), torch.uint8)
-        _lib.check(L.cbl_pyramid_layer(_i(b), _i(n), _lib.ptr(pts), _lib.ptr(lens), _f(r), _f(0.0 if last else 2 * dl), _i(lim),
-                                       _lib.ptr(grid_ws), ctypes.c_size_t(grid_ws.numel()), _i(built),
-                                       _lib.ptr(nb), _lib.ptr(pool_p), _lib.ptr(pool_l), _lib.ptr(pools), _lib.ptr(ups),
-                                       _lib.ptr(next_ws), ctypes.c_size_t(next_ws.numel() if next_ws is not None else 0),
-                                       ctypes.c_void_p(mcs.data_ptr() + 12 * layer), ctypes.c_void_p(host.data_ptr()),
-                                       _lib.ptr(ws), ctypes.c_size_t(ws.numel()), stream), "cbl_pyramid_layer")
-        out["points"].append(pts); out["batches_len"].append(lens)
-        tables.append(("neighbors", nb, 3 * layer))
-        if last:
-            break
-        m = int(host[0])                                                     # the call waited for it
-        tables.append(("pools", pools[:m], 3 * layer + 1))
-        tables.append(("upsamples", ups, 3 * layer + 2))
-        pts, lens, grid_ws, built = pool_p[:m], pool_l, next_ws, 1
-        r *= 2; dl *= 2
+    gbytes = max(int(L.cbl_radius_neighbors_workspace_bytes(_i(b), _i(n))), 1)
+    grids = [e(gbytes, torch.uint8) for _ in range(nl)]
+    nbs = [e((n, lims[l])) for l in range(nl)]
+    pool_p = [e((n, 3), torch.float32) for _ in range(nl - 1)]
+    pool_l = [e(b) for _ in range(nl - 1)]
+    pools = [e((n, lims[l])) for l in range(nl - 1)]
+    ups = [e((n, lims[l])) for l in range(nl - 1)]
+    mcs = e(3 * nl)
+    host = torch.empty(nl, dtype=torch.int32, pin_memory=True)
+    ws = _workspace("pyramid", L.cbl_pyramid_layer_workspace_bytes(_i(b), _i(n)), dev)
+    arr = lambda ts: (ctypes.c_void_p * max(len(ts), 1))(*[t.data_ptr() for t in ts])
+    _lib.check(L.cbl_pyramid(_i(b), _i(n), _lib.ptr(stacked_points), _lib.ptr(stacks_lengths), _f(r), _f(dl), _i(nl), (ctypes.c_int * nl)(*lims),
+                             arr(grids), ctypes.c_size_t(gbytes), arr(nbs), arr(pool_p), arr(pool_l), arr(pools), arr(ups), _lib.ptr(mcs),
+                             ctypes.c_void_p(host.data_ptr()), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(stacked_points)), "cbl_pyramid")
+    sizes = host.tolist()                                                    # the call waited for every one of them
     widths = mcs.tolist()                                                    # ONE device-to-host copy for the 13 table widths
-    for key, table, k in tables:
-        out[key].append(table if widths[k] >= table.shape[1] else table[:, :widths[k]].contiguous())
+    out = {"points": [stacked_points] + [pool_p[l][:sizes[l + 1]] for l in range(nl - 1)],
+           "batches_len": [stacks_lengths] + pool_l,
+           "neighbors": [], "pools": [], "upsamples": [torch.zeros((0, 1), dtype=torch.int32, device=dev)]}
+    cut = lambda table, rows, w: (table[:rows] if w >= table.shape[1] else table[:rows, :w].contiguous())
+    for l in range(nl):
+        out["neighbors"].append(cut(nbs[l], sizes[l], widths[3 * l]))
+        if l < nl - 1:
+            out["pools"].append(cut(pools[l], sizes[l + 1], widths[3 * l + 1]))
+            out["upsamples"].append(cut(ups[l], sizes[l], widths[3 * l + 2]))
     out["pools"].append(torch.zeros((0, 1), dtype=torch.int32, device=dev))
     return out
 
@@ -277,7 +269,7 @@ def segmentation_inputs_radius(stacked_points, stacks_lengths, first_subsampling
     """The pyramid builder tf_segmentation_inputs_radius (datasets/base.py:767-842), geometry part: per layer the radius
     neighbours, the grid-subsampled next layer, the pooling and upsampling indices, all cropped to neighborhood_limits.
     13 radius searches + 4 grid subsamplings, on the GPU instead of single-threaded C++ inside tf.data workers.
-    native (default): one cbl_pyramid_layer call per layer; False: the same kernels issued op by op from here (identical tables)."""
+    native (default): one cbl_pyramid call per scene; False: the same kernels issued op by op from here (identical tables)."""
     if native:
         return _segmentation_inputs_radius_native(stacked_points, stacks_lengths, first_subsampling_dl, density_parameter, num_layers, neighborhood_limits)
     with _offsets_cached():

@@ -627,6 +627,15 @@ int cbl_pyramid_layer(int b, int n, const float* points, const int* lengths, flo
                       void* next_grid_ws, size_t next_grid_ws_bytes, int* max_counts, int* host_pool_points,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* The whole pyramid of tf_segmentation_inputs_radius (base.py:784-820) in one call: cbl_pyramid_layer for every layer, all outputs at the capacity of
+ * layer 0 (n rows), the sizes handed on through host_sizes (num_layers ints on the host, [0] = n; valid when the call returns).  limits (host, num_layers);
+ * arrays indexed by layer: grid_ws[l] (cbl_radius_neighbors_workspace_bytes(b, n) bytes each), neighbors[l] (n, limits[l]); for l < num_layers - 1:
+ * pool_points[l] (n, 3), pool_lengths[l] (b), pools[l] (n, limits[l]), upsamples[l] (n, limits[l]); max_counts (3 num_layers, device);
+ * workspace cbl_pyramid_layer_workspace_bytes(b, n). */
+int cbl_pyramid(int b, int n, const float* points, const int* lengths, float radius0, float dl0, int num_layers, const int* limits,
+                void* const* grid_ws, size_t grid_ws_bytes, int* const* neighbors, float* const* pool_points, int* const* pool_lengths,
+                int* const* pools, int* const* upsamples, int* max_counts, int* host_sizes, void* workspace, size_t workspace_bytes, void* stream);
+
 /* N4  cpp_knn_batch_omp  tensorflow/ops/nearest_neighbors/knn_.cxx:104-135: dense batch (B,N,3) x (B,M,3) -> (B,M,K) int64 LOCAL indices.
  *     = cbl_knnquery on the flattened batch (offset = N, 2N, ...) followed by this conversion of the global int32 rows. */
 int cbl_knn_indices_to_local(int B, int M, int K, int N, const int* idx, long long* out, void* stream);
