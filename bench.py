@@ -592,7 +592,9 @@ def workload_legs(args):
 
     steps = str(min(args.steps, 30)); warm = str(min(args.warmup, 5))
     return {"pt_block": leg(["--block", "pt", "--steps", steps, "--warmup", warm], pick_pt),
-            "convnet": leg(["--workload", "convnet", "--steps", str(min(args.steps, 20)), "--warmup", str(min(args.warmup, 3))], pick_convnet)}
+            # the ConvNet step is issued eagerly by two host threads: short timed regions (20 steps = 60 ms) caught the threads' start-up in two of four runs
+            # (3.1 or 3.6-4.1 ms per step); 40 steps and 5 warm-up steps cost 0.3 s more
+            "convnet": leg(["--workload", "convnet", "--steps", "40", "--warmup", "5"], pick_convnet)}
 
 # ------------------------------------------------------------------------------------------------ ConvNet workload (BASELINE configs C5 / C3)
 def run_convnet(args, D, world, rank, local):
