@@ -438,13 +438,11 @@ class Pipeline:
     SLOTS = 3
     LAYOUT = "split_t36_first"                                            # which of the layouts below; CBL_PIPELINE_LAYOUT / CBL_PIPELINE_SLOTS override (experiments)
 
-    def __init__(self, sched, layout=None, slots=None):
-        import os
-        assert sched.hints, "the pipeline is built on the one-search-per-geometry schedule"
-        self.sched = sched
-        self.layout = layout or os.environ.get("CBL_PIPELINE_LAYOUT", self.LAYOUT)
-        self.SLOTS = int(slots or os.environ.get("CBL_PIPELINE_SLOTS", self.SLOTS))
-        names = [st[0] for st in sched.stage_list]
+    @staticmethod
+    def plan(names, layout):
+        """-> (stream names, segments) of `layout` for a step whose stages are called `names` (hotpath.stages / stages_pt conventions); a segment is
+        (name, stream, stage indices in issue order, events waited for, event recorded behind it), segments in issue order.  Pure: no device needed
+        (tests/test_host_pipeline_layouts.py checks every layout's coverage and ordering)."""
         ix = lambda pred: [i for i, nm in enumerate(names) if pred(nm)]
         search = ix(lambda nm: "knnquery" in nm)                    # the block's search, then the CBL head's request (cache hit)
         t16 = ix(lambda nm: "neighbor_transpose" in nm and not nm.startswith("cbl_"))
@@ -455,8 +453,8 @@ class Pipeline:
         fwd_b, bwd_b = [i for i in block if not bwd(i)], [i for i in block if bwd(i)]
         fwd_c, bwd_c = [i for i in cbl if not bwd(i)], [i for i in cbl if bwd(i)]
         # (name, stream, stages in issue order, events waited for, event recorded behind it) in issue order
-        if self.layout == "tables":
-            self.STREAMS = ("search", "tables", "rest", "side")
+        if layout == "tables":
+            streams = ("search", "tables", "rest", "side")
             segs = [("search", "search", search, (), "found"),
                     ("t16", "tables", t16, ("found",), "t16"),
                     ("fwd", "rest", fwd_b, ("found",), None),
@@ -464,63 +462,71 @@ class Pipeline:
                     ("t36", "tables", t36, ("found",), "t36"),
                     ("bwd", "rest", bwd_b, ("t16",) if t16 else (), None),
                     ("cblbwd", "side", bwd_c, ("t36",) if t36 else (), None)]
-        elif self.layout == "split":
+        elif layout == "split":
             # the block's backward on a stream of its own behind its table: the backward kernels of step i run beside the forward kernels of
             # step i+1; every table is built on the stream that consumes it (no table stream, no table events)
-            self.STREAMS = ("search", "fwd", "bwd", "side")
+            streams = ("search", "fwd", "bwd", "side")
             segs = [("search", "search", search, (), "found"),
                     ("fwd", "fwd", fwd_b, ("found",), "fdone"),
                     ("cbl", "side", fwd_c + t36 + bwd_c, ("found",), None),
                     ("bwd", "bwd", t16 + bwd_b, ("fdone",), None)]
-        elif self.layout == "split_fwd":
+        elif layout == "split_fwd":
             # as "split", the K = 16 table behind the forward kernels on THEIR stream: off the backward chain, which is the longest
-            self.STREAMS = ("search", "fwd", "bwd", "side")
+            streams = ("search", "fwd", "bwd", "side")
             segs = [("search", "search", search, (), "found"),
                     ("fwd", "fwd", fwd_b + t16, ("found",), "fdone"),
                     ("cbl", "side", fwd_c + t36 + bwd_c, ("found",), None),
                     ("bwd", "bwd", bwd_b, ("fdone",), None)]
-        elif self.layout == "split_side_late":
+        elif layout == "split_side_late":
             # as "split", the CBL chain behind the forward kernels (the wave search of the next step then overlaps gather / KPConv only): pins the fast regime too
-            self.STREAMS = ("search", "fwd", "bwd", "side")
+            streams = ("search", "fwd", "bwd", "side")
             segs = [("search", "search", search, (), "found"),
                     ("fwd", "fwd", fwd_b, ("found",), "fdone"),
                     ("cbl", "side", fwd_c + t36 + bwd_c, ("fdone",), None),
                     ("bwd", "bwd", t16 + bwd_b, ("fdone",), None)]
-        elif self.layout == "split_t36_first":
+        elif layout == "split_t36_first":
             # The default.  As "split", the K=36 table in front of the CBL forward.  "split" has two stable regimes, 0.270 and 0.290 ms per step, picked by the
             # timing of the first steps after an idle device (4 : 3 over processes, and from block to block inside one); with the table's small kernels — not the
             # full-device pair kernel — beside the start of the next wave search and the gather, every run is the fast one (6 of 6, three and four slots).
-            self.STREAMS = ("search", "fwd", "bwd", "side")
+            streams = ("search", "fwd", "bwd", "side")
             segs = [("search", "search", search, (), "found"),
                     ("fwd", "fwd", fwd_b, ("found",), "fdone"),
                     ("cbl", "side", t36 + fwd_c + bwd_c, ("found",), None),
                     ("bwd", "bwd", t16 + bwd_b, ("fdone",), None)]
-        elif self.layout == "split_fwd_t36_first":
-            self.STREAMS = ("search", "fwd", "bwd", "side")
+        elif layout == "split_fwd_t36_first":
+            streams = ("search", "fwd", "bwd", "side")
             segs = [("search", "search", search, (), "found"),
                     ("fwd", "fwd", fwd_b + t16, ("found",), "fdone"),
                     ("cbl", "side", t36 + fwd_c + bwd_c, ("found",), None),
                     ("bwd", "bwd", bwd_b, ("fdone",), None)]
-        elif self.layout == "alt_bwd":
+        elif layout == "alt_bwd":
             # for a block whose backward chain is longer than everything else of the step together (the Point Transformer block: 0.46 of 0.56 ms): consecutive
             # steps' backward chains on TWO streams in turn ("bwd*": by step parity), so that they overlap; the searches and the CBL chain share the fourth
             # stream.  PT block 0.549 -> 0.505 ms (four slots; the CBL chain on the forward stream instead: 0.55); the KPConv block LOSES with it (0.348)
-            self.STREAMS = ("search", "fwd", "bwd0", "bwd1")
+            streams = ("search", "fwd", "bwd0", "bwd1")
             segs = [("search", "search", search, (), "found"),
                     ("fwd", "fwd", fwd_b + t16, ("found",), "fdone"),
                     ("cbl", "search", t36 + fwd_c + bwd_c, (), None),
                     ("bwd", "bwd*", bwd_b, ("fdone",), None)]
-        elif self.layout == "three":
+        elif layout == "three":
             # three chains for three hardware queues (a process has four, the default stream keeps one: a kernel trace of "split" showed the search and the
             # forward chain on ONE queue, one behind the other): search | forward, then the CBL branch | the block's backward behind its table
-            self.STREAMS = ("search", "main", "bwd")
+            streams = ("search", "main", "bwd")
             segs = [("search", "search", search, (), "found"),
                     ("fwd", "main", fwd_b, ("found",), "fdone"),
                     ("cbl", "main", fwd_c + t36 + bwd_c, (), None),
                     ("bwd", "bwd", t16 + bwd_b, ("fdone",), None)]
         else:
-            raise ValueError("unknown pipeline layout %r" % self.layout)
-        self.segments = [sg for sg in segs if sg[2]]
+            raise ValueError("unknown pipeline layout %r" % layout)
+        return streams, [sg for sg in segs if sg[2]]
+
+    def __init__(self, sched, layout=None, slots=None):
+        import os
+        assert sched.hints, "the pipeline is built on the one-search-per-geometry schedule"
+        self.sched = sched
+        self.layout = layout or os.environ.get("CBL_PIPELINE_LAYOUT", self.LAYOUT)
+        self.SLOTS = int(slots or os.environ.get("CBL_PIPELINE_SLOTS", self.SLOTS))
+        self.STREAMS, self.segments = self.plan([st[0] for st in sched.stage_list], self.layout)
         self.streams = dict(zip(self.STREAMS, concurrent_streams(len(self.STREAMS))))        # streams with hardware queues of their own
         self.states = [{} for _ in range(self.SLOTS)]
         self.graphs = [dict() for _ in range(self.SLOTS)]
