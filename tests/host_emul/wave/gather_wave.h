@@ -17,5 +17,6 @@ static inline int gw_uniform(int v)
     emul::wave_collective(&pay, 1, &r, 1, [](emul::Wave& w) { int first = 0; while (first < 63 && !w.present[first]) first++; for (int l = 0; l < 64; l++) w.out[l][0] = w.in[first][0]; });
     return __float_as_int(r);
 }
+static inline int gw_readlane(int v, int src_lane) { return gw_shfl(v, src_lane); }      // every active lane asks for the same lane
 static inline void gw_wave_sync() { float z = 0.f, r; emul::wave_collective(&z, 1, &r, 1, [](emul::Wave&) {}); }
 static inline void gw_store16_streaming(float* dst, const float* src) { std::memcpy(dst, src, 16); }
