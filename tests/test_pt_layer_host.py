@@ -150,3 +150,39 @@ def test_layer_kernels_on_the_host_against_autograd(host, n, K, C, ordered):
     for k in ["x_v", "x_q", "x_k"] + PARAMS:
         # biases in front of a BatchNorm have a zero true gradient: both sides return rounding noise (absolute bound relative to the largest gradient)
         assert rel(g[k], grads[k]) < 2e-4 or float(np.abs(g[k] - grads[k]).max()) < 1e-5 * gmax, (k, rel(g[k], grads[k]))
+
+
+@pytest.mark.parametrize("n,K,C", [(33, 16, 64), (26, 8, 32)])
+def test_evaluation_mode_on_the_host_uses_the_running_statistics(host, n, K, C):
+    """cbl_pt_layer_forward_eval (nn.Module.eval(): the three BatchNorms normalise with their running statistics, no statistics passes, no buffer touched)
+    against the layer's formula in float64 with the same running statistics"""
+    t = make(n, K, C, seed=3 * n + C)
+    G = C // 8
+    rng = np.random.default_rng(n)
+    rm = [rng.normal(size=d).astype(np.float32) * 0.3 for d in (3, C, G)]
+    rv = [rng.uniform(0.5, 2.0, size=d).astype(np.float32) for d in (3, C, G)]
+    z = lambda *s: np.zeros(s, np.float32)
+    buf = dict(p_r=z(n, K, 3), p0=z(n, K, 3), p1=z(n, K, 3), w2=z(n, K, G), a=z(n, K, G), out=z(n, C), consts=z(host.cbl_pt_layer_consts_floats()))
+    ws = np.zeros(host.cbl_pt_layer_workspace_bytes(n, K, C) // 4 + 16, np.float32)
+    arr3 = lambda xs: (ctypes.c_void_p * 3)(*[x.ctypes.data for x in xs])
+    eps3 = (ctypes.c_float * 3)(EPS, EPS, EPS)
+    keep = [x.copy() for x in rm + rv]
+    rc = host.cbl_pt_layer_forward_eval(n, K, C, P(t["xyz"]), P(t["x_q"]), P(t["x_k"]), P(t["x_v"]), P(t["idx"]), None, *[P(t[k]) for k in PARAMS], eps3,
+                                        arr3(rm), arr3(rv), P(buf["p_r"]), P(buf["p0"]), P(buf["p1"]), P(buf["w2"]), P(buf["a"]), P(buf["out"]), P(buf["consts"]),
+                                        P(ws), ctypes.c_size_t(ws.nbytes), None)
+    assert rc == 0, rc
+    for a, b in zip(rm + rv, keep):
+        assert np.array_equal(a, b)                                           # evaluation mode leaves the running statistics alone
+    T = {k: torch.tensor(v, dtype=torch.float64) for k, v in t.items() if k != "idx"}
+    idx = torch.tensor(t["idx"].astype(np.int64))
+    bn = lambda x, q, g, b: (x - torch.tensor(rm[q], dtype=torch.float64)) / torch.sqrt(torch.tensor(rv[q], dtype=torch.float64) + EPS) * g + b
+    p_r = T["xyz"][idx] - T["xyz"][:, None, :]
+    p1 = torch.relu(bn(p_r @ T["Wp"].T + T["bp"], 0, T["gamma_p"], T["beta_p"]))
+    pe = p1 @ T["W3C"].T + T["b3C"]
+    w = T["x_k"][idx] - T["x_q"][:, None, :] + pe
+    w2 = torch.relu(bn(w, 1, T["gamma_c"], T["beta_c"])) @ T["Wa"].T + T["ba"]
+    logits = torch.relu(bn(w2, 2, T["gamma_g"], T["beta_g"])) @ T["Wb"].T + T["bb"]
+    a = torch.softmax(logits, dim=1)
+    out = ((T["x_v"][idx] + pe).view(n, K, 8, G) * a.unsqueeze(2)).sum(1).view(n, C)
+    assert rel(buf["a"], a.numpy()) < 1e-5
+    assert rel(buf["out"], out.numpy()) < 1e-5
