@@ -130,7 +130,7 @@ def rel(a, b):
     return float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b), 1e-30))
 
 
-@pytest.mark.parametrize("n,K,C,ordered", [(40, 16, 64, True), (37, 8, 32, True), (24, 16, 32, False), (29, 8, 64, False)])
+@pytest.mark.parametrize("n,K,C,ordered", [(40, 16, 64, True), (37, 8, 32, True), (24, 16, 32, False), (29, 8, 64, False), (16, 16, 32, True), (17, 8, 64, True)])
 def test_layer_kernels_on_the_host_against_autograd(host, n, K, C, ordered):
     t = make(n, K, C, seed=n + C)
     order = np.random.default_rng(1).permutation(n).astype(np.int32) if ordered else None
