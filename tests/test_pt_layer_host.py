@@ -186,3 +186,22 @@ def test_evaluation_mode_on_the_host_uses_the_running_statistics(host, n, K, C):
     out = ((T["x_v"][idx] + pe).view(n, K, 8, G) * a.unsqueeze(2)).sum(1).view(n, C)
     assert rel(buf["a"], a.numpy()) < 1e-5
     assert rel(buf["out"], out.numpy()) < 1e-5
+
+
+def test_targets_with_long_pair_lists_on_the_host(host):
+    """a neighbour table in which three points are almost everybody's neighbours: their lists in the transposed table hold hundreds of pairs (the
+    gather pass over the table walks them in batches), every other point's list is short or empty"""
+    n, K, C = 48, 16, 32
+    t = make(n, K, C, seed=77)
+    rng = np.random.default_rng(5)
+    idx = t["idx"].copy()
+    idx[:, 1:] = rng.integers(0, 3, size=(n, K - 1))
+    idx[5:9, 1:4] = rng.integers(3, n, size=(4, 3))
+    t["idx"] = idx.astype(np.int32)
+    assert np.bincount(t["idx"].reshape(-1), minlength=n).max() > 64
+    out, grads, mid, stats = reference(t, K, C)
+    buf, g, run = run_host(host, t, K, C, np.random.default_rng(2).permutation(n).astype(np.int32))
+    assert rel(buf["out"], out) < 1e-5
+    gmax = max(float(np.abs(v).max()) for v in grads.values())
+    for k in ["x_v", "x_q", "x_k"] + PARAMS:
+        assert rel(g[k], grads[k]) < 2e-4 or float(np.abs(g[k] - grads[k]).max()) < 1e-5 * gmax, (k, rel(g[k], grads[k]))
