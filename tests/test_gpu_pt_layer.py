@@ -3,6 +3,7 @@ shapes, against the same layer on the separate kernels (`fused = False`, which t
 against the round-3 split kernels; determinism; the matrix-instruction / fmaf-chain bit equality the passes' ReLU masks rest on."""
 import copy
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -135,3 +136,79 @@ def test_evaluation_mode_uses_the_running_statistics(n, K, C):
     for b0, b1 in zip(before, fused.buffers()):
         assert torch.equal(b0, b1)
     assert not pt_layer.supported(fused, x)                           # evaluation WITH gradients enabled: the other paths
+
+
+# ---- the fused layer against the REFERENCE at the bench shapes -------------------------------------------------------------------------
+# tests/golden/pt_layer_bench_pytorch.npz (tests/golden/gen_pt_layer_bench_goldens.py): a FLOAT64 pass of the reference's own PointTransformerLayer
+# (blocks.py:8-44, imported in the build container) on the scene bench.py times.  Sampled rows are held entry by entry, the column sums and the norm
+# hold every row; the weights come from the seed (checksums asserted), the inputs from a CPU generator.
+BENCH_GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "pt_layer_bench_pytorch.npz")
+
+
+def redraw_bn_affine(layer, seed):
+    """the same function as in tests/golden/gen_pt_layer_bench_goldens.py"""
+    gen = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in layer.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.copy_(torch.rand(m.weight.shape, generator=gen) + 0.5)
+                m.bias.copy_(torch.rand(m.bias.shape, generator=gen) * 0.6 - 0.3)
+
+
+def held_by_summary(got, rows_ref, colsum_ref, norm_ref, step, what, outlier_entries=0):
+    """got (n, C) on the GPU against the fixture's every-`step`-th rows (float32 of the float64 pass), float64 column sums and [sum of squares, max]"""
+    n, C = got.shape
+    g64 = got.double()
+    ref_rows = torch.from_numpy(np.asarray(rows_ref)).cuda().double()
+    scale = float(norm_ref[1])                                       # the tensor's largest magnitude
+    rms = float(np.sqrt(norm_ref[0] / (n * C)))
+    err = (g64[::step] - ref_rows).abs()
+    bound = 1e-4 * (ref_rows.abs() + scale)                          # north_star's 1e-4, as tests/test_gpu_blocks.py::close64 states it
+    beyond = int((err > bound).sum())
+    assert beyond <= outlier_entries, f"{what}: {beyond} of {err.numel()} sampled entries beyond 1e-4 (allowed {outlier_entries}), worst {float((err / bound).max()):.2f}x"
+    assert float(err.max()) < 2.0 * scale, f"{what}: an entry off by more than any entry's size"
+    col = (g64.sum(0).cpu().numpy() - np.asarray(colsum_ref))
+    assert np.abs(col).max() <= 1e-4 * n * rms, f"{what}: column sums off by {np.abs(col).max():.3e} (mean error per entry beyond 1e-4 of the rms {rms:.3e})"
+    sq = float((g64 * g64).sum())
+    assert abs(np.sqrt(sq) - np.sqrt(norm_ref[0])) <= 1e-4 * np.sqrt(norm_ref[0]), f"{what}: norm {np.sqrt(sq)} vs {np.sqrt(norm_ref[0])}"
+    return beyond
+
+
+@pytest.mark.parametrize("n,K,C", [(40960, 16, 64), (40960, 8, 32)])
+def test_full_resolution_stage_against_the_reference_in_float64(n, K, C):
+    """csrc/pt_layer.hip at (40960, 16, 64) — BASELINE's shape — and (40960, 8, 32) — the network's first stage — against the reference layer itself"""
+    from contrastboundary_amd import blocks, pt_layer, synthetic as S
+    Z = np.load(BENCH_GOLDEN)
+    pre = f"n{n}_k{K}_c{C}"
+    _, _, _, seed, step = (int(v) for v in Z[f"{pre}/meta"])
+    torch.manual_seed(seed)
+    layer = blocks.PointTransformerLayer(C, C, 8, K)
+    sd = layer.state_dict()
+    for name, want in zip(Z[f"{pre}/sd_names"], Z[f"{pre}/sd_sums"]):   # same construction order: same initial parameters as the reference's layer
+        assert abs(float(sd[str(name)].double().sum()) - float(want)) <= 1e-9 * (1.0 + abs(float(want))), name
+    redraw_bn_affine(layer, 2000 + seed)
+    layer = layer.cuda().train()
+    gen = torch.Generator().manual_seed(1000 + seed)
+    x = torch.randn(n, C, generator=gen); g = torch.randn(n, C, generator=gen)
+    assert np.allclose([float(x.double().sum()), float(g.double().sum())], Z[f"{pre}/xg_sums"], rtol=0, atol=1e-6)
+    xyz = torch.from_numpy(S.s_room(n, seed=0)[0]).cuda(); o = torch.tensor([n], dtype=torch.int32, device="cuda")
+    x = x.cuda().requires_grad_(True); g = g.cuda()
+    assert pt_layer.supported(layer, x)
+    y = layer([xyz, x, o])
+    y.backward(g)
+    held_by_summary(y.detach(), Z[f"{pre}/out_rows"], Z[f"{pre}/out_colsum"], Z[f"{pre}/out_norm"], step, "output")
+    # the input gradient sits behind ReLU(BatchNorm(.)) masks: an activation within fp32 rounding of 0 flips against the float64 pass, and one flipped
+    # (pair, channel) moves two whole rows (2 C entries) of d x (close_up_to_mask_flips above: <= 4096 entries of the full tensor; a sixteenth of the rows is sampled)
+    flipped = held_by_summary(x.grad, Z[f"{pre}/gx_rows"], Z[f"{pre}/gx_colsum"], Z[f"{pre}/gx_norm"], step, "input gradient", outlier_entries=4096 // step * 2)
+    print("sampled input-gradient entries beyond 1e-4: %d" % flipped)
+    grads = {k: p.grad for k, p in layer.named_parameters()}
+    gmax = max(float(np.abs(Z[f"{pre}/grad/{k}"]).max()) for k in grads)
+    for k, got in grads.items():
+        ref = torch.from_numpy(np.asarray(Z[f"{pre}/grad/{k}"])).cuda()
+        assert got is not None and got.shape == ref.shape, k
+        # sums over all 655 360 / 327 680 pairs: the handful of flipped masks moves them by ~1e-3 relative at this size (the bound the comparison with the
+        # unfused layer uses above); everything that is not behind a mask is at 1e-6
+        assert rel(got, ref) < 5e-3 or float((got.double() - ref).abs().max()) < 1e-3 * gmax, (k, rel(got, ref))
+    for k, b in layer.named_buffers():
+        ref = torch.from_numpy(np.asarray(Z[f"{pre}/buffer/{k}"])).cuda()
+        assert rel(b.double().reshape(-1), ref.reshape(-1)) < 1e-5, k
