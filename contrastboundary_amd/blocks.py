@@ -43,7 +43,13 @@ class PointTransformerLayer(nn.Module):
         x_q, x_k, x_v = dense.triple_linear(x, self.linear_q, self.linear_k, self.linear_v)                        # :33, one launch per direction
         if idx is None:
             idx, _ = pointops.knnquery(self.nsample, p, p, o, o)              # once, not twice (:34-35)
-        if self.fused and self.fused != "split" and pt_layer.supported(self, x):
+        else:
+            # a caller-supplied table (shared per stage) reaches the kernels as a raw pointer with K = idx.shape[1]: anything but (n, nsample) int32 rows
+            # would be read as garbage row ids — fail here, loudly (a sliced table is made contiguous: values, not layout, are the contract)
+            idx = pointops._req(idx.contiguous(), torch.int32, "idx", 2)
+            if tuple(idx.shape) != (x.shape[0], int(self.nsample)) or idx.device != x.device:
+                raise ValueError(f"idx: expected a ({x.shape[0]}, {int(self.nsample)}) table on {x.device}, got {tuple(idx.shape)} on {idx.device}")
+        if self.fused and self.fused != "split" and pt_layer.supported(self, x, idx, p):
             # the two full-resolution shapes: everything behind the three projections as one pass structure (csrc/pt_layer.hip)
             return pt_layer.attention(self, p, x_q, x_k, x_v, idx)
         p_r = pointops.queryandgroup(self.nsample, p, p, p.new_zeros((p.shape[0], 0)), idx, o, o, use_xyz=True)   # (n,K,3) relative xyz

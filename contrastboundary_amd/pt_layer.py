@@ -25,14 +25,30 @@ def _bn_ok(bn):
     return (isinstance(bn, torch.nn.BatchNorm1d) and bn.affine and bn.track_running_stats and bn.momentum is not None and bn.weight.dtype == torch.float32)
 
 
-def supported(layer, x):
+def _stats_ok(bn):
+    """the raw running-statistics pointers the C entry takes: contiguous fp32 (int64 batch counter)"""
+    return (bn.running_mean is not None and bn.running_mean.dtype == torch.float32 and bn.running_mean.is_contiguous()
+            and bn.running_var.dtype == torch.float32 and bn.running_var.is_contiguous()
+            and bn.num_batches_tracked is not None and bn.num_batches_tracked.dtype == torch.int64)
+
+
+def supported(layer, x, idx=None, p=None):
     """training mode (forward + backward), or evaluation mode under torch.no_grad() (the reference's test loop, tool/test.py:217-240: running statistics,
-    no backward pass); evaluation WITH gradients takes the other paths"""
+    no backward pass); evaluation WITH gradients takes the other paths.  `idx` / `p`: the neighbour table and coordinates the caller is about to hand over —
+    the C entry reads them through raw pointers (K = idx.shape[1]), so a table that is not exactly (n, layer.nsample) int32 contiguous on x's device, or
+    coordinates that are not (n, 3) fp32, send the layer down attention.py's path (which validates through pointops._req) instead of into the kernels."""
     C = layer.out_planes
     mode_ok = layer.training or not torch.is_grad_enabled()
-    return (mode_ok and x.is_cuda and x.dtype == torch.float32 and layer.mid_planes == C and layer.share_planes == 8 and C in (32, 64)
-            and int(layer.nsample) in (8, 16) and 16 <= x.shape[0] <= MAX_POINTS
-            and _bn_ok(layer.linear_p[1]) and _bn_ok(layer.linear_w[0]) and _bn_ok(layer.linear_w[3]))
+    ok = (mode_ok and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and layer.mid_planes == C and layer.share_planes == 8 and C in (32, 64)
+          and int(layer.nsample) in (8, 16) and 16 <= x.shape[0] <= MAX_POINTS
+          and _bn_ok(layer.linear_p[1]) and _bn_ok(layer.linear_w[0]) and _bn_ok(layer.linear_w[3])
+          and _stats_ok(layer.linear_p[1]) and _stats_ok(layer.linear_w[0]) and _stats_ok(layer.linear_w[3]))
+    if ok and idx is not None:
+        ok = (idx.dtype == torch.int32 and idx.device == x.device and idx.dim() == 2 and idx.is_contiguous()
+              and tuple(idx.shape) == (x.shape[0], int(layer.nsample)))
+    if ok and p is not None:
+        ok = p.dtype == torch.float32 and p.device == x.device and tuple(p.shape) == (x.shape[0], 3)
+    return bool(ok)
 
 
 _i, _f = ctypes.c_int, ctypes.c_float

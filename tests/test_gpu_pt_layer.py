@@ -212,3 +212,31 @@ def test_full_resolution_stage_against_the_reference_in_float64(n, K, C):
     for k, b in layer.named_buffers():
         ref = torch.from_numpy(np.asarray(Z[f"{pre}/buffer/{k}"])).cuda()
         assert rel(b.double().reshape(-1), ref.reshape(-1)) < 1e-5, k
+
+
+def test_a_caller_supplied_table_is_validated_before_any_pointer_is_taken():
+    """blocks.PointTransformerLayer.forward(pxo, idx=...): the C entries take idx by raw pointer with K = idx.shape[1] — a table of another width, int64 ids or a
+    strided view must never reach them as they are (round-4 advisor finding)"""
+    from contrastboundary_amd import pointops, pt_layer, synthetic as S
+    n, K, C = 4096, 16, 64
+    xyz = torch.from_numpy(S.s_room(n, seed=9)[0]).cuda(); o = torch.tensor([n], dtype=torch.int32, device="cuda")
+    layer = layers(C, K, 5)
+    torch.manual_seed(4)
+    x = torch.randn(n, C, device="cuda")
+    idx, _ = pointops.knnquery(K, xyz, xyz, o, o)
+    wide, _ = pointops.knnquery(2 * K, xyz, xyz, o, o)
+    y0 = layer([xyz, x, o]).detach()
+    assert torch.equal(layer([xyz, x, o], idx=idx).detach(), y0)
+    view = wide[:, :K]                                               # a strided view of a wider table: same values as idx wherever no tie decides
+    assert not view.is_contiguous()
+    y1 = layer([xyz, x, o], idx=view).detach()
+    if torch.equal(view, idx):
+        assert torch.equal(y1, y0)
+    with pytest.raises(TypeError):
+        layer([xyz, x, o], idx=idx.long())
+    with pytest.raises(ValueError):
+        layer([xyz, x, o], idx=wide)                                 # (n, 32) against nsample = 16
+    with pytest.raises(ValueError):
+        layer([xyz, x, o], idx=idx[: n // 2])
+    assert not pt_layer.supported(layer, x, idx=idx.long()) and not pt_layer.supported(layer, x, idx=view) and not pt_layer.supported(layer, x, idx=wide)
+    assert not pt_layer.supported(layer, x, p=xyz.double()) and pt_layer.supported(layer, x, idx, xyz)
