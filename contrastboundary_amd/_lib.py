@@ -36,8 +36,17 @@ def lib():
             _build.build()          # raises if hipcc is absent or a source does not compile
         if not os.path.exists(_SO):
             raise CblError("libcbl_amd.so is missing: run `python -m contrastboundary_amd.build`")
-        _lib = ctypes.CDLL(os.environ.get("CBL_AMD_LIB") or _SO)      # CBL_AMD_LIB: another build of the same library (kernel experiments)
+        override = os.environ.get("CBL_AMD_LIB")                     # another build of the same library (kernel experiments)
+        _lib = ctypes.CDLL(override or _SO)
+        if not hasattr(_lib, "cbl_version"):
+            raise CblError(f"{override or _SO} is not a build of this library (no cbl_version)")
         _lib.cbl_version.restype = ctypes.c_char_p
+        if override:
+            # an override must be the SAME ABI: the version string of the in-tree build (csrc/version.hip) and every declared symbol (checked below)
+            mine = ctypes.CDLL(_SO)
+            mine.cbl_version.restype = ctypes.c_char_p
+            if _lib.cbl_version() != mine.cbl_version():
+                raise CblError(f"CBL_AMD_LIB={override}: version {_lib.cbl_version()!r} does not match the in-tree library's {mine.cbl_version()!r}")
         for name in declared_symbols():
             fn = getattr(_lib, name, None)
             if fn is None:

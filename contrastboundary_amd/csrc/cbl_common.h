@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include "../../include/cbl_amd.h"
 
 #define CBL_EXPORT extern "C" __attribute__((visibility("default")))
@@ -29,20 +30,29 @@ static inline unsigned cbl_grid_for(long long work_items, int block, int max_blo
 // Workgroups of `kernel` that are resident at once on the current device (occupancy x compute units), for persistent launches: a kernel that walks its
 // work with a grid-stride loop is launched with at most this many workgroups, so a wave takes several trips (what it fetches a trip ahead gets used) and
 // the dispatcher is not kept busy with thousands of one-trip workgroups while other streams' kernels wait for slots.  Cached per (kernel, LDS, device).
-static inline unsigned cbl_resident_blocks(const void* kernel, int block, size_t dynamic_lds = 0)
+// Launches come from several host threads at once (the caller's, autograd's backward thread, a pyramid loader thread): the table is guarded by a mutex
+// (one shared instance across translation units: an inline function's statics).
+inline unsigned cbl_resident_blocks(const void* kernel, int block, size_t dynamic_lds = 0)
 {
     struct Entry { const void* fn; size_t lds; int dev; unsigned n; };
-    static Entry cache[48] = {};
+    static Entry cache[64] = {};
+    static std::mutex guard;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    for (int i = 0; i < 48 && cache[i].fn; i++)
-        if (cache[i].fn == kernel && cache[i].lds == dynamic_lds && cache[i].dev == dev) return cache[i].n;
+    {
+        std::lock_guard<std::mutex> hold(guard);
+        for (int i = 0; i < 64 && cache[i].fn; i++)
+            if (cache[i].fn == kernel && cache[i].lds == dynamic_lds && cache[i].dev == dev) return cache[i].n;
+    }
     int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, dynamic_lds) != hipSuccess || per_cu <= 0) per_cu = 4;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     const unsigned n = ((unsigned)(per_cu * cus) + 7u) & ~7u;           // a multiple of the 8 XCDs
-    for (int i = 0; i < 48; i++)
+    std::lock_guard<std::mutex> hold(guard);
+    for (int i = 0; i < 64; i++) {
+        if (cache[i].fn == kernel && cache[i].lds == dynamic_lds && cache[i].dev == dev) break;      // another thread was faster
         if (!cache[i].fn) { cache[i].lds = dynamic_lds; cache[i].dev = dev; cache[i].n = n; cache[i].fn = kernel; break; }
+    }
     return n;
 }
 template <class F> static inline unsigned cbl_persistent_grid(unsigned wanted, F kernel, int block, size_t dynamic_lds = 0)

@@ -611,17 +611,8 @@ static int queryandgroup_impl(int m, int nsample, int c, int use_xyz, const floa
     if (lds_ok && order && (c == 32 || c == 64) && (nsample == 8 || nsample == 16)) {
         // the networks' full-resolution shapes: persistent waves (as many workgroups as are resident at once), pieces = whole points
         const unsigned npieces = (unsigned)m, nwg = (npieces + 3) / 4;
-        static int resident[4][16] = {};                                // workgroups resident at once, per kernel and device
-        auto grid_of = [&](const void* fn, int slot) -> unsigned {
-            int dev = 0;
-            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-            if (!resident[slot][dev]) {
-                int per_cu = 0, cus = 0;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, GB, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
-                if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-                resident[slot][dev] = per_cu * cus;
-            }
-            const unsigned g = cbl_round_up8((unsigned)resident[slot][dev]);
+        auto grid_of = [&](const void* fn, int) -> unsigned {           // workgroups resident at once (cbl_resident_blocks: cached per kernel and device, thread-safe)
+            const unsigned g = cbl_resident_blocks(fn, GB, 0);
             return g < cbl_round_up8(nwg) ? g : cbl_round_up8(nwg);
         };
 #define CBL_QG_PIPE(C4T, PR, SLOT) hipLaunchKernelGGL((query_group_lds_pipe<C4T, PR>), dim3(grid_of(reinterpret_cast<const void*>(&query_group_lds_pipe<C4T, PR>), SLOT)), dim3(GB), 0, \

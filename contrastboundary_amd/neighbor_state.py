@@ -140,6 +140,24 @@ def spatial_order(points):
 use_spatial_order = True
 
 
+class natural_order:
+    """inside: no processing orders — every point-walking kernel takes the points in index order, and no search exports its cell order.  Values never depend
+    on an order EXCEPT through summation order: csrc/pt_layer.hip sums its BatchNorm statistics tile by tile in processing order, and which search of a geometry
+    ran first (neighbour cache or not, geometry prefetch or not) decides that order.  Two runs that must be compared bit for bit (tests/test_gpu_model.py) run
+    in here; costs the gathers their L2 locality, nothing else."""
+
+    def __enter__(self):
+        global use_spatial_order
+        self.was = use_spatial_order
+        use_spatial_order = False
+        return self
+
+    def __exit__(self, *exc):
+        global use_spatial_order
+        use_spatial_order = self.was
+        return False
+
+
 # ------------------------------------------------------------------------------------------------ transposed neighbour tables
 # cbl_neighbor_transpose of a neighbour table, kept per table.  A module-level registry (not the thread-local cache): backward passes run on
 # autograd's device thread and must find what the forward thread built.  Unlike a processing order the VALUES of a consumer depend on

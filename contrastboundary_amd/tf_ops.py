@@ -28,33 +28,38 @@ def _chk(t, dtype, name, dim):
     return t
 
 
-_offset_cache = {}                    # id(lengths) -> (lengths tensor kept alive, offsets); only while a pyramid is being built (see below)
-_offset_cache_on = [0]
+import threading
+
+_offset_state = threading.local()     # per thread (the pyramid loader builds on a thread of its own): .on = nesting depth, .cache = id(lengths) -> (lengths kept alive, version, offsets)
 
 
 class _offsets_cached:
     """Inside this block `_offsets` remembers the cumulative sums of the length vectors it has seen: the op-by-op pyramid builder asks for the same five
     vectors thirty times per scene.  Only there: the vectors a builder handles are written once (by the subsampling that produced them) and read afterwards —
-    outside it a caller may rewrite a lengths buffer in place through the C ABI, which no tensor version counter sees, so nothing is remembered."""
+    outside it a caller may rewrite a lengths buffer in place through the C ABI, which no tensor version counter sees, so nothing is remembered.  The state is
+    thread-local: a loader thread's block neither sees nor clears what the main thread's block remembers."""
 
     def __enter__(self):
-        _offset_cache_on[0] += 1
+        _offset_state.on = getattr(_offset_state, "on", 0) + 1
+        if not hasattr(_offset_state, "cache"):
+            _offset_state.cache = {}
 
     def __exit__(self, *exc):
-        _offset_cache_on[0] -= 1
-        if not _offset_cache_on[0]:
-            _offset_cache.clear()
+        _offset_state.on -= 1
+        if not _offset_state.on:
+            _offset_state.cache.clear()
 
 
 def _offsets(lengths):
     """cumulative offsets of per-cloud lengths"""
-    if not _offset_cache_on[0]:
+    if not getattr(_offset_state, "on", 0):
         return torch.cumsum(lengths, 0, dtype=torch.int32)
-    hit = _offset_cache.get(id(lengths))
+    cache = _offset_state.cache
+    hit = cache.get(id(lengths))
     if hit is not None and hit[0] is lengths and hit[1] == lengths._version:
         return hit[2]
     off = torch.cumsum(lengths, 0, dtype=torch.int32)
-    _offset_cache[id(lengths)] = (lengths, lengths._version, off)
+    cache[id(lengths)] = (lengths, lengths._version, off)
     return off
 
 
@@ -252,15 +257,23 @@ def _segmentation_inputs_radius_native(stacked_points, stacks_lengths, first_sub
                              ctypes.c_void_p(host.data_ptr()), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(stacked_points)), "cbl_pyramid")
     sizes = host.tolist()                                                    # the call waited for every one of them
     widths = mcs.tolist()                                                    # ONE device-to-host copy for the 13 table widths
-    out = {"points": [stacked_points] + [pool_p[l][:sizes[l + 1]] for l in range(nl - 1)],
+    # Everything below layer 0 is returned as an exactly sized COPY: a view would keep its layer-0-capacity buffer alive (13 full-size tables per pyramid,
+    # hundreds of MB at 100k+ points, and the loader holds two pyramids) — the deeper layers are small, so the copies are cheap; layer 0's own table is
+    # already full height and is returned as it is (cut in width only where the widest neighbourhood is below the limit).
+    def cut(table, rows, w):
+        w = min(int(w), table.shape[1])
+        if rows == table.shape[0] and w == table.shape[1]:
+            return table
+        return table[:rows, :w].clone(memory_format=torch.contiguous_format)
+    out = {"points": [stacked_points] + [pool_p[l][:sizes[l + 1]].clone() for l in range(nl - 1)],
            "batches_len": [stacks_lengths] + pool_l,
            "neighbors": [], "pools": [], "upsamples": [torch.zeros((0, 1), dtype=torch.int32, device=dev)]}
-    cut = lambda table, rows, w: (table[:rows] if w >= table.shape[1] else table[:rows, :w].contiguous())
     for l in range(nl):
         out["neighbors"].append(cut(nbs[l], sizes[l], widths[3 * l]))
         if l < nl - 1:
             out["pools"].append(cut(pools[l], sizes[l + 1], widths[3 * l + 1]))
             out["upsamples"].append(cut(ups[l], sizes[l], widths[3 * l + 2]))
+    del grids, nbs, pool_p, pools, ups                                       # the capacity-sized buffers go back to the allocator with this frame
     out["pools"].append(torch.zeros((0, 1), dtype=torch.int32, device=dev))
     return out
 

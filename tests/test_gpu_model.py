@@ -95,6 +95,13 @@ def test_neighbor_cache_does_not_change_the_forward():
     # (same indices, same values; measured 5e-7 on the first layer, 1e-5 on the logits)
     scale = float(b.abs().max())
     assert float((a - b).abs().max()) <= 1e-4 * scale and torch.allclose(la, lb, rtol=1e-4, atol=1e-6)
+    # ... and that IS the only difference: with the same processing order in both runs (index order) the cached and the uncached forward are bit-identical
+    from contrastboundary_amd import neighbor_state
+    with neighbor_state.natural_order(), torch.no_grad():
+        a, _, la, _ = M.forward_and_loss(model, crit, inputs, target)
+        b, sl = model(inputs)
+        lb = crit(b, target, sl)
+    assert torch.equal(a, b) and torch.equal(la, lb)
 
 
 @pytest.mark.gpu
@@ -115,12 +122,30 @@ def test_geometry_prefetch_on_a_side_stream_answers_every_request():
     assert torch.equal(b, c) and torch.equal(lb, lc)
     assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) and torch.allclose(la, lb, rtol=1e-4, atol=1e-6)
     assert nc1.misses == 0 and nc1.hits == nc0.hits + nc0.misses
+    # the same processing order (index order) on both sides: prefetched and inline geometry give the same bits
+    from contrastboundary_amd import neighbor_state
+    with neighbor_state.natural_order(), torch.no_grad():
+        a, _, la, _ = M.forward_and_loss(model, crit, inputs, target)
+        b, _, lb, _ = M.forward_and_loss(model, crit, inputs, target, geometry=M.prefetch_geometry(model, inputs, crit))
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(la, lb)
 
 
 @pytest.mark.gpu
-def test_graphed_training_step_matches_eager_steps():
+@pytest.mark.parametrize("natural", [False, True])
+def test_graphed_training_step_matches_eager_steps(natural):
     """the whole step (forward, criterion, backward, SGD) replayed from a hipGraph with double-buffered static geometry gives the same
-    training trajectory as eagerly issued steps (atomics make the two differ in the last bits only)"""
+    training trajectory as eagerly issued steps (atomics make the two differ in the last bits only).  natural = True: both runs walk the points in
+    index order (neighbor_state.natural_order), which removes the one legitimate difference between them that is NOT an atomic — the processing order
+    of the fused attention layers' BatchNorm sums — so the comparison is held to the spread of two reruns of the same eager trajectory."""
+    import contextlib
+    import copy
+    from contrastboundary_amd import neighbor_state
+    with (neighbor_state.natural_order() if natural else contextlib.nullcontext()):
+        _graphed_vs_eager(natural)
+
+
+def _graphed_vs_eager(natural):
     import copy
     M, model, crit, g = build(CASES[0])
     model = model.cuda().train()
@@ -158,15 +183,16 @@ def test_graphed_training_step_matches_eager_steps():
             step.stage(*batches[i + step.depth])
         graphed.append(loss.detach().cpu().numpy().copy())
     torch.cuda.synchronize()
-    np.testing.assert_allclose(graphed[0], eager[0], rtol=2e-3, atol=1e-5)          # same parameters, same batch: the forward pass itself
+    np.testing.assert_allclose(graphed[0], eager[0], rtol=1e-5 if natural else 2e-3, atol=1e-6 if natural else 1e-5)   # same parameters, same batch: the forward pass itself
     # Later steps: the two runs differ by ROUNDING at step 0 (the static geometry's searches and the per-forward cache's searches build different grids, so
     # the fused attention layers sum their BatchNorm statistics in a different processing order; fp32 atomics in the small deep stages), and training
     # amplifies a difference ~30-50 x per step on this scene (tools/traj_determinism.py: reruns of the SAME eager trajectory spread 8e-7 / 4e-5 / 1.4e-3
     # at steps 1 / 2 / 3).  A broken replay (stale buffers, a lost dependency) shows as O(1) garbage at step 1, far outside these bounds.
-    for (a, b), rtol in zip(zip(graphed[1:], eager[1:]), (5e-3, 3e-2, 2e-1)):
+    # In index order on both sides only the atomics are left: 25 - 100 x the rerun spread above, and the weight drift bound of round 3.
+    for (a, b), rtol in zip(zip(graphed[1:], eager[1:]), (1e-4, 2e-3, 3e-2) if natural else (5e-3, 3e-2, 2e-1)):
         np.testing.assert_allclose(a, b, rtol=rtol, atol=1e-4)
     w_g, w_e = model.enc1[0].linear.weight.detach(), twin.enc1[0].linear.weight.detach()
-    assert float((w_g - w_e).norm() / w_e.norm()) < 2e-2
+    assert float((w_g - w_e).norm() / w_e.norm()) < (1e-2 if natural else 2e-2)
     # the in-place refresh really holds the staged batch's geometry: bitwise the eagerly computed one
     from contrastboundary_amd import geometry
     step.stage(inputs2, target2)

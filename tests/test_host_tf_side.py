@@ -74,7 +74,30 @@ def test_cumulative_offsets_are_cached_per_tensor_and_version():
         assert tf_ops._offsets(lens).tolist() == [3, 9, 14]
         other = torch.tensor([3, 6, 5], dtype=torch.int32)
         assert tf_ops._offsets(other) is not tf_ops._offsets(lens)
-    assert not tf_ops._offset_cache                                        # dropped with the block
+    assert not tf_ops._offset_state.cache                                     # dropped with the block
+
+
+def test_offset_cache_is_per_thread():
+    """the pyramid loader builds on a thread of its own: its block must neither switch the main thread's caching on nor clear what the main
+    thread's block remembers"""
+    import threading
+    from contrastboundary_amd import tf_ops
+    lens = torch.tensor([2, 2], dtype=torch.int32)
+    seen = {}
+
+    def worker():
+        seen["on_before"] = getattr(tf_ops._offset_state, "on", 0)
+        with tf_ops._offsets_cached():
+            a = tf_ops._offsets(lens)
+            seen["cached_inside"] = tf_ops._offsets(lens) is a
+        seen["on_after"] = tf_ops._offset_state.on
+
+    with tf_ops._offsets_cached():
+        mine = tf_ops._offsets(lens)
+        t = threading.Thread(target=worker); t.start(); t.join()
+        assert tf_ops._offsets(lens) is mine                                # the worker's exit did not clear this thread's cache
+    assert seen == {"on_before": 0, "cached_inside": True, "on_after": 0}
+    assert tf_ops._offsets(lens) is not mine                                # and outside every block nothing is remembered
 
 
 def test_capture_flag_is_scoped_to_its_streams():
