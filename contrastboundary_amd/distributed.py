@@ -87,7 +87,8 @@ class GradientReducer:
         assert self.params, "no trainable parameters"
         dev, dt = self.params[0].device, self.params[0].dtype
         assert all(p.device == dev and p.dtype == dt for p in self.params), "one device and one dtype per reducer"
-        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.grouped = bool(dist.is_available() and dist.is_initialized())          # a process group exists: the collective is ISSUED, whatever its size
+        self.world = dist.get_world_size(process_group) if self.grouped else 1
         # flat layout in REVERSE parameter order: bucket 0 holds the last layers, whose gradients arrive first
         order = list(reversed(range(len(self.params))))
         sizes = [self.params[i].numel() for i in order]
@@ -124,7 +125,7 @@ class GradientReducer:
     # ---- collective issue
     def _launch(self, k):
         s, e, _ = self.buckets[k]
-        if self.world > 1:
+        if self.grouped:                                             # also on a ONE-rank group: hooks + flat buffer + RCCL run together (no special case to hide behind)
             self.works.append(self.dist.all_reduce(self.flat[s:e], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _arrived(self, i):
@@ -205,3 +206,185 @@ def broadcast_buffers(modules, src=0):
                 b.copy_(flat[pos:pos + b.numel()].view_as(b)); pos += b.numel()
             n += len(group)
     return n
+
+
+class FlatState:
+    """The trainable parameters of `modules` as views of ONE flat fp32 buffer per optimizer param group, their gradients as views of a second one, the
+    floating-point buffers (BatchNorm running statistics) as views of a third — what makes a data-parallel step cost what a single-GPU step costs:
+
+      * gradients: the captured backward leaves every `.grad` where autograd put it (no per-parameter accumulate kernel), `pack()` gathers them into the flat
+        gradient buffer with a handful of multi-tensor copies (inside the graph), and the bucketed all-reduce runs over slices of that buffer;
+      * optimizer: `flat_optimizer(opt)` is the caller's optimizer re-created over ONE Parameter per param group (the flat buffer, `.grad` = the flat gradient):
+        the update of 300 tensors is one fused kernel.  Valid for optimizers whose update is elementwise (SGD / momentum / weight decay, Adam, AdamW: every
+        optimizer the reference configures, train.py:154); hyper-parameters are re-read from the caller's optimizer before every step (LR schedulers keep working);
+      * buffers: DDP re-broadcasts rank 0's buffers at the start of every forward (broadcast_buffers=True, train.py:181-189): here ONE broadcast of the flat buffer
+        (int64 batch counters ride in a second, tiny one).
+
+    Build it AFTER the modules are on their device (a later .cuda() / .to() re-allocates every tensor and drops the views) and BEFORE any graph capture."""
+
+    ALIGN = 64                                                       # elements
+
+    def __init__(self, modules, optimizer=None):
+        seen, groups = set(), []
+        if optimizer is not None:
+            for g in optimizer.param_groups:
+                ps = [p for p in g["params"] if p.requires_grad and id(p) not in seen]
+                seen.update(id(p) for p in ps)
+                groups.append(ps)
+        rest = [p for m in modules for p in m.parameters() if p.requires_grad and id(p) not in seen]
+        uniq = []
+        for p in rest:
+            if id(p) not in seen:
+                seen.add(id(p)); uniq.append(p)
+        if uniq:
+            assert optimizer is None, "trainable parameters the optimizer does not hold"
+            groups.append(uniq)
+        self.groups = [g for g in groups if g]
+        assert self.groups, "no trainable parameters"
+        dev, dt = self.groups[0][0].device, self.groups[0][0].dtype
+        assert all(p.device == dev and p.dtype == dt for g in self.groups for p in g), "one device and one dtype"
+        self.params = [p for g in self.groups for p in g]
+        # every tensor starts on a 256-byte boundary of the flat buffer: the kernels take parameters by raw pointer and load them 16 bytes at a time
+        # (cbl_host_aligned16 in the C entries); the padding holds zeros for ever (zero gradient, weight decay of 0 is 0)
+        al = self.ALIGN
+        total = sum((p.numel() + al - 1) // al * al for p in self.params)
+        self.flat_param = torch.zeros(total, dtype=dt, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=dt, device=dev)
+        self.group_range, self.grad_views = [], []
+        pos = 0
+        with torch.no_grad():
+            for g in self.groups:
+                start = pos
+                for p in g:
+                    n = p.numel()
+                    view = self.flat_param[pos:pos + n].view(p.shape)
+                    view.copy_(p.data)
+                    p.data = view                                    # the Parameter object (and everything that references it) stays; its storage is the flat buffer now
+                    self.grad_views.append(self.flat_grad[pos:pos + n].view(p.shape))
+                    pos += (n + al - 1) // al * al
+                self.group_range.append((start, pos))
+        # buffers: floating point ones in one flat tensor, integer ones (num_batches_tracked) in another
+        self.flat_buffers = {}
+        bufs, seen_b = [], set()
+        for m in modules:
+            for mod in m.modules():
+                for name, b in mod._buffers.items():
+                    if b is not None and id(b) not in seen_b:
+                        seen_b.add(id(b)); bufs.append((mod, name, b))
+        for key, pick in (("float", lambda b: b.is_floating_point()), ("int", lambda b: not b.is_floating_point())):
+            mine = [(mod, name, b) for mod, name, b in bufs if pick(b) and b.device == dev]
+            if not mine:
+                continue
+            dtb = mine[0][2].dtype
+            mine = [t for t in mine if t[2].dtype == dtb]
+            flat = torch.zeros(sum((b.numel() + 15) // 16 * 16 for _, _, b in mine), dtype=dtb, device=dev)
+            pos = 0
+            with torch.no_grad():
+                for mod, name, b in mine:
+                    n = b.numel()
+                    view = flat[pos:pos + n].view(b.shape)
+                    view.copy_(b)
+                    mod._buffers[name] = view
+                    pos += (n + 15) // 16 * 16
+            self.flat_buffers[key] = flat
+
+    # ---- gradients
+    def drop_grads(self):
+        """before a backward pass whose gradients `pack()` will collect: autograd then WRITES each gradient (a fresh tensor) instead of accumulating into one"""
+        for p in self.params:
+            p.grad = None
+
+    def pack(self):
+        """every parameter's gradient into its slice of the flat gradient buffer: multi-tensor copies (a few launches for hundreds of tensors); parameters that
+        received none contribute zeros"""
+        have = [(v, p.grad) for v, p in zip(self.grad_views, self.params) if p.grad is not None]
+        if len(have) != len(self.params):
+            self.flat_grad.zero_()
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+
+    # ---- optimizer
+    def flat_optimizer(self, optimizer):
+        """the same optimizer class and hyper-parameters over one Parameter per param group (storage: the flat buffers)"""
+        assert len(optimizer.param_groups) == len(self.groups), "FlatState was built for another optimizer"
+        self._src_optimizer = optimizer
+        self.flat_tensors = []
+        groups = []
+        for g, (s0, s1) in zip(optimizer.param_groups, self.group_range):
+            P = torch.nn.Parameter(self.flat_param[s0:s1], requires_grad=True)
+            P.grad = self.flat_grad[s0:s1]
+            self.flat_tensors.append(P)
+            groups.append(dict({k: v for k, v in g.items() if k != "params"}, params=[P]))
+        flat = type(optimizer)(groups)
+        # momentum the caller's optimizer already holds (warm-up steps) moves over: SGD's buffer is elementwise state like the parameter itself
+        for g, P, (s0, s1), ps in zip(optimizer.param_groups, self.flat_tensors, self.group_range, self.groups):
+            bufs = [optimizer.state.get(p, {}).get("momentum_buffer") for p in ps]
+            if any(b is not None for b in bufs):
+                mom = torch.zeros(s1 - s0, dtype=P.dtype, device=P.device)
+                pos = 0
+                for p, b in zip(ps, bufs):
+                    if b is not None:
+                        mom[pos:pos + p.numel()].copy_(b.reshape(-1))
+                    pos += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+                flat.state[P]["momentum_buffer"] = mom
+        self.optimizer = flat
+        return flat
+
+    def step(self):
+        """one optimizer step on the flat buffers; the caller's optimizer is the source of truth for the hyper-parameters (an LR scheduler steps THAT one)"""
+        for gs, gf in zip(self._src_optimizer.param_groups, self.optimizer.param_groups):
+            for k, v in gs.items():
+                if k != "params":
+                    gf[k] = v
+        self.optimizer.step()
+
+    # ---- buffers
+    def broadcast_buffers(self, src=0, group=None):
+        """rank `src`'s buffers on every rank: one collective per flat buffer (two in all)"""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return 0
+        for flat in self.flat_buffers.values():
+            dist.broadcast(flat, src, group=group)
+        return len(self.flat_buffers)
+
+
+class PackedGradientReducer:
+    """GradientReducer's role for a step whose gradients arrive PACKED (FlatState.pack inside a replayed hipGraph): the flat gradient buffer is cut into
+    buckets of `bucket_bytes` in parameter order and `reduce_all()` issues one all-reduce per bucket, in order, behind the replay, then averages.  The
+    collective is issued whenever a process group exists — also a one-rank group, so that a 1-GPU box runs RCCL, the packing and the graph together."""
+
+    def __init__(self, state, bucket_bytes=8 << 20, process_group=None):
+        import torch.distributed as dist
+        self.dist, self.group, self.state = dist, process_group, state
+        self.flat = state.flat_grad
+        self.grouped = bool(dist.is_available() and dist.is_initialized())
+        self.world = dist.get_world_size(process_group) if self.grouped else 1
+        per = max(1, int(bucket_bytes) // self.flat.element_size())
+        n = self.flat.numel()
+        self.buckets = [(s, min(n, s + per), ()) for s in range(0, n, per)]
+        self.params = state.params
+        self.handles = []
+
+    def reduce_all(self):
+        if not self.grouped:
+            return
+        works = [self.dist.all_reduce(self.flat[s:e], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True) for s, e, _ in self.buckets]
+        for w in works:
+            w.wait()                                                 # the current stream waits for the collective's stream; the host does not block (NCCL / RCCL backend)
+        if self.world > 1:
+            self.flat.mul_(1.0 / self.world)
+
+    def zero_grad(self):
+        self.state.drop_grads()
+
+    def finish(self):
+        """eager use (warm-up steps): pack what the backward produced, reduce"""
+        self.state.pack()
+        self.reduce_all()
+
+    def rehook(self):
+        pass
+
+    def remove(self):
+        pass

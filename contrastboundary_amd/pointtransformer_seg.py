@@ -237,6 +237,9 @@ class GraphedTrainStep:
         behind the replay and the optimizer step behind that, eagerly."""
         from . import geometry
         self.model, self.criterion, self.optimizer, self.reducer = model, criterion, optimizer, reducer
+        # a distributed.PackedGradientReducer: gradients are packed into the flat buffer INSIDE the graph, the optimizer is its FlatState's one-tensor twin
+        self.packed = getattr(reducer, "state", None)
+        self.events = None                                            # profile(): per-step (start, replayed, reduced, stepped) events
         plan = dict(stride=model.STRIDE, nsample=model.NSAMPLE, multi_head=model.head is not None)
         if getattr(criterion, "contrast_head", None) is not None:
             plan.update(cbl_nsample=model.config.nsample, nstride=model.config.nstride)
@@ -253,7 +256,10 @@ class GraphedTrainStep:
                 loss.sum().backward()
                 if reducer is not None:
                     reducer.finish()
-                optimizer.step()
+                if self.packed is not None:
+                    self.packed.step()
+                else:
+                    optimizer.step()
         torch.cuda.current_stream(dev).wait_stream(side)
         self.depth = min(3, max(1, int(depth)))
         from . import hotpath
@@ -282,6 +288,8 @@ class GraphedTrainStep:
                     reducer.zero_grad()
                     out, _, loss, _ = forward_and_loss(model, criterion, st_in, st_tg, geometry=geom)
                     loss.sum().backward()
+                    if self.packed is not None:
+                        self.packed.pack()                           # a handful of multi-tensor copies: every gradient into its slice of the flat buffer
             self.sets.append(dict(inputs=st_in, target=st_tg, geom=geom, graph=graph, loss=loss, logits=out))
         self.run_turn = self.stage_turn = self.staged = 0
 
@@ -318,12 +326,49 @@ class GraphedTrainStep:
         s = self.sets[self.run_turn]
         cur = torch.cuda.current_stream(s["target"].device)
         cur.wait_event(s["geom"].ready)
+        ev = None
+        if self.events is not None:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record(cur)
+        if self.reducer is not None:
+            # DDP's broadcast_buffers (train.py:181-189): rank 0's running statistics on every rank before the forward that updates them — the fused
+            # attention layers update them INSIDE the replayed graph, so without this the ranks' statistics drift apart (one flat collective when packed)
+            if self.packed is not None:
+                self.packed.broadcast_buffers()
+            elif self.reducer.world > 1:
+                from . import distributed as D
+                D.broadcast_buffers([m for m in (self.model, self.criterion) if isinstance(m, nn.Module)])
         s["graph"].replay()
+        if ev:
+            ev[1].record(cur)
         if self.reducer is not None:
             self.reducer.reduce_all()                               # every bucket, in order, behind the replay; averaged on this stream
-            self.optimizer.step()
+            if ev:
+                ev[2].record(cur)
+            if self.packed is not None:
+                self.packed.step()                                  # one fused kernel over the flat parameter buffer
+            else:
+                self.optimizer.step()
+        elif ev:
+            ev[2].record(cur)
+        if ev:
+            ev[3].record(cur)
+            self.events.append(ev)
         s["done"] = torch.cuda.Event()
         s["done"].record(cur)
         self.run_turn = (self.run_turn + 1) % len(self.sets)
         self.staged -= 1
         return s["loss"], s["logits"]
+
+    def profile(self, on=True):
+        """record four events per run() from now on: before the replay, behind it, behind the gradient all-reduce, behind the optimizer step"""
+        self.events = [] if on else None
+
+    def profile_summary(self):
+        """-> mean milliseconds per step of the three segments (synchronises); {} when nothing was recorded"""
+        if not self.events:
+            return {}
+        torch.cuda.synchronize()
+        n = len(self.events)
+        seg = lambda a, b: sum(e[a].elapsed_time(e[b]) for e in self.events) / n
+        return {"steps": n, "replay_ms": seg(0, 1), "allreduce_ms": seg(1, 2), "optimizer_ms": seg(2, 3)}

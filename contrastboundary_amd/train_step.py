@@ -20,7 +20,7 @@ def _pt_forward_loss(model, criterion, inputs, target):
 
 
 class DataParallelTrainer:
-    def __init__(self, model, criterion, optimizer, bucket_bytes=8 << 20, forward_loss=None, broadcast=True, sync_buffers=True):
+    def __init__(self, model, criterion, optimizer, bucket_bytes=8 << 20, forward_loss=None, broadcast=True, sync_buffers=True, flat=False):
         """The criterion is a module too: the reference wraps it in DistributedDataParallel whenever it has trainable parameters (the CBL head's
         `project` MLP, train.py:189), so its parameters are broadcast and averaged with the model's, and — sync_buffers, DDP's broadcast_buffers
         default — rank 0's buffers (BatchNorm running statistics) are re-broadcast at the start of every step, model's and criterion's alike."""
@@ -31,26 +31,42 @@ class DataParallelTrainer:
             for m in self.modules:
                 D.broadcast_parameters(m)                           # rank 0's initial weights (and buffers) everywhere
         params = [p for m in self.modules for p in m.parameters()]
-        self.reducer = D.GradientReducer(params, bucket_bytes=bucket_bytes)
+        self.state = None
+        if flat:
+            # parameters, gradients and buffers as views of flat buffers (distributed.FlatState): the step then costs what a single-GPU step costs —
+            # gradients packed by a few multi-tensor copies, bucketed all-reduce over slices, ONE fused optimizer kernel, ONE buffer broadcast
+            self.state = D.FlatState(self.modules, optimizer)
+            self.state.flat_optimizer(optimizer)
+            self.reducer = D.PackedGradientReducer(self.state, bucket_bytes=bucket_bytes)
+        else:
+            self.reducer = D.GradientReducer(params, bucket_bytes=bucket_bytes)
         self.world = self.reducer.world
         self.sync_buffers = sync_buffers
 
     def step(self, inputs, target):
         """buffers from rank 0 -> zero -> forward -> backward (buckets all-reduced as they complete) -> wait + average -> optimizer step; returns the loss vector"""
         if self.sync_buffers:
-            D.broadcast_buffers(self.modules)
+            if self.state is not None:
+                self.state.broadcast_buffers()
+            else:
+                D.broadcast_buffers(self.modules)
         self.reducer.zero_grad()
         loss = self.forward_loss(self.model, self.criterion, inputs, target)
         loss.sum().backward()
         from . import neighbor_state
         neighbor_state.release_unowned_transposes()                 # tables the backward built for itself (no neighbour cache on autograd's thread)
         self.reducer.finish()
-        self.optimizer.step()
+        if self.state is not None:
+            self.state.step()
+        else:
+            self.optimizer.step()
         return loss.detach()
 
     def describe(self):
         r = self.reducer
         return {"gradient_bytes": r.flat.numel() * r.flat.element_size(), "buckets": len(r.buckets),
-                "bucket_bytes": [(e - s) * r.flat.element_size() for s, e, _ in r.buckets], "ranks": r.world,
+                "bucket_bytes": [(e - s) * r.flat.element_size() for s, e, _ in r.buckets], "ranks": r.world, "collective_issued": bool(r.grouped),
+                "layout": "flat parameter / gradient / buffer tensors, gradients packed behind the backward, one fused optimizer kernel" if self.state is not None
+                          else "every .grad a view of one flat buffer, accumulated in place by autograd",
                 "overlap": "bucket k's all-reduce is started by autograd's post-accumulate hooks when its last gradient is written (reverse parameter order), "
                            "and joined before the optimizer step"}

@@ -317,3 +317,119 @@ def test_trainer_averages_criterion_parameters_and_broadcasts_buffers():
     assert np.array_equal(b0, b1)                                     # after the broadcast: rank 0's running statistics everywhere
     assert not np.array_equal(own0, own1)                             # ... which the ranks' own batches had moved apart within the step
     assert h0 == 0 and h1 == n0                                       # hooks can be re-registered after a capture removed them
+
+
+# ---- round 5: the flat state (distributed.FlatState + PackedGradientReducer): parameters / gradients / buffers as views of flat tensors, gradients
+#      packed behind the backward, ONE optimizer kernel, ONE buffer broadcast — and the collective issued on a ONE-rank group too --------------------
+def _flat_trainer_worker(rank, world, port, out, flat):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from contrastboundary_amd import distributed as D, train_step
+    D.init("gloo")
+    if world == 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    torch.manual_seed(50 + rank)
+    model, crit = _BnNet(), _Crit()
+    opt = torch.optim.SGD(list(model.parameters()) + list(crit.parameters()), lr=0.1, momentum=0.9, weight_decay=1e-3)
+    tr = train_step.DataParallelTrainer(model, crit, opt, bucket_bytes=64, forward_loss=lambda m, c, x, y: c(m(x), y), flat=flat)
+    issued = []
+    if flat:
+        import torch.distributed as dist
+        orig = dist.all_reduce
+        dist.all_reduce = lambda *a, **k: (issued.append(1), orig(*a, **k))[1]
+    x, y = _rank_batch(rank)
+    for it in range(4):
+        if it == 2:
+            for g in opt.param_groups:                                # an LR scheduler steps the CALLER's optimizer: the flat twin must follow
+                g["lr"] = 0.05
+        tr.step(x, y)
+    params = torch.cat([p.detach().reshape(-1) for m in (model, crit) for p in m.parameters()])
+    bufs = torch.cat([b.reshape(-1).float() for m in (model, crit) for b in m.buffers()])
+    aligned = views = True
+    if flat:
+        st = tr.state
+        lo, hi = st.flat_param.data_ptr(), st.flat_param.data_ptr() + 4 * st.flat_param.numel()
+        views = all(lo <= p.data_ptr() < hi for m in (model, crit) for p in m.parameters())
+        aligned = all((p.data_ptr() - lo) % 256 == 0 for m in (model, crit) for p in m.parameters())
+        fb = st.flat_buffers["float"]
+        views = views and all(fb.data_ptr() <= b.data_ptr() < fb.data_ptr() + 4 * fb.numel() for m in (model, crit) for b in m.buffers() if b.is_floating_point())
+    out.put((rank, params.numpy().copy(), bufs.numpy().copy(), views, aligned, len(issued), len(tr.reducer.buckets)))
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def _run_flat(world, flat):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_flat_trainer_worker, args=(r, world, port, q, flat)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    return res
+
+
+@rendezvous_retry
+def test_flat_state_trainer_equals_the_hook_trainer_over_two_ranks():
+    """four steps (momentum, weight decay, a learning-rate change between steps): the packed-gradient / one-tensor-optimizer step lands on the SAME parameters
+    as round 4's per-tensor step, replicas identical, parameters and buffers views of the flat tensors on 256-byte boundaries"""
+    import numpy as np
+    a, b = _run_flat(2, True), _run_flat(2, False)
+    assert np.array_equal(a[0][1], a[1][1]) and np.array_equal(b[0][1], b[1][1])          # replicas identical, either layout
+    np.testing.assert_allclose(a[0][1], b[0][1], rtol=1e-6, atol=1e-7)                   # same trajectory (elementwise update: flat == per tensor)
+    np.testing.assert_allclose(a[0][2], b[0][2], rtol=1e-6, atol=1e-7)
+    assert all(r[3] and r[4] for r in a)
+    assert all(r[5] == 4 * r[6] and r[6] >= 2 for r in a)                                # every bucket all-reduced in every step
+
+
+@rendezvous_retry
+def test_flat_state_issues_the_collective_on_a_one_rank_group():
+    """a one-rank run must exercise packing + collective + optimizer together — the all-reduce is issued whenever a process group exists"""
+    (rank, params, bufs, views, aligned, issued, nbuckets), = _run_flat(1, True)
+    assert views and aligned and issued == 4 * nbuckets and nbuckets >= 2
+    # ... and the hook reducer does the same on a one-rank group
+    import torch.distributed as dist
+    from contrastboundary_amd import distributed as D
+    port = _free_port()
+    dist.init_process_group(backend="gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        m = _tiny_model(3)
+        red = D.GradientReducer(m.parameters(), bucket_bytes=128)
+        calls = []
+        orig = dist.all_reduce
+        dist.all_reduce = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            x, y = _rank_batch(0)
+            red.zero_grad(); ((m(x) - y) ** 2).mean().backward(); red.finish()
+        finally:
+            dist.all_reduce = orig
+        assert red.grouped and red.world == 1 and len(calls) == len(red.buckets)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_state_single_process_matches_the_plain_optimizer():
+    """no process group: FlatState + its one-tensor optimizer follow torch.optim.SGD over the separate tensors step for step, momentum carried over from
+    steps the caller's optimizer took before the state was built (the graph step's warm-up)"""
+    from contrastboundary_amd import distributed as D
+    torch.manual_seed(5)
+    a, b = _BnNet(), _BnNet()
+    b.load_state_dict(a.state_dict())
+    oa = torch.optim.SGD(a.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-3)
+    ob = torch.optim.SGD(b.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-3)
+    x, y = _rank_batch(0)
+    for m, o in ((a, oa), (b, ob)):                                   # one plain step on both: `ob` holds momentum when the state takes over
+        o.zero_grad(); ((m(x) - y) ** 2).mean().backward(); o.step()
+    st = D.FlatState([b], ob)
+    st.flat_optimizer(ob)
+    red = D.PackedGradientReducer(st, bucket_bytes=64)
+    assert not red.grouped
+    for _ in range(3):
+        oa.zero_grad(); ((a(x) - y) ** 2).mean().backward(); oa.step()
+        red.zero_grad(); ((b(x) - y) ** 2).mean().backward(); red.finish(); st.step()
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.allclose(pa, pb, rtol=1e-6, atol=1e-7)
+    for ba, bb in zip(a.buffers(), b.buffers()):
+        assert torch.allclose(ba.float(), bb.float(), rtol=1e-6, atol=1e-7)
+    assert b.state_dict().keys() == a.state_dict().keys()

@@ -40,7 +40,9 @@ def parse(argv=None):
     ap.add_argument("--foreach-sgd", action="store_true", help="torch.optim.SGD's default foreach implementation instead of fused=True (the same update in ~3 kernels instead of ~32)")
     ap.add_argument("--prefetch", action="store_true", help="geometry (FPS + every neighbour search) of the NEXT step on a side stream, one step ahead")
     ap.add_argument("--bucket-mb", type=float, default=8.0, help="gradient bucket size of the all-reduce (xGMI rings want few large messages)")
-    ap.add_argument("--single-rank-group", action="store_true", help="N = 1 through a one-rank RCCL group and the gradient reducer")
+    ap.add_argument("--single-rank-group", action="store_true", help="N = 1 through a one-rank RCCL group and the gradient reducer (the all-reduce IS issued)")
+    ap.add_argument("--hook-reducer", action="store_true", help="data-parallel runs: round 4's layout (every .grad a view of the flat buffer, accumulated in place, per-tensor optimizer) "
+                                                               "instead of the flat state (packed gradients, one fused optimizer kernel, one buffer broadcast)")
     ap.add_argument("--host-dry-run", action="store_true")
     return ap.parse_args(argv)
 
@@ -130,7 +132,7 @@ def run(a, D, world, rank, local):
     inputs = {"points": torch.from_numpy(np.concatenate(xs)).cuda(), "features": torch.rand(a.n * len(mine), 3, device="cuda"),
               "offset": torch.tensor(np.cumsum([a.n] * len(mine)), dtype=torch.int32, device="cuda")}
     target = torch.from_numpy(np.concatenate(ls)).cuda()
-    trainer = train_step.DataParallelTrainer(model, crit, opt, bucket_bytes=int(a.bucket_mb * (1 << 20))) if dist_on else None
+    trainer = train_step.DataParallelTrainer(model, crit, opt, bucket_bytes=int(a.bucket_mb * (1 << 20)), flat=not a.hook_reducer) if dist_on else None
     nc_last = [None]
     geom_next = [M.prefetch_geometry(model, inputs, crit) if a.prefetch else None]
 
@@ -138,6 +140,7 @@ def run(a, D, world, rank, local):
         gstep = M.GraphedTrainStep(model, crit, opt, inputs, target, depth=a.depth, reducer=trainer.reducer if trainer else None)
         for _ in range(gstep.depth):
             gstep.stage(inputs, target)
+        gstep.profile(True)                                          # four event records per step: replay / all-reduce / optimizer segments on the step's stream
 
         def step():                                                  # replay batch t while batches t+1 .. t+depth are staged (here: the same scenes again)
             loss, _ = gstep.run()
@@ -171,11 +174,15 @@ def run(a, D, world, rank, local):
 
     elapsed, loss = timed(step, a, torch.cuda.synchronize, D)
     dt = elapsed / a.steps
+    segments = None
+    if a.graph:
+        gstep.events = gstep.events[-a.steps:]                       # the timed steps only
+        segments = gstep.profile_summary()
     nc = nc_last[0]
     out = {"workload": f"PointTransformerSeg+CBL train step, {a.scenes} x S-room({a.n}) per rank", "n_gpus": world, "ranks": timed.ranks, "ms_per_step": dt * 1e3,
            "points_per_s": a.n * a.scenes * world / dt, "scaling": "weak", "scenes_of_rank0": mine,
            "knn_requests": None if nc is None else nc.hits + nc.misses, "knn_searches": None if nc is None else nc.misses,
-           "geometry_prefetch": bool(a.prefetch or a.graph), "hipgraph": bool(a.graph), "blas": a.blas,
+           "geometry_prefetch": bool(a.prefetch or a.graph), "hipgraph": bool(a.graph), "blas": a.blas, "segments_ms": segments,
            "grad_allreduce": None if trainer is None else dict(trainer.describe(), mode="behind the graph replay, in bucket order" if a.graph else "from autograd hooks, beside the backward pass"),
            "loss": [round(float(v), 5) for v in loss.detach().cpu()]}
     if rank == 0:
