@@ -30,6 +30,9 @@ constexpr int PT_BLOCK = 512;                       // 8 waves (256-thread workg
 constexpr int PT_WPB = PT_BLOCK / 64;
 constexpr int PT_MAX_ROWS = 512;                    // partial rows of a pass = its workgroups
 constexpr int PT_NARROW_BLOCK = 256;
+// element indices inside the tile passes are 32-bit (one v_lshl_add_u64 per address instead of a sign extension, a 64-bit multiply and a 64-bit add: a third of the
+// address arithmetic of a tile); pt_shape_ok bounds n K max(3, C / 8) and n C below 2^32
+using pt_ix = unsigned;
 
 // forward constants (floats) written by the finalize kernels, kept for the backward pass
 constexpr int PT_CST_P = 0;                         // [4][4]  scale, shift, mean, invstd of BN_p (3 channels)
@@ -136,13 +139,13 @@ __device__ __forceinline__ PtStaged<NX> pt_stage_rows(const float* __restrict__ 
     PtStaged<NX> r;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     const int piece = lo < C / 4 ? lo : 0;                           // C = 32: a row is 8 pieces; the upper lanes fetch piece 0 again (never read back)
-    r.k0 = *reinterpret_cast<const float4*>(rows + (size_t)j.x * C + 4 * piece);
-    r.k1 = *reinterpret_cast<const float4*>(rows + (size_t)j.y * C + 4 * piece);
-    r.k2 = *reinterpret_cast<const float4*>(rows + (size_t)j.z * C + 4 * piece);
-    r.k3 = *reinterpret_cast<const float4*>(rows + (size_t)j.w * C + 4 * piece);
+    r.k0 = *reinterpret_cast<const float4*>(rows + (pt_ix)j.x * C + 4 * piece);
+    r.k1 = *reinterpret_cast<const float4*>(rows + (pt_ix)j.y * C + 4 * piece);
+    r.k2 = *reinterpret_cast<const float4*>(rows + (pt_ix)j.z * C + 4 * piece);
+    r.k3 = *reinterpret_cast<const float4*>(rows + (pt_ix)j.w * C + 4 * piece);
     r.x0 = zero; r.x1 = zero;
-    if (NX >= 1 && ((4 * hi) % K) == 0) r.x0 = *reinterpret_cast<const float4*>(xa + (size_t)iD * C + 4 * piece);
-    if (NX >= 2 && ((4 * hi) % K) == 0) r.x1 = *reinterpret_cast<const float4*>(xb + (size_t)iD * C + 4 * piece);
+    if (NX >= 1 && ((4 * hi) % K) == 0) r.x0 = *reinterpret_cast<const float4*>(xa + (pt_ix)iD * C + 4 * piece);
+    if (NX >= 2 && ((4 * hi) % K) == 0) r.x1 = *reinterpret_cast<const float4*>(xb + (pt_ix)iD * C + 4 * piece);
     return r;
 }
 template <int K, int NX>
@@ -343,13 +346,13 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_wstats_kernel(int n, const int* _
     struct S1 { int4 j; float p0v; };
     pt_pipeline(ntiles,
         [&](unsigned tl) { return pt_stage0<K>(tl, ntiles, n, order, lo, hi); },
-        [&](const PtS0& a) { S1 b; b.j = *reinterpret_cast<const int4*>(idx + a.pD); b.p0v = hi < 3 ? p0[3 * (size_t)a.pA + hi] : 0.f; return b; },
+        [&](const PtS0& a) { S1 b; b.j = *reinterpret_cast<const int4*>(idx + a.pD); b.p0v = hi < 3 ? p0[3 * (pt_ix)a.pA + hi] : 0.f; return b; },
         [&](const PtS0& a, const S1& b) { return pt_stage_rows<C, K, 1>(xk, b.j, xq, nullptr, a.iD, lo, hi); },
         [&](const PtS0& a, const S1& b, const PtStaged<1>& r) {
             pt_stage_store<K, 1>(T, r, lo, hi);
             // p1 of (pair, d = hi): this lane's B operand; hi = 3 carries the 1 that multiplies the bias
             const float p1x = fmaxf(fmaf(b.p0v, psc, psh), 0.f);
-            if (hi < 3 && a.vA) p1[3 * (size_t)a.pA + hi] = p1x;
+            if (hi < 3 && a.vA) p1[3 * (pt_ix)a.pA + hi] = p1x;
 #pragma unroll
             for (int ct = 0; ct < CT; ct++) {
                 const float4 kv = *reinterpret_cast<const float4*>(&T[lo][16 * ct + 4 * hi]), qv = *reinterpret_cast<const float4*>(&T[16 + lo / K][16 * ct + 4 * hi]);
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_kernel(int n, const int* __res
     struct S1 { int4 j; float p1x; };
     pt_pipeline(ntiles,
         [&](unsigned tl) { return pt_stage0<K>(tl, ntiles, n, order, lo, hi); },
-        [&](const PtS0& a) { S1 b; b.j = *reinterpret_cast<const int4*>(idx + a.pD); b.p1x = hi < 3 ? p1[3 * (size_t)a.pA + hi] : 1.f; return b; },
+        [&](const PtS0& a) { S1 b; b.j = *reinterpret_cast<const int4*>(idx + a.pD); b.p1x = hi < 3 ? p1[3 * (pt_ix)a.pA + hi] : 1.f; return b; },
         [&](const PtS0& a, const S1& b) { return pt_stage_rows<C, K, 1>(xk, b.j, xq, nullptr, a.iD, lo, hi); },
         [&](const PtS0& a, const S1& b, const PtStaged<1>& r) {
             pt_stage_store<K, 1>(T, r, lo, hi);
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_kernel(int n, const int* __res
             // D[pair slot 4 hi + v][g = lo]
             if (lo < G && a.vD) {
 #pragma unroll
-                for (int v = 0; v < 4; v++) { const float x = o0[v] + o1[v]; w2[(size_t)(a.pD + v) * G + lo] = x; t0 += x; t1 = fmaf(x, x, t1); }
+                for (int v = 0; v < 4; v++) { const float x = o0[v] + o1[v]; w2[(pt_ix)(a.pD + v) * G + lo] = x; t0 += x; t1 = fmaf(x, x, t1); }
             }
         });
     t0 += pt_xor16(t0); t0 += pt_xor32(t0); t1 += pt_xor16(t1); t1 += pt_xor32(t1);
@@ -492,9 +495,9 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_agg_kernel(int n, const int* __re
         [&](const PtS0& t) {
             S1 b;
             b.j = *reinterpret_cast<const int4*>(idx + t.pD);
-            b.p1x = hi < 3 ? p1[3 * (size_t)t.pA + hi] : 1.f;                     // A[pair slot lo][d = hi]
+            b.p1x = hi < 3 ? p1[3 * (pt_ix)t.pA + hi] : 1.f;                     // A[pair slot lo][d = hi]
 #pragma unroll
-            for (int v = 0; v < 4; v++) b.av[v] = a[(size_t)(t.pD + v) * G + (lo % G)];
+            for (int v = 0; v < 4; v++) b.av[v] = a[(pt_ix)(t.pD + v) * G + (lo % G)];
             return b;
         },
         [&](const PtS0& t, const S1& b) { return pt_stage_rows<C, K, NX>(xv, b.j, gout, nullptr, t.iD, lo, hi); },
@@ -511,7 +514,7 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_agg_kernel(int n, const int* __re
                 for (int ct = 0; ct < CT; ct++) {
                     float o = fmaf(b.av[3], val[ct][3], fmaf(b.av[2], val[ct][2], fmaf(b.av[1], val[ct][1], b.av[0] * val[ct][0])));
                     o = pt_point_sum<K>(o);
-                    if (t.vD && (K == 16 ? hi == 0 : (hi & 1) == 0)) out[(size_t)t.iD * C + 16 * ct + lo] = o;
+                    if (t.vD && (K == 16 ? hi == 0 : (hi & 1) == 0)) out[(pt_ix)t.iD * C + 16 * ct + lo] = o;
                 }
             } else {
                 float ga[4] = {0.f, 0.f, 0.f, 0.f};
@@ -531,7 +534,7 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_agg_kernel(int n, const int* __re
                 dot = pt_point_sum<K>(dot);
                 if (lo < G && t.vD) {
 #pragma unroll
-                    for (int v = 0; v < 4; v++) glogit[(size_t)(t.pD + v) * G + lo] = b.av[v] * (ga[v] - dot);
+                    for (int v = 0; v < 4; v++) glogit[(pt_ix)(t.pD + v) * G + lo] = b.av[v] * (ga[v] - dot);
                 }
             }
         });
@@ -607,20 +610,31 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
     constexpr int CT = C / 16, G = C / 8;
     constexpr int W = APPLY ? 4 * C : 2 * C + G * C;
     constexpr int TILEF = PT_TROWS * PT_ROWF;
-    __shared__ float lds[PT_WPB * (W > TILEF ? W : TILEF)];          // the waves' staged tiles, then the workgroup's partial row
+    constexpr int W3F = APPLY ? 4 * C : 0;                            // APPLY: the B operands of the d p1 product, one float4 per (channel block, lane)
+    __shared__ float lds[PT_WPB * (W > TILEF ? W : TILEF) + W3F];    // the waves' staged tiles (then the workgroup's partial row) | W3F  — ONE array: a second
+                                                                     // __shared__ object makes the compiler drain the prefetched loads before every LDS read
     const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4, wave = threadIdx.x >> 6;
     float (*T)[PT_ROWF] = reinterpret_cast<float (*)[PT_ROWF]>(lds + wave * TILEF);
     const PtPe<C> pe = pt_pe_load<C>(W3C, b3C, lo, hi);
-    float sc[CT], sh[CT], k1[CT], k2[CT], k3[CT], wa0[CT], wa1[CT], w3[CT][3];
+    float sc[CT], sh[CT], k1[CT], k2[CT], k3[CT], wa0[CT], wa1[CT];
+    // APPLY: B operand of d p1 = d pe . W3C (contraction over channels, pair-major A): element (k = hi -> channel 16 ct + 4 hi + v, column d = lo), kept in
+    // LDS (16 registers at C = 64 would cost the C = 32 kernels their third wave per SIMD)
+    float4* w3b = reinterpret_cast<float4*>(lds + PT_WPB * (W > TILEF ? W : TILEF));
+    if (APPLY && wave == 0) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+            const int cb = 16 * ct + 4 * hi;
+            w3b[ct * 64 + lane] = lo < 3 ? make_float4(W3C[3 * cb + lo], W3C[3 * (cb + 1) + lo], W3C[3 * (cb + 2) + lo], W3C[3 * (cb + 3) + lo]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    if (APPLY) __syncthreads();
 #pragma unroll
     for (int ct = 0; ct < CT; ct++) {
         const int c = 16 * ct + lo;
         sc[ct] = cst[PT_CST_C + c]; sh[ct] = cst[PT_CST_C + 64 + c];
-        k3[ct] = 0.f; w3[ct][0] = 0.f; w3[ct][1] = 0.f; w3[ct][2] = 0.f;
+        k3[ct] = 0.f;
         if (APPLY) {
             k1[ct] = bc[PT_BC_C + c]; k2[ct] = bc[PT_BC_C + 64 + c]; k3[ct] = bc[PT_BC_C + 128 + c];
-#pragma unroll
-            for (int d = 0; d < 3; d++) w3[ct][d] = W3C[3 * c + d];
         } else {
             k1[ct] = cst[PT_CST_C + 192 + c];                                    // invstd
             k2[ct] = -cst[PT_CST_C + 128 + c] * k1[ct];                          // - mean invstd
@@ -650,9 +664,9 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
         [&](const PtS0& t) {
             S1 b;
             b.j = *reinterpret_cast<const int4*>(idx + t.pD);
-            b.p1x = hi < 3 ? p1[3 * (size_t)t.pA + hi] : 1.f;
+            b.p1x = hi < 3 ? p1[3 * (pt_ix)t.pA + hi] : 1.f;
             b.x0 = b.x1 = b.x2 = b.x3 = 0.f;
-            const size_t ra = (size_t)t.pA * G;
+            const pt_ix ra = (pt_ix)t.pA * G;
             if (APPLY) {
                 if (hi < G) b.x0 = gw2[ra + hi];
                 if (G == 8) b.x1 = gw2[ra + hi + 4];
@@ -662,7 +676,7 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
             }
 #pragma unroll
             for (int v = 0; v < 4; v++) {
-                const size_t rd = (size_t)(t.pD + v);
+                const pt_ix rd = (pt_ix)(t.pD + v);
                 if (APPLY) { b.u[v] = lo < 3 ? p1[3 * rd + lo] : (lo == 3 ? 1.f : 0.f); b.y[v] = a[rd * G + (lo % G)]; }
                 else { b.u[v] = lo < G ? pre[rd * G + lo] : 0.f; b.y[v] = lo < G ? w2[rd * G + lo] : 0.f; }
             }
@@ -676,7 +690,7 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
             if (APPLY) {
                 if (t.vA) { da0 = b.x0; da1 = b.x1; }
             } else {
-                const size_t ra = (size_t)t.pA * G;
+                const pt_ix ra = (pt_ix)t.pA * G;
                 if (t.vA && hi < G) { da0 = fmaf(ga1[0], b.x0, fmaf(ga2[0], b.x2, ga3[0])); gw2[ra + hi] = da0; }
                 if (t.vA && G == 8) { da1 = fmaf(ga1[1], b.x1, fmaf(ga2[1], b.x3, ga3[1])); gw2[ra + hi + 4] = da1; }
             }
@@ -687,9 +701,6 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
                 if (APPLY) { nv[v] = t.vD ? b.u[v] : 0.f; av[v] = t.vD ? b.y[v] : 0.f; }
                 else { nv[v] = (t.vD && lo < G) ? fmaf(ga1[2], b.u[v], fmaf(ga2[2], b.y[v], ga3[2])) : 0.f; av[v] = 0.f; }
             }
-            float t3[4][3];
-#pragma unroll
-            for (int v = 0; v < 4; v++) { t3[v][0] = 0.f; t3[v][1] = 0.f; t3[v][2] = 0.f; }
 #pragma unroll
             for (int ct = 0; ct < CT; ct++) {
                 const float q = T[16 + (4 * hi) / K][16 * ct + lo], go = APPLY ? T[18 + (4 * hi) / K][16 * ct + lo] : 0.f;
@@ -706,8 +717,9 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
                         const float dw = t.vD ? fmaf(k1[ct], g1, fmaf(k2[ct], w[v], k3[ct])) : 0.f;
                         sq += dw;
                         const float dpe = fmaf(go, av[v], dw);
-#pragma unroll
-                        for (int d = 0; d < 3; d++) t3[v][d] = fmaf(w3[ct][d], dpe, t3[v][d]);
+                        // d pe takes the place of the x_k element this lane has just consumed (same lane, same cell: no hand-over); the tile is read
+                        // back pair-major below for the contraction over CHANNELS (d p1), which the channel-major registers cannot feed to the matrix cores
+                        T[4 * hi + v][16 * ct + lo] = dpe;
                         accw[ct] = pt_mfma(nv[v], dpe, accw[ct]);               // D[d][channel] += [p1, 1][slot][d] d pe[slot][channel]
                     } else {
                         if (t.vD) { s1[ct] += g1; s2[ct] = fmaf(g1, fmaf(w[v], k1[ct], k2[ct]), s2[ct]); }
@@ -716,14 +728,26 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
                 }
                 if (APPLY) {
                     sq = pt_point_sum<K>(sq);
-                    if (t.vD && (K == 16 ? hi == 0 : (hi & 1) == 0)) gxq[(size_t)t.iD * C + 16 * ct + lo] = -sq;
+                    if (t.vD && (K == 16 ? hi == 0 : (hi & 1) == 0)) gxq[(pt_ix)t.iD * C + 16 * ct + lo] = -sq;
                 }
             }
             if (APPLY) {
+                // d p1[slot][d] = sum over channels of d pe[slot][c] W3C[c][d]: A[slot lo][k = hi] = d pe of channel 16 ct + 4 hi + v (one 16-byte read of
+                // the parked tile per 16 channels), four steps per channel block, two independent accumulator chains
+                pt_wave_sync();
+                pt_f32x4 d0 = pt_vec4(0.f, 0.f, 0.f, 0.f), d1 = pt_vec4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int v = 0; v < 4; v++) {
-                    const float r0 = pt_row_sum(t3[v][0]), r1 = pt_row_sum(t3[v][1]), r2 = pt_row_sum(t3[v][2]);
-                    if (t.vD && lo < 3) gp1[3 * (size_t)(t.pD + v) + lo] = lo == 0 ? r0 : (lo == 1 ? r1 : r2);
+                for (int ct = 0; ct < CT; ct++) {
+                    const float4 e = *reinterpret_cast<const float4*>(&T[lo][16 * ct + 4 * hi]), b4 = w3b[ct * 64 + lane];
+                    d0 = pt_mfma(e.x, b4.x, d0);
+                    d1 = pt_mfma(e.y, b4.y, d1);
+                    d0 = pt_mfma(e.z, b4.z, d0);
+                    d1 = pt_mfma(e.w, b4.w, d1);
+                }
+                // D[slot 4 hi + v][d = lo]
+                if (t.vD && lo < 3) {
+#pragma unroll
+                    for (int v = 0; v < 4; v++) gp1[3 * (pt_ix)(t.pD + v) + lo] = d0[v] + d1[v];
                 }
             }
         });
@@ -943,7 +967,7 @@ PtWs pt_workspace(float* base, int n, int K, int C)
     return w;
 }
 
-bool pt_shape_ok(int n, int K, int C) { return n >= 1 && (K == 8 || K == 16) && (C == 32 || C == 64) && (long long)n * K < (1ll << 31); }
+bool pt_shape_ok(int n, int K, int C) { return n >= 1 && (K == 8 || K == 16) && (C == 32 || C == 64) && (long long)n * K < (1ll << 28); }   // 32-bit element indices (pt_ix): n K 8 and n C below 2^31
 
 }  // namespace
 

@@ -239,6 +239,7 @@ class GraphedTrainStep:
         self.model, self.criterion, self.optimizer, self.reducer = model, criterion, optimizer, reducer
         # a distributed.PackedGradientReducer: gradients are packed into the flat buffer INSIDE the graph, the optimizer is its FlatState's one-tensor twin
         self.packed = getattr(reducer, "state", None)
+        self.sync_buffers = True                                      # rank 0's buffers before every replay (DDP's broadcast_buffers)
         self.events = None                                            # profile(): per-step (start, replayed, reduced, stepped) events
         plan = dict(stride=model.STRIDE, nsample=model.NSAMPLE, multi_head=model.head is not None)
         if getattr(criterion, "contrast_head", None) is not None:
@@ -265,8 +266,14 @@ class GraphedTrainStep:
         from . import hotpath
         # streams with hardware queues of their own, also beside the stream the step replays on (two fresh streams can share a queue, or the step's)
         from . import geometry
-        first = geometry.side_stream(dev)
-        self.geo_streams = [first] + (hotpath.concurrent_streams(self.depth - 1, beside=[torch.cuda.current_stream(dev), first]) if self.depth > 1 else [])
+        # EVERY geometry stream is probed against the step's stream: the sampler is one workgroup for ~10 ms, and a geometry stream that shares a hardware
+        # queue with the replaying stream puts the whole step behind it; which streams share a queue depends on what the process created before
+        import os
+        if os.environ.get("CBL_GEO_STREAMS") == "unprobed_first":     # round 4's choice, kept for the A/B of tools/gpu_r05_call2.sh
+            first = geometry.side_stream(dev)
+            self.geo_streams = [first] + (hotpath.concurrent_streams(self.depth - 1, beside=[torch.cuda.current_stream(dev), first]) if self.depth > 1 else [])
+        else:
+            self.geo_streams = hotpath.concurrent_streams(self.depth, beside=[torch.cuda.current_stream(dev)])
         self.sets = []
         for _ in range(self.depth + 1):
             st_in = {k: v.clone() for k, v in inputs.items()}
@@ -328,9 +335,11 @@ class GraphedTrainStep:
         cur.wait_event(s["geom"].ready)
         ev = None
         if self.events is not None:
+            import time
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            host = [time.perf_counter()]                              # host clock at the same points: what the issuing thread itself spends in each segment
             ev[0].record(cur)
-        if self.reducer is not None:
+        if self.reducer is not None and self.sync_buffers:
             # DDP's broadcast_buffers (train.py:181-189): rank 0's running statistics on every rank before the forward that updates them — the fused
             # attention layers update them INSIDE the replayed graph, so without this the ranks' statistics drift apart (one flat collective when packed)
             if self.packed is not None:
@@ -338,22 +347,24 @@ class GraphedTrainStep:
             elif self.reducer.world > 1:
                 from . import distributed as D
                 D.broadcast_buffers([m for m in (self.model, self.criterion) if isinstance(m, nn.Module)])
+        if ev:
+            host.append(time.perf_counter())
         s["graph"].replay()
         if ev:
-            ev[1].record(cur)
+            ev[1].record(cur); host.append(time.perf_counter())
         if self.reducer is not None:
             self.reducer.reduce_all()                               # every bucket, in order, behind the replay; averaged on this stream
             if ev:
-                ev[2].record(cur)
+                ev[2].record(cur); host.append(time.perf_counter())
             if self.packed is not None:
                 self.packed.step()                                  # one fused kernel over the flat parameter buffer
             else:
                 self.optimizer.step()
         elif ev:
-            ev[2].record(cur)
+            ev[2].record(cur); host.append(time.perf_counter())
         if ev:
-            ev[3].record(cur)
-            self.events.append(ev)
+            ev[3].record(cur); host.append(time.perf_counter())
+            self.events.append(ev + [host])
         s["done"] = torch.cuda.Event()
         s["done"].record(cur)
         self.run_turn = (self.run_turn + 1) % len(self.sets)
@@ -371,4 +382,8 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         n = len(self.events)
         seg = lambda a, b: sum(e[a].elapsed_time(e[b]) for e in self.events) / n
-        return {"steps": n, "replay_ms": seg(0, 1), "allreduce_ms": seg(1, 2), "optimizer_ms": seg(2, 3)}
+        hseg = lambda a, b: sum(e[4][b] - e[4][a] for e in self.events) / n * 1e3
+        gap = sum(a[3].elapsed_time(b[0]) for a, b in zip(self.events[:-1], self.events[1:])) / max(n - 1, 1)
+        return {"steps": n, "replay_ms": seg(0, 1), "allreduce_ms": seg(1, 2), "optimizer_ms": seg(2, 3), "stream_idle_between_steps_ms": gap,
+                "host_ms": {"buffers": hseg(0, 1), "replay_launch": hseg(1, 2), "allreduce_issue": hseg(2, 3), "optimizer_issue": hseg(3, 4),
+                            "between_runs": sum(b[4][0] - a[4][4] for a, b in zip(self.events[:-1], self.events[1:])) / max(n - 1, 1) * 1e3}}

@@ -43,6 +43,7 @@ def parse(argv=None):
     ap.add_argument("--single-rank-group", action="store_true", help="N = 1 through a one-rank RCCL group and the gradient reducer (the all-reduce IS issued)")
     ap.add_argument("--hook-reducer", action="store_true", help="data-parallel runs: round 4's layout (every .grad a view of the flat buffer, accumulated in place, per-tensor optimizer) "
                                                                "instead of the flat state (packed gradients, one fused optimizer kernel, one buffer broadcast)")
+    ap.add_argument("--no-buffer-broadcast", action="store_true", help="data-parallel graph runs: skip the per-step broadcast of rank 0's buffers (bisecting the wrapper's cost)")
     ap.add_argument("--host-dry-run", action="store_true")
     return ap.parse_args(argv)
 
@@ -141,11 +142,16 @@ def run(a, D, world, rank, local):
         for _ in range(gstep.depth):
             gstep.stage(inputs, target)
         gstep.profile(True)                                          # four event records per step: replay / all-reduce / optimizer segments on the step's stream
+        gstep.sync_buffers = not a.no_buffer_broadcast
+        stage_host = []
 
         def step():                                                  # replay batch t while batches t+1 .. t+depth are staged (here: the same scenes again)
             loss, _ = gstep.run()
+            t0 = time.perf_counter()
             gstep.stage(inputs, target)
+            stage_host.append(time.perf_counter() - t0)
             return loss
+
     elif trainer is not None:
         def fwd(model_, crit_, inputs_, target_):
             geom = geom_next[0]
@@ -178,6 +184,7 @@ def run(a, D, world, rank, local):
     if a.graph:
         gstep.events = gstep.events[-a.steps:]                       # the timed steps only
         segments = gstep.profile_summary()
+        segments["host_ms"]["stage_next_batch"] = sum(stage_host[-a.steps:]) / a.steps * 1e3
     nc = nc_last[0]
     out = {"workload": f"PointTransformerSeg+CBL train step, {a.scenes} x S-room({a.n}) per rank", "n_gpus": world, "ranks": timed.ranks, "ms_per_step": dt * 1e3,
            "points_per_s": a.n * a.scenes * world / dt, "scaling": "weak", "scenes_of_rank0": mine,
