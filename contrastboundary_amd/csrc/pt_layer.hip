@@ -23,6 +23,7 @@
 // BatchNorm sums: per-workgroup partial rows, reduced in double by the finalize kernels in a fixed order (deterministic, no atomics).
 #include "cbl_common.h"
 #include <pt_wave.h>
+#include <cstdlib>
 
 namespace {
 
@@ -943,10 +944,22 @@ unsigned pt_tile_grid(long long ntiles)
     g = (g + 7) & ~7ll;
     return (unsigned)(g < 8 ? 8 : g);
 }
+// workgroups (= partial rows) of the lane-per-pair passes (p chain, narrow backward): they stream (n, K, 3 | G) tensors with one dependent
+// round trip per iteration, so they want more waves in flight than the tile passes do
+constexpr int PT_NARROW_MAX_ROWS = 2048;
+int pt_narrow_rows()
+{
+    static const int rows = [] {
+        const char* e = getenv("CBL_PT_NARROW_ROWS");               // measurement knob (tools/gpu_r05_call2.sh); default below
+        int v = e ? atoi(e) : 512;
+        return v < 1 ? 1 : (v > PT_NARROW_MAX_ROWS ? PT_NARROW_MAX_ROWS : v);
+    }();
+    return rows;
+}
 unsigned pt_pair_grid(long long npairs)
 {
     long long g = (npairs + PT_NARROW_BLOCK - 1) / PT_NARROW_BLOCK;
-    if (g > PT_MAX_ROWS) g = PT_MAX_ROWS;
+    if (g > pt_narrow_rows()) g = pt_narrow_rows();
     return (unsigned)(g < 1 ? 1 : g);
 }
 
@@ -958,15 +971,16 @@ PtWs pt_workspace(float* base, int n, int K, int C)
     PtWs w; size_t o = 0;
     auto take = [&](size_t cnt) { float* p = base ? base + o : nullptr; o += (cnt + 63) & ~(size_t)63; return p; };
     w.part_a = take((size_t)PT_MAX_ROWS * (2 * C + G * C));      // wstats, w2, reduce
-    w.part_b = take((size_t)PT_MAX_ROWS * (4 * C));              // pchain, apply
-    w.part_c = take((size_t)PT_MAX_ROWS * (3 * G + G * G));      // narrow backward
-    w.part_d = take((size_t)PT_MAX_ROWS * 16);                   // pchain backward
+    w.part_b = take((size_t)PT_MAX_ROWS * (4 * C));              // pchain (PT_NARROW_MAX_ROWS x 18 fits: static_assert below), apply
+    w.part_c = take((size_t)PT_NARROW_MAX_ROWS * (3 * G + G * G));   // narrow backward
+    w.part_d = take((size_t)PT_NARROW_MAX_ROWS * 16);            // pchain backward
     w.bc = take(PT_BC_FLOATS);
     w.glogit = take(np * G); w.pre = take(np * G); w.gw2 = take(np * G); w.gp1 = take(np * 3);
     w.floats = o;
     return w;
 }
 
+static_assert(PT_NARROW_MAX_ROWS * 18 <= PT_MAX_ROWS * 4 * 32, "pchain's partial rows share part_b with the apply pass");
 bool pt_shape_ok(int n, int K, int C) { return n >= 1 && (K == 8 || K == 16) && (C == 32 || C == 64) && (long long)n * K < (1ll << 28); }   // 32-bit element indices (pt_ix): n K 8 and n C below 2^31
 
 }  // namespace
