@@ -611,7 +611,7 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
     constexpr int CT = C / 16, G = C / 8;
     constexpr int W = APPLY ? 4 * C : 2 * C + G * C;
     constexpr int TILEF = PT_TROWS * PT_ROWF;
-    constexpr int W3F = APPLY ? 4 * C : 0;                            // APPLY: the B operands of the d p1 product, one float4 per (channel block, lane)
+    constexpr int W3F = APPLY ? CT * 64 * 4 : 0;                      // APPLY: the B operands of the d p1 product, one float4 per (channel block, lane) = 16 C floats
     __shared__ float lds[PT_WPB * (W > TILEF ? W : TILEF) + W3F];    // the waves' staged tiles (then the workgroup's partial row) | W3F  — ONE array: a second
                                                                      // __shared__ object makes the compiler drain the prefetched loads before every LDS read
     const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4, wave = threadIdx.x >> 6;

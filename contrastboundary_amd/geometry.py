@@ -71,12 +71,19 @@ class StaticGeometry:
         self.cache.ignore_version = True
         prefetch(points, offset, stream=torch.cuda.current_stream(points.device), cache=self.cache, **plan)
         self.ready = None
+        # the cloud boundaries on the host, read ONCE: every later batch has the first one's cloud sizes (the class's contract), and refresh() must not ask the
+        # device for them — a blocking device-to-host read on the side stream waits for everything queued there, including the event of the replay that last
+        # used this buffer set, so the issuing thread sat in stage() for a whole step (measured: 8 - 17 ms of host time per step, the graph step host-bound)
+        self.host_ends = offset.cpu().tolist()
 
     def refresh(self, stream=None):
         """recompute for the CURRENT contents of self.points / self.offset; returns after enqueueing (self.ready = event)"""
         dev = self.points.device
         stream = stream if stream is not None else side_stream(dev)
-        fresh = prefetch(self.points, self.offset, stream=stream, after_caller=False, **self.plan)   # ordering is the caller's (events)
+        fresh = pointops.neighbor_cache()
+        fresh.record_events = True
+        fresh.host[fresh._host_key(self.offset)] = (self.host_ends, self.offset)                      # known: no device-to-host read in here
+        fresh = prefetch(self.points, self.offset, stream=stream, cache=fresh, after_caller=False, **self.plan)   # ordering is the caller's (events)
         with torch.cuda.stream(stream), torch.no_grad():
             old, new = list(self.cache.store.values()), list(fresh.store.values())
             assert len(old) == len(new)

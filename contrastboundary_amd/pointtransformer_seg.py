@@ -281,9 +281,15 @@ class GraphedTrainStep:
             geom = geometry.StaticGeometry(st_in["points"], st_in["offset"], **plan)
             torch.cuda.synchronize(dev)
             graph = torch.cuda.CUDAGraph()
+            # with a process group alive its watchdog THREAD polls the events of finished collectives; under the default (global) capture mode any such
+            # call from another thread while this one captures is an error that takes the process down ("operation not permitted when stream is
+            # capturing", seen on the first run that happened to capture while the watchdog still held work): thread-local mode confines the check to
+            # the capturing thread
+            import torch.distributed as _dist
+            mode = dict(capture_error_mode="thread_local") if (_dist.is_available() and _dist.is_initialized()) else {}
             if reducer is None:
                 optimizer.zero_grad(set_to_none=True)
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, **mode):
                     out, _, loss, _ = forward_and_loss(model, criterion, st_in, st_tg, geometry=geom)
                     loss.sum().backward()
                     optimizer.step()
@@ -291,7 +297,7 @@ class GraphedTrainStep:
                 for h in reducer.handles:                           # no collective inside a capture: the buckets go out behind the replay (reducer.rehook() for eager use afterwards)
                     h.remove()
                 reducer.handles = []
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, **mode):
                     reducer.zero_grad()
                     out, _, loss, _ = forward_and_loss(model, criterion, st_in, st_tg, geometry=geom)
                     loss.sum().backward()

@@ -205,3 +205,36 @@ def test_targets_with_long_pair_lists_on_the_host(host):
     gmax = max(float(np.abs(v).max()) for v in grads.values())
     for k in ["x_v", "x_q", "x_k"] + PARAMS:
         assert rel(g[k], grads[k]) < 2e-4 or float(np.abs(g[k] - grads[k]).max()) < 1e-5 * gmax, (k, rel(g[k], grads[k]))
+
+
+def test_kernels_under_address_sanitizer(tmp_path):
+    """The same host build with -fsanitize=address, one forward + backward per template shape in a subprocess (libasan must be the first library of the
+    process): `__shared__` arrays are static arrays there, so an LDS index past an array's end — which the device answers with another workgroup's LDS and
+    the plain host build with whatever static follows — is a reported global-buffer-overflow.  (Round 5: the apply pass's operand table was sized 4 C floats
+    for 16 C; every host test passed, the device returned a wrong d p1.)"""
+    import sys
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not asan or not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("no libasan beside gcc")
+    so = os.path.join(ROOT, "oracle", "_build", "libpt_layer_host_asan.so")
+    deps = [SRC, os.path.join(EMUL, "pt_wave.h"), os.path.join(EMUL, "hip", "hip_runtime.h"), os.path.join(ROOT, "contrastboundary_amd", "csrc", "cbl_common.h")]
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-x", "c++", "-std=c++17", "-O1", "-g", "-fsanitize=address", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas",
+                               "-I" + EMUL, "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "contrastboundary_amd", "csrc"), SRC, "-o", so])
+    script = tmp_path / "run.py"
+    script.write_text(
+        "import ctypes, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "import tests.test_pt_layer_host as T\n"
+        "L = ctypes.CDLL(%r)\n"
+        "L.cbl_pt_layer_workspace_bytes.restype = ctypes.c_size_t\n"
+        "for n, K, C in ((40, 16, 64), (37, 8, 32), (24, 16, 32), (29, 8, 64)):\n"
+        "    t = T.make(n, K, C, seed=n + C)\n"
+        "    T.run_host(L, t, K, C, np.random.default_rng(1).permutation(n).astype(np.int32))\n"
+        "print('ASAN_RUN_DONE')\n" % (ROOT, so))
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+    assert r.returncode == 0 and "ASAN_RUN_DONE" in r.stdout, (r.returncode, r.stderr[-2000:])
