@@ -612,12 +612,16 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
     constexpr int W = APPLY ? 4 * C : 2 * C + G * C;
     constexpr int TILEF = PT_TROWS * PT_ROWF;
     constexpr int W3F = APPLY ? CT * 64 * 4 : 0;                      // APPLY: the B operands of the d p1 product, one float4 per (channel block, lane) = 16 C floats
-    __shared__ float lds[PT_WPB * (W > TILEF ? W : TILEF) + W3F];    // the waves' staged tiles (then the workgroup's partial row) | W3F  — ONE array: a second
-                                                                     // __shared__ object makes the compiler drain the prefetched loads before every LDS read
+    constexpr int CTF = (5 + G) * C;                                  // per-channel constants: scale, shift, k1, k2, k3 | Wa [G][C]
+    __shared__ float lds[PT_WPB * (W > TILEF ? W : TILEF) + W3F + CTF];   // the waves' staged tiles (then the workgroup's partial row) | W3F | CTF — ONE array: a
+                                                                     // second __shared__ object makes the compiler drain the prefetched loads before every LDS read
     const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4, wave = threadIdx.x >> 6;
     float (*T)[PT_ROWF] = reinterpret_cast<float (*)[PT_ROWF]>(lds + wave * TILEF);
     const PtPe<C> pe = pt_pe_load<C>(W3C, b3C, lo, hi);
-    float sc[CT], sh[CT], k1[CT], k2[CT], k3[CT], wa0[CT], wa1[CT];
+    // The per-channel constants live in LDS, not in registers (28 at C = 64): these two passes sit at 184 - 191 registers = 2 waves per SIMD and are bound by
+    // what two waves can cover of their own load -> LDS -> matrix -> vector chains (43 % fewer vector instructions moved the apply pass by nothing, round 5);
+    // a read costs one LDS instruction beside ~50 per tile.
+    float* ctab = lds + PT_WPB * (W > TILEF ? W : TILEF) + W3F;
     // APPLY: B operand of d p1 = d pe . W3C (contraction over channels, pair-major A): element (k = hi -> channel 16 ct + 4 hi + v, column d = lo), kept in
     // LDS (16 registers at C = 64 would cost the C = 32 kernels their third wave per SIMD)
     float4* w3b = reinterpret_cast<float4*>(lds + PT_WPB * (W > TILEF ? W : TILEF));
@@ -628,21 +632,18 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
             w3b[ct * 64 + lane] = lo < 3 ? make_float4(W3C[3 * cb + lo], W3C[3 * (cb + 1) + lo], W3C[3 * (cb + 2) + lo], W3C[3 * (cb + 3) + lo]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    if (APPLY) __syncthreads();
-#pragma unroll
-    for (int ct = 0; ct < CT; ct++) {
-        const int c = 16 * ct + lo;
-        sc[ct] = cst[PT_CST_C + c]; sh[ct] = cst[PT_CST_C + 64 + c];
-        k3[ct] = 0.f;
-        if (APPLY) {
-            k1[ct] = bc[PT_BC_C + c]; k2[ct] = bc[PT_BC_C + 64 + c]; k3[ct] = bc[PT_BC_C + 128 + c];
-        } else {
-            k1[ct] = cst[PT_CST_C + 192 + c];                                    // invstd
-            k2[ct] = -cst[PT_CST_C + 128 + c] * k1[ct];                          // - mean invstd
+    for (int c = threadIdx.x; c < C; c += PT_BLOCK) {
+        ctab[c] = cst[PT_CST_C + c]; ctab[C + c] = cst[PT_CST_C + 64 + c];
+        if (APPLY) { ctab[2 * C + c] = bc[PT_BC_C + c]; ctab[3 * C + c] = bc[PT_BC_C + 64 + c]; ctab[4 * C + c] = bc[PT_BC_C + 128 + c]; }
+        else {
+            const float is = cst[PT_CST_C + 192 + c];
+            ctab[2 * C + c] = is;                                                // invstd
+            ctab[3 * C + c] = -cst[PT_CST_C + 128 + c] * is;                     // - mean invstd
+            ctab[4 * C + c] = 0.f;
         }
-        wa0[ct] = hi < G ? Wa[(size_t)hi * C + c] : 0.f;                         // B[k = g][col = channel]
-        wa1[ct] = G == 8 ? Wa[(size_t)(hi + 4) * C + c] : 0.f;
     }
+    for (int e = threadIdx.x; e < G * C; e += PT_BLOCK) ctab[5 * C + e] = Wa[e];
+    __syncthreads();
     // BN_g backward constants of the narrow values this lane forms: g = hi, hi + 4 (pair-major operand of d y) and g = lo (operand of d Wa)
     float ga1[3] = {0.f, 0.f, 0.f}, ga2[3] = {0.f, 0.f, 0.f}, ga3[3] = {0.f, 0.f, 0.f};
     if (!APPLY) {
@@ -702,20 +703,25 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
                 if (APPLY) { nv[v] = t.vD ? b.u[v] : 0.f; av[v] = t.vD ? b.y[v] : 0.f; }
                 else { nv[v] = (t.vD && lo < G) ? fmaf(ga1[2], b.u[v], fmaf(ga2[2], b.y[v], ga3[2])) : 0.f; av[v] = 0.f; }
             }
+            int lo_t = lo;
+            asm volatile("" : "+v"(lo_t));                            // opaque per tile: the constant reads below stay LDS reads inside the loop (not hoisted back into 28 registers)
 #pragma unroll
             for (int ct = 0; ct < CT; ct++) {
+                const int cc = 16 * ct + lo_t;
+                const float sc_c = ctab[cc], sh_c = ctab[C + cc], k1_c = ctab[2 * C + cc], k2_c = ctab[3 * C + cc], k3_c = APPLY ? ctab[4 * C + cc] : 0.f;
+                const float wa0_c = ctab[5 * C + hi * C + cc], wa1_c = G == 8 ? ctab[5 * C + (hi + 4) * C + cc] : 0.f;
                 const float q = T[16 + (4 * hi) / K][16 * ct + lo], go = APPLY ? T[18 + (4 * hi) / K][16 * ct + lo] : 0.f;
                 pt_f32x4 w = pt_vec4(T[4 * hi][16 * ct + lo] - q, T[4 * hi + 1][16 * ct + lo] - q, T[4 * hi + 2][16 * ct + lo] - q, T[4 * hi + 3][16 * ct + lo] - q);
                 w = pt_mfma(b.p1x, pe.w[ct], w);
-                pt_f32x4 gy = pt_mfma(da0, wa0[ct], pt_vec4(0.f, 0.f, 0.f, 0.f));
-                if (G == 8) gy = pt_mfma(da1, wa1[ct], gy);
+                pt_f32x4 gy = pt_mfma(da0, wa0_c, pt_vec4(0.f, 0.f, 0.f, 0.f));
+                if (G == 8) gy = pt_mfma(da1, wa1_c, gy);
                 float sq = 0.f;
 #pragma unroll
                 for (int v = 0; v < 4; v++) {
-                    const float y = fmaf(w[v], sc[ct], sh[ct]);
+                    const float y = fmaf(w[v], sc_c, sh_c);
                     const float g1 = y > 0.f ? gy[v] : 0.f;
                     if (APPLY) {
-                        const float dw = t.vD ? fmaf(k1[ct], g1, fmaf(k2[ct], w[v], k3[ct])) : 0.f;
+                        const float dw = t.vD ? fmaf(k1_c, g1, fmaf(k2_c, w[v], k3_c)) : 0.f;
                         sq += dw;
                         const float dpe = fmaf(go, av[v], dw);
                         // d pe takes the place of the x_k element this lane has just consumed (same lane, same cell: no hand-over); the tile is read
@@ -723,7 +729,7 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
                         T[4 * hi + v][16 * ct + lo] = dpe;
                         accw[ct] = pt_mfma(nv[v], dpe, accw[ct]);               // D[d][channel] += [p1, 1][slot][d] d pe[slot][channel]
                     } else {
-                        if (t.vD) { s1[ct] += g1; s2[ct] = fmaf(g1, fmaf(w[v], k1[ct], k2[ct]), s2[ct]); }
+                        if (t.vD) { s1[ct] += g1; s2[ct] = fmaf(g1, fmaf(w[v], k1_c, k2_c), s2[ct]); }
                         accw[ct] = pt_mfma(nv[v], fmaxf(y, 0.f), accw[ct]);      // D[g][channel] += d w2[slot][g] w1[slot][channel]
                     }
                 }
