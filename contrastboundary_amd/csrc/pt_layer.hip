@@ -129,13 +129,13 @@ __device__ __forceinline__ void pt_pipeline(unsigned ntiles, L0 load0, L1 load1,
 // its arithmetic wants (pair-major: one ds_read_b128 per 16 channels; channel-major: ds_read_b32).  Rows 16.. hold the rows of the tile's own
 // point(s): x_q[i] and / or d out[i].
 constexpr int PT_ROWF = 68;                         // floats per staged row: 64 + 4 (rows land 4 banks apart: conflict-free 16-byte reads down a column)
-constexpr int PT_TROWS = 20;                        // 16 neighbour rows, 2 x up to 2 point rows
-template <int NX> struct PtStaged { float4 k0, k1, k2, k3, x0, x1; };     // named members: an array here ends up in scratch memory (measured)
+constexpr int PT_TROWS = 21;                        // 16 neighbour rows, 2 x up to 2 point rows, the tile's p1 values [slot][3] (apply pass)
+template <int NX> struct PtStaged { float4 k0, k1, k2, k3, x0, x1, pv; };     // named members: an array here ends up in scratch memory (measured)
 
 // lane (lo, hi): piece lo of the rows of slots 4 hi .. 4 hi + 3 (ids j) and, in the first lane row of a point, of that point's rows in x0 / x1
-template <int C, int K, int NX>
+template <int C, int K, int NX, bool NP = false>
 __device__ __forceinline__ PtStaged<NX> pt_stage_rows(const float* __restrict__ rows, const int4& j, const float* __restrict__ xa, const float* __restrict__ xb,
-                                                      int iD, int lo, int hi)
+                                                      int iD, int lo, int hi, const float* __restrict__ p1 = nullptr)
 {
     PtStaged<NX> r;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -147,9 +147,12 @@ __device__ __forceinline__ PtStaged<NX> pt_stage_rows(const float* __restrict__ 
     r.x0 = zero; r.x1 = zero;
     if (NX >= 1 && ((4 * hi) % K) == 0) r.x0 = *reinterpret_cast<const float4*>(xa + (pt_ix)iD * C + 4 * piece);
     if (NX >= 2 && ((4 * hi) % K) == 0) r.x1 = *reinterpret_cast<const float4*>(xb + (pt_ix)iD * C + 4 * piece);
+    // NP: the p1 values of the point's K pairs are 3 K contiguous floats: the first 3 K / 4 lanes of the point's first lane row fetch them
+    r.pv = zero;
+    if (NP && ((4 * hi) % K) == 0 && lo < 3 * K / 4) r.pv = *reinterpret_cast<const float4*>(p1 + 3 * (pt_ix)iD * K + 4 * lo);
     return r;
 }
-template <int K, int NX>
+template <int K, int NX, bool NP = false>
 __device__ __forceinline__ void pt_stage_store(float (*T)[PT_ROWF], const PtStaged<NX>& r, int lo, int hi)
 {
     pt_wave_sync();                                                  // the previous tile's reads are done
@@ -160,6 +163,7 @@ __device__ __forceinline__ void pt_stage_store(float (*T)[PT_ROWF], const PtStag
     if (((4 * hi) % K) == 0) {
         if (NX >= 1) *reinterpret_cast<float4*>(&T[16 + (4 * hi) / K][4 * lo]) = r.x0;
         if (NX >= 2) *reinterpret_cast<float4*>(&T[18 + (4 * hi) / K][4 * lo]) = r.x1;
+        if (NP && lo < 3 * K / 4) *reinterpret_cast<float4*>(&T[20][12 * hi + 4 * lo]) = r.pv;      // row 20: [slot][3], slot = 4 hi .. of this point
     }
     pt_wave_sync();
 }
@@ -611,27 +615,16 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
     constexpr int CT = C / 16, G = C / 8;
     constexpr int W = APPLY ? 4 * C : 2 * C + G * C;
     constexpr int TILEF = PT_TROWS * PT_ROWF;
-    constexpr int W3F = APPLY ? CT * 64 * 4 : 0;                      // APPLY: the B operands of the d p1 product, one float4 per (channel block, lane) = 16 C floats
-    constexpr int CTF = (5 + G) * C;                                  // per-channel constants: scale, shift, k1, k2, k3 | Wa [G][C]
-    __shared__ float lds[PT_WPB * (W > TILEF ? W : TILEF) + W3F + CTF];   // the waves' staged tiles (then the workgroup's partial row) | W3F | CTF — ONE array: a
-                                                                     // second __shared__ object makes the compiler drain the prefetched loads before every LDS read
+    constexpr int CTF = (5 + G + 3) * C;                              // per-channel constants: scale, shift, k1, k2, k3 | Wa [G][C] | W3C transposed [3][C]
+    __shared__ float lds[PT_WPB * (W > TILEF ? W : TILEF) + CTF];    // the waves' staged tiles (then the workgroup's partial row) | CTF — ONE array: a second
+                                                                     // __shared__ object makes the compiler drain the prefetched loads before every LDS read
     const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4, wave = threadIdx.x >> 6;
     float (*T)[PT_ROWF] = reinterpret_cast<float (*)[PT_ROWF]>(lds + wave * TILEF);
     const PtPe<C> pe = pt_pe_load<C>(W3C, b3C, lo, hi);
     // The per-channel constants live in LDS, not in registers (28 at C = 64): these two passes sit at 184 - 191 registers = 2 waves per SIMD and are bound by
     // what two waves can cover of their own load -> LDS -> matrix -> vector chains (43 % fewer vector instructions moved the apply pass by nothing, round 5);
     // a read costs one LDS instruction beside ~50 per tile.
-    float* ctab = lds + PT_WPB * (W > TILEF ? W : TILEF) + W3F;
-    // APPLY: B operand of d p1 = d pe . W3C (contraction over channels, pair-major A): element (k = hi -> channel 16 ct + 4 hi + v, column d = lo), kept in
-    // LDS (16 registers at C = 64 would cost the C = 32 kernels their third wave per SIMD)
-    float4* w3b = reinterpret_cast<float4*>(lds + PT_WPB * (W > TILEF ? W : TILEF));
-    if (APPLY && wave == 0) {
-#pragma unroll
-        for (int ct = 0; ct < CT; ct++) {
-            const int cb = 16 * ct + 4 * hi;
-            w3b[ct * 64 + lane] = lo < 3 ? make_float4(W3C[3 * cb + lo], W3C[3 * (cb + 1) + lo], W3C[3 * (cb + 2) + lo], W3C[3 * (cb + 3) + lo]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
+    float* ctab = lds + PT_WPB * (W > TILEF ? W : TILEF);
     for (int c = threadIdx.x; c < C; c += PT_BLOCK) {
         ctab[c] = cst[PT_CST_C + c]; ctab[C + c] = cst[PT_CST_C + 64 + c];
         if (APPLY) { ctab[2 * C + c] = bc[PT_BC_C + c]; ctab[3 * C + c] = bc[PT_BC_C + 64 + c]; ctab[4 * C + c] = bc[PT_BC_C + 128 + c]; }
@@ -643,6 +636,7 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
         }
     }
     for (int e = threadIdx.x; e < G * C; e += PT_BLOCK) ctab[5 * C + e] = Wa[e];
+    if (APPLY) for (int e = threadIdx.x; e < 3 * C; e += PT_BLOCK) ctab[(5 + G) * C + e] = W3C[3 * (e % C) + e / C];     // [d][c]
     __syncthreads();
     // BN_g backward constants of the narrow values this lane forms: g = hi, hi + 4 (pair-major operand of d y) and g = lo (operand of d Wa)
     float ga1[3] = {0.f, 0.f, 0.f}, ga2[3] = {0.f, 0.f, 0.f}, ga3[3] = {0.f, 0.f, 0.f};
@@ -652,6 +646,9 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
         for (int t = 0; t < 3; t++)
             if (gs[t] < G) { ga1[t] = bc[PT_BC_G + gs[t]]; ga2[t] = bc[PT_BC_G + 8 + gs[t]]; ga3[t] = bc[PT_BC_G + 16 + gs[t]]; }
     }
+    // accw: REDUCE d Wa[g][channel] in matrix accumulators (rows g: 8 of 16 used); APPLY d [W3C | b3C][channel][d] as four plain sums per channel block —
+    // the f32 matrix instruction runs at the vector rate (32 cycles = 16 v_fma issue slots per 16 x 16 x 4 tile), so a product that uses 4 of its 16 rows
+    // costs four times the 16 v_fma that do the same work (round 5: per-tile issue cycles 2 VALU + 32 MFMA explain every pass of this file)
     float s1[CT], s2[CT];
     pt_f32x4 accw[CT];
 #pragma unroll
@@ -679,14 +676,14 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
 #pragma unroll
             for (int v = 0; v < 4; v++) {
                 const pt_ix rd = (pt_ix)(t.pD + v);
-                if (APPLY) { b.u[v] = lo < 3 ? p1[3 * rd + lo] : (lo == 3 ? 1.f : 0.f); b.y[v] = a[rd * G + (lo % G)]; }
+                if (APPLY) { b.u[v] = 0.f; b.y[v] = a[rd * G + (lo % G)]; }
                 else { b.u[v] = lo < G ? pre[rd * G + lo] : 0.f; b.y[v] = lo < G ? w2[rd * G + lo] : 0.f; }
             }
             return b;
         },
-        [&](const PtS0& t, const S1& b) { return pt_stage_rows<C, K, NX>(xk, b.j, xq, gout, t.iD, lo, hi); },
+        [&](const PtS0& t, const S1& b) { return pt_stage_rows<C, K, NX, APPLY>(xk, b.j, xq, gout, t.iD, lo, hi, p1); },
         [&](const PtS0& t, const S1& b, const PtStaged<NX>& r) {
-            pt_stage_store<K, NX>(T, r, lo, hi);
+            pt_stage_store<K, NX, APPLY>(T, r, lo, hi);
             // d w2 of (pair slot lo, g = hi / hi + 4): the A operand of d y = d w2 . Wa
             float da0 = 0.f, da1 = 0.f;
             if (APPLY) {
@@ -700,8 +697,19 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
             float nv[4], av[4];
 #pragma unroll
             for (int v = 0; v < 4; v++) {
-                if (APPLY) { nv[v] = t.vD ? b.u[v] : 0.f; av[v] = t.vD ? b.y[v] : 0.f; }
+                if (APPLY) { nv[v] = 0.f; av[v] = t.vD ? b.y[v] : 0.f; }
                 else { nv[v] = (t.vD && lo < G) ? fmaf(ga1[2], b.u[v], fmaf(ga2[2], b.y[v], ga3[2])) : 0.f; av[v] = 0.f; }
+            }
+            // APPLY: p1 of this lane's four slots (row 20 of the staged tile, [slot][3]) and the d p1 partial sums over this lane's channels
+            float pq[12], t3[12];
+#pragma unroll
+            for (int e = 0; e < 12; e++) { pq[e] = 0.f; t3[e] = 0.f; }
+            if (APPLY) {
+#pragma unroll
+                for (int e4 = 0; e4 < 3; e4++) {
+                    const float4 x = *reinterpret_cast<const float4*>(&T[20][12 * hi + 4 * e4]);
+                    pq[4 * e4] = x.x; pq[4 * e4 + 1] = x.y; pq[4 * e4 + 2] = x.z; pq[4 * e4 + 3] = x.w;
+                }
             }
             int lo_t = lo;
             asm volatile("" : "+v"(lo_t));                            // opaque per tile: the constant reads below stay LDS reads inside the loop (not hoisted back into 28 registers)
@@ -710,6 +718,7 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
                 const int cc = 16 * ct + lo_t;
                 const float sc_c = ctab[cc], sh_c = ctab[C + cc], k1_c = ctab[2 * C + cc], k2_c = ctab[3 * C + cc], k3_c = APPLY ? ctab[4 * C + cc] : 0.f;
                 const float wa0_c = ctab[5 * C + hi * C + cc], wa1_c = G == 8 ? ctab[5 * C + (hi + 4) * C + cc] : 0.f;
+                const float w3x = APPLY ? ctab[(5 + G) * C + cc] : 0.f, w3y = APPLY ? ctab[(6 + G) * C + cc] : 0.f, w3z = APPLY ? ctab[(7 + G) * C + cc] : 0.f;
                 const float q = T[16 + (4 * hi) / K][16 * ct + lo], go = APPLY ? T[18 + (4 * hi) / K][16 * ct + lo] : 0.f;
                 pt_f32x4 w = pt_vec4(T[4 * hi][16 * ct + lo] - q, T[4 * hi + 1][16 * ct + lo] - q, T[4 * hi + 2][16 * ct + lo] - q, T[4 * hi + 3][16 * ct + lo] - q);
                 w = pt_mfma(b.p1x, pe.w[ct], w);
@@ -724,10 +733,11 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
                         const float dw = t.vD ? fmaf(k1_c, g1, fmaf(k2_c, w[v], k3_c)) : 0.f;
                         sq += dw;
                         const float dpe = fmaf(go, av[v], dw);
-                        // d pe takes the place of the x_k element this lane has just consumed (same lane, same cell: no hand-over); the tile is read
-                        // back pair-major below for the contraction over CHANNELS (d p1), which the channel-major registers cannot feed to the matrix cores
-                        T[4 * hi + v][16 * ct + lo] = dpe;
-                        accw[ct] = pt_mfma(nv[v], dpe, accw[ct]);               // D[d][channel] += [p1, 1][slot][d] d pe[slot][channel]
+                        // d p1 partials (contraction over this lane's channels; the 16 lanes of the row are summed below) and d [W3C | b3C] (contraction
+                        // over this lane's pairs; the lane rows and waves are summed at the end of the kernel): 7 v_fma per (slot, channel)
+                        t3[3 * v] = fmaf(w3x, dpe, t3[3 * v]); t3[3 * v + 1] = fmaf(w3y, dpe, t3[3 * v + 1]); t3[3 * v + 2] = fmaf(w3z, dpe, t3[3 * v + 2]);
+                        accw[ct][0] = fmaf(dpe, pq[3 * v], accw[ct][0]); accw[ct][1] = fmaf(dpe, pq[3 * v + 1], accw[ct][1]);
+                        accw[ct][2] = fmaf(dpe, pq[3 * v + 2], accw[ct][2]); accw[ct][3] += dpe;
                     } else {
                         if (t.vD) { s1[ct] += g1; s2[ct] = fmaf(g1, fmaf(w[v], k1_c, k2_c), s2[ct]); }
                         accw[ct] = pt_mfma(nv[v], fmaxf(y, 0.f), accw[ct]);      // D[g][channel] += d w2[slot][g] w1[slot][channel]
@@ -739,22 +749,10 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
                 }
             }
             if (APPLY) {
-                // d p1[slot][d] = sum over channels of d pe[slot][c] W3C[c][d]: A[slot lo][k = hi] = d pe of channel 16 ct + 4 hi + v (one 16-byte read of
-                // the parked tile per 16 channels), four steps per channel block, two independent accumulator chains
-                pt_wave_sync();
-                pt_f32x4 d0 = pt_vec4(0.f, 0.f, 0.f, 0.f), d1 = pt_vec4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int ct = 0; ct < CT; ct++) {
-                    const float4 e = *reinterpret_cast<const float4*>(&T[lo][16 * ct + 4 * hi]), b4 = w3b[ct * 64 + lane];
-                    d0 = pt_mfma(e.x, b4.x, d0);
-                    d1 = pt_mfma(e.y, b4.y, d1);
-                    d0 = pt_mfma(e.z, b4.z, d0);
-                    d1 = pt_mfma(e.w, b4.w, d1);
-                }
-                // D[slot 4 hi + v][d = lo]
-                if (t.vD && lo < 3) {
-#pragma unroll
-                    for (int v = 0; v < 4; v++) gp1[3 * (pt_ix)(t.pD + v) + lo] = d0[v] + d1[v];
+                for (int v = 0; v < 4; v++) {
+                    const float r0 = pt_row_sum(t3[3 * v]), r1 = pt_row_sum(t3[3 * v + 1]), r2 = pt_row_sum(t3[3 * v + 2]);
+                    if (t.vD && lo < 3) gp1[3 * (pt_ix)(t.pD + v) + lo] = lo == 0 ? r0 : (lo == 1 ? r1 : r2);
                 }
             }
         });
@@ -762,13 +760,17 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
     __syncthreads();                                                 // every wave is done with its tile
     float (*red)[W] = reinterpret_cast<float (*)[W]>(lds);
     if (APPLY) {
-        // accw: D[d = 4 hi + v][channel 16 ct + lo], rows d < 4 live in hi = 0; stored as torch lays out Linear(3, C): weight [c][d], then the bias
-        if (hi == 0) {
+        // accw[ct][d]: this lane's sum over its slots for channel 16 ct + lo; the four lane rows are added here; stored as torch lays out Linear(3, C):
+        // weight [c][d], then the bias
 #pragma unroll
-            for (int ct = 0; ct < CT; ct++) {
+        for (int ct = 0; ct < CT; ct++) {
+            float x[4];
 #pragma unroll
-                for (int v = 0; v < 3; v++) red[wave][3 * (16 * ct + lo) + v] = accw[ct][v];
-                red[wave][3 * C + 16 * ct + lo] = accw[ct][3];
+            for (int v = 0; v < 4; v++) { x[v] = accw[ct][v] + pt_xor16(accw[ct][v]); x[v] += pt_xor32(x[v]); }
+            if (hi == 0) {
+#pragma unroll
+                for (int v = 0; v < 3; v++) red[wave][3 * (16 * ct + lo) + v] = x[v];
+                red[wave][3 * C + 16 * ct + lo] = x[3];
             }
         }
     } else {

@@ -13,7 +13,7 @@ __device__ __forceinline__ pt_f32x4 pt_mfma(float a, float b, pt_f32x4 c) { retu
 
 template <int CTRL> __device__ __forceinline__ float pt_dpp(float v)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));     // old = 0 + bound_ctrl: every source lane of these permutations exists, and in this form the move folds into its user (v_add_f32_dpp)
 }
 // value of another lane of the same 16-lane row
 __device__ __forceinline__ float pt_quad_xor1(float v) { return pt_dpp<0xB1>(v); }        // lane ^ 1   (quad_perm 1,0,3,2)
