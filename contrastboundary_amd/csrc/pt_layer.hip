@@ -615,29 +615,36 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
     constexpr int CT = C / 16, G = C / 8;
     constexpr int W = APPLY ? 4 * C : 2 * C + G * C;
     constexpr int TILEF = PT_TROWS * PT_ROWF;
-    constexpr int CTF = (5 + G + 3) * C;                              // per-channel constants: scale, shift, k1, k2, k3 | Wa [G][C] | W3C transposed [3][C]
+    constexpr int CTF = APPLY ? (5 + G + 3) * C : 0;                  // APPLY's per-channel constants: scale, shift, k1, k2, k3 | Wa [G][C] | W3C transposed [3][C]
     __shared__ float lds[PT_WPB * (W > TILEF ? W : TILEF) + CTF];    // the waves' staged tiles (then the workgroup's partial row) | CTF — ONE array: a second
                                                                      // __shared__ object makes the compiler drain the prefetched loads before every LDS read
     const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4, wave = threadIdx.x >> 6;
     float (*T)[PT_ROWF] = reinterpret_cast<float (*)[PT_ROWF]>(lds + wave * TILEF);
     const PtPe<C> pe = pt_pe_load<C>(W3C, b3C, lo, hi);
-    // The per-channel constants live in LDS, not in registers (28 at C = 64): these two passes sit at 184 - 191 registers = 2 waves per SIMD and are bound by
-    // what two waves can cover of their own load -> LDS -> matrix -> vector chains (43 % fewer vector instructions moved the apply pass by nothing, round 5);
-    // a read costs one LDS instruction beside ~50 per tile.
+    // APPLY: the per-channel constants (scale, shift, k1..k3, Wa, W3C: 40 values per lane at C = 64) live in an LDS table and are read where they are used
     float* ctab = lds + PT_WPB * (W > TILEF ? W : TILEF);
-    for (int c = threadIdx.x; c < C; c += PT_BLOCK) {
-        ctab[c] = cst[PT_CST_C + c]; ctab[C + c] = cst[PT_CST_C + 64 + c];
-        if (APPLY) { ctab[2 * C + c] = bc[PT_BC_C + c]; ctab[3 * C + c] = bc[PT_BC_C + 64 + c]; ctab[4 * C + c] = bc[PT_BC_C + 128 + c]; }
-        else {
-            const float is = cst[PT_CST_C + 192 + c];
-            ctab[2 * C + c] = is;                                                // invstd
-            ctab[3 * C + c] = -cst[PT_CST_C + 128 + c] * is;                     // - mean invstd
-            ctab[4 * C + c] = 0.f;
+    float sc[CT], sh[CT], k1[CT], k2[CT], wa0[CT], wa1[CT];           // REDUCE: 24 registers (its table reads measured slower: 57.6 against 54.4 us)
+    if (APPLY) {
+        for (int c = threadIdx.x; c < C; c += PT_BLOCK) {
+            ctab[c] = cst[PT_CST_C + c]; ctab[C + c] = cst[PT_CST_C + 64 + c];
+            ctab[2 * C + c] = bc[PT_BC_C + c]; ctab[3 * C + c] = bc[PT_BC_C + 64 + c]; ctab[4 * C + c] = bc[PT_BC_C + 128 + c];
+        }
+        for (int e = threadIdx.x; e < G * C; e += PT_BLOCK) ctab[5 * C + e] = Wa[e];
+        for (int e = threadIdx.x; e < 3 * C; e += PT_BLOCK) ctab[(5 + G) * C + e] = W3C[3 * (e % C) + e / C];     // [d][c]
+        __syncthreads();
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) {
+        const int c = 16 * ct + lo;
+        sc[ct] = sh[ct] = k1[ct] = k2[ct] = wa0[ct] = wa1[ct] = 0.f;
+        if (!APPLY) {
+            sc[ct] = cst[PT_CST_C + c]; sh[ct] = cst[PT_CST_C + 64 + c];
+            k1[ct] = cst[PT_CST_C + 192 + c];                                    // invstd
+            k2[ct] = -cst[PT_CST_C + 128 + c] * k1[ct];                          // - mean invstd
+            wa0[ct] = hi < G ? Wa[(size_t)hi * C + c] : 0.f;                     // B[k = g][col = channel]
+            wa1[ct] = G == 8 ? Wa[(size_t)(hi + 4) * C + c] : 0.f;
         }
     }
-    for (int e = threadIdx.x; e < G * C; e += PT_BLOCK) ctab[5 * C + e] = Wa[e];
-    if (APPLY) for (int e = threadIdx.x; e < 3 * C; e += PT_BLOCK) ctab[(5 + G) * C + e] = W3C[3 * (e % C) + e / C];     // [d][c]
-    __syncthreads();
     // BN_g backward constants of the narrow values this lane forms: g = hi, hi + 4 (pair-major operand of d y) and g = lo (operand of d Wa)
     float ga1[3] = {0.f, 0.f, 0.f}, ga2[3] = {0.f, 0.f, 0.f}, ga3[3] = {0.f, 0.f, 0.f};
     if (!APPLY) {
@@ -712,12 +719,13 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
                 }
             }
             int lo_t = lo;
-            asm volatile("" : "+v"(lo_t));                            // opaque per tile: the constant reads below stay LDS reads inside the loop (not hoisted back into 28 registers)
+            if (APPLY) asm volatile("" : "+v"(lo_t));                 // opaque per tile: the apply pass's constant reads stay LDS reads inside the loop (not hoisted back into 40 registers)
 #pragma unroll
             for (int ct = 0; ct < CT; ct++) {
                 const int cc = 16 * ct + lo_t;
-                const float sc_c = ctab[cc], sh_c = ctab[C + cc], k1_c = ctab[2 * C + cc], k2_c = ctab[3 * C + cc], k3_c = APPLY ? ctab[4 * C + cc] : 0.f;
-                const float wa0_c = ctab[5 * C + hi * C + cc], wa1_c = G == 8 ? ctab[5 * C + (hi + 4) * C + cc] : 0.f;
+                const float sc_c = APPLY ? ctab[cc] : sc[ct], sh_c = APPLY ? ctab[C + cc] : sh[ct], k1_c = APPLY ? ctab[2 * C + cc] : k1[ct],
+                            k2_c = APPLY ? ctab[3 * C + cc] : k2[ct], k3_c = APPLY ? ctab[4 * C + cc] : 0.f;
+                const float wa0_c = APPLY ? ctab[5 * C + hi * C + cc] : wa0[ct], wa1_c = APPLY ? (G == 8 ? ctab[5 * C + (hi + 4) * C + cc] : 0.f) : wa1[ct];
                 const float w3x = APPLY ? ctab[(5 + G) * C + cc] : 0.f, w3y = APPLY ? ctab[(6 + G) * C + cc] : 0.f, w3z = APPLY ? ctab[(7 + G) * C + cc] : 0.f;
                 const float q = T[16 + (4 * hi) / K][16 * ct + lo], go = APPLY ? T[18 + (4 * hi) / K][16 * ct + lo] : 0.f;
                 pt_f32x4 w = pt_vec4(T[4 * hi][16 * ct + lo] - q, T[4 * hi + 1][16 * ct + lo] - q, T[4 * hi + 2][16 * ct + lo] - q, T[4 * hi + 3][16 * ct + lo] - q);
