@@ -37,7 +37,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 matrix = f32 vector peak
 GRAD_ALLREDUCE_FLOATS = 7800497   # parameters of the reference's PointTransformerSeg + heads: 31.2 MB fp32
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")     # collected by tools/gpu_r04_final.sh; its _meta.commit names the kernel set
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")     # collected by tools/gpu_r05_final.sh; its _meta.commit names the kernel set
+PMC_MIX_FILE = os.path.join(ROOT, "profiles", "r05_pmc_instruction_mix.json")   # same script: SQ_* counters per kernel of the same command (separate --pmc passes)
 
 
 def parse(argv=None):
@@ -338,6 +339,39 @@ def kernel_times(scene, k, backward, reps=10):
     return out
 
 
+def search_roofline(scene, k, stage_ms, nested):
+    """The step's longest stage is the neighbour search, and its bound is neither HBM nor the matrix cores (compulsory bytes 6 MB): a cell-list
+    search is priced in PAIRS VISITED (candidate supports whose distance a query evaluates) against the n_cloud pairs per query of the brute-force kernel it
+    replaces (knnquery_cuda_kernel.cu:65-111), and in the share of the device's vector-issue slots its kernel fills (PMC, profiles/)."""
+    from contrastboundary_amd import hotpath, pointops
+    ks = hotpath.CBL_NSAMPLE if nested else k                       # the search that actually runs (the K = 16 rows are derived from it)
+    cnt = pointops.knn_block_candidates(ks, scene.xyz, scene.offset, "set")
+    pairs = int(cnt.to(torch.int64).sum().item())
+    ends = scene.offset.cpu().tolist()
+    lens = [e - s for s, e in zip([0] + ends[:-1], ends)]
+    brute = float(sum(l * l for l in lens))
+    out = {"kernel": "knn_grid_wave_kernel<true, false> (K = %d, one wave per query: select-then-sort over the 27-cell block) behind the 6-launch grid build; "
+                     "tie replay knn_replay_kernel" % ks,
+           "stage": "knnquery_k%d" % k, "stage_ms": round(stage_ms, 4), "bound": "vector issue (VALU)", "nsample": ks,
+           "pairs_visited": pairs, "pairs_per_query": round(pairs / scene.n, 1), "pairs_per_query_min_max": [int(cnt.min().item()), int(cnt.max().item())],
+           "brute_force_pairs": brute, "pairs_vs_brute_force": pairs / brute,
+           "pairs_per_s": pairs / (stage_ms * 1e-3), "candidate_read_GBps": 16.0 * pairs / (stage_ms * 1e-3) / 1e9,
+           "note": "pairs visited = candidate supports in the 27-cell block of every query (cbl_knn_grid_block_candidates, recomputed from the grid the search built: "
+                   "what its first round evaluates; a further shell is taken by well under 1 % of the queries); 16 B (float4) read per candidate from the "
+                   "cell-sorted copy, L2-resident at this size — the kernel is bound by its vector instructions, not by those reads"}
+    if os.path.exists(PMC_MIX_FILE) and (scene.n, scene.c, k) == (40960, 64, 16):
+        mix = json.load(open(PMC_MIX_FILE))
+        for name, v in mix.items():
+            if name.startswith("knn_grid_wave_kernel") and isinstance(v, dict):
+                out["valu_issue_fraction"] = v.get("valu_issue_utilisation")
+                out["valu_instructions_per_launch"] = v.get("SQ_INSTS_VALU")
+                out["valu_instructions_per_pair"] = (v.get("SQ_INSTS_VALU") or 0) * 64.0 / max(pairs, 1)    # lane-instructions per candidate pair
+                out["kernel_us_under_counters"] = v.get("duration_us_at_2.4GHz")
+                out["pmc_source"] = "%s (rocprofv3 --kernel-trace --pmc, separate passes; commit %s)" % (os.path.relpath(PMC_MIX_FILE, ROOT), mix.get("_meta", {}).get("commit", "?"))
+                break
+    return out
+
+
 def gather_200k(n=200000, c=64, k=16, reps=10):
     """The gather at a size that is HBM for certain: S-room scaled to n = 200 000 points (same density), K = 16, C = 64 — output 4 n K (3 + C)
     = 857 MB per launch, past the 256 MiB Infinity Cache, consecutive launches alternating between three output buffers.  Returns the roofline
@@ -475,6 +509,7 @@ def run_gpu(args, D, world, rank, local):
                 "stage_ms": {names[i]: round(stage_ms[i], 4) for i in range(len(stages))},
                 "stage_sum_ms": round(float(sum(stage_ms)), 4),
                 "stage_algorithmic_GBps": {names[i]: (round(gbps(i), 1) if stage_bytes[i] else None) for i in range(len(stages))}}
+    roofline["search"] = search_roofline(scene, k, stage_ms[names.index("knnquery_k%d" % k)], bool(st_in.hints))
     if "queryandgroup_bwd" in names:
         bi = names.index("queryandgroup_bwd")
         roofline["scatter_k4"] = {"kernel": MAIN_KERNEL["queryandgroup_bwd"], "bound": "hbm", "achieved": kgbps("queryandgroup_bwd"), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -62,6 +62,17 @@ CBL_EXPORT int cbl_knnquery_ordered(int b, int n, int m, int nsample, const floa
     return knnquery_impl(b, n, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, workspace, workspace_bytes, tie_policy, stream, cell_order);
 }
 
+int cbl_knn_block_candidates_launch(int b, int n, const int* offset, void* ws, int* count, hipStream_t st);    // knn_grid.hip
+
+// measurement support (bench.py roofline.search): candidates per query of the grid search that last used `workspace` for a SELF-search over these (b, n)
+CBL_EXPORT int cbl_knn_grid_block_candidates(int b, int n, int nsample, const int* offset, int* count, void* workspace, size_t workspace_bytes, void* stream)
+{
+    const size_t need = cbl_knn_grid_workspace_bytes(b, n, n, nsample);
+    if (need == 0) return CBL_ERR_UNSUPPORTED;
+    if (workspace_bytes < need) return CBL_ERR_WORKSPACE;
+    return cbl_knn_block_candidates_launch(b, n, offset, workspace, count, cbl_stream(stream));
+}
+
 // ---- a narrower search from a wider one over the same (supports, queries) ----------------------------------------------------
 // The K nearest neighbours are the first K of the K' > K nearest.  A row of the wider result (ascending distances, exact K' smallest —
 // every tie policy delivers that) gives the narrower result directly unless a tie decides it: equal distances among its first K entries

@@ -890,6 +890,35 @@ int cbl_grid_build(int b, int n, float pts_per_cell, const float* xyz, const int
     return cbl_status();
 }
 
+// ---- measurement support: how many candidate supports a self-search's 27-cell block holds per query (the pairs the wave / group kernels evaluate in their
+// first round: what SURVEY 8(d) asks the cell-list search to report as "pairs visited") — recomputed from the grid a finished search left in its workspace
+__global__ __launch_bounds__(256) void knn_block_candidates_kernel(int b, int n, const int* __restrict__ offset, const CblGrid* __restrict__ grids,
+                                                                   const int* __restrict__ cell_start, const float4* __restrict__ sorted, int* __restrict__ count)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;                    // query = t-th support in cell order (the kernels' own enumeration of a self-search)
+    if (t >= n) return;
+    const float4 s = sorted[t];
+    const int q = __float_as_int(s.w);
+    const CblGrid g = grids[cbl_cloud_of(q, offset, b)];
+    const int cx = cbl_cell_coord(cbl_u(s.x, g.ox, g.inv_cs), g.nx), cy = cbl_cell_coord(cbl_u(s.y, g.oy, g.inv_cs), g.ny), cz = cbl_cell_coord(cbl_u(s.z, g.oz, g.inv_cs), g.nz);
+    int T = 0;
+    for (int r = 0; r < 9; r++) {
+        const int y = cy + r % 3 - 1, z = cz + r / 3 - 1;
+        if (y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
+            const int row = g.cell_base + g.nx * (y + g.ny * z);
+            T += cell_start[row + min(cx + 1, g.nx - 1) + 1] - cell_start[row + max(cx - 1, 0)];
+        }
+    }
+    count[q] = T;
+}
+
+int cbl_knn_block_candidates_launch(int b, int n, const int* offset, void* ws, int* count, hipStream_t st)
+{
+    Workspace w = carve(ws, b, n, n);
+    hipLaunchKernelGGL(knn_block_candidates_kernel, dim3(cbl_grid_for(n, 256, 1 << 20)), dim3(256), 0, st, b, n, offset, w.grids, w.cell_start, w.sorted, count);
+    return cbl_status();
+}
+
 size_t cbl_knn_grid_workspace_bytes(int b, int n, int m, int nsample)
 {
     // the grid pays off once the brute-force scan is long; tiny problems and huge K stay on the exact kernel

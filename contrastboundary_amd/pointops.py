@@ -273,6 +273,22 @@ def _knnquery_uncached(nsample, xyz, new_xyz, offset, new_offset, algo):
     return idx, dist2
 
 
+def knn_block_candidates(nsample, xyz, offset, algo="set"):
+    """measurement support (bench.py `roofline.search`): run the grid self-search over `xyz` and return, per query, how many candidate supports its
+    27-cell block held — the pairs the search evaluated in its first round ("pairs visited") -> int32 (n,).  CblError off the grid path."""
+    n, b = xyz.shape[0], offset.shape[0]
+    L = _lib.lib()
+    need = L.cbl_knnquery_workspace_bytes(_c_int(b), _c_int(n), _c_int(n), _c_int(nsample))
+    if need == 0:
+        raise _lib.CblError("knn_block_candidates: this shape does not take the grid search")
+    _knnquery_uncached(nsample, xyz, xyz, offset, offset, algo)
+    ws = _workspace(need, xyz.device)                               # the same buffer (one per device and stream), holding the grid that search built
+    count = torch.empty(n, dtype=torch.int32, device=xyz.device)
+    _lib.check(L.cbl_knn_grid_block_candidates(_c_int(b), _c_int(n), _c_int(nsample), _lib.ptr(offset), _lib.ptr(count), _lib.ptr(ws),
+                                               ctypes.c_size_t(ws.numel()), _lib.stream_of(xyz)), "cbl_knn_grid_block_candidates")
+    return count
+
+
 # ------------------------------------------------------------------------------------------------ transposed neighbour table
 TRANSPOSE_MIN_PAIRS = 1 << 16      # below this a scatter with atomics is as quick as building the table (unless the table is cached)
 

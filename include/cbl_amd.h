@@ -92,6 +92,11 @@ int cbl_knnquery_ordered(int b, int n, int m, int nsample,
                          int* idx, float* dist2, int tie_policy, int* cell_order,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* Measurement support (no counterpart in the reference): count[q] (n ints) = number of candidate supports in the 27-cell block around query q of the grid
+ * search that LAST used `workspace` for a self-search over these (b, n, nsample) — the pairs that search evaluated in its first round ("pairs visited",
+ * SURVEY 8(d)); the brute-force kernel it replaces (knnquery_cuda_kernel.cu:65-111) visits n_cloud pairs per query.  CBL_ERR_UNSUPPORTED off the grid path. */
+int cbl_knn_grid_block_candidates(int b, int n, int nsample, const int* offset, int* count, void* workspace, size_t workspace_bytes, void* stream);
+
 /* A narrower search derived from a wider one over the SAME supports and queries: idx_wide / dist2_wide (m, nsample_wide) from
  * cbl_knnquery (any tie policy), nsample < nsample_wide.  Rows whose first nsample entries are decided by the distances alone are copied;
  * rows with a tie that matters under tie_policy (0: reference order, 1: reference set — as cbl_knnquery / cbl_knnquery_set) or that are

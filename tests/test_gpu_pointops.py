@@ -524,3 +524,18 @@ def test_fps_speculative_rounds_vs_dense_kernels(seed):
     idx_d, tmp_d = _fps_raw(xyz, offset, noff, bucket=False)
     np.testing.assert_array_equal(idx_b, idx_d)
     np.testing.assert_array_equal(tmp_b.view(np.uint32), tmp_d.view(np.uint32))
+
+
+def test_block_candidates_of_a_grid_search_cover_its_neighbours():
+    """cbl_knn_grid_block_candidates (bench.py roofline.search: "pairs visited"): per query the number of supports in its 27-cell block, recomputed from the
+    grid the search left in the workspace — at least the query itself, never more than its cloud, for nearly every query at least K (the block certifies
+    the list) and on average a few cells' worth of points, not the cloud"""
+    import torch
+    from contrastboundary_amd import pointops, synthetic as S
+    n, K = 20000, 36
+    xyz = torch.from_numpy(S.s_room(n, seed=4)[0]).cuda(); o = torch.tensor([n // 2, n], dtype=torch.int32, device="cuda")
+    cnt = pointops.knn_block_candidates(K, xyz, o, "set")
+    torch.cuda.synchronize()
+    assert cnt.shape == (n,) and int(cnt.min()) >= 1 and int(cnt.max()) <= n // 2
+    assert float((cnt >= K).float().mean()) > 0.98
+    assert K <= float(cnt.float().mean()) <= 40 * K                       # a few cells' worth of points per query, not the cloud (n / 2 = 10000)
