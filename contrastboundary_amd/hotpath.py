@@ -421,9 +421,9 @@ class Pipeline:
     chain matters: with the pair kernel first ("split") the pipeline has two stable alignments, 0.270 and 0.290 ms per step, picked by the timing of the
     first steps after an idle device; with the table's small kernels first every run is the fast one.  "alt_bwd" (the Point Transformer
     block, whose backward chain is 0.46 of its 0.55 ms): consecutive steps' backward chains on two streams in turn, searches and CBL chain sharing one.
-    "tables" is round 2's layout: tables on a stream of their own, forward and backward of the block on one stream (`rest`), which serialises the backward of
-    step i with the forward of step i+1: 0.310 ms per step against 0.272 for the KPConv block, 0.68 (one step at a time was faster) against 0.505 ms for
-    the Point Transformer block, same box, same kernels.  The other layouts are measured alternatives.
+    "tables" is round 2's layout, kept as the baseline the two defaults are measured against: tables on a stream of their own, forward and backward of the
+    block on one stream (`rest`), which serialises the backward of step i with the forward of step i+1: 0.310 ms per step against 0.272 for the KPConv block,
+    0.68 (one step at a time was faster) against 0.505 ms for the Point Transformer block, same box, same kernels.
     Steps are independent scenes (in bench.py: the same resident scene); a step writes into one of SLOTS slots (its neighbour tables, orders,
     outputs: self.states[slot]) and the search of step i+SLOTS waits for every other stream's part of step i before it overwrites their slot.  A
     step runs inside its own neighbour cache, which only exists while the step is captured.
@@ -462,43 +462,18 @@ class Pipeline:
                     ("t36", "tables", t36, ("found",), "t36"),
                     ("bwd", "rest", bwd_b, ("t16",) if t16 else (), None),
                     ("cblbwd", "side", bwd_c, ("t36",) if t36 else (), None)]
-        elif layout == "split":
-            # the block's backward on a stream of its own behind its table: the backward kernels of step i run beside the forward kernels of
-            # step i+1; every table is built on the stream that consumes it (no table stream, no table events)
-            streams = ("search", "fwd", "bwd", "side")
-            segs = [("search", "search", search, (), "found"),
-                    ("fwd", "fwd", fwd_b, ("found",), "fdone"),
-                    ("cbl", "side", fwd_c + t36 + bwd_c, ("found",), None),
-                    ("bwd", "bwd", t16 + bwd_b, ("fdone",), None)]
-        elif layout == "split_fwd":
-            # as "split", the K = 16 table behind the forward kernels on THEIR stream: off the backward chain, which is the longest
-            streams = ("search", "fwd", "bwd", "side")
-            segs = [("search", "search", search, (), "found"),
-                    ("fwd", "fwd", fwd_b + t16, ("found",), "fdone"),
-                    ("cbl", "side", fwd_c + t36 + bwd_c, ("found",), None),
-                    ("bwd", "bwd", bwd_b, ("fdone",), None)]
-        elif layout == "split_side_late":
-            # as "split", the CBL chain behind the forward kernels (the wave search of the next step then overlaps gather / KPConv only): pins the fast regime too
-            streams = ("search", "fwd", "bwd", "side")
-            segs = [("search", "search", search, (), "found"),
-                    ("fwd", "fwd", fwd_b, ("found",), "fdone"),
-                    ("cbl", "side", fwd_c + t36 + bwd_c, ("fdone",), None),
-                    ("bwd", "bwd", t16 + bwd_b, ("fdone",), None)]
         elif layout == "split_t36_first":
-            # The default.  As "split", the K=36 table in front of the CBL forward.  "split" has two stable regimes, 0.270 and 0.290 ms per step, picked by the
-            # timing of the first steps after an idle device (4 : 3 over processes, and from block to block inside one); with the table's small kernels — not the
-            # full-device pair kernel — beside the start of the next wave search and the gather, every run is the fast one (6 of 6, three and four slots).
+            # The default: the block's backward on a stream of its own behind its table, so that the backward kernels of step i run beside the forward kernels of
+            # step i+1; every table is built on the stream that consumes it (no table stream, no table events); the K=36 table IN FRONT of the CBL forward: with
+            # the pair kernel first the pipeline had two stable regimes, 0.270 and 0.290 ms per step, picked by the timing of the first steps after an idle
+            # device; with the table's small kernels — not the full-device pair kernel — beside the start of the next wave search and the gather, every run
+            # is the fast one (round 4: 12 of 12; the six other orders and a timed re-dealing of chains to streams that were measured then are in the history
+            # of this file and in DESIGN.md 6.4).
             streams = ("search", "fwd", "bwd", "side")
             segs = [("search", "search", search, (), "found"),
                     ("fwd", "fwd", fwd_b, ("found",), "fdone"),
                     ("cbl", "side", t36 + fwd_c + bwd_c, ("found",), None),
                     ("bwd", "bwd", t16 + bwd_b, ("fdone",), None)]
-        elif layout == "split_fwd_t36_first":
-            streams = ("search", "fwd", "bwd", "side")
-            segs = [("search", "search", search, (), "found"),
-                    ("fwd", "fwd", fwd_b + t16, ("found",), "fdone"),
-                    ("cbl", "side", t36 + fwd_c + bwd_c, ("found",), None),
-                    ("bwd", "bwd", bwd_b, ("fdone",), None)]
         elif layout == "alt_bwd":
             # for a block whose backward chain is longer than everything else of the step together (the Point Transformer block: 0.46 of 0.56 ms): consecutive
             # steps' backward chains on TWO streams in turn ("bwd*": by step parity), so that they overlap; the searches and the CBL chain share the fourth
@@ -508,14 +483,6 @@ class Pipeline:
                     ("fwd", "fwd", fwd_b + t16, ("found",), "fdone"),
                     ("cbl", "search", t36 + fwd_c + bwd_c, (), None),
                     ("bwd", "bwd*", bwd_b, ("fdone",), None)]
-        elif layout == "three":
-            # three chains for three hardware queues (a process has four, the default stream keeps one: a kernel trace of "split" showed the search and the
-            # forward chain on ONE queue, one behind the other): search | forward, then the CBL branch | the block's backward behind its table
-            streams = ("search", "main", "bwd")
-            segs = [("search", "search", search, (), "found"),
-                    ("fwd", "main", fwd_b, ("found",), "fdone"),
-                    ("cbl", "main", fwd_c + t36 + bwd_c, (), None),
-                    ("bwd", "bwd", t16 + bwd_b, ("fdone",), None)]
         else:
             raise ValueError("unknown pipeline layout %r" % layout)
         return streams, [sg for sg in segs if sg[2]]
@@ -538,11 +505,8 @@ class Pipeline:
     def describe(self):
         """the layout in words (bench.py's `config.issue`)"""
         chains = " | ".join("%s: %s" % (sg[1], "+".join(self.sched.stage_list[i][0] for i in sg[2])) for sg in self.segments)
-        tuned = getattr(self, "tuning", None)
         return ("layout '%s': one linear graph per segment on %d streams (stream: stages — %s), consecutive steps software-pipelined over %d output slots"
-                % (self.layout, len(self.STREAMS), chains, self.SLOTS)
-                + ("; chains dealt to the hardware queues by a timed trial of the %d assignments (best %.4f, worst %.4f, as created %.4f ms per step)"
-                   % (tuned["assignments_tried"], tuned["best_ms"], tuned["worst_ms"], tuned["as_created_ms"]) if tuned else ""))
+                % (self.layout, len(self.STREAMS), chains, self.SLOTS))
 
     def _segment(self, seg, state):
         for i in seg[2]:
@@ -575,40 +539,6 @@ class Pipeline:
         self.count = 0
         for _ in range(2 * self.SLOTS):                             # every graph has run, in pipeline order
             self.step()
-        torch.cuda.synchronize()
-        import os
-        if os.environ.get("CBL_PIPELINE_TUNE", "0") == "1":        # opt-in: the assignment did not decide the regime (see tune)
-            self.tune()
-
-    def tune(self, short=16, long=96, finalists=4):
-        """Re-deal the chains to the streams after capture (a replayed graph runs on the stream it is launched on): every assignment is timed over a few
-        steps, the best few again over more, the fastest kept (~0.4 s).  Written when the same build on the same box ran the step in 0.270 or in 0.291 ms
-        from process to process; the assignment turned out NOT to be the cause — blocks of steps inside one process, same assignment, fall into either regime
-        (tools/pipeline_regimes.py): the pipeline has two stable alignments of its chains, picked by the timing of the first steps after an idle device.  What
-        pins the fast one is in the layout (the CBL chain's table in front of its pair kernel: "split_t36_first").  Kept as an opt-in (CBL_PIPELINE_TUNE=1)."""
-        import itertools
-        import time
-        names = list(self.STREAMS)
-        base = [self.streams[nm] for nm in names]
-
-        def trial(perm, steps):
-            self.streams = {nm: base[i] for nm, i in zip(names, perm)}
-            self.count = 0
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                self.step()
-            self.join()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / steps * 1e3
-        first = {perm: trial(perm, short) for perm in itertools.permutations(range(len(base)))}
-        ranked = sorted(first, key=first.get)
-        second = {perm: min(trial(perm, long), trial(perm, long)) for perm in ranked[:finalists]}
-        best = min(second, key=second.get)
-        self.streams = {nm: base[i] for nm, i in zip(names, best)}
-        self.count = 0
-        self.tuning = {"assignments_tried": len(first), "best_ms": round(second[best], 4), "worst_ms": round(max(first.values()), 4),
-                       "as_created_ms": round(first[tuple(range(len(base)))], 4)}
         torch.cuda.synchronize()
 
     def step(self):

@@ -92,10 +92,10 @@ def test_the_step_bench_times_against_the_oracles(oracle, backward, pipeline):
     check_state(st_in.state, oracle, backward)
 
 
-@pytest.mark.parametrize("layout,slots", [("tables", 2), ("split", 3), ("split_fwd", 3), ("split_side_late", 2), ("split_fwd_t36_first", 3), ("three", 2), ("alt_bwd", 4)])
+@pytest.mark.parametrize("layout,slots", [("tables", 2), ("split_t36_first", 4), ("alt_bwd", 4)])
 def test_every_pipeline_layout_computes_the_step(oracle, layout, slots):
     """hotpath.Pipeline's stream layouts differ in what runs beside what, never in what is computed: every slot of every layout against the oracles
-    (the default, "split_t36_first" with three slots, is the pipeline case of the test above)"""
+    (the default, "split_t36_first" with three slots, is also the pipeline case of the test above)"""
     import bench
     from contrastboundary_amd import hotpath
     args = bench.parse([])
@@ -111,14 +111,5 @@ def test_every_pipeline_layout_computes_the_step(oracle, layout, slots):
     torch.cuda.synchronize()
     for st in pipe.states:
         check_state(st, oracle, True)
-    if layout == "tables":
-        pipe.tune(short=4, long=8, finalists=2)                           # the opt-in re-dealing of chains to streams leaves a working pipeline behind
-        assert pipe.tuning["assignments_tried"] == 24
-        for _ in range(slots + 1):
-            pipe.step()
-        pipe.join()
-        torch.cuda.synchronize()
-        for st in pipe.states:
-            check_state(st, oracle, True)
     with pytest.raises(ValueError):
         hotpath.Pipeline(step.sched, layout="no such layout")

@@ -7,7 +7,7 @@ KPCONV = ["knnquery_k16", "queryandgroup", "kpconv_fwd", "cbl_knnquery_k36", "cb
 PT = ["knnquery_k16", "pt_layer_fwd", "cbl_knnquery_k36", "cbl_neighbor_transpose", "cbl_mining_loss_fwd", "cbl_mining_loss_bwd", "neighbor_transpose_k16",
       "pt_layer_bwd"]
 FORWARD_ONLY = ["knnquery_k16", "queryandgroup", "kpconv_fwd", "cbl_knnquery_k36", "cbl_neighbor_transpose", "cbl_mining_loss_fwd", "cbl_mining_loss_bwd"]
-LAYOUTS = ["tables", "split", "split_fwd", "split_side_late", "split_t36_first", "split_fwd_t36_first", "alt_bwd", "three"]
+LAYOUTS = ["tables", "split_t36_first", "alt_bwd"]
 # stage -> stages that must have been issued on the same stream earlier, or on another stream behind an event the stage's segment waits for
 NEEDS = {"queryandgroup": ["knnquery_k16"], "kpconv_fwd": ["knnquery_k16"], "pt_layer_fwd": ["knnquery_k16"], "cbl_neighbor_transpose": ["cbl_knnquery_k36"],
          "cbl_mining_loss_fwd": ["cbl_knnquery_k36"], "cbl_mining_loss_bwd": ["cbl_mining_loss_fwd", "cbl_neighbor_transpose"],
