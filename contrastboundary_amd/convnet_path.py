@@ -12,6 +12,8 @@ multi-scale grid subsampling stress", and the per-scene work of "S3DIS full trai
 Shapes are data dependent (the number of voxels a layer keeps), so a step carries the host syncs the TF ops' dynamic shapes carry and is issued
 eagerly; `stages()` lists the stages with the ALGORITHMIC bytes of SURVEY.md 8(d), evaluated on the sizes the step produced.
 """
+import ctypes
+
 import numpy as np
 import torch
 
@@ -156,6 +158,84 @@ class PyramidLoader:
         self.pool.shutdown()
 
 
+class _CLayer(ctypes.Structure):
+    """include/cbl_amd.h CblConvnetLayer"""
+    _c = ctypes
+    _fields_ = [("n", _c.c_int), ("K", _c.c_int), ("C", _c.c_int), ("Kp", _c.c_int), ("d", _c.c_int), ("radius", _c.c_float),
+                ("points", _c.c_void_p), ("neighbors", _c.c_void_p), ("features", _c.c_void_p), ("fc_weight", _c.c_void_p), ("fc_bias", _c.c_void_p),
+                ("grad_out", _c.c_void_p), ("latent", _c.c_void_p), ("pools", _c.c_void_p),
+                ("aw_out", _c.c_void_p), ("grad_features", _c.c_void_p), ("grad_fc_weight", _c.c_void_p), ("grad_fc_bias", _c.c_void_p),
+                ("cbl_loss", _c.c_void_p), ("cbl_mask", _c.c_void_p), ("grad_latent", _c.c_void_p), ("labels", _c.c_void_p)]
+
+
+class NativeLayers:
+    """Every layer's AdaptiveWeight forward + backward, the scene labels and the contrast head forward + backward of one scene as ONE native call
+    (cbl_convnet_step, csrc/convnet_step.hip): what `stages()` issues op by op from Python — the same kernels in the same order — without the interpreter, the
+    autograd engine and the allocator between the ~70 launches.  Output buffers and the workspace are kept per layer-size signature (a resident scene
+    rebuilds the same pyramid; another scene's sizes get buffers of their own), so a step allocates nothing.
+
+        run = NativeLayers(scene)
+        out = run(pyr)        # -> {"aw_out": [...], "aw_grads": [(g_feat, g_w, g_b), ...], "labels": [...], "cbl_loss": [...], "cbl_mask": [...], "cbl_grad": [...]}"""
+
+    def __init__(self, scene, temperature=1.0, weight=0.1):
+        self.scene, self.temperature, self.weight = scene, float(temperature), float(weight)
+        self.buffers = {}
+
+    def _buffers(self, sizes, widths):
+        key = (tuple(sizes), tuple(widths))
+        hit = self.buffers.get(key)
+        if hit is not None:
+            return hit
+        sc, dev = self.scene, self.scene.device
+        f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        i = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
+        out = {"aw_out": [], "aw_grads": [], "labels": [], "cbl_loss": [], "cbl_mask": [], "cbl_grad": []}
+        for l, n in enumerate(sizes):
+            c = sc.widths[l]
+            out["aw_out"].append(f(n, c)); out["aw_grads"].append((f(n, c), f(3, c), f(c)))
+            out["labels"].append(i(n)); out["cbl_loss"].append(f(1)); out["cbl_mask"].append(i(n)); out["cbl_grad"].append(f(n, CBL_DIM))
+        hit = self.buffers[key] = {"out": out, "ws": None}
+        if len(self.buffers) > 8:                                   # a handful of scenes' signatures; drop the oldest
+            self.buffers.pop(next(iter(self.buffers)))
+        return hit
+
+    def __call__(self, pyr):
+        from . import _lib
+        sc = self.scene
+        L = _lib.lib()
+        nl = sc.layers
+        sizes = [int(p.shape[0]) for p in pyr["points"][:nl]]
+        widths = [int(nb.shape[1]) for nb in pyr["neighbors"][:nl]]
+        buf = self._buffers(sizes, widths)
+        out = buf["out"]
+        arr = (_CLayer * nl)()
+        keep = []
+        P = lambda t: ctypes.c_void_p(t.data_ptr())
+        for l in range(nl):
+            a = sc.layer_arrays(l, sizes[l])
+            nb = pyr["neighbors"][l]
+            pool = pyr["pools"][l - 1] if l > 0 else None
+            keep.append((a, nb, pool))
+            e = arr[l]
+            e.n, e.K, e.C, e.Kp, e.d = sizes[l], widths[l], sc.widths[l], (int(pool.shape[1]) if pool is not None else 0), CBL_DIM
+            e.radius = DL0 * DENSITY / 2.0 * 2 ** l
+            e.points, e.neighbors, e.features = P(pyr["points"][l]), P(nb), P(a["feat"])
+            e.fc_weight, e.fc_bias, e.grad_out, e.latent = P(sc.fc_weight[l]), P(sc.fc_bias[l]), P(a["grad"]), P(a["latent"])
+            e.pools = P(pool) if pool is not None else None
+            gf, gw, gb = out["aw_grads"][l]
+            e.aw_out, e.grad_features, e.grad_fc_weight, e.grad_fc_bias = P(out["aw_out"][l]), P(gf), P(gw), P(gb)
+            e.cbl_loss, e.cbl_mask, e.grad_latent, e.labels = P(out["cbl_loss"][l]), P(out["cbl_mask"][l]), P(out["cbl_grad"][l]), P(out["labels"][l])
+        if buf["ws"] is None:
+            L.cbl_convnet_step_workspace_bytes.restype = ctypes.c_size_t
+            need = L.cbl_convnet_step_workspace_bytes(ctypes.c_int(nl), arr, ctypes.c_int(NUM_CLASSES))
+            buf["ws"] = torch.empty(max(int(need), 1), dtype=torch.uint8, device=sc.device)
+        ws = buf["ws"]
+        labels64 = sc.labels if sc.labels.dtype == torch.int64 else sc.labels.long()
+        _lib.check(L.cbl_convnet_step(ctypes.c_int(nl), arr, P(labels64), ctypes.c_int(NUM_CLASSES), ctypes.c_float(self.temperature), ctypes.c_float(self.weight),
+                                      P(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(ws)), "cbl_convnet_step")
+        return out
+
+
 def stages(scene, backward=True, cbl=True, loader=None):
     """-> list of (name, fn(state), bytes_fn(state) -> algorithmic bytes, flops_fn(state)); fns communicate through `state`.
     loader (a PyramidLoader): the pyramid stage takes the pyramid the loader built beside the previous step and asks for the next one."""
@@ -218,6 +298,25 @@ def stages(scene, backward=True, cbl=True, loader=None):
         st.append(("tf_cbl_fwd_bwd_l%d" % l, cbl_fb, lambda s, l=l: 4 * s["pyr"]["neighbors"][l].numel() + s["pyr"]["neighbors"][l].shape[0] * (8 * CBL_DIM + 4),
                    lambda s, l=l: 1.0 * s["pyr"]["neighbors"][l].numel() * (3 * CBL_DIM + 20)))
     return st
+
+
+def native_stages(scene, loader=None, runner=None):
+    """the step as two stages: the pyramid (from the loader thread when there is one), then every layer's work as ONE native call (NativeLayers)"""
+    L = scene.layers
+    limits = LIMITS[:L]
+    runner = runner if runner is not None else NativeLayers(scene)
+
+    def pyramid(s):
+        if loader is not None:
+            s["pyr"] = loader.take()
+            loader.submit()
+            return
+        s["pyr"] = tf_ops.segmentation_inputs_radius(scene.points, scene.lengths, DL0, DENSITY, L, limits + [limits[-1]])
+
+    def layers(s):
+        s["native"] = runner(s["pyr"])
+    return [("pyramid_radius_grid", pyramid, lambda s: pyramid_bytes(s["pyr"]), lambda s: 0.0),
+            ("layers_native_call", layers, lambda s: 0, lambda s: 0.0)]
 
 
 def run_once(scene, state=None, backward=True, cbl=True, stage_list=None):

@@ -641,6 +641,38 @@ int cbl_pyramid(int b, int n, const float* points, const int* lengths, float rad
                 void* const* grid_ws, size_t grid_ws_bytes, int* const* neighbors, float* const* pool_points, int* const* pool_lengths,
                 int* const* pools, int* const* upsamples, int* max_counts, int* host_sizes, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The ConvNet's per-scene work behind the pyramid as ONE host call (no counterpart as a single function in the reference: there these are TF graph ops
+ * issued by the TF runtime — local_aggregation_operators.py:360-484 under tf.gradients, heads/head.py:25-49 and :462-807): for every layer
+ * AdaptiveWeight forward + backward ('mean' reduction, gradients as gathers over the layer's transposed neighbour table), the scene labels of the
+ * layer (layer 0: point_labels; layer l: arg-max of the label histogram over `pools`, indices into layer l-1, pad = its point count) and the
+ * contrast head ('softnn', 'l2', sample 'label') forward + gradient w.r.t. `latent` (loss upstream gradient 1).  The same kernels, in the same order,
+ * as cbl_index_max / cbl_adaptive_weight_forward / cbl_neighbor_transpose / cbl_adaptive_weight_backward_csr / cbl_tf_scene_label /
+ * cbl_label_argmax / cbl_contrast_pairs_forward_samples / cbl_contrast_pairs_backward called one by one; nothing waits for the device.
+ * All pointers are device pointers; outputs are written (no pre-zeroing).  C % 4 == 0, d in {4,8,16,32,64}, K <= 65. */
+typedef struct CblConvnetLayer {
+    int n, K, C, Kp, d;            /* points of the layer; width of `neighbors`; AdaptiveWeight width; width of `pools` (0 at layer 0); latent width */
+    float radius;                  /* AdaptiveWeight's radius of this layer */
+    const float* points;           /* (n,3) */
+    const int* neighbors;          /* (n,K) radius neighbours incl. the self column, padded with n */
+    const float* features;         /* (n,C) */
+    const float* fc_weight;        /* (3,C) */
+    const float* fc_bias;          /* (C) */
+    const float* grad_out;         /* (n,C) upstream gradient of the aggregation's output */
+    const float* latent;           /* (n,d) features of the contrast head */
+    const int* pools;              /* (n,Kp) pooling neighbours into layer l-1 (NULL at layer 0) */
+    float* aw_out;                 /* (n,C) */
+    float* grad_features;          /* (n,C) */
+    float* grad_fc_weight;         /* (3,C) */
+    float* grad_fc_bias;           /* (C) */
+    float* cbl_loss;               /* (1) */
+    int* cbl_mask;                 /* (n) 1 = the point has positive and negative neighbours */
+    float* grad_latent;            /* (n,d) */
+    int* labels;                   /* (n) hard scene labels of this layer */
+} CblConvnetLayer;
+size_t cbl_convnet_step_workspace_bytes(int nlayers, const CblConvnetLayer* layers, int num_classes);
+int cbl_convnet_step(int nlayers, const CblConvnetLayer* layers, const long long* point_labels, int num_classes, float temperature, float weight,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
 /* N4  cpp_knn_batch_omp  tensorflow/ops/nearest_neighbors/knn_.cxx:104-135: dense batch (B,N,3) x (B,M,3) -> (B,M,K) int64 LOCAL indices.
  *     = cbl_knnquery on the flattened batch (offset = N, 2N, ...) followed by this conversion of the global int32 rows. */
 int cbl_knn_indices_to_local(int B, int M, int K, int N, const int* idx, long long* out, void* stream);

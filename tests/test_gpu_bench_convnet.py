@@ -66,6 +66,41 @@ def test_convnet_step_against_the_oracles():
         p, l, r, dl = pp, pl, 2 * r, 2 * dl
 
 
+@pytest.mark.parametrize("n", [30000, 200000])
+def test_native_layers_call_equals_the_ops_issued_one_by_one(n):
+    """cbl_convnet_step (convnet_path.NativeLayers: every layer's AdaptiveWeight forward + backward, scene labels and contrast head as ONE native call) against
+    the same scene through the autograd Functions (which the test above holds to the oracles): the same kernels in the same order — bit-identical wherever
+    the op-by-op path takes the transposed table too (tables of >= 65536 pairs; below that it scatters with float atomics: 1e-5 there), run twice (buffers
+    and workspace are re-used), and a second scene of other sizes through the same runner"""
+    from contrastboundary_amd import convnet_path as CP, pointops
+    scene = CP.ConvNetScene(n, seed=2)
+    state = CP.run_once(scene)
+    runner = CP.NativeLayers(scene)
+    for rep in range(2):
+        out = runner(state["pyr"])
+    torch.cuda.synchronize()
+    for lay in range(CP.NUM_LAYERS):
+        exact = state["pyr"]["neighbors"][lay].numel() >= pointops.TRANSPOSE_MIN_PAIRS
+        same = (lambda a, b: torch.equal(a, b)) if exact else (lambda a, b: torch.allclose(a, b, rtol=1e-5, atol=1e-5 * float(b.abs().max())))
+        assert torch.equal(out["aw_out"][lay], state["aw_out%d" % lay]), lay
+        for got, ref in zip(out["aw_grads"][lay], state["aw_grads%d" % lay]):
+            assert got.shape == ref.shape and same(got, ref), (lay, exact)
+        assert torch.equal(out["labels"][lay].long(), state["labels"][lay].long()), lay
+        assert torch.equal(out["cbl_loss"][lay].reshape(()), state["cbl_loss%d" % lay].reshape(())), lay
+        assert torch.equal(out["cbl_mask"][lay], state["cbl_mask%d" % lay]), lay
+        assert same(out["cbl_grad"][lay], state["cbl_grad%d" % lay]), (lay, exact)
+    # the native stage list (pyramid + one call) is what bench.py times
+    st = CP.run_once(scene, stage_list=CP.native_stages(scene, runner=runner))
+    torch.cuda.synchronize()
+    assert torch.equal(st["native"]["aw_out"][0], state["aw_out0"])
+    if n == 30000:
+        other = CP.ConvNetScene(21000, seed=5)
+        st2 = CP.run_once(other)
+        out2 = CP.NativeLayers(other)(st2["pyr"])
+        torch.cuda.synchronize()
+        assert torch.equal(out2["aw_out"][1], st2["aw_out1"]) and torch.equal(out2["cbl_mask"][0], st2["cbl_mask0"])
+
+
 def test_convnet_step_full_size_properties():
     """N = 200000 (BASELINE config C5): linearity of AdaptiveWeight in its features, rows sorted and inside the ball, idempotent stage labels"""
     from contrastboundary_amd import convnet_path as CP, local_aggregation as LA
