@@ -696,8 +696,8 @@ def run_convnet(args, D, world, rank, local):
         e_p, p_regions = timed_median(p_step, args.steps, args.warmup, p_sync, D)
         pipelined = {"ms_per_step": e_p / args.steps * 1e3, "value": n * args.steps * world / e_p, "timed_regions_ms_per_step": p_regions,
                      "host_issue_ms_per_step": timed_region.issue_s / args.steps * 1e3,
-                     "issue": "eager on two host threads: a loader thread builds the next step's pyramid (one native cbl_pyramid_layer call per layer, stream of "
-                              "its own) beside this step's layers (convnet_path.PyramidLoader)"}
+                     "issue": "eager: loader threads (convnet_path.PyramidLoader, %d pyramids in flight, a thread and stream each: the input pipeline's prefetch) build the "
+                              "coming steps' pyramids (one native cbl_pyramid call each) beside this step's layers, issued op by op from Python" % loader.depth}
         loader.close()
         if e_p < elapsed:
             elapsed = e_p
@@ -718,9 +718,9 @@ def run_convnet(args, D, world, rank, local):
         e_n, n_regions = timed_median(n_step, args.steps, args.warmup, n_sync, D)
         native = {"ms_per_step": e_n / args.steps * 1e3, "value": n * args.steps * world / e_n, "timed_regions_ms_per_step": n_regions,
                   "host_issue_ms_per_step": timed_region.issue_s / args.steps * 1e3,
-                  "issue": "two host threads, two native calls per step: a loader thread builds the next step's pyramid (cbl_pyramid, stream of its own) beside ONE "
-                           "cbl_convnet_step call that issues every layer's AdaptiveWeight forward + backward, scene labels and contrast head "
-                           "(convnet_path.NativeLayers; tests/test_gpu_bench_convnet.py: bit-identical to the op-by-op step)"}
+                  "issue": "two native calls per step: loader threads (%d pyramids in flight, a thread and stream each) build the coming steps' pyramids (cbl_pyramid) "
+                           "beside ONE cbl_convnet_step call that issues every layer's AdaptiveWeight forward + backward, scene labels and contrast head "
+                           "(convnet_path.NativeLayers; tests/test_gpu_bench_convnet.py: bit-identical to the op-by-op step)" % loader.depth}
         loader.close()
         pipelined_ops = pipelined
         if e_n <= elapsed:

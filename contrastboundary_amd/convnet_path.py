@@ -112,49 +112,58 @@ class PyramidLoader:
     Python lock, so the two threads really run side by side (the op-by-op builder on a Python thread was measured SLOWER than in order:
     4.5-4.9 ms against 4.2 — the interpreter lock).  take() hands the finished pyramid to the caller's stream (event + record_stream)."""
 
-    def __init__(self, scene):
+    def __init__(self, scene, depth=2):
+        """depth: pyramids in flight ahead of the consumer, each on a loader thread and stream of its own (tf.data's num_parallel_calls + prefetch).  One
+        pyramid is a chain of ~130 mostly small launches with four host waits (the sub-sampled counts): ~3 ms of wall time for 1.9 ms of kernels, so with ONE
+        pyramid in flight the step waited for the loader (3.04 ms per step whether the layers were issued by Python or by one native call, round 5); two
+        chains side by side deliver a pyramid every ~1.5 ms."""
         from concurrent.futures import ThreadPoolExecutor
         self.scene = scene
         self.device = scene.points.device
-        self.stream = torch.cuda.Stream(device=self.device)
-        self.pool = ThreadPoolExecutor(max_workers=1)
-        self.pending = None
+        self.depth = max(1, int(depth))
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
+        self.pool = ThreadPoolExecutor(max_workers=self.depth)
+        self.pending = []                                            # futures, oldest first
+        self.turn = 0
 
-    def _build(self):
+    def _build(self, stream):
         torch.cuda.set_device(self.device)
         sc, L = self.scene, self.scene.layers
         limits = LIMITS[:L]
-        with torch.cuda.stream(self.stream):
+        with torch.cuda.stream(stream):
             pyr = tf_ops.segmentation_inputs_radius(sc.points, sc.lengths, DL0, DENSITY, L, limits + [limits[-1]])
             ev = torch.cuda.Event()
             ev.record()
         return pyr, ev
 
     def submit(self):
-        if self.pending is None:
-            self.stream.wait_stream(torch.cuda.current_stream(self.device))     # whatever prepared the scene
-            self.pending = self.pool.submit(self._build)
+        """keep `depth` pyramids in flight"""
+        while len(self.pending) < self.depth:
+            stream = self.streams[self.turn % self.depth]
+            self.turn += 1
+            stream.wait_stream(torch.cuda.current_stream(self.device))          # whatever prepared the scene
+            self.pending.append(self.pool.submit(self._build, stream))
 
     def take(self):
-        """the pyramid submitted last (built now if none was), usable on the caller's current stream"""
+        """the oldest pyramid in flight (built now if none was), usable on the caller's current stream"""
         self.submit()
-        pyr, ev = self.pending.result()
-        self.pending = None
+        pyr, ev = self.pending.pop(0).result()
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(ev)
         for v in pyr.values():
             for t in v:
                 if torch.is_tensor(t) and t.is_cuda:
-                    t.record_stream(cur)                                        # allocated on the loader's stream, consumed on the caller's
+                    t.record_stream(cur)                                        # allocated on a loader's stream, consumed on the caller's
         return pyr
 
     def drain(self):
-        """wait until the loader thread has issued everything it was asked for (before a device-wide synchronize that closes a timed region)"""
-        if self.pending is not None:
-            self.pending.result()
+        """wait until the loader threads have issued everything they were asked for (before a device-wide synchronize that closes a timed region)"""
+        for f in self.pending:
+            f.result()
 
     def close(self):
         self.drain()
+        self.pending = []
         self.pool.shutdown()
 
 
