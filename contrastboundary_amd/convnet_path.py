@@ -112,11 +112,11 @@ class PyramidLoader:
     Python lock, so the two threads really run side by side (the op-by-op builder on a Python thread was measured SLOWER than in order:
     4.5-4.9 ms against 4.2 — the interpreter lock).  take() hands the finished pyramid to the caller's stream (event + record_stream)."""
 
-    def __init__(self, scene, depth=2):
-        """depth: pyramids in flight ahead of the consumer, each on a loader thread and stream of its own (tf.data's num_parallel_calls + prefetch).  One
-        pyramid is a chain of ~130 mostly small launches with four host waits (the sub-sampled counts): ~3 ms of wall time for 1.9 ms of kernels, so with ONE
-        pyramid in flight the step waited for the loader (3.04 ms per step whether the layers were issued by Python or by one native call, round 5); two
-        chains side by side deliver a pyramid every ~1.5 ms."""
+    def __init__(self, scene, depth=1):
+        """depth: pyramids in flight ahead of the consumer, each on a loader thread and stream of its own (tf.data's num_parallel_calls + prefetch).  One is
+        enough here: with the layers issued by one native call the step is 3.04 ms whether one or two pyramids are in flight (two: 3.13 - 3.30 ms) — the
+        device, not the loader, is what the step waits for (1.9 ms of pyramid kernels + 2.5 ms of layer kernels share it).  `waited_s` accumulates the time
+        take() spent waiting for a loader thread (a consumer that is faster than the pyramid chain), so that callers can tell issue time from waiting."""
         from concurrent.futures import ThreadPoolExecutor
         self.scene = scene
         self.device = scene.points.device
@@ -125,6 +125,7 @@ class PyramidLoader:
         self.pool = ThreadPoolExecutor(max_workers=self.depth)
         self.pending = []                                            # futures, oldest first
         self.turn = 0
+        self.waited_s = 0.0
 
     def _build(self, stream):
         torch.cuda.set_device(self.device)
@@ -146,8 +147,11 @@ class PyramidLoader:
 
     def take(self):
         """the oldest pyramid in flight (built now if none was), usable on the caller's current stream"""
+        import time
         self.submit()
+        t0 = time.perf_counter()
         pyr, ev = self.pending.pop(0).result()
+        self.waited_s += time.perf_counter() - t0
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(ev)
         for v in pyr.values():
