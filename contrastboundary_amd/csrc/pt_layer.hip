@@ -804,7 +804,7 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
 // partial row: T1[a] = sum d, T2[a] = sum d p0hat[a], T3[a][b] = sum d[a] p_r[b]   with d = (p1 > 0) d p1
 __global__ __launch_bounds__(PT_NARROW_BLOCK) void pt_pchain_bwd_kernel(long long npairs, const float* __restrict__ p_r, const float* __restrict__ p0,
                                                                         const float* __restrict__ p1, const float* __restrict__ gp1, const float* __restrict__ cst,
-                                                                        float* __restrict__ partial)
+                                                                        float* __restrict__ partial, const float* __restrict__ gp1b = nullptr)
 {
     __shared__ float red[PT_NARROW_BLOCK / 64][15];
     float is[3], nm[3], acc[15];
@@ -815,7 +815,7 @@ __global__ __launch_bounds__(PT_NARROW_BLOCK) void pt_pchain_bwd_kernel(long lon
     for (long long p = (long long)blockIdx.x * PT_NARROW_BLOCK + threadIdx.x; p < npairs; p += (long long)gridDim.x * PT_NARROW_BLOCK) {
         float d[3], r[3];
 #pragma unroll
-        for (int t = 0; t < 3; t++) { d[t] = p1[3 * p + t] > 0.f ? gp1[3 * p + t] : 0.f; r[t] = p_r[3 * p + t]; }
+        for (int t = 0; t < 3; t++) { d[t] = p1[3 * p + t] > 0.f ? (gp1b ? gp1[3 * p + t] + gp1b[3 * p + t] : gp1[3 * p + t]) : 0.f; r[t] = p_r[3 * p + t]; }
 #pragma unroll
         for (int a = 0; a < 3; a++) {
             acc[a] += d[a]; acc[3 + a] = fmaf(d[a], fmaf(p0[3 * p + a], is[a], nm[a]), acc[3 + a]);
@@ -1139,7 +1139,7 @@ CBL_EXPORT int cbl_pt_layer_backward(int n, int K, int C, const float* x_q, cons
                        ws.bc + PT_BC_C, 64, g_gamma_c, g_beta_c, (const float*)nullptr, (float*)nullptr);
 #define PT_APPLY(CC, KK) hipLaunchKernelGGL((pt_w2_bwd_kernel<CC, KK, true>), dim3(gt), dim3(PT_BLOCK), 0, st, n, order, x_q, x_k, idx, p1, consts, ws.bc, W3C, b3C, Wa, w2, ws.pre, ws.gw2, a, grad_out, g_xq, ws.gp1, ws.part_b)
     PT_DISPATCH(PT_APPLY)
-    hipLaunchKernelGGL(pt_pchain_bwd_kernel, dim3(gp), dim3(PT_NARROW_BLOCK), 0, st, np, p_r, p0, p1, ws.gp1, consts, ws.part_d);
+    hipLaunchKernelGGL(pt_pchain_bwd_kernel, dim3(gp), dim3(PT_NARROW_BLOCK), 0, st, np, p_r, p0, p1, ws.gp1, consts, ws.part_d, (const float*)nullptr);
     hipLaunchKernelGGL(pt_pchain_epilogue_kernel, dim3(1), dim3(PT_FIN_THREADS), 0, st, (int)gp, ws.part_d, np, consts, gamma_p, g_Wp, g_bp, g_gamma_p, g_beta_p);
     {
         const unsigned tg = cbl_round_up8(cbl_grid_for(((long long)n + (256 / (C / 4)) - 1) / (256 / (C / 4)), 1, 2048));
@@ -1153,6 +1153,242 @@ CBL_EXPORT int cbl_pt_layer_backward(int n, int K, int C, const float* x_q, cons
     segs.s[2] = PtSumSeg{ws.part_b, g_b3C, (int)gt, 4 * C, 3 * C, C};
     segs.s[3] = PtSumSeg{ws.part_c, g_Wb, (int)gp, WN, 2 * G, G * G};
     segs.s[4] = PtSumSeg{ws.part_c, g_bb, (int)gp, WN, 2 * G + G * G, G};
+    unsigned nblk = 0;
+    for (int q = 0; q < segs.n; q++) nblk += (unsigned)((segs.s[q].count + 15) / 16);
+    hipLaunchKernelGGL(pt_sum_rows_kernel, dim3(nblk), dim3(PT_FIN_THREADS), 0, st, segs);
+    return cbl_status();
+}
+
+
+// =====================================================================================================================================
+// The WIDE stages (C = 128 / 256 / 512, G = C / 8 = 16 / 32 / 64, K = 16; n = 2560 / 640 / 160 points of a 40960-point scene): 13 of the network's 18
+// Point Transformer blocks.  Their C-wide work already runs as six fused kernels (csrc/attention.hip: statistics, w2, aggregation, and the three
+// backward passes — pair values recomputed, nothing (n, K, C) stored), but everything around them was issued op by op through autograd: ~100 launches
+// per layer, most of them at their launch floor (profiles/r05_wide_layer_kernel_stats.csv).  These two entries are the whole layer behind its q / k / v
+// projections as ONE call each way: the p chain, BN_p / BN_g statistics and their finalizes (the kernels of the full-resolution layer above: they do not
+// depend on C), the six attention.hip kernels through their C entries, and four small kernels of this file for the narrow (n, K, G) tensors at any
+// G <= 64 — ~10 launches forward, ~15 backward, no allocator, no autograd engine, no gradient-accumulation adds in between.
+// =====================================================================================================================================
+namespace {
+
+constexpr int PW_CST_G = 352;                       // [4][64]  scale, shift, mean, invstd of BN_g (G <= 64); BN_p stays at PT_CST_P, the p sums at PT_FS_P
+constexpr int PW_FS_G = 608;                        // raw sums of w2 [64]
+constexpr int PW_CST_FLOATS = 672;
+constexpr int PW_ROWS = 256;                        // partial rows (= workgroups) of the narrow kernels below
+
+// p1 = ReLU(BN_p(p0)) on (n K, 3): the attention.hip kernels take it materialised
+__global__ __launch_bounds__(256) void pw_p1_kernel(long long total, const float* __restrict__ p0, const float* __restrict__ cst, float* __restrict__ p1)
+{
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int t = (int)(e % 3);
+        p1[e] = fmaxf(fmaf(p0[e], cst[PT_CST_P + t], cst[PT_CST_P + 4 + t]), 0.f);
+    }
+}
+
+// BN_g statistics of w2 (n K, G): partial row = sum [G] | sum of squares [G]; thread (slice, g) walks the workgroup's pairs
+__global__ __launch_bounds__(256) void pw_gstats_kernel(long long npairs, int G, const float* __restrict__ w2, float* __restrict__ partial)
+{
+    __shared__ float red[2][256];
+    const int g = threadIdx.x % G, sl = threadIdx.x / G, nsl = 256 / G;
+    const long long per = (npairs + gridDim.x - 1) / gridDim.x, p0 = (long long)blockIdx.x * per, p1 = min(npairs, p0 + per);
+    float a = 0.f, b = 0.f;
+    for (long long p = p0 + sl; p < p1; p += nsl) { const float x = w2[p * G + g]; a += x; b = fmaf(x, x, b); }
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = b;
+    __syncthreads();
+    if (threadIdx.x < G) {
+        float sa = 0.f, sb = 0.f;
+        for (int q = 0; q < nsl; q++) { sa += red[0][q * G + threadIdx.x]; sb += red[1][q * G + threadIdx.x]; }
+        partial[(size_t)blockIdx.x * (2 * G) + threadIdx.x] = sa; partial[(size_t)blockIdx.x * (2 * G) + G + threadIdx.x] = sb;
+    }
+}
+
+// logits = Linear(G, G)(ReLU(BN_g(w2))): a batch of 256 / G pairs per trip, thread (pair of the batch, output o); Wb in LDS (rows padded by one: threads of
+// consecutive o read consecutive rows)
+__global__ __launch_bounds__(256) void pw_logits_kernel(long long npairs, int G, const float* __restrict__ w2, const float* __restrict__ cst, const float* __restrict__ Wb,
+                                                        const float* __restrict__ bb, float* __restrict__ logits)
+{
+    extern __shared__ float lds[];
+    float* wbs = lds;                                               // [G][G + 1]
+    float* w3s = lds + G * (G + 1);                                 // [256 / G][G]
+    for (int e = threadIdx.x; e < G * G; e += 256) wbs[(e / G) * (G + 1) + e % G] = Wb[e];
+    const int o = threadIdx.x % G, pl = threadIdx.x / G, PB = 256 / G;
+    const float sc = cst[PW_CST_G + o], sh = cst[PW_CST_G + 64 + o], bias = bb[o];
+    const long long nb = (npairs + PB - 1) / PB;
+    for (long long bt = blockIdx.x; bt < nb; bt += gridDim.x) {
+        const long long p = bt * PB + pl;
+        __syncthreads();                                            // the previous batch is consumed (first trip: Wb is in place)
+        w3s[pl * G + o] = p < npairs ? fmaxf(fmaf(w2[p * G + o], sc, sh), 0.f) : 0.f;
+        __syncthreads();
+        float acc = bias;
+        for (int g = 0; g < G; g++) acc = fmaf(wbs[o * (G + 1) + g], w3s[pl * G + g], acc);
+        if (p < npairs) logits[p * G + o] = acc;
+    }
+}
+
+// backward of Linear(G, G), ReLU and (its sums only) BN_g: pre = (y > 0) Wb^T d logits, written; partial row = S1 [G] | S2 [G] | d Wb [G][G] | d bb [G]
+// (the layout of pt_narrow_bwd_kernel, so the finalize / sum kernels above serve both)
+__global__ __launch_bounds__(256) void pw_narrow_bwd_kernel(long long npairs, int G, const float* __restrict__ w2, const float* __restrict__ cst, const float* __restrict__ Wb,
+                                                            const float* __restrict__ glogit, float* __restrict__ pre, float* __restrict__ partial)
+{
+    extern __shared__ float lds[];
+    const int PB = 256 / G, NE = G * G / 256;                       // pairs per batch; d Wb entries per thread (1, 4, 16)
+    float* wbs = lds;                                               // [G][G]      (thread g reads column g: consecutive)
+    float* gls = wbs + G * G;                                       // [PB][G]  d logits of the batch
+    float* w3s = gls + 256;                                         // [PB][G]  ReLU(BN_g(w2))
+    float* prs = w3s + 256;                                         // [PB][G]  pre
+    float* pxs = prs + 256;                                         // [PB][G]  pre * xhat
+    for (int e = threadIdx.x; e < G * G; e += 256) wbs[e] = Wb[e];
+    const int g = threadIdx.x % G, pl = threadIdx.x / G;
+    const float sc = cst[PW_CST_G + g], sh = cst[PW_CST_G + 64 + g], is = cst[PW_CST_G + 192 + g], nm = -cst[PW_CST_G + 128 + g] * is;
+    float acc[16], s1 = 0.f, s2 = 0.f, sb = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; q++) acc[q] = 0.f;
+    const long long per = (npairs + gridDim.x - 1) / gridDim.x, b0 = (long long)blockIdx.x * per, b1 = min(npairs, b0 + per);
+    for (long long base = b0; base < b1; base += PB) {
+        const long long p = base + pl;
+        const bool live = p < b1;
+        __syncthreads();
+        const float x = live ? w2[p * G + g] : 0.f, y = fmaf(x, sc, sh);
+        gls[pl * G + g] = live ? glogit[p * G + g] : 0.f;
+        w3s[pl * G + g] = live ? fmaxf(y, 0.f) : 0.f;
+        __syncthreads();
+        float sacc = 0.f;
+        for (int o = 0; o < G; o++) sacc = fmaf(wbs[o * G + g], gls[pl * G + o], sacc);
+        const float d = (live && y > 0.f) ? sacc : 0.f;
+        if (live) pre[p * G + g] = d;
+        prs[pl * G + g] = d; pxs[pl * G + g] = d * fmaf(x, is, nm);
+        __syncthreads();
+        if (threadIdx.x < G) {                                      // thread g: the batch's column sums (fixed order)
+            for (int q = 0; q < PB; q++) { s1 += prs[q * G + g]; s2 += pxs[q * G + g]; sb += gls[q * G + g]; }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            if (q < NE) {
+                const int e = threadIdx.x + 256 * q, eo = e / G, eg = e % G;
+                float t = acc[q];
+                for (int r = 0; r < PB; r++) t = fmaf(gls[r * G + eo], w3s[r * G + eg], t);
+                acc[q] = t;
+            }
+        }
+    }
+    float* row = partial + (size_t)blockIdx.x * (3 * G + G * G);
+    if (threadIdx.x < G) { row[threadIdx.x] = s1; row[G + threadIdx.x] = s2; row[2 * G + G * G + threadIdx.x] = sb; }
+#pragma unroll
+    for (int q = 0; q < 16; q++)
+        if (q < NE) row[2 * G + threadIdx.x + 256 * q] = acc[q];
+}
+
+// d w2 = A1 pre + A2 w2 + A3  (BatchNorm backward with the batch sums folded into the three per-channel coefficients)
+__global__ __launch_bounds__(256) void pw_bn_apply_kernel(long long total, int G, const float* __restrict__ pre, const float* __restrict__ w2, const float* __restrict__ bc,
+                                                          float* __restrict__ gw2)
+{
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int g = (int)(e % G);
+        gw2[e] = fmaf(bc[g], pre[e], fmaf(bc[64 + g], w2[e], bc[128 + g]));
+    }
+}
+
+struct PwWs { float *part_p, *part_g, *part_n, *part_d, *bc_g, *logits, *glogit, *pre, *gw2, *gp1a, *gp1b, *w3c2, *b3c2, *gba2; void* attn; size_t attn_bytes; size_t bytes; };
+PwWs pw_workspace(char* base, int n, int K, int C)
+{
+    const size_t np = (size_t)n * K, G = C / 8;
+    PwWs w; size_t o = 0;
+    auto takeb = [&](size_t bytes) { char* p = base ? base + o : nullptr; o += (bytes + 255) & ~(size_t)255; return p; };
+    auto take = [&](size_t cnt) { return reinterpret_cast<float*>(takeb(cnt * sizeof(float))); };
+    w.part_p = take((size_t)PT_NARROW_MAX_ROWS * 18);
+    w.part_g = take((size_t)PW_ROWS * 2 * G);
+    w.part_n = take((size_t)PW_ROWS * (3 * G + G * G));
+    w.part_d = take((size_t)PT_NARROW_MAX_ROWS * 16);
+    w.bc_g = take(192);
+    w.logits = take(np * G); w.glogit = take(np * G); w.pre = take(np * G); w.gw2 = take(np * G);
+    w.gp1a = take(np * 3); w.gp1b = take(np * 3);
+    w.w3c2 = take(2 * 3 * (size_t)C); w.b3c2 = take(2 * (size_t)C); w.gba2 = take(2 * G);
+    w.attn_bytes = cbl_attn_workspace_bytes(C, (int)G);
+    w.attn = takeb(w.attn_bytes);
+    w.bytes = o;
+    return w;
+}
+bool pw_shape_ok(int n, int K, int C) { return n >= 1 && K >= 1 && K <= 64 && (C == 128 || C == 256 || C == 512) && (long long)n * K < (1ll << 28); }
+
+}  // namespace
+
+CBL_EXPORT size_t cbl_pt_layer_wide_workspace_bytes(int n, int K, int C) { return pw_shape_ok(n, K, C) ? pw_workspace(nullptr, n, K, C).bytes : 0; }
+CBL_EXPORT int cbl_pt_layer_wide_consts_floats(void) { return PW_CST_FLOATS; }
+
+CBL_EXPORT int cbl_pt_layer_wide_forward(int n, int K, int C, const float* xyz, const float* x_q, const float* x_k, const float* x_v, const int* idx,
+                                         const float* Wp, const float* bp, const float* gamma_p, const float* beta_p, const float* W3C, const float* b3C,
+                                         const float* gamma_c, const float* beta_c, const float* Wa, const float* ba, const float* gamma_g, const float* beta_g,
+                                         const float* Wb, const float* bb, const float* eps3, const float* momentum3, float* const* running_mean3,
+                                         float* const* running_var3, long long* const* num_batches3, float* p_r, float* p0, float* p1, float* w2, float* a, float* out,
+                                         float* consts, float* bnc_stats, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!pw_shape_ok(n, K, C)) return CBL_ERR_UNSUPPORTED;
+    if (!eps3 || !momentum3 || !consts || !bnc_stats || !workspace) return CBL_ERR_BAD_ARG;
+    if (workspace_bytes < cbl_pt_layer_wide_workspace_bytes(n, K, C)) return CBL_ERR_WORKSPACE;
+    const PwWs ws = pw_workspace(static_cast<char*>(workspace), n, K, C);
+    hipStream_t st = cbl_stream(stream);
+    const long long np = (long long)n * K;
+    const int G = C / 8;
+    const unsigned gp = pt_pair_grid(np);
+    float* rm[3] = {nullptr, nullptr, nullptr}; float* rv[3] = {nullptr, nullptr, nullptr}; long long* nb[3] = {nullptr, nullptr, nullptr};
+    for (int t = 0; t < 3; t++) { if (running_mean3) rm[t] = running_mean3[t]; if (running_var3) rv[t] = running_var3[t]; if (num_batches3) nb[t] = num_batches3[t]; }
+    int rc;
+    // p chain + BN_p, then p1 materialised for the attention kernels
+    hipLaunchKernelGGL(pt_pchain_kernel, dim3(gp), dim3(PT_NARROW_BLOCK), 0, st, np, cbl_fastdiv_make((unsigned)K), xyz, idx, Wp, bp, p_r, p0, ws.part_p, (const float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL(pt_bn_finalize_kernel, dim3(2), dim3(PT_FIN_THREADS), 0, st, (int)gp, 18, ws.part_p, 3, 0, 3, np, gamma_p, beta_p, eps3[0], momentum3[0],
+                       rm[0], rv[0], nb[0], consts + PT_CST_P, 4, 18, consts + PT_FS_P);
+    hipLaunchKernelGGL(pw_p1_kernel, dim3(cbl_grid_for(3 * np, 256, 1024)), dim3(256), 0, st, 3 * np, p0, consts, p1);
+    // w2 = Wa ReLU(BN_c(x_k[j] - x_q[i] + pe)) + ba: statistics pass, finalize (running statistics), product — attention.hip
+    if ((rc = cbl_attn_w2_forward(n, K, C, G, x_q, x_k, idx, p1, W3C, b3C, gamma_c, beta_c, eps3[1], momentum3[1], rm[1], rv[1], nb[1], 1, Wa, ba,
+                                  bnc_stats, bnc_stats + C, w2, ws.attn, ws.attn_bytes, stream))) return rc;
+    // BN_g + ReLU + Linear(G, G), the softmax inside the aggregation kernel
+    const unsigned gg = (unsigned)(np < PW_ROWS ? (np > 0 ? np : 1) : PW_ROWS);
+    hipLaunchKernelGGL(pw_gstats_kernel, dim3(gg), dim3(256), 0, st, np, G, w2, ws.part_g);
+    hipLaunchKernelGGL(pt_bn_finalize_kernel, dim3(cbl_div_up(G, 16)), dim3(PT_FIN_THREADS), 0, st, (int)gg, 2 * G, ws.part_g, G, 0, G, np, gamma_g, beta_g, eps3[2],
+                       momentum3[2], rm[2], rv[2], nb[2], consts + PW_CST_G, 64, G, consts + PW_FS_G);
+    hipLaunchKernelGGL(pw_logits_kernel, dim3(cbl_grid_for(np * G, 256, 2048)), dim3(256), sizeof(float) * (G * (G + 1) + 256), st, np, G, w2, consts, Wb, bb, ws.logits);
+    if ((rc = cbl_attn_agg_softmax_forward(n, K, C, G, x_v, idx, p1, W3C, b3C, ws.logits, a, out, stream))) return rc;
+    return cbl_status();
+}
+
+CBL_EXPORT int cbl_pt_layer_wide_backward(int n, int K, int C, const float* x_q, const float* x_k, const float* x_v, const int* idx, const float* gamma_p,
+                                          const float* W3C, const float* b3C, const float* gamma_c, const float* beta_c, const float* Wa, const float* gamma_g,
+                                          const float* Wb, const float* p_r, const float* p0, const float* p1, const float* w2, const float* a, const float* consts,
+                                          const float* bnc_stats, const float* grad_out, float* g_xq, float* g_xk, float* g_xv, float* g_Wp, float* g_bp,
+                                          float* g_gamma_p, float* g_beta_p, float* g_W3C, float* g_b3C, float* g_gamma_c, float* g_beta_c, float* g_Wa, float* g_ba,
+                                          float* g_gamma_g, float* g_beta_g, float* g_Wb, float* g_bb, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!pw_shape_ok(n, K, C)) return CBL_ERR_UNSUPPORTED;
+    if (!consts || !bnc_stats || !workspace || !grad_out) return CBL_ERR_BAD_ARG;
+    if (workspace_bytes < cbl_pt_layer_wide_workspace_bytes(n, K, C)) return CBL_ERR_WORKSPACE;
+    const PwWs ws = pw_workspace(static_cast<char*>(workspace), n, K, C);
+    hipStream_t st = cbl_stream(stream);
+    const long long np = (long long)n * K;
+    const int G = C / 8, WN = 3 * G + G * G;
+    const unsigned gp = pt_pair_grid(np);
+    int rc;
+    // the two scatters (d x_k, d x_v) of the wide kernels are float atomics: zero their targets
+    if (hipMemsetAsync(g_xk, 0, sizeof(float) * (size_t)n * C, st) != hipSuccess || hipMemsetAsync(g_xv, 0, sizeof(float) * (size_t)n * C, st) != hipSuccess) return cbl_status();
+    // aggregation backward with the softmax backward inside: d x_v, its share of d p1 / d W3C / d b3C, d logits
+    if ((rc = cbl_attn_agg_softmax_backward(n, K, C, G, x_v, idx, p1, W3C, b3C, a, grad_out, g_xv, ws.gp1a, ws.w3c2, ws.b3c2, ws.glogit, ws.attn, ws.attn_bytes, stream))) return rc;
+    // Linear(G, G), ReLU, BN_g backward
+    const unsigned gn = (unsigned)(np < PW_ROWS ? (np > 0 ? np : 1) : PW_ROWS);
+    hipLaunchKernelGGL(pw_narrow_bwd_kernel, dim3(gn), dim3(256), sizeof(float) * (G * G + 4 * 256), st, np, G, w2, consts, Wb, ws.glogit, ws.pre, ws.part_n);
+    hipLaunchKernelGGL(pt_bn_bwd_finalize_kernel, dim3(cbl_div_up(G, 16)), dim3(PT_FIN_THREADS), 0, st, (int)gn, WN, 0, G, G, np, ws.part_n, gamma_g, consts + PW_CST_G, 64,
+                       ws.bc_g, 64, g_gamma_g, g_beta_g, consts + PW_FS_G, ws.gba2);
+    hipLaunchKernelGGL(pw_bn_apply_kernel, dim3(cbl_grid_for(np * G, 256, 1024)), dim3(256), 0, st, np * G, G, ws.pre, w2, ws.bc_g, ws.gw2);
+    // the C-wide backward: d x_q, d x_k, its share of d p1 / d W3C / d b3C, BN_c's and Wa's gradients
+    if ((rc = cbl_attn_w2_backward(n, K, C, G, x_q, x_k, idx, p1, W3C, b3C, gamma_c, beta_c, bnc_stats, bnc_stats + C, Wa, ws.gw2, g_xq, g_xk, ws.gp1b,
+                                   ws.w3c2 + 3 * (size_t)C, ws.b3c2 + C, g_gamma_c, g_beta_c, g_Wa, g_ba, ws.attn, ws.attn_bytes, stream))) return rc;
+    // p chain backward over the sum of the two d p1
+    hipLaunchKernelGGL(pt_pchain_bwd_kernel, dim3(gp), dim3(PT_NARROW_BLOCK), 0, st, np, p_r, p0, p1, ws.gp1a, consts, ws.part_d, (const float*)ws.gp1b);
+    hipLaunchKernelGGL(pt_pchain_epilogue_kernel, dim3(1), dim3(PT_FIN_THREADS), 0, st, (int)gp, ws.part_d, np, consts, gamma_p, g_Wp, g_bp, g_gamma_p, g_beta_p);
+    PtSumSegs segs;
+    segs.n = 4;
+    segs.s[0] = PtSumSeg{ws.part_n, g_Wb, (int)gn, WN, 2 * G, G * G};
+    segs.s[1] = PtSumSeg{ws.part_n, g_bb, (int)gn, WN, 2 * G + G * G, G};
+    segs.s[2] = PtSumSeg{ws.w3c2, g_W3C, 2, 3 * C, 0, 3 * C};       // the two uses of pe: aggregation and w
+    segs.s[3] = PtSumSeg{ws.b3c2, g_b3C, 2, C, 0, C};
     unsigned nblk = 0;
     for (int q = 0; q < segs.n; q++) nblk += (unsigned)((segs.s[q].count + 15) / 16);
     hipLaunchKernelGGL(pt_sum_rows_kernel, dim3(nblk), dim3(PT_FIN_THREADS), 0, st, segs);

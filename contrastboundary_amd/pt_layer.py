@@ -109,6 +109,74 @@ class PTAttention(Function):
         return (None, g_xq, g_xk, g_xv, None, None, *g_params)
 
 
+def supported_wide(layer, x, idx=None, p=None):
+    """the wide stages (C = 128 | 256 | 512, share_planes 8, K <= 64) in TRAINING mode: the whole layer behind its projections as one call each way
+    (cbl_pt_layer_wide_*: the attention.hip kernels for the C-wide passes, pt_layer.hip's for the narrow ones)"""
+    C = layer.out_planes
+    ok = (layer.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and layer.mid_planes == C and layer.share_planes == 8 and C in (128, 256, 512)
+          and 1 <= int(layer.nsample) <= 64 and 16 <= x.shape[0] <= MAX_POINTS
+          and _bn_ok(layer.linear_p[1]) and _bn_ok(layer.linear_w[0]) and _bn_ok(layer.linear_w[3])
+          and _stats_ok(layer.linear_p[1]) and _stats_ok(layer.linear_w[0]) and _stats_ok(layer.linear_w[3]))
+    if ok and idx is not None:
+        ok = (idx.dtype == torch.int32 and idx.device == x.device and idx.dim() == 2 and idx.is_contiguous()
+              and tuple(idx.shape) == (x.shape[0], int(layer.nsample)))
+    if ok and p is not None:
+        ok = p.dtype == torch.float32 and p.device == x.device and tuple(p.shape) == (x.shape[0], 3)
+    return bool(ok)
+
+
+class PTAttentionWide(Function):
+    """PTAttention for the wide stages (cbl_pt_layer_wide_forward / _backward); same argument and parameter order"""
+
+    @staticmethod
+    def forward(ctx, p, x_q, x_k, x_v, idx, bns, *params):
+        n, C = x_q.shape
+        K, G = idx.shape[1], C // 8
+        L = _lib.lib()
+        dev = x_q.device
+        x_q, x_k, x_v, p = x_q.contiguous(), x_k.contiguous(), x_v.contiguous(), p.contiguous()
+        params = [t.contiguous() for t in params]
+        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        p_r, p0, p1, w2, a, out = e(n, K, 3), e(n, K, 3), e(n, K, 3), e(n, K, G), e(n, K, G), e(n, C)
+        consts, bnc = e(L.cbl_pt_layer_wide_consts_floats()), e(2 * C)
+        ws = _workspace(L.cbl_pt_layer_wide_workspace_bytes(_i(n), _i(K), _i(C)), dev)
+        eps3 = (_f * 3)(*[float(b.eps) for b in bns])
+        mom3 = (_f * 3)(*[float(b.momentum) for b in bns])
+        arr = lambda ts: (ctypes.c_void_p * 3)(*[t.data_ptr() for t in ts])
+        _lib.check(L.cbl_pt_layer_wide_forward(_i(n), _i(K), _i(C), _P(p), _P(x_q), _P(x_k), _P(x_v), _P(idx), *[_P(t) for t in params], eps3, mom3,
+                                               arr([b.running_mean for b in bns]), arr([b.running_var for b in bns]), arr([b.num_batches_tracked for b in bns]),
+                                               _P(p_r), _P(p0), _P(p1), _P(w2), _P(a), _P(out), _P(consts), _P(bnc), _P(ws), ctypes.c_size_t(ws.numel()),
+                                               _lib.stream_of(x_q)), "cbl_pt_layer_wide_forward")
+        ctx.save_for_backward(x_q, x_k, x_v, idx, p_r, p0, p1, w2, a, consts, bnc, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x_q, x_k, x_v, idx, p_r, p0, p1, w2, a, consts, bnc = ctx.saved_tensors[:11]
+        Wp, bp, gamma_p, beta_p, W3C, b3C, gamma_c, beta_c, Wa, ba, gamma_g, beta_g, Wb, bb = params = ctx.saved_tensors[11:]
+        n, C = x_q.shape
+        K = idx.shape[1]
+        L = _lib.lib()
+        dev = x_q.device
+        g_out = g_out.contiguous()
+        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        g_xq, g_xk, g_xv = e(n, C), e(n, C), e(n, C)
+        g_params = [torch.empty_like(t) for t in params]
+        ws = _workspace(L.cbl_pt_layer_wide_workspace_bytes(_i(n), _i(K), _i(C)), dev)
+        _lib.check(L.cbl_pt_layer_wide_backward(_i(n), _i(K), _i(C), _P(x_q), _P(x_k), _P(x_v), _P(idx), _P(gamma_p), _P(W3C), _P(b3C), _P(gamma_c), _P(beta_c),
+                                                _P(Wa), _P(gamma_g), _P(Wb), _P(p_r), _P(p0), _P(p1), _P(w2), _P(a), _P(consts), _P(bnc), _P(g_out),
+                                                _P(g_xq), _P(g_xk), _P(g_xv), *[_P(t) for t in g_params], _P(ws), ctypes.c_size_t(ws.numel()),
+                                                _lib.stream_of(x_q)), "cbl_pt_layer_wide_backward")
+        return (None, g_xq, g_xk, g_xv, None, None, *g_params)
+
+
+def attention_wide(layer, p, x_q, x_k, x_v, idx):
+    """the fused part of a wide-stage `layer` on its q / k / v projections (training mode)"""
+    lp, lw = layer.linear_p, layer.linear_w
+    return PTAttentionWide.apply(p, x_q, x_k, x_v, idx, (lp[1], lw[0], lw[3]), lp[0].weight, lp[0].bias, lp[1].weight, lp[1].bias, lp[3].weight, lp[3].bias,
+                                 lw[0].weight, lw[0].bias, lw[2].weight, lw[2].bias, lw[3].weight, lw[3].bias, lw[5].weight, lw[5].bias)
+
+
 def _forward_eval(p, x_q, x_k, x_v, idx, bns, params):
     """evaluation mode: cbl_pt_layer_forward_eval (running statistics, nothing kept for a backward pass)"""
     from . import pointops

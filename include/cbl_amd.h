@@ -510,6 +510,26 @@ int cbl_attn_agg_backward_csr(int n, int K, int C, int G, const float* x_v, cons
  *   All sums in a fixed order: run-to-run deterministic.  CBL_ERR_UNSUPPORTED for other shapes (callers take the cbl_attn_* kernels above). */
 size_t cbl_pt_layer_workspace_bytes(int n, int K, int C);
 int cbl_pt_layer_consts_floats(void);
+/* The same layer at the WIDE stages (C = 128 | 256 | 512, G = C / 8, K <= 64; training mode): everything behind the q / k / v projections as one call each
+ * way — the p chain and the narrow (n, K, G) work by kernels of pt_layer.hip, the C-wide passes by the cbl_attn_* kernels above (pair values recomputed,
+ * d x_k / d x_v by float atomics into buffers this call zeroes) — ~10 launches forward, ~15 backward instead of ~100 issued op by op.  Arguments as
+ * cbl_pt_layer_forward / _backward; `a` receives the softmax weights, consts cbl_pt_layer_wide_consts_floats() floats, bnc_stats (2 C) the batch mean and
+ * inverse standard deviation of BN_c (kept for the backward pass).  The table-based backward is not needed: no inv_start / inv_src. */
+size_t cbl_pt_layer_wide_workspace_bytes(int n, int K, int C);
+int cbl_pt_layer_wide_consts_floats(void);
+int cbl_pt_layer_wide_forward(int n, int K, int C, const float* xyz, const float* x_q, const float* x_k, const float* x_v, const int* idx,
+                              const float* Wp, const float* bp, const float* gamma_p, const float* beta_p, const float* W3C, const float* b3C,
+                              const float* gamma_c, const float* beta_c, const float* Wa, const float* ba, const float* gamma_g, const float* beta_g,
+                              const float* Wb, const float* bb, const float* eps3, const float* momentum3, float* const* running_mean3,
+                              float* const* running_var3, long long* const* num_batches3, float* p_r, float* p0, float* p1, float* w2, float* a, float* out,
+                              float* consts, float* bnc_stats, void* workspace, size_t workspace_bytes, void* stream);
+int cbl_pt_layer_wide_backward(int n, int K, int C, const float* x_q, const float* x_k, const float* x_v, const int* idx, const float* gamma_p,
+                               const float* W3C, const float* b3C, const float* gamma_c, const float* beta_c, const float* Wa, const float* gamma_g,
+                               const float* Wb, const float* p_r, const float* p0, const float* p1, const float* w2, const float* a, const float* consts,
+                               const float* bnc_stats, const float* grad_out, float* g_xq, float* g_xk, float* g_xv, float* g_Wp, float* g_bp,
+                               float* g_gamma_p, float* g_beta_p, float* g_W3C, float* g_b3C, float* g_gamma_c, float* g_beta_c, float* g_Wa, float* g_ba,
+                               float* g_gamma_g, float* g_beta_g, float* g_Wb, float* g_bb, void* workspace, size_t workspace_bytes, void* stream);
+
 /* self-test of the numerical assumption the passes' agreeing ReLU masks rest on: one v_mfma_f32_16x16x4_f32 tile D = A (16,4) . B (4,16) + C (16,16)
  * (row-major device arrays) next to the k-ordered fmaf chain of the same tile; callers compare the two outputs bit for bit. */
 int cbl_pt_layer_selftest_chain(const float* A, const float* B, const float* C, float* d_mfma, float* d_fma, void* stream);
