@@ -1174,7 +1174,8 @@ namespace {
 constexpr int PW_CST_G = 352;                       // [4][64]  scale, shift, mean, invstd of BN_g (G <= 64); BN_p stays at PT_CST_P, the p sums at PT_FS_P
 constexpr int PW_FS_G = 608;                        // raw sums of w2 [64]
 constexpr int PW_CST_FLOATS = 672;
-constexpr int PW_ROWS = 256;                        // partial rows (= workgroups) of the narrow kernels below
+constexpr int PW_ROWS = 256;                        // partial rows (= workgroups) of the statistics kernel below
+constexpr int PW_NROWS = 1024;                      // ... of the narrow backward: its per-batch work is a chain of LDS round trips, so short chains on many workgroups
 
 // p1 = ReLU(BN_p(p0)) on (n K, 3): the attention.hip kernels take it materialised
 __global__ __launch_bounds__(256) void pw_p1_kernel(long long total, const float* __restrict__ p0, const float* __restrict__ cst, float* __restrict__ p1)
@@ -1204,7 +1205,8 @@ __global__ __launch_bounds__(256) void pw_gstats_kernel(long long npairs, int G,
 
 // logits = Linear(G, G)(ReLU(BN_g(w2))): a batch of 256 / G pairs per trip, thread (pair of the batch, output o); Wb in LDS (rows padded by one: threads of
 // consecutive o read consecutive rows)
-__global__ __launch_bounds__(256) void pw_logits_kernel(long long npairs, int G, const float* __restrict__ w2, const float* __restrict__ cst, const float* __restrict__ Wb,
+template <int G>
+__global__ __launch_bounds__(256) void pw_logits_kernel(long long npairs, const float* __restrict__ w2, const float* __restrict__ cst, const float* __restrict__ Wb,
                                                         const float* __restrict__ bb, float* __restrict__ logits)
 {
     extern __shared__ float lds[];
@@ -1220,6 +1222,7 @@ __global__ __launch_bounds__(256) void pw_logits_kernel(long long npairs, int G,
         w3s[pl * G + o] = p < npairs ? fmaxf(fmaf(w2[p * G + o], sc, sh), 0.f) : 0.f;
         __syncthreads();
         float acc = bias;
+#pragma unroll 16
         for (int g = 0; g < G; g++) acc = fmaf(wbs[o * (G + 1) + g], w3s[pl * G + g], acc);
         if (p < npairs) logits[p * G + o] = acc;
     }
@@ -1227,11 +1230,12 @@ __global__ __launch_bounds__(256) void pw_logits_kernel(long long npairs, int G,
 
 // backward of Linear(G, G), ReLU and (its sums only) BN_g: pre = (y > 0) Wb^T d logits, written; partial row = S1 [G] | S2 [G] | d Wb [G][G] | d bb [G]
 // (the layout of pt_narrow_bwd_kernel, so the finalize / sum kernels above serve both)
-__global__ __launch_bounds__(256) void pw_narrow_bwd_kernel(long long npairs, int G, const float* __restrict__ w2, const float* __restrict__ cst, const float* __restrict__ Wb,
+template <int G>
+__global__ __launch_bounds__(256) void pw_narrow_bwd_kernel(long long npairs, const float* __restrict__ w2, const float* __restrict__ cst, const float* __restrict__ Wb,
                                                             const float* __restrict__ glogit, float* __restrict__ pre, float* __restrict__ partial)
 {
     extern __shared__ float lds[];
-    const int PB = 256 / G, NE = G * G / 256;                       // pairs per batch; d Wb entries per thread (1, 4, 16)
+    constexpr int PB = 256 / G, NE = G * G / 256;                   // pairs per batch; d Wb entries per thread (1, 4, 16)
     float* wbs = lds;                                               // [G][G]      (thread g reads column g: consecutive)
     float* gls = wbs + G * G;                                       // [PB][G]  d logits of the batch
     float* w3s = gls + 256;                                         // [PB][G]  ReLU(BN_g(w2))
@@ -1240,9 +1244,9 @@ __global__ __launch_bounds__(256) void pw_narrow_bwd_kernel(long long npairs, in
     for (int e = threadIdx.x; e < G * G; e += 256) wbs[e] = Wb[e];
     const int g = threadIdx.x % G, pl = threadIdx.x / G;
     const float sc = cst[PW_CST_G + g], sh = cst[PW_CST_G + 64 + g], is = cst[PW_CST_G + 192 + g], nm = -cst[PW_CST_G + 128 + g] * is;
-    float acc[16], s1 = 0.f, s2 = 0.f, sb = 0.f;
+    float acc[NE], s1 = 0.f, s2 = 0.f, sb = 0.f;
 #pragma unroll
-    for (int q = 0; q < 16; q++) acc[q] = 0.f;
+    for (int q = 0; q < NE; q++) acc[q] = 0.f;
     const long long per = (npairs + gridDim.x - 1) / gridDim.x, b0 = (long long)blockIdx.x * per, b1 = min(npairs, b0 + per);
     for (long long base = b0; base < b1; base += PB) {
         const long long p = base + pl;
@@ -1253,29 +1257,29 @@ __global__ __launch_bounds__(256) void pw_narrow_bwd_kernel(long long npairs, in
         w3s[pl * G + g] = live ? fmaxf(y, 0.f) : 0.f;
         __syncthreads();
         float sacc = 0.f;
+#pragma unroll 16
         for (int o = 0; o < G; o++) sacc = fmaf(wbs[o * G + g], gls[pl * G + o], sacc);
         const float d = (live && y > 0.f) ? sacc : 0.f;
         if (live) pre[p * G + g] = d;
         prs[pl * G + g] = d; pxs[pl * G + g] = d * fmaf(x, is, nm);
         __syncthreads();
         if (threadIdx.x < G) {                                      // thread g: the batch's column sums (fixed order)
+#pragma unroll
             for (int q = 0; q < PB; q++) { s1 += prs[q * G + g]; s2 += pxs[q * G + g]; sb += gls[q * G + g]; }
         }
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            if (q < NE) {
-                const int e = threadIdx.x + 256 * q, eo = e / G, eg = e % G;
-                float t = acc[q];
-                for (int r = 0; r < PB; r++) t = fmaf(gls[r * G + eo], w3s[r * G + eg], t);
-                acc[q] = t;
-            }
+        for (int q = 0; q < NE; q++) {
+            const int e = threadIdx.x + 256 * q, eo = e / G, eg = e % G;
+            float t = acc[q];
+#pragma unroll
+            for (int r = 0; r < PB; r++) t = fmaf(gls[r * G + eo], w3s[r * G + eg], t);
+            acc[q] = t;
         }
     }
     float* row = partial + (size_t)blockIdx.x * (3 * G + G * G);
     if (threadIdx.x < G) { row[threadIdx.x] = s1; row[G + threadIdx.x] = s2; row[2 * G + G * G + threadIdx.x] = sb; }
 #pragma unroll
-    for (int q = 0; q < 16; q++)
-        if (q < NE) row[2 * G + threadIdx.x + 256 * q] = acc[q];
+    for (int q = 0; q < NE; q++) row[2 * G + threadIdx.x + 256 * q] = acc[q];
 }
 
 // d w2 = A1 pre + A2 w2 + A3  (BatchNorm backward with the batch sums folded into the three per-channel coefficients)
@@ -1297,7 +1301,7 @@ PwWs pw_workspace(char* base, int n, int K, int C)
     auto take = [&](size_t cnt) { return reinterpret_cast<float*>(takeb(cnt * sizeof(float))); };
     w.part_p = take((size_t)PT_NARROW_MAX_ROWS * 18);
     w.part_g = take((size_t)PW_ROWS * 2 * G);
-    w.part_n = take((size_t)PW_ROWS * (3 * G + G * G));
+    w.part_n = take((size_t)PW_NROWS * (3 * G + G * G));
     w.part_d = take((size_t)PT_NARROW_MAX_ROWS * 16);
     w.bc_g = take(192);
     w.logits = take(np * G); w.glogit = take(np * G); w.pre = take(np * G); w.gw2 = take(np * G);
@@ -1346,7 +1350,8 @@ CBL_EXPORT int cbl_pt_layer_wide_forward(int n, int K, int C, const float* xyz, 
     hipLaunchKernelGGL(pw_gstats_kernel, dim3(gg), dim3(256), 0, st, np, G, w2, ws.part_g);
     hipLaunchKernelGGL(pt_bn_finalize_kernel, dim3(cbl_div_up(G, 16)), dim3(PT_FIN_THREADS), 0, st, (int)gg, 2 * G, ws.part_g, G, 0, G, np, gamma_g, beta_g, eps3[2],
                        momentum3[2], rm[2], rv[2], nb[2], consts + PW_CST_G, 64, G, consts + PW_FS_G);
-    hipLaunchKernelGGL(pw_logits_kernel, dim3(cbl_grid_for(np * G, 256, 2048)), dim3(256), sizeof(float) * (G * (G + 1) + 256), st, np, G, w2, consts, Wb, bb, ws.logits);
+#define PW_LOGITS(GG) hipLaunchKernelGGL(pw_logits_kernel<GG>, dim3(cbl_grid_for(np * G, 256, 2048)), dim3(256), sizeof(float) * (G * (G + 1) + 256), st, np, w2, consts, Wb, bb, ws.logits)
+    if (G == 16) { PW_LOGITS(16); } else if (G == 32) { PW_LOGITS(32); } else { PW_LOGITS(64); }
     if ((rc = cbl_attn_agg_softmax_forward(n, K, C, G, x_v, idx, p1, W3C, b3C, ws.logits, a, out, stream))) return rc;
     return cbl_status();
 }
@@ -1368,12 +1373,16 @@ CBL_EXPORT int cbl_pt_layer_wide_backward(int n, int K, int C, const float* x_q,
     const unsigned gp = pt_pair_grid(np);
     int rc;
     // the two scatters (d x_k, d x_v) of the wide kernels are float atomics: zero their targets
-    if (hipMemsetAsync(g_xk, 0, sizeof(float) * (size_t)n * C, st) != hipSuccess || hipMemsetAsync(g_xv, 0, sizeof(float) * (size_t)n * C, st) != hipSuccess) return cbl_status();
+    if (g_xv == g_xk + (size_t)n * C) {                             // one buffer (the Python mirror allocates them together): one fill
+        if (hipMemsetAsync(g_xk, 0, 2 * sizeof(float) * (size_t)n * C, st) != hipSuccess) return cbl_status();
+    } else if (hipMemsetAsync(g_xk, 0, sizeof(float) * (size_t)n * C, st) != hipSuccess || hipMemsetAsync(g_xv, 0, sizeof(float) * (size_t)n * C, st) != hipSuccess) return cbl_status();
     // aggregation backward with the softmax backward inside: d x_v, its share of d p1 / d W3C / d b3C, d logits
     if ((rc = cbl_attn_agg_softmax_backward(n, K, C, G, x_v, idx, p1, W3C, b3C, a, grad_out, g_xv, ws.gp1a, ws.w3c2, ws.b3c2, ws.glogit, ws.attn, ws.attn_bytes, stream))) return rc;
     // Linear(G, G), ReLU, BN_g backward
-    const unsigned gn = (unsigned)(np < PW_ROWS ? (np > 0 ? np : 1) : PW_ROWS);
-    hipLaunchKernelGGL(pw_narrow_bwd_kernel, dim3(gn), dim3(256), sizeof(float) * (G * G + 4 * 256), st, np, G, w2, consts, Wb, ws.glogit, ws.pre, ws.part_n);
+    const long long nbatch = (np + 256 / G - 1) / (256 / G);        // a workgroup takes whole batches of 256 / G pairs
+    const unsigned gn = (unsigned)(nbatch < PW_NROWS ? (nbatch > 0 ? nbatch : 1) : PW_NROWS);
+#define PW_NBWD(GG) hipLaunchKernelGGL(pw_narrow_bwd_kernel<GG>, dim3(gn), dim3(256), sizeof(float) * (G * G + 4 * 256), st, np, w2, consts, Wb, ws.glogit, ws.pre, ws.part_n)
+    if (G == 16) { PW_NBWD(16); } else if (G == 32) { PW_NBWD(32); } else { PW_NBWD(64); }
     hipLaunchKernelGGL(pt_bn_bwd_finalize_kernel, dim3(cbl_div_up(G, 16)), dim3(PT_FIN_THREADS), 0, st, (int)gn, WN, 0, G, G, np, ws.part_n, gamma_g, consts + PW_CST_G, 64,
                        ws.bc_g, 64, g_gamma_g, g_beta_g, consts + PW_FS_G, ws.gba2);
     hipLaunchKernelGGL(pw_bn_apply_kernel, dim3(cbl_grid_for(np * G, 256, 1024)), dim3(256), 0, st, np * G, G, ws.pre, w2, ws.bc_g, ws.gw2);

@@ -160,7 +160,8 @@ class PTAttentionWide(Function):
         dev = x_q.device
         g_out = g_out.contiguous()
         e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        g_xq, g_xk, g_xv = e(n, C), e(n, C), e(n, C)
+        g_xq, g_kv = e(n, C), e(2, n, C)
+        g_xk, g_xv = g_kv[0], g_kv[1]                                 # adjacent: the call zeroes both scatter targets with one fill
         g_params = [torch.empty_like(t) for t in params]
         ws = _workspace(L.cbl_pt_layer_wide_workspace_bytes(_i(n), _i(K), _i(C)), dev)
         _lib.check(L.cbl_pt_layer_wide_backward(_i(n), _i(K), _i(C), _P(x_q), _P(x_k), _P(x_v), _P(idx), _P(gamma_p), _P(W3C), _P(b3C), _P(gamma_c), _P(beta_c),
