@@ -1160,6 +1160,7 @@ CBL_EXPORT int cbl_pt_layer_backward(int n, int K, int C, const float* x_q, cons
 }
 
 
+#ifndef CBL_HOST_WAVE_EMULATION     // (the CPU build of this file for tests/test_pt_layer_host.py stops here: the section below calls attention.hip's entry points and the runtime)
 // =====================================================================================================================================
 // The WIDE stages (C = 128 / 256 / 512, G = C / 8 = 16 / 32 / 64, K = 16; n = 2560 / 640 / 160 points of a 40960-point scene): 13 of the network's 18
 // Point Transformer blocks.  Their C-wide work already runs as six fused kernels (csrc/attention.hip: statistics, w2, aggregation, and the three
@@ -1403,3 +1404,4 @@ CBL_EXPORT int cbl_pt_layer_wide_backward(int n, int K, int C, const float* x_q,
     hipLaunchKernelGGL(pt_sum_rows_kernel, dim3(nblk), dim3(PT_FIN_THREADS), 0, st, segs);
     return cbl_status();
 }
+#endif  // CBL_HOST_WAVE_EMULATION

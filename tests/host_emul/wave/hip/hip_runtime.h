@@ -20,6 +20,7 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define __shared__ static
+#define CBL_HOST_WAVE_EMULATION 1      // sections of a kernel file that only make sense on the device (dynamic LDS, runtime API calls, entry points of other translation units) are compiled out
 
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
