@@ -53,7 +53,7 @@ class PointTransformerLayer(nn.Module):
             # the two full-resolution shapes: everything behind the three projections as one pass structure (csrc/pt_layer.hip)
             return pt_layer.attention(self, p, x_q, x_k, x_v, idx)
         if self.fused and self.fused not in ("split", "ops") and pt_layer.supported_wide(self, x, idx, p):
-            # the wide stages: the same as ONE call each way (cbl_pt_layer_wide_*: ~25 launches per layer and pass pair instead of ~100); fused = "ops" keeps
+            # the wide stages: the same as ONE call each way (cbl_pt_layer_wide_*: ~23 launches per layer and pass pair instead of ~42); fused = "ops" keeps
             # round 3's op-by-op issue of the same kernels reachable for A/B runs
             return pt_layer.attention_wide(self, p, x_q, x_k, x_v, idx)
         p_r = pointops.queryandgroup(self.nsample, p, p, p.new_zeros((p.shape[0], 0)), idx, o, o, use_xyz=True)   # (n,K,3) relative xyz

@@ -1164,11 +1164,11 @@ CBL_EXPORT int cbl_pt_layer_backward(int n, int K, int C, const float* x_q, cons
 // =====================================================================================================================================
 // The WIDE stages (C = 128 / 256 / 512, G = C / 8 = 16 / 32 / 64, K = 16; n = 2560 / 640 / 160 points of a 40960-point scene): 13 of the network's 18
 // Point Transformer blocks.  Their C-wide work already runs as six fused kernels (csrc/attention.hip: statistics, w2, aggregation, and the three
-// backward passes — pair values recomputed, nothing (n, K, C) stored), but everything around them was issued op by op through autograd: ~100 launches
-// per layer, most of them at their launch floor (profiles/r05_wide_layer_kernel_stats.csv).  These two entries are the whole layer behind its q / k / v
+// backward passes — pair values recomputed, nothing (n, K, C) stored), but everything around them was issued op by op through autograd: ~42 launches
+// per layer and pass pair behind the projections, most of them at their launch floor (profiles/r05_wide_layer_kernel_stats.csv).  These two entries are the whole layer behind its q / k / v
 // projections as ONE call each way: the p chain, BN_p / BN_g statistics and their finalizes (the kernels of the full-resolution layer above: they do not
 // depend on C), the six attention.hip kernels through their C entries, and four small kernels of this file for the narrow (n, K, G) tensors at any
-// G <= 64 — ~10 launches forward, ~15 backward, no allocator, no autograd engine, no gradient-accumulation adds in between.
+// G <= 64 — ~9 launches forward, ~14 backward, no allocator, no autograd engine, no gradient-accumulation adds in between.
 // =====================================================================================================================================
 namespace {
 

@@ -512,7 +512,7 @@ size_t cbl_pt_layer_workspace_bytes(int n, int K, int C);
 int cbl_pt_layer_consts_floats(void);
 /* The same layer at the WIDE stages (C = 128 | 256 | 512, G = C / 8, K <= 64; training mode): everything behind the q / k / v projections as one call each
  * way — the p chain and the narrow (n, K, G) work by kernels of pt_layer.hip, the C-wide passes by the cbl_attn_* kernels above (pair values recomputed,
- * d x_k / d x_v by float atomics into buffers this call zeroes) — ~10 launches forward, ~15 backward instead of ~100 issued op by op.  Arguments as
+ * d x_k / d x_v by float atomics into buffers this call zeroes) — ~9 launches forward, ~14 backward instead of ~42 issued op by op.  Arguments as
  * cbl_pt_layer_forward / _backward; `a` receives the softmax weights, consts cbl_pt_layer_wide_consts_floats() floats, bnc_stats (2 C) the batch mean and
  * inverse standard deviation of BN_c (kept for the backward pass).  The table-based backward is not needed: no inv_start / inv_src. */
 size_t cbl_pt_layer_wide_workspace_bytes(int n, int K, int C);
