@@ -40,7 +40,6 @@ class PointTransformerLayer(nn.Module):
 
     def forward(self, pxo, idx=None) -> torch.Tensor:
         p, x, o = pxo                                                        # (n,3), (n,c), (b)
-        x_q, x_k, x_v = dense.triple_linear(x, self.linear_q, self.linear_k, self.linear_v)                        # :33, one launch per direction
         if idx is None:
             idx, _ = pointops.knnquery(self.nsample, p, p, o, o)              # once, not twice (:34-35)
         else:
@@ -49,12 +48,17 @@ class PointTransformerLayer(nn.Module):
             idx = pointops._req(idx.contiguous(), torch.int32, "idx", 2)
             if tuple(idx.shape) != (x.shape[0], int(self.nsample)) or idx.device != x.device:
                 raise ValueError(f"idx: expected a ({x.shape[0]}, {int(self.nsample)}) table on {x.device}, got {tuple(idx.shape)} on {idx.device}")
+        wide = self.fused and self.fused not in ("split", "ops") and pt_layer.supported_wide(self, x, idx, p)
+        if wide and self.fused != "qkv3" and all(l.bias is not None and l.weight.shape == (self.out_planes, self.out_planes) for l in (self.linear_q, self.linear_k, self.linear_v)):
+            # the wide stages: projections and everything behind them as one node (one batched product for q / k / v each way, then cbl_pt_layer_wide_*)
+            return pt_layer.attention_wide_projected(self, p, x, idx)
+        x_q, x_k, x_v = dense.triple_linear(x, self.linear_q, self.linear_k, self.linear_v)                        # :33, one launch per direction
         if self.fused and self.fused != "split" and pt_layer.supported(self, x, idx, p):
             # the two full-resolution shapes: everything behind the three projections as one pass structure (csrc/pt_layer.hip)
             return pt_layer.attention(self, p, x_q, x_k, x_v, idx)
-        if self.fused and self.fused not in ("split", "ops") and pt_layer.supported_wide(self, x, idx, p):
-            # the wide stages: the same as ONE call each way (cbl_pt_layer_wide_*: ~23 launches per layer and pass pair instead of ~42); fused = "ops" keeps
-            # round 3's op-by-op issue of the same kernels reachable for A/B runs
+        if wide:
+            # fused = "qkv3": the three projections as separate Linear layers in front of the one call each way (cbl_pt_layer_wide_*: ~23 launches per layer
+            # and pass pair instead of ~42); fused = "ops" keeps round 3's op-by-op issue of the same kernels reachable for A/B runs
             return pt_layer.attention_wide(self, p, x_q, x_k, x_v, idx)
         p_r = pointops.queryandgroup(self.nsample, p, p, p.new_zeros((p.shape[0], 0)), idx, o, o, use_xyz=True)   # (n,K,3) relative xyz
         if self.fused and attention.supported(self, x):

@@ -224,6 +224,31 @@ class FlatState:
 
     ALIGN = 64                                                       # elements
 
+    @classmethod
+    def _triples_adjacent(cls, group, modules):
+        """`group` reordered so that the q / k / v weights (and biases) of every attention layer follow one another: with sizes that are multiples of ALIGN they
+        then lie back to back in the flat buffer, and pt_layer._stacked takes the three as ONE (3, ...) view for its batched product"""
+        from .blocks import PointTransformerLayer
+        pos = {id(p): i for i, p in enumerate(group)}
+        follow, taken = {}, set()
+        for m in modules:
+            for layer in m.modules():
+                if not isinstance(layer, PointTransformerLayer):
+                    continue
+                for name in ("weight", "bias"):
+                    t = [getattr(l, name) for l in (layer.linear_q, layer.linear_k, layer.linear_v)]
+                    if (all(x is not None and id(x) in pos and id(x) not in taken for x in t) and len({id(x) for x in t}) == 3
+                            and t[0].shape == t[1].shape == t[2].shape and t[0].numel() % cls.ALIGN == 0):
+                        follow[id(t[0])] = t[1:]
+                        taken.update(id(x) for x in t)
+        out = []
+        for p in group:
+            if id(p) in taken and id(p) not in follow:
+                continue                                             # placed behind its q
+            out.append(p)
+            out.extend(follow.get(id(p), ()))
+        return out
+
     def __init__(self, modules, optimizer=None):
         seen, groups = set(), []
         if optimizer is not None:
@@ -239,7 +264,7 @@ class FlatState:
         if uniq:
             assert optimizer is None, "trainable parameters the optimizer does not hold"
             groups.append(uniq)
-        self.groups = [g for g in groups if g]
+        self.groups = [self._triples_adjacent(g, modules) for g in groups if g]
         assert self.groups, "no trainable parameters"
         dev, dt = self.groups[0][0].device, self.groups[0][0].dtype
         assert all(p.device == dev and p.dtype == dt for g in self.groups for p in g), "one device and one dtype"

@@ -239,6 +239,9 @@ class GraphedTrainStep:
         self.model, self.criterion, self.optimizer, self.reducer = model, criterion, optimizer, reducer
         # a distributed.PackedGradientReducer: gradients are packed into the flat buffer INSIDE the graph, the optimizer is its FlatState's one-tensor twin
         self.packed = getattr(reducer, "state", None)
+        if self.packed is None:
+            from . import pt_layer
+            pt_layer.adjoin_qkv(model)                               # q / k / v weights back to back: one batched product per wide layer without a copy (a flat state does this itself)
         self.sync_buffers = True                                      # rank 0's buffers before every replay (DDP's broadcast_buffers)
         self.events = None                                            # profile(): per-step (start, replayed, reduced, stepped) events
         plan = dict(stride=model.STRIDE, nsample=model.NSAMPLE, multi_head=model.head is not None)

@@ -213,3 +213,35 @@ def test_wide_layer_one_call_equals_ops(C, n, clouds):
         assert pa.grad is not None and (rel(pa.grad, pb.grad) < 5e-4 or float((pa.grad - pb.grad).abs().max()) < 1e-4 * gmax), name
     for (name, ba), (_, bb) in zip(fused.named_buffers(), ops.named_buffers()):
         assert rel(ba.float(), bb.float()) < 1e-5, name
+
+
+@pytest.mark.parametrize("C,n", [(128, 2560), (256, 640), (512, 160)])
+def test_wide_layer_with_adjacent_projections(C, n):
+    """pt_layer.adjoin_qkv lays the q / k / v weights back to back, the layer's batched product then reads them as one view instead of a stacked copy, and the
+    separate-projections route (fused = "qkv3") is the comparison: same output, same gradients (the three products differ in summation order only), the
+    state_dict untouched"""
+    import copy
+    from contrastboundary_amd import blocks, pt_layer, synthetic as S
+    torch.manual_seed(7 * C + n)
+    xyz = torch.from_numpy(S.s_room(n, seed=5)[0]).cuda()
+    o = torch.tensor([n], dtype=torch.int32, device="cuda")
+    layer = blocks.PointTransformerLayer(C, C, 8, 16).cuda().train()
+    before = {k: v.clone() for k, v in layer.state_dict().items()}
+    sep = copy.deepcopy(layer); sep.fused = "qkv3"
+    assert pt_layer._stacked((layer.linear_q.weight, layer.linear_k.weight, layer.linear_v.weight)).data_ptr() != layer.linear_q.weight.data_ptr()
+    pt_layer.adjoin_qkv(layer)
+    for name in ("weight", "bias"):
+        t = [getattr(l, name) for l in (layer.linear_q, layer.linear_k, layer.linear_v)]
+        st = pt_layer._stacked(t)
+        assert st.data_ptr() == t[0].data_ptr() and torch.equal(st, torch.stack(t))
+    assert all(torch.equal(v, before[k]) for k, v in layer.state_dict().items())
+    x1 = torch.randn(n, C, device="cuda", requires_grad=True); x2 = x1.detach().clone().requires_grad_(True)
+    g = torch.randn(n, C, device="cuda")
+    layer([xyz, x1, o]).backward(g)
+    y1 = layer([xyz, x1, o]); x1.grad = None; layer.zero_grad(); y1.backward(g)
+    sep([xyz, x2, o]); y2 = sep([xyz, x2, o]); x2.grad = None; sep.zero_grad(); y2.backward(g)
+    rel = lambda a, b: float((a.detach().double() - b.detach().double()).norm() / max(float(b.detach().double().norm()), 1e-30))
+    assert rel(y1, y2) < 2e-5 and rel(x1.grad, x2.grad) < 2e-4, (rel(y1, y2), rel(x1.grad, x2.grad))
+    gmax = max(float(pb.grad.abs().max()) for pb in sep.parameters())
+    for (name, pa), (_, pb) in zip(layer.named_parameters(), sep.named_parameters()):
+        assert pa.grad is not None and (rel(pa.grad, pb.grad) < 5e-4 or float((pa.grad - pb.grad).abs().max()) < 1e-4 * gmax), name
