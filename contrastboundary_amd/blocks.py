@@ -152,9 +152,7 @@ class PointTransformerBlock(nn.Module):
         identity = x
         x = dense.batch_norm(dense.apply(self.linear1, x), self.bn1, relu=True)
         x = dense.batch_norm(self.transformer2([p, x, o], idx), self.bn2, relu=True)
-        x = dense.batch_norm(dense.apply(self.linear3, x), self.bn3)
-        x = x + identity
-        x = self.relu(x)
+        x = dense.batch_norm(dense.apply(self.linear3, x), self.bn3, relu=True, residual=identity)     # :130-133 bn3, += identity, relu: one call each way
         return [p, x, o]
 
 

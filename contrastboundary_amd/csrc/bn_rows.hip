@@ -34,13 +34,13 @@ inline BnShape bn_shape(long long rows, int C)
 
 // partial[b][0][c] = sum over the workgroup's rows of A(r,c), partial[b][1][c] = sum of B(r,c)
 //   MODE 0 (forward):  A = x, B = x*x
-//   MODE 1 (backward): A = g, B = g * xhat   with g = gy * (relu ? y > 0 : 1), xhat = (x - mean) * invstd, y = xhat * w + b
+//   MODE 1 (backward): A = g, B = g * xhat   with g = gy * (relu ? y > 0 : 1), xhat = (x - mean) * invstd, y = xhat * w + b (+ residual)
 template <int VEC, int MODE>
 __global__ __launch_bounds__(BN_BLOCK) void bn_partial_kernel(long long rows, int C, int tpr, int slots, long long rows_per_block,
                                                               const float* __restrict__ x, const float* __restrict__ gy,
                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
                                                               const float* __restrict__ weight, const float* __restrict__ bias, int relu,
-                                                              float* __restrict__ partial)
+                                                              const float* __restrict__ residual, float* __restrict__ partial)
 {
     __shared__ float red[2][BN_BLOCK][VEC];
     const int tid = threadIdx.x;
@@ -59,21 +59,25 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_partial_kernel(long long rows, in
     const long long r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     if (live) {
         for (long long r = r0 + slot; r < r1; r += slots) {
-            float xv[VEC], gv[VEC];
+            float xv[VEC], gv[VEC], rv[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; v++) rv[v] = 0.f;
             if (VEC == 4) {
                 const float4 t = *reinterpret_cast<const float4*>(x + r * C + c0);
                 xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
                 if (MODE == 1) { const float4 u = *reinterpret_cast<const float4*>(gy + r * C + c0); gv[0] = u.x; gv[1] = u.y; gv[2] = u.z; gv[3] = u.w; }
+                if (MODE == 1 && residual) { const float4 u = *reinterpret_cast<const float4*>(residual + r * C + c0); rv[0] = u.x; rv[1] = u.y; rv[2] = u.z; rv[3] = u.w; }
             } else {
                 xv[0] = x[r * C + c0];
                 if (MODE == 1) gv[0] = gy[r * C + c0];
+                if (MODE == 1 && residual) rv[0] = residual[r * C + c0];
             }
 #pragma unroll
             for (int v = 0; v < VEC; v++) {
                 if (MODE == 0) { a0[v] += xv[v]; a1[v] += xv[v] * xv[v]; }
                 else {
                     const float xh = (xv[v] - m[v]) * is[v];
-                    const float g = (relu && !(xh * w[v] + b[v] > 0.f)) ? 0.f : gv[v];
+                    const float g = (relu && !((xh * w[v] + b[v]) + rv[v] > 0.f)) ? 0.f : gv[v];
                     a0[v] += g; a1[v] += g * xh;
                 }
             }
@@ -151,40 +155,49 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(long long rows, in
     }
 }
 
-// MODE 0: y = [relu](xhat * w + b);   MODE 1: grad_x = w * invstd * (g - coef0 - xhat * coef1)
+// MODE 0: y = [relu](xhat * w + b [+ residual]);   MODE 1: grad_x = w * invstd * (g - coef0 - xhat * coef1), grad_residual = g (the masked gradient)
 template <int VEC, int MODE>
 __global__ __launch_bounds__(BN_BLOCK) void bn_element_kernel(long long rows, int C, const float* __restrict__ x, const float* __restrict__ gy,
                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
                                                               const float* __restrict__ weight, const float* __restrict__ bias, const float* __restrict__ coef,
-                                                              int relu, float* __restrict__ out)
+                                                              int relu, const float* __restrict__ residual, float* __restrict__ out, float* __restrict__ gres)
 {
     const int tpr = C / VEC;
     const long long total = rows * tpr;
     for (long long e = (long long)blockIdx.x * BN_BLOCK + threadIdx.x; e < total; e += (long long)gridDim.x * BN_BLOCK) {
         const int c0 = (int)(e % tpr) * VEC;
-        float xv[VEC], gv[VEC], o[VEC];
+        float xv[VEC], gv[VEC], o[VEC], rv[VEC], gm[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; v++) rv[v] = 0.f;
         if (VEC == 4) {
             const float4 t = *reinterpret_cast<const float4*>(x + e * 4);
             xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
             if (MODE == 1) { const float4 u = *reinterpret_cast<const float4*>(gy + e * 4); gv[0] = u.x; gv[1] = u.y; gv[2] = u.z; gv[3] = u.w; }
+            if (residual) { const float4 u = *reinterpret_cast<const float4*>(residual + e * 4); rv[0] = u.x; rv[1] = u.y; rv[2] = u.z; rv[3] = u.w; }
         } else {
             xv[0] = x[e];
             if (MODE == 1) gv[0] = gy[e];
+            if (residual) rv[0] = residual[e];
         }
 #pragma unroll
         for (int v = 0; v < VEC; v++) {
             const int c = c0 + v;
             const float w = weight ? weight[c] : 1.f, b = bias ? bias[c] : 0.f;
             const float xh = (xv[v] - mean[c]) * invstd[c];
-            const float y = xh * w + b;
+            const float y = (xh * w + b) + rv[v];
             if (MODE == 0) o[v] = (relu && !(y > 0.f)) ? 0.f : y;
             else {
                 const float g = (relu && !(y > 0.f)) ? 0.f : gv[v];
+                gm[v] = g;
                 o[v] = w * invstd[c] * ((g - coef[c]) - xh * coef[C + c]);
             }
         }
         if (VEC == 4) *reinterpret_cast<float4*>(out + e * 4) = make_float4(o[0], o[1], o[2], o[3]);
         else out[e] = o[0];
+        if (MODE == 1 && gres) {
+            if (VEC == 4) *reinterpret_cast<float4*>(gres + e * 4) = make_float4(gm[0], gm[1], gm[2], gm[3]);
+            else gres[e] = gm[0];
+        }
     }
 }
 
@@ -212,7 +225,7 @@ __device__ __forceinline__ void bn_block_sums(const float (&v)[NV], double (&tot
 __global__ __launch_bounds__(BN_BLOCK) void bn_small_fwd_kernel(int rows, int C, const float* __restrict__ x, const float* __restrict__ weight,
                                                                 const float* __restrict__ bias, float eps, float momentum,
                                                                 float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                                long long* __restrict__ num_batches_tracked, int relu,
+                                                                long long* __restrict__ num_batches_tracked, int relu, const float* __restrict__ residual,
                                                                 float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ y)
 {
     __shared__ double red[4][4];
@@ -268,9 +281,11 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_small_fwd_kernel(int rows, int C,
         const int r = k * BN_BLOCK + (int)threadIdx.x;
         if (r < rows) {
             const float in[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w};
+            const float4 rr = residual ? *reinterpret_cast<const float4*>(residual + (size_t)r * C + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float rs4[4] = {rr.x, rr.y, rr.z, rr.w};
             float o[4];
 #pragma unroll
-            for (int v = 0; v < 4; v++) { const float yv = ((in[v] - mu[v]) * is[v]) * w[v] + b[v]; o[v] = (relu && !(yv > 0.f)) ? 0.f : yv; }
+            for (int v = 0; v < 4; v++) { const float yv = (((in[v] - mu[v]) * is[v]) * w[v] + b[v]) + rs4[v]; o[v] = (relu && !(yv > 0.f)) ? 0.f : yv; }
             *reinterpret_cast<float4*>(y + (size_t)r * C + c0) = make_float4(o[0], o[1], o[2], o[3]);
         }
     }
@@ -279,7 +294,8 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_small_fwd_kernel(int rows, int C,
 __global__ __launch_bounds__(BN_BLOCK) void bn_small_bwd_kernel(int rows, int C, const float* __restrict__ x, const float* __restrict__ gy,
                                                                 const float* __restrict__ weight, const float* __restrict__ bias,
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
-                                                                float* __restrict__ gx, float* __restrict__ grad_weight, float* __restrict__ grad_bias)
+                                                                const float* __restrict__ residual, float* __restrict__ gx, float* __restrict__ gres,
+                                                                float* __restrict__ grad_weight, float* __restrict__ grad_bias)
 {
     __shared__ double red[4][8];
     const int c0 = blockIdx.x * 4;
@@ -294,11 +310,12 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_small_bwd_kernel(int rows, int C,
         float a[4] = {0.f, 0.f, 0.f, 0.f}, gg[4] = {0.f, 0.f, 0.f, 0.f};
         if (r < rows) {
             const float4 xr = *reinterpret_cast<const float4*>(x + (size_t)r * C + c0), gr = *reinterpret_cast<const float4*>(gy + (size_t)r * C + c0);
-            const float in[4] = {xr.x, xr.y, xr.z, xr.w}, gi[4] = {gr.x, gr.y, gr.z, gr.w};
+            const float4 rr = residual ? *reinterpret_cast<const float4*>(residual + (size_t)r * C + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float in[4] = {xr.x, xr.y, xr.z, xr.w}, gi[4] = {gr.x, gr.y, gr.z, gr.w}, rs4[4] = {rr.x, rr.y, rr.z, rr.w};
 #pragma unroll
             for (int v = 0; v < 4; v++) {
                 a[v] = (in[v] - mu[v]) * is[v];
-                const float yv = a[v] * w[v] + b[v];
+                const float yv = (a[v] * w[v] + b[v]) + rs4[v];
                 gg[v] = (relu && !(yv > 0.f)) ? 0.f : gi[v];
             }
         }
@@ -323,6 +340,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_small_bwd_kernel(int rows, int C,
 #pragma unroll
             for (int v = 0; v < 4; v++) o[v] = w[v] * is[v] * ((gg[v] - k0[v]) - a[v] * k1[v]);
             *reinterpret_cast<float4*>(gx + (size_t)r * C + c0) = make_float4(o[0], o[1], o[2], o[3]);
+            if (gres) *reinterpret_cast<float4*>(gres + (size_t)r * C + c0) = g[k];
         }
     }
 }
@@ -345,9 +363,9 @@ CBL_EXPORT size_t cbl_bn_rows_workspace_bytes(long long rows, int C)
     return sizeof(float) * ((size_t)BN_MAX_BLOCKS * 2 * C + 2 * (size_t)C) + 256;
 }
 
-CBL_EXPORT int cbl_bn_rows_forward(long long rows, int C, const float* x, const float* weight, const float* bias, float eps, float momentum,
-                                   float* running_mean, float* running_var, long long* num_batches_tracked, int relu, float* save_mean,
-                                   float* save_invstd, float* y, void* workspace, size_t workspace_bytes, void* stream)
+CBL_EXPORT int cbl_bn_rows_forward_residual(long long rows, int C, const float* x, const float* residual, const float* weight, const float* bias, float eps,
+                                            float momentum, float* running_mean, float* running_var, long long* num_batches_tracked, int relu, float* save_mean,
+                                            float* save_invstd, float* y, void* workspace, size_t workspace_bytes, void* stream)
 {
     const int rc = bn_check(rows, C);
     if (rc) return rc;
@@ -357,26 +375,34 @@ CBL_EXPORT int cbl_bn_rows_forward(long long rows, int C, const float* x, const 
     const BnShape s = bn_shape(rows, C);
     float* partial = reinterpret_cast<float*>(workspace);
     hipStream_t st = cbl_stream(stream);
-    if (bn_small(rows, C) && cbl_host_aligned16(x) && cbl_host_aligned16(y)) {
+    if (bn_small(rows, C) && cbl_host_aligned16(x) && cbl_host_aligned16(y) && cbl_host_aligned16(residual)) {
         hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(C / 4), dim3(BN_BLOCK), 0, st, (int)rows, C, x, weight, bias, eps, momentum, running_mean, running_var,
-                           num_batches_tracked, relu, save_mean, save_invstd, y);
+                           num_batches_tracked, relu, residual, save_mean, save_invstd, y);
         return cbl_status();
     }
-    const bool vec = s.vec == 4 && cbl_host_aligned16(x) && cbl_host_aligned16(y);
+    const bool vec = s.vec == 4 && cbl_host_aligned16(x) && cbl_host_aligned16(y) && cbl_host_aligned16(residual);
     const BnShape s1 = vec ? s : [&] { BnShape t = s; t.vec = 1; t.tpr = C; t.slots = BN_BLOCK / C; return t; }();
     if (s1.slots < 1) return CBL_ERR_UNSUPPORTED;
-    if (vec) hipLaunchKernelGGL((bn_partial_kernel<4, 0>), dim3(s1.nblocks), dim3(BN_BLOCK), 0, st, rows, C, s1.tpr, s1.slots, s1.rows_per_block, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0, partial);
-    else     hipLaunchKernelGGL((bn_partial_kernel<1, 0>), dim3(s1.nblocks), dim3(BN_BLOCK), 0, st, rows, C, s1.tpr, s1.slots, s1.rows_per_block, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0, partial);
+    if (vec) hipLaunchKernelGGL((bn_partial_kernel<4, 0>), dim3(s1.nblocks), dim3(BN_BLOCK), 0, st, rows, C, s1.tpr, s1.slots, s1.rows_per_block, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, partial);
+    else     hipLaunchKernelGGL((bn_partial_kernel<1, 0>), dim3(s1.nblocks), dim3(BN_BLOCK), 0, st, rows, C, s1.tpr, s1.slots, s1.rows_per_block, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, partial);
     hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(cbl_div_up(C, 16)), dim3(256), 0, st, rows, C, s1.nblocks, partial, eps, momentum, running_mean, running_var, num_batches_tracked, save_mean, save_invstd);
     const dim3 grid(cbl_grid_for(rows * (C / (vec ? 4 : 1)), BN_BLOCK, 4096));
-    if (vec) hipLaunchKernelGGL((bn_element_kernel<4, 0>), grid, dim3(BN_BLOCK), 0, st, rows, C, x, nullptr, save_mean, save_invstd, weight, bias, nullptr, relu, y);
-    else     hipLaunchKernelGGL((bn_element_kernel<1, 0>), grid, dim3(BN_BLOCK), 0, st, rows, C, x, nullptr, save_mean, save_invstd, weight, bias, nullptr, relu, y);
+    if (vec) hipLaunchKernelGGL((bn_element_kernel<4, 0>), grid, dim3(BN_BLOCK), 0, st, rows, C, x, nullptr, save_mean, save_invstd, weight, bias, nullptr, relu, residual, y, nullptr);
+    else     hipLaunchKernelGGL((bn_element_kernel<1, 0>), grid, dim3(BN_BLOCK), 0, st, rows, C, x, nullptr, save_mean, save_invstd, weight, bias, nullptr, relu, residual, y, nullptr);
     return cbl_status();
 }
 
-CBL_EXPORT int cbl_bn_rows_backward(long long rows, int C, const float* x, const float* grad_y, const float* weight, const float* bias,
-                                    const float* save_mean, const float* save_invstd, int relu, float* grad_x, float* grad_weight, float* grad_bias,
-                                    void* workspace, size_t workspace_bytes, void* stream)
+CBL_EXPORT int cbl_bn_rows_forward(long long rows, int C, const float* x, const float* weight, const float* bias, float eps, float momentum,
+                                   float* running_mean, float* running_var, long long* num_batches_tracked, int relu, float* save_mean,
+                                   float* save_invstd, float* y, void* workspace, size_t workspace_bytes, void* stream)
+{
+    return cbl_bn_rows_forward_residual(rows, C, x, nullptr, weight, bias, eps, momentum, running_mean, running_var, num_batches_tracked, relu, save_mean, save_invstd, y,
+                                        workspace, workspace_bytes, stream);
+}
+
+CBL_EXPORT int cbl_bn_rows_backward_residual(long long rows, int C, const float* x, const float* residual, const float* grad_y, const float* weight, const float* bias,
+                                             const float* save_mean, const float* save_invstd, int relu, float* grad_x, float* grad_residual, float* grad_weight,
+                                             float* grad_bias, void* workspace, size_t workspace_bytes, void* stream)
 {
     const int rc = bn_check(rows, C);
     if (rc) return rc;
@@ -387,19 +413,28 @@ CBL_EXPORT int cbl_bn_rows_backward(long long rows, int C, const float* x, const
     float* partial = reinterpret_cast<float*>(workspace);
     float* coef = partial + (size_t)BN_MAX_BLOCKS * 2 * C;
     hipStream_t st = cbl_stream(stream);
-    if (bn_small(rows, C) && cbl_host_aligned16(x) && cbl_host_aligned16(grad_y) && cbl_host_aligned16(grad_x)) {
+    const bool al = cbl_host_aligned16(x) && cbl_host_aligned16(grad_y) && cbl_host_aligned16(grad_x) && cbl_host_aligned16(residual) && cbl_host_aligned16(grad_residual);
+    if (bn_small(rows, C) && al) {
         hipLaunchKernelGGL(bn_small_bwd_kernel, dim3(C / 4), dim3(BN_BLOCK), 0, st, (int)rows, C, x, grad_y, weight, bias, save_mean, save_invstd, relu,
-                           grad_x, grad_weight, grad_bias);
+                           residual, grad_x, grad_residual, grad_weight, grad_bias);
         return cbl_status();
     }
-    const bool vec = s.vec == 4 && cbl_host_aligned16(x) && cbl_host_aligned16(grad_y) && cbl_host_aligned16(grad_x);
+    const bool vec = s.vec == 4 && al;
     const BnShape s1 = vec ? s : [&] { BnShape t = s; t.vec = 1; t.tpr = C; t.slots = BN_BLOCK / C; return t; }();
     if (s1.slots < 1) return CBL_ERR_UNSUPPORTED;
-    if (vec) hipLaunchKernelGGL((bn_partial_kernel<4, 1>), dim3(s1.nblocks), dim3(BN_BLOCK), 0, st, rows, C, s1.tpr, s1.slots, s1.rows_per_block, x, grad_y, save_mean, save_invstd, weight, bias, relu, partial);
-    else     hipLaunchKernelGGL((bn_partial_kernel<1, 1>), dim3(s1.nblocks), dim3(BN_BLOCK), 0, st, rows, C, s1.tpr, s1.slots, s1.rows_per_block, x, grad_y, save_mean, save_invstd, weight, bias, relu, partial);
+    if (vec) hipLaunchKernelGGL((bn_partial_kernel<4, 1>), dim3(s1.nblocks), dim3(BN_BLOCK), 0, st, rows, C, s1.tpr, s1.slots, s1.rows_per_block, x, grad_y, save_mean, save_invstd, weight, bias, relu, residual, partial);
+    else     hipLaunchKernelGGL((bn_partial_kernel<1, 1>), dim3(s1.nblocks), dim3(BN_BLOCK), 0, st, rows, C, s1.tpr, s1.slots, s1.rows_per_block, x, grad_y, save_mean, save_invstd, weight, bias, relu, residual, partial);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cbl_div_up(C, 16)), dim3(256), 0, st, rows, C, s1.nblocks, partial, grad_weight, grad_bias, coef);
     const dim3 grid(cbl_grid_for(rows * (C / (vec ? 4 : 1)), BN_BLOCK, 4096));
-    if (vec) hipLaunchKernelGGL((bn_element_kernel<4, 1>), grid, dim3(BN_BLOCK), 0, st, rows, C, x, grad_y, save_mean, save_invstd, weight, bias, coef, relu, grad_x);
-    else     hipLaunchKernelGGL((bn_element_kernel<1, 1>), grid, dim3(BN_BLOCK), 0, st, rows, C, x, grad_y, save_mean, save_invstd, weight, bias, coef, relu, grad_x);
+    if (vec) hipLaunchKernelGGL((bn_element_kernel<4, 1>), grid, dim3(BN_BLOCK), 0, st, rows, C, x, grad_y, save_mean, save_invstd, weight, bias, coef, relu, residual, grad_x, grad_residual);
+    else     hipLaunchKernelGGL((bn_element_kernel<1, 1>), grid, dim3(BN_BLOCK), 0, st, rows, C, x, grad_y, save_mean, save_invstd, weight, bias, coef, relu, residual, grad_x, grad_residual);
     return cbl_status();
+}
+
+CBL_EXPORT int cbl_bn_rows_backward(long long rows, int C, const float* x, const float* grad_y, const float* weight, const float* bias,
+                                    const float* save_mean, const float* save_invstd, int relu, float* grad_x, float* grad_weight, float* grad_bias,
+                                    void* workspace, size_t workspace_bytes, void* stream)
+{
+    return cbl_bn_rows_backward_residual(rows, C, x, nullptr, grad_y, weight, bias, save_mean, save_invstd, relu, grad_x, nullptr, grad_weight, grad_bias,
+                                         workspace, workspace_bytes, stream);
 }

@@ -17,6 +17,7 @@
 //    one barrier, double-buffered), so the next iteration does not start with a dependent global load of xyz[winner].
 //  * One barrier per sample instead of the reference's 11, and no read-after-write race on the winner (:125 vs :60-61).
 #include "cbl_common.h"
+#include "fps_wave.h"
 #include <math.h>
 
 namespace {
@@ -60,34 +61,7 @@ struct FpsBest {
     __device__ __forceinline__ void offer(float d2, int jj) { const bool up = d2 > d; d = up ? d2 : d; row = up ? jj : row; }
 };
 
-// ---- cross-lane reductions on the VALU's data-parallel primitives (no LDS traffic): xor-butterfly inside each 16-lane row
-// (quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror, row_mirror), then row_bcast:15 / row_bcast:31 to fold the 4 rows into lane 63
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dppf(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false)); }
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ unsigned dppu(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false); }
-__device__ __forceinline__ float row_max_f(float v)
-{
-    v = fmaxf(v, dppf<0xB1, 0xf>(v)); v = fmaxf(v, dppf<0x4E, 0xf>(v)); v = fmaxf(v, dppf<0x141, 0xf>(v)); v = fmaxf(v, dppf<0x140, 0xf>(v));
-    return v;                                                       // every lane of a row holds the row's max
-}
-__device__ __forceinline__ unsigned row_min_u(unsigned v)
-{
-    v = min(v, dppu<0xB1, 0xf>(v)); v = min(v, dppu<0x4E, 0xf>(v)); v = min(v, dppu<0x141, 0xf>(v)); v = min(v, dppu<0x140, 0xf>(v));
-    return v;
-}
-__device__ __forceinline__ float wave_max_f(float v)
-{
-    v = row_max_f(v);
-    v = fmaxf(v, dppf<0x142, 0xa>(v));                             // rows 1,3 <- lane 15 of the row below
-    v = fmaxf(v, dppf<0x143, 0xc>(v));                             // rows 2,3 <- lane 31
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-__device__ __forceinline__ unsigned wave_min_u(unsigned v)
-{
-    v = row_min_u(v);
-    v = min(v, dppu<0x142, 0xa>(v));
-    v = min(v, dppu<0x143, 0xc>(v));
-    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
+// ---- cross-lane reductions: fps_wave.h (row_max_f, row_min_u, wave_max_f, wave_min_u)
 
 // Block-wide winner of the lexicographic (larger d2, smaller rank) maximum, with its coordinates.  `coords(row, x, y, z)` is
 // called by ONE lane per wave (the wave's winner) to fetch the coordinates of its best row.  One barrier; slots[par] alternates.

@@ -16,6 +16,7 @@
 // sample on average); the t values, and therefore the arg-max sequence, are identical by construction.  One barrier and one L2
 // round trip per sample.
 #include "cbl_common.h"
+#include "fps_wave.h"
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -129,41 +130,23 @@ __global__ __launch_bounds__(256) void fb_writeback_kernel(int n, const int* __r
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) tmp[order[i]] = sorted[i].w;   // side effect of :56
 }
 
-// ---- DPP reductions (as in fps.hip) ----------------------------------------------------------------------------------------
+// ---- DPP reductions: fps_wave.h; the minima over floats are used once per bucket (its box), outside the sample loop
 template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dppf(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false)); }
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ unsigned dppu(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false); }
-__device__ __forceinline__ float row_max_f(float v)
-{
-    v = fmaxf(v, dppf<0xB1, 0xf>(v)); v = fmaxf(v, dppf<0x4E, 0xf>(v)); v = fmaxf(v, dppf<0x141, 0xf>(v)); v = fmaxf(v, dppf<0x140, 0xf>(v));
-    return v;
-}
-__device__ __forceinline__ float row_min_f(float v)
-{
-    v = fminf(v, dppf<0xB1, 0xf>(v)); v = fminf(v, dppf<0x4E, 0xf>(v)); v = fminf(v, dppf<0x141, 0xf>(v)); v = fminf(v, dppf<0x140, 0xf>(v));
-    return v;
-}
-__device__ __forceinline__ unsigned row_min_u(unsigned v)
-{
-    v = min(v, dppu<0xB1, 0xf>(v)); v = min(v, dppu<0x4E, 0xf>(v)); v = min(v, dppu<0x141, 0xf>(v)); v = min(v, dppu<0x140, 0xf>(v));
-    return v;
-}
-__device__ __forceinline__ float wave_max_f(float v)
-{
-    v = row_max_f(v); v = fmaxf(v, dppf<0x142, 0xa>(v)); v = fmaxf(v, dppf<0x143, 0xc>(v));
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
 __device__ __forceinline__ float wave_min_f(float v)
 {
-    v = row_min_f(v); v = fminf(v, dppf<0x142, 0xa>(v)); v = fminf(v, dppf<0x143, 0xc>(v));
+    v = fminf(v, dppf<0xB1, 0xf>(v)); v = fminf(v, dppf<0x4E, 0xf>(v)); v = fminf(v, dppf<0x141, 0xf>(v)); v = fminf(v, dppf<0x140, 0xf>(v));
+    v = fminf(v, dppf<0x142, 0xa>(v)); v = fminf(v, dppf<0x143, 0xc>(v));
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
-__device__ __forceinline__ unsigned wave_min_u(unsigned v)
+// coordinates may be negative: the float maximum proper (box corners, once per bucket)
+__device__ __forceinline__ float wave_max_any_f(float v)
 {
-    v = row_min_u(v); v = min(v, dppu<0x142, 0xa>(v)); v = min(v, dppu<0x143, 0xc>(v));
-    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+    v = fmaxf(v, dppf<0xB1, 0xf>(v)); v = fmaxf(v, dppf<0x4E, 0xf>(v)); v = fmaxf(v, dppf<0x141, 0xf>(v)); v = fmaxf(v, dppf<0x140, 0xf>(v));
+    v = fmaxf(v, dppf<0x142, 0xa>(v)); v = fmaxf(v, dppf<0x143, 0xc>(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-struct FbSlot { float d; unsigned rank; float x, y, z; float pad[3]; };      // 32 B
+struct __attribute__((aligned(16))) FbSlot { float d; unsigned rank; float x, y, z; float pad[3]; };      // 32 B: {d, rank, x, y} and {z, tie flag} are one read each
 
 // One 1024-lane workgroup per cloud.  Bucket g belongs to wave g % 16, lane (g / 16) % 64, register set g / 1024: box, best
 // distance / rank / coordinates all live in the owner lane's registers, and the owner WAVE is also the one that reprocesses the
@@ -222,7 +205,7 @@ __global__ __launch_bounds__(1024) void fps_bucket_kernel(int bits, const float*
         o.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.z), lb));
         if (first) {                                                             // invalid lanes copy the last valid point: harmless
             blo[0] = wave_min_f(p.x); blo[1] = wave_min_f(p.y); blo[2] = wave_min_f(p.z);
-            bhi[0] = wave_max_f(p.x); bhi[1] = wave_max_f(p.y); bhi[2] = wave_max_f(p.z);
+            bhi[0] = wave_max_any_f(p.x); bhi[1] = wave_max_any_f(p.y); bhi[2] = wave_max_any_f(p.z);
         }
         // the write-back goes last and is never waited for (gfx9 counts loads and stores in one counter)
         __builtin_amdgcn_sched_barrier(0);
@@ -329,8 +312,12 @@ __global__ __launch_bounds__(1024) void fps_bucket_kernel(int bits, const float*
         if (lane == 0) { FbSlot s; s.d = wb.d; s.rank = wb.rank; s.x = wb.x; s.y = wb.y; s.z = wb.z; s.pad[0] = (CERT && wb.tie) ? 1.f : 0.f; s.pad[1] = s.pad[2] = 0.f; slots[par][wave] = s; }
         __syncthreads();
         // S3: every wave reduces the 16 slots (each row of 16 lanes holds all of them)
+        // lane l reads the whole of slot l & 15 at once; the winner's fields then come out of its lane by v_readlane — no second LDS round trip on the
+        // sample's critical path
         const int sl = lane & (W - 1);
-        const float sd = slots[par][sl].d; const unsigned sr = slots[par][sl].rank;
+        const float4 s4 = *reinterpret_cast<const float4*>(&slots[par][sl]);          // d, rank, x, y
+        const float2 s2 = *reinterpret_cast<const float2*>(&slots[par][sl].z);        // z, tie flag
+        const float sd = s4.x; const unsigned sr = __float_as_uint(s4.y);
         const float bd = row_max_f(sd);
         unsigned mk16 = (unsigned)__ballot(sd == bd) & 0xffffu;
         const bool block_tie = __popc(mk16) != 1;
@@ -339,11 +326,13 @@ __global__ __launch_bounds__(1024) void fps_bucket_kernel(int bits, const float*
             mk16 = (unsigned)__ballot(sd == bd && sr == br) & 0xffffu;
         }
         const int slot = __builtin_ctz(mk16);
-        sx = slots[par][slot].x; sy = slots[par][slot].y; sz = slots[par][slot].z;
-        if (CERT && j - m0 < track_n && first_tie == 0x7fffffff && (block_tie || slots[par][slot].pad[0] != 0.f)) first_tie = j - m0;
+        sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s4.z), slot));
+        sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s4.w), slot));
+        sz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s2.x), slot));
+        if (CERT && j - m0 < track_n && first_tie == 0x7fffffff && (block_tie || __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s2.y), slot)) != 0.f)) first_tie = j - m0;
         if (wave == W - 1) {
             const int jj = j - m0;
-            const int win = n0 + fb_unrank(slots[par][slot].rank, bits);
+            const int win = n0 + fb_unrank((unsigned)__builtin_amdgcn_readlane((int)sr, slot), bits);
             if (lane == (jj & 63)) myidx = win;
             if ((jj & 63) == 63 || j == m1 - 1) { if (lane <= (jj & 63)) idx[m0 + (jj & ~63) + lane] = myidx; }
         }

@@ -107,25 +107,27 @@ MIN_ROWS_BN = 64            # below this torch's own kernels; up to 4096 rows cs
 
 
 class _BnRows(Function):
+    """y = [relu](bn(x) [+ residual]) (cbl_bn_rows_*_residual); the residual's gradient is the masked incoming gradient"""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, num_batches_tracked, eps, momentum, relu):
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, num_batches_tracked, eps, momentum, relu):
         rows, C = x.shape
         L = _lib.lib()
         ws = _bn_workspace(L.cbl_bn_rows_workspace_bytes(ctypes.c_longlong(rows), ctypes.c_int(C)), x.device)
         mean = torch.empty(C, dtype=torch.float32, device=x.device)
         invstd = torch.empty(C, dtype=torch.float32, device=x.device)
         y = torch.empty_like(x)
-        _lib.check(L.cbl_bn_rows_forward(ctypes.c_longlong(rows), ctypes.c_int(C), _lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), ctypes.c_float(eps),
-                                         ctypes.c_float(momentum), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(num_batches_tracked),
-                                         ctypes.c_int(relu), _lib.ptr(mean),
-                                         _lib.ptr(invstd), _lib.ptr(y), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(x)), "cbl_bn_rows_forward")
-        ctx.save_for_backward(x, weight, bias, mean, invstd)
+        _lib.check(L.cbl_bn_rows_forward_residual(ctypes.c_longlong(rows), ctypes.c_int(C), _lib.ptr(x), _lib.ptr(residual), _lib.ptr(weight), _lib.ptr(bias),
+                                                  ctypes.c_float(eps), ctypes.c_float(momentum), _lib.ptr(running_mean), _lib.ptr(running_var),
+                                                  _lib.ptr(num_batches_tracked), ctypes.c_int(relu), _lib.ptr(mean),
+                                                  _lib.ptr(invstd), _lib.ptr(y), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(x)), "cbl_bn_rows_forward_residual")
+        ctx.save_for_backward(x, residual, weight, bias, mean, invstd)
         ctx.relu = relu
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight, bias, mean, invstd = ctx.saved_tensors
+        x, residual, weight, bias, mean, invstd = ctx.saved_tensors
         rows, C = x.shape
         gy = gy.contiguous()
         L = _lib.lib()
@@ -133,10 +135,15 @@ class _BnRows(Function):
         gx = torch.empty_like(x)
         gw = torch.empty(C, dtype=torch.float32, device=x.device) if weight is not None else None
         gb = torch.empty(C, dtype=torch.float32, device=x.device) if bias is not None else None
-        _lib.check(L.cbl_bn_rows_backward(ctypes.c_longlong(rows), ctypes.c_int(C), _lib.ptr(x), _lib.ptr(gy), _lib.ptr(weight), _lib.ptr(bias),
-                                          _lib.ptr(mean), _lib.ptr(invstd), ctypes.c_int(ctx.relu), _lib.ptr(gx), _lib.ptr(gw), _lib.ptr(gb),
-                                          _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(x)), "cbl_bn_rows_backward")
-        return gx, gw, gb, None, None, None, None, None, None
+        # without a ReLU the skip connection's gradient IS the incoming one: no copy
+        want_gr = residual is not None and ctx.needs_input_grad[1]
+        gr = torch.empty_like(x) if (want_gr and ctx.relu) else None
+        _lib.check(L.cbl_bn_rows_backward_residual(ctypes.c_longlong(rows), ctypes.c_int(C), _lib.ptr(x), _lib.ptr(residual), _lib.ptr(gy), _lib.ptr(weight),
+                                                   _lib.ptr(bias), _lib.ptr(mean), _lib.ptr(invstd), ctypes.c_int(ctx.relu), _lib.ptr(gx), _lib.ptr(gr), _lib.ptr(gw),
+                                                   _lib.ptr(gb), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(x)), "cbl_bn_rows_backward_residual")
+        if want_gr and not ctx.relu:
+            gr = gy
+        return gx, gr, gw, gb, None, None, None, None, None, None
 
 
 _bn_ws = {}
@@ -147,20 +154,24 @@ def _bn_workspace(nbytes, device):
     return scratch(_bn_ws, "bn", nbytes, device)
 
 
-def batch_norm(x, bn, relu=False):
+def batch_norm(x, bn, relu=False, residual=None):
     """`relu(bn(x))` / `bn(x)` for an nn.BatchNorm1d over the last dimension of x (..., C), every leading dimension a batch row —
     what the reference writes as bn(x.transpose(1, 2)).transpose(1, 2) for (n, K, C) tensors (blocks.py:38,40).  Train mode with
     running statistics and a float momentum goes through csrc/bn_rows.hip (2 passes forward, 2 backward, ReLU folded in); anything
-    else through torch with identical semantics."""
+    else through torch with identical semantics.  residual (same shape as x): `[relu](bn(x) + residual)`, the tail of a residual block
+    (blocks.py:130-133) as the same one call."""
     C = x.shape[-1]
     rows = x.numel() // max(C, 1)
     fused = (bn.training and x.is_cuda and x.dtype == torch.float32 and rows >= MIN_ROWS_BN and bn.track_running_stats and bn.momentum is not None
-             and (C % 4 == 0 and C <= 1024 or C <= 256))
+             and (C % 4 == 0 and C <= 1024 or C <= 256)
+             and (residual is None or (residual.shape == x.shape and residual.dtype == x.dtype and residual.device == x.device)))
     if not fused:
         y = bn(x.reshape(-1, C)).view(x.shape)
+        if residual is not None:
+            y = y + residual
         return F.relu(y) if relu else y
-    y = _BnRows.apply(x.reshape(rows, C).contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                      float(bn.eps), float(bn.momentum), int(relu))
+    y = _BnRows.apply(x.reshape(rows, C).contiguous(), None if residual is None else residual.reshape(rows, C).contiguous(), bn.weight, bn.bias,
+                      bn.running_mean, bn.running_var, bn.num_batches_tracked, float(bn.eps), float(bn.momentum), int(relu))
     return y.view(x.shape)
 
 

@@ -589,6 +589,16 @@ int cbl_bn_rows_forward(long long rows, int C, const float* x, const float* weig
 int cbl_bn_rows_backward(long long rows, int C, const float* x, const float* grad_y, const float* weight, const float* bias,
                          const float* save_mean, const float* save_invstd, int relu, float* grad_x, float* grad_weight, float* grad_bias,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* the tail of a residual block as ONE BatchNorm call  pytorch/model/blocks.py:130-133 (x = bn3(linear3(x)); x += identity; x = relu(x))
+ *   y = [relu](bn(x) + residual); residual (rows,C) or NULL (then exactly cbl_bn_rows_forward).
+ *   backward: the mask is (bn(x) + residual > 0) recomputed from x and residual; grad_residual (rows,C) or NULL receives the masked grad_y
+ *   (the gradient of the skip connection), grad_x / grad_weight / grad_bias as above. */
+int cbl_bn_rows_forward_residual(long long rows, int C, const float* x, const float* residual, const float* weight, const float* bias, float eps, float momentum,
+                                 float* running_mean, float* running_var, long long* num_batches_tracked, int relu, float* save_mean, float* save_invstd,
+                                 float* y, void* workspace, size_t workspace_bytes, void* stream);
+int cbl_bn_rows_backward_residual(long long rows, int C, const float* x, const float* residual, const float* grad_y, const float* weight, const float* bias,
+                                  const float* save_mean, const float* save_invstd, int relu, float* grad_x, float* grad_residual, float* grad_weight,
+                                  float* grad_bias, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ind_max_pool / ind_closest_pool  tensorflow/models/basic_operators.py:155-172 / :175-192
  *   x (n1,d), inds (n2,k) i32 (pad = n1) -> out (n2,d): max over the row's entries (shadow row = column-wise min of x; scratch_d (d) u32)

@@ -77,6 +77,40 @@ def test_batch_norm_rows_matches_torch(shape, relu):
     assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("shape,relu", [((163840, 32), True), ((40960, 64), True), ((10240, 64), False), ((2560, 128), True), ((640, 256), True), ((160, 512), False),
+                                        ((5000, 6), True), ((3000, 6), True), ((100, 16), True)])
+def test_batch_norm_with_residual_matches_torch(shape, relu):
+    """[relu](bn(x) + residual) as one call each way (cbl_bn_rows_*_residual: the tail of a residual block, blocks.py:130-133) against nn.BatchNorm1d, `+` and ReLU in
+    float64: output, the gradients of x, of the residual and of the affine parameters, running statistics"""
+    import copy
+    from contrastboundary_amd import dense
+    torch.manual_seed(shape[0] % 97)
+    C = shape[-1]
+    bn = torch.nn.BatchNorm1d(C).cuda().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5); bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
+    ref = copy.deepcopy(bn).double()
+    x = (torch.randn(*shape, device="cuda") * 1.7 + 0.3).requires_grad_(True)
+    res = torch.randn(*shape, device="cuda").requires_grad_(True)
+    g = torch.randn(*shape, device="cuda")
+    y = dense.batch_norm(x, bn, relu=relu, residual=res)
+    y.backward(g)
+    x64 = x.detach().double().requires_grad_(True); r64 = res.detach().double().requires_grad_(True)
+    r = ref(x64.reshape(-1, C)).view(shape) + r64
+    if relu:
+        r = torch.relu(r)
+    r.backward(g.double())
+    close = lambda a, b, tol: float((a.double() - b).abs().max()) <= tol * max(float(b.abs().max()), 1e-30)
+    assert close(y.detach(), r.detach(), 2e-5)
+    l2 = lambda a, b: float((a.double() - b).norm() / b.norm())
+    assert l2(x.grad, x64.grad) < 1e-4 and l2(res.grad, r64.grad) < 1e-4
+    assert l2(bn.weight.grad, ref.weight.grad) < 1e-4 and l2(bn.bias.grad, ref.bias.grad) < 1e-4
+    assert close(bn.running_mean, ref.running_mean, 1e-5) and close(bn.running_var, ref.running_var, 1e-5)
+    # the residual that needs no gradient (a block input without one) and the same tensor on both sides (x + x)
+    y2 = dense.batch_norm(x.detach().requires_grad_(True), bn, relu=relu, residual=res.detach())
+    assert close(y2.detach(), r.detach(), 2e-5)
+
+
 def test_batch_norm_eval_mode_and_small_inputs_use_torch():
     from contrastboundary_amd import dense
     bn = torch.nn.BatchNorm1d(16).cuda().eval()

@@ -8,7 +8,7 @@ model() { tag=$1; shift; timeout 300 python tools/bench_model.py "$@" 2> $out/mo
 import json, sys
 try:
     d = json.loads(open(sys.argv[1]).read())
-    print(sys.argv[2], "ms_per_step", round(d["ms_per_step"], 3), "value", round(d["value"] / 1e6, 3), "M pts/s", "replay", (d.get("segments_ms") or {}).get("replay_ms"))
+    print(sys.argv[2], "ms_per_step", round(d["ms_per_step"], 3), round(d["points_per_s"] / 1e6, 3), "M pts/s", "replay", (d.get("segments_ms") or {}).get("replay_ms"))
 except Exception as e:
     print(sys.argv[2], "failed", e)
 PY
