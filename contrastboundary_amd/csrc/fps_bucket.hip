@@ -251,7 +251,10 @@ __global__ __launch_bounds__(1024) void fps_bucket_kernel(int bits, const float*
     }
     float sx = xyz[3 * (size_t)n0], sy = xyz[3 * (size_t)n0 + 1], sz = xyz[3 * (size_t)n0 + 2];   // first sample = first point (:26 / :34)
     int myidx = n0;                                                              // wave 15 collects 64 results per coalesced store (:39)
-    Best wb; wb.d = -3.f; wb.rank = 0xffffffffu; wb.x = wb.y = wb.z = 0.f; wb.tie = 0;       // this wave's best over its buckets
+    // this wave's best over its buckets: per-lane merge of the lane's register sets (cd ..), held by lane `wlane`
+    float cd = -3.f, cx = 0.f, cy = 0.f, cz = 0.f; unsigned crk = 0xffffffffu;
+    int wlane = 0, fresh = 2;
+    bool wtie = false;
     bool dirty = true;
     int first_tie = 0x7fffffff;                                                  // first sample (counted in the cloud) whose maximum was not unique
     // only the first half of the samples is certified: the next stage of a chain asks for a fraction of them (1/4 in the reference's network), and the
@@ -294,22 +297,29 @@ __global__ __launch_bounds__(1024) void fps_bucket_kernel(int bits, const float*
                 if (CERT) lt = (bm[r] == d) ? 1 : (up ? bt[r] : lt);             // two of this lane's buckets at the same maximum: not unique
                 d = up ? bm[r] : d; rk = up ? brk[r] : rk; x = up ? bxr[r] : x; y = up ? byr[r] : y; z = up ? bzr[r] : z;
             }
-            wb.d = wave_max_f(d);
-            unsigned long long mk = __ballot(d == wb.d);
-            wb.tie = CERT && (j - m0 < track_n) && ((__popcll(mk) != 1) || (__ballot(d == wb.d && lt) != 0ull));
+            const float wd = wave_max_f(d);
+            unsigned long long mk = __ballot(d == wd);
+            wtie = CERT && (j - m0 < track_n) && ((__popcll(mk) != 1) || (__ballot(d == wd && lt) != 0ull));
             if (__popcll(mk) != 1) {
-                const unsigned wr = wave_min_u(d == wb.d ? rk : 0xffffffffu);
-                mk = __ballot(d == wb.d && rk == wr);
+                const unsigned wr = wave_min_u(d == wd ? rk : 0xffffffffu);
+                mk = __ballot(d == wd && rk == wr);
             }
-            const int lb = __builtin_ctzll(mk);
-            wb.rank = (unsigned)__builtin_amdgcn_readlane((int)rk, lb);
-            wb.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lb));
-            wb.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), lb));
-            wb.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z), lb));
+            // the wave's best stays where it is — in the registers of lane `wlane` — and that lane writes the slot itself: no v_readlane / v_mov detour
+            wlane = __builtin_ctzll(mk);
+            cd = d; crk = rk; cx = x; cy = y; cz = z;
             dirty = false;
+            fresh = 2;
         }
         const int par = j & 1;
-        if (lane == 0) { FbSlot s; s.d = wb.d; s.rank = wb.rank; s.x = wb.x; s.y = wb.y; s.z = wb.z; s.pad[0] = (CERT && wb.tie) ? 1.f : 0.f; s.pad[1] = s.pad[2] = 0.f; slots[par][wave] = s; }
+        // a wave whose best did not change writes nothing: both parities of its slot hold it after two samples
+        if (fresh > 0) {
+            fresh--;
+            if (lane == wlane) {
+                FbSlot* sp = &slots[par][wave];
+                *reinterpret_cast<float4*>(sp) = make_float4(cd, __uint_as_float(crk), cx, cy);
+                *reinterpret_cast<float2*>(&sp->z) = make_float2(cz, (CERT && wtie) ? 1.f : 0.f);   // the tie flag is part of the wave's state, like its best
+            }
+        }
         __syncthreads();
         // S3: every wave reduces the 16 slots (each row of 16 lanes holds all of them)
         // lane l reads the whole of slot l & 15 at once; the winner's fields then come out of its lane by v_readlane — no second LDS round trip on the
