@@ -164,8 +164,23 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_element_kernel(long long rows, in
 {
     const int tpr = C / VEC;
     const long long total = rows * tpr;
-    for (long long e = (long long)blockIdx.x * BN_BLOCK + threadIdx.x; e < total; e += (long long)gridDim.x * BN_BLOCK) {
-        const int c0 = (int)(e % tpr) * VEC;
+    const long long stride = (long long)gridDim.x * BN_BLOCK;
+    // a lane's channels are the same on every trip when the grid stride is a multiple of the lanes per row (every power-of-two C): its per-channel
+    // constants are then read ONCE (they were 4 .. 6 scalar loads per channel and trip, the bulk of the kernel's memory instructions) — same arithmetic
+    const bool fixed = (stride % tpr) == 0;
+    float cw[VEC], cb[VEC], cm[VEC], cis[VEC], k0[VEC], k1[VEC];
+    auto constants = [&](int c0) {
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+            const int c = c0 + v;
+            cw[v] = weight ? weight[c] : 1.f; cb[v] = bias ? bias[c] : 0.f; cm[v] = mean[c]; cis[v] = invstd[c];
+            k0[v] = (MODE == 1) ? coef[c] : 0.f; k1[v] = (MODE == 1) ? coef[C + c] : 0.f;
+        }
+    };
+    const long long e0 = (long long)blockIdx.x * BN_BLOCK + threadIdx.x;
+    if (fixed && e0 < total) constants((int)(e0 % tpr) * VEC);
+    for (long long e = e0; e < total; e += stride) {
+        if (!fixed) constants((int)(e % tpr) * VEC);
         float xv[VEC], gv[VEC], o[VEC], rv[VEC], gm[VEC];
 #pragma unroll
         for (int v = 0; v < VEC; v++) rv[v] = 0.f;
@@ -181,15 +196,13 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_element_kernel(long long rows, in
         }
 #pragma unroll
         for (int v = 0; v < VEC; v++) {
-            const int c = c0 + v;
-            const float w = weight ? weight[c] : 1.f, b = bias ? bias[c] : 0.f;
-            const float xh = (xv[v] - mean[c]) * invstd[c];
-            const float y = (xh * w + b) + rv[v];
+            const float xh = (xv[v] - cm[v]) * cis[v];
+            const float y = (xh * cw[v] + cb[v]) + rv[v];
             if (MODE == 0) o[v] = (relu && !(y > 0.f)) ? 0.f : y;
             else {
                 const float g = (relu && !(y > 0.f)) ? 0.f : gv[v];
                 gm[v] = g;
-                o[v] = w * invstd[c] * ((g - coef[c]) - xh * coef[C + c]);
+                o[v] = cw[v] * cis[v] * ((g - k0[v]) - xh * k1[v]);
             }
         }
         if (VEC == 4) *reinterpret_cast<float4*>(out + e * 4) = make_float4(o[0], o[1], o[2], o[3]);
