@@ -18,6 +18,7 @@
 #include "cbl_common.h"
 #include "fps_wave.h"
 #include <cstring>
+#include <cstdlib>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <math.h>
@@ -154,13 +155,12 @@ struct __attribute__((aligned(16))) FbSlot { float d; unsigned rank; float x, y,
 // are neighbours in Morton order sit in different waves) -> wave best -> LDS slot -> barrier -> every wave reduces the 16 slots.
 // CERT: also certify which leading samples were unique maxima (the prefix certificate of fps.hip); compiled out otherwise — the bookkeeping costs ~9 % of
 // the kernel, and only the head of a sampling chain needs it
-template <int R, bool CERT>
-__global__ __launch_bounds__(1024) void fps_bucket_kernel(int bits, const float* __restrict__ xyz, const int* __restrict__ offset,
+template <int R, bool CERT, int W = 16>
+__global__ __launch_bounds__(64 * W) void fps_bucket_kernel(int bits, const float* __restrict__ xyz, const int* __restrict__ offset,
                                                           const int* __restrict__ new_offset, float4* __restrict__ sorted,
                                                           const unsigned* __restrict__ rank, int* __restrict__ idx,
                                                           const int* __restrict__ prefix_cert, int* __restrict__ cert_out)
 {
-    constexpr int W = 16;
     __shared__ FbSlot slots[2][W];
     const int c = blockIdx.x;
     const int n0 = c ? offset[c - 1] : 0, n1 = offset[c];
@@ -329,11 +329,12 @@ __global__ __launch_bounds__(1024) void fps_bucket_kernel(int bits, const float*
         const float2 s2 = *reinterpret_cast<const float2*>(&slots[par][sl].z);        // z, tie flag
         const float sd = s4.x; const unsigned sr = __float_as_uint(s4.y);
         const float bd = row_max_f(sd);
-        unsigned mk16 = (unsigned)__ballot(sd == bd) & 0xffffu;
+        constexpr unsigned WM = (1u << W) - 1u;                                    // W < 16: a row holds every slot more than once, the first copy counts
+        unsigned mk16 = (unsigned)__ballot(sd == bd) & WM;
         const bool block_tie = __popc(mk16) != 1;
         if (__popc(mk16) != 1) {
             const unsigned br = row_min_u(sd == bd ? sr : 0xffffffffu);
-            mk16 = (unsigned)__ballot(sd == bd && sr == br) & 0xffffu;
+            mk16 = (unsigned)__ballot(sd == bd && sr == br) & WM;
         }
         const int slot = __builtin_ctz(mk16);
         sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s4.z), slot));
@@ -372,10 +373,14 @@ int cbl_fps_bucket_launch(int b, int n, int n_max, int bits, const float* xyz, c
     hipError_t e = rocprim::radix_sort_pairs(w.cub, cb, w.keys_in, w.keys_out, w.vals_in, w.vals_out, (size_t)n, 0u, 48u, st);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(fb_gather_kernel, g, blk, 0, st, b, n, bits, xyz, offset, tmp, w.keys_out, w.vals_out, w.sorted, w.rank);
-    if (nb_max <= 1024) { if (cert_out) hipLaunchKernelGGL((fps_bucket_kernel<1, true>), dim3(b), dim3(1024), 0, st, bits, xyz, offset, new_offset, w.sorted, w.rank, idx, prefix_cert, cert_out);
-                          else          hipLaunchKernelGGL((fps_bucket_kernel<1, false>), dim3(b), dim3(1024), 0, st, bits, xyz, offset, new_offset, w.sorted, w.rank, idx, prefix_cert, cert_out); }
-    else                { if (cert_out) hipLaunchKernelGGL((fps_bucket_kernel<2, true>), dim3(b), dim3(1024), 0, st, bits, xyz, offset, new_offset, w.sorted, w.rank, idx, prefix_cert, cert_out);
-                          else          hipLaunchKernelGGL((fps_bucket_kernel<2, false>), dim3(b), dim3(1024), 0, st, bits, xyz, offset, new_offset, w.sorted, w.rank, idx, prefix_cert, cert_out); }
+    // waves per workgroup: 16 (one bucket per lane up to 1024 buckets); CBL_FPS_WAVES=8 runs two buckets per lane on 8 waves where that covers the cloud
+    static const int waves = [] { const char* e = getenv("CBL_FPS_WAVES"); return (e && atoi(e) == 8) ? 8 : 16; }();
+#define CBL_FB(R_, W_) do { if (cert_out) hipLaunchKernelGGL((fps_bucket_kernel<R_, true, W_>), dim3(b), dim3(64 * W_), 0, st, bits, xyz, offset, new_offset, w.sorted, w.rank, idx, prefix_cert, cert_out); \
+                            else          hipLaunchKernelGGL((fps_bucket_kernel<R_, false, W_>), dim3(b), dim3(64 * W_), 0, st, bits, xyz, offset, new_offset, w.sorted, w.rank, idx, prefix_cert, cert_out); } while (0)
+    if (waves == 8 && nb_max <= 1024) { if (nb_max <= 512) CBL_FB(1, 8); else CBL_FB(2, 8); }
+    else if (nb_max <= 1024) CBL_FB(1, 16);
+    else CBL_FB(2, 16);
+#undef CBL_FB
     hipLaunchKernelGGL(fb_writeback_kernel, g, blk, 0, st, n, w.vals_out, w.sorted, tmp);
     return cbl_status();
 }
