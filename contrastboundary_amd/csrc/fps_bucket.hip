@@ -254,6 +254,7 @@ __global__ __launch_bounds__(64 * W) void fps_bucket_kernel(int bits, const floa
     // this wave's best over its buckets: per-lane merge of the lane's register sets (cd ..), held by lane `wlane`
     float cd = -3.f, cx = 0.f, cy = 0.f, cz = 0.f; unsigned crk = 0xffffffffu;
     int wlane = 0, fresh = 2;
+    float wdv = -4.f;                                                            // the wave's best distance (wave-uniform copy of lane wlane's cd)
     bool wtie = false;
     bool dirty = true;
     int first_tie = 0x7fffffff;                                                  // first sample (counted in the cloud) whose maximum was not unique
@@ -271,6 +272,9 @@ __global__ __launch_bounds__(64 * W) void fps_bucket_kernel(int bits, const floa
             const float gz = fmaxf(fmaxf(lo[r][2] - sz, sz - hi[r][2]), 0.f);
             const float L = (gx * gx + gy * gy) + gz * gz;
             unsigned long long mk = __ballot(L < bm[r]);                        // unowned register sets hold bm = -3: never touched
+            // running distances only fall: the wave's best can change only if a touched bucket HELD it (or tied with it: the certificate's uniqueness flag) —
+            // the other waves with touched buckets skip the wave reduction and the slot write
+            if (mk) dirty |= (__ballot(bm[r] == wdv) & mk) != 0ull;
             while (mk) {
                 // up to two touched buckets per trip: their loads and reduction chains overlap
                 const int l1 = __builtin_ctzll(mk);
@@ -286,7 +290,6 @@ __global__ __launch_bounds__(64 * W) void fps_bucket_kernel(int bits, const floa
                     const Best o = process((l1 + 64 * r) * W + wave, sx, sy, sz, false, nullptr, nullptr);
                     if (lane == l1) { bm[r] = o.d; brk[r] = o.rank; bxr[r] = o.x; byr[r] = o.y; bzr[r] = o.z; bt[r] = o.tie; }
                 }
-                dirty = true;
             }
         }
         if (dirty) {                                                             // wave-uniform
@@ -306,6 +309,7 @@ __global__ __launch_bounds__(64 * W) void fps_bucket_kernel(int bits, const floa
             }
             // the wave's best stays where it is — in the registers of lane `wlane` — and that lane writes the slot itself: no v_readlane / v_mov detour
             wlane = __builtin_ctzll(mk);
+            wdv = wd;
             cd = d; crk = rk; cx = x; cy = y; cz = z;
             dirty = false;
             fresh = 2;
