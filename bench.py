@@ -727,7 +727,9 @@ def run_convnet(args, D, world, rank, local):
                            "(convnet_path.NativeLayers; tests/test_gpu_bench_convnet.py: bit-identical to the op-by-op step)" % loader.depth}
         loader.close()
         pipelined_ops = pipelined
-        if e_n <= elapsed:
+        # the reported step IS the native-call one (the design of this path; its issue time is what `host_issue_ms_per_step` is asked about) unless it
+        # measures clearly slower than the op-by-op issue of the same kernels (then that one, and both are in the line either way)
+        if e_n <= 1.05 * elapsed:
             elapsed, pipelined = e_n, native
     spread = rank_spread(D)
     pyr = state["pyr"]

@@ -40,7 +40,7 @@ CBL_HD int cbl_as_int(float f) { union { float f; int i; } v; v.f = f; return v.
 CBL_HD float cbl_as_float(int i) { union { float f; int i; } v; v.i = i; return v.f; }
 
 // Choose the grid of a cloud from its bbox [lo,hi], point count and neighbour count k.
-// target: ~0.42*k points per cell if the cloud filled its bbox uniformly (then the k-th neighbour is
+// target: ~0.33*k points per cell (the caller's factor, knn_grid.hip) if the cloud filled its bbox uniformly (then the k-th neighbour is
 // closer than one cell edge and the 27-cell block certifies most queries); `cap` bounds nx*ny*nz.
 CBL_HD void cbl_grid_choose(CblGrid& g, const float lo[3], const float hi[3], int count, float pts_per_cell, int cap)
 {

@@ -15,6 +15,7 @@
 //      (ties, clouds with <= K supports) is appended to a worklist and recomputed by the exact kernel
 //      (knn_exact.hip) in the reference's visiting order.  No host synchronisation anywhere.
 #include "cbl_common.h"
+#include <cstdlib>
 #include "grid_core.h"
 
 int cbl_knn_exact_worklist(int b, int m, int K, const float* xyz, const float* new_xyz, const int* offset,
@@ -944,8 +945,11 @@ int cbl_knn_grid_launch(int b, int n, int m, int nsample, const float* xyz, cons
 {
     Workspace w = carve(ws, b, n, m);
     if (ws_bytes < w.bytes) return CBL_ERR_WORKSPACE;
-    // ~0.42*K points per cell if the cloud filled its bbox: the K-th neighbour is then usually inside the 27-cell block
-    int rc = cbl_grid_build(b, n, 0.42f * (float)(nsample < 4 ? 4 : nsample), xyz, offset, ws, st, order_out);
+    // ~0.33*K points per cell if the cloud filled its bbox: the K-th neighbour is then usually inside the 27-cell block.  (0.42 until round 5; measured on the
+    // bench scene, pairs visited / in-order step: 0.20: 7.4 M / 0.395 ms, 0.25: 9.1 M / 0.386, 0.33: 11.0 M / 0.388, 0.42: 13.0 M / 0.40, 0.60: 18.6 M / 0.416 —
+    // smaller cells trade candidates for queries that need a second shell; CBL_KNN_CELL_FILL overrides for such sweeps)
+    static const float fill = [] { const char* e = getenv("CBL_KNN_CELL_FILL"); const float v = e ? (float)atof(e) : 0.f; return (v > 0.05f && v < 4.f) ? v : 0.33f; }();
+    int rc = cbl_grid_build(b, n, fill * (float)(nsample < 4 ? 4 : nsample), xyz, offset, ws, st, order_out);
     if (rc) return rc;
     const bool self = (new_xyz == xyz) && (m == n);
     if (nsample > 16) {                                              // select-then-sort, one wave per query

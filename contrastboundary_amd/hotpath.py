@@ -368,38 +368,46 @@ def concurrent_streams(count, candidates=12, spin_cycles=2_000_000, beside=None)
     creation order, so two fresh streams can share a queue and then execute strictly one after the other — measured: the search chain and the
     branch it was supposed to overlap landed on one queue and the pipeline ran in order.  The mapping cannot be queried, so it is observed: a
     one-thread spin kernel on two streams takes T if they have queues of their own and 2T if they share one.
+    The spin kernel counts CLOCK CYCLES, and a device that was idle a moment ago (the first process on a box) is still raising its clocks: a reference time
+    taken once at the start made every later pair look fast, shared queue or not (measured: the first bench run on a fresh box ran its pipeline in order,
+    0.43 instead of 0.28 ms per step).  So the device is kept busy for a moment first, and every pair is compared with the SAME two kernels on ONE stream,
+    issued right before it: clocks cancel out of the ratio.
     beside: stream(s) the chosen ones must ALSO run beside (e.g. the stream the caller's own work is on); not part of the result."""
-    def together(a, b):
+    def timed(streams):
         torch.cuda.synchronize()
         t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         cur = torch.cuda.current_stream()
         t0.record(cur)
-        for s in (a, b):
+        for s in streams:
             s.wait_event(t0)
+        for s in streams:
             with torch.cuda.stream(s):
                 torch.cuda._sleep(spin_cycles)
-        for s in (a, b):
+        for s in set(streams):
             cur.wait_stream(s)
         t1.record(cur)
         torch.cuda.synchronize()
         return t0.elapsed_time(t1)
+
+    def together(a, b):
+        # two trials; a pair counts as concurrent only if it is in both (a hiccup can make a concurrent pair look serial, never the reverse)
+        for _ in range(2):
+            serial = timed([a, a])
+            if not timed([a, b]) < 0.75 * serial:
+                return False
+        return True
     pool = [torch.cuda.Stream() for _ in range(candidates)]
     if not hasattr(torch.cuda, "_sleep"):                           # no spin kernel to observe with: take the streams as they come
         return pool[:count]
-    with torch.cuda.stream(pool[0]):
+    for _ in range(40):                                             # ~40 ms of work: the clocks are up before anything is compared
         torch.cuda._sleep(spin_cycles)
     torch.cuda.synchronize()
-    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    with torch.cuda.stream(pool[0]):
-        t0.record(); torch.cuda._sleep(spin_cycles); t1.record()
-    torch.cuda.synchronize()
-    alone = t0.elapsed_time(t1)
     fixed = [] if beside is None else (list(beside) if isinstance(beside, (list, tuple)) else [beside])
     chosen = []
     for s in pool:
         if len(chosen) == count:
             break
-        if all(together(c, s) < 1.5 * alone for c in fixed + chosen):
+        if all(together(c, s) for c in fixed + chosen):
             chosen.append(s)
     if len(chosen) < count:                                         # fewer independent queues than asked for: the rest share
         chosen += [p for p in pool if p not in chosen][:count - len(chosen)]
