@@ -10,6 +10,9 @@ one neighbour search per geometry (the K = 16 table derived from the K = 36 sear
 replayed) and the CBL branch on a side stream beside the gather / KPConv branch; `run_once` is the plain in-order step with every
 search on its own — the tests hold the two against each other.
 """
+import os
+import sys
+
 import torch
 
 from . import heads, local_aggregation, pointops
@@ -389,19 +392,30 @@ def concurrent_streams(count, candidates=12, spin_cycles=2_000_000, beside=None)
         torch.cuda.synchronize()
         return t0.elapsed_time(t1)
 
+    debug = os.environ.get("CBL_STREAM_PROBE_DEBUG")
+
     def together(a, b):
-        # two trials; a pair counts as concurrent only if it is in both (a hiccup can make a concurrent pair look serial, never the reverse)
+        # two trials, each bracketed by the serial reference on both sides (clocks still rising make the LATER measurement the faster one: the pair
+        # is compared with the faster of the two references); a pair counts as concurrent only if it is in both trials
         for _ in range(2):
-            serial = timed([a, a])
-            if not timed([a, b]) < 0.75 * serial:
+            s0 = timed([a, a]); pair = timed([a, b]); s1 = timed([a, a])
+            if debug:
+                print("probe: serial %.3f pair %.3f serial %.3f ms -> %s" % (s0, pair, s1, pair < 0.75 * min(s0, s1)), file=sys.stderr)
+            if not pair < 0.75 * min(s0, s1):
                 return False
         return True
     pool = [torch.cuda.Stream() for _ in range(candidates)]
     if not hasattr(torch.cuda, "_sleep"):                           # no spin kernel to observe with: take the streams as they come
         return pool[:count]
-    for _ in range(40):                                             # ~40 ms of work: the clocks are up before anything is compared
-        torch.cuda._sleep(spin_cycles)
-    torch.cuda.synchronize()
+    # keep the device busy until two consecutive measurements of the same kernel agree (the clocks are up), at most ~0.5 s
+    last = None
+    for _ in range(60):
+        for _ in range(8):
+            torch.cuda._sleep(spin_cycles)
+        t = timed([pool[0]])
+        if last is not None and abs(t - last) < 0.02 * last:
+            break
+        last = t
     fixed = [] if beside is None else (list(beside) if isinstance(beside, (list, tuple)) else [beside])
     chosen = []
     for s in pool:
