@@ -238,6 +238,130 @@ __global__ __launch_bounds__(256) void row_linear_wgrad_mfma_kernel(long long ro
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------------
+// Widths between the multiples of 16: the TransitionDown layers' Linear(3 + C, C') over the grouped (m * nsample) rows (pytorch/model/blocks.py:62-76; 35 -> 64 at
+// the first down-sampling: 163 840 rows per 40960-point scene).  The streaming kernel above spends one lane per OUTPUT element with c_in scalar loads and LDS
+// reads each: 100 us forward, 60 us input gradient, 80 us weight gradient per scene (`skinny_linear_kernel<false, false>` and friends in the network's profile).
+// The same MFMA walks as above over operands padded with zeros IN REGISTERS: the ragged side (k < kvalid of the input rows, n < nvalid of the output rows)
+// is read and written with the true row strides, 4 bytes at a time (rows of 35 floats are not 16-byte aligned).
+template <int KD, int ND, bool WT>
+__global__ __launch_bounds__(256) void row_linear_ragged_mfma_kernel(long long rows, int kvalid, int nvalid, int w_ld, const float* __restrict__ in, const float* __restrict__ W,
+                                                                     const float* __restrict__ bias, float* __restrict__ out)
+{
+    constexpr int KC = KD / 4, NT = ND / 16;
+    const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
+    float bw[NT][KC];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int s2 = 0; s2 < KC; s2++) {
+            const int k = KC * kq + s2, n = 16 * t + row;
+            const bool ok = k < kvalid && n < nvalid;
+            const int kc = min(k, kvalid - 1), nc = min(n, nvalid - 1);
+            const float v = WT ? W[(size_t)kc * w_ld + nc] : W[(size_t)nc * w_ld + kc];
+            bw[t][s2] = ok ? v : 0.f;
+        }
+    float bv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) bv[t] = (bias && 16 * t + row < nvalid) ? bias[16 * t + row] : 0.f;
+    const long long ntiles = (rows + 15) / 16;
+    const long long stride = (long long)gridDim.x * 4;
+    long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    float a[KC];
+    const bool vec = kvalid == KD && ((reinterpret_cast<uintptr_t>(in) & 15u) == 0);   // the input side is whole (the input gradient: grad_y rows): 16-byte loads
+    auto load = [&](long long tl) {
+        const long long r = min(tl * 16 + row, rows - 1);
+        const float* src = in + r * kvalid;
+        if (vec) {
+            const float4* s4 = reinterpret_cast<const float4*>(src + KC * kq);
+#pragma unroll
+            for (int v = 0; v < KC / 4; v++) { const float4 t = s4[v]; a[4 * v] = t.x; a[4 * v + 1] = t.y; a[4 * v + 2] = t.z; a[4 * v + 3] = t.w; }
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < KC; j++) {
+            const int k = KC * kq + j;
+            const float v = src[min(k, kvalid - 1)];                 // clamped, unconditional: all KC loads in flight together
+            a[j] = k < kvalid ? v : 0.f;
+        }
+    };
+    if (tile < ntiles) load(tile);
+    for (; tile < ntiles; tile += stride) {
+        float av[KC];
+#pragma unroll
+        for (int j = 0; j < KC; j++) av[j] = a[j];
+        if (tile + stride < ntiles) load(tile + stride);
+        rl_f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = rl_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < KC; s2++)
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bw[t][s2], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const long long orow = tile * 16 + 4 * kq + r;
+            if (orow < rows) {
+#pragma unroll
+                for (int t = 0; t < NT; t++) if (16 * t + row < nvalid) out[orow * nvalid + 16 * t + row] = acc[t][r] + bv[t];
+            }
+        }
+    }
+}
+
+// weight / bias gradient with a ragged c_in: x rows of `cin` floats (CINP = cin rounded up to 16), partial rows of the true cin * COUT + COUT floats
+template <int CINP, int COUT>
+__global__ __launch_bounds__(256) void row_linear_wgrad_ragged_mfma_kernel(long long rows, int cin, const float* __restrict__ x, const float* __restrict__ gy,
+                                                                           float* __restrict__ partial, int want_bias)
+{
+    constexpr int MT = COUT / 16, NTI = CINP / 16;
+    __shared__ float red[4][COUT * CINP + COUT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, kq = lane >> 4;
+    rl_f32x4 acc[MT][NTI];
+#pragma unroll
+    for (int tm = 0; tm < MT; tm++)
+#pragma unroll
+        for (int tn = 0; tn < NTI; tn++) acc[tm][tn] = rl_f32x4{0.f, 0.f, 0.f, 0.f};
+    float sb[MT];
+#pragma unroll
+    for (int tm = 0; tm < MT; tm++) sb[tm] = 0.f;
+    const long long nsteps = (rows + 3) / 4;
+    const long long gw = (long long)gridDim.x * 4;
+    for (long long st = (long long)blockIdx.x * 4 + wave; st < nsteps; st += gw) {
+        const long long r = st * 4 + kq;
+        const bool ok = r < rows;
+        const long long rc = ok ? r : rows - 1;
+        float a[MT], b[NTI];
+#pragma unroll
+        for (int tm = 0; tm < MT; tm++) { a[tm] = gy[rc * COUT + 16 * tm + col]; a[tm] = ok ? a[tm] : 0.f; sb[tm] += a[tm]; }
+#pragma unroll
+        for (int tn = 0; tn < NTI; tn++) { const int n = 16 * tn + col; const float v = x[rc * cin + min(n, cin - 1)]; b[tn] = n < cin ? v : 0.f; }
+#pragma unroll
+        for (int tm = 0; tm < MT; tm++)
+#pragma unroll
+            for (int tn = 0; tn < NTI; tn++) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+    }
+#pragma unroll
+    for (int tm = 0; tm < MT; tm++)
+#pragma unroll
+        for (int tn = 0; tn < NTI; tn++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) red[wave][(16 * tm + 4 * kq + r) * CINP + 16 * tn + col] = acc[tm][tn][r];
+#pragma unroll
+    for (int tm = 0; tm < MT; tm++) {
+        float v = sb[tm];
+        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        if (kq == 0) red[wave][COUT * CINP + 16 * tm + col] = v;
+    }
+    __syncthreads();
+    float* mine = partial + (size_t)blockIdx.x * ((size_t)COUT * cin + COUT);
+    for (int e = threadIdx.x; e < COUT * CINP + COUT; e += 256) {
+        const float sum = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        if (e < COUT * CINP) { const int m = e / CINP, n = e - m * CINP; if (n < cin) mine[(size_t)m * cin + n] = sum; }
+        else if (want_bias) mine[(size_t)COUT * cin + (e - COUT * CINP)] = sum;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
 // The three projections of PointTransformerLayer (blocks.py:33: x_q, x_k, x_v = linear_q(x), linear_k(x), linear_v(x); C = 32 / 64) as ONE launch
 // per direction: forward with blockIdx.y = the projection; input gradient d x = d x_q Wq + d x_k Wk + d x_v Wv accumulated in the MFMA accumulators
 // of one pass over the three gradient tensors (weights in LDS: 3 C^2 operands do not fit the registers), weight / bias gradients with
@@ -423,6 +547,33 @@ __global__ __launch_bounds__(1024) void triple_linear_wgrad_finalize_kernel(int 
 constexpr int TL_WGRAD_BLOCKS = 256;
 
 inline bool rl_mfma_ok(int cin, int cout) { return cin % 16 == 0 && cout % 16 == 0 && cin <= 64 && cout <= 64 && cin >= 16 && cout >= 16; }
+// a ragged c_in between 17 and 63 beside a c_out the matrix tiles cover: the padded-in-registers kernels
+inline bool rl_ragged_ok(int cin, int cout) { return cin > 16 && cin < 64 && cin % 16 != 0 && cout % 16 == 0 && cout >= 16 && cout <= 64; }
+inline int rl_up16(int v) { return (v + 15) & ~15; }
+
+// WT = false: forward (in = x, kvalid = cin, out stride nvalid = cout);  WT = true: input gradient (in = grad_y, kvalid = cout, nvalid = cin)
+template <bool WT>
+int rl_ragged_launch(long long rows, int kvalid, int nvalid, int w_ld, const float* in, const float* W, const float* bias, float* out, hipStream_t st)
+{
+    const int kd = rl_up16(kvalid), nd = rl_up16(nvalid);
+    const long long tiles = (rows + 15) / 16;
+    const dim3 grid((unsigned)min((tiles + 3) / 4, (long long)2048)), blk(256);
+#define CBL_RLR(KD_, ND_) if (kd == KD_ && nd == ND_) { hipLaunchKernelGGL((row_linear_ragged_mfma_kernel<KD_, ND_, WT>), grid, blk, 0, st, rows, kvalid, nvalid, w_ld, in, W, bias, out); return cbl_status(); }
+    CBL_RLR(16, 32) CBL_RLR(16, 48) CBL_RLR(16, 64) CBL_RLR(32, 16) CBL_RLR(32, 32) CBL_RLR(32, 48) CBL_RLR(32, 64)
+    CBL_RLR(48, 16) CBL_RLR(48, 32) CBL_RLR(48, 48) CBL_RLR(48, 64) CBL_RLR(64, 16) CBL_RLR(64, 32) CBL_RLR(64, 48) CBL_RLR(64, 64)
+#undef CBL_RLR
+    return CBL_ERR_UNSUPPORTED;
+}
+
+int rl_wgrad_ragged_launch(long long rows, int cin, int cout, const float* x, const float* gy, float* partial, int want_bias, int nblocks, hipStream_t st)
+{
+    const int cp = rl_up16(cin);
+#define CBL_RLWR(CI_, CO_) if (cp == CI_ && cout == CO_) { hipLaunchKernelGGL((row_linear_wgrad_ragged_mfma_kernel<CI_, CO_>), dim3(nblocks), dim3(256), 0, st, rows, cin, x, gy, partial, want_bias); return cbl_status(); }
+    CBL_RLWR(32, 16) CBL_RLWR(32, 32) CBL_RLWR(32, 48) CBL_RLWR(32, 64) CBL_RLWR(48, 16) CBL_RLWR(48, 32) CBL_RLWR(48, 48) CBL_RLWR(48, 64)
+    CBL_RLWR(64, 16) CBL_RLWR(64, 32) CBL_RLWR(64, 48) CBL_RLWR(64, 64)
+#undef CBL_RLWR
+    return CBL_ERR_UNSUPPORTED;
+}
 
 template <bool WT>
 int rl_launch(long long rows, int kd, int nd, const float* in, const float* W, const float* bias, float* out, hipStream_t st)
@@ -461,6 +612,7 @@ CBL_EXPORT int cbl_skinny_linear_forward(long long rows, int cin, int cout, cons
     if (rows == 0) return CBL_OK;
     if (!x || !weight || !y) return CBL_ERR_BAD_ARG;
     if (rl_mfma_ok(cin, cout) && cbl_host_aligned16(x)) return rl_launch<false>(rows, cin, cout, x, weight, bias, y, cbl_stream(stream));
+    if (rl_ragged_ok(cin, cout)) return rl_ragged_launch<false>(rows, cin, cout, cin, x, weight, bias, y, cbl_stream(stream));
     const dim3 grid(cbl_grid_for(rows * cout, SL_BLOCK, 2048));
     const size_t lds = sizeof(float) * (size_t)cout * (cin + 1);
     if (cin % 4 == 0 && cbl_host_aligned16(x))
@@ -477,6 +629,7 @@ CBL_EXPORT int cbl_skinny_linear_backward_input(long long rows, int cin, int cou
     if (rows == 0) return CBL_OK;
     if (!grad_y || !weight || !grad_x) return CBL_ERR_BAD_ARG;
     if (rl_mfma_ok(cin, cout) && cbl_host_aligned16(grad_y)) return rl_launch<true>(rows, cout, cin, grad_y, weight, nullptr, grad_x, cbl_stream(stream));
+    if (rl_ragged_ok(cin, cout)) return rl_ragged_launch<true>(rows, cout, cin, cin, grad_y, weight, nullptr, grad_x, cbl_stream(stream));
     // dx = dy @ W: the same kernel with the roles of c_in / c_out swapped and W read transposed
     const dim3 grid(cbl_grid_for(rows * cin, SL_BLOCK, 2048));
     const size_t lds = sizeof(float) * (size_t)cin * (cout + 1);
@@ -513,6 +666,14 @@ CBL_EXPORT int cbl_skinny_linear_backward_weight(long long rows, int cin, int co
     if (rl_mfma_ok(cin, cout)) {
         const int nb = (int)min((rows + 63) / 64, (long long)SL_WGRAD_BLOCKS);
         const int rc2 = rl_wgrad_launch(rows, cin, cout, x, grad_y, partial, grad_bias ? 1 : 0, nb, st);
+        if (rc2) return rc2;
+        hipLaunchKernelGGL(skinny_linear_wgrad_finalize_kernel, dim3(cbl_div_up(cin * cout + cout, 16)), dim3(256), 0, st, cin * cout, cout, nb, partial,
+                           grad_weight, grad_bias);
+        return cbl_status();
+    }
+    if (rl_ragged_ok(cin, cout)) {
+        const int nb = (int)min((rows + 63) / 64, (long long)SL_WGRAD_BLOCKS);
+        const int rc2 = rl_wgrad_ragged_launch(rows, cin, cout, x, grad_y, partial, grad_bias ? 1 : 0, nb, st);
         if (rc2) return rc2;
         hipLaunchKernelGGL(skinny_linear_wgrad_finalize_kernel, dim3(cbl_div_up(cin * cout + cout, 16)), dim3(256), 0, st, cin * cout, cout, nb, partial,
                            grad_weight, grad_bias);

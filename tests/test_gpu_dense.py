@@ -11,7 +11,9 @@ pytestmark = pytest.mark.gpu
                                                 (40960, 128, 16, True), (327680, 3, 32, True), (327680, 32, 4, False), (20001, 7, 5, True),
                                                 (9000, 64, 64, True),
                                                 # widths that are multiples of 16 (<= 64) run on the matrix cores: q / k / v of the two full-resolution stages
-                                                (40960, 64, 64, True), (40961, 32, 32, True), (10243, 16, 48, False), (8200, 48, 16, True), (9999, 64, 32, True)])
+                                                (40960, 64, 64, True), (40961, 32, 32, True), (10243, 16, 48, False), (8200, 48, 16, True), (9999, 64, 32, True),
+                                                # ragged c_in beside a tiled c_out (TransitionDown: Linear(3 + C, C')): operands padded in registers
+                                                (163840, 35, 64, False), (40963, 35, 64, True), (9001, 19, 32, True), (12345, 50, 16, False), (8193, 63, 48, True)])
 def test_skinny_linear_matches_torch(rows, cin, cout, bias):
     from contrastboundary_amd import dense
     torch.manual_seed(rows % 97 + cin)
