@@ -52,11 +52,50 @@ class _SkinnyLinear(Function):
         return gx, gw, gb
 
 
+TALL_ROWS = 16384        # a library GEMM's weight gradient over at least this many rows is cut into chunks (below)
+
+
+class _TallLinear(Function):
+    """F.linear for inputs with MANY rows and widths a GEMM library tiles (the TransitionDown layers' Linear(3 + C, C') over m * nsample grouped rows, the blocks'
+    Linear layers of a multi-scene batch): forward and input gradient are the library's; the WEIGHT gradient grad_y^T x — a (c_out x c_in) result contracted
+    over all rows — is computed as a batch of S partial products over row chunks and summed.  The library's heuristic answers the unsplit problem with one or
+    two workgroups walking the whole contraction (measured: (128 x 327 680) . (327 680 x 67) in 1.95 ms, two such calls and one of 2.2 ms = 15 % of an 8-scene
+    training step); the batched form puts S x tiles workgroups on it."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        rows, cin = x.shape
+        cout = weight.shape[0]
+        gy = gy.contiguous()
+        gx = gy @ weight if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1]:
+            S = max(1, min(256, rows // 1024))
+            L = rows // S
+            main = S * L
+            gw = torch.bmm(gy[:main].view(S, L, cout).transpose(1, 2), x[:main].view(S, L, cin)).sum(0)
+            if main < rows:
+                gw = gw + gy[main:].t() @ x[main:]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum(0)
+        return gx, gw, gb
+
+
 def linear(x, weight, bias=None):
     """x (..., c_in) -> (..., c_out), same values as F.linear up to fp32 summation order"""
     cin, cout = weight.shape[1], weight.shape[0]
     rows = x.numel() // max(cin, 1)
     if not (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and _fits(rows, cin, cout)):
+        if x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and rows >= TALL_ROWS and torch.is_grad_enabled() and weight.requires_grad:
+            y = _TallLinear.apply(x.reshape(rows, cin).contiguous(), weight, bias)
+            return y.view(*x.shape[:-1], cout)
         return F.linear(x, weight, bias)
     y = _SkinnyLinear.apply(x.reshape(rows, cin).contiguous(), weight.contiguous(), None if bias is None else bias.contiguous())
     return y.view(*x.shape[:-1], cout)

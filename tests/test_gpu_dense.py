@@ -36,6 +36,30 @@ def test_skinny_linear_matches_torch(rows, cin, cout, bias):
         assert close(b.grad, b64.grad, 2e-5)
 
 
+@pytest.mark.parametrize("shape,cin,cout,bias", [((2560, 16), 67, 128, False), ((20000,), 131, 256, True), ((16384,), 128, 128, False), ((40961,), 259, 512, True)])
+def test_tall_linear_splits_its_weight_gradient(shape, cin, cout, bias):
+    """dense.linear outside the streaming kernels' range with many rows (dense._TallLinear: the library's forward and input gradient, the weight gradient as a
+    batched product over row chunks) against F.linear in float64"""
+    from contrastboundary_amd import dense
+    torch.manual_seed(cin)
+    x = torch.randn(*shape, cin, device="cuda", requires_grad=True)
+    w = (torch.randn(cout, cin, device="cuda") / cin ** 0.5).requires_grad_(True)
+    b = torch.randn(cout, device="cuda", requires_grad=True) if bias else None
+    g = torch.randn(*shape, cout, device="cuda")
+    rows = x.numel() // cin
+    assert not dense._fits(rows, cin, cout) and rows >= dense.TALL_ROWS
+    y = dense.linear(x, w, b)
+    y.backward(g)
+    x64, w64 = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    b64 = b.detach().double().requires_grad_(True) if bias else None
+    r = torch.nn.functional.linear(x64, w64, b64)
+    r.backward(g.double())
+    close = lambda a, ref, tol: float((a.double() - ref).abs().max()) <= tol * max(float(ref.abs().max()), 1e-30)
+    assert close(y, r, 2e-5) and close(x.grad, x64.grad, 2e-5) and close(w.grad, w64.grad, 5e-5)
+    if bias:
+        assert close(b.grad, b64.grad, 5e-5)
+
+
 def test_linear_falls_back_to_torch_outside_its_range():
     from contrastboundary_amd import dense
     x = torch.randn(100, 64, device="cuda"); w = torch.randn(512, 64, device="cuda")
