@@ -107,7 +107,9 @@ class MultiHead(nn.Module):
         for (n, i), func in zip(self.ni_list, self.infer_list):
             stage_list[n][i][self.ftype] = func(stage_list[n][i], "f_out")         # :56-57
             collect_list.append(self.upsample(n, i, stage_list))
-        return self.cls(torch.cat(collect_list, 1)), stage_list
+        x = torch.cat(collect_list, 1)
+        # the classifier runs over EVERY point: through dense (streaming / split weight-gradient kernels), not the library's single-tile GEMM over 10^5 rows
+        return (dense.sequential(self.cls, x) if isinstance(self.cls, nn.Sequential) else dense.apply(self.cls, x)), stage_list
 
 
 class Loss(nn.Module):
@@ -191,7 +193,7 @@ class PointTransformerSeg(nn.Module):
         if self.head is not None:
             logits, stage_list = self.head(stage_list)
         else:
-            logits = self.cls(feats[0])
+            logits = dense.sequential(self.cls, feats[0])
         return logits, stage_list
 
 
