@@ -112,6 +112,51 @@ class MultiHead(nn.Module):
         return (dense.sequential(self.cls, x) if isinstance(self.cls, nn.Sequential) else dense.apply(self.cls, x)), stage_list
 
 
+class _CrossEntropy(torch.autograd.Function):
+    """nn.CrossEntropyLoss(ignore_index) over (n, k) logits as two launches forward and one backward (cbl_cross_entropy_*); the library's nll_loss reduction
+    is one workgroup over every point, each way"""
+
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        import ctypes
+        from . import _lib
+        from .neighbor_state import scratch
+        n, k = logits.shape
+        L = _lib.lib()
+        loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+        stats = torch.empty(2, dtype=torch.float32, device=logits.device)
+        ws = scratch(_xe_ws, "xe", L.cbl_cross_entropy_workspace_bytes(ctypes.c_longlong(n)), logits.device)
+        _lib.check(L.cbl_cross_entropy_forward(ctypes.c_longlong(n), ctypes.c_int(k), _lib.ptr(logits), _lib.ptr(target), ctypes.c_longlong(int(ignore_index)),
+                                               _lib.ptr(loss), _lib.ptr(stats), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(logits)), "cbl_cross_entropy_forward")
+        ctx.save_for_backward(logits, target, stats)
+        ctx.ignore_index = int(ignore_index)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes
+        from . import _lib
+        logits, target, stats = ctx.saved_tensors
+        n, k = logits.shape
+        grad = torch.empty_like(logits)
+        g = g.reshape(1).to(torch.float32).contiguous()
+        _lib.check(_lib.lib().cbl_cross_entropy_backward(ctypes.c_longlong(n), ctypes.c_int(k), _lib.ptr(logits), _lib.ptr(target), ctypes.c_longlong(ctx.ignore_index),
+                                                         _lib.ptr(stats), _lib.ptr(g), _lib.ptr(grad), _lib.stream_of(logits)), "cbl_cross_entropy_backward")
+        return grad, None, None
+
+
+_xe_ws = {}
+
+
+def cross_entropy(logits, target, ignore_index=-100):
+    """F.cross_entropy(logits, target, ignore_index=ignore_index) (mean over the points that count); the fused kernels for (n, k <= 64) float32 logits and int64
+    targets on the GPU, the library otherwise"""
+    if (logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2 and 1 <= logits.shape[1] <= 64 and target.dtype == torch.int64
+            and target.shape == logits.shape[:1] and target.device == logits.device):
+        return _CrossEntropy.apply(logits.contiguous(), target.contiguous(), ignore_index)
+    return nn.functional.cross_entropy(logits, target, ignore_index=ignore_index)
+
+
 class Loss(nn.Module):
     """pointtransformer_seg.py:15-25: cross entropy + the CBL losses, stacked (1 + stages,)"""
 
@@ -122,7 +167,7 @@ class Loss(nn.Module):
         self.xen = nn.CrossEntropyLoss(ignore_index=config.ignore_label)
 
     def forward(self, output, target, stage_list):
-        loss_list = [self.xen(output, target)]
+        loss_list = [cross_entropy(output, target, self.xen.ignore_index)]          # self.xen: the reference's module, kept for its attributes / state_dict shape
         if self.contrast_head is not None:
             loss_list += self.contrast_head(output, target, stage_list)
         return torch.stack(loss_list)

@@ -600,6 +600,17 @@ int cbl_bn_rows_backward_residual(long long rows, int C, const float* x, const f
                                   const float* save_mean, const float* save_invstd, int relu, float* grad_x, float* grad_residual, float* grad_weight,
                                   float* grad_bias, void* workspace, size_t workspace_bytes, void* stream);
 
+/* the criterion's cross entropy  pytorch/model/pointtransformer_seg.py:20-22 (nn.CrossEntropyLoss(ignore_index), reduction 'mean')
+ *   logits (n,k) f32, k <= 64; target (n) i64; points with target == ignore_index (or outside [0,k)) do not count.
+ *   forward: loss (1) = sum_i (logsumexp(logits[i]) - logits[i, target[i]]) / count; stats (2) = {sum, count}, kept for the backward call.
+ *   backward: grad_logits (n,k) = (softmax(logits[i]) - onehot(target[i])) * grad_loss[0] / count, 0 for points that do not count (written, not accumulated).
+ *   Deterministic (per-workgroup partial sums combined in fp64 in a fixed order).  workspace: cbl_cross_entropy_workspace_bytes. */
+size_t cbl_cross_entropy_workspace_bytes(long long n);
+int cbl_cross_entropy_forward(long long n, int k, const float* logits, const long long* target, long long ignore_index, float* loss, float* stats,
+                              void* workspace, size_t workspace_bytes, void* stream);
+int cbl_cross_entropy_backward(long long n, int k, const float* logits, const long long* target, long long ignore_index, const float* stats,
+                               const float* grad_loss, float* grad_logits, void* stream);
+
 /* ind_max_pool / ind_closest_pool  tensorflow/models/basic_operators.py:155-172 / :175-192
  *   x (n1,d), inds (n2,k) i32 (pad = n1) -> out (n2,d): max over the row's entries (shadow row = column-wise min of x; scratch_d (d) u32)
  *   / the entry of the FIRST column (shadow row = 0) */

@@ -204,3 +204,29 @@ def _graphed_vs_eager(natural):
     for (a_outs, *_), (b_outs, *_) in zip(static.cache.store.values(), fresh.store.values()):
         for a, b in zip(a_outs, b_outs):
             assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,k,ignored", [(40960, 13, 0.0), (163840, 13, 0.1), (1000, 2, 0.5), (777, 64, 0.0), (5000, 20, 1.0)])
+def test_cross_entropy_matches_torch_in_float64(n, k, ignored):
+    """pointtransformer_seg.cross_entropy (cbl_cross_entropy_*: the criterion's nn.CrossEntropyLoss(ignore_index), pointtransformer_seg.py:20-22) against
+    F.cross_entropy in float64: the loss, the gradient of the logits under an upstream factor, ignored points, the all-ignored batch (nan, like the library)"""
+    from contrastboundary_amd import pointtransformer_seg as M
+    torch.manual_seed(n + k)
+    z = (torch.randn(n, k, device="cuda") * 3).requires_grad_(True)
+    t = torch.randint(0, k, (n,), device="cuda")
+    if ignored > 0:
+        t[torch.rand(n, device="cuda") < ignored] = 255
+    loss = M.cross_entropy(z, t, 255)
+    (loss * 1.7).backward()
+    z64 = z.detach().double().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(z64, t, ignore_index=255)
+    if ignored >= 1.0:
+        assert torch.isnan(loss) and torch.isnan(ref)
+        return
+    (ref * 1.7).backward()
+    assert abs(float(loss) - float(ref)) <= 2e-6 * abs(float(ref))
+    assert float((z.grad.double() - z64.grad).abs().max()) <= 1e-6 * float(z64.grad.abs().max())
+    assert torch.equal(z.grad[t == 255], torch.zeros_like(z.grad[t == 255]))
+    # twice the same bits (fixed-order fp64 combination of the partial sums)
+    assert torch.equal(M.cross_entropy(z.detach(), t, 255), loss.detach())
