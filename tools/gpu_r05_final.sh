@@ -56,12 +56,13 @@ model() { tag=$1; shift; timeout 300 python tools/bench_model.py "$@" 2> $O/mode
 model graph --graph --steps 10 --warmup 3
 model graph_d1 --graph --depth 1 --steps 10 --warmup 3
 model graph_4scenes --graph --scenes 4 --steps 6 --warmup 2
+model graph_8scenes --graph --scenes 8 --steps 4 --warmup 2
 model srg_flat --single-rank-group --graph --steps 10 --warmup 3
 model srg_flat_4scenes --single-rank-group --graph --scenes 4 --steps 6 --warmup 2
 model srg_hook --single-rank-group --graph --hook-reducer --steps 10 --warmup 3
 CBL_GEO_STREAMS=unprobed_first model srg_flat_unprobed_streams --single-rank-group --graph --steps 10 --warmup 3
 model eager_srg_flat --single-rank-group --steps 10 --warmup 3
-cat $O/model_graph.json $O/model_graph_d1.json $O/model_graph_4scenes.json $O/model_srg_flat.json $O/model_srg_flat_4scenes.json $O/model_srg_hook.json $O/model_srg_flat_unprobed_streams.json $O/model_eager_srg_flat.json > $O/bench_model.jsonl
+cat $O/model_graph.json $O/model_graph_d1.json $O/model_graph_4scenes.json $O/model_graph_8scenes.json $O/model_srg_flat.json $O/model_srg_flat_4scenes.json $O/model_srg_hook.json $O/model_srg_flat_unprobed_streams.json $O/model_eager_srg_flat.json > $O/bench_model.jsonl
 prof model python $GRAFT_REPO_ROOT/tools/bench_model.py --graph --steps 10 --warmup 3
 timeout 600 python tools/bench_stages.py > $O/stage_shapes.json 2> $O/stage_shapes.err; echo "stages rc=$?"
 bash tools/gpu_pmc_any.sh r05_radius "radius|grid_" python $GRAFT_REPO_ROOT/tools/radius_time.py > $O/pmc_radius.txt 2>&1; cp gpurun_out/pmc_r05_radius/pmc_mix.json $O/pmc_radius.json 2>/dev/null
