@@ -121,7 +121,11 @@ class PyramidLoader:
         self.scene = scene
         self.device = scene.points.device
         self.depth = max(1, int(depth))
-        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
+        # streams with hardware queues of their own beside the consumer's (hotpath.concurrent_streams: a fresh stream can share the queue of the stream the
+        # layers are issued on, and the pyramid then runs behind them instead of beside them)
+        from . import hotpath
+        with torch.cuda.device(self.device):
+            self.streams = hotpath.concurrent_streams(self.depth, beside=[torch.cuda.current_stream(self.device)])
         self.pool = ThreadPoolExecutor(max_workers=self.depth)
         self.pending = []                                            # futures, oldest first
         self.turn = 0
