@@ -18,9 +18,15 @@ _side_streams = {}
 
 
 def side_stream(device):
+    """the device's geometry stream: one that really runs beside the caller's (hotpath.concurrent_streams observes which fresh streams share a hardware queue
+    with it; during a graph capture nothing can be observed and a plain stream is taken)"""
     s = _side_streams.get(device)
     if s is None:
-        s = _side_streams[device] = torch.cuda.Stream(device=device)
+        if torch.cuda.is_current_stream_capturing():
+            return torch.cuda.Stream(device=device)
+        from . import hotpath
+        with torch.cuda.device(device):
+            s = _side_streams[device] = hotpath.concurrent_streams(1, beside=[torch.cuda.current_stream(device)])[0]
     return s
 
 
