@@ -11,8 +11,8 @@
 // Widths outside 16 / 32 / 48 / 64: fp32 FMA chains in index order.  Widths 16 / 32 / 48 / 64 (row_linear_mfma_kernel, row_linear_wgrad_mfma_kernel, the
 // triple_linear kernels): v_mfma_f32_16x16x4_f32 chains — the contraction index is walked four at a time in the MFMA's own order (a row's quarters per
 // lane), the weight gradient sums the rows four per step and the waves' partial tiles through LDS in wave order.  Either way the results differ from a GEMM
-// library's by summation order only (tests: 1e-4 of the largest element).  row_linear_wgrad_mfma_kernel<64,64> keeps 4 x (4096 + 64) floats = 65 KB of LDS
-// (gfx950: 160 KB per CU, two workgroups per CU; the kernel is for this architecture only).
+// library's by summation order only (tests: 1e-4 of the largest element).  row_linear_wgrad_mfma_kernel<64,64> keeps 2 x (4096 + 64) floats = 33 KB of LDS
+// (the four waves' tiles are combined two at a time).
 #include "cbl_common.h"
 #include <stdlib.h>
 
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void row_linear_wgrad_mfma_kernel(long long ro
                                                                     int want_bias)
 {
     constexpr int MT = COUT / 16, NTI = CIN / 16;
-    __shared__ float red[4][COUT * CIN + COUT];
+    __shared__ float red[2][COUT * CIN + COUT];                     // two waves' tiles at a time (waves 2, 3 first, then 0 + 2 and 1 + 3): 33 KB at 64 x 64, not 66
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, kq = lane >> 4;
     rl_f32x4 acc[MT][NTI];
 #pragma unroll
@@ -217,22 +217,35 @@ __global__ __launch_bounds__(256) void row_linear_wgrad_mfma_kernel(long long ro
             for (int tn = 0; tn < NTI; tn++) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
     }
     // D[m = 4 (lane / 16) + r][n = lane % 16] of tile (tm, tn) = grad_weight[16 tm + m][16 tn + n]
+    float bsum[MT];
 #pragma unroll
-    for (int tm = 0; tm < MT; tm++)
+    for (int tm = 0; tm < MT; tm++) { float v = sb[tm]; v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); bsum[tm] = v; }
+    float* slot = red[wave & 1];
+    if (wave >= 2) {
 #pragma unroll
-        for (int tn = 0; tn < NTI; tn++)
+        for (int tm = 0; tm < MT; tm++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) red[wave][(16 * tm + 4 * kq + r) * CIN + 16 * tn + col] = acc[tm][tn][r];
+            for (int tn = 0; tn < NTI; tn++)
 #pragma unroll
-    for (int tm = 0; tm < MT; tm++) {
-        float v = sb[tm];
-        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-        if (kq == 0) red[wave][COUT * CIN + 16 * tm + col] = v;
+                for (int r = 0; r < 4; r++) slot[(16 * tm + 4 * kq + r) * CIN + 16 * tn + col] = acc[tm][tn][r];
+#pragma unroll
+        for (int tm = 0; tm < MT; tm++) if (kq == 0) slot[COUT * CIN + 16 * tm + col] = bsum[tm];
+    }
+    __syncthreads();
+    if (wave < 2) {                                                  // wave w adds wave w + 2's tile to its own, in place (each entry has one owner lane)
+#pragma unroll
+        for (int tm = 0; tm < MT; tm++)
+#pragma unroll
+            for (int tn = 0; tn < NTI; tn++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) { float& e = slot[(16 * tm + 4 * kq + r) * CIN + 16 * tn + col]; e = acc[tm][tn][r] + e; }
+#pragma unroll
+        for (int tm = 0; tm < MT; tm++) if (kq == 0) { float& e = slot[COUT * CIN + 16 * tm + col]; e = bsum[tm] + e; }
     }
     __syncthreads();
     float* mine = partial + (size_t)blockIdx.x * (COUT * CIN + COUT);
     for (int e = threadIdx.x; e < COUT * CIN + COUT; e += 256) {
-        const float sum = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        const float sum = red[0][e] + red[1][e];
         if (e < COUT * CIN || want_bias) mine[e] = sum;
     }
 }
@@ -314,7 +327,7 @@ __global__ __launch_bounds__(256) void row_linear_wgrad_ragged_mfma_kernel(long 
                                                                            float* __restrict__ partial, int want_bias)
 {
     constexpr int MT = COUT / 16, NTI = CINP / 16;
-    __shared__ float red[4][COUT * CINP + COUT];
+    __shared__ float red[2][COUT * CINP + COUT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, kq = lane >> 4;
     rl_f32x4 acc[MT][NTI];
 #pragma unroll
@@ -340,22 +353,35 @@ __global__ __launch_bounds__(256) void row_linear_wgrad_ragged_mfma_kernel(long 
 #pragma unroll
             for (int tn = 0; tn < NTI; tn++) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
     }
+    float bsum[MT];
 #pragma unroll
-    for (int tm = 0; tm < MT; tm++)
+    for (int tm = 0; tm < MT; tm++) { float v = sb[tm]; v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); bsum[tm] = v; }
+    float* slot = red[wave & 1];
+    if (wave >= 2) {
 #pragma unroll
-        for (int tn = 0; tn < NTI; tn++)
+        for (int tm = 0; tm < MT; tm++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) red[wave][(16 * tm + 4 * kq + r) * CINP + 16 * tn + col] = acc[tm][tn][r];
+            for (int tn = 0; tn < NTI; tn++)
 #pragma unroll
-    for (int tm = 0; tm < MT; tm++) {
-        float v = sb[tm];
-        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-        if (kq == 0) red[wave][COUT * CINP + 16 * tm + col] = v;
+                for (int r = 0; r < 4; r++) slot[(16 * tm + 4 * kq + r) * CINP + 16 * tn + col] = acc[tm][tn][r];
+#pragma unroll
+        for (int tm = 0; tm < MT; tm++) if (kq == 0) slot[COUT * CINP + 16 * tm + col] = bsum[tm];
+    }
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+        for (int tm = 0; tm < MT; tm++)
+#pragma unroll
+            for (int tn = 0; tn < NTI; tn++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) { float& e = slot[(16 * tm + 4 * kq + r) * CINP + 16 * tn + col]; e = acc[tm][tn][r] + e; }
+#pragma unroll
+        for (int tm = 0; tm < MT; tm++) if (kq == 0) { float& e = slot[COUT * CINP + 16 * tm + col]; e = bsum[tm] + e; }
     }
     __syncthreads();
     float* mine = partial + (size_t)blockIdx.x * ((size_t)COUT * cin + COUT);
     for (int e = threadIdx.x; e < COUT * CINP + COUT; e += 256) {
-        const float sum = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        const float sum = red[0][e] + red[1][e];
         if (e < COUT * CINP) { const int m = e / CINP, n = e - m * CINP; if (n < cin) mine[(size_t)m * cin + n] = sum; }
         else if (want_bias) mine[(size_t)COUT * cin + (e - COUT * CINP)] = sum;
     }
