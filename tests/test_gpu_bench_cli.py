@@ -33,6 +33,14 @@ def test_bench_json_contract_and_rccl_allreduce_leg():
     rf = out["roofline"]
     assert rf["bound"] == "hbm" and 0.3 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert "backward" in out["config"]["workload"] and "forward_only" in out
+    # the headline is the median of three timed regions, and the pipeline was held against one step at a time before it was timed (and overlaps)
+    regions = out["timed_regions_ms_per_step"]
+    assert len(regions) == 3 and abs(sorted(regions)[1] - out["ms_per_step"]) < 1e-3 * out["ms_per_step"]
+    pc = out["pipeline_check"]
+    assert pc["rebuilt"] in (0, 1, 2) and pc["pipelined_ms"] < 0.92 * pc["one_at_a_time_ms"], pc
+    assert out["ms_per_step"] < 0.9 * out["no_pipeline"]["ms_per_step"]
+    sr = rf["search"]
+    assert sr["pairs_visited"] > 36 * 40960 and 0 < sr["pairs_vs_brute_force"] < 0.05
     ar = out["grad_allreduce"]                                        # one flat fp32 buffer of the network's 7,800,497 gradients per step over RCCL
     assert ar["bytes"] == 4 * 7800497 and ar["ranks"] == 1 and ar["ms_per_step"] > 0 and ar["allreduce_alone_ms"] > 0
     # the default line carries BASELINE's other single-GPU configurations as legs (each measured in a process of its own)
