@@ -920,7 +920,9 @@ __global__ __launch_bounds__(C) void attn_agg_backward_wide_kernel(int n, int K,
 }
 
 // partial rows per pass: one per workgroup; enough workgroups to fill 256 CUs, few enough that the (2C + GC + G)-float rows stay ~30 MB
-constexpr int at_wide_blocks(int C) { return C <= 128 ? 1024 : (C <= 256 ? 768 : 256); }
+// (C = 128: 2048 since round 5 — with several scenes per step the stage has 10^4 points and more, and the passes are latency chains per point: twice the workgroups
+//  in flight took the layer from 1400 to 1214 us at 20480 points, 729 to 654 at 10240; four times measured no better; one scene has 2560 points = 2560 workgroups either way)
+constexpr int at_wide_blocks(int C) { return C <= 128 ? 2048 : (C <= 256 ? 768 : 256); }
 
 int at_check(int n, int K, int C, int G)
 {
