@@ -28,16 +28,16 @@ constexpr int AT_MAX_BLOCKS = 1024;
 constexpr int AT_U = 4;                     // pairs whose loads are in flight together
 constexpr int AT_MAXG = 8;                  // C / share_planes with C <= 64
 
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dppf(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false)); }
 // sum over the C lanes of a group, result in every lane of the group (C = 32: two groups per wave)
+// (one v_add_f32_dpp per step: the move folds into the add with old = 0 + bound_ctrl; the lanes read afterwards receive the same terms in the same order as with
+//  row-masked moves — wave_ops.h group_sum)
+template <int CTRL> __device__ __forceinline__ float dpp_add0(float v) { return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); }
 template <int C> __device__ __forceinline__ float group_sum(float v)
 {
-    v += dppf<0xB1, 0xf>(v); v += dppf<0x4E, 0xf>(v); v += dppf<0x141, 0xf>(v); v += dppf<0x140, 0xf>(v);
-    const float r1 = v + dppf<0x142, 0xa>(v);
-    v = (threadIdx.x & 16) ? r1 : v;
+    v = dpp_add0<0xB1>(v); v = dpp_add0<0x4E>(v); v = dpp_add0<0x141>(v); v = dpp_add0<0x140>(v);
+    v = dpp_add0<0x142>(v);
     if (C == 32) return __shfl(v, 31, 32);
-    const float r2 = v + dppf<0x143, 0xc>(v);
-    v = (threadIdx.x & 32) ? r2 : v;
+    v = dpp_add0<0x143>(v);
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
@@ -452,10 +452,10 @@ __global__ __launch_bounds__(AT_BLOCK) void attn_agg_forward_kernel(int n, int K
 template <int G> __device__ __forceinline__ float low_lanes_sum(float v)
 {
     static_assert(G == 4 || G == 8 || G == 16, "group width");
-    v += dppf<0xB1, 0xf>(v);                                         // quad_perm [1,0,3,2]
-    v += dppf<0x4E, 0xf>(v);                                         // quad_perm [2,3,0,1]
-    if (G >= 8) v += dppf<0x141, 0xf>(v);                       // row_half_mirror
-    if (G >= 16) v += dppf<0x140, 0xf>(v);                      // row_mirror
+    v = dpp_add0<0xB1>(v);                                           // quad_perm [1,0,3,2]
+    v = dpp_add0<0x4E>(v);                                           // quad_perm [2,3,0,1]
+    if (G >= 8) v = dpp_add0<0x141>(v);                         // row_half_mirror
+    if (G >= 16) v = dpp_add0<0x140>(v);                        // row_mirror
     return v;
 }
 
