@@ -20,19 +20,19 @@ namespace {
 // sum over the LR lanes that share a row (LR consecutive lanes, LR | 16): every one of them ends up with the total
 template <int LR> __device__ __forceinline__ float row_lanes_sum(float v)
 {
-    if (LR >= 2) v += dpp_mov_f<0xB1, 0xf>(v);                      // quad_perm [1,0,3,2]
-    if (LR >= 4) v += dpp_mov_f<0x4E, 0xf>(v);                      // quad_perm [2,3,0,1]
-    if (LR >= 8) v += dpp_mov_f<0x141, 0xf>(v);                     // row_half_mirror
-    if (LR >= 16) v += dpp_mov_f<0x140, 0xf>(v);                    // row_mirror
+    if (LR >= 2) v = dpp_add0<0xB1>(v);                      // quad_perm [1,0,3,2]
+    if (LR >= 4) v = dpp_add0<0x4E>(v);                      // quad_perm [2,3,0,1]
+    if (LR >= 8) v = dpp_add0<0x141>(v);                     // row_half_mirror
+    if (LR >= 16) v = dpp_add0<0x140>(v);                    // row_mirror
     return v;
 }
 // sum over the PP = 64 / LR row slots (lanes with the same position inside their row)
 template <int LR> __device__ __forceinline__ float slots_sum(float v)
 {
-    if (LR <= 8) v += dpp_mov_f<0x128, 0xf>(v);                     // row_ror:8  (lane ^ 8 inside a row of 16)
-    if (LR <= 4) v += dpp_mov_f<0x124, 0xf>(v);                     // row_ror:4  (after ^8 every lane l holds l and l^8: rotate by 4 adds l^4, l^12)
-    if (LR <= 2) v += dpp_mov_f<0x122, 0xf>(v);
-    if (LR <= 1) v += dpp_mov_f<0x121, 0xf>(v);
+    if (LR <= 8) v = dpp_add0<0x128>(v);                     // row_ror:8  (lane ^ 8 inside a row of 16)
+    if (LR <= 4) v = dpp_add0<0x124>(v);                     // row_ror:4  (after ^8 every lane l holds l and l^8: rotate by 4 adds l^4, l^12)
+    if (LR <= 2) v = dpp_add0<0x122>(v);
+    if (LR <= 1) v = dpp_add0<0x121>(v);
     v += __shfl_xor(v, 16);
     v += __shfl_xor(v, 32);
     return v;
