@@ -266,13 +266,13 @@ def prefetch_geometry(model, inputs, criterion=None):
 
 
 class GraphedTrainStep:
-    """forward + criterion + backward + optimizer step captured once in a hipGraph and replayed per batch — the network is ~2700 kernel
-    launches per step, which bounds an eagerly issued step by the host.  depth + 1 buffer sets (inputs, geometry, graph) rotate: while one set
-    replays, the geometry of the next `depth` batches (furthest point sampling: one workgroup on one CU, ~1 us per sample whatever the cloud)
-    is refreshed into the other sets on `depth` side streams.  depth = 2 because one batch's geometry (17 ms per 40960-point scene, a serial
-    chain) takes as long as the step itself: with a single batch in flight the step waited for it (measured: 3 ms of kernel time removed from
-    the step changed nothing); two chains side by side deliver a batch every 8.5 ms.  All batches must have the first batch's shapes (fixed
-    points per scene, as the reference's voxel_max crop gives).
+    """forward + criterion + backward + optimizer step captured once in a hipGraph and replayed per batch — the network is ~1500 kernel
+    launches per step (round 5; ~2700 in round 2), which bounds an eagerly issued step by the host.  depth + 1 buffer sets (inputs, geometry, graph)
+    rotate: while one set replays, the geometry of the next `depth` batches (furthest point sampling: one workgroup on one CU, ~0.9 us per sample
+    whatever the cloud) is refreshed into the other sets on `depth` side streams.  depth = 2 because one batch's geometry (a serial chain: 11 ms per
+    40960-point scene in round 5, 17 ms when this was written) takes as long as the step itself (10.7 ms): with a single batch in flight the step
+    waits for it (round 5, `--depth 1`: 13.3 ms per step, 3.7 ms of it idle); two chains side by side deliver a batch every 5.5 ms.  All batches must
+    have the first batch's shapes (fixed points per scene, as the reference's voxel_max crop gives).
 
         step = GraphedTrainStep(model, criterion, optimizer, first_inputs, first_target)
         step.stage(batch0); step.stage(batch1)                  # `depth` batches ahead
