@@ -42,3 +42,24 @@ def test_flat_state_keeps_the_projections_adjacent():
     assert pt_layer._stacked(w).data_ptr() == w[0].data_ptr()
     assert torch.equal(pt_layer._stacked(b), torch.stack(b))
     assert all(torch.equal(v, before[k]) for k, v in net.state_dict().items())
+
+
+def test_state_dict_round_trip_keeps_the_layout_and_an_optimizer_step_is_seen_through_the_view():
+    torch.manual_seed(2)
+    a, b = blocks.PointTransformerLayer(128, 128, 8, 16), blocks.PointTransformerLayer(128, 128, 8, 16)
+    pt_layer.adjoin_qkv(a)
+    a.load_state_dict(b.state_dict())                                           # copies in place: the three weights stay back to back
+    w = _triples(a)[0]
+    st = pt_layer._stacked(w)
+    assert st.data_ptr() == w[0].data_ptr() and torch.equal(st, torch.stack([b.linear_q.weight, b.linear_k.weight, b.linear_v.weight]))
+    opt = torch.optim.SGD(a.parameters(), lr=0.5, momentum=0.9)
+    for p in a.parameters():
+        p.grad = torch.ones_like(p)
+    opt.step()
+    st2 = pt_layer._stacked(_triples(a)[0])
+    assert st2.data_ptr() == a.linear_q.weight.data_ptr()
+    assert torch.allclose(st2, torch.stack([b.linear_q.weight, b.linear_k.weight, b.linear_v.weight]) - 0.5)
+    # a deep copy is a model of its own: its projections may or may not be adjacent, the stack is right either way
+    import copy
+    c = copy.deepcopy(a)
+    assert torch.equal(pt_layer._stacked(_triples(c)[0]), torch.stack(_triples(c)[0]))
