@@ -1,0 +1,77 @@
+// TEST INFRASTRUCTURE (not product code): the cross-lane builtins the sampling kernels (contrastboundary_amd/csrc/fps_bucket.hip, fps_wave.h) use directly,
+// emulated on the fibre waves of hip/hip_runtime.h — every call is a rendezvous of the wave's alive lanes.  Semantics follow the gfx9 ISA:
+//   update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl): lane l of an enabled row reads src of lane s(l); a lane without a source keeps `old`, or gets 0
+//   with bound_ctrl; lanes of rows the row_mask disables keep `old` (bank_mask is always 0xf in our kernels).  Controls: quad_perm (0x00..0xFF),
+//   row_ror:n (0x121..0x12F), row_mirror (0x140), row_half_mirror (0x141), row_bcast:15 (0x142), row_bcast:31 (0x143).
+#pragma once
+#include <hip/hip_runtime.h>
+
+static inline unsigned __float_as_uint(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+static inline unsigned __brev(unsigned v) { unsigned r = 0; for (int i = 0; i < 32; i++) r |= ((v >> i) & 1u) << (31 - i); return r; }
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+
+namespace emul {
+// one int per lane in, one int per lane out, computed from all lanes' inputs
+template <class F> inline int lanes_i(int v, int aux, F f)
+{
+    float pay[2] = {__int_as_float(v), __int_as_float(aux)}, r;
+    wave_collective(pay, 2, &r, 1, [&](Wave& w) {
+        int in[WAVE], ax[WAVE], out[WAVE];
+        for (int l = 0; l < WAVE; l++) { in[l] = __float_as_int(w.in[l][0]); ax[l] = __float_as_int(w.in[l][1]); }
+        f(in, ax, out, w.present);
+        for (int l = 0; l < WAVE; l++) w.out[l][0] = __int_as_float(out[l]);
+    });
+    return __float_as_int(r);
+}
+inline int dpp_source(int l, int ctrl)                              // -1: no source
+{
+    const int row = l & ~15, i = l & 15;
+    if (ctrl >= 0 && ctrl <= 0xFF) return (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);
+    if (ctrl >= 0x121 && ctrl <= 0x12F) return row | ((i - (ctrl & 15)) & 15);      // row_ror:n — lane i reads lane i - n (mod 16)
+    if (ctrl == 0x140) return row | (15 - i);
+    if (ctrl == 0x141) return (l & ~7) | (7 - (l & 7));
+    if (ctrl == 0x142) return (l >= 16) ? row - 1 : -1;                              // lane 15 of the row below
+    if (ctrl == 0x143) return (l >= 32) ? 31 : -1;
+    std::fprintf(stderr, "emul: DPP control 0x%x not emulated\n", ctrl); std::abort();
+}
+}  // namespace emul
+
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
+{
+    (void)bank_mask;
+    return emul::lanes_i(src, old, [&](const int* in, const int* ax, int* out, const bool* present) {
+        for (int l = 0; l < emul::WAVE; l++) {
+            if (!((row_mask >> (l >> 4)) & 1)) { out[l] = ax[l]; continue; }
+            const int s = emul::dpp_source(l, ctrl);
+            out[l] = (s >= 0 && present[s]) ? in[s] : (bound_ctrl ? 0 : ax[l]);
+        }
+    });
+}
+static inline int __builtin_amdgcn_readlane(int v, int lane)
+{
+    return emul::lanes_i(v, lane, [&](const int* in, const int* ax, int* out, const bool* present) {
+        for (int l = 0; l < emul::WAVE; l++) out[l] = present[l] ? in[ax[l] & 63] : 0;
+    });
+}
+static inline int __builtin_amdgcn_readfirstlane(int v)
+{
+    return emul::lanes_i(v, 0, [&](const int* in, const int*, int* out, const bool* present) {
+        int first = 0; while (first < emul::WAVE - 1 && !present[first]) first++;
+        for (int l = 0; l < emul::WAVE; l++) out[l] = in[first];
+    });
+}
+static inline unsigned long long __ballot(int pred)
+{
+    const int lo = emul::lanes_i(pred ? 1 : 0, 0, [&](const int* in, const int*, int* out, const bool* present) {
+        unsigned m = 0; for (int l = 0; l < 32; l++) if (present[l] && in[l]) m |= 1u << l;
+        for (int l = 0; l < emul::WAVE; l++) out[l] = (int)m;
+    });
+    const int hi = emul::lanes_i(pred ? 1 : 0, 0, [&](const int* in, const int*, int* out, const bool* present) {
+        unsigned m = 0; for (int l = 32; l < 64; l++) if (present[l] && in[l]) m |= 1u << (l - 32);
+        for (int l = 0; l < emul::WAVE; l++) out[l] = (int)m;
+    });
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
