@@ -75,3 +75,35 @@ static inline unsigned long long __ballot(int pred)
     });
     return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
 }
+
+// ---- wave shuffles (ds_bpermute-backed on the device): width = 64 or a power of two below it; lanes of a width-group exchange among themselves
+namespace emul {
+template <class T, class F> inline T lanes_any(T v, F src_of)
+{
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "4- or 8-byte values");
+    float pay[2] = {0.f, 0.f}, r[2];
+    std::memcpy(pay, &v, sizeof(T));
+    wave_collective(pay, 2, r, 2, [&](Wave& w) {
+        for (int l = 0; l < WAVE; l++) { const int s = src_of(l); const int t = (s >= 0 && s < WAVE && w.present[s]) ? s : l; w.out[l][0] = w.in[t][0]; w.out[l][1] = w.in[t][1]; }
+    });
+    T o; std::memcpy(&o, r, sizeof(T));
+    return o;
+}
+}  // namespace emul
+template <class T> static inline T __shfl_xor(T v, int mask, int width = 64) { (void)width; return emul::lanes_any(v, [&](int l) { return l ^ mask; }); }
+template <class T> static inline T __shfl(T v, int src, int width = 64)
+{
+    // every lane names its own source: the lane index travels with the value
+    float pay[3] = {0.f, 0.f, __int_as_float(src)}, r[2];
+    std::memcpy(pay, &v, sizeof(T));
+    emul::wave_collective(pay, 3, r, 2, [&](emul::Wave& w) {
+        for (int l = 0; l < emul::WAVE; l++) {
+            const int s = (l & ~(width - 1)) | (__float_as_int(w.in[l][2]) & (width - 1));
+            const int t = w.present[s] ? s : l;
+            w.out[l][0] = w.in[t][0]; w.out[l][1] = w.in[t][1];
+        }
+    });
+    T o; std::memcpy(&o, r, sizeof(T));
+    return o;
+}
+static inline float __builtin_amdgcn_rsqf(float x) { return 1.0f / std::sqrt(x); }
