@@ -107,3 +107,23 @@ template <class T> static inline T __shfl(T v, int src, int width = 64)
     return o;
 }
 static inline float __builtin_amdgcn_rsqf(float x) { return 1.0f / std::sqrt(x); }
+
+// ---- v_mfma_f32_16x16x4_f32 on a wave of fibres: D = A (16 x 4) . B (4 x 16) + C, operands and results in the instruction's own lane layout
+//   A[i][k] in lane i + 16 k (one float), B[k][j] in lane 16 k + j (one float), C / D[4 (lane / 16) + r][lane % 16] in element r of the lane's four
+typedef float emul_f32x4 __attribute__((vector_size(16)));
+static inline emul_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, emul_f32x4 c, int, int, int)
+{
+    const float pay[6] = {a, b, c[0], c[1], c[2], c[3]};
+    float d[4];
+    emul::wave_collective(pay, 6, d, 4, [](emul::Wave& w) {
+        for (int l = 0; l < 64; l++)
+            for (int v = 0; v < 4; v++) {
+                const int row = 4 * (l / 16) + v, col = l % 16;
+                float acc = w.in[l][2 + v];
+                for (int k = 0; k < 4; k++) acc = std::fmaf(w.in[row + 16 * k][0], w.in[16 * k + col][1], acc);
+                w.out[l][v] = acc;
+            }
+    });
+    return emul_f32x4{d[0], d[1], d[2], d[3]};
+}
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return hipSuccess; }
