@@ -44,6 +44,10 @@ def close(a, ref, tol):
 @pytest.mark.parametrize("rows,C,relu,residual", [(300, 8, 1, True), (4096, 4, 1, False), (100, 16, 0, True),           # one kernel per direction
                                                   (5000, 8, 1, True), (4500, 6, 1, True), (6000, 12, 0, False)])      # two passes; C = 6: one channel per lane
 def test_batch_norm_rows_with_residual(host, rows, C, relu, residual):
+    bn_case(host, rows, C, relu, residual)
+
+
+def bn_case(host, rows, C, relu, residual):
     rng = np.random.default_rng(rows + C)
     f = lambda *s: rng.normal(size=s).astype(np.float32)
     x, res, gy = f(rows, C) * 1.7 + 0.3, (f(rows, C) if residual else None), f(rows, C)
@@ -83,6 +87,10 @@ def test_batch_norm_rows_with_residual(host, rows, C, relu, residual):
 
 @pytest.mark.parametrize("n,k,ignored", [(3000, 13, 0.1), (257, 2, 0.5), (1000, 64, 0.0)])
 def test_cross_entropy(host, n, k, ignored):
+    xe_case(host, n, k, ignored)
+
+
+def xe_case(host, n, k, ignored):
     rng = np.random.default_rng(n + k)
     z = (rng.normal(size=(n, k)) * 3).astype(np.float32)
     t = rng.integers(0, k, n).astype(np.int64)
@@ -99,3 +107,32 @@ def test_cross_entropy(host, n, k, ignored):
     assert int(stats[1]) == int((t != 255).sum())
     assert close(g, z64.grad.numpy(), 2e-6)
     assert not g[t == 255].any()
+
+
+def test_kernels_under_address_sanitizer(tmp_path):
+    """the same host build with -fsanitize=address in a subprocess: operands are numpy buffers of exactly their logical sizes, `__shared__` arrays static arrays"""
+    import sys
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not asan or not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("no libasan beside gcc")
+    so = os.path.join(ROOT, "oracle", "_build", "libdense_host_asan.so")
+    deps = [SRC, os.path.join(CSRC, "bn_rows.hip"), os.path.join(CSRC, "cross_entropy.hip"), os.path.join(CSRC, "wave_ops.h"), os.path.join(CSRC, "cbl_common.h"),
+            os.path.join(EMUL, "amdgcn.h"), os.path.join(EMUL, "hip", "hip_runtime.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-x", "c++", "-std=c++17", "-O1", "-g", "-fsanitize=address", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas",
+                               "-I" + EMUL, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, SRC, "-o", so])
+    script = tmp_path / "run.py"
+    script.write_text(
+        "import ctypes, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import tests.test_dense_host as T\n"
+        "L = ctypes.CDLL(%r)\n"
+        "L.cbl_bn_rows_workspace_bytes.restype = ctypes.c_size_t; L.cbl_cross_entropy_workspace_bytes.restype = ctypes.c_size_t\n"
+        "for rows, C, relu, res in ((301, 8, 1, True), (4097, 4, 1, True), (4500, 6, 1, True)):\n"
+        "    T.bn_case(L, rows, C, relu, res)\n"
+        "T.xe_case(L, 1001, 13, 0.2)\n"
+        "print('ASAN_RUN_DONE')\n" % (ROOT, so))
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900, env=env)
+    assert "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+    assert r.returncode == 0 and "ASAN_RUN_DONE" in r.stdout, (r.returncode, r.stderr[-2000:])
