@@ -108,3 +108,38 @@ def test_certificate_counts_leading_unique_maxima(host):
             assert cur == int(idx[j])
         if kind == "lattice":
             assert k <= 2                                               # a lattice ties at once
+
+
+def test_sample_loop_under_address_sanitizer(tmp_path):
+    """the same host build with -fsanitize=address in a subprocess: the bucket reads (`sorted`, `rank`: clamped past the cloud's end), the slot array and the
+    64-at-a-time index stores of a ragged batch"""
+    import sys
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not asan or not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("no libasan beside gcc")
+    so = os.path.join(ROOT, "oracle", "_build", "libfps_bucket_host_asan.so")
+    deps = [SRC, os.path.join(CSRC, "fps_bucket.hip"), os.path.join(CSRC, "fps_wave.h"), os.path.join(CSRC, "cbl_common.h"), os.path.join(EMUL, "amdgcn.h"),
+            os.path.join(EMUL, "hip", "hip_runtime.h"), os.path.join(EMUL, "rocprim", "device", "device_radix_sort.hpp")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-x", "c++", "-std=c++17", "-O1", "-g", "-fsanitize=address", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas",
+                               "-I" + EMUL, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, SRC, "-o", so])
+    script = tmp_path / "run.py"
+    script.write_text(
+        "import ctypes, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "import tests.test_fps_bucket_host as T\n"
+        "from tests import oracle_lib as O\n"
+        "L = ctypes.CDLL(%r)\n"
+        "L.host_fps_bucket_workspace_bytes.restype = ctypes.c_size_t\n"
+        "sizes = [333, 65, 1]\n"
+        "xyz = np.concatenate([T.cloud('uniform', n, i) + 2.0 * i for i, n in enumerate(sizes)])\n"
+        "off, noff = np.cumsum(sizes), np.cumsum([111, 30, 1])\n"
+        "idx, tmp, certs, n_max = T.run(L, xyz, off, noff, cert=True)\n"
+        "ref, _ = O.furthestsampling(xyz, off, noff, n_max)\n"
+        "assert np.array_equal(idx, ref)\n"
+        "print('ASAN_RUN_DONE')\n" % (ROOT, so))
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900, env=env)
+    assert "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+    assert r.returncode == 0 and "ASAN_RUN_DONE" in r.stdout, (r.returncode, r.stderr[-2000:])
