@@ -55,7 +55,7 @@ struct Wave {
     float in[WAVE][8]; float out[WAVE][4]; bool present[WAVE];
 };
 struct Fiber {
-    ucontext_t ctx; dim3 tid; int lin = 0, wave = 0, lane = 0; bool done = false; char* stack = nullptr;
+    ucontext_t ctx; dim3 tid; int lin = 0, wave = 0, lane = 0; bool done = false; char* stack = nullptr; size_t stack_size = 0;
 };
 struct State {
     ucontext_t main_ctx;
@@ -118,10 +118,12 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body)
     State& s = S();
     const int nt = (int)(block.x * block.y * block.z);
     const int nw = (nt + WAVE - 1) / WAVE;
-    if ((int)s.fibers.size() < nt) {
-        const size_t old = s.fibers.size();
-        s.fibers.resize(nt);
-        for (size_t i = old; i < s.fibers.size(); i++) s.fibers[i].stack = (char*)std::malloc(s.stack_bytes);
+    // (the state is ONE per process even when several host builds are loaded — inline statics are unique symbols — so a fibre made by an earlier launch
+    //  may carry a smaller stack than this launch asks for: every fibre remembers its own size)
+    if ((int)s.fibers.size() < nt) s.fibers.resize(nt);
+    for (int i = 0; i < nt; i++) {
+        Fiber& f = s.fibers[i];
+        if (!f.stack || f.stack_size < s.stack_bytes) { std::free(f.stack); f.stack = (char*)std::malloc(s.stack_bytes); f.stack_size = s.stack_bytes; }
     }
     s.body = &body; s.block_dim = block; s.grid_dim = grid;
     for (unsigned bz = 0; bz < grid.z; bz++) for (unsigned by = 0; by < grid.y; by++) for (unsigned bx = 0; bx < grid.x; bx++) {
@@ -135,7 +137,7 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body)
             f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
             s.waves[f.wave].alive++;
             getcontext(&f.ctx);
-            f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = s.stack_bytes; f.ctx.uc_link = &s.main_ctx;
+            f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = f.stack_size; f.ctx.uc_link = &s.main_ctx;
             makecontext(&f.ctx, (void (*)())trampoline, 0);
         }
         int remaining = nt; long rounds = 0;
