@@ -127,3 +127,36 @@ static inline emul_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, 
     return emul_f32x4{d[0], d[1], d[2], d[3]};
 }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return hipSuccess; }
+
+// ---- atomics (fibres are cooperative: a read-modify-write is never interleaved), lane-position counts, the LDS crossbar's push form, fast math
+template <class T> static inline T atomicAdd(T* p, T v) { const T o = *p; *p = o + v; return o; }
+template <class T> static inline T atomicMax(T* p, T v) { const T o = *p; if (v > o) *p = v; return o; }
+template <class T> static inline T atomicMin(T* p, T v) { const T o = *p; if (v < o) *p = v; return o; }
+static inline void unsafeAtomicAdd(float* p, float v) { *p += v; }
+static inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned mask, unsigned base)
+{
+    const int lane = emul::S().cur->lane;
+    return base + (unsigned)__builtin_popcount(lane >= 32 ? mask : (mask & ((1u << lane) - 1u)));
+}
+static inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned mask, unsigned base)
+{
+    const int lane = emul::S().cur->lane;
+    return base + (lane > 32 ? (unsigned)__builtin_popcount(mask & ((1u << (lane - 32)) - 1u)) : 0u);
+}
+// ds_permute_b32 (forward / push): lane l sends `v` to lane (addr / 4) % 64; a lane nobody sends to reads 0; of several senders the highest lane wins
+static inline int __builtin_amdgcn_ds_permute(int addr, int v)
+{
+    return emul::lanes_i(v, addr, [&](const int* in, const int* ax, int* out, const bool* present) {
+        for (int l = 0; l < emul::WAVE; l++) out[l] = 0;
+        for (int l = 0; l < emul::WAVE; l++) if (present[l]) out[(ax[l] >> 2) & 63] = in[l];
+    });
+}
+static inline int __builtin_amdgcn_ds_bpermute(int addr, int v)
+{
+    return emul::lanes_i(v, addr, [&](const int* in, const int* ax, int* out, const bool* present) {
+        for (int l = 0; l < emul::WAVE; l++) { const int s = (ax[l] >> 2) & 63; out[l] = present[s] ? in[s] : 0; }
+    });
+}
+static inline float __builtin_amdgcn_sqrtf(float x) { return std::sqrt(x); }
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+static inline float __builtin_amdgcn_exp2f(float x) { return std::exp2(x); }

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(ROOT, "contrastboundary_amd", "csrc")
 EMUL = os.path.join(HERE, "host_emul", "wave")
-GEN = os.path.join(HERE, "host_emul", "skinny_linear_host.py")
+GEN = os.path.join(HERE, "host_emul", "host_tu.py")
 TU = os.path.join(ROOT, "oracle", "_build", "skinny_linear_host.cpp")
 SO = os.path.join(ROOT, "oracle", "_build", "libskinny_linear_host.so")
 
@@ -25,7 +25,7 @@ def host():
     deps = [src, GEN, os.path.join(CSRC, "cbl_common.h"), os.path.join(EMUL, "amdgcn.h"), os.path.join(EMUL, "hip", "hip_runtime.h")]
     os.makedirs(os.path.dirname(SO), exist_ok=True)
     if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(d) for d in deps):
-        subprocess.check_call([sys.executable, GEN, src, TU])
+        subprocess.check_call([sys.executable, GEN, TU, src])
         subprocess.check_call(["g++", "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas",
                                "-I" + EMUL, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, TU, "-o", SO])
     L = ctypes.CDLL(SO)
@@ -79,7 +79,7 @@ def test_kernels_under_address_sanitizer(tmp_path):
     deps = [src, GEN, os.path.join(CSRC, "cbl_common.h"), os.path.join(EMUL, "amdgcn.h"), os.path.join(EMUL, "hip", "hip_runtime.h")]
     os.makedirs(os.path.dirname(so), exist_ok=True)
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
-        subprocess.check_call([sys.executable, GEN, src, tu])
+        subprocess.check_call([sys.executable, GEN, tu, src])
         subprocess.check_call(["g++", "-x", "c++", "-std=c++17", "-O1", "-g", "-fsanitize=address", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas",
                                "-I" + EMUL, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, tu, "-o", so])
     script = tmp_path / "run.py"
