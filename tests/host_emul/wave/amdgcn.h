@@ -160,3 +160,34 @@ static inline int __builtin_amdgcn_ds_bpermute(int addr, int v)
 static inline float __builtin_amdgcn_sqrtf(float x) { return std::sqrt(x); }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline float __builtin_amdgcn_exp2f(float x) { return std::exp2(x); }
+
+// ---- what local_aggregation.hip / kpconv_backward.hip use beyond the above
+struct float3 { float x, y, z; };
+static inline float3 make_float3(float x, float y, float z) { return float3{x, y, z}; }
+static inline unsigned min(unsigned a, int b) { return b < 0 ? 0u : (a < (unsigned)b ? a : (unsigned)b); }
+static inline unsigned min(int a, unsigned b) { return min(b, a); }
+static inline long long min(long long a, int b) { return a < b ? a : (long long)b; }
+static inline long long min(int a, long long b) { return a < b ? (long long)a : b; }
+static inline long long max(long long a, int b) { return a > b ? a : (long long)b; }
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+static inline void __builtin_amdgcn_wave_barrier() { float z = 0.f, r; emul::wave_collective(&z, 1, &r, 1, [](emul::Wave&) {}); }
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+// v_permlane16_swap / v_permlane32_swap: rows 1, 3 (lanes 32..63) of the first operand change places with rows 0, 2 (lanes 0..31) of the second; {first', second'}
+struct emul_u32x2 { unsigned v[2]; unsigned operator[](int i) const { return v[i]; } };
+static inline emul_u32x2 emul_permlane_swap(unsigned a, unsigned b, int span)
+{
+    emul_u32x2 o;
+    float pay[2] = {__int_as_float((int)a), __int_as_float((int)b)}, r[2];
+    emul::wave_collective(pay, 2, r, 2, [&](emul::Wave& w) {
+        for (int l = 0; l < emul::WAVE; l++) {
+            const bool upper = (l / span) & 1;                      // the half of a 2 * span group that is exchanged
+            // first' : lower part keeps first, upper part takes second's lower part;  second' : lower part takes first's upper part, upper part keeps second
+            w.out[l][0] = upper ? w.in[l - span][1] : w.in[l][0];
+            w.out[l][1] = upper ? w.in[l][1] : w.in[l + span][0];
+        }
+    });
+    o.v[0] = (unsigned)__float_as_int(r[0]); o.v[1] = (unsigned)__float_as_int(r[1]);
+    return o;
+}
+static inline emul_u32x2 __builtin_amdgcn_permlane16_swap(unsigned a, unsigned b, bool, bool) { return emul_permlane_swap(a, b, 16); }
+static inline emul_u32x2 __builtin_amdgcn_permlane32_swap(unsigned a, unsigned b, bool, bool) { return emul_permlane_swap(a, b, 32); }
