@@ -24,14 +24,16 @@ SO = os.path.join(ROOT, "oracle", "_build", "liblocal_aggregation_host.so")
 
 @pytest.fixture(scope="module")
 def host():
-    srcs = [os.path.join(CSRC, "local_aggregation.hip")]
-    deps = srcs + [GEN, os.path.join(CSRC, "cbl_common.h"), os.path.join(EMUL, "amdgcn.h"), os.path.join(EMUL, "hip", "hip_runtime.h")]
+    srcs = [os.path.join(CSRC, "local_aggregation.hip"), os.path.join(CSRC, "kpconv_backward.hip")]
+    deps = srcs + [GEN, os.path.abspath(__file__), os.path.join(CSRC, "cbl_common.h"), os.path.join(EMUL, "amdgcn.h"), os.path.join(EMUL, "hip", "hip_runtime.h")]
     os.makedirs(os.path.dirname(SO), exist_ok=True)
     if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call([sys.executable, GEN, TU] + srcs)
         subprocess.check_call(["g++", "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas",
                                "-I" + EMUL, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, TU, "-o", SO])
-    return ctypes.CDLL(SO)
+    L = ctypes.CDLL(SO)
+    L.cbl_kpconv_backward_csr_workspace_bytes.restype = ctypes.c_size_t
+    return L
 
 
 def P(a):
@@ -101,3 +103,37 @@ def test_adaptive_weight_forward_and_backward(host, K, C, reduction):
     np.testing.assert_allclose(gf, rgf, rtol=1e-4, atol=1e-4 * np.abs(rgf).max())
     np.testing.assert_allclose(gW, rgW, rtol=1e-4, atol=1e-4 * np.abs(rgW).max())
     np.testing.assert_allclose(gb, rgb, rtol=1e-4, atol=1e-4 * np.abs(rgb).max())
+
+
+def transposed_table(idx, n0):
+    """cbl_neighbor_transpose's output, restated: for every target row t < n0 the ascending list of the pairs p = i * K + k whose neighbour is t (CSR: inv_start (n0 + 1),
+    inv_src); shadow neighbours (== n0) are in no list"""
+    flat = idx.reshape(-1)
+    keep = np.nonzero(flat < n0)[0]
+    order = np.argsort(flat[keep], kind="stable")
+    inv_src = keep[order].astype(np.int32)
+    inv_start = np.zeros(n0 + 1, np.int32)
+    np.add.at(inv_start, flat[keep] + 1, 1)
+    return np.cumsum(inv_start).astype(np.int32), inv_src
+
+
+@pytest.mark.parametrize("K,C,KP,influence,mode", [(16, 64, 15, "linear", "sum"), (26, 72, 15, "linear", "sum"), (9, 16, 7, "linear", "closest"), (40, 32, 15, "constant", "sum")])
+def test_kpconv_backward_as_a_gather(host, K, C, KP, influence, mode):
+    """cbl_kpconv_backward_csr (csrc/kpconv_backward.hip: the scatter-add of the feature gradient as a gather over the transposed neighbour table, on MFMA) — the
+    backward pass the headline step runs — against the same analytic gradients; outputs are WRITTEN (pre-filled with NaN here), no atomics"""
+    n0, n = 260, 150
+    q, s, idx, f, rng = make(n0, n, K, C, seed=3 * K + C)
+    kpts = (rng.normal(size=(KP, 3)) * 0.06).astype(np.float32); kpts[0] = 0
+    kw = aligned(rng.normal(size=(KP, C)).astype(np.float32))
+    extent, infl, closest = 0.09, int(influence == "linear"), int(mode == "closest")
+    go = aligned(rng.normal(size=(n, C)).astype(np.float32))
+    inv_start, inv_src = transposed_table(idx, n0)
+    gf, gkw = aligned(np.full((n0, C), np.nan, np.float32)), aligned(np.full((KP, C), np.nan, np.float32))
+    nbytes = host.cbl_kpconv_backward_csr_workspace_bytes(n0, C, KP)
+    ws = np.zeros(nbytes + 64, np.uint8)
+    rc = host.cbl_kpconv_backward_csr(n, n0, K, C, KP, P(q), P(s), P(f), P(kpts), P(kw), ctypes.c_float(extent), infl, closest, P(go), None, P(inv_start), P(inv_src),
+                                      P(gf), P(gkw), P(ws), ctypes.c_size_t(nbytes), None)
+    assert rc == 0
+    rgf, rgkw = LA.kpconv_grads(q, s, idx, f, kpts, kw, extent, go, influence, mode)
+    np.testing.assert_allclose(gf, rgf, rtol=1e-4, atol=1e-4 * np.abs(rgf).max())
+    np.testing.assert_allclose(gkw, rgkw, rtol=1e-4, atol=1e-4 * np.abs(rgkw).max())
