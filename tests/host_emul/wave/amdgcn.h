@@ -191,3 +191,7 @@ static inline emul_u32x2 emul_permlane_swap(unsigned a, unsigned b, int span)
 }
 static inline emul_u32x2 __builtin_amdgcn_permlane16_swap(unsigned a, unsigned b, bool, bool) { return emul_permlane_swap(a, b, 16); }
 static inline emul_u32x2 __builtin_amdgcn_permlane32_swap(unsigned a, unsigned b, bool, bool) { return emul_permlane_swap(a, b, 32); }
+// v_sin_f32 takes its argument in REVOLUTIONS; v_fract_f32
+static inline float __builtin_amdgcn_sinf(float x) { return (float)std::sin(6.283185307179586476925 * (double)x); }
+static inline float __builtin_amdgcn_cosf(float x) { return (float)std::cos(6.283185307179586476925 * (double)x); }
+static inline float __builtin_amdgcn_fractf(float x) { return x - std::floor(x); }

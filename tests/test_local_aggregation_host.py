@@ -24,7 +24,7 @@ SO = os.path.join(ROOT, "oracle", "_build", "liblocal_aggregation_host.so")
 
 @pytest.fixture(scope="module")
 def host():
-    srcs = [os.path.join(CSRC, "local_aggregation.hip"), os.path.join(CSRC, "kpconv_backward.hip")]
+    srcs = [os.path.join(CSRC, "local_aggregation.hip"), os.path.join(CSRC, "kpconv_backward.hip"), os.path.join(CSRC, "pospool.hip")]
     deps = srcs + [GEN, os.path.abspath(__file__), os.path.join(CSRC, "cbl_common.h"), os.path.join(EMUL, "amdgcn.h"), os.path.join(EMUL, "hip", "hip_runtime.h")]
     os.makedirs(os.path.dirname(SO), exist_ok=True)
     if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(d) for d in deps):
@@ -33,6 +33,7 @@ def host():
                                "-I" + EMUL, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, TU, "-o", SO])
     L = ctypes.CDLL(SO)
     L.cbl_kpconv_backward_csr_workspace_bytes.restype = ctypes.c_size_t
+    L.cbl_adaptive_weight_backward_csr_workspace_bytes.restype = ctypes.c_size_t
     return L
 
 
@@ -137,3 +138,53 @@ def test_kpconv_backward_as_a_gather(host, K, C, KP, influence, mode):
     rgf, rgkw = LA.kpconv_grads(q, s, idx, f, kpts, kw, extent, go, influence, mode)
     np.testing.assert_allclose(gf, rgf, rtol=1e-4, atol=1e-4 * np.abs(rgf).max())
     np.testing.assert_allclose(gkw, rgkw, rtol=1e-4, atol=1e-4 * np.abs(rgkw).max())
+
+
+@pytest.mark.parametrize("K,C,reduction", [(26, 72, "mean"), (16, 64, "mean"), (21, 40, "sum"), (9, 8, "mean"), (12, 288, "mean")])
+def test_adaptive_weight_backward_as_a_gather(host, K, C, reduction):
+    """cbl_adaptive_weight_backward_csr — the backward pass of the ConvNet step (cbl_convnet_step) — over the same numpy-built table: every lane width
+    (lanes own one, two or three float4 columns), outputs written over NaN, no atomics"""
+    n0, n = 300, 170
+    q, s, idx, f, rng = make(n0, n, K, C, seed=7 * C + K)
+    W = aligned((rng.normal(size=(3, C)) * 0.5).astype(np.float32)); b = aligned(rng.normal(size=(C,)).astype(np.float32))
+    radius, mean = 0.1, int(reduction == "mean")
+    pad = np.array([int(idx.max())], np.int32)
+    go = aligned(rng.normal(size=(n, C)).astype(np.float32))
+    inv_start, inv_src = transposed_table(idx, n0)
+    gf, gW, gb = aligned(np.full((n0, C), np.nan, np.float32)), aligned(np.full((3, C), np.nan, np.float32)), aligned(np.full(C, np.nan, np.float32))
+    nbytes = host.cbl_adaptive_weight_backward_csr_workspace_bytes(n, n0, C)
+    ws = np.zeros(nbytes + 64, np.uint8)
+    rc = host.cbl_adaptive_weight_backward_csr(n, n0, K, C, P(q), P(s), P(idx), P(f), ctypes.c_float(radius), P(W), P(b), P(pad), mean, P(go), None, P(inv_start), P(inv_src),
+                                               P(gf), P(gW), P(gb), P(ws), ctypes.c_size_t(nbytes), None)
+    assert rc == 0
+    rgf, rgW, rgb = LA.adaptive_weight_grads(q, s, idx, f, radius, W, b, go, reduction)
+    np.testing.assert_allclose(gf, rgf, rtol=1e-4, atol=1e-4 * np.abs(rgf).max())
+    np.testing.assert_allclose(gW, rgW, rtol=1e-4, atol=1e-4 * np.abs(rgW).max())
+    np.testing.assert_allclose(gb, rgb, rtol=1e-4, atol=1e-4 * np.abs(rgb).max())
+
+
+POSPOOL_EMBEDDINGS = {"one": 0, "xyz": 1, "distance": 2, "exp_-d": 3, "direction_exp_-d": 4, "direction_d": 5, "sin_cos": 6, "two_order": 7, "three_order": 8}
+POSPOOL_REDUCTIONS = {"sum": 0, "mean": 1, "max": 2}
+
+
+@pytest.mark.parametrize("K,C,embedding,reduction", [(16, 72, "sin_cos", "mean"), (20, 36, "xyz", "sum"), (9, 9, "sin_cos", "mean"), (26, 18, "two_order", "mean"),
+                                                     (12, 36, "direction_exp_-d", "mean"), (16, 24, "distance", "max")])
+def test_pospool_forward_and_backward(host, K, C, embedding, reduction):
+    """PosPool (csrc/pospool.hip; local_aggregation_operators.py:15-250): parameter-free position embeddings (v_sin_f32 works in revolutions) times the gathered
+    features, reduced over the neighbours; the gradient of the features through the scatter entry"""
+    n0, n = 280, 160
+    q, s, idx, f, rng = make(n0, n, K, C, seed=C + 13 * K)
+    radius = 0.1
+    pad = np.array([int(idx.max())], np.int32)
+    out = aligned(np.full((n, C), np.nan, np.float32))
+    pe, red = POSPOOL_EMBEDDINGS[embedding], POSPOOL_REDUCTIONS[reduction]
+    assert host.cbl_pospool_forward(n, n0, K, C, P(q), P(s), P(idx), P(f), ctypes.c_float(radius), pe, red, P(pad), P(out), None) == 0
+    ref, _, _ = LA.pospool(q, s, idx, f, radius, embedding, reduction)
+    np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+    if reduction == "max":
+        return
+    go = aligned(rng.normal(size=ref.shape).astype(np.float32))
+    gf = aligned(np.zeros((n0, C), np.float32))
+    assert host.cbl_pospool_backward(n, n0, K, C, P(q), P(s), P(idx), P(f), ctypes.c_float(radius), pe, red, P(pad), P(go), P(gf), None) == 0
+    rgf = LA.pospool_grad_features(q, s, idx, f, radius, go, embedding, reduction)
+    np.testing.assert_allclose(gf, rgf, rtol=1e-4, atol=1e-4 * np.abs(rgf).max())
