@@ -2,8 +2,10 @@
 // emulated on the fibre waves of hip/hip_runtime.h — every call is a rendezvous of the wave's alive lanes.  Semantics follow the gfx9 ISA:
 //   update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl): lane l of an enabled row reads src of lane s(l); a lane without a source keeps `old`, or gets 0
 //   with bound_ctrl; lanes of rows the row_mask disables keep `old` (bank_mask is always 0xf in our kernels).  Controls: quad_perm (0x00..0xFF),
-//   row_ror:n (0x121..0x12F), row_mirror (0x140), row_half_mirror (0x141), row_bcast:15 (0x142), row_bcast:31 (0x143).
+//   row_shl / row_shr / row_ror:n (0x101.. / 0x111.. / 0x121..), wave_shl / rol / shr / ror:1 (0x130 / 0x134 / 0x138 / 0x13C), row_mirror (0x140),
+//   row_half_mirror (0x141), row_bcast:15 (0x142), row_bcast:31 (0x143).
 #pragma once
+#define __HIPCC__ 1                                                  // our headers that also serve plain-C++ builds (grid_core.h) take their device branch
 #include <hip/hip_runtime.h>
 
 static inline unsigned __float_as_uint(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
@@ -30,7 +32,13 @@ inline int dpp_source(int l, int ctrl)                              // -1: no so
 {
     const int row = l & ~15, i = l & 15;
     if (ctrl >= 0 && ctrl <= 0xFF) return (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);
+    if (ctrl >= 0x101 && ctrl <= 0x10F) return (i + (ctrl & 15) <= 15) ? l + (ctrl & 15) : -1;      // row_shl:n — lane i reads lane i + n of its row
+    if (ctrl >= 0x111 && ctrl <= 0x11F) return (i - (ctrl & 15) >= 0) ? l - (ctrl & 15) : -1;       // row_shr:n — lane i reads lane i - n of its row
     if (ctrl >= 0x121 && ctrl <= 0x12F) return row | ((i - (ctrl & 15)) & 15);      // row_ror:n — lane i reads lane i - n (mod 16)
+    if (ctrl == 0x130) return l < 63 ? l + 1 : -1;                                   // wave_shl:1
+    if (ctrl == 0x134) return (l + 1) & 63;                                          // wave_rol:1
+    if (ctrl == 0x138) return l > 0 ? l - 1 : -1;                                    // wave_shr:1
+    if (ctrl == 0x13C) return (l - 1) & 63;                                          // wave_ror:1
     if (ctrl == 0x140) return row | (15 - i);
     if (ctrl == 0x141) return (l & ~7) | (7 - (l & 7));
     if (ctrl == 0x142) return (l >= 16) ? row - 1 : -1;                              // lane 15 of the row below
@@ -195,3 +203,53 @@ static inline emul_u32x2 __builtin_amdgcn_permlane32_swap(unsigned a, unsigned b
 static inline float __builtin_amdgcn_sinf(float x) { return (float)std::sin(6.283185307179586476925 * (double)x); }
 static inline float __builtin_amdgcn_cosf(float x) { return (float)std::cos(6.283185307179586476925 * (double)x); }
 static inline float __builtin_amdgcn_fractf(float x) { return x - std::floor(x); }
+
+// ---- the rest of what the search / table / gather files use
+static inline int2 make_int2(int x, int y) { return int2{x, y}; }
+static inline int __any(int pred) { return __ballot(pred) != 0ull; }
+static inline int __all(int pred)
+{
+    return emul::lanes_i(pred ? 1 : 0, 0, [&](const int* in, const int*, int* out, const bool* present) {
+        int a = 1; for (int l = 0; l < emul::WAVE; l++) if (present[l] && !in[l]) a = 0;
+        for (int l = 0; l < emul::WAVE; l++) out[l] = a;
+    });
+}
+#define __hip_atomic_load(ptr, order, scope) (*(ptr))
+#define __hip_atomic_store(ptr, v, order, scope) (*(ptr) = (v))
+static inline void __threadfence_block() {}
+static inline void __threadfence() {}
+static inline long long __double_as_longlong(double d) { long long v; std::memcpy(&v, &d, 8); return v; }
+static inline double __longlong_as_double(long long v) { double d; std::memcpy(&d, &v, 8); return d; }
+template <class T> static inline void __builtin_nontemporal_store(T v, T* p) { *p = v; }
+template <class T> static inline T __builtin_nontemporal_load(const T* p) { return *p; }
+template <class T> static inline T __shfl_up(T v, unsigned delta, int width = 64)
+{
+    return emul::lanes_any(v, [&](int l) { const int i = l & (width - 1); return i >= (int)delta ? l - (int)delta : l; });
+}
+template <class T> static inline T __shfl_down(T v, unsigned delta, int width = 64)
+{
+    return emul::lanes_any(v, [&](int l) { const int i = l & (width - 1); return i + (int)delta < width ? l + (int)delta : l; });
+}
+// ds_swizzle_b32, bit-mask mode (offset bit 15 = 0): inside every group of 32 lanes, lane' = ((lane & and_mask) | or_mask) ^ xor_mask
+static inline int __builtin_amdgcn_ds_swizzle(int v, int pattern)
+{
+    if (pattern & 0x8000) { std::fprintf(stderr, "emul: ds_swizzle quad-perm mode not emulated\n"); std::abort(); }
+    const int and_mask = pattern & 31, or_mask = (pattern >> 5) & 31, xor_mask = (pattern >> 10) & 31;
+    return emul::lanes_i(v, 0, [&](const int* in, const int*, int* out, const bool* present) {
+        for (int l = 0; l < emul::WAVE; l++) { const int s = (l & 32) | ((((l & 31) & and_mask) | or_mask) ^ xor_mask); out[l] = present[s] ? in[s] : 0; }
+    });
+}
+typedef void* hipEvent_t;
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+constexpr unsigned hipEventDisableTiming = 2;
+enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
+static inline hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind, hipStream_t) { std::memmove(dst, src, n); return hipSuccess; }
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+template <class F> static inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
+template <class T> static inline T atomicSub(T* p, T v) { const T o = *p; *p = o - v; return o; }
+template <class T> static inline T atomicOr(T* p, T v) { const T o = *p; *p = o | v; return o; }
+template <class T> static inline T atomicExch(T* p, T v) { const T o = *p; *p = v; return o; }
+template <class T> static inline T atomicCAS(T* p, T cmp, T v) { const T o = *p; if (o == cmp) *p = v; return o; }

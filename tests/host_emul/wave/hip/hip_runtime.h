@@ -65,6 +65,7 @@ struct State {
     int block_alive = 0, block_arrived = 0; unsigned block_gen = 0;
     const std::function<void()>* body = nullptr;
     size_t stack_bytes = 96 * 1024;
+    State() { if (const char* e = std::getenv("CBL_EMUL_STACK_KB")) { const long kb = std::atol(e); if (kb >= 64 && kb <= 8192) stack_bytes = (size_t)kb * 1024; } }
 };
 inline State& S() { static State s; return s; }
 
