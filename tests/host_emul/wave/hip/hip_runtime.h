@@ -96,6 +96,10 @@ inline void wave_collective(const float* payload, int np, float* result, int nr,
             compute(w);
             w.arrived = 0; for (int l = 0; l < WAVE; l++) w.present[l] = false;
             w.gen++;
+            // the lane that completed the rendezvous steps aside once: the wave's lanes then run the code up to the next rendezvous in ASCENDING lane order.
+            // A wave executes in lockstep, so "lane 0 stores to LDS, every lane loads it" needs no barrier on the device; here it needs the storing lane
+            // to run first, which this order gives for the idiom's usual writer (the first lane of a wave or of a lane group).
+            yield();
             break;
         }
         yield();
