@@ -47,7 +47,38 @@ static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((un
 static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
 static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
 
+// Switching fibres: glibc's swapcontext saves and restores the signal mask — one system call per switch, a third of an emulated kernel's run time.  On x86-64
+// (without a sanitizer, which has to see the stack change through its swapcontext interceptor) the switch is the callee-saved registers and the stack pointer.
+#if defined(__x86_64__) && !defined(__SANITIZE_ADDRESS__) && !defined(CBL_EMUL_UCONTEXT)
+#define CBL_EMUL_FAST_SWITCH 1
+#endif
+
 namespace emul {
+
+#ifdef CBL_EMUL_FAST_SWITCH
+// saves the caller's callee-saved state on its stack, leaves that stack pointer in *from, continues on the stack `to` (prepared by a previous switch or by fresh_stack)
+__attribute__((naked, noinline, unused)) static void switch_stack(void** /*from: rdi*/, void* /*to: rsi*/)
+{
+    __asm__ volatile(
+        "pushq %rbp\n\tpushq %rbx\n\tpushq %r12\n\tpushq %r13\n\tpushq %r14\n\tpushq %r15\n\t"
+        "subq $8, %rsp\n\tstmxcsr (%rsp)\n\tfnstcw 4(%rsp)\n\t"
+        "movq %rsp, (%rdi)\n\tmovq %rsi, %rsp\n\t"
+        "ldmxcsr (%rsp)\n\tfldcw 4(%rsp)\n\taddq $8, %rsp\n\t"
+        "popq %r15\n\tpopq %r14\n\tpopq %r13\n\tpopq %r12\n\tpopq %rbx\n\tpopq %rbp\n\tret");
+}
+// a stack on which switch_stack "returns" into entry() (which never returns), with the launching thread's floating-point control words
+inline void* fresh_stack(char* stack, size_t size, void (*entry)())
+{
+    unsigned long long* sp = (unsigned long long*)(((unsigned long long)(stack + size)) & ~15ull);
+    unsigned int csr; unsigned short cw;
+    __asm__ volatile("stmxcsr %0" : "=m"(csr)); __asm__ volatile("fnstcw %0" : "=m"(cw));
+    *--sp = 0;                                   // where entry's return address would be: entry starts, as after a call, 8 below a 16-byte boundary
+    *--sp = (unsigned long long)entry;
+    for (int i = 0; i < 6; i++) *--sp = 0;
+    *--sp = (unsigned long long)csr | ((unsigned long long)cw << 32);
+    return sp;
+}
+#endif
 
 constexpr int WAVE = 64;
 struct Wave {
@@ -55,10 +86,10 @@ struct Wave {
     float in[WAVE][8]; float out[WAVE][4]; bool present[WAVE];
 };
 struct Fiber {
-    ucontext_t ctx; dim3 tid; int lin = 0, wave = 0, lane = 0; bool done = false; char* stack = nullptr; size_t stack_size = 0;
+    ucontext_t ctx; void* sp = nullptr; dim3 tid; int lin = 0, wave = 0, lane = 0; bool done = false; char* stack = nullptr; size_t stack_size = 0;
 };
 struct State {
-    ucontext_t main_ctx;
+    ucontext_t main_ctx; void* main_sp = nullptr;
     std::vector<Fiber> fibers; std::vector<Wave> waves;
     Fiber* cur = nullptr;
     dim3 block_idx, block_dim, grid_dim;
@@ -69,7 +100,14 @@ struct State {
 };
 inline State& S() { static State s; return s; }
 
-inline void yield() { State& s = S(); swapcontext(&s.cur->ctx, &s.main_ctx); }
+#ifdef CBL_EMUL_FAST_SWITCH
+inline void to_main(Fiber* f) { switch_stack(&f->sp, S().main_sp); }
+inline void to_fiber(Fiber* f) { switch_stack(&S().main_sp, f->sp); }
+#else
+inline void to_main(Fiber* f) { swapcontext(&f->ctx, &S().main_ctx); }
+inline void to_fiber(Fiber* f) { swapcontext(&S().main_ctx, &f->ctx); }
+#endif
+inline void yield() { to_main(S().cur); }
 
 inline void trampoline()
 {
@@ -79,7 +117,8 @@ inline void trampoline()
     f->done = true;
     s.waves[f->wave].alive--;
     s.block_alive--;
-    swapcontext(&f->ctx, &s.main_ctx);
+    to_main(f);
+    std::abort();                                 // a finished fibre is never resumed
 }
 
 // every alive lane of the calling wave deposits `np` floats; when all have, `compute(wave)` fills wave.out; each lane then takes its `nr` results
@@ -141,9 +180,13 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body)
             f.lin = t; f.wave = t / WAVE; f.lane = t % WAVE; f.done = false;
             f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
             s.waves[f.wave].alive++;
+#ifdef CBL_EMUL_FAST_SWITCH
+            f.sp = fresh_stack(f.stack, f.stack_size, trampoline);
+#else
             getcontext(&f.ctx);
             f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = f.stack_size; f.ctx.uc_link = &s.main_ctx;
             makecontext(&f.ctx, (void (*)())trampoline, 0);
+#endif
         }
         int remaining = nt; long rounds = 0;
         while (remaining > 0) {
@@ -152,7 +195,7 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body)
                 Fiber& f = s.fibers[t];
                 if (f.done) continue;
                 s.cur = &f;
-                swapcontext(&s.main_ctx, &f.ctx);
+                to_fiber(&f);
                 if (!f.done) remaining++;
             }
             if (++rounds > 50000000) { std::fprintf(stderr, "emul: no progress (divergent rendezvous?)\n"); std::abort(); }

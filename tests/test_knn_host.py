@@ -48,11 +48,6 @@ def P(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 
 
-# the cases that replay many tied rows take a minute each under emulation: they run with CBL_HOST_EMUL_FULL=1 (all of them passed when this file was written)
-FULL = bool(os.environ.get("CBL_HOST_EMUL_FULL"))
-slow = pytest.mark.skipif(not FULL, reason="minutes under emulation: set CBL_HOST_EMUL_FULL=1")
-
-
 def cloud(kind, n, seed):
     rng = np.random.default_rng(seed)
     if kind == "uniform":
@@ -61,8 +56,12 @@ def cloud(kind, n, seed):
         u = rng.uniform(0, 1, (n, 2)).astype(np.float32)
         z = np.where(np.arange(n) % 2 == 0, 0.0, u[:, 0] * 0.3).astype(np.float32)
         return np.concatenate([u, z[:, None]], 1)
+    if kind == "grid":                                                # a whole lattice: every row is tied at its K-th distance and takes the replay
+        s = int(round(n ** (1 / 3.0))) + 1
+        g = np.stack(np.meshgrid(np.arange(s), np.arange(s), np.arange(s), indexing="ij"), -1).reshape(-1, 3)[:n].astype(np.float32) * 0.0625
+        return g[rng.permutation(n)]
     if kind == "lattice":                                             # a uniform cloud with a lattice patch inside: a few dozen rows whose distances are exactly tied take
-        s = 3                                                         # the tie logic and the replay (a whole lattice works too, at minutes per case under emulation)
+        s = 3                                                         # the tie logic and the replay
         g = np.stack(np.meshgrid(np.arange(s), np.arange(s), np.arange(s), indexing="ij"), -1).reshape(-1, 3).astype(np.float32) * 0.0625 + 0.3
         pts = np.concatenate([rng.uniform(0, 1, (n - len(g), 3)).astype(np.float32), g])
         return pts[rng.permutation(n)]
@@ -81,7 +80,7 @@ def run(L, entry, K, xyz, q, off, qoff):
 
 
 @pytest.mark.parametrize("kind,sizes,K", [("uniform", [2300], 16), ("uniform", [2300], 36), ("surface", [2500], 8), ("lattice", [2200], 16),
-                                          pytest.param("lattice", [2100], 36, marks=slow), ("uniform", [2100, 300], 16)])
+                                          ("lattice", [2100], 36), ("uniform", [2100, 300], 16), ("grid", [2197], 16)])
 def test_self_queries_equal_the_oracle_bit_for_bit(host, kind, sizes, K):
     xyz = np.concatenate([cloud(kind, n, 20 + i) + 2.5 * i for i, n in enumerate(sizes)])
     off = np.cumsum(sizes)
@@ -103,7 +102,7 @@ def test_foreign_queries_and_the_brute_force_entry(host):
     np.testing.assert_array_equal(idx2, ridx); np.testing.assert_array_equal(d22.view(np.uint32), rd2.view(np.uint32))
 
 
-@pytest.mark.parametrize("kind", ["uniform", pytest.param("lattice", marks=slow)])
+@pytest.mark.parametrize("kind", ["uniform", "lattice"])
 def test_nested_search_equals_two_searches(host, kind):
     """cbl_knnquery_nested: the K = 36 search of the CBL head with the K = 16 table of the block derived from it (what the bench step runs)"""
     n = 2300
