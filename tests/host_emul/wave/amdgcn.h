@@ -17,7 +17,8 @@ static inline unsigned __brev(unsigned v) { unsigned r = 0; for (int i = 0; i < 
 
 namespace emul {
 // one int per lane in, one int per lane out, computed from all lanes' inputs
-template <class F> inline int lanes_i(int v, int aux, F f)
+// tag / scope: which collective this is and whether it spans the wave (1) or a lane group (0) — see hip_runtime.h resolve()
+template <class F> inline int lanes_i(int v, int aux, F f, unsigned tag = 0, int scope = 1)
 {
     float pay[2] = {__int_as_float(v), __int_as_float(aux)}, r;
     wave_collective(pay, 2, &r, 1, [&](Wave& w) {
@@ -25,7 +26,7 @@ template <class F> inline int lanes_i(int v, int aux, F f)
         for (int l = 0; l < WAVE; l++) { in[l] = __float_as_int(w.in[l][0]); ax[l] = __float_as_int(w.in[l][1]); }
         f(in, ax, out, w.present);
         for (int l = 0; l < WAVE; l++) w.out[l][0] = __int_as_float(out[l]);
-    });
+    }, tag, scope);
     return __float_as_int(r);
 }
 inline int dpp_source(int l, int ctrl)                              // -1: no source
@@ -56,7 +57,7 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int ro
             const int s = emul::dpp_source(l, ctrl);
             out[l] = (s >= 0 && present[s]) ? in[s] : (bound_ctrl ? 0 : ax[l]);
         }
-    });
+    }, 0x10000u | (unsigned)ctrl, (ctrl == 0x130 || ctrl == 0x134 || ctrl == 0x138 || ctrl == 0x13C) ? 1 : 0);
 }
 static inline int __builtin_amdgcn_readlane(int v, int lane)
 {
@@ -86,19 +87,19 @@ static inline unsigned long long __ballot(int pred)
 
 // ---- wave shuffles (ds_bpermute-backed on the device): width = 64 or a power of two below it; lanes of a width-group exchange among themselves
 namespace emul {
-template <class T, class F> inline T lanes_any(T v, F src_of)
+template <class T, class F> inline T lanes_any(T v, F src_of, int width = 64)
 {
     static_assert(sizeof(T) == 4 || sizeof(T) == 8, "4- or 8-byte values");
     float pay[2] = {0.f, 0.f}, r[2];
     std::memcpy(pay, &v, sizeof(T));
     wave_collective(pay, 2, r, 2, [&](Wave& w) {
         for (int l = 0; l < WAVE; l++) { const int s = src_of(l); const int t = (s >= 0 && s < WAVE && w.present[s]) ? s : l; w.out[l][0] = w.in[t][0]; w.out[l][1] = w.in[t][1]; }
-    });
+    }, 0x20000u | (unsigned)width, width < 64 ? 0 : 1);
     T o; std::memcpy(&o, r, sizeof(T));
     return o;
 }
 }  // namespace emul
-template <class T> static inline T __shfl_xor(T v, int mask, int width = 64) { (void)width; return emul::lanes_any(v, [&](int l) { return l ^ mask; }); }
+template <class T> static inline T __shfl_xor(T v, int mask, int width = 64) { return emul::lanes_any(v, [&](int l) { return l ^ mask; }, width); }
 template <class T> static inline T __shfl(T v, int src, int width = 64)
 {
     // every lane names its own source: the lane index travels with the value
@@ -110,7 +111,7 @@ template <class T> static inline T __shfl(T v, int src, int width = 64)
             const int t = w.present[s] ? s : l;
             w.out[l][0] = w.in[t][0]; w.out[l][1] = w.in[t][1];
         }
-    });
+    }, 0x30000u | (unsigned)width, width < 64 ? 0 : 1);
     T o; std::memcpy(&o, r, sizeof(T));
     return o;
 }
@@ -224,11 +225,11 @@ template <class T> static inline void __builtin_nontemporal_store(T v, T* p) { *
 template <class T> static inline T __builtin_nontemporal_load(const T* p) { return *p; }
 template <class T> static inline T __shfl_up(T v, unsigned delta, int width = 64)
 {
-    return emul::lanes_any(v, [&](int l) { const int i = l & (width - 1); return i >= (int)delta ? l - (int)delta : l; });
+    return emul::lanes_any(v, [&](int l) { const int i = l & (width - 1); return i >= (int)delta ? l - (int)delta : l; }, width);
 }
 template <class T> static inline T __shfl_down(T v, unsigned delta, int width = 64)
 {
-    return emul::lanes_any(v, [&](int l) { const int i = l & (width - 1); return i + (int)delta < width ? l + (int)delta : l; });
+    return emul::lanes_any(v, [&](int l) { const int i = l & (width - 1); return i + (int)delta < width ? l + (int)delta : l; }, width);
 }
 // ds_swizzle_b32, bit-mask mode (offset bit 15 = 0): inside every group of 32 lanes, lane' = ((lane & and_mask) | or_mask) ^ xor_mask
 static inline int __builtin_amdgcn_ds_swizzle(int v, int pattern)

@@ -81,9 +81,15 @@ inline void* fresh_stack(char* stack, size_t size, void (*entry)())
 #endif
 
 constexpr int WAVE = 64;
+struct Wave;
+struct Thunk { void (*call)(void*, Wave&) = nullptr; void* ctx = nullptr; };
+template <class F> inline void invoke_thunk(void* c, Wave& w) { (*static_cast<F*>(c))(w); }
 struct Wave {
-    int alive = 0, arrived = 0; unsigned gen = 0;
-    float in[WAVE][8]; float out[WAVE][4]; bool present[WAVE];
+    int alive = 0, arrived = 0;
+    float in[WAVE][8]; float out[WAVE][4]; bool present[WAVE];      // present: takes part in the collective being computed
+    float pay[WAVE][8];
+    // per waiting lane: which collective it waits in (tag), whether that one spans the wave (scope 1) or a lane group (scope 0), and how to compute it
+    bool waiting[WAVE]; unsigned tag[WAVE]; int scope[WAVE]; Thunk thunk[WAVE];
 };
 struct Fiber {
     ucontext_t ctx; void* sp = nullptr; dim3 tid; int lin = 0, wave = 0, lane = 0; bool done = false; char* stack = nullptr; size_t stack_size = 0;
@@ -121,29 +127,45 @@ inline void trampoline()
     std::abort();                                 // a finished fibre is never resumed
 }
 
-// every alive lane of the calling wave deposits `np` floats; when all have, `compute(wave)` fills wave.out; each lane then takes its `nr` results
+// Every alive lane of the calling wave deposits `np` floats and waits; when all alive lanes wait, the collective is computed (`compute(wave)` fills wave.out)
+// and each lane takes its `nr` results.
+// Divergence: a wave executes the two sides of a branch one after the other and meets again behind it, so lanes may wait in DIFFERENT collectives — the idiom in
+// our kernels is a lane GROUP (16 / 32 lanes that share a point) skipping a group reduction the other groups of the wave take (cbl.hip contrast_row: a point
+// without both kinds of neighbours returns before the DPP sums), all of them meeting at the next wave-wide operation.  When every alive lane waits and their
+// (scope, tag) differ, the lanes of ONE collective run it among themselves — lanes outside count as inactive, as the exec mask makes them on the device — and go
+// on; group-scoped collectives (DPP, shuffles narrower than the wave) go before wave-wide ones, which are the meeting points.  The others keep waiting.
+inline void resolve(Wave& w)
+{
+    int pick = -1;
+    for (int l = 0; l < WAVE; l++) if (w.waiting[l] && (pick < 0 || w.scope[l] < w.scope[pick])) pick = l;
+    if (pick < 0) return;
+    for (int l = 0; l < WAVE; l++) {
+        w.present[l] = w.waiting[l] && w.scope[l] == w.scope[pick] && w.tag[l] == w.tag[pick];
+        if (!w.present[l]) for (int i = 0; i < 8; i++) w.pay[l][i] = 0.f; else std::memcpy(w.pay[l], w.in[l], sizeof(w.pay[l]));
+    }
+    std::swap(w.in, w.pay);                                         // compute reads `in`: the participants' payloads, zeros elsewhere (waiting lanes keep theirs in `pay`)
+    w.thunk[pick].call(w.thunk[pick].ctx, w);
+    std::swap(w.in, w.pay);
+    for (int l = 0; l < WAVE; l++) if (w.present[l]) { w.waiting[l] = false; w.present[l] = false; w.arrived--; }
+}
+
 template <class F>
-inline void wave_collective(const float* payload, int np, float* result, int nr, F compute)
+inline void wave_collective(const float* payload, int np, float* result, int nr, F compute, unsigned tag = 0, int scope = 1)
 {
     State& s = S(); Fiber* f = s.cur; Wave& w = s.waves[f->wave];
-    const unsigned g = w.gen;
-    for (int i = 0; i < np; i++) w.in[f->lane][i] = payload[i];
-    w.present[f->lane] = true; w.arrived++;
-    while (w.gen == g) {
-        if (w.arrived == w.alive) {
-            for (int l = 0; l < WAVE; l++) if (!w.present[l]) for (int i = 0; i < 8; i++) w.in[l][i] = 0.f;
-            compute(w);
-            w.arrived = 0; for (int l = 0; l < WAVE; l++) w.present[l] = false;
-            w.gen++;
-            // the lane that completed the rendezvous steps aside once: the wave's lanes then run the code up to the next rendezvous in ASCENDING lane order.
-            // A wave executes in lockstep, so "lane 0 stores to LDS, every lane loads it" needs no barrier on the device; here it needs the storing lane
-            // to run first, which this order gives for the idiom's usual writer (the first lane of a wave or of a lane group).
-            yield();
-            break;
-        }
+    const int me = f->lane;
+    for (int i = 0; i < np; i++) w.in[me][i] = payload[i];
+    w.waiting[me] = true; w.tag[me] = tag; w.scope[me] = scope;
+    w.thunk[me].call = &invoke_thunk<F>; w.thunk[me].ctx = (void*)&compute;
+    w.arrived++;
+    while (w.waiting[me]) {
+        if (w.arrived == w.alive) resolve(w);
+        // (also the lane that completed a rendezvous steps aside once: the wave's lanes then run the code up to the next rendezvous in ASCENDING lane order.
+        //  A wave executes in lockstep, so "lane 0 stores to LDS, every lane loads it" needs no barrier on the device; here it needs the storing lane
+        //  to run first, which this order gives for the idiom's usual writer — the first lane of a wave or of a lane group.)
         yield();
     }
-    for (int i = 0; i < nr; i++) result[i] = w.out[f->lane][i];
+    for (int i = 0; i < nr; i++) result[i] = w.out[me][i];
 }
 
 inline void block_barrier()
@@ -173,7 +195,7 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body)
     for (unsigned bz = 0; bz < grid.z; bz++) for (unsigned by = 0; by < grid.y; by++) for (unsigned bx = 0; bx < grid.x; bx++) {
         s.block_idx = dim3(bx, by, bz);
         s.waves.assign(nw, Wave());
-        for (auto& w : s.waves) for (int l = 0; l < WAVE; l++) w.present[l] = false;
+        for (auto& w : s.waves) for (int l = 0; l < WAVE; l++) w.present[l] = w.waiting[l] = false;
         s.block_alive = nt; s.block_arrived = 0; s.block_gen = 0;
         for (int t = 0; t < nt; t++) {
             Fiber& f = s.fibers[t];

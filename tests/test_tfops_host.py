@@ -2,7 +2,8 @@
 /root/reference/tensorflow/ops/cpp_wrappers/cpp_subsampling/grid_subsampling/grid_subsampling.cpp — and the sorted radius search cropped to a limit —
 tf_custom_ops/tf_neighbors/neighbors/neighbors.cpp:213-336, datasets/base.py:756-765) compiled for the HOST and run with wave semantics (tests/host_emul/wave),
 through `cbl_grid_subsampling` / `cbl_radius_neighbors`, against the oracle (oracle/tfops_oracle.c, itself pinned by the reference's own C++ built as oracle/_ref):
-barycentres, voxel counts, features and majority labels bit for bit in the canonical order; neighbour tables, counts and the largest neighbourhood bit for bit."""
+barycentres, voxel counts, features and majority labels bit for bit in the canonical order; neighbour tables, counts and the largest neighbourhood bit for bit.
+The whole input pyramid as one native call (pyramid.hip: `cbl_pyramid`, datasets/base.py:767-842) against the oracle's operators applied layer by layer."""
 import ctypes
 import os
 import subprocess
@@ -21,7 +22,7 @@ EMUL = os.path.join(HERE, "host_emul", "wave")
 GEN = os.path.join(HERE, "host_emul", "host_tu.py")
 BUILD = os.path.join(ROOT, "oracle", "_build")
 SO = os.path.join(BUILD, "libtfops_host.so")
-FILES = ["tfops", "knn_grid", "knn_exact", "knn_select", "knn_dispatch"]
+FILES = ["tfops", "pyramid", "knn_grid", "knn_exact", "knn_select", "knn_dispatch"]
 
 
 @pytest.fixture(scope="module")
@@ -42,6 +43,7 @@ def host():
     L = ctypes.CDLL(SO)
     L.cbl_grid_subsampling_workspace_bytes.restype = ctypes.c_size_t
     L.cbl_radius_neighbors_workspace_bytes.restype = ctypes.c_size_t
+    L.cbl_pyramid_layer_workspace_bytes.restype = ctypes.c_size_t
     return L
 
 
@@ -99,3 +101,53 @@ def test_radius_neighbors(host, r, limit):
         np.testing.assert_array_equal(out, ref)
         np.testing.assert_array_equal(counts, rcounts)
         assert int(mx[0]) == mc
+
+
+def test_pyramid_in_one_call_equals_the_operators_layer_by_layer(host):
+    """tf_segmentation_inputs_radius (datasets/base.py:795-820): per layer conv_i = neighbors(points, points, r) cropped to the layer's limit, pool points =
+    subsampling at 2 dl, pool_i = neighbors(pool, points, r), up_i = neighbors(points, pool, 2 r); r and dl double from layer to layer; the last layer only
+    searches.  Layer l > 0 reuses the search grid its predecessor's upsampling built (grid_is_built), which this case exercises twice."""
+    xyz, _ = S.s_room(3600, seed=11)
+    lens = np.int32([1500, 2100])
+    b, n = len(lens), xyz.shape[0]
+    r0, dl0, layers = 0.12, 0.05, 3
+    limits = np.int32([24, 20, 33])
+    grid_bytes = host.cbl_radius_neighbors_workspace_bytes(b, n)
+    grids = [np.zeros(grid_bytes + 64, np.uint8) for _ in range(layers)]
+    nb = [np.full((n, int(limits[l])), -5, np.int32) for l in range(layers)]
+    pp = [np.full((n, 3), np.nan, np.float32) for _ in range(layers - 1)]
+    pl = [np.full(b, -1, np.int32) for _ in range(layers - 1)]
+    po = [np.full((n, int(limits[l])), -5, np.int32) for l in range(layers - 1)]
+    up = [np.full((n, int(limits[l])), -5, np.int32) for l in range(layers - 1)]
+    mx, sizes = np.full(3 * layers, -1, np.int32), np.full(layers, -1, np.int32)
+    nbytes = host.cbl_pyramid_layer_workspace_bytes(b, n)
+    ws = np.zeros(nbytes + 64, np.uint8)
+
+    def ptrs(arrs, count):
+        a = (ctypes.c_void_p * count)()
+        for i, x in enumerate(arrs):
+            a[i] = x.ctypes.data
+        return a
+    rc = host.cbl_pyramid(b, n, P(xyz), P(lens), ctypes.c_float(r0), ctypes.c_float(dl0), layers, P(limits), ptrs(grids, layers), ctypes.c_size_t(grid_bytes),
+                          ptrs(nb, layers), ptrs(pp, layers), ptrs(pl, layers), ptrs(po, layers), ptrs(up, layers), P(mx), P(sizes), P(ws), ctypes.c_size_t(nbytes), None)
+    assert rc == 0
+    pts, ln, r, dl = xyz, lens, r0, dl0
+    for l in range(layers):
+        m = pts.shape[0]
+        assert int(sizes[l]) == m
+        lim = int(limits[l])
+        ref, _, mc = O.radius_neighbors(pts, pts, ln, ln, r, lim)
+        np.testing.assert_array_equal(nb[l][:m], ref)
+        assert int(mx[3 * l]) == mc
+        if l == layers - 1:
+            break
+        sub, sl = O.grid_subsampling(pts, ln, 2 * dl)
+        k = sub.shape[0]
+        assert 0 < k < m
+        np.testing.assert_array_equal(pl[l], sl)
+        np.testing.assert_array_equal(pp[l][:k].view(np.uint32), sub.view(np.uint32))
+        ref, _, mc = O.radius_neighbors(sub, pts, sl, ln, r, lim)
+        np.testing.assert_array_equal(po[l][:k], ref); assert int(mx[3 * l + 1]) == mc
+        ref, _, mc = O.radius_neighbors(pts, sub, ln, sl, 2 * r, lim)
+        np.testing.assert_array_equal(up[l][:m], ref); assert int(mx[3 * l + 2]) == mc
+        pts, ln, r, dl = np.ascontiguousarray(sub), sl.astype(np.int32), 2 * r, 2 * dl
