@@ -6,8 +6,10 @@ product build) and its composite entry points run as the device library issues t
     what bench.py's ConvNet leg times per scene — against the oracles layer by layer, with the tolerances tests/test_gpu_bench_convnet.py uses on the device;
   - the test loop's accumulation of per-crop predictions (`cbl_cumulate_probs`, /root/reference/pytorch/tool/test.py:330-352) against numpy's indexed assignment."""
 import ctypes
+import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -151,3 +153,19 @@ def test_cumulate_probs_keeps_the_last_row_of_a_duplicated_point(host, mode, smo
     rc = host.cbl_cumulate_probs(n, ncls, m, P(inds), P(pred), ctypes.c_float(smooth), mode, P(probs), P(scratch), None)
     assert rc == 0
     np.testing.assert_array_equal(probs.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.skipif(not os.environ.get("CBL_HOST_EMUL_FULL"), reason="a sanitizer build of the whole library and a quarter of an hour of emulation: set CBL_HOST_EMUL_FULL=1")
+def test_whole_library_cases_under_address_sanitizer():
+    """every test module over the whole-library host build again, against the same build with -fsanitize=address (operands are numpy buffers of exactly their logical
+    sizes, `__shared__` arrays static arrays): the clamped loads, masked stores and workspace carving of every entry point.  Last run clean at the commit that
+    added this test (14 minutes)."""
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not asan or not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("no libasan beside gcc")
+    env = dict(os.environ, CBL_FULL_LIBRARY_ASAN="1", LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0")
+    env.pop("CBL_HOST_EMUL_FULL")                                    # (not this test again)
+    mods = ["tests/test_heads_host.py", "tests/test_gather_variants_host.py", "tests/test_full_library_host.py", "tests/test_attention_host.py", "tests/test_knn_variants_host.py"]
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider"] + mods, capture_output=True, text=True, timeout=3600, env=env, cwd=full_library.ROOT)
+    assert "AddressSanitizer" not in r.stdout + r.stderr, (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
