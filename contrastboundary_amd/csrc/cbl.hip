@@ -216,7 +216,8 @@ __global__ __launch_bounds__(256) void contrast_bwd_kernel(int m, int nsample, c
         if (t < m && r.valid && r.nb) {
             const float scale = fused ? 1.f : grad_loss[0] * weight / count;
             const float ratio = r.P / r.A;
-            coef = scale * r.e * ((r.pos ? r.A : 0.f) - r.P) * inv_temperature / (r.A * r.A * (ratio + 1e-12f)) / r.dist;
+            // ((pos ? A : 0) - P) / A^2 as two quotients by A: A^2 underflows in fp32 once A < 1e-19 (see cbl_pairs.hip)
+            coef = scale * (r.e / r.A) * (((r.pos ? r.A : 0.f) - r.P) / r.A) * inv_temperature / (ratio + 1e-12f) / r.dist;
             if ((tf_variant & 1) && r.dist <= 1e-6f) coef = 0.f;     // sqrt(max(s, 1e-12)): flat below the clamp
         }
     }

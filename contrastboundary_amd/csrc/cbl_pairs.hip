@@ -154,28 +154,35 @@ __global__ __launch_bounds__(256) void contrast_pairs_kernel(unsigned m, int nsa
             mxl = fmaxf(mxl, ex[u]);
         }
         const float mx = group_max<64>(mxl);                         // :153
-        float pl = 0.f, al = 0.f;
+        float pl = 0.f, al = 0.f, nl = 0.f;
 #pragma unroll
         for (int u = 0; u < UM; u++) {
             ex[u] = isnb[u] ? fast_exp((ex[u] - mx) * inv_temperature) : 0.f;       // shift, then / T (:153-155)
-            pl += ispos[u] ? ex[u] : 0.f; al += ex[u];
+            pl += ispos[u] ? ex[u] : 0.f; al += ex[u]; nl += ispos[u] ? 0.f : ex[u];
         }
         const float P = group_sum<64>(pl) * (1.0f / LR), A = group_sum<64>(al) * (1.0f / LR);   // every pair is held by LR lanes
+        // the negatives' sum where a variant uses it by itself ('nce', margin 'S'): summed as the reference sums it (heads.py:171, head.py:757) — A - P loses
+        // it to cancellation once the negatives are 1e-7 of the positives
+        const float Nsum = (nce || sep) ? group_sum<64>(nl) * (1.0f / LR) : 0.f;
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!nce) {
             // margin 'S' (head.py:759-760): pos / max(neg, eps) instead of pos / (pos + neg)
-            const float Nn = A - P, Nc = fmaxf(Nn, 1e-12f);
+            const float Nn = sep ? Nsum : A - P, Nc = fmaxf(Nn, 1e-12f);
             const float ratio = sep ? P / Nc : P / A;
             if (lane == 0) { per_point[i] = -logf(ratio + 1e-12f); point_mask[i] = 1; }          // contrast_softnn :161-163
             if (!GRAD) continue;
             // ---- gradient coefficients: d term / d dist_j, then / dist_j for the direction (f_i - f_j) / dist_j
-            const float base = sep ? inv_temperature / (ratio + 1e-12f) : inv_temperature / (A * A * (ratio + 1e-12f));
-            const float xpos = sep ? 1.0f / Nc : A - P, xneg = sep ? (Nn > 1e-12f ? -P / (Nc * Nc) : 0.f) : -P;
+            // d(P / A) / d e_j = ((j positive ? A : 0) - P) / A^2, written as two quotients by A: A^2 underflows in fp32 once A < 1e-19 — every valid neighbour
+            // more than 44 T farther away than a masked column that holds the maximum of the shift (head.py:752) — and the coefficient became inf / NaN
+            // where the reference's autodiff (x / y / y) stays finite
+            const float invA = 1.0f / A;
+            const float base = inv_temperature / (ratio + 1e-12f), es = sep ? 1.0f : invA;
+            const float xpos = sep ? 1.0f / Nc : (A - P) * invA, xneg = sep ? (Nn > 1e-12f ? -P / (Nc * Nc) : 0.f) : -P * invA;
             if (lane == 0) coef[(size_t)i * nsample] = 0.f;          // the self column takes no part
 #pragma unroll
             for (int u = 0; u < UM; u++) {
                 const int j = u * PP + s;
-                float c = isnb[u] ? ex[u] * (ispos[u] ? xpos : xneg) * base * fast_rcp(dist[u]) : 0.f;
+                float c = isnb[u] ? (ex[u] * es) * (ispos[u] ? xpos : xneg) * base * fast_rcp(dist[u]) : 0.f;
                 if (tf_variant && dist[u] <= 1e-6f) c = 0.f;        // sqrt(max(s, 1e-12)): flat below the clamp
                 if (q == 0 && j < ns) coef[(size_t)i * nsample + 1 + j] = c;
                 g.x += c * diff[u].x; g.y += c * diff[u].y; g.z += c * diff[u].z; g.w += c * diff[u].w;
@@ -183,14 +190,14 @@ __global__ __launch_bounds__(256) void contrast_pairs_kernel(unsigned m, int nsa
         } else {
             // ---- contrast 'nce'.  pytorch (heads.py:167-183): term_j = -log(e_j / (e_j + N)), N = sum of the negatives' e, one term per
             // positive; TF (head.py:773-795): -sum over positives of log(e_j / A + eps) per point
-            const float N = A - P;
+            const float N = Nsum;
             float tl = 0.f, ql = 0.f;
 #pragma unroll
             for (int u = 0; u < UM; u++) {
                 if (ispos[u]) {
                     if (tf_variant && sep) {                        // 'S': under_j = e_j + N (head.py:783-785), eps inside the log (:793)
                         const float un = ex[u] + N, r = ex[u] / un;
-                        tl += -logf(r + 1e-12f); ql += ex[u] / ((r + 1e-12f) * un * un);
+                        tl += -logf(r + 1e-12f); ql += r / ((r + 1e-12f) * un);              // e_j / ((r + eps) un^2) without the square (underflow, as above)
                     }
                     else if (tf_variant) { const float r = ex[u] / A; tl += -logf(r + 1e-12f); ql += r / (r + 1e-12f); }
                     else                 { tl += -logf(ex[u] / (ex[u] + N)); ql += 1.0f / (ex[u] + N); }
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(256) void contrast_pairs_kernel(unsigned m, int nsa
                 if (isnb[u]) {
                     if (tf_variant && sep) {
                         const float un = ex[u] + N, r = ex[u] / un;
-                        c = (ispos[u] ? inv_temperature * ex[u] * N / ((r + 1e-12f) * un * un) : -inv_temperature * ex[u] * Q) / dist[u];
+                        c = (ispos[u] ? inv_temperature * r * (N / un) / (r + 1e-12f) : -inv_temperature * ex[u] * Q) / dist[u];
                     }
                     else if (tf_variant) { const float r = ex[u] / A; c = inv_temperature * ((ispos[u] ? r / (r + 1e-12f) : 0.f) - r * Q) / dist[u]; }
                     else                 c = (ispos[u] ? inv_temperature * N / (ex[u] + N) : -inv_temperature * ex[u] * Q) / dist[u];
