@@ -85,7 +85,7 @@ struct Wave;
 struct Thunk { void (*call)(void*, Wave&) = nullptr; void* ctx = nullptr; };
 template <class F> inline void invoke_thunk(void* c, Wave& w) { (*static_cast<F*>(c))(w); }
 struct Wave {
-    int alive = 0, arrived = 0;
+    int alive = 0, arrived = 0, at_barrier = 0;                     // at_barrier: lanes of this wave parked in __syncthreads (they take part in no wave collective)
     float in[WAVE][8]; float out[WAVE][4]; bool present[WAVE];      // present: takes part in the collective being computed
     float pay[WAVE][8];
     // per waiting lane: which collective it waits in (tag), whether that one spans the wave (scope 1) or a lane group (scope 0), and how to compute it
@@ -159,7 +159,7 @@ inline void wave_collective(const float* payload, int np, float* result, int nr,
     w.thunk[me].call = &invoke_thunk<F>; w.thunk[me].ctx = (void*)&compute;
     w.arrived++;
     while (w.waiting[me]) {
-        if (w.arrived == w.alive) resolve(w);
+        if (w.arrived == w.alive - w.at_barrier) resolve(w);       // lanes at the workgroup barrier are behind the meeting point: the others go on among themselves
         // (also the lane that completed a rendezvous steps aside once: the wave's lanes then run the code up to the next rendezvous in ASCENDING lane order.
         //  A wave executes in lockstep, so "lane 0 stores to LDS, every lane loads it" needs no barrier on the device; here it needs the storing lane
         //  to run first, which this order gives for the idiom's usual writer — the first lane of a wave or of a lane group.)
@@ -171,10 +171,15 @@ inline void wave_collective(const float* payload, int np, float* result, int nr,
 inline void block_barrier()
 {
     State& s = S();
+    Wave& w = s.waves[s.cur->wave];
     const unsigned g = s.block_gen;
-    s.block_arrived++;
+    s.block_arrived++; w.at_barrier++;
     while (s.block_gen == g) {
-        if (s.block_arrived == s.block_alive) { s.block_arrived = 0; s.block_gen++; break; }
+        if (s.block_arrived == s.block_alive) {                      // released: every lane of the workgroup is past the barrier from here on, whenever it runs next
+            s.block_arrived = 0; s.block_gen++;
+            for (auto& x : s.waves) x.at_barrier = 0;
+            break;
+        }
         yield();
     }
 }
@@ -233,4 +238,6 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body)
 #define blockDim (emul::S().block_dim)
 #define gridDim (emul::S().grid_dim)
 static inline void __syncthreads() { emul::block_barrier(); }
-#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) emul::launch((grid), (block), [&]() { kern(__VA_ARGS__); })
+// CBL_EMUL_TRACE=1 names every kernel as it is launched (which one a "no progress" abort belongs to)
+namespace emul { inline void trace(const char* name) { static const bool on = std::getenv("CBL_EMUL_TRACE") != nullptr; if (on) std::fprintf(stderr, "emul: launch %s\n", name); } }
+#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) (emul::trace(#kern), emul::launch((grid), (block), [&]() { kern(__VA_ARGS__); }))
