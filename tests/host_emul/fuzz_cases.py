@@ -2,7 +2,7 @@
 sides of every dispatch threshold, ragged batches with one-point clouds, clouds smaller than K, coincident points, lattices and planes (exactly tied distances),
 shadow entries, hub targets, ignored labels, every contrast flavour.  tests/test_fuzz_host.py runs a bounded, seeded share of them; a campaign is
 
-    python tests/host_emul/fuzz_cases.py <knn|radius|grid|fps|transpose|cbl> <seed> <cases>
+    python tests/host_emul/fuzz_cases.py <knn|radius|grid|fps|transpose|cbl|gather|aggregation|attention> <seed> <cases>
 
 What the round-5 campaign (a few thousand cases) found is in DESIGN.md 5: two numerical defects of the contrast kernels in extreme regimes (fixed, regression tests in
 tests/test_cbl_host.py) and one limit of the emulation (K > 64 of the brute-force search keeps its heap in LDS and every lane of the wave replays the same update —
@@ -246,7 +246,85 @@ def cbl_case(rng, it, extreme=True):
     return ok
 
 
-CASES = dict(knn=knn_case, radius=radius_case, grid=grid_case, fps=fps_case, transpose=transpose_case, cbl=cbl_case)
+def _held(fn, *args):
+    """a hand-written test's body on drawn parameters: True if its assertions hold"""
+    try:
+        fn(*args)
+        return True
+    except AssertionError as e:
+        print("FAIL", fn.__name__, args[1:], str(e).replace("\n", " ")[:160])
+        return False
+
+
+def _full(names):
+    L = lib()
+    for name in names:
+        getattr(L, name).restype = ctypes.c_size_t
+    return L
+
+
+def gather_case(rng, it):
+    """queryandgroup / grouping / interpolation / subtraction / aggregation (tests/test_pointops_gather_host.py's checks) over point counts, neighbour counts and
+    channel counts on both sides of every kernel choice: one query point, K = 1, channel counts that are not a multiple of 4, rows that start on 4-byte boundaries"""
+    import tests.test_pointops_gather_host as T
+    L = lib()
+    which = int(rng.integers(0, 5))
+    n = int(rng.choice([20, 64, 65, 300, 1000, 2100])); m = n if rng.random() < 0.5 else min(n, int(rng.choice([1, 7, 64, 150])))
+    K = min(n, int(rng.choice([1, 2, 3, 8, 9, 16, 17, 32, 36])))
+    c = int(rng.choice([1, 3, 4, 6, 8, 16, 32, 33, 64, 72, 128, 132]))
+    if which == 0:
+        return _held(T.test_queryandgroup, L, n, m, K, c, int(rng.integers(0, 2)))
+    if which == 1:
+        return _held(T.test_grouping, L, n, m, K, c)
+    if which == 2:
+        return _held(T.test_interpolation, L, max(n, 4), m, c)
+    if which == 3:
+        return _held(T.test_subtraction, L, n, K, c)
+    c8 = int(rng.choice([8, 16, 32, 64, 128]))
+    return _held(T.test_aggregation, L, n, K, c8, int(rng.choice([1, c8 // 8, c8])))
+
+
+def aggregation_case(rng, it):
+    """KPConv (MFMA and general kernels, scatter and gather backward), AdaptiveWeight, PosPool (tests/test_local_aggregation_host.py's checks): K = 1 .. 64 with
+    shadow neighbours, widths 4 .. 288, 1 .. 16 kernel points"""
+    import tests.test_local_aggregation_host as T
+    L = _full(["cbl_neighbor_transpose_workspace_bytes", "cbl_adaptive_weight_backward_csr_workspace_bytes", "cbl_kpconv_backward_csr_workspace_bytes",
+               "cbl_pospool_backward_csr_workspace_bytes"])
+    which = int(rng.integers(0, 5))
+    if which in (0, 2):
+        K = int(rng.choice([1, 2, 3, 15, 16, 17, 31, 33, 48, 64])); C = int(rng.choice([4, 8, 12, 16, 20, 32, 64, 68, 72, 128] if which == 0 else [4, 8, 16, 32, 64, 72]))
+        args = (K, C, int(rng.choice([1, 2, 7, 15, 16])), str(rng.choice(["linear", "constant"])), str(rng.choice(["sum", "closest"])))
+        return _held(T.test_kpconv_forward_and_backward if which == 0 else T.test_kpconv_backward_as_a_gather, L, *args)
+    if which in (1, 3):
+        args = (int(rng.choice([1, 2, 9, 16, 26, 33, 41, 64])), int(rng.choice([4, 8, 16, 40, 64, 72, 144, 288])), str(rng.choice(["mean", "sum"])))
+        return _held(T.test_adaptive_weight_forward_and_backward if which == 1 else T.test_adaptive_weight_backward_as_a_gather, L, *args)
+    return _held(T.test_pospool_forward_and_backward, L, int(rng.choice([1, 2, 9, 16, 26, 41, 64])), int(rng.choice([6, 12, 18, 24, 36, 72])),
+                 str(rng.choice(["xyz", "sin_cos"])), str(rng.choice(["mean", "sum", "max"])))
+
+
+def attention_case(rng, it):
+    """the attention passes and the fused layer, narrow and wide (tests/test_attention_host.py, test_pt_layer_host.py, test_pt_layer_wide_host.py): point counts that
+    leave lane groups without a point, K = 1 .. 64 for the passes, every width"""
+    import tests.test_attention_host as A
+    import tests.test_pt_layer_host as T
+    import tests.test_pt_layer_wide_host as W
+    L = _full(["cbl_attn_workspace_bytes", "cbl_neighbor_transpose_workspace_bytes", "cbl_triple_linear_workspace_bytes", "cbl_pt_layer_workspace_bytes"])
+    which = int(rng.integers(0, 5))
+    n = int(rng.choice([9, 15, 16, 17, 63, 64, 65, 130, 400])); K = int(rng.choice([1, 2, 3, 8, 9, 16, 17, 32, 33, 64])); C = int(rng.choice([32, 64, 128, 256]))
+    if which == 0:
+        return _held(A.test_attention_logits_pass, L, n, K, C)
+    if which == 1:
+        return _held(A.test_attention_aggregation_pass, L, n, K, C, bool(rng.integers(0, 2)))
+    if which == 2:
+        return _held(A.test_three_projections_in_one_launch, L, int(rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 255, 1000])), int(rng.choice([32, 64])))
+    if which == 3:
+        return _held(T.test_layer_kernels_on_the_host_against_autograd, L, int(rng.choice([16, 17, 31, 33, 47, 64, 65, 100, 130])), int(rng.choice([8, 16])),
+                     int(rng.choice([32, 64])), bool(rng.integers(0, 2)))
+    return _held(W.test_wide_layer_on_the_host_against_autograd, L, int(rng.choice([17, 23, 40, 64, 65])), int(rng.choice([8, 16])), int(rng.choice([128, 256, 512])))
+
+
+CASES = dict(knn=knn_case, radius=radius_case, grid=grid_case, fps=fps_case, transpose=transpose_case, cbl=cbl_case, gather=gather_case, aggregation=aggregation_case,
+             attention=attention_case)
 
 
 def run(which, seed, iters):

@@ -221,8 +221,9 @@ static inline void __threadfence_block() {}
 static inline void __threadfence() {}
 static inline long long __double_as_longlong(double d) { long long v; std::memcpy(&v, &d, 8); return v; }
 static inline double __longlong_as_double(long long v) { double d; std::memcpy(&d, &v, 8); return d; }
-template <class T> static inline void __builtin_nontemporal_store(T v, T* p) { *p = v; }
-template <class T> static inline T __builtin_nontemporal_load(const T* p) { return *p; }
+// (byte copies: a template argument loses the `aligned(4)` of the kernels' unaligned 16-byte vector type, and g++ would store it with movaps)
+template <class T> static inline void __builtin_nontemporal_store(T v, T* p) { std::memcpy((void*)p, &v, sizeof(T)); }
+template <class T> static inline T __builtin_nontemporal_load(const T* p) { T v; std::memcpy(&v, (const void*)p, sizeof(T)); return v; }
 template <class T> static inline T __shfl_up(T v, unsigned delta, int width = 64)
 {
     return emul::lanes_any(v, [&](int l) { const int i = l & (width - 1); return i >= (int)delta ? l - (int)delta : l; }, width);
