@@ -2,7 +2,7 @@
 sides of every dispatch threshold, ragged batches with one-point clouds, clouds smaller than K, coincident points, lattices and planes (exactly tied distances),
 shadow entries, hub targets, ignored labels, every contrast flavour.  tests/test_fuzz_host.py runs a bounded, seeded share of them; a campaign is
 
-    python tests/host_emul/fuzz_cases.py <knn|radius|grid|fps|transpose|cbl|gather|aggregation|attention> <seed> <cases>
+    python tests/host_emul/fuzz_cases.py <knn|radius|grid|subsample|fps|transpose|cbl|gather|aggregation|attention> <seed> <cases>
 
 What the round-5 campaign (a few thousand cases) found is in DESIGN.md 5: two numerical defects of the contrast kernels in extreme regimes (fixed, regression tests in
 tests/test_cbl_host.py) and one limit of the emulation (K > 64 of the brute-force search keeps its heap in LDS and every lane of the wave replays the same update —
@@ -134,6 +134,31 @@ def grid_case(rng, it):
     if not (np.array_equal(out_len, rl) and m == len(rp) and np.array_equal(op[:m].view(np.uint32), rp.view(np.uint32))):
         print("GRID MISMATCH", it, sizes, kind, dl, m, len(rp), out_len, rl); return False
     return True
+
+def subsample_case(rng, it):
+    """grid subsampling with features and labels (barycentres of points and features, majority label per column — the deterministic rule of oracle/tfops_oracle.c
+    where votes tie), cloud by cloud against the wrapper flavour of the oracle, bit for bit"""
+    b = int(rng.integers(1, 4)); sizes = [int(rng.integers(1, 500)) for _ in range(b)]; kind = int(rng.integers(0, 5))
+    xyz = np.concatenate([cloud(rng, n, kind) for n in sizes]); lens = np.int32(sizes); off = np.cumsum(lens).astype(np.int32); n = len(xyz)
+    dl = float(rng.choice([0.01, 0.1, 0.3, 5.0])); fd = int(rng.choice([1, 3, 5])); ld = int(rng.choice([1, 2]))
+    feat = rng.normal(size=(n, fd)).astype(np.float32); labels = rng.integers(0, int(rng.choice([2, 13])), (n, ld)).astype(np.int32)
+    op, of, ol = np.full((n, 3), np.nan, np.float32), np.full((n, fd), np.nan, np.float32), np.full((n, ld), -1, np.int32)
+    out_len, total = np.full(b, -1, np.int32), np.full(1, -1, np.int32)
+    nbytes = lib().cbl_grid_subsampling_workspace_bytes(b, n); ws = np.zeros(nbytes + 64, np.uint8)
+    rc = lib().cbl_grid_subsampling(b, n, P(xyz), P(off), F(dl), fd, P(feat), ld, P(labels), P(op), P(of), P(ol), P(out_len), P(total), P(ws), ctypes.c_size_t(nbytes), None)
+    ok = rc == 0
+    s = t = 0
+    for c in range(b):
+        e = s + int(lens[c])
+        fp, ff, fl, _ = O.grid_subsampling_full(xyz[s:e], feat[s:e], labels[s:e], dl)
+        k = fp.shape[0]
+        ok = (ok and int(out_len[c]) == k and np.array_equal(op[t:t + k].view(np.uint32), fp.view(np.uint32)) and np.array_equal(of[t:t + k].view(np.uint32), ff.view(np.uint32))
+              and np.array_equal(ol[t:t + k], fl))
+        s, t = e, t + k
+    if not ok:
+        print("SUBSAMPLE MISMATCH", it, sizes, kind, dl, fd, ld, rc)
+    return ok
+
 
 def fps_case(rng, it):
     b = int(rng.integers(1, 4))
@@ -323,7 +348,7 @@ def attention_case(rng, it):
     return _held(W.test_wide_layer_on_the_host_against_autograd, L, int(rng.choice([17, 23, 40, 64, 65])), int(rng.choice([8, 16])), int(rng.choice([128, 256, 512])))
 
 
-CASES = dict(knn=knn_case, radius=radius_case, grid=grid_case, fps=fps_case, transpose=transpose_case, cbl=cbl_case, gather=gather_case, aggregation=aggregation_case,
+CASES = dict(knn=knn_case, radius=radius_case, grid=grid_case, subsample=subsample_case, fps=fps_case, transpose=transpose_case, cbl=cbl_case, gather=gather_case, aggregation=aggregation_case,
              attention=attention_case)
 
 
