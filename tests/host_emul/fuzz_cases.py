@@ -2,7 +2,7 @@
 sides of every dispatch threshold, ragged batches with one-point clouds, clouds smaller than K, coincident points, lattices and planes (exactly tied distances),
 shadow entries, hub targets, ignored labels, every contrast flavour.  tests/test_fuzz_host.py runs a bounded, seeded share of them; a campaign is
 
-    python tests/host_emul/fuzz_cases.py <knn|radius|grid|subsample|fps|transpose|cbl|gather|aggregation|attention> <seed> <cases>
+    python tests/host_emul/fuzz_cases.py <knn|radius|grid|subsample|pyramid|fps|transpose|cbl|gather|aggregation|attention> <seed> <cases>
 
 What the round-5 campaign (a few thousand cases) found is in DESIGN.md 5: two numerical defects of the contrast kernels in extreme regimes (fixed, regression tests in
 tests/test_cbl_host.py) and one limit of the emulation (K > 64 of the brute-force search keeps its heap in LDS and every lane of the wave replays the same update —
@@ -157,6 +157,52 @@ def subsample_case(rng, it):
         s, t = e, t + k
     if not ok:
         print("SUBSAMPLE MISMATCH", it, sizes, kind, dl, fd, ld, rc)
+    return ok
+
+
+def pyramid_case(rng, it):
+    """the ConvNet's input pyramid as one native call (cbl_pyramid, /root/reference/tensorflow/datasets/base.py:767-842) on drawn scenes — 1 .. 3 clouds, 1 .. 4 layers,
+    neighbourhood limits 1 .. 40 — against the oracle's operators applied layer by layer, every table bit for bit"""
+    L = _full(["cbl_pyramid_layer_workspace_bytes"])
+
+    def ptrs(arrs, count):
+        a = (ctypes.c_void_p * count)()
+        for i, x in enumerate(arrs):
+            a[i] = x.ctypes.data
+        return a
+    b = int(rng.integers(1, 4)); sizes = [int(rng.integers(1, 900)) for _ in range(b)]; kind = int(rng.choice([0, 0, 1, 2, 4]))
+    xyz = np.concatenate([cloud(rng, n, kind) for n in sizes]).astype(np.float32); lens = np.int32(sizes); n = len(xyz)
+    layers = int(rng.integers(1, 5)); r0 = float(rng.choice([0.05, 0.12, 0.3])); dl0 = float(rng.choice([0.02, 0.05, 0.15]))
+    limits = rng.integers(1, 41, layers).astype(np.int32)
+    gb = L.cbl_radius_neighbors_workspace_bytes(b, n)
+    grids = [np.zeros(gb + 64, np.uint8) for _ in range(layers)]
+    nb = [np.full((n, int(limits[l])), -5, np.int32) for l in range(layers)]
+    m1 = max(layers - 1, 1)
+    pp = [np.full((n, 3), np.nan, np.float32) for _ in range(m1)]; pl = [np.full(b, -1, np.int32) for _ in range(m1)]
+    po = [np.full((n, int(limits[min(l, layers - 1)])), -5, np.int32) for l in range(m1)]; up = [np.full((n, int(limits[min(l, layers - 1)])), -5, np.int32) for l in range(m1)]
+    mx, sizes_out = np.full(3 * layers, -1, np.int32), np.full(layers, -1, np.int32)
+    nbytes = L.cbl_pyramid_layer_workspace_bytes(b, n); ws = np.zeros(nbytes + 64, np.uint8)
+    many = layers > 1
+    rc = L.cbl_pyramid(b, n, P(xyz), P(lens), F(r0), F(dl0), layers, P(limits), ptrs(grids, layers), ctypes.c_size_t(gb), ptrs(nb, layers),
+                       ptrs(pp, m1) if many else None, ptrs(pl, m1) if many else None, ptrs(po, m1) if many else None, ptrs(up, m1) if many else None,
+                       P(mx), P(sizes_out), P(ws), ctypes.c_size_t(nbytes), None)
+    ok = rc == 0
+    pts, ln, r, dl = xyz, lens, r0, dl0
+    for l in range(layers):
+        if not ok:
+            break
+        m = pts.shape[0]; lim = int(limits[l])
+        ref, _, mc = O.radius_neighbors(pts, pts, ln, ln, r, lim)
+        ok = int(sizes_out[l]) == m and np.array_equal(nb[l][:m], ref) and int(mx[3 * l]) == mc
+        if l == layers - 1 or not ok:
+            break
+        sub, sl = O.grid_subsampling(pts, ln, 2 * dl); k = sub.shape[0]
+        ok = np.array_equal(pl[l], sl) and np.array_equal(pp[l][:k].view(np.uint32), sub.view(np.uint32))
+        ref, _, mc = O.radius_neighbors(sub, pts, sl, ln, r, lim); ok = ok and np.array_equal(po[l][:k], ref) and int(mx[3 * l + 1]) == mc
+        ref, _, mc = O.radius_neighbors(pts, sub, ln, sl, 2 * r, lim); ok = ok and np.array_equal(up[l][:m], ref) and int(mx[3 * l + 2]) == mc
+        pts, ln, r, dl = np.ascontiguousarray(sub), sl.astype(np.int32), 2 * r, 2 * dl
+    if not ok:
+        print("PYRAMID MISMATCH", it, sizes, kind, layers, r0, dl0, limits, rc)
     return ok
 
 
@@ -348,7 +394,7 @@ def attention_case(rng, it):
     return _held(W.test_wide_layer_on_the_host_against_autograd, L, int(rng.choice([17, 23, 40, 64, 65])), int(rng.choice([8, 16])), int(rng.choice([128, 256, 512])))
 
 
-CASES = dict(knn=knn_case, radius=radius_case, grid=grid_case, subsample=subsample_case, fps=fps_case, transpose=transpose_case, cbl=cbl_case, gather=gather_case, aggregation=aggregation_case,
+CASES = dict(knn=knn_case, radius=radius_case, grid=grid_case, subsample=subsample_case, pyramid=pyramid_case, fps=fps_case, transpose=transpose_case, cbl=cbl_case, gather=gather_case, aggregation=aggregation_case,
              attention=attention_case)
 
 
