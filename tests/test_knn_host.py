@@ -80,7 +80,8 @@ def run(L, entry, K, xyz, q, off, qoff):
 
 
 @pytest.mark.parametrize("kind,sizes,K", [("uniform", [2300], 16), ("uniform", [2300], 36), ("surface", [2500], 8), ("lattice", [2200], 16),
-                                          ("lattice", [2100], 36), ("uniform", [2100, 300], 16), ("grid", [2197], 16)])
+                                          ("lattice", [2100], 36), ("uniform", [2100, 300], 16),
+                                          pytest.param("grid", [2197], 16, marks=pytest.mark.skipif(not os.environ.get("CBL_HOST_EMUL_FULL"), reason="every row replayed: 16 s; set CBL_HOST_EMUL_FULL=1"))])
 def test_self_queries_equal_the_oracle_bit_for_bit(host, kind, sizes, K):
     xyz = np.concatenate([cloud(kind, n, 20 + i) + 2.5 * i for i, n in enumerate(sizes)])
     off = np.cumsum(sizes)
