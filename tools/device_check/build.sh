@@ -9,11 +9,11 @@ cd "$(dirname "$0")/../.."
 python -c "from contrastboundary_amd import build; build.build()"
 HOSTLIB=$(python -c "from tests.host_emul import full_library as f; import os; print(os.path.dirname(f.build()))")
 D=tools/device_check
-for p in cbl_check path_check float_check layer_check gather_time; do
+for p in cbl_check path_check float_check layer_check wide_check gather_time; do
     hipcc --offload-arch=gfx950 -O2 -std=c++17 $D/$p.cpp -o $D/${p}_dev -Lcontrastboundary_amd/lib -lcbl_amd -Wl,-rpath,'$ORIGIN/../../contrastboundary_amd/lib'
 done
 hipcc --offload-arch=gfx950 -O2 -std=c++17 $D/cbl_time.cpp -o $D/cbl_time_dev -ldl
-for p in cbl_check path_check float_check layer_check; do
+for p in cbl_check path_check float_check layer_check wide_check; do
     g++ -std=c++17 -O1 -DHOST_EMULATED $D/$p.cpp -o /tmp/${p}_host -L"$HOSTLIB" -lcbl_amd_host -Wl,-rpath,"$HOSTLIB"
 done
 echo "built: $D/*_dev, /tmp/cbl_check_host, /tmp/path_check_host"
