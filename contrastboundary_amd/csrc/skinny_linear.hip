@@ -509,7 +509,7 @@ template <int C>
 __global__ __launch_bounds__(256) void triple_linear_wgrad_kernel(long long rows, const float* __restrict__ x, RlTriple t3, float* __restrict__ partial)
 {
     constexpr int MT = C / 16, NTI = C / 16, WIDTH = C * C + C;
-    __shared__ float red[4][WIDTH];
+    __shared__ float red[2][WIDTH];                                 // two slots for four waves (33 KB at C = 64, was 66.5): waves 2, 3 store, waves 0, 1 add theirs on top
     const float* __restrict__ gy = t3.in[blockIdx.y];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, kq = lane >> 4;
     rl_f32x4 acc[MT][NTI];
@@ -537,20 +537,32 @@ __global__ __launch_bounds__(256) void triple_linear_wgrad_kernel(long long rows
             for (int tn = 0; tn < NTI; tn++) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
     }
 #pragma unroll
-    for (int tm = 0; tm < MT; tm++)
+    for (int tm = 0; tm < MT; tm++) { sb[tm] += __shfl_xor(sb[tm], 16); sb[tm] += __shfl_xor(sb[tm], 32); }
+    float* slot = red[wave & 1];                                     // every element of a slot belongs to one lane of the wave that owns it
+    if (wave >= 2) {
 #pragma unroll
-        for (int tn = 0; tn < NTI; tn++)
+        for (int tm = 0; tm < MT; tm++) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) red[wave][(16 * tm + 4 * kq + r) * C + 16 * tn + col] = acc[tm][tn][r];
+            for (int tn = 0; tn < NTI; tn++)
 #pragma unroll
-    for (int tm = 0; tm < MT; tm++) {
-        float v = sb[tm];
-        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-        if (kq == 0) red[wave][C * C + 16 * tm + col] = v;
+                for (int r = 0; r < 4; r++) slot[(16 * tm + 4 * kq + r) * C + 16 * tn + col] = acc[tm][tn][r];
+            if (kq == 0) slot[C * C + 16 * tm + col] = sb[tm];
+        }
+    }
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+        for (int tm = 0; tm < MT; tm++) {
+#pragma unroll
+            for (int tn = 0; tn < NTI; tn++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) slot[(16 * tm + 4 * kq + r) * C + 16 * tn + col] += acc[tm][tn][r];
+            if (kq == 0) slot[C * C + 16 * tm + col] += sb[tm];
+        }
     }
     __syncthreads();
     float* mine = partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * WIDTH;
-    for (int e = threadIdx.x; e < WIDTH; e += 256) mine[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    for (int e = threadIdx.x; e < WIDTH; e += 256) mine[e] = red[0][e] + red[1][e];
 }
 
 __global__ __launch_bounds__(1024) void triple_linear_wgrad_finalize_kernel(int C, int nblocks, const float* __restrict__ partial, RlTriple t3)
