@@ -314,6 +314,9 @@ def cbl_case(rng, it, extreme=True):
     if not ok:
         print("CBL MISMATCH", it, "tf" if tf else "pt", contrast, "S" if sep else "", n, nsample, d, ncls, T, "loss", float(loss[0]), float(rl), "gerr", gerr,
               "nan ours / oracle", int(np.isnan(np.array(grad)).sum()), int(np.isnan(rg).sum()))
+        if os.environ.get("CBL_FUZZ_DUMP"):                          # the case as arrays, for a closer look
+            np.savez(os.path.join(os.environ["CBL_FUZZ_DUMP"], "cbl_case_%d.npz" % it), feat=np.array(feat), lab=lab, idx=idx, T=T, weight=weight, flags=flags,
+                     grad=np.array(grad), rg=rg, coef=coef, own=np.array(own), mask=mask, stats=stats, per_point=per_point)
     return ok
 
 
