@@ -17,6 +17,7 @@
 #include "cbl_common.h"
 #include <cstdlib>
 #include "grid_core.h"
+#include <knn_wave.h>
 
 int cbl_knn_exact_worklist(int b, int m, int K, const float* xyz, const float* new_xyz, const int* offset,
                            const int* new_offset, int* idx, float* dist2,
@@ -418,11 +419,7 @@ __global__ __launch_bounds__(256) void knn_grid_group_kernel(int b, int m, int K
                             const int d2i = __float_as_int(d2);
                             auto step = [&]() {                               // each group inserts its next passing candidate
                                 const bool has = gm != 0;
-#ifdef CBL_HOST_WAVE_EMULATION                                      // tests/host_emul: find-first-bit-low of a 32-bit value, -1 when empty
-                                const int l = gm ? __builtin_ctz((unsigned)gm) : -1;
-#else
-                                int l; asm("v_ffbl_b32 %0, %1" : "=v"(l) : "v"(gm));      // -1 when empty: any lane, masked by `has`
-#endif
+                                const int l = kw_ffbl(gm);                    // -1 when empty: any lane, masked by `has`
                                 gm &= gm - 1;
                                 const int src = (l << 2) + grp * (G * 4);
                                 int dci = __builtin_amdgcn_ds_bpermute(src, d2i); const int ic = __builtin_amdgcn_ds_bpermute(src, ci);
@@ -538,11 +535,7 @@ __global__ __launch_bounds__(256) void knn_grid_wave_kernel(int b, int m, int K,
         // operands (gfx9 allows one), so the compiler would copy the scalar into a register at every use (3 VALU per row and block, not 2)
         int delta_v[9];
 #pragma unroll
-#ifdef CBL_HOST_WAVE_EMULATION                                      // tests/host_emul: a plain copy (the device line below only chooses the register class)
-        for (int r = 0; r < 9; r++) delta_v[r] = delta[r];
-#else
-        for (int r = 0; r < 9; r++) asm volatile("v_mov_b32 %0, %1" : "=v"(delta_v[r]) : "s"(delta[r]));
-#endif
+        for (int r = 0; r < 9; r++) delta_v[r] = kw_in_vgpr(delta[r]);
         // four blocks of 64 candidates at a time: their loads are all issued before the first distance is computed (one memory
         // round trip per four blocks instead of one per block — the wave's lifetime was dominated by those waits); positions
         // past T read the last candidate again (no divergent branch around the load) and are masked afterwards
