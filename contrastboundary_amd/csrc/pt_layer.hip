@@ -98,8 +98,11 @@ template <int K> __device__ __forceinline__ PtS0 pt_stage0(unsigned tile, unsign
 // level 0 three tiles ahead, level 1 two, level 2 (the rows) one.  Two tiles per trip of the loop, so that the two row buffers alternate
 // without register copies (a copy of a just-requested value would wait for it); inside a phase the small levels are requested BEFORE the rows:
 // memory returns in request order, so rotating the small values at the end of the trip waits for them only, the rows stay in flight.
-template <class L0, class L1, class L2, class CP>
-__device__ __forceinline__ void pt_pipeline(unsigned ntiles, L0 load0, L1 load1, L2 load2, CP compute)
+// `pre` runs once, after the first tiles' loads are issued and before the first compute: a pass's in-consumer finalize (pt_fin_forward / pt_fin_backward) waits
+// for its own round trip under the prefetch instead of in front of it.
+struct PtNoPre { __device__ __forceinline__ void operator()() const {} };
+template <class L0, class L1, class L2, class CP, class PRE = PtNoPre>
+__device__ __forceinline__ void pt_pipeline(unsigned ntiles, L0 load0, L1 load1, L2 load2, CP compute, PRE pre = PRE())
 {
     const unsigned ntrips = (ntiles + PT_WPB - 1) / PT_WPB, vend = 8u * cbl_xcd_per(ntrips), step = gridDim.x, wave = threadIdx.x >> 6;
     auto tile_of = [&](unsigned v) -> unsigned { return v < vend ? cbl_xcd_slot(v, ntrips) * PT_WPB + wave : 0xffffffffu; };
@@ -107,6 +110,7 @@ __device__ __forceinline__ void pt_pipeline(unsigned ntiles, L0 load0, L1 load1,
     auto a0 = load0(tile_of(v)); auto a1 = load0(tile_of(v + step)); auto a2 = load0(tile_of(v + 2 * step));
     auto b0 = load1(a0); auto b1 = load1(a1);
     auto c0 = load2(a0, b0);
+    pre();
     for (; v < vend; v += 2 * step) {
         auto a3 = load0(tile_of(v + 3 * step));
         auto b2 = load1(a2);
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(PT_FIN_THREADS) void pt_bn_bwd_finalize_kernel(int 
 // plain column sums of partial rows (parameter gradients): out[seg.dst + t] = sum over rows of partial[row * stride + off + t]
 struct PtSumSeg { const float* src; float* dst; int nrows, stride, off, count; };
 struct PtSumSegs { PtSumSeg s[6]; int n; };
-__global__ __launch_bounds__(PT_FIN_THREADS) void pt_sum_rows_kernel(PtSumSegs segs)
+__device__ __forceinline__ void pt_sum_rows_body(const PtSumSegs& segs)
 {
     __shared__ double red[64][16];
     int b = blockIdx.x;
@@ -314,6 +318,108 @@ __global__ __launch_bounds__(PT_FIN_THREADS) void pt_sum_rows_kernel(PtSumSegs s
         if (sl == 0 && c < sg.count) { double s = 0.0; for (int j = 0; j < 64; j++) s += red[j][cl]; sg.dst[c] = (float)s; }
         return;
     }
+}
+
+__global__ __launch_bounds__(PT_FIN_THREADS) void pt_sum_rows_kernel(PtSumSegs segs) { pt_sum_rows_body(segs); }
+
+// ---- statistics finalize inside the CONSUMER pass ------------------------------------------------------------------------------------
+// The narrow BatchNorms (BN_p: 3 channels, BN_g: G <= 8) have partial rows of <= 32 floats: instead of a one-workgroup finalize launch between the
+// producer and the consumer (5 - 6 us of kernel + the launch boundary, four times per layer and direction pair), every workgroup of the consumer sums
+// the producer's partial rows itself — in double, in one fixed order, so all workgroups hold the same bits — and workgroup 0 also writes what the later
+// passes read (consts, running statistics, parameter gradients).  BN_c (2 C = 128 columns x 512 rows per workgroup) keeps its finalize launch.
+struct PtFin {
+    const float* partial; int nrows, stride; long long rows;
+    const float* gamma; const float* beta; float eps, momentum;
+    float* running_mean; float* running_var; long long* num_batches; float* consts;
+};
+// column sums [0, ncols <= PITCH <= 32) of partial (nrows x stride): a thread fetches one ROW (independent 8-byte loads, one memory round trip per NT rows —
+// a thread that walks a column pays a dependent round trip per row it owns: measured 8 - 17 us per workgroup with every workgroup of the launch reading the
+// same lines), parks it in LDS, and thread (column t % 32, slice t / 32) sums its NT / 32 rows of the chunk from there in double; chunks and slices in a fixed
+// order.  Rows and the row stride are 8-byte aligned (every partial-row layout of this file is: strides 18, 16, 8, 88, 28).
+// scratch: NT * PITCH floats + NT + 32 doubles of LDS; returns the totals (valid for every thread after the call's barrier)
+template <int NT, int PITCH>
+__device__ __forceinline__ const double* pt_colsum_block(const float* __restrict__ partial, int nrows, int stride, int ncols, float* scratch_f)
+{
+    constexpr int S = NT / 32, NQ = PITCH / 2;
+    float* rows = scratch_f;                                          // [NT][PITCH]
+    double* scratch = reinterpret_cast<double*>(scratch_f + NT * PITCH);
+    const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int nq = (ncols + 1) >> 1;
+    double acc = 0.0;
+    for (int base = 0; base < nrows; base += NT) {
+        const int r = base + threadIdx.x;
+        float2 v[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) v[q] = (q < nq && r < nrows) ? *reinterpret_cast<const float2*>(partial + (size_t)r * stride + 2 * q) : make_float2(0.f, 0.f);
+        if (base) __syncthreads();                                    // the previous chunk is consumed
+#pragma unroll
+        for (int q = 0; q < NQ; q++) *reinterpret_cast<float2*>(rows + threadIdx.x * PITCH + 2 * q) = v[q];
+        __syncthreads();
+        if (c < ncols) {
+            const int lim = min(NT, nrows - base);
+            for (int rr = sl; rr < lim; rr += S) acc += (double)rows[rr * PITCH + c];
+        }
+    }
+    scratch[threadIdx.x] = acc;
+    __syncthreads();
+    if ((int)threadIdx.x < ncols) { double t = 0.0; for (int j = 0; j < S; j++) t += scratch[j * 32 + threadIdx.x]; scratch[NT + threadIdx.x] = t; }
+    __syncthreads();
+    return scratch + NT;
+}
+// forward: scale / shift of n_bn <= 16 channels (sums at columns [0, n_bn), squares at [off1, off1 + n_bn)) -> fout[c], fout[16 + c] (LDS floats behind the doubles);
+// workgroup 0: consts (scale, shift, mean, invstd at cst_off + {0, 1, 2, 3} cst_stride), the raw sums of the first n_raw columns at raw_off, running statistics.
+// The caller reads fout and passes a barrier before the scratch memory is used for anything else.
+template <int NT, int PITCH>
+__device__ __forceinline__ const float* pt_fin_forward(const PtFin& f, int n_bn, int off1, int ncols, int cst_off, int cst_stride, int n_raw, int raw_off, float* scratch)
+{
+    const double* tot = pt_colsum_block<NT, PITCH>(f.partial, f.nrows, f.stride, ncols, scratch);
+    float* fout = scratch;                                            // the row chunk is consumed: [2][16] floats over it
+    if ((int)threadIdx.x < n_bn) {
+        const int c = threadIdx.x;
+        const double mu = tot[c] / (double)f.rows;
+        double var = tot[off1 + c] / (double)f.rows - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+        const float scale = f.gamma[c] * invstd, shift = f.beta[c] - (float)mu * scale;
+        fout[c] = scale; fout[16 + c] = shift;
+        if (blockIdx.x == 0) {
+            float* cst = f.consts + cst_off;
+            cst[c] = scale; cst[cst_stride + c] = shift; cst[2 * cst_stride + c] = (float)mu; cst[3 * cst_stride + c] = invstd;
+            if (f.running_mean) f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mu;
+            if (f.running_var) f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)(f.rows > 1 ? var * (double)f.rows / (double)(f.rows - 1) : var);
+        }
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < n_raw) f.consts[raw_off + threadIdx.x] = (float)tot[threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && f.num_batches) f.num_batches[0] += 1;
+    __syncthreads();
+    return fout;
+}
+
+// backward: d x = A1 d y + A2 x + A3 of Cn <= 8 channels from the sums S1 = sum d y (columns [0, Cn)) and S2 = sum d y xhat ([Cn, 2 Cn)) -> fout[c], fout[8 + c],
+// fout[16 + c]; workgroup 0: d gamma = S2, d beta = S1, and (lin_bias_grad) the gradient of a bias that feeds the BatchNorm directly (pt_bn_bwd_finalize_kernel)
+struct PtFinBwd {
+    const float* partial; int nrows, stride; long long rows;
+    const float* gamma; const float* cst; int cst_stride; const float* raw_x; float* g_gamma; float* g_beta; float* lin_bias_grad;
+};
+template <int NT, int PITCH>
+__device__ __forceinline__ const float* pt_fin_backward(const PtFinBwd& f, int Cn, float* scratch)
+{
+    const double* tot = pt_colsum_block<NT, PITCH>(f.partial, f.nrows, f.stride, 2 * Cn, scratch);
+    float* fout = scratch;                                            // the row chunk is consumed: [3][8] floats over it
+    if ((int)threadIdx.x < Cn) {
+        const int c = threadIdx.x;
+        const double s1 = tot[c], s2 = tot[Cn + c];
+        const double mean = (double)f.cst[2 * f.cst_stride + c], invstd = (double)f.cst[3 * f.cst_stride + c];
+        const double A1 = (double)f.gamma[c] * invstd, m1 = s1 / (double)f.rows, m2 = s2 / (double)f.rows;
+        const double A2 = -A1 * m2 * invstd, A3 = A1 * (m2 * invstd * mean - m1);
+        fout[c] = (float)A1; fout[8 + c] = (float)A2; fout[16 + c] = (float)A3;
+        if (blockIdx.x == 0) {
+            f.g_gamma[c] = (float)s2; f.g_beta[c] = (float)s1;
+            if (f.lin_bias_grad) f.lin_bias_grad[c] = (float)(A1 * s1 + A2 * (double)f.raw_x[c] + (double)f.rows * A3);
+        }
+    }
+    __syncthreads();
+    return fout;
 }
 
 // ---- the C-wide pair chain ------------------------------------------------------------------------------------------------------------
@@ -332,16 +438,16 @@ template <int C> __device__ __forceinline__ PtPe<C> pt_pe_load(const float* __re
 // partial row: sum w [C] | sum w^2 [C]
 template <int C, int K>
 __global__ __launch_bounds__(PT_BLOCK) void pt_wstats_kernel(int n, const int* __restrict__ order, const float* __restrict__ xq, const float* __restrict__ xk,
-                                                             const int* __restrict__ idx, const float* __restrict__ p0, const float* __restrict__ cst,
+                                                             const int* __restrict__ idx, const float* __restrict__ p0, PtFin fin_p,
                                                              const float* __restrict__ W3C, const float* __restrict__ b3C, float* __restrict__ p1,
                                                              float* __restrict__ partial)
 {
     constexpr int CT = C / 16;
-    __shared__ float tile[PT_WPB][PT_TROWS][PT_ROWF];
+    __shared__ __attribute__((aligned(16))) float tile[PT_WPB][PT_TROWS][PT_ROWF];
     const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4, wave = threadIdx.x >> 6;
     float (*T)[PT_ROWF] = tile[wave];
     const PtPe<C> pe = pt_pe_load<C>(W3C, b3C, lo, hi);
-    const float psc = hi < 3 ? cst[PT_CST_P + hi] : 0.f, psh = hi < 3 ? cst[PT_CST_P + 4 + hi] : 1.f;
+    float psc = 0.f, psh = 1.f;                                      // BN_p's scale / shift of channel hi (hi = 3: the 1 that multiplies the bias)
     float s0[CT][4], s1[CT][4];
 #pragma unroll
     for (int ct = 0; ct < CT; ct++)
@@ -368,6 +474,12 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_wstats_kernel(int n, const int* _
                     for (int v = 0; v < 4; v++) { s0[ct][v] += w[v]; s1[ct][v] = fmaf(w[v], w[v], s1[ct][v]); }
                 }
             }
+        },
+        [&]() {
+            // BN_p's constants from the p chain's partial rows (every workgroup the same bits; workgroup 0 keeps them in consts and moves the running statistics)
+            const float* fo = pt_fin_forward<PT_BLOCK, 18>(fin_p, 3, 3, 18, PT_CST_P, 4, 18, PT_FS_P, &tile[0][0][0]);
+            if (hi < 3) { psc = fo[hi]; psh = fo[16 + hi]; }
+            __syncthreads();                                         // the scratch becomes the waves' tiles
         });
     __syncthreads();                                                 // the tiles are done with: their LDS carries the workgroup's partial row now
     float* red = &tile[0][0][0];
@@ -444,70 +556,78 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_kernel(int n, const int* __res
     }
 }
 
-// ---- narrow forward: a = softmax over K of Linear(G,G)(ReLU(BN_g(w2)))   (lane = pair; the K pairs of a point are K consecutive lanes) ----
-template <int G, int K>
-__global__ __launch_bounds__(PT_NARROW_BLOCK) void pt_softmax_kernel(long long npairs, const float* __restrict__ w2, const float* __restrict__ cst,
-                                                                     const float* __restrict__ Wb, const float* __restrict__ bb, float* __restrict__ a)
-{
-    float sc[G], sh[G];
-#pragma unroll
-    for (int g = 0; g < G; g++) { sc[g] = cst[PT_CST_G + g]; sh[g] = cst[PT_CST_G + 8 + g]; }
-    const long long span = (npairs + 63) & ~63ll;                   // whole waves: the group moves need every lane
-    for (long long pp = (long long)blockIdx.x * PT_NARROW_BLOCK + threadIdx.x; pp < span; pp += (long long)gridDim.x * PT_NARROW_BLOCK) {
-        const bool valid = pp < npairs;
-        const long long p = valid ? pp : npairs - 1;
-        float x[G], l[G];
-#pragma unroll
-        for (int q = 0; q < G / 4; q++) {
-            const float4 t = *reinterpret_cast<const float4*>(w2 + p * G + 4 * q);
-            x[4 * q] = t.x; x[4 * q + 1] = t.y; x[4 * q + 2] = t.z; x[4 * q + 3] = t.w;
-        }
-#pragma unroll
-        for (int g = 0; g < G; g++) x[g] = fmaxf(fmaf(x[g], sc[g], sh[g]), 0.f);
-#pragma unroll
-        for (int o = 0; o < G; o++) {
-            float s = bb[o];
-#pragma unroll
-            for (int g = 0; g < G; g++) s = fmaf(Wb[o * G + g], x[g], s);
-            const float m = pt_group_max<K>(s);
-            const float e = expf(s - m);
-            l[o] = e / pt_group_sum<K>(e);
-        }
-        if (valid) {
-#pragma unroll
-            for (int q = 0; q < G / 4; q++) *reinterpret_cast<float4*>(a + p * G + 4 * q) = make_float4(l[4 * q], l[4 * q + 1], l[4 * q + 2], l[4 * q + 3]);
-        }
-    }
-}
-
-// ---- aggregation (channel-major): out[i, c] = sum_k (x_v[j] + pe) a[.., c % G] ---------------------------------------------------------
-// BWD: also d logits = a (d a - sum_k a d a) with d a[k, g] = sum over c = g (mod G) of d out[c] (x_v[j, c] + pe[c])
+// ---- softmax + aggregation (channel-major): a = softmax over K of Linear(G,G)(ReLU(BN_g(w2))); out[i, c] = sum_k (x_v[j] + pe) a[.., c % G] ----------
+// !BWD (forward): BN_g's constants come from the w2 pass's partial rows in the prologue (fin_g.nrows > 0; evaluation mode: from cst), the logits of
+// (slot lo, g = hi | hi + 4) are formed pair-major — the K slots of a point are K adjacent lanes of a row, so the softmax is two DPP folds —, pass through a
+// [slot][g] table in the wave's LDS tile into the channel-major operand a[slot 4 hi + v][lo % G], and are stored for the backward pass from that table
+// (16 bytes per lane).  The separate softmax launch of round 4 read w2 and wrote a (2 x 21 MB at (40960, 16, 64)) for 12 us + a launch boundary.
+// BWD: d logits = a (d a - sum_k a d a) with d a[k, g] = sum over c = g (mod G) of d out[c] (x_v[j, c] + pe[c])
 template <int C, int K, bool BWD>
 __global__ __launch_bounds__(PT_BLOCK) void pt_agg_kernel(int n, const int* __restrict__ order, const float* __restrict__ xv, const int* __restrict__ idx,
                                                           const float* __restrict__ p1, const float* __restrict__ W3C, const float* __restrict__ b3C,
-                                                          const float* __restrict__ a, float* __restrict__ out, const float* __restrict__ gout,
-                                                          float* __restrict__ glogit)
+                                                          float* __restrict__ a, float* __restrict__ out, const float* __restrict__ gout,
+                                                          float* __restrict__ glogit, const float* __restrict__ w2, const float* __restrict__ Wb,
+                                                          const float* __restrict__ bb, const float* __restrict__ cst, PtFin fin_g)
 {
     constexpr int CT = C / 16, G = C / 8, NX = BWD ? 1 : 0;
-    __shared__ float tile[PT_WPB][PT_TROWS][PT_ROWF];
+    constexpr int TILEF = PT_TROWS * PT_ROWF;
+    __shared__ __attribute__((aligned(16))) float lds[PT_WPB * TILEF + 96];     // the waves' tiles | forward: scale [8], shift [8], Wb [G][G], bb [8] — ONE array (pt_w2_bwd_kernel)
     const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4, wave = threadIdx.x >> 6;
-    float (*T)[PT_ROWF] = tile[wave];
+    float (*T)[PT_ROWF] = reinterpret_cast<float (*)[PT_ROWF]>(lds + wave * TILEF);
+    float* AT = &T[16][0];                                           // forward: the tile's softmax weights [slot][g] (rows 16.. hold nothing else when NX = 0)
+    float* ctab = lds + PT_WPB * TILEF;
     const PtPe<C> pe = pt_pe_load<C>(W3C, b3C, lo, hi);
+    const int o0 = hi < G ? hi : 0, o1 = G == 8 ? hi + 4 : 0;
     const unsigned ntiles = (unsigned)(((long long)n * K + 15) / 16);
-    struct S1 { int4 j; float p1x; float av[4]; };
+    struct S1 { int4 j; float p1x; float av[4]; float4 wlo, whi; };
     pt_pipeline(ntiles,
         [&](unsigned tl) { return pt_stage0<K>(tl, ntiles, n, order, lo, hi); },
         [&](const PtS0& t) {
             S1 b;
             b.j = *reinterpret_cast<const int4*>(idx + t.pD);
             b.p1x = hi < 3 ? p1[3 * (pt_ix)t.pA + hi] : 1.f;                     // A[pair slot lo][d = hi]
+            b.wlo = b.whi = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int v = 0; v < 4; v++) b.av[v] = a[(pt_ix)(t.pD + v) * G + (lo % G)];
+            for (int v = 0; v < 4; v++) b.av[v] = 0.f;
+            if (BWD) {
+#pragma unroll
+                for (int v = 0; v < 4; v++) b.av[v] = a[(pt_ix)(t.pD + v) * G + (lo % G)];
+            } else {                                                             // w2 of pair slot lo, all G values
+                b.wlo = *reinterpret_cast<const float4*>(w2 + (pt_ix)t.pA * G);
+                if (G == 8) b.whi = *reinterpret_cast<const float4*>(w2 + (pt_ix)t.pA * G + 4);
+            }
             return b;
         },
         [&](const PtS0& t, const S1& b) { return pt_stage_rows<C, K, NX>(xv, b.j, gout, nullptr, t.iD, lo, hi); },
         [&](const PtS0& t, const S1& b, const PtStaged<NX>& r) {
             pt_stage_store<K, NX>(T, r, lo, hi);
+            float av[4] = {b.av[0], b.av[1], b.av[2], b.av[3]};
+            if (!BWD) {
+                const float xin[8] = {b.wlo.x, b.wlo.y, b.wlo.z, b.wlo.w, b.whi.x, b.whi.y, b.whi.z, b.whi.w};
+                int z = 0;
+                asm volatile("" : "+v"(z));                           // opaque per tile: the table reads stay LDS reads inside the loop
+                const float* ct = ctab + z;
+                float l0 = ct[80 + o0], l1 = ct[80 + o1];
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    const float x = fmaxf(fmaf(xin[g], ct[g], ct[8 + g]), 0.f);
+                    l0 = fmaf(ct[16 + o0 * G + g], x, l0);
+                    if (G == 8) l1 = fmaf(ct[16 + o1 * G + g], x, l1);
+                }
+                // (v_exp_f32 / v_rcp_f32 forms measured: no faster — the pass is not bound by these)
+                const float e0 = expf(l0 - pt_group_max<K>(l0));
+                const float a0 = e0 / pt_group_sum<K>(e0);
+                if (hi < G) AT[lo * G + hi] = a0;
+                if (G == 8) {
+                    const float e1 = expf(l1 - pt_group_max<K>(l1));
+                    AT[lo * G + hi + 4] = e1 / pt_group_sum<K>(e1);
+                }
+                pt_wave_sync();
+#pragma unroll
+                for (int v = 0; v < 4; v++) av[v] = AT[(4 * hi + v) * G + (lo % G)];
+                // the four slots of this lane row are 4 G consecutive floats of `a`: lane lo < G stores 16 bytes of them
+                if (lo < G && t.vD) *reinterpret_cast<float4*>(a + (pt_ix)t.pD * G + 4 * lo) = *reinterpret_cast<const float4*>(&AT[4 * hi * G + 4 * lo]);
+            }
             pt_f32x4 val[CT];
 #pragma unroll
             for (int ct = 0; ct < CT; ct++) {
@@ -517,7 +637,7 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_agg_kernel(int n, const int* __re
             if (!BWD) {
 #pragma unroll
                 for (int ct = 0; ct < CT; ct++) {
-                    float o = fmaf(b.av[3], val[ct][3], fmaf(b.av[2], val[ct][2], fmaf(b.av[1], val[ct][1], b.av[0] * val[ct][0])));
+                    float o = fmaf(av[3], val[ct][3], fmaf(av[2], val[ct][2], fmaf(av[1], val[ct][1], av[0] * val[ct][0])));
                     o = pt_point_sum<K>(o);
                     if (t.vD && (K == 16 ? hi == 0 : (hi & 1) == 0)) out[(pt_ix)t.iD * C + 16 * ct + lo] = o;
                 }
@@ -534,13 +654,25 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_agg_kernel(int n, const int* __re
                 for (int v = 0; v < 4; v++) {
                     ga[v] += pt_row_ror8(ga[v]);                                     // the lanes lo = g (mod G)
                     if (G == 4) ga[v] += pt_row_ror4(ga[v]);
-                    dot = fmaf(b.av[v], ga[v], dot);
+                    dot = fmaf(av[v], ga[v], dot);
                 }
                 dot = pt_point_sum<K>(dot);
                 if (lo < G && t.vD) {
 #pragma unroll
-                    for (int v = 0; v < 4; v++) glogit[(pt_ix)(t.pD + v) * G + lo] = b.av[v] * (ga[v] - dot);
+                    for (int v = 0; v < 4; v++) glogit[(pt_ix)(t.pD + v) * G + lo] = av[v] * (ga[v] - dot);
                 }
+            }
+        },
+        [&]() {
+            if (!BWD) {
+                // the narrow constants live in an LDS table and are read where they are used (34 values per lane otherwise: 143 registers, one workgroup per CU)
+                if (fin_g.nrows > 0) {
+                    const float* fo = pt_fin_forward<PT_BLOCK, 2 * G>(fin_g, G, G, 2 * G, PT_CST_G, 8, G, PT_FS_G, lds);
+                    if ((int)threadIdx.x < G) { ctab[threadIdx.x] = fo[threadIdx.x]; ctab[8 + threadIdx.x] = fo[16 + threadIdx.x]; }
+                } else if ((int)threadIdx.x < G) { ctab[threadIdx.x] = cst[PT_CST_G + threadIdx.x]; ctab[8 + threadIdx.x] = cst[PT_CST_G + 8 + threadIdx.x]; }
+                if ((int)threadIdx.x < G * G) ctab[16 + threadIdx.x] = Wb[threadIdx.x];
+                if ((int)threadIdx.x < G) ctab[16 + 64 + threadIdx.x] = bb[threadIdx.x];
+                __syncthreads();                                             // table complete; the scratch becomes the waves' tiles
             }
         });
 }
@@ -610,13 +742,13 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
                                                              const float* __restrict__ bc, const float* __restrict__ W3C, const float* __restrict__ b3C,
                                                              const float* __restrict__ Wa, const float* __restrict__ w2, const float* __restrict__ pre,
                                                              float* __restrict__ gw2, const float* __restrict__ a, const float* __restrict__ gout,
-                                                             float* __restrict__ gxq, float* __restrict__ gp1, float* __restrict__ partial)
+                                                             float* __restrict__ gxq, float* __restrict__ gp1, float* __restrict__ partial, PtFinBwd fin_g)
 {
     constexpr int CT = C / 16, G = C / 8;
     constexpr int W = APPLY ? 4 * C : 2 * C + G * C;
     constexpr int TILEF = PT_TROWS * PT_ROWF;
     constexpr int CTF = APPLY ? (5 + G + 3) * C : 0;                  // APPLY's per-channel constants: scale, shift, k1, k2, k3 | Wa [G][C] | W3C transposed [3][C]
-    __shared__ float lds[PT_WPB * (W > TILEF ? W : TILEF) + CTF];    // the waves' staged tiles (then the workgroup's partial row) | CTF — ONE array: a second
+    __shared__ __attribute__((aligned(16))) float lds[PT_WPB * (W > TILEF ? W : TILEF) + CTF];    // the waves' staged tiles (then the workgroup's partial row) | CTF — ONE array: a second
                                                                      // __shared__ object makes the compiler drain the prefetched loads before every LDS read
     const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4, wave = threadIdx.x >> 6;
     float (*T)[PT_ROWF] = reinterpret_cast<float (*)[PT_ROWF]>(lds + wave * TILEF);
@@ -647,12 +779,6 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
     }
     // BN_g backward constants of the narrow values this lane forms: g = hi, hi + 4 (pair-major operand of d y) and g = lo (operand of d Wa)
     float ga1[3] = {0.f, 0.f, 0.f}, ga2[3] = {0.f, 0.f, 0.f}, ga3[3] = {0.f, 0.f, 0.f};
-    if (!APPLY) {
-        const int gs[3] = {hi, hi + 4, lo};
-#pragma unroll
-        for (int t = 0; t < 3; t++)
-            if (gs[t] < G) { ga1[t] = bc[PT_BC_G + gs[t]]; ga2[t] = bc[PT_BC_G + 8 + gs[t]]; ga3[t] = bc[PT_BC_G + 16 + gs[t]]; }
-    }
     // accw: REDUCE d Wa[g][channel] in matrix accumulators (rows g: 8 of 16 used); APPLY d [W3C | b3C][channel][d] as four plain sums per channel block —
     // the f32 matrix instruction runs at the vector rate (32 cycles = 16 v_fma issue slots per 16 x 16 x 4 tile), so a product that uses 4 of its 16 rows
     // costs four times the 16 v_fma that do the same work (round 5: per-tile issue cycles 2 VALU + 32 MFMA explain every pass of this file)
@@ -763,6 +889,16 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
                     if (t.vD && lo < 3) gp1[3 * (pt_ix)(t.pD + v) + lo] = lo == 0 ? r0 : (lo == 1 ? r1 : r2);
                 }
             }
+        },
+        [&]() {
+            if (APPLY) return;
+            // BN_g's backward coefficients from the narrow backward pass's partial rows, in every workgroup (pt_fin_backward); workgroup 0 writes d gamma_g, d beta_g, d ba
+            const float* fo = pt_fin_backward<PT_BLOCK, 2 * G>(fin_g, G, lds);
+            const int gs[3] = {hi, hi + 4, lo};
+#pragma unroll
+            for (int t = 0; t < 3; t++)
+                if (gs[t] < G) { ga1[t] = fo[gs[t]]; ga2[t] = fo[8 + gs[t]]; ga3[t] = fo[16 + gs[t]]; }
+            __syncthreads();                                         // the scratch becomes the waves' tiles
         });
     // workgroup partial row
     __syncthreads();                                                 // every wave is done with its tile
@@ -834,9 +970,9 @@ __global__ __launch_bounds__(PT_NARROW_BLOCK) void pt_pchain_bwd_kernel(long lon
 }
 
 // one workgroup: gradients of Linear(3,3) and BN_p from the backward sums T and the forward sums (BatchNorm's backward is linear in d)
-__global__ __launch_bounds__(PT_FIN_THREADS) void pt_pchain_epilogue_kernel(int nrows, const float* __restrict__ partial, long long rows, const float* __restrict__ cst,
-                                                                            const float* __restrict__ gamma_p, float* __restrict__ g_Wp, float* __restrict__ g_bp,
-                                                                            float* __restrict__ g_gamma_p, float* __restrict__ g_beta_p)
+__device__ __forceinline__ void pt_pchain_epilogue_body(int nrows, const float* __restrict__ partial, long long rows, const float* __restrict__ cst,
+                                                        const float* __restrict__ gamma_p, float* __restrict__ g_Wp, float* __restrict__ g_bp,
+                                                        float* __restrict__ g_gamma_p, float* __restrict__ g_beta_p)
 {
     __shared__ double red[64][16];
     __shared__ double T[16];
@@ -860,6 +996,13 @@ __global__ __launch_bounds__(PT_FIN_THREADS) void pt_pchain_epilogue_kernel(int 
             g_Wp[3 * a + b] = (float)(A * (T[6 + 3 * a + b] - m1 * R - m2 * invstd * (X - mean * R)));
         }
     }
+}
+
+__global__ __launch_bounds__(PT_FIN_THREADS) void pt_pchain_epilogue_kernel(int nrows, const float* __restrict__ partial, long long rows, const float* __restrict__ cst,
+                                                                            const float* __restrict__ gamma_p, float* __restrict__ g_Wp, float* __restrict__ g_bp,
+                                                                            float* __restrict__ g_gamma_p, float* __restrict__ g_beta_p)
+{
+    pt_pchain_epilogue_body(nrows, partial, rows, cst, gamma_p, g_Wp, g_bp, g_gamma_p, g_beta_p);
 }
 
 // ---- target pass: d x_k[j] and d x_v[j] as gathers over the transposed neighbour table -----------------------------------------------
@@ -953,10 +1096,19 @@ __global__ __launch_bounds__(64) void pt_chain_selftest_kernel(const float* __re
     }
 }
 
-unsigned pt_tile_grid(long long ntiles)
+// the backward pass's last launch: the parameter gradients' column sums (pt_sum_rows_kernel's blocks) and, in the block behind them, the p chain's epilogue
+__global__ __launch_bounds__(PT_FIN_THREADS) void pt_bwd_tail_kernel(PtSumSegs segs, int sum_blocks, int nrows, const float* __restrict__ partial, long long rows,
+                                                                     const float* __restrict__ cst, const float* __restrict__ gamma_p, float* __restrict__ g_Wp,
+                                                                     float* __restrict__ g_bp, float* __restrict__ g_gamma_p, float* __restrict__ g_beta_p)
+{
+    if ((int)blockIdx.x < sum_blocks) pt_sum_rows_body(segs);
+    else pt_pchain_epilogue_body(nrows, partial, rows, cst, gamma_p, g_Wp, g_bp, g_gamma_p, g_beta_p);
+}
+
+unsigned pt_tile_grid(long long ntiles, int max_rows = PT_MAX_ROWS)
 {
     const long long trips = (ntiles + PT_WPB - 1) / PT_WPB;
-    long long g = trips < PT_MAX_ROWS ? trips : PT_MAX_ROWS;
+    long long g = trips < max_rows ? trips : max_rows;
     g = (g + 7) & ~7ll;
     return (unsigned)(g < 8 ? 8 : g);
 }
@@ -997,6 +1149,7 @@ PtWs pt_workspace(float* base, int n, int K, int C)
 }
 
 static_assert(PT_NARROW_MAX_ROWS * 18 <= PT_MAX_ROWS * 4 * 32, "pchain's partial rows share part_b with the apply pass");
+static_assert((PT_BLOCK * 18 + 2 * (PT_BLOCK + 32)) <= PT_WPB * PT_TROWS * PT_ROWF, "the in-consumer finalize's scratch (rows of a chunk + the doubles) lies over the waves' tiles");
 bool pt_shape_ok(int n, int K, int C) { return n >= 1 && (K == 8 || K == 16) && (C == 32 || C == 64) && (long long)n * K < (1ll << 28); }   // 32-bit element indices (pt_ix): n K 8 and n C below 2^31
 
 }  // namespace
@@ -1037,24 +1190,23 @@ CBL_EXPORT int cbl_pt_layer_forward(int n, int K, int C, const float* xyz, const
     const long long np = (long long)n * K;
     const int G = C / 8;
     const unsigned gp = pt_pair_grid(np), gt = pt_tile_grid((np + 15) / 16);
+    // the passes that hold one workgroup per CU (reduce, apply: 148 - 189 registers; w2 at C = 64: 139): one per CU in the launch, so that the pass's start-up (constants,
+    // pipeline fill, in-consumer finalize) is paid once — the reduce pass 61.7 -> 53.4 us at (40960, 16, 64)
+    const unsigned gt1 = pt_tile_grid((np + 15) / 16, 256), gw = C == 64 ? gt1 : gt;
     float* rm[3] = {nullptr, nullptr, nullptr}; float* rv[3] = {nullptr, nullptr, nullptr}; long long* nb[3] = {nullptr, nullptr, nullptr};
     for (int t = 0; t < 3; t++) { if (running_mean3) rm[t] = running_mean3[t]; if (running_var3) rv[t] = running_var3[t]; if (num_batches3) nb[t] = num_batches3[t]; }
 
     hipLaunchKernelGGL(pt_pchain_kernel, dim3(gp), dim3(PT_NARROW_BLOCK), 0, st, np, cbl_fastdiv_make((unsigned)K), xyz, idx, Wp, bp, p_r, p0, ws.part_b, (const float*)nullptr, (float*)nullptr);
-    hipLaunchKernelGGL(pt_bn_finalize_kernel, dim3(2), dim3(PT_FIN_THREADS), 0, st, (int)gp, 18, ws.part_b, 3, 0, 3, np, gamma_p, beta_p, eps3[0], momentum3[0],
-                       rm[0], rv[0], nb[0], consts + PT_CST_P, 4, 18, consts + PT_FS_P);
-#define PT_WSTATS(CC, KK) hipLaunchKernelGGL((pt_wstats_kernel<CC, KK>), dim3(gt), dim3(PT_BLOCK), 0, st, n, order, x_q, x_k, idx, p0, consts, W3C, b3C, p1, ws.part_a)
+    // BN_p's finalize runs in the prologue of the statistics pass, BN_g's in the prologue of the softmax + aggregation pass (pt_fin_forward); BN_c keeps its launch
+    const PtFin fin_p = {ws.part_b, (int)gp, 18, np, gamma_p, beta_p, eps3[0], momentum3[0], rm[0], rv[0], nb[0], consts};
+    const PtFin fin_g = {ws.part_a, (int)gw, 2 * G, np, gamma_g, beta_g, eps3[2], momentum3[2], rm[2], rv[2], nb[2], consts};
+#define PT_WSTATS(CC, KK) hipLaunchKernelGGL((pt_wstats_kernel<CC, KK>), dim3(gt), dim3(PT_BLOCK), 0, st, n, order, x_q, x_k, idx, p0, fin_p, W3C, b3C, p1, ws.part_a)
     PT_DISPATCH(PT_WSTATS)
     hipLaunchKernelGGL(pt_bn_finalize_kernel, dim3(cbl_div_up(C, 16)), dim3(PT_FIN_THREADS), 0, st, (int)gt, 2 * C, ws.part_a, C, 0, C, np, gamma_c, beta_c, eps3[1],
                        momentum3[1], rm[1], rv[1], nb[1], consts + PT_CST_C, 64, 0, (float*)nullptr);
-#define PT_W2(CC, KK) hipLaunchKernelGGL((pt_w2_kernel<CC, KK>), dim3(gt), dim3(PT_BLOCK), 0, st, n, order, x_q, x_k, idx, p1, consts, W3C, b3C, Wa, ba, w2, ws.part_a)
+#define PT_W2(CC, KK) hipLaunchKernelGGL((pt_w2_kernel<CC, KK>), dim3(gw), dim3(PT_BLOCK), 0, st, n, order, x_q, x_k, idx, p1, consts, W3C, b3C, Wa, ba, w2, ws.part_a)
     PT_DISPATCH(PT_W2)
-    hipLaunchKernelGGL(pt_bn_finalize_kernel, dim3(1), dim3(PT_FIN_THREADS), 0, st, (int)gt, 2 * G, ws.part_a, G, 0, G, np, gamma_g, beta_g, eps3[2], momentum3[2],
-                       rm[2], rv[2], nb[2], consts + PT_CST_G, 8, G, consts + PT_FS_G);
-    const unsigned gs = cbl_grid_for(np, PT_NARROW_BLOCK, 1 << 16);   // a pair per thread, all in flight (no partial rows here: no cap)
-#define PT_SOFTMAX(GG, KK) hipLaunchKernelGGL((pt_softmax_kernel<GG, KK>), dim3(gs), dim3(PT_NARROW_BLOCK), 0, st, np, w2, consts, Wb, bb, a)
-    if (G == 8 && K == 16) { PT_SOFTMAX(8, 16); } else if (G == 8) { PT_SOFTMAX(8, 8); } else if (K == 16) { PT_SOFTMAX(4, 16); } else { PT_SOFTMAX(4, 8); }
-#define PT_AGG(CC, KK) hipLaunchKernelGGL((pt_agg_kernel<CC, KK, false>), dim3(gt), dim3(PT_BLOCK), 0, st, n, order, x_v, idx, p1, W3C, b3C, a, out, (const float*)nullptr, (float*)nullptr)
+#define PT_AGG(CC, KK) hipLaunchKernelGGL((pt_agg_kernel<CC, KK, false>), dim3(gt), dim3(PT_BLOCK), 0, st, n, order, x_v, idx, p1, W3C, b3C, a, out, (const float*)nullptr, (float*)nullptr, (const float*)w2, Wb, bb, (const float*)consts, fin_g)
     PT_DISPATCH(PT_AGG)
     return cbl_status();
 }
@@ -1096,15 +1248,17 @@ CBL_EXPORT int cbl_pt_layer_forward_eval(int n, int K, int C, const float* xyz, 
     const PtWs ws = pt_workspace(static_cast<float*>(workspace), n, K, C);
     hipStream_t st = cbl_stream(stream);
     const long long np = (long long)n * K;
-    const int G = C / 8;
     const unsigned gp = pt_pair_grid(np), gt = pt_tile_grid((np + 15) / 16);
+    // the passes that hold one workgroup per CU (reduce, apply: 148 - 189 registers; w2 at C = 64: 139): one per CU in the launch, so that the pass's start-up (constants,
+    // pipeline fill, in-consumer finalize) is paid once — the reduce pass 61.7 -> 53.4 us at (40960, 16, 64)
+    const unsigned gt1 = pt_tile_grid((np + 15) / 16, 256), gw = C == 64 ? gt1 : gt;
+    const int G = C / 8;
     hipLaunchKernelGGL(pt_eval_consts_kernel, dim3(1), dim3(128), 0, st, C, G, gamma_p, beta_p, gamma_c, beta_c, gamma_g, beta_g, running_mean3[0], running_var3[0],
                        running_mean3[1], running_var3[1], running_mean3[2], running_var3[2], eps3[0], eps3[1], eps3[2], consts);
     hipLaunchKernelGGL(pt_pchain_kernel, dim3(gp), dim3(PT_NARROW_BLOCK), 0, st, np, cbl_fastdiv_make((unsigned)K), xyz, idx, Wp, bp, p_r, p0, ws.part_b,
                        (const float*)consts, p1);
     PT_DISPATCH(PT_W2)
-    const unsigned gs = cbl_grid_for(np, PT_NARROW_BLOCK, 1 << 16);
-    if (G == 8 && K == 16) { PT_SOFTMAX(8, 16); } else if (G == 8) { PT_SOFTMAX(8, 8); } else if (K == 16) { PT_SOFTMAX(4, 16); } else { PT_SOFTMAX(4, 8); }
+    const PtFin fin_g = {nullptr, 0, 0, np, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, nullptr, consts};      // BN_g's constants are in consts already
     PT_DISPATCH(PT_AGG)
     return cbl_status();
 }
@@ -1126,21 +1280,25 @@ CBL_EXPORT int cbl_pt_layer_backward(int n, int K, int C, const float* x_q, cons
     const long long np = (long long)n * K;
     const int G = C / 8, WN = 3 * G + G * G;
     const unsigned gp = pt_pair_grid(np), gt = pt_tile_grid((np + 15) / 16);
+    // the passes that hold one workgroup per CU (reduce, apply: 148 - 189 registers; w2 at C = 64: 139): one per CU in the launch, so that the pass's start-up (constants,
+    // pipeline fill, in-consumer finalize) is paid once — the reduce pass 61.7 -> 53.4 us at (40960, 16, 64)
+    const unsigned gt1 = pt_tile_grid((np + 15) / 16, 256), gw = C == 64 ? gt1 : gt;
 
-#define PT_AGGB(CC, KK) hipLaunchKernelGGL((pt_agg_kernel<CC, KK, true>), dim3(gt), dim3(PT_BLOCK), 0, st, n, order, x_v, idx, p1, W3C, b3C, a, (float*)nullptr, grad_out, ws.glogit)
+    const PtFin no_fin = {nullptr, 0, 0, np, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr};
+#define PT_AGGB(CC, KK) hipLaunchKernelGGL((pt_agg_kernel<CC, KK, true>), dim3(gt), dim3(PT_BLOCK), 0, st, n, order, x_v, idx, p1, W3C, b3C, const_cast<float*>(a), (float*)nullptr, grad_out, ws.glogit, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, no_fin)
     PT_DISPATCH(PT_AGGB)
     if (G == 8) hipLaunchKernelGGL(pt_narrow_bwd_kernel<8>, dim3(gp), dim3(PT_NARROW_BLOCK), 0, st, np, w2, consts, Wb, ws.glogit, ws.pre, ws.part_c);
     else        hipLaunchKernelGGL(pt_narrow_bwd_kernel<4>, dim3(gp), dim3(PT_NARROW_BLOCK), 0, st, np, w2, consts, Wb, ws.glogit, ws.pre, ws.part_c);
-    hipLaunchKernelGGL(pt_bn_bwd_finalize_kernel, dim3(1), dim3(PT_FIN_THREADS), 0, st, (int)gp, WN, 0, G, G, np, ws.part_c, gamma_g, consts + PT_CST_G, 8, ws.bc + PT_BC_G, 8,
-                       g_gamma_g, g_beta_g, consts + PT_FS_G, g_ba);
-#define PT_REDUCE(CC, KK) hipLaunchKernelGGL((pt_w2_bwd_kernel<CC, KK, false>), dim3(gt), dim3(PT_BLOCK), 0, st, n, order, x_q, x_k, idx, p1, consts, ws.bc, W3C, b3C, Wa, w2, ws.pre, ws.gw2, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, ws.part_a)
+    // BN_g's backward finalize runs in the prologue of the reduce pass (pt_fin_backward)
+    const PtFinBwd fin_gb = {ws.part_c, (int)gp, WN, np, gamma_g, consts + PT_CST_G, 8, consts + PT_FS_G, g_gamma_g, g_beta_g, g_ba};
+    const PtFinBwd no_finb = {nullptr, 0, 0, np, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+#define PT_REDUCE(CC, KK) hipLaunchKernelGGL((pt_w2_bwd_kernel<CC, KK, false>), dim3(gt1), dim3(PT_BLOCK), 0, st, n, order, x_q, x_k, idx, p1, consts, ws.bc, W3C, b3C, Wa, w2, ws.pre, ws.gw2, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, ws.part_a, fin_gb)
     PT_DISPATCH(PT_REDUCE)
-    hipLaunchKernelGGL(pt_bn_bwd_finalize_kernel, dim3(cbl_div_up(C, 16)), dim3(PT_FIN_THREADS), 0, st, (int)gt, 2 * C + G * C, 0, C, C, np, ws.part_a, gamma_c, consts + PT_CST_C, 64,
+    hipLaunchKernelGGL(pt_bn_bwd_finalize_kernel, dim3(cbl_div_up(C, 16)), dim3(PT_FIN_THREADS), 0, st, (int)gt1, 2 * C + G * C, 0, C, C, np, ws.part_a, gamma_c, consts + PT_CST_C, 64,
                        ws.bc + PT_BC_C, 64, g_gamma_c, g_beta_c, (const float*)nullptr, (float*)nullptr);
-#define PT_APPLY(CC, KK) hipLaunchKernelGGL((pt_w2_bwd_kernel<CC, KK, true>), dim3(gt), dim3(PT_BLOCK), 0, st, n, order, x_q, x_k, idx, p1, consts, ws.bc, W3C, b3C, Wa, w2, ws.pre, ws.gw2, a, grad_out, g_xq, ws.gp1, ws.part_b)
+#define PT_APPLY(CC, KK) hipLaunchKernelGGL((pt_w2_bwd_kernel<CC, KK, true>), dim3(gt1), dim3(PT_BLOCK), 0, st, n, order, x_q, x_k, idx, p1, consts, ws.bc, W3C, b3C, Wa, w2, ws.pre, ws.gw2, a, grad_out, g_xq, ws.gp1, ws.part_b, no_finb)
     PT_DISPATCH(PT_APPLY)
     hipLaunchKernelGGL(pt_pchain_bwd_kernel, dim3(gp), dim3(PT_NARROW_BLOCK), 0, st, np, p_r, p0, p1, ws.gp1, consts, ws.part_d, (const float*)nullptr);
-    hipLaunchKernelGGL(pt_pchain_epilogue_kernel, dim3(1), dim3(PT_FIN_THREADS), 0, st, (int)gp, ws.part_d, np, consts, gamma_p, g_Wp, g_bp, g_gamma_p, g_beta_p);
     {
         const unsigned tg = cbl_round_up8(cbl_grid_for(((long long)n + (256 / (C / 4)) - 1) / (256 / (C / 4)), 1, 2048));
 #define PT_TARGET(CC, KK) hipLaunchKernelGGL((pt_target_kernel<CC, KK>), dim3(tg), dim3(256), 0, st, (unsigned)n, order, inv_start, inv_src, x_q, x_k, p1, consts, ws.bc, W3C, b3C, Wa, ws.gw2, a, grad_out, g_xk, g_xv)
@@ -1148,14 +1306,15 @@ CBL_EXPORT int cbl_pt_layer_backward(int n, int K, int C, const float* x_q, cons
     }
     PtSumSegs segs;
     segs.n = 5;
-    segs.s[0] = PtSumSeg{ws.part_a, g_Wa, (int)gt, 2 * C + G * C, 2 * C, G * C};
-    segs.s[1] = PtSumSeg{ws.part_b, g_W3C, (int)gt, 4 * C, 0, 3 * C};
-    segs.s[2] = PtSumSeg{ws.part_b, g_b3C, (int)gt, 4 * C, 3 * C, C};
+    segs.s[0] = PtSumSeg{ws.part_a, g_Wa, (int)gt1, 2 * C + G * C, 2 * C, G * C};
+    segs.s[1] = PtSumSeg{ws.part_b, g_W3C, (int)gt1, 4 * C, 0, 3 * C};
+    segs.s[2] = PtSumSeg{ws.part_b, g_b3C, (int)gt1, 4 * C, 3 * C, C};
     segs.s[3] = PtSumSeg{ws.part_c, g_Wb, (int)gp, WN, 2 * G, G * G};
     segs.s[4] = PtSumSeg{ws.part_c, g_bb, (int)gp, WN, 2 * G + G * G, G};
     unsigned nblk = 0;
     for (int q = 0; q < segs.n; q++) nblk += (unsigned)((segs.s[q].count + 15) / 16);
-    hipLaunchKernelGGL(pt_sum_rows_kernel, dim3(nblk), dim3(PT_FIN_THREADS), 0, st, segs);
+    // + the p chain's epilogue as one more block of the same launch
+    hipLaunchKernelGGL(pt_bwd_tail_kernel, dim3(nblk + 1), dim3(PT_FIN_THREADS), 0, st, segs, (int)nblk, (int)gp, ws.part_d, np, consts, gamma_p, g_Wp, g_bp, g_gamma_p, g_beta_p);
     return cbl_status();
 }
 

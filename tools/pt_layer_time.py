@@ -1,5 +1,5 @@
 """Per-kernel and per-pass timing of the Point-Transformer layer (csrc/pt_layer.hip) at a stage shape, eager, HIP events:
-    python tools/pt_layer_time.py [n K C]      -> one JSON line (layer forward / backward, new path and round 3's split kernels)"""
+    python tools/pt_layer_time.py [n K C] [--graph]      -> one JSON line (layer forward / backward: the fused path issued eagerly and as replayed hipGraphs ("graph"), and round 3's split kernels)"""
 import json
 import os
 import sys
@@ -22,8 +22,22 @@ def timed(fn, reps=20, warm=3):
     return a.elapsed_time(b) / reps * 1e3
 
 
+def graphed(fn):
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            fn()
+    torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        fn()
+    g.replay(); torch.cuda.synchronize()
+    return g
+
+
 def main():
-    n, K, C = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (40960, 16, 64)
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    n, K, C = (int(v) for v in args[:3]) if len(args) >= 3 else (40960, 16, 64)
     xyz = torch.from_numpy(S.s_room(n, seed=0)[0]).cuda(); o = torch.tensor([n], dtype=torch.int32, device="cuda")
     torch.manual_seed(0)
     x = torch.randn(n, C, device="cuda"); g = torch.randn(n, C, device="cuda")
@@ -44,6 +58,15 @@ def main():
         def both():
             fwd(); torch.autograd.grad(state["y"], [state["x"]] + params, g)
 
+        if mode is True and "--graph" in sys.argv:
+            # the two passes as replayed hipGraphs, BEFORE anything of this layer runs on the default stream (a parameter's gradient accumulator remembers the stream
+            # it was created on; a capture that meets one from the default stream crashes on ROCm 7.2): device time with the launch gaps a graph leaves, without
+            # the interpreter's issue time — the eager figures below are bounded by it at the small shapes (~25 launches of 5 - 25 us each)
+            gf = graphed(fwd); gb = graphed(bwd)
+            out["graph"] = {"fwd_us": round(timed(gf.replay), 1), "bwd_us": round(timed(gb.replay), 1)}
+            out["graph"]["fwd_bwd_us"] = round(out["graph"]["fwd_us"] + out["graph"]["bwd_us"], 1)
+            del gf, gb
+            print("graph", out["graph"], file=sys.stderr, flush=True)
         fwd(); torch.cuda.synchronize(); print('fwd ok', mode, file=sys.stderr, flush=True)
         bwd(); torch.cuda.synchronize(); print('bwd ok', mode, file=sys.stderr, flush=True)
         tag = "new" if mode is True else str(mode)
