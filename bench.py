@@ -49,9 +49,10 @@ def parse(argv=None):
     ap.add_argument("--points", type=int, default=None, help="points per scene (default: 40960 for the block, 200000 for the ConvNet workload)")
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--k", type=int, default=16)
-    ap.add_argument("--workload", choices=("block", "convnet"), default="block",
+    ap.add_argument("--workload", choices=("block", "convnet", "stage_shapes"), default="block",
                     help="block: BASELINE's headline (KNN + group + KPConv + CBL, N=40960); convnet: config C5 / the per-scene work of C3 "
-                         "(radius + grid pyramid of a 200000-point cloud, AdaptiveWeight forward + backward on its 5 layers, TF-side CBL)")
+                         "(radius + grid pyramid of a 200000-point cloud, AdaptiveWeight forward + backward on its 5 layers, TF-side CBL); stage_shapes: "
+                         "gather / attention layer / FPS at the Point Transformer's five REAL stage shapes (SURVEY 8 caveat), a measurement, no step")
     ap.add_argument("--block", choices=("kpconv", "pt"), default="kpconv",
                     help="local aggregation of the block: kpconv = BASELINE's headline (KNN + group + KPConv + CBL); pt = the Point Transformer's vector "
                          "attention layer in its place (BASELINE.md: a1 + a3 + a4 + a8, pytorch/model/blocks.py:31-44)")
@@ -317,21 +318,32 @@ def checked_pipeline_step(scene, k, backward, args, overlap, pipeline):
 
 def stage_times(scene, k, backward, args, reps=8):
     """per-stage device time: the step IN ORDER on one stream (a stage's time is that stage alone), HIP events on the launch stream around
-    every stage.  The steps are issued eagerly behind a filler kernel (~0.6 ms of device work), so the host is a whole step ahead of the
-    device and an interval holds the stage's kernels and their launch gaps, not the host.  (ROCm has no event-record graph nodes, and one
-    hipGraph per stage costs ~20 us of replay overhead per stage: measured, dropped.)"""
+    every stage.  The steps are issued eagerly behind filler kernels sized from the host's own issue time of one step (1.5 x), so the host is a
+    whole step ahead of the device and an interval holds the stage's kernels and their launch gaps, not the host.  (ROCm has no event-record
+    graph nodes, and one hipGraph per stage costs ~20 us of replay overhead per stage: measured, dropped.)"""
     st = Step(scene, k, backward, args, overlap=False)
     settle(st, 0.2)
     filler = torch.empty(1 << 31, dtype=torch.uint8, device="cuda")
+    # how long the host needs to issue one step, and how long one fill of the filler keeps the device busy: the step is issued behind enough fills that the
+    # device is still in them when the host is done (round 5: a fixed 0.6 ms was shorter than a slow host's issue time, and the late stages read host time)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); st.eager(); host_ms = (time.perf_counter() - t0) * 1e3
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); filler.fill_(0); b.record(); torch.cuda.synchronize()
+    fill_ms = max(a.elapsed_time(b), 0.05)
+    fills = int(min(64, max(2, np.ceil(1.5 * host_ms / fill_ms))))
     samples = []
     for _ in range(reps + 2):
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in st.stages]
-        filler.fill_(0); filler.fill_(1)
+        for f in range(fills):
+            filler.fill_(f & 1)
         st.eager(ev)
         torch.cuda.synchronize()
         samples.append([a.elapsed_time(b) for a, b in ev])
     del filler
-    how = "HIP events on the launch stream around every stage of eagerly issued in-order steps, each issued behind a 0.6 ms filler kernel (host ahead of the device), median of %d right after the timed region" % reps
+    how = ("HIP events on the launch stream around every stage of eagerly issued in-order steps, each issued behind %d fills of a 2 GiB buffer (%.2f ms of device work "
+           "for %.2f ms of host issue time per step: the host stays ahead of the device), median of %d right after the timed region" % (fills, fills * fill_ms, host_ms, reps))
     return st, [float(v) for v in np.median(np.asarray(samples[2:]), axis=0)], how
 
 
@@ -657,7 +669,7 @@ def workload_legs(args):
     def pick_pt(d):
         r = d.get("roofline", {})
         return {"roofline": {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "bytes_per_launch", "launch_us", "flops_per_launch",
-                                                  "achieved_TFLOPs", "frac_of_f32_mfma_peak", "layer_bwd_us", "stage_ms") if k in r},
+                                                  "achieved_TFLOPs", "frac_of_f32_mfma_peak", "layer_bwd_us", "layer_bwd_note", "stage_ms") if k in r},
                 "forward_only_ms_per_step": d.get("forward_only", {}).get("ms_per_step"),
                 "no_pipeline_ms_per_step": (d.get("no_pipeline") or {}).get("ms_per_step"),
                 "pipelined_ms_per_step": (d.get("pipelined") or {}).get("ms_per_step")}
@@ -674,8 +686,60 @@ def workload_legs(args):
                 "native_call": {k: (d.get("pipelined_native_call") or {}).get(k) for k in ("ms_per_step", "host_issue_ms_per_step")},
                 "timed_regions_ms_per_step": (d.get("pipelined") or {}).get("timed_regions_ms_per_step")}
 
+    def tool_leg(script, extra, pick, timeout=240):
+        """a measurement script of tools/ in a process of its own: its last JSON line, reduced by `pick`"""
+        cmd = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", script)] + extra
+        env = dict(os.environ)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        try:
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not lines:
+                return {"error": "rc %d: %s" % (r.returncode, (r.stderr or "").strip()[-300:]), "command": "python tools/%s %s" % (script, " ".join(extra))}
+            o = pick(json.loads(lines[-1]))
+            o["command"] = "python tools/%s %s" % (script, " ".join(extra)); o["wall_s"] = round(time.perf_counter() - t0, 1)
+            return o
+        except Exception as e:                                       # noqa: BLE001
+            return {"error": repr(e)[:300], "command": "python tools/%s %s" % (script, " ".join(extra))}
+
+    def pick_train(d):
+        seg = d.get("segments_ms") or {}
+        ga = d.get("grad_allreduce") or {}
+        return {"workload": d.get("workload"), "ms_per_step": d.get("ms_per_step"), "points_per_s": d.get("points_per_s"), "hipgraph": d.get("hipgraph"),
+                "replay_ms": seg.get("replay_ms"), "allreduce_ms": seg.get("allreduce_ms"), "optimizer_ms": seg.get("optimizer_ms"),
+                "launches_per_step": seg.get("launches_per_step", seg.get("graph_nodes")), "rccl_ranks": (d.get("ranks") or {}).get("rccl_ranks"),
+                "backend": (d.get("ranks") or {}).get("backend"), "collective_issued": ga.get("collective_issued"), "gradient_bytes": ga.get("gradient_bytes"), "loss": d.get("loss")}
+
+    def train_step():
+        """config C4's full training step (PointTransformerSeg + CBL, 7.8 M parameters, forward + CE + CBL + backward + SGD) of one 40960-point scene as a replayed hipGraph,
+        plain and through a one-rank RCCL group with the flat gradient reducer (the collective IS issued; not a scaling number)"""
+        plain = tool_leg("bench_model.py", ["--graph", "--steps", "10", "--warmup", "3"], pick_train)
+        group = tool_leg("bench_model.py", ["--graph", "--single-rank-group", "--steps", "10", "--warmup", "3"], pick_train)
+        o = {"plain": plain, "single_rank_group": group}
+        if plain.get("ms_per_step") and group.get("ms_per_step"):
+            o["single_rank_group_over_plain"] = round(group["ms_per_step"] / plain["ms_per_step"], 3)
+        return o
+
+    def stage_shapes_leg():
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", "stage_shapes"]
+        env = dict(os.environ)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not lines:
+                return {"error": "rc %d: %s" % (r.returncode, (r.stderr or "").strip()[-300:]), "command": "python bench.py --workload stage_shapes"}
+            d = json.loads(lines[-1]); d["command"] = "python bench.py --workload stage_shapes"
+            return d
+        except Exception as e:                                       # noqa: BLE001
+            return {"error": repr(e)[:300], "command": "python bench.py --workload stage_shapes"}
+
     steps = str(min(args.steps, 30)); warm = str(min(args.warmup, 5))
-    return {"pt_block": leg(["--block", "pt", "--steps", steps, "--warmup", warm], pick_pt),
+    return {"train_step": train_step(), "stage_shapes": stage_shapes_leg(),
+            "pt_block": leg(["--block", "pt", "--steps", steps, "--warmup", warm], pick_pt),
             # the ConvNet step is issued eagerly by two host threads: short timed regions (20 steps = 60 ms) caught the threads' start-up in two of four runs
             # (3.1 or 3.6-4.1 ms per step); 40 steps and 5 warm-up steps cost 0.3 s more
             "convnet": leg(["--workload", "convnet", "--steps", "40", "--warmup", "5"], pick_convnet)}
@@ -852,6 +916,135 @@ def run_convnet(args, D, world, rank, local):
 
 
 # ------------------------------------------------------------------------------------------------ Point Transformer block (a1 + a3 + a4 + a8)
+def layer_backward_graph_us(layer, scene, idx, reps=20):
+    """the attention layer's backward as a replayed hipGraph, on a COPY of the layer (fresh parameters: their gradient accumulators are created on the
+    capture stream — a capture that meets accumulators of another stream crashes on ROCm 7.2, see Step.capture)"""
+    import copy
+    import gc
+    try:
+        lay = copy.deepcopy(layer).train()
+        params = list(lay.parameters())
+        g_up = scene.upstream(idx.shape[1])["grad_kpconv"]
+        gc.collect()
+        st = {}
+
+        def fwd():
+            st["x"] = scene.feat.detach().requires_grad_(True)
+            st["y"] = lay([scene.xyz, st["x"], scene.offset], idx=idx)
+
+        def bwd():
+            st["g"] = torch.autograd.grad(st["y"], [st["x"]] + params, g_up, retain_graph=True)
+        cap = torch.cuda.Stream(); cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap):
+            for _ in range(3):
+                fwd(); bwd()
+        torch.cuda.current_stream().wait_stream(cap); torch.cuda.synchronize()
+        gf, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gf, capture_error_mode="thread_local"):
+            fwd()
+        with torch.cuda.graph(gb, capture_error_mode="thread_local"):
+            bwd()
+        gf.replay(); gb.replay(); torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            gb.replay()
+        b.record(); torch.cuda.synchronize()
+        us = a.elapsed_time(b) / reps * 1e3
+        del gf, gb, st
+        return round(us, 2)
+    except Exception as e:                                           # noqa: BLE001 - a measurement beside the leg must not take it down
+        torch.cuda.synchronize()
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:120])}
+
+
+def graph_us(fn, reps=20, warm=3):
+    """device time of fn() as a replayed hipGraph: `reps` replays between two HIP events / reps (a graph's launch gaps, no host issue time)"""
+    cap = torch.cuda.Stream(); cap.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cap):
+        for _ in range(warm):
+            fn()
+    torch.cuda.current_stream().wait_stream(cap); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        fn()
+    g.replay(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        g.replay()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e3
+
+
+def run_stage_shapes(args, local):
+    """python bench.py --workload stage_shapes: the north-star gather (a3), the attention layer (a4, forward and backward) and the sampler (a2) at the five REAL
+    stage shapes of the reference's Point Transformer — (n, K, C) = (40960, 8, 32) (10240, 16, 64) (2560, 16, 128) (640, 16, 256) (160, 16, 512),
+    /root/reference/pytorch/model/pointtransformer_seg.py:35,49-58 — on an S-room scene whose stages are this build's own FPS (stride 4).  Gather and layer
+    times are replayed hipGraphs (device time, no host issue time); FPS is one eager call between two events (milliseconds of one workgroup)."""
+    import gc
+    torch.cuda.set_device(local)
+    torch.backends.cuda.preferred_blas_library("cublas")
+    from contrastboundary_amd import blocks, pointops, synthetic as S
+    dev = "cuda"
+    shapes = [(40960, 8, 32), (10240, 16, 64), (2560, 16, 128), (640, 16, 256), (160, 16, 512)]
+    xyz = torch.from_numpy(S.s_room(40960, 0)[0]).to(dev)
+    p, o, fps_us = [xyz], [torch.tensor([40960], dtype=torch.int32, device=dev)], [None]
+    for i in range(1, 5):
+        no = torch.tensor([shapes[i][0]], dtype=torch.int32, device=dev)
+        ts = []
+        for r in range(3):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(); a.record()
+            idx = pointops.furthestsampling(p[i - 1], o[i - 1], no)
+            b.record(); torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b) * 1e3)
+        fps_us.append(float(np.median(ts[1:])))
+        p.append(p[i - 1][idx.long()].contiguous()); o.append(no)
+    rows = []
+    for i, (n, K, C) in enumerate(shapes):
+        torch.manual_seed(100 + i)
+        feat = torch.randn(n, C, device=dev)
+        g_up = torch.randn(n, C, device=dev)
+        idx, _ = pointops.knnquery(K, p[i], p[i], o[i], o[i])
+        row = {"stage": i, "n": n, "K": K, "C": C}
+        gb = 4 * n * K + 12 * n + 12 * n + 4 * n * C + 4 * n * K * (3 + C)                      # SURVEY 8(d) a3
+        try:
+            us = graph_us(lambda: pointops.queryandgroup(K, p[i], p[i], feat, idx, o[i], o[i], use_xyz=True))
+            row["queryandgroup_us"] = round(us, 2); row["queryandgroup_GBps"] = round(gb / (us * 1e-6) / 1e9, 1); row["queryandgroup_frac_of_8TBps"] = round(gb / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 3)
+            layer = blocks.PointTransformerLayer(C, C, 8, K).to(dev).train()
+            params = list(layer.parameters())
+            gc.collect()
+            st = {}
+
+            def fwd():
+                st["x"] = feat.detach().requires_grad_(True)
+                st["y"] = layer([p[i], st["x"], o[i]], idx=idx)
+
+            def bwd():
+                st["g"] = torch.autograd.grad(st["y"], [st["x"]] + params, g_up, retain_graph=True)
+            cap = torch.cuda.Stream(); cap.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cap):                              # the layer's first use, the transposed table, the gradient accumulators: all on the capture stream
+                for _ in range(2):
+                    fwd(); bwd()
+            torch.cuda.current_stream().wait_stream(cap); torch.cuda.synchronize()
+            row["pt_layer_fwd_us"] = round(graph_us(fwd, warm=1), 2)
+            row["pt_layer_bwd_us"] = round(graph_us(bwd, warm=1), 2)
+            del st, layer, params
+        except Exception as e:                                       # noqa: BLE001 - report what was measured
+            row["error"] = "%s: %s" % (type(e).__name__, str(e)[:120])
+            torch.cuda.synchronize()
+        if fps_us[i] is not None:
+            row["fps_from_prev_us"] = round(fps_us[i], 1)
+        rows.append(row)
+    out = {"workload": "stage_shapes", "scene": "S-room(40960, seed 0), stages by this build's FPS (stride 4)", "device": torch.cuda.get_device_name(0),
+           "timing": "queryandgroup / pt_layer: 20 replays of a hipGraph of the call between two HIP events / 20; fps: one eager call between two events, median of 2",
+           "pt_layer": "blocks.PointTransformerLayer(C, C, share_planes 8, nsample K), train mode: q / k / v projections + the fused attention passes; backward w.r.t. the input features and all parameters (transposed table already built)",
+           "stages": rows}
+    print(json.dumps(out), flush=True)
+    return 0
+
+
 def run_pt(args, D, world, rank, local):
     """python bench.py --block pt: the block with the Point Transformer's vector-attention layer (pytorch/model/blocks.py:31-44) as its local
     aggregation — KNN -> PointTransformerLayer (q/k/v, linear_p, attention over the K neighbours, softmax, aggregation; forward + backward
@@ -889,23 +1082,13 @@ def run_pt(args, D, world, rank, local):
     # the layer's forward alone: one hipGraph of it, replayed back to back between two HIP events
     layer = hotpath.pt_layer(scene)
     from contrastboundary_amd import pointops
+    # inside ONE neighbour cache: the cell order the search registers (the layer's processing order) lives as long as the cache that owns it — measured outside,
+    # the layer walks its tiles in index order: 142 / 313 us instead of 132 / 272 us forward / backward
     with pointops.neighbor_cache():
         idx, _ = pointops.knnquery_raw(k, scene.xyz, scene.xyz, scene.offset, scene.offset)
-    cap = torch.cuda.Stream(); cap.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(cap), torch.no_grad():
-        for _ in range(3):
-            layer([scene.xyz, scene.feat, scene.offset], idx=idx)
-    torch.cuda.current_stream().wait_stream(cap); sync()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g), torch.no_grad():
-        y = layer([scene.xyz, scene.feat, scene.offset], idx=idx)
-    g.replay(); sync()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(20):
-        g.replay()
-    b.record(); sync()
-    us = a.elapsed_time(b) / 20 * 1e3
+        with torch.no_grad():
+            us = graph_us(lambda: layer([scene.xyz, scene.feat, scene.offset], idx=idx))
+        bwd_us = layer_backward_graph_us(layer, scene, idx) if backward else None
     li = names.index("pt_layer_fwd")
     nbytes, flops = stages[li][2], stages[li][3]
     out["roofline"] = {"kernel": "PointTransformerLayer forward (csrc/pt_layer.hip + cbl_triple_linear): q/k/v projections (1 launch), p chain, BN_c statistics, w2 on MFMA tiles, softmax, aggregation; 3 BatchNorm finalizes",
@@ -915,6 +1098,10 @@ def run_pt(args, D, world, rank, local):
                        "note": "SURVEY 8(d) a4 (idx given): bytes 12n + 12nC + 4nK + 4nC, flops 2nK(9 + 3C + C^2/8 + C^2/64) + 6nC^2; duration = 20 replays of a "
                                "hipGraph of the layer's forward alone between two HIP events / 20.  stage_ms: " + how,
                        "stage_ms": {names[i]: round(stage_ms[i], 4) for i in range(len(stages))}, "stage_sum_ms": round(float(sum(stage_ms)), 4)}
+    if bwd_us is not None:
+        out["roofline"]["layer_bwd_us"] = bwd_us                     # float, or {"error": ...}
+        out["roofline"]["layer_bwd_note"] = ("the layer's backward alone (w.r.t. its input features and all parameters, the transposed table already built): 20 replays of a hipGraph "
+                                             "between two HIP events / 20 — device time with a graph's launch gaps, no host issue time (stage_ms.pt_layer_bwd is the eager stage)")
     if backward:
         fstep = make_step(scene, k, False, args, overlap=not args.no_overlap, pipeline=pipeline)
         e_f = timed_region(fstep, args.steps, args.warmup, sync, D)
@@ -956,6 +1143,8 @@ def main(argv=None):
     if not torch.cuda.is_available():
         sys.stderr.write("bench.py: no GPU visible (the hot path has no CPU fallback)\n")
         return 2
+    if args.workload == "stage_shapes":
+        return run_stage_shapes(args, local)
     return (run_convnet if args.workload == "convnet" else run_pt if args.block == "pt" else run_gpu)(args, D, world, rank, local)
 
 

@@ -42,7 +42,28 @@ def main():
     torch.manual_seed(0)
     x = torch.randn(n, C, device="cuda"); g = torch.randn(n, C, device="cuda")
     idx, _ = pointops.knnquery(K, xyz, xyz, o, o)
+    which = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--order=")]
+    if which:
+        # experiment: another processing order than the search's cell order — "morton:<cell edge in metres>" (Z-curve over cells of that edge, ids ascending
+        # inside a cell), "hilbertish:<edge>" (Z-curve with the x runs of odd rows reversed), "index" (the rows as they are)
+        from contrastboundary_amd import neighbor_state as NS
+        kind, _, edge = which[0].partition(":")
+        if kind == "index":
+            NS.use_spatial_order = False
+        else:
+            q = ((xyz - xyz.min(0).values) / float(edge or 0.1)).long()
+            code = torch.zeros(n, dtype=torch.long, device="cuda")
+            for b in range(10):
+                for d in range(3):
+                    code |= ((q[:, d] >> b) & 1) << (3 * b + d)
+            order = torch.argsort(code * n + torch.arange(n, device="cuda")).to(torch.int32).contiguous()
+            cur = torch.cuda.current_stream()
+            for t in (xyz, idx):
+                NS._order_registry[NS._order_key(t)] = {cur.cuda_stream: (order, cur)}
+        out_order = which[0]
     out = {"n": n, "K": K, "C": C}
+    if which:
+        out["order"] = out_order
     for mode in ((True, "ops") if C > 64 else (True, "split")):
         layer = blocks.PointTransformerLayer(C, C, 8, K).cuda().train(); layer.fused = mode
         params = list(layer.parameters())
