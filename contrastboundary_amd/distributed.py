@@ -297,11 +297,13 @@ class FlatState:
                     if b is not None and id(b) not in seen_b:
                         seen_b.add(id(b)); bufs.append((mod, name, b))
         for key, pick in (("float", lambda b: b.is_floating_point()), ("int", lambda b: not b.is_floating_point())):
-            mine = [(mod, name, b) for mod, name, b in bufs if pick(b) and b.device == dev]
+            assert all(b.device == dev for _, _, b in bufs), "FlatState: buffers on another device than the parameters"
+            mine = [(mod, name, b) for mod, name, b in bufs if pick(b)]
             if not mine:
                 continue
             dtb = mine[0][2].dtype
-            mine = [t for t in mine if t[2].dtype == dtb]
+            odd = [name for _, name, b in mine if b.dtype != dtb]
+            assert not odd, "FlatState: %s buffers of more than one dtype (%s): they would drop out of broadcast_buffers" % (key, odd[:4])
             flat = torch.zeros(sum((b.numel() + 15) // 16 * 16 for _, _, b in mine), dtype=dtb, device=dev)
             pos = 0
             with torch.no_grad():
@@ -323,6 +325,7 @@ class FlatState:
         """every parameter's gradient into its slice of the flat gradient buffer: multi-tensor copies (a few launches for hundreds of tensors); parameters that
         received none contribute zeros"""
         have = [(v, p.grad) for v, p in zip(self.grad_views, self.params) if p.grad is not None]
+        self._idle = [p for p in self.params if p.grad is None]      # left alone by step()
         if len(have) != len(self.params):
             self.flat_grad.zero_()
         if have:
@@ -341,27 +344,103 @@ class FlatState:
             self.flat_tensors.append(P)
             groups.append(dict({k: v for k, v in g.items() if k != "params"}, params=[P]))
         flat = type(optimizer)(groups)
-        # momentum the caller's optimizer already holds (warm-up steps) moves over: SGD's buffer is elementwise state like the parameter itself
-        for g, P, (s0, s1), ps in zip(optimizer.param_groups, self.flat_tensors, self.group_range, self.groups):
-            bufs = [optimizer.state.get(p, {}).get("momentum_buffer") for p in ps]
-            if any(b is not None for b in bufs):
-                mom = torch.zeros(s1 - s0, dtype=P.dtype, device=P.device)
-                pos = 0
-                for p, b in zip(ps, bufs):
-                    if b is not None:
-                        mom[pos:pos + p.numel()].copy_(b.reshape(-1))
-                    pos += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
-                flat.state[P]["momentum_buffer"] = mom
         self.optimizer = flat
+        self._import_state()                                         # state the caller's optimizer already holds (warm-up steps, a loaded checkpoint) moves over
         return flat
 
+    def _slices(self, gi):
+        """(parameter, start, stop) of group gi's parameters inside the group's flat range"""
+        out, pos = [], 0
+        for p in self.groups[gi]:
+            out.append((p, pos, pos + p.numel()))
+            pos += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        return out
+
+    def _import_state(self):
+        """per-parameter optimizer state of the caller's optimizer -> the flat optimizer's one-tensor-per-group state.  Elementwise state tensors (SGD's
+        momentum_buffer, Adam's exp_avg / exp_avg_sq: same shape as the parameter) are laid into a flat tensor at the parameter's offset (zeros where a parameter
+        has none yet); per-parameter scalars (Adam's `step`) must agree inside a group and are taken once.  Anything else cannot be carried and raises."""
+        src = self._src_optimizer
+        for gi, (P, (s0, s1)) in enumerate(zip(self.flat_tensors, self.group_range)):
+            per = [(p, a, b, src.state.get(p, {})) for p, a, b in self._slices(gi)]
+            keys = []
+            for _, _, _, st in per:
+                keys.extend(k for k in st if k not in keys)
+            fstate = {}
+            for k in keys:
+                vals = [st[k] for _, _, _, st in per if k in st and st[k] is not None]
+                if not vals:
+                    continue
+                if all(torch.is_tensor(v) and v.dim() > 0 for v in vals) and all(v.numel() == p.numel() for p, _, _, st in per if st.get(k) is not None for v in [st[k]]):
+                    flat_v = torch.zeros(s1 - s0, dtype=vals[0].dtype, device=P.device)
+                    for p, a, b, st in per:
+                        if st.get(k) is not None:
+                            flat_v[a:b].copy_(st[k].reshape(-1))
+                    fstate[k] = flat_v
+                elif all((torch.is_tensor(v) and v.dim() == 0) or isinstance(v, (int, float)) for v in vals):
+                    nums = {float(v) for v in vals}
+                    if len(nums) != 1 or len(vals) != len(per):
+                        raise ValueError("FlatState: optimizer state %r differs between the parameters of one group (%s): it cannot be carried by one flat tensor" % (k, sorted(nums)))
+                    fstate[k] = vals[0].clone() if torch.is_tensor(vals[0]) else vals[0]
+                else:
+                    raise ValueError("FlatState: optimizer state %r is neither elementwise nor a per-parameter scalar; this optimizer cannot run on the flat buffers" % k)
+            if fstate:
+                self.optimizer.state[P] = fstate
+            elif P in self.optimizer.state:
+                del self.optimizer.state[P]
+
+    def _export_state(self):
+        """the flat optimizer's state written through to the caller's optimizer in its own per-parameter format (copies: a checkpoint taken from
+        `optimizer.state_dict()` afterwards holds the live momentum)"""
+        src = self._src_optimizer
+        for gi, P in enumerate(self.flat_tensors):
+            fstate = self.optimizer.state.get(P, {})
+            for p, a, b in self._slices(gi):
+                st = src.state[p]                                    # defaultdict: creates the entry
+                for k, v in fstate.items():
+                    if torch.is_tensor(v) and v.dim() > 0:
+                        st[k] = v[a:b].view(p.shape).clone()
+                    else:
+                        st[k] = v.clone() if torch.is_tensor(v) else v
+
+    def state_dict(self):
+        """the optimizer state in the reference's checkpoint format ('optimizer': optimizer.state_dict(), /root/reference/pytorch/tool/train.py:216): the caller's
+        optimizer with the live flat state written through to its per-parameter entries"""
+        self._export_state()
+        return self._src_optimizer.state_dict()
+
+    def load_state_dict(self, state_dict):
+        """resume (train.py:292 optimizer.load_state_dict): into the caller's optimizer, then into the flat one"""
+        self._src_optimizer.load_state_dict(state_dict)
+        self._import_state()
+
     def step(self):
-        """one optimizer step on the flat buffers; the caller's optimizer is the source of truth for the hyper-parameters (an LR scheduler steps THAT one)"""
+        """one optimizer step on the flat buffers; the caller's optimizer is the source of truth for the hyper-parameters (an LR scheduler steps THAT one).
+        Parameters that received no gradient in the packed backward pass keep their value and state: torch's optimizers skip a parameter whose .grad is None
+        (DDP with find_unused_parameters, train.py:184), while the fused flat step would decay and move them."""
         for gs, gf in zip(self._src_optimizer.param_groups, self.optimizer.param_groups):
             for k, v in gs.items():
                 if k != "params":
                     gf[k] = v
+        idle = getattr(self, "_idle", ())
+        keep = []
+        if idle:
+            offs = {}
+            for gi in range(len(self.groups)):
+                for p, a, b in self._slices(gi):
+                    offs[id(p)] = (gi, a, b)
+            for p in idle:
+                gi, a, b = offs[id(p)]
+                P = self.flat_tensors[gi]
+                saved = [(P.data[a:b], P.data[a:b].clone())]
+                for v in self.optimizer.state.get(P, {}).values():
+                    if torch.is_tensor(v) and v.dim() > 0:
+                        saved.append((v[a:b], v[a:b].clone()))
+                keep.append(saved)
         self.optimizer.step()
+        for saved in keep:
+            for dst, val in saved:
+                dst.copy_(val)
 
     # ---- buffers
     def broadcast_buffers(self, src=0, group=None):

@@ -180,26 +180,34 @@ class PTAttentionWide(Function):
         return (None, g_qkv[0], g_qkv[1], g_qkv[2], None, None, *g_params)
 
 
+def _adjacent(ts):
+    """do the three tensors already lie one after the other in one storage?"""
+    a, b, c = ts
+    step = a.numel()
+    return (a.is_contiguous() and b.is_contiguous() and c.is_contiguous() and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() == c.untyped_storage().data_ptr()
+            and b.storage_offset() == a.storage_offset() + step and c.storage_offset() == a.storage_offset() + 2 * step)
+
+
 def _stacked(ts):
     """the three tensors as one (3, ...) tensor: a view when they already lie one after the other in memory (`adjoin_qkv`), a copy otherwise"""
     a, b, c = ts
-    step = a.numel()
-    if (a.is_contiguous() and b.is_contiguous() and c.is_contiguous() and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() == c.untyped_storage().data_ptr()
-            and b.storage_offset() == a.storage_offset() + step and c.storage_offset() == a.storage_offset() + 2 * step):
-        return a.as_strided((3,) + tuple(a.shape), (step,) + tuple(a.stride()))
+    if _adjacent(ts):
+        return a.as_strided((3,) + tuple(a.shape), (a.numel(),) + tuple(a.stride()))
     return torch.stack((a, b, c))
 
 
 def adjoin_qkv(module):
     """lay the q / k / v projections' weights (and biases) of every PointTransformerLayer under `module` out one after the other, so that `_stacked` is a view.
     Values, Parameter objects and state_dict entries stay what they were; call it after the module reached its device and before an optimizer state / flat state
-    takes views of the parameters (distributed.FlatState keeps such groups adjacent itself)."""
+    takes views of the parameters (distributed.FlatState keeps such groups adjacent itself).  Idempotent: a triple that is adjacent already keeps its storage —
+    a captured hipGraph (an earlier GraphedTrainStep on the same model) holds the addresses of that storage, and moving the weights away would leave it reading
+    and updating memory that went back to the allocator."""
     from .blocks import PointTransformerLayer
     for m in module.modules():
         if isinstance(m, PointTransformerLayer) and m.linear_q.weight.shape == m.linear_k.weight.shape == m.linear_v.weight.shape:
             for name in ("weight", "bias"):
                 ps = [getattr(l, name) for l in (m.linear_q, m.linear_k, m.linear_v)]
-                if any(t is None for t in ps):
+                if any(t is None for t in ps) or _adjacent([t.data for t in ps]):
                     continue
                 with torch.no_grad():
                     whole = torch.stack([t.data for t in ps])

@@ -433,3 +433,74 @@ def test_flat_state_single_process_matches_the_plain_optimizer():
     for ba, bb in zip(a.buffers(), b.buffers()):
         assert torch.allclose(ba.float(), bb.float(), rtol=1e-6, atol=1e-7)
     assert b.state_dict().keys() == a.state_dict().keys()
+
+
+def test_flat_state_checkpoint_round_trip_and_adam_state():
+    """the reference checkpoints 'optimizer': optimizer.state_dict() and resumes with load_state_dict (/root/reference/pytorch/tool/train.py:216,292): with the
+    flat state the live momentum sits in the one-tensor optimizer — FlatState.state_dict() writes it through in the caller's per-parameter format, and
+    load_state_dict() brings a checkpoint back into the flat tensors.  Adam's exp_avg / exp_avg_sq / step are carried like SGD's momentum_buffer."""
+    from contrastboundary_amd import distributed as D
+    x, y = _rank_batch(0)
+    for make in (lambda ps: torch.optim.SGD(ps, lr=0.1, momentum=0.9, weight_decay=1e-3), lambda ps: torch.optim.Adam(ps, lr=1e-2)):
+        torch.manual_seed(7)
+        a, b = _BnNet(), _BnNet()
+        b.load_state_dict(a.state_dict())
+        oa, ob = make(a.parameters()), make(b.parameters())
+        for m, o in ((a, oa), (b, ob)):                               # two plain steps: both optimizers hold state when the flat one takes over
+            for _ in range(2):
+                o.zero_grad(); ((m(x) - y) ** 2).mean().backward(); o.step()
+        st = D.FlatState([b], ob)
+        st.flat_optimizer(ob)
+        red = D.PackedGradientReducer(st, bucket_bytes=64)
+        for _ in range(2):
+            oa.zero_grad(); ((a(x) - y) ** 2).mean().backward(); oa.step()
+            red.zero_grad(); ((b(x) - y) ** 2).mean().backward(); red.finish(); st.step()
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            assert torch.allclose(pa, pb, rtol=1e-5, atol=1e-7)
+        # checkpoint: the per-parameter state of the flat run equals the plain run's
+        sd, ref = st.state_dict(), oa.state_dict()
+        assert sd["state"].keys() == ref["state"].keys()
+        for k in ref["state"]:
+            for name, v in ref["state"][k].items():
+                got = sd["state"][k][name]
+                assert torch.allclose(torch.as_tensor(got).float(), torch.as_tensor(v).float(), rtol=1e-5, atol=1e-7), (type(oa).__name__, k, name)
+        # resume: a fresh model + optimizer + flat state loaded from the checkpoint continues like the plain run
+        import copy
+        c = _BnNet(); c.load_state_dict(copy.deepcopy(b.state_dict()))
+        oc = make(c.parameters())
+        sc = D.FlatState([c], oc); sc.flat_optimizer(oc)
+        sc.load_state_dict(copy.deepcopy(sd))
+        rc = D.PackedGradientReducer(sc, bucket_bytes=64)
+        oa.zero_grad(); ((a(x) - y) ** 2).mean().backward(); oa.step()
+        rc.zero_grad(); ((c(x) - y) ** 2).mean().backward(); rc.finish(); sc.step()
+        for pa, pc in zip(a.parameters(), c.parameters()):
+            assert torch.allclose(pa, pc, rtol=1e-5, atol=1e-7)
+
+
+def test_flat_state_leaves_parameters_without_a_gradient_alone():
+    """torch's optimizers skip a parameter whose .grad is None (the reference's DDP runs with find_unused_parameters, train.py:184): an unused head must not
+    decay or coast on its momentum under the fused flat step either"""
+    from contrastboundary_amd import distributed as D
+    torch.manual_seed(9)
+
+    class TwoHeads(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.body = torch.nn.Linear(6, 16); self.used = torch.nn.Linear(16, 4); self.unused = torch.nn.Linear(16, 4)
+
+        def forward(self, x):
+            return self.used(torch.relu(self.body(x)))
+    a, b = TwoHeads(), TwoHeads()
+    b.load_state_dict(a.state_dict())
+    oa = torch.optim.SGD(a.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-2)
+    ob = torch.optim.SGD(b.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-2)
+    st = D.FlatState([b], ob); st.flat_optimizer(ob)
+    red = D.PackedGradientReducer(st, bucket_bytes=64)
+    x = torch.randn(32, 6); y = torch.randn(32, 4)
+    before = b.unused.weight.detach().clone()
+    for _ in range(3):
+        oa.zero_grad(); ((a(x) - y) ** 2).mean().backward(); oa.step()
+        red.zero_grad(); ((b(x) - y) ** 2).mean().backward(); red.finish(); st.step()
+    assert torch.equal(b.unused.weight, before) and torch.equal(a.unused.weight, before)
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.allclose(pa, pb, rtol=1e-6, atol=1e-7)

@@ -29,6 +29,16 @@ def test_adjoin_makes_the_stack_a_view_and_keeps_the_values():
     assert torch.equal(pt_layer._stacked(_triples(layer)[0])[1], layer.linear_k.weight)
 
 
+def test_adjoin_twice_keeps_the_storage():
+    """a second adjoin_qkv (another GraphedTrainStep on the same model) must not move weights an earlier capture holds by address"""
+    torch.manual_seed(2)
+    layer = blocks.PointTransformerLayer(64, 64, 8, 16)
+    pt_layer.adjoin_qkv(layer)
+    where = [[t.data_ptr() for t in tri] for tri in _triples(layer)]
+    pt_layer.adjoin_qkv(layer)
+    assert [[t.data_ptr() for t in tri] for tri in _triples(layer)] == where
+
+
 def test_flat_state_keeps_the_projections_adjacent():
     torch.manual_seed(1)
     net = torch.nn.Sequential(torch.nn.Linear(8, 8), blocks.PointTransformerLayer(128, 128, 8, 16), blocks.PointTransformerLayer(32, 32, 8, 16))
