@@ -28,7 +28,9 @@ __global__ __launch_bounds__(XE_BLOCK) void xe_forward_kernel(long long n, int k
     double sum = 0.0, cnt = 0.0;
     for (long long i = (long long)blockIdx.x * XE_BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * XE_BLOCK) {
         const long long t = target[i];
-        if (t == ignore_index || t < 0 || t >= k) continue;          // labels outside [0, k) other than ignore_index: the library asserts; here they are skipped
+        if (t == ignore_index) continue;
+        if (t < 0 || t >= k) { sum += (double)NAN; continue; }       // a label outside [0, k) that is not ignore_index (a mapping bug: 255 against another ignore label):
+                                                                     // nn.CrossEntropyLoss device-asserts; here the loss turns NaN — loud, and legal inside a replayed hipGraph
         float mx, lse;
         xe_row(logits + i * k, k, mx, lse);
         sum += (double)(lse - logits[i * k + t]);

@@ -82,6 +82,20 @@ class StaticGeometry:
         # used this buffer set, so the issuing thread sat in stage() for a whole step (measured: 8 - 17 ms of host time per step, the graph step host-bound)
         self.host_ends = offset.cpu().tolist()
 
+    def check_offset(self, offset):
+        """a batch about to be staged into this buffer set must have the FIRST batch's cloud boundaries (host_ends: FPS counts, n_max and new_offset were derived
+        from them once).  Checked when the boundaries are readable without a device wait (a host / pinned tensor, a list); a device tensor is the caller's promise."""
+        if offset is None:
+            return
+        if torch.is_tensor(offset):
+            if offset.is_cuda:
+                return
+            ends = offset.tolist()
+        else:
+            ends = [int(v) for v in offset]
+        if ends != self.host_ends:
+            raise ValueError("StaticGeometry: cloud boundaries %s differ from the captured batch's %s (same total is not enough)" % (ends[:8], self.host_ends[:8]))
+
     def refresh(self, stream=None):
         """recompute for the CURRENT contents of self.points / self.offset; returns after enqueueing (self.ready = event)"""
         dev = self.points.device

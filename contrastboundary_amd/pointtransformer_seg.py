@@ -371,6 +371,7 @@ class GraphedTrainStep:
             side.wait_event(s["done"])
         if ready is not None:
             side.wait_event(ready)
+        s["geom"].check_offset(inputs.get("offset"))                 # a host-side batch with other cloud boundaries than the captured one: refuse, not a silently wrong geometry
         with torch.cuda.stream(side):
             for k, v in inputs.items():
                 s["inputs"][k].copy_(v, non_blocking=True)

@@ -601,7 +601,8 @@ int cbl_bn_rows_backward_residual(long long rows, int C, const float* x, const f
                                   float* grad_bias, void* workspace, size_t workspace_bytes, void* stream);
 
 /* the criterion's cross entropy  pytorch/model/pointtransformer_seg.py:20-22 (nn.CrossEntropyLoss(ignore_index), reduction 'mean')
- *   logits (n,k) f32, k <= 64; target (n) i64; points with target == ignore_index (or outside [0,k)) do not count.
+ *   logits (n,k) f32, k <= 64; target (n) i64; points with target == ignore_index do not count; any OTHER target outside [0,k) makes the loss NaN (the library
+ *   device-asserts on it; zero gradient rows for those points).
  *   forward: loss (1) = sum_i (logsumexp(logits[i]) - logits[i, target[i]]) / count; stats (2) = {sum, count}, kept for the backward call.
  *   backward: grad_logits (n,k) = (softmax(logits[i]) - onehot(target[i])) * grad_loss[0] / count, 0 for points that do not count (written, not accumulated).
  *   Deterministic (per-workgroup partial sums combined in fp64 in a fixed order).  workspace: cbl_cross_entropy_workspace_bytes. */

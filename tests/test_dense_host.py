@@ -109,6 +109,23 @@ def xe_case(host, n, k, ignored):
     assert not g[t == 255].any()
 
 
+def test_cross_entropy_label_outside_the_classes_is_loud(host):
+    """a label outside [0, k) that is not ignore_index (255 against ignore_label 0: a mapping bug) — nn.CrossEntropyLoss device-asserts; the fused kernel
+    returns a NaN loss instead of quietly training on fewer points, and a zero gradient row for that point"""
+    n, k = 500, 13
+    rng = np.random.default_rng(3)
+    z = rng.normal(size=(n, k)).astype(np.float32)
+    t = rng.integers(0, k, n).astype(np.int64)
+    t[7] = 255
+    loss, stats, g, up = np.zeros(1, np.float32), np.zeros(2, np.float32), np.ones((n, k), np.float32), np.array([1.0], np.float32)
+    nbytes = host.cbl_cross_entropy_workspace_bytes(ctypes.c_longlong(n))
+    ws = np.zeros(nbytes + 64, np.uint8)
+    assert host.cbl_cross_entropy_forward(ctypes.c_longlong(n), k, P(z), P(t), ctypes.c_longlong(-100), P(loss), P(stats), P(ws), ctypes.c_size_t(nbytes), None) == 0
+    assert np.isnan(loss[0])
+    assert host.cbl_cross_entropy_backward(ctypes.c_longlong(n), k, P(z), P(t), ctypes.c_longlong(-100), P(stats), P(up), P(g), None) == 0
+    assert not g[7].any()
+
+
 @pytest.mark.skipif(not os.environ.get("CBL_HOST_EMUL_FULL"), reason="a second (sanitizer) build of the host library: set CBL_HOST_EMUL_FULL=1")
 def test_kernels_under_address_sanitizer(tmp_path):
     """the same host build with -fsanitize=address in a subprocess: operands are numpy buffers of exactly their logical sizes, `__shared__` arrays static arrays"""

@@ -73,3 +73,18 @@ def test_caches_nest_and_restore_the_outer_one():
             assert pointops.neighbor_cache.active() is inner
         assert pointops.neighbor_cache.active() is outer
     assert pointops.neighbor_cache.active() is None
+
+
+def test_static_geometry_refuses_a_batch_with_other_cloud_boundaries():
+    """StaticGeometry derives FPS counts / n_max / new_offset from the FIRST batch's cloud boundaries once (host_ends); a later batch with the same total but other
+    boundaries must be refused where that is checkable without a device wait (host tensors, lists)"""
+    import pytest
+    import torch
+    from contrastboundary_amd import geometry
+    g = object.__new__(geometry.StaticGeometry)
+    g.host_ends = [1000, 2500, 4096]
+    g.check_offset(torch.tensor([1000, 2500, 4096], dtype=torch.int32))
+    g.check_offset([1000, 2500, 4096])
+    g.check_offset(None)
+    with pytest.raises(ValueError):
+        g.check_offset(torch.tensor([1200, 2500, 4096], dtype=torch.int32))
