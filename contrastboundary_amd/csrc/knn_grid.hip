@@ -233,10 +233,10 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(int n, int total, int
 // to run in the last bit, which a few SGD steps amplify (measured: 6e-7 on the loss at step 0, 3e-2 at step 3).  One thread per point: its
 // rank among the ids of its cell (read from the scattered copies: ~15 independent loads) is its slot.  Cells beyond 1024 points (degenerate
 // clouds) keep the scatter's order.  (A thread per CELL sorting its segment in place was 350 us: a chain of dependent global accesses.)
-__global__ __launch_bounds__(256) void grid_order_canon_kernel(int n, const int* __restrict__ pt_cell, const int* __restrict__ cell_start,
-                                                               const float4* __restrict__ sorted, int* __restrict__ order)
+__device__ __forceinline__ void grid_order_canon_body(int n, const int* __restrict__ pt_cell, const int* __restrict__ cell_start,
+                                                      const float4* __restrict__ sorted, int* __restrict__ order, int block, int nblocks)
 {
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    for (int i = block * 256 + threadIdx.x; i < n; i += nblocks * 256) {
         const int cell = pt_cell[i];
         const int s = cell_start[cell], e = cell_start[cell + 1];
         if (e - s < 2 || e - s > 1024) continue;
@@ -251,6 +251,14 @@ __global__ __launch_bounds__(256) void grid_order_canon_kernel(int n, const int*
         order[s + rank] = i;
     }
 }
+__global__ __launch_bounds__(256) void grid_order_canon_kernel(int n, const int* __restrict__ pt_cell, const int* __restrict__ cell_start,
+                                                               const float4* __restrict__ sorted, int* __restrict__ order)
+{
+    grid_order_canon_body(n, pt_cell, cell_start, sorted, order, blockIdx.x, gridDim.x);
+}
+// the same pass riding in the search launch (knn_grid_wave_kernel's first `canon_blocks` workgroups): nothing of the search reads the exported order, so the
+// ~8 us of dependent loads run beside the queries instead of in a launch of their own in front of them
+struct CblCanon { int blocks, n; const int* pt_cell; int* order; };
 
 // ---- 3. queries: one G-lane group per query ------------------------------------------------------------------
 template <int G> __device__ __forceinline__ float dpp_shr1_f(float v);
@@ -494,11 +502,15 @@ __global__ __launch_bounds__(256) void knn_grid_wave_kernel(int b, int m, int K,
                                                             const float4* __restrict__ sorted, int* __restrict__ idx, float* __restrict__ dist2,
                                                             int* __restrict__ worklist, int* __restrict__ counters, int set_exact,
                                                             int ks, int* __restrict__ idx_n, float* __restrict__ dist2_n,
-                                                            int* __restrict__ worklist_n, int set_exact_n)
+                                                            int* __restrict__ worklist_n, int set_exact_n, CblCanon canon)
 {
     __shared__ float2 slots[4][64];
+    if ((int)blockIdx.x < canon.blocks) {                            // the exported cell order's canonical form (grid_order_canon_body), beside the queries
+        grid_order_canon_body(canon.n, canon.pt_cell, cell_start, sorted, canon.order, blockIdx.x, canon.blocks);
+        return;
+    }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int t = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);      // one query per wave
+    const int t = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - canon.blocks) * 4 + wv);      // one query per wave
     if (t >= m) return;
     int q; float qx, qy, qz;
     if (SELF) { const float4 s = sorted[t]; q = __float_as_int(s.w); qx = s.x; qy = s.y; qz = s.z; }   // cell order
@@ -876,9 +888,10 @@ __global__ __launch_bounds__(256) void grid_init_kernel(int b, int total, int* _
     for (int i = i0; i < total; i += gridDim.x * 256) cell_count[i] = 0;
 }
 
-int cbl_grid_build(int b, int n, float pts_per_cell, const float* xyz, const int* offset, void* ws, hipStream_t st, int* order_out = nullptr)
+int cbl_grid_build(int b, int n, float pts_per_cell, const float* xyz, const int* offset, void* ws, hipStream_t st, int* order_out = nullptr, bool canon_later = false)
 {
-    // 5 launches: init+zero | bbox | grid params + histogram | tile scans | scan finish + scatter
+    // 5 launches: init+zero | bbox | grid params + histogram | tile scans | scan finish + scatter (+ the exported order's canonical form: a launch here, or —
+    // canon_later — workgroups of the search launch that follows)
     Workspace w = carve(ws, b, n, 0);
     const int total = w.ncap + 1, ntiles = (total + SCAN_TILE - 1) / SCAN_TILE;
     hipLaunchKernelGGL(grid_init_kernel, dim3(cbl_grid_for(total, 256, 512)), dim3(256), 0, st, b, total, w.counters, w.bbox, w.cell_count);
@@ -887,7 +900,7 @@ int cbl_grid_build(int b, int n, float pts_per_cell, const float* xyz, const int
     hipLaunchKernelGGL(grid_scan_tiles_kernel, dim3(ntiles), dim3(256), 0, st, total, w.cell_count, w.cell_local, w.tile_sum);
     hipLaunchKernelGGL(grid_scatter_kernel, dim3(cbl_grid_for(n, 256)), dim3(256), 2 * sizeof(int) * (size_t)ntiles, st, n, total, ntiles, xyz, w.pt_cell,
                        w.tile_sum, w.cell_local, w.cell_start, w.cell_count, w.sorted, order_out);
-    if (order_out)
+    if (order_out && !canon_later)
         hipLaunchKernelGGL(grid_order_canon_kernel, dim3(cbl_grid_for(n, 256)), dim3(256), 0, st, n, w.pt_cell, w.cell_start, w.sorted, order_out);
     return cbl_status();
 }
@@ -950,18 +963,21 @@ int cbl_knn_grid_launch(int b, int n, int m, int nsample, const float* xyz, cons
     // bench scene, pairs visited / in-order step: 0.20: 7.4 M / 0.395 ms, 0.25: 9.1 M / 0.386, 0.33: 11.0 M / 0.388, 0.42: 13.0 M / 0.40, 0.60: 18.6 M / 0.416 —
     // smaller cells trade candidates for queries that need a second shell; CBL_KNN_CELL_FILL overrides for such sweeps)
     static const float fill = [] { const char* e = getenv("CBL_KNN_CELL_FILL"); const float v = e ? (float)atof(e) : 0.f; return (v > 0.05f && v < 4.f) ? v : 0.33f; }();
-    int rc = cbl_grid_build(b, n, fill * (float)(nsample < 4 ? 4 : nsample), xyz, offset, ws, st, order_out);
+    const bool wave_search = nsample > 16;
+    int rc = cbl_grid_build(b, n, fill * (float)(nsample < 4 ? 4 : nsample), xyz, offset, ws, st, order_out, wave_search);
     if (rc) return rc;
     const bool self = (new_xyz == xyz) && (m == n);
-    if (nsample > 16) {                                              // select-then-sort, one wave per query
-        const dim3 grid(cbl_div_up(m, 4)), block(256);
+    if (wave_search) {                                               // select-then-sort, one wave per query
+        CblCanon canon = {0, n, w.pt_cell, order_out};
+        if (order_out) canon.blocks = (int)cbl_grid_for(n, 256);
+        const dim3 grid(cbl_div_up(m, 4) + canon.blocks), block(256);
         // a narrower result of the same search rides along (its worklist: worklist2, counted in counters[1])
         const int ks = narrow ? narrow->nsample : 0;
         int* idx_n = narrow ? narrow->idx : nullptr; float* dist2_n = narrow ? narrow->dist2 : nullptr;
         const int set_n = narrow ? narrow->set_exact : 0;
         if (narrow) narrow->fused = true;
 #define CBL_LAUNCH_WAVE(SELF_, LEX_) hipLaunchKernelGGL((knn_grid_wave_kernel<SELF_, LEX_>), grid, block, 0, st, b, m, nsample, new_xyz, offset, new_offset, w.grids, \
-                                                       w.cell_start, w.sorted, idx, dist2, w.worklist, w.counters, set_exact, ks, idx_n, dist2_n, w.worklist2, set_n)
+                                                       w.cell_start, w.sorted, idx, dist2, w.worklist, w.counters, set_exact, ks, idx_n, dist2_n, w.worklist2, set_n, canon)
         if (set_exact == 2) { if (self) CBL_LAUNCH_WAVE(true, true); else CBL_LAUNCH_WAVE(false, true); }
         else                { if (self) CBL_LAUNCH_WAVE(true, false); else CBL_LAUNCH_WAVE(false, false); }
 #undef CBL_LAUNCH_WAVE
