@@ -31,6 +31,11 @@ constexpr int PT_BLOCK = 512;                       // 8 waves (256-thread workg
 constexpr int PT_WPB = PT_BLOCK / 64;
 constexpr int PT_MAX_ROWS = 512;                    // partial rows of a pass = its workgroups
 constexpr int PT_NARROW_BLOCK = 256;
+// pairs in flight per target and trip of the target pass: measured at (40960, 16, 64) 2: 51.4, 3: 52.0, 4: 59.1 us (196 registers: two waves per SIMD — the pass
+// needs its waves more than deeper trips), at (40960, 8, 32) 2: 20.4, 3: 18.6, 4: 20.5 us
+#ifndef PT_TARGET_PAIRS
+#define PT_TARGET_PAIRS(C) ((C) == 32 ? 3 : 2)
+#endif
 // element indices inside the tile passes are 32-bit (one v_lshl_add_u64 per address instead of a sign extension, a 64-bit multiply and a 64-bit add: a third of the
 // address arithmetic of a tile); pt_shape_ok bounds n K max(3, C / 8) and n C below 2^32
 using pt_ix = unsigned;
@@ -1008,7 +1013,7 @@ __global__ __launch_bounds__(PT_FIN_THREADS) void pt_pchain_epilogue_kernel(int 
 // ---- target pass: d x_k[j] and d x_v[j] as gathers over the transposed neighbour table -----------------------------------------------
 // C / 4 lanes own a target row (lane = 4 channels); the pairs that list the target are walked in ascending order; the chain of a pair is
 // rebuilt from the target's own x_k row, x_q[i], p1 and d w2 with the fmaf order of the matrix instruction (same w bits, same ReLU mask).
-template <int C, int K>
+template <int C, int K, int PP>
 __global__ __launch_bounds__(256) void pt_target_kernel(unsigned n, const int* __restrict__ order, const int* __restrict__ inv_start, const int* __restrict__ inv_src,
                                                         const float* __restrict__ xq, const float* __restrict__ xk, const float* __restrict__ p1,
                                                         const float* __restrict__ cst, const float* __restrict__ bc, const float* __restrict__ W3C,
@@ -1017,16 +1022,25 @@ __global__ __launch_bounds__(256) void pt_target_kernel(unsigned n, const int* _
 {
     constexpr int LPR = C / 4, G = C / 8, TPB = 256 / LPR;
     const int m = threadIdx.x % LPR, grp = threadIdx.x / LPR, c0 = 4 * m;
-    float w0[4], w1[4], w2c[4], wbias[4], sc[4], sh[4], k1[4], k2[4], k3[4], wa[G][4];
+    // the per-channel constants (W3C columns, bias, BN_c forward and backward coefficients, Wa: 9 + G values per channel) in an LDS table, one 16-byte entry per
+    // (quantity, channel quad), read where they are used: in registers they were 68 of the kernel's 166 (three waves per SIMD on a pass that waits for memory)
+    constexpr int NQ = 9 + G;
+    __shared__ float4 ctab[NQ][LPR];
+    if ((int)threadIdx.x < LPR) {
+        float q[NQ][4];
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-        const int c = c0 + e;
-        w0[e] = W3C[3 * c]; w1[e] = W3C[3 * c + 1]; w2c[e] = W3C[3 * c + 2]; wbias[e] = b3C[c];
-        sc[e] = cst[PT_CST_C + c]; sh[e] = cst[PT_CST_C + 64 + c];
-        k1[e] = bc[PT_BC_C + c]; k2[e] = bc[PT_BC_C + 64 + c]; k3[e] = bc[PT_BC_C + 128 + c];
+        for (int e = 0; e < 4; e++) {
+            const int c = 4 * threadIdx.x + e;
+            q[0][e] = W3C[3 * c]; q[1][e] = W3C[3 * c + 1]; q[2][e] = W3C[3 * c + 2]; q[3][e] = b3C[c];
+            q[4][e] = cst[PT_CST_C + c]; q[5][e] = cst[PT_CST_C + 64 + c];
+            q[6][e] = bc[PT_BC_C + c]; q[7][e] = bc[PT_BC_C + 64 + c]; q[8][e] = bc[PT_BC_C + 128 + c];
 #pragma unroll
-        for (int g = 0; g < G; g++) wa[g][e] = Wa[(size_t)g * C + c];
+            for (int g = 0; g < G; g++) q[9 + g][e] = Wa[(size_t)g * C + c];
+        }
+#pragma unroll
+        for (int k = 0; k < NQ; k++) ctab[k][threadIdx.x] = make_float4(q[k][0], q[k][1], q[k][2], q[k][3]);
     }
+    __syncthreads();
     const unsigned ntrips = (n + TPB - 1) / TPB;
     for (unsigned v = blockIdx.x; v < 8u * cbl_xcd_per(ntrips); v += gridDim.x) {
         const unsigned tr = cbl_xcd_slot(v, ntrips) * TPB + grp;
@@ -1036,16 +1050,19 @@ __global__ __launch_bounds__(256) void pt_target_kernel(unsigned n, const int* _
         const float4 kj = *reinterpret_cast<const float4*>(xk + (size_t)j * C + c0);
         const float kx[4] = {kj.x, kj.y, kj.z, kj.w};
         float ak[4] = {0.f, 0.f, 0.f, 0.f}, av[4] = {0.f, 0.f, 0.f, 0.f};
-        // two pairs per trip, their rows requested together; the ids of the NEXT two pairs are requested before this trip's arithmetic
+        // PP pairs per trip, their rows requested together; the ids of the NEXT PP pairs are requested before this trip's arithmetic
         // (a list's walk was one dependent id -> rows round trip per pair: 0.74 of the wave cycles parked on memory)
         int e = e0;
-        unsigned pa = e < e1 ? (unsigned)inv_src[e] : 0u, pb = e + 1 < e1 ? (unsigned)inv_src[e + 1] : pa;
-        for (; e < e1; e += 2) {
-            const bool two = e + 1 < e1;
-            const unsigned pp[2] = {pa, pb};
-            float4 q4[2], g4[2], a4[2], d0[2], d1[2]; float b0[2], b1[2], b2[2];
+        unsigned pn[PP];
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
+        for (int u = 0; u < PP; u++) pn[u] = e + u < e1 ? (unsigned)inv_src[e + u] : (u ? pn[0] : 0u);
+        for (; e < e1; e += PP) {
+            unsigned pp[PP];
+#pragma unroll
+            for (int u = 0; u < PP; u++) pp[u] = pn[u];
+            float4 q4[PP], g4[PP], a4[PP], d0[PP], d1[PP]; float b0[PP], b1[PP], b2[PP];
+#pragma unroll
+            for (int u = 0; u < PP; u++) {
                 const unsigned p = pp[u], i = p / (unsigned)K;
                 q4[u] = *reinterpret_cast<const float4*>(xq + (size_t)i * C + c0);
                 g4[u] = *reinterpret_cast<const float4*>(gout + (size_t)i * C + c0);
@@ -1054,11 +1071,20 @@ __global__ __launch_bounds__(256) void pt_target_kernel(unsigned n, const int* _
                 d0[u] = *reinterpret_cast<const float4*>(gw2 + (size_t)p * G);
                 d1[u] = G == 8 ? *reinterpret_cast<const float4*>(gw2 + (size_t)p * G + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            pa = e + 2 < e1 ? (unsigned)inv_src[e + 2] : 0u;
-            pb = e + 3 < e1 ? (unsigned)inv_src[e + 3] : pa;
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const float live = (u == 0 || two) ? 1.f : 0.f;       // an odd list's last trip repeats its pair with weight 0
+            for (int u = 0; u < PP; u++) pn[u] = e + PP + u < e1 ? (unsigned)inv_src[e + PP + u] : (u ? pn[0] : 0u);
+            int mo = m;
+            asm volatile("" : "+v"(mo));                              // opaque per trip: the table reads stay LDS reads inside the loop
+            float w0[4], w1[4], w2c[4], wbias[4], sc[4], sh[4], k1[4], k2[4], k3[4], wa[G][4];
+            {
+                auto get = [&](int k, float (&o)[4]) { const float4 t = ctab[k][mo]; o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w; };
+                get(0, w0); get(1, w1); get(2, w2c); get(3, wbias); get(4, sc); get(5, sh); get(6, k1); get(7, k2); get(8, k3);
+#pragma unroll
+                for (int g = 0; g < G; g++) get(9 + g, wa[g]);
+            }
+#pragma unroll
+            for (int u = 0; u < PP; u++) {
+                const float live = (e + u < e1) ? 1.f : 0.f;          // a list's last trip repeats a pair with weight 0 where it runs past the end
                 const float qx[4] = {q4[u].x, q4[u].y, q4[u].z, q4[u].w}, gx[4] = {g4[u].x, g4[u].y, g4[u].z, g4[u].w}, ax[4] = {a4[u].x, a4[u].y, a4[u].z, a4[u].w};
                 const float dv[8] = {d0[u].x, d0[u].y, d0[u].z, d0[u].w, d1[u].x, d1[u].y, d1[u].z, d1[u].w};
 #pragma unroll
@@ -1301,7 +1327,7 @@ CBL_EXPORT int cbl_pt_layer_backward(int n, int K, int C, const float* x_q, cons
     hipLaunchKernelGGL(pt_pchain_bwd_kernel, dim3(gp), dim3(PT_NARROW_BLOCK), 0, st, np, p_r, p0, p1, ws.gp1, consts, ws.part_d, (const float*)nullptr);
     {
         const unsigned tg = cbl_round_up8(cbl_grid_for(((long long)n + (256 / (C / 4)) - 1) / (256 / (C / 4)), 1, 2048));
-#define PT_TARGET(CC, KK) hipLaunchKernelGGL((pt_target_kernel<CC, KK>), dim3(tg), dim3(256), 0, st, (unsigned)n, order, inv_start, inv_src, x_q, x_k, p1, consts, ws.bc, W3C, b3C, Wa, ws.gw2, a, grad_out, g_xk, g_xv)
+#define PT_TARGET(CC, KK) hipLaunchKernelGGL((pt_target_kernel<CC, KK, PT_TARGET_PAIRS(CC)>), dim3(tg), dim3(256), 0, st, (unsigned)n, order, inv_start, inv_src, x_q, x_k, p1, consts, ws.bc, W3C, b3C, Wa, ws.gw2, a, grad_out, g_xk, g_xv)
         PT_DISPATCH(PT_TARGET)
     }
     PtSumSegs segs;

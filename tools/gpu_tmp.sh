@@ -1,8 +1,6 @@
-export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; export PYTHONPATH=$R; O=$R/gpurun_out/r06bench; mkdir -p $O
-python -m pytest tests/test_gpu_pointops.py tests/test_gpu_hotpath.py tests/test_gpu_bench_step.py tests/test_gpu_order.py tests/test_gpu_nested.py -x -q -m gpu > $O/tests2.log 2>&1; echo "tests rc=$?"; tail -3 $O/tests2.log
-python bench.py --no-legs --no-cpu-baseline --steps 30 > $O/bench_head.json 2>$O/bench_head.err
-python - <<'P'
-import json,os
-d=json.loads(open(os.environ["GRAFT_REPO_ROOT"]+"/gpurun_out/r06bench/bench_head.json").read().strip().splitlines()[-1])
-r=d["roofline"]; print(d["ms_per_step"], d.get("no_pipeline",{}).get("ms_per_step"), r["stage_ms"])
-P
+export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; export PYTHONPATH=$R
+for lib in "" $R/contrastboundary_amd/lib/libcbl_amd_pp3.so $R/contrastboundary_amd/lib/libcbl_amd_pp2.so; do
+  echo "== lib=$lib"
+  CBL_AMD_LIB=$lib bash tools/gpu_prof_any.sh ppx 60 python $R/tools/pt_layer_time.py 40960 16 64 2>&1 | grep -E "pt_target"
+  CBL_AMD_LIB=$lib bash tools/gpu_prof_any.sh ppy 60 python $R/tools/pt_layer_time.py 40960 8 32 2>&1 | grep -E "pt_target"
+done
