@@ -27,9 +27,18 @@
 
 namespace {
 
-constexpr int PT_BLOCK = 512;                       // 8 waves (256-thread workgroups measured no faster: the passes are bound by their waves' serial instruction streams)
+#ifndef PT_BLOCK_THREADS
+#define PT_BLOCK_THREADS 512
+#endif
+#ifndef PT_BWD_WAVES
+#define PT_BWD_WAVES 2                 // waves per SIMD the two C-wide backward passes are compiled for (amdgpu_waves_per_eu)
+#endif
+constexpr int PT_BLOCK = PT_BLOCK_THREADS;                       // 8 waves.  Round 6, -DPT_BLOCK_THREADS=256 -DPT_BWD_WAVES=3 (three 4-wave workgroups per CU for the backward passes, constants
+                                                                 // in LDS tables) against this at (40960, 16, 64): apply 56.1 -> 50.8 us, reduce 53.6 -> 57.8, softmax + aggregation 32.7 -> 38.3, statistics 22.0 -> 24.8
+                                                                 // (every workgroup pays the in-consumer finalize): forward + backward 402 -> 421 us.  Kept at 512.
 constexpr int PT_WPB = PT_BLOCK / 64;
-constexpr int PT_MAX_ROWS = 512;                    // partial rows of a pass = its workgroups
+constexpr int PT_MAX_ROWS = PT_BLOCK == 512 ? 512 : 1024;     // partial rows of a pass = its workgroups (all resident: two 512-lane or four 256-lane workgroups per CU)
+constexpr int PT_ONE_PER_CU = 256 * (PT_BLOCK == 512 ? 1 : PT_BWD_WAVES);     // workgroups of a pass whose registers allow PT_BWD_WAVES waves per SIMD
 constexpr int PT_NARROW_BLOCK = 256;
 // pairs in flight per target and trip of the target pass: measured at (40960, 16, 64) 2: 51.4, 3: 52.0, 4: 59.1 us (196 registers: two waves per SIMD — the pass
 // needs its waves more than deeper trips), at (40960, 8, 32) 2: 20.4, 3: 18.6, 4: 20.5 us
@@ -742,7 +751,7 @@ __global__ __launch_bounds__(PT_NARROW_BLOCK) void pt_narrow_bwd_kernel(long lon
 // APPLY:  d w = A1 d y1 + A2 w + A3; d x_q = - sum_k d w; d pe = d w + d out . a; d p1 = W3C^T d pe; d [W3C | b3C] = sum over pairs of d pe (x) [p1, 1].
 //         partial row: d W3C [C][3] | d b3C [C]
 template <int C, int K, bool APPLY>
-__global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* __restrict__ order, const float* __restrict__ xq, const float* __restrict__ xk,
+__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_BWD_WAVES, PT_BWD_WAVES))) void pt_w2_bwd_kernel(int n, const int* __restrict__ order, const float* __restrict__ xq, const float* __restrict__ xk,
                                                              const int* __restrict__ idx, const float* __restrict__ p1, const float* __restrict__ cst,
                                                              const float* __restrict__ bc, const float* __restrict__ W3C, const float* __restrict__ b3C,
                                                              const float* __restrict__ Wa, const float* __restrict__ w2, const float* __restrict__ pre,
@@ -752,7 +761,8 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
     constexpr int CT = C / 16, G = C / 8;
     constexpr int W = APPLY ? 4 * C : 2 * C + G * C;
     constexpr int TILEF = PT_TROWS * PT_ROWF;
-    constexpr int CTF = APPLY ? (5 + G + 3) * C : 0;                  // APPLY's per-channel constants: scale, shift, k1, k2, k3 | Wa [G][C] | W3C transposed [3][C]
+    constexpr bool TAB = APPLY || PT_BWD_WAVES >= 3;                  // per-channel constants in an LDS table (REDUCE: only where the register budget asks for it)
+    constexpr int CTF = TAB ? (5 + G + 3) * C : 0;                    // scale, shift, k1, k2, k3 | Wa [G][C] | (APPLY) W3C transposed [3][C]
     __shared__ __attribute__((aligned(16))) float lds[PT_WPB * (W > TILEF ? W : TILEF) + CTF];    // the waves' staged tiles (then the workgroup's partial row) | CTF — ONE array: a second
                                                                      // __shared__ object makes the compiler drain the prefetched loads before every LDS read
     const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4, wave = threadIdx.x >> 6;
@@ -769,12 +779,19 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
         for (int e = threadIdx.x; e < G * C; e += PT_BLOCK) ctab[5 * C + e] = Wa[e];
         for (int e = threadIdx.x; e < 3 * C; e += PT_BLOCK) ctab[(5 + G) * C + e] = W3C[3 * (e % C) + e / C];     // [d][c]
         __syncthreads();
+    } else if (TAB) {
+        for (int c = threadIdx.x; c < C; c += PT_BLOCK) {
+            const float is = cst[PT_CST_C + 192 + c];
+            ctab[c] = cst[PT_CST_C + c]; ctab[C + c] = cst[PT_CST_C + 64 + c]; ctab[2 * C + c] = is; ctab[3 * C + c] = -cst[PT_CST_C + 128 + c] * is;
+        }
+        for (int e = threadIdx.x; e < G * C; e += PT_BLOCK) ctab[5 * C + e] = Wa[e];
+        __syncthreads();
     }
 #pragma unroll
     for (int ct = 0; ct < CT; ct++) {
         const int c = 16 * ct + lo;
         sc[ct] = sh[ct] = k1[ct] = k2[ct] = wa0[ct] = wa1[ct] = 0.f;
-        if (!APPLY) {
+        if (!TAB) {
             sc[ct] = cst[PT_CST_C + c]; sh[ct] = cst[PT_CST_C + 64 + c];
             k1[ct] = cst[PT_CST_C + 192 + c];                                    // invstd
             k2[ct] = -cst[PT_CST_C + 128 + c] * k1[ct];                          // - mean invstd
@@ -850,13 +867,13 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_bwd_kernel(int n, const int* _
                 }
             }
             int lo_t = lo;
-            if (APPLY) asm volatile("" : "+v"(lo_t));                 // opaque per tile: the apply pass's constant reads stay LDS reads inside the loop (not hoisted back into 40 registers)
+            if (TAB) asm volatile("" : "+v"(lo_t));                   // opaque per tile: the table's constant reads stay LDS reads inside the loop (not hoisted back into 40 registers)
 #pragma unroll
             for (int ct = 0; ct < CT; ct++) {
                 const int cc = 16 * ct + lo_t;
-                const float sc_c = APPLY ? ctab[cc] : sc[ct], sh_c = APPLY ? ctab[C + cc] : sh[ct], k1_c = APPLY ? ctab[2 * C + cc] : k1[ct],
-                            k2_c = APPLY ? ctab[3 * C + cc] : k2[ct], k3_c = APPLY ? ctab[4 * C + cc] : 0.f;
-                const float wa0_c = APPLY ? ctab[5 * C + hi * C + cc] : wa0[ct], wa1_c = APPLY ? (G == 8 ? ctab[5 * C + (hi + 4) * C + cc] : 0.f) : wa1[ct];
+                const float sc_c = TAB ? ctab[cc] : sc[ct], sh_c = TAB ? ctab[C + cc] : sh[ct], k1_c = TAB ? ctab[2 * C + cc] : k1[ct],
+                            k2_c = TAB ? ctab[3 * C + cc] : k2[ct], k3_c = APPLY ? ctab[4 * C + cc] : 0.f;
+                const float wa0_c = TAB ? ctab[5 * C + hi * C + cc] : wa0[ct], wa1_c = TAB ? (G == 8 ? ctab[5 * C + (hi + 4) * C + cc] : 0.f) : wa1[ct];
                 const float w3x = APPLY ? ctab[(5 + G) * C + cc] : 0.f, w3y = APPLY ? ctab[(6 + G) * C + cc] : 0.f, w3z = APPLY ? ctab[(7 + G) * C + cc] : 0.f;
                 const float q = T[16 + (4 * hi) / K][16 * ct + lo], go = APPLY ? T[18 + (4 * hi) / K][16 * ct + lo] : 0.f;
                 pt_f32x4 w = pt_vec4(T[4 * hi][16 * ct + lo] - q, T[4 * hi + 1][16 * ct + lo] - q, T[4 * hi + 2][16 * ct + lo] - q, T[4 * hi + 3][16 * ct + lo] - q);
@@ -1218,7 +1235,7 @@ CBL_EXPORT int cbl_pt_layer_forward(int n, int K, int C, const float* xyz, const
     const unsigned gp = pt_pair_grid(np), gt = pt_tile_grid((np + 15) / 16);
     // the passes that hold one workgroup per CU (reduce, apply: 148 - 189 registers; w2 at C = 64: 139): one per CU in the launch, so that the pass's start-up (constants,
     // pipeline fill, in-consumer finalize) is paid once — the reduce pass 61.7 -> 53.4 us at (40960, 16, 64)
-    const unsigned gt1 = pt_tile_grid((np + 15) / 16, 256), gw = C == 64 ? gt1 : gt;
+    const unsigned gt1 = pt_tile_grid((np + 15) / 16, PT_ONE_PER_CU), gw = C == 64 ? gt1 : gt;
     float* rm[3] = {nullptr, nullptr, nullptr}; float* rv[3] = {nullptr, nullptr, nullptr}; long long* nb[3] = {nullptr, nullptr, nullptr};
     for (int t = 0; t < 3; t++) { if (running_mean3) rm[t] = running_mean3[t]; if (running_var3) rv[t] = running_var3[t]; if (num_batches3) nb[t] = num_batches3[t]; }
 
@@ -1277,7 +1294,7 @@ CBL_EXPORT int cbl_pt_layer_forward_eval(int n, int K, int C, const float* xyz, 
     const unsigned gp = pt_pair_grid(np), gt = pt_tile_grid((np + 15) / 16);
     // the passes that hold one workgroup per CU (reduce, apply: 148 - 189 registers; w2 at C = 64: 139): one per CU in the launch, so that the pass's start-up (constants,
     // pipeline fill, in-consumer finalize) is paid once — the reduce pass 61.7 -> 53.4 us at (40960, 16, 64)
-    const unsigned gt1 = pt_tile_grid((np + 15) / 16, 256), gw = C == 64 ? gt1 : gt;
+    const unsigned gt1 = pt_tile_grid((np + 15) / 16, PT_ONE_PER_CU), gw = C == 64 ? gt1 : gt;
     const int G = C / 8;
     hipLaunchKernelGGL(pt_eval_consts_kernel, dim3(1), dim3(128), 0, st, C, G, gamma_p, beta_p, gamma_c, beta_c, gamma_g, beta_g, running_mean3[0], running_var3[0],
                        running_mean3[1], running_var3[1], running_mean3[2], running_var3[2], eps3[0], eps3[1], eps3[2], consts);
@@ -1308,7 +1325,7 @@ CBL_EXPORT int cbl_pt_layer_backward(int n, int K, int C, const float* x_q, cons
     const unsigned gp = pt_pair_grid(np), gt = pt_tile_grid((np + 15) / 16);
     // the passes that hold one workgroup per CU (reduce, apply: 148 - 189 registers; w2 at C = 64: 139): one per CU in the launch, so that the pass's start-up (constants,
     // pipeline fill, in-consumer finalize) is paid once — the reduce pass 61.7 -> 53.4 us at (40960, 16, 64)
-    const unsigned gt1 = pt_tile_grid((np + 15) / 16, 256), gw = C == 64 ? gt1 : gt;
+    const unsigned gt1 = pt_tile_grid((np + 15) / 16, PT_ONE_PER_CU), gw = C == 64 ? gt1 : gt;
 
     const PtFin no_fin = {nullptr, 0, 0, np, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr};
 #define PT_AGGB(CC, KK) hipLaunchKernelGGL((pt_agg_kernel<CC, KK, true>), dim3(gt), dim3(PT_BLOCK), 0, st, n, order, x_v, idx, p1, W3C, b3C, const_cast<float*>(a), (float*)nullptr, grad_out, ws.glogit, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, no_fin)
