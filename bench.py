@@ -717,7 +717,10 @@ def workload_legs(args):
         plain and through a one-rank RCCL group with the flat gradient reducer (the collective IS issued; not a scaling number)"""
         plain = tool_leg("bench_model.py", ["--graph", "--steps", "10", "--warmup", "3"], pick_train)
         group = tool_leg("bench_model.py", ["--graph", "--single-rank-group", "--steps", "10", "--warmup", "3"], pick_train)
-        o = {"plain": plain, "single_rank_group": group}
+        # the reference's own per-GPU batch (config/s3dis: batch_size 16 over 4 GPUs, tool/train.py:178): at one scene per step the sampler of the NEXT batch
+        # (one workgroup per cloud, ~9 ms) is as long as the step it runs beside; four clouds sample side by side
+        four = tool_leg("bench_model.py", ["--graph", "--scenes", "4", "--steps", "6", "--warmup", "2"], pick_train)
+        o = {"plain": plain, "single_rank_group": group, "four_scenes": four}
         if plain.get("ms_per_step") and group.get("ms_per_step"):
             o["single_rank_group_over_plain"] = round(group["ms_per_step"] / plain["ms_per_step"], 3)
         return o
