@@ -575,23 +575,38 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_w2_kernel(int n, const int* __res
 // (slot lo, g = hi | hi + 4) are formed pair-major — the K slots of a point are K adjacent lanes of a row, so the softmax is two DPP folds —, pass through a
 // [slot][g] table in the wave's LDS tile into the channel-major operand a[slot 4 hi + v][lo % G], and are stored for the backward pass from that table
 // (16 bytes per lane).  The separate softmax launch of round 4 read w2 and wrote a (2 x 21 MB at (40960, 16, 64)) for 12 us + a launch boundary.
-// BWD: d logits = a (d a - sum_k a d a) with d a[k, g] = sum over c = g (mod G) of d out[c] (x_v[j, c] + pe[c])
+// BWD: d logits = a (d a - sum_k a d a) with d a[k, g] = sum over c = g (mod G) of d out[c] (x_v[j, c] + pe[c]) — and, in the same pass (round 6; a launch of
+// its own until then: 63 MB of narrow traffic for 19 us), the narrow backward behind it: pre = (y > 0) Wb^T d logits with y = BN_g(w2) (d w2 BEFORE BN_g's
+// backward, written in place of d logits, which no other pass reads), its two BatchNorm sums, d Wb, d bb.  The G logit gradients of a slot sit in the G lanes
+// lo < G of a lane row; they pass through the wave's [slot][g] table, and lane g' of the row forms column g' of the product and owns the sums of channel g'.
+//   partial row (BWD): S1 [G] | S2 [G] | d Wb [G][G] | d bb [G]
 template <int C, int K, bool BWD>
 __global__ __launch_bounds__(PT_BLOCK) void pt_agg_kernel(int n, const int* __restrict__ order, const float* __restrict__ xv, const int* __restrict__ idx,
                                                           const float* __restrict__ p1, const float* __restrict__ W3C, const float* __restrict__ b3C,
                                                           float* __restrict__ a, float* __restrict__ out, const float* __restrict__ gout,
                                                           float* __restrict__ glogit, const float* __restrict__ w2, const float* __restrict__ Wb,
-                                                          const float* __restrict__ bb, const float* __restrict__ cst, PtFin fin_g)
+                                                          const float* __restrict__ bb, const float* __restrict__ cst, PtFin fin_g, float* __restrict__ partial)
 {
-    constexpr int CT = C / 16, G = C / 8, NX = BWD ? 1 : 0;
+    constexpr int CT = C / 16, G = C / 8, NX = BWD ? 1 : 0, WN = 3 * G + G * G;
     constexpr int TILEF = PT_TROWS * PT_ROWF;
-    __shared__ __attribute__((aligned(16))) float lds[PT_WPB * TILEF + 96];     // the waves' tiles | forward: scale [8], shift [8], Wb [G][G], bb [8] — ONE array (pt_w2_bwd_kernel)
+    static_assert(PT_WPB * WN <= PT_WPB * TILEF, "the backward's partial rows lie over the tiles");
+    __shared__ __attribute__((aligned(16))) float lds[PT_WPB * TILEF + 96];     // the waves' tiles | scale [8], shift [8], Wb [G][G], bb [8] (forward) / invstd, -mean invstd (backward) — ONE array (pt_w2_bwd_kernel)
     const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4, wave = threadIdx.x >> 6;
     float (*T)[PT_ROWF] = reinterpret_cast<float (*)[PT_ROWF]>(lds + wave * TILEF);
-    float* AT = &T[16][0];                                           // forward: the tile's softmax weights [slot][g] (rows 16.. hold nothing else when NX = 0)
+    float* AT = &T[18][0];                                           // the tile's narrow [slot][g] table (forward: softmax weights, backward: d logits): rows 18 - 19, which no staging of this pass uses
     float* ctab = lds + PT_WPB * TILEF;
     const PtPe<C> pe = pt_pe_load<C>(W3C, b3C, lo, hi);
     const int o0 = hi < G ? hi : 0, o1 = G == 8 ? hi + 4 : 0;
+    // BWD: this lane's channel g' = lo % G of the narrow backward: BN_g constants, column g' of Wb, and the sums it owns
+    float nsc = 0.f, nsh = 0.f, nis = 0.f, nnm = 0.f, wcol[G], nacc[G], ns1 = 0.f, ns2 = 0.f, nsb = 0.f;
+#pragma unroll
+    for (int g = 0; g < G; g++) { wcol[g] = 0.f; nacc[g] = 0.f; }
+    if (BWD) {
+        const int gq = lo % G;
+        nsc = cst[PT_CST_G + gq]; nsh = cst[PT_CST_G + 8 + gq]; nis = cst[PT_CST_G + 24 + gq]; nnm = -cst[PT_CST_G + 16 + gq] * nis;
+#pragma unroll
+        for (int g = 0; g < G; g++) wcol[g] = Wb[g * G + gq];
+    }
     const unsigned ntiles = (unsigned)(((long long)n * K + 15) / 16);
     struct S1 { int4 j; float p1x; float av[4]; float4 wlo, whi; };
     pt_pipeline(ntiles,
@@ -606,6 +621,7 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_agg_kernel(int n, const int* __re
             if (BWD) {
 #pragma unroll
                 for (int v = 0; v < 4; v++) b.av[v] = a[(pt_ix)(t.pD + v) * G + (lo % G)];
+                b.wlo = make_float4(w2[(pt_ix)t.pD * G + (lo % G)], w2[(pt_ix)(t.pD + 1) * G + (lo % G)], w2[(pt_ix)(t.pD + 2) * G + (lo % G)], w2[(pt_ix)(t.pD + 3) * G + (lo % G)]);
             } else {                                                             // w2 of pair slot lo, all G values
                 b.wlo = *reinterpret_cast<const float4*>(w2 + (pt_ix)t.pA * G);
                 if (G == 8) b.whi = *reinterpret_cast<const float4*>(w2 + (pt_ix)t.pA * G + 4);
@@ -671,9 +687,30 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_agg_kernel(int n, const int* __re
                     dot = fmaf(av[v], ga[v], dot);
                 }
                 dot = pt_point_sum<K>(dot);
-                if (lo < G && t.vD) {
+                // d logits of (slot 4 hi + v, g = lo) in the lanes lo < G -> the wave's [slot][g] table; 0 for slots past the end (they add nothing below)
+                float gl[4];
 #pragma unroll
-                    for (int v = 0; v < 4; v++) glogit[(pt_ix)(t.pD + v) * G + lo] = av[v] * (ga[v] - dot);
+                for (int v = 0; v < 4; v++) { gl[v] = t.vD ? av[v] * (ga[v] - dot) : 0.f; if (lo < G) AT[(4 * hi + v) * G + lo] = gl[v]; }
+                pt_wave_sync();
+                const float w2v[4] = {b.wlo.x, b.wlo.y, b.wlo.z, b.wlo.w};
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    float row[G];
+#pragma unroll
+                    for (int q = 0; q < G / 4; q++) {
+                        const float4 x = *reinterpret_cast<const float4*>(&AT[(4 * hi + v) * G + 4 * q]);
+                        row[4 * q] = x.x; row[4 * q + 1] = x.y; row[4 * q + 2] = x.z; row[4 * q + 3] = x.w;
+                    }
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int g = 0; g < G; g++) sacc = fmaf(wcol[g], row[g], sacc);
+                    const float y = fmaf(w2v[v], nsc, nsh);
+                    const float d = y > 0.f ? sacc : 0.f;
+                    if (lo < G && t.vD) glogit[(pt_ix)(t.pD + v) * G + lo] = d;            // `pre`: what the reduce pass takes through BN_g's backward
+                    const float ry = fmaxf(y, 0.f), glo = gl[v];         // this lane's own d logit (g = lo % G: every lane of the row holds its channel's value)
+                    ns1 += d; ns2 = fmaf(d, fmaf(w2v[v], nis, nnm), ns2); nsb += glo;
+#pragma unroll
+                    for (int g = 0; g < G; g++) nacc[g] = fmaf(row[g], ry, nacc[g]);          // d Wb[g][g'] += d logit[g] relu(y)[g']
                 }
             }
         },
@@ -689,59 +726,24 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_agg_kernel(int n, const int* __re
                 __syncthreads();                                             // table complete; the scratch becomes the waves' tiles
             }
         });
-}
-
-// ---- narrow backward (lane = pair): d w2 BEFORE BN_g's backward, its two sums, d Wb, d bb ------------------------------------------------
-// partial row: S1 [G] | S2 [G] | d Wb [G][G] | d bb [G]
-template <int G>
-__global__ __launch_bounds__(PT_NARROW_BLOCK) void pt_narrow_bwd_kernel(long long npairs, const float* __restrict__ w2, const float* __restrict__ cst,
-                                                                        const float* __restrict__ Wb, const float* __restrict__ glogit, float* __restrict__ pre,
-                                                                        float* __restrict__ partial)
-{
-    constexpr int W = 3 * G + G * G;
-    __shared__ float red[PT_NARROW_BLOCK / 64][W];
-    float sc[G], sh[G], is[G], nm[G], acc[W];
+    if (BWD) {
+        // the narrow backward's partial row: lanes lo < G of the four lane rows hold channel g' = lo's sums over their slots (lanes lo >= G repeat them: not read)
+        __syncthreads();                                             // every wave is done with its tile
+        float (*red)[WN] = reinterpret_cast<float (*)[WN]>(lds);
+        ns1 = pt_point_sum<16>(ns1); ns2 = pt_point_sum<16>(ns2); nsb = pt_point_sum<16>(nsb);
 #pragma unroll
-    for (int g = 0; g < G; g++) {
-        sc[g] = cst[PT_CST_G + g]; sh[g] = cst[PT_CST_G + 8 + g]; is[g] = cst[PT_CST_G + 24 + g]; nm[g] = -cst[PT_CST_G + 16 + g] * is[g];
-    }
+        for (int g = 0; g < G; g++) nacc[g] = pt_point_sum<16>(nacc[g]);
+        if (hi == 0 && lo < G) {
+            red[wave][lo] = ns1; red[wave][G + lo] = ns2; red[wave][2 * G + G * G + lo] = nsb;
 #pragma unroll
-    for (int t = 0; t < W; t++) acc[t] = 0.f;
-    for (long long p = (long long)blockIdx.x * PT_NARROW_BLOCK + threadIdx.x; p < npairs; p += (long long)gridDim.x * PT_NARROW_BLOCK) {
-        float x[G], gl[G], y[G];
-#pragma unroll
-        for (int q = 0; q < G / 4; q++) {
-            const float4 t = *reinterpret_cast<const float4*>(w2 + p * G + 4 * q), u = *reinterpret_cast<const float4*>(glogit + p * G + 4 * q);
-            x[4 * q] = t.x; x[4 * q + 1] = t.y; x[4 * q + 2] = t.z; x[4 * q + 3] = t.w;
-            gl[4 * q] = u.x; gl[4 * q + 1] = u.y; gl[4 * q + 2] = u.z; gl[4 * q + 3] = u.w;
+            for (int g = 0; g < G; g++) red[wave][2 * G + g * G + lo] = nacc[g];
         }
-        float out[G];
-#pragma unroll
-        for (int g = 0; g < G; g++) {
-            y[g] = fmaf(x[g], sc[g], sh[g]);
-            float s = 0.f;
-#pragma unroll
-            for (int o = 0; o < G; o++) s = fmaf(Wb[o * G + g], gl[o], s);
-            const float d = y[g] > 0.f ? s : 0.f;
-            out[g] = d;
-            acc[g] += d; acc[G + g] = fmaf(d, fmaf(x[g], is[g], nm[g]), acc[G + g]);
+        __syncthreads();
+        for (int tt = threadIdx.x; tt < WN; tt += PT_BLOCK) {
+            float sum = 0.f;
+            for (int wv = 0; wv < PT_WPB; wv++) sum += red[wv][tt];
+            partial[(size_t)blockIdx.x * WN + tt] = sum;
         }
-#pragma unroll
-        for (int o = 0; o < G; o++) {
-#pragma unroll
-            for (int g = 0; g < G; g++) acc[2 * G + o * G + g] = fmaf(gl[o], fmaxf(y[g], 0.f), acc[2 * G + o * G + g]);
-            acc[2 * G + G * G + o] += gl[o];
-        }
-#pragma unroll
-        for (int q = 0; q < G / 4; q++) *reinterpret_cast<float4*>(pre + p * G + 4 * q) = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
-    }
-#pragma unroll
-    for (int t = 0; t < W; t++) { const float s = pt_wave_sum(acc[t]); if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][t] = s; }
-    __syncthreads();
-    for (int t = threadIdx.x; t < W; t += PT_NARROW_BLOCK) {
-        float s = 0.f;
-        for (int wv = 0; wv < PT_NARROW_BLOCK / 64; wv++) s += red[wv][t];
-        partial[(size_t)blockIdx.x * W + t] = s;
     }
 }
 
@@ -1249,7 +1251,7 @@ CBL_EXPORT int cbl_pt_layer_forward(int n, int K, int C, const float* xyz, const
                        momentum3[1], rm[1], rv[1], nb[1], consts + PT_CST_C, 64, 0, (float*)nullptr);
 #define PT_W2(CC, KK) hipLaunchKernelGGL((pt_w2_kernel<CC, KK>), dim3(gw), dim3(PT_BLOCK), 0, st, n, order, x_q, x_k, idx, p1, consts, W3C, b3C, Wa, ba, w2, ws.part_a)
     PT_DISPATCH(PT_W2)
-#define PT_AGG(CC, KK) hipLaunchKernelGGL((pt_agg_kernel<CC, KK, false>), dim3(gt), dim3(PT_BLOCK), 0, st, n, order, x_v, idx, p1, W3C, b3C, a, out, (const float*)nullptr, (float*)nullptr, (const float*)w2, Wb, bb, (const float*)consts, fin_g)
+#define PT_AGG(CC, KK) hipLaunchKernelGGL((pt_agg_kernel<CC, KK, false>), dim3(gt), dim3(PT_BLOCK), 0, st, n, order, x_v, idx, p1, W3C, b3C, a, out, (const float*)nullptr, (float*)nullptr, (const float*)w2, Wb, bb, (const float*)consts, fin_g, (float*)nullptr)
     PT_DISPATCH(PT_AGG)
     return cbl_status();
 }
@@ -1328,12 +1330,11 @@ CBL_EXPORT int cbl_pt_layer_backward(int n, int K, int C, const float* x_q, cons
     const unsigned gt1 = pt_tile_grid((np + 15) / 16, PT_ONE_PER_CU), gw = C == 64 ? gt1 : gt;
 
     const PtFin no_fin = {nullptr, 0, 0, np, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr};
-#define PT_AGGB(CC, KK) hipLaunchKernelGGL((pt_agg_kernel<CC, KK, true>), dim3(gt), dim3(PT_BLOCK), 0, st, n, order, x_v, idx, p1, W3C, b3C, const_cast<float*>(a), (float*)nullptr, grad_out, ws.glogit, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, no_fin)
-    PT_DISPATCH(PT_AGGB)
-    if (G == 8) hipLaunchKernelGGL(pt_narrow_bwd_kernel<8>, dim3(gp), dim3(PT_NARROW_BLOCK), 0, st, np, w2, consts, Wb, ws.glogit, ws.pre, ws.part_c);
-    else        hipLaunchKernelGGL(pt_narrow_bwd_kernel<4>, dim3(gp), dim3(PT_NARROW_BLOCK), 0, st, np, w2, consts, Wb, ws.glogit, ws.pre, ws.part_c);
+    const unsigned gab = gt1;                                        // 155 registers with the narrow backward inside: one workgroup per CU (against two per CU launched: 34.7 -> 31.9 us, and the reduce pass's prologue reads half the rows)
+#define PT_AGGB(CC, KK) hipLaunchKernelGGL((pt_agg_kernel<CC, KK, true>), dim3(gab), dim3(PT_BLOCK), 0, st, n, order, x_v, idx, p1, W3C, b3C, const_cast<float*>(a), (float*)nullptr, grad_out, ws.pre, w2, Wb, (const float*)nullptr, consts, no_fin, ws.part_c)
+    PT_DISPATCH(PT_AGGB)                                             // d logits and the narrow backward behind them: writes `pre`, partial rows in part_c
     // BN_g's backward finalize runs in the prologue of the reduce pass (pt_fin_backward)
-    const PtFinBwd fin_gb = {ws.part_c, (int)gp, WN, np, gamma_g, consts + PT_CST_G, 8, consts + PT_FS_G, g_gamma_g, g_beta_g, g_ba};
+    const PtFinBwd fin_gb = {ws.part_c, (int)gab, WN, np, gamma_g, consts + PT_CST_G, 8, consts + PT_FS_G, g_gamma_g, g_beta_g, g_ba};
     const PtFinBwd no_finb = {nullptr, 0, 0, np, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
 #define PT_REDUCE(CC, KK) hipLaunchKernelGGL((pt_w2_bwd_kernel<CC, KK, false>), dim3(gt1), dim3(PT_BLOCK), 0, st, n, order, x_q, x_k, idx, p1, consts, ws.bc, W3C, b3C, Wa, w2, ws.pre, ws.gw2, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, ws.part_a, fin_gb)
     PT_DISPATCH(PT_REDUCE)
@@ -1352,8 +1353,8 @@ CBL_EXPORT int cbl_pt_layer_backward(int n, int K, int C, const float* x_q, cons
     segs.s[0] = PtSumSeg{ws.part_a, g_Wa, (int)gt1, 2 * C + G * C, 2 * C, G * C};
     segs.s[1] = PtSumSeg{ws.part_b, g_W3C, (int)gt1, 4 * C, 0, 3 * C};
     segs.s[2] = PtSumSeg{ws.part_b, g_b3C, (int)gt1, 4 * C, 3 * C, C};
-    segs.s[3] = PtSumSeg{ws.part_c, g_Wb, (int)gp, WN, 2 * G, G * G};
-    segs.s[4] = PtSumSeg{ws.part_c, g_bb, (int)gp, WN, 2 * G + G * G, G};
+    segs.s[3] = PtSumSeg{ws.part_c, g_Wb, (int)gab, WN, 2 * G, G * G};
+    segs.s[4] = PtSumSeg{ws.part_c, g_bb, (int)gab, WN, 2 * G + G * G, G};
     unsigned nblk = 0;
     for (int q = 0; q < segs.n; q++) nblk += (unsigned)((segs.s[q].count + 15) / 16);
     // + the p chain's epilogue as one more block of the same launch
