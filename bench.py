@@ -191,18 +191,36 @@ def host_dry_run(args, D, world, rank):
 
 
 # ------------------------------------------------------------------------------------------------ the step
+# measured in one gpurun call each (profiles/r06_pair_tables_ab.txt), three runs per arm: Point Transformer block pipelined 0.486 -> 0.477 ms, one step at a time
+# 0.624 -> 0.600; KPConv block pipelined 0.280 -> 0.284 ("pair_split"; the pair build on the search stream: 0.349), one step at a time unchanged (its block table
+# is built on a stream of its own beside the forward either way)
+PAIR_TABLES_DEFAULT = {"pt": "1", "kpconv": "0"}
+
+
+def pair_layout_forced(step):
+    """CBL_PIPELINE_LAYOUT only applies where it fits how the step's stages build their tables (a forward-only step builds no pair: its layouts are the plain ones)"""
+    env = os.environ.get("CBL_PIPELINE_LAYOUT")
+    return bool(env) and env.startswith("pair_") != step.pair_tables
+
+
 class Step:
     """the hot path over one resident scene as bench.py runs it: schedule + its hipGraph(s).
     pipeline: consecutive steps software-pipelined over four streams, one linear hipGraph per chain (hotpath.Pipeline: the search of step i+1
     beside the forward kernels of step i and the backward kernels of step i-1); steps rotate through the pipeline's output slots (self.states)."""
 
-    def __init__(self, scene, k, backward, args, overlap=True, pipeline=False):
+    def __init__(self, scene, k, backward, args, overlap=True, pipeline=False, pair_tables=None):
         from contrastboundary_amd import hotpath
         self.block = getattr(args, "block", "kpconv")
-        self.stages = (hotpath.stages_pt if self.block == "pt" else hotpath.stages)(scene, k, backward)
+        # the two transposed tables of the step's one geometry (K = 36 for the CBL head, K = 16 for the block) by one set of launches (cbl_neighbor_transpose_pair);
+        # CBL_PAIR_TABLES=0 (or a CBL_PIPELINE_LAYOUT that is not a "pair_" one): one after the other, each on the stream of its consumer (the round-5 step)
+        env_layout = os.environ.get("CBL_PIPELINE_LAYOUT")
+        if pair_tables is None:
+            pair_tables = env_layout.startswith("pair_") if env_layout else os.environ.get("CBL_PAIR_TABLES", PAIR_TABLES_DEFAULT[self.block]) != "0"
+        self.pair_tables = bool(backward) and bool(pair_tables)
+        self.stages = (hotpath.stages_pt if self.block == "pt" else hotpath.stages)(scene, k, backward, pair_tables=self.pair_tables)
         self.names = [st[0] for st in self.stages]
         self.hints = () if args.no_nested else hotpath.search_hints(scene)
-        self.sched = hotpath.Schedule(self.stages, overlap=overlap, hints=self.hints, aux_tables=getattr(args, "block", "kpconv") != "pt")
+        self.sched = hotpath.Schedule(self.stages, overlap=overlap, hints=self.hints, aux_tables=getattr(args, "block", "kpconv") != "pt", pair_tables=self.pair_tables)
         self.pipeline = bool(pipeline and overlap and self.hints)
         self.pipe = None
         self.states = [{}]
@@ -228,7 +246,8 @@ class Step:
             from contrastboundary_amd import hotpath
             # KPConv block: the backward on a stream of its own, the CBL chain's table first, three slots; Point Transformer block (its backward chain is 0.46 of
             # the 0.55 ms): consecutive steps' backward chains on two streams in turn, four slots — all measured against the other layouts in one call (hotpath.Pipeline)
-            pipe = hotpath.Pipeline(self.sched, layout=os.environ.get("CBL_PIPELINE_LAYOUT") or ("alt_bwd" if self.block == "pt" else "split_t36_first"),
+            default_layout = ("pair_alt_bwd" if self.block == "pt" else "pair_split") if self.pair_tables else ("alt_bwd" if self.block == "pt" else "split_t36_first")
+            pipe = hotpath.Pipeline(self.sched, layout=(os.environ.get("CBL_PIPELINE_LAYOUT") if not pair_layout_forced(self) else None) or default_layout,
                                     slots=os.environ.get("CBL_PIPELINE_SLOTS") or (4 if self.block == "pt" else 3))
             pipe.capture()
             self.pipe, self.states = pipe, pipe.states
@@ -317,10 +336,68 @@ def checked_pipeline_step(scene, k, backward, args, overlap, pipeline):
 
 
 def stage_times(scene, k, backward, args, reps=8):
-    """per-stage device time: the step IN ORDER on one stream (a stage's time is that stage alone), HIP events on the launch stream around
-    every stage.  The steps are issued eagerly behind filler kernels sized from the host's own issue time of one step (1.5 x), so the host is a
-    whole step ahead of the device and an interval holds the stage's kernels and their launch gaps, not the host.  (ROCm has no event-record
-    graph nodes, and one hipGraph per stage costs ~20 us of replay overhead per stage: measured, dropped.)"""
+    """per-stage device time of the step IN ORDER on one stream -> (step, ms per stage, how).  Round 6: differences of PREFIX graphs — the stages 0..i of the
+    in-order step captured as one hipGraph per i, every graph replayed back to back between two HIP events; stage i = T(0..i) - T(0..i-1).  No host time can
+    enter (a replay is one launch; the eager harness below read 0.42 ms for the attention layer's backward whose graph takes 0.27: its ~40 launches out-ran the
+    filler on a slow host), the per-replay overhead of a graph cancels in the difference, and every stage runs behind the stages it follows in the step (same
+    cache state).  Falls back to the eager harness (events around eagerly issued stages behind filler kernels) if a capture fails."""
+    try:
+        return stage_times_prefix_graphs(scene, k, backward, args, reps)
+    except Exception as e:                                           # noqa: BLE001 - any capture problem: the eager harness, and say so
+        torch.cuda.synchronize()
+        st, ms, how = stage_times_eager(scene, k, backward, args, reps)
+        return st, ms, how + " (prefix-graph harness failed: %s: %s)" % (type(e).__name__, str(e)[:80])
+
+
+def stage_times_prefix_graphs(scene, k, backward, args, reps=8):
+    import gc
+    from contrastboundary_amd import hotpath
+    st = Step(scene, k, backward, args, overlap=False)
+    settle(st, 0.2)
+    gc.collect()
+    cap = torch.cuda.Stream()
+    graphs, state = [], None
+    for i in range(len(st.stages)):
+        sched = hotpath.Schedule(st.stages[:i + 1], overlap=False, hints=st.hints, pair_tables=st.pair_tables)
+        gstate = {}
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap):
+            sched.run(gstate, None)                                  # once eagerly: workspaces of this stream, code objects
+        torch.cuda.current_stream().wait_stream(cap)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=cap, capture_error_mode="thread_local"):
+            sched.run(gstate, None)
+        graphs.append(g); state = gstate
+    inner = 5
+
+    def timed(g):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(cap):
+            g.replay()
+            a.record()
+            for _ in range(inner):
+                g.replay()
+            b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / inner
+    for g in graphs:
+        g.replay()
+    torch.cuda.synchronize()
+    samples = [[timed(g) for g in graphs] for _ in range(max(3, reps // 2))]
+    T = np.median(np.asarray(samples), axis=0)
+    ms = [float(T[0])] + [float(max(T[i] - T[i - 1], 0.0)) for i in range(1, len(T))]
+    st.states = [state]                                               # the full step's outputs (the last prefix), for the callers that check them
+    how = ("differences of prefix graphs: stages 0..i of the in-order step as one hipGraph per i, %d back-to-back replays between two HIP events, median of %d rounds; "
+           "stage i = T(0..i) - T(0..i-1) (device time with a graph's launch gaps, no host issue time; the first stage also carries a replay's fixed cost)"
+           % (inner, len(samples)))
+    return st, ms, how
+
+
+def stage_times_eager(scene, k, backward, args, reps=8):
+    """the round-5 harness: HIP events on the launch stream around every stage of eagerly issued in-order steps.  The steps are issued behind filler kernels
+    sized from the host's own issue time of one step (1.5 x), so the host is a whole step ahead of the device and an interval holds the stage's kernels and
+    their launch gaps, not the host — as long as the host out-runs the device inside the step too."""
     st = Step(scene, k, backward, args, overlap=False)
     settle(st, 0.2)
     filler = torch.empty(1 << 31, dtype=torch.uint8, device="cuda")
@@ -530,7 +607,7 @@ def run_gpu(args, D, world, rank, local):
         first, later = names.index("knnquery_k%d" % k), names.index("cbl_knnquery_k%d" % hotpath.CBL_NSAMPLE)
         stage_bytes[first] += stage_bytes[later]
         stage_bytes[later] = 0
-    gbps = lambda i: stage_bytes[i] / (stage_ms[i] * 1e-3) / 1e9
+    gbps = lambda i: stage_bytes[i] / (stage_ms[i] * 1e-3) / 1e9 if stage_ms[i] > 0 else 0.0       # (a stage that launches nothing — a registry hit — measures 0)
     pmc = {}
     if os.path.exists(PMC_FILE) and (n, c, k) == (40960, 64, 16):
         pmc = json.load(open(PMC_FILE))
@@ -1104,7 +1181,7 @@ def run_pt(args, D, world, rank, local):
     if bwd_us is not None:
         out["roofline"]["layer_bwd_us"] = bwd_us                     # float, or {"error": ...}
         out["roofline"]["layer_bwd_note"] = ("the layer's backward alone (w.r.t. its input features and all parameters, the transposed table already built): 20 replays of a hipGraph "
-                                             "between two HIP events / 20 — device time with a graph's launch gaps, no host issue time (stage_ms.pt_layer_bwd is the eager stage)")
+                                             "between two HIP events / 20 — device time with a graph's launch gaps and one replay's fixed cost (stage_ms.pt_layer_bwd: the same chain inside the in-order step, by difference of prefix graphs)")
     if backward:
         fstep = make_step(scene, k, False, args, overlap=not args.no_overlap, pipeline=pipeline)
         e_f = timed_region(fstep, args.steps, args.warmup, sync, D)

@@ -65,11 +65,12 @@ static size_t nt_carve(NtWs& w, char* base, int m, int n, int nsample)
     return off;
 }
 
-__global__ __launch_bounds__(NB) void nt_prep_kernel(int n, int nzero, const int* __restrict__ order, int* __restrict__ rank, int* __restrict__ zero)
+__global__ __launch_bounds__(NB) void nt_prep_kernel(int n, int nzero, const int* __restrict__ order, int* __restrict__ rank, int* __restrict__ zero,
+                                                     int* __restrict__ zero2)
 {
     const int i = blockIdx.x * NB + threadIdx.x;
     if (order && i < n) rank[order[i]] = i;
-    if (i < nzero) zero[i] = 0;
+    if (i < nzero) { zero[i] = 0; if (zero2) zero2[i] = 0; }          // zero2: the second table of a pair build (cbl_neighbor_transpose_pair)
 }
 
 // A source tile's pairs are walked UN pairs per thread at a time — UN chosen so that ONE batch covers the tile (64 x nsample pairs over 256
@@ -97,12 +98,19 @@ __device__ __forceinline__ void nt_load_pairs(NtPairs<UN>& q, unsigned base, uns
     }
 }
 
+// one table's share of a pair build: what the kernels below take as separate arguments.  Both tables of a pair have the same sources, targets and orders
+// (two neighbour tables of ONE geometry: the block's K = 8 / 16 and the CBL head's K = 36), so rank, order_src and the tile counts are shared.
+struct NtJob {
+    int ns; CblFastDiv dv; const int* idx;
+    int *tile_cursor, *list_cursor, *tile_list_off, *tile_list_n, *tile_base; int2 *lists, *bins; int* scratch;
+    int *inv_start, *inv_src;
+};
+
 template <int UN>
-__global__ __launch_bounds__(NB) void nt_count_kernel(int m, int n, int ns, int ntt, CblFastDiv dv, const int* __restrict__ idx, const int* __restrict__ order_src,
-                                                      const int* __restrict__ rank, int* __restrict__ tile_cursor, int* __restrict__ list_cursor,
-                                                      int* __restrict__ tile_list_off, int* __restrict__ tile_list_n, int2* __restrict__ lists)
+__device__ __forceinline__ void nt_count_body(int* lds, int m, int n, int ns, int ntt, CblFastDiv dv, const int* __restrict__ idx, const int* __restrict__ order_src,
+                                              const int* __restrict__ rank, int* __restrict__ tile_cursor, int* __restrict__ list_cursor,
+                                              int* __restrict__ tile_list_off, int* __restrict__ tile_list_n, int2* __restrict__ lists)
 {
-    extern __shared__ int lds[];
     int* hist = lds;                                                 // ntt
     int2* mine = reinterpret_cast<int2*>(lds + ((ntt + 1) & ~1));    // up to min(ntt, TS * ns) records (8-byte aligned)
     __shared__ int nmine, gbase, src_ids[TS];
@@ -133,6 +141,23 @@ __global__ __launch_bounds__(NB) void nt_count_kernel(int m, int n, int ns, int 
     __syncthreads();
     for (int e = threadIdx.x; e < nmine; e += NB) lists[gbase + e] = mine[e];
 }
+template <int UN>
+__global__ __launch_bounds__(NB) void nt_count_kernel(int m, int n, int ns, int ntt, CblFastDiv dv, const int* __restrict__ idx, const int* __restrict__ order_src,
+                                                      const int* __restrict__ rank, int* __restrict__ tile_cursor, int* __restrict__ list_cursor,
+                                                      int* __restrict__ tile_list_off, int* __restrict__ tile_list_n, int2* __restrict__ lists)
+{
+    extern __shared__ int lds[];
+    nt_count_body<UN>(lds, m, n, ns, ntt, dv, idx, order_src, rank, tile_cursor, list_cursor, tile_list_off, tile_list_n, lists);
+}
+// the two tables of a pair in ONE launch: blockIdx.y picks the table.  The build is a chain of L2 round trips on a few workgroups per CU; side by side the two
+// chains cover each other, and a step has four launches less.
+template <int UNA, int UNB>
+__global__ __launch_bounds__(NB) void nt_count_pair_kernel(int m, int n, int ntt, const int* __restrict__ order_src, const int* __restrict__ rank, NtJob a, NtJob b)
+{
+    extern __shared__ int lds[];
+    if (blockIdx.y == 0) nt_count_body<UNA>(lds, m, n, a.ns, ntt, a.dv, a.idx, order_src, rank, a.tile_cursor, a.list_cursor, a.tile_list_off, a.tile_list_n, a.lists);
+    else                 nt_count_body<UNB>(lds, m, n, b.ns, ntt, b.dv, b.idx, order_src, rank, b.tile_cursor, b.list_cursor, b.tile_list_off, b.tile_list_n, b.lists);
+}
 
 // exclusive scan of the bin sizes by ONE workgroup (ntt <= NT_MAX_TILES = 16 per lane of 1024): only launched for large tables, where every
 // source-tile workgroup scanning all bin sizes itself (nt_bin_kernel<UN, false>) is a term quadratic in the number of tiles — nothing at 640
@@ -157,12 +182,11 @@ __global__ __launch_bounds__(1024) void nt_scan_kernel(int ntt, const int* __res
 }
 
 template <int UN, bool SCANNED>
-__global__ __launch_bounds__(NB) void nt_bin_kernel(int m, int n, int ns, int ntt, CblFastDiv dv, const int* __restrict__ idx, const int* __restrict__ order_src,
-                                                    const int* __restrict__ rank, const int* __restrict__ tile_cursor, const int* __restrict__ tile_list_off,
-                                                    const int* __restrict__ tile_list_n, const int2* __restrict__ lists, int* __restrict__ tile_base,
-                                                    int2* __restrict__ bins)
+__device__ __forceinline__ void nt_bin_body(int* lds, int m, int n, int ns, int ntt, CblFastDiv dv, const int* __restrict__ idx, const int* __restrict__ order_src,
+                                            const int* __restrict__ rank, const int* __restrict__ tile_cursor, const int* __restrict__ tile_list_off,
+                                            const int* __restrict__ tile_list_n, const int2* __restrict__ lists, int* __restrict__ tile_base,
+                                            int2* __restrict__ bins)
 {
-    extern __shared__ int lds[];
     int* where = lds;                                                // ntt: size of bin tt -> its start -> (touched bins) start of this tile's range in it
     int* hist = lds + ntt;                                           // ntt: running position inside the range
     __shared__ int wave_tot[NB / 64], src_ids[TS];
@@ -202,6 +226,22 @@ __global__ __launch_bounds__(NB) void nt_bin_kernel(int m, int n, int ns, int nt
         for (int u = 0; u < UN; u++)
             if (q.r[u] >= 0) { const int tt = q.r[u] / TT; bins[where[tt] + atomicAdd(&hist[tt], 1)] = make_int2(q.r[u] & (TT - 1), (int)q.p[u]); }
     }
+}
+template <int UN, bool SCANNED>
+__global__ __launch_bounds__(NB) void nt_bin_kernel(int m, int n, int ns, int ntt, CblFastDiv dv, const int* __restrict__ idx, const int* __restrict__ order_src,
+                                                    const int* __restrict__ rank, const int* __restrict__ tile_cursor, const int* __restrict__ tile_list_off,
+                                                    const int* __restrict__ tile_list_n, const int2* __restrict__ lists, int* __restrict__ tile_base,
+                                                    int2* __restrict__ bins)
+{
+    extern __shared__ int lds[];
+    nt_bin_body<UN, SCANNED>(lds, m, n, ns, ntt, dv, idx, order_src, rank, tile_cursor, tile_list_off, tile_list_n, lists, tile_base, bins);
+}
+template <int UNA, int UNB>
+__global__ __launch_bounds__(NB) void nt_bin_pair_kernel(int m, int n, int ntt, const int* __restrict__ order_src, const int* __restrict__ rank, NtJob a, NtJob b)
+{
+    extern __shared__ int lds[];
+    if (blockIdx.y == 0) nt_bin_body<UNA, false>(lds, m, n, a.ns, ntt, a.dv, a.idx, order_src, rank, a.tile_cursor, a.tile_list_off, a.tile_list_n, a.lists, a.tile_base, a.bins);
+    else                 nt_bin_body<UNB, false>(lds, m, n, b.ns, ntt, b.dv, b.idx, order_src, rank, b.tile_cursor, b.tile_list_off, b.tile_list_n, b.lists, b.tile_base, b.bins);
 }
 
 // counting sort of a target tile's bin by target, then a rank sort by pair inside every target's segment (pair ids are distinct):
@@ -284,8 +324,8 @@ __device__ __forceinline__ void nt_rank_sort(const int* __restrict__ stage, cons
     }
 }
 
-__global__ __launch_bounds__(NB) void nt_finish_kernel(int n, int ntt, const int* __restrict__ tile_base, const int2* __restrict__ bins, int* __restrict__ scratch,
-                                                       int* __restrict__ inv_start, int* __restrict__ inv_src)
+__device__ __forceinline__ void nt_finish_body(int n, int ntt, const int* __restrict__ tile_base, const int2* __restrict__ bins, int* __restrict__ scratch,
+                                               int* __restrict__ inv_start, int* __restrict__ inv_src)
 {
     __shared__ int cnt[TT], lstart[TT + 1];
     __shared__ int stage_lds[STAGE_CAP];
@@ -334,6 +374,16 @@ __global__ __launch_bounds__(NB) void nt_finish_kernel(int n, int ntt, const int
         __syncthreads();
         nt_rank_sort(stage, lstart, inv_src + b0);
     }
+}
+__global__ __launch_bounds__(NB) void nt_finish_kernel(int n, int ntt, const int* __restrict__ tile_base, const int2* __restrict__ bins, int* __restrict__ scratch,
+                                                       int* __restrict__ inv_start, int* __restrict__ inv_src)
+{
+    nt_finish_body(n, ntt, tile_base, bins, scratch, inv_start, inv_src);
+}
+__global__ __launch_bounds__(NB) void nt_finish_pair_kernel(int n, int ntt, NtJob a, NtJob b)
+{
+    const bool fa = blockIdx.y == 0;                                  // (one call of the body: its 48 KB staging tile exists once)
+    nt_finish_body(n, ntt, fa ? a.tile_base : b.tile_base, fa ? a.bins : b.bins, fa ? a.scratch : b.scratch, fa ? a.inv_start : b.inv_start, fa ? a.inv_src : b.inv_src);
 }
 
 // ---------------------------------------------------------------- K4 as a gather
@@ -457,7 +507,7 @@ CBL_EXPORT int cbl_neighbor_transpose(int m, int n, int nsample, const int* idx,
     if (nt_carve(w, (char*)workspace, m, n, nsample) > workspace_bytes) return CBL_ERR_WORKSPACE;
     const CblFastDiv dv = cbl_fastdiv_make((unsigned)nsample);
     const int nzero = ntt + 2;
-    hipLaunchKernelGGL(nt_prep_kernel, dim3(cbl_div_up(n > nzero ? n : nzero, NB)), dim3(NB), 0, st, n, nzero, order_dst, w.rank, w.tile_cursor);
+    hipLaunchKernelGGL(nt_prep_kernel, dim3(cbl_div_up(n > nzero ? n : nzero, NB)), dim3(NB), 0, st, n, nzero, order_dst, w.rank, w.tile_cursor, (int*)nullptr);
     const int* rank = order_dst ? w.rank : nullptr;
     const long long cap = (long long)TS * nsample < ntt ? (long long)TS * nsample : ntt;
     const size_t lds_count = sizeof(int) * (size_t)((ntt + 1) & ~1) + sizeof(int2) * (size_t)cap, lds_bin = sizeof(int) * 2 * (size_t)ntt;
@@ -475,6 +525,65 @@ CBL_EXPORT int cbl_neighbor_transpose(int m, int n, int nsample, const int* idx,
     if (per_thread <= 4) { CBL_NT(4); } else if (per_thread <= 8) { CBL_NT(8); } else { CBL_NT(16); }
 #undef CBL_NT
     hipLaunchKernelGGL(nt_finish_kernel, dim3(ntt), dim3(NB), 0, st, n, ntt, w.tile_base, w.bins, w.scratch, inv_start, inv_src);
+    return cbl_status();
+}
+
+// Two neighbour tables of ONE geometry (same sources, same targets, same orders: the block's K = 8 / 16 table and the CBL head's K = 36 table of a stage) transposed
+// by the same four launches: the values are those of two cbl_neighbor_transpose calls — the same kernels' bodies, blockIdx.y picks the table, the rank array is shared.
+// Workspace: the second table's scratch behind the first's.
+CBL_EXPORT size_t cbl_neighbor_transpose_pair_workspace_bytes(int m, int n, int nsample_a, int nsample_b)
+{
+    if (m < 0 || n < 0 || nsample_a <= 0 || nsample_b <= 0) return 0;
+    NtWs w;
+    return nt_carve(w, nullptr, m, n, nsample_a) + nt_carve(w, nullptr, m, n, nsample_b);
+}
+
+CBL_EXPORT int cbl_neighbor_transpose_pair(int m, int n, int nsample_a, const int* idx_a, int nsample_b, const int* idx_b, const int* order_src, const int* order_dst,
+                                           int* inv_start_a, int* inv_src_a, int* inv_start_b, int* inv_src_b, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (m < 0 || n < 0 || nsample_a <= 0 || nsample_b <= 0 || !inv_start_a || !inv_start_b) return CBL_ERR_BAD_ARG;
+    if ((long long)m * nsample_a > 0x7fffffffLL || (long long)m * nsample_b > 0x7fffffffLL) return CBL_ERR_BAD_ARG;
+    const int ntt = nt_tiles(n), nst = nt_src_tiles(m);
+    NtWs wa, wb;
+    const size_t bytes_a = nt_carve(wa, (char*)workspace, m, n, nsample_a);
+    if (m == 0 || n == 0 || ntt > NT_SCAN_SPLIT) {
+        // empty tables, or tables large enough for the split scan: one after the other (second table's scratch behind the first's, as below)
+        if (m > 0 && n > 0 && (!workspace || bytes_a + nt_carve(wb, nullptr, m, n, nsample_b) > workspace_bytes)) return workspace ? CBL_ERR_WORKSPACE : CBL_ERR_BAD_ARG;
+        const int rc = cbl_neighbor_transpose(m, n, nsample_a, idx_a, order_src, order_dst, inv_start_a, inv_src_a, workspace, bytes_a, stream);
+        if (rc) return rc;
+        return cbl_neighbor_transpose(m, n, nsample_b, idx_b, order_src, order_dst, inv_start_b, inv_src_b, workspace ? (char*)workspace + bytes_a : nullptr,
+                                      workspace_bytes > bytes_a ? workspace_bytes - bytes_a : 0, stream);
+    }
+    if (!idx_a || !idx_b || !inv_src_a || !inv_src_b || !workspace) return CBL_ERR_BAD_ARG;
+    if (bytes_a + nt_carve(wb, (char*)workspace + bytes_a, m, n, nsample_b) > workspace_bytes) return CBL_ERR_WORKSPACE;
+    hipStream_t st = cbl_stream(stream);
+    auto job = [&](const NtWs& w, int ns, const int* idx, int* inv_start, int* inv_src) {
+        NtJob j;
+        j.ns = ns; j.dv = cbl_fastdiv_make((unsigned)ns); j.idx = idx;
+        j.tile_cursor = w.tile_cursor; j.list_cursor = w.list_cursor; j.tile_list_off = w.tile_list_off; j.tile_list_n = w.tile_list_n; j.tile_base = w.tile_base;
+        j.lists = w.lists; j.bins = w.bins; j.scratch = w.scratch; j.inv_start = inv_start; j.inv_src = inv_src;
+        return j;
+    };
+    // the wider table first: the launch's template arguments are dispatched on (wide, narrow) batch sizes
+    const bool swap = nsample_b > nsample_a;
+    const NtJob ja = swap ? job(wb, nsample_b, idx_b, inv_start_b, inv_src_b) : job(wa, nsample_a, idx_a, inv_start_a, inv_src_a);
+    const NtJob jb = swap ? job(wa, nsample_a, idx_a, inv_start_a, inv_src_a) : job(wb, nsample_b, idx_b, inv_start_b, inv_src_b);
+    const int nzero = ntt + 2;
+    hipLaunchKernelGGL(nt_prep_kernel, dim3(cbl_div_up(n > nzero ? n : nzero, NB)), dim3(NB), 0, st, n, nzero, order_dst, wa.rank, wa.tile_cursor, wb.tile_cursor);
+    const int* rank = order_dst ? wa.rank : nullptr;
+    const int ns_max = ja.ns;
+    const long long cap = (long long)TS * ns_max < ntt ? (long long)TS * ns_max : ntt;
+    const size_t lds_count = sizeof(int) * (size_t)((ntt + 1) & ~1) + sizeof(int2) * (size_t)cap, lds_bin = sizeof(int) * 2 * (size_t)ntt;
+    auto un_of = [](int ns) { const int per_thread = (TS * ns + NB - 1) / NB; return per_thread <= 4 ? 4 : per_thread <= 8 ? 8 : 16; };
+    const int una = un_of(ja.ns), unb = un_of(jb.ns);
+    const dim3 gsrc(nst, 2), gdst(ntt, 2);
+#define CBL_NTP(UA_, UB_)                                                                                                                        \
+    { hipLaunchKernelGGL((nt_count_pair_kernel<UA_, UB_>), gsrc, dim3(NB), lds_count, st, m, n, ntt, order_src, rank, ja, jb);                  \
+      hipLaunchKernelGGL((nt_bin_pair_kernel<UA_, UB_>), gsrc, dim3(NB), lds_bin, st, m, n, ntt, order_src, rank, ja, jb); }
+    if (una == 16 && unb == 16) CBL_NTP(16, 16) else if (una == 16 && unb == 8) CBL_NTP(16, 8) else if (una == 16) CBL_NTP(16, 4)
+    else if (una == 8 && unb == 8) CBL_NTP(8, 8) else if (una == 8) CBL_NTP(8, 4) else CBL_NTP(4, 4)
+#undef CBL_NTP
+    hipLaunchKernelGGL(nt_finish_pair_kernel, gdst, dim3(NB), 0, st, n, ntt, ja, jb);
     return cbl_status();
 }
 

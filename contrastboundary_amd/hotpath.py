@@ -74,9 +74,11 @@ class Scene:
 SIDE_STAGES = ("cbl_knnquery_k%d" % CBL_NSAMPLE,)
 
 
-def stages(scene, k=16, backward=False):
+def stages(scene, k=16, backward=False, pair_tables=False):
     """-> list of (name, fn(state) -> None, algorithmic_bytes, algorithmic_flops); fns communicate through `state`.
-    backward: also the backward legs of the block (BASELINE config C2)."""
+    backward: also the backward legs of the block (BASELINE config C2).
+    pair_tables (with backward): the stage that builds the CBL head's transposed K = 36 table builds the block's own K = 16 table with it (one geometry, the
+    same four launches: pointops.neighbor_transpose(companion=)); the block's table stage is then a registry hit that launches nothing."""
     n, c = scene.n, scene.c
     st = []
     # leaves are made inside the step (on the stream the step runs on) and gradients are taken with torch.autograd.grad: no AccumulateGrad
@@ -113,7 +115,7 @@ def stages(scene, k=16, backward=False):
 
     def cbl_transpose(s):
         # the CBL gradient's neighbour half is a gather over the transposed K = 36 table (no atomics): 4nK idx in, 4(n+1) + 4nK out
-        s["cbl_transposed"] = pointops.neighbor_transpose(s["cbl_idx"], n)
+        s["cbl_transposed"] = pointops.neighbor_transpose(s["cbl_idx"], n, companion=s.get("idx") if (pair_tables and backward) else None)
     st.append(("cbl_neighbor_transpose", cbl_transpose, 8 * n * CBL_NSAMPLE + 4 * (n + 1), 0.0))
 
     def cbl_fwd(s):
@@ -161,7 +163,7 @@ def pt_layer(scene, seed=0):
     return cache[seed]
 
 
-def stages_pt(scene, k=16, backward=False):
+def stages_pt(scene, k=16, backward=False, pair_tables=False):
     """The block with the Point Transformer's local aggregation (BASELINE.md 3 / SURVEY 8(d): a1 + a3 + a4 + a8) instead of KPConv:
         KNN (K=16) -> relative-xyz grouping (n,K,3) (what blocks.py:36-37 gathers; the (n,K,C) gathers of x_k / x_v happen inside the fused kernels)
         -> PointTransformerLayer: q/k/v Linear, linear_p, vector attention over the K neighbours, softmax, aggregation (blocks.py:31-44)
@@ -195,7 +197,7 @@ def stages_pt(scene, k=16, backward=False):
     st.append(("cbl_knnquery_k%d" % CBL_NSAMPLE, cbl_knn, 24 * n + 8 * n * CBL_NSAMPLE, 8.0 * n * n))
 
     def cbl_transpose(s):
-        s["cbl_transposed"] = pointops.neighbor_transpose(s["cbl_idx"], n)
+        s["cbl_transposed"] = pointops.neighbor_transpose(s["cbl_idx"], n, companion=s.get("idx") if (pair_tables and backward) else None)
     st.append(("cbl_neighbor_transpose", cbl_transpose, 8 * n * CBL_NSAMPLE + 4 * (n + 1), 0.0))
 
     def cbl_fwd(s):
@@ -250,13 +252,14 @@ class Schedule:
 
     events: optional list (one entry per stage) of (start, end) torch.cuda.Event pairs, recorded on the stream the stage runs on."""
 
-    def __init__(self, stage_list, overlap=True, hints=(), aux_tables=True):
+    def __init__(self, stage_list, overlap=True, hints=(), aux_tables=True, pair_tables=False):
         """hints: (xyz, nsample, algo) triples for pointops.neighbor_cache.hint — the widest search each geometry sees during the step.
         With hints the step runs inside a neighbour cache that is dropped at the end of the step: nothing is carried from step to step.
         aux_tables: the block's own transposed table on a stream of its own right behind the search (False: in stage order on the main stream —
         measured faster for the Point Transformer block's one-step-at-a-time graph, 0.68 against 0.705 ms: a third branch in the replayed graph
         costs that block more than the 40 us of table build it takes off the backward chain)."""
         self.stage_list = stage_list
+        self.pair_tables = pair_tables                              # the stage list was made with pair_tables=True (stages / stages_pt): Pipeline picks its layouts by it
         self.aux_tables = aux_tables
         self.hints = tuple(hints)
         self.overlap = overlap
@@ -505,6 +508,23 @@ class Pipeline:
                     ("fwd", "fwd", fwd_b + t16, ("found",), "fdone"),
                     ("cbl", "search", t36 + fwd_c + bwd_c, (), None),
                     ("bwd", "bwd*", bwd_b, ("fdone",), None)]
+        elif layout == "pair_split":
+            # "split_t36_first" for stage lists whose K = 36 table stage builds the block's K = 16 table with it (stages(pair_tables=True)): the pair build is a
+            # graph of its own at the head of the CBL chain, the event behind it is what the backward chain waits for besides the forward's
+            streams = ("search", "fwd", "bwd", "side")
+            segs = [("search", "search", search, (), "found"),
+                    ("fwd", "fwd", fwd_b, ("found",), "fdone"),
+                    ("tabs", "side", t36, ("found",), "tabs"),
+                    ("cbl", "side", fwd_c + bwd_c, (), None),
+                    ("bwd", "bwd", t16 + bwd_b, ("fdone", "tabs") if t36 else ("fdone",), None)]
+        elif layout == "pair_alt_bwd":
+            # "alt_bwd" with the pair build at the head of the CBL chain (on the search stream)
+            streams = ("search", "fwd", "bwd0", "bwd1")
+            segs = [("search", "search", search, (), "found"),
+                    ("fwd", "fwd", fwd_b, ("found",), "fdone"),
+                    ("tabs", "search", t36, (), "tabs"),
+                    ("cbl", "search", fwd_c + bwd_c, (), None),
+                    ("bwd", "bwd*", t16 + bwd_b, ("fdone", "tabs") if t36 else ("fdone",), None)]
         else:
             raise ValueError("unknown pipeline layout %r" % layout)
         return streams, [sg for sg in segs if sg[2]]
@@ -515,6 +535,10 @@ class Pipeline:
         self.sched = sched
         self.layout = layout or os.environ.get("CBL_PIPELINE_LAYOUT", self.LAYOUT)
         self.SLOTS = int(slots or os.environ.get("CBL_PIPELINE_SLOTS", self.SLOTS))
+        if self.layout.startswith("pair_") != bool(getattr(sched, "pair_tables", False)):
+            # a plain layout runs the block's table stage on a stream that is not ordered behind the stage that built the pair (and a pair layout's extra
+            # event orders nothing the plain stages need): refuse instead of racing
+            raise ValueError("pipeline layout %r does not fit a step whose stages were made with pair_tables=%s" % (self.layout, bool(getattr(sched, "pair_tables", False))))
         self.STREAMS, self.segments = self.plan([st[0] for st in sched.stage_list], self.layout)
         self.streams = dict(zip(self.STREAMS, concurrent_streams(len(self.STREAMS))))        # streams with hardware queues of their own
         self.states = [{} for _ in range(self.SLOTS)]

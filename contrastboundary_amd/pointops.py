@@ -293,13 +293,16 @@ def knn_block_candidates(nsample, xyz, offset, algo="set"):
 TRANSPOSE_MIN_PAIRS = 1 << 16      # below this a scatter with atomics is as quick as building the table (unless the table is cached)
 
 
-def neighbor_transpose(idx, n, build=True):
+def neighbor_transpose(idx, n, build=True, companion=None):
     """Transposed neighbour table of idx (m, nsample) over n target rows (cbl_neighbor_transpose, SURVEY.md 7 hard part 6):
     -> (order or None, inv_start (n+1) i32, inv_src (m*nsample) i32), or None (build=False and nothing cached).
     Segment r of inv_src lists, ascending, the flat pairs p = source * nsample + column with idx[p] == order[r] (== r without an order).
     It depends on the table alone: it is built once per table (kept in neighbor_state's registry; a neighbour cache drops what was built
     during its pass) and shared by every backward pass that scatters through it, also on autograd's thread; the processing order (cell
-    order of the search that made idx) only makes build and consumers local."""
+    order of the search that made idx) only makes build and consumers local.
+    companion: another neighbour table (m, nsample') of the SAME geometry (same m sources, n targets — the block's K = 8 / 16 table beside the CBL head's
+    K = 36 table of a stage) whose transposed table a later pass of the step will ask for: both are built by the same four launches
+    (cbl_neighbor_transpose_pair) and registered; the later request is a registry hit on whatever stream it comes from."""
     _req(idx, torch.int32, "idx", 2)
     hit = neighbor_state.transpose_lookup(idx)
     if hit is not None or not build:
@@ -309,6 +312,21 @@ def neighbor_transpose(idx, n, build=True):
     L = _lib.lib()
     inv_start = torch.empty(n + 1, dtype=torch.int32, device=idx.device)
     inv_src = torch.empty(max(m * nsample, 1), dtype=torch.int32, device=idx.device)
+    if companion is not None and companion.dim() == 2 and companion.shape[0] == m and companion.dtype == torch.int32 and companion.device == idx.device \
+            and companion.data_ptr() != idx.data_ptr() and neighbor_state.transpose_lookup(companion) is None:
+        ns2 = companion.shape[1]
+        inv_start2 = torch.empty(n + 1, dtype=torch.int32, device=idx.device)
+        inv_src2 = torch.empty(max(m * ns2, 1), dtype=torch.int32, device=idx.device)
+        ws = _workspace(max(L.cbl_neighbor_transpose_pair_workspace_bytes(_c_int(m), _c_int(n), _c_int(nsample), _c_int(ns2)), 1), idx.device)
+        rc = L.cbl_neighbor_transpose_pair(_c_int(m), _c_int(n), _c_int(nsample), _lib.ptr(idx), _c_int(ns2), _lib.ptr(companion), _lib.ptr(order), _lib.ptr(order),
+                                           _lib.ptr(inv_start), _lib.ptr(inv_src), _lib.ptr(inv_start2), _lib.ptr(inv_src2), _lib.ptr(ws), ctypes.c_size_t(ws.numel()),
+                                           _lib.stream_of(idx))
+        if rc == _lib.ERR_UNSUPPORTED:
+            return None
+        _lib.check(rc, "cbl_neighbor_transpose_pair")
+        neighbor_state.transpose_register(idx, order, inv_start, inv_src)
+        neighbor_state.transpose_register(companion, order, inv_start2, inv_src2)
+        return order, inv_start, inv_src
     ws = _workspace(max(L.cbl_neighbor_transpose_workspace_bytes(_c_int(m), _c_int(n), _c_int(nsample)), 1), idx.device)
     rc = L.cbl_neighbor_transpose(_c_int(m), _c_int(n), _c_int(nsample), _lib.ptr(idx), _lib.ptr(order), _lib.ptr(order), _lib.ptr(inv_start),
                                   _lib.ptr(inv_src), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(idx))

@@ -169,6 +169,12 @@ int cbl_grouping_backward(int m, int nsample, int c, const float* grad_output, c
 size_t cbl_neighbor_transpose_workspace_bytes(int m, int n, int nsample);
 int cbl_neighbor_transpose(int m, int n, int nsample, const int* idx, const int* order_src, const int* order_dst, int* inv_start, int* inv_src,
                            void* workspace, size_t workspace_bytes, void* stream);
+/* Two neighbour tables of ONE geometry (same m sources, n targets and orders — e.g. the K = 8 / 16 table of a stage's blocks and the K = 36 table of its CBL
+ * head, blocks.py:34-35 / heads.py:190-196) transposed together: the outputs are those of two cbl_neighbor_transpose calls, by four launches instead of eight
+ * (the build is a chain of small latency-bound kernels; the two tables' chains run side by side).  Tables beyond 131072 targets are built one after the other. */
+size_t cbl_neighbor_transpose_pair_workspace_bytes(int m, int n, int nsample_a, int nsample_b);
+int cbl_neighbor_transpose_pair(int m, int n, int nsample_a, const int* idx_a, int nsample_b, const int* idx_b, const int* order_src, const int* order_dst,
+                                int* inv_start_a, int* inv_src_a, int* inv_start_b, int* inv_src_b, void* workspace, size_t workspace_bytes, void* stream);
 /* K4 grouping_backward_cuda_launcher (grouping_cuda_kernel.h:14) as a gather over the transposed table of its idx:
  *   grad_input[order_dst[r], :] = sum over segment r of grad_output[p, :]   (written, not accumulated: no pre-zeroing; same summation order
  *   as the reference loop run sequentially, so bit-identical to the CPU oracle) */

@@ -136,6 +136,31 @@ def test_scatter_adds_as_gathers_over_the_transposed_table(host, n, m, K, c):
         np.testing.assert_allclose(g1, r1, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("n,Ka,Kb", [(900, 36, 16), (700, 8, 36), (300, 16, 16), (130, 3, 40)])
+def test_two_tables_of_one_geometry_transposed_together(host, n, Ka, Kb):
+    """cbl_neighbor_transpose_pair: the K = 8 / 16 table of a stage's blocks and the K = 36 table of its CBL head (blocks.py:34-35, heads.py:190-196) by the same four
+    launches — byte for byte the outputs of two cbl_neighbor_transpose calls, with and without a processing order, shadow entries left out"""
+    host.cbl_neighbor_transpose_pair_workspace_bytes.restype = ctypes.c_size_t
+    xyz, _, idx_a, rng = scene(n, n, Ka, seed=n)
+    idx_b, _ = O.knnquery(Kb, xyz, xyz, np.int32([n]), np.int32([n]))
+    idx_b = np.ascontiguousarray(idx_b, np.int32)
+    idx_a[rng.random(idx_a.shape) < 0.05] = n                           # shadow / padding entries
+    idx_b[n // 3] = 7                                                   # Kb pairs of one source on one target
+    order = rng.permutation(n).astype(np.int32)
+    for od in (None, order):
+        sa, ia = transposed(host, idx_a, n, od)
+        sb, ib = transposed(host, idx_b, n, od)
+        nbytes = host.cbl_neighbor_transpose_pair_workspace_bytes(n, n, Ka, Kb)
+        assert nbytes >= host.cbl_neighbor_transpose_workspace_bytes(n, n, Ka) + host.cbl_neighbor_transpose_workspace_bytes(n, n, Kb)
+        ws = np.zeros(nbytes + 64, np.uint8)
+        pa, qa = np.full(n + 1, -1, np.int32), np.full(n * Ka, -1, np.int32)
+        pb, qb = np.full(n + 1, -1, np.int32), np.full(n * Kb, -1, np.int32)
+        assert host.cbl_neighbor_transpose_pair(n, n, Ka, P(idx_a), Kb, P(idx_b), P(od), P(od), P(pa), P(qa), P(pb), P(qb), P(ws), ctypes.c_size_t(nbytes), None) == 0
+        np.testing.assert_array_equal(pa, sa); np.testing.assert_array_equal(pb, sb)
+        np.testing.assert_array_equal(qa[:sa[n]], ia[:sa[n]]); np.testing.assert_array_equal(qb[:sb[n]], ib[:sb[n]])
+        assert host.cbl_neighbor_transpose_pair(n, n, Ka, P(idx_a), Kb, P(idx_b), P(od), P(od), P(pa), P(qa), P(pb), P(qb), P(ws), ctypes.c_size_t(nbytes - 256), None) == -2
+
+
 @pytest.mark.parametrize("K,C,embedding,reduction", [(16, 36, 1, 1), (20, 24, 0, 0)])
 def test_pospool_feature_gradient_as_a_gather(host, K, C, embedding, reduction):
     n = 400

@@ -92,7 +92,7 @@ def test_the_step_bench_times_against_the_oracles(oracle, backward, pipeline):
     check_state(st_in.state, oracle, backward)
 
 
-@pytest.mark.parametrize("layout,slots", [("tables", 2), ("split_t36_first", 4), ("alt_bwd", 4)])
+@pytest.mark.parametrize("layout,slots", [("tables", 2), ("split_t36_first", 4), ("alt_bwd", 4), ("pair_split", 3), ("pair_alt_bwd", 4)])
 def test_every_pipeline_layout_computes_the_step(oracle, layout, slots):
     """hotpath.Pipeline's stream layouts differ in what runs beside what, never in what is computed: every slot of every layout against the oracles
     (the default, "split_t36_first" with three slots, is also the pipeline case of the test above)"""
@@ -100,8 +100,11 @@ def test_every_pipeline_layout_computes_the_step(oracle, layout, slots):
     from contrastboundary_amd import hotpath
     args = bench.parse([])
     scene = hotpath.Scene.synthetic(N, C, seed=0, b=1)
-    step = bench.Step(scene, K, True, args, overlap=True, pipeline=False)
+    # "pair_" layouts: the K = 36 table stage builds the block's K = 16 table with it (cbl_neighbor_transpose_pair), the backward chain waits for that stage
+    step = bench.Step(scene, K, True, args, overlap=True, pipeline=False, pair_tables=layout.startswith("pair_"))
     bench.settle(step, 0.1)
+    with pytest.raises(ValueError):                                  # a layout that does not order the backward behind the pair build is refused, not raced
+        hotpath.Pipeline(step.sched, layout="split_t36_first" if layout.startswith("pair_") else "pair_split", slots=slots)
     pipe = hotpath.Pipeline(step.sched, layout=layout, slots=slots)
     pipe.capture()
     assert pipe.layout == layout and pipe.SLOTS == slots and len(pipe.states) == slots

@@ -112,6 +112,53 @@ def test_transpose_of_a_real_search_with_its_cell_order():
     assert np.array_equal(s, rs) and np.array_equal(src[:rs[-1]], rsrc)
 
 
+@pytest.mark.parametrize("m,n,ka,kb,ordered", [(40960, 40960, 36, 16, True), (10240, 10240, 8, 36, True), (3000, 3000, 16, 16, False), (5000, 777, 3, 40, False),
+                                                (70, 50, 65, 1, False), (140000, 140000, 4, 6, True)])
+def test_two_tables_of_one_geometry_transposed_together(m, n, ka, kb, ordered):
+    """cbl_neighbor_transpose_pair: both tables against the numpy restatement (the last case is beyond the pair launches' size: built one after the other inside the call)"""
+    rng = np.random.default_rng(m + ka)
+    idx_a = rng.integers(-1, n + 2, size=(m, ka)).astype(np.int32)       # shadow / padding entries on both sides of [0, n)
+    idx_b = rng.integers(0, n, size=(m, kb)).astype(np.int32)
+    idx_b[m // 2] = n // 3                                              # kb pairs of one source on one target
+    order = rng.permutation(n).astype(np.int32) if ordered else None
+    L = _lib.lib()
+    a_d, b_d = dev(idx_a), dev(idx_b)
+    o_d = None if order is None else dev(order)
+    os_d = o_d if m == n else None
+    outs = [torch.full((n + 1,), -7, dtype=torch.int32, device="cuda"), torch.full((m * ka,), -7, dtype=torch.int32, device="cuda"),
+            torch.full((n + 1,), -7, dtype=torch.int32, device="cuda"), torch.full((m * kb,), -7, dtype=torch.int32, device="cuda")]
+    L.cbl_neighbor_transpose_pair_workspace_bytes.restype = ctypes.c_size_t
+    need = L.cbl_neighbor_transpose_pair_workspace_bytes(_i(m), _i(n), _i(ka), _i(kb))
+    ws = torch.empty(max(need, 1), dtype=torch.uint8, device="cuda")
+    _lib.check(L.cbl_neighbor_transpose_pair(_i(m), _i(n), _i(ka), _lib.ptr(a_d), _i(kb), _lib.ptr(b_d), _lib.ptr(os_d), _lib.ptr(o_d), *[_lib.ptr(t) for t in outs],
+                                             _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_of(a_d)), "cbl_neighbor_transpose_pair")
+    torch.cuda.synchronize()
+    for idx, st, src in ((idx_a, outs[0], outs[1]), (idx_b, outs[2], outs[3])):
+        rs, rsrc = transpose_numpy(idx, n, order)
+        assert np.array_equal(st.cpu().numpy(), rs)
+        assert np.array_equal(src.cpu().numpy()[:rs[-1]], rsrc)
+
+
+def test_a_companion_table_is_built_with_the_first_and_served_from_the_registry():
+    """pointops.neighbor_transpose(companion=): the second table's later request launches nothing and returns what a build of its own returns"""
+    xyz, _ = S.s_room(20000, 3)
+    p = dev(xyz); o = torch.tensor([20000], dtype=torch.int32, device="cuda")
+    with pointops.neighbor_cache() as nc:
+        nc.hint(p, 36, "set")
+        i16, _ = pointops.knnquery_raw(16, p, p, o, o)
+        i36, _ = pointops.knnquery_raw(36, p, p, o, o, algo="set")
+        order36, s36, src36 = pointops.neighbor_transpose(i36, 20000, companion=i16)
+        hit = pointops.neighbor_transpose(i16, 20000, build=False)
+        assert hit is not None and hit[0] is order36
+        torch.cuda.synchronize()
+        got = [t.cpu().numpy() for t in (s36, src36, hit[1], hit[2])]
+        order = None if order36 is None else order36.cpu().numpy()
+        a, b = i36.cpu().numpy(), i16.cpu().numpy()
+    for idx, st, src in ((a, got[0], got[1]), (b, got[2], got[3])):
+        rs, rsrc = transpose_numpy(idx, 20000, order)
+        assert np.array_equal(st, rs) and np.array_equal(src[:rs[-1]], rsrc)
+
+
 @pytest.mark.parametrize("c", [64, 32, 4, 3, 128, 20])
 def test_grouping_backward_csr_bit_exact(c):
     rng = np.random.default_rng(c)

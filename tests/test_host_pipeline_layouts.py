@@ -7,7 +7,10 @@ KPCONV = ["knnquery_k16", "queryandgroup", "kpconv_fwd", "cbl_knnquery_k36", "cb
 PT = ["knnquery_k16", "pt_layer_fwd", "cbl_knnquery_k36", "cbl_neighbor_transpose", "cbl_mining_loss_fwd", "cbl_mining_loss_bwd", "neighbor_transpose_k16",
       "pt_layer_bwd"]
 FORWARD_ONLY = ["knnquery_k16", "queryandgroup", "kpconv_fwd", "cbl_knnquery_k36", "cbl_neighbor_transpose", "cbl_mining_loss_fwd", "cbl_mining_loss_bwd"]
-LAYOUTS = ["tables", "split_t36_first", "alt_bwd"]
+LAYOUTS = ["tables", "split_t36_first", "alt_bwd", "pair_split", "pair_alt_bwd"]
+# pair layouts: the K = 36 table stage builds the block's K = 16 table with it (hotpath.stages(pair_tables=True)), so the block's table stage — a registry hit —
+# and its consumers must also sit behind the K = 36 table stage
+PAIR_NEEDS = {"neighbor_transpose_k16": ["cbl_neighbor_transpose"]}
 # stage -> stages that must have been issued on the same stream earlier, or on another stream behind an event the stage's segment waits for
 NEEDS = {"queryandgroup": ["knnquery_k16"], "kpconv_fwd": ["knnquery_k16"], "pt_layer_fwd": ["knnquery_k16"], "cbl_neighbor_transpose": ["cbl_knnquery_k36"],
          "cbl_mining_loss_fwd": ["cbl_knnquery_k36"], "cbl_mining_loss_bwd": ["cbl_mining_loss_fwd", "cbl_neighbor_transpose"],
@@ -44,7 +47,7 @@ def test_layout_covers_every_stage_once_and_orders_them(names, layout):
                 todo.append(j); visible.update(segs[j][2])
         for pos, i in enumerate(sg[2]):
             have = visible | set(sg[2][:pos])
-            for need in NEEDS.get(names[i], []):
+            for need in NEEDS.get(names[i], []) + (PAIR_NEEDS.get(names[i], []) if layout.startswith("pair_") else []):
                 if need in names:
                     assert names.index(need) in have, (layout, names[i], "before", need)
 
