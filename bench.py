@@ -436,16 +436,20 @@ def kernel_times(scene, k, backward, reps=10):
     def timed(fn):
         # the outputs of the last three launches stay referenced: consecutive launches write DIFFERENT buffers (the caching allocator would
         # otherwise hand every launch the buffer the previous one just freed, and a 190 MB output re-written in place sits in the 256 MB Infinity Cache)
-        ring = [fn(), fn(), None]
-        torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        filler.fill_(0); filler.fill_(1)                             # ~1.2 ms: the host enqueues all `reps` launches meanwhile
-        a.record()
-        for r in range(reps):
-            ring[(r + 2) % 3] = fn()
-        b.record()
-        torch.cuda.synchronize()
-        return a.elapsed_time(b) / reps * 1e3                        # us
+        ring = [fn(), fn(), fn()]                                   # all three buffers exist before anything is timed (round 6: one run in ~20 read 940 us for the
+        torch.cuda.synchronize()                                     # 39 us gather — the third buffer's first allocation, a device malloc, inside the timed region)
+        rounds = []
+        for _ in range(3):                                           # ... and one glitch does not decide the figure: the median of three rounds
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            filler.fill_(0); filler.fill_(1)                         # ~1.2 ms: the host enqueues all `reps` launches meanwhile
+            a.record()
+            for r in range(reps):
+                ring[r % 3] = None                                   # freed first: the allocator hands the same three blocks round
+                ring[r % 3] = fn()
+            b.record()
+            torch.cuda.synchronize()
+            rounds.append(a.elapsed_time(b) / reps * 1e3)            # us
+        return sorted(rounds)[1]
     with pointops.neighbor_cache() as nc:
         for xyz, nsample, algo in hotpath.search_hints(scene):
             nc.hint(xyz, nsample, algo)
