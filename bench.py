@@ -37,8 +37,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 matrix = f32 vector peak
 GRAD_ALLREDUCE_FLOATS = 7800497   # parameters of the reference's PointTransformerSeg + heads: 31.2 MB fp32
-PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")     # collected by tools/gpu_r05_final.sh; its _meta.commit names the kernel set
-PMC_MIX_FILE = os.path.join(ROOT, "profiles", "r05_pmc_instruction_mix.json")   # same script: SQ_* counters per kernel of the same command (separate --pmc passes)
+PMC_FILE = os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")     # collected by tools/gpu_r06_final.sh; its _meta.commit names the kernel set
+PMC_MIX_FILE = os.path.join(ROOT, "profiles", "r06_pmc_instruction_mix.json")   # same script: SQ_* counters per kernel of the same command (separate --pmc passes)
 
 
 def parse(argv=None):
