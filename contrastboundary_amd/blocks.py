@@ -41,7 +41,7 @@ class PointTransformerLayer(nn.Module):
     def forward(self, pxo, idx=None) -> torch.Tensor:
         p, x, o = pxo                                                        # (n,3), (n,c), (b)
         if idx is None:
-            idx, _ = pointops.knnquery(self.nsample, p, p, o, o)              # once, not twice (:34-35)
+            idx = pointops.knn_indices(self.nsample, p, p, o, o)              # once, not twice (:34-35); the distances are not used here
         else:
             # a caller-supplied table (shared per stage) reaches the kernels as a raw pointer with K = idx.shape[1]: anything but (n, nsample) int32 rows
             # would be read as garbage row ids — fail here, loudly (a sliced table is made contiguous: values, not layout, are the contract)

@@ -377,6 +377,15 @@ class KNNQuery(Function):
 knnquery = KNNQuery.apply
 
 
+def knn_indices(nsample, xyz, new_xyz, offset, new_offset):
+    """the neighbour table alone, for the mirrors' own calls that drop knnquery's second output (blocks.py:34-35, pointops.py:88-89 `idx, _ = knnquery(...)`): the
+    same search, cache and tensor as `knnquery(...)[0]`, without the sqrt launch over distances nobody reads (22 of them per training step of the network)"""
+    idx, _ = knnquery_raw(nsample, xyz, new_xyz if new_xyz is not None else xyz, offset, new_offset)
+    if neighbor_cache.active() is not None:
+        idx = idx.view(idx.shape)              # a cached result is shared by several calls: every caller its own tensor object (as KNNQuery.forward)
+    return idx
+
+
 # ------------------------------------------------------------------------------------------------ K3/K4
 class Grouping(Function):
     @staticmethod
@@ -444,7 +453,7 @@ def queryandgroup(nsample, xyz, new_xyz, feat, idx, offset, new_offset, use_xyz=
         new_xyz = xyz
     _req(xyz, torch.float32, "xyz", 2); _req(new_xyz, torch.float32, "new_xyz", 2); _req(feat, torch.float32, "feat", 2)
     if idx is None:
-        idx, _ = knnquery(nsample, xyz, new_xyz, offset, new_offset)
+        idx = knn_indices(nsample, xyz, new_xyz, offset, new_offset)
     _req(idx, torch.int32, "idx", 2)
     return _QueryAndGroup.apply(xyz, new_xyz, feat, idx, bool(use_xyz))
 
